@@ -1,0 +1,206 @@
+/*
+ * mcf.h — C ABI of libmcfhip: the MI355X (gfx950) grid microclimate solver.
+ *
+ * Drop-in boundary for the reference's `.Call` entry points (all paths below are
+ * under the upstream repository root):
+ *
+ *   mcf_runmicro1()  replaces  _microclimf_runmicro1Cpp   src/RcppExports.cpp:250-272
+ *                    (R stub   runmicro1Cpp               R/RcppExports.R:72-74,
+ *                     body     runmicro1Cpp               src/microclimfCpp.cpp:2052-2337)
+ *   mcf_runmicro2()  replaces  _microclimf_runmicro2Cpp   src/RcppExports.cpp:275-297
+ *                    (R stub   runmicro2Cpp               R/RcppExports.R:76-78,
+ *                     body     runmicro2Cpp               src/microclimfCpp.cpp:2340-2621)
+ *
+ * Everything is plain pointers + sizes; no R, Rcpp or torch types.  All arrays
+ * are IEEE fp64, column-major with the raster row as the fastest index, exactly
+ * as R hands them to the reference:
+ *
+ *   matrix  [rows, cols]          element (i,j)     at  i + rows*j
+ *   3-D     [rows, cols, n]       element (i,j,k)   at  i + rows*j + rows*cols*k
+ *
+ * "NA" follows Rcpp's NumericVector::is_na, i.e. any NaN.  Cells whose `hgt`
+ * is NA are skipped and every requested output holds R's NA_real_ bit pattern
+ * (0x7FF00000000007A2) there, as do time steps past the last whole day
+ * (ndays = tsteps / 24 truncates, src/microclimfCpp.cpp:2116).
+ *
+ * Two levels:
+ *   1. one-shot host calls (mcf_runmicro1 / mcf_runmicro2): host pointers in,
+ *      host pointers out; the library stages everything through HBM in day
+ *      chunks.  This is what the R glue binds.
+ *   2. the plan API: inputs are uploaded once and stay resident in HBM, day
+ *      chunks are solved into a device-resident output ring, and the caller
+ *      decides what (if anything) is copied back.  bench.py and multi-GPU row
+ *      tiling use this level.
+ *
+ * There is no CPU fallback: every entry point fails with MCF_ERR_NO_DEVICE when
+ * no HIP device is usable.
+ */
+#ifndef MCF_H
+#define MCF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCF_ABI_VERSION 1
+
+/* Output variables, in the order of the reference's returned list
+ * (src/microclimfCpp.cpp:2326-2335) and of its `out` logical(10). */
+enum {
+    MCF_OUT_TZ = 0,       /* "Tz"        air T at reqhgt (reqhgt>0), ground T (==0), soil T (<0) */
+    MCF_OUT_TLEAF = 1,    /* "tleaf"     leaf T (reqhgt>0 only)                              */
+    MCF_OUT_RELHUM = 2,   /* "relhum"    relative humidity % (reqhgt>0 only)                 */
+    MCF_OUT_SOILM = 3,    /* "soilm"     distributed volumetric soil moisture                */
+    MCF_OUT_WINDSPEED = 4,/* "windspeed" wind speed at reqhgt                                */
+    MCF_OUT_RDIRDOWN = 5, /* "Rdirdown"  downward direct SW at reqhgt                        */
+    MCF_OUT_RDIFDOWN = 6, /* "Rdifdown"  downward diffuse SW                                 */
+    MCF_OUT_RLWDOWN = 7,  /* "Rlwdown"   downward LW (reqhgt>=0)                             */
+    MCF_OUT_RSWUP = 8,    /* "Rswup"     upward SW                                           */
+    MCF_OUT_RLWUP = 9,    /* "Rlwup"     upward LW (reqhgt>=0)                               */
+    MCF_NOUT = 10
+};
+
+/* Error codes (0 = success).  mcf_last_error() gives the message of the most
+ * recent failure on the calling thread. */
+enum {
+    MCF_OK = 0,
+    MCF_ERR_ARG = 1,        /* NULL/ill-sized argument                                  */
+    MCF_ERR_NO_DEVICE = 2,  /* no usable HIP device / kernels not loadable              */
+    MCF_ERR_HIP = 3,        /* a HIP runtime call failed (message has the HIP error)    */
+    MCF_ERR_NOMEM = 4,      /* request does not fit device memory                       */
+    MCF_ERR_STATE = 5       /* plan used out of order                                   */
+};
+
+/* obstime data.frame (src/microclimfCpp.cpp:2057-2060).  R passes year/month/day
+ * as doubles that Rcpp coerces to int; the glue does that coercion. */
+typedef struct mcf_obstime {
+    const int32_t *year, *month, *day; /* [tsteps] */
+    const double *hour;                /* [tsteps] decimal hour */
+} mcf_obstime;
+
+/* climdata (src/microclimfCpp.cpp:2062-2071 data.frame columns temp, es, ea,
+ * tdew, pres, swdown, difrad, lwdown, windspeed, winddir; :2350-2359 list
+ * entries tc, es, ea, tdew, pk, ...).  Vector forcing: each [tsteps].  Array
+ * forcing: each [rows,cols,tsteps] except winddir, which stays [tsteps]. */
+typedef struct mcf_climate {
+    const double *tc, *es, *ea, *tdew, *pk, *swdown, *difrad, *lwdown, *windspeed, *winddir;
+} mcf_climate;
+
+/* pointm (src/microclimfCpp.cpp:2073-2082; :2361-2370, where G is named Gp).
+ * T0p and DDp are accepted by the reference but never read; they are not part
+ * of this ABI.  Tg/Tbp are only read when reqhgt < 0 and complete == 0 and may
+ * be NULL otherwise.  Shapes as mcf_climate. */
+typedef struct mcf_pointm {
+    const double *soilm, *Tg, *Tbp, *G, *umu, *kp, *muGp, *dtrp;
+} mcf_pointm;
+
+/* vegp list (src/microclimfCpp.cpp:2084-2094), each [rows,cols]. */
+typedef struct mcf_vegp {
+    const double *hgt, *pai, *x, *gsmax, *leafr, *leaft, *clump, *leafd, *paia, *leafden;
+} mcf_vegp;
+
+/* soilc list (src/microclimfCpp.cpp:2096-2111): 13 matrices + wsa[rows,cols,8]
+ * + hor[rows,cols,24]. */
+typedef struct mcf_soilc {
+    const double *Smin, *Smax, *gref, *soilb, *Psie, *Vq, *Vm, *Mc, *rho;
+    const double *slope, *aspect, *twi, *svfa;
+    const double *wsa; /* [rows,cols,8]  */
+    const double *hor; /* [rows,cols,24] */
+} mcf_soilc;
+
+typedef struct mcf_grid_inputs {
+    int64_t rows, cols, tsteps;
+    int32_t array_forcing; /* 0: runmicro1Cpp geometry, 1: runmicro2Cpp geometry */
+    int32_t reserved0;
+    mcf_obstime obstime;
+    mcf_climate clim;
+    mcf_pointm pointm;
+    mcf_vegp vegp;
+    mcf_soilc soilc;
+    double lat, lon;           /* vector forcing (runmicro1Cpp args lat, lon)            */
+    const double *lats, *lons; /* array forcing  (runmicro2Cpp args lats, lons), [rows,cols] */
+} mcf_grid_inputs;
+
+typedef struct mcf_options {
+    double reqhgt, zref;
+    double Sminp, Smaxp; /* accepted for signature parity; unused by the reference (cpp:975) */
+    double tfact;
+    double mat;          /* mean annual temperature, reqhgt<0 && !complete */
+    int32_t complete;
+    int32_t out[MCF_NOUT];
+    int32_t device;          /* HIP device ordinal                                      */
+    int32_t days_per_chunk;  /* 0 = choose from free HBM                                */
+    int32_t cells_per_block; /* 0 = default (16); 16 or 32                              */
+} mcf_options;
+
+/* Host output buffers, each [rows,cols,tsteps] or NULL when out[v]==0. */
+typedef struct mcf_outputs {
+    double *var[MCF_NOUT];
+} mcf_outputs;
+
+int mcf_abi_version(void);
+const char *mcf_last_error(void);
+/* Number of visible HIP devices (0 when none); never fails. */
+int mcf_device_count(void);
+
+/* One-shot host-to-host solves. */
+int mcf_runmicro1(const mcf_grid_inputs *in, const mcf_options *opt, mcf_outputs *out);
+int mcf_runmicro2(const mcf_grid_inputs *in, const mcf_options *opt, mcf_outputs *out);
+
+/* ---- plan API: HBM-resident inputs, device output ring ---------------------- */
+typedef struct mcf_plan mcf_plan;
+
+/* Uploads all static inputs (and, for vector forcing, builds the per-timestep
+ * table on the device).  `ring_days` is the capacity of each output ring slot in
+ * days, `ring_slots` the number of slots (>=1).  For reqhgt<0 the ring must hold
+ * the whole series (ring_days >= tsteps/24, enforced). */
+int mcf_plan_create(const mcf_grid_inputs *in, const mcf_options *opt,
+                    int32_t ring_days, int32_t ring_slots, mcf_plan **plan);
+void mcf_plan_destroy(mcf_plan *plan);
+
+/* Raster-wide mean of log(twi)/tfact over non-NA cells (src/microclimfCpp.cpp:
+ * 993-1004) is the solver's only global reduction.  mcf_plan_create computes it
+ * for the plan's own cells; row-tiled multi-GPU runs fetch the partial
+ * (sum,count), all-reduce them (RCCL) and install the global mean. */
+int mcf_plan_twi_partial(mcf_plan *plan, double *sum, int64_t *count);
+int mcf_plan_set_twi_mean(mcf_plan *plan, double mean);
+
+/* Array forcing only: upload the [rows,cols,24*ndays] slabs of every forcing
+ * array for days [day0, day0+ndays) into the plan's forcing buffer (slot). */
+int mcf_plan_upload_forcing_days(mcf_plan *plan, const mcf_grid_inputs *in,
+                                 int32_t day0, int32_t ndays, int32_t slot);
+
+/* Solve days [day0, day0+ndays) into ring slot `slot` (async on the plan's
+ * stream).  Slot layout per variable: [rows,cols,24*ndays]. */
+int mcf_plan_run_days(mcf_plan *plan, int32_t day0, int32_t ndays, int32_t slot);
+/* reqhgt<0: after every day has been solved into slot 0, smooth the stored
+ * ground-temperature series into Tz (Tbelowgroundv, cpp:1474-1539). */
+int mcf_plan_belowground(mcf_plan *plan);
+int mcf_plan_sync(mcf_plan *plan);
+
+/* Copy `nsteps` time steps of variable `var` from ring slot `slot` (starting at
+ * step `step0` within the slot) to host memory. */
+int mcf_plan_fetch(mcf_plan *plan, int32_t slot, int32_t var, int64_t step0,
+                   int64_t nsteps, double *host_dst);
+/* Device address of a ring slot variable (for device-side consumers). */
+int mcf_plan_slot_ptr(mcf_plan *plan, int32_t slot, int32_t var, void **dev_ptr);
+
+/* HIP-event timing on the plan's stream: start records an event, stop records
+ * another, synchronises and returns the elapsed milliseconds between them. */
+int mcf_plan_timer_start(mcf_plan *plan);
+int mcf_plan_timer_stop(mcf_plan *plan, float *ms);
+/* Accumulated device time (ms) and launch count of the solver kernel alone,
+ * measured with per-launch HIP events when enabled. */
+int mcf_plan_kernel_timing(mcf_plan *plan, int32_t enable);
+int mcf_plan_kernel_stats(mcf_plan *plan, double *total_ms, int64_t *launches);
+
+/* Information. */
+int64_t mcf_plan_valid_cells(const mcf_plan *plan); /* cells with non-NA hgt */
+int64_t mcf_plan_bytes(const mcf_plan *plan);       /* device bytes held      */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCF_H */

@@ -1,0 +1,150 @@
+"""ctypes mirror of include/mcf.h and the loader for libmcfhip.so.
+
+The structs here are a field-for-field transcription of the C header; the
+shared library is the product (hand-written HIP for gfx950).  There is no CPU
+fallback: `load()` raises if the library is not built, and every solve raises
+if no HIP device is usable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+NOUT = 10
+OUT_NAMES = ("Tz", "tleaf", "relhum", "soilm", "windspeed", "Rdirdown",
+             "Rdifdown", "Rlwdown", "Rswup", "Rlwup")
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class Obstime(C.Structure):
+    _fields_ = [("year", c_int32_p), ("month", c_int32_p), ("day", c_int32_p),
+                ("hour", c_double_p)]
+
+
+CLIM_FIELDS = ("tc", "es", "ea", "tdew", "pk", "swdown", "difrad", "lwdown",
+               "windspeed", "winddir")
+POINTM_FIELDS = ("soilm", "Tg", "Tbp", "G", "umu", "kp", "muGp", "dtrp")
+VEGP_FIELDS = ("hgt", "pai", "x", "gsmax", "leafr", "leaft", "clump", "leafd",
+               "paia", "leafden")
+SOILC_FIELDS = ("Smin", "Smax", "gref", "soilb", "Psie", "Vq", "Vm", "Mc", "rho",
+                "slope", "aspect", "twi", "svfa", "wsa", "hor")
+
+
+def _ptr_struct(name, fields):
+    return type(name, (C.Structure,), {"_fields_": [(f, c_double_p) for f in fields]})
+
+
+Climate = _ptr_struct("Climate", CLIM_FIELDS)
+Pointm = _ptr_struct("Pointm", POINTM_FIELDS)
+Vegp = _ptr_struct("Vegp", VEGP_FIELDS)
+Soilc = _ptr_struct("Soilc", SOILC_FIELDS)
+
+
+class GridInputs(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("cols", C.c_int64), ("tsteps", C.c_int64),
+                ("array_forcing", C.c_int32), ("reserved0", C.c_int32),
+                ("obstime", Obstime), ("clim", Climate), ("pointm", Pointm),
+                ("vegp", Vegp), ("soilc", Soilc),
+                ("lat", C.c_double), ("lon", C.c_double),
+                ("lats", c_double_p), ("lons", c_double_p)]
+
+
+class Options(C.Structure):
+    _fields_ = [("reqhgt", C.c_double), ("zref", C.c_double),
+                ("Sminp", C.c_double), ("Smaxp", C.c_double),
+                ("tfact", C.c_double), ("mat", C.c_double),
+                ("complete", C.c_int32), ("out", C.c_int32 * NOUT),
+                ("device", C.c_int32), ("days_per_chunk", C.c_int32),
+                ("cells_per_block", C.c_int32)]
+
+
+class Outputs(C.Structure):
+    _fields_ = [("var", c_double_p * NOUT)]
+
+
+_PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = _PKG_DIR / "csrc" / "libmcfhip.so"
+
+# every symbol include/mcf.h declares (tests check the .so exports all of them)
+EXPORTS = (
+    "mcf_abi_version", "mcf_last_error", "mcf_device_count",
+    "mcf_runmicro1", "mcf_runmicro2",
+    "mcf_plan_create", "mcf_plan_destroy", "mcf_plan_twi_partial",
+    "mcf_plan_set_twi_mean", "mcf_plan_upload_forcing_days", "mcf_plan_run_days",
+    "mcf_plan_belowground", "mcf_plan_sync", "mcf_plan_fetch", "mcf_plan_slot_ptr",
+    "mcf_plan_timer_start", "mcf_plan_timer_stop", "mcf_plan_kernel_timing",
+    "mcf_plan_kernel_stats", "mcf_plan_valid_cells", "mcf_plan_bytes",
+)
+
+_lib = None
+
+
+class McfError(RuntimeError):
+    """Raised when libmcfhip reports a non-zero status."""
+
+
+def load() -> C.CDLL:
+    """Load libmcfhip.so (built by `make -C microclimf_amd/csrc` / build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("MCF_LIB", LIB_PATH))
+    if not path.exists():
+        raise McfError(
+            f"{path} not found: the HIP extension is not built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C microclimf_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(str(path))
+    lib.mcf_abi_version.restype = C.c_int
+    lib.mcf_last_error.restype = C.c_char_p
+    lib.mcf_device_count.restype = C.c_int
+    GI, OP, OU = C.POINTER(GridInputs), C.POINTER(Options), C.POINTER(Outputs)
+    for fn in (lib.mcf_runmicro1, lib.mcf_runmicro2):
+        fn.restype = C.c_int
+        fn.argtypes = [GI, OP, OU]
+    P = C.c_void_p
+    lib.mcf_plan_create.restype = C.c_int
+    lib.mcf_plan_create.argtypes = [GI, OP, C.c_int32, C.c_int32, C.POINTER(P)]
+    lib.mcf_plan_destroy.restype = None
+    lib.mcf_plan_destroy.argtypes = [P]
+    lib.mcf_plan_twi_partial.restype = C.c_int
+    lib.mcf_plan_twi_partial.argtypes = [P, c_double_p, C.POINTER(C.c_int64)]
+    lib.mcf_plan_set_twi_mean.restype = C.c_int
+    lib.mcf_plan_set_twi_mean.argtypes = [P, C.c_double]
+    lib.mcf_plan_upload_forcing_days.restype = C.c_int
+    lib.mcf_plan_upload_forcing_days.argtypes = [P, GI, C.c_int32, C.c_int32, C.c_int32]
+    lib.mcf_plan_run_days.restype = C.c_int
+    lib.mcf_plan_run_days.argtypes = [P, C.c_int32, C.c_int32, C.c_int32]
+    lib.mcf_plan_belowground.restype = C.c_int
+    lib.mcf_plan_belowground.argtypes = [P]
+    lib.mcf_plan_sync.restype = C.c_int
+    lib.mcf_plan_sync.argtypes = [P]
+    lib.mcf_plan_fetch.restype = C.c_int
+    lib.mcf_plan_fetch.argtypes = [P, C.c_int32, C.c_int32, C.c_int64, C.c_int64, c_double_p]
+    lib.mcf_plan_slot_ptr.restype = C.c_int
+    lib.mcf_plan_slot_ptr.argtypes = [P, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.mcf_plan_timer_start.restype = C.c_int
+    lib.mcf_plan_timer_start.argtypes = [P]
+    lib.mcf_plan_timer_stop.restype = C.c_int
+    lib.mcf_plan_timer_stop.argtypes = [P, C.POINTER(C.c_float)]
+    lib.mcf_plan_kernel_timing.restype = C.c_int
+    lib.mcf_plan_kernel_timing.argtypes = [P, C.c_int32]
+    lib.mcf_plan_kernel_stats.restype = C.c_int
+    lib.mcf_plan_kernel_stats.argtypes = [P, c_double_p, C.POINTER(C.c_int64)]
+    lib.mcf_plan_valid_cells.restype = C.c_int64
+    lib.mcf_plan_valid_cells.argtypes = [P]
+    lib.mcf_plan_bytes.restype = C.c_int64
+    lib.mcf_plan_bytes.argtypes = [P]
+    if lib.mcf_abi_version() != 1:
+        raise McfError("libmcfhip ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        msg = load().mcf_last_error()
+        raise McfError(f"libmcfhip error {status}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,127 @@
+"""Marshalling of R-style arguments (named lists of column-major arrays) into the
+flat C structs of include/mcf.h.
+
+Mirrors what Rcpp does for the reference at src/microclimfCpp.cpp:2056-2111
+(runmicro1Cpp) and :2344-2399 (runmicro2Cpp): lookup is BY NAME, year/month/day
+are coerced to int, every array is read as column-major fp64 with the raster
+row as the fastest index.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Mapping, Sequence
+
+import numpy as np
+
+from . import _abi
+
+
+class Marshalled:
+    """GridInputs/Options plus the numpy arrays that back their pointers."""
+
+    def __init__(self):
+        self.inputs = _abi.GridInputs()
+        self.options = _abi.Options()
+        self._keep = []
+        self.rows = self.cols = self.tsteps = 0
+
+    def _f64(self, a, shape=None, name="?"):
+        arr = np.asarray(a, dtype=np.float64)
+        if shape is not None and tuple(arr.shape) != tuple(shape):
+            if arr.size != int(np.prod(shape)):
+                raise ValueError(f"{name}: expected shape {tuple(shape)}, got {arr.shape}")
+            arr = arr.reshape(shape, order="F")
+        arr = np.asfortranarray(arr)
+        self._keep.append(arr)
+        return arr.ctypes.data_as(_abi.c_double_p)
+
+    def _i32(self, a, n, name):
+        arr = np.ascontiguousarray(np.asarray(a).astype(np.int32))
+        if arr.shape != (n,):
+            raise ValueError(f"{name}: expected length {n}")
+        self._keep.append(arr)
+        return arr.ctypes.data_as(_abi.c_int32_p)
+
+
+def _get(d: Mapping, *names):
+    for n in names:
+        if n in d:
+            return d[n]
+    raise KeyError(f"none of {names} present (have {sorted(d)})")
+
+
+def marshal(obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Mapping,
+            soilc: Mapping, reqhgt: float, zref: float, lat, lon, Sminp: float,
+            Smaxp: float, tfact: float, complete: bool, mat: float,
+            out: Sequence, array_forcing: bool, device: int = 0,
+            days_per_chunk: int = 0, cells_per_block: int = 0) -> Marshalled:
+    m = Marshalled()
+    hgt = np.asarray(vegp["hgt"], dtype=np.float64)
+    if hgt.ndim != 2:
+        raise ValueError("vegp$hgt must be a rows x cols matrix")
+    R, Cc = hgt.shape
+    T = len(np.asarray(obstime["year"]))
+    m.rows, m.cols, m.tsteps = R, Cc, T
+    gi = m.inputs
+    gi.rows, gi.cols, gi.tsteps = R, Cc, T
+    gi.array_forcing = 1 if array_forcing else 0
+    gi.obstime.year = m._i32(obstime["year"], T, "obstime$year")
+    gi.obstime.month = m._i32(obstime["month"], T, "obstime$month")
+    gi.obstime.day = m._i32(obstime["day"], T, "obstime$day")
+    gi.obstime.hour = m._f64(obstime["hour"], (T,), "obstime$hour")
+    fshape = (R, Cc, T) if array_forcing else (T,)
+    # climdata: data.frame names (1Cpp) or list names (2Cpp)
+    names = {"tc": ("temp", "tc"), "pk": ("pres", "pk")}
+    for f in _abi.CLIM_FIELDS:
+        src = _get(climdata, *names.get(f, (f,)))
+        shape = (T,) if f == "winddir" else fshape
+        setattr(gi.clim, f, m._f64(src, shape, f"climdata${f}"))
+    need_tgp = (reqhgt < 0) and (not complete)
+    for f in _abi.POINTM_FIELDS:
+        if f in ("Tg", "Tbp") and not need_tgp:
+            setattr(gi.pointm, f, None)
+            continue
+        src = _get(pointm, *(("G", "Gp") if f == "G" else (f,)))
+        if f == "Tbp" and np.ndim(src) == 0:       # `pointm$Tbp <- 0` (R/internal.R:1096)
+            src = np.full(fshape, float(src))
+        setattr(gi.pointm, f, m._f64(src, fshape, f"pointm${f}"))
+    for f in _abi.VEGP_FIELDS:
+        setattr(gi.vegp, f, m._f64(vegp[f], (R, Cc), f"vegp${f}"))
+    for f in _abi.SOILC_FIELDS:
+        shape = (R, Cc, 8) if f == "wsa" else (R, Cc, 24) if f == "hor" else (R, Cc)
+        setattr(gi.soilc, f, m._f64(soilc[f], shape, f"soilc${f}"))
+    if array_forcing:
+        gi.lats = m._f64(lat, (R, Cc), "lats")
+        gi.lons = m._f64(lon, (R, Cc), "lons")
+        gi.lat = gi.lon = float("nan")
+    else:
+        gi.lat, gi.lon = float(lat), float(lon)
+        gi.lats = gi.lons = None
+    op = m.options
+    op.reqhgt, op.zref = float(reqhgt), float(zref)
+    op.Sminp, op.Smaxp = float(Sminp), float(Smaxp)
+    op.tfact, op.mat = float(tfact), float(mat)
+    op.complete = 1 if complete else 0
+    out = list(out)
+    if len(out) != _abi.NOUT:
+        raise ValueError("out must have 10 entries")
+    for v in range(_abi.NOUT):
+        op.out[v] = 1 if out[v] else 0     # may arrive as numeric 0/1 (R/internal.R:1161)
+    op.device = device
+    op.days_per_chunk = days_per_chunk
+    op.cells_per_block = cells_per_block
+    return m
+
+
+def alloc_outputs(m: Marshalled):
+    """Host output arrays [rows, cols, tsteps] (column-major) for requested vars."""
+    outs = _abi.Outputs()
+    arrays = {}
+    for v, name in enumerate(_abi.OUT_NAMES):
+        if m.options.out[v]:
+            a = np.empty((m.rows, m.cols, m.tsteps), dtype=np.float64, order="F")
+            arrays[name] = a
+            outs.var[v] = a.ctypes.data_as(_abi.c_double_p)
+        else:
+            outs.var[v] = None
+    return outs, arrays

@@ -1,0 +1,92 @@
+"""ctypes front end of the CPU oracle (TEST INFRASTRUCTURE — see mcf_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  It reuses the product's argument marshalling so that the oracle
+and libmcfhip see byte-identical inputs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from microclimf_amd import _abi
+from microclimf_amd.marshal import alloc_outputs, marshal
+
+_DIR = Path(__file__).resolve().parent
+LIB_PATH = _DIR / "libmcf_oracle.so"
+_lib = None
+
+
+def build(force: bool = False) -> Path:
+    srcs = [_DIR / "mcf_oracle.c", _DIR / "mcf_oracle.h", _DIR / "pointmodel.c",
+            _DIR / "pointmodel.h", _DIR.parent / "include" / "mcf.h"]
+    srcs = [s for s in srcs if s.exists()]
+    if force or not LIB_PATH.exists() or any(s.stat().st_mtime > LIB_PATH.stat().st_mtime for s in srcs):
+        subprocess.run(["make", "-C", str(_DIR), "-B", "libmcf_oracle.so"], check=True,
+                       capture_output=True)
+    return LIB_PATH
+
+
+class Solmodel(C.Structure):
+    _fields_ = [("zend", C.c_double), ("zenr", C.c_double), ("azid", C.c_double), ("azir", C.c_double)]
+
+
+class Kstruct(C.Structure):
+    _fields_ = [("k", C.c_double), ("kd", C.c_double), ("Kc", C.c_double)]
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        lib = C.CDLL(str(LIB_PATH))
+        lib.orc_run_grid.restype = C.c_int
+        lib.orc_run_grid.argtypes = [C.POINTER(_abi.GridInputs), C.POINTER(_abi.Options),
+                                     C.POINTER(_abi.Outputs)]
+        lib.orc_solposition.restype = Solmodel
+        lib.orc_solposition.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double]
+        lib.orc_solarindex.restype = C.c_double
+        lib.orc_solarindex.argtypes = [C.c_double] * 4 + [C.c_int]
+        lib.orc_cank.restype = Kstruct
+        lib.orc_cank.argtypes = [C.c_double] * 3
+        lib.orc_satvap.restype = C.c_double
+        lib.orc_satvap.argtypes = [C.c_double]
+        lib.orc_julday.restype = C.c_int
+        lib.orc_julday.argtypes = [C.c_int] * 3
+        lib.orc_na_real.restype = C.c_double
+        lib.orc_soild.restype = C.c_double
+        lib.orc_soild.argtypes = [C.c_double] * 4
+        lib.orc_zeroplanedis.restype = C.c_double
+        lib.orc_zeroplanedis.argtypes = [C.c_double] * 2
+        lib.orc_roughlength.restype = C.c_double
+        lib.orc_roughlength.argtypes = [C.c_double] * 4
+        lib.orc_man.restype = None
+        lib.orc_man.argtypes = [_abi.c_double_p, C.c_int, C.c_int, _abi.c_double_p]
+        _lib = lib
+    return _lib
+
+
+def run_grid(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact,
+             complete, mat, out, array_forcing=False):
+    """Oracle for runmicro1Cpp (array_forcing=False) / runmicro2Cpp (True)."""
+    lib = load()
+    m = marshal(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact,
+                complete, mat, out, array_forcing)
+    outs, arrays = alloc_outputs(m)
+    rc = lib.orc_run_grid(C.byref(m.inputs), C.byref(m.options), C.byref(outs))
+    if rc != 0:
+        raise RuntimeError(f"oracle failed: {rc}")
+    return arrays
+
+
+def solposition(lat, lon, year, month, day, hour):
+    s = load().orc_solposition(lat, lon, int(year), int(month), int(day), hour)
+    return s.zend, s.zenr, s.azid, s.azir
+
+
+def satvap(tc):
+    f = load().orc_satvap
+    return np.vectorize(f, otypes=[float])(tc)
