@@ -1,0 +1,142 @@
+"""Host-side mirror of the reference's operator interface for the grid solver.
+
+`runmicro1Cpp` / `runmicro2Cpp` take the same 15 positional arguments, with the
+same names and meaning, as the R functions of the reference
+(R/RcppExports.R:72-78) that `.runmodel1Cpp` / `.runmodel2Cpp` call
+(R/internal.R:1168, 1342): R named lists / data.frames become Python mappings
+of numpy arrays, R's column-major arrays become Fortran-ordered numpy arrays,
+and the returned named list becomes a dict holding only the requested
+variables, in the reference's order (src/microclimfCpp.cpp:2326-2335), each of
+shape (rows, cols, tsteps).
+
+All arithmetic happens in libmcfhip.so (hand-written HIP, gfx950); this module
+only marshals pointers.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Mapping, Sequence
+
+import numpy as np
+
+from . import _abi
+from .marshal import Marshalled, alloc_outputs, marshal
+
+
+def _run(fn_name, array_forcing, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon,
+         Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block):
+    lib = _abi.load()
+    m = marshal(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp,
+                tfact, complete, mat, out, array_forcing, device, days_per_chunk, cells_per_block)
+    outs, arrays = alloc_outputs(m)
+    _abi.check(getattr(lib, fn_name)(C.byref(m.inputs), C.byref(m.options), C.byref(outs)))
+    return arrays
+
+
+def runmicro1Cpp(obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Mapping, soilc: Mapping,
+                 reqhgt: float, zref: float, lat: float, lon: float, Sminp: float, Smaxp: float,
+                 tfact: float, complete: bool, mat: float, out: Sequence, *, device: int = 0,
+                 days_per_chunk: int = 0, cells_per_block: int = 0) -> dict:
+    """Grid microclimate model, hourly, static vegetation, data.frame (vector) climate.
+
+    Drop-in for the reference's runmicro1Cpp (src/microclimfCpp.cpp:2052-2337)."""
+    return _run("mcf_runmicro1", False, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon,
+                Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block)
+
+
+def runmicro2Cpp(obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Mapping, soilc: Mapping,
+                 reqhgt: float, zref: float, lats, lons, Sminp: float, Smaxp: float, tfact: float,
+                 complete: bool, mat: float, out: Sequence, *, device: int = 0,
+                 days_per_chunk: int = 0, cells_per_block: int = 0) -> dict:
+    """Grid microclimate model, hourly, static vegetation, array climate inputs.
+
+    Drop-in for the reference's runmicro2Cpp (src/microclimfCpp.cpp:2340-2621)."""
+    return _run("mcf_runmicro2", True, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons,
+                Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block)
+
+
+class Plan:
+    """HBM-resident solver plan (include/mcf.h plan API): inputs uploaded once,
+    day chunks solved into a device output ring."""
+
+    def __init__(self, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp,
+                 tfact, complete, mat, out, *, array_forcing=False, ring_days=1, ring_slots=1,
+                 device=0, cells_per_block=0):
+        self._lib = _abi.load()
+        self._m: Marshalled = marshal(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon,
+                                      Sminp, Smaxp, tfact, complete, mat, out, array_forcing, device,
+                                      0, cells_per_block)
+        self._p = C.c_void_p()
+        _abi.check(self._lib.mcf_plan_create(C.byref(self._m.inputs), C.byref(self._m.options),
+                                             int(ring_days), int(ring_slots), C.byref(self._p)))
+        self.rows, self.cols, self.tsteps = self._m.rows, self._m.cols, self._m.tsteps
+        self.ndays = self.tsteps // 24
+        self.array_forcing = bool(array_forcing)
+
+    def close(self):
+        if getattr(self, "_p", None) is not None and self._p.value:
+            self._lib.mcf_plan_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def valid_cells(self) -> int:
+        return int(self._lib.mcf_plan_valid_cells(self._p))
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self._lib.mcf_plan_bytes(self._p))
+
+    def twi_partial(self):
+        s, n = C.c_double(), C.c_int64()
+        _abi.check(self._lib.mcf_plan_twi_partial(self._p, C.byref(s), C.byref(n)))
+        return s.value, n.value
+
+    def set_twi_mean(self, mean: float):
+        _abi.check(self._lib.mcf_plan_set_twi_mean(self._p, float(mean)))
+
+    def upload_forcing_days(self, day0: int, ndays: int, slot: int = 0):
+        _abi.check(self._lib.mcf_plan_upload_forcing_days(self._p, C.byref(self._m.inputs), day0, ndays, slot))
+
+    def run_days(self, day0: int, ndays: int, slot: int = 0):
+        _abi.check(self._lib.mcf_plan_run_days(self._p, day0, ndays, slot))
+
+    def belowground(self):
+        _abi.check(self._lib.mcf_plan_belowground(self._p))
+
+    def sync(self):
+        _abi.check(self._lib.mcf_plan_sync(self._p))
+
+    def fetch(self, slot: int, var, step0: int, nsteps: int) -> np.ndarray:
+        v = _abi.OUT_NAMES.index(var) if isinstance(var, str) else int(var)
+        a = np.empty((self.rows, self.cols, nsteps), dtype=np.float64, order="F")
+        _abi.check(self._lib.mcf_plan_fetch(self._p, slot, v, step0, nsteps,
+                                            a.ctypes.data_as(_abi.c_double_p)))
+        return a
+
+    def timer_start(self):
+        _abi.check(self._lib.mcf_plan_timer_start(self._p))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        _abi.check(self._lib.mcf_plan_timer_stop(self._p, C.byref(ms)))
+        return ms.value
+
+    def kernel_timing(self, enable: bool = True):
+        _abi.check(self._lib.mcf_plan_kernel_timing(self._p, 1 if enable else 0))
+
+    def kernel_stats(self):
+        ms, n = C.c_double(), C.c_int64()
+        _abi.check(self._lib.mcf_plan_kernel_stats(self._p, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

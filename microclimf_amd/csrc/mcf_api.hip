@@ -1,0 +1,630 @@
+// mcf_api.hip — the C ABI of include/mcf.h: plan management, day-chunk streaming
+// through HBM, and the one-shot host-to-host entry points that stand in for the
+// reference's _microclimf_runmicro1Cpp / _microclimf_runmicro2Cpp
+// (src/RcppExports.cpp:250-297).
+//
+// No CPU fallback: every entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/mcf.h"
+#include "mcf_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            char b_[512];                                                                    \
+            snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                     __FILE__, __LINE__);                                                    \
+            return fail(e_ == hipErrorOutOfMemory ? MCF_ERR_NOMEM : MCF_ERR_HIP, b_);        \
+        }                                                                                    \
+    } while (0)
+
+const uint64_t kNaBits = 0x7FF00000000007A2ULL;
+double na_real_host() {
+    double d;
+    memcpy(&d, &kNaBits, 8);
+    return d;
+}
+
+}  // namespace
+
+struct mcf_plan {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int64_t rows = 0, cols = 0, N = 0, tsteps = 0;
+    int ndays = 0;
+    bool af = false, bg = false;
+    int cpb = 16;
+    mcf_options opt{};
+    mcf::Globals g{};
+    int hiy = 8760;
+    double lat = 0, lon = 0;
+    std::vector<void*> allocs;
+    int64_t bytes = 0;
+    // static inputs
+    const double* d_veg[10] = {};
+    const double* d_soil[13] = {};
+    const double *d_wsa = nullptr, *d_hor = nullptr, *d_lats = nullptr, *d_lons = nullptr;
+    double* d_cellc = nullptr;
+    double* d_tt = nullptr;
+    double* d_twi2 = nullptr;
+    double twi_sum = 0;
+    int64_t twi_count = 0;
+    double twi_mean = 0;
+    bool cells_ready = false;
+    // array forcing
+    double* d_dt = nullptr;
+    int32_t* d_windex = nullptr;
+    double* d_mxtc = nullptr;
+    double* d_force = nullptr;  // [slots][15][N*ring_days*24]
+    std::vector<int> force_day0, force_ndays;
+    // outputs
+    int ring_days = 0, ring_slots = 0;
+    double* d_ring = nullptr;   // [slots][nvars][N*ring_days*24]
+    int var_slot[MCF_NOUT];     // index among enabled vars or -1
+    int nvars = 0;
+    // reqhgt < 0
+    double *d_tgser = nullptr, *d_ddsum = nullptr, *d_scratch = nullptr;
+    const double *d_Tgp = nullptr, *d_Tbp = nullptr;
+    // timing
+    bool ktiming = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> kev;
+    double ktotal_ms = 0;
+    int64_t klaunches = 0;
+    int64_t valid_cells = 0;
+};
+
+namespace {
+
+int dalloc(mcf_plan* p, void** ptr, int64_t nbytes) {
+    if (nbytes <= 0) nbytes = 8;
+    hipError_t e = hipMalloc(ptr, (size_t)nbytes);
+    if (e != hipSuccess) {
+        char b[256];
+        snprintf(b, sizeof b, "hipMalloc(%lld bytes) failed: %s", (long long)nbytes, hipGetErrorString(e));
+        return fail(MCF_ERR_NOMEM, b);
+    }
+    p->allocs.push_back(*ptr);
+    p->bytes += nbytes;
+    return MCF_OK;
+}
+
+int upload(mcf_plan* p, const double* host, int64_t n, const double** dev, const char* name) {
+    if (!host) return fail(MCF_ERR_ARG, std::string("missing input array: ") + name);
+    void* d = nullptr;
+    int rc = dalloc(p, &d, n * 8);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d, host, (size_t)n * 8, hipMemcpyHostToDevice, p->stream));
+    *dev = (const double*)d;
+    return MCF_OK;
+}
+
+int check_inputs(const mcf_grid_inputs* in, const mcf_options* opt) {
+    if (!in || !opt) return fail(MCF_ERR_ARG, "null inputs/options");
+    if (in->rows <= 0 || in->cols <= 0) return fail(MCF_ERR_ARG, "rows/cols must be positive");
+    if (in->tsteps < 0) return fail(MCF_ERR_ARG, "negative tsteps");
+    if (in->tsteps > 0 && (!in->obstime.year || !in->obstime.month || !in->obstime.day || !in->obstime.hour))
+        return fail(MCF_ERR_ARG, "obstime columns missing");
+    if (in->array_forcing && (!in->lats || !in->lons)) return fail(MCF_ERR_ARG, "lats/lons missing");
+    if (!(opt->cells_per_block == 0 || opt->cells_per_block == 16 || opt->cells_per_block == 32))
+        return fail(MCF_ERR_ARG, "cells_per_block must be 0, 16 or 32");
+    return MCF_OK;
+}
+
+int ensure_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(MCF_ERR_NO_DEVICE, "no HIP device available (libmcfhip has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(MCF_ERR_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    return MCF_OK;
+}
+
+const double* const* clim_ptrs(const mcf_grid_inputs* in, const double* out[15]) {
+    // TF_TC .. TF_DTRP order
+    out[0] = in->clim.tc; out[1] = in->clim.es; out[2] = in->clim.ea; out[3] = in->clim.tdew;
+    out[4] = in->clim.pk; out[5] = in->clim.swdown; out[6] = in->clim.difrad; out[7] = in->clim.lwdown;
+    out[8] = in->clim.windspeed; out[9] = in->pointm.soilm; out[10] = in->pointm.G;
+    out[11] = in->pointm.umu; out[12] = in->pointm.kp; out[13] = in->pointm.muGp; out[14] = in->pointm.dtrp;
+    return out;
+}
+const char* kRawNames[15] = {"tc", "es", "ea", "tdew", "pk", "swdown", "difrad", "lwdown", "windspeed",
+                             "pointm$soilm", "pointm$G", "pointm$umu", "pointm$kp", "pointm$muGp",
+                             "pointm$dtrp"};
+
+int ensure_cells(mcf_plan* p) {
+    if (p->cells_ready) return MCF_OK;
+    mcf::CellSetupArgs a{};
+    a.N = p->N;
+    a.hgt = p->d_veg[0]; a.pai = p->d_veg[1]; a.x = p->d_veg[2]; a.gsmax = p->d_veg[3];
+    a.leafr = p->d_veg[4]; a.leaft = p->d_veg[5]; a.clump = p->d_veg[6]; a.leafd = p->d_veg[7];
+    a.paia = p->d_veg[8]; a.leafden = p->d_veg[9];
+    a.Smin = p->d_soil[0]; a.Smax = p->d_soil[1]; a.gref = p->d_soil[2]; a.soilb = p->d_soil[3];
+    a.Psie = p->d_soil[4]; a.Vq = p->d_soil[5]; a.Vm = p->d_soil[6]; a.Mc = p->d_soil[7];
+    a.rho = p->d_soil[8]; a.slope = p->d_soil[9]; a.aspect = p->d_soil[10]; a.twi = p->d_soil[11];
+    a.svfa = p->d_soil[12];
+    a.lats = p->d_lats; a.lons = p->d_lons; a.lat = p->lat; a.lon = p->lon;
+    a.tfact = p->opt.tfact;
+    a.twi_mean = p->twi_mean;
+    a.g = p->g;
+    a.cellc = p->d_cellc;
+    mcf::launch_cell_setup(a, p->stream);
+    HIP_TRY(hipGetLastError());
+    p->cells_ready = true;
+    return MCF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mcf_abi_version(void) { return MCF_ABI_VERSION; }
+const char* mcf_last_error(void) { return g_err.c_str(); }
+int mcf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void mcf_plan_destroy(mcf_plan* p) {
+    if (!p) return;
+    hipSetDevice(p->device);
+    if (p->stream) hipStreamSynchronize(p->stream);
+    for (auto& e : p->kev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    for (void* a : p->allocs) hipFree(a);
+    if (p->ev0) hipEventDestroy(p->ev0);
+    if (p->ev1) hipEventDestroy(p->ev1);
+    if (p->stream) hipStreamDestroy(p->stream);
+    delete p;
+}
+
+int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t ring_days, int32_t ring_slots,
+                    mcf_plan** out) {
+    if (!out) return fail(MCF_ERR_ARG, "null plan pointer");
+    *out = nullptr;
+    int rc = check_inputs(in, opt);
+    if (rc) return rc;
+    rc = ensure_device(opt->device);
+    if (rc) return rc;
+    mcf_plan* p = new mcf_plan();
+    struct Guard { mcf_plan* p; ~Guard() { if (p) mcf_plan_destroy(p); } } guard{p};
+    p->device = opt->device;
+    HIP_TRY(hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&p->ev0));
+    HIP_TRY(hipEventCreate(&p->ev1));
+    p->rows = in->rows; p->cols = in->cols; p->N = in->rows * in->cols; p->tsteps = in->tsteps;
+    p->ndays = (int)(in->tsteps / 24);                       // cpp:2116 truncation
+    p->af = in->array_forcing != 0;
+    p->bg = opt->reqhgt < 0.0;
+    p->cpb = opt->cells_per_block ? opt->cells_per_block : 16;
+    p->opt = *opt;
+    p->lat = in->lat; p->lon = in->lon;
+    const int64_t N = p->N, T = p->tsteps;
+    if (ring_slots < 1) ring_slots = 1;
+    if (ring_days < 1) ring_days = 1;
+    if (ring_days > std::max(p->ndays, 1)) ring_days = std::max(p->ndays, 1);
+    // reqhgt < 0 smooths the whole series (incl. steps past the last whole day, which read as 0)
+    if (p->bg) { ring_slots = 1; ring_days = (int)std::max<int64_t>((in->tsteps + 23) / 24, 1); }
+    p->ring_days = ring_days; p->ring_slots = ring_slots;
+
+    // ---- static rasters
+    const double* veg[10] = {in->vegp.hgt, in->vegp.pai, in->vegp.x, in->vegp.gsmax, in->vegp.leafr,
+                             in->vegp.leaft, in->vegp.clump, in->vegp.leafd, in->vegp.paia, in->vegp.leafden};
+    const char* vegn[10] = {"hgt", "pai", "x", "gsmax", "leafr", "leaft", "clump", "leafd", "paia", "leafden"};
+    for (int i = 0; i < 10; ++i)
+        if ((rc = upload(p, veg[i], N, &p->d_veg[i], vegn[i]))) return rc;
+    const double* soil[13] = {in->soilc.Smin, in->soilc.Smax, in->soilc.gref, in->soilc.soilb, in->soilc.Psie,
+                              in->soilc.Vq, in->soilc.Vm, in->soilc.Mc, in->soilc.rho, in->soilc.slope,
+                              in->soilc.aspect, in->soilc.twi, in->soilc.svfa};
+    const char* soiln[13] = {"Smin", "Smax", "gref", "soilb", "Psie", "Vq", "Vm", "Mc", "rho", "slope",
+                             "aspect", "twi", "svfa"};
+    for (int i = 0; i < 13; ++i)
+        if ((rc = upload(p, soil[i], N, &p->d_soil[i], soiln[i]))) return rc;
+    if ((rc = upload(p, in->soilc.wsa, N * 8, &p->d_wsa, "wsa"))) return rc;
+    if ((rc = upload(p, in->soilc.hor, N * 24, &p->d_hor, "hor"))) return rc;
+    if (p->af) {
+        if ((rc = upload(p, in->lats, N, &p->d_lats, "lats"))) return rc;
+        if ((rc = upload(p, in->lons, N, &p->d_lons, "lons"))) return rc;
+    }
+    int64_t nvalid = 0;
+    for (int64_t c = 0; c < N; ++c) nvalid += !std::isnan(in->vegp.hgt[c]);
+    p->valid_cells = nvalid;
+
+    // ---- solver constants
+    p->g.reqhgt = opt->reqhgt;
+    p->g.reqhgt2 = opt->reqhgt < 0.00001 ? 0.00001 : opt->reqhgt;      // cpp:2246-2247
+    p->g.zref = opt->zref;
+    p->g.hf0 = mcf::hf0_constant();
+    p->g.shadowmask = p->af ? 0 : 1;
+    p->g.dTmx = 0.0;
+    p->hiy = 365 * 24;
+    if (T > 0 && in->obstime.year[0] % 4 == 0) p->hiy = 366 * 24;      // cpp:2171-2172
+
+    // ---- the one global reduction: mean of log(twi)/tfact, cpp:993-1004
+    void* tmp = nullptr;
+    if ((rc = dalloc(p, &tmp, 16))) return rc;
+    p->d_twi2 = (double*)tmp;
+    mcf::launch_twi_partial(p->d_soil[11], N, opt->tfact, p->d_twi2, p->stream);
+    double h2[2];
+    HIP_TRY(hipMemcpyAsync(h2, p->d_twi2, 16, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    p->twi_sum = h2[0];
+    p->twi_count = (int64_t)h2[1];
+    p->twi_mean = h2[0] / h2[1];
+
+    if ((rc = dalloc(p, &tmp, (int64_t)mcf::cell_field_count() * N * 8))) return rc;
+    p->d_cellc = (double*)tmp;
+
+    // ---- time tables
+    const double* raw[15];
+    clim_ptrs(in, raw);
+    for (int f = 0; f < 15; ++f)
+        if (T > 0 && !raw[f]) return fail(MCF_ERR_ARG, std::string("missing forcing array: ") + kRawNames[f]);
+    if (T > 0 && !in->clim.winddir) return fail(MCF_ERR_ARG, "missing forcing array: winddir");
+    std::vector<void*> temps;   // freed after setup
+    auto up_tmp = [&](const void* host, int64_t nbytes, void** dev) -> int {
+        if (nbytes <= 0) nbytes = 8;
+        HIP_TRY(hipMalloc(dev, (size_t)nbytes));
+        temps.push_back(*dev);
+        if (host) HIP_TRY(hipMemcpyAsync(*dev, host, (size_t)nbytes, hipMemcpyHostToDevice, p->stream));
+        return MCF_OK;
+    };
+    struct TmpGuard { std::vector<void*>& t; ~TmpGuard() { for (void* q : t) hipFree(q); } } tguard{temps};
+    void *dy = nullptr, *dm = nullptr, *dd = nullptr, *dh = nullptr, *dw = nullptr;
+    if (T > 0) {
+        if ((rc = up_tmp(in->obstime.year, T * 4, &dy))) return rc;
+        if ((rc = up_tmp(in->obstime.month, T * 4, &dm))) return rc;
+        if ((rc = up_tmp(in->obstime.day, T * 4, &dd))) return rc;
+        if ((rc = up_tmp(in->obstime.hour, T * 8, &dh))) return rc;
+        if ((rc = up_tmp(in->clim.winddir, T * 8, &dw))) return rc;
+    }
+    if (!p->af) {
+        double mxtc = -273.15;                                           // cpp:2159-2168
+        for (int64_t k = 0; k < T; ++k)
+            if (in->clim.tc[k] > mxtc) mxtc = in->clim.tc[k];
+        p->g.dTmx = -0.6273 * mxtc + 49.79;                              // cpp:1236
+        if ((rc = dalloc(p, &tmp, (int64_t)std::max(p->ndays, 1) * mcf::time_field_count() * 24 * 8))) return rc;
+        p->d_tt = (double*)tmp;
+        if (p->ndays > 0) {
+            mcf::TimeSetupArgs ta{};
+            ta.nsteps = p->ndays * 24;
+            ta.year = (const int32_t*)dy; ta.month = (const int32_t*)dm; ta.day = (const int32_t*)dd;
+            ta.hour = (const double*)dh; ta.winddir = (const double*)dw;
+            for (int f = 0; f < 15; ++f) {
+                void* q = nullptr;
+                if ((rc = up_tmp(raw[f], T * 8, &q))) return rc;
+                ta.raw[f] = (const double*)q;
+            }
+            ta.lat = in->lat; ta.lon = in->lon;
+            ta.tt = p->d_tt;
+            mcf::launch_time_setup(ta, p->stream);
+            HIP_TRY(hipGetLastError());
+        }
+    } else {
+        if ((rc = dalloc(p, &tmp, std::max<int64_t>(T, 1) * 4 * 8))) return rc;
+        p->d_dt = (double*)tmp;
+        if ((rc = dalloc(p, &tmp, std::max<int64_t>(T, 1) * 4))) return rc;
+        p->d_windex = (int32_t*)tmp;
+        if ((rc = dalloc(p, &tmp, N * 8))) return rc;
+        p->d_mxtc = (double*)tmp;
+        if (T > 0) {
+            mcf::DateSetupArgs da{};
+            da.nsteps = (int)T;
+            da.year = (const int32_t*)dy; da.month = (const int32_t*)dm; da.day = (const int32_t*)dd;
+            da.hour = (const double*)dh; da.winddir = (const double*)dw;
+            da.dt = p->d_dt; da.windex = p->d_windex;
+            mcf::launch_date_setup(da, p->stream);
+            HIP_TRY(hipGetLastError());
+        }
+        // per-cell max air temperature over the WHOLE series (cpp:2467-2471), streamed in slabs
+        mcf::launch_fill(p->d_mxtc, N, -273.15, p->stream);
+        int64_t slab_steps = std::max<int64_t>(1, std::min<int64_t>(T, (int64_t)(256LL << 20) / (N * 8)));
+        void* dslab = nullptr;
+        if (T > 0) {
+            if ((rc = up_tmp(nullptr, slab_steps * N * 8, &dslab))) return rc;
+            for (int64_t k0 = 0; k0 < T; k0 += slab_steps) {
+                int64_t ns = std::min(slab_steps, T - k0);
+                HIP_TRY(hipMemcpyAsync(dslab, in->clim.tc + N * k0, (size_t)(ns * N * 8), hipMemcpyHostToDevice,
+                                       p->stream));
+                mcf::launch_mxtc((const double*)dslab, N, (int)ns, p->d_mxtc, p->stream);
+            }
+            HIP_TRY(hipGetLastError());
+        }
+        // forcing ring
+        int64_t fbytes = (int64_t)ring_slots * 15 * N * ring_days * 24 * 8;
+        if ((rc = dalloc(p, &tmp, fbytes))) return rc;
+        p->d_force = (double*)tmp;
+        p->force_day0.assign(ring_slots, -1);
+        p->force_ndays.assign(ring_slots, 0);
+    }
+
+    // ---- output ring
+    p->nvars = 0;
+    for (int v = 0; v < MCF_NOUT; ++v) p->var_slot[v] = opt->out[v] ? p->nvars++ : -1;
+    int64_t slot_elems = N * (int64_t)ring_days * 24;
+    if ((rc = dalloc(p, &tmp, (int64_t)ring_slots * std::max(p->nvars, 1) * slot_elems * 8))) return rc;
+    p->d_ring = (double*)tmp;
+
+    // ---- below-ground series
+    if (p->bg) {
+        if ((rc = dalloc(p, &tmp, N * std::max<int64_t>(T, 1) * 8))) return rc;
+        p->d_tgser = (double*)tmp;
+        // steps past the last whole day read as 0 in the reference (std::vector<double> Tg(tsteps))
+        mcf::launch_fill(p->d_tgser, N * T, 0.0, p->stream);
+        if ((rc = dalloc(p, &tmp, N * 8))) return rc;
+        p->d_ddsum = (double*)tmp;
+        mcf::launch_fill(p->d_ddsum, N, 0.0, p->stream);
+        if ((rc = dalloc(p, &tmp, N * 2 * (int64_t)std::max(p->ndays, 1) * 8))) return rc;
+        p->d_scratch = (double*)tmp;
+        if (!opt->complete) {
+            int64_t n = p->af ? N * T : T;
+            if ((rc = upload(p, in->pointm.Tg, n, &p->d_Tgp, "pointm$Tg"))) return rc;
+            if ((rc = upload(p, in->pointm.Tbp, n, &p->d_Tbp, "pointm$Tbp"))) return rc;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    guard.p = nullptr;
+    *out = p;
+    return MCF_OK;
+}
+
+int mcf_plan_twi_partial(mcf_plan* p, double* sum, int64_t* count) {
+    if (!p || !sum || !count) return fail(MCF_ERR_ARG, "null argument");
+    *sum = p->twi_sum;
+    *count = p->twi_count;
+    return MCF_OK;
+}
+
+int mcf_plan_set_twi_mean(mcf_plan* p, double mean) {
+    if (!p) return fail(MCF_ERR_ARG, "null plan");
+    p->twi_mean = mean;
+    p->cells_ready = false;
+    return MCF_OK;
+}
+
+int mcf_plan_upload_forcing_days(mcf_plan* p, const mcf_grid_inputs* in, int32_t day0, int32_t ndays, int32_t slot) {
+    if (!p || !in) return fail(MCF_ERR_ARG, "null argument");
+    if (!p->af) return fail(MCF_ERR_STATE, "plan uses vector forcing");
+    if (slot < 0 || slot >= p->ring_slots) return fail(MCF_ERR_ARG, "slot out of range");
+    if (day0 < 0 || ndays < 1 || ndays > p->ring_days || day0 + ndays > p->ndays)
+        return fail(MCF_ERR_ARG, "day range out of bounds");
+    HIP_TRY(hipSetDevice(p->device));
+    const double* raw[15];
+    clim_ptrs(in, raw);
+    const int64_t N = p->N, cap = N * (int64_t)p->ring_days * 24, n = N * (int64_t)ndays * 24;
+    for (int f = 0; f < 15; ++f) {
+        if (!raw[f]) return fail(MCF_ERR_ARG, std::string("missing forcing array: ") + kRawNames[f]);
+        double* dst = p->d_force + ((int64_t)slot * 15 + f) * cap;
+        HIP_TRY(hipMemcpyAsync(dst, raw[f] + N * (int64_t)day0 * 24, (size_t)n * 8, hipMemcpyHostToDevice,
+                               p->stream));
+    }
+    p->force_day0[slot] = day0;
+    p->force_ndays[slot] = ndays;
+    return MCF_OK;
+}
+
+int mcf_plan_run_days(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot) {
+    if (!p) return fail(MCF_ERR_ARG, "null plan");
+    if (slot < 0 || slot >= p->ring_slots) return fail(MCF_ERR_ARG, "slot out of range");
+    if (day0 < 0 || ndays < 1 || day0 + ndays > p->ndays) return fail(MCF_ERR_ARG, "day range out of bounds");
+    if (!p->bg && ndays > p->ring_days) return fail(MCF_ERR_ARG, "more days than the ring slot holds");
+    HIP_TRY(hipSetDevice(p->device));
+    int rc = ensure_cells(p);
+    if (rc) return rc;
+    mcf::SolveArgs a{};
+    a.N = p->N;
+    a.cellc = p->d_cellc; a.hor = p->d_hor; a.wsa = p->d_wsa; a.tt = p->d_tt;
+    const int64_t cap = p->N * (int64_t)p->ring_days * 24;
+    if (p->af) {
+        if (p->force_day0[slot] != day0 || p->force_ndays[slot] < ndays)
+            return fail(MCF_ERR_STATE, "forcing for these days has not been uploaded to this slot");
+        for (int f = 0; f < 15; ++f) a.af[f] = p->d_force + ((int64_t)slot * 15 + f) * cap;
+        a.dt = p->d_dt; a.windex = p->d_windex; a.mxtc = p->d_mxtc;
+        a.force_step0 = 0;
+    }
+    for (int v = 0; v < MCF_NOUT; ++v)
+        a.out[v] = p->var_slot[v] < 0 ? nullptr : p->d_ring + ((int64_t)slot * p->nvars + p->var_slot[v]) * cap;
+    a.slot_step0 = p->bg ? (int64_t)day0 * 24 : 0;
+    a.tgser = p->d_tgser; a.ddsum = p->d_ddsum;
+    a.day0 = day0; a.ndays = ndays;
+    a.g = p->g;
+    if (p->ktiming) {
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, p->stream));
+        mcf::launch_solve(a, p->cpb, p->af, p->bg, p->stream);
+        HIP_TRY(hipEventRecord(e1, p->stream));
+        p->kev.emplace_back(e0, e1);
+    } else {
+        mcf::launch_solve(a, p->cpb, p->af, p->bg, p->stream);
+    }
+    HIP_TRY(hipGetLastError());
+    return MCF_OK;
+}
+
+int mcf_plan_belowground(mcf_plan* p) {
+    if (!p) return fail(MCF_ERR_ARG, "null plan");
+    if (!p->bg) return fail(MCF_ERR_STATE, "reqhgt >= 0: nothing to smooth");
+    if (p->var_slot[MCF_OUT_TZ] < 0) return MCF_OK;                      // cpp:2307 `&& out[0]`
+    HIP_TRY(hipSetDevice(p->device));
+    mcf::BelowArgs b{};
+    b.N = p->N; b.tsteps = (int)p->tsteps; b.complete = p->opt.complete; b.hiy = p->hiy;
+    b.per_cell_pointm = p->af ? 1 : 0;
+    b.reqhgt = p->opt.reqhgt; b.mat = p->opt.mat;
+    b.cellflag_hgt = p->d_veg[0];
+    b.tg = p->d_tgser; b.ddsum = p->d_ddsum; b.Tgp = p->d_Tgp; b.Tbp = p->d_Tbp;
+    b.scratch = p->d_scratch;
+    b.tz = p->d_ring + (int64_t)p->var_slot[MCF_OUT_TZ] * (p->N * (int64_t)p->ring_days * 24);
+    if (p->tsteps > (int64_t)p->ring_days * 24)
+        return fail(MCF_ERR_STATE, "ring slot smaller than the series");
+    mcf::launch_belowground(b, p->stream);
+    HIP_TRY(hipGetLastError());
+    return MCF_OK;
+}
+
+int mcf_plan_sync(mcf_plan* p) {
+    if (!p) return fail(MCF_ERR_ARG, "null plan");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return MCF_OK;
+}
+
+int mcf_plan_fetch(mcf_plan* p, int32_t slot, int32_t var, int64_t step0, int64_t nsteps, double* host_dst) {
+    if (!p || !host_dst) return fail(MCF_ERR_ARG, "null argument");
+    if (slot < 0 || slot >= p->ring_slots || var < 0 || var >= MCF_NOUT) return fail(MCF_ERR_ARG, "bad slot/var");
+    if (p->var_slot[var] < 0) return fail(MCF_ERR_ARG, "variable was not requested in out[]");
+    const int64_t cap_steps = (int64_t)p->ring_days * 24;
+    if (step0 < 0 || nsteps < 0 || step0 + nsteps > cap_steps) return fail(MCF_ERR_ARG, "step range out of slot");
+    HIP_TRY(hipSetDevice(p->device));
+    const double* src = p->d_ring + ((int64_t)slot * p->nvars + p->var_slot[var]) * (p->N * cap_steps) + p->N * step0;
+    HIP_TRY(hipMemcpyAsync(host_dst, src, (size_t)(p->N * nsteps) * 8, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    return MCF_OK;
+}
+
+int mcf_plan_slot_ptr(mcf_plan* p, int32_t slot, int32_t var, void** dev_ptr) {
+    if (!p || !dev_ptr) return fail(MCF_ERR_ARG, "null argument");
+    if (slot < 0 || slot >= p->ring_slots || var < 0 || var >= MCF_NOUT || p->var_slot[var] < 0)
+        return fail(MCF_ERR_ARG, "bad slot/var");
+    *dev_ptr = p->d_ring + ((int64_t)slot * p->nvars + p->var_slot[var]) * (p->N * (int64_t)p->ring_days * 24);
+    return MCF_OK;
+}
+
+int mcf_plan_timer_start(mcf_plan* p) {
+    if (!p) return fail(MCF_ERR_ARG, "null plan");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipEventRecord(p->ev0, p->stream));
+    return MCF_OK;
+}
+
+int mcf_plan_timer_stop(mcf_plan* p, float* ms) {
+    if (!p || !ms) return fail(MCF_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipEventRecord(p->ev1, p->stream));
+    HIP_TRY(hipEventSynchronize(p->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, p->ev0, p->ev1));
+    return MCF_OK;
+}
+
+int mcf_plan_kernel_timing(mcf_plan* p, int32_t enable) {
+    if (!p) return fail(MCF_ERR_ARG, "null plan");
+    p->ktiming = enable != 0;
+    if (!enable) return MCF_OK;
+    for (auto& e : p->kev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    p->kev.clear();
+    p->ktotal_ms = 0;
+    p->klaunches = 0;
+    return MCF_OK;
+}
+
+int mcf_plan_kernel_stats(mcf_plan* p, double* total_ms, int64_t* launches) {
+    if (!p || !total_ms || !launches) return fail(MCF_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    for (auto& e : p->kev) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
+        p->ktotal_ms += ms;
+        p->klaunches += 1;
+        hipEventDestroy(e.first);
+        hipEventDestroy(e.second);
+    }
+    p->kev.clear();
+    *total_ms = p->ktotal_ms;
+    *launches = p->klaunches;
+    return MCF_OK;
+}
+
+int64_t mcf_plan_valid_cells(const mcf_plan* p) { return p ? p->valid_cells : 0; }
+int64_t mcf_plan_bytes(const mcf_plan* p) { return p ? p->bytes : 0; }
+
+// ---- one-shot host-to-host solve ---------------------------------------------------------
+static int run_oneshot(const mcf_grid_inputs* in, const mcf_options* opt, mcf_outputs* out, int want_af) {
+    int rc = check_inputs(in, opt);
+    if (rc) return rc;
+    if (!out) return fail(MCF_ERR_ARG, "null outputs");
+    if ((in->array_forcing != 0) != (want_af != 0))
+        return fail(MCF_ERR_ARG, want_af ? "mcf_runmicro2 needs array_forcing = 1" : "mcf_runmicro1 needs array_forcing = 0");
+    for (int v = 0; v < MCF_NOUT; ++v)
+        if (opt->out[v] && !out->var[v]) return fail(MCF_ERR_ARG, "requested output has a null buffer");
+    rc = ensure_device(opt->device);
+    if (rc) return rc;
+    const int64_t N = in->rows * in->cols, T = in->tsteps;
+    const int ndays = (int)(T / 24);
+    int nvars = 0;
+    for (int v = 0; v < MCF_NOUT; ++v) nvars += opt->out[v] ? 1 : 0;
+    const bool bg = opt->reqhgt < 0.0;
+    // ---- chunk size from free HBM
+    int chunk = opt->days_per_chunk;
+    if (bg) {
+        chunk = std::max(ndays, 1);
+    } else if (chunk <= 0) {
+        size_t fr = 0, tot = 0;
+        HIP_TRY(hipMemGetInfo(&fr, &tot));
+        double per_day = (double)N * 24 * 8 * (nvars + (in->array_forcing ? 15 : 0));
+        double budget = 0.6 * (double)fr - (double)N * 8 * 200;
+        chunk = (int)std::max(1.0, std::min((double)std::max(ndays, 1), budget / std::max(per_day, 1.0)));
+        chunk = std::min(chunk, 64);
+    }
+    chunk = std::max(1, std::min(chunk, std::max(ndays, 1)));
+    mcf_plan* p = nullptr;
+    rc = mcf_plan_create(in, opt, chunk, 1, &p);
+    if (rc) return rc;
+    struct Guard { mcf_plan* p; ~Guard() { mcf_plan_destroy(p); } } guard{p};
+    for (int d0 = 0; d0 < ndays; d0 += chunk) {
+        int nd = std::min(chunk, ndays - d0);
+        if (in->array_forcing && (rc = mcf_plan_upload_forcing_days(p, in, d0, nd, 0))) return rc;
+        if ((rc = mcf_plan_run_days(p, d0, nd, 0))) return rc;
+        if (!bg) {
+            for (int v = 0; v < MCF_NOUT; ++v)
+                if (opt->out[v])
+                    if ((rc = mcf_plan_fetch(p, 0, v, 0, (int64_t)nd * 24, out->var[v] + N * (int64_t)d0 * 24)))
+                        return rc;
+        }
+    }
+    if (bg && ndays > 0) {
+        for (int v = 0; v < MCF_NOUT; ++v)
+            if (opt->out[v] && v != MCF_OUT_TZ)
+                if ((rc = mcf_plan_fetch(p, 0, v, 0, (int64_t)ndays * 24, out->var[v]))) return rc;
+    }
+    // steps past the last whole day are never computed by the reference and stay NA (cpp:2116)
+    const double na = na_real_host();
+    for (int v = 0; v < MCF_NOUT; ++v)
+        if (opt->out[v])
+            for (int64_t q = N * (int64_t)ndays * 24; q < N * T; ++q) out->var[v][q] = na;
+    if (bg && opt->out[MCF_OUT_TZ] && T > 0) {
+        // Tbelowgroundv runs over all tsteps (cpp:2314-2319)
+        if ((rc = mcf_plan_belowground(p))) return rc;
+        if ((rc = mcf_plan_fetch(p, 0, MCF_OUT_TZ, 0, T, out->var[MCF_OUT_TZ]))) return rc;
+    }
+    return mcf_plan_sync(p);
+}
+
+int mcf_runmicro1(const mcf_grid_inputs* in, const mcf_options* opt, mcf_outputs* out) {
+    return run_oneshot(in, opt, out, 0);
+}
+int mcf_runmicro2(const mcf_grid_inputs* in, const mcf_options* opt, mcf_outputs* out) {
+    return run_oneshot(in, opt, out, 1);
+}
+
+}  // extern "C"

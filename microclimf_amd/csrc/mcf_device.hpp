@@ -1,0 +1,628 @@
+// mcf_device.hpp — device-side physics of the grid microclimate solver (gfx950).
+//
+// From-scratch restatement of the arithmetic of runmicro1Cpp / runmicro2Cpp
+// (reference: src/microclimfCpp.cpp, cited as cpp:LINE) organised by HOISTING
+// CLASS instead of by the reference's call tree:
+//
+//   CellConst  (CF_*)  depends on the raster cell only; computed once per plan by
+//                      k_cell_setup into an SoA table, staged in LDS by the solver.
+//   TimeConst  (TF_*)  depends on the time step only (vector forcing); computed
+//                      once per plan by k_time_setup; a day's 24 rows are staged
+//                      in LDS.  For array forcing the same values are derived
+//                      per cell-step in registers.
+//   pass1 / pass2      the remaining cell x time work.  One lane = one
+//                      (cell, hour); the two passes of a day are separated by
+//                      one workgroup barrier that carries the day's
+//                      max/min/|Rnet|max reduction through LDS.
+//
+// All arithmetic is IEEE fp64 (no fast-math): NaN comparison semantics are
+// load-bearing for bare (pai = hgt = 0) cells, see DESIGN.md.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mcf_kernels.h"
+
+namespace mcf {
+
+constexpr double kPi = 3.14159265358979323846;     // cpp:14
+constexpr double kToRad = kPi / 180.0;             // cpp:15
+constexpr double kSb = 5.67e-8;                    // cpp:16
+constexpr double kThetam = 0.365;                  // cpp:17
+constexpr double kKa = 0.4;                        // cpp:18
+constexpr double kOmdy = (2.0 * kPi) / (24.0 * 3600.0);  // cpp:19
+constexpr uint64_t kNaRealBits = 0x7FF00000000007A2ULL;  // R's NA_real_
+
+// ---- cell flags -------------------------------------------------------------
+enum : int {
+    FL_VALID = 1,      // hgt is not NA                       cpp:2182-2183
+    FL_PAI = 2,        // pai > 0                             cpp:1093,1165
+    FL_BELOW = 4,      // !(reqhgt2 >= hgt): below canopy     cpp:1434
+    FL_XONE = 8,       // x == 1                              cpp:109
+    FL_XINF = 16,      // isinf(x)                            cpp:112
+    FL_XZERO = 32,     // x == 0                              cpp:115
+    FL_ABOVE1 = 64,    // reqhgt2 > d + zh                    cpp:1303 (TVabove at reqhgt)
+    FL_ABOVE2 = 128,   // hgt > d + zh                        cpp:1303 (TVabove at hgt)
+    FL_OMPNAN = 256,   // isnan(omp)                          cpp:464
+    FL_STOM = 512      // gsmax < 999.99                      cpp:1351
+};
+
+// ---- per-cell constant table ------------------------------------------------
+enum CellField : int {
+    CF_FLAGS = 0,
+    // solar index (cpp:85-102): si = cz*cs + sz*(ssca*caz + sssa*saz)
+    CF_CS, CF_SSCA, CF_SSSA,
+    // soil moisture spread (cpp:1021-1032): sm = th/(th + (1-th)*eta), eta = exp(-tadd)
+    CF_SMIN, CF_RGE, CF_INVRGE, CF_ETA,
+    // canopy extinction (cpp:104-132)
+    CF_XX, CF_KDENINV,
+    // two-stream diffuse constants (cpp:134-162, 1034-1084)
+    CF_PAIT, CF_OM, CF_JDEL, CF_GMA, CF_GMA2, CF_AGM, CF_AGM2, CF_U1, CF_U2, CF_H, CF_S1, CF_INVS1,
+    CF_INVD1, CF_INVD2, CF_GREF, CF_GMAGREF, CF_LOGCLUMP, CF_LOGGI, CF_TRDN, CF_TRDU, CF_AMX,
+    CF_EHP, CF_PAIAA, CF_EHPA, CF_EMHPA, CF_ALBD, CF_RDDNG, CF_RDDNZ, CF_RDUPZ, CF_SVFA,
+    CF_HOM, CF_HOMP,
+    // long wave (cpp:1165-1175)
+    CF_TSV, CF_OMTRDIF,
+    // wind (cpp:1179-1218)
+    CF_UFC, CF_UZFAC, CF_GHAFAC,
+    // soil surface (cpp:1262-1275) and conductivity (cpp:1249-1260, 628-636)
+    CF_ABSPSIE, CF_INVSMAX, CF_SOILB, CF_RHO, CF_CSA, CF_C1, CF_C1MC4, CF_C3,
+    // stomata (cpp:391-458)
+    CF_GSMAX, CF_RSMX, CF_INV02RSMX, CF_RAT, CF_RATC, CF_PSIW0, CF_KK, CF_MUDENINV,
+    // canopy conductance (cpp:460-477, 1425-1428)
+    CF_PAI, CF_OMPC, CF_KSAT, CF_PSUNSAT, CF_SHADEFAC,
+    // TVabove log-profile weights (cpp:1298-1313)
+    CF_OML1, CF_OML2,
+    // leaf temperature (cpp:1333-1364)
+    CF_EMG, CF_EMA, CF_INVLEAFD,
+    // below-canopy Lagrangian model (cpp:1365-1409)
+    CF_A2H, CF_INTHH, CF_INTHZ, CF_HGT, CF_INVHMZ, CF_NEARFAC, CF_LEAFDEN, CF_OMEMPAI,
+    // array forcing: per-cell solar geometry (cpp:2497)
+    CF_SINLAT, CF_COSLAT, CF_LON,
+    CF_COUNT
+};
+constexpr int kCellDirs = 32;  // 24 horizon + 8 wind-shelter values follow the CF_ rows
+
+// ---- per-timestep table (vector forcing) --------------------------------------
+enum TimeField : int {
+    // raw forcing / point-model series
+    TF_TC = 0, TF_ES, TF_EA, TF_TDEW, TF_PK, TF_RSW, TF_RDIF, TF_RLW, TF_U2,
+    TF_SOILMP, TF_GP, TF_UMU, TF_KP, TF_MUGP, TF_DTRP,
+    // solar geometry
+    TF_CZ, TF_SZ, TF_CAZ, TF_SAZ, TF_TANSA, TF_ZEND,
+    // canopy extinction operands, radians call (cpp:2231) ...
+    TF_COSC, TF_TAN2C, TF_TANC, TF_INV2COSC,
+    // ... and the degrees call inside TVaboveground (cpp:1425)
+    TF_TAN2B, TF_TANB, TF_INV2COSB,
+    // Penman-Monteith operands (cpp:1220-1247)
+    TF_DE, TF_GHRRAD, TF_REM, TF_LA, TF_WFAC,
+    // beam normalisation (cpp:1122-1124)
+    TF_RBEAM, TF_RB,
+    // packed ints: sindex | windex<<5 | ksat<<8
+    TF_IDX,
+    TF_COUNT
+};
+
+__device__ __forceinline__ double na_real() { return __longlong_as_double((long long)kNaRealBits); }
+
+// pow(x, y) for the positive-base uses on this path, as exp(y*log(x)); the
+// relative error (|y log x| * 2^-52) is far below the 1e-4 acceptance bar.
+__device__ __forceinline__ double powxy(double x, double y) { return exp(y * log(x)); }
+__device__ __forceinline__ double sq(double x) { return x * x; }
+__device__ __forceinline__ double pow4(double x) { double x2 = x * x; return x2 * x2; }
+
+// cpp:480-490 satvapCpp
+__device__ __forceinline__ double satvap(double tc) {
+    double a = tc > 0 ? 17.27 : 21.875;
+    double b = tc > 0 ? 237.3 : 265.5;
+    return 0.61078 * exp(a * tc / (tc + b));
+}
+// cpp:24-26 with the 0.97*sb factor every caller applies
+__device__ __forceinline__ double lw_emit(double tc) { return 0.97 * kSb * pow4(tc + 273.15); }
+// cpp:1227-1232
+__device__ __forceinline__ double latent(double tc) {
+    return tc >= 0 ? 45068.7 - 42.8428 * tc : 51078.69 - 4.338 * tc - 0.06367 * tc * tc;
+}
+
+struct SolPos { double zend, zenr, azid; };
+
+// cpp:28-37 juldayCpp
+__host__ __device__ inline int julday(int year, int month, int day) {
+    double dd = day + 0.5;
+    int madj = month + (month < 3) * 12;
+    int yadj = year + (month < 3) * -1;
+    double j = trunc(365.25 * (yadj + 4716)) + trunc(30.6001 * (madj + 1)) + dd - 1524.5;
+    int b = (int)(2 - trunc((double)(yadj / 100)) + trunc(trunc((double)(yadj / 100)) / 4));
+    return (int)(j + (j > 2299160) * b);
+}
+
+// cpp:48-83 solpositionCpp, split so that the date-only part (dec, eot) can be
+// tabulated per time step and the site part (lat, lon) applied per cell.
+struct SolDate { double sindec, cosdec, eot; };
+__device__ inline SolDate sol_date(int year, int month, int day) {
+    int jd = julday(year, month, day);
+    double m = 6.24004077 + 0.01720197 * (jd - 2451545.0);                       // cpp:42
+    SolDate s;
+    s.eot = -7.659 * sin(m) + 9.863 * sin(2 * m + 3.5932);                          // cpp:43
+    double dec = (kPi * 23.5 / 180) * cos(2 * kPi * ((jd - 159.5) / 365.25));      // cpp:55
+    s.sindec = sin(dec);
+    s.cosdec = cos(dec);
+    return s;
+}
+__device__ inline SolPos sol_site(const SolDate& sd, double lt, double sinlat, double coslat, double lon) {
+    double st = lt + (4.0 * lon + sd.eot) / 60.0;                                   // cpp:44
+    double tt = 0.261799 * (st - 12);                                               // cpp:54
+    double ctt = cos(tt), stt = sin(tt);
+    double coh = sd.sindec * sinlat + sd.cosdec * coslat * ctt;                     // cpp:56
+    double z = acos(coh) * (180 / kPi);                                             // cpp:57
+    double sh = coh;                                                                // cpp:59
+    double hh = atan(sh / sqrt(1 - sh * sh));                                       // cpp:60
+    double sazi = sd.cosdec * stt / cos(hh);                                        // cpp:61
+    double num = sinlat * sd.cosdec * ctt - coslat * sd.sindec;
+    double cazi = num / sqrt(sq(sd.cosdec * stt) + sq(num));                        // cpp:62-64
+    double sqt = 1 - sazi * sazi;
+    if (sqt < 0) sqt = 0;
+    double azi = 180 + (180 * atan(sazi / sqrt(sqt))) / kPi;                        // cpp:67
+    if (cazi < 0) azi = (sazi < 0) ? 180 - azi : 540 - azi;                         // cpp:68-75
+    SolPos o;
+    o.zend = z;
+    o.zenr = z * kToRad;
+    o.azid = azi;
+    return o;
+}
+
+// half-away-from-zero round then C remainder (cpp:2166-2167); negative
+// directions (out of bounds in the reference) are wrapped into range.
+__device__ __forceinline__ int dir_index(double v, double step, int n) {
+    int r = ((int)round(v / step)) % n;
+    return r < 0 ? r + n : r;
+}
+
+// Register-resident per-timestep values; TF_ order.  Filled by derive_time().
+struct TimeVals {
+    double v[TF_COUNT];
+};
+
+// Fills the derived TF_ fields of `t` from its raw fields and the solar position.
+__device__ inline void derive_time(TimeVals& t, const SolPos& sp, int windex) {
+    const double tc = t.v[TF_TC];
+    const double zenr = sp.zenr;
+    t.v[TF_ZEND] = sp.zend;
+    t.v[TF_CZ] = cos(zenr);                       // cpp:1092 (unclamped), cpp:93/96
+    t.v[TF_SZ] = sin(zenr);
+    double azr = sp.azid * kToRad;
+    t.v[TF_CAZ] = cos(azr);
+    t.v[TF_SAZ] = sin(azr);
+    t.v[TF_TANSA] = tan((kPi / 2.0) - zenr);      // cpp:2222-2223
+    double zc = zenr > (kPi / 2.0) ? (kPi / 2.0) : zenr;    // cpp:106
+    double cc = cos(zc), tn = tan(zc);
+    t.v[TF_COSC] = cc;
+    t.v[TF_TANC] = tn;
+    t.v[TF_TAN2C] = tn * tn;
+    t.v[TF_INV2COSC] = 1.0 / (2.0 * cc);
+    // the reference passes the zenith in DEGREES to cankCpp at cpp:1425
+    double zb = sp.zend > (kPi / 2.0) ? (kPi / 2.0) : sp.zend;
+    double cb = cos(zb), tb = tan(zb);
+    t.v[TF_TANB] = tb;
+    t.v[TF_TAN2B] = tb * tb;
+    t.v[TF_INV2COSB] = 1.0 / (2.0 * cb);
+    t.v[TF_DE] = satvap(tc + 0.5) - satvap(tc - 0.5);                       // cpp:1223
+    double tk = tc + 273.15;
+    t.v[TF_GHRRAD] = (4 * 0.97 * kSb * (tk * tk * tk)) / 29.3;               // cpp:1224
+    t.v[TF_REM] = lw_emit(tc);                                              // cpp:1225, 1167
+    t.v[TF_LA] = latent(tc);
+    t.v[TF_WFAC] = 0.018 / (8.31 * tk);                                     // cpp:1268
+    double rbeam = (t.v[TF_RSW] - t.v[TF_RDIF]) / t.v[TF_CZ];               // cpp:1122
+    if (rbeam > 1352.0) rbeam = 1352.0;
+    t.v[TF_RBEAM] = rbeam;
+    t.v[TF_RB] = rbeam * t.v[TF_CZ];                                        // cpp:1124
+    int sindex = dir_index(sp.azid, 15.0, 24);
+    int ksat = (sp.zend > (kPi / 2.0)) ? 1 : 0;
+    t.v[TF_IDX] = (double)(sindex | (windex << 5) | (ksat << 8));
+}
+
+// ---- accessors ----------------------------------------------------------------
+// Cell constants in LDS, laid out [field][cells_per_block]; `dirs` holds the 24
+// horizon + 8 wind-shelter values [dir][cells_per_block].
+template <int CPB>
+struct CellLds {
+    const double* f;
+    const double* dirs;
+    int c;
+    __device__ __forceinline__ double operator()(int field) const { return f[field * CPB + c]; }
+    __device__ __forceinline__ double hor(int s) const { return dirs[s * CPB + c]; }
+    __device__ __forceinline__ double wsa(int w) const { return dirs[(24 + w) * CPB + c]; }
+};
+// A day's time table in LDS, laid out [field][24].
+struct TimeLds {
+    const double* row;  // + hour
+    __device__ __forceinline__ double operator()(int field) const { return row[field * 24]; }
+};
+struct TimeReg {
+    const TimeVals* t;
+    __device__ __forceinline__ double operator()(int field) const { return t->v[field]; }
+};
+
+// Values a lane carries from pass 1 to pass 2 of the same cell-hour.
+struct Carry {
+    double soilm, num0, den, radCsw, Rddown, Rbdown, X, uf;
+};
+struct Pass1Out {
+    double Tg0, absRnet;   // to the day reduction
+    double uz, Rdup;       // outputs only
+};
+
+// Penman-Monteith surface temperature, cpp:1220-1247, from pre-assembled parts.
+template <class TM>
+__device__ __forceinline__ double pm_temperature(double num, double den, double dTmx, const TM& T) {
+    double dT = num / den;
+    if (dT > dTmx) dT = dTmx;
+    if (dT > 80.0) dT = 80.0;
+    double Ts = dT + T(TF_TC);
+    if (Ts < T(TF_TDEW)) Ts = T(TF_TDEW);
+    return Ts;
+}
+
+// ---------------------------------------------------------------------------------
+// PASS 1 (cpp:2214-2262): terrain-adjusted solar index, soil moisture spread,
+// two-stream radiation, wind, G = 0 soil surface temperature.
+// ---------------------------------------------------------------------------------
+template <class CL, class TM>
+__device__ __forceinline__ void pass1(const CL& C, const TM& T, const Globals& g, int flags, double dTmx,
+                                      Carry& cy, Pass1Out& o) {
+    const int idx = (int)T(TF_IDX);
+    const double rsw = T(TF_RSW), rdif = T(TF_RDIF);
+    // --- distributed soil moisture, cpp:1021-1032 --------------------------------
+    double theta = (T(TF_SOILMP) - C(CF_SMIN)) * C(CF_INVRGE);
+    if (theta > 0.9999) theta = 0.9999;
+    if (theta < 0.0001) theta = 0.0001;
+    double sm = theta / (theta + (1.0 - theta) * C(CF_ETA));
+    const double soilm = sm * C(CF_RGE) + C(CF_SMIN);
+    cy.soilm = soilm;
+    // --- short wave, cpp:1086-1163 --------------------------------------------------
+    double radGsw = 0.0, radCsw = 0.0, Rbdown = 0.0, Rddown = 0.0, Rdup = 0.0, X = 0.0;
+    if (rsw > 0.0) {
+        const double cz = T(TF_CZ);
+        // solar index, cpp:85-102 + horizon shading cpp:2219-2223
+        double si = cz * C(CF_CS) + T(TF_SZ) * (C(CF_SSCA) * T(TF_CAZ) + C(CF_SSSA) * T(TF_SAZ));
+        if (!g.shadowmask && T(TF_ZEND) > 90.0) si = 0.0;
+        if (si < 0.0) si = 0.0;
+        if (C.hor(idx & 31) > T(TF_TANSA)) si = 0.0;
+        const double svfa = C(CF_SVFA), gref = C(CF_GREF);
+        if (flags & FL_PAI) {
+            // canopy extinction, cpp:104-132
+            double k = sqrt(C(CF_XX) + T(TF_TAN2C)) * C(CF_KDENINV);
+            if (flags & (FL_XONE | FL_XINF | FL_XZERO))
+                k = (flags & FL_XONE) ? T(TF_INV2COSC) : (flags & FL_XINF) ? 1.0 : T(TF_TANC);
+            if (k > 6000.0) k = 6000.0;
+            double rsi = 1.0 / si;
+            double kd = k * T(TF_COSC) * rsi;
+            double Kc = rsi;
+            if (si == 0.0) { kd = 1.0; Kc = 600.0; }
+            // direct-beam two-stream coefficients, cpp:164-185
+            const double om = C(CF_OM), gma = C(CF_GMA), agm = C(CF_AGM), u1 = C(CF_U1), u2 = C(CF_U2),
+                         h = C(CF_H), S1 = C(CF_S1);
+            double sig = kd * kd + C(CF_GMA2) - C(CF_AGM2);
+            double ss = 0.5 * (om + C(CF_JDEL) / kd) * kd;
+            double sstr = om * kd - ss;
+            double S2 = exp(-kd * C(CF_PAIT));
+            double isig = 1.0 / sig;
+            double p5 = -ss * (agm - kd) - gma * sstr;
+            double p5s = p5 * isig;
+            double v1 = ss - (p5 * (agm + kd)) * isig;
+            double v2 = ss - gma - p5s * (u1 + kd);
+            double gS2v2 = S2 * v2;
+            double p6 = C(CF_INVD1) * ((v1 * C(CF_INVS1)) * (u1 - h) - (agm - h) * gS2v2);
+            double p7 = -C(CF_INVD1) * ((v1 * S1) * (u1 + h) - (agm + h) * gS2v2);
+            double p8 = sstr * (agm + kd) - gma * ss;
+            double p8s = -p8 * isig;  // p8 / (-sig)
+            double v3 = (sstr + C(CF_GMAGREF) - p8s * (u2 - kd)) * S2;
+            double p9 = -C(CF_INVD2) * ((p8s * C(CF_INVS1)) * (u2 + h) + v3);
+            double p10 = C(CF_INVD2) * ((p8s * S1) * (u2 - h) + v3);
+            // gap transmissions, cpp:1095-1100
+            double trbn = exp(Kc * C(CF_LOGCLUMP));
+            if (trbn > 0.999) trbn = 0.999;
+            if (trbn < 0.0) trbn = 0.0;
+            double trb = exp(Kc * C(CF_LOGGI));
+            if (trb > 0.999) trb = 0.999;
+            if (trb < 0.0) trb = 0.0;
+            const double amx = C(CF_AMX), trdn = C(CF_TRDN), trdu = C(CF_TRDU);
+            double albb = (1.0 - trdn * trbn) * (p5s + p6 + p7) + trdn * trbn * gref;      // cpp:1102
+            if (albb > amx) albb = amx;
+            if (albb < 0.01) albb = 0.01;
+            double Rdbdn_g = (1.0 - trbn) * (p8s * S2 + p9 * S1 + p10 * C(CF_EHP));         // cpp:1106
+            if (Rdbdn_g > amx) Rdbdn_g = amx;
+            if (Rdbdn_g < 0.0) Rdbdn_g = 0.0;
+            double S2a = exp(-kd * C(CF_PAIAA));
+            const double emhpa = C(CF_EMHPA), ehpa = C(CF_EHPA);
+            double Rdbup_z = (1.0 - trdu * trbn) * (p5s * S2a + p6 * emhpa + p7 * ehpa) + trdu * trbn * gref;
+            if (Rdbup_z > amx) Rdbup_z = amx;
+            if (Rdbup_z < 0.0) Rdbup_z = 0.0;
+            double Rdbdn_z = (1.0 - trb) * (p8s * S2a + p9 * emhpa + p10 * ehpa);           // cpp:1117
+            if (Rdbdn_z > amx) Rdbdn_z = amx;
+            if (Rdbdn_z < 0.0) Rdbdn_z = 0.0;
+            const double Rbeam = T(TF_RBEAM), Rb = T(TF_RB);
+            double trg = trb + (1 - trb) * S2;                                              // cpp:1125
+            double Rbc = (trg * si + (1 - trg) * cz) * Rbeam;
+            double Rbdn_g = trbn + (1.0 - trbn) * S2;
+            if (Rbdn_g > 1.0) Rbdn_g = 1.0;
+            if (Rbdn_g < 0.0) Rbdn_g = 0.0;
+            const double rds = rdif * svfa;
+            radGsw = (1.0 - gref) * (C(CF_RDDNG) * rds + Rdbdn_g * Rb + Rbdn_g * Rbeam * si);  // cpp:1131
+            double maxg = (1.0 - gref) * (rds + Rbeam * si);
+            if (radGsw > maxg) radGsw = maxg;
+            radCsw = (1.0 - C(CF_ALBD)) * rds + (1.0 - albb) * Rbc;                          // cpp:1136
+            Rbdown = (trb + (1.0 - trb) * S2a) * Rbeam;
+            Rddown = C(CF_RDDNZ) * rds + Rdbdn_z * Rb;
+            Rdup = C(CF_RDUPZ) * rds + Rdbup_z * Rb;
+            X = Rddown + Rdup + k * cz * Rbdown;                                             // cpp:1142-1143
+        } else {
+            // bare ground, cpp:1145-1153
+            Rbdown = (rsw - rdif) / cz;
+            Rddown = rdif * svfa;
+            Rdup = gref * (rdif * svfa + (rsw - rdif));
+            radGsw = (1.0 - gref) * (svfa * rdif + si * Rbdown);
+            radCsw = radGsw;
+        }
+    }
+    cy.radCsw = radCsw;
+    cy.Rddown = Rddown;
+    cy.Rbdown = Rbdown;
+    cy.X = X;
+    o.Rdup = Rdup;
+    // --- long wave absorbed by the ground, cpp:1165-1175 -----------------------------
+    const double radGlw = 0.97 * (C(CF_TSV) * T(TF_RLW) + C(CF_OMTRDIF) * T(TF_REM));
+    // --- wind, cpp:1189-1218 ------------------------------------------------------------
+    double ws = C.wsa((idx >> 5) & 7);
+    if (isnan(ws)) ws = 1.0;
+    if (ws < 0.05) ws = 0.05;
+    const double u2m = T(TF_U2);
+    double uf = u2m * C(CF_UFC) * T(TF_UMU) * ws;
+    if (uf < 0.001) uf = 0.001;
+    double uz = uf * C(CF_UZFAC);
+    if (uz > u2m) uz = u2m;
+    double gHa = uf * C(CF_GHAFAC);
+    if (gHa < 0.0001) gHa = 0.0001;
+    cy.uf = uf;
+    o.uz = uz;
+    // --- soil surface temperature with G = 0, cpp:1262-1275 ------------------------------
+    const double radabs = radGsw + radGlw;
+    double matric = -C(CF_ABSPSIE) * powxy(soilm * C(CF_INVSMAX), -C(CF_SOILB));
+    double surfwet = exp(matric * T(TF_WFAC));
+    if (surfwet > 1.0) surfwet = 1.0;
+    const double m = T(TF_LA) * (gHa / T(TF_PK));
+    const double num0 = radabs - T(TF_REM) - m * (T(TF_ES) - T(TF_EA)) * surfwet;
+    const double den = 29.3 * (gHa + T(TF_GHRRAD)) + m * T(TF_DE);
+    cy.num0 = num0;
+    cy.den = den;
+    double Tg0 = pm_temperature(num0, den, dTmx, T);
+    o.Tg0 = Tg0;
+    o.absRnet = fabs(radabs - lw_emit(Tg0));
+}
+
+// cpp:442-458 stomcondCpp with the soil-water factor `gs2 = mu*gsmax` passed in.
+template <class CL>
+__device__ __forceinline__ double stomcond(double Rswabs, double gs2, const CL& C) {
+    if (Rswabs <= 0.0) return 0.0;
+    const double rsmx = C(CF_RSMX);
+    if (Rswabs > rsmx) Rswabs = rsmx;
+    double gs = C(CF_GSMAX) * exp2(-(rsmx - Rswabs) * C(CF_INV02RSMX));
+    if (gs > gs2) gs = gs2;
+    return gs;
+}
+// the theta-only part of stomcondCpp, cpp:451-455
+template <class CL>
+__device__ __forceinline__ double stom_gs2(double theta, const CL& C) {
+    double thetan = C(CF_RAT) * theta + C(CF_RATC);
+    double Se = thetan * C(CF_INVSMAX);
+    if (Se > 1.0) Se = 1.0;
+    double psiw = -C(CF_ABSPSIE) * powxy(Se, -C(CF_SOILB)) * 0.01;   // cpp:382-389
+    if (psiw < C(CF_PSIW0)) psiw = C(CF_PSIW0);
+    double mu = 1.0 - (exp(-C(CF_KK) * psiw) - 1.0) * C(CF_MUDENINV);
+    return mu * C(CF_GSMAX);
+}
+
+// cpp:1316-1331 mincondCpp
+__device__ __forceinline__ double mincond_from_hf(double Hf, double Rnet, double invleafd) {
+    double H = Hf * Rnet;
+    double gmin = 0.0463 * powxy(fabs(H) * invleafd, 0.2);
+    // pow(0, 0.2) = 0 -> exp(0.2*log(0)) = exp(-inf) = 0: same limit
+    if (gmin < 0.05) gmin = 0.05;
+    return gmin;
+}
+
+struct Pass2Out {
+    double Tg, DD, Tz, tleaf, rh, lwdn, lwup;
+};
+
+// ---------------------------------------------------------------------------------
+// PASS 2 (cpp:2264-2305): ground temperature with the scaled ground heat flux,
+// canopy / leaf / air temperature and humidity at reqhgt.
+// ---------------------------------------------------------------------------------
+template <class CL, class TM>
+__device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g, int flags, double dTmx,
+                                      const Carry& cy, double dtr, double Rmx, bool above_ground,
+                                      Pass2Out& o) {
+    const double soilm = cy.soilm;
+    const double tc = T(TF_TC), ea = T(TF_EA), pk = T(TF_PK);
+    // --- soil conductivity / damping depth, cpp:1249-1260 ---------------------------------
+    const double rho = C(CF_RHO);
+    double cs = C(CF_CSA) + 4180.0 * soilm;
+    double ph = (rho * (1.0 - soilm) + soilm) * 1000.0;
+    double c2 = 1.06 * rho * soilm;
+    double ksoil = C(CF_C1) + c2 * soilm - C(CF_C1MC4) * exp(-pow4(C(CF_C3) * soilm));
+    double kap = ksoil / (cs * ph);
+    double DD = sqrt(2.0 * kap / kOmdy);
+    // --- ground heat flux and ground temperature, cpp:1277-1296 ------------------------------
+    double dtR = dtr / T(TF_DTRP);
+    double Gmu = dtR * (ksoil * T(TF_MUGP)) / (T(TF_KP) * DD);
+    double G = T(TF_GP) * Gmu;
+    if (G > 0.6 * Rmx) G = 0.6 * Rmx;
+    if (G < -0.6 * Rmx) G = -0.6 * Rmx;
+    const double Tg = pm_temperature(cy.num0 - G, cy.den, dTmx, T);
+    o.Tg = Tg;
+    o.DD = DD;
+    if (!above_ground) return;
+    // --- TVaboveground, cpp:1411-1472 ----------------------------------------------------------
+    const double rlw = T(TF_RLW);
+    const double uf = cy.uf;
+    double gHa = uf * C(CF_GHAFAC);
+    if (gHa < 0.0001) gHa = 0.0001;
+    const double esTg = satvap(Tg);
+    double eT = esTg - ea;
+    if (eT < 0.001) eT = 0.001;
+    double plf = 0.8753 - 1.7126 * log(eT);
+    double gwet = 1.0 / (1.0 + exp(-plf));
+    const double surfwet = (soilm - C(CF_SMIN)) * C(CF_INVRGE);
+    if (surfwet > gwet) gwet = surfwet;
+    // canopy conductance, cpp:1425-1428 + 460-477
+    const double rsw = T(TF_RSW), rdif = T(TF_RDIF);
+    const int idx = (int)T(TF_IDX);
+    double gS = 9999.99;
+    double gs2 = 0.0;
+    bool have_gs2 = false;
+    if (!(flags & FL_OMPNAN)) {
+        double kb, P_sun;
+        if (idx & 256) {  // zenith (in degrees) beyond pi/2: k is the per-cell saturated value
+            kb = C(CF_KSAT);
+            P_sun = C(CF_PSUNSAT);
+        } else {
+            kb = sqrt(C(CF_XX) + T(TF_TAN2B)) * C(CF_KDENINV);
+            if (flags & (FL_XONE | FL_XINF | FL_XZERO))
+                kb = (flags & FL_XONE) ? T(TF_INV2COSB) : (flags & FL_XINF) ? 1.0 : T(TF_TANB);
+            if (kb > 6000.0) kb = 6000.0;
+            P_sun = (1.0 - exp(-kb * C(CF_PAI))) / kb;
+        }
+        double P_shade = C(CF_PAI) - P_sun;
+        double Rshade_abs = rdif * C(CF_SHADEFAC);
+        double Rsun_abs = (rsw - rdif) * kb * (1 - C(CF_OMPC)) + Rshade_abs;
+        double gs_sun = 0.0, gs_shade = 0.0;
+        if (!(Rsun_abs <= 0.0) || !(Rshade_abs <= 0.0)) {
+            gs2 = stom_gs2(soilm, C);
+            have_gs2 = true;
+            gs_sun = stomcond(Rsun_abs, gs2, C);
+            gs_shade = stomcond(Rshade_abs, gs2, C);
+        }
+        gS = gs_sun * P_sun + gs_shade * P_shade;
+    }
+    double gV = 0.0;
+    if (gS > 0.0) gV = 1.0 / (1.0 / gHa + 1 / gS);
+    // canopy temperature, cpp:1430-1432 (Penman-Monteith with the linear surface wetness)
+    const double la = T(TF_LA), es = T(TF_ES), De = T(TF_DE), rem = T(TF_REM), ghr = T(TF_GHRRAD);
+    const double Rabs = cy.radCsw + 0.97 * C(CF_SVFA) * rlw;
+    const double mC = la * (gV / pk);
+    const double Tcan = pm_temperature(Rabs - rem - mC * (es - ea) * surfwet - G,
+                                       29.3 * (gHa + ghr) + mC * De, dTmx, T);
+    const double esTcan = satvap(Tcan);
+    double ez;
+    if (!(flags & FL_BELOW)) {
+        // above canopy: log profile, cpp:1298-1313 / 1434-1441
+        double w = C(CF_OML1);
+        bool prof = (flags & FL_ABOVE1) != 0;
+        o.Tz = prof ? tc + (Tcan - tc) * w : Tcan;
+        ez = prof ? ea + (esTcan - ea) * surfwet * w : ea + (esTcan - ea) * surfwet;
+        o.tleaf = Tcan;
+        o.lwup = lw_emit(Tcan);
+        o.lwdn = rlw;
+    } else {
+        // ---- leaf temperature, cpp:1333-1364 -------------------------------------------------
+        double uz = uf * C(CF_UZFAC);
+        if (uz > T(TF_U2)) uz = T(TF_U2);
+        const double lwcan = lw_emit(Tcan), lwgro = lw_emit(Tg);
+        const double emg = C(CF_EMG), ema = C(CF_EMA), invleafd = C(CF_INVLEAFD);
+        const double lwup = emg * lwgro + (1 - emg) * lwcan;
+        const double lwdn = ema * rlw + (1 - ema) * lwcan;
+        const double lwabs = 0.97 * 0.5 * (lwup + lwdn);
+        const double leafabs = C(CF_HOM) * cy.X + lwabs;     // radLsw + lwabs
+        double gh = 0.135 * sqrt(uz * invleafd) * 1.4;
+        const double RnetL = leafabs - lwcan;                // cpp:1319 with tc = Tcan
+        double gmin = mincond_from_hf(g.hf0, RnetL, invleafd);
+        if (gh < gmin) gh = gmin;
+        double gVl = gh;
+        if (flags & FL_STOM) {
+            gVl = 0.0;
+            const double PARabs = C(CF_HOMP) * cy.X;         // radLpar
+            double gs = 0.0;
+            if (PARabs > 0.0) {
+                if (!have_gs2) gs2 = stom_gs2(soilm, C);
+                gs = stomcond(PARabs, gs2, C);
+            }
+            double rs = 500.0;                               // cpp:1321-1325
+            if (gs > 0.0) rs = 1 / gs;
+            if (rs > 500.0) rs = 500.0;
+            double Hlf = 1.09767 * powxy(rs, 0.2672778);
+            double Hf = -1.0 / (1.0 + exp(2.0 - Hlf));
+            gmin = mincond_from_hf(Hf, RnetL, invleafd);
+            if (gh < gmin) gh = gmin;
+            if (gs > 0.0) gVl = 1 / (1 / gh + 1 / gs);
+        }
+        const double mL = la * (gVl / pk);
+        const double tleaf = pm_temperature(leafabs - rem - mL * (es - ea) * surfwet - 0.0,
+                                            29.3 * (gh + ghr) + mL * De, dTmx, T);
+        const double esTl = satvap(tleaf);
+        const double HL = 29.3 * gh * (tleaf - tc);                       // cpp:1242
+        const double LL = mL * (esTl - ea) * surfwet;                     // cpp:1243
+        o.tleaf = tleaf;
+        o.lwdn = lwdn;
+        o.lwup = lwup;
+        // ---- canopy-top source, cpp:1449 ---------------------------------------------------------
+        const double HC = 29.3 * gHa * (Tcan - tc);
+        const double LC = mC * (esTcan - ea) * surfwet;
+        const double mu = la * (43.0 / pk);                               // cpp:1245
+        double w2 = C(CF_OML2);
+        bool prof2 = (flags & FL_ABOVE2) != 0;
+        const double Th = prof2 ? tc + (Tcan - tc) * w2 : Tcan;
+        const double eh = prof2 ? ea + (esTcan - ea) * surfwet * w2 : ea + (esTcan - ea) * surfwet;
+        // ---- Lagrangian near/far field, cpp:1365-1409 ---------------------------------------------
+        const double hgt = C(CF_HGT), z = g.reqhgt2;
+        const double muR = 1.0 / (C(CF_A2H) * uf);          // uf/(a2*h) / uf^2
+        double Rc = C(CF_INTHH) * muR;
+        if (Rc < 0.001) Rc = 0.001;
+        double Rz = C(CF_INTHZ) * muR;
+        if (Rz < 0.001) Rz = 0.001;
+        const double Kc = hgt / Rc;
+        const double Kg = (1.0 / Rz) / z;
+        const double Kh = (1.0 / (Rc - Rz)) * C(CF_INVHMZ);
+        const double invK = 1.0 / (Kg + Kh + Kc);
+        const double omem = C(CF_OMEMPAI), nf = C(CF_NEARFAC), lden = C(CF_LEAFDEN);
+        const double cp43 = 29.3 * 43.0;
+        // temperature
+        {
+            double Flux = HC * omem, SH = Th * cp43, SG = Tg * cp43;
+            double mxnear = fabs(tleaf - Th) * cp43;
+            double SC = SH + Flux / Kc;
+            double farg = (Kg * SG + Kh * SH + Kc * SC) * invK;
+            double near = nf * (HL * lden);
+            if (fabs(near) > mxnear) near = near > 0.0 ? mxnear : -mxnear;
+            if (isnan(near)) near = 0;
+            o.Tz = (near + farg) / cp43;
+        }
+        // vapour pressure
+        {
+            double Flux = LC * omem, SH = eh * mu, SG = esTg * gwet * mu;
+            double mxnear = fabs(esTl - eh) * mu;
+            double SC = SH + Flux / Kc;
+            double farg = (Kg * SG + Kh * SH + Kc * SC) * invK;
+            double near = nf * (LL * lden);
+            if (fabs(near) > mxnear) near = near > 0.0 ? mxnear : -mxnear;
+            if (isnan(near)) near = 0;
+            ez = (near + farg) / mu;
+        }
+    }
+    double rh = (ez / satvap(o.Tz)) * 100.0;
+    if (rh > 100.0) rh = 100.0;
+    o.rh = rh;
+    // clamp Tz to the source temperatures +-2, cpp:1467-1470
+    double tmx = o.tleaf;
+    if (tmx < tc) tmx = tc;
+    if (tmx < Tg) tmx = Tg;
+    if (tmx < Tcan) tmx = Tcan;
+    double tmn = o.tleaf;
+    if (tc < tmn) tmn = tc;
+    if (Tg < tmn) tmn = Tg;
+    if (Tcan < tmn) tmn = Tcan;
+    if (o.Tz > tmx + 2.0) o.Tz = tmx + 2.0;
+    if (o.Tz < tmn - 2.0) o.Tz = tmn - 2.0;
+}
+
+}  // namespace mcf

@@ -1,0 +1,96 @@
+// mcf_kernels.h — kernel argument blocks and launchers (host-visible part).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mcf {
+
+struct Globals {
+    double reqhgt;   // as given
+    double reqhgt2;  // max(reqhgt, 1e-5)                       cpp:2246-2247
+    double zref;
+    double dTmx;     // -0.6273*mxtc + 49.79 (vector forcing)   cpp:1236
+    double hf0;      // mincondCpp's Hf for gs = 999.99          cpp:1321-1325
+    int shadowmask;  // 1: runmicro1Cpp, 0: runmicro2Cpp         cpp:2218 vs 2499
+};
+
+struct CellSetupArgs {
+    int64_t N;
+    // vegp
+    const double *hgt, *pai, *x, *gsmax, *leafr, *leaft, *clump, *leafd, *paia, *leafden;
+    // soilc
+    const double *Smin, *Smax, *gref, *soilb, *Psie, *Vq, *Vm, *Mc, *rho, *slope, *aspect, *twi, *svfa;
+    const double *lats, *lons;  // array forcing, else null
+    double lat, lon;
+    double tfact, twi_mean;
+    Globals g;
+    double* cellc;  // [CF_COUNT][N]
+};
+
+struct TimeSetupArgs {
+    int nsteps;
+    const int32_t *year, *month, *day;
+    const double* hour;
+    const double* raw[15];  // TF_TC .. TF_DTRP, each [tsteps]
+    const double* winddir;
+    double lat, lon;
+    double* tt;  // [ndays][TF_COUNT][24]
+};
+
+struct DateSetupArgs {
+    int nsteps;
+    const int32_t *year, *month, *day;
+    const double* hour;
+    const double* winddir;
+    double* dt;       // [tsteps][4]: sin(dec), cos(dec), eot, hour
+    int32_t* windex;  // [tsteps]
+};
+
+struct SolveArgs {
+    int64_t N;
+    const double* cellc;  // [CF_COUNT][N]
+    const double* hor;    // [24][N]
+    const double* wsa;    // [8][N]
+    const double* tt;     // vector forcing: [ndays][TF_COUNT][24]
+    // array forcing
+    const double* af[15];   // forcing slabs [N][steps in buffer], TF_TC .. TF_DTRP order
+    const double* dt;       // [tsteps][4]
+    const int32_t* windex;  // [tsteps]
+    const double* mxtc;     // [N]
+    int64_t force_step0;    // first step of this launch inside the forcing slabs
+    // outputs: slot base pointers [N][slot steps] or null
+    double* out[10];
+    int64_t slot_step0;     // first step of this launch inside the slot
+    // reqhgt < 0
+    double* tgser;          // [N][tsteps]
+    double* ddsum;          // [N]
+    int32_t day0, ndays;
+    Globals g;
+};
+
+struct BelowArgs {
+    int64_t N;
+    int32_t tsteps, complete, hiy, per_cell_pointm;
+    double reqhgt, mat;
+    const double* cellflag_hgt;  // hgt [N] (NA test)
+    const double* tg;            // [N][tsteps]
+    const double* ddsum;         // [N]
+    const double *Tgp, *Tbp;     // [tsteps] or [N][tsteps]; complete==0 only
+    double* scratch;             // [N][2*ndays]
+    double* tz;                  // [N][tsteps]
+};
+
+void launch_fill(double* p, int64_t n, double v, hipStream_t s);
+void launch_twi_partial(const double* twi, int64_t n, double tfact, double* out2, hipStream_t s);
+void launch_cell_setup(const CellSetupArgs& a, hipStream_t s);
+void launch_time_setup(const TimeSetupArgs& a, hipStream_t s);
+void launch_date_setup(const DateSetupArgs& a, hipStream_t s);
+void launch_mxtc(const double* tc, int64_t N, int nsteps, double* mx, hipStream_t s);
+void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, hipStream_t s);
+void launch_belowground(const BelowArgs& a, hipStream_t s);
+
+int cell_field_count();
+int time_field_count();
+double hf0_constant();
+
+}  // namespace mcf

@@ -1,0 +1,631 @@
+// mcf_kernels.hip — gfx950 kernels of the grid microclimate solver.
+//
+//   k_twi_partial   sum/count of log(twi)/tfact (the solver's one global reduction, cpp:993-1004)
+//   k_cell_setup    per-cell constant table (CellConst), cpp:2185-2190 + everything hoistable
+//   k_time_setup    per-timestep table (TimeConst) for vector forcing, cpp:2153-2169 + hoistable
+//   k_solve         the hot loop cpp:2180-2306 / 2452-2586: one lane per (cell, hour)
+//   k_mxtc          per-cell running max of air temperature (array forcing, cpp:2467-2471)
+//   k_belowground   Tbelowgroundv, cpp:1474-1539, one lane per cell
+//   k_fill          constant fill (NA_real_ for steps past the last whole day)
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "mcf_device.hpp"
+#include "mcf_kernels.h"
+
+namespace mcf {
+
+// ------------------------------------------------------------------------------------
+__global__ void k_fill(double* __restrict__ p, int64_t n, double v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------
+// Deterministic single-block reduction: fixed strided partials, then an LDS tree.
+__global__ __launch_bounds__(1024) void k_twi_partial(const double* __restrict__ twi, int64_t n, double tfact,
+                                                      double* __restrict__ out /* [2]: sum, count */) {
+    __shared__ double ssum[1024];
+    __shared__ double scnt[1024];
+    double s = 0.0, c = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        double v = twi[i];
+        if (!isnan(v)) {
+            s += log(v) / tfact;
+            c += 1.0;
+        }
+    }
+    ssum[threadIdx.x] = s;
+    scnt[threadIdx.x] = c;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            ssum[threadIdx.x] += ssum[threadIdx.x + w];
+            scnt[threadIdx.x] += scnt[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = ssum[0];
+        out[1] = scnt[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// cpp:294-310
+__device__ inline double zeroplanedis(double h, double pai) {
+    if (pai < 0.001) pai = 0.001;
+    return (1.0 - (1.0 - exp(-sqrt(7.5 * pai))) / sqrt(7.5 * pai)) * h;
+}
+__device__ inline double roughlength(double h, double pai, double d, double psi_h) {
+    double Be = sqrt(0.003 + (0.2 * pai) / 2);
+    double zm = (h - d) * exp(-kKa / Be) * exp(kKa * psi_h);
+    if (zm > (0.9 * (h - d))) zm = 0.9 * (h - d);
+    if (zm < 0.0005) zm = 0.0005;
+    return zm;
+}
+// cpp:104-121 (k only)
+__device__ inline double cank_k(double zenr, double x) {
+    double k;
+    if (zenr > (kPi / 2.0)) zenr = kPi / 2.0;
+    if (x == 1.0) k = 1.0 / (2.0 * cos(zenr));
+    else if (isinf(x)) k = 1.0;
+    else if (x == 0.0) k = tan(zenr);
+    else k = sqrt(x * x + (tan(zenr) * tan(zenr))) / (x + 1.774 * pow((x + 1.182), -0.733));
+    if (k > 6000.0) k = 6000.0;
+    return k;
+}
+// cpp:1365-1375, the height integral of rhcanopy
+__device__ inline double rh_integral(double h, double z) {
+    if (!(z != h)) return 4.293251 * h;
+    double a = (kPi * z) / h;
+    double s = sin(a), c1 = cos(a) + 1;
+    return (2.0 * h *
+            ((48 * atan((sqrt(5.0) * s) / c1)) / pow(5.0, 1.5) +
+             (32.0 * s) / (c1 * ((25.0 * (s * s)) / (c1 * c1) + 5.0)))) / kPi;
+}
+
+__global__ __launch_bounds__(256) void k_cell_setup(CellSetupArgs a) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.N) return;
+    const int64_t N = a.N;
+    double* out = a.cellc;
+    auto put = [&](int f, double v) { out[(int64_t)f * N + c] = v; };
+    const double hgt = a.hgt[c], pai = a.pai[c], x = a.x[c], lref = a.leafr[c], ltra = a.leaft[c],
+                 clump = a.clump[c], gref = a.gref[c], paia = a.paia[c];
+    int flags = 0;
+    if (!isnan(hgt)) flags |= FL_VALID;
+    if (pai > 0.0) flags |= FL_PAI;
+    if (!(a.g.reqhgt2 >= hgt)) flags |= FL_BELOW;
+    if (x == 1.0) flags |= FL_XONE;
+    else if (isinf(x)) flags |= FL_XINF;
+    else if (x == 0.0) flags |= FL_XZERO;
+    // ---- solar index operands, cpp:96-97
+    const double slope = a.slope[c], aspect = a.aspect[c];
+    double ss = sin(slope * kToRad);
+    put(CF_CS, cos(slope * kToRad));
+    put(CF_SSCA, ss * cos(aspect * kToRad));
+    put(CF_SSSA, ss * sin(aspect * kToRad));
+    // ---- soil moisture spread, cpp:1005-1032
+    const double Smin = a.Smin[c], Smax = a.Smax[c];
+    double tadd = log(a.twi[c]) / a.tfact - a.twi_mean;
+    put(CF_SMIN, Smin);
+    put(CF_RGE, Smax - Smin);
+    put(CF_INVRGE, 1.0 / (Smax - Smin));
+    put(CF_ETA, exp(-tadd));
+    // ---- canopy extinction, cpp:119
+    put(CF_XX, x * x);
+    put(CF_KDENINV, 1.0 / (x + 1.774 * pow((x + 1.182), -0.733)));
+    // ---- two-stream diffuse constants, cpp:134-162 and 1034-1084
+    const double pait = pai / (1.0 - clump);
+    const double om = lref + ltra, aa = 1.0 - om, del = lref - ltra;
+    double J = 1.0 / 3.0;
+    if (x != 1.0) {
+        double mla = 9.65 * pow((3.0 + x), -1.65);
+        if (mla > kPi / 2.0) mla = kPi / 2.0;
+        J = cos(mla) * cos(mla);
+    }
+    const double gma = 0.5 * (om + J * del);
+    const double h = sqrt(aa * aa + 2.0 * aa * gma);
+    const double S1 = exp(-h * pait);
+    const double u1 = aa + gma * (1.0 - 1.0 / gref);
+    const double u2 = aa + gma * (1.0 - gref);
+    const double D1 = (aa + gma + h) * (u1 - h) * 1.0 / S1 - (aa + gma - h) * (u1 + h) * S1;
+    const double D2 = (u2 + h) * 1.0 / S1 - (u2 - h) * S1;
+    const double p1 = (gma / (D1 * S1)) * (u1 - h);
+    const double p2 = (-gma * S1 / D1) * (u1 + h);
+    const double p3 = (1.0 / (D2 * S1)) * (u2 + h);
+    const double p4 = (-S1 / D2) * (u2 - h);
+    double gi = 0.0;
+    if (clump > 0.0) gi = pow(clump, paia / pai);
+    if (gi > 0.99) gi = 0.99;
+    double giu = 0.0;
+    if (clump > 0.0) giu = pow(clump, (pai - paia) / pai);
+    if (giu > 0.99) giu = 0.99;
+    const double trd = gi * gi, trdn = clump * clump, trdu = giu * giu;
+    const double paiaa = paia / (1.0 - gi);
+    double amx = gref;
+    if (amx < lref) amx = lref;
+    double albd = (1.0 - trdn * trdn) * (p1 + p2) + trdn * trdn * gref;
+    if (albd > amx) albd = amx;
+    if (albd < 0.01) albd = 0.01;
+    const double ehp = exp(h * pait), ehpa = exp(h * paiaa), emhpa = exp(-h * paiaa);
+    double Rddn_g = (1.0 - trdn) * (p3 * S1 + p4 * ehp) + trdn;
+    if (Rddn_g > 1.0) Rddn_g = 1.0;
+    if (Rddn_g < 0.0) Rddn_g = 0.0;
+    double Rdup_z = (1.0 - trdu * trdn) * (p1 * emhpa + p2 * ehpa) + trdu * trdn * gref;
+    if (Rdup_z > 1.0) Rdup_z = 1.0;
+    if (Rdup_z < 0.0) Rdup_z = 0.0;
+    double Rddn_z = (1.0 - trd) * (p3 * emhpa + p4 * ehpa) + trd;
+    if (Rddn_z > 1.0) Rddn_z = 1.0;
+    if (Rddn_z < 0.0) Rddn_z = 0.0;
+    const double omp = 0.5 * om;
+    if (isnan(omp)) flags |= FL_OMPNAN;
+    put(CF_PAIT, pait); put(CF_OM, om); put(CF_JDEL, J * del); put(CF_GMA, gma); put(CF_GMA2, gma * gma);
+    put(CF_AGM, aa + gma); put(CF_AGM2, (aa + gma) * (aa + gma)); put(CF_U1, u1); put(CF_U2, u2);
+    put(CF_H, h); put(CF_S1, S1); put(CF_INVS1, 1.0 / S1); put(CF_INVD1, 1.0 / D1); put(CF_INVD2, 1.0 / D2);
+    put(CF_GREF, gref); put(CF_GMAGREF, gma * gref); put(CF_LOGCLUMP, log(clump)); put(CF_LOGGI, log(gi));
+    put(CF_TRDN, trdn); put(CF_TRDU, trdu); put(CF_AMX, amx); put(CF_EHP, ehp); put(CF_PAIAA, paiaa);
+    put(CF_EHPA, ehpa); put(CF_EMHPA, emhpa); put(CF_ALBD, albd); put(CF_RDDNG, Rddn_g);
+    put(CF_RDDNZ, Rddn_z); put(CF_RDUPZ, Rdup_z);
+    const double svfa = a.svfa[c];
+    put(CF_SVFA, svfa);
+    put(CF_HOM, 0.5 * (1.0 - om));
+    put(CF_HOMP, 0.5 * (1.0 - omp));
+    // ---- long wave, cpp:1165-1175 (pai == 0 is the trdif = 1 special case)
+    double trdif = 1.0;
+    if (pai > 0.0) trdif = (1.0 - trdn) * exp(-pait) + trdn;
+    put(CF_TSV, trdif * svfa);
+    put(CF_OMTRDIF, 1.0 - trdif);
+    // ---- wind, cpp:1179-1218
+    const double d = zeroplanedis(hgt, pai);
+    double zm = roughlength(hgt, pai, d, 0.0);
+    if (zm < 1e-6) zm = 1e-6;
+    const double aw = pai / hgt;
+    const double zref = a.g.zref, z = a.g.reqhgt2;
+    put(CF_UFC, kKa / log((zref - d) / zm));
+    double uzfac;
+    if (z >= hgt) {
+        uzfac = log((z - d) / zm) / kKa;
+    } else {
+        double r = log((hgt - d) / zm) / kKa;   // uh = uf * r
+        if (r < 1.0) r = 1.0;                   // cpp:1206
+        double Be = 1.0 / r;
+        if (Be < 0.001) Be = 0.001;
+        double Lc = 1.0 / (0.25 * aw);
+        double Lm = 2 * (Be * Be * Be) * Lc;
+        uzfac = r * exp(Be * (z - hgt) / Lm);
+    }
+    put(CF_UZFAC, uzfac);
+    {
+        double z0 = 0.2 * zm + d;                // cpp:375-377
+        put(CF_GHAFAC, (kKa * 43) / log((zref - d) / (z0 - d)));
+    }
+    // ---- soil, cpp:628-636, 1249-1268
+    const double psie = a.Psie[c], soilb = a.soilb[c], Vq = a.Vq[c], Vm = a.Vm[c], Mc = a.Mc[c], rho = a.rho[c];
+    put(CF_ABSPSIE, fabs(psie));
+    put(CF_INVSMAX, 1.0 / Smax);
+    put(CF_SOILB, soilb);
+    put(CF_RHO, rho);
+    put(CF_CSA, 2400 * rho / 2.64);
+    {
+        double frs = Vm + Vq;
+        double c1 = (0.57 + 1.73 * Vq + 0.93 * Vm) / (1.0 - 0.74 * Vq - 0.49 * Vm) - 2.8 * frs * (1.0 - frs);
+        double c3 = 1.0 + 2.6 * pow(Mc, -0.5);
+        double c4 = 0.03 + 0.7 * frs * frs;
+        put(CF_C1, c1);
+        put(CF_C1MC4, c1 - c4);
+        put(CF_C3, c3);
+    }
+    // ---- stomatal parameters, cpp:391-440
+    {
+        const double lat = a.lats ? a.lats[c] : a.lat;
+        double Rsmx = 420.0, psiw0 = -3.1, kk = 0.34, rat = 0.9;
+        if (hgt < 1.0 && fabs(lat) < 22.5) { Rsmx = 450.0; psiw0 = -2.7; kk = 0.39; rat = 0.9; }
+        if (hgt >= 1.0 && hgt < 7.0) { Rsmx = 430.0; psiw0 = -4.0; kk = 0.28; rat = 0.75; }
+        if (hgt >= 7.0) {
+            if (fabs(lat) < 22.5) { Rsmx = 500.0; psiw0 = -1.75; kk = 0.67; rat = 0.4; }
+            else if (x < 0.8 || fabs(lat) > 58.0) { Rsmx = 420.0; psiw0 = -4.09; kk = 0.29; rat = 0.6; }
+            else { Rsmx = 500.0; psiw0 = -2.51; kk = 0.46; rat = 0.45; }
+        }
+        const double gsmax = a.gsmax[c];
+        if (gsmax < 999.99) flags |= FL_STOM;
+        put(CF_GSMAX, gsmax); put(CF_RSMX, Rsmx); put(CF_INV02RSMX, 1.0 / (0.2 * Rsmx)); put(CF_RAT, rat);
+        put(CF_RATC, (1 - rat) * kThetam); put(CF_PSIW0, psiw0); put(CF_KK, kk);
+        put(CF_MUDENINV, 1.0 / (exp(-kk * psiw0) - 1.0));
+        put(CF_SINLAT, sin(lat * kPi / 180.0));
+        put(CF_COSLAT, cos(lat * kPi / 180.0));
+        put(CF_LON, a.lons ? a.lons[c] : a.lon);
+    }
+    // ---- canopy conductance operands for the saturated (degrees) cankCpp call, cpp:1425, 466-469
+    {
+        double ksat = cank_k(kPi / 2.0, x);
+        put(CF_PAI, pai);
+        put(CF_OMPC, omp);
+        put(CF_KSAT, ksat);
+        put(CF_PSUNSAT, (1.0 - exp(-ksat * pai)) / ksat);
+        put(CF_SHADEFAC, ((1.0 - exp(-pai)) / pai) * (1.0 - omp));
+    }
+    // ---- log-profile weights, cpp:1298-1313
+    {
+        double zh = 0.2 * zm;
+        double lden = log((zref - d) / zh);
+        if (z > (d + zh)) flags |= FL_ABOVE1;
+        if (hgt > (d + zh)) flags |= FL_ABOVE2;
+        put(CF_OML1, 1 - log((z - d) / zh) / lden);
+        put(CF_OML2, 1 - log((hgt - d) / zh) / lden);
+    }
+    // ---- leaf / below-canopy constants, cpp:1341-1347, 1365-1398, 1447
+    put(CF_EMG, exp(-(pai - paia)));
+    put(CF_EMA, exp(-paia));
+    put(CF_INVLEAFD, 1.0 / a.leafd[c]);
+    {
+        double a2 = 0.4 * (1.0 - (d / hgt)) / (1.25 * 1.25);
+        put(CF_A2H, a2 * hgt);
+        put(CF_INTHH, 4.293251 * hgt);
+        put(CF_INTHZ, rh_integral(hgt, z));
+        put(CF_HGT, hgt);
+        put(CF_INVHMZ, 1.0 / (hgt - z));
+        put(CF_NEARFAC, 3.047519 + 0.128642 * log(pai));
+        put(CF_LEAFDEN, a.leafden[c]);
+        put(CF_OMEMPAI, 1.0 - exp(-pai));
+    }
+    put(CF_FLAGS, (double)flags);
+}
+
+// ------------------------------------------------------------------------------------
+// Vector forcing: one lane per time step.  Table layout [day][field][hour].
+__global__ __launch_bounds__(256) void k_time_setup(TimeSetupArgs a) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.nsteps) return;
+    TimeVals t;
+    for (int f = 0; f < 15; ++f) t.v[f] = a.raw[f][k];
+    SolDate sd = sol_date(a.year[k], a.month[k], a.day[k]);
+    SolPos sp = sol_site(sd, a.hour[k], sin(a.lat * kPi / 180.0), cos(a.lat * kPi / 180.0), a.lon);
+    derive_time(t, sp, dir_index(a.winddir[k], 45.0, 8));
+    int dy = k / 24, hr = k % 24;
+    double* dst = a.tt + ((int64_t)dy * TF_COUNT) * 24 + hr;
+    for (int f = 0; f < TF_COUNT; ++f) dst[f * 24] = t.v[f];
+}
+
+// Array forcing: per-timestep date part of the solar position + wind index.
+__global__ __launch_bounds__(256) void k_date_setup(DateSetupArgs a) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.nsteps) return;
+    SolDate sd = sol_date(a.year[k], a.month[k], a.day[k]);
+    a.dt[4 * (int64_t)k + 0] = sd.sindec;
+    a.dt[4 * (int64_t)k + 1] = sd.cosdec;
+    a.dt[4 * (int64_t)k + 2] = sd.eot;
+    a.dt[4 * (int64_t)k + 3] = a.hour[k];
+    a.windex[k] = dir_index(a.winddir[k], 45.0, 8);
+}
+
+// Array forcing: running per-cell max of tc over a slab of `nsteps` steps.
+__global__ __launch_bounds__(256) void k_mxtc(const double* __restrict__ tc, int64_t N, int nsteps,
+                                              double* __restrict__ mx) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    double m = mx[c];
+    for (int k = 0; k < nsteps; ++k) {
+        double v = tc[c + N * k];
+        if (v > m) m = v;
+    }
+    mx[c] = m;
+}
+
+// ------------------------------------------------------------------------------------
+// The solver.  Workgroup = CPB cells x 24 hours; thread t -> cell t % CPB, hour t / CPB,
+// so the lanes of a wave are CPB consecutive raster rows (coalesced stores of
+// CPB*8 B per hour) and 64/CPB consecutive hours.
+//   AF   array forcing (runmicro2Cpp geometry)
+//   BG   reqhgt < 0: store the ground temperature series and the damping-depth sum
+// ------------------------------------------------------------------------------------
+template <int CPB, bool AF, bool BG>
+__global__ __launch_bounds__(CPB * 24) void k_solve(SolveArgs a) {
+    constexpr int NT = CPB * 24;
+    __shared__ double s_cell[CF_COUNT * CPB];
+    __shared__ double s_dirs[kCellDirs * CPB];
+    __shared__ double s_time[AF ? 1 : 3 * TF_COUNT * 24];
+    __shared__ double s_red[2][2][24 * CPB];
+    __shared__ double s_dd[BG ? 24 * CPB : 1];
+
+    const int tid = threadIdx.x;
+    const int cl = tid % CPB;
+    const int hr = tid / CPB;
+    const int64_t N = a.N;
+    const int64_t c0 = (int64_t)blockIdx.x * CPB;
+    const int64_t c = c0 + cl;
+    const bool in_grid = c < N;
+
+    // ---- stage the tile's cell constants and direction tables in LDS
+    for (int q = tid; q < CF_COUNT * CPB; q += NT) {
+        int f = q / CPB, l = q % CPB;
+        int64_t cc = c0 + l;
+        s_cell[q] = cc < N ? a.cellc[(int64_t)f * N + cc] : 0.0;
+    }
+    for (int q = tid; q < kCellDirs * CPB; q += NT) {
+        int dI = q / CPB, l = q % CPB;
+        int64_t cc = c0 + l;
+        double v = 0.0;
+        if (cc < N) v = dI < 24 ? a.hor[(int64_t)dI * N + cc] : a.wsa[(int64_t)(dI - 24) * N + cc];
+        s_dirs[q] = v;
+    }
+    if (!AF) {
+        const double* src = a.tt + (int64_t)a.day0 * TF_COUNT * 24;
+        for (int q = tid; q < TF_COUNT * 24; q += NT) s_time[q] = src[q];
+    }
+    __syncthreads();
+
+    CellLds<CPB> C{s_cell, s_dirs, cl};
+    const int flags = in_grid ? (int)s_cell[CF_FLAGS * CPB + cl] : 0;
+    const bool valid = (flags & FL_VALID) != 0;
+    Globals g = a.g;
+    double dTmx = g.dTmx;
+    if (AF && in_grid) dTmx = -0.6273 * a.mxtc[c] + 49.79;   // cpp:1236 with the per-cell mxtc
+    const bool above_ground = g.reqhgt >= 0.0;
+    const double NA = na_real();
+
+    for (int dl = 0; dl < a.ndays; ++dl) {
+        const int dabs = a.day0 + dl;
+        const int64_t kl = (int64_t)dl * 24 + hr;            // step within the slot
+        const int64_t oidx = c + N * (a.slot_step0 + kl);
+        if (!AF) {
+            // prefetch the next day's table rows into the third buffer
+            if (dl + 1 < a.ndays) {
+                const double* src = a.tt + (int64_t)(dabs + 1) * TF_COUNT * 24;
+                double* dst = s_time + ((dl + 1) % 3) * (TF_COUNT * 24);
+                for (int q = tid; q < TF_COUNT * 24; q += NT) dst[q] = src[q];
+            }
+        }
+        TimeVals tv;
+        if (AF && valid) {
+            const int64_t fidx = c + N * (a.force_step0 + kl);
+            for (int f = 0; f < 15; ++f) tv.v[f] = a.af[f][fidx];
+            const int64_t kabs = (int64_t)dabs * 24 + hr;
+            SolDate sd{a.dt[4 * kabs + 0], a.dt[4 * kabs + 1], a.dt[4 * kabs + 2]};
+            SolPos sp = sol_site(sd, a.dt[4 * kabs + 3], C(CF_SINLAT), C(CF_COSLAT), C(CF_LON));
+            derive_time(tv, sp, a.windex[kabs]);
+        }
+        TimeLds TL{s_time + (AF ? 0 : (dl % 3) * (TF_COUNT * 24)) + hr};
+        TimeReg TR{&tv};
+
+        Carry cy;
+        Pass1Out p1;
+        double* red_t = &s_red[dl & 1][0][hr * CPB + cl];
+        double* red_r = &s_red[dl & 1][1][hr * CPB + cl];
+        if (valid) {
+            if (AF) pass1(C, TR, g, flags, dTmx, cy, p1);
+            else pass1(C, TL, g, flags, dTmx, cy, p1);
+            *red_t = p1.Tg0;
+            *red_r = p1.absRnet;
+            if (a.out[3]) a.out[3][oidx] = cy.soilm;     // soilm      cpp:2227
+            if (a.out[4]) a.out[4][oidx] = p1.uz;        // windspeed  cpp:2253
+            if (a.out[5]) a.out[5][oidx] = cy.Rbdown;    // Rdirdown   cpp:2242
+            if (a.out[6]) a.out[6][oidx] = cy.Rddown;    // Rdifdown   cpp:2243
+            if (a.out[8]) a.out[8][oidx] = p1.Rdup;      // Rswup      cpp:2244
+        } else if (in_grid) {
+            if (a.out[3]) a.out[3][oidx] = NA;
+            if (a.out[4]) a.out[4][oidx] = NA;
+            if (a.out[5]) a.out[5][oidx] = NA;
+            if (a.out[6]) a.out[6][oidx] = NA;
+            if (a.out[8]) a.out[8][oidx] = NA;
+        }
+        __syncthreads();
+        if (valid) {
+            // day reductions in hour order with the reference's comparisons, cpp:2196-2198, 2256-2263
+            double Rmx = -999.9, tmx = -999.0, tmn = 999.0;
+            const double* rt = &s_red[dl & 1][0][cl];
+            const double* rr = &s_red[dl & 1][1][cl];
+#pragma unroll
+            for (int hh = 0; hh < 24; ++hh) {
+                double tg = rt[hh * CPB], rv = rr[hh * CPB];
+                if (Rmx < rv) Rmx = rv;
+                if (tmx < tg) tmx = tg;
+                if (tmn > tg) tmn = tg;
+            }
+            const double dtr = tmx - tmn;
+            Pass2Out p2;
+            if (AF) pass2(C, TR, g, flags, dTmx, cy, dtr, Rmx, above_ground, p2);
+            else pass2(C, TL, g, flags, dTmx, cy, dtr, Rmx, above_ground, p2);
+            if (BG) {
+                a.tgser[c + N * ((int64_t)dabs * 24 + hr)] = p2.Tg;
+                s_dd[hr * CPB + cl] = p2.DD;
+            } else {
+                const bool pos = g.reqhgt > 0.0;
+                if (a.out[0]) a.out[0][oidx] = pos ? p2.Tz : p2.Tg;          // cpp:2292-2297
+                if (a.out[1]) a.out[1][oidx] = pos ? p2.tleaf : NA;          // cpp:2300-2303
+                if (a.out[2]) a.out[2][oidx] = pos ? p2.rh : NA;
+                if (a.out[7]) a.out[7][oidx] = p2.lwdn;                      // cpp:2298
+                if (a.out[9]) a.out[9][oidx] = p2.lwup;                      // cpp:2299
+            }
+        } else if (in_grid) {
+            if (BG) a.tgser[c + N * ((int64_t)dabs * 24 + hr)] = NA;
+            if (a.out[0] && !BG) a.out[0][oidx] = NA;
+            if (a.out[1]) a.out[1][oidx] = NA;
+            if (a.out[2]) a.out[2][oidx] = NA;
+            if (a.out[7]) a.out[7][oidx] = NA;
+            if (a.out[9]) a.out[9][oidx] = NA;
+        }
+        if (BG) {
+            // reqhgt < 0 never writes tleaf/relhum/Rlw* (cpp:2272): they stay NA
+            if (valid) {
+                if (a.out[1]) a.out[1][oidx] = NA;
+                if (a.out[2]) a.out[2][oidx] = NA;
+                if (a.out[7]) a.out[7][oidx] = NA;
+                if (a.out[9]) a.out[9][oidx] = NA;
+            }
+            __syncthreads();
+            if (valid && hr == 0) {
+                double s = 0.0;
+                for (int hh = 0; hh < 24; ++hh) s += s_dd[hh * CPB + cl];
+                a.ddsum[c] += s;                                             // cpp:2309-2312
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Tbelowgroundv, cpp:1474-1539; maCpp cpp:561-572; manCpp cpp:597-627; one lane per cell.
+// tg / tz are [N, tsteps] (cell fastest).  scratch is [N, 2*ndays].
+__device__ inline double series(const double* p, int64_t N, int64_t c, int k, bool per_cell) {
+    return per_cell ? p[c + N * k] : p[k];
+}
+__global__ __launch_bounds__(64) void k_belowground(BelowArgs a) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t N = a.N;
+    if (c >= N) return;
+    const int m = a.tsteps;
+    const double* x = a.tg + c;
+    double* z = a.tz + c;
+    if (isnan(a.cellflag_hgt[c])) {
+        for (int i = 0; i < m; ++i) z[N * i] = na_real();
+        return;
+    }
+    const double meanD = a.ddsum[c] / (double)m;                           // cpp:2313
+    const double nb = -118.35 * a.reqhgt / meanD;
+    const int n = (int)round(nb);
+    if (a.complete) {
+        if (n < m) {
+            if (n <= 48) {                                                   // cpp:600-602
+                for (int i = 0; i < m; ++i) {
+                    double s = 0.0;
+                    for (int j = 0; j < n; ++j) s += x[N * ((i - j + m) % m)];
+                    z[N * i] = s / n;
+                }
+            } else {                                                         // cpp:604-625
+                const int nd = m / 24;
+                double* d = a.scratch + c;             // [nd]
+                double* y = a.scratch + c + N * nd;    // [nd]
+                for (int i = 0; i < nd; ++i) {
+                    double s = 0.0;
+                    for (int j = 0; j < 24; ++j) s += x[N * (i * 24 + j)];
+                    d[N * i] = s / 24.0;
+                }
+                const int n2 = n / 24;
+                for (int i = 0; i < nd; ++i) {
+                    double s = 0.0;
+                    for (int j = 0; j < n2; ++j) s += d[N * ((i - j + nd) % nd)];
+                    y[N * i] = s / n2;
+                }
+                for (int i = 0; i < m; ++i) {
+                    double s = 0.0;
+                    for (int j = 0; j < 24; ++j) {
+                        int q = (i - j + m) % m;
+                        s += (q < nd * 24) ? y[N * (q / 24)] : 0.0;
+                    }
+                    z[N * i] = s / 24;
+                }
+            }
+        } else {                                                             // cpp:1487-1492
+            double s = 0;
+            for (int i = 0; i < m; ++i) s = s + x[N * i];
+            double meanT = s / m;
+            for (int i = 0; i < m; ++i) z[N * i] = meanT;
+        }
+        return;
+    }
+    // incomplete time sequence, cpp:1495-1536
+    for (int i = 0; i < m; ++i) z[N * i] = x[N * i];
+    const int nd = m / 24;
+    const bool pc = a.per_cell_pointm != 0;
+    const bool blend_day = (nb > 1.0 && nb <= 24.0);
+    const bool blend_year = nb > 24.0;
+    if (!blend_day && !blend_year) return;
+    for (int dI = 0; dI < nd; ++dI) {
+        double gmx = x[N * (dI * 24)], gmn = gmx, gsum = 0.0;
+        double pmx = series(a.Tgp, N, c, dI * 24, pc), pmn = pmx, psum = 0.0, bsum = 0.0;
+        for (int j = 0; j < 24; ++j) {
+            double gv = x[N * (dI * 24 + j)], pv = series(a.Tgp, N, c, dI * 24 + j, pc);
+            if (j > 0) {
+                gmx = fmax(gmx, gv); gmn = fmin(gmn, gv);
+                pmx = fmax(pmx, pv); pmn = fmin(pmn, pv);
+            }
+            gsum += gv; psum += pv;
+            bsum += series(a.Tbp, N, c, dI * 24 + j, pc);
+        }
+        double gme = gsum / 24, pme = psum / 24, Tbpd = bsum / 24;
+        double rat = (gmx - gmn) / (pmx - pmn);
+        double dif = gme - pme;
+        for (int j = 0; j < 24; ++j) {
+            int i = dI * 24 + j;
+            double Tzd = rat * (series(a.Tbp, N, c, i, pc) - Tbpd) + Tbpd + dif;
+            if (blend_day) {
+                double w1 = 1.0 / nb, w2 = nb / 24.0;
+                double wgt = w1 / (w1 + w2);
+                z[N * i] = wgt * x[N * i] + (1 - wgt) * Tzd;
+            }
+            if (blend_year) {
+                if (nb < a.hiy) {
+                    double w1 = 24.0 / nb, w2 = nb / a.hiy;
+                    double wgt = w1 / (w1 + w2);
+                    z[N * i] = wgt * Tzd + (1 - wgt) * a.mat;
+                } else {
+                    z[N * i] = a.mat;
+                }
+            }
+        }
+    }
+    if (blend_year && !(nb < a.hiy))
+        for (int i = nd * 24; i < m; ++i) z[N * i] = a.mat;
+}
+
+// ------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------
+void launch_fill(double* p, int64_t n, double v, hipStream_t s) {
+    if (n <= 0) return;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)blocks), dim3(256), 0, s, p, n, v);
+}
+void launch_twi_partial(const double* twi, int64_t n, double tfact, double* out2, hipStream_t s) {
+    hipLaunchKernelGGL(k_twi_partial, dim3(1), dim3(1024), 0, s, twi, n, tfact, out2);
+}
+void launch_cell_setup(const CellSetupArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_cell_setup, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, s, a);
+}
+void launch_time_setup(const TimeSetupArgs& a, hipStream_t s) {
+    if (a.nsteps <= 0) return;
+    hipLaunchKernelGGL(k_time_setup, dim3((unsigned)((a.nsteps + 255) / 256)), dim3(256), 0, s, a);
+}
+void launch_date_setup(const DateSetupArgs& a, hipStream_t s) {
+    if (a.nsteps <= 0) return;
+    hipLaunchKernelGGL(k_date_setup, dim3((unsigned)((a.nsteps + 255) / 256)), dim3(256), 0, s, a);
+}
+void launch_mxtc(const double* tc, int64_t N, int nsteps, double* mx, hipStream_t s) {
+    hipLaunchKernelGGL(k_mxtc, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, tc, N, nsteps, mx);
+}
+void launch_belowground(const BelowArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_belowground, dim3((unsigned)((a.N + 63) / 64)), dim3(64), 0, s, a);
+}
+
+template <int CPB>
+static void launch_solve_cpb(const SolveArgs& a, bool af, bool bg, hipStream_t s) {
+    dim3 grid((unsigned)((a.N + CPB - 1) / CPB)), block(CPB * 24);
+    if (af) {
+        if (bg) hipLaunchKernelGGL((k_solve<CPB, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_solve<CPB, true, false>), grid, block, 0, s, a);
+    } else {
+        if (bg) hipLaunchKernelGGL((k_solve<CPB, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_solve<CPB, false, false>), grid, block, 0, s, a);
+    }
+}
+int cell_field_count() { return CF_COUNT; }
+int time_field_count() { return TF_COUNT; }
+// mincondCpp (cpp:1321-1325) evaluated for gs = 999.99: rs = 1/gs, Hlf, Hf are constants
+double hf0_constant() {
+    double rs = 1 / 999.99;
+    double Hlf = 1.09767 * pow(rs, 0.2672778);
+    return -1.0 / (1.0 + exp(2.0 - Hlf));
+}
+
+void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, hipStream_t s) {
+    if (a.N <= 0 || a.ndays <= 0) return;
+    if (cells_per_block == 32) launch_solve_cpb<32>(a, af, bg, s);
+    else launch_solve_cpb<16>(a, af, bg, s);
+}
+
+}  // namespace mcf

@@ -1,0 +1,59 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol that
+include/mcf.h declares, and fails loudly (no CPU fallback) without a GPU."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from microclimf_amd import _abi, synthetic
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _build():
+    import __graft_entry__ as g
+    g.build_library()
+
+
+def test_header_symbols_are_exported():
+    _build()
+    hdr = (ROOT / "include" / "mcf.h").read_text()
+    declared = set(re.findall(r"\b(mcf_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_abi.EXPORTS), declared ^ set(_abi.EXPORTS)
+    lib = C.CDLL(str(_abi.LIB_PATH))
+    for name in declared:
+        assert hasattr(lib, name), f"libmcfhip.so does not export {name}"
+    assert lib.mcf_abi_version() == 1
+
+
+def test_struct_layout_matches_header():
+    # sizes implied by include/mcf.h on LP64
+    assert C.sizeof(_abi.Obstime) == 4 * 8
+    assert C.sizeof(_abi.Climate) == 10 * 8
+    assert C.sizeof(_abi.Pointm) == 8 * 8
+    assert C.sizeof(_abi.Vegp) == 10 * 8
+    assert C.sizeof(_abi.Soilc) == 15 * 8
+    assert C.sizeof(_abi.GridInputs) == 3 * 8 + 8 + (4 + 10 + 8 + 10 + 15) * 8 + 2 * 8 + 2 * 8
+    assert C.sizeof(_abi.Options) == 6 * 8 + 4 + 40 + 3 * 4
+    assert C.sizeof(_abi.Outputs) == 80
+
+
+def test_no_cpu_fallback_without_device():
+    _build()
+    lib = _abi.load()
+    if lib.mcf_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from microclimf_amd.api import runmicro1Cpp
+    a = synthetic.workload(4, 4, 24)
+    with pytest.raises(_abi.McfError, match="no HIP device"):
+        runmicro1Cpp(**a)
+
+
+def test_marshal_rejects_bad_shapes():
+    from microclimf_amd.marshal import marshal
+    a = synthetic.workload(4, 4, 24)
+    a["vegp"] = dict(a["vegp"], pai=np.zeros((3, 4)))
+    with pytest.raises(ValueError):
+        marshal(**a, array_forcing=False)
