@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py — cell-steps/s of the grid microclimate solver on MI355X.
+
+One "step" = one pass of the hot path (runmicro1Cpp geometry: vector forcing,
+reqhgt = 0.05 m, all 10 outputs) over the whole workload of a rank:
+BASELINE.json configs[1], a 1024 x 1024 synthetic DTM x 8760 hourly steps.
+Inputs are resident in HBM before the timed region; outputs go to a device ring
+(sink: HBM ring, no D2H) because one year of outputs (735 GB at 1024^2) does not
+fit HBM.  With --gpus N (launched by torch.distributed.run, one rank per GPU)
+the raster is row-tiled: every rank owns a 1024-row block of a (1024*N) x 1024
+raster (weak scaling); the only data-path collective is the all-reduce of the
+(sum, count) of log(twi)/tfact (src/microclimfCpp.cpp:993-1004) over RCCL.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=1024, help="rows per GPU")
+    ap.add_argument("--cols", type=int, default=1024)
+    ap.add_argument("--tsteps", type=int, default=8760)
+    ap.add_argument("--reqhgt", type=float, default=0.05)
+    ap.add_argument("--ring-days", type=int, default=5)
+    ap.add_argument("--ring-slots", type=int, default=2)
+    ap.add_argument("--cells-per-block", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=str, default="96x96x720")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The oracle (a scalar C restatement of the reference loop, kind 'port') timed on one
+    host core over a bounded sample of the same synthetic workload."""
+    from microclimf_amd import synthetic
+    from oracle import oracle as O
+    r, c, t = (int(v) for v in args.cpu_sample.split("x"))
+    a = synthetic.workload(r, c, t, reqhgt=args.reqhgt, start_doy=152)
+    O.load()
+    t0 = time.perf_counter()
+    O.run_grid(**a)
+    dt = time.perf_counter() - t0
+    valid = int((~np.isnan(a["vegp"]["hgt"])).sum())
+    return {"value": valid * (t // 24) * 24 / dt, "unit": "cell-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{r}x{c} cells x {t} hourly steps of the same seeded synthetic workload, "
+                      f"oracle/mcf_oracle.c (gcc -O2, 1 thread), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build_library()
+    if world > 1:
+        dist.barrier()
+    from microclimf_amd import synthetic
+    from microclimf_amd.api import Plan
+
+    rows, cols, T = args.rows, args.cols, args.tsteps
+    ndays = T // 24
+    a = synthetic.workload(rows, cols, T, reqhgt=args.reqhgt, row0=rank * rows, rows_total=rows * world)
+    n_out = 10
+    plan = Plan(**a, ring_days=args.ring_days, ring_slots=args.ring_slots, device=local_rank,
+                cells_per_block=args.cells_per_block)
+    # the solver's one global reduction: mean of log(twi)/tfact over the WHOLE raster
+    s, n = plan.twi_partial()
+    if world > 1:
+        red = torch.tensor([s, float(n)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(red, op=dist.ReduceOp.SUM)          # RCCL over xGMI
+        s, n = float(red[0].item()), float(red[1].item())
+    plan.set_twi_mean(s / n)
+    valid = plan.valid_cells
+
+    def one_step():
+        slot = 0
+        for d0 in range(0, ndays, args.ring_days):
+            plan.run_days(d0, min(args.ring_days, ndays - d0), slot)
+            slot = (slot + 1) % args.ring_slots
+
+    def fence():
+        plan.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    plan.kernel_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    dt = time.perf_counter() - t0
+    kms, klaunches = plan.kernel_stats()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        vv = torch.tensor([float(valid)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(vv, op=dist.ReduceOp.SUM)
+        valid_all = float(vv.item())
+    else:
+        valid_all = float(valid)
+    cellsteps_per_step = valid_all * ndays * 24
+    value = cellsteps_per_step * args.steps / dt
+
+    if rank == 0:
+        # roofline of the dominant kernel (k_solve): ALGORITHMIC bytes per launch =
+        # valid cells x steps per launch x (8 B x n_out written + 440 B / T read)   [SURVEY §8d]
+        steps_per_launch = (ndays * 24 * args.steps) / max(klaunches, 1)
+        bytes_per_launch = valid * steps_per_launch * (8.0 * n_out + 440.0 / T)
+        avg_ms = kms / max(klaunches, 1)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tf = ROOT / "profiles" / "traffic.json"
+        if tf.exists():
+            try:
+                tj = json.loads(tf.read_text())
+                if tj.get("rows") == rows and tj.get("cols") == cols and tj.get("ring_days") == args.ring_days:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "cell-steps/s", "value": value, "unit": "cell-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{rows}x{cols} synthetic DTM per GPU, {T} hourly steps, vector forcing "
+                            f"(runmicro1Cpp geometry), reqhgt={args.reqhgt}, no snow "
+                            "[BASELINE.json configs[1]]",
+                "rows_per_gpu": rows, "cols": cols, "tsteps": T, "outputs": n_out,
+                "valid_cells": int(valid_all),
+                "sink": f"HBM ring ({args.ring_slots} slots x {args.ring_days} days), no D2H",
+                "partition": "row blocks, one per GPU; all-reduce of twi (sum,count) only",
+            },
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": traffic,
+                         "kernel": "k_solve", "avg_launch_ms": avg_ms, "launches": int(klaunches),
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "note": "fp64 VALU (software transcendentals) is the binding roof, see DESIGN.md"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    plan.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

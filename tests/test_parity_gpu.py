@@ -136,7 +136,7 @@ def test_large_grid_properties():
     na = np.isnan(a["vegp"]["hgt"])
     assert np.array_equal(np.isnan(tz_big[:, :, 0]), na)
     assert np.nanmax(rh_big) <= 100.0 and np.nanmin(rh_big) > 0
-    assert np.nanmax(np.abs(tz_big - a["climdata"]["temp"][None, None, :])) < 30
+    assert np.nanmax(np.abs(tz_big - a["climdata"]["temp"][None, None, :])) < 50   # the reference caps dT at -0.6273*mxtc + 49.79 (cpp:1236)
     sub = synthetic.workload(64, Cn, T, reqhgt=0.05, start_doy=172, row0=128, rows_total=R)
     for k in sub["vegp"]:
         assert np.array_equal(sub["vegp"][k], a["vegp"][k][128:192], equal_nan=True)
