@@ -14,6 +14,10 @@
 #include "mcf_device.hpp"
 #include "mcf_kernels.h"
 
+#ifndef MCF_WAVES_PER_EU
+#define MCF_WAVES_PER_EU 3
+#endif
+
 namespace mcf {
 
 // ------------------------------------------------------------------------------------
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256) void k_mxtc(const double* __restrict__ tc, int
 //   BG   reqhgt < 0: store the ground temperature series and the damping-depth sum
 // ------------------------------------------------------------------------------------
 template <int CPB, bool AF, bool BG>
-__global__ __launch_bounds__(CPB * 24) void k_solve(SolveArgs a) {
+__global__ __launch_bounds__(CPB * 24, MCF_WAVES_PER_EU) void k_solve(SolveArgs a) {
     constexpr int NT = CPB * 24;
     __shared__ double s_cell[CF_COUNT * CPB];
     __shared__ double s_dirs[kCellDirs * CPB];
