@@ -132,7 +132,7 @@ typedef struct mcf_options {
     int32_t out[MCF_NOUT];
     int32_t device;          /* HIP device ordinal                                      */
     int32_t days_per_chunk;  /* 0 = choose from free HBM                                */
-    int32_t cells_per_block; /* 0 = default (16); 16 or 32                              */
+    int32_t cells_per_block; /* 0 = default (32); 16 or 32                              */
 } mcf_options;
 
 /* Host output buffers, each [rows,cols,tsteps] or NULL when out[v]==0. */
@@ -195,6 +195,12 @@ int mcf_plan_timer_stop(mcf_plan *plan, float *ms);
  * measured with per-launch HIP events when enabled. */
 int mcf_plan_kernel_timing(mcf_plan *plan, int32_t enable);
 int mcf_plan_kernel_stats(mcf_plan *plan, double *total_ms, int64_t *launches);
+
+/* Diagnostics: evaluate one of the solver's lean device elementary functions
+ * elementwise on host arrays (kind 0 exp, 1 log, 2 x/y, 3 sqrt, 4 1/x, 5 satvap
+ * (cpp:480-490), 6 x^y); used by tests to bound their error against libm. */
+int mcf_selftest_math(int32_t kind, const double *x, const double *y, double *out, int64_t n,
+                      int32_t device);
 
 /* Information. */
 int64_t mcf_plan_valid_cells(const mcf_plan *plan); /* cells with non-NA hgt */

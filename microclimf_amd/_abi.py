@@ -76,7 +76,7 @@ EXPORTS = (
     "mcf_plan_set_twi_mean", "mcf_plan_upload_forcing_days", "mcf_plan_run_days",
     "mcf_plan_belowground", "mcf_plan_sync", "mcf_plan_fetch", "mcf_plan_slot_ptr",
     "mcf_plan_timer_start", "mcf_plan_timer_stop", "mcf_plan_kernel_timing",
-    "mcf_plan_kernel_stats", "mcf_plan_valid_cells", "mcf_plan_bytes",
+    "mcf_plan_kernel_stats", "mcf_plan_valid_cells", "mcf_plan_bytes", "mcf_selftest_math",
 )
 
 _lib = None
@@ -138,6 +138,8 @@ def load() -> C.CDLL:
     lib.mcf_plan_valid_cells.argtypes = [P]
     lib.mcf_plan_bytes.restype = C.c_int64
     lib.mcf_plan_bytes.argtypes = [P]
+    lib.mcf_selftest_math.restype = C.c_int
+    lib.mcf_selftest_math.argtypes = [C.c_int32, c_double_p, c_double_p, c_double_p, C.c_int64, C.c_int32]
     if lib.mcf_abi_version() != 1:
         raise McfError("libmcfhip ABI version mismatch")
     _lib = lib

@@ -215,7 +215,7 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
     p->ndays = (int)(in->tsteps / 24);                       // cpp:2116 truncation
     p->af = in->array_forcing != 0;
     p->bg = opt->reqhgt < 0.0;
-    p->cpb = opt->cells_per_block ? opt->cells_per_block : 16;
+    p->cpb = opt->cells_per_block ? opt->cells_per_block : 32;
     p->opt = *opt;
     p->lat = in->lat; p->lon = in->lon;
     const int64_t N = p->N, T = p->tsteps;
@@ -437,12 +437,16 @@ int mcf_plan_run_days(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot) {
     if (p->af) {
         if (p->force_day0[slot] != day0 || p->force_ndays[slot] < ndays)
             return fail(MCF_ERR_STATE, "forcing for these days has not been uploaded to this slot");
-        for (int f = 0; f < 15; ++f) a.af[f] = p->d_force + ((int64_t)slot * 15 + f) * cap;
+        a.af_base = p->d_force + (int64_t)slot * 15 * cap;
+        a.af_stride = cap;
         a.dt = p->d_dt; a.windex = p->d_windex; a.mxtc = p->d_mxtc;
         a.force_step0 = 0;
     }
+    a.out_base = p->d_ring + (int64_t)slot * p->nvars * cap;
+    a.out_stride = cap;
+    a.out_sel = 0;
     for (int v = 0; v < MCF_NOUT; ++v)
-        a.out[v] = p->var_slot[v] < 0 ? nullptr : p->d_ring + ((int64_t)slot * p->nvars + p->var_slot[v]) * cap;
+        a.out_sel |= (uint64_t)(p->var_slot[v] < 0 ? 15 : p->var_slot[v]) << (4 * v);
     a.slot_step0 = p->bg ? (int64_t)day0 * 24 : 0;
     a.tgser = p->d_tgser; a.ddsum = p->d_ddsum;
     a.day0 = day0; a.ndays = ndays;
@@ -552,6 +556,26 @@ int mcf_plan_kernel_stats(mcf_plan* p, double* total_ms, int64_t* launches) {
     p->kev.clear();
     *total_ms = p->ktotal_ms;
     *launches = p->klaunches;
+    return MCF_OK;
+}
+
+int mcf_selftest_math(int32_t kind, const double* x, const double* y, double* out, int64_t n, int32_t device) {
+    if (!x || !out || n < 0) return fail(MCF_ERR_ARG, "null argument");
+    int rc = ensure_device(device);
+    if (rc) return rc;
+    double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    struct G { double *&a, *&b, *&c; ~G() { hipFree(a); hipFree(b); hipFree(c); } } g{dx, dy, dout};
+    size_t nb = (size_t)std::max<int64_t>(n, 1) * 8;
+    HIP_TRY(hipMalloc((void**)&dx, nb));
+    HIP_TRY(hipMalloc((void**)&dout, nb));
+    HIP_TRY(hipMemcpy(dx, x, (size_t)n * 8, hipMemcpyHostToDevice));
+    if (y) {
+        HIP_TRY(hipMalloc((void**)&dy, nb));
+        HIP_TRY(hipMemcpy(dy, y, (size_t)n * 8, hipMemcpyHostToDevice));
+    }
+    mcf::launch_selftest_math(kind, dx, dy, dout, n, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, (size_t)n * 8, hipMemcpyDeviceToHost));
     return MCF_OK;
 }
 

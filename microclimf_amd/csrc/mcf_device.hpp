@@ -76,7 +76,7 @@ enum CellField : int {
     // leaf temperature (cpp:1333-1364)
     CF_EMG, CF_EMA, CF_INVLEAFD,
     // below-canopy Lagrangian model (cpp:1365-1409)
-    CF_A2H, CF_INTHH, CF_INTHZ, CF_HGT, CF_INVHMZ, CF_NEARFAC, CF_LEAFDEN, CF_OMEMPAI,
+    CF_A2H, CF_INTHH, CF_INTHZ, CF_HGT, CF_INVHGT, CF_INVHMZ, CF_NEARFAC, CF_LEAFDEN, CF_OMEMPAI,
     // array forcing: per-cell solar geometry (cpp:2497)
     CF_SINLAT, CF_COSLAT, CF_LON,
     CF_COUNT
@@ -95,7 +95,7 @@ enum TimeField : int {
     // ... and the degrees call inside TVaboveground (cpp:1425)
     TF_TAN2B, TF_TANB, TF_INV2COSB,
     // Penman-Monteith operands (cpp:1220-1247)
-    TF_DE, TF_GHRRAD, TF_REM, TF_LA, TF_WFAC,
+    TF_DE, TF_GHRRAD, TF_REM, TF_LAPK, TF_MUPM, TF_INVMUPM, TF_WFAC, TF_GFAC,
     // beam normalisation (cpp:1122-1124)
     TF_RBEAM, TF_RB,
     // packed ints: sindex | windex<<5 | ksat<<8
@@ -105,9 +105,76 @@ enum TimeField : int {
 
 __device__ __forceinline__ double na_real() { return __longlong_as_double((long long)kNaRealBits); }
 
+// ---- lean fp64 elementary functions -------------------------------------------------
+// The hot loop spends most of its issue slots in exp / log / divide.  The device
+// libm versions are correctly rounded over the whole domain and pay for it (log: 98
+// VALU instructions, exp: 22 + constants, divide: 11, sqrt: 20).  The versions
+// below are valid on the domains this path produces (finite, normal operands; exp
+// also for very negative arguments, where it returns 0) and are accurate to ~1 ulp
+// (checked against numpy by tests/test_math_gpu.py through mcf_selftest_math).
+__device__ __forceinline__ double frcp(double b) {           // 1/b, b finite normal non-zero
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double fdiv(double a, double b) {  // a/b, b finite normal non-zero
+    double r = frcp(b);
+    double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+__device__ __forceinline__ double fsqrt(double x) {           // sqrt(x), x finite normal positive
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double e = fma(-g, g, x);
+    g = fma(e, h, g);
+    e = fma(-g, g, x);
+    return fma(e, h, g);
+}
+// exp(x): Cody-Waite reduction + degree-11 minimax polynomial on [-ln2/2, ln2/2].
+// No overflow/underflow branches: ldexp saturates to inf / flushes to 0 by itself.
+__device__ __forceinline__ double fexp(double x) {
+    double n = __builtin_rint(x * 0x1.71547652b82fep+0);
+    double r = fma(n, -0x1.62e42fefa39efp-1, x);
+    r = fma(n, -0x1.abc9e3b39803fp-56, r);
+    double p = fma(r, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
+    p = fma(r, p, 0x1.71dee623fde64p-19);
+    p = fma(r, p, 0x1.a01997c89e6b0p-16);
+    p = fma(r, p, 0x1.a01a014761f6ep-13);
+    p = fma(r, p, 0x1.6c16c1852b7b0p-10);
+    p = fma(r, p, 0x1.1111111122322p-7);
+    p = fma(r, p, 0x1.55555555502a1p-5);
+    p = fma(r, p, 0x1.5555555555511p-3);
+    p = fma(r, p, 0x1.000000000000bp-1);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)n);
+}
+// log(x) for finite normal x > 0: m in [sqrt(1/2), sqrt(2)), s = f/(2+f), the
+// classic 7-term series in s^2 with the hi/lo split of ln2.
+__device__ __forceinline__ double flog(double x) {
+    double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double f = m - 1.0;
+    const double s = fdiv(f, 2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                     2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
 // pow(x, y) for the positive-base uses on this path, as exp(y*log(x)); the
 // relative error (|y log x| * 2^-52) is far below the 1e-4 acceptance bar.
-__device__ __forceinline__ double powxy(double x, double y) { return exp(y * log(x)); }
+__device__ __forceinline__ double powxy(double x, double y) { return fexp(y * flog(x)); }
 __device__ __forceinline__ double sq(double x) { return x * x; }
 __device__ __forceinline__ double pow4(double x) { double x2 = x * x; return x2 * x2; }
 
@@ -115,7 +182,7 @@ __device__ __forceinline__ double pow4(double x) { double x2 = x * x; return x2 
 __device__ __forceinline__ double satvap(double tc) {
     double a = tc > 0 ? 17.27 : 21.875;
     double b = tc > 0 ? 237.3 : 265.5;
-    return 0.61078 * exp(a * tc / (tc + b));
+    return 0.61078 * fexp(fdiv(a * tc, tc + b));
 }
 // cpp:24-26 with the 0.97*sb factor every caller applies
 __device__ __forceinline__ double lw_emit(double tc) { return 0.97 * kSb * pow4(tc + 273.15); }
@@ -210,7 +277,12 @@ __device__ inline void derive_time(TimeVals& t, const SolPos& sp, int windex) {
     double tk = tc + 273.15;
     t.v[TF_GHRRAD] = (4 * 0.97 * kSb * (tk * tk * tk)) / 29.3;               // cpp:1224
     t.v[TF_REM] = lw_emit(tc);                                              // cpp:1225, 1167
-    t.v[TF_LA] = latent(tc);
+    const double la = latent(tc);
+    t.v[TF_LAPK] = la / t.v[TF_PK];                                         // m = la*(gV/pk), cpp:1233
+    t.v[TF_MUPM] = la * (43.0 / t.v[TF_PK]);                                // cpp:1245
+    t.v[TF_INVMUPM] = 1.0 / t.v[TF_MUPM];
+    // G = Gp*(dtr/dtrp)*(k*muGp)/(kp*DD) = GFAC*dtr*k/DD, cpp:1282-1289
+    t.v[TF_GFAC] = t.v[TF_GP] * t.v[TF_MUGP] / (t.v[TF_DTRP] * t.v[TF_KP]);
     t.v[TF_WFAC] = 0.018 / (8.31 * tk);                                     // cpp:1268
     double rbeam = (t.v[TF_RSW] - t.v[TF_RDIF]) / t.v[TF_CZ];               // cpp:1122
     if (rbeam > 1352.0) rbeam = 1352.0;
@@ -255,7 +327,7 @@ struct Pass1Out {
 // Penman-Monteith surface temperature, cpp:1220-1247, from pre-assembled parts.
 template <class TM>
 __device__ __forceinline__ double pm_temperature(double num, double den, double dTmx, const TM& T) {
-    double dT = num / den;
+    double dT = fdiv(num, den);
     if (dT > dTmx) dT = dTmx;
     if (dT > 80.0) dT = 80.0;
     double Ts = dT + T(TF_TC);
@@ -291,11 +363,11 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const Globals& g
         const double svfa = C(CF_SVFA), gref = C(CF_GREF);
         if (flags & FL_PAI) {
             // canopy extinction, cpp:104-132
-            double k = sqrt(C(CF_XX) + T(TF_TAN2C)) * C(CF_KDENINV);
+            double k = fsqrt(C(CF_XX) + T(TF_TAN2C)) * C(CF_KDENINV);
             if (flags & (FL_XONE | FL_XINF | FL_XZERO))
                 k = (flags & FL_XONE) ? T(TF_INV2COSC) : (flags & FL_XINF) ? 1.0 : T(TF_TANC);
             if (k > 6000.0) k = 6000.0;
-            double rsi = 1.0 / si;
+            double rsi = frcp(si);
             double kd = k * T(TF_COSC) * rsi;
             double Kc = rsi;
             if (si == 0.0) { kd = 1.0; Kc = 600.0; }
@@ -303,10 +375,10 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const Globals& g
             const double om = C(CF_OM), gma = C(CF_GMA), agm = C(CF_AGM), u1 = C(CF_U1), u2 = C(CF_U2),
                          h = C(CF_H), S1 = C(CF_S1);
             double sig = kd * kd + C(CF_GMA2) - C(CF_AGM2);
-            double ss = 0.5 * (om + C(CF_JDEL) / kd) * kd;
+            double ss = 0.5 * (om * kd + C(CF_JDEL));           // 0.5*(om + J*del/kd)*kd
             double sstr = om * kd - ss;
-            double S2 = exp(-kd * C(CF_PAIT));
-            double isig = 1.0 / sig;
+            double S2 = fexp(-kd * C(CF_PAIT));
+            double isig = frcp(sig);
             double p5 = -ss * (agm - kd) - gma * sstr;
             double p5s = p5 * isig;
             double v1 = ss - (p5 * (agm + kd)) * isig;
@@ -320,10 +392,10 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const Globals& g
             double p9 = -C(CF_INVD2) * ((p8s * C(CF_INVS1)) * (u2 + h) + v3);
             double p10 = C(CF_INVD2) * ((p8s * S1) * (u2 - h) + v3);
             // gap transmissions, cpp:1095-1100
-            double trbn = exp(Kc * C(CF_LOGCLUMP));
+            double trbn = fexp(Kc * C(CF_LOGCLUMP));
             if (trbn > 0.999) trbn = 0.999;
             if (trbn < 0.0) trbn = 0.0;
-            double trb = exp(Kc * C(CF_LOGGI));
+            double trb = fexp(Kc * C(CF_LOGGI));
             if (trb > 0.999) trb = 0.999;
             if (trb < 0.0) trb = 0.0;
             const double amx = C(CF_AMX), trdn = C(CF_TRDN), trdu = C(CF_TRDU);
@@ -333,7 +405,7 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const Globals& g
             double Rdbdn_g = (1.0 - trbn) * (p8s * S2 + p9 * S1 + p10 * C(CF_EHP));         // cpp:1106
             if (Rdbdn_g > amx) Rdbdn_g = amx;
             if (Rdbdn_g < 0.0) Rdbdn_g = 0.0;
-            double S2a = exp(-kd * C(CF_PAIAA));
+            double S2a = fexp(-kd * C(CF_PAIAA));
             const double emhpa = C(CF_EMHPA), ehpa = C(CF_EHPA);
             double Rdbup_z = (1.0 - trdu * trbn) * (p5s * S2a + p6 * emhpa + p7 * ehpa) + trdu * trbn * gref;
             if (Rdbup_z > amx) Rdbup_z = amx;
@@ -388,9 +460,9 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const Globals& g
     // --- soil surface temperature with G = 0, cpp:1262-1275 ------------------------------
     const double radabs = radGsw + radGlw;
     double matric = -C(CF_ABSPSIE) * powxy(soilm * C(CF_INVSMAX), -C(CF_SOILB));
-    double surfwet = exp(matric * T(TF_WFAC));
+    double surfwet = fexp(matric * T(TF_WFAC));
     if (surfwet > 1.0) surfwet = 1.0;
-    const double m = T(TF_LA) * (gHa / T(TF_PK));
+    const double m = T(TF_LAPK) * gHa;
     const double num0 = radabs - T(TF_REM) - m * (T(TF_ES) - T(TF_EA)) * surfwet;
     const double den = 29.3 * (gHa + T(TF_GHRRAD)) + m * T(TF_DE);
     cy.num0 = num0;
@@ -406,7 +478,7 @@ __device__ __forceinline__ double stomcond(double Rswabs, double gs2, const CL& 
     if (Rswabs <= 0.0) return 0.0;
     const double rsmx = C(CF_RSMX);
     if (Rswabs > rsmx) Rswabs = rsmx;
-    double gs = C(CF_GSMAX) * exp2(-(rsmx - Rswabs) * C(CF_INV02RSMX));
+    double gs = C(CF_GSMAX) * fexp(-(rsmx - Rswabs) * C(CF_INV02RSMX) * 0.693147180559945309417);
     if (gs > gs2) gs = gs2;
     return gs;
 }
@@ -418,15 +490,16 @@ __device__ __forceinline__ double stom_gs2(double theta, const CL& C) {
     if (Se > 1.0) Se = 1.0;
     double psiw = -C(CF_ABSPSIE) * powxy(Se, -C(CF_SOILB)) * 0.01;   // cpp:382-389
     if (psiw < C(CF_PSIW0)) psiw = C(CF_PSIW0);
-    double mu = 1.0 - (exp(-C(CF_KK) * psiw) - 1.0) * C(CF_MUDENINV);
+    double mu = 1.0 - (fexp(-C(CF_KK) * psiw) - 1.0) * C(CF_MUDENINV);
     return mu * C(CF_GSMAX);
 }
 
 // cpp:1316-1331 mincondCpp
 __device__ __forceinline__ double mincond_from_hf(double Hf, double Rnet, double invleafd) {
     double H = Hf * Rnet;
-    double gmin = 0.0463 * powxy(fabs(H) * invleafd, 0.2);
-    // pow(0, 0.2) = 0 -> exp(0.2*log(0)) = exp(-inf) = 0: same limit
+    double arg = fabs(H) * invleafd;
+    if (arg < 1e-300) arg = 1e-300;      // pow(0, 0.2) = 0 and tiny values end in the 0.05 floor alike
+    double gmin = 0.0463 * powxy(arg, 0.2);
     if (gmin < 0.05) gmin = 0.05;
     return gmin;
 }
@@ -444,19 +517,17 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
                                       const Carry& cy, double dtr, double Rmx, bool above_ground,
                                       Pass2Out& o) {
     const double soilm = cy.soilm;
-    const double tc = T(TF_TC), ea = T(TF_EA), pk = T(TF_PK);
+    const double tc = T(TF_TC), ea = T(TF_EA);
     // --- soil conductivity / damping depth, cpp:1249-1260 ---------------------------------
     const double rho = C(CF_RHO);
     double cs = C(CF_CSA) + 4180.0 * soilm;
     double ph = (rho * (1.0 - soilm) + soilm) * 1000.0;
     double c2 = 1.06 * rho * soilm;
-    double ksoil = C(CF_C1) + c2 * soilm - C(CF_C1MC4) * exp(-pow4(C(CF_C3) * soilm));
-    double kap = ksoil / (cs * ph);
-    double DD = sqrt(2.0 * kap / kOmdy);
+    double ksoil = C(CF_C1) + c2 * soilm - C(CF_C1MC4) * fexp(-pow4(C(CF_C3) * soilm));
+    double kap = fdiv(ksoil, cs * ph);
+    double DD = fsqrt(kap * (2.0 / kOmdy));
     // --- ground heat flux and ground temperature, cpp:1277-1296 ------------------------------
-    double dtR = dtr / T(TF_DTRP);
-    double Gmu = dtR * (ksoil * T(TF_MUGP)) / (T(TF_KP) * DD);
-    double G = T(TF_GP) * Gmu;
+    double G = fdiv(T(TF_GFAC) * dtr * ksoil, DD);
     if (G > 0.6 * Rmx) G = 0.6 * Rmx;
     if (G < -0.6 * Rmx) G = -0.6 * Rmx;
     const double Tg = pm_temperature(cy.num0 - G, cy.den, dTmx, T);
@@ -471,8 +542,8 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
     const double esTg = satvap(Tg);
     double eT = esTg - ea;
     if (eT < 0.001) eT = 0.001;
-    double plf = 0.8753 - 1.7126 * log(eT);
-    double gwet = 1.0 / (1.0 + exp(-plf));
+    double plf = 0.8753 - 1.7126 * flog(eT);
+    double gwet = frcp(1.0 + fexp(-plf));
     const double surfwet = (soilm - C(CF_SMIN)) * C(CF_INVRGE);
     if (surfwet > gwet) gwet = surfwet;
     // canopy conductance, cpp:1425-1428 + 460-477
@@ -487,11 +558,11 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
             kb = C(CF_KSAT);
             P_sun = C(CF_PSUNSAT);
         } else {
-            kb = sqrt(C(CF_XX) + T(TF_TAN2B)) * C(CF_KDENINV);
+            kb = fsqrt(C(CF_XX) + T(TF_TAN2B)) * C(CF_KDENINV);
             if (flags & (FL_XONE | FL_XINF | FL_XZERO))
                 kb = (flags & FL_XONE) ? T(TF_INV2COSB) : (flags & FL_XINF) ? 1.0 : T(TF_TANB);
             if (kb > 6000.0) kb = 6000.0;
-            P_sun = (1.0 - exp(-kb * C(CF_PAI))) / kb;
+            P_sun = fdiv(1.0 - fexp(-kb * C(CF_PAI)), kb);
         }
         double P_shade = C(CF_PAI) - P_sun;
         double Rshade_abs = rdif * C(CF_SHADEFAC);
@@ -506,11 +577,11 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
         gS = gs_sun * P_sun + gs_shade * P_shade;
     }
     double gV = 0.0;
-    if (gS > 0.0) gV = 1.0 / (1.0 / gHa + 1 / gS);
+    if (gS > 0.0) gV = fdiv(gHa * gS, gHa + gS);           // 1/(1/gHa + 1/gS)
     // canopy temperature, cpp:1430-1432 (Penman-Monteith with the linear surface wetness)
-    const double la = T(TF_LA), es = T(TF_ES), De = T(TF_DE), rem = T(TF_REM), ghr = T(TF_GHRRAD);
+    const double lapk = T(TF_LAPK), es = T(TF_ES), De = T(TF_DE), rem = T(TF_REM), ghr = T(TF_GHRRAD);
     const double Rabs = cy.radCsw + 0.97 * C(CF_SVFA) * rlw;
-    const double mC = la * (gV / pk);
+    const double mC = lapk * gV;
     const double Tcan = pm_temperature(Rabs - rem - mC * (es - ea) * surfwet - G,
                                        29.3 * (gHa + ghr) + mC * De, dTmx, T);
     const double esTcan = satvap(Tcan);
@@ -534,7 +605,7 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
         const double lwdn = ema * rlw + (1 - ema) * lwcan;
         const double lwabs = 0.97 * 0.5 * (lwup + lwdn);
         const double leafabs = C(CF_HOM) * cy.X + lwabs;     // radLsw + lwabs
-        double gh = 0.135 * sqrt(uz * invleafd) * 1.4;
+        double gh = 0.135 * fsqrt(uz * invleafd) * 1.4;
         const double RnetL = leafabs - lwcan;                // cpp:1319 with tc = Tcan
         double gmin = mincond_from_hf(g.hf0, RnetL, invleafd);
         if (gh < gmin) gh = gmin;
@@ -547,16 +618,15 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
                 if (!have_gs2) gs2 = stom_gs2(soilm, C);
                 gs = stomcond(PARabs, gs2, C);
             }
-            double rs = 500.0;                               // cpp:1321-1325
-            if (gs > 0.0) rs = 1 / gs;
-            if (rs > 500.0) rs = 500.0;
-            double Hlf = 1.09767 * powxy(rs, 0.2672778);
-            double Hf = -1.0 / (1.0 + exp(2.0 - Hlf));
+            // rs = min(1/gs, 500) (500 when gs <= 0), Hlf = 1.09767*rs^0.2672778, cpp:1321-1324
+            double lrs = (gs > 0.002) ? -flog(gs) : 6.214608098422191;   // log(500)
+            double Hlf = 1.09767 * fexp(0.2672778 * lrs);
+            double Hf = -frcp(1.0 + fexp(2.0 - Hlf));
             gmin = mincond_from_hf(Hf, RnetL, invleafd);
             if (gh < gmin) gh = gmin;
-            if (gs > 0.0) gVl = 1 / (1 / gh + 1 / gs);
+            if (gs > 0.0) gVl = fdiv(gh * gs, gh + gs);
         }
-        const double mL = la * (gVl / pk);
+        const double mL = lapk * gVl;
         const double tleaf = pm_temperature(leafabs - rem - mL * (es - ea) * surfwet - 0.0,
                                             29.3 * (gh + ghr) + mL * De, dTmx, T);
         const double esTl = satvap(tleaf);
@@ -568,48 +638,49 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
         // ---- canopy-top source, cpp:1449 ---------------------------------------------------------
         const double HC = 29.3 * gHa * (Tcan - tc);
         const double LC = mC * (esTcan - ea) * surfwet;
-        const double mu = la * (43.0 / pk);                               // cpp:1245
+        const double mu = T(TF_MUPM);                                     // cpp:1245
         double w2 = C(CF_OML2);
         bool prof2 = (flags & FL_ABOVE2) != 0;
         const double Th = prof2 ? tc + (Tcan - tc) * w2 : Tcan;
         const double eh = prof2 ? ea + (esTcan - ea) * surfwet * w2 : ea + (esTcan - ea) * surfwet;
         // ---- Lagrangian near/far field, cpp:1365-1409 ---------------------------------------------
         const double hgt = C(CF_HGT), z = g.reqhgt2;
-        const double muR = 1.0 / (C(CF_A2H) * uf);          // uf/(a2*h) / uf^2
+        const double muR = frcp(C(CF_A2H) * uf);          // uf/(a2*h) / uf^2
         double Rc = C(CF_INTHH) * muR;
         if (Rc < 0.001) Rc = 0.001;
         double Rz = C(CF_INTHZ) * muR;
         if (Rz < 0.001) Rz = 0.001;
-        const double Kc = hgt / Rc;
-        const double Kg = (1.0 / Rz) / z;
-        const double Kh = (1.0 / (Rc - Rz)) * C(CF_INVHMZ);
-        const double invK = 1.0 / (Kg + Kh + Kc);
+        const double Kc = fdiv(hgt, Rc);
+        const double rKc = Rc * C(CF_INVHGT);                // 1/Kc
+        const double Kg = frcp(Rz * z);
+        const double Kh = fdiv(C(CF_INVHMZ), Rc - Rz);
+        const double invK = frcp(Kg + Kh + Kc);
         const double omem = C(CF_OMEMPAI), nf = C(CF_NEARFAC), lden = C(CF_LEAFDEN);
         const double cp43 = 29.3 * 43.0;
         // temperature
         {
             double Flux = HC * omem, SH = Th * cp43, SG = Tg * cp43;
             double mxnear = fabs(tleaf - Th) * cp43;
-            double SC = SH + Flux / Kc;
+            double SC = SH + Flux * rKc;
             double farg = (Kg * SG + Kh * SH + Kc * SC) * invK;
             double near = nf * (HL * lden);
             if (fabs(near) > mxnear) near = near > 0.0 ? mxnear : -mxnear;
             if (isnan(near)) near = 0;
-            o.Tz = (near + farg) / cp43;
+            o.Tz = (near + farg) * (1.0 / cp43);
         }
         // vapour pressure
         {
             double Flux = LC * omem, SH = eh * mu, SG = esTg * gwet * mu;
             double mxnear = fabs(esTl - eh) * mu;
-            double SC = SH + Flux / Kc;
+            double SC = SH + Flux * rKc;
             double farg = (Kg * SG + Kh * SH + Kc * SC) * invK;
             double near = nf * (LL * lden);
             if (fabs(near) > mxnear) near = near > 0.0 ? mxnear : -mxnear;
             if (isnan(near)) near = 0;
-            ez = (near + farg) / mu;
+            ez = (near + farg) * T(TF_INVMUPM);
         }
     }
-    double rh = (ez / satvap(o.Tz)) * 100.0;
+    double rh = fdiv(ez, satvap(o.Tz)) * 100.0;
     if (rh > 100.0) rh = 100.0;
     o.rh = rh;
     // clamp Tz to the source temperatures +-2, cpp:1467-1470

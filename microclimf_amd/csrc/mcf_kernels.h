@@ -53,13 +53,17 @@ struct SolveArgs {
     const double* wsa;    // [8][N]
     const double* tt;     // vector forcing: [ndays][TF_COUNT][24]
     // array forcing
-    const double* af[15];   // forcing slabs [N][steps in buffer], TF_TC .. TF_DTRP order
+    const double* af_base;  // forcing slabs [15][N][steps in buffer], TF_TC .. TF_DTRP order
+    int64_t af_stride;      // elements between consecutive forcing slabs
     const double* dt;       // [tsteps][4]
     const int32_t* windex;  // [tsteps]
     const double* mxtc;     // [N]
     int64_t force_step0;    // first step of this launch inside the forcing slabs
-    // outputs: slot base pointers [N][slot steps] or null
-    double* out[10];
+    // outputs: enabled variables are consecutive slabs [N][slot steps] from out_base;
+    // out_sel packs, 4 bits per variable, the slab index of variable v (15 = not requested)
+    double* out_base;
+    int64_t out_stride;
+    uint64_t out_sel;
     int64_t slot_step0;     // first step of this launch inside the slot
     // reqhgt < 0
     double* tgser;          // [N][tsteps]
@@ -88,6 +92,7 @@ void launch_date_setup(const DateSetupArgs& a, hipStream_t s);
 void launch_mxtc(const double* tc, int64_t N, int nsteps, double* mx, hipStream_t s);
 void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, hipStream_t s);
 void launch_belowground(const BelowArgs& a, hipStream_t s);
+void launch_selftest_math(int kind, const double* x, const double* y, double* out, int64_t n, hipStream_t s);
 
 int cell_field_count();
 int time_field_count();

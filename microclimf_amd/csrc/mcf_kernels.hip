@@ -17,6 +17,9 @@
 #ifndef MCF_WAVES_PER_EU
 #define MCF_WAVES_PER_EU 3
 #endif
+#ifndef MCF_DAYPRIO
+#define MCF_DAYPRIO 0
+#endif
 
 namespace mcf {
 
@@ -170,7 +173,9 @@ __global__ __launch_bounds__(256) void k_cell_setup(CellSetupArgs a) {
     put(CF_PAIT, pait); put(CF_OM, om); put(CF_JDEL, J * del); put(CF_GMA, gma); put(CF_GMA2, gma * gma);
     put(CF_AGM, aa + gma); put(CF_AGM2, (aa + gma) * (aa + gma)); put(CF_U1, u1); put(CF_U2, u2);
     put(CF_H, h); put(CF_S1, S1); put(CF_INVS1, 1.0 / S1); put(CF_INVD1, 1.0 / D1); put(CF_INVD2, 1.0 / D2);
-    put(CF_GREF, gref); put(CF_GMAGREF, gma * gref); put(CF_LOGCLUMP, log(clump)); put(CF_LOGGI, log(gi));
+    put(CF_GREF, gref); put(CF_GMAGREF, gma * gref); // pow(clump, Kc) is evaluated as exp(Kc*log(clump)); log(0) = -inf is stored as -1e5 so that
+    // the product stays finite (exp still underflows to exactly 0, as pow(0, Kc) does)
+    put(CF_LOGCLUMP, fmax(log(clump), -1e5)); put(CF_LOGGI, fmax(log(gi), -1e5));
     put(CF_TRDN, trdn); put(CF_TRDU, trdu); put(CF_AMX, amx); put(CF_EHP, ehp); put(CF_PAIAA, paiaa);
     put(CF_EHPA, ehpa); put(CF_EMHPA, emhpa); put(CF_ALBD, albd); put(CF_RDDNG, Rddn_g);
     put(CF_RDDNZ, Rddn_z); put(CF_RDUPZ, Rdup_z);
@@ -271,6 +276,7 @@ __global__ __launch_bounds__(256) void k_cell_setup(CellSetupArgs a) {
         put(CF_INTHH, 4.293251 * hgt);
         put(CF_INTHZ, rh_integral(hgt, z));
         put(CF_HGT, hgt);
+        put(CF_INVHGT, 1.0 / hgt);
         put(CF_INVHMZ, 1.0 / (hgt - z));
         put(CF_NEARFAC, 3.047519 + 0.128642 * log(pai));
         put(CF_LEAFDEN, a.leafden[c]);
@@ -375,18 +381,26 @@ __global__ __launch_bounds__(CPB * 24, MCF_WAVES_PER_EU) void k_solve(SolveArgs 
         const int dabs = a.day0 + dl;
         const int64_t kl = (int64_t)dl * 24 + hr;            // step within the slot
         const int64_t oidx = c + N * (a.slot_step0 + kl);
-        if (!AF) {
-            // prefetch the next day's table rows into the third buffer
-            if (dl + 1 < a.ndays) {
-                const double* src = a.tt + (int64_t)(dabs + 1) * TF_COUNT * 24;
-                double* dst = s_time + ((dl + 1) % 3) * (TF_COUNT * 24);
-                for (int q = tid; q < TF_COUNT * 24; q += NT) dst[q] = src[q];
+        auto put = [&](int v, double val) {
+            unsigned sel = (unsigned)(a.out_sel >> (4 * v)) & 15u;
+            if (sel != 15u) a.out_base[(int64_t)sel * a.out_stride + oidx] = val;
+        };
+        // issue the loads of the next day's table rows now; they land in LDS after pass 1
+        constexpr int TPER = (TF_COUNT * 24 + NT - 1) / NT;
+        double pre[TPER];
+        const bool stage = !AF && (dl + 1 < a.ndays);
+        if (stage) {
+            const double* src = a.tt + (int64_t)(dabs + 1) * TF_COUNT * 24;
+#pragma unroll
+            for (int i = 0; i < TPER; ++i) {
+                int q = tid + i * NT;
+                pre[i] = q < TF_COUNT * 24 ? src[q] : 0.0;
             }
         }
         TimeVals tv;
         if (AF && valid) {
             const int64_t fidx = c + N * (a.force_step0 + kl);
-            for (int f = 0; f < 15; ++f) tv.v[f] = a.af[f][fidx];
+            for (int f = 0; f < 15; ++f) tv.v[f] = a.af_base[(int64_t)f * a.af_stride + fidx];
             const int64_t kabs = (int64_t)dabs * 24 + hr;
             SolDate sd{a.dt[4 * kabs + 0], a.dt[4 * kabs + 1], a.dt[4 * kabs + 2]};
             SolPos sp = sol_site(sd, a.dt[4 * kabs + 3], C(CF_SINLAT), C(CF_COSLAT), C(CF_LON));
@@ -395,6 +409,10 @@ __global__ __launch_bounds__(CPB * 24, MCF_WAVES_PER_EU) void k_solve(SolveArgs 
         TimeLds TL{s_time + (AF ? 0 : (dl % 3) * (TF_COUNT * 24)) + hr};
         TimeReg TR{&tv};
 
+#if MCF_DAYPRIO
+        // daytime waves carry the short-wave block and are the critical path to the barrier
+        if (!AF && __builtin_amdgcn_readfirstlane((int)(TL(TF_RSW) > 0.0))) __builtin_amdgcn_s_setprio(1);
+#endif
         Carry cy;
         Pass1Out p1;
         double* red_t = &s_red[dl & 1][0][hr * CPB + cl];
@@ -404,18 +422,29 @@ __global__ __launch_bounds__(CPB * 24, MCF_WAVES_PER_EU) void k_solve(SolveArgs 
             else pass1(C, TL, g, flags, dTmx, cy, p1);
             *red_t = p1.Tg0;
             *red_r = p1.absRnet;
-            if (a.out[3]) a.out[3][oidx] = cy.soilm;     // soilm      cpp:2227
-            if (a.out[4]) a.out[4][oidx] = p1.uz;        // windspeed  cpp:2253
-            if (a.out[5]) a.out[5][oidx] = cy.Rbdown;    // Rdirdown   cpp:2242
-            if (a.out[6]) a.out[6][oidx] = cy.Rddown;    // Rdifdown   cpp:2243
-            if (a.out[8]) a.out[8][oidx] = p1.Rdup;      // Rswup      cpp:2244
+            put(3, cy.soilm);     // soilm      cpp:2227
+            put(4, p1.uz);        // windspeed  cpp:2253
+            put(5, cy.Rbdown);    // Rdirdown   cpp:2242
+            put(6, cy.Rddown);    // Rdifdown   cpp:2243
+            put(8, p1.Rdup);      // Rswup      cpp:2244
         } else if (in_grid) {
-            if (a.out[3]) a.out[3][oidx] = NA;
-            if (a.out[4]) a.out[4][oidx] = NA;
-            if (a.out[5]) a.out[5][oidx] = NA;
-            if (a.out[6]) a.out[6][oidx] = NA;
-            if (a.out[8]) a.out[8][oidx] = NA;
+            put(3, NA);
+            put(4, NA);
+            put(5, NA);
+            put(6, NA);
+            put(8, NA);
         }
+        if (stage) {
+            double* dst = s_time + ((dl + 1) % 3) * (TF_COUNT * 24);
+#pragma unroll
+            for (int i = 0; i < TPER; ++i) {
+                int q = tid + i * NT;
+                if (q < TF_COUNT * 24) dst[q] = pre[i];
+            }
+        }
+#if MCF_DAYPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __syncthreads();
         if (valid) {
             // day reductions in hour order with the reference's comparisons, cpp:2196-2198, 2256-2263
@@ -438,27 +467,27 @@ __global__ __launch_bounds__(CPB * 24, MCF_WAVES_PER_EU) void k_solve(SolveArgs 
                 s_dd[hr * CPB + cl] = p2.DD;
             } else {
                 const bool pos = g.reqhgt > 0.0;
-                if (a.out[0]) a.out[0][oidx] = pos ? p2.Tz : p2.Tg;          // cpp:2292-2297
-                if (a.out[1]) a.out[1][oidx] = pos ? p2.tleaf : NA;          // cpp:2300-2303
-                if (a.out[2]) a.out[2][oidx] = pos ? p2.rh : NA;
-                if (a.out[7]) a.out[7][oidx] = p2.lwdn;                      // cpp:2298
-                if (a.out[9]) a.out[9][oidx] = p2.lwup;                      // cpp:2299
+                put(0, pos ? p2.Tz : p2.Tg);          // cpp:2292-2297
+                put(1, pos ? p2.tleaf : NA);          // cpp:2300-2303
+                put(2, pos ? p2.rh : NA);
+                put(7, p2.lwdn);                      // cpp:2298
+                put(9, p2.lwup);                      // cpp:2299
             }
         } else if (in_grid) {
             if (BG) a.tgser[c + N * ((int64_t)dabs * 24 + hr)] = NA;
-            if (a.out[0] && !BG) a.out[0][oidx] = NA;
-            if (a.out[1]) a.out[1][oidx] = NA;
-            if (a.out[2]) a.out[2][oidx] = NA;
-            if (a.out[7]) a.out[7][oidx] = NA;
-            if (a.out[9]) a.out[9][oidx] = NA;
+            if (!BG) put(0, NA);
+            put(1, NA);
+            put(2, NA);
+            put(7, NA);
+            put(9, NA);
         }
         if (BG) {
             // reqhgt < 0 never writes tleaf/relhum/Rlw* (cpp:2272): they stay NA
             if (valid) {
-                if (a.out[1]) a.out[1][oidx] = NA;
-                if (a.out[2]) a.out[2][oidx] = NA;
-                if (a.out[7]) a.out[7][oidx] = NA;
-                if (a.out[9]) a.out[9][oidx] = NA;
+                put(1, NA);
+                put(2, NA);
+                put(7, NA);
+                put(9, NA);
             }
             __syncthreads();
             if (valid && hr == 0) {
@@ -574,6 +603,29 @@ __global__ __launch_bounds__(64) void k_belowground(BelowArgs a) {
     }
     if (blend_year && !(nb < a.hiy))
         for (int i = nd * 24; i < m; ++i) z[N * i] = a.mat;
+}
+
+// ------------------------------------------------------------------------------------
+// Diagnostics: evaluates the lean elementary functions of mcf_device.hpp elementwise.
+__global__ void k_selftest_math(int kind, const double* __restrict__ x, const double* __restrict__ y,
+                                double* __restrict__ out, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a = x[i], b = y ? y[i] : 0.0, r;
+    switch (kind) {
+        case 0: r = fexp(a); break;
+        case 1: r = flog(a); break;
+        case 2: r = fdiv(a, b); break;
+        case 3: r = fsqrt(a); break;
+        case 4: r = frcp(a); break;
+        case 5: r = satvap(a); break;
+        default: r = powxy(a, b); break;
+    }
+    out[i] = r;
+}
+void launch_selftest_math(int kind, const double* x, const double* y, double* out, int64_t n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_selftest_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, kind, x, y, out, n);
 }
 
 // ------------------------------------------------------------------------------------

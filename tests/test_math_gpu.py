@@ -1,0 +1,65 @@
+"""Accuracy of the lean fp64 elementary functions used in the hot loop
+(mcf_device.hpp) against numpy, on and beyond the domains the solver produces."""
+import numpy as np
+import pytest
+
+from microclimf_amd import _abi
+
+pytestmark = pytest.mark.gpu
+
+
+def run(kind, x, y=None):
+    lib = _abi.load()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    p = lambda a: None if a is None else a.ctypes.data_as(_abi.c_double_p)
+    if y is not None:
+        y = np.ascontiguousarray(y, dtype=np.float64)
+    _abi.check(lib.mcf_selftest_math(kind, p(x), p(y), p(out), x.size, 0))
+    return out
+
+
+def relerr(got, want):
+    return np.max(np.abs(got - want) / np.abs(want))
+
+
+def test_exp():
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-700, 700, 200000), rng.uniform(-2, 2, 200000),
+                        np.array([0.0, -0.0, 1e-300, -1e-300, 709.0, -745.0])])
+    assert relerr(run(0, x), np.exp(x)) < 4e-16
+    # very negative arguments (kd*pait with the sun grazing a slope) flush to exactly 0
+    big = np.array([-800.0, -1e5, -6e7, -1e15, -1e22])
+    assert (run(0, big) == 0.0).all()
+    assert np.isnan(run(0, np.array([np.nan]))).all()
+
+
+def test_log():
+    rng = np.random.default_rng(2)
+    x = np.concatenate([np.exp(rng.uniform(-700, 700, 300000)), rng.uniform(0.5, 2.0, 300000),
+                        np.array([1.0, 1e-300, 1e300, 0.001, 0.70710678118654746, 0.70710678118654757])])
+    got, want = run(1, x), np.log(x)
+    err = np.abs(got - want)
+    assert np.max(err / np.maximum(np.abs(want), 1e-3)) < 1e-15
+    assert np.max(err[np.abs(want) < 1e-3]) < 1e-18 if (np.abs(want) < 1e-3).any() else True
+    assert np.isnan(run(1, np.array([np.nan]))).all()
+
+
+def test_div_rcp_sqrt():
+    rng = np.random.default_rng(3)
+    a = rng.normal(size=300000) * np.exp(rng.uniform(-50, 50, 300000))
+    b = np.exp(rng.uniform(-200, 200, 300000)) * rng.choice([-1.0, 1.0], 300000)
+    assert relerr(run(2, a, b), a / b) < 3e-16
+    assert relerr(run(4, b), 1.0 / b) < 3e-16
+    x = np.exp(rng.uniform(-600, 600, 300000))
+    assert relerr(run(3, x), np.sqrt(x)) < 3e-16
+
+
+def test_satvap_and_pow():
+    t = np.linspace(-60, 60, 100001)
+    want = np.where(t > 0, 0.61078 * np.exp(17.27 * t / (t + 237.3)), 0.61078 * np.exp(21.875 * t / (t + 265.5)))
+    assert relerr(run(5, t), want) < 2e-15
+    rng = np.random.default_rng(4)
+    x = rng.uniform(1e-4, 1.0, 200000)
+    y = rng.uniform(-12, 1, 200000)
+    assert relerr(run(6, x, y), x ** y) < 3e-14
