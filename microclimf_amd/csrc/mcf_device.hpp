@@ -134,43 +134,78 @@ __device__ __forceinline__ double fsqrt(double x) {           // sqrt(x), x fini
     e = fma(-g, g, x);
     return fma(e, h, g);
 }
+// A 64-bit literal used as a VALU operand has to live in a register pair.  Left alone,
+// hipcc copies every polynomial coefficient into a VGPR pair (v_mov_b64) in front of each
+// v_fmac: one extra VALU issue per term.  The two functions below are therefore written as
+// single asm blocks: coefficients are pinned to SGPR pairs ("s" constraint: s_mov_b32 on the
+// otherwise idle scalar unit) and consumed by the VOP3 forms; nothing inside needs wait
+// states (plain dependent VALU ops).
+//
 // exp(x): Cody-Waite reduction + degree-11 minimax polynomial on [-ln2/2, ln2/2].
-// No overflow/underflow branches: ldexp saturates to inf / flushes to 0 by itself.
+// No overflow/underflow branches: v_cvt_i32_f64 saturates and v_ldexp_f64 saturates to
+// inf / flushes to 0 by itself, so very negative arguments return exactly 0.
 __device__ __forceinline__ double fexp(double x) {
-    double n = __builtin_rint(x * 0x1.71547652b82fep+0);
-    double r = fma(n, -0x1.62e42fefa39efp-1, x);
-    r = fma(n, -0x1.abc9e3b39803fp-56, r);
-    double p = fma(r, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
-    p = fma(r, p, 0x1.71dee623fde64p-19);
-    p = fma(r, p, 0x1.a01997c89e6b0p-16);
-    p = fma(r, p, 0x1.a01a014761f6ep-13);
-    p = fma(r, p, 0x1.6c16c1852b7b0p-10);
-    p = fma(r, p, 0x1.1111111122322p-7);
-    p = fma(r, p, 0x1.55555555502a1p-5);
-    p = fma(r, p, 0x1.5555555555511p-3);
-    p = fma(r, p, 0x1.000000000000bp-1);
-    p = fma(r, p, 1.0);
-    p = fma(r, p, 1.0);
-    return __builtin_amdgcn_ldexp(p, (int)n);
+    double n, r, p, out;
+    int t;
+    const double c11 = 0x1.ade156a5dcb37p-26;
+    asm("v_mul_f64 %0, %5, %6\n\t"
+        "v_rndne_f64 %0, %0\n\t"
+        "v_fma_f64 %1, %0, %7, %5\n\t"
+        "v_fma_f64 %1, %0, %8, %1\n\t"
+        "v_fma_f64 %2, %1, %9, %10\n\t"
+        "v_fma_f64 %2, %1, %2, %11\n\t"
+        "v_fma_f64 %2, %1, %2, %12\n\t"
+        "v_fma_f64 %2, %1, %2, %13\n\t"
+        "v_fma_f64 %2, %1, %2, %14\n\t"
+        "v_fma_f64 %2, %1, %2, %15\n\t"
+        "v_fma_f64 %2, %1, %2, %16\n\t"
+        "v_fma_f64 %2, %1, %2, %17\n\t"
+        "v_fma_f64 %2, %1, %2, %18\n\t"
+        "v_fma_f64 %2, %1, %2, 1.0\n\t"
+        "v_fma_f64 %2, %1, %2, 1.0\n\t"
+        "v_cvt_i32_f64 %3, %0\n\t"
+        "v_ldexp_f64 %4, %2, %3"
+        : "=&v"(n), "=&v"(r), "=&v"(p), "=&v"(t), "=v"(out)
+        : "v"(x), "s"(0x1.71547652b82fep+0), "s"(-0x1.62e42fefa39efp-1), "s"(-0x1.abc9e3b39803fp-56),
+          "v"(c11), "s"(0x1.28af3fca7ab0cp-22), "s"(0x1.71dee623fde64p-19), "s"(0x1.a01997c89e6b0p-16),
+          "s"(0x1.a01a014761f6ep-13), "s"(0x1.6c16c1852b7b0p-10), "s"(0x1.1111111122322p-7),
+          "s"(0x1.55555555502a1p-5), "s"(0x1.5555555555511p-3), "s"(0x1.000000000000bp-1));
+    return out;
 }
 // log(x) for finite normal x > 0: m in [sqrt(1/2), sqrt(2)), s = f/(2+f), the
 // classic 7-term series in s^2 with the hi/lo split of ln2.
 __device__ __forceinline__ double flog(double x) {
     double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
     int e = __builtin_amdgcn_frexp_exp(x);
-    const bool lo = m < 0.70710678118654752440;
-    m = lo ? m + m : m;
-    e = lo ? e - 1 : e;
+    const int lo = m < 0.70710678118654752440 ? 1 : 0;
+    m = __builtin_amdgcn_ldexp(m, lo);
+    e -= lo;
     const double f = m - 1.0;
     const double s = fdiv(f, 2.0 + f);
-    const double z = s * s, w = z * z;
-    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
-    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
-                                     2.857142874366239149e-01), 6.666666666666735130e-01);
-    const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
     const double dk = (double)e;
-    return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+    const double lg6 = 1.531383769920937332e-01, lg7 = 1.479819860511658591e-01;
+    double z, w, t1, t2, out;
+    asm("v_mul_f64 %0, %5, %5\n\t"              // z = s*s
+        "v_mul_f64 %1, %0, %0\n\t"              // w = z*z
+        "v_fma_f64 %2, %1, %9, %10\n\t"         // t1 = w*Lg6 + Lg4
+        "v_fma_f64 %3, %1, %11, %12\n\t"        // t2 = w*Lg7 + Lg5
+        "v_fma_f64 %2, %1, %2, %13\n\t"         // t1 = w*t1 + Lg2
+        "v_fma_f64 %3, %1, %3, %14\n\t"         // t2 = w*t2 + Lg3
+        "v_mul_f64 %2, %1, %2\n\t"              // t1 = w*t1
+        "v_fma_f64 %3, %1, %3, %15\n\t"         // t2 = w*t2 + Lg1
+        "v_fma_f64 %2, %0, %3, %2\n\t"          // R  = z*t2 + t1
+        "v_add_f64 %2, %6, %2\n\t"              // hfsq + R
+        "v_mul_f64 %2, %5, %2\n\t"              // s*(hfsq + R)
+        "v_fma_f64 %2, %8, %16, %2\n\t"         // + dk*ln2_lo
+        "v_add_f64 %2, %6, -%2\n\t"             // hfsq - (...)
+        "v_add_f64 %2, %2, -%7\n\t"             // (...) - f
+        "v_fma_f64 %4, %8, %17, -%2"              // dk*ln2_hi - (...)
+        : "=&v"(z), "=&v"(w), "=&v"(t1), "=&v"(t2), "=v"(out)
+        : "v"(s), "v"(hfsq), "v"(f), "v"(dk), "v"(lg6), "s"(2.222219843214978396e-01), "v"(lg7),
+          "s"(1.818357216161805012e-01), "s"(3.999999999940941908e-01), "s"(2.857142874366239149e-01),
+          "s"(6.666666666666735130e-01), "s"(1.90821492927058770002e-10), "s"(6.93147180369123816490e-01));
+    return out;
 }
 // pow(x, y) for the positive-base uses on this path, as exp(y*log(x)); the
 // relative error (|y log x| * 2^-52) is far below the 1e-4 acceptance bar.

@@ -445,7 +445,9 @@ __global__ __launch_bounds__(CPB * 24, MCF_WAVES_PER_EU) void k_solve(SolveArgs 
 #if MCF_DAYPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
+#if !MCF_EXPERIMENT_NOBARRIER
         __syncthreads();
+#endif
         if (valid) {
             // day reductions in hour order with the reference's comparisons, cpp:2196-2198, 2256-2263
             double Rmx = -999.9, tmx = -999.0, tmn = 999.0;
