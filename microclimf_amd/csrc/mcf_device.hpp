@@ -359,14 +359,23 @@ struct Pass1Out {
     double uz, Rdup;       // outputs only
 };
 
+// Pins values in registers at this point of the program: the compiler has to have
+// finished the LDS loads that produce them.  Loading a section's operands in one batch
+// and pinning them exposes ONE LDS latency per section instead of one per operand (hipcc
+// otherwise places each ds_read right in front of its first use and waits on it at once).
+__device__ __forceinline__ void pin1(double& a) { asm volatile("" : "+v"(a)); }
+template <class... A>
+__device__ __forceinline__ void pin(A&... a) {
+    (pin1(a), ...);
+}
+
 // Penman-Monteith surface temperature, cpp:1220-1247, from pre-assembled parts.
-template <class TM>
-__device__ __forceinline__ double pm_temperature(double num, double den, double dTmx, const TM& T) {
+__device__ __forceinline__ double pm_temperature(double num, double den, double dTmx, double tc, double tdew) {
     double dT = fdiv(num, den);
     if (dT > dTmx) dT = dTmx;
     if (dT > 80.0) dT = 80.0;
-    double Ts = dT + T(TF_TC);
-    if (Ts < T(TF_TDEW)) Ts = T(TF_TDEW);
+    double Ts = dT + tc;
+    if (Ts < tdew) Ts = tdew;
     return Ts;
 }
 
@@ -377,91 +386,109 @@ __device__ __forceinline__ double pm_temperature(double num, double den, double 
 template <class CL, class TM>
 __device__ __forceinline__ void pass1(const CL& C, const TM& T, const Globals& g, int flags, double dTmx,
                                       Carry& cy, Pass1Out& o) {
-    const int idx = (int)T(TF_IDX);
-    const double rsw = T(TF_RSW), rdif = T(TF_RDIF);
+    // ---- section A operands: soil moisture spread + branch selectors
+    double t_idx = T(TF_IDX), rsw = T(TF_RSW), rdif = T(TF_RDIF), t_soilmp = T(TF_SOILMP);
+    double c_smin = C(CF_SMIN), c_invrge = C(CF_INVRGE), c_eta = C(CF_ETA), c_rge = C(CF_RGE);
+    pin(t_idx, rsw, rdif, t_soilmp, c_smin, c_invrge, c_eta, c_rge);
+    const int idx = (int)t_idx;
     // --- distributed soil moisture, cpp:1021-1032 --------------------------------
-    double theta = (T(TF_SOILMP) - C(CF_SMIN)) * C(CF_INVRGE);
+    double theta = (t_soilmp - c_smin) * c_invrge;
     if (theta > 0.9999) theta = 0.9999;
     if (theta < 0.0001) theta = 0.0001;
-    double sm = theta / (theta + (1.0 - theta) * C(CF_ETA));
-    const double soilm = sm * C(CF_RGE) + C(CF_SMIN);
+    double sm = theta / (theta + (1.0 - theta) * c_eta);
+    const double soilm = sm * c_rge + c_smin;
     cy.soilm = soilm;
     // --- short wave, cpp:1086-1163 --------------------------------------------------
     double radGsw = 0.0, radCsw = 0.0, Rbdown = 0.0, Rddown = 0.0, Rdup = 0.0, X = 0.0;
     if (rsw > 0.0) {
-        const double cz = T(TF_CZ);
+        // ---- section B operands: solar index, horizon, canopy extinction
+        double cz = T(TF_CZ), t_sz = T(TF_SZ), t_caz = T(TF_CAZ), t_saz = T(TF_SAZ), t_tansa = T(TF_TANSA),
+               t_zend = T(TF_ZEND);
+        double c_cs = C(CF_CS), c_ssca = C(CF_SSCA), c_sssa = C(CF_SSSA), c_hor = C.hor(idx & 31),
+               svfa = C(CF_SVFA), gref = C(CF_GREF);
+        pin(cz, t_sz, t_caz, t_saz, t_tansa, t_zend, c_cs, c_ssca, c_sssa, c_hor, svfa, gref);
         // solar index, cpp:85-102 + horizon shading cpp:2219-2223
-        double si = cz * C(CF_CS) + T(TF_SZ) * (C(CF_SSCA) * T(TF_CAZ) + C(CF_SSSA) * T(TF_SAZ));
-        if (!g.shadowmask && T(TF_ZEND) > 90.0) si = 0.0;
+        double si = cz * c_cs + t_sz * (c_ssca * t_caz + c_sssa * t_saz);
+        if (!g.shadowmask && t_zend > 90.0) si = 0.0;
         if (si < 0.0) si = 0.0;
-        if (C.hor(idx & 31) > T(TF_TANSA)) si = 0.0;
-        const double svfa = C(CF_SVFA), gref = C(CF_GREF);
+        if (c_hor > t_tansa) si = 0.0;
         if (flags & FL_PAI) {
+            // ---- section C operands: extinction + direct-beam two-stream coefficients
+            double t_tan2c = T(TF_TAN2C), t_cosc = T(TF_COSC);
+            double c_xx = C(CF_XX), c_kdeninv = C(CF_KDENINV), om = C(CF_OM), gma = C(CF_GMA), agm = C(CF_AGM),
+                   u1 = C(CF_U1), u2 = C(CF_U2), h = C(CF_H), S1 = C(CF_S1), c_gma2 = C(CF_GMA2),
+                   c_agm2 = C(CF_AGM2), c_jdel = C(CF_JDEL), c_pait = C(CF_PAIT), c_invd1 = C(CF_INVD1),
+                   c_invs1 = C(CF_INVS1), c_invd2 = C(CF_INVD2), c_gmagref = C(CF_GMAGREF);
+            pin(t_tan2c, t_cosc, c_xx, c_kdeninv, om, gma, agm, u1, u2, h, S1, c_gma2, c_agm2, c_jdel, c_pait,
+                c_invd1, c_invs1, c_invd2, c_gmagref);
             // canopy extinction, cpp:104-132
-            double k = fsqrt(C(CF_XX) + T(TF_TAN2C)) * C(CF_KDENINV);
+            double k = fsqrt(c_xx + t_tan2c) * c_kdeninv;
             if (flags & (FL_XONE | FL_XINF | FL_XZERO))
                 k = (flags & FL_XONE) ? T(TF_INV2COSC) : (flags & FL_XINF) ? 1.0 : T(TF_TANC);
             if (k > 6000.0) k = 6000.0;
             double rsi = frcp(si);
-            double kd = k * T(TF_COSC) * rsi;
+            double kd = k * t_cosc * rsi;
             double Kc = rsi;
             if (si == 0.0) { kd = 1.0; Kc = 600.0; }
             // direct-beam two-stream coefficients, cpp:164-185
-            const double om = C(CF_OM), gma = C(CF_GMA), agm = C(CF_AGM), u1 = C(CF_U1), u2 = C(CF_U2),
-                         h = C(CF_H), S1 = C(CF_S1);
-            double sig = kd * kd + C(CF_GMA2) - C(CF_AGM2);
-            double ss = 0.5 * (om * kd + C(CF_JDEL));           // 0.5*(om + J*del/kd)*kd
+            double sig = kd * kd + c_gma2 - c_agm2;
+            double ss = 0.5 * (om * kd + c_jdel);           // 0.5*(om + J*del/kd)*kd
             double sstr = om * kd - ss;
-            double S2 = fexp(-kd * C(CF_PAIT));
+            double S2 = fexp(-kd * c_pait);
             double isig = frcp(sig);
             double p5 = -ss * (agm - kd) - gma * sstr;
             double p5s = p5 * isig;
             double v1 = ss - (p5 * (agm + kd)) * isig;
             double v2 = ss - gma - p5s * (u1 + kd);
             double gS2v2 = S2 * v2;
-            double p6 = C(CF_INVD1) * ((v1 * C(CF_INVS1)) * (u1 - h) - (agm - h) * gS2v2);
-            double p7 = -C(CF_INVD1) * ((v1 * S1) * (u1 + h) - (agm + h) * gS2v2);
+            double p6 = c_invd1 * ((v1 * c_invs1) * (u1 - h) - (agm - h) * gS2v2);
+            double p7 = -c_invd1 * ((v1 * S1) * (u1 + h) - (agm + h) * gS2v2);
             double p8 = sstr * (agm + kd) - gma * ss;
             double p8s = -p8 * isig;  // p8 / (-sig)
-            double v3 = (sstr + C(CF_GMAGREF) - p8s * (u2 - kd)) * S2;
-            double p9 = -C(CF_INVD2) * ((p8s * C(CF_INVS1)) * (u2 + h) + v3);
-            double p10 = C(CF_INVD2) * ((p8s * S1) * (u2 - h) + v3);
+            double v3 = (sstr + c_gmagref - p8s * (u2 - kd)) * S2;
+            double p9 = -c_invd2 * ((p8s * c_invs1) * (u2 + h) + v3);
+            double p10 = c_invd2 * ((p8s * S1) * (u2 - h) + v3);
+            // ---- section D operands: gap transmissions and fluxes
+            double c_logclump = C(CF_LOGCLUMP), c_loggi = C(CF_LOGGI), amx = C(CF_AMX), trdn = C(CF_TRDN),
+                   trdu = C(CF_TRDU), c_ehp = C(CF_EHP), c_paiaa = C(CF_PAIAA), emhpa = C(CF_EMHPA),
+                   ehpa = C(CF_EHPA), c_rddng = C(CF_RDDNG), c_albd = C(CF_ALBD), c_rddnz = C(CF_RDDNZ),
+                   c_rdupz = C(CF_RDUPZ);
+            double Rbeam = T(TF_RBEAM), Rb = T(TF_RB);
+            pin(c_logclump, c_loggi, amx, trdn, trdu, c_ehp, c_paiaa, emhpa, ehpa, c_rddng, c_albd, c_rddnz,
+                c_rdupz, Rbeam, Rb);
             // gap transmissions, cpp:1095-1100
-            double trbn = fexp(Kc * C(CF_LOGCLUMP));
+            double trbn = fexp(Kc * c_logclump);
             if (trbn > 0.999) trbn = 0.999;
             if (trbn < 0.0) trbn = 0.0;
-            double trb = fexp(Kc * C(CF_LOGGI));
+            double trb = fexp(Kc * c_loggi);
             if (trb > 0.999) trb = 0.999;
             if (trb < 0.0) trb = 0.0;
-            const double amx = C(CF_AMX), trdn = C(CF_TRDN), trdu = C(CF_TRDU);
             double albb = (1.0 - trdn * trbn) * (p5s + p6 + p7) + trdn * trbn * gref;      // cpp:1102
             if (albb > amx) albb = amx;
             if (albb < 0.01) albb = 0.01;
-            double Rdbdn_g = (1.0 - trbn) * (p8s * S2 + p9 * S1 + p10 * C(CF_EHP));         // cpp:1106
+            double Rdbdn_g = (1.0 - trbn) * (p8s * S2 + p9 * S1 + p10 * c_ehp);            // cpp:1106
             if (Rdbdn_g > amx) Rdbdn_g = amx;
             if (Rdbdn_g < 0.0) Rdbdn_g = 0.0;
-            double S2a = fexp(-kd * C(CF_PAIAA));
-            const double emhpa = C(CF_EMHPA), ehpa = C(CF_EHPA);
+            double S2a = fexp(-kd * c_paiaa);
             double Rdbup_z = (1.0 - trdu * trbn) * (p5s * S2a + p6 * emhpa + p7 * ehpa) + trdu * trbn * gref;
             if (Rdbup_z > amx) Rdbup_z = amx;
             if (Rdbup_z < 0.0) Rdbup_z = 0.0;
             double Rdbdn_z = (1.0 - trb) * (p8s * S2a + p9 * emhpa + p10 * ehpa);           // cpp:1117
             if (Rdbdn_z > amx) Rdbdn_z = amx;
             if (Rdbdn_z < 0.0) Rdbdn_z = 0.0;
-            const double Rbeam = T(TF_RBEAM), Rb = T(TF_RB);
             double trg = trb + (1 - trb) * S2;                                              // cpp:1125
             double Rbc = (trg * si + (1 - trg) * cz) * Rbeam;
             double Rbdn_g = trbn + (1.0 - trbn) * S2;
             if (Rbdn_g > 1.0) Rbdn_g = 1.0;
             if (Rbdn_g < 0.0) Rbdn_g = 0.0;
             const double rds = rdif * svfa;
-            radGsw = (1.0 - gref) * (C(CF_RDDNG) * rds + Rdbdn_g * Rb + Rbdn_g * Rbeam * si);  // cpp:1131
+            radGsw = (1.0 - gref) * (c_rddng * rds + Rdbdn_g * Rb + Rbdn_g * Rbeam * si);  // cpp:1131
             double maxg = (1.0 - gref) * (rds + Rbeam * si);
             if (radGsw > maxg) radGsw = maxg;
-            radCsw = (1.0 - C(CF_ALBD)) * rds + (1.0 - albb) * Rbc;                          // cpp:1136
+            radCsw = (1.0 - c_albd) * rds + (1.0 - albb) * Rbc;                              // cpp:1136
             Rbdown = (trb + (1.0 - trb) * S2a) * Rbeam;
-            Rddown = C(CF_RDDNZ) * rds + Rdbdn_z * Rb;
-            Rdup = C(CF_RDUPZ) * rds + Rdbup_z * Rb;
+            Rddown = c_rddnz * rds + Rdbdn_z * Rb;
+            Rdup = c_rdupz * rds + Rdbup_z * Rb;
             X = Rddown + Rdup + k * cz * Rbdown;                                             // cpp:1142-1143
         } else {
             // bare ground, cpp:1145-1153
@@ -477,56 +504,54 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const Globals& g
     cy.Rbdown = Rbdown;
     cy.X = X;
     o.Rdup = Rdup;
+    // ---- section E operands: long wave, wind, G = 0 soil surface temperature
+    double c_tsv = C(CF_TSV), c_omtrdif = C(CF_OMTRDIF), ws = C.wsa((idx >> 5) & 7), c_ufc = C(CF_UFC),
+           c_uzfac = C(CF_UZFAC), c_ghafac = C(CF_GHAFAC), c_abspsie = C(CF_ABSPSIE), c_invsmax = C(CF_INVSMAX),
+           c_soilb = C(CF_SOILB);
+    double t_rlw = T(TF_RLW), t_rem = T(TF_REM), u2m = T(TF_U2), t_umu = T(TF_UMU), t_wfac = T(TF_WFAC),
+           t_lapk = T(TF_LAPK), t_es = T(TF_ES), t_ea = T(TF_EA), t_ghr = T(TF_GHRRAD), t_de = T(TF_DE),
+           tc = T(TF_TC), tdew = T(TF_TDEW);
+    pin(c_tsv, c_omtrdif, ws, c_ufc, c_uzfac, c_ghafac, c_abspsie, c_invsmax, c_soilb, t_rlw, t_rem, u2m, t_umu,
+        t_wfac, t_lapk, t_es, t_ea, t_ghr, t_de, tc, tdew);
     // --- long wave absorbed by the ground, cpp:1165-1175 -----------------------------
-    const double radGlw = 0.97 * (C(CF_TSV) * T(TF_RLW) + C(CF_OMTRDIF) * T(TF_REM));
+    const double radGlw = 0.97 * (c_tsv * t_rlw + c_omtrdif * t_rem);
     // --- wind, cpp:1189-1218 ------------------------------------------------------------
-    double ws = C.wsa((idx >> 5) & 7);
     if (isnan(ws)) ws = 1.0;
     if (ws < 0.05) ws = 0.05;
-    const double u2m = T(TF_U2);
-    double uf = u2m * C(CF_UFC) * T(TF_UMU) * ws;
+    double uf = u2m * c_ufc * t_umu * ws;
     if (uf < 0.001) uf = 0.001;
-    double uz = uf * C(CF_UZFAC);
+    double uz = uf * c_uzfac;
     if (uz > u2m) uz = u2m;
-    double gHa = uf * C(CF_GHAFAC);
+    double gHa = uf * c_ghafac;
     if (gHa < 0.0001) gHa = 0.0001;
     cy.uf = uf;
     o.uz = uz;
     // --- soil surface temperature with G = 0, cpp:1262-1275 ------------------------------
     const double radabs = radGsw + radGlw;
-    double matric = -C(CF_ABSPSIE) * powxy(soilm * C(CF_INVSMAX), -C(CF_SOILB));
-    double surfwet = fexp(matric * T(TF_WFAC));
+    double matric = -c_abspsie * powxy(soilm * c_invsmax, -c_soilb);
+    double surfwet = fexp(matric * t_wfac);
     if (surfwet > 1.0) surfwet = 1.0;
-    const double m = T(TF_LAPK) * gHa;
-    const double num0 = radabs - T(TF_REM) - m * (T(TF_ES) - T(TF_EA)) * surfwet;
-    const double den = 29.3 * (gHa + T(TF_GHRRAD)) + m * T(TF_DE);
+    const double m = t_lapk * gHa;
+    const double num0 = radabs - t_rem - m * (t_es - t_ea) * surfwet;
+    const double den = 29.3 * (gHa + t_ghr) + m * t_de;
     cy.num0 = num0;
     cy.den = den;
-    double Tg0 = pm_temperature(num0, den, dTmx, T);
+    double Tg0 = pm_temperature(num0, den, dTmx, tc, tdew);
     o.Tg0 = Tg0;
     o.absRnet = fabs(radabs - lw_emit(Tg0));
 }
 
+// Stomatal operands shared by the three stomcondCpp evaluations of a cell-step.
+struct Stom {
+    double gsmax, rsmx, inv02rsmx, gs2;
+};
 // cpp:442-458 stomcondCpp with the soil-water factor `gs2 = mu*gsmax` passed in.
-template <class CL>
-__device__ __forceinline__ double stomcond(double Rswabs, double gs2, const CL& C) {
+__device__ __forceinline__ double stomcond(double Rswabs, const Stom& s) {
     if (Rswabs <= 0.0) return 0.0;
-    const double rsmx = C(CF_RSMX);
-    if (Rswabs > rsmx) Rswabs = rsmx;
-    double gs = C(CF_GSMAX) * fexp(-(rsmx - Rswabs) * C(CF_INV02RSMX) * 0.693147180559945309417);
-    if (gs > gs2) gs = gs2;
+    if (Rswabs > s.rsmx) Rswabs = s.rsmx;
+    double gs = s.gsmax * fexp(-(s.rsmx - Rswabs) * s.inv02rsmx * 0.693147180559945309417);
+    if (gs > s.gs2) gs = s.gs2;
     return gs;
-}
-// the theta-only part of stomcondCpp, cpp:451-455
-template <class CL>
-__device__ __forceinline__ double stom_gs2(double theta, const CL& C) {
-    double thetan = C(CF_RAT) * theta + C(CF_RATC);
-    double Se = thetan * C(CF_INVSMAX);
-    if (Se > 1.0) Se = 1.0;
-    double psiw = -C(CF_ABSPSIE) * powxy(Se, -C(CF_SOILB)) * 0.01;   // cpp:382-389
-    if (psiw < C(CF_PSIW0)) psiw = C(CF_PSIW0);
-    double mu = 1.0 - (fexp(-C(CF_KK) * psiw) - 1.0) * C(CF_MUDENINV);
-    return mu * C(CF_GSMAX);
 }
 
 // cpp:1316-1331 mincondCpp
@@ -552,73 +577,98 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
                                       const Carry& cy, double dtr, double Rmx, bool above_ground,
                                       Pass2Out& o) {
     const double soilm = cy.soilm;
-    const double tc = T(TF_TC), ea = T(TF_EA);
+    // ---- section A operands: soil conductivity, ground heat flux, ground temperature
+    double rho = C(CF_RHO), c_csa = C(CF_CSA), c_c1 = C(CF_C1), c_c1mc4 = C(CF_C1MC4), c_c3 = C(CF_C3);
+    double t_gfac = T(TF_GFAC), tc = T(TF_TC), tdew = T(TF_TDEW), ea = T(TF_EA);
+    pin(rho, c_csa, c_c1, c_c1mc4, c_c3, t_gfac, tc, tdew, ea);
     // --- soil conductivity / damping depth, cpp:1249-1260 ---------------------------------
-    const double rho = C(CF_RHO);
-    double cs = C(CF_CSA) + 4180.0 * soilm;
+    double cs = c_csa + 4180.0 * soilm;
     double ph = (rho * (1.0 - soilm) + soilm) * 1000.0;
     double c2 = 1.06 * rho * soilm;
-    double ksoil = C(CF_C1) + c2 * soilm - C(CF_C1MC4) * fexp(-pow4(C(CF_C3) * soilm));
+    double ksoil = c_c1 + c2 * soilm - c_c1mc4 * fexp(-pow4(c_c3 * soilm));
     double kap = fdiv(ksoil, cs * ph);
     double DD = fsqrt(kap * (2.0 / kOmdy));
     // --- ground heat flux and ground temperature, cpp:1277-1296 ------------------------------
-    double G = fdiv(T(TF_GFAC) * dtr * ksoil, DD);
+    double G = fdiv(t_gfac * dtr * ksoil, DD);
     if (G > 0.6 * Rmx) G = 0.6 * Rmx;
     if (G < -0.6 * Rmx) G = -0.6 * Rmx;
-    const double Tg = pm_temperature(cy.num0 - G, cy.den, dTmx, T);
+    const double Tg = pm_temperature(cy.num0 - G, cy.den, dTmx, tc, tdew);
     o.Tg = Tg;
     o.DD = DD;
     if (!above_ground) return;
+    // ---- section B operands: TVaboveground up to the canopy temperature
+    double c_ghafac = C(CF_GHAFAC), c_smin = C(CF_SMIN), c_invrge = C(CF_INVRGE), c_pai = C(CF_PAI),
+           c_ksat = C(CF_KSAT), c_psunsat = C(CF_PSUNSAT), c_shadefac = C(CF_SHADEFAC), c_ompc = C(CF_OMPC),
+           c_svfa = C(CF_SVFA);
+    double rlw = T(TF_RLW), rsw = T(TF_RSW), rdif = T(TF_RDIF), t_idx = T(TF_IDX), lapk = T(TF_LAPK),
+           es = T(TF_ES), De = T(TF_DE), rem = T(TF_REM), ghr = T(TF_GHRRAD);
+    pin(c_ghafac, c_smin, c_invrge, c_pai, c_ksat, c_psunsat, c_shadefac, c_ompc, c_svfa, rlw, rsw, rdif, t_idx,
+        lapk, es, De, rem, ghr);
     // --- TVaboveground, cpp:1411-1472 ----------------------------------------------------------
-    const double rlw = T(TF_RLW);
     const double uf = cy.uf;
-    double gHa = uf * C(CF_GHAFAC);
+    double gHa = uf * c_ghafac;
     if (gHa < 0.0001) gHa = 0.0001;
     const double esTg = satvap(Tg);
     double eT = esTg - ea;
     if (eT < 0.001) eT = 0.001;
     double plf = 0.8753 - 1.7126 * flog(eT);
     double gwet = frcp(1.0 + fexp(-plf));
-    const double surfwet = (soilm - C(CF_SMIN)) * C(CF_INVRGE);
+    const double surfwet = (soilm - c_smin) * c_invrge;
     if (surfwet > gwet) gwet = surfwet;
     // canopy conductance, cpp:1425-1428 + 460-477
-    const double rsw = T(TF_RSW), rdif = T(TF_RDIF);
-    const int idx = (int)T(TF_IDX);
+    const int idx = (int)t_idx;
     double gS = 9999.99;
-    double gs2 = 0.0;
+    Stom st;
+    st.gs2 = 0.0;
     bool have_gs2 = false;
+    auto load_stom = [&]() {
+        // theta-only part of stomcondCpp, cpp:451-455 with psiwfromthetaCpp cpp:382-389
+        double c_rat = C(CF_RAT), c_ratc = C(CF_RATC), c_invsmax = C(CF_INVSMAX), c_abspsie = C(CF_ABSPSIE),
+               c_soilb = C(CF_SOILB), c_psiw0 = C(CF_PSIW0), c_kk = C(CF_KK), c_mudeninv = C(CF_MUDENINV);
+        st.gsmax = C(CF_GSMAX);
+        st.rsmx = C(CF_RSMX);
+        st.inv02rsmx = C(CF_INV02RSMX);
+        pin(c_rat, c_ratc, c_invsmax, c_abspsie, c_soilb, c_psiw0, c_kk, c_mudeninv, st.gsmax, st.rsmx,
+            st.inv02rsmx);
+        double thetan = c_rat * soilm + c_ratc;
+        double Se = thetan * c_invsmax;
+        if (Se > 1.0) Se = 1.0;
+        double psiw = -c_abspsie * powxy(Se, -c_soilb) * 0.01;
+        if (psiw < c_psiw0) psiw = c_psiw0;
+        double mu = 1.0 - (fexp(-c_kk * psiw) - 1.0) * c_mudeninv;
+        st.gs2 = mu * st.gsmax;
+        have_gs2 = true;
+    };
     if (!(flags & FL_OMPNAN)) {
         double kb, P_sun;
         if (idx & 256) {  // zenith (in degrees) beyond pi/2: k is the per-cell saturated value
-            kb = C(CF_KSAT);
-            P_sun = C(CF_PSUNSAT);
+            kb = c_ksat;
+            P_sun = c_psunsat;
         } else {
             kb = fsqrt(C(CF_XX) + T(TF_TAN2B)) * C(CF_KDENINV);
             if (flags & (FL_XONE | FL_XINF | FL_XZERO))
                 kb = (flags & FL_XONE) ? T(TF_INV2COSB) : (flags & FL_XINF) ? 1.0 : T(TF_TANB);
             if (kb > 6000.0) kb = 6000.0;
-            P_sun = fdiv(1.0 - fexp(-kb * C(CF_PAI)), kb);
+            P_sun = fdiv(1.0 - fexp(-kb * c_pai), kb);
         }
-        double P_shade = C(CF_PAI) - P_sun;
-        double Rshade_abs = rdif * C(CF_SHADEFAC);
-        double Rsun_abs = (rsw - rdif) * kb * (1 - C(CF_OMPC)) + Rshade_abs;
+        double P_shade = c_pai - P_sun;
+        double Rshade_abs = rdif * c_shadefac;
+        double Rsun_abs = (rsw - rdif) * kb * (1 - c_ompc) + Rshade_abs;
         double gs_sun = 0.0, gs_shade = 0.0;
         if (!(Rsun_abs <= 0.0) || !(Rshade_abs <= 0.0)) {
-            gs2 = stom_gs2(soilm, C);
-            have_gs2 = true;
-            gs_sun = stomcond(Rsun_abs, gs2, C);
-            gs_shade = stomcond(Rshade_abs, gs2, C);
+            load_stom();
+            gs_sun = stomcond(Rsun_abs, st);
+            gs_shade = stomcond(Rshade_abs, st);
         }
         gS = gs_sun * P_sun + gs_shade * P_shade;
     }
     double gV = 0.0;
     if (gS > 0.0) gV = fdiv(gHa * gS, gHa + gS);           // 1/(1/gHa + 1/gS)
     // canopy temperature, cpp:1430-1432 (Penman-Monteith with the linear surface wetness)
-    const double lapk = T(TF_LAPK), es = T(TF_ES), De = T(TF_DE), rem = T(TF_REM), ghr = T(TF_GHRRAD);
-    const double Rabs = cy.radCsw + 0.97 * C(CF_SVFA) * rlw;
+    const double Rabs = cy.radCsw + 0.97 * c_svfa * rlw;
     const double mC = lapk * gV;
     const double Tcan = pm_temperature(Rabs - rem - mC * (es - ea) * surfwet - G,
-                                       29.3 * (gHa + ghr) + mC * De, dTmx, T);
+                                       29.3 * (gHa + ghr) + mC * De, dTmx, tc, tdew);
     const double esTcan = satvap(Tcan);
     double ez;
     if (!(flags & FL_BELOW)) {
@@ -631,15 +681,18 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
         o.lwup = lw_emit(Tcan);
         o.lwdn = rlw;
     } else {
+        // ---- section C operands: leaf temperature
+        double c_uzfac = C(CF_UZFAC), emg = C(CF_EMG), ema = C(CF_EMA), invleafd = C(CF_INVLEAFD),
+               c_hom = C(CF_HOM), c_homp = C(CF_HOMP), t_u2 = T(TF_U2);
+        pin(c_uzfac, emg, ema, invleafd, c_hom, c_homp, t_u2);
         // ---- leaf temperature, cpp:1333-1364 -------------------------------------------------
-        double uz = uf * C(CF_UZFAC);
-        if (uz > T(TF_U2)) uz = T(TF_U2);
+        double uz = uf * c_uzfac;
+        if (uz > t_u2) uz = t_u2;
         const double lwcan = lw_emit(Tcan), lwgro = lw_emit(Tg);
-        const double emg = C(CF_EMG), ema = C(CF_EMA), invleafd = C(CF_INVLEAFD);
         const double lwup = emg * lwgro + (1 - emg) * lwcan;
         const double lwdn = ema * rlw + (1 - ema) * lwcan;
         const double lwabs = 0.97 * 0.5 * (lwup + lwdn);
-        const double leafabs = C(CF_HOM) * cy.X + lwabs;     // radLsw + lwabs
+        const double leafabs = c_hom * cy.X + lwabs;         // radLsw + lwabs
         double gh = 0.135 * fsqrt(uz * invleafd) * 1.4;
         const double RnetL = leafabs - lwcan;                // cpp:1319 with tc = Tcan
         double gmin = mincond_from_hf(g.hf0, RnetL, invleafd);
@@ -647,11 +700,11 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
         double gVl = gh;
         if (flags & FL_STOM) {
             gVl = 0.0;
-            const double PARabs = C(CF_HOMP) * cy.X;         // radLpar
+            const double PARabs = c_homp * cy.X;             // radLpar
             double gs = 0.0;
             if (PARabs > 0.0) {
-                if (!have_gs2) gs2 = stom_gs2(soilm, C);
-                gs = stomcond(PARabs, gs2, C);
+                if (!have_gs2) load_stom();
+                gs = stomcond(PARabs, st);
             }
             // rs = min(1/gs, 500) (500 when gs <= 0), Hlf = 1.09767*rs^0.2672778, cpp:1321-1324
             double lrs = (gs > 0.002) ? -flog(gs) : 6.214608098422191;   // log(500)
@@ -663,34 +716,37 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
         }
         const double mL = lapk * gVl;
         const double tleaf = pm_temperature(leafabs - rem - mL * (es - ea) * surfwet - 0.0,
-                                            29.3 * (gh + ghr) + mL * De, dTmx, T);
+                                            29.3 * (gh + ghr) + mL * De, dTmx, tc, tdew);
         const double esTl = satvap(tleaf);
         const double HL = 29.3 * gh * (tleaf - tc);                       // cpp:1242
         const double LL = mL * (esTl - ea) * surfwet;                     // cpp:1243
         o.tleaf = tleaf;
         o.lwdn = lwdn;
         o.lwup = lwup;
+        // ---- section D operands: canopy-top source + Lagrangian near/far field
+        double w2 = C(CF_OML2), hgt = C(CF_HGT), c_a2h = C(CF_A2H), c_inthh = C(CF_INTHH), c_inthz = C(CF_INTHZ),
+               c_invhgt = C(CF_INVHGT), c_invhmz = C(CF_INVHMZ), omem = C(CF_OMEMPAI), nf = C(CF_NEARFAC),
+               lden = C(CF_LEAFDEN);
+        double mu = T(TF_MUPM), invmu = T(TF_INVMUPM);
+        pin(w2, hgt, c_a2h, c_inthh, c_inthz, c_invhgt, c_invhmz, omem, nf, lden, mu, invmu);
         // ---- canopy-top source, cpp:1449 ---------------------------------------------------------
         const double HC = 29.3 * gHa * (Tcan - tc);
         const double LC = mC * (esTcan - ea) * surfwet;
-        const double mu = T(TF_MUPM);                                     // cpp:1245
-        double w2 = C(CF_OML2);
         bool prof2 = (flags & FL_ABOVE2) != 0;
         const double Th = prof2 ? tc + (Tcan - tc) * w2 : Tcan;
         const double eh = prof2 ? ea + (esTcan - ea) * surfwet * w2 : ea + (esTcan - ea) * surfwet;
         // ---- Lagrangian near/far field, cpp:1365-1409 ---------------------------------------------
-        const double hgt = C(CF_HGT), z = g.reqhgt2;
-        const double muR = frcp(C(CF_A2H) * uf);          // uf/(a2*h) / uf^2
-        double Rc = C(CF_INTHH) * muR;
+        const double z = g.reqhgt2;
+        const double muR = frcp(c_a2h * uf);                 // uf/(a2*h) / uf^2
+        double Rc = c_inthh * muR;
         if (Rc < 0.001) Rc = 0.001;
-        double Rz = C(CF_INTHZ) * muR;
+        double Rz = c_inthz * muR;
         if (Rz < 0.001) Rz = 0.001;
         const double Kc = fdiv(hgt, Rc);
-        const double rKc = Rc * C(CF_INVHGT);                // 1/Kc
+        const double rKc = Rc * c_invhgt;                    // 1/Kc
         const double Kg = frcp(Rz * z);
-        const double Kh = fdiv(C(CF_INVHMZ), Rc - Rz);
+        const double Kh = fdiv(c_invhmz, Rc - Rz);
         const double invK = frcp(Kg + Kh + Kc);
-        const double omem = C(CF_OMEMPAI), nf = C(CF_NEARFAC), lden = C(CF_LEAFDEN);
         const double cp43 = 29.3 * 43.0;
         // temperature
         {
@@ -712,7 +768,7 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
             double near = nf * (LL * lden);
             if (fabs(near) > mxnear) near = near > 0.0 ? mxnear : -mxnear;
             if (isnan(near)) near = 0;
-            ez = (near + farg) * T(TF_INVMUPM);
+            ez = (near + farg) * invmu;
         }
     }
     double rh = fdiv(ez, satvap(o.Tz)) * 100.0;
