@@ -17,6 +17,9 @@
 #ifndef MCF_WAVES_PER_EU
 #define MCF_WAVES_PER_EU 3
 #endif
+#ifndef MCF_HOUR_PERMUTE
+#define MCF_HOUR_PERMUTE 1
+#endif
 #ifndef MCF_DAYPRIO
 #define MCF_DAYPRIO 0
 #endif
@@ -343,7 +346,24 @@ __global__ __launch_bounds__(CPB * 24, MCF_WAVES_PER_EU) void k_solve(SolveArgs 
 
     const int tid = threadIdx.x;
     const int cl = tid % CPB;
+#if MCF_HOUR_PERMUTE
+    // Waves w, w+4, w+8 of a workgroup share a SIMD.  Daytime waves carry the short-wave block
+    // (about twice the work of a night wave), so hour groups are dealt to waves so that every
+    // SIMD gets one midday, one morning/evening and one night group.
+    int hr;
+    if (CPB == 32) {
+        const int wave = tid >> 6;
+        const int tab = ((wave & 3) == 0) ? (wave == 0 ? 12 : wave == 4 ? 16 : 20)
+                      : ((wave & 3) == 1) ? (wave == 1 ? 10 : wave == 5 ? 6 : 2)
+                      : ((wave & 3) == 2) ? (wave == 2 ? 14 : wave == 6 ? 18 : 22)
+                                          : (wave == 3 ? 8 : wave == 7 ? 4 : 0);
+        hr = tab + ((tid >> 5) & 1);
+    } else {
+        hr = tid / CPB;
+    }
+#else
     const int hr = tid / CPB;
+#endif
     const int64_t N = a.N;
     const int64_t c0 = (int64_t)blockIdx.x * CPB;
     const int64_t c = c0 + cl;
@@ -383,12 +403,20 @@ __global__ __launch_bounds__(CPB * 24, MCF_WAVES_PER_EU) void k_solve(SolveArgs 
         const int64_t oidx = c + N * (a.slot_step0 + kl);
         auto put = [&](int v, double val) {
             unsigned sel = (unsigned)(a.out_sel >> (4 * v)) & 15u;
+#if MCF_EXPERIMENT_NOSTORE
+            if (sel != 15u && val == 1.2345e300) a.out_base[(int64_t)sel * a.out_stride + oidx] = val;
+#else
             if (sel != 15u) a.out_base[(int64_t)sel * a.out_stride + oidx] = val;
+#endif
         };
         // issue the loads of the next day's table rows now; they land in LDS after pass 1
         constexpr int TPER = (TF_COUNT * 24 + NT - 1) / NT;
         double pre[TPER];
+#if MCF_EXPERIMENT_NOPREFETCH
+        const bool stage = false;
+#else
         const bool stage = !AF && (dl + 1 < a.ndays);
+#endif
         if (stage) {
             const double* src = a.tt + (int64_t)(dabs + 1) * TF_COUNT * 24;
 #pragma unroll
