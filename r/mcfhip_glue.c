@@ -1,0 +1,150 @@
+/*
+ * mcfhip_glue.c — R .Call() shim over libmcfhip's C ABI (include/mcf.h).
+ *
+ * Stands where the reference's generated Rcpp glue stands:
+ *   _microclimf_runmicro1Cpp  src/RcppExports.cpp:250-272  ->  mcfhip_runmicro1
+ *   _microclimf_runmicro2Cpp  src/RcppExports.cpp:275-297  ->  mcfhip_runmicro2
+ * Same 15 arguments in the same order as R/RcppExports.R:72-78, same named-list
+ * result (src/microclimfCpp.cpp:2326-2335).  Uses only R's C API (Rinternals.h);
+ * no Rcpp.  NOT compiled in the build image (R is not installed there): build with
+ *   R CMD SHLIB mcfhip_glue.c -I../include -L../microclimf_amd/csrc -lmcfhip
+ *
+ * Error discipline: libmcfhip never longjmps; it returns a status and
+ * has released every device resource by then, so Rf_error() is raised from here only
+ * after the call has returned.
+ */
+#include <R.h>
+#include <Rinternals.h>
+#include <R_ext/Rdynload.h>
+#include <string.h>
+
+#include "mcf.h"
+
+static SEXP elt(SEXP list, const char *name, const char *alt) {
+    SEXP names = getAttrib(list, R_NamesSymbol);
+    for (R_xlen_t i = 0; i < XLENGTH(list); ++i) {
+        const char *n = CHAR(STRING_ELT(names, i));
+        if (strcmp(n, name) == 0 || (alt && strcmp(n, alt) == 0)) return VECTOR_ELT(list, i);
+    }
+    Rf_error("mcfhip: list element '%s' not found", name);
+    return R_NilValue;
+}
+
+/* numeric column/array as double*; *np counts PROTECTs added by coercion */
+static const double *dbl(SEXP x, int *np) {
+    if (TYPEOF(x) != REALSXP) { x = PROTECT(coerceVector(x, REALSXP)); ++*np; }
+    return REAL(x);
+}
+static const int *intcol(SEXP x, int *np) {   /* obstime$year etc. arrive as doubles (int:1085) */
+    if (TYPEOF(x) != INTSXP) { x = PROTECT(coerceVector(x, INTSXP)); ++*np; }
+    return INTEGER(x);
+}
+
+static SEXP run(int array_forcing, SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc,
+                SEXP reqhgt, SEXP zref, SEXP lat, SEXP lon, SEXP Sminp, SEXP Smaxp, SEXP tfact,
+                SEXP complete, SEXP mat, SEXP out) {
+    int np = 0;
+    mcf_grid_inputs in;
+    mcf_options opt;
+    mcf_outputs res;
+    memset(&in, 0, sizeof in); memset(&opt, 0, sizeof opt); memset(&res, 0, sizeof res);
+
+    SEXP hgt = elt(vegp, "hgt", NULL);
+    SEXP dim = getAttrib(hgt, R_DimSymbol);
+    if (TYPEOF(dim) != INTSXP || LENGTH(dim) != 2) Rf_error("mcfhip: vegp$hgt must be a matrix");
+    in.rows = INTEGER(dim)[0]; in.cols = INTEGER(dim)[1];
+    in.tsteps = XLENGTH(elt(obstime, "year", NULL));
+    in.array_forcing = array_forcing;
+    in.obstime.year = intcol(elt(obstime, "year", NULL), &np);
+    in.obstime.month = intcol(elt(obstime, "month", NULL), &np);
+    in.obstime.day = intcol(elt(obstime, "day", NULL), &np);
+    in.obstime.hour = dbl(elt(obstime, "hour", NULL), &np);
+    /* climdata: data.frame columns (1Cpp, cpp:2062-2071) or list entries (2Cpp, cpp:2350-2359) */
+    in.clim.tc = dbl(elt(climdata, "temp", "tc"), &np);
+    in.clim.es = dbl(elt(climdata, "es", NULL), &np);
+    in.clim.ea = dbl(elt(climdata, "ea", NULL), &np);
+    in.clim.tdew = dbl(elt(climdata, "tdew", NULL), &np);
+    in.clim.pk = dbl(elt(climdata, "pres", "pk"), &np);
+    in.clim.swdown = dbl(elt(climdata, "swdown", NULL), &np);
+    in.clim.difrad = dbl(elt(climdata, "difrad", NULL), &np);
+    in.clim.lwdown = dbl(elt(climdata, "lwdown", NULL), &np);
+    in.clim.windspeed = dbl(elt(climdata, "windspeed", NULL), &np);
+    in.clim.winddir = dbl(elt(climdata, "winddir", NULL), &np);
+    in.pointm.soilm = dbl(elt(pointm, "soilm", NULL), &np);
+    in.pointm.Tg = dbl(elt(pointm, "Tg", NULL), &np);
+    in.pointm.Tbp = dbl(elt(pointm, "Tbp", NULL), &np);
+    in.pointm.G = dbl(elt(pointm, "G", "Gp"), &np);
+    in.pointm.umu = dbl(elt(pointm, "umu", NULL), &np);
+    in.pointm.kp = dbl(elt(pointm, "kp", NULL), &np);
+    in.pointm.muGp = dbl(elt(pointm, "muGp", NULL), &np);
+    in.pointm.dtrp = dbl(elt(pointm, "dtrp", NULL), &np);
+    static const char *vn[10] = {"hgt", "pai", "x", "gsmax", "leafr", "leaft", "clump", "leafd", "paia", "leafden"};
+    const double **vp = (const double **)&in.vegp;
+    for (int i = 0; i < 10; ++i) vp[i] = dbl(elt(vegp, vn[i], NULL), &np);
+    static const char *sn[15] = {"Smin", "Smax", "gref", "soilb", "Psie", "Vq", "Vm", "Mc", "rho", "slope",
+                                 "aspect", "twi", "svfa", "wsa", "hor"};
+    const double **sp = (const double **)&in.soilc;
+    for (int i = 0; i < 15; ++i) sp[i] = dbl(elt(soilc, sn[i], NULL), &np);
+    if (array_forcing) { in.lats = dbl(lat, &np); in.lons = dbl(lon, &np); }
+    else { in.lat = asReal(lat); in.lon = asReal(lon); }
+
+    opt.reqhgt = asReal(reqhgt); opt.zref = asReal(zref);
+    opt.Sminp = asReal(Sminp); opt.Smaxp = asReal(Smaxp);
+    opt.tfact = asReal(tfact); opt.mat = asReal(mat);
+    opt.complete = asLogical(complete) == TRUE;
+    /* `out` may be logical or numeric 0/1 after `out2*out` (int:1161) */
+    SEXP outl = PROTECT(coerceVector(out, LGLSXP)); ++np;
+    if (LENGTH(outl) != MCF_NOUT) Rf_error("mcfhip: out must have 10 elements");
+    for (int v = 0; v < MCF_NOUT; ++v) opt.out[v] = LOGICAL(outl)[v] == TRUE;
+    /* Tg/Tbp are only read for reqhgt < 0 && !complete; the marshaller passes Tbp = 0 otherwise (int:1096) */
+    if (!(opt.reqhgt < 0 && !opt.complete)) { in.pointm.Tg = NULL; in.pointm.Tbp = NULL; }
+
+    static const char *on[MCF_NOUT] = {"Tz", "tleaf", "relhum", "soilm", "windspeed", "Rdirdown", "Rdifdown",
+                                       "Rlwdown", "Rswup", "Rlwup"};
+    int nreq = 0;
+    for (int v = 0; v < MCF_NOUT; ++v) nreq += opt.out[v];
+    SEXP ans = PROTECT(allocVector(VECSXP, nreq)); ++np;
+    SEXP nms = PROTECT(allocVector(STRSXP, nreq)); ++np;
+    R_xlen_t n = (R_xlen_t)in.rows * in.cols * in.tsteps;   /* long vectors: no 2^31 overflow (cpp:2118) */
+    for (int v = 0, k = 0; v < MCF_NOUT; ++v) {
+        if (!opt.out[v]) continue;
+        SEXP a = PROTECT(allocVector(REALSXP, n)); ++np;
+        SEXP d = PROTECT(allocVector(INTSXP, 3)); ++np;
+        INTEGER(d)[0] = (int)in.rows; INTEGER(d)[1] = (int)in.cols; INTEGER(d)[2] = (int)in.tsteps;
+        setAttrib(a, R_DimSymbol, d);
+        SET_VECTOR_ELT(ans, k, a);
+        SET_STRING_ELT(nms, k, mkChar(on[v]));
+        res.var[v] = REAL(a);
+        ++k;
+    }
+    setAttrib(ans, R_NamesSymbol, nms);
+
+    int rc = array_forcing ? mcf_runmicro2(&in, &opt, &res) : mcf_runmicro1(&in, &opt, &res);
+    if (rc != MCF_OK) {
+        char msg[600];
+        strncpy(msg, mcf_last_error(), sizeof msg - 1); msg[sizeof msg - 1] = 0;
+        UNPROTECT(np);
+        Rf_error("mcfhip (%d): %s", rc, msg);
+    }
+    UNPROTECT(np);
+    return ans;
+}
+
+SEXP mcfhip_runmicro1(SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc, SEXP reqhgt, SEXP zref,
+                      SEXP lat, SEXP lon, SEXP Sminp, SEXP Smaxp, SEXP tfact, SEXP complete, SEXP mat, SEXP out) {
+    return run(0, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact, complete, mat, out);
+}
+SEXP mcfhip_runmicro2(SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc, SEXP reqhgt, SEXP zref,
+                      SEXP lats, SEXP lons, SEXP Sminp, SEXP Smaxp, SEXP tfact, SEXP complete, SEXP mat, SEXP out) {
+    return run(1, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons, Sminp, Smaxp, tfact, complete, mat, out);
+}
+
+static const R_CallMethodDef CallEntries[] = {
+    {"mcfhip_runmicro1", (DL_FUNC)&mcfhip_runmicro1, 15},
+    {"mcfhip_runmicro2", (DL_FUNC)&mcfhip_runmicro2, 15},
+    {NULL, NULL, 0}};
+
+void R_init_mcfhip_glue(DllInfo *dll) {
+    R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);
+    R_useDynamicSymbols(dll, FALSE);
+}

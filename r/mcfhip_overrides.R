@@ -1,0 +1,26 @@
+# mcfhip_overrides.R — route microclimf's grid solver through libmcfhip.
+#
+# The reference reaches its C++ through two generated stubs (R/RcppExports.R:72-78):
+#   runmicro1Cpp <- function(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, long,
+#                            Sminp, Smaxp, tfact, complete, mat, out)
+#     .Call(`_microclimf_runmicro1Cpp`, ...)
+# which .runmodel1Cpp / .runmodel2Cpp call (R/internal.R:1168, 1342).  Replacing those two
+# bindings is all it takes: modelin()/runmicro()/runmicro_big()/runbioclim() above stay untouched.
+#
+# Usage (after building r/mcfhip_glue.so, see INTEGRATION.md):
+#   library(microclimf); source("r/mcfhip_overrides.R"); mcfhip_enable()
+
+mcfhip_enable <- function(glue = "r/mcfhip_glue.so") {
+  dyn.load(glue)
+  rm1 <- function(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, long,
+                  Sminp, Smaxp, tfact, complete, mat, out)
+    .Call("mcfhip_runmicro1", obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, long,
+          Sminp, Smaxp, tfact, complete, mat, out)
+  rm2 <- function(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons,
+                  Sminp, Smaxp, tfact, complete, mat, out)
+    .Call("mcfhip_runmicro2", obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons,
+          Sminp, Smaxp, tfact, complete, mat, out)
+  utils::assignInNamespace("runmicro1Cpp", rm1, ns = "microclimf")
+  utils::assignInNamespace("runmicro2Cpp", rm2, ns = "microclimf")
+  invisible(TRUE)
+}
