@@ -84,6 +84,7 @@ def main():
         dist.barrier()
     from microclimf_amd import synthetic
     from microclimf_amd.api import Plan
+    from microclimf_amd.distributed import allreduce_max, allreduce_sum, allreduce_twi_mean
 
     rows, cols, T = args.rows, args.cols, args.tsteps
     ndays = T // 24
@@ -93,11 +94,7 @@ def main():
                 cells_per_block=args.cells_per_block)
     # the solver's one global reduction: mean of log(twi)/tfact over the WHOLE raster
     s, n = plan.twi_partial()
-    if world > 1:
-        red = torch.tensor([s, float(n)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(red, op=dist.ReduceOp.SUM)          # RCCL over xGMI
-        s, n = float(red[0].item()), float(red[1].item())
-    plan.set_twi_mean(s / n)
+    plan.set_twi_mean(allreduce_twi_mean(s, float(n)))      # one 2-double all-reduce (RCCL over xGMI)
     valid = plan.valid_cells
 
     def one_step():
@@ -123,15 +120,8 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     kms, klaunches = plan.kernel_stats()
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        vv = torch.tensor([float(valid)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(vv, op=dist.ReduceOp.SUM)
-        valid_all = float(vv.item())
-    else:
-        valid_all = float(valid)
+    dt = allreduce_max(dt)                   # slowest rank
+    valid_all = allreduce_sum(float(valid))  # whole-job units
     cellsteps_per_step = valid_all * ndays * 24
     value = cellsteps_per_step * args.steps / dt
 

@@ -18,9 +18,11 @@
  * is not allowed), and the reference ships no golden vectors for this path: its
  * only test that touches this arithmetic (tests/testthat/
  * test-microclimatemodel_wrapper.R) asserts interval bounds for one point.
- * That test is replayed against this file by oracle/replay_reference_tests.py
- * (tests/test_oracle_reference_bounds.py).  Beyond those bounds the numeric
- * parity of this oracle with the reference is UNPINNED — see DESIGN.md.
+ * That test (and test-BigLeafCpp.R) is replayed against this file by
+ * oracle/replay_reference_tests.py (tests/test_oracle_reference_bounds.py): all
+ * 33 of the reference's assertions hold.  Beyond those bounds the numeric
+ * parity of this oracle with the reference is UNPINNED ("parity unpinned") —
+ * see DESIGN.md §2.
  *
  * Build: gcc -O2 -ffp-contract=off -shared -fPIC (oracle/Makefile).
  */
@@ -348,6 +350,15 @@ static soilc_t soilpfun(double Vm, double Vq, double Mc, double rho) {
     return o;
 }
 
+/* Row-block tests: a rank solving one block of a larger raster must use the mean of the
+ * WHOLE raster (cpp:1004); the test installs it here (enable = 0 restores cpp:993-1004). */
+static int g_mean_override_on = 0;
+static double g_mean_override = 0.0;
+void orc_set_twi_mean_override(double mean, int enable) {
+    g_mean_override = mean;
+    g_mean_override_on = enable;
+}
+
 /* cpp:975-1019 soildCppm: tadd = log(twi)/tfact - mean over non-NA cells */
 void orc_soild_tadd(const double *twi, int64_t n_cells, int64_t rows, int64_t cols, double tfact,
                     double *tadd) {
@@ -364,6 +375,7 @@ void orc_soild_tadd(const double *twi, int64_t n_cells, int64_t rows, int64_t co
             }
         }
     double me = sum / (double)count;
+    if (g_mean_override_on) me = g_mean_override;
     for (int64_t c = 0; c < rows * cols; ++c) {
         double v = twi[c];
         tadd[c] = isnan(v) ? orc_na_real() : log(v) / tfact - me;

@@ -23,6 +23,7 @@ double orc_satvap(double tc);
 double orc_soild(double soilm, double Smin, double Smax, double tadd);
 void orc_soild_tadd(const double *twi, int64_t n_cells, int64_t rows, int64_t cols, double tfact,
                     double *tadd);
+void orc_set_twi_mean_override(double mean, int enable);
 void orc_man(const double *x, int m, int n, double *z);
 void orc_tbelowground(double reqhgt, const double *Tg, const double *Tgp, const double *Tbp, int tsteps,
                       double meanD, double mat, int hiy, int complete, double *Tz);

@@ -21,8 +21,8 @@ _lib = None
 
 
 def build(force: bool = False) -> Path:
-    srcs = [_DIR / "mcf_oracle.c", _DIR / "mcf_oracle.h", _DIR / "pointmodel.c",
-            _DIR / "pointmodel.h", _DIR.parent / "include" / "mcf.h"]
+    srcs = [_DIR / "oracle_unit.c", _DIR / "mcf_oracle.c", _DIR / "mcf_oracle.h", _DIR / "pointmodel.c",
+            _DIR / "pointmodel.h", _DIR / "Makefile", _DIR.parent / "include" / "mcf.h"]
     srcs = [s for s in srcs if s.exists()]
     if force or not LIB_PATH.exists() or any(s.stat().st_mtime > LIB_PATH.stat().st_mtime for s in srcs):
         subprocess.run(["make", "-C", str(_DIR), "-B", "libmcf_oracle.so"], check=True,

@@ -1,0 +1,24 @@
+"""libmcfhip against the committed golden vectors (no oracle involved at run time)."""
+import numpy as np
+import pytest
+
+from golden_util import CASES, load
+from microclimf_amd.api import runmicro1Cpp, runmicro2Cpp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_hip_reproduces_golden(name):
+    a, af, expect = load(name)
+    if af:
+        a["lats"], a["lons"] = a.pop("lat"), a.pop("lon")
+        got = runmicro2Cpp(**a)
+    else:
+        got = runmicro1Cpp(**a)
+    assert list(got) == list(expect)
+    for k, w in expect.items():
+        assert np.array_equal(np.isnan(got[k]), np.isnan(w)), k
+        fin = np.isfinite(w)
+        err = np.abs(got[k][fin] - w[fin]) / (1 + np.abs(w[fin]))
+        assert err.max() <= 1e-6, (k, err.max())     # acceptance bar is 1e-4
