@@ -20,5 +20,7 @@ def test_hip_reproduces_golden(name):
     for k, w in expect.items():
         assert np.array_equal(np.isnan(got[k]), np.isnan(w)), k
         fin = np.isfinite(w)
+        if not fin.any():          # tleaf / relhum are all-NA for reqhgt <= 0 (cpp:2300-2303)
+            continue
         err = np.abs(got[k][fin] - w[fin]) / (1 + np.abs(w[fin]))
         assert err.max() <= 1e-6, (k, err.max())     # acceptance bar is 1e-4
