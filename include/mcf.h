@@ -196,6 +196,37 @@ int mcf_plan_timer_stop(mcf_plan *plan, float *ms);
 int mcf_plan_kernel_timing(mcf_plan *plan, int32_t enable);
 int mcf_plan_kernel_stats(mcf_plan *plan, double *total_ms, int64_t *launches);
 
+/* ---- terrain pre-compute (the solver's terrain inputs, built on the device) ------
+ * Restates the R-side arithmetic of the reference's marshaller (R/internal.R):
+ *   hor   = .horizon(dtm, 15*d), d = 0..23            R/internal.R:909-925, 1144
+ *   svfa  = 0.5*cos(2*tan(mean(atan(hor))))+0.5       R/internal.R:1147-1148
+ *   wsa   = .windsheltera(dtm, zref, s)               R/internal.R:949-991
+ *   slope, aspect = terra::terrain (Horn), NA -> 0    R/internal.R:1124-1136
+ * `dtm` is the caller's row block of the raster plus `halo_north` / `halo_south` extra rows
+ * (column-major [(halo_north+rows+halo_south), cols]).  Outside the raster the reference's
+ * zero padding applies; inside it a block needs 100 halo rows for hor/svfa and
+ * 100 + 2.5*s for wsa (or every row up to the raster edge).  Outputs cover the own rows only
+ * and may be NULL individually.  rows_total = 0 means "the block is the whole raster". */
+typedef struct mcf_terrain_in {
+    int64_t rows, cols;
+    int32_t halo_north, halo_south;
+    const double *dtm;
+    double res;           /* cell size (m)                                   */
+    double zref;          /* wind-shelter height, .windsheltera's whgt       */
+    int32_t agg;          /* .windsheltera's s (0 -> 10)                     */
+    int32_t reserved0;
+    int64_t row0, rows_total;
+} mcf_terrain_in;
+
+typedef struct mcf_terrain_out {
+    double *slope, *aspect; /* [rows,cols]    degrees                        */
+    double *hor;            /* [rows,cols,24] tan(horizon angle)             */
+    double *svfa;           /* [rows,cols]                                   */
+    double *wsa;            /* [rows,cols,8]                                 */
+} mcf_terrain_out;
+
+int mcf_precompute_terrain(const mcf_terrain_in *in, const mcf_terrain_out *out, int32_t device);
+
 /* Diagnostics: evaluate one of the solver's lean device elementary functions
  * elementwise on host arrays (kind 0 exp, 1 log, 2 x/y, 3 sqrt, 4 1/x, 5 satvap
  * (cpp:480-490), 6 x^y); used by tests to bound their error against libm. */

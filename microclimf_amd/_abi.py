@@ -61,6 +61,18 @@ class Options(C.Structure):
                 ("cells_per_block", C.c_int32)]
 
 
+class TerrainIn(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("cols", C.c_int64), ("halo_north", C.c_int32),
+                ("halo_south", C.c_int32), ("dtm", c_double_p), ("res", C.c_double),
+                ("zref", C.c_double), ("agg", C.c_int32), ("reserved0", C.c_int32),
+                ("row0", C.c_int64), ("rows_total", C.c_int64)]
+
+
+class TerrainOut(C.Structure):
+    _fields_ = [("slope", c_double_p), ("aspect", c_double_p), ("hor", c_double_p),
+                ("svfa", c_double_p), ("wsa", c_double_p)]
+
+
 class Outputs(C.Structure):
     _fields_ = [("var", c_double_p * NOUT)]
 
@@ -77,6 +89,7 @@ EXPORTS = (
     "mcf_plan_belowground", "mcf_plan_sync", "mcf_plan_fetch", "mcf_plan_slot_ptr",
     "mcf_plan_timer_start", "mcf_plan_timer_stop", "mcf_plan_kernel_timing",
     "mcf_plan_kernel_stats", "mcf_plan_valid_cells", "mcf_plan_bytes", "mcf_selftest_math",
+    "mcf_precompute_terrain",
 )
 
 _lib = None
@@ -140,6 +153,8 @@ def load() -> C.CDLL:
     lib.mcf_plan_bytes.argtypes = [P]
     lib.mcf_selftest_math.restype = C.c_int
     lib.mcf_selftest_math.argtypes = [C.c_int32, c_double_p, c_double_p, c_double_p, C.c_int64, C.c_int32]
+    lib.mcf_precompute_terrain.restype = C.c_int
+    lib.mcf_precompute_terrain.argtypes = [C.POINTER(TerrainIn), C.POINTER(TerrainOut), C.c_int32]
     if lib.mcf_abi_version() != 1:
         raise McfError("libmcfhip ABI version mismatch")
     _lib = lib

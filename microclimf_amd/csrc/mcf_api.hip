@@ -45,6 +45,10 @@ double na_real_host() {
 
 }  // namespace
 
+namespace mcf {
+int api_fail(int code, const std::string& msg) { return fail(code, msg); }
+}
+
 struct mcf_plan {
     int device = 0;
     hipStream_t stream = nullptr;

@@ -1,0 +1,96 @@
+"""Host side of the on-device terrain pre-compute (include/mcf.h, mcf_precompute_terrain).
+
+`precompute_terrain(dtm, res, zref)` builds what the reference's marshaller builds in R
+before it calls the solver (R/internal.R:1124-1154): slope, aspect, hor[,,24], svfa and
+wsa[,,8].  `precompute_terrain_tiled` does the same for one rank's row block of a larger
+raster: the +-100-cell stencil (and the wind-shelter smoothing) needs HALO rows from the
+neighbouring ranks, exchanged point-to-point with torch.distributed (RCCL send/recv over
+xGMI when the backend is nccl; gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+HALO = 128          # >= 100 + 2.5 * s for s = 10
+WHAT = ("slope", "aspect", "hor", "svfa", "wsa")
+
+
+def precompute_terrain(dtm, res: float, zref: float, *, agg: int = 10, halo_north: int = 0,
+                       halo_south: int = 0, row0: int = 0, rows_total: int = 0, what=WHAT, device: int = 0):
+    """dtm: [(halo_north + rows + halo_south), cols] elevations (NaN = NA)."""
+    lib = _abi.load()
+    z = np.asfortranarray(np.asarray(dtm, dtype=np.float64))
+    rb, cols = z.shape
+    rows = rb - halo_north - halo_south
+    tin = _abi.TerrainIn()
+    tin.rows, tin.cols = rows, cols
+    tin.halo_north, tin.halo_south = halo_north, halo_south
+    tin.dtm = z.ctypes.data_as(_abi.c_double_p)
+    tin.res, tin.zref, tin.agg = float(res), float(zref), int(agg)
+    tin.row0, tin.rows_total = int(row0), int(rows_total)
+    shapes = {"slope": (rows, cols), "aspect": (rows, cols), "hor": (rows, cols, 24),
+              "svfa": (rows, cols), "wsa": (rows, cols, 8)}
+    tout = _abi.TerrainOut()
+    res_arrays = {}
+    for k in WHAT:
+        if k in what:
+            a = np.empty(shapes[k], dtype=np.float64, order="F")
+            res_arrays[k] = a
+            setattr(tout, k, a.ctypes.data_as(_abi.c_double_p))
+        else:
+            setattr(tout, k, None)
+    _abi.check(lib.mcf_precompute_terrain(C.byref(tin), C.byref(tout), device))
+    return res_arrays
+
+
+def exchange_halo(block: np.ndarray, rank: int, world: int, halo: int = HALO, device=None):
+    """Returns (extended block, halo_north, halo_south): up to `halo` rows from each neighbouring
+    rank's block (row blocks are ordered north to south by rank).  Point-to-point
+    isend/irecv between ring neighbours only; nothing is exchanged across the raster's edge."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return block, 0, 0
+    if device is None:
+        device = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    rows, cols = block.shape
+    # every rank learns its neighbours' row counts (they cap the halo actually available)
+    counts = torch.zeros(world, dtype=torch.int64, device=device)
+    counts[rank] = rows
+    dist.all_reduce(counts)
+    counts = [int(v) for v in counts.tolist()]
+    t = torch.from_numpy(np.ascontiguousarray(block)).to(device)      # [rows, cols] row-major
+    ops, recv_n, recv_s = [], None, None
+    if rank > 0:
+        hn = min(halo, counts[rank - 1])
+        recv_n = torch.empty((hn, cols), dtype=torch.float64, device=device)
+        ops.append(dist.P2POp(dist.irecv, recv_n, rank - 1))
+        ops.append(dist.P2POp(dist.isend, t[:min(halo, rows)].contiguous(), rank - 1))
+    if rank < world - 1:
+        hs = min(halo, counts[rank + 1])
+        recv_s = torch.empty((hs, cols), dtype=torch.float64, device=device)
+        ops.append(dist.P2POp(dist.isend, t[max(rows - halo, 0):].contiguous(), rank + 1))
+        ops.append(dist.P2POp(dist.irecv, recv_s, rank + 1))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    parts, hn, hs = [], 0, 0
+    if recv_n is not None:
+        parts.append(recv_n.cpu().numpy()); hn = recv_n.shape[0]
+    parts.append(np.asarray(block))
+    if recv_s is not None:
+        parts.append(recv_s.cpu().numpy()); hs = recv_s.shape[0]
+    return np.concatenate(parts, axis=0), hn, hs
+
+
+def precompute_terrain_tiled(block, res, zref, rank, world, row0, rows_total, *, agg=10, what=WHAT,
+                             device=0, compute=precompute_terrain):
+    """One rank's share of the terrain pre-compute: halo exchange, then the local kernels.
+    `compute` is injectable so that the CPU tests can put the numpy oracle behind the same
+    exchange."""
+    ext, hn, hs = exchange_halo(np.asarray(block, dtype=np.float64), rank, world)
+    return compute(ext, res, zref, agg=agg, halo_north=hn, halo_south=hs, row0=row0,
+                   rows_total=rows_total, what=what, device=device)
