@@ -10,6 +10,8 @@
  *   mcf_runmicro2()  replaces  _microclimf_runmicro2Cpp   src/RcppExports.cpp:275-297
  *                    (R stub   runmicro2Cpp               R/RcppExports.R:76-78,
  *                     body     runmicro2Cpp               src/microclimfCpp.cpp:2340-2621)
+ *   mcf_runmicro3/4() replace  _microclimf_runmicro3Cpp/4Cpp (time-varying vegetation,
+ *                     bodies src/microclimfCpp.cpp:2624-3226), R stubs R/RcppExports.R:80-86
  *
  * Everything is plain pointers + sizes; no R, Rcpp or torch types.  All arrays
  * are IEEE fp64, column-major with the raster row as the fastest index, exactly
@@ -96,7 +98,9 @@ typedef struct mcf_pointm {
     const double *soilm, *Tg, *Tbp, *G, *umu, *kp, *muGp, *dtrp;
 } mcf_pointm;
 
-/* vegp list (src/microclimfCpp.cpp:2084-2094), each [rows,cols]. */
+/* vegp list (src/microclimfCpp.cpp:2084-2094), each [rows,cols]; with time-varying
+ * vegetation (runmicro3Cpp / runmicro4Cpp, src/microclimfCpp.cpp:2667-2679) each is
+ * [rows,cols,veg_layers]. */
 typedef struct mcf_vegp {
     const double *hgt, *pai, *x, *gsmax, *leafr, *leaft, *clump, *leafd, *paia, *leafden;
 } mcf_vegp;
@@ -112,8 +116,8 @@ typedef struct mcf_soilc {
 
 typedef struct mcf_grid_inputs {
     int64_t rows, cols, tsteps;
-    int32_t array_forcing; /* 0: runmicro1Cpp geometry, 1: runmicro2Cpp geometry */
-    int32_t reserved0;
+    int32_t array_forcing; /* 0: runmicro1Cpp/3Cpp geometry, 1: runmicro2Cpp/4Cpp geometry */
+    int32_t veg_layers;    /* 0 or 1: static vegetation; >1: runmicro3Cpp/4Cpp `dfsel` layers    */
     mcf_obstime obstime;
     mcf_climate clim;
     mcf_pointm pointm;
@@ -121,6 +125,9 @@ typedef struct mcf_grid_inputs {
     mcf_soilc soilc;
     double lat, lon;           /* vector forcing (runmicro1Cpp args lat, lon)            */
     const double *lats, *lons; /* array forcing  (runmicro2Cpp args lats, lons), [rows,cols] */
+    /* dfsel of runmicro3Cpp/4Cpp (src/microclimfCpp.cpp:2629-2640): layer l drives the steps
+     * lyr_st[l] .. lyr_ed[l] (0-based, whole days); NULL when veg_layers <= 1 */
+    const int32_t *lyr_st, *lyr_ed;
 } mcf_grid_inputs;
 
 typedef struct mcf_options {
@@ -148,6 +155,12 @@ int mcf_device_count(void);
 /* One-shot host-to-host solves. */
 int mcf_runmicro1(const mcf_grid_inputs *in, const mcf_options *opt, mcf_outputs *out);
 int mcf_runmicro2(const mcf_grid_inputs *in, const mcf_options *opt, mcf_outputs *out);
+/* Time-varying vegetation: replace _microclimf_runmicro3Cpp / _microclimf_runmicro4Cpp
+ * (src/RcppExports.cpp:300-322 / 326-348; bodies src/microclimfCpp.cpp:2624-2924 / 2926-3226).
+ * Same physics with the vegetation layer chosen per day from `dfsel`; steps outside every
+ * layer's range stay NA. */
+int mcf_runmicro3(const mcf_grid_inputs *in, const mcf_options *opt, mcf_outputs *out);
+int mcf_runmicro4(const mcf_grid_inputs *in, const mcf_options *opt, mcf_outputs *out);
 
 /* ---- plan API: HBM-resident inputs, device output ring ---------------------- */
 typedef struct mcf_plan mcf_plan;

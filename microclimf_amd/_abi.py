@@ -45,11 +45,12 @@ Soilc = _ptr_struct("Soilc", SOILC_FIELDS)
 
 class GridInputs(C.Structure):
     _fields_ = [("rows", C.c_int64), ("cols", C.c_int64), ("tsteps", C.c_int64),
-                ("array_forcing", C.c_int32), ("reserved0", C.c_int32),
+                ("array_forcing", C.c_int32), ("veg_layers", C.c_int32),
                 ("obstime", Obstime), ("clim", Climate), ("pointm", Pointm),
                 ("vegp", Vegp), ("soilc", Soilc),
                 ("lat", C.c_double), ("lon", C.c_double),
-                ("lats", c_double_p), ("lons", c_double_p)]
+                ("lats", c_double_p), ("lons", c_double_p),
+                ("lyr_st", c_int32_p), ("lyr_ed", c_int32_p)]
 
 
 class Options(C.Structure):
@@ -83,7 +84,7 @@ LIB_PATH = _PKG_DIR / "csrc" / "libmcfhip.so"
 # every symbol include/mcf.h declares (tests check the .so exports all of them)
 EXPORTS = (
     "mcf_abi_version", "mcf_last_error", "mcf_device_count",
-    "mcf_runmicro1", "mcf_runmicro2",
+    "mcf_runmicro1", "mcf_runmicro2", "mcf_runmicro3", "mcf_runmicro4",
     "mcf_plan_create", "mcf_plan_destroy", "mcf_plan_twi_partial",
     "mcf_plan_set_twi_mean", "mcf_plan_upload_forcing_days", "mcf_plan_run_days",
     "mcf_plan_belowground", "mcf_plan_sync", "mcf_plan_fetch", "mcf_plan_slot_ptr",
@@ -115,7 +116,7 @@ def load() -> C.CDLL:
     lib.mcf_last_error.restype = C.c_char_p
     lib.mcf_device_count.restype = C.c_int
     GI, OP, OU = C.POINTER(GridInputs), C.POINTER(Options), C.POINTER(Outputs)
-    for fn in (lib.mcf_runmicro1, lib.mcf_runmicro2):
+    for fn in (lib.mcf_runmicro1, lib.mcf_runmicro2, lib.mcf_runmicro3, lib.mcf_runmicro4):
         fn.restype = C.c_int
         fn.argtypes = [GI, OP, OU]
     P = C.c_void_p

@@ -24,10 +24,10 @@ from .marshal import Marshalled, alloc_outputs, marshal
 
 
 def _run(fn_name, array_forcing, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon,
-         Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block):
+         Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block, dfsel=None):
     lib = _abi.load()
     m = marshal(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp,
-                tfact, complete, mat, out, array_forcing, device, days_per_chunk, cells_per_block)
+                tfact, complete, mat, out, array_forcing, device, days_per_chunk, cells_per_block, dfsel)
     outs, arrays = alloc_outputs(m)
     _abi.check(getattr(lib, fn_name)(C.byref(m.inputs), C.byref(m.options), C.byref(outs)))
     return arrays
@@ -55,17 +55,38 @@ def runmicro2Cpp(obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Map
                 Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block)
 
 
+def runmicro3Cpp(dfsel: Mapping, obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Mapping,
+                 soilc: Mapping, reqhgt: float, zref: float, lat: float, lon: float, Sminp: float,
+                 Smaxp: float, tfact: float, complete: bool, mat: float, out: Sequence, *, device: int = 0,
+                 days_per_chunk: int = 0, cells_per_block: int = 0) -> dict:
+    """Hourly, changing vegetation, data.frame climate: drop-in for the reference's runmicro3Cpp
+    (src/microclimfCpp.cpp:2624-2924).  `dfsel` has columns lyr, st, ed (0-based step ranges of
+    each vegetation layer, R/internal.R:1391-1399); vegp entries are [rows, cols, layers]."""
+    return _run("mcf_runmicro3", False, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon,
+                Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block, dfsel)
+
+
+def runmicro4Cpp(dfsel: Mapping, obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Mapping,
+                 soilc: Mapping, reqhgt: float, zref: float, lats, lons, Sminp: float, Smaxp: float,
+                 tfact: float, complete: bool, mat: float, out: Sequence, *, device: int = 0,
+                 days_per_chunk: int = 0, cells_per_block: int = 0) -> dict:
+    """Hourly, changing vegetation, array climate: drop-in for the reference's runmicro4Cpp
+    (src/microclimfCpp.cpp:2926-3226)."""
+    return _run("mcf_runmicro4", True, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons,
+                Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block, dfsel)
+
+
 class Plan:
     """HBM-resident solver plan (include/mcf.h plan API): inputs uploaded once,
     day chunks solved into a device output ring."""
 
     def __init__(self, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp,
                  tfact, complete, mat, out, *, array_forcing=False, ring_days=1, ring_slots=1,
-                 device=0, cells_per_block=0):
+                 device=0, cells_per_block=0, dfsel=None):
         self._lib = _abi.load()
         self._m: Marshalled = marshal(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon,
                                       Sminp, Smaxp, tfact, complete, mat, out, array_forcing, device,
-                                      0, cells_per_block)
+                                      0, cells_per_block, dfsel)
         self._p = C.c_void_p()
         _abi.check(self._lib.mcf_plan_create(C.byref(self._m.inputs), C.byref(self._m.options),
                                              int(ring_days), int(ring_slots), C.byref(self._p)))

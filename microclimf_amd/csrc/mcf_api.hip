@@ -57,6 +57,8 @@ struct mcf_plan {
     int ndays = 0;
     bool af = false, bg = false;
     int cpb = 16;
+    int layers = 1;
+    int32_t* d_daylayer = nullptr;
     mcf_options opt{};
     mcf::Globals g{};
     int hiy = 8760;
@@ -128,6 +130,16 @@ int check_inputs(const mcf_grid_inputs* in, const mcf_options* opt) {
     if (in->tsteps > 0 && (!in->obstime.year || !in->obstime.month || !in->obstime.day || !in->obstime.hour))
         return fail(MCF_ERR_ARG, "obstime columns missing");
     if (in->array_forcing && (!in->lats || !in->lons)) return fail(MCF_ERR_ARG, "lats/lons missing");
+    if (in->veg_layers > 1) {
+        if (!in->lyr_st || !in->lyr_ed) return fail(MCF_ERR_ARG, "dfsel (lyr_st / lyr_ed) missing");
+        for (int l = 0; l < in->veg_layers; ++l) {
+            int span = in->lyr_ed[l] - in->lyr_st[l] + 1;
+            if (span < 24)      // the reference's Rcpp::stop, src/microclimfCpp.cpp:2636-2637
+                return fail(MCF_ERR_ARG, "Too many layers in vegp. Max layers must be <= max days");
+            if (in->lyr_st[l] < 0 || in->lyr_st[l] % 24 != 0 || in->lyr_st[l] + (span / 24) * 24 > in->tsteps)
+                return fail(MCF_ERR_ARG, "dfsel: layer ranges must start on whole days inside the series");
+        }
+    }
     if (!(opt->cells_per_block == 0 || opt->cells_per_block == 16 || opt->cells_per_block == 32))
         return fail(MCF_ERR_ARG, "cells_per_block must be 0, 16 or 32");
     return MCF_OK;
@@ -157,11 +169,14 @@ const char* kRawNames[15] = {"tc", "es", "ea", "tdew", "pk", "swdown", "difrad",
 
 int ensure_cells(mcf_plan* p) {
     if (p->cells_ready) return MCF_OK;
+  for (int l = 0; l < p->layers; ++l) {
     mcf::CellSetupArgs a{};
     a.N = p->N;
-    a.hgt = p->d_veg[0]; a.pai = p->d_veg[1]; a.x = p->d_veg[2]; a.gsmax = p->d_veg[3];
-    a.leafr = p->d_veg[4]; a.leaft = p->d_veg[5]; a.clump = p->d_veg[6]; a.leafd = p->d_veg[7];
-    a.paia = p->d_veg[8]; a.leafden = p->d_veg[9];
+    const int64_t lo = (int64_t)l * p->N;      // layer l of the [rows,cols,layers] vegetation arrays
+    a.hgt = p->d_veg[0] + lo; a.pai = p->d_veg[1] + lo; a.x = p->d_veg[2] + lo; a.gsmax = p->d_veg[3] + lo;
+    a.leafr = p->d_veg[4] + lo; a.leaft = p->d_veg[5] + lo; a.clump = p->d_veg[6] + lo; a.leafd = p->d_veg[7] + lo;
+    a.paia = p->d_veg[8] + lo; a.leafden = p->d_veg[9] + lo;
+    a.hgt0 = p->d_veg[0];
     a.Smin = p->d_soil[0]; a.Smax = p->d_soil[1]; a.gref = p->d_soil[2]; a.soilb = p->d_soil[3];
     a.Psie = p->d_soil[4]; a.Vq = p->d_soil[5]; a.Vm = p->d_soil[6]; a.Mc = p->d_soil[7];
     a.rho = p->d_soil[8]; a.slope = p->d_soil[9]; a.aspect = p->d_soil[10]; a.twi = p->d_soil[11];
@@ -170,9 +185,10 @@ int ensure_cells(mcf_plan* p) {
     a.tfact = p->opt.tfact;
     a.twi_mean = p->twi_mean;
     a.g = p->g;
-    a.cellc = p->d_cellc;
+    a.cellc = p->d_cellc + (int64_t)l * mcf::cell_field_count() * p->N;
     mcf::launch_cell_setup(a, p->stream);
     HIP_TRY(hipGetLastError());
+  }
     p->cells_ready = true;
     return MCF_OK;
 }
@@ -220,6 +236,7 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
     p->af = in->array_forcing != 0;
     p->bg = opt->reqhgt < 0.0;
     p->cpb = opt->cells_per_block ? opt->cells_per_block : 32;
+    p->layers = in->veg_layers > 1 ? in->veg_layers : 1;
     p->opt = *opt;
     p->lat = in->lat; p->lon = in->lon;
     const int64_t N = p->N, T = p->tsteps;
@@ -235,7 +252,7 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
                              in->vegp.leaft, in->vegp.clump, in->vegp.leafd, in->vegp.paia, in->vegp.leafden};
     const char* vegn[10] = {"hgt", "pai", "x", "gsmax", "leafr", "leaft", "clump", "leafd", "paia", "leafden"};
     for (int i = 0; i < 10; ++i)
-        if ((rc = upload(p, veg[i], N, &p->d_veg[i], vegn[i]))) return rc;
+        if ((rc = upload(p, veg[i], N * p->layers, &p->d_veg[i], vegn[i]))) return rc;
     const double* soil[13] = {in->soilc.Smin, in->soilc.Smax, in->soilc.gref, in->soilc.soilb, in->soilc.Psie,
                               in->soilc.Vq, in->soilc.Vm, in->soilc.Mc, in->soilc.rho, in->soilc.slope,
                               in->soilc.aspect, in->soilc.twi, in->soilc.svfa};
@@ -275,8 +292,20 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
     p->twi_count = (int64_t)h2[1];
     p->twi_mean = h2[0] / h2[1];
 
-    if ((rc = dalloc(p, &tmp, (int64_t)mcf::cell_field_count() * N * 8))) return rc;
+    if ((rc = dalloc(p, &tmp, (int64_t)p->layers * mcf::cell_field_count() * N * 8))) return rc;
     p->d_cellc = (double*)tmp;
+    if (p->layers > 1) {
+        // day -> layer map from dfsel (cpp:2629-2640, k = dy*24 + hr + st[lyr]); -1 = not covered
+        std::vector<int32_t> dl((size_t)std::max(p->ndays, 1), -1);
+        for (int l = 0; l < p->layers; ++l) {
+            int nd = (in->lyr_ed[l] - in->lyr_st[l] + 1) / 24, d0 = in->lyr_st[l] / 24;
+            for (int d = d0; d < d0 + nd && d < p->ndays; ++d) dl[d] = l;
+        }
+        if ((rc = dalloc(p, &tmp, (int64_t)dl.size() * 4))) return rc;
+        p->d_daylayer = (int32_t*)tmp;
+        HIP_TRY(hipMemcpyAsync(p->d_daylayer, dl.data(), dl.size() * 4, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+    }
 
     // ---- time tables
     const double* raw[15];
@@ -437,6 +466,7 @@ int mcf_plan_run_days(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot) {
     mcf::SolveArgs a{};
     a.N = p->N;
     a.cellc = p->d_cellc; a.hor = p->d_hor; a.wsa = p->d_wsa; a.tt = p->d_tt;
+    a.daylayer = p->d_daylayer;
     const int64_t cap = p->N * (int64_t)p->ring_days * 24;
     if (p->af) {
         if (p->force_day0[slot] != day0 || p->force_ndays[slot] < ndays)
@@ -652,6 +682,14 @@ int mcf_runmicro1(const mcf_grid_inputs* in, const mcf_options* opt, mcf_outputs
     return run_oneshot(in, opt, out, 0);
 }
 int mcf_runmicro2(const mcf_grid_inputs* in, const mcf_options* opt, mcf_outputs* out) {
+    return run_oneshot(in, opt, out, 1);
+}
+int mcf_runmicro3(const mcf_grid_inputs* in, const mcf_options* opt, mcf_outputs* out) {
+    if (in && in->veg_layers < 1) return fail(MCF_ERR_ARG, "mcf_runmicro3 needs veg_layers >= 1 and dfsel");
+    return run_oneshot(in, opt, out, 0);
+}
+int mcf_runmicro4(const mcf_grid_inputs* in, const mcf_options* opt, mcf_outputs* out) {
+    if (in && in->veg_layers < 1) return fail(MCF_ERR_ARG, "mcf_runmicro4 needs veg_layers >= 1 and dfsel");
     return run_oneshot(in, opt, out, 1);
 }
 

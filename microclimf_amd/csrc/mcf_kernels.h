@@ -18,6 +18,7 @@ struct CellSetupArgs {
     int64_t N;
     // vegp
     const double *hgt, *pai, *x, *gsmax, *leafr, *leaft, *clump, *leafd, *paia, *leafden;
+    const double* hgt0;  // layer-0 height: the NA test of the cell (cpp:2182 / 2759)
     // soilc
     const double *Smin, *Smax, *gref, *soilb, *Psie, *Vq, *Vm, *Mc, *rho, *slope, *aspect, *twi, *svfa;
     const double *lats, *lons;  // array forcing, else null
@@ -48,7 +49,8 @@ struct DateSetupArgs {
 
 struct SolveArgs {
     int64_t N;
-    const double* cellc;  // [CF_COUNT][N]
+    const double* cellc;  // [layers][CF_COUNT][N]
+    const int32_t* daylayer;  // [ndays] vegetation layer of each day, -1: no layer covers it; null: layer 0
     const double* hor;    // [24][N]
     const double* wsa;    // [8][N]
     const double* tt;     // vector forcing: [ndays][TF_COUNT][24]

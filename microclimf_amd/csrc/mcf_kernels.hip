@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_cell_setup(CellSetupArgs a) {
     const double hgt = a.hgt[c], pai = a.pai[c], x = a.x[c], lref = a.leafr[c], ltra = a.leaft[c],
                  clump = a.clump[c], gref = a.gref[c], paia = a.paia[c];
     int flags = 0;
-    if (!isnan(hgt)) flags |= FL_VALID;
+    if (!isnan(a.hgt0[c])) flags |= FL_VALID;
     if (pai > 0.0) flags |= FL_PAI;
     if (!(a.g.reqhgt2 >= hgt)) flags |= FL_BELOW;
     if (x == 1.0) flags |= FL_XONE;
@@ -369,12 +369,7 @@ __global__ __launch_bounds__(CPB * 24, MCF_WAVES_PER_EU) void k_solve(SolveArgs 
     const int64_t c = c0 + cl;
     const bool in_grid = c < N;
 
-    // ---- stage the tile's cell constants and direction tables in LDS
-    for (int q = tid; q < CF_COUNT * CPB; q += NT) {
-        int f = q / CPB, l = q % CPB;
-        int64_t cc = c0 + l;
-        s_cell[q] = cc < N ? a.cellc[(int64_t)f * N + cc] : 0.0;
-    }
+    // ---- stage the tile's direction tables and the first day's time table in LDS
     for (int q = tid; q < kCellDirs * CPB; q += NT) {
         int dI = q / CPB, l = q % CPB;
         int64_t cc = c0 + l;
@@ -386,11 +381,11 @@ __global__ __launch_bounds__(CPB * 24, MCF_WAVES_PER_EU) void k_solve(SolveArgs 
         const double* src = a.tt + (int64_t)a.day0 * TF_COUNT * 24;
         for (int q = tid; q < TF_COUNT * 24; q += NT) s_time[q] = src[q];
     }
-    __syncthreads();
 
     CellLds<CPB> C{s_cell, s_dirs, cl};
-    const int flags = in_grid ? (int)s_cell[CF_FLAGS * CPB + cl] : 0;
-    const bool valid = (flags & FL_VALID) != 0;
+    int flags = 0;
+    bool valid = false;
+    int cur_layer = -2;
     Globals g = a.g;
     double dTmx = g.dTmx;
     if (AF && in_grid) dTmx = -0.6273 * a.mxtc[c] + 49.79;   // cpp:1236 with the per-cell mxtc
@@ -399,6 +394,24 @@ __global__ __launch_bounds__(CPB * 24, MCF_WAVES_PER_EU) void k_solve(SolveArgs 
 
     for (int dl = 0; dl < a.ndays; ++dl) {
         const int dabs = a.day0 + dl;
+        // vegetation layer of this day (runmicro3Cpp/4Cpp `dfsel`, cpp:2760-2768); the tile's cell
+        // constants are (re)staged whenever it changes — a workgroup-uniform, rare event
+        const int layer = a.daylayer ? a.daylayer[dabs] : 0;
+        if (layer != cur_layer) {
+            __syncthreads();
+            if (layer >= 0) {
+                const double* src = a.cellc + (int64_t)layer * CF_COUNT * N;
+                for (int q = tid; q < CF_COUNT * CPB; q += NT) {
+                    int f = q / CPB, l = q % CPB;
+                    int64_t cc = c0 + l;
+                    s_cell[q] = cc < N ? src[(int64_t)f * N + cc] : 0.0;
+                }
+            }
+            __syncthreads();
+            cur_layer = layer;
+            flags = (in_grid && layer >= 0) ? (int)s_cell[CF_FLAGS * CPB + cl] : 0;
+            valid = (flags & FL_VALID) != 0;
+        }
         const int64_t kl = (int64_t)dl * 24 + hr;            // step within the slot
         const int64_t oidx = c + N * (a.slot_step0 + kl);
         auto put = [&](int v, double val) {
@@ -504,7 +517,6 @@ __global__ __launch_bounds__(CPB * 24, MCF_WAVES_PER_EU) void k_solve(SolveArgs 
                 put(9, p2.lwup);                      // cpp:2299
             }
         } else if (in_grid) {
-            if (BG) a.tgser[c + N * ((int64_t)dabs * 24 + hr)] = NA;
             if (!BG) put(0, NA);
             put(1, NA);
             put(2, NA);

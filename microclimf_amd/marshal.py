@@ -54,12 +54,20 @@ def marshal(obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Mapping,
             soilc: Mapping, reqhgt: float, zref: float, lat, lon, Sminp: float,
             Smaxp: float, tfact: float, complete: bool, mat: float,
             out: Sequence, array_forcing: bool, device: int = 0,
-            days_per_chunk: int = 0, cells_per_block: int = 0) -> Marshalled:
+            days_per_chunk: int = 0, cells_per_block: int = 0, dfsel: Mapping | None = None) -> Marshalled:
     m = Marshalled()
     hgt = np.asarray(vegp["hgt"], dtype=np.float64)
-    if hgt.ndim != 2:
-        raise ValueError("vegp$hgt must be a rows x cols matrix")
-    R, Cc = hgt.shape
+    if dfsel is None:
+        if hgt.ndim != 2:
+            raise ValueError("vegp$hgt must be a rows x cols matrix")
+        L = 1
+    else:                       # runmicro3Cpp/4Cpp: vegetation arrays are [rows, cols, layers]
+        if hgt.ndim != 3:
+            raise ValueError("vegp$hgt must be a rows x cols x layers array")
+        L = hgt.shape[2]
+        if len(np.asarray(dfsel["st"])) != L:
+            raise ValueError("dfsel must have one row per vegetation layer")
+    R, Cc = hgt.shape[:2]
     T = len(np.asarray(obstime["year"]))
     m.rows, m.cols, m.tsteps = R, Cc, T
     gi = m.inputs
@@ -86,7 +94,14 @@ def marshal(obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Mapping,
             src = np.full(fshape, float(src))
         setattr(gi.pointm, f, m._f64(src, fshape, f"pointm${f}"))
     for f in _abi.VEGP_FIELDS:
-        setattr(gi.vegp, f, m._f64(vegp[f], (R, Cc), f"vegp${f}"))
+        setattr(gi.vegp, f, m._f64(vegp[f], (R, Cc) if dfsel is None else (R, Cc, L), f"vegp${f}"))
+    if dfsel is None:
+        gi.veg_layers = 0
+        gi.lyr_st = gi.lyr_ed = None
+    else:
+        gi.veg_layers = L
+        gi.lyr_st = m._i32(dfsel["st"], L, "dfsel$st")
+        gi.lyr_ed = m._i32(dfsel["ed"], L, "dfsel$ed")
     for f in _abi.SOILC_FIELDS:
         shape = (R, Cc, 8) if f == "wsa" else (R, Cc, 24) if f == "hor" else (R, Cc)
         setattr(gi.soilc, f, m._f64(soilc[f], shape, f"soilc${f}"))

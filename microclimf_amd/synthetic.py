@@ -236,3 +236,31 @@ def workload(rows: int, cols: int, tsteps: int, reqhgt: float = 0.05, zref: floa
         lons = lon + 0.01 * (fj / max(cols, 1)) + 0 * fi
         args.update(climdata=clim2, pointm=pm2, lat=lats, lon=lons)
     return args
+
+
+def layered(args: dict, layers: int, cover_days: int | None = None, seed=SEED):
+    """Turns a static-vegetation workload into a runmicro3Cpp/4Cpp one: `layers` vegetation layers
+    (pai / hgt / x scaled per layer) and the `dfsel` table that deals whole days to them
+    (R/internal.R:1391-1399).  `cover_days` < total days leaves the tail uncovered."""
+    a = dict(args)
+    T = len(a["obstime"]["year"])
+    ndays = T // 24 if cover_days is None else cover_days
+    rows, cols = np.shape(a["vegp"]["hgt"])
+    veg = {}
+    for k, v in a["vegp"].items():
+        stack = []
+        for l in range(layers):
+            f = 1.0
+            if k == "pai" or k == "paia":
+                f = 0.6 + 0.8 * l / max(layers - 1, 1)
+            elif k == "hgt":
+                f = 0.9 + 0.2 * l / max(layers - 1, 1)
+            stack.append(v * f)
+        veg[k] = np.stack(stack, axis=2)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        veg["leafden"] = veg["pai"] / veg["hgt"]
+    veg["paia"] = np.where(a["reqhgt"] < veg["hgt"], veg["paia"], 0.0)
+    a["vegp"] = veg
+    edges = np.linspace(0, ndays, layers + 1).round().astype(int)
+    a["dfsel"] = {"lyr": np.arange(1, layers + 1), "st": edges[:-1] * 24, "ed": edges[1:] * 24 - 1}
+    return a

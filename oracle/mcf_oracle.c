@@ -879,6 +879,8 @@ int orc_run_grid(const mcf_grid_inputs *in, const mcf_options *opt, mcf_outputs 
     const int tsteps = (int)in->tsteps;
     const int ndays = tsteps / 24;
     const int af = in->array_forcing;
+    const int layered = in->veg_layers > 1;
+    const int nlyrs = layered ? in->veg_layers : 1;
     const double reqhgt = opt->reqhgt, zref = opt->zref;
     const double na = orc_na_real();
     double *O[MCF_NOUT];
@@ -915,11 +917,8 @@ int orc_run_grid(const mcf_grid_inputs *in, const mcf_options *opt, mcf_outputs 
     for (int64_t i = 0; i < rows; ++i) {
         for (int64_t j = 0; j < cols; ++j) {
             const int64_t c = i + rows * j;
-            if (isnan(V->hgt[c])) continue;
-            const double hgt = V->hgt[c], pai = V->pai[c], x = V->x[c], gref = S->gref[c];
-            tir_t tir = twostreamdif(pai, V->paia[c], x, V->leafr[c], V->leaft[c], V->clump[c], gref);
-            stomp_t st = stomparams(hgt, af ? in->lats[c] : in->lat, x);
-            tiw_t tiw = windti(hgt, pai);
+            if (isnan(V->hgt[c])) continue;   /* layer 0 decides, cpp:2182 / 2759 */
+            const double gref = S->gref[c];
             soilp_t spa;
             spa.Smax = S->Smax[c]; spa.Smin = S->Smin[c]; spa.soilb = S->soilb[c]; spa.psi_e = S->Psie[c];
             spa.Vq = S->Vq[c]; spa.Vm = S->Vm[c]; spa.Mc = S->Mc[c]; spa.rho = S->rho[c];
@@ -932,12 +931,22 @@ int orc_run_grid(const mcf_grid_inputs *in, const mcf_options *opt, mcf_outputs 
                 for (int k = 0; k < tsteps; ++k)
                     if (in->clim.tc[c + N * k] > mxtc) mxtc = in->clim.tc[c + N * k];
             }
-            for (int dy = 0; dy < ndays; ++dy) {
+            /* runmicro3Cpp/4Cpp (cpp:2760-2768, 3062-3070): one pass per vegetation layer over the
+             * days dfsel assigns to it; with static vegetation a single layer covers every day */
+            for (int lyr = 0; lyr < nlyrs; ++lyr) {
+            const int64_t cl = c + N * lyr;
+            const double hgt = V->hgt[cl], pai = V->pai[cl], x = V->x[cl];
+            tir_t tir = twostreamdif(pai, V->paia[cl], x, V->leafr[cl], V->leaft[cl], V->clump[cl], gref);
+            stomp_t st = stomparams(hgt, af ? in->lats[c] : in->lat, x);
+            tiw_t tiw = windti(hgt, pai);
+            const int lst = layered ? in->lyr_st[lyr] : 0;
+            const int lnd = layered ? (in->lyr_ed[lyr] - in->lyr_st[lyr] + 1) / 24 : ndays;
+            for (int dy = 0; dy < lnd; ++dy) {
                 double Rmx = -999.9, tmx = -999.0, tmn = 999.0;
                 double surfwet[24], radabs[24], soilmday[24], radCsw[24], radClw[24], Rddown[24], Rbdown[24],
                     radLsw[24], radLpar[24], uf[24], uzday[24], gHa[24], zendday[24];
                 for (int hr = 0; hr < 24; ++hr) {
-                    const int k = dy * 24 + hr;
+                    const int k = dy * 24 + hr + lst;
                     const int64_t idx = c + N * k;
                     const int64_t f = af ? idx : k; /* forcing index */
                     orc_solmodel solp;
@@ -965,7 +974,7 @@ int orc_run_grid(const mcf_grid_inputs *in, const mcf_options *opt, mcf_outputs 
                     orc_kstruct kpp = orc_cank(solp.zenr, x, si);
                     tsdir_t tsd = twostreamdir_params(tir.pait, tir.om, tir.a, tir.gma, tir.J, tir.del, tir.h,
                                                       gref, kpp.kd, tir.u1, tir.S1, tir.D1, tir.D2);
-                    rad_t rm = twostream(pai, V->clump[c], gref, S->svfa[c], si, in->clim.tc[f],
+                    rad_t rm = twostream(pai, V->clump[cl], gref, S->svfa[c], si, in->clim.tc[f],
                                          in->clim.swdown[f], in->clim.difrad[f], in->clim.lwdown[f], solp, kpp,
                                          tsd, tir);
                     radCsw[hr] = rm.radCsw; radClw[hr] = rm.radClw; Rddown[hr] = rm.Rddown;
@@ -989,7 +998,7 @@ int orc_run_grid(const mcf_grid_inputs *in, const mcf_options *opt, mcf_outputs 
                 }
                 double dtr = tmx - tmn;
                 for (int hr = 0; hr < 24; ++hr) {
-                    const int k = dy * 24 + hr;
+                    const int k = dy * 24 + hr + lst;
                     const int64_t idx = c + N * k;
                     const int64_t f = af ? idx : k;
                     soilhr_t gv = soiltemp_hr(in->clim.tc[f], in->clim.es[f], in->clim.ea[f], in->clim.pk[f],
@@ -1011,8 +1020,8 @@ int orc_run_grid(const mcf_grid_inputs *in, const mcf_options *opt, mcf_outputs 
                         above_t tv = TVaboveground(reqhgt2, zref, in->clim.tc[f], in->clim.pk[f], in->clim.ea[f],
                                                    in->clim.es[f], in->clim.tdew[f], in->clim.swdown[f],
                                                    in->clim.difrad[f], in->clim.lwdown[f], soilmday[hr], hgt, pai,
-                                                   V->paia[c], x, V->leafd[c], V->leafden[c], S->Smin[c],
-                                                   S->Smax[c], S->Psie[c], S->soilb[c], V->gsmax[c], mxtc, st,
+                                                   V->paia[cl], x, V->leafd[cl], V->leafden[cl], S->Smin[c],
+                                                   S->Smax[c], S->Psie[c], S->soilb[c], V->gsmax[cl], mxtc, st,
                                                    tir, rv, tiw, wv, gv);
                         if (reqhgt > 0.0) {
                             if (O[MCF_OUT_TZ]) O[MCF_OUT_TZ][idx] = tv.Tz;
@@ -1028,6 +1037,7 @@ int orc_run_grid(const mcf_grid_inputs *in, const mcf_options *opt, mcf_outputs 
                     }
                 }
             }
+            } /* layers */
             if (reqhgt < 0.0 && O[MCF_OUT_TZ]) { /* cpp:2307-2320 / 2587-2604 */
                 double sumD = 0.0;
                 for (int k = 0; k < tsteps; ++k) {

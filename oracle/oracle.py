@@ -70,11 +70,12 @@ def load() -> C.CDLL:
 
 
 def run_grid(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact,
-             complete, mat, out, array_forcing=False):
-    """Oracle for runmicro1Cpp (array_forcing=False) / runmicro2Cpp (True)."""
+             complete, mat, out, array_forcing=False, dfsel=None):
+    """Oracle for runmicro1Cpp (array_forcing=False) / runmicro2Cpp (True); with `dfsel`
+    the time-varying-vegetation variants runmicro3Cpp / runmicro4Cpp."""
     lib = load()
     m = marshal(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact,
-                complete, mat, out, array_forcing)
+                complete, mat, out, array_forcing, dfsel=dfsel)
     outs, arrays = alloc_outputs(m)
     rc = lib.orc_run_grid(C.byref(m.inputs), C.byref(m.options), C.byref(outs))
     if rc != 0:

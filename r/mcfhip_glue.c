@@ -4,6 +4,8 @@
  * Stands where the reference's generated Rcpp glue stands:
  *   _microclimf_runmicro1Cpp  src/RcppExports.cpp:250-272  ->  mcfhip_runmicro1
  *   _microclimf_runmicro2Cpp  src/RcppExports.cpp:275-297  ->  mcfhip_runmicro2
+ *   _microclimf_runmicro3Cpp  src/RcppExports.cpp:300-322  ->  mcfhip_runmicro3  (dfsel + the same 15)
+ *   _microclimf_runmicro4Cpp  src/RcppExports.cpp:326-348  ->  mcfhip_runmicro4
  * Same 15 arguments in the same order as R/RcppExports.R:72-78, same named-list
  * result (src/microclimfCpp.cpp:2326-2335).  Uses only R's C API (Rinternals.h);
  * no Rcpp.  NOT compiled in the build image (R is not installed there): build with
@@ -40,7 +42,7 @@ static const int *intcol(SEXP x, int *np) {   /* obstime$year etc. arrive as dou
     return INTEGER(x);
 }
 
-static SEXP run(int array_forcing, SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc,
+static SEXP run(int array_forcing, SEXP dfsel, SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc,
                 SEXP reqhgt, SEXP zref, SEXP lat, SEXP lon, SEXP Sminp, SEXP Smaxp, SEXP tfact,
                 SEXP complete, SEXP mat, SEXP out) {
     int np = 0;
@@ -51,7 +53,16 @@ static SEXP run(int array_forcing, SEXP obstime, SEXP climdata, SEXP pointm, SEX
 
     SEXP hgt = elt(vegp, "hgt", NULL);
     SEXP dim = getAttrib(hgt, R_DimSymbol);
-    if (TYPEOF(dim) != INTSXP || LENGTH(dim) != 2) Rf_error("mcfhip: vegp$hgt must be a matrix");
+    if (dfsel == R_NilValue) {
+        if (TYPEOF(dim) != INTSXP || LENGTH(dim) != 2) Rf_error("mcfhip: vegp$hgt must be a matrix");
+    } else {
+        /* runmicro3Cpp/4Cpp: vegetation arrays [rows, cols, layers] + dfsel (lyr, st, ed), cpp:2629-2640 */
+        if (TYPEOF(dim) != INTSXP || LENGTH(dim) != 3) Rf_error("mcfhip: vegp$hgt must be a 3-D array");
+        in.veg_layers = INTEGER(dim)[2];
+        if (XLENGTH(elt(dfsel, "st", NULL)) != in.veg_layers) Rf_error("mcfhip: dfsel rows != vegetation layers");
+        in.lyr_st = intcol(elt(dfsel, "st", NULL), &np);
+        in.lyr_ed = intcol(elt(dfsel, "ed", NULL), &np);
+    }
     in.rows = INTEGER(dim)[0]; in.cols = INTEGER(dim)[1];
     in.tsteps = XLENGTH(elt(obstime, "year", NULL));
     in.array_forcing = array_forcing;
@@ -119,7 +130,9 @@ static SEXP run(int array_forcing, SEXP obstime, SEXP climdata, SEXP pointm, SEX
     }
     setAttrib(ans, R_NamesSymbol, nms);
 
-    int rc = array_forcing ? mcf_runmicro2(&in, &opt, &res) : mcf_runmicro1(&in, &opt, &res);
+    int rc = dfsel == R_NilValue
+                 ? (array_forcing ? mcf_runmicro2(&in, &opt, &res) : mcf_runmicro1(&in, &opt, &res))
+                 : (array_forcing ? mcf_runmicro4(&in, &opt, &res) : mcf_runmicro3(&in, &opt, &res));
     if (rc != MCF_OK) {
         char msg[600];
         strncpy(msg, mcf_last_error(), sizeof msg - 1); msg[sizeof msg - 1] = 0;
@@ -132,16 +145,29 @@ static SEXP run(int array_forcing, SEXP obstime, SEXP climdata, SEXP pointm, SEX
 
 SEXP mcfhip_runmicro1(SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc, SEXP reqhgt, SEXP zref,
                       SEXP lat, SEXP lon, SEXP Sminp, SEXP Smaxp, SEXP tfact, SEXP complete, SEXP mat, SEXP out) {
-    return run(0, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact, complete, mat, out);
+    return run(0, R_NilValue, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact, complete, mat, out);
 }
 SEXP mcfhip_runmicro2(SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc, SEXP reqhgt, SEXP zref,
                       SEXP lats, SEXP lons, SEXP Sminp, SEXP Smaxp, SEXP tfact, SEXP complete, SEXP mat, SEXP out) {
-    return run(1, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons, Sminp, Smaxp, tfact, complete, mat, out);
+    return run(1, R_NilValue, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons, Sminp, Smaxp, tfact, complete, mat, out);
+}
+/* _microclimf_runmicro3Cpp / 4Cpp (src/RcppExports.cpp:300-348): dfsel first, then the same 15 */
+SEXP mcfhip_runmicro3(SEXP dfsel, SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc, SEXP reqhgt,
+                      SEXP zref, SEXP lat, SEXP lon, SEXP Sminp, SEXP Smaxp, SEXP tfact, SEXP complete, SEXP mat,
+                      SEXP out) {
+    return run(0, dfsel, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact, complete, mat, out);
+}
+SEXP mcfhip_runmicro4(SEXP dfsel, SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc, SEXP reqhgt,
+                      SEXP zref, SEXP lats, SEXP lons, SEXP Sminp, SEXP Smaxp, SEXP tfact, SEXP complete, SEXP mat,
+                      SEXP out) {
+    return run(1, dfsel, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons, Sminp, Smaxp, tfact, complete, mat, out);
 }
 
 static const R_CallMethodDef CallEntries[] = {
     {"mcfhip_runmicro1", (DL_FUNC)&mcfhip_runmicro1, 15},
     {"mcfhip_runmicro2", (DL_FUNC)&mcfhip_runmicro2, 15},
+    {"mcfhip_runmicro3", (DL_FUNC)&mcfhip_runmicro3, 16},
+    {"mcfhip_runmicro4", (DL_FUNC)&mcfhip_runmicro4, 16},
     {NULL, NULL, 0}};
 
 void R_init_mcfhip_glue(DllInfo *dll) {

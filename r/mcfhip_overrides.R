@@ -20,7 +20,18 @@ mcfhip_enable <- function(glue = "r/mcfhip_glue.so") {
                   Sminp, Smaxp, tfact, complete, mat, out)
     .Call("mcfhip_runmicro2", obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons,
           Sminp, Smaxp, tfact, complete, mat, out)
+  # time-varying vegetation (R/RcppExports.R:80-86, called at R/internal.R:1458 and 1640)
+  rm3 <- function(dfsel, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon,
+                  Sminp, Smaxp, tfact, complete, mat, out)
+    .Call("mcfhip_runmicro3", dfsel, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon,
+          Sminp, Smaxp, tfact, complete, mat, out)
+  rm4 <- function(dfsel, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons,
+                  Sminp, Smaxp, tfact, complete, mat, out)
+    .Call("mcfhip_runmicro4", dfsel, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons,
+          Sminp, Smaxp, tfact, complete, mat, out)
   utils::assignInNamespace("runmicro1Cpp", rm1, ns = "microclimf")
   utils::assignInNamespace("runmicro2Cpp", rm2, ns = "microclimf")
+  utils::assignInNamespace("runmicro3Cpp", rm3, ns = "microclimf")
+  utils::assignInNamespace("runmicro4Cpp", rm4, ns = "microclimf")
   invisible(TRUE)
 }
