@@ -274,7 +274,8 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
     p->g.reqhgt = opt->reqhgt;
     p->g.reqhgt2 = opt->reqhgt < 0.00001 ? 0.00001 : opt->reqhgt;      // cpp:2246-2247
     p->g.zref = opt->zref;
-    p->g.hf0 = mcf::hf0_constant();
+    p->g.hf0p = mcf::hf_pow02(1 / 999.99);   // mincondCpp(leafabs, 999.99, ...) at cpp:1348
+    p->g.hf500p = mcf::hf_pow02(500.0);      // rs capped at 500 (gs <= 0.002), cpp:1321-1323
     p->g.shadowmask = p->af ? 0 : 1;
     p->g.dTmx = 0.0;
     p->hiy = 365 * 24;

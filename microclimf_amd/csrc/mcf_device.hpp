@@ -548,18 +548,22 @@ struct Stom {
 // cpp:442-458 stomcondCpp with the soil-water factor `gs2 = mu*gsmax` passed in.
 __device__ __forceinline__ double stomcond(double Rswabs, const Stom& s) {
     if (Rswabs <= 0.0) return 0.0;
-    if (Rswabs > s.rsmx) Rswabs = s.rsmx;
-    double gs = s.gsmax * fexp(-(s.rsmx - Rswabs) * s.inv02rsmx * 0.693147180559945309417);
+    double gs = s.gsmax;          // light-saturated (Rswabs >= Rsmx): 2^0 = 1
+    if (Rswabs < s.rsmx) gs = s.gsmax * fexp(-(s.rsmx - Rswabs) * s.inv02rsmx * 0.693147180559945309417);
     if (gs > s.gs2) gs = s.gs2;
     return gs;
 }
 
-// cpp:1316-1331 mincondCpp
-__device__ __forceinline__ double mincond_from_hf(double Hf, double Rnet, double invleafd) {
-    double H = Hf * Rnet;
-    double arg = fabs(H) * invleafd;
+// cpp:1316-1331 mincondCpp: gmin = max(0.0463*(|Hf*Rnet|/leafd)^0.2, 0.05).  The two calls of a
+// cell-step share Rnet and leafd, so (|Rnet|/leafd)^0.2 is evaluated once (`a02`) and each call
+// supplies |Hf|^0.2 (`hf02`).
+__device__ __forceinline__ double mincond_a02(double Rnet, double invleafd) {
+    double arg = fabs(Rnet) * invleafd;
     if (arg < 1e-300) arg = 1e-300;      // pow(0, 0.2) = 0 and tiny values end in the 0.05 floor alike
-    double gmin = 0.0463 * powxy(arg, 0.2);
+    return powxy(arg, 0.2);
+}
+__device__ __forceinline__ double mincond_gmin(double hf02, double a02) {
+    double gmin = 0.0463 * (hf02 * a02);
     if (gmin < 0.05) gmin = 0.05;
     return gmin;
 }
@@ -695,7 +699,8 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
         const double leafabs = c_hom * cy.X + lwabs;         // radLsw + lwabs
         double gh = 0.135 * fsqrt(uz * invleafd) * 1.4;
         const double RnetL = leafabs - lwcan;                // cpp:1319 with tc = Tcan
-        double gmin = mincond_from_hf(g.hf0, RnetL, invleafd);
+        const double a02 = mincond_a02(RnetL, invleafd);
+        double gmin = mincond_gmin(g.hf0p, a02);             // mincondCpp(leafabs, 999.99, Tcan, leafd)
         if (gh < gmin) gh = gmin;
         double gVl = gh;
         if (flags & FL_STOM) {
@@ -706,11 +711,14 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
                 if (!have_gs2) load_stom();
                 gs = stomcond(PARabs, st);
             }
-            // rs = min(1/gs, 500) (500 when gs <= 0), Hlf = 1.09767*rs^0.2672778, cpp:1321-1324
-            double lrs = (gs > 0.002) ? -flog(gs) : 6.214608098422191;   // log(500)
-            double Hlf = 1.09767 * fexp(0.2672778 * lrs);
-            double Hf = -frcp(1.0 + fexp(2.0 - Hlf));
-            gmin = mincond_from_hf(Hf, RnetL, invleafd);
+            // rs = min(1/gs, 500) (500 when gs <= 0), Hlf = 1.09767*rs^0.2672778,
+            // Hf = -1/(1 + exp(2 - Hlf)), cpp:1321-1325; |Hf|^0.2 = exp(-0.2*log(1 + exp(2 - Hlf)))
+            double hf02 = g.hf500p;                           // rs = 500: a constant (night, closed stomata)
+            if (gs > 0.002) {
+                double Hlf = 1.09767 * fexp(-0.2672778 * flog(gs));
+                hf02 = fexp(-0.2 * flog(1.0 + fexp(2.0 - Hlf)));
+            }
+            gmin = mincond_gmin(hf02, a02);                   // mincondCpp(leafabs, gs, Tcan, leafd)
             if (gh < gmin) gh = gmin;
             if (gs > 0.0) gVl = fdiv(gh * gs, gh + gs);
         }

@@ -10,7 +10,8 @@ struct Globals {
     double reqhgt2;  // max(reqhgt, 1e-5)                       cpp:2246-2247
     double zref;
     double dTmx;     // -0.6273*mxtc + 49.79 (vector forcing)   cpp:1236
-    double hf0;      // mincondCpp's Hf for gs = 999.99          cpp:1321-1325
+    double hf0p;     // |Hf|^0.2 of mincondCpp for gs = 999.99    cpp:1321-1328
+    double hf500p;   // |Hf|^0.2 of mincondCpp for rs = 500       cpp:1321-1328
     int shadowmask;  // 1: runmicro1Cpp, 0: runmicro2Cpp         cpp:2218 vs 2499
 };
 
@@ -98,6 +99,6 @@ void launch_selftest_math(int kind, const double* x, const double* y, double* ou
 
 int cell_field_count();
 int time_field_count();
-double hf0_constant();
+double hf_pow02(double rs);
 
 }  // namespace mcf

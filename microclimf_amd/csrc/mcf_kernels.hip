@@ -713,11 +713,12 @@ static void launch_solve_cpb(const SolveArgs& a, bool af, bool bg, hipStream_t s
 }
 int cell_field_count() { return CF_COUNT; }
 int time_field_count() { return TF_COUNT; }
-// mincondCpp (cpp:1321-1325) evaluated for gs = 999.99: rs = 1/gs, Hlf, Hf are constants
-double hf0_constant() {
-    double rs = 1 / 999.99;
+// mincondCpp (cpp:1321-1328): for a fixed stomatal resistance rs, Hlf and Hf are constants and
+// gmin = 0.0463*|Hf|^0.2 * (|Rnet|/leafd)^0.2; returns |Hf|^0.2
+double hf_pow02(double rs) {
     double Hlf = 1.09767 * pow(rs, 0.2672778);
-    return -1.0 / (1.0 + exp(2.0 - Hlf));
+    double Hf = -1.0 / (1.0 + exp(2.0 - Hlf));
+    return pow(fabs(Hf), 0.2);
 }
 
 void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, hipStream_t s) {
