@@ -140,8 +140,9 @@ int check_inputs(const mcf_grid_inputs* in, const mcf_options* opt) {
                 return fail(MCF_ERR_ARG, "dfsel: layer ranges must start on whole days inside the series");
         }
     }
-    if (!(opt->cells_per_block == 0 || opt->cells_per_block == 16 || opt->cells_per_block == 32))
-        return fail(MCF_ERR_ARG, "cells_per_block must be 0, 16 or 32");
+    if (!(opt->cells_per_block == 0 || opt->cells_per_block == 16 || opt->cells_per_block == 21 ||
+          opt->cells_per_block == 32 || opt->cells_per_block == 42))
+        return fail(MCF_ERR_ARG, "cells_per_block must be 0, 16, 21, 32 or 42");
     return MCF_OK;
 }
 
@@ -235,7 +236,7 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
     p->ndays = (int)(in->tsteps / 24);                       // cpp:2116 truncation
     p->af = in->array_forcing != 0;
     p->bg = opt->reqhgt < 0.0;
-    p->cpb = opt->cells_per_block ? opt->cells_per_block : 32;
+    p->cpb = opt->cells_per_block ? opt->cells_per_block : 21;
     p->layers = in->veg_layers > 1 ? in->veg_layers : 1;
     p->opt = *opt;
     p->lat = in->lat; p->lon = in->lon;

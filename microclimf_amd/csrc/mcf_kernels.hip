@@ -15,7 +15,7 @@
 #include "mcf_kernels.h"
 
 #ifndef MCF_WAVES_PER_EU
-#define MCF_WAVES_PER_EU 3
+#define MCF_WAVES_PER_EU 4
 #endif
 #ifndef MCF_HOUR_PERMUTE
 #define MCF_HOUR_PERMUTE 1
@@ -335,9 +335,12 @@ __global__ __launch_bounds__(256) void k_mxtc(const double* __restrict__ tc, int
 //   AF   array forcing (runmicro2Cpp geometry)
 //   BG   reqhgt < 0: store the ground temperature series and the damping-depth sum
 // ------------------------------------------------------------------------------------
+// threads per workgroup: CPB*24 lanes rounded up to whole waves on all four SIMDs
+constexpr int solve_threads(int cpb) { return ((cpb * 24 + 255) / 256) * 256; }
+
 template <int CPB, bool AF, bool BG>
-__global__ __launch_bounds__(CPB * 24, MCF_WAVES_PER_EU) void k_solve(SolveArgs a) {
-    constexpr int NT = CPB * 24;
+__global__ __launch_bounds__(solve_threads(CPB), MCF_WAVES_PER_EU) void k_solve(SolveArgs a) {
+    constexpr int NT = solve_threads(CPB);
     __shared__ double s_cell[CF_COUNT * CPB];
     __shared__ double s_dirs[kCellDirs * CPB];
     __shared__ double s_time[AF ? 1 : 3 * TF_COUNT * 24];
@@ -360,14 +363,16 @@ __global__ __launch_bounds__(CPB * 24, MCF_WAVES_PER_EU) void k_solve(SolveArgs 
         hr = tab + ((tid >> 5) & 1);
     } else {
         hr = tid / CPB;
+        if (hr > 23) hr = 23;
     }
 #else
-    const int hr = tid / CPB;
+    int hr = tid / CPB;
+    if (hr > 23) hr = 23;
 #endif
     const int64_t N = a.N;
     const int64_t c0 = (int64_t)blockIdx.x * CPB;
     const int64_t c = c0 + cl;
-    const bool in_grid = c < N;
+    const bool in_grid = tid < CPB * 24 && c < N;   // lanes past CPB*24 only help staging and keep the barriers
 
     // ---- stage the tile's direction tables and the first day's time table in LDS
     for (int q = tid; q < kCellDirs * CPB; q += NT) {
@@ -702,7 +707,7 @@ void launch_belowground(const BelowArgs& a, hipStream_t s) {
 
 template <int CPB>
 static void launch_solve_cpb(const SolveArgs& a, bool af, bool bg, hipStream_t s) {
-    dim3 grid((unsigned)((a.N + CPB - 1) / CPB)), block(CPB * 24);
+    dim3 grid((unsigned)((a.N + CPB - 1) / CPB)), block(solve_threads(CPB));
     if (af) {
         if (bg) hipLaunchKernelGGL((k_solve<CPB, true, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((k_solve<CPB, true, false>), grid, block, 0, s, a);
@@ -724,6 +729,8 @@ double hf_pow02(double rs) {
 void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, hipStream_t s) {
     if (a.N <= 0 || a.ndays <= 0) return;
     if (cells_per_block == 32) launch_solve_cpb<32>(a, af, bg, s);
+    else if (cells_per_block == 21) launch_solve_cpb<21>(a, af, bg, s);
+    else if (cells_per_block == 42) launch_solve_cpb<42>(a, af, bg, s);
     else launch_solve_cpb<16>(a, af, bg, s);
 }
 

@@ -42,7 +42,7 @@ def with_na(a, frac_cells=((0, 0), (3, 2))):
     (5.0, 10.0, (0.5, 9.0)),       # above canopy, shrub + tree stomatal classes
     (0.0, 2.0, (0.05, 1.5)),       # ground surface
 ])
-@pytest.mark.parametrize("cpb", [16, 32])
+@pytest.mark.parametrize("cpb", [16, 21, 32, 42])
 def test_runmicro1_matches_oracle(oracle, reqhgt, zref, hgt_range, cpb):
     a = with_na(synthetic.workload(21, 13, 96, reqhgt=reqhgt, zref=zref, hgt_range=hgt_range,
                                    variety=True, start_doy=170))
@@ -91,9 +91,11 @@ def test_chunking_is_bitwise_invariant():
     r1 = runmicro1Cpp(**a, days_per_chunk=7)
     r2 = runmicro1Cpp(**a, days_per_chunk=2)
     r3 = runmicro1Cpp(**a, days_per_chunk=3, cells_per_block=32)
+    r4 = runmicro1Cpp(**a, days_per_chunk=4, cells_per_block=42)
     for k in r1:
         assert np.array_equal(r1[k], r2[k], equal_nan=True), k
         assert np.array_equal(r1[k], r3[k], equal_nan=True), k
+        assert np.array_equal(r1[k], r4[k], equal_nan=True), k
 
 
 @pytest.mark.parametrize("reqhgt", [0.05, 0.0, -0.2])
