@@ -42,6 +42,10 @@ def parse():
     ap.add_argument("--cells-per-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=str, default="96x96x720")
+    ap.add_argument("--array-forcing", action="store_true",
+                    help="secondary measurement: runmicro2Cpp geometry; ring_slots x ring_days days of forcing are "
+                         "resident in HBM and solved repeatedly (a year of array forcing, 1.1 TB at 1024^2, "
+                         "cannot be resident)")
     return ap.parse_args()
 
 
@@ -88,10 +92,18 @@ def main():
 
     rows, cols, T = args.rows, args.cols, args.tsteps
     ndays = T // 24
-    a = synthetic.workload(rows, cols, T, reqhgt=args.reqhgt, row0=rank * rows, rows_total=rows * world)
+    af = args.array_forcing
+    if af:
+        T = min(T, args.ring_days * args.ring_slots * 24)
+        ndays = T // 24
+    a = synthetic.workload(rows, cols, T, reqhgt=args.reqhgt, row0=rank * rows, rows_total=rows * world,
+                           array_forcing=af, start_doy=152 if af else 1)
     n_out = 10
     plan = Plan(**a, ring_days=args.ring_days, ring_slots=args.ring_slots, device=local_rank,
-                cells_per_block=args.cells_per_block)
+                cells_per_block=args.cells_per_block, array_forcing=af)
+    if af:
+        for sl, d0 in enumerate(range(0, ndays, args.ring_days)):
+            plan.upload_forcing_days(d0, min(args.ring_days, ndays - d0), sl)
     # the solver's one global reduction: mean of log(twi)/tfact over the WHOLE raster
     s, n = plan.twi_partial()
     plan.set_twi_mean(allreduce_twi_mean(s, float(n)))      # one 2-double all-reduce (RCCL over xGMI)
@@ -129,7 +141,8 @@ def main():
         # roofline of the dominant kernel (k_solve): ALGORITHMIC bytes per launch =
         # valid cells x steps per launch x (8 B x n_out written + 440 B / T read)   [SURVEY §8d]
         steps_per_launch = (ndays * 24 * args.steps) / max(klaunches, 1)
-        bytes_per_launch = valid * steps_per_launch * (8.0 * n_out + 440.0 / T)
+        # array forcing reads 15 arrays per cell-step (+8 B for the mxtc pre-pass): 208 B   [SURVEY §8d]
+        bytes_per_launch = valid * steps_per_launch * ((8.0 * n_out + 128.0) if af else (8.0 * n_out + 440.0 / T))
         avg_ms = kms / max(klaunches, 1)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         traffic = None
@@ -147,9 +160,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{rows}x{cols} synthetic DTM per GPU, {T} hourly steps, vector forcing "
-                            f"(runmicro1Cpp geometry), reqhgt={args.reqhgt}, no snow "
-                            "[BASELINE.json configs[1]]",
+                "workload": (f"{rows}x{cols} synthetic DTM per GPU, {T} hourly steps, "
+                             + ("array forcing (runmicro2Cpp geometry), forcing resident in HBM, "
+                                if af else "vector forcing (runmicro1Cpp geometry), ")
+                             + f"reqhgt={args.reqhgt}, no snow"
+                             + ("" if af else " [BASELINE.json configs[1]]")),
                 "rows_per_gpu": rows, "cols": cols, "tsteps": T, "outputs": n_out,
                 "valid_cells": int(valid_all),
                 "sink": f"HBM ring ({args.ring_slots} slots x {args.ring_days} days), no D2H",
