@@ -236,7 +236,8 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
     p->ndays = (int)(in->tsteps / 24);                       // cpp:2116 truncation
     p->af = in->array_forcing != 0;
     p->bg = opt->reqhgt < 0.0;
-    p->cpb = opt->cells_per_block ? opt->cells_per_block : 21;
+    // vector forcing: two 8-wave workgroups per CU (21 cells); array forcing: one 12-wave workgroup
+    p->cpb = opt->cells_per_block ? opt->cells_per_block : (in->array_forcing ? 32 : 21);
     p->layers = in->veg_layers > 1 ? in->veg_layers : 1;
     p->opt = *opt;
     p->lat = in->lat; p->lon = in->lon;

@@ -77,8 +77,9 @@ enum CellField : int {
     CF_EMG, CF_EMA, CF_INVLEAFD,
     // below-canopy Lagrangian model (cpp:1365-1409)
     CF_A2H, CF_INTHH, CF_INTHZ, CF_HGT, CF_INVHGT, CF_INVHMZ, CF_NEARFAC, CF_LEAFDEN, CF_OMEMPAI,
-    // array forcing: per-cell solar geometry (cpp:2497)
-    CF_SINLAT, CF_COSLAT, CF_LON,
+    // array forcing: per-cell solar geometry (cpp:2497): latitude and the longitude part B of the
+    // hour angle tt = A(time) + B(cell), B = 0.261799*4*lon/60 (cpp:44, 54)
+    CF_SINLAT, CF_COSLAT, CF_COSB, CF_SINB,
     CF_COUNT
 };
 constexpr int kCellDirs = 32;  // 24 horizon + 8 wind-shelter values follow the CF_ rows
@@ -326,6 +327,95 @@ __device__ inline void derive_time(TimeVals& t, const SolPos& sp, int windex) {
     int sindex = dir_index(sp.azid, 15.0, 24);
     int ksat = (sp.zend > (kPi / 2.0)) ? 1 : 0;
     t.v[TF_IDX] = (double)(sindex | (windex << 5) | (ksat << 8));
+}
+
+// Array forcing (runmicro2Cpp geometry): the same TF_ values per CELL-step, from the date part of
+// the solar position tabulated per time step (sin/cos of the declination and of the hour-angle part
+// A = 0.261799*(hour + eot/60 - 12)) and per-cell constants.  cpp:48-83 is followed algebraically
+// instead of through its inverse trig calls: with coh = cos(zenith),
+//   cos(zenr) = coh, sin(zenr) = sqrt(1-coh^2), tan(pi/2 - zenr) = coh/sin(zenr),
+//   cos(hh) = sin(zenr)  (hh = atan(sh/sqrt(1-sh^2)) = asin(coh)),
+//   sin(azimuth) = -sazi, cos(azimuth) = -+sqrt(1-sazi^2) by the sign of cazi (cpp:65-75),
+// and the 15-degree horizon sector round(azid/15) % 24 is found by comparing against tangents.
+// Differences to the literal evaluation are rounding-level (1e-16 relative).
+struct DateRow { double sindec, cosdec, cosA, sinA; };
+__device__ __forceinline__ void derive_time_af(TimeVals& t, const DateRow& dr, double sinlat, double coslat,
+                                               double cosB, double sinB, int windex) {
+    const double ctt = dr.cosA * cosB - dr.sinA * sinB;
+    const double stt = dr.sinA * cosB + dr.cosA * sinB;
+    const double coh = dr.sindec * sinlat + dr.cosdec * coslat * ctt;          // cpp:56
+    double s2 = 1.0 - coh * coh;
+    if (s2 < 0.0) s2 = 0.0;
+    const double sz = fsqrt(s2 > 1e-300 ? s2 : 1e-300);
+    t.v[TF_CZ] = coh;
+    t.v[TF_SZ] = sz;
+    t.v[TF_TANSA] = fdiv(coh, sz);
+    // zenith in degrees is only compared with 90 (cpp:88) and with pi/2 (the degrees call, cpp:1425)
+    const bool up = coh >= 0.0;                    // zenith <= 90 degrees
+    const bool nearzen = coh > 0.99962422;         // zenith (deg) may be below pi/2 = 1.5708
+    double zend = up ? 45.0 : 135.0;
+    if (nearzen) zend = acos(coh) * (180 / kPi);
+    t.v[TF_ZEND] = zend;
+    // canopy extinction operands, radians call: zenr clamped to pi/2 (cpp:106)
+    const double cc = up ? coh : 6.123233995736766e-17;                        // cos(pi/2) in fp64
+    const double tn = up ? fdiv(sz, coh) : 1.633123935319537e16;               // tan(pi/2) in fp64
+    t.v[TF_COSC] = cc;
+    t.v[TF_TANC] = tn;
+    t.v[TF_TAN2C] = tn * tn;
+    t.v[TF_INV2COSC] = 0.5 * frcp(cc);
+    const int ksat = zend > (kPi / 2.0) ? 1 : 0;
+    if (!ksat) {
+        double cb = cos(zend), tb = tan(zend);     // rare: sun within 1.57 degrees of the zenith
+        t.v[TF_TANB] = tb;
+        t.v[TF_TAN2B] = tb * tb;
+        t.v[TF_INV2COSB] = 1.0 / (2.0 * cb);
+    }
+    // azimuth, cpp:59-75
+    double sazi = fdiv(dr.cosdec * stt, sz);
+    const double num = sinlat * dr.cosdec * ctt - coslat * dr.sindec;         // sign of cazi
+    double sqt = 1.0 - sazi * sazi;
+    if (sqt < 0.0) sqt = 0.0;
+    if (sazi > 1.0) sazi = 1.0;
+    if (sazi < -1.0) sazi = -1.0;
+    const double rq = fsqrt(sqt > 1e-300 ? sqt : 1e-300);
+    const double saz = -sazi;
+    const double caz = num < 0.0 ? rq : -rq;
+    t.v[TF_SAZ] = saz;
+    t.v[TF_CAZ] = caz;
+    // sindex = round(azid/15) % 24 (cpp:2501): rotate by +7.5 deg, quadrant, then tangent tests
+    const double xr = caz * 0.99144486137381038 - saz * 0.13052619222005157;
+    const double yr = saz * 0.99144486137381038 + caz * 0.13052619222005157;
+    int q;
+    double u, v;
+    if (yr >= 0.0) {
+        if (xr > 0.0) { q = 0; u = xr; v = yr; } else { q = 1; u = yr; v = -xr; }
+    } else {
+        if (xr < 0.0) { q = 2; u = -xr; v = -yr; } else { q = 3; u = -yr; v = xr; }
+    }
+    int n = (v >= u * 0.26794919243112270) + (v >= u * 0.57735026918962573) + (v >= u) +
+            (v >= u * 1.7320508075688772) + (v >= u * 3.7320508075688776);
+    const int sindex = (6 * q + n) % 24;
+    t.v[TF_IDX] = (double)(sindex | (windex << 5) | (ksat << 8));
+    // Penman-Monteith operands (cpp:1220-1247) and beam normalisation (cpp:1122-1124)
+    const double tc = t.v[TF_TC];
+    t.v[TF_DE] = satvap(tc + 0.5) - satvap(tc - 0.5);
+    const double tk = tc + 273.15;
+    t.v[TF_GHRRAD] = (4 * 0.97 * kSb * (tk * tk * tk)) * (1.0 / 29.3);
+    t.v[TF_REM] = lw_emit(tc);
+    const double ipk = frcp(t.v[TF_PK]);
+    t.v[TF_LAPK] = latent(tc) * ipk;
+    t.v[TF_WFAC] = fdiv(0.018, 8.31 * tk);
+    double rbeam = fdiv(t.v[TF_RSW] - t.v[TF_RDIF], coh);
+    if (rbeam > 1352.0) rbeam = 1352.0;
+    t.v[TF_RBEAM] = rbeam;
+    t.v[TF_RB] = rbeam * coh;
+}
+// second half, evaluated in front of pass 2 (keeps these out of the registers during pass 1)
+__device__ __forceinline__ void derive_time_af_pass2(TimeVals& t, double gp, double mugp, double dtrp, double kp) {
+    const double mu = latent(t.v[TF_TC]) * (43.0 * frcp(t.v[TF_PK]));          // cpp:1245
+    t.v[TF_MUPM] = mu;
+    t.v[TF_INVMUPM] = frcp(mu);
+    t.v[TF_GFAC] = fdiv(gp * mugp, dtrp * kp);                                 // cpp:1282-1289
 }
 
 // ---- accessors ----------------------------------------------------------------

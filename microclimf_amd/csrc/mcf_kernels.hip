@@ -252,7 +252,9 @@ __global__ __launch_bounds__(256) void k_cell_setup(CellSetupArgs a) {
         put(CF_MUDENINV, 1.0 / (exp(-kk * psiw0) - 1.0));
         put(CF_SINLAT, sin(lat * kPi / 180.0));
         put(CF_COSLAT, cos(lat * kPi / 180.0));
-        put(CF_LON, a.lons ? a.lons[c] : a.lon);
+        const double B = 0.261799 * ((4.0 * (a.lons ? a.lons[c] : a.lon)) / 60.0);   // cpp:44, 54
+        put(CF_COSB, cos(B));
+        put(CF_SINB, sin(B));
     }
     // ---- canopy conductance operands for the saturated (degrees) cankCpp call, cpp:1425, 466-469
     {
@@ -311,10 +313,11 @@ __global__ __launch_bounds__(256) void k_date_setup(DateSetupArgs a) {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.nsteps) return;
     SolDate sd = sol_date(a.year[k], a.month[k], a.day[k]);
+    const double A = 0.261799 * (a.hour[k] + sd.eot / 60.0 - 12.0);      // time part of tt, cpp:44, 54
     a.dt[4 * (int64_t)k + 0] = sd.sindec;
     a.dt[4 * (int64_t)k + 1] = sd.cosdec;
-    a.dt[4 * (int64_t)k + 2] = sd.eot;
-    a.dt[4 * (int64_t)k + 3] = a.hour[k];
+    a.dt[4 * (int64_t)k + 2] = cos(A);
+    a.dt[4 * (int64_t)k + 3] = sin(A);
     a.windex[k] = dir_index(a.winddir[k], 45.0, 8);
 }
 
@@ -342,7 +345,9 @@ __global__ __launch_bounds__(256) void k_mxtc(const double* __restrict__ tc, int
 constexpr int solve_threads(int cpb) { return ((cpb * 24 + 255) / 256) * 256; }
 
 template <int CPB, bool AF, bool BG>
-__global__ __launch_bounds__(solve_threads(CPB), MCF_WAVES_PER_EU) void k_solve(SolveArgs a) {
+// array forcing keeps ~17 more doubles live per lane (forcing values instead of an LDS table):
+// it is built for 3 waves/SIMD (168 VGPRs, no scratch) and run with 32-cell workgroups
+__global__ __launch_bounds__(solve_threads(CPB), AF ? 3 : MCF_WAVES_PER_EU) void k_solve(SolveArgs a) {
     constexpr int NT = solve_threads(CPB);
     __shared__ double s_cell[CF_COUNT * CPB];
     __shared__ double s_dirs[kCellDirs * CPB];
@@ -459,13 +464,14 @@ __global__ __launch_bounds__(solve_threads(CPB), MCF_WAVES_PER_EU) void k_solve(
             }
         }
         TimeVals tv;
+        const int64_t fidx = c + N * (a.force_step0 + kl);
         if (AF && valid) {
-            const int64_t fidx = c + N * (a.force_step0 + kl);
-            for (int f = 0; f < 15; ++f) tv.v[f] = a.af_base[(int64_t)f * a.af_stride + fidx];
+            // TF_TC .. TF_SOILMP and TF_UMU feed pass 1; Gp, kp, muGp, dtrp are reloaded for pass 2
+            for (int f = 0; f < 10; ++f) tv.v[f] = a.af_base[(int64_t)f * a.af_stride + fidx];
+            tv.v[TF_UMU] = a.af_base[(int64_t)TF_UMU * a.af_stride + fidx];
             const int64_t kabs = (int64_t)dabs * 24 + hr;
-            SolDate sd{a.dt[4 * kabs + 0], a.dt[4 * kabs + 1], a.dt[4 * kabs + 2]};
-            SolPos sp = sol_site(sd, a.dt[4 * kabs + 3], C(CF_SINLAT), C(CF_COSLAT), C(CF_LON));
-            derive_time(tv, sp, a.windex[kabs]);
+            DateRow dr{a.dt[4 * kabs + 0], a.dt[4 * kabs + 1], a.dt[4 * kabs + 2], a.dt[4 * kabs + 3]};
+            derive_time_af(tv, dr, C(CF_SINLAT), C(CF_COSLAT), C(CF_COSB), C(CF_SINB), a.windex[kabs]);
         }
         TimeLds TL{s_time + (AF ? 0 : (dl % 3) * (TF_COUNT * 24)) + hr};
         TimeReg TR{&tv};
@@ -523,6 +529,11 @@ __global__ __launch_bounds__(solve_threads(CPB), MCF_WAVES_PER_EU) void k_solve(
             }
             const double dtr = tmx - tmn;
             Pass2Out p2;
+            if (AF)
+                derive_time_af_pass2(tv, a.af_base[(int64_t)TF_GP * a.af_stride + fidx],
+                                     a.af_base[(int64_t)TF_MUGP * a.af_stride + fidx],
+                                     a.af_base[(int64_t)TF_DTRP * a.af_stride + fidx],
+                                     a.af_base[(int64_t)TF_KP * a.af_stride + fidx]);
             if (AF) pass2(C, TR, g, flags, dTmx, cy, dtr, Rmx, above_ground, p2);
             else pass2(C, TL, g, flags, dTmx, cy, dtr, Rmx, above_ground, p2);
             if (BG) {
