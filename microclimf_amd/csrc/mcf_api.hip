@@ -10,6 +10,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -648,21 +650,31 @@ static int run_oneshot(const mcf_grid_inputs* in, const mcf_options* opt, mcf_ou
         chunk = std::min(chunk, 64);
     }
     chunk = std::max(1, std::min(chunk, std::max(ndays, 1)));
+    const bool timing = getenv("MCF_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now(), t_solve = 0, t_fetch = 0;
     mcf_plan* p = nullptr;
     rc = mcf_plan_create(in, opt, chunk, 1, &p);
     if (rc) return rc;
     struct Guard { mcf_plan* p; ~Guard() { mcf_plan_destroy(p); } } guard{p};
+    double t_create = now() - t0;
     for (int d0 = 0; d0 < ndays; d0 += chunk) {
         int nd = std::min(chunk, ndays - d0);
         if (in->array_forcing && (rc = mcf_plan_upload_forcing_days(p, in, d0, nd, 0))) return rc;
+        double ta = now();
         if ((rc = mcf_plan_run_days(p, d0, nd, 0))) return rc;
+        if (timing) { mcf_plan_sync(p); t_solve += now() - ta; ta = now(); }
         if (!bg) {
             for (int v = 0; v < MCF_NOUT; ++v)
                 if (opt->out[v])
                     if ((rc = mcf_plan_fetch(p, 0, v, 0, (int64_t)nd * 24, out->var[v] + N * (int64_t)d0 * 24)))
                         return rc;
         }
+        if (timing) t_fetch += now() - ta;
     }
+    if (timing)
+        fprintf(stderr, "[mcf] one-shot: chunk %d days, plan create %.3f s, solve %.3f s, fetch %.3f s\n", chunk,
+                t_create, t_solve, t_fetch);
     if (bg && ndays > 0) {
         for (int v = 0; v < MCF_NOUT; ++v)
             if (opt->out[v] && v != MCF_OUT_TZ)
