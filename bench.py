@@ -68,6 +68,11 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    # stdout must carry exactly ONE JSON line: native libraries (RCCL prints its library path at
+    # init) write to fd 1 directly, so fd 1 is pointed at stderr until the line is ready
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -76,15 +81,18 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # MCF_BENCH_FORCE_DIST=1 exercises the RCCL path (init, all-reduce, barrier) on a single rank
+    use_dist = world > 1 or os.environ.get("MCF_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as ge
     if rank == 0:
         ge.build_library()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     from microclimf_amd import synthetic
     from microclimf_amd.api import Plan
@@ -118,7 +126,7 @@ def main():
     def fence():
         plan.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -178,9 +186,12 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     plan.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

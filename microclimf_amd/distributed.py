@@ -24,7 +24,7 @@ def allreduce_twi_mean(local_sum: float, local_count: float, device=None) -> flo
     process group."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local_sum / local_count
     if device is None:
         device = "cuda" if dist.get_backend() == "nccl" else "cpu"
