@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--cells-per-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=str, default="96x96x720")
+    ap.add_argument("--terrain", choices=["random", "device"], default="random",
+                    help="'device': slope/aspect/hor/svfa/wsa come from mcf_precompute_terrain run on the "
+                         "synthetic DTM (BASELINE.json configs[2]); 'random': SURVEY 8d's random terrain inputs")
     ap.add_argument("--array-forcing", action="store_true",
                     help="secondary measurement: runmicro2Cpp geometry; ring_slots x ring_days days of forcing are "
                          "resident in HBM and solved repeatedly (a year of array forcing, 1.1 TB at 1024^2, "
@@ -106,6 +109,15 @@ def main():
         ndays = T // 24
     a = synthetic.workload(rows, cols, T, reqhgt=args.reqhgt, row0=rank * rows, rows_total=rows * world,
                            array_forcing=af, start_doy=152 if af else 1)
+    terrain_s = None
+    if args.terrain == "device":
+        from microclimf_amd.terrain import precompute_terrain_tiled
+        _, _, dtm = synthetic.rasters(rows, cols, rank * rows, rows * world, reqhgt=args.reqhgt)
+        tt0 = time.perf_counter()
+        ter = precompute_terrain_tiled(dtm, 1.0, a["zref"], rank, world, rank * rows, rows * world,
+                                       device=local_rank)
+        terrain_s = time.perf_counter() - tt0
+        a["soilc"].update(ter)
     n_out = 10
     plan = Plan(**a, ring_days=args.ring_days, ring_slots=args.ring_slots, device=local_rank,
                 cells_per_block=args.cells_per_block, array_forcing=af)
@@ -172,11 +184,15 @@ def main():
                              + ("array forcing (runmicro2Cpp geometry), forcing resident in HBM, "
                                 if af else "vector forcing (runmicro1Cpp geometry), ")
                              + f"reqhgt={args.reqhgt}, no snow"
-                             + ("" if af else " [BASELINE.json configs[1]]")),
+                             + ("" if af else (" [BASELINE.json configs[1]]" if (rows, cols) == (1024, 1024) else
+                                               " [BASELINE.json configs[2]]" if (rows, cols) == (4096, 4096)
+                                               else ""))),
                 "rows_per_gpu": rows, "cols": cols, "tsteps": T, "outputs": n_out,
                 "valid_cells": int(valid_all),
                 "sink": f"HBM ring ({args.ring_slots} slots x {args.ring_days} days), no D2H",
                 "partition": "row blocks, one per GPU; all-reduce of twi (sum,count) only",
+                "terrain": ("on-device pre-compute from the synthetic DTM, %.2f s incl. H2D/D2H (untimed)" % terrain_s
+                            if terrain_s is not None else "random (SURVEY 8d config 2)"),
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
