@@ -786,7 +786,10 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
         const double lwup = emg * lwgro + (1 - emg) * lwcan;
         const double lwdn = ema * rlw + (1 - ema) * lwcan;
         const double lwabs = 0.97 * 0.5 * (lwup + lwdn);
-        const double leafabs = c_hom * cy.X + lwabs;         // radLsw + lwabs
+        // radLsw / radLpar are set to exactly 0 at night and for pai == 0 (cpp:1151-1162); written this
+        // way a NaN leaf reflectance stays confined to the daytime values, as in the reference
+        const bool lit = rsw > 0.0 && (flags & FL_PAI);
+        const double leafabs = (lit ? c_hom * cy.X : 0.0) + lwabs;   // radLsw + lwabs
         double gh = 0.135 * fsqrt(uz * invleafd) * 1.4;
         const double RnetL = leafabs - lwcan;                // cpp:1319 with tc = Tcan
         const double a02 = mincond_a02(RnetL, invleafd);
@@ -795,7 +798,7 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
         double gVl = gh;
         if (flags & FL_STOM) {
             gVl = 0.0;
-            const double PARabs = c_homp * cy.X;             // radLpar
+            const double PARabs = lit ? c_homp * cy.X : 0.0; // radLpar
             double gs = 0.0;
             if (PARabs > 0.0) {
                 if (!have_gs2) load_stom();

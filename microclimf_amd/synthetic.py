@@ -197,10 +197,10 @@ def workload(rows: int, cols: int, tsteps: int, reqhgt: float = 0.05, zref: floa
              row0: int = 0, rows_total: int | None = None, seed=SEED, start_doy: int = 1,
              array_forcing: bool = False, variety: bool = False, cold: float = 0.0,
              hgt_range=(0.05, 1.5), lat: float = 50.0, lon: float = -5.0, out=None,
-             complete: bool = True):
+             complete: bool = True, year: int = 2023, na_frac: float = 0.01):
     """Positional-argument dict for runmicro1Cpp / runmicro2Cpp."""
-    obstime, climdata, pointm = forcing_vectors(tsteps, lat, lon, 2023, start_doy, seed, cold)
-    vegp, soilc, _ = rasters(rows, cols, row0, rows_total, seed, reqhgt, hgt_range, variety=variety)
+    obstime, climdata, pointm = forcing_vectors(tsteps, lat, lon, year, start_doy, seed, cold)
+    vegp, soilc, _ = rasters(rows, cols, row0, rows_total, seed, reqhgt, hgt_range, na_frac=na_frac, variety=variety)
     args = dict(obstime=obstime, climdata=climdata, pointm=pointm, vegp=vegp, soilc=soilc,
                 reqhgt=reqhgt, zref=zref, lat=lat, lon=lon, Sminp=0.074, Smaxp=0.42, tfact=1.5,
                 complete=complete, mat=10.0, out=[True] * 10 if out is None else list(out))

@@ -70,10 +70,16 @@ def load() -> C.CDLL:
 
 
 def run_grid(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact,
-             complete, mat, out, array_forcing=False, dfsel=None):
+             complete, mat, out, array_forcing=False, dfsel=None, lib=None):
     """Oracle for runmicro1Cpp (array_forcing=False) / runmicro2Cpp (True); with `dfsel`
-    the time-varying-vegetation variants runmicro3Cpp / runmicro4Cpp."""
-    lib = load()
+    the time-varying-vegetation variants runmicro3Cpp / runmicro4Cpp.  `lib` substitutes another
+    build of the oracle (the gcov-instrumented one of tests/test_branch_coverage_cpu.py)."""
+    if lib is None:
+        lib = load()
+    else:
+        lib.orc_run_grid.restype = C.c_int
+        lib.orc_run_grid.argtypes = [C.POINTER(_abi.GridInputs), C.POINTER(_abi.Options),
+                                     C.POINTER(_abi.Outputs)]
     m = marshal(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact,
                 complete, mat, out, array_forcing, dfsel=dfsel)
     outs, arrays = alloc_outputs(m)

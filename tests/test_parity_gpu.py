@@ -24,66 +24,43 @@ def compare(got, want, tol=TOL):
         err = np.abs(g[fin] - w[fin]) / (1.0 + np.abs(w[fin]))
         worst[k] = float(err.max()) if err.size else 0.0
         assert worst[k] <= tol, f"{k}: max scaled error {worst[k]:.3e}"
-        na = np.isnan(g)
-        if na.any():                          # R's NA_real_ payload, not just any NaN
+        na = np.isnan(w) & (w.view(np.uint64) == NA_BITS)
+        if na.any():                          # NA cells / steps carry R's NA_real_ payload, not just any NaN
             assert (g[na].view(np.uint64) == NA_BITS).all(), k
     return worst
 
 
-def with_na(a, frac_cells=((0, 0), (3, 2))):
-    for (i, j) in frac_cells:
-        a["vegp"]["hgt"][i, j] = np.nan
-    return a
+from parity_cases import CASES, build, with_na  # noqa: E402,F401  (re-exported for the other GPU tests)
 
 
-@pytest.mark.parametrize("reqhgt,zref,hgt_range", [
-    (0.05, 2.0, (0.05, 1.5)),      # below canopy for ~all cells
-    (1.0, 2.0, (0.05, 1.9)),       # mixed above / below canopy
-    (5.0, 10.0, (0.5, 9.0)),       # above canopy, shrub + tree stomatal classes
-    (0.0, 2.0, (0.05, 1.5)),       # ground surface
-])
-@pytest.mark.parametrize("cpb", [16, 21, 32, 42])
-def test_runmicro1_matches_oracle(oracle, reqhgt, zref, hgt_range, cpb):
-    a = with_na(synthetic.workload(21, 13, 96, reqhgt=reqhgt, zref=zref, hgt_range=hgt_range,
-                                   variety=True, start_doy=170))
-    want = oracle.run_grid(**a)
-    got = runmicro1Cpp(**a, cells_per_block=cpb)
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_case_matches_oracle(oracle, name):
+    """every workload of tests/parity_cases.py (which together flip every reachable branch of the
+    path, tests/test_branch_coverage_cpu.py) through the C ABI against the oracle"""
+    a, af = build(name)
+    want = oracle.run_grid(**a, array_forcing=af)
+    if af:
+        a["lats"], a["lons"] = a.pop("lat"), a.pop("lon")
+        got = runmicro2Cpp(**a)
+    else:
+        got = runmicro1Cpp(**a)
     compare(got, want)
 
 
-@pytest.mark.parametrize("start_doy,cold", [(1, 12.0), (355, 4.0), (80, 0.0)])
-def test_runmicro1_cold_and_low_sun(oracle, start_doy, cold):
-    """sub-zero branches of satvap / latent heat, long nights, low sun (large Rbeam)."""
-    a = with_na(synthetic.workload(17, 9, 72, reqhgt=0.05, variety=True, start_doy=start_doy, cold=cold))
-    compare(runmicro1Cpp(**a), oracle.run_grid(**a))
+@pytest.mark.parametrize("cpb", [16, 21, 32, 42])
+@pytest.mark.parametrize("name", ["below_canopy", "mixed_canopy", "ground", "soil_5cm"])
+def test_workgroup_geometries(oracle, name, cpb):
+    a, af = build(name)
+    compare(runmicro1Cpp(**a, cells_per_block=cpb), oracle.run_grid(**a))
 
 
-def test_runmicro1_tropical_latitude(oracle):
-    """near-zenith sun exercises the un-saturated branch of the cankCpp degrees call (cpp:1425)
-    and the C4 / tropical stomatal classes (cpp:399, 415)."""
-    a = synthetic.workload(16, 8, 48, reqhgt=0.05, zref=12.0, hgt_range=(0.2, 11.0), variety=True,
-                           start_doy=80, lat=0.5, lon=0.0)
-    compare(runmicro1Cpp(**a), oracle.run_grid(**a))
-
-
-@pytest.mark.parametrize("reqhgt", [-0.05, -0.4, -3.0, -40.0])
-@pytest.mark.parametrize("complete", [True, False])
-def test_runmicro1_below_ground(oracle, reqhgt, complete):
-    """rolling-mean window <= 48 h, daily route, and n >= tsteps (cpp:1483-1492); the blends
-    of the incomplete route (cpp:1495-1536)."""
-    a = with_na(synthetic.workload(18, 7, 240, reqhgt=reqhgt, variety=True, start_doy=100,
-                                   out=[1, 0, 0, 1, 0, 0, 0, 0, 0, 0], complete=complete))
-    compare(runmicro1Cpp(**a), oracle.run_grid(**a))
-
-
-def test_out_mask_and_partial_day(oracle):
-    """only requested variables come back; steps past the last whole day stay NA (cpp:2116)."""
-    a = with_na(synthetic.workload(16, 5, 60, reqhgt=0.05, variety=True, start_doy=200,
-                                   out=[1, 0, 1, 0, 1, 0, 0, 1, 0, 0]))
+def test_out_mask_returns_only_requested(oracle):
+    """only requested variables come back, in the reference's order; steps past the last whole day
+    stay NA (cpp:2116)"""
+    a, _ = build("partial_day_mask")
     got = runmicro1Cpp(**a)
     assert list(got) == ["Tz", "relhum", "windspeed", "Rlwdown"]
     assert np.isnan(got["Tz"][:, :, 48:]).all() and np.isfinite(got["Tz"][1, 1, :48]).all()
-    compare(got, oracle.run_grid(**a))
 
 
 def test_chunking_is_bitwise_invariant():
@@ -96,16 +73,6 @@ def test_chunking_is_bitwise_invariant():
         assert np.array_equal(r1[k], r2[k], equal_nan=True), k
         assert np.array_equal(r1[k], r3[k], equal_nan=True), k
         assert np.array_equal(r1[k], r4[k], equal_nan=True), k
-
-
-@pytest.mark.parametrize("reqhgt", [0.05, 0.0, -0.2])
-def test_runmicro2_matches_oracle(oracle, reqhgt):
-    out = [1, 0, 0, 1, 0, 0, 0, 0, 0, 0] if reqhgt < 0 else [1] * 10
-    a = with_na(synthetic.workload(19, 6, 72, reqhgt=reqhgt, variety=True, start_doy=170,
-                                   array_forcing=True, out=out))
-    want = oracle.run_grid(**a, array_forcing=True)
-    a["lats"], a["lons"] = a.pop("lat"), a.pop("lon")
-    compare(runmicro2Cpp(**a), want)
 
 
 def test_plan_ring_and_twi_mean(oracle):
