@@ -209,6 +209,30 @@ int mcf_plan_timer_stop(mcf_plan *plan, float *ms);
 int mcf_plan_kernel_timing(mcf_plan *plan, int32_t enable);
 int mcf_plan_kernel_stats(mcf_plan *plan, double *total_ms, int64_t *launches);
 
+/* ---- fused bioclim sink --------------------------------------------------------------
+ * Replace _microclimf_runbioclim1Cpp / _microclimf_runbioclim2Cpp (bodies
+ * src/microclimfCpp.cpp:3563-3588 / 3590-3616): the grid solver run with
+ * out = {Tz | tleaf, soilm} followed by runbioclimCpp's per-cell reductions over time
+ * (src/microclimfCpp.cpp:3245-3560).  Both stages stay on the device; only the requested
+ * [rows,cols] matrices come back.  `opt->out` and `opt->complete` are ignored (the reference
+ * passes its own mask and complete = true).  Time layout expected by the reference: steps
+ * 0..287 twelve monthly days, 288..311 hottest day, 312..335 coldest day, then the quarter days
+ * addressed by the 0-based index vectors. */
+#define MCF_NBIO 19
+typedef struct mcf_bioclim_sel {
+    const int32_t *wetq, *dryq, *hotq, *colq; /* 0-based step indices                 */
+    int32_t nwet, ndry, nhot, ncol;
+    int32_t air;                              /* 1: Tz, 0: tleaf (runbioclim*Cpp `air`) */
+    int32_t out[MCF_NBIO];                    /* bio1..bio19 requested                */
+} mcf_bioclim_sel;
+typedef struct mcf_bioclim_out {
+    double *bio[MCF_NBIO]; /* each [rows,cols] or NULL; NA_real_ where the first step of Tz is NA */
+} mcf_bioclim_out;
+int mcf_runbioclim1(const mcf_grid_inputs *in, const mcf_options *opt, const mcf_bioclim_sel *sel,
+                    mcf_bioclim_out *out);
+int mcf_runbioclim2(const mcf_grid_inputs *in, const mcf_options *opt, const mcf_bioclim_sel *sel,
+                    mcf_bioclim_out *out);
+
 /* ---- terrain pre-compute (the solver's terrain inputs, built on the device) ------
  * Restates the R-side arithmetic of the reference's marshaller (R/internal.R):
  *   hor   = .horizon(dtm, 15*d), d = 0..23            R/internal.R:909-925, 1144

@@ -74,6 +74,19 @@ class TerrainOut(C.Structure):
                 ("svfa", c_double_p), ("wsa", c_double_p)]
 
 
+NBIO = 19
+
+
+class BioclimSel(C.Structure):
+    _fields_ = [("wetq", c_int32_p), ("dryq", c_int32_p), ("hotq", c_int32_p), ("colq", c_int32_p),
+                ("nwet", C.c_int32), ("ndry", C.c_int32), ("nhot", C.c_int32), ("ncol", C.c_int32),
+                ("air", C.c_int32), ("out", C.c_int32 * NBIO)]
+
+
+class BioclimOut(C.Structure):
+    _fields_ = [("bio", c_double_p * NBIO)]
+
+
 class Outputs(C.Structure):
     _fields_ = [("var", c_double_p * NOUT)]
 
@@ -90,7 +103,7 @@ EXPORTS = (
     "mcf_plan_belowground", "mcf_plan_sync", "mcf_plan_fetch", "mcf_plan_slot_ptr",
     "mcf_plan_timer_start", "mcf_plan_timer_stop", "mcf_plan_kernel_timing",
     "mcf_plan_kernel_stats", "mcf_plan_valid_cells", "mcf_plan_bytes", "mcf_selftest_math",
-    "mcf_precompute_terrain",
+    "mcf_precompute_terrain", "mcf_runbioclim1", "mcf_runbioclim2",
 )
 
 _lib = None
@@ -154,6 +167,9 @@ def load() -> C.CDLL:
     lib.mcf_plan_bytes.argtypes = [P]
     lib.mcf_selftest_math.restype = C.c_int
     lib.mcf_selftest_math.argtypes = [C.c_int32, c_double_p, c_double_p, c_double_p, C.c_int64, C.c_int32]
+    for fn in (lib.mcf_runbioclim1, lib.mcf_runbioclim2):
+        fn.restype = C.c_int
+        fn.argtypes = [GI, OP, C.POINTER(BioclimSel), C.POINTER(BioclimOut)]
     lib.mcf_precompute_terrain.restype = C.c_int
     lib.mcf_precompute_terrain.argtypes = [C.POINTER(TerrainIn), C.POINTER(TerrainOut), C.c_int32]
     if lib.mcf_abi_version() != 1:

@@ -76,6 +76,52 @@ def runmicro4Cpp(dfsel: Mapping, obstime: Mapping, climdata: Mapping, pointm: Ma
                 Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block, dfsel)
 
 
+def _bioclim(fn_name, array_forcing, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp,
+             Smaxp, tfact, mat, out, wetq, dryq, hotq, colq, air, device):
+    lib = _abi.load()
+    m = marshal(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact, True, mat,
+                [1] * 10, array_forcing, device)
+    sel = _abi.BioclimSel()
+    keep = []
+    for name, q in (("wet", wetq), ("dry", dryq), ("hot", hotq), ("col", colq)):
+        arr = np.ascontiguousarray(np.asarray(q).astype(np.int32))
+        keep.append(arr)
+        setattr(sel, name + "q", arr.ctypes.data_as(_abi.c_int32_p))
+        setattr(sel, "n" + name, arr.size)
+    sel.air = 1 if air else 0
+    out = list(out)
+    if len(out) != _abi.NBIO:
+        raise ValueError("out must have 19 entries")
+    bo = _abi.BioclimOut()
+    res = {}
+    for v in range(_abi.NBIO):
+        sel.out[v] = 1 if out[v] else 0
+        if out[v]:
+            a = np.empty((m.rows, m.cols), dtype=np.float64, order="F")
+            res[f"bio{v + 1}"] = a
+            bo.bio[v] = a.ctypes.data_as(_abi.c_double_p)
+        else:
+            bo.bio[v] = None
+    _abi.check(getattr(lib, fn_name)(C.byref(m.inputs), C.byref(m.options), C.byref(sel), C.byref(bo)))
+    return res
+
+
+def runbioclim1Cpp(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact, mat, out,
+                   wetq, dryq, hotq, colq, air, *, device: int = 0) -> dict:
+    """Drop-in for the reference's runbioclim1Cpp (src/microclimfCpp.cpp:3563-3588): the grid solver on
+    the selected days followed by the 19 per-cell bioclim reductions, both on the device; only the
+    requested [rows, cols] matrices are copied back."""
+    return _bioclim("mcf_runbioclim1", False, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon,
+                    Sminp, Smaxp, tfact, mat, out, wetq, dryq, hotq, colq, air, device)
+
+
+def runbioclim2Cpp(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons, Sminp, Smaxp, tfact, mat, out,
+                   wetq, dryq, hotq, colq, air, *, device: int = 0) -> dict:
+    """Drop-in for the reference's runbioclim2Cpp (src/microclimfCpp.cpp:3590-3616), array climate."""
+    return _bioclim("mcf_runbioclim2", True, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons,
+                    Sminp, Smaxp, tfact, mat, out, wetq, dryq, hotq, colq, air, device)
+
+
 class Plan:
     """HBM-resident solver plan (include/mcf.h plan API): inputs uploaded once,
     day chunks solved into a device output ring."""

@@ -618,6 +618,66 @@ int mcf_selftest_math(int32_t kind, const double* x, const double* y, double* ou
     return MCF_OK;
 }
 
+static int run_bioclim(const mcf_grid_inputs* in, const mcf_options* opt_in, const mcf_bioclim_sel* sel,
+                       mcf_bioclim_out* out, int want_af) {
+    if (!sel || !out) return fail(MCF_ERR_ARG, "null bioclim argument");
+    int rc = check_inputs(in, opt_in);
+    if (rc) return rc;
+    if ((in->array_forcing != 0) != (want_af != 0)) return fail(MCF_ERR_ARG, "forcing geometry does not match the entry point");
+    const int64_t T = in->tsteps, N = in->rows * in->cols;
+    if (T < 336 || T % 24 != 0) return fail(MCF_ERR_ARG, "runbioclim needs >= 336 hourly steps in whole days");
+    const int32_t* q[4] = {sel->wetq, sel->dryq, sel->hotq, sel->colq};
+    const int32_t nq[4] = {sel->nwet, sel->ndry, sel->nhot, sel->ncol};
+    for (int i = 0; i < 4; ++i) {
+        if (nq[i] < 0 || (nq[i] > 0 && !q[i])) return fail(MCF_ERR_ARG, "bad quarter index vector");
+        for (int j = 0; j < nq[i]; ++j)
+            if (q[i][j] < 0 || q[i][j] >= T) return fail(MCF_ERR_ARG, "quarter index outside the time series");
+    }
+    mcf_options opt = *opt_in;
+    opt.complete = 1;                                                   // cpp:3576: complete = true
+    for (int v = 0; v < MCF_NOUT; ++v) opt.out[v] = 0;
+    const int tvar = sel->air ? MCF_OUT_TZ : MCF_OUT_TLEAF;              // cpp:3569-3575
+    opt.out[tvar] = 1;
+    opt.out[MCF_OUT_SOILM] = 1;
+    if ((rc = ensure_device(opt.device))) return rc;
+    const int ndays = (int)(T / 24);
+    mcf_plan* p = nullptr;
+    if ((rc = mcf_plan_create(in, &opt, ndays, 1, &p))) return rc;
+    struct Guard { mcf_plan* p; ~Guard() { mcf_plan_destroy(p); } } guard{p};
+    if (in->array_forcing && (rc = mcf_plan_upload_forcing_days(p, in, 0, ndays, 0))) return rc;
+    if ((rc = mcf_plan_run_days(p, 0, ndays, 0))) return rc;
+    if (p->bg && (rc = mcf_plan_belowground(p))) return rc;
+    void *d_t = nullptr, *d_s = nullptr, *tmp = nullptr;
+    if ((rc = mcf_plan_slot_ptr(p, 0, tvar, &d_t))) return rc;
+    if ((rc = mcf_plan_slot_ptr(p, 0, MCF_OUT_SOILM, &d_s))) return rc;
+    mcf::BioclimArgs b{};
+    b.N = N; b.tsteps = (int)T;
+    b.tz = (const double*)d_t; b.soilm = (const double*)d_s;
+    const int32_t** dq[4] = {&b.wetq, &b.dryq, &b.hotq, &b.colq};
+    b.nwet = nq[0]; b.ndry = nq[1]; b.nhot = nq[2]; b.ncol = nq[3];
+    for (int i = 0; i < 4; ++i) {
+        if ((rc = dalloc(p, &tmp, (int64_t)std::max(nq[i], 1) * 4))) return rc;
+        if (nq[i] > 0) HIP_TRY(hipMemcpyAsync(tmp, q[i], (size_t)nq[i] * 4, hipMemcpyHostToDevice, p->stream));
+        *dq[i] = (const int32_t*)tmp;
+    }
+    if ((rc = dalloc(p, &tmp, (int64_t)MCF_NBIO * N * 8))) return rc;
+    b.bio = (double*)tmp;
+    mcf::launch_bioclim(b, p->stream);
+    HIP_TRY(hipGetLastError());
+    for (int v = 0; v < MCF_NBIO; ++v)
+        if (sel->out[v]) {
+            if (!out->bio[v]) return fail(MCF_ERR_ARG, "requested bioclim variable has a null buffer");
+            HIP_TRY(hipMemcpyAsync(out->bio[v], b.bio + (int64_t)v * N, (size_t)N * 8, hipMemcpyDeviceToHost, p->stream));
+        }
+    return mcf_plan_sync(p);
+}
+int mcf_runbioclim1(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_bioclim_sel* sel, mcf_bioclim_out* out) {
+    return run_bioclim(in, opt, sel, out, 0);
+}
+int mcf_runbioclim2(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_bioclim_sel* sel, mcf_bioclim_out* out) {
+    return run_bioclim(in, opt, sel, out, 1);
+}
+
 int64_t mcf_plan_valid_cells(const mcf_plan* p) { return p ? p->valid_cells : 0; }
 int64_t mcf_plan_bytes(const mcf_plan* p) { return p ? p->bytes : 0; }
 

@@ -87,6 +87,16 @@ struct BelowArgs {
     double* tz;                  // [N][tsteps]
 };
 
+struct BioclimArgs {
+    int64_t N;
+    int32_t tsteps;
+    const double* tz;      // [N][tsteps] Tz or tleaf
+    const double* soilm;   // [N][tsteps]
+    const int32_t *wetq, *dryq, *hotq, *colq;
+    int32_t nwet, ndry, nhot, ncol;
+    double* bio;           // [19][N]
+};
+void launch_bioclim(const BioclimArgs& a, hipStream_t s);
 void launch_fill(double* p, int64_t n, double v, hipStream_t s);
 void launch_twi_partial(const double* twi, int64_t n, double tfact, double* out2, hipStream_t s);
 void launch_cell_setup(const CellSetupArgs& a, hipStream_t s);

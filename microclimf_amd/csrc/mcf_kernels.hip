@@ -679,6 +679,95 @@ __global__ __launch_bounds__(64) void k_belowground(BelowArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// runbioclimCpp, cpp:3245-3560: per-cell reductions of Tz (or tleaf) and soilm over time; one
+// lane per cell, lanes along raster rows (coalesced).  All 19 values are produced; bio7 / bio3
+// come from the values, not from possibly unrequested matrices.
+__device__ inline double quarter_mean(const double* __restrict__ x, int64_t N, const int32_t* q, int nq) {
+    double s = 0.0;
+    for (int i = 0; i < nq; ++i) s = s + x[N * q[i]];
+    return s / 72.0;                                                    // cpp:3325 (fixed divisor)
+}
+__global__ __launch_bounds__(64) void k_bioclim(BioclimArgs a) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t N = a.N;
+    if (c >= N) return;
+    const double* tz = a.tz + c;
+    const double* sm = a.soilm + c;
+    double* out = a.bio + c;
+    const double NA = na_real();
+    if (isnan(tz[0])) {                                                 // cpp:3505-3506
+        for (int b = 0; b < 19; ++b) out[N * b] = NA;
+        return;
+    }
+    const int T = a.tsteps;
+    double bio[19];
+    {   // bio1 cpp:3245, bio2 cpp:3256, bio4 cpp:3279
+        double s = 0.0, dsum = 0.0, mon[12];
+        for (int d = 0; d < 12; ++d) {
+            double tmx = -273.15, tmn = 273.15, ms = 0.0;
+            for (int h = 0; h < 24; ++h) {
+                double v = tz[N * (d * 24 + h)];
+                s = s + v;
+                if (v > tmx) tmx = v;
+                if (v < tmn) tmn = v;
+                ms = ms + v;
+            }
+            dsum = dsum + (tmx - tmn);
+            mon[d] = ms / 24;
+        }
+        bio[0] = s / 288.0;
+        bio[1] = dsum / 12;
+        double mean = 0.0;                                              // calc_std_dev cpp:3227
+        for (int d = 0; d < 12; ++d) mean += mon[d];
+        mean /= 12;
+        double ss = 0.0;
+        for (int d = 0; d < 12; ++d) ss += (mon[d] - mean) * (mon[d] - mean);
+        bio[3] = sqrt(ss / 11) * 100.0;
+    }
+    {   // bio5 cpp:3297, bio6 cpp:3307
+        double tmx = -273.15, tmn = 273.15;
+        for (int i = 288; i < 312; ++i) { double v = tz[N * i]; if (v > tmx) tmx = v; }
+        for (int i = 312; i < 336; ++i) { double v = tz[N * i]; if (v < tmn) tmn = v; }
+        bio[4] = tmx;
+        bio[5] = tmn;
+    }
+    bio[7] = quarter_mean(tz, N, a.wetq, a.nwet);
+    bio[8] = quarter_mean(tz, N, a.dryq, a.ndry);
+    bio[9] = quarter_mean(tz, N, a.hotq, a.nhot);
+    bio[10] = quarter_mean(tz, N, a.colq, a.ncol);
+    {   // bio12..bio15 cpp:3361-3404
+        double me = 0.0;
+        for (int i = 0; i < 288; ++i) me = me + sm[N * i];
+        me = me / 288.0;
+        double mx = 0.0, mn = 1.0, all = 0.0;
+        for (int i = 0; i < T; ++i) {
+            double v = sm[N * i];
+            if (v > mx) mx = v;
+            if (v < mn) mn = v;
+            all += v;
+        }
+        double mean = all / T, ss = 0.0;
+        for (int i = 0; i < T; ++i) { double dlt = sm[N * i] - mean; ss += dlt * dlt; }
+        double sd = T <= 1 ? NA : sqrt(ss / (T - 1));
+        bio[11] = me;
+        bio[12] = mx;
+        bio[13] = mn;
+        bio[14] = me / sd;                                              // cpp:3402 (sic: mean / sd)
+    }
+    bio[15] = quarter_mean(sm, N, a.wetq, a.nwet);
+    bio[16] = quarter_mean(sm, N, a.dryq, a.ndry);
+    bio[17] = quarter_mean(sm, N, a.hotq, a.nhot);
+    bio[18] = quarter_mean(sm, N, a.colq, a.ncol);
+    bio[6] = bio[4] - bio[5];                                           // cpp:3533
+    bio[2] = bio[1] / bio[6];                                           // cpp:3534
+    for (int b = 0; b < 19; ++b) out[N * b] = bio[b];
+}
+void launch_bioclim(const BioclimArgs& a, hipStream_t s) {
+    if (a.N <= 0) return;
+    hipLaunchKernelGGL(k_bioclim, dim3((unsigned)((a.N + 63) / 64)), dim3(64), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------
 // Diagnostics: evaluates the lean elementary functions of mcf_device.hpp elementwise.
 __global__ void k_selftest_math(int kind, const double* __restrict__ x, const double* __restrict__ y,
                                 double* __restrict__ out, int64_t n) {

@@ -97,3 +97,34 @@ def solposition(lat, lon, year, month, day, hour):
 def satvap(tc):
     f = load().orc_satvap
     return np.vectorize(f, otypes=[float])(tc)
+
+
+def run_bioclim(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact, mat,
+                out, wetq, dryq, hotq, colq, air, array_forcing=False):
+    """Oracle for runbioclim1Cpp / runbioclim2Cpp (cpp:3563-3616): the grid oracle with the reference's
+    output mask, then runbioclimCpp's reductions cell by cell."""
+    lib = load()
+    mask = [0] * 10
+    mask[0 if air else 1] = 1
+    mask[3] = 1
+    res = run_grid(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact,
+                   True, mat, mask, array_forcing)
+    tz = res["Tz" if air else "tleaf"]
+    sm = res["soilm"]
+    R, Cc, T = tz.shape
+    qs = [np.ascontiguousarray(np.asarray(q, dtype=np.int32)) for q in (wetq, dryq, hotq, colq)]
+    bio = np.full((19, R, Cc), lib.orc_na_real())
+    tmp = np.zeros(19)
+    IP, DP = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    lib.orc_bioclim_cell.restype = None
+    for i in range(R):
+        for j in range(Cc):
+            if np.isnan(tz[i, j, 0]):
+                continue
+            a = np.ascontiguousarray(tz[i, j, :]); b = np.ascontiguousarray(sm[i, j, :])
+            lib.orc_bioclim_cell(a.ctypes.data_as(DP), b.ctypes.data_as(DP), C.c_int(T),
+                                 qs[0].ctypes.data_as(IP), C.c_int(len(qs[0])), qs[1].ctypes.data_as(IP),
+                                 C.c_int(len(qs[1])), qs[2].ctypes.data_as(IP), C.c_int(len(qs[2])),
+                                 qs[3].ctypes.data_as(IP), C.c_int(len(qs[3])), tmp.ctypes.data_as(DP))
+            bio[:, i, j] = tmp
+    return {f"bio{v + 1}": bio[v] for v in range(19) if out[v]}

@@ -428,3 +428,69 @@ int orc_wrapper(int n, const int *year, const int *month, const int *day, const 
     }
     return 0;
 }
+
+/* ---- runbioclimCpp, cpp:3245-3560 (one cell's series; bio[] gets all 19 values) ---------- */
+static double std_dev(const double *v, int n) { /* calc_std_dev cpp:3227-3244 */
+    if (n <= 1) return orc_na_real();
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += v[i];
+    double mean = s / n, ss = 0.0;
+    for (int i = 0; i < n; ++i) ss += pow(v[i] - mean, 2.0);
+    return sqrt(ss / (n - 1));
+}
+static double qmean(const double *x, const int *q, int nq) { /* bioclim8..11, 16..19 */
+    double o = 0.0;
+    for (int i = 0; i < nq; ++i) o = o + x[q[i]];
+    return o / 72.0;
+}
+void orc_bioclim_cell(const double *Tz, const double *soilm, int tsteps, const int *wetq, int nwet,
+                      const int *dryq, int ndry, const int *hotq, int nhot, const int *colq, int ncol,
+                      double *bio) {
+    double o = 0.0;
+    for (int i = 0; i < 288; ++i) o = o + Tz[i];                                 /* bioclim1 */
+    bio[0] = o / 288.0;
+    double dtr[12], mon[12];
+    int index = 0;
+    for (int day = 0; day < 12; day++) {                                         /* bioclim2 */
+        double tmx = -273.15, tmn = 273.15;
+        for (int hr = 0; hr < 24; hr++) {
+            if (Tz[index] > tmx) tmx = Tz[index];
+            if (Tz[index] < tmn) tmn = Tz[index];
+            index++;
+        }
+        dtr[day] = tmx - tmn;
+    }
+    o = 0.0;
+    for (int day = 0; day < 12; day++) o = o + dtr[day];
+    bio[1] = o / 12;
+    index = 0;
+    for (int mth = 0; mth < 12; mth++) {                                         /* bioclim4 */
+        mon[mth] = 0.0;
+        for (int hr = 0; hr < 24; hr++) { mon[mth] = mon[mth] + Tz[index]; index++; }
+        mon[mth] = mon[mth] / 24;
+    }
+    bio[3] = std_dev(mon, 12) * 100.0;
+    double tmx = -273.15, tmn = 273.15;
+    for (int i = 288; i < 312; i++) if (Tz[i] > tmx) tmx = Tz[i];                /* bioclim5 */
+    for (int i = 312; i < 336; i++) if (Tz[i] < tmn) tmn = Tz[i];                /* bioclim6 */
+    bio[4] = tmx;
+    bio[5] = tmn;
+    bio[7] = qmean(Tz, wetq, nwet); bio[8] = qmean(Tz, dryq, ndry);
+    bio[9] = qmean(Tz, hotq, nhot); bio[10] = qmean(Tz, colq, ncol);
+    double me = 0.0;
+    for (int i = 0; i < 288; i++) me = me + soilm[i];                            /* bioclim12 */
+    me = me / 288.0;
+    bio[11] = me;
+    double mx = 0.0, mn = 1.0;
+    for (int i = 0; i < tsteps; i++) {                                           /* bioclim13, 14 */
+        if (soilm[i] > mx) mx = soilm[i];
+        if (soilm[i] < mn) mn = soilm[i];
+    }
+    bio[12] = mx;
+    bio[13] = mn;
+    bio[14] = me / std_dev(soilm, tsteps);                                       /* bioclim15 (sic) */
+    bio[15] = qmean(soilm, wetq, nwet); bio[16] = qmean(soilm, dryq, ndry);
+    bio[17] = qmean(soilm, hotq, nhot); bio[18] = qmean(soilm, colq, ncol);
+    bio[6] = bio[4] - bio[5];                                                    /* cpp:3533 */
+    bio[2] = bio[1] / bio[6];                                                    /* cpp:3534 */
+}

@@ -29,6 +29,9 @@ int orc_wrapper(int n, const int *year, const int *month, const int *day, const 
                 const double *wspeed, const double *BL_Tg, const double *BL_G, const double *BL_uf,
                 const double *vegp, const double *groundp, double reqhgt, double zref, double lat, double lon,
                 orc_wrapper_out *o);
+void orc_bioclim_cell(const double *Tz, const double *soilm, int tsteps, const int *wetq, int nwet,
+                      const int *dryq, int ndry, const int *hotq, int nhot, const int *colq, int ncol,
+                      double *bio);
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,7 @@
 #include <R.h>
 #include <Rinternals.h>
 #include <R_ext/Rdynload.h>
+#include <stdio.h>
 #include <string.h>
 
 #include "mcf.h"
@@ -42,14 +43,15 @@ static const int *intcol(SEXP x, int *np) {   /* obstime$year etc. arrive as dou
     return INTEGER(x);
 }
 
-static SEXP run(int array_forcing, SEXP dfsel, SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc,
-                SEXP reqhgt, SEXP zref, SEXP lat, SEXP lon, SEXP Sminp, SEXP Smaxp, SEXP tfact,
-                SEXP complete, SEXP mat, SEXP out) {
-    int np = 0;
-    mcf_grid_inputs in;
-    mcf_options opt;
-    mcf_outputs res;
-    memset(&in, 0, sizeof in); memset(&opt, 0, sizeof opt); memset(&res, 0, sizeof res);
+/* Fills in/opt from the R arguments shared by runmicro*Cpp and runbioclim*Cpp; *np counts PROTECTs. */
+static void fill_inputs(mcf_grid_inputs *pin, mcf_options *popt, int *pnp, int array_forcing, SEXP dfsel,
+                        SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc, SEXP reqhgt, SEXP zref,
+                        SEXP lat, SEXP lon, SEXP Sminp, SEXP Smaxp, SEXP tfact, SEXP complete, SEXP mat, SEXP out) {
+#define in (*pin)
+#define opt (*popt)
+#define np (*pnp)
+
+    memset(&in, 0, sizeof in); memset(&opt, 0, sizeof opt);
 
     SEXP hgt = elt(vegp, "hgt", NULL);
     SEXP dim = getAttrib(hgt, R_DimSymbol);
@@ -110,6 +112,21 @@ static SEXP run(int array_forcing, SEXP dfsel, SEXP obstime, SEXP climdata, SEXP
     /* Tg/Tbp are only read for reqhgt < 0 && !complete; the marshaller passes Tbp = 0 otherwise (int:1096) */
     if (!(opt.reqhgt < 0 && !opt.complete)) { in.pointm.Tg = NULL; in.pointm.Tbp = NULL; }
 
+#undef in
+#undef opt
+#undef np
+}
+
+static SEXP run(int array_forcing, SEXP dfsel, SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc,
+                SEXP reqhgt, SEXP zref, SEXP lat, SEXP lon, SEXP Sminp, SEXP Smaxp, SEXP tfact,
+                SEXP complete, SEXP mat, SEXP out) {
+    int np = 0;
+    mcf_grid_inputs in;
+    mcf_options opt;
+    mcf_outputs res;
+    memset(&res, 0, sizeof res);
+    fill_inputs(&in, &opt, &np, array_forcing, dfsel, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon,
+                Sminp, Smaxp, tfact, complete, mat, out);
     static const char *on[MCF_NOUT] = {"Tz", "tleaf", "relhum", "soilm", "windspeed", "Rdirdown", "Rdifdown",
                                        "Rlwdown", "Rswup", "Rlwup"};
     int nreq = 0;
@@ -163,11 +180,74 @@ SEXP mcfhip_runmicro4(SEXP dfsel, SEXP obstime, SEXP climdata, SEXP pointm, SEXP
     return run(1, dfsel, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons, Sminp, Smaxp, tfact, complete, mat, out);
 }
 
+/* _microclimf_runbioclim1Cpp / 2Cpp (src/microclimfCpp.cpp:3563-3616): 19 arguments; returns the list
+ * bio1..bio19 (requested ones) of [rows, cols] matrices.  Solver and reductions stay on the device. */
+static SEXP run_bioclim(int array_forcing, SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc,
+                        SEXP reqhgt, SEXP zref, SEXP lat, SEXP lon, SEXP Sminp, SEXP Smaxp, SEXP tfact, SEXP mat,
+                        SEXP out, SEXP wetq, SEXP dryq, SEXP hotq, SEXP colq, SEXP air) {
+    int np = 0;
+    mcf_grid_inputs in;
+    mcf_options opt;
+    SEXP mask = PROTECT(allocVector(LGLSXP, MCF_NOUT)); ++np;
+    for (int v = 0; v < MCF_NOUT; ++v) LOGICAL(mask)[v] = TRUE;
+    SEXP tru = PROTECT(ScalarLogical(TRUE)); ++np;
+    fill_inputs(&in, &opt, &np, array_forcing, R_NilValue, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat,
+                lon, Sminp, Smaxp, tfact, tru, mat, mask);
+    mcf_bioclim_sel sel;
+    mcf_bioclim_out bo;
+    memset(&sel, 0, sizeof sel); memset(&bo, 0, sizeof bo);
+    sel.wetq = intcol(wetq, &np); sel.nwet = LENGTH(wetq);
+    sel.dryq = intcol(dryq, &np); sel.ndry = LENGTH(dryq);
+    sel.hotq = intcol(hotq, &np); sel.nhot = LENGTH(hotq);
+    sel.colq = intcol(colq, &np); sel.ncol = LENGTH(colq);
+    sel.air = asLogical(air) == TRUE;
+    SEXP outl = PROTECT(coerceVector(out, LGLSXP)); ++np;
+    if (LENGTH(outl) != MCF_NBIO) Rf_error("mcfhip: out must have 19 elements");
+    int nreq = 0;
+    for (int v = 0; v < MCF_NBIO; ++v) { sel.out[v] = LOGICAL(outl)[v] == TRUE; nreq += sel.out[v]; }
+    SEXP ans = PROTECT(allocVector(VECSXP, nreq)); ++np;
+    SEXP nms = PROTECT(allocVector(STRSXP, nreq)); ++np;
+    for (int v = 0, k = 0; v < MCF_NBIO; ++v) {
+        if (!sel.out[v]) continue;
+        SEXP a = PROTECT(allocMatrix(REALSXP, (int)in.rows, (int)in.cols)); ++np;
+        char nm[8];
+        snprintf(nm, sizeof nm, "bio%d", v + 1);
+        SET_VECTOR_ELT(ans, k, a);
+        SET_STRING_ELT(nms, k, mkChar(nm));
+        bo.bio[v] = REAL(a);
+        ++k;
+    }
+    setAttrib(ans, R_NamesSymbol, nms);
+    int rc = array_forcing ? mcf_runbioclim2(&in, &opt, &sel, &bo) : mcf_runbioclim1(&in, &opt, &sel, &bo);
+    if (rc != MCF_OK) {
+        char msg[600];
+        strncpy(msg, mcf_last_error(), sizeof msg - 1); msg[sizeof msg - 1] = 0;
+        UNPROTECT(np);
+        Rf_error("mcfhip (%d): %s", rc, msg);
+    }
+    UNPROTECT(np);
+    return ans;
+}
+SEXP mcfhip_runbioclim1(SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc, SEXP reqhgt, SEXP zref,
+                        SEXP lat, SEXP lon, SEXP Sminp, SEXP Smaxp, SEXP tfact, SEXP mat, SEXP out, SEXP wetq,
+                        SEXP dryq, SEXP hotq, SEXP colq, SEXP air) {
+    return run_bioclim(0, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact, mat, out,
+                       wetq, dryq, hotq, colq, air);
+}
+SEXP mcfhip_runbioclim2(SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc, SEXP reqhgt, SEXP zref,
+                        SEXP lats, SEXP lons, SEXP Sminp, SEXP Smaxp, SEXP tfact, SEXP mat, SEXP out, SEXP wetq,
+                        SEXP dryq, SEXP hotq, SEXP colq, SEXP air) {
+    return run_bioclim(1, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons, Sminp, Smaxp, tfact, mat,
+                       out, wetq, dryq, hotq, colq, air);
+}
+
 static const R_CallMethodDef CallEntries[] = {
     {"mcfhip_runmicro1", (DL_FUNC)&mcfhip_runmicro1, 15},
     {"mcfhip_runmicro2", (DL_FUNC)&mcfhip_runmicro2, 15},
     {"mcfhip_runmicro3", (DL_FUNC)&mcfhip_runmicro3, 16},
     {"mcfhip_runmicro4", (DL_FUNC)&mcfhip_runmicro4, 16},
+    {"mcfhip_runbioclim1", (DL_FUNC)&mcfhip_runbioclim1, 19},
+    {"mcfhip_runbioclim2", (DL_FUNC)&mcfhip_runbioclim2, 19},
     {NULL, NULL, 0}};
 
 void R_init_mcfhip_glue(DllInfo *dll) {
