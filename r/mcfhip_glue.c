@@ -44,14 +44,11 @@ static const int *intcol(SEXP x, int *np) {   /* obstime$year etc. arrive as dou
 }
 
 /* Fills in/opt from the R arguments shared by runmicro*Cpp and runbioclim*Cpp; *np counts PROTECTs. */
-static void fill_inputs(mcf_grid_inputs *pin, mcf_options *popt, int *pnp, int array_forcing, SEXP dfsel,
+static void fill_inputs(mcf_grid_inputs *in, mcf_options *opt, int *np, int array_forcing, SEXP dfsel,
                         SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc, SEXP reqhgt, SEXP zref,
                         SEXP lat, SEXP lon, SEXP Sminp, SEXP Smaxp, SEXP tfact, SEXP complete, SEXP mat, SEXP out) {
-#define in (*pin)
-#define opt (*popt)
-#define np (*pnp)
 
-    memset(&in, 0, sizeof in); memset(&opt, 0, sizeof opt);
+    memset(in, 0, sizeof *in); memset(opt, 0, sizeof *opt);
 
     SEXP hgt = elt(vegp, "hgt", NULL);
     SEXP dim = getAttrib(hgt, R_DimSymbol);
@@ -60,61 +57,58 @@ static void fill_inputs(mcf_grid_inputs *pin, mcf_options *popt, int *pnp, int a
     } else {
         /* runmicro3Cpp/4Cpp: vegetation arrays [rows, cols, layers] + dfsel (lyr, st, ed), cpp:2629-2640 */
         if (TYPEOF(dim) != INTSXP || LENGTH(dim) != 3) Rf_error("mcfhip: vegp$hgt must be a 3-D array");
-        in.veg_layers = INTEGER(dim)[2];
-        if (XLENGTH(elt(dfsel, "st", NULL)) != in.veg_layers) Rf_error("mcfhip: dfsel rows != vegetation layers");
-        in.lyr_st = intcol(elt(dfsel, "st", NULL), &np);
-        in.lyr_ed = intcol(elt(dfsel, "ed", NULL), &np);
+        in->veg_layers = INTEGER(dim)[2];
+        if (XLENGTH(elt(dfsel, "st", NULL)) != in->veg_layers) Rf_error("mcfhip: dfsel rows != vegetation layers");
+        in->lyr_st = intcol(elt(dfsel, "st", NULL), np);
+        in->lyr_ed = intcol(elt(dfsel, "ed", NULL), np);
     }
-    in.rows = INTEGER(dim)[0]; in.cols = INTEGER(dim)[1];
-    in.tsteps = XLENGTH(elt(obstime, "year", NULL));
-    in.array_forcing = array_forcing;
-    in.obstime.year = intcol(elt(obstime, "year", NULL), &np);
-    in.obstime.month = intcol(elt(obstime, "month", NULL), &np);
-    in.obstime.day = intcol(elt(obstime, "day", NULL), &np);
-    in.obstime.hour = dbl(elt(obstime, "hour", NULL), &np);
+    in->rows = INTEGER(dim)[0]; in->cols = INTEGER(dim)[1];
+    in->tsteps = XLENGTH(elt(obstime, "year", NULL));
+    in->array_forcing = array_forcing;
+    in->obstime.year = intcol(elt(obstime, "year", NULL), np);
+    in->obstime.month = intcol(elt(obstime, "month", NULL), np);
+    in->obstime.day = intcol(elt(obstime, "day", NULL), np);
+    in->obstime.hour = dbl(elt(obstime, "hour", NULL), np);
     /* climdata: data.frame columns (1Cpp, cpp:2062-2071) or list entries (2Cpp, cpp:2350-2359) */
-    in.clim.tc = dbl(elt(climdata, "temp", "tc"), &np);
-    in.clim.es = dbl(elt(climdata, "es", NULL), &np);
-    in.clim.ea = dbl(elt(climdata, "ea", NULL), &np);
-    in.clim.tdew = dbl(elt(climdata, "tdew", NULL), &np);
-    in.clim.pk = dbl(elt(climdata, "pres", "pk"), &np);
-    in.clim.swdown = dbl(elt(climdata, "swdown", NULL), &np);
-    in.clim.difrad = dbl(elt(climdata, "difrad", NULL), &np);
-    in.clim.lwdown = dbl(elt(climdata, "lwdown", NULL), &np);
-    in.clim.windspeed = dbl(elt(climdata, "windspeed", NULL), &np);
-    in.clim.winddir = dbl(elt(climdata, "winddir", NULL), &np);
-    in.pointm.soilm = dbl(elt(pointm, "soilm", NULL), &np);
-    in.pointm.Tg = dbl(elt(pointm, "Tg", NULL), &np);
-    in.pointm.Tbp = dbl(elt(pointm, "Tbp", NULL), &np);
-    in.pointm.G = dbl(elt(pointm, "G", "Gp"), &np);
-    in.pointm.umu = dbl(elt(pointm, "umu", NULL), &np);
-    in.pointm.kp = dbl(elt(pointm, "kp", NULL), &np);
-    in.pointm.muGp = dbl(elt(pointm, "muGp", NULL), &np);
-    in.pointm.dtrp = dbl(elt(pointm, "dtrp", NULL), &np);
+    in->clim.tc = dbl(elt(climdata, "temp", "tc"), np);
+    in->clim.es = dbl(elt(climdata, "es", NULL), np);
+    in->clim.ea = dbl(elt(climdata, "ea", NULL), np);
+    in->clim.tdew = dbl(elt(climdata, "tdew", NULL), np);
+    in->clim.pk = dbl(elt(climdata, "pres", "pk"), np);
+    in->clim.swdown = dbl(elt(climdata, "swdown", NULL), np);
+    in->clim.difrad = dbl(elt(climdata, "difrad", NULL), np);
+    in->clim.lwdown = dbl(elt(climdata, "lwdown", NULL), np);
+    in->clim.windspeed = dbl(elt(climdata, "windspeed", NULL), np);
+    in->clim.winddir = dbl(elt(climdata, "winddir", NULL), np);
+    in->pointm.soilm = dbl(elt(pointm, "soilm", NULL), np);
+    in->pointm.Tg = dbl(elt(pointm, "Tg", NULL), np);
+    in->pointm.Tbp = dbl(elt(pointm, "Tbp", NULL), np);
+    in->pointm.G = dbl(elt(pointm, "G", "Gp"), np);
+    in->pointm.umu = dbl(elt(pointm, "umu", NULL), np);
+    in->pointm.kp = dbl(elt(pointm, "kp", NULL), np);
+    in->pointm.muGp = dbl(elt(pointm, "muGp", NULL), np);
+    in->pointm.dtrp = dbl(elt(pointm, "dtrp", NULL), np);
     static const char *vn[10] = {"hgt", "pai", "x", "gsmax", "leafr", "leaft", "clump", "leafd", "paia", "leafden"};
-    const double **vp = (const double **)&in.vegp;
-    for (int i = 0; i < 10; ++i) vp[i] = dbl(elt(vegp, vn[i], NULL), &np);
+    const double **vp = (const double **)&in->vegp;
+    for (int i = 0; i < 10; ++i) vp[i] = dbl(elt(vegp, vn[i], NULL), np);
     static const char *sn[15] = {"Smin", "Smax", "gref", "soilb", "Psie", "Vq", "Vm", "Mc", "rho", "slope",
                                  "aspect", "twi", "svfa", "wsa", "hor"};
-    const double **sp = (const double **)&in.soilc;
-    for (int i = 0; i < 15; ++i) sp[i] = dbl(elt(soilc, sn[i], NULL), &np);
-    if (array_forcing) { in.lats = dbl(lat, &np); in.lons = dbl(lon, &np); }
-    else { in.lat = asReal(lat); in.lon = asReal(lon); }
+    const double **sp = (const double **)&in->soilc;
+    for (int i = 0; i < 15; ++i) sp[i] = dbl(elt(soilc, sn[i], NULL), np);
+    if (array_forcing) { in->lats = dbl(lat, np); in->lons = dbl(lon, np); }
+    else { in->lat = asReal(lat); in->lon = asReal(lon); }
 
-    opt.reqhgt = asReal(reqhgt); opt.zref = asReal(zref);
-    opt.Sminp = asReal(Sminp); opt.Smaxp = asReal(Smaxp);
-    opt.tfact = asReal(tfact); opt.mat = asReal(mat);
-    opt.complete = asLogical(complete) == TRUE;
+    opt->reqhgt = asReal(reqhgt); opt->zref = asReal(zref);
+    opt->Sminp = asReal(Sminp); opt->Smaxp = asReal(Smaxp);
+    opt->tfact = asReal(tfact); opt->mat = asReal(mat);
+    opt->complete = asLogical(complete) == TRUE;
     /* `out` may be logical or numeric 0/1 after `out2*out` (int:1161) */
-    SEXP outl = PROTECT(coerceVector(out, LGLSXP)); ++np;
+    SEXP outl = PROTECT(coerceVector(out, LGLSXP)); ++*np;
     if (LENGTH(outl) != MCF_NOUT) Rf_error("mcfhip: out must have 10 elements");
-    for (int v = 0; v < MCF_NOUT; ++v) opt.out[v] = LOGICAL(outl)[v] == TRUE;
+    for (int v = 0; v < MCF_NOUT; ++v) opt->out[v] = LOGICAL(outl)[v] == TRUE;
     /* Tg/Tbp are only read for reqhgt < 0 && !complete; the marshaller passes Tbp = 0 otherwise (int:1096) */
-    if (!(opt.reqhgt < 0 && !opt.complete)) { in.pointm.Tg = NULL; in.pointm.Tbp = NULL; }
+    if (!(opt->reqhgt < 0 && !opt->complete)) { in->pointm.Tg = NULL; in->pointm.Tbp = NULL; }
 
-#undef in
-#undef opt
-#undef np
 }
 
 static SEXP run(int array_forcing, SEXP dfsel, SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc,
