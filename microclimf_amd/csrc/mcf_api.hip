@@ -489,6 +489,16 @@ int mcf_plan_run_days(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot) {
     a.slot_step0 = p->bg ? (int64_t)day0 * 24 : 0;
     a.tgser = p->d_tgser; a.ddsum = p->d_ddsum;
     a.day0 = day0; a.ndays = ndays;
+    {
+        // pass 2 yields Tz (+ tleaf, relhum for reqhgt > 0) and the long-wave fluxes; requests for
+        // soilm / windspeed / short-wave fluxes alone are served by pass 1
+        const bool o0 = p->var_slot[MCF_OUT_TZ] >= 0, o1 = p->var_slot[MCF_OUT_TLEAF] >= 0,
+                   o2 = p->var_slot[MCF_OUT_RELHUM] >= 0, o7 = p->var_slot[MCF_OUT_RLWDOWN] >= 0,
+                   o9 = p->var_slot[MCF_OUT_RLWUP] >= 0;
+        const double rq = p->opt.reqhgt;
+        a.need_tv = (rq > 0.0 && (o0 || o1 || o2 || o7 || o9)) || (rq == 0.0 && (o7 || o9));
+        a.need_pass2 = p->bg ? (o0 ? 1 : 0) : (a.need_tv || (rq == 0.0 && o0));
+    }
     a.g = p->g;
     if (p->ktiming) {
         hipEvent_t e0, e1;

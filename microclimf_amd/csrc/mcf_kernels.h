@@ -72,6 +72,8 @@ struct SolveArgs {
     double* tgser;          // [N][tsteps]
     double* ddsum;          // [N]
     int32_t day0, ndays;
+    int32_t need_pass2;  // 0: no requested output comes from pass 2 (Tz, tleaf, relhum, Rlwdown, Rlwup)
+    int32_t need_tv;     // 0: no requested output comes from TVaboveground (cpp:2287-2303)
     Globals g;
 };
 

@@ -414,7 +414,8 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? 3 : MCF_WAVES_PER_EU) void
     Globals g = a.g;
     double dTmx = g.dTmx;
     if (AF && in_grid) dTmx = -0.6273 * a.mxtc[c] + 49.79;   // cpp:1236 with the per-cell mxtc
-    const bool above_ground = g.reqhgt >= 0.0;
+    // TVaboveground (cpp:2272) is only evaluated when one of its outputs was requested
+    const bool need_tv = g.reqhgt >= 0.0 && a.need_tv != 0;
     const double NA = na_real();
 
     for (int dl = 0; dl < a.ndays; ++dl) {
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? 3 : MCF_WAVES_PER_EU) void
 #if !MCF_EXPERIMENT_NOBARRIER
         __syncthreads();
 #endif
-        if (valid) {
+        if (valid && a.need_pass2) {
             // day reductions in hour order with the reference's comparisons, cpp:2196-2198, 2256-2263
             double Rmx = -999.9, tmx = -999.0, tmn = 999.0;
             const double* rt = &s_red[dl & 1][0][cl];
@@ -528,14 +529,14 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? 3 : MCF_WAVES_PER_EU) void
                 if (tmn > tg) tmn = tg;
             }
             const double dtr = tmx - tmn;
-            Pass2Out p2;
+            Pass2Out p2{};
             if (AF)
                 derive_time_af_pass2(tv, a.af_base[(int64_t)TF_GP * a.af_stride + fidx],
                                      a.af_base[(int64_t)TF_MUGP * a.af_stride + fidx],
                                      a.af_base[(int64_t)TF_DTRP * a.af_stride + fidx],
                                      a.af_base[(int64_t)TF_KP * a.af_stride + fidx]);
-            if (AF) pass2(C, TR, g, flags, dTmx, cy, dtr, Rmx, above_ground, p2);
-            else pass2(C, TL, g, flags, dTmx, cy, dtr, Rmx, above_ground, p2);
+            if (AF) pass2(C, TR, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2);
+            else pass2(C, TL, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2);
             if (BG) {
                 a.tgser[c + N * ((int64_t)dabs * 24 + hr)] = p2.Tg;
                 s_dd[hr * CPB + cl] = p2.DD;

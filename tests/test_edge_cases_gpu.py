@@ -87,3 +87,16 @@ def test_array_forcing_plan_needs_uploaded_days():
         p.upload_forcing_days(1, 1, 1)
         p.run_days(1, 1, 1)
         p.sync()
+
+
+@pytest.mark.parametrize("reqhgt,out", [
+    (0.05, [0, 0, 0, 1, 1, 1, 1, 0, 1, 0]),     # pass-1 outputs only: pass 2 is skipped
+    (0.0, [1, 0, 0, 1, 0, 0, 0, 0, 0, 0]),      # ground temperature without TVaboveground
+    (0.0, [0, 1, 0, 0, 0, 0, 0, 1, 0, 0]),      # tleaf (always NA at reqhgt 0) + Rlwdown
+    (-0.1, [0, 0, 0, 1, 0, 0, 0, 0, 0, 0]),     # soil run without Tz: no smoothing pass
+    (0.05, [0, 0, 1, 0, 0, 0, 0, 0, 0, 0]),     # relhum alone
+])
+def test_output_subsets_skip_unneeded_work(oracle, reqhgt, out):
+    a = synthetic.workload(14, 6, 72, reqhgt=reqhgt, variety=True, start_doy=170, out=out)
+    a["vegp"]["hgt"][1, 1] = np.nan
+    compare(runmicro1Cpp(**a), oracle.run_grid(**a))
