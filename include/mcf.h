@@ -264,6 +264,87 @@ typedef struct mcf_terrain_out {
 
 int mcf_precompute_terrain(const mcf_terrain_in *in, const mcf_terrain_out *out, int32_t device);
 
+/* ---- snow branch ----------------------------------------------------------------------
+ *   mcf_gridmodelsnow1/2()  replace  _microclimf_gridmodelsnow1 / _microclimf_gridmodelsnow2
+ *                           src/RcppExports.cpp:483-514  (R stubs R/RcppExports.R:108-114,
+ *                           bodies src/microclimfCpp.cpp:4172-4423 / 4426-4673): the per-cell,
+ *                           sequential-in-time snowpack energy and mass balance (snowoneB,
+ *                           src/microclimfCpp.cpp:3835-3972) that `.snowmodel1/2` call once per
+ *                           5-day chunk (R/internal.R:2587).
+ *   mcf_gridmicrosnow1/2()  replace  _microclimf_gridmicrosnow1 / _microclimf_gridmicrosnow2
+ *                           src/RcppExports.cpp:542-578  (R stubs R/RcppExports.R:124-130,
+ *                           bodies src/microclimfCpp.cpp:4894-5056 / 5059-5214): the microclimate
+ *                           of snow-covered cell-steps, written over the no-snow solver's output
+ *                           (`.runmicrosnow1/2`, R/internal.R:3625).
+ * Vector forcing (…1): climate and pointm entries are [tsteps]; array forcing (…2): they are
+ * [rows,cols,tsteps] except winddir, and lats/lons replace lat/lon. */
+enum { /* snowdenp's snow environments (src/microclimfCpp.cpp:3741-3749); any other name = Alpine */
+    MCF_SNOWENV_ALPINE = 0, MCF_SNOWENV_MARITIME = 1, MCF_SNOWENV_PRAIRIE = 2, MCF_SNOWENV_TUNDRA = 3,
+    MCF_SNOWENV_TAIGA = 4
+};
+/* Maps the reference's `snowenv` string to the enum (exact, case-sensitive match as in the reference). */
+int32_t mcf_snowenv_from_name(const char *name);
+
+/* climdata columns temp, relhum, pres, swdown, difrad, lwdown, windspeed, winddir, precip
+ * (src/microclimfCpp.cpp:4206-4214; gridmicrosnow2 names the last one "prec", :5083) and, for
+ * gridmicrosnow only, umu (:4911). */
+typedef struct mcf_snow_climate {
+    const double *temp, *relhum, *pres, *swdown, *difrad, *lwdown, *windspeed, *winddir, *precip, *umu;
+} mcf_snow_climate;
+/* pointm of gridmodelsnow (src/microclimfCpp.cpp:4181-4186): output of pointmodelsnow.  `tr` is
+ * only used for its length (ndays = tr.size()/24, :4231) and is not part of this ABI. */
+typedef struct mcf_snow_pointm {
+    const double *Gp, *Tc, *RswabsG, *RlwabsG, *umu;
+} mcf_snow_pointm;
+/* vegp (src/microclimfCpp.cpp:4188-4191; gridmicrosnow adds paia, leafd, leafden :4913-4919). */
+typedef struct mcf_snow_vegp {
+    const double *pai, *hgt, *leaft, *clump; /* [rows,cols] */
+    const double *paia, *leafd, *leafden;    /* gridmicrosnow only */
+} mcf_snow_vegp;
+/* other (src/microclimfCpp.cpp:4193-4204, :4921-4929). */
+typedef struct mcf_snow_other {
+    const double *slope, *aspect, *skyview; /* [rows,cols]                                   */
+    const double *wsa;                      /* [rows,cols,8]                                 */
+    const double *hor;                      /* [rows,cols,24]                                */
+    double lat, lon;                        /* vector forcing                                */
+    const double *lats, *lons;              /* array forcing, [rows,cols]                    */
+    double zref;
+    const double *isnowdc, *isnowdg;        /* gridmodelsnow: initial snow depth (m)         */
+    const int32_t *isnowac, *isnowag;       /* gridmodelsnow: initial snow age (h), IntegerMatrix */
+    const double *Smax;                     /* gridmicrosnow: written to soilm under snow    */
+} mcf_snow_other;
+typedef struct mcf_snow_inputs {
+    int64_t rows, cols, tsteps;
+    int32_t array_forcing;
+    int32_t snowenv; /* MCF_SNOWENV_* (gridmodelsnow only) */
+    mcf_obstime obstime;
+    mcf_snow_climate clim;
+    mcf_snow_pointm pointm; /* gridmodelsnow only */
+    mcf_snow_vegp vegp;
+    mcf_snow_other other;
+} mcf_snow_inputs;
+/* Returned list of gridmodelsnow (src/microclimfCpp.cpp:4412-4422): Tc, Tg, sdepc, sdepg, sden are
+ * [rows,cols,tsteps]; agec, ageg, meltc, meltg are [rows,cols].  Any pointer may be NULL (not
+ * wanted).  Cells with NA hgt hold NA_real_ everywhere. */
+typedef struct mcf_snowmodel_out {
+    double *Tc, *Tg, *sdepc, *sdepg, *sden;
+    double *agec, *ageg, *meltc, *meltg;
+} mcf_snowmodel_out;
+int mcf_gridmodelsnow1(const mcf_snow_inputs *in, mcf_snowmodel_out *out, int32_t device);
+int mcf_gridmodelsnow2(const mcf_snow_inputs *in, mcf_snowmodel_out *out, int32_t device);
+
+/* snowm list of gridmicrosnow (src/microclimfCpp.cpp:4935-4939), each [rows,cols,tsteps]. */
+typedef struct mcf_snowm {
+    const double *Tc, *Tg, *totalSWE, *groundsnowdepth, *snowden;
+} mcf_snowm;
+/* `micro` holds the no-snow solver's output on entry and is updated IN PLACE for every cell-step
+ * with totalSWE > 0 (src/microclimfCpp.cpp:4993-5038); only variables with out[v] != 0 are read
+ * or written, their pointers must then be non-NULL. */
+int mcf_gridmicrosnow1(const mcf_snow_inputs *in, const mcf_snowm *snowm, double reqhgt, double mat,
+                       const int32_t out[MCF_NOUT], mcf_outputs *micro, int32_t device);
+int mcf_gridmicrosnow2(const mcf_snow_inputs *in, const mcf_snowm *snowm, double reqhgt, double mat,
+                       const int32_t out[MCF_NOUT], mcf_outputs *micro, int32_t device);
+
 /* Diagnostics: evaluate one of the solver's lean device elementary functions
  * elementwise on host arrays (kind 0 exp, 1 log, 2 x/y, 3 sqrt, 4 1/x, 5 satvap
  * (cpp:480-490), 6 x^y); used by tests to bound their error against libm. */

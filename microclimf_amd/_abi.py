@@ -91,6 +91,35 @@ class Outputs(C.Structure):
     _fields_ = [("var", c_double_p * NOUT)]
 
 
+# ---- snow branch (include/mcf.h "snow branch") ----
+SNOWENV = {"Alpine": 0, "Maritime": 1, "Prairie": 2, "Tundra": 3, "Taiga": 4}
+SNOW_CLIM_FIELDS = ("temp", "relhum", "pres", "swdown", "difrad", "lwdown", "windspeed", "winddir", "precip", "umu")
+SNOW_POINTM_FIELDS = ("Gp", "Tc", "RswabsG", "RlwabsG", "umu")
+SNOW_VEGP_FIELDS = ("pai", "hgt", "leaft", "clump", "paia", "leafd", "leafden")
+SNOWM_FIELDS = ("Tc", "Tg", "totalSWE", "groundsnowdepth", "snowden")
+SNOWMODEL_OUT3 = ("Tc", "Tg", "sdepc", "sdepg", "sden")
+SNOWMODEL_OUT2 = ("agec", "ageg", "meltc", "meltg")
+
+SnowClimate = _ptr_struct("SnowClimate", SNOW_CLIM_FIELDS)
+SnowPointm = _ptr_struct("SnowPointm", SNOW_POINTM_FIELDS)
+SnowVegp = _ptr_struct("SnowVegp", SNOW_VEGP_FIELDS)
+Snowm = _ptr_struct("Snowm", SNOWM_FIELDS)
+SnowModelOut = _ptr_struct("SnowModelOut", SNOWMODEL_OUT3 + SNOWMODEL_OUT2)
+
+
+class SnowOther(C.Structure):
+    _fields_ = [("slope", c_double_p), ("aspect", c_double_p), ("skyview", c_double_p), ("wsa", c_double_p),
+                ("hor", c_double_p), ("lat", C.c_double), ("lon", C.c_double), ("lats", c_double_p),
+                ("lons", c_double_p), ("zref", C.c_double), ("isnowdc", c_double_p), ("isnowdg", c_double_p),
+                ("isnowac", c_int32_p), ("isnowag", c_int32_p), ("Smax", c_double_p)]
+
+
+class SnowInputs(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("cols", C.c_int64), ("tsteps", C.c_int64), ("array_forcing", C.c_int32),
+                ("snowenv", C.c_int32), ("obstime", Obstime), ("clim", SnowClimate), ("pointm", SnowPointm),
+                ("vegp", SnowVegp), ("other", SnowOther)]
+
+
 _PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = _PKG_DIR / "csrc" / "libmcfhip.so"
 
@@ -104,6 +133,8 @@ EXPORTS = (
     "mcf_plan_timer_start", "mcf_plan_timer_stop", "mcf_plan_kernel_timing",
     "mcf_plan_kernel_stats", "mcf_plan_valid_cells", "mcf_plan_bytes", "mcf_selftest_math",
     "mcf_precompute_terrain", "mcf_runbioclim1", "mcf_runbioclim2",
+    "mcf_snowenv_from_name", "mcf_gridmodelsnow1", "mcf_gridmodelsnow2", "mcf_gridmicrosnow1",
+    "mcf_gridmicrosnow2",
 )
 
 _lib = None
@@ -170,6 +201,15 @@ def load() -> C.CDLL:
     for fn in (lib.mcf_runbioclim1, lib.mcf_runbioclim2):
         fn.restype = C.c_int
         fn.argtypes = [GI, OP, C.POINTER(BioclimSel), C.POINTER(BioclimOut)]
+    lib.mcf_snowenv_from_name.restype = C.c_int32
+    lib.mcf_snowenv_from_name.argtypes = [C.c_char_p]
+    SI = C.POINTER(SnowInputs)
+    for fn in (lib.mcf_gridmodelsnow1, lib.mcf_gridmodelsnow2):
+        fn.restype = C.c_int
+        fn.argtypes = [SI, C.POINTER(SnowModelOut), C.c_int32]
+    for fn in (lib.mcf_gridmicrosnow1, lib.mcf_gridmicrosnow2):
+        fn.restype = C.c_int
+        fn.argtypes = [SI, C.POINTER(Snowm), C.c_double, C.c_double, C.POINTER(C.c_int32 * NOUT), OU, C.c_int32]
     lib.mcf_precompute_terrain.restype = C.c_int
     lib.mcf_precompute_terrain.argtypes = [C.POINTER(TerrainIn), C.POINTER(TerrainOut), C.c_int32]
     if lib.mcf_abi_version() != 1:

@@ -1,0 +1,700 @@
+// mcf_snow.hip — the snow branch on the device: kernels and C-ABI entry points
+//   mcf_gridmodelsnow1/2   per-cell, sequential-in-time snowpack model   cpp:4172-4673
+//   mcf_gridmicrosnow1/2   microclimate of snow-covered cell-steps       cpp:4894-5214
+// ("cpp:" = the reference's src/microclimfCpp.cpp).  Physics: mcf_snow_device.hpp.
+//
+// Parallel shape.  The snowpack is a recurrence in time (depth, density and age of two layers
+// carried from step to step), so gridmodelsnow runs ONE LANE PER CELL with the lanes of a wave
+// along the raster rows: every [rows,cols,tsteps] store is a coalesced 512-B line per wave and
+// step, the state lives in registers, and — with data.frame climate — the per-step table row is
+// wave-uniform (scalar loads).  gridmicrosnow has no recurrence: one lane per (cell, day) walks
+// 24 hours after forming the day's mean snow temperature (snowdayan, cpp:4679-4712).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mcf.h"
+#include "mcf_snow_device.hpp"
+
+namespace mcf {
+int api_fail(int code, const std::string& msg);   // mcf_api.hip
+}
+
+namespace {
+using namespace mcf;
+using namespace mcf::snow;
+
+// One time step with data.frame climate: everything that does not depend on the cell.
+struct StepRow {
+    MetT m;
+    DayT d;
+    SunT s;
+    double rnet;     // RswabsG + RlwabsG - Rem of the point model, cpp:4229
+    int32_t sindex, windex;
+};
+// Date part of a step for array climate (site part applied per cell).
+struct DateRow2 {
+    double sindec, cosdec, eot, hour;
+    int32_t windex, pad;
+};
+
+struct StepArgs {
+    int tsteps;
+    const int32_t *year, *month, *day;
+    const double* hour;
+    const double *temp, *relhum, *pres, *swdown, *difrad, *lwdown, *windspeed, *winddir, *precip;
+    const double *Gp, *Tcp, *RswabsG, *RlwabsG, *umu;   // null for gridmicrosnow
+    double lat, lon;
+    int32_t degrees;   // horizon test in degrees (gridmodelsnow1) or radians
+    StepRow* rows;
+    DateRow2* dates;   // array climate
+    double* mxtc;      // [1]
+};
+
+// ---- data.frame climate: per-step table -------------------------------------------------------
+__global__ __launch_bounds__(256) void k_snow_steps(StepArgs a) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.tsteps) return;
+    StepRow r;
+    memset(&r, 0, sizeof r);
+    const SolDate sd = sol_date(a.year[k], a.month[k], a.day[k]);
+    const double latr = a.lat * kPi / 180.0;
+    const SolPos sp = sol_site(sd, a.hour[k], sin(latr), cos(latr), a.lon);
+    r.s = sun_derive(sp, a.degrees != 0);
+    r.sindex = dir_index(sp.azid, 15.0, 24);
+    r.windex = dir_index(a.winddir[k], 45.0, 8);
+    if (a.Gp) {
+        met_derive(r.m, a.temp[k], a.relhum[k], a.pres[k], a.Tcp[k]);
+        r.m.prec = a.precip[k];
+        r.m.rsw = a.swdown[k]; r.m.rdif = a.difrad[k]; r.m.rlw = a.lwdown[k];
+        r.m.umu = a.umu[k]; r.m.u2 = a.windspeed[k]; r.m.gp = a.Gp[k];
+        r.rnet = a.RswabsG[k] + a.RlwabsG[k] - r.m.rem;
+    }
+    a.rows[k] = r;
+}
+// daily extremes of the point model's net radiation (cpp:4231-4282): one lane per day
+__global__ __launch_bounds__(64) void k_snow_days(StepRow* rows, int tsteps) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= tsteps / 24) return;
+    DayT dy;
+    day_init(dy);
+    for (int h = 0; h < 24; ++h) {
+        const StepRow& r = rows[d * 24 + h];
+        day_accum(dy, r.rnet, r.m.rsw, r.m.rlw);
+    }
+    for (int h = 0; h < 24; ++h) rows[d * 24 + h].d = dy;
+}
+// snowalbCpp is a scan over time (hours since snowfall): a single lane walks the series once;
+// the same walk yields the series maximum of temperature that gridmicrosnow1 needs (cpp:4973-4974)
+__global__ void k_snow_alb(StepRow* rows, const double* precip, const double* temp, int tsteps, double* mxtc) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int hs = 0;
+    double mx = -273.15;
+    for (int k = 0; k < tsteps; ++k) {
+        if (k > 0) hs = precip[k] > 0 ? 0 : hs + 1;
+        rows[k].m.alb = snow_albedo(hs);
+        if (temp[k] > mx) mx = temp[k];
+    }
+    if (mxtc) *mxtc = mx;
+}
+// array climate: date-only part of the sun position
+__global__ __launch_bounds__(256) void k_snow_dates(StepArgs a) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.tsteps) return;
+    const SolDate sd = sol_date(a.year[k], a.month[k], a.day[k]);
+    DateRow2 r;
+    r.sindec = sd.sindec; r.cosdec = sd.cosdec; r.eot = sd.eot; r.hour = a.hour[k];
+    r.windex = dir_index(a.winddir[k], 45.0, 8);
+    r.pad = 0;
+    a.dates[k] = r;
+}
+
+// ---- gridmodelsnow ---------------------------------------------------------------------------------
+struct ModelArgs {
+    int64_t N;
+    int tsteps;
+    const double *pai, *hgt, *leaft, *clump, *slope, *aspect, *skyview, *wsa, *hor, *lats, *lons;
+    const double *isnowdc, *isnowdg;
+    const int32_t *isnowac, *isnowag;
+    double zref;
+    double sdp[4];
+    const StepRow* rows;     // data.frame climate
+    const DateRow2* dates;   // array climate
+    const double *temp, *relhum, *pres, *swdown, *difrad, *lwdown, *windspeed, *precip;   // [N][T]
+    const double *Gp, *Tcp, *RswabsG, *RlwabsG, *umu;                                     // [N][T]
+    double *Tc, *Tg, *sdepc, *sdepg, *sden;   // [N][T] or null
+    double *agec, *ageg, *meltc, *meltg;      // [N] or null
+};
+
+template <bool AF>
+__global__ __launch_bounds__(256) void k_snowmodel(ModelArgs a) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.N) return;
+    const int64_t N = a.N;
+    const double NA = na_real();
+    const double hgt0 = a.hgt[c];
+    if (isnan(hgt0)) {   // cpp:4320-4321
+        for (int k = 0; k < a.tsteps; ++k) {
+            const int64_t o = c + N * k;
+            if (a.Tc) a.Tc[o] = NA;
+            if (a.Tg) a.Tg[o] = NA;
+            if (a.sdepc) a.sdepc[o] = NA;
+            if (a.sdepg) a.sdepg[o] = NA;
+            if (a.sden) a.sden[o] = NA;
+        }
+        if (a.agec) a.agec[c] = NA;
+        if (a.ageg) a.ageg[c] = NA;
+        if (a.meltc) a.meltc[c] = NA;
+        if (a.meltg) a.meltg[c] = NA;
+        return;
+    }
+    CellV cv;
+    cv.pai = a.pai[c]; cv.hgt = hgt0; cv.clump = a.clump[c]; cv.ltra = a.leaft[c]; cv.skyview = a.skyview[c];
+    cv.site = site_derive(a.slope[c], a.aspect[c]);
+    double sinlat = 0.0, coslat = 0.0, lon = 0.0;
+    if (AF) {
+        const double latr = a.lats[c] * kPi / 180.0;
+        sinlat = sin(latr); coslat = cos(latr); lon = a.lons[c];
+    }
+    Pack s;   // cpp:4325-4332
+    s.agec = a.isnowac[c];
+    s.ageg = a.isnowag[c];
+    s.sdenc = snow_density(a.sdp, a.isnowdc[c], (double)s.agec);
+    s.sdeng = ((a.sdp[0] - a.sdp[1]) * (1 - exp(-a.sdp[2] * a.isnowdg[c] * 0.5 / 100.0 - a.sdp[3] * s.ageg / 24.0)) +
+               a.sdp[1]) * 1000.0;
+    s.sdepc = a.isnowdc[c];
+    s.sdepg = a.isnowdg[c];
+    double meltc = AF ? NA : 0.0;   // only gridmodelsnow1 zeroes it (cpp:4333); gridmodelsnow2 adds to NA
+    double meltg = NA;              // never zeroed in either (cpp:4308, 4396)
+    const double nosnow_den = a.sdp[1] * 1000.0;
+    const int ndays = a.tsteps / 24;
+    int hs = 0;
+    DayT dy;
+    for (int k = 0; k < a.tsteps; ++k) {
+        const int64_t o = c + N * k;
+        double tc, prec;
+        if (AF) {
+            tc = a.temp[o]; prec = a.precip[o];
+            if (k > 0) hs = prec > 0 ? 0 : hs + 1;
+            if (k % 24 == 0) {   // the day's extremes of the point model's net radiation, cpp:4514-4566
+                if (k / 24 < ndays) {
+                    day_init(dy);
+                    for (int h = 0; h < 24; ++h) {
+                        const int64_t q = c + N * (k + h);
+                        const double rnet = a.RswabsG[q] + a.RlwabsG[q] - 0.97 * kSb * rad4(a.temp[q]);
+                        day_accum(dy, rnet, a.swdown[q], a.lwdown[q]);
+                    }
+                } else {
+                    dy.rmx = dy.rmn = dy.rswmx = dy.rlwmx = dy.rswmn = dy.rlwmn = dy.gmx = 0.0;
+                }
+            }
+        } else {
+            tc = a.rows[k].m.tc; prec = a.rows[k].m.prec;
+        }
+        bool snowtest = s.sdepc > 0.0;                       // cpp:4336-4338
+        if (tc < 2.0 && prec > 0.0) snowtest = true;
+        double vTc = 0.0, vTg = 0.0, vdc = 0.0, vdg = 0.0, vden = nosnow_den;
+        if (snowtest) {
+            PackOut po;
+            if (AF) {
+                MetT m;
+                met_derive(m, tc, a.relhum[o], a.pres[o], a.Tcp[o]);
+                m.prec = prec;
+                m.rsw = a.swdown[o]; m.rdif = a.difrad[o]; m.rlw = a.lwdown[o];
+                m.umu = a.umu[o]; m.u2 = a.windspeed[o]; m.gp = a.Gp[o];
+                m.alb = snow_albedo(hs);
+                const DateRow2 dr = a.dates[k];
+                SolDate sd;
+                sd.sindec = dr.sindec; sd.cosdec = dr.cosdec; sd.eot = dr.eot;
+                const SolPos sp = sol_site(sd, dr.hour, sinlat, coslat, lon);
+                const SunT sun = sun_derive(sp, false);
+                const double ha = a.hor[(int64_t)dir_index(sp.azid, 15.0, 24) * N + c];
+                const double ws = a.wsa[(int64_t)dr.windex * N + c];
+                pack_step(m, dy, sun, cv, ha, ws, a.sdp, a.zref, s, po);
+            } else {
+                const StepRow& r = a.rows[k];
+                const double ha = a.hor[(int64_t)r.sindex * N + c];
+                const double ws = a.wsa[(int64_t)r.windex * N + c];
+                pack_step(r.m, r.d, r.s, cv, ha, ws, a.sdp, a.zref, s, po);
+            }
+            vTc = po.Tc; vTg = po.Tg; vdc = s.sdepc; vdg = s.sdepg; vden = s.sdenc;
+            meltc = meltc + po.melc;                          // cpp:4394-4396 (meltc is added twice)
+            meltc = meltc + (po.melc * 1000.0) / s.sdenc;
+            meltg = meltg + (po.melg * 1000.0) / s.sdeng;
+        }
+        if (a.Tc) a.Tc[o] = vTc;
+        if (a.Tg) a.Tg[o] = vTg;
+        if (a.sdepc) a.sdepc[o] = vdc;
+        if (a.sdepg) a.sdepg[o] = vdg;
+        if (a.sden) a.sden[o] = vden;
+    }
+    if (a.agec) a.agec[c] = (double)s.agec;
+    if (a.ageg) a.ageg[c] = (double)s.ageg;
+    if (a.meltc) a.meltc[c] = meltc;
+    if (a.meltg) a.meltg[c] = meltg;
+}
+
+// ---- gridmicrosnow ---------------------------------------------------------------------------------
+struct MicroArgs {
+    int64_t N;
+    int tsteps;
+    double reqhgt, mat, zref, hiy;
+    const double *pai, *hgt, *leaft, *clump, *paia, *leafd, *leafden, *slope, *aspect, *skyview, *wsa, *hor;
+    const double *lats, *lons, *Smax;
+    const StepRow* rows;
+    const DateRow2* dates;
+    const double* mxtc1;   // [1] data.frame climate
+    const double *temp, *relhum, *pres, *swdown, *difrad, *lwdown, *windspeed, *precip, *umu;   // [T] or [N][T]
+    const double *sTc, *sTg, *swe, *sdepg, *sden;   // snowm, [N][T]
+    double* meanD;      // [N]
+    double* mxtc;       // [N]        array climate
+    int32_t* hs0;       // [N][nchunks] hours since snowfall at the start of each day (array climate)
+    double* out[MCF_NOUT];   // [N][T] or null
+};
+
+// per-cell reductions over the whole series: meanDsnow (cpp:4713-4737) and, with array climate, the
+// cell's maximum temperature (cpp:5139-5145) and the albedo clock at every day start
+template <bool AF>
+__global__ __launch_bounds__(256) void k_microsnow_cell(MicroArgs a) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.N) return;
+    if (isnan(a.hgt[c])) return;
+    const int64_t N = a.N;
+    double meanD = na_real();
+    if (!isnan(a.sden[c])) {
+        double sumD = 0.0;
+        for (int k = 0; k < a.tsteps; ++k) {
+            const double den = a.sden[c + N * k];
+            const double co = 0.0442 * exp(5.181 * den / 1000.0);
+            const double kap = co / (den * 2090.0);
+            sumD += sqrt(2.0 * kap / kOmdy);
+        }
+        meanD = sumD / (double)a.tsteps;
+    }
+    a.meanD[c] = meanD;
+    if (AF) {
+        const int nch = (a.tsteps + 23) / 24;
+        double mx = -273.15;
+        int hs = 0;
+        for (int k = 0; k < a.tsteps; ++k) {
+            const double t = a.temp[c + N * k];
+            if (t > mx) mx = t;
+            if (k > 0) hs = a.precip[c + N * k] > 0 ? 0 : hs + 1;
+            if (k % 24 == 0) a.hs0[c + N * (k / 24)] = hs;
+        }
+        (void)nch;
+        a.mxtc[c] = mx;
+    }
+}
+
+template <bool AF>
+__global__ __launch_bounds__(256) void k_microsnow(MicroArgs a) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t N = a.N;
+    const int nch = (a.tsteps + 23) / 24;
+    if (t >= N * nch) return;
+    const int64_t c = t % N;
+    const int day = (int)(t / N);
+    const double hgt = a.hgt[c];
+    if (isnan(hgt)) return;   // cpp:4988-4989
+    const int k0 = day * 24;
+    const int nh = min(24, a.tsteps - k0);
+    // snowdayan: daily mean of the ground-snow temperature; NA when the first step is NA and for the
+    // hours past the last whole day
+    double Tzd = na_real();
+    if (nh == 24 && !isnan(a.sTg[c])) {
+        double sumd = 0.0;
+        for (int h = 0; h < 24; ++h) sumd += a.sTg[c + N * (k0 + h)];
+        Tzd = sumd / 24.0;
+    }
+    const double meanD = a.meanD[c];
+    const SiteK site = site_derive(a.slope[c], a.aspect[c]);
+    const double pai = a.pai[c], paia = a.paia[c], leafd = a.leafd[c], clump = a.clump[c], ltra = a.leaft[c],
+                 leafden = a.leafden[c], svfa = a.skyview[c];
+    double sinlat = 0.0, coslat = 0.0, lon = 0.0, mxtc;
+    int hs = 0;
+    if (AF) {
+        const double latr = a.lats[c] * kPi / 180.0;
+        sinlat = sin(latr); coslat = cos(latr); lon = a.lons[c];
+        mxtc = a.mxtc[c];
+        hs = a.hs0[c + N * day];
+    } else {
+        mxtc = *a.mxtc1;
+    }
+    for (int h = 0; h < nh; ++h) {
+        const int k = k0 + h;
+        const int64_t o = c + N * k;
+        const int64_t f = AF ? o : k;
+        if (AF && h > 0) hs = a.precip[o] > 0 ? 0 : hs + 1;
+        if (!(a.swe[o] > 0.0)) continue;   // cpp:4993
+        const double reqhgts = a.reqhgt - a.sdepg[o];
+        double v[MCF_NOUT];
+        if (reqhgts >= 0.0) {
+            SunT sun;
+            int sindex, windex;
+            double alb;
+            if (AF) {
+                const DateRow2 dr = a.dates[k];
+                SolDate sd;
+                sd.sindec = dr.sindec; sd.cosdec = dr.cosdec; sd.eot = dr.eot;
+                const SolPos sp = sol_site(sd, dr.hour, sinlat, coslat, lon);
+                sun = sun_derive(sp, false);
+                sindex = dir_index(sp.azid, 15.0, 24);
+                windex = dr.windex;
+                alb = snow_albedo(hs);
+            } else {
+                const StepRow& r = a.rows[k];
+                sun = r.s; sindex = r.sindex; windex = r.windex; alb = r.m.alb;
+            }
+            MicroIn q;
+            q.si = solar_index(sun, site, true);
+            if (isnan(q.si)) q.si = AF ? sun.cosz : sun.cz;          // cpp:5002 / 5161
+            q.shadowmask = a.hor[(int64_t)sindex * N + c] > sun.tansa ? 0 : 1;
+            q.ws = a.wsa[(int64_t)windex * N + c];
+            q.reqhgt = reqhgts; q.zref = a.zref;
+            q.tc = a.temp[f]; q.relhum = a.relhum[f]; q.pk = a.pres[f]; q.u2 = a.windspeed[f];
+            q.Rsw = a.swdown[f]; q.Rdif = a.difrad[f]; q.Rlw = a.lwdown[f]; q.umu = a.umu[f];
+            q.hgt = hgt; q.pai = pai; q.paia = paia; q.leafd = leafd; q.clump = clump; q.ltra = ltra;
+            q.leafden = leafden; q.svfa = svfa; q.mxtc = mxtc;
+            q.Tg = a.sTg[o]; q.Tc = a.sTc[o]; q.sden = a.sden[o]; q.sdepg = a.sdepg[o];
+            q.sdepc = a.swe[o] / q.sden;
+            q.alb = alb;
+            const MicroOut m = micro_above(q, sun);
+            v[0] = m.Tz; v[1] = m.tleaf; v[2] = m.rh; v[4] = m.uz; v[5] = m.Rbdown; v[6] = m.Rddown;
+            v[7] = m.Rlwdn; v[8] = m.Rdup; v[9] = m.Rlwup;
+        } else {
+            const double b = micro_below(reqhgts, meanD, a.sTg[o], Tzd, a.mat, a.hiy);
+            v[0] = b; v[1] = b; v[2] = 100.0;
+            v[4] = v[5] = v[6] = v[7] = v[8] = v[9] = 0.0;
+        }
+        v[3] = a.Smax ? a.Smax[c] : 0.0;
+#pragma unroll
+        for (int i = 0; i < MCF_NOUT; ++i)
+            if (a.out[i]) a.out[i][o] = v[i];
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+#define S_TRY(expr)                                                                          \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            char b_[512];                                                                    \
+            snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                     __FILE__, __LINE__);                                                    \
+            return mcf::api_fail(e_ == hipErrorOutOfMemory ? MCF_ERR_NOMEM : MCF_ERR_HIP, b_); \
+        }                                                                                    \
+    } while (0)
+
+struct Bufs {
+    std::vector<void*> p;
+    int64_t bytes = 0;
+    ~Bufs() { for (void* q : p) (void)hipFree(q); }
+    int alloc(void** out, int64_t n) {
+        if (n <= 0) n = 8;
+        hipError_t e = hipMalloc(out, (size_t)n);
+        if (e != hipSuccess)
+            return mcf::api_fail(MCF_ERR_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+        p.push_back(*out);
+        bytes += n;
+        return MCF_OK;
+    }
+    // device copy of a host array of `n` elements of size `esz`
+    template <class T>
+    int up(const T** dev, const T* host, int64_t n, const char* what) {
+        if (!host) return mcf::api_fail(MCF_ERR_ARG, std::string("null input: ") + what);
+        void* d;
+        int rc = alloc(&d, n * (int64_t)sizeof(T));
+        if (rc) return rc;
+        hipError_t e = hipMemcpy(d, host, (size_t)n * sizeof(T), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return mcf::api_fail(MCF_ERR_HIP, std::string("upload failed: ") + what);
+        *dev = (const T*)d;
+        return MCF_OK;
+    }
+};
+#define UP(dst, src, n) do { if ((rc = b.up(&(dst), (src), (n), #src))) return rc; } while (0)
+
+int pick_device(int32_t device) {
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0)
+        return mcf::api_fail(MCF_ERR_NO_DEVICE, "no HIP device available (libmcfhip has no CPU fallback)");
+    if (device < 0 || device >= nd) return mcf::api_fail(MCF_ERR_ARG, "device ordinal out of range");
+    if (hipSetDevice(device) != hipSuccess) return mcf::api_fail(MCF_ERR_HIP, "hipSetDevice failed");
+    return MCF_OK;
+}
+int check_room(int64_t need) {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return MCF_OK;
+    if ((double)need > 0.95 * (double)fr) {
+        char m[200];
+        snprintf(m, sizeof m, "snow call needs %.2f GB of device memory, %.2f GB free; split the time range",
+                 need / 1e9, fr / 1e9);
+        return mcf::api_fail(MCF_ERR_NOMEM, m);
+    }
+    return MCF_OK;
+}
+
+void snow_density_params(int snowenv, double sdp[4]) {   // snowdenp, cpp:3741-3749
+    static const double tab[5][4] = {{0.5975, 0.2237, 0.0012, 0.0038},
+                                     {0.5979, 0.2578, 0.001, 0.0038},
+                                     {0.594, 0.2332, 0.0016, 0.0031},
+                                     {0.363, 0.2425, 0.0029, 0.0049},
+                                     {0.217, 0.217, 0.0, 0.0}};
+    if (snowenv < 0 || snowenv > 4) snowenv = 0;
+    for (int i = 0; i < 4; ++i) sdp[i] = tab[snowenv][i];
+}
+
+int common_checks(const mcf_snow_inputs* in) {
+    if (!in) return mcf::api_fail(MCF_ERR_ARG, "null snow inputs");
+    if (in->rows <= 0 || in->cols <= 0 || in->tsteps <= 0) return mcf::api_fail(MCF_ERR_ARG, "bad snow dimensions");
+    if (in->tsteps > (1 << 30)) return mcf::api_fail(MCF_ERR_ARG, "tsteps too large");
+    if (!in->obstime.year || !in->obstime.month || !in->obstime.day || !in->obstime.hour)
+        return mcf::api_fail(MCF_ERR_ARG, "null obstime");
+    return MCF_OK;
+}
+
+// fills the time-class device tables shared by both entry points
+int build_step_tables(Bufs& b, const mcf_snow_inputs* in, bool af, bool model, bool degrees, const StepRow** rows,
+                      const DateRow2** dates, const double** mxtc1) {
+    const int T = (int)in->tsteps;
+    int rc;
+    StepArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.tsteps = T;
+    UP(sa.year, in->obstime.year, T);
+    UP(sa.month, in->obstime.month, T);
+    UP(sa.day, in->obstime.day, T);
+    UP(sa.hour, in->obstime.hour, T);
+    UP(sa.winddir, in->clim.winddir, T);
+    sa.lat = in->other.lat; sa.lon = in->other.lon;
+    sa.degrees = degrees ? 1 : 0;
+    const unsigned grid = (unsigned)((T + 255) / 256);
+    if (af) {
+        if ((rc = b.alloc((void**)&sa.dates, (int64_t)T * sizeof(DateRow2)))) return rc;
+        hipLaunchKernelGGL(k_snow_dates, dim3(grid), dim3(256), 0, nullptr, sa);
+        *dates = sa.dates;
+        *rows = nullptr;
+        *mxtc1 = nullptr;
+    } else {
+        UP(sa.temp, in->clim.temp, T);
+        UP(sa.precip, in->clim.precip, T);
+        if (model) {
+            UP(sa.relhum, in->clim.relhum, T);
+            UP(sa.pres, in->clim.pres, T);
+            UP(sa.swdown, in->clim.swdown, T);
+            UP(sa.difrad, in->clim.difrad, T);
+            UP(sa.lwdown, in->clim.lwdown, T);
+            UP(sa.windspeed, in->clim.windspeed, T);
+            UP(sa.Gp, in->pointm.Gp, T);
+            UP(sa.Tcp, in->pointm.Tc, T);
+            UP(sa.RswabsG, in->pointm.RswabsG, T);
+            UP(sa.RlwabsG, in->pointm.RlwabsG, T);
+            UP(sa.umu, in->pointm.umu, T);
+        }
+        if ((rc = b.alloc((void**)&sa.rows, (int64_t)T * sizeof(StepRow)))) return rc;
+        if ((rc = b.alloc((void**)&sa.mxtc, 8))) return rc;
+        hipLaunchKernelGGL(k_snow_steps, dim3(grid), dim3(256), 0, nullptr, sa);
+        if (model && T / 24 > 0)
+            hipLaunchKernelGGL(k_snow_days, dim3((unsigned)((T / 24 + 63) / 64)), dim3(64), 0, nullptr, sa.rows, T);
+        hipLaunchKernelGGL(k_snow_alb, dim3(1), dim3(64), 0, nullptr, sa.rows, sa.precip, sa.temp, T, sa.mxtc);
+        *rows = sa.rows;
+        *dates = nullptr;
+        *mxtc1 = sa.mxtc;
+    }
+    if (hipGetLastError() != hipSuccess) return mcf::api_fail(MCF_ERR_HIP, "snow table kernels failed to launch");
+    return MCF_OK;
+}
+
+int run_snowmodel(const mcf_snow_inputs* in, mcf_snowmodel_out* out, int32_t device, bool af) {
+    int rc;
+    if ((rc = common_checks(in))) return rc;
+    if (!out) return mcf::api_fail(MCF_ERR_ARG, "null snow outputs");
+    if ((in->array_forcing != 0) != af) return mcf::api_fail(MCF_ERR_ARG, "array_forcing does not match the entry point");
+    if ((rc = pick_device(device))) return rc;
+    const int64_t N = in->rows * in->cols;
+    const int T = (int)in->tsteps;
+    const int64_t NT = N * T;
+    int nout3 = 0;
+    double* host3[5] = {out->Tc, out->Tg, out->sdepc, out->sdepg, out->sden};
+    for (double* p : host3) nout3 += p != nullptr;
+    if ((rc = check_room((af ? 13 * NT : 0) * 8 + (int64_t)nout3 * NT * 8 + 60 * N * 8))) return rc;
+    Bufs b;
+    ModelArgs a;
+    memset(&a, 0, sizeof a);
+    a.N = N; a.tsteps = T; a.zref = in->other.zref;
+    snow_density_params(in->snowenv, a.sdp);
+    UP(a.pai, in->vegp.pai, N);
+    UP(a.hgt, in->vegp.hgt, N);
+    UP(a.leaft, in->vegp.leaft, N);
+    UP(a.clump, in->vegp.clump, N);
+    UP(a.slope, in->other.slope, N);
+    UP(a.aspect, in->other.aspect, N);
+    UP(a.skyview, in->other.skyview, N);
+    UP(a.wsa, in->other.wsa, 8 * N);
+    UP(a.hor, in->other.hor, 24 * N);
+    UP(a.isnowdc, in->other.isnowdc, N);
+    UP(a.isnowdg, in->other.isnowdg, N);
+    UP(a.isnowac, in->other.isnowac, N);
+    UP(a.isnowag, in->other.isnowag, N);
+    const double* unused = nullptr;
+    if ((rc = build_step_tables(b, in, af, true, !af, &a.rows, &a.dates, &unused))) return rc;
+    if (af) {
+        UP(a.lats, in->other.lats, N);
+        UP(a.lons, in->other.lons, N);
+        UP(a.temp, in->clim.temp, NT);
+        UP(a.relhum, in->clim.relhum, NT);
+        UP(a.pres, in->clim.pres, NT);
+        UP(a.swdown, in->clim.swdown, NT);
+        UP(a.difrad, in->clim.difrad, NT);
+        UP(a.lwdown, in->clim.lwdown, NT);
+        UP(a.windspeed, in->clim.windspeed, NT);
+        UP(a.precip, in->clim.precip, NT);
+        UP(a.Gp, in->pointm.Gp, NT);
+        UP(a.Tcp, in->pointm.Tc, NT);
+        UP(a.RswabsG, in->pointm.RswabsG, NT);
+        UP(a.RlwabsG, in->pointm.RlwabsG, NT);
+        UP(a.umu, in->pointm.umu, NT);
+    }
+    double** dev3[5] = {&a.Tc, &a.Tg, &a.sdepc, &a.sdepg, &a.sden};
+    for (int v = 0; v < 5; ++v)
+        if (host3[v] && (rc = b.alloc((void**)dev3[v], NT * 8))) return rc;
+    double* host2[4] = {out->agec, out->ageg, out->meltc, out->meltg};
+    double** dev2[4] = {&a.agec, &a.ageg, &a.meltc, &a.meltg};
+    for (int v = 0; v < 4; ++v)
+        if (host2[v] && (rc = b.alloc((void**)dev2[v], N * 8))) return rc;
+    const unsigned grid = (unsigned)((N + 255) / 256);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool timing = getenv("MCF_TIMING") != nullptr;
+    if (timing) { S_TRY(hipEventCreate(&e0)); S_TRY(hipEventCreate(&e1)); S_TRY(hipEventRecord(e0, nullptr)); }
+    if (af) hipLaunchKernelGGL(k_snowmodel<true>, dim3(grid), dim3(256), 0, nullptr, a);
+    else hipLaunchKernelGGL(k_snowmodel<false>, dim3(grid), dim3(256), 0, nullptr, a);
+    S_TRY(hipGetLastError());
+    if (timing) {
+        S_TRY(hipEventRecord(e1, nullptr));
+        S_TRY(hipEventSynchronize(e1));
+        float ms = 0;
+        S_TRY(hipEventElapsedTime(&ms, e0, e1));
+        fprintf(stderr, "[mcf] k_snowmodel<%d>: %lld cells x %d steps in %.3f ms (%.3e cell-steps/s)\n", (int)af,
+                (long long)N, T, ms, (double)NT / (ms * 1e-3));
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    for (int v = 0; v < 5; ++v)
+        if (host3[v]) S_TRY(hipMemcpy(host3[v], *dev3[v], (size_t)NT * 8, hipMemcpyDeviceToHost));
+    for (int v = 0; v < 4; ++v)
+        if (host2[v]) S_TRY(hipMemcpy(host2[v], *dev2[v], (size_t)N * 8, hipMemcpyDeviceToHost));
+    S_TRY(hipDeviceSynchronize());
+    return MCF_OK;
+}
+
+int run_microsnow(const mcf_snow_inputs* in, const mcf_snowm* sm, double reqhgt, double mat, const int32_t* outsel,
+                  mcf_outputs* micro, int32_t device, bool af) {
+    int rc;
+    if ((rc = common_checks(in))) return rc;
+    if (!sm || !outsel || !micro) return mcf::api_fail(MCF_ERR_ARG, "null gridmicrosnow argument");
+    if ((in->array_forcing != 0) != af) return mcf::api_fail(MCF_ERR_ARG, "array_forcing does not match the entry point");
+    for (int v = 0; v < MCF_NOUT; ++v)
+        if (outsel[v] && !micro->var[v]) return mcf::api_fail(MCF_ERR_ARG, "requested micro variable has a null buffer");
+    if (outsel[MCF_OUT_SOILM] && !in->other.Smax) return mcf::api_fail(MCF_ERR_ARG, "soilm requested but other$Smax is null");
+    if ((rc = pick_device(device))) return rc;
+    const int64_t N = in->rows * in->cols;
+    const int T = (int)in->tsteps;
+    const int64_t NT = N * T;
+    const int nch = (T + 23) / 24;
+    int nsel = 0;
+    for (int v = 0; v < MCF_NOUT; ++v) nsel += outsel[v] != 0;
+    if ((rc = check_room(((af ? 9 : 0) + 5 + nsel) * NT * 8 + 60 * N * 8))) return rc;
+    Bufs b;
+    MicroArgs a;
+    memset(&a, 0, sizeof a);
+    a.N = N; a.tsteps = T; a.reqhgt = reqhgt; a.mat = mat; a.zref = in->other.zref;
+    const int y0 = in->obstime.year[0];
+    a.hiy = (y0 % 4 == 0 && (y0 % 100 != 0 || y0 % 400 == 0)) ? 366 * 24 : 365 * 24;   // cpp:4984
+    UP(a.pai, in->vegp.pai, N);
+    UP(a.hgt, in->vegp.hgt, N);
+    UP(a.leaft, in->vegp.leaft, N);
+    UP(a.clump, in->vegp.clump, N);
+    UP(a.paia, in->vegp.paia, N);
+    UP(a.leafd, in->vegp.leafd, N);
+    UP(a.leafden, in->vegp.leafden, N);
+    UP(a.slope, in->other.slope, N);
+    UP(a.aspect, in->other.aspect, N);
+    UP(a.skyview, in->other.skyview, N);
+    UP(a.wsa, in->other.wsa, 8 * N);
+    UP(a.hor, in->other.hor, 24 * N);
+    if (outsel[MCF_OUT_SOILM]) UP(a.Smax, in->other.Smax, N);
+    if ((rc = build_step_tables(b, in, af, false, false, &a.rows, &a.dates, &a.mxtc1))) return rc;
+    const int64_t F = af ? NT : T;
+    if (af) {
+        UP(a.lats, in->other.lats, N);
+        UP(a.lons, in->other.lons, N);
+    }
+    UP(a.temp, in->clim.temp, F);
+    UP(a.relhum, in->clim.relhum, F);
+    UP(a.pres, in->clim.pres, F);
+    UP(a.swdown, in->clim.swdown, F);
+    UP(a.difrad, in->clim.difrad, F);
+    UP(a.lwdown, in->clim.lwdown, F);
+    UP(a.windspeed, in->clim.windspeed, F);
+    UP(a.precip, in->clim.precip, F);
+    UP(a.umu, in->clim.umu, F);
+    UP(a.sTc, sm->Tc, NT);
+    UP(a.sTg, sm->Tg, NT);
+    UP(a.swe, sm->totalSWE, NT);
+    UP(a.sdepg, sm->groundsnowdepth, NT);
+    UP(a.sden, sm->snowden, NT);
+    if ((rc = b.alloc((void**)&a.meanD, N * 8))) return rc;
+    if (af) {
+        if ((rc = b.alloc((void**)&a.mxtc, N * 8))) return rc;
+        if ((rc = b.alloc((void**)&a.hs0, N * (int64_t)nch * 4))) return rc;
+    }
+    for (int v = 0; v < MCF_NOUT; ++v) {
+        if (!outsel[v]) continue;
+        const double* d;
+        UP(d, (const double*)micro->var[v], NT);   // in/out: starts as the no-snow solver's field
+        a.out[v] = const_cast<double*>(d);
+    }
+    const unsigned gridN = (unsigned)((N + 255) / 256);
+    const unsigned gridD = (unsigned)((N * nch + 255) / 256);
+    if (af) {
+        hipLaunchKernelGGL(k_microsnow_cell<true>, dim3(gridN), dim3(256), 0, nullptr, a);
+        hipLaunchKernelGGL(k_microsnow<true>, dim3(gridD), dim3(256), 0, nullptr, a);
+    } else {
+        hipLaunchKernelGGL(k_microsnow_cell<false>, dim3(gridN), dim3(256), 0, nullptr, a);
+        hipLaunchKernelGGL(k_microsnow<false>, dim3(gridD), dim3(256), 0, nullptr, a);
+    }
+    S_TRY(hipGetLastError());
+    for (int v = 0; v < MCF_NOUT; ++v)
+        if (outsel[v]) S_TRY(hipMemcpy(micro->var[v], a.out[v], (size_t)NT * 8, hipMemcpyDeviceToHost));
+    S_TRY(hipDeviceSynchronize());
+    return MCF_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t mcf_snowenv_from_name(const char* name) {
+    if (!name) return MCF_SNOWENV_ALPINE;
+    if (!strcmp(name, "Maritime")) return MCF_SNOWENV_MARITIME;
+    if (!strcmp(name, "Prairie")) return MCF_SNOWENV_PRAIRIE;
+    if (!strcmp(name, "Tundra")) return MCF_SNOWENV_TUNDRA;
+    if (!strcmp(name, "Taiga")) return MCF_SNOWENV_TAIGA;
+    return MCF_SNOWENV_ALPINE;
+}
+extern "C" int mcf_gridmodelsnow1(const mcf_snow_inputs* in, mcf_snowmodel_out* out, int32_t device) {
+    return run_snowmodel(in, out, device, false);
+}
+extern "C" int mcf_gridmodelsnow2(const mcf_snow_inputs* in, mcf_snowmodel_out* out, int32_t device) {
+    return run_snowmodel(in, out, device, true);
+}
+extern "C" int mcf_gridmicrosnow1(const mcf_snow_inputs* in, const mcf_snowm* snowm, double reqhgt, double mat,
+                                  const int32_t out[MCF_NOUT], mcf_outputs* micro, int32_t device) {
+    return run_microsnow(in, snowm, reqhgt, mat, out, micro, device, false);
+}
+extern "C" int mcf_gridmicrosnow2(const mcf_snow_inputs* in, const mcf_snowm* snowm, double reqhgt, double mat,
+                                  const int32_t out[MCF_NOUT], mcf_outputs* micro, int32_t device) {
+    return run_microsnow(in, snowm, reqhgt, mat, out, micro, device, true);
+}

@@ -1,0 +1,647 @@
+// mcf_snow_device.hpp — device physics of the snow branch.
+//
+// Restates, for one lane = one cell, the reference's snowpack energy / mass balance
+//   snowoneB + radoneB + canopysnowintCpp          src/microclimfCpp.cpp:3713-3972  ("cpp:")
+// and snow microclimate
+//   snowabovepoint, belowpointsnow                  cpp:4739-4891
+// Everything that depends only on the time step (vapour pressures, Penman-Monteith coefficients,
+// sun position, albedo, daily radiation extremes) is gathered in StepT: with data.frame climate
+// it is tabulated once per step on the device (k_snow_steps / k_snow_days), with array climate
+// the same derive functions run per cell-step.
+//
+// Plain device libm here (exp/log/pow/tan): unlike the no-snow solver this path has zero and
+// non-finite operands by construction (log(0) in the albedo, pow(0, Kc) for clump = 0, NaN
+// propagation past the last whole day), and the reference's comparison directions are kept so
+// that NaNs fall through the same branches.
+#pragma once
+#include "mcf_device.hpp"
+
+namespace mcf {
+namespace snow {
+
+__device__ __forceinline__ double svp(double tc) {  // cpp:480-490 satvapCpp
+    return tc > 0 ? 0.61078 * exp(17.27 * tc / (tc + 237.3)) : 0.61078 * exp(21.875 * tc / (tc + 265.5));
+}
+__device__ __forceinline__ double rad4(double tc) {  // cpp:24-26 radem
+    double t = tc + 273.15;
+    t *= t;
+    return t * t;
+}
+__device__ __forceinline__ double dewpoint(double ea) {  // cpp:493-496
+    const double l = log(ea / 0.6112);
+    return 243.5 * l / (17.67 - l);
+}
+// latent heat of vaporisation / sublimation, the `T < 0` flavour of cpp:3879-3884, 4837-4842
+__device__ __forceinline__ double latent_lt0(double t) {
+    return t < 0.0 ? 51078.69 - 4.338 * t - 0.06367 * t * t : 45068.7 - 42.8428 * t;
+}
+__device__ __forceinline__ double zeroplane(double h, double pai) {  // cpp:294-299
+    if (pai < 0.001) pai = 0.001;
+    const double s = sqrt(7.5 * pai);
+    return (1.0 - (1.0 - exp(-s)) / s) * h;
+}
+__device__ __forceinline__ double roughlen0(double h, double pai, double d) {  // cpp:302-310, psi_h = 0
+    const double Be = sqrt(0.003 + (0.2 * pai) / 2);
+    double zm = (h - d) * exp(-kKa / Be);
+    if (zm > (0.9 * (h - d))) zm = 0.9 * (h - d);
+    if (zm < 0.0005) zm = 0.0005;
+    return zm;
+}
+
+// ---- two-stream coefficients for spherical leaves (x = 1 -> J = 1/3), cpp:134-185 -------------
+struct TsDif { double om, a, gma, del, h, S1, u1, u2, D1, D2, p1, p2, p3, p4; };
+__device__ __forceinline__ TsDif ts_dif(double pait, double lref, double ltra, double gref) {
+    TsDif p;
+    p.om = lref + ltra;
+    p.a = 1.0 - p.om;
+    p.del = lref - ltra;
+    p.gma = 0.5 * (p.om + (1.0 / 3.0) * p.del);
+    p.h = sqrt(p.a * p.a + 2.0 * p.a * p.gma);
+    p.S1 = exp(-p.h * pait);
+    p.u1 = p.a + p.gma * (1.0 - 1.0 / gref);
+    p.u2 = p.a + p.gma * (1.0 - gref);
+    p.D1 = (p.a + p.gma + p.h) * (p.u1 - p.h) * 1.0 / p.S1 - (p.a + p.gma - p.h) * (p.u1 + p.h) * p.S1;
+    p.D2 = (p.u2 + p.h) * 1.0 / p.S1 - (p.u2 - p.h) * p.S1;
+    p.p1 = (p.gma / (p.D1 * p.S1)) * (p.u1 - p.h);
+    p.p2 = (-p.gma * p.S1 / p.D1) * (p.u1 + p.h);
+    p.p3 = (1.0 / (p.D2 * p.S1)) * (p.u2 + p.h);
+    p.p4 = (-p.S1 / p.D2) * (p.u2 - p.h);
+    return p;
+}
+struct TsDir { double sig, p5, p6, p7, p8, p9, p10; };
+__device__ __forceinline__ TsDir ts_dir(double pait, const TsDif& f, double gref, double kd) {
+    TsDir p;
+    const double ag = f.a + f.gma;
+    const double sig = kd * kd + f.gma * f.gma - ag * ag;
+    const double ss = 0.5 * (f.om + (1.0 / 3.0) * f.del / kd) * kd;
+    const double sstr = f.om * kd - ss;
+    const double S2 = exp(-kd * pait);
+    p.p5 = -ss * (ag - kd) - f.gma * sstr;
+    const double v1 = ss - (p.p5 * (ag + kd)) / sig;
+    const double v2 = ss - f.gma - (p.p5 / sig) * (f.u1 + kd);
+    p.p6 = (1.0 / f.D1) * ((v1 / f.S1) * (f.u1 - f.h) - (ag - f.h) * S2 * v2);
+    p.p7 = (-1.0 / f.D1) * ((v1 * f.S1) * (f.u1 + f.h) - (ag + f.h) * S2 * v2);
+    p.sig = -sig;
+    p.p8 = sstr * (ag + kd) - f.gma * ss;
+    const double v3 = (sstr + f.gma * gref - (p.p8 / p.sig) * (f.u2 - kd)) * S2;
+    p.p9 = (-1 / f.D2) * ((p.p8 / (p.sig * f.S1)) * (f.u2 + f.h) + v3);
+    p.p10 = (1 / f.D2) * (((p.p8 * f.S1) / p.sig) * (f.u2 - f.h) + v3);
+    return p;
+}
+// cankCpp for x = 1 (cpp:104-132): k, kd = k cos(z)/si, Kc = 1/si
+struct CanK { double k, kd, Kc; };
+__device__ __forceinline__ CanK cank1(double kx, double kcos, double si) {
+    if (si < 0.0) si = 0.0;
+    CanK o;
+    o.k = kx;
+    o.kd = kcos / si;
+    if (si == 0) o.kd = 1.0;
+    o.Kc = 1.0 / si;
+    if (si == 0.0) o.Kc = 600.0;
+    return o;
+}
+__device__ __forceinline__ double clamp01(double v) {  // `if (v > 1) v = 1; if (v < 0) v = 0;`
+    if (v > 1.0) v = 1.0;
+    if (v < 0.0) v = 0.0;
+    return v;
+}
+
+// ---- per-time-step values ----------------------------------------------------------------------
+struct SunT {          // sun position pieces of one step at one site
+    double zend, zenr, azid;
+    double cosz;       // cos(zenr)                                  cpp:3798
+    double cz, sz;     // cos / sin (zend * torad)                   cpp:85-102
+    double ca, sa;     // cos / sin (azid * torad)
+    double kx, kcos;   // cankCpp(zenr, 1, .): k and k*cos(zenr')    cpp:104-132
+    double tansa;      // horizon-test threshold                     cpp:4357-4359 / 4604-4606
+};
+// `degrees`: gridmodelsnow1 tests `ha > tan((90 - zend) * torad)`, every other caller
+// `ha > tan(pi/2 - zenr)`.
+__device__ __forceinline__ SunT sun_derive(const SolPos& sp, bool degrees) {
+    SunT s;
+    s.zend = sp.zend; s.zenr = sp.zenr; s.azid = sp.azid;
+    s.cosz = cos(sp.zenr);
+    s.cz = cos(sp.zend * kToRad);
+    s.sz = sin(sp.zend * kToRad);
+    s.ca = cos(sp.azid * kToRad);
+    s.sa = sin(sp.azid * kToRad);
+    double zr = sp.zenr;
+    if (zr > (kPi / 2.0)) zr = kPi / 2.0;
+    const double c = cos(zr);
+    double k = 1.0 / (2.0 * c);
+    if (k > 6000.0) k = 6000.0;
+    s.kx = k;
+    s.kcos = k * c;
+    s.tansa = degrees ? tan((90 - sp.zend) * kToRad) : tan(kPi / 2.0 - sp.zenr);
+    return s;
+}
+struct SiteK { double cS, sS, cA, sA; bool flat; };   // slope / aspect of the cell
+__device__ __forceinline__ SiteK site_derive(double slope, double aspect) {
+    SiteK k;
+    k.cS = cos(slope * kToRad); k.sS = sin(slope * kToRad);
+    k.cA = cos(aspect * kToRad); k.sA = sin(aspect * kToRad);
+    k.flat = (slope == 0.0);
+    return k;
+}
+// solarindexCpp (cpp:85-102) with cos((azid - aspect) torad) expanded
+__device__ __forceinline__ double solar_index(const SunT& s, const SiteK& k, bool shadowmask) {
+    double si;
+    if (s.zend > 90.0 && !shadowmask) {
+        si = 0;
+    } else if (k.flat) {
+        si = s.cz;
+    } else {
+        si = s.cz * k.cS + s.sz * k.sS * (s.ca * k.cA + s.sa * k.sA);
+    }
+    if (si < 0.0) si = 0.0;
+    return si;
+}
+
+struct MetT {          // weather-only values of one step (snowpack model)
+    double tc, prec, pk, ea, te, rcan, rem;
+    double la, cp, Da, gR, De;   // PenmanMonteithCpp's step-only terms, cpp:498-514
+    double tdew, ph, sint;       // dewpoint, molar density, max snow load per branch area (cpp:3728-3729)
+    double rsw, rdif, rlw, umu, u2, gp, alb;
+};
+__device__ __forceinline__ void met_derive(MetT& m, double tc, double rh, double pk, double tci) {
+    m.tc = tc; m.pk = pk;
+    const double es = svp(tc);
+    m.ea = es * rh / 100.0;                                    // cpp:4226
+    m.te = (tci + tc) / 2.0;                                   // cpp:4227
+    m.rem = 0.97 * kSb * rad4(tc);                             // cpp:4228, 501
+    m.rcan = 0.97 * kSb * rad4(tci);                           // cpp:3785
+    const double te = m.te;
+    m.la = te >= 0 ? 45068.7 - 42.8428 * te : 51078.69 - 4.338 * te - 0.06367 * te * te;
+    m.cp = 2e-05 * te * te + 0.0002 * te + 29.119;             // cpp:287-291
+    m.Da = es - m.ea;
+    const double tk = te + 273.15;
+    m.gR = (4.0 * 0.97 * kSb * (tk * tk * tk)) / m.cp;
+    m.De = svp(te + 0.5) - svp(te - 0.5);
+    m.tdew = dewpoint(m.ea);
+    m.ph = 44.6 * (pk / 101.3) * (273.15 / (tc + 273.15));     // cpp:280-285
+    const double rhos = 67.92 + 51.25 * exp(tc / 2.59);
+    m.sint = 6.2 * (0.26 + 46 / rhos);
+}
+struct DayT { double rmx, rmn, rswmx, rlwmx, rswmn, rlwmn, gmx; };   // cpp:4231-4282
+__device__ __forceinline__ void day_init(DayT& d) {
+    d.rmx = -1352.0; d.rmn = 1352.0;
+    d.rswmx = d.rlwmx = d.rswmn = d.rlwmn = 0.0;
+    d.gmx = 0.0;
+}
+__device__ __forceinline__ void day_accum(DayT& d, double rnet, double rsw, double rlw) {
+    if (d.rmx < rnet) { d.rmx = rnet; d.rswmx = rsw; d.rlwmx = rlw; }
+    if (d.rmn > rnet) { d.rmn = rnet; d.rswmn = rsw; d.rlwmn = rlw; }
+    if (fabs(rnet) > d.gmx) d.gmx = fabs(rnet);
+}
+// snowalbCpp (cpp:3752-3771): the logarithm's argument is the INTEGER quotient hs / 24
+__device__ __forceinline__ double snow_albedo(int hs) {
+    double alb = (-9.8740 * log((double)(hs / 24)) + 78.3434) / 100.0;
+    if (alb > 0.95) alb = 0.95;
+    if (alb < 0.1) alb = 0.1;
+    return alb;
+}
+
+// ---- snowpack state and one step of snowoneB ----------------------------------------------------
+struct Pack { double sdenc, sdeng, sdepc, sdepg; int agec, ageg; };
+struct PackOut { double Tc, Tg, melc, melg; };
+struct CellV { double pai, hgt, clump, ltra, skyview; SiteK site; };
+
+__device__ __forceinline__ double snow_density(const double* sdp, double depth, double age_h) {  // cpp:3952-3955
+    return ((sdp[0] - sdp[1]) * (1.0 - exp(-sdp[2] * depth / 100.0 - sdp[3] * age_h / 24.0)) + sdp[1]) * 1000.0;
+}
+
+// The body of the k loop of gridmodelsnow1/2 for a step that passed `snowtest` (cpp:4340-4396).
+__device__ __forceinline__ void pack_step(const MetT& m, const DayT& dy, const SunT& sun, const CellV& c, double ha,
+                                          double ws, const double* sdp, double zref, Pack& s, PackOut& o) {
+    // ground heat flux of the cell from the point model's (cpp:4341-4354)
+    double paip = c.pai;
+    if (c.hgt > s.sdepg) paip = paip * (c.hgt - s.sdepg) / c.hgt;
+    const double dtR = dy.rmx - dy.rmn;
+    const double trS = c.skyview * exp(-paip);
+    const double dmxS = trS * dy.rswmx + trS * dy.rlwmx + (1 - trS) * m.rem - m.rem;
+    const double dmnS = trS * dy.rswmn + trS * dy.rlwmn + (1 - trS) * m.rem - m.rem;
+    double G = m.gp * ((dmxS - dmnS) / dtR);
+    if (G > dy.gmx) G = dy.gmx;
+    if (G < -dy.gmx) G = -dy.gmx;
+    // terrain-adjusted forcing (cpp:4355-4367)
+    double smu = 1.0;
+    if (ha > sun.tansa) smu = 0.0;
+    const double u2p = m.umu * ws * m.u2;
+    const double Rdif = m.rdif * c.skyview;
+    const double Rsw = (m.rsw - m.rdif) * smu + Rdif;
+    const double Rlw = m.rlw * c.skyview;
+    // vegetation above the ground snow (cpp:3840-3852)
+    double pai = 0.0;
+    if (c.hgt > s.sdepg) pai = c.pai * (c.hgt - s.sdepg) / c.hgt;
+    double hgt = c.hgt - s.sdepg;
+    if (hgt < 0.0) hgt = 0.0;
+    double zi = 0.0;
+    if (s.sdepg > 0.0 && hgt > 0.0) zi = ((s.sdepc - s.sdepg) * s.sdenc) / (hgt * 1000.0);
+    double ltra = c.ltra * exp(-10.1 * zi);
+    // radoneB (cpp:3773-3833)
+    const double RlwabsC = 0.97 * Rlw;
+    double RlwabsG = RlwabsC;
+    const double cld = c.clump * c.clump;
+    const double pait = pai / (1.0 - c.clump);
+    const double ept = exp(-pait);
+    const double tr = (1.0 - cld) * ept + cld;
+    if (hgt > 0.0) RlwabsG = 0.97 * (tr * Rlw + (1.0 - tr) * m.rcan);
+    double RabsC = RlwabsC, RswabsG = 0.0;
+    if (Rsw > 0.0) {
+        const double si = solar_index(sun, c.site, false);
+        double Rbeam = (Rsw - Rdif) / sun.cosz;
+        if (Rbeam > 1352.2) Rbeam = 1352.2;
+        const double RswabsC = (1.0 - m.alb) * (Rdif + Rbeam * sun.cosz);
+        RabsC = RswabsC + RlwabsC;
+        RswabsG = RswabsC;
+        if (hgt > 0.0) {
+            if ((m.alb + ltra) > 0.999) ltra = 0.999 - m.alb;
+            const TsDif f = ts_dif(pait, m.alb, ltra, m.alb);
+            const CanK kp = cank1(sun.kx, sun.kcos, si);
+            const TsDir d = ts_dir(pait, f, m.alb, kp.kd);
+            const double clb = pow(c.clump, kp.Kc);
+            const double ehp = exp(f.h * pait);
+            const double ekp = exp(-kp.kd * pait);
+            const double Rddm = clamp01((1.0 - cld) * (f.p3 * f.S1 + f.p4 * ehp) + cld);
+            const double Rdbm = clamp01((1.0 - clb) * ((d.p8 / d.sig) * ekp + d.p9 * f.S1 + d.p10 * ehp));
+            const double Rbgm = clamp01((1.0 - clb) * ekp + clb);
+            const double RdifG = (1.0 - m.alb) * (Rdbm * Rbeam * sun.cosz) + Rddm * Rdif;
+            const double RdirG = (1.0 - m.alb) * (Rbgm * Rbeam * 0.5);
+            RswabsG = RdifG + RdirG;
+        }
+    }
+    const double RabsG = RswabsG + RlwabsG;
+    // turbulent exchange (cpp:3857-3869)
+    double d0 = 0.0, zm = 0.005;
+    if (hgt > 0.0) {
+        d0 = zeroplane(hgt, pai);
+        zm = roughlen0(hgt, pai, d0);
+    }
+    if (zm < 0.0009) zm = 0.0009;
+    const double uf = (kKa * u2p) / log((zref - d0) / zm);
+    double gHa = (kKa * m.ph * uf) / log((zref - d0) / (0.2 * zm + d0 - d0));   // gturbCpp, cpp:373-380
+    if (gHa < 0.03) gHa = 0.03;
+    // surface temperatures (cpp:3871-3875, PenmanMonteithCpp cpp:498-514 with gV = gHa, erh = 1)
+    const double lg = m.la * (gHa / m.pk);
+    const double den = m.cp * (gHa + m.gR) + lg * m.De;
+    double Tc = m.tc + ((RabsC - m.rem - lg * m.Da - G) / den);
+    double Tg = m.tc + ((RabsG - m.rem - lg * m.Da - G) / den);
+    if (Tc < m.tdew) Tc = m.tdew;
+    if (Tg < m.tdew) Tg = m.tdew;
+    // canopy + ground pack: sublimation, melt, rain melt (cpp:3878-3901)
+    double la = latent_lt0(Tc);
+    double L = la * (gHa / m.pk) * (svp(Tc) - m.ea);
+    la = la / 0.018015;
+    const double mSc = (L / la) * 3.6;
+    double mMc = 0.0;
+    if (Tc > 0.0) {
+        const double S = s.sdepc * (s.sdenc / 1000);
+        mMc = ((583.3 * Tc * S) / 334000.0) * 3.6;
+        if (s.sdepc > 0.0) Tc = 0.0;
+    }
+    double mRc = 0.0;
+    if (m.tc > 0.0) mRc = 0.0125 * m.tc * m.prec / 1000;
+    // ground pack (cpp:3904-3922)
+    la = latent_lt0(Tg);
+    double mu = exp(-pai);
+    if (mu > 1.0) mu = 1.0;
+    L = la * (gHa / m.pk) * (svp(Tg) - m.ea) * mu;
+    la = la / 0.018015;
+    const double mSg = (L / la) * 3.6;
+    double mMg = 0.0;
+    if (Tg > 0.0) {
+        const double S = s.sdepg * (s.sdeng / 1000.0);
+        mMg = ((583.3 * Tg * S) / 334000.0) * 3.6;
+        if (s.sdepg > 0.0) Tg = 0.0;
+    }
+    // canopy interception (cpp:3924-3934, canopysnowintCpp cpp:3713-3739)
+    double Li = 0.0;
+    if (s.sdepc > 0.0) {
+        double wgtg = s.sdepg / s.sdepc;
+        if (wgtg < 0.0) wgtg = 0.0;
+        if (wgtg > 1.0) wgtg = 1.0;
+        Li = (s.sdepc - s.sdepg) * (wgtg * s.sdeng + (1.0 - wgtg) * s.sdenc);
+    }
+    if (Li < 0.0) Li = 0.0;
+    double cis;
+    {
+        double h = hgt, p = pai;
+        if (h < 0.001) h = 0.001;
+        if (p < 0.001) p = 0.001;
+        const double Be = sqrt(0.003 + (0.2 * p) / 2.0);
+        const double uh = uf / Be;
+        const double Lc = 1.0 / (0.25 * (p / h));
+        const double Lm = 2.0 * (Be * Be * Be) * Lc;
+        const double k1 = Be / Lm;
+        double uzm = (uh / (h * k1)) * (1 - exp(-k1 * h));
+        if (uzm < uf) uzm = uf;
+        const double Lstr = m.sint * p;
+        const double Z = atan(uzm / 0.8);
+        const double kc = 1.0 / (2.0 * cos(Z));
+        const double Cp = 1.0 - exp(-kc * p);
+        const double I1 = (Lstr - Li) * (1.0 - exp(-(Cp / Lstr) * m.prec));
+        cis = I1 * 0.678;
+        if (cis > m.prec) cis = m.prec;
+    }
+    double mRg = 0.0;
+    if (m.tc > 0.0) mRg = 0.0125 * m.tc * (m.prec - cis) / 1000.0;
+    // mass balance, density, age (cpp:3941-3965)
+    double snowc = m.prec, snowg = m.prec - cis;
+    if (m.tc > 2.0) { snowc = 0.0; snowg = 0.0; }
+    const double swec = snowc / 1000.0 - mSc - mMc - mRc;
+    const double sweg = snowg / 1000.0 - mSg - mMg - mRg;
+    double agec = (double)s.agec + 1.0, ageg = (double)s.ageg + 1.0;
+    const double sdenc = snow_density(sdp, s.sdepc, agec);
+    const double sdeng = snow_density(sdp, s.sdepg, ageg);
+    double sdepc = s.sdepc + (swec * 1000.0) / sdenc;
+    double sdepg = s.sdepg + (sweg * 1000.0) / sdeng;
+    if (sdepc < 0.0) { sdepc = 0.0; agec = 0.0; }
+    if (sdepg < 0.0) { sdepg = 0.0; ageg = 0.0; }
+    s.sdenc = sdenc; s.sdeng = sdeng; s.sdepc = sdepc; s.sdepg = sdepg;
+    s.agec = (int)agec; s.ageg = (int)ageg;
+    o.Tc = Tc; o.Tg = Tg;
+    o.melc = mSc + mMc + mRc;
+    o.melg = mSg + mMg + mRg;
+}
+
+// ---- snow microclimate: snowabovepoint (cpp:4739-4866) ------------------------------------------
+struct MicroIn {
+    double reqhgt, zref, tc, relhum, pk, u2, Rsw, Rdif, Rlw;       // step
+    double hgt, pai, paia, leafd, clump, ltra, leafden, svfa;      // cell
+    double si, ws, umu, mxtc;
+    int shadowmask;
+    double Tg, Tc, sdepc, sdepg, sden, alb;                        // snowpoint2
+};
+struct MicroOut { double Tz, tleaf, rh, uz, Rbdown, Rddown, Rlwdn, Rdup, Rlwup; };
+
+__device__ __forceinline__ double rh_canopy(double uf, double h, double d, double z) {  // cpp:1365-1380
+    const double a2 = 0.4 * (1.0 - (d / h)) / (1.25 * 1.25);
+    double inth = 4.293251 * h;
+    if (z != h) {
+        const double sn = sin((kPi * z) / h), c1 = cos((kPi * z) / h) + 1;
+        inth = (2.0 * h * ((48 * atan((sqrt(5.0) * sn) / c1)) / pow(5.0, 1.5) +
+                           (32.0 * sn) / (c1 * ((25.0 * (sn * sn)) / (c1 * c1) + 5.0)))) / kPi;
+    }
+    const double mu = uf / (a2 * h) * 1.0 / (uf * uf);
+    double r = inth * mu;
+    if (r < 0.001) r = 0.001;
+    return r;
+}
+struct BelowK { double Kg, Kh, Kc; };   // TVbelow's diffusivities (cpp:1385-1390): shared by T and e
+__device__ __forceinline__ BelowK below_k(double z, double d, double h, double uf) {
+    const double Rc = rh_canopy(uf, h, d, h);
+    const double rz = rh_canopy(uf, h, d, z);
+    BelowK k;
+    k.Kc = h / Rc;
+    k.Kg = (1.0 / rz) / z;
+    k.Kh = (1.0 / (Rc - rz)) / (h - z);
+    return k;
+}
+__device__ __forceinline__ double tv_below(const BelowK& k, double lnpai, double leafden, double Flux, double Fluxz,
+                                           double SH, double SG, double mxnear) {   // cpp:1391-1409
+    const double SC = SH + Flux / k.Kc;
+    const double farg = (k.Kg * SG + k.Kh * SH + k.Kc * SC) / (k.Kg + k.Kh + k.Kc);
+    double near = (3.047519 + 0.128642 * lnpai) * (Fluxz * leafden);
+    if (fabs(near) > mxnear) near = near > 0.0 ? mxnear : -mxnear;
+    if (isnan(near)) near = 0;
+    return near + farg;
+}
+struct AboveTV { double Tz, ez; };
+__device__ __forceinline__ AboveTV tv_above(double reqhgt, double zref, double d, double zm, double T0, double tc,
+                                            double ea) {   // cpp:1298-1313, surfwet = 1
+    const double zh = 0.2 * zm;
+    const double estl = svp(T0);
+    AboveTV o;
+    if (reqhgt > (d + zh)) {
+        const double lnr = log((reqhgt - d) / zh) / log((zref - d) / zh);
+        o.Tz = tc + (T0 - tc) * (1 - lnr);
+        o.ez = ea + (estl - ea) * (1 - lnr);
+    } else {
+        o.Tz = T0;
+        o.ez = ea + (estl - ea);
+    }
+    return o;
+}
+__device__ __forceinline__ double max4(double a, double b, double c, double d) {  // std::max({..})
+    double m = a;
+    if (m < b) m = b;
+    if (m < c) m = c;
+    if (m < d) m = d;
+    return m;
+}
+__device__ __forceinline__ double min4(double a, double b, double c, double d) {
+    double m = a;
+    if (b < m) m = b;
+    if (c < m) m = c;
+    if (d < m) m = d;
+    return m;
+}
+
+__device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const SunT& sun) {
+    MicroOut out;
+    double reqhgt = q.reqhgt;
+    if (reqhgt == 0.0) reqhgt = 0.001;
+    const double es = svp(q.tc);
+    const double ea = es * q.relhum / 100.0;
+    const double tdew = dewpoint(ea);
+    double hgts = q.hgt - q.sdepg;
+    if (hgts < 0.0) hgts = 0.0;
+    double pais = 0.0, d = 0.0, zm = 1e-5, wa = 0.0;
+    if (hgts > 0.0) {                                            // windtiCpp cpp:1179-1187
+        pais = q.pai * hgts / q.hgt;
+        d = zeroplane(hgts, pais);
+        zm = roughlen0(hgts, pais, d);
+        if (zm < 1e-6) zm = 1e-6;
+        wa = pais / hgts;
+    }
+    // windCpp cpp:1189-1218
+    double ws = q.ws;
+    if (isnan(ws)) ws = 1.0;
+    if (ws < 0.05) ws = 0.05;
+    double uf = ((kKa * q.u2) / log((q.zref - d) / zm)) * q.umu * ws;
+    if (uf < 0.001) uf = 0.001;
+    double uz = uf;
+    if (reqhgt > 0) {
+        if (reqhgt >= hgts) {
+            uz = (uf / kKa) * log((reqhgt - d) / zm);
+        } else {
+            double uh = (uf / kKa) * log((hgts - d) / zm);
+            if (uh < uf) uh = uf;
+            double Be = uf / uh;
+            if (Be < 0.001) Be = 0.001;
+            const double Lc = 1.0 / (0.25 * wa);
+            const double Lm = 2 * (Be * Be * Be) * Lc;
+            uz = uh * exp(Be * (reqhgt - hgts) / Lm);
+        }
+        if (uz > q.u2) uz = q.u2;
+    }
+    double gHa = (kKa * 43 * uf) / log((q.zref - d) / (0.2 * zm + d - d));   // gturbCpp(.., 43, 0, 0.0001)
+    if (gHa < 0.0001) gHa = 0.0001;
+    out.uz = uz;
+    double ez;
+    if (reqhgt >= hgts) {                                        // above the canopy, cpp:4768-4798
+        if (q.Rsw > 0.0) {
+            out.Rddown = q.Rdif * q.svfa;
+            if (q.si > 0.0 && q.shadowmask > 0) {
+                out.Rbdown = (q.Rsw - q.Rdif) / q.si;
+                if (out.Rbdown > 1352.0) out.Rbdown = 1352.0;
+                out.Rdup = q.alb * q.Rsw * q.svfa;
+            } else {
+                out.Rbdown = 0.0;
+                out.Rdup = q.alb * q.Rdif * q.svfa;
+            }
+        } else {
+            out.Rbdown = 0.0; out.Rddown = 0.0; out.Rdup = 0.0;
+        }
+        out.Rlwdn = q.svfa * q.Rlw;
+        out.Rlwup = q.svfa * 0.97 * kSb * rad4(q.Tc);
+        const AboveTV tv = tv_above(reqhgt, q.zref, d, zm, q.Tc, q.tc, ea);
+        out.Tz = tv.Tz;
+        out.tleaf = q.Tc;
+        ez = tv.ez;
+    } else {                                                     // inside the canopy, cpp:4799-4857
+        double paias = 0.0;
+        if (hgts > 0.0) paias = q.paia * hgts / q.hgt;
+        double zi = 0.0;
+        if (q.sdepg > 0.0) zi = ((q.sdepc - q.sdepg) * q.sden) / (hgts * 1000.0);
+        double ltras = q.ltra * exp(-10.1 * zi);
+        if ((ltras + q.alb) > 0.999) ltras = 0.999 - q.alb;
+        double clumps = q.clump;
+        if (q.clump > 0.0) clumps = pow(q.clump, pais / q.pai);
+        double pait = pais;
+        if (q.clump > 0.0) pait = pais / (1.0 - clumps);
+        // twostreamdif (cpp:1034-1084) with lref = gref = snow albedo
+        const double pait2 = pais / (1.0 - clumps);
+        const TsDif f = ts_dif(pait2, q.alb, ltras, q.alb);
+        double gi = 0.0, giu = 0.0;
+        if (clumps > 0.0) {
+            gi = pow(clumps, paias / pais);
+            giu = pow(clumps, (pais - paias) / pais);
+        }
+        if (gi > 0.99) gi = 0.99;
+        if (giu > 0.99) giu = 0.99;
+        const double trd = gi * gi, trdn = clumps * clumps, trdu = giu * giu;
+        const double paiaa = paias / (1.0 - gi);
+        const double amx = q.alb;                                // max(gref, lref), both the albedo
+        const double eh_a = exp(-f.h * paiaa), eH_a = exp(f.h * paiaa);
+        double Rdup_z = (1.0 - trdu * trdn) * (f.p1 * eh_a + f.p2 * eH_a) + trdu * trdn * q.alb;
+        Rdup_z = clamp01(Rdup_z);
+        const double Rddn_z = clamp01((1.0 - trd) * (f.p3 * eh_a + f.p4 * eH_a) + trd);
+        // the direct-beam coefficients use twostreamdifCpp(pait, ..) (cpp:4814) but tir's D1, D2 come from pait2;
+        // the reference passes tspdif's own (cpp:4817), so they are recomputed when the two differ
+        const TsDif fd = (pait == pait2) ? f : ts_dif(pait, q.alb, ltras, q.alb);
+        const CanK kp = cank1(sun.kx, sun.kcos, q.si);
+        const TsDir dr = ts_dir(pait, fd, q.alb, kp.kd);
+        // twostreamCpp (cpp:1086-1178)
+        double Rbdown = 0.0, Rddown = 0.0, Rdup = 0.0, radLsw = 0.0;
+        if (q.Rsw > 0.0) {
+            const double cosz = sun.cosz;
+            if (pais > 0.0) {
+                double trbn = pow(clumps, kp.Kc);
+                if (trbn > 0.999) trbn = 0.999;
+                if (trbn < 0.0) trbn = 0.0;
+                double trb = pow(gi, kp.Kc);
+                if (trb > 0.999) trb = 0.999;
+                if (trb < 0.0) trb = 0.0;
+                const double ek_a = exp(-kp.kd * paiaa);
+                double Rdbup_z = (1.0 - trdu * trbn) * ((dr.p5 / -dr.sig) * ek_a + dr.p6 * eh_a + dr.p7 * eH_a) +
+                                 trdu * trbn * q.alb;
+                if (Rdbup_z > amx) Rdbup_z = amx;
+                if (Rdbup_z < 0.0) Rdbup_z = 0.0;
+                double Rdbdn_z = (1.0 - trb) * ((dr.p8 / dr.sig) * ek_a + dr.p9 * eh_a + dr.p10 * eH_a);
+                if (Rdbdn_z > amx) Rdbdn_z = amx;
+                if (Rdbdn_z < 0.0) Rdbdn_z = 0.0;
+                double Rbeam = (q.Rsw - q.Rdif) / cosz;
+                if (Rbeam > 1352.0) Rbeam = 1352.0;
+                const double Rb = Rbeam * cosz;
+                Rbdown = (trb + (1.0 - trb) * ek_a) * Rbeam;
+                Rddown = Rddn_z * q.Rdif * q.svfa + Rdbdn_z * Rb;
+                Rdup = Rdup_z * q.Rdif * q.svfa + Rdbup_z * Rb;
+                radLsw = 0.5 * (1.0 - f.om) * (Rddown + Rdup + kp.k * cosz * Rbdown);
+            } else {
+                Rbdown = (q.Rsw - q.Rdif) / cosz;
+                Rddown = q.Rdif * q.svfa;
+                Rdup = q.alb * (q.Rdif * q.svfa + (q.Rsw - q.Rdif));
+            }
+        }
+        if (q.shadowmask == 0) Rbdown = 0.0;
+        // leaftemp (cpp:1333-1364) with gsmax = 999.999: gV = gh
+        const double lwcan = 0.97 * kSb * rad4(q.Tc);
+        const double lwgro = 0.97 * kSb * rad4(q.Tg);
+        const double eg = exp(-(pais - paias)), eaa = exp(-paias);
+        const double lwup = eg * lwgro + (1 - eg) * lwcan;
+        const double lwdn = eaa * q.Rlw + (1 - eaa) * lwcan;
+        const double leafabs = radLsw + 0.97 * 0.5 * (lwup + lwdn);
+        double gh = 0.135 * sqrt(uz / q.leafd) * 1.4;
+        {   // mincondCpp(leafabs, 999.99, Tcan, leafd) cpp:1316-1331
+            const double Rnet = leafabs - 0.97 * kSb * rad4(q.Tc);
+            const double rs = 1 / 999.99;
+            const double Hf = -1.0 / (1.0 + exp(2.0 - 1.09767 * pow(rs, 0.2672778)));
+            double gmin = 0.0463 * pow(fabs(Hf * Rnet) / q.leafd, 0.2);
+            if (gmin < 0.05) gmin = 0.05;
+            if (gh < gmin) gh = gmin;
+        }
+        // PenmanMonteith2Cpp (cpp:1220-1247), G = 0, surfwet = 1
+        const double De = svp(q.tc + 0.5) - svp(q.tc - 0.5);
+        const double tk = q.tc + 273.15;
+        const double gHr = gh + (4 * 0.97 * kSb * (tk * tk * tk)) / 29.3;
+        const double Rem = 0.97 * kSb * rad4(q.tc);
+        const double la_pm = q.tc >= 0 ? 45068.7 - 42.8428 * q.tc : 51078.69 - 4.338 * q.tc - 0.06367 * q.tc * q.tc;
+        const double mpm = la_pm * (gh / q.pk);
+        double dT = (leafabs - Rem - mpm * (es - ea)) / (29.3 * gHr + mpm * De);
+        const double dTmx = -0.6273 * q.mxtc + 49.79;
+        if (dT > dTmx) dT = dTmx;
+        if (dT > 80.0) dT = 80.0;
+        double tleaf = dT + q.tc;
+        if (tleaf < tdew) tleaf = tdew;
+        const double Hl = 29.3 * gh * (tleaf - q.tc);
+        const double Ll = mpm * (svp(tleaf) - ea);
+        out.tleaf = tleaf;
+        // Lagrangian below-canopy profile (cpp:4827-4851)
+        const BelowK bk = below_k(reqhgt, d, hgts, uf);
+        const double lnpai = log(pais);
+        const double H = 29.3 * gHa * (q.Tc - q.tc);
+        const double fr = 1.0 - exp(-pais);
+        const AboveTV tv = tv_above(hgts, q.zref, d, zm, q.Tc, q.tc, ea);
+        out.Tz = tv_below(bk, lnpai, q.leafden, H * fr, Hl, tv.Tz * 29.3 * 43.0, q.Tg * 29.3 * 43.0,
+                          fabs(tleaf - tv.Tz) * 29.3 * 43.0) / (29.3 * 43);
+        const double la = latent_lt0(q.tc);
+        const double mm = la * (gHa / q.pk);
+        const double mu = la * (43 / q.pk);
+        ez = tv_below(bk, lnpai, q.leafden, (mm * (es - ea)) * fr, Ll, tv.ez * mu, svp(q.Tg) * mu,
+                      fabs(svp(tleaf) - tv.ez) * mu) / mu;
+        out.Rbdown = Rbdown; out.Rddown = Rddown; out.Rdup = Rdup;
+        out.Rlwdn = lwdn; out.Rlwup = lwup;
+    }
+    out.rh = (ez / svp(out.Tz)) * 100.0;
+    if (out.rh > 100.0) out.rh = 100.0;
+    const double tmx = max4(out.tleaf, q.tc, q.Tg, q.Tc) + 2.0;
+    const double tmn = min4(out.tleaf, q.tc, q.Tg, q.Tc) - 2.0;
+    if (out.Tz > tmx) out.Tz = tmx;
+    if (out.Tz < tmn) out.Tz = tmn;
+    return out;
+}
+
+// belowpointsnow (cpp:4868-4891)
+__device__ __forceinline__ double micro_below(double reqhgt, double meanD, double tg, double Tzd, double Tza,
+                                              double hiy) {
+    const double nb = -118.35 * reqhgt / meanD;
+    double Tz = tg;
+    if (nb > 1.0) {
+        if (nb <= 24.0) {
+            const double w1 = 1.0 / nb, w2 = nb / 24.0;
+            const double wgt = w1 / (w1 + w2);
+            Tz = wgt * tg + (1 - wgt) * Tzd;
+        } else if (nb <= hiy) {
+            const double w1 = 24.0 / nb, w2 = nb / hiy;
+            const double wgt = w1 / (w1 + w2);
+            Tz = wgt * Tzd + (1 - wgt) * Tza;
+        } else {
+            Tz = Tza;
+        }
+    }
+    return Tz;
+}
+
+}  // namespace snow
+}  // namespace mcf

@@ -1,0 +1,193 @@
+"""Host-side mirror of the reference's snow-branch operators.
+
+`gridmodelsnow1/2` and `gridmicrosnow1/2` take the arguments of the R functions of the
+same names (R/RcppExports.R:108-114, 124-130; bodies src/microclimfCpp.cpp:4172-4673,
+4894-5214): R named lists / data.frames become mappings of numpy arrays, column-major,
+and the returned named list becomes a dict.  All arithmetic happens in libmcfhip.so
+(mcf_snow.hip); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Mapping, Sequence
+
+import numpy as np
+
+from . import _abi
+
+
+class SnowMarshalled:
+    def __init__(self):
+        self.inputs = _abi.SnowInputs()
+        self._keep = []
+        self.rows = self.cols = self.tsteps = 0
+
+    def f64(self, a, shape, name):
+        arr = np.asarray(a, dtype=np.float64)
+        if tuple(arr.shape) != tuple(shape):
+            if arr.size != int(np.prod(shape)):
+                raise ValueError(f"{name}: expected shape {tuple(shape)}, got {arr.shape}")
+            arr = arr.reshape(shape, order="F")
+        arr = np.asfortranarray(arr)
+        self._keep.append(arr)
+        return arr.ctypes.data_as(_abi.c_double_p)
+
+    def i32(self, a, shape, name):
+        # Rcpp's as<IntegerVector/IntegerMatrix>() truncates doubles towards zero
+        arr = np.asfortranarray(np.trunc(np.asarray(a, dtype=np.float64)).astype(np.int32))
+        if tuple(arr.shape) != tuple(shape):
+            raise ValueError(f"{name}: expected shape {tuple(shape)}, got {arr.shape}")
+        self._keep.append(arr)
+        return arr.ctypes.data_as(_abi.c_int32_p)
+
+
+def _get(d: Mapping, *names):
+    for n in names:
+        if n in d:
+            return d[n]
+    raise KeyError(f"none of {names} present (have {sorted(d)})")
+
+
+def marshal_snow(obstime: Mapping, climdata: Mapping, vegp: Mapping, other: Mapping, array_forcing: bool,
+                 pointm: Mapping | None = None, snowenv: str = "Alpine", micro: bool = False) -> SnowMarshalled:
+    """Builds mcf_snow_inputs.  `pointm` (gridmodelsnow) and `micro` (gridmicrosnow: paia, leafd,
+    leafden, umu, Smax) select which optional members are filled."""
+    m = SnowMarshalled()
+    pai = np.asarray(vegp["pai"], dtype=np.float64)
+    if pai.ndim != 2:
+        raise ValueError("vegp$pai must be a rows x cols matrix")
+    R, Cc = pai.shape
+    T = len(np.asarray(obstime["year"]))
+    m.rows, m.cols, m.tsteps = R, Cc, T
+    si = m.inputs
+    si.rows, si.cols, si.tsteps = R, Cc, T
+    si.array_forcing = 1 if array_forcing else 0
+    si.snowenv = _abi.SNOWENV.get(snowenv, 0)     # unknown names fall back to the default (cpp:3743)
+    si.obstime.year = m.i32(obstime["year"], (T,), "obstime$year")
+    si.obstime.month = m.i32(obstime["month"], (T,), "obstime$month")
+    si.obstime.day = m.i32(obstime["day"], (T,), "obstime$day")
+    si.obstime.hour = m.f64(obstime["hour"], (T,), "obstime$hour")
+    fshape = (R, Cc, T) if array_forcing else (T,)
+    for f in _abi.SNOW_CLIM_FIELDS:
+        if f == "umu" and not micro:
+            setattr(si.clim, f, None)
+            continue
+        src = _get(climdata, *(("precip", "prec") if f == "precip" else (f,)))   # cpp:5083 reads "prec"
+        setattr(si.clim, f, m.f64(src, (T,) if f == "winddir" else fshape, f"climdata${f}"))
+    for f in _abi.SNOW_POINTM_FIELDS:
+        setattr(si.pointm, f, m.f64(pointm[f], fshape, f"pointm${f}") if pointm is not None else None)
+    for f in _abi.SNOW_VEGP_FIELDS:
+        if f in ("paia", "leafd", "leafden") and not micro:
+            setattr(si.vegp, f, None)
+            continue
+        setattr(si.vegp, f, m.f64(vegp[f], (R, Cc), f"vegp${f}"))
+    o = si.other
+    o.slope = m.f64(other["slope"], (R, Cc), "other$slope")
+    o.aspect = m.f64(other["aspect"], (R, Cc), "other$aspect")
+    o.skyview = m.f64(other["skyview"], (R, Cc), "other$skyview")
+    o.wsa = m.f64(other["wsa"], (R, Cc, 8), "other$wsa")
+    o.hor = m.f64(other["hor"], (R, Cc, 24), "other$hor")
+    o.zref = float(other["zref"])
+    if array_forcing:
+        o.lats = m.f64(_get(other, "lats", "lat"), (R, Cc), "other$lats")    # cpp:4457 "lats", cpp:5091 "lat"
+        o.lons = m.f64(_get(other, "lons", "lon"), (R, Cc), "other$lons")
+        o.lat = o.lon = float("nan")
+    else:
+        o.lat, o.lon = float(other["lat"]), float(other["lon"])
+        o.lats = o.lons = None
+    if micro:
+        o.Smax = m.f64(other["Smax"], (R, Cc), "other$Smax")
+        o.isnowdc = o.isnowdg = None
+        o.isnowac = o.isnowag = None
+    else:
+        o.Smax = None
+        o.isnowdc = m.f64(other["isnowdc"], (R, Cc), "other$isnowdc")
+        o.isnowdg = m.f64(other["isnowdg"], (R, Cc), "other$isnowdg")
+        o.isnowac = m.i32(other["isnowac"], (R, Cc), "other$isnowac")
+        o.isnowag = m.i32(other["isnowag"], (R, Cc), "other$isnowag")
+    return m
+
+
+def alloc_snowmodel_out(m: SnowMarshalled):
+    out = _abi.SnowModelOut()
+    arrays = {}
+    for f in _abi.SNOWMODEL_OUT3:
+        a = np.empty((m.rows, m.cols, m.tsteps), dtype=np.float64, order="F")
+        arrays[f] = a
+        setattr(out, f, a.ctypes.data_as(_abi.c_double_p))
+    for f in _abi.SNOWMODEL_OUT2:
+        a = np.empty((m.rows, m.cols), dtype=np.float64, order="F")
+        arrays[f] = a
+        setattr(out, f, a.ctypes.data_as(_abi.c_double_p))
+    return out, arrays
+
+
+def marshal_snowm(m: SnowMarshalled, snowm: Mapping):
+    s = _abi.Snowm()
+    shape = (m.rows, m.cols, m.tsteps)
+    for f in _abi.SNOWM_FIELDS:
+        setattr(s, f, m.f64(snowm[f], shape, f"snowm${f}"))
+    return s
+
+
+def marshal_micro(m: SnowMarshalled, micro: Mapping, out: Sequence):
+    """Copies of the requested `micro` fields (the reference updates its argument's storage and
+    returns it; here the caller's arrays are left alone and the updated copies are returned)."""
+    out = list(out)
+    if len(out) != _abi.NOUT:
+        raise ValueError("out must have 10 entries")
+    sel = (C.c_int32 * _abi.NOUT)(*[1 if v else 0 for v in out])
+    outs = _abi.Outputs()
+    arrays = {}
+    shape = (m.rows, m.cols, m.tsteps)
+    for v, name in enumerate(_abi.OUT_NAMES):
+        if out[v]:
+            a = np.array(np.asarray(micro[name], dtype=np.float64).reshape(shape, order="F"), order="F", copy=True)
+            arrays[name] = a
+            outs.var[v] = a.ctypes.data_as(_abi.c_double_p)
+        else:
+            outs.var[v] = None
+    return sel, outs, arrays
+
+
+def _model(fn_name, af, obstime, climdata, pointm, vegp, other, snowenv, device):
+    lib = _abi.load()
+    m = marshal_snow(obstime, climdata, vegp, other, af, pointm=pointm, snowenv=snowenv)
+    out, arrays = alloc_snowmodel_out(m)
+    _abi.check(getattr(lib, fn_name)(C.byref(m.inputs), C.byref(out), device))
+    return arrays
+
+
+def gridmodelsnow1(obstime, climdata, pointm, vegp, other, snowenv, *, device: int = 0) -> dict:
+    """Snowpack energy and mass balance, data.frame climate: drop-in for the reference's
+    gridmodelsnow1 (src/microclimfCpp.cpp:4172-4423).  Returns Tc, Tg, sdepc, sdepg, sden
+    [rows, cols, tsteps] and agec, ageg, meltc, meltg [rows, cols]."""
+    return _model("mcf_gridmodelsnow1", False, obstime, climdata, pointm, vegp, other, snowenv, device)
+
+
+def gridmodelsnow2(obstime, climdata, pointm, vegp, other, snowenv, *, device: int = 0) -> dict:
+    """Array-climate variant: drop-in for gridmodelsnow2 (src/microclimfCpp.cpp:4426-4673)."""
+    return _model("mcf_gridmodelsnow2", True, obstime, climdata, pointm, vegp, other, snowenv, device)
+
+
+def _micro(fn_name, af, reqhgt, obstime, climdata, snowm, micro, vegp, other, mat, out, device):
+    lib = _abi.load()
+    m = marshal_snow(obstime, climdata, vegp, other, af, micro=True)
+    sm = marshal_snowm(m, snowm)
+    sel, outs, arrays = marshal_micro(m, micro, out)
+    _abi.check(getattr(lib, fn_name)(C.byref(m.inputs), C.byref(sm), float(reqhgt), float(mat), C.byref(sel),
+                                     C.byref(outs), device))
+    return arrays
+
+
+def gridmicrosnow1(reqhgt, obstime, climdata, snowm, micro, vegp, other, mat, out, *, device: int = 0) -> dict:
+    """Microclimate of snow-covered cell-steps written over `micro`: drop-in for the reference's
+    gridmicrosnow1 (src/microclimfCpp.cpp:4894-5056)."""
+    return _micro("mcf_gridmicrosnow1", False, reqhgt, obstime, climdata, snowm, micro, vegp, other, mat, out,
+                  device)
+
+
+def gridmicrosnow2(reqhgt, obstime, climdata, snowm, micro, vegp, other, mat, out, *, device: int = 0) -> dict:
+    """Array-climate variant: drop-in for gridmicrosnow2 (src/microclimfCpp.cpp:5059-5214)."""
+    return _micro("mcf_gridmicrosnow2", True, reqhgt, obstime, climdata, snowm, micro, vegp, other, mat, out,
+                  device)

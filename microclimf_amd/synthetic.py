@@ -264,3 +264,78 @@ def layered(args: dict, layers: int, cover_days: int | None = None, seed=SEED):
     edges = np.linspace(0, ndays, layers + 1).round().astype(int)
     a["dfsel"] = {"lyr": np.arange(1, layers + 1), "st": edges[:-1] * 24, "ed": edges[1:] * 24 - 1}
     return a
+
+
+def snow_workload(rows: int, cols: int, tsteps: int, seed=SEED, array_forcing: bool = False, start_doy: int = 15,
+                  cold: float = 11.0, lat: float = 57.0, lon: float = -4.0, zref: float = 2.0,
+                  hgt_range=(0.05, 3.0), na_frac: float = 0.02, bare_frac: float = 0.1, snowenv: str = "Alpine",
+                  year: int = 2023):
+    """Seeded inputs of the snow branch: the argument lists of gridmodelsnow1/2
+    (src/microclimfCpp.cpp:4172, 4426).  Winter calendar, temperatures straddling 0 and 2 degC so
+    that snowfall, rain-on-snow, melt and snow-free steps all occur; cells start with 0 - 0.6 m of
+    snow (a fifth of them bare) and vegetation from below to well above the pack."""
+    obstime, clim, pm = forcing_vectors(tsteps, lat, lon, year, start_doy, seed, cold)
+    vegp0, soilc, _ = rasters(rows, cols, 0, None, seed, 0.05, hgt_range, bare_frac=bare_frac, na_frac=na_frac,
+                              variety=True)
+    k = np.arange(tsteps, dtype=np.uint64) + np.uint64((start_doy - 1) * 24)
+    h = obstime["hour"]
+    relhum = 100 * clim["ea"] / clim["es"]
+    wet = uniform(80, k // np.uint64(6), seed) < 0.3          # 6-hour wet spells
+    precip = np.where(wet, 0.2 + 2.5 * uniform(81, k, seed), 0.0)
+    climdata = {"temp": clim["temp"], "relhum": relhum, "pres": clim["pres"], "swdown": clim["swdown"],
+                "difrad": clim["difrad"], "lwdown": clim["lwdown"], "windspeed": clim["windspeed"],
+                "winddir": clim["winddir"], "precip": precip, "umu": pm["umu"]}
+    pointm = {"Gp": 15 * np.sin(2 * np.pi * (h - 11) / 24) + 4 * (uniform(82, k, seed) - 0.5),
+              "Tc": np.minimum(clim["temp"] - 0.8 + 0.004 * clim["swdown"], 0.5),
+              "RswabsG": 0.2 * clim["swdown"], "RlwabsG": 0.9 * 0.97 * clim["lwdown"], "umu": pm["umu"],
+              "tr": np.full(tsteps, 0.5)}
+    i = np.arange(rows, dtype=np.uint64)[:, None]
+    j = np.arange(cols, dtype=np.uint64)[None, :]
+    idx = i + np.uint64(rows) * j
+
+    def U(f, lo=0.0, hi=1.0):
+        return lo + (hi - lo) * uniform(f, idx, seed)
+
+    vegp = {kk: vegp0[kk] for kk in ("pai", "hgt", "leaft", "clump", "paia", "leafd", "leafden")}
+    dc = np.where(U(90) < 0.2, 0.0, U(91, 0.0, 0.6))
+    other = {"slope": soilc["slope"], "aspect": soilc["aspect"], "skyview": soilc["svfa"], "wsa": soilc["wsa"],
+             "hor": soilc["hor"], "lat": lat, "lon": lon, "zref": zref, "isnowdc": dc, "isnowdg": dc * U(92, 0.3, 1.0),
+             "isnowac": np.floor(U(93, 0, 200)), "isnowag": np.floor(U(94, 0, 300)), "Smax": soilc["Smax"]}
+    if array_forcing:
+        kk = (np.arange(tsteps, dtype=np.uint64) * np.uint64(rows * cols))[None, None, :]
+        pert = uniform(70, idx[:, :, None] + kk, seed) - 0.5
+
+        def add(v, s):
+            return np.asfortranarray(v[None, None, :] + s * pert)
+
+        def mul(v, s):
+            return np.asfortranarray(v[None, None, :] * (1 + s * pert))
+
+        climdata = {"temp": add(climdata["temp"], 1.0), "relhum": np.clip(add(relhum, 6.0), 20, 100),
+                    "pres": add(climdata["pres"], 0.5), "swdown": mul(climdata["swdown"], 0.1),
+                    "difrad": mul(climdata["difrad"], 0.1), "lwdown": add(climdata["lwdown"], 5.0),
+                    "windspeed": mul(climdata["windspeed"], 0.2), "winddir": climdata["winddir"],
+                    "precip": np.asfortranarray(np.maximum(precip[None, None, :] * (1 + 1.5 * pert) - 0.15, 0.0)),
+                    "umu": mul(pm["umu"], 0.05)}
+        pointm = {kk2: (mul(v, 0.05) if kk2 != "Tc" else add(v, 0.3)) for kk2, v in pointm.items()}
+        fi, fj = i.astype(np.float64), j.astype(np.float64)
+        other["lats"] = lat + 0.01 * (fi / max(rows, 1)) + 0 * fj
+        other["lons"] = lon + 0.01 * (fj / max(cols, 1)) + 0 * fi
+    return dict(obstime=obstime, climdata=climdata, pointm=pointm, vegp=vegp, other=other, snowenv=snowenv)
+
+
+def microsnow_inputs(sw: dict, smod: dict, seed=SEED):
+    """Arguments of gridmicrosnow1/2 from a snow_workload and a gridmodelsnow result: `snowm` as
+    `.snowmodel1` assembles it (R/internal.R:2611-2615: totalSWE = depth * density) and a `micro`
+    list of recognisable stand-in fields for the no-snow solver's output."""
+    R, Cc, T = smod["Tc"].shape
+    with np.errstate(invalid="ignore"):      # NA_real_ is a signalling NaN
+        swe = smod["sdepc"] * smod["sden"]
+    snowm = {"Tc": smod["Tc"], "Tg": smod["Tg"], "totalSWE": swe,
+             "groundsnowdepth": smod["sdepg"], "snowden": smod["sden"]}
+    n = R * Cc * T
+    base = np.arange(n, dtype=np.uint64)
+    names = ("Tz", "tleaf", "relhum", "soilm", "windspeed", "Rdirdown", "Rdifdown", "Rlwdown", "Rswup", "Rlwup")
+    micro = {nm: np.asfortranarray((1000.0 * (v + 1) + uniform(100 + v, base, seed)).reshape((R, Cc, T), order="F"))
+             for v, nm in enumerate(names)}
+    return snowm, micro

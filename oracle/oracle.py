@@ -22,7 +22,7 @@ _lib = None
 
 def build(force: bool = False) -> Path:
     srcs = [_DIR / "oracle_unit.c", _DIR / "mcf_oracle.c", _DIR / "mcf_oracle.h", _DIR / "pointmodel.c",
-            _DIR / "pointmodel.h", _DIR / "Makefile", _DIR.parent / "include" / "mcf.h"]
+            _DIR / "pointmodel.h", _DIR / "snow_oracle.c", _DIR / "snow_oracle.h", _DIR / "Makefile", _DIR.parent / "include" / "mcf.h"]
     srcs = [s for s in srcs if s.exists()]
     if force or not LIB_PATH.exists() or any(s.stat().st_mtime > LIB_PATH.stat().st_mtime for s in srcs):
         subprocess.run(["make", "-C", str(_DIR), "-B", "libmcf_oracle.so"], check=True,
@@ -128,3 +128,35 @@ def run_bioclim(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, 
                                  qs[3].ctypes.data_as(IP), C.c_int(len(qs[3])), tmp.ctypes.data_as(DP))
             bio[:, i, j] = tmp
     return {f"bio{v + 1}": bio[v] for v in range(19) if out[v]}
+
+
+# ---- snow branch (snow_oracle.c) ----
+def run_snowmodel(obstime, climdata, pointm, vegp, other, snowenv, array_forcing=False):
+    """Oracle for gridmodelsnow1 (array_forcing=False) / gridmodelsnow2 (True)."""
+    from microclimf_amd import snow as S
+    lib = load()
+    m = S.marshal_snow(obstime, climdata, vegp, other, array_forcing, pointm=pointm, snowenv=snowenv)
+    out, arrays = S.alloc_snowmodel_out(m)
+    lib.orc_gridmodelsnow.restype = C.c_int
+    lib.orc_gridmodelsnow.argtypes = [C.POINTER(_abi.SnowInputs), C.POINTER(_abi.SnowModelOut)]
+    rc = lib.orc_gridmodelsnow(C.byref(m.inputs), C.byref(out))
+    if rc != 0:
+        raise RuntimeError(f"snow oracle failed: {rc}")
+    return arrays
+
+
+def run_microsnow(reqhgt, obstime, climdata, snowm, micro, vegp, other, mat, out, array_forcing=False):
+    """Oracle for gridmicrosnow1 / gridmicrosnow2; returns updated copies of the requested fields."""
+    from microclimf_amd import snow as S
+    lib = load()
+    m = S.marshal_snow(obstime, climdata, vegp, other, array_forcing, micro=True)
+    sm = S.marshal_snowm(m, snowm)
+    sel, outs, arrays = S.marshal_micro(m, micro, out)
+    lib.orc_gridmicrosnow.restype = C.c_int
+    lib.orc_gridmicrosnow.argtypes = [C.POINTER(_abi.SnowInputs), C.POINTER(_abi.Snowm), C.c_double, C.c_double,
+                                      C.POINTER(C.c_int32 * _abi.NOUT), C.POINTER(_abi.Outputs)]
+    rc = lib.orc_gridmicrosnow(C.byref(m.inputs), C.byref(sm), float(reqhgt), float(mat), C.byref(sel),
+                               C.byref(outs))
+    if rc != 0:
+        raise RuntimeError(f"snow oracle failed: {rc}")
+    return arrays

@@ -6,6 +6,8 @@ touch its arithmetic assert interval bounds:
 
   tests/testthat/test-microclimatemodel_wrapper.R   (twostream*, windCpp, TVaboveground, manCpp ...)
   tests/testthat/test-BigLeafCpp.R                  (the point model that feeds it)
+  tests/testthat/test-pointmodelsnow.R              (snowoneB, radoneB, canopysnowintCpp, snowalbCpp,
+                                                     GFluxCppsnow: the snow branch's arithmetic)
 
 This module rebuilds their inputs line for line (R -> numpy), runs the oracle's
 restatement of the same functions and evaluates every `expect_*` of the two
@@ -34,6 +36,37 @@ class BigLeafOut(C.Structure):
 class WrapperOut(C.Structure):
     _fields_ = [(k, DP) for k in ("Tz", "tleaf", "rh", "uz", "Rdirdown", "Rdifdown", "Rswup", "Rlwdown",
                                   "Rlwup", "soilm")]
+
+
+class PointSnowOut(C.Structure):
+    _fields_ = [(k, DP) for k in ("Tc", "Tg", "sdepc", "sdepg", "sdenc", "sdeng", "G", "RswabsG", "RlwabsG", "tr",
+                                  "umu", "sublmelt", "tempmelt", "rainmelt", "sstemp")] \
+        + [("mxdif", C.c_double), ("iters", C.c_int)]
+
+
+SNOWENV = {"Alpine": 0, "Maritime": 1, "Prairie": 2, "Tundra": 3, "Taiga": 4}
+
+
+def pointmodelsnow(obst, clim, vegp, other, snowenv, tol=0.5, maxiter=100):
+    """orc_pointmodelsnow (cpp:4000-4169); returns dict of arrays + mxdif, iters."""
+    lib = _lib()
+    n = len(clim["temp"])
+    out = PointSnowOut()
+    arrs = {}
+    for k, _ in PointSnowOut._fields_[:15]:
+        arrs[k] = np.zeros(n + 1 if k in ("sdepc", "sdepg") else n)
+        setattr(out, k, _d(arrs[k]))
+    vegp = np.ascontiguousarray(vegp, dtype=np.float64)
+    other = np.ascontiguousarray(other, dtype=np.float64)
+    lib.orc_pointmodelsnow.restype = C.c_int
+    lib.orc_pointmodelsnow(C.c_int(n), _i(obst["year"]), _i(obst["month"]), _i(obst["day"]), _d(obst["hour"]),
+                           _d(clim["temp"]), _d(clim["relhum"]), _d(clim["pres"]), _d(clim["swdown"]),
+                           _d(clim["difrad"]), _d(clim["lwdown"]), _d(clim["windspeed"]), _d(clim["precip"]),
+                           _d(vegp), _d(other), C.c_int(SNOWENV.get(snowenv, 0)), C.c_double(tol),
+                           C.c_double(maxiter), C.byref(out))
+    arrs["mxdif"] = out.mxdif
+    arrs["iters"] = out.iters
+    return arrs
 
 
 def _d(a):
@@ -220,8 +253,65 @@ def replay_bigleaf_test():
     return checks, {"err": out["err"], "iters": out["iters"]}
 
 
+def replay_pointmodelsnow_test():
+    """tests/testthat/test-pointmodelsnow.R."""
+    lib = _lib()
+    checks = []
+
+    def ck(label, ok, detail=""):
+        checks.append((label, bool(ok), str(detail)))
+
+    # test-pointmodelsnow.R:2-41
+    hrs = np.arange(24, dtype=np.float64)
+    n = 24
+    obst = {"year": np.full(n, 2024, dtype=np.int32), "month": np.full(n, 3, dtype=np.int32),
+            "day": np.full(n, 21, dtype=np.int32), "hour": hrs.copy()}
+    Tair = -5 + 5 * np.sin((hrs - 8) / 24 * 2 * np.pi)
+    ea = 0.7 * lib.orc_satvap(float(np.mean(Tair)))
+    RH = np.array([ea / lib.orc_satvap(float(t)) * 100 for t in Tair])
+    Pk = np.full(n, 101.3)
+    csr = np.zeros(n)
+    lib.orc_clearskyrad(C.c_int(n), _i(obst["year"]), _i(obst["month"]), _i(obst["day"]), _d(obst["hour"]),
+                        C.c_double(50.0), C.c_double(-5.0), _d(Tair), _d(RH), _d(Pk), _d(csr))
+    zen, azi, si = np.zeros(n), np.zeros(n), np.zeros(n)
+    lib.orc_solpositionv(C.c_int(n), _i(obst["year"]), _i(obst["month"]), _i(obst["day"]), _d(obst["hour"]),
+                         C.c_double(50.0), C.c_double(-5.0), C.c_double(0.0), C.c_double(180.0), _d(zen), _d(azi),
+                         _d(si))
+    Rdir = 0.3 * csr * si
+    SWd = 0.5 * csr
+    Rdif = SWd - Rdir
+    LWd = np.full(n, 350.0)
+    U2 = np.full(n, 2.0)
+    Prec = np.full(n, 1.0)
+    clim = {"temp": Tair, "relhum": RH, "pres": Pk, "swdown": SWd, "difrad": Rdif, "lwdown": LWd,
+            "windspeed": U2, "winddir": np.full(n, 180.0), "precip": Prec}
+    vegp = np.array([2, 0.5, 0.05, 0])          # pai, hgt, ltra, clump
+    other = np.array([0, 180, 50, -5, 2, 0, 0])  # slope, aspect, lat, lon, zref, isnowd, isnowa
+    pm = pointmodelsnow(obst, clim, vegp, other, "Taiga")
+    Tc, Tg, sdepc, sdepg, sdenc, sdeng = (pm[k] for k in ("Tc", "Tg", "sdepc", "sdepg", "sdenc", "sdeng"))
+    # :52-74 (R indices are 1-based: sdepc[n] is element n-1 here)
+    nums = np.concatenate([Tc, Tg, sdepc, sdepg, sdenc, sdeng])
+    ck("snow: all finite", np.isfinite(nums).all())
+    ck("snow: lengths", all(len(x) == n for x in (Tc, Tg, sdenc, sdeng)) and len(sdepc) == n + 1 and
+       len(sdepg) == n + 1)
+    Tcdif = np.abs(Tc - Tair)
+    Tgdif = np.abs(Tg - Tair)
+    depdif = sdepc - sdepg
+    snowacc = (sdepc[n - 1] - sdepc[0]) * sdenc[n - 1]
+    precsum = Prec.sum()
+    ck("snow: max|Tc-Tair| <= 2", Tcdif.max() <= 2.0, Tcdif.max())
+    ck("snow: max|Tg-Tair| <= 2.1", Tgdif.max() <= 2.1, Tgdif.max())
+    ck("snow: depdif in [0, 0.05]", depdif.min() >= 0 and depdif.max() <= 0.05, (depdif.min(), depdif.max()))
+    ck("snow: snowacc in [0.8, 1] * precsum", 0.8 * precsum <= snowacc <= precsum, snowacc)
+    ck("snow: sdenc in [216, 218]", sdenc.min() >= 216 and sdenc.max() <= 218, (sdenc.min(), sdenc.max()))
+    ck("snow: sdeng in [216, 218]", sdeng.min() >= 216 and sdeng.max() <= 218, (sdeng.min(), sdeng.max()))
+    return checks, {"mxdif": pm["mxdif"], "iters": pm["iters"], "snowacc": snowacc,
+                    "maxTcdif": Tcdif.max(), "maxTgdif": Tgdif.max()}
+
+
 if __name__ == "__main__":
-    for name, fn in (("wrapper", replay_wrapper_test), ("bigleaf", replay_bigleaf_test)):
+    for name, fn in (("wrapper", replay_wrapper_test), ("bigleaf", replay_bigleaf_test),
+                     ("pointmodelsnow", replay_pointmodelsnow_test)):
         checks, info = fn()
         print(name, info)
         for label, ok, detail in checks:
