@@ -6,6 +6,8 @@
  *   _microclimf_runmicro2Cpp  src/RcppExports.cpp:275-297  ->  mcfhip_runmicro2
  *   _microclimf_runmicro3Cpp  src/RcppExports.cpp:300-322  ->  mcfhip_runmicro3  (dfsel + the same 15)
  *   _microclimf_runmicro4Cpp  src/RcppExports.cpp:326-348  ->  mcfhip_runmicro4
+ *   _microclimf_gridmodelsnow1/2  src/RcppExports.cpp:483-514  ->  mcfhip_gridmodelsnow1/2
+ *   _microclimf_gridmicrosnow1/2  src/RcppExports.cpp:542-578  ->  mcfhip_gridmicrosnow1/2
  * Same 15 arguments in the same order as R/RcppExports.R:72-78, same named-list
  * result (src/microclimfCpp.cpp:2326-2335).  Uses only R's C API (Rinternals.h);
  * no Rcpp.  NOT compiled in the build image (R is not installed there): build with
@@ -235,6 +237,157 @@ SEXP mcfhip_runbioclim2(SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEX
                        out, wetq, dryq, hotq, colq, air);
 }
 
+/* ---- snow branch ------------------------------------------------------------------------------
+ * _microclimf_gridmodelsnow1/2 (bodies src/microclimfCpp.cpp:4172-4673): (obstime, climdata, pointm,
+ * vegp, other, snowenv) -> list(Tc, Tg, sdepc, sdepg, sden, agec, ageg, meltc, meltg). */
+static SEXP opt_elt(SEXP list, const char *name, const char *alt) {   /* like elt(), NULL when absent */
+    SEXP names = getAttrib(list, R_NamesSymbol);
+    for (R_xlen_t i = 0; i < XLENGTH(list); ++i) {
+        const char *n = CHAR(STRING_ELT(names, i));
+        if (strcmp(n, name) == 0 || (alt && strcmp(n, alt) == 0)) return VECTOR_ELT(list, i);
+    }
+    return R_NilValue;
+}
+static void fill_snow(mcf_snow_inputs *in, int *np, int array_forcing, int micro, SEXP obstime, SEXP climdata,
+                      SEXP pointm, SEXP vegp, SEXP other) {
+    memset(in, 0, sizeof *in);
+    SEXP dim = getAttrib(elt(vegp, "pai", NULL), R_DimSymbol);
+    if (TYPEOF(dim) != INTSXP || LENGTH(dim) != 2) Rf_error("mcfhip: vegp$pai must be a matrix");
+    in->rows = INTEGER(dim)[0]; in->cols = INTEGER(dim)[1];
+    in->tsteps = XLENGTH(elt(obstime, "year", NULL));
+    in->array_forcing = array_forcing;
+    in->obstime.year = intcol(elt(obstime, "year", NULL), np);
+    in->obstime.month = intcol(elt(obstime, "month", NULL), np);
+    in->obstime.day = intcol(elt(obstime, "day", NULL), np);
+    in->obstime.hour = dbl(elt(obstime, "hour", NULL), np);
+    static const char *cn[9] = {"temp", "relhum", "pres", "swdown", "difrad", "lwdown", "windspeed", "winddir",
+                                "precip"};
+    const double **cp = (const double **)&in->clim;
+    for (int i = 0; i < 9; ++i) cp[i] = dbl(elt(climdata, cn[i], i == 8 ? "prec" : NULL), np);   /* cpp:5083 */
+    if (micro) in->clim.umu = dbl(elt(climdata, "umu", NULL), np);
+    if (pointm != R_NilValue) {
+        static const char *pn[5] = {"Gp", "Tc", "RswabsG", "RlwabsG", "umu"};
+        const double **pp = (const double **)&in->pointm;
+        for (int i = 0; i < 5; ++i) pp[i] = dbl(elt(pointm, pn[i], NULL), np);
+    }
+    static const char *vn[7] = {"pai", "hgt", "leaft", "clump", "paia", "leafd", "leafden"};
+    const double **vp = (const double **)&in->vegp;
+    for (int i = 0; i < (micro ? 7 : 4); ++i) vp[i] = dbl(elt(vegp, vn[i], NULL), np);
+    in->other.slope = dbl(elt(other, "slope", NULL), np);
+    in->other.aspect = dbl(elt(other, "aspect", NULL), np);
+    in->other.skyview = dbl(elt(other, "skyview", NULL), np);
+    in->other.wsa = dbl(elt(other, "wsa", NULL), np);
+    in->other.hor = dbl(elt(other, "hor", NULL), np);
+    in->other.zref = asReal(elt(other, "zref", NULL));
+    if (array_forcing) {   /* cpp:4457-4458 "lats"/"lons"; cpp:5091-5092 "lat"/"lon" */
+        in->other.lats = dbl(elt(other, "lats", "lat"), np);
+        in->other.lons = dbl(elt(other, "lons", "lon"), np);
+    } else {
+        in->other.lat = asReal(elt(other, "lat", NULL));
+        in->other.lon = asReal(elt(other, "lon", NULL));
+    }
+    if (micro) {
+        in->other.Smax = dbl(elt(other, "Smax", NULL), np);
+    } else {
+        in->other.isnowdc = dbl(elt(other, "isnowdc", NULL), np);
+        in->other.isnowdg = dbl(elt(other, "isnowdg", NULL), np);
+        in->other.isnowac = intcol(elt(other, "isnowac", NULL), np);   /* IntegerMatrix, cpp:4203-4204 */
+        in->other.isnowag = intcol(elt(other, "isnowag", NULL), np);
+    }
+}
+static void raise_last(int rc, int np) {
+    char msg[600];
+    strncpy(msg, mcf_last_error(), sizeof msg - 1); msg[sizeof msg - 1] = 0;
+    UNPROTECT(np);
+    Rf_error("mcfhip (%d): %s", rc, msg);
+}
+static SEXP run_snowmodel(int array_forcing, SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP other,
+                          SEXP snowenv) {
+    int np = 0;
+    mcf_snow_inputs in;
+    fill_snow(&in, &np, array_forcing, 0, obstime, climdata, pointm, vegp, other);
+    in.snowenv = mcf_snowenv_from_name(CHAR(asChar(snowenv)));
+    static const char *on[9] = {"Tc", "Tg", "sdepc", "sdepg", "sden", "agec", "ageg", "meltc", "meltg"};
+    mcf_snowmodel_out res;
+    double **rp = (double **)&res;
+    SEXP ans = PROTECT(allocVector(VECSXP, 9)); ++np;
+    SEXP nms = PROTECT(allocVector(STRSXP, 9)); ++np;
+    for (int v = 0; v < 9; ++v) {
+        SEXP a;
+        if (v < 5) {
+            a = PROTECT(allocVector(REALSXP, (R_xlen_t)in.rows * in.cols * in.tsteps)); ++np;
+            SEXP d = PROTECT(allocVector(INTSXP, 3)); ++np;
+            INTEGER(d)[0] = (int)in.rows; INTEGER(d)[1] = (int)in.cols; INTEGER(d)[2] = (int)in.tsteps;
+            setAttrib(a, R_DimSymbol, d);
+        } else {
+            a = PROTECT(allocMatrix(REALSXP, (int)in.rows, (int)in.cols)); ++np;
+        }
+        SET_VECTOR_ELT(ans, v, a);
+        SET_STRING_ELT(nms, v, mkChar(on[v]));
+        rp[v] = REAL(a);
+    }
+    setAttrib(ans, R_NamesSymbol, nms);
+    int rc = array_forcing ? mcf_gridmodelsnow2(&in, &res, 0) : mcf_gridmodelsnow1(&in, &res, 0);
+    if (rc != MCF_OK) raise_last(rc, np);
+    UNPROTECT(np);
+    return ans;
+}
+SEXP mcfhip_gridmodelsnow1(SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP other, SEXP snowenv) {
+    return run_snowmodel(0, obstime, climdata, pointm, vegp, other, snowenv);
+}
+SEXP mcfhip_gridmodelsnow2(SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP other, SEXP snowenv) {
+    return run_snowmodel(1, obstime, climdata, pointm, vegp, other, snowenv);
+}
+/* _microclimf_gridmicrosnow1/2 (bodies src/microclimfCpp.cpp:4894-5214): (reqhgt, obstime, climdata, snowm,
+ * micro, vegp, other, mat, out) -> the requested fields of `micro`, updated where snow lies.  The reference
+ * writes into `micro`'s own storage; this shim updates duplicates and leaves the argument alone. */
+static SEXP run_microsnow(int array_forcing, SEXP reqhgt, SEXP obstime, SEXP climdata, SEXP snowm, SEXP micro,
+                          SEXP vegp, SEXP other, SEXP mat, SEXP out) {
+    int np = 0;
+    mcf_snow_inputs in;
+    fill_snow(&in, &np, array_forcing, 1, obstime, climdata, R_NilValue, vegp, other);
+    mcf_snowm sm;
+    sm.Tc = dbl(elt(snowm, "Tc", NULL), &np);
+    sm.Tg = dbl(elt(snowm, "Tg", NULL), &np);
+    sm.totalSWE = dbl(elt(snowm, "totalSWE", NULL), &np);
+    sm.groundsnowdepth = dbl(elt(snowm, "groundsnowdepth", NULL), &np);
+    sm.snowden = dbl(elt(snowm, "snowden", NULL), &np);
+    static const char *on[MCF_NOUT] = {"Tz", "tleaf", "relhum", "soilm", "windspeed", "Rdirdown", "Rdifdown",
+                                       "Rlwdown", "Rswup", "Rlwup"};
+    SEXP outl = PROTECT(coerceVector(out, LGLSXP)); ++np;
+    if (LENGTH(outl) != MCF_NOUT) Rf_error("mcfhip: out must have 10 elements");
+    int32_t sel[MCF_NOUT];
+    int nreq = 0;
+    for (int v = 0; v < MCF_NOUT; ++v) { sel[v] = LOGICAL(outl)[v] == TRUE; nreq += sel[v]; }
+    mcf_outputs res;
+    memset(&res, 0, sizeof res);
+    SEXP ans = PROTECT(allocVector(VECSXP, nreq)); ++np;
+    SEXP nms = PROTECT(allocVector(STRSXP, nreq)); ++np;
+    for (int v = 0, k = 0; v < MCF_NOUT; ++v) {
+        if (!sel[v]) continue;
+        SEXP src = elt(micro, on[v], NULL);
+        SEXP a = PROTECT(TYPEOF(src) == REALSXP ? duplicate(src) : coerceVector(src, REALSXP)); ++np;
+        SET_VECTOR_ELT(ans, k, a);
+        SET_STRING_ELT(nms, k, mkChar(on[v]));
+        res.var[v] = REAL(a);
+        ++k;
+    }
+    setAttrib(ans, R_NamesSymbol, nms);
+    int rc = array_forcing ? mcf_gridmicrosnow2(&in, &sm, asReal(reqhgt), asReal(mat), sel, &res, 0)
+                           : mcf_gridmicrosnow1(&in, &sm, asReal(reqhgt), asReal(mat), sel, &res, 0);
+    if (rc != MCF_OK) raise_last(rc, np);
+    UNPROTECT(np);
+    return ans;
+}
+SEXP mcfhip_gridmicrosnow1(SEXP reqhgt, SEXP obstime, SEXP climdata, SEXP snowm, SEXP micro, SEXP vegp, SEXP other,
+                           SEXP mat, SEXP out) {
+    return run_microsnow(0, reqhgt, obstime, climdata, snowm, micro, vegp, other, mat, out);
+}
+SEXP mcfhip_gridmicrosnow2(SEXP reqhgt, SEXP obstime, SEXP climdata, SEXP snowm, SEXP micro, SEXP vegp, SEXP other,
+                           SEXP mat, SEXP out) {
+    return run_microsnow(1, reqhgt, obstime, climdata, snowm, micro, vegp, other, mat, out);
+}
+
 static const R_CallMethodDef CallEntries[] = {
     {"mcfhip_runmicro1", (DL_FUNC)&mcfhip_runmicro1, 15},
     {"mcfhip_runmicro2", (DL_FUNC)&mcfhip_runmicro2, 15},
@@ -242,6 +395,10 @@ static const R_CallMethodDef CallEntries[] = {
     {"mcfhip_runmicro4", (DL_FUNC)&mcfhip_runmicro4, 16},
     {"mcfhip_runbioclim1", (DL_FUNC)&mcfhip_runbioclim1, 19},
     {"mcfhip_runbioclim2", (DL_FUNC)&mcfhip_runbioclim2, 19},
+    {"mcfhip_gridmodelsnow1", (DL_FUNC)&mcfhip_gridmodelsnow1, 6},
+    {"mcfhip_gridmodelsnow2", (DL_FUNC)&mcfhip_gridmodelsnow2, 6},
+    {"mcfhip_gridmicrosnow1", (DL_FUNC)&mcfhip_gridmicrosnow1, 9},
+    {"mcfhip_gridmicrosnow2", (DL_FUNC)&mcfhip_gridmicrosnow2, 9},
     {NULL, NULL, 0}};
 
 void R_init_mcfhip_glue(DllInfo *dll) {

@@ -29,6 +29,17 @@ mcfhip_enable <- function(glue = "r/mcfhip_glue.so") {
                   Sminp, Smaxp, tfact, complete, mat, out)
     .Call("mcfhip_runmicro4", dfsel, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons,
           Sminp, Smaxp, tfact, complete, mat, out)
+  # snow branch (R/RcppExports.R:108-114, 124-130; called at R/internal.R:2587 and 3625)
+  for (nm in c("gridmodelsnow1", "gridmodelsnow2")) local({
+    sym <- paste0("mcfhip_", nm)
+    utils::assignInNamespace(nm, function(obstime, climdata, pointm, vegp, other, snowenv)
+      .Call(sym, obstime, climdata, pointm, vegp, other, snowenv), ns = "microclimf")
+  })
+  for (nm in c("gridmicrosnow1", "gridmicrosnow2")) local({
+    sym <- paste0("mcfhip_", nm)
+    utils::assignInNamespace(nm, function(reqhgt, obstime, climdata, snowm, micro, vegp, other, mat, out)
+      .Call(sym, reqhgt, obstime, climdata, snowm, micro, vegp, other, mat, out), ns = "microclimf")
+  })
   utils::assignInNamespace("runmicro1Cpp", rm1, ns = "microclimf")
   utils::assignInNamespace("runmicro2Cpp", rm2, ns = "microclimf")
   utils::assignInNamespace("runmicro3Cpp", rm3, ns = "microclimf")
