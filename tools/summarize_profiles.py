@@ -40,7 +40,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc"):
     ds = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(kt))
           if "k_solve" in r["Kernel_Name"]]
     dur[d] = sum(ds) / len(ds)
-summary = {"kernel": "k_solve<32,false,false>", "per_launch_mean": pmc, "avg_launch_ms_under_pmc": dur,
+summary = {"kernel": "k_solve<21,false,false>", "per_launch_mean": pmc, "avg_launch_ms_under_pmc": dur,
            "command": "python3 bench.py --tsteps 1200 --steps 1 --warmup 0 --no-cpu-baseline (5-day launches)"}
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     fetch_b = pmc["FETCH_SIZE"] * 1024 * 2       # gfx950: FETCH_SIZE reports half of a coalesced stream
