@@ -345,6 +345,34 @@ int mcf_gridmicrosnow1(const mcf_snow_inputs *in, const mcf_snowm *snowm, double
 int mcf_gridmicrosnow2(const mcf_snow_inputs *in, const mcf_snowm *snowm, double reqhgt, double mat,
                        const int32_t out[MCF_NOUT], mcf_outputs *micro, int32_t device);
 
+/* The chunk loop of `.snowmodel1` (R/internal.R:2553-2617) resident on the device: for every chunk of
+ * `chunk_steps` hours (5 days) the terrain inputs are re-derived from dtm + ground snow depth
+ * (slope/aspect with NA -> 0/180, hor x24, sky view, wsa with s = 10 if res <= 100 else 1:
+ * R/internal.R:2566-2580 — the kernels of mcf_precompute_terrain), gridmodelsnow1 runs on the chunk
+ * (:2587), snow-depth changes are redistributed by the topographic position index `.tpicalc`
+ * (:2471-2485, 2589-2600) and depths / ages are fed back (:2607-2612).  Only the requested series cross
+ * PCIe.  `base` carries obstime / clim / pointm for the whole series (vector forcing), vegp, and
+ * other.{lat, lon, zref, isnowdc, isnowdg, isnowac, isnowag}; other.{slope, aspect, skyview, wsa, hor}
+ * are ignored.  As in R, n5days = tsteps / chunk_steps chunks are run (`1:n5days` truncates; at least
+ * one); later steps stay NA.  Kept on purpose: other$isnowdg is never updated inside the loop
+ * (every chunk restarts the ground layer from the initial depth) and each chunk restarts the albedo
+ * clock (gridmodelsnow1 calls snowalbCpp on its own slice).  terra's aggregate/resample inside
+ * .tpicalc are restated as in mcf_precompute_terrain (block means from the top-left, bilinear between
+ * block centres). */
+typedef struct mcf_snowdriver_in {
+    mcf_snow_inputs base;
+    const double *dtm;      /* [rows,cols] elevations (m), NaN = NA                        */
+    double res;             /* cell size (m)                                              */
+    double tfact;           /* .tpicalc's tfact (runsnowmodel default 0.02)               */
+    int32_t chunk_steps;    /* 0 -> 120                                                   */
+    int32_t reserved;
+} mcf_snowdriver_in;
+/* Returned list of .snowmodel1 (R/internal.R:2619): each [rows,cols,tsteps] or NULL. */
+typedef struct mcf_snowdriver_out {
+    double *Tc, *Tg, *groundsnowdepth, *totalSWE, *snowden;
+} mcf_snowdriver_out;
+int mcf_snowmodel1(const mcf_snowdriver_in *in, mcf_snowdriver_out *out, int32_t device);
+
 /* Diagnostics: evaluate one of the solver's lean device elementary functions
  * elementwise on host arrays (kind 0 exp, 1 log, 2 x/y, 3 sqrt, 4 1/x, 5 satvap
  * (cpp:480-490), 6 x^y); used by tests to bound their error against libm. */

@@ -120,6 +120,14 @@ class SnowInputs(C.Structure):
                 ("vegp", SnowVegp), ("other", SnowOther)]
 
 
+class SnowDriverIn(C.Structure):
+    _fields_ = [("base", SnowInputs), ("dtm", c_double_p), ("res", C.c_double), ("tfact", C.c_double),
+                ("chunk_steps", C.c_int32), ("reserved", C.c_int32)]
+
+
+SNOWDRIVER_OUT = ("Tc", "Tg", "groundsnowdepth", "totalSWE", "snowden")
+SnowDriverOut = _ptr_struct("SnowDriverOut", SNOWDRIVER_OUT)
+
 _PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = _PKG_DIR / "csrc" / "libmcfhip.so"
 
@@ -134,7 +142,7 @@ EXPORTS = (
     "mcf_plan_kernel_stats", "mcf_plan_valid_cells", "mcf_plan_bytes", "mcf_selftest_math",
     "mcf_precompute_terrain", "mcf_runbioclim1", "mcf_runbioclim2",
     "mcf_snowenv_from_name", "mcf_gridmodelsnow1", "mcf_gridmodelsnow2", "mcf_gridmicrosnow1",
-    "mcf_gridmicrosnow2",
+    "mcf_gridmicrosnow2", "mcf_snowmodel1",
 )
 
 _lib = None
@@ -210,6 +218,8 @@ def load() -> C.CDLL:
     for fn in (lib.mcf_gridmicrosnow1, lib.mcf_gridmicrosnow2):
         fn.restype = C.c_int
         fn.argtypes = [SI, C.POINTER(Snowm), C.c_double, C.c_double, C.POINTER(C.c_int32 * NOUT), OU, C.c_int32]
+    lib.mcf_snowmodel1.restype = C.c_int
+    lib.mcf_snowmodel1.argtypes = [C.POINTER(SnowDriverIn), C.POINTER(SnowDriverOut), C.c_int32]
     lib.mcf_precompute_terrain.restype = C.c_int
     lib.mcf_precompute_terrain.argtypes = [C.POINTER(TerrainIn), C.POINTER(TerrainOut), C.c_int32]
     if lib.mcf_abi_version() != 1:

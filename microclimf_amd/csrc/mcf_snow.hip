@@ -15,11 +15,13 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
 #include "../../include/mcf.h"
 #include "mcf_snow_device.hpp"
+#include "mcf_terrain.h"
 
 namespace mcf {
 int api_fail(int code, const std::string& msg);   // mcf_api.hip
@@ -379,6 +381,124 @@ __global__ __launch_bounds__(256) void k_microsnow(MicroArgs a) {
     }
 }
 
+// ---- .snowmodel1's chunk loop (R/internal.R "int:" 2553-2617) ---------------------------------------
+// albedo clock restarted at every chunk start: each gridmodelsnow1 call runs snowalbCpp on its own slice
+__global__ void k_snow_alb_chunks(StepRow* rows, const double* precip, int tsteps, int chunk, int nchunks) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    const int k0 = c * chunk, k1 = min(tsteps, k0 + chunk);
+    int hs = 0;
+    for (int k = k0; k < k1; ++k) {
+        if (k > k0) hs = precip[k] > 0 ? 0 : hs + 1;
+        rows[k].m.alb = snow_albedo(hs);
+    }
+}
+// dtms = dtm + ground snow depth (int:2562, 2614); NaN where the dtm is NA
+__global__ __launch_bounds__(256) void k_add_snow(const double* __restrict__ dtm, const double* __restrict__ dep,
+                                                  double scale, int64_t N, double* __restrict__ dtms) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < N) dtms[c] = dtm[c] + dep[c] * scale;
+}
+// mask(x, dtm): NA where the dtm is NA (int:2568, 2571)
+__global__ __launch_bounds__(256) void k_mask2(const double* __restrict__ dtm, int64_t N, double* __restrict__ a,
+                                               double* __restrict__ b) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < N && isnan(dtm[c])) { a[c] = na_real(); b[c] = na_real(); }
+}
+// deterministic (sum, count) of the non-NaN entries of x, one workgroup
+__global__ __launch_bounds__(1024) void k_sumcount(const double* __restrict__ x, int64_t N, double* __restrict__ out2) {
+    __shared__ double ss[1024];
+    __shared__ double sc[1024];
+    double s = 0.0, n = 0.0;
+    for (int64_t i = threadIdx.x; i < N; i += 1024) {
+        const double v = x[i];
+        if (!isnan(v)) { s += v; n += 1.0; }
+    }
+    ss[threadIdx.x] = s; sc[threadIdx.x] = n;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) { ss[threadIdx.x] += ss[threadIdx.x + w]; sc[threadIdx.x] += sc[threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out2[0] = ss[0]; out2[1] = sc[0]; }
+}
+// .tpicalc (int:2471-2485), coarse part: aggregate(dtm, af, na.rm = TRUE) — af x af block means from the
+// top-left corner over the non-NA cells
+__global__ __launch_bounds__(256) void k_tpi_coarse(const double* __restrict__ z, int64_t rows, int64_t cols, int af,
+                                                    int64_t nI, int64_t nJ, double* __restrict__ cm) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nI * nJ) return;
+    const int64_t I = q % nI, J = q / nI;
+    const int64_t ra = I * af, rb = min(ra + af, rows), ca = J * af, cb = min(ca + af, cols);
+    double s = 0.0, n = 0.0;
+    for (int64_t c = ca; c < cb; ++c)
+        for (int64_t r = ra; r < rb; ++r) {
+            const double v = z[r + rows * c];
+            if (!isnan(v)) { s += v; n += 1.0; }
+        }
+    cm[q] = s / n;   // 0/0 = NaN for an all-NA block
+}
+// .tpicalc, fine part: resample (bilinear between block centres, clamped) or the raster mean, then
+// tpic = exp((dtmc - dtm) * tfact) with its two clamps (`tpic[tpic < 0.05] <- 0.1` sic)
+__global__ __launch_bounds__(256) void k_tpi_fine(const double* __restrict__ z, int64_t rows, int64_t cols, int af,
+                                                  int64_t nI, int64_t nJ, const double* __restrict__ cm,
+                                                  const double* __restrict__ mean2, double tfact,
+                                                  double* __restrict__ tpic) {
+    const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= rows * cols) return;
+    double zc;
+    if (cm) {
+        const int64_t r = cell % rows, c = cell / rows;
+        const double tr = ((double)r - (af - 1) / 2.0) / af, tcc = ((double)c - (af - 1) / 2.0) / af;
+        const int64_t i0 = (int64_t)floor(tr), j0 = (int64_t)floor(tcc);
+        const double wr = tr - (double)i0, wc = tcc - (double)j0;
+        const int64_t ia = min(max(i0, (int64_t)0), nI - 1), ib = min(max(i0 + 1, (int64_t)0), nI - 1);
+        const int64_t ja = min(max(j0, (int64_t)0), nJ - 1), jb = min(max(j0 + 1, (int64_t)0), nJ - 1);
+        const double top = cm[ia + nI * ja] * (1 - wc) + cm[ia + nI * jb] * wc;
+        const double bot = cm[ib + nI * ja] * (1 - wc) + cm[ib + nI * jb] * wc;
+        zc = top * (1 - wr) + bot * wr;
+    } else {
+        zc = z[cell] * 0 + mean2[0] / mean2[1];   // dtm * 0 + mean(dtm, na.rm = TRUE)
+    }
+    double t = exp((zc - z[cell]) * tfact);
+    if (t < 0.05) t = 0.1;
+    if (t > 10) t = 10;
+    tpic[cell] = t;
+}
+// redistribution of the chunk's snow-depth changes and hand-over to the next chunk (int:2589-2614);
+// sdepc / sdepg are overwritten by totalSWE / groundsnowdepth
+struct RedistArgs {
+    int64_t N;
+    int nsteps;
+    const double* hgt;
+    const double *dtm, *tpic, *tpimean2, *isnowdg, *sden, *agec, *ageg;
+    double *sdepc, *sdepg;          // in: smod$sdepc / sdepg, out: swe / snowdepg   [N][nsteps]
+    double *isnowdc, *dtms;         // state for the next chunk
+    int32_t *isnowac, *isnowag;
+};
+__global__ __launch_bounds__(256) void k_snow_redistribute(RedistArgs a) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.N) return;
+    const double tpi = a.tpic[c] / (a.tpimean2[0] / a.tpimean2[1]);   // tpic / mean(tpic, na.rm = TRUE)
+    const double asd = a.isnowdg[c], asc = a.isnowdc[c];
+    double tot = 0.0, gd = 0.0;
+    for (int k = 0; k < a.nsteps; ++k) {
+        const int64_t o = c + a.N * k;
+        const double dsnow = a.sdepg[o] - asd;
+        double dsnow2 = dsnow * tpi;
+        if (dsnow < 0) dsnow2 = dsnow;
+        const double cdsnow = a.sdepc[o] - asc - dsnow;
+        tot = asc + cdsnow + dsnow2;
+        gd = asd + dsnow2;
+        a.sdepc[o] = tot * a.sden[o];
+        a.sdepg[o] = gd;
+    }
+    a.isnowdc[c] = tot;
+    a.dtms[c] = a.dtm[c] + gd;
+    if (!isnan(a.agec[c])) a.isnowac[c] = (int32_t)a.agec[c];
+    if (!isnan(a.ageg[c])) a.isnowag[c] = (int32_t)a.ageg[c];
+}
+
 // ---- host side -------------------------------------------------------------------------------------
 #define S_TRY(expr)                                                                          \
     do {                                                                                     \
@@ -674,7 +794,154 @@ int run_microsnow(const mcf_snow_inputs* in, const mcf_snowm* sm, double reqhgt,
     return MCF_OK;
 }
 
+int run_snowdriver(const mcf_snowdriver_in* din, mcf_snowdriver_out* out, int32_t device) {
+    int rc;
+    if (!din || !out) return mcf::api_fail(MCF_ERR_ARG, "null snow driver argument");
+    const mcf_snow_inputs* in = &din->base;
+    if ((rc = common_checks(in))) return rc;
+    if (in->array_forcing) return mcf::api_fail(MCF_ERR_ARG, "mcf_snowmodel1 takes data.frame (vector) climate");
+    if (!din->dtm || !(din->res > 0)) return mcf::api_fail(MCF_ERR_ARG, "snow driver needs dtm and res > 0");
+    if ((rc = pick_device(device))) return rc;
+    const int64_t rows = in->rows, cols = in->cols, N = rows * cols;
+    const int T = (int)in->tsteps;
+    const int chunk = din->chunk_steps > 0 ? din->chunk_steps : 120;
+    if (chunk % 24) return mcf::api_fail(MCF_ERR_ARG, "snow driver: chunk_steps must be whole days");
+    int nchunks = T / chunk;             // `for (day in 1:n5days)`: 1:x truncates, and 1:0.4 still runs once
+    if (nchunks < 1) nchunks = 1;
+    Bufs b;
+    ModelArgs a;
+    memset(&a, 0, sizeof a);
+    a.N = N; a.zref = in->other.zref;
+    snow_density_params(in->snowenv, a.sdp);
+    UP(a.pai, in->vegp.pai, N);
+    UP(a.hgt, in->vegp.hgt, N);
+    UP(a.leaft, in->vegp.leaft, N);
+    UP(a.clump, in->vegp.clump, N);
+    const double *d_dtm, *d_isnowdg;
+    double *d_isnowdc, *d_dtms, *d_slope, *d_aspect, *d_svf, *d_wsa, *d_hor, *d_tpic, *d_mean2, *d_cm = nullptr;
+    int32_t *d_ac, *d_ag;
+    UP(d_dtm, din->dtm, N);
+    UP(d_isnowdg, in->other.isnowdg, N);
+    { const double* t; UP(t, in->other.isnowdc, N); d_isnowdc = const_cast<double*>(t); }
+    { const int32_t* t; UP(t, in->other.isnowac, N); d_ac = const_cast<int32_t*>(t); }
+    { const int32_t* t; UP(t, in->other.isnowag, N); d_ag = const_cast<int32_t*>(t); }
+    if ((rc = b.alloc((void**)&d_dtms, N * 8))) return rc;
+    if ((rc = b.alloc((void**)&d_slope, N * 8))) return rc;
+    if ((rc = b.alloc((void**)&d_aspect, N * 8))) return rc;
+    if ((rc = b.alloc((void**)&d_svf, N * 8))) return rc;
+    if ((rc = b.alloc((void**)&d_wsa, 8 * N * 8))) return rc;
+    if ((rc = b.alloc((void**)&d_hor, 24 * N * 8))) return rc;
+    if ((rc = b.alloc((void**)&d_tpic, N * 8))) return rc;
+    if ((rc = b.alloc((void**)&d_mean2, 16))) return rc;
+    a.slope = d_slope; a.aspect = d_aspect; a.skyview = d_svf; a.wsa = d_wsa; a.hor = d_hor;
+    a.isnowdc = d_isnowdc; a.isnowdg = d_isnowdg; a.isnowac = d_ac; a.isnowag = d_ag;
+    const StepRow* rows_tab;
+    const DateRow2* dates_unused;
+    const double* mx_unused;
+    if ((rc = build_step_tables(b, in, false, true, true, &rows_tab, &dates_unused, &mx_unused))) return rc;
+    {   // albedo per chunk (overrides the whole-series scan of build_step_tables)
+        const double* d_prec;
+        UP(d_prec, in->clim.precip, T);
+        hipLaunchKernelGGL(k_snow_alb_chunks, dim3((unsigned)((nchunks + 63) / 64)), dim3(64), 0, nullptr,
+                           const_cast<StepRow*>(rows_tab), d_prec, T, chunk, nchunks);
+    }
+    const int64_t CN = (int64_t)chunk * N;
+    if ((rc = b.alloc((void**)&a.Tc, CN * 8))) return rc;
+    if ((rc = b.alloc((void**)&a.Tg, CN * 8))) return rc;
+    if ((rc = b.alloc((void**)&a.sdepc, CN * 8))) return rc;
+    if ((rc = b.alloc((void**)&a.sdepg, CN * 8))) return rc;
+    if ((rc = b.alloc((void**)&a.sden, CN * 8))) return rc;
+    if ((rc = b.alloc((void**)&a.agec, N * 8))) return rc;
+    if ((rc = b.alloc((void**)&a.ageg, N * 8))) return rc;
+    const unsigned gridN = (unsigned)((N + 255) / 256);
+    // steps that no chunk covers stay NA (R pre-fills its arrays with NA, int:2554-2558)
+    double* hostv[5] = {out->Tc, out->Tg, out->groundsnowdepth, out->totalSWE, out->snowden};
+    {
+        union { uint64_t u; double d; } na; na.u = kNaRealBits;
+        const int covered = std::min(T, nchunks * chunk);
+        for (double* h : hostv)
+            if (h) for (int64_t q = (int64_t)covered * N; q < (int64_t)T * N; ++q) h[q] = na.d;
+    }
+    hipLaunchKernelGGL(k_add_snow, dim3(gridN), dim3(256), 0, nullptr, d_dtm, d_isnowdg, 1.0, N, d_dtms);   // int:2562
+    const int ss = din->res <= 100 ? 10 : 1;                                                                 // int:2577-2578
+    const int64_t me = std::min(rows, cols);
+    const bool timing = getenv("MCF_TIMING") != nullptr;
+    double t_terrain = 0, t_model = 0, t_redist = 0, t_copy = 0;
+    hipEvent_t ev[5];
+    if (timing) for (auto& e : ev) S_TRY(hipEventCreate(&e));
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int k0 = ch * chunk, ns = std::min(chunk, T - k0);
+        if (timing) S_TRY(hipEventRecord(ev[0], nullptr));
+        // terrain of dtm + snow (int:2566-2580)
+        mcf::TerrainDev td;
+        memset(&td, 0, sizeof td);
+        td.rows = rows; td.cols = cols; td.d_dtm = d_dtms; td.res = din->res; td.zref = in->other.zref; td.agg = ss;
+        td.aspect_na = 180.0;
+        td.d_slope = d_slope; td.d_aspect = d_aspect; td.d_hor = d_hor; td.d_svfa = d_svf; td.d_wsa = d_wsa;
+        if ((rc = mcf::terrain_device(td))) return rc;
+        hipLaunchKernelGGL(k_mask2, dim3(gridN), dim3(256), 0, nullptr, d_dtm, N, d_slope, d_aspect);
+        if (timing) S_TRY(hipEventRecord(ev[1], nullptr));
+        // gridmodelsnow1 on the chunk (int:2587)
+        a.rows = rows_tab + k0;
+        a.tsteps = ns;
+        hipLaunchKernelGGL(k_snowmodel<false>, dim3(gridN), dim3(256), 0, nullptr, a);
+        if (timing) S_TRY(hipEventRecord(ev[2], nullptr));
+        // topographic positioning index (int:2589-2592, 2471-2485)
+        double wsum = 0.0;
+        for (int k = 0; k < ns; ++k) wsum += in->clim.windspeed[k0 + k];
+        const double tpr = 10 * sqrt(wsum / ns);
+        const double afd = nearbyint(tpr / din->res);          // R's round(x, 0): half to even
+        if (!(afd >= 1.0)) return mcf::api_fail(MCF_ERR_ARG, "snow driver: aggregation factor round(10*sqrt(mean wind)/res) is 0 (terra::aggregate fails)");
+        const int af = (int)std::min(afd, 1e9);
+        if ((double)af < me / 2.0) {
+            const int64_t nI = (rows + af - 1) / af, nJ = (cols + af - 1) / af;
+            if (d_cm) { (void)hipFree(d_cm); d_cm = nullptr; }
+            S_TRY(hipMalloc((void**)&d_cm, (size_t)(nI * nJ * 8)));
+            hipLaunchKernelGGL(k_tpi_coarse, dim3((unsigned)((nI * nJ + 255) / 256)), dim3(256), 0, nullptr, d_dtms, rows,
+                               cols, af, nI, nJ, d_cm);
+            hipLaunchKernelGGL(k_tpi_fine, dim3(gridN), dim3(256), 0, nullptr, d_dtms, rows, cols, af, nI, nJ, d_cm,
+                               d_mean2, din->tfact, d_tpic);
+        } else {
+            hipLaunchKernelGGL(k_sumcount, dim3(1), dim3(1024), 0, nullptr, d_dtms, N, d_mean2);
+            hipLaunchKernelGGL(k_tpi_fine, dim3(gridN), dim3(256), 0, nullptr, d_dtms, rows, cols, af, (int64_t)0,
+                               (int64_t)0, (const double*)nullptr, d_mean2, din->tfact, d_tpic);
+        }
+        hipLaunchKernelGGL(k_sumcount, dim3(1), dim3(1024), 0, nullptr, d_tpic, N, d_mean2);
+        RedistArgs ra;
+        ra.N = N; ra.nsteps = ns; ra.hgt = a.hgt; ra.dtm = d_dtm; ra.tpic = d_tpic; ra.tpimean2 = d_mean2;
+        ra.isnowdg = d_isnowdg; ra.sden = a.sden; ra.agec = a.agec; ra.ageg = a.ageg; ra.sdepc = a.sdepc;
+        ra.sdepg = a.sdepg; ra.isnowdc = d_isnowdc; ra.dtms = d_dtms; ra.isnowac = d_ac; ra.isnowag = d_ag;
+        hipLaunchKernelGGL(k_snow_redistribute, dim3(gridN), dim3(256), 0, nullptr, ra);
+        S_TRY(hipGetLastError());
+        if (timing) S_TRY(hipEventRecord(ev[3], nullptr));
+        double* devv[5] = {a.Tc, a.Tg, a.sdepg, a.sdepc, a.sden};
+        for (int v = 0; v < 5; ++v)
+            if (hostv[v]) S_TRY(hipMemcpy(hostv[v] + (int64_t)k0 * N, devv[v], (size_t)ns * N * 8, hipMemcpyDeviceToHost));
+        if (timing) {
+            S_TRY(hipEventRecord(ev[4], nullptr));
+            S_TRY(hipEventSynchronize(ev[4]));
+            float ms;
+            S_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); t_terrain += ms;
+            S_TRY(hipEventElapsedTime(&ms, ev[1], ev[2])); t_model += ms;
+            S_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); t_redist += ms;
+            S_TRY(hipEventElapsedTime(&ms, ev[3], ev[4])); t_copy += ms;
+        }
+    }
+    if (d_cm) (void)hipFree(d_cm);
+    S_TRY(hipDeviceSynchronize());
+    if (timing) {
+        fprintf(stderr, "[mcf] snowmodel1: %d chunks of %d steps, %lld cells: terrain %.2f ms, gridmodelsnow %.2f ms, "
+                "tpi+redistribute %.2f ms, D2H %.2f ms\n", nchunks, chunk, (long long)N, t_terrain, t_model, t_redist, t_copy);
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+    return MCF_OK;
+}
+
 }  // namespace
+
+extern "C" int mcf_snowmodel1(const mcf_snowdriver_in* in, mcf_snowdriver_out* out, int32_t device) {
+    return run_snowdriver(in, out, device);
+}
 
 extern "C" int32_t mcf_snowenv_from_name(const char* name) {
     if (!name) return MCF_SNOWENV_ALPINE;

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "../../include/mcf.h"
+#include "mcf_terrain.h"
 
 namespace mcf {
 int api_fail(int code, const std::string& msg);   // mcf_api.hip
@@ -150,13 +151,14 @@ __global__ __launch_bounds__(256) void k_resample_blend(const double* __restrict
 
 // Horn (1981) 8-neighbour slope / aspect in degrees on the RAW elevations
 __global__ __launch_bounds__(256) void k_slope_aspect(const double* __restrict__ dtm, Geo g, double res,
-                                                      double* __restrict__ slope, double* __restrict__ aspect) {
+                                                      double aspect_na, double* __restrict__ slope,
+                                                      double* __restrict__ aspect) {
     int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t N = g.rows * g.cols;
     if (cell >= N) return;
     int64_t r = cell % g.rows, c = cell / g.rows;
     int64_t grow = g.row0 + r;
-    double sl = 0.0, as = 0.0;
+    double sl = 0.0, as = aspect_na;   // terra's NA (raster edge, NA neighbour) -> 0 / aspect_na
     if (grow > 0 && grow < g.rows_total - 1 && c > 0 && c < g.cols - 1) {
         auto z = [&](int64_t dr, int64_t dc) {
             int64_t b = grow + dr - (g.row0 - g.hn);
@@ -216,6 +218,62 @@ struct DevBufs {
 
 }  // namespace
 
+// Device-level entry: `t.d_dtm` and every output pointer are device memory.  Used by
+// mcf_precompute_terrain (host arrays) and by the snow driver's 5-day terrain refresh (mcf_snow.hip).
+namespace mcf {
+int terrain_device(const TerrainDev& t) {
+    const int64_t rows_total = t.rows_total > 0 ? t.rows_total : t.rows;
+    const int64_t row0 = t.rows_total > 0 ? t.row0 : 0;
+    const int s = t.agg > 0 ? t.agg : 10;
+    const bool want_wsa = t.d_wsa != nullptr;
+    Geo g;
+    g.rows = t.rows; g.cols = t.cols; g.hn = t.halo_north;
+    g.RB = t.halo_north + t.rows + t.halo_south;
+    g.row0 = row0; g.rows_total = rows_total;
+    const int64_t N = g.rows * g.cols, NB = g.RB * g.cols;
+    DevBufs db;
+    int rc;
+    double* d_Z;
+    if ((rc = db.alloc((void**)&d_Z, NB * 8))) return rc;
+    hipLaunchKernelGGL(k_prep, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, nullptr, t.d_dtm, d_Z, NB, 1.0 / t.res);
+    const unsigned gridN = (unsigned)((N + 255) / 256);
+    if (t.d_hor || t.d_svfa) {
+        ShiftTable t24;
+        fill_shifts(t24, 24);
+        hipLaunchKernelGGL(k_horizon, dim3(gridN), dim3(256), 0, nullptr, d_Z, g, t24, t.d_hor, t.d_svfa);
+        T_TRY(hipGetLastError());
+    }
+    if (want_wsa) {
+        ShiftTable t16;
+        memset(&t16, 0, sizeof t16);
+        fill_shifts(t16, 16);
+        const int64_t NItot = (rows_total + s - 1) / s, nJ = (g.cols + s - 1) / s;
+        auto clampI = [&](int64_t i) { return std::min<int64_t>(std::max<int64_t>(i, 0), NItot - 1); };
+        const int64_t I0 = clampI((int64_t)floor(((double)row0 - (s - 1) / 2.0) / s));
+        const int64_t I1 = clampI((int64_t)floor(((double)(row0 + g.rows - 1) - (s - 1) / 2.0) / s) + 1);
+        const int64_t nI = I1 - I0 + 1;
+        const int64_t e0 = I0 * s, e1 = std::min<int64_t>((I1 + 1) * s, rows_total), ne = e1 - e0;
+        double *d_W, *d_C;
+        if ((rc = db.alloc((void**)&d_W, 16 * ne * g.cols * 8))) return rc;
+        if ((rc = db.alloc((void**)&d_C, 16 * nI * nJ * 8))) return rc;
+        int64_t M = ne * g.cols;
+        hipLaunchKernelGGL(k_windcoef, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, nullptr, d_Z, g, t16,
+                           t.zref / t.res, e0, ne, d_W);
+        hipLaunchKernelGGL(k_block_mean, dim3((unsigned)((16 * nI * nJ + 255) / 256)), dim3(256), 0, nullptr, d_W, g,
+                           s, e0, ne, I0, nI, nJ, d_C);
+        hipLaunchKernelGGL(k_resample_blend, dim3(gridN), dim3(256), 0, nullptr, d_C, g, s, I0, nI, nJ, NItot, t.d_wsa);
+        T_TRY(hipGetLastError());
+    }
+    if (t.d_slope || t.d_aspect) {
+        hipLaunchKernelGGL(k_slope_aspect, dim3(gridN), dim3(256), 0, nullptr, t.d_dtm, g, t.res, t.aspect_na,
+                           t.d_slope, t.d_aspect);
+        T_TRY(hipGetLastError());
+    }
+    T_TRY(hipDeviceSynchronize());   // temporaries are released on return
+    return MCF_OK;
+}
+}  // namespace mcf
+
 extern "C" int mcf_precompute_terrain(const mcf_terrain_in* in, const mcf_terrain_out* out, int32_t device) {
     if (!in || !out || !in->dtm) return mcf::api_fail(MCF_ERR_ARG, "null terrain argument");
     if (in->rows <= 0 || in->cols <= 0 || in->halo_north < 0 || in->halo_south < 0 || !(in->res > 0))
@@ -240,63 +298,27 @@ extern "C" int mcf_precompute_terrain(const mcf_terrain_in* in, const mcf_terrai
     if (device < 0 || device >= nd) return mcf::api_fail(MCF_ERR_ARG, "device ordinal out of range");
     T_TRY(hipSetDevice(device));
 
-    Geo g;
-    g.rows = in->rows; g.cols = in->cols; g.hn = in->halo_north;
-    g.RB = in->halo_north + in->rows + in->halo_south;
-    g.row0 = row0; g.rows_total = rows_total;
-    const int64_t N = g.rows * g.cols, NB = g.RB * g.cols;
+    const int64_t N = in->rows * in->cols, NB = (in->halo_north + in->rows + in->halo_south) * in->cols;
     DevBufs db;
     int rc;
-    double *d_dtm, *d_Z;
+    double* d_dtm;
     if ((rc = db.alloc((void**)&d_dtm, NB * 8))) return rc;
-    if ((rc = db.alloc((void**)&d_Z, NB * 8))) return rc;
     T_TRY(hipMemcpy(d_dtm, in->dtm, (size_t)NB * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_prep, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, nullptr, d_dtm, d_Z, NB, 1.0 / in->res);
-    const unsigned gridN = (unsigned)((N + 255) / 256);
-
-    if (out->hor || out->svfa) {
-        ShiftTable t24;
-        fill_shifts(t24, 24);
-        double *d_hor = nullptr, *d_svf = nullptr;
-        if (out->hor && (rc = db.alloc((void**)&d_hor, N * 24 * 8))) return rc;
-        if (out->svfa && (rc = db.alloc((void**)&d_svf, N * 8))) return rc;
-        hipLaunchKernelGGL(k_horizon, dim3(gridN), dim3(256), 0, nullptr, d_Z, g, t24, d_hor, d_svf);
-        T_TRY(hipGetLastError());
-        if (out->hor) T_TRY(hipMemcpy(out->hor, d_hor, (size_t)N * 24 * 8, hipMemcpyDeviceToHost));
-        if (out->svfa) T_TRY(hipMemcpy(out->svfa, d_svf, (size_t)N * 8, hipMemcpyDeviceToHost));
-    }
-    if (want_wsa) {
-        ShiftTable t16;
-        memset(&t16, 0, sizeof t16);
-        fill_shifts(t16, 16);
-        const int64_t NItot = (rows_total + s - 1) / s, nJ = (g.cols + s - 1) / s;
-        auto clampI = [&](int64_t i) { return std::min<int64_t>(std::max<int64_t>(i, 0), NItot - 1); };
-        const int64_t I0 = clampI((int64_t)floor(((double)row0 - (s - 1) / 2.0) / s));
-        const int64_t I1 = clampI((int64_t)floor(((double)(row0 + g.rows - 1) - (s - 1) / 2.0) / s) + 1);
-        const int64_t nI = I1 - I0 + 1;
-        const int64_t e0 = I0 * s, e1 = std::min<int64_t>((I1 + 1) * s, rows_total), ne = e1 - e0;
-        double *d_W, *d_C, *d_wsa;
-        if ((rc = db.alloc((void**)&d_W, 16 * ne * g.cols * 8))) return rc;
-        if ((rc = db.alloc((void**)&d_C, 16 * nI * nJ * 8))) return rc;
-        if ((rc = db.alloc((void**)&d_wsa, N * 8 * 8))) return rc;
-        int64_t M = ne * g.cols;
-        hipLaunchKernelGGL(k_windcoef, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, nullptr, d_Z, g, t16,
-                           in->zref / in->res, e0, ne, d_W);
-        hipLaunchKernelGGL(k_block_mean, dim3((unsigned)((16 * nI * nJ + 255) / 256)), dim3(256), 0, nullptr, d_W, g,
-                           s, e0, ne, I0, nI, nJ, d_C);
-        hipLaunchKernelGGL(k_resample_blend, dim3(gridN), dim3(256), 0, nullptr, d_C, g, s, I0, nI, nJ, NItot, d_wsa);
-        T_TRY(hipGetLastError());
-        T_TRY(hipMemcpy(out->wsa, d_wsa, (size_t)N * 8 * 8, hipMemcpyDeviceToHost));
-    }
-    if (out->slope || out->aspect) {
-        double *d_sl = nullptr, *d_as = nullptr;
-        if (out->slope && (rc = db.alloc((void**)&d_sl, N * 8))) return rc;
-        if (out->aspect && (rc = db.alloc((void**)&d_as, N * 8))) return rc;
-        hipLaunchKernelGGL(k_slope_aspect, dim3(gridN), dim3(256), 0, nullptr, d_dtm, g, in->res, d_sl, d_as);
-        T_TRY(hipGetLastError());
-        if (out->slope) T_TRY(hipMemcpy(out->slope, d_sl, (size_t)N * 8, hipMemcpyDeviceToHost));
-        if (out->aspect) T_TRY(hipMemcpy(out->aspect, d_as, (size_t)N * 8, hipMemcpyDeviceToHost));
-    }
-    T_TRY(hipDeviceSynchronize());
+    mcf::TerrainDev t;
+    memset(&t, 0, sizeof t);
+    t.rows = in->rows; t.cols = in->cols; t.halo_north = in->halo_north; t.halo_south = in->halo_south;
+    t.row0 = in->row0; t.rows_total = in->rows_total;
+    t.d_dtm = d_dtm; t.res = in->res; t.zref = in->zref; t.agg = in->agg; t.aspect_na = 0.0;   // int:1132-1136
+    if (out->slope && (rc = db.alloc((void**)&t.d_slope, N * 8))) return rc;
+    if (out->aspect && (rc = db.alloc((void**)&t.d_aspect, N * 8))) return rc;
+    if (out->hor && (rc = db.alloc((void**)&t.d_hor, N * 24 * 8))) return rc;
+    if (out->svfa && (rc = db.alloc((void**)&t.d_svfa, N * 8))) return rc;
+    if (out->wsa && (rc = db.alloc((void**)&t.d_wsa, N * 8 * 8))) return rc;
+    if ((rc = mcf::terrain_device(t))) return rc;
+    if (out->slope) T_TRY(hipMemcpy(out->slope, t.d_slope, (size_t)N * 8, hipMemcpyDeviceToHost));
+    if (out->aspect) T_TRY(hipMemcpy(out->aspect, t.d_aspect, (size_t)N * 8, hipMemcpyDeviceToHost));
+    if (out->hor) T_TRY(hipMemcpy(out->hor, t.d_hor, (size_t)N * 24 * 8, hipMemcpyDeviceToHost));
+    if (out->svfa) T_TRY(hipMemcpy(out->svfa, t.d_svfa, (size_t)N * 8, hipMemcpyDeviceToHost));
+    if (out->wsa) T_TRY(hipMemcpy(out->wsa, t.d_wsa, (size_t)N * 8 * 8, hipMemcpyDeviceToHost));
     return MCF_OK;
 }

@@ -191,3 +191,32 @@ def gridmicrosnow2(reqhgt, obstime, climdata, snowm, micro, vegp, other, mat, ou
     """Array-climate variant: drop-in for gridmicrosnow2 (src/microclimfCpp.cpp:5059-5214)."""
     return _micro("mcf_gridmicrosnow2", True, reqhgt, obstime, climdata, snowm, micro, vegp, other, mat, out,
                   device)
+
+
+def snowmodel1_chunks(obstime, climdata, pointm, vegp, other, snowenv, dtm, res, tfact=0.02, *,
+                      chunk_steps: int = 120, device: int = 0) -> dict:
+    """The chunk loop of the reference's `.snowmodel1` (R/internal.R:2553-2617) resident on the
+    device: per 5-day chunk terrain refresh from dtm + snow, gridmodelsnow1, `.tpicalc`
+    redistribution, hand-over of depths and ages.  Arguments are what the loop works with:
+    `pointm` is pointmodelsnow's output, `vegp` the snow-season means of `.sortl`, `other`
+    holds lat, lon, zref and the initial isnowdc / isnowdg / isnowac / isnowag.  Returns the
+    list `.snowmodel1` returns (R/internal.R:2619) minus `umu`."""
+    lib = _abi.load()
+    R, Cc = np.shape(vegp["pai"])
+    oth = dict(other)
+    for k, shp in (("slope", (R, Cc)), ("aspect", (R, Cc)), ("skyview", (R, Cc)), ("wsa", (R, Cc, 8)),
+                   ("hor", (R, Cc, 24))):
+        oth.setdefault(k, np.zeros(shp))          # recomputed on the device every chunk
+    m = marshal_snow(obstime, climdata, vegp, oth, False, pointm=pointm, snowenv=snowenv)
+    din = _abi.SnowDriverIn()
+    din.base = m.inputs
+    din.dtm = m.f64(dtm, (R, Cc), "dtm")
+    din.res, din.tfact, din.chunk_steps = float(res), float(tfact), int(chunk_steps)
+    out = _abi.SnowDriverOut()
+    arrays = {}
+    for f in _abi.SNOWDRIVER_OUT:
+        a = np.empty((R, Cc, m.tsteps), dtype=np.float64, order="F")
+        arrays[f] = a
+        setattr(out, f, a.ctypes.data_as(_abi.c_double_p))
+    _abi.check(lib.mcf_snowmodel1(C.byref(din), C.byref(out), device))
+    return arrays

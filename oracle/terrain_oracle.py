@@ -126,14 +126,14 @@ def windsheltera(dtm, whgt: float, s: int = 10, reso: float = 1.0):
     return a2
 
 
-def slope_aspect(dtm, reso: float = 1.0):
+def slope_aspect(dtm, reso: float = 1.0, aspect_na: float = 0.0):
     """Horn 8-neighbour slope and aspect in degrees (aspect clockwise from north, downslope
     direction, 90 where flat); raster-edge cells and cells with an NA neighbour are NA in
     terra and become 0 in the marshaller (R/internal.R:1132-1133)."""
     z = np.array(dtm, dtype=np.float64)
     x, y = z.shape
     slope = np.zeros((x, y))
-    aspect = np.zeros((x, y))
+    aspect = np.full((x, y), float(aspect_na))
     zn = z[:-2, :]; zs = z[2:, :]; zc = z[1:-1, :]
     # row index grows southwards, column index eastwards
     nw, n_, ne = zn[:, :-2], zn[:, 1:-1], zn[:, 2:]
@@ -146,7 +146,7 @@ def slope_aspect(dtm, reso: float = 1.0):
     asp = np.where((dzdx == 0) & (dzdy == 0), 90.0, asp)
     bad = np.isnan(sl)
     slope[1:-1, 1:-1] = np.where(bad, 0.0, sl)
-    aspect[1:-1, 1:-1] = np.where(bad, 0.0, asp)
+    aspect[1:-1, 1:-1] = np.where(bad, float(aspect_na), asp)
     return slope, aspect
 
 

@@ -30,6 +30,8 @@ def test_snow_struct_layout():
     assert C.sizeof(_abi.SnowInputs) == 3 * 8 + 8 + 4 * 8 + (10 + 5 + 7 + 15) * 8
     assert C.sizeof(_abi.SnowModelOut) == 9 * 8
     assert C.sizeof(_abi.Snowm) == 5 * 8
+    assert C.sizeof(_abi.SnowDriverIn) == C.sizeof(_abi.SnowInputs) + 8 + 8 + 8 + 8
+    assert C.sizeof(_abi.SnowDriverOut) == 5 * 8
 
 
 def test_snowenv_names():
@@ -133,3 +135,21 @@ def test_out_mask_only_touches_requested(oracle):
     out = [1, 0, 1, 0, 0, 0, 0, 0, 0, 1]
     mo = oracle.run_microsnow(0.05, sw["obstime"], sw["climdata"], snowm, micro, sw["vegp"], sw["other"], 3.0, out)
     assert list(mo) == ["Tz", "relhum", "Rlwup"]
+
+
+def test_tpicalc_oracle_properties():
+    """.tpicalc (R/internal.R:2471-2485): mean 1 over non-NA cells, hollows (below their surroundings)
+    collect snow, NA cells stay NA, the raster-mean branch when the window exceeds half the raster"""
+    from oracle import snowdriver_oracle as SD
+    _, _, dtm = synthetic.rasters(40, 36)
+    dtm[3, 4] = np.nan
+    t = SD.tpicalc(7, 36, dtm, 0.02)
+    assert np.isnan(t[3, 4]) and np.isnan(t).sum() == 1
+    assert abs(np.nanmean(t) - 1) < 1e-12
+    smooth = SD.TO.bilinear_from_blocks(SD.block_mean_narm(dtm, 7), 7, *dtm.shape)
+    ok = ~np.isnan(dtm)
+    assert np.corrcoef((smooth - dtm)[ok], t[ok])[0, 1] > 0.99
+    t2 = SD.tpicalc(30, 36, dtm, 0.02)                     # af >= me / 2
+    want = np.exp((np.nanmean(dtm) - dtm) * 0.02)
+    want = want / np.nanmean(want)
+    assert np.allclose(t2[ok], want[ok], rtol=1e-12)

@@ -106,6 +106,44 @@ def test_microsnow_out_mask(oracle):
         assert_close(got[k], want[k], TOL, k)
 
 
+def _driver_case(rows, cols, tsteps, **kw):
+    sw = synthetic.snow_workload(rows, cols, tsteps, cold=3.0, zref=3.5, **kw)
+    _, _, dtm = synthetic.rasters(rows, cols)
+    dtm = np.where(np.isnan(sw["vegp"]["hgt"]), np.nan, dtm)
+    return sw, dtm
+
+
+@pytest.mark.parametrize("case", [
+    dict(rows=40, cols=30, tsteps=240, res=1.0, chunk=120),          # two 5-day chunks, af = 17 < me/2
+    dict(rows=24, cols=31, tsteps=96, res=1.0, chunk=48),            # af >= me/2: raster-mean branch of .tpicalc
+    dict(rows=33, cols=40, tsteps=130, res=2.0, chunk=120),          # 10 trailing hours stay NA (1:n5days truncates)
+    dict(rows=30, cols=30, tsteps=60, res=5.0, chunk=120),           # fewer steps than one chunk: runs once
+])
+def test_snowmodel1_chunk_loop_matches_oracle(oracle, case):
+    """`.snowmodel1`'s 5-day loop on the device (terrain refresh from dtm + snow, gridmodelsnow1,
+    `.tpicalc` redistribution, hand-over) against its numpy/C oracle"""
+    from microclimf_amd.snow import snowmodel1_chunks
+    from oracle import snowdriver_oracle as SD
+    sw, dtm = _driver_case(case["rows"], case["cols"], case["tsteps"])
+    args = (sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"], sw["other"], sw["snowenv"], dtm, case["res"], 0.02)
+    want = SD.snowmodel1_chunks(*args, chunk_steps=case["chunk"])
+    got = snowmodel1_chunks(*args, chunk_steps=case["chunk"])
+    assert list(got) == ["Tc", "Tg", "groundsnowdepth", "totalSWE", "snowden"]       # int:2619
+    for k in want:
+        assert_close(got[k], want[k], TOL, f"{case}:{k}")
+    covered = max(1, case["tsteps"] // case["chunk"]) * case["chunk"]
+    if covered < case["tsteps"]:
+        assert (got["Tc"][:, :, covered:].view(np.uint64) == NA_BITS).all()
+
+
+def test_snowmodel1_rejects_zero_aggregation_factor():
+    from microclimf_amd.snow import snowmodel1_chunks
+    sw, dtm = _driver_case(12, 12, 48)
+    with pytest.raises(_abi.McfError, match="aggregation factor"):
+        snowmodel1_chunks(sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"], sw["other"], sw["snowenv"], dtm,
+                          500.0, chunk_steps=48)
+
+
 def test_snow_entry_points_reject_bad_arguments():
     lib = _abi.load()
     sw, _ = build_snow("prairie_short")
