@@ -373,6 +373,15 @@ typedef struct mcf_snowdriver_out {
 } mcf_snowdriver_out;
 int mcf_snowmodel1(const mcf_snowdriver_in *in, mcf_snowdriver_out *out, int32_t device);
 
+/* applycpp3 (src/microclimfCpp.cpp:5553-5588; `.runmicrosnow1/2` use it on totalSWE, R/internal.R:3592-3593):
+ * reduction of a [rows,cols,tsteps] array over space, per time step, skipping NA.  fun: 0 mean, 1 sum,
+ * 2 max, 3 min (max / min of an all-NA step: -Inf / +Inf, mean: NaN).  `count` (optional, [tsteps])
+ * receives the number of non-NA cells so that row blocks of a tiled raster can be combined: sum and
+ * count add, max / min combine by max / min (microclimf_amd/distributed.py). */
+enum { MCF_APPLY_MEAN = 0, MCF_APPLY_SUM = 1, MCF_APPLY_MAX = 2, MCF_APPLY_MIN = 3 };
+int mcf_applycpp3(const double *a, int64_t rows, int64_t cols, int64_t tsteps, int32_t fun, double *result,
+                  double *count, int32_t device);
+
 /* Diagnostics: evaluate one of the solver's lean device elementary functions
  * elementwise on host arrays (kind 0 exp, 1 log, 2 x/y, 3 sqrt, 4 1/x, 5 satvap
  * (cpp:480-490), 6 x^y); used by tests to bound their error against libm. */

@@ -142,7 +142,7 @@ EXPORTS = (
     "mcf_plan_kernel_stats", "mcf_plan_valid_cells", "mcf_plan_bytes", "mcf_selftest_math",
     "mcf_precompute_terrain", "mcf_runbioclim1", "mcf_runbioclim2",
     "mcf_snowenv_from_name", "mcf_gridmodelsnow1", "mcf_gridmodelsnow2", "mcf_gridmicrosnow1",
-    "mcf_gridmicrosnow2", "mcf_snowmodel1",
+    "mcf_gridmicrosnow2", "mcf_snowmodel1", "mcf_applycpp3",
 )
 
 _lib = None
@@ -218,6 +218,9 @@ def load() -> C.CDLL:
     for fn in (lib.mcf_gridmicrosnow1, lib.mcf_gridmicrosnow2):
         fn.restype = C.c_int
         fn.argtypes = [SI, C.POINTER(Snowm), C.c_double, C.c_double, C.POINTER(C.c_int32 * NOUT), OU, C.c_int32]
+    lib.mcf_applycpp3.restype = C.c_int
+    lib.mcf_applycpp3.argtypes = [c_double_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, c_double_p, c_double_p,
+                                  C.c_int32]
     lib.mcf_snowmodel1.restype = C.c_int
     lib.mcf_snowmodel1.argtypes = [C.POINTER(SnowDriverIn), C.POINTER(SnowDriverOut), C.c_int32]
     lib.mcf_precompute_terrain.restype = C.c_int

@@ -499,6 +499,43 @@ __global__ __launch_bounds__(256) void k_snow_redistribute(RedistArgs a) {
     if (!isnan(a.ageg[c])) a.isnowag[c] = (int32_t)a.ageg[c];
 }
 
+// applycpp3 (cpp:5553-5588): one workgroup per time step, lanes stride over the cells (coalesced),
+// fixed-shape tree in LDS -> deterministic; NaN cells are skipped
+__global__ __launch_bounds__(256) void k_apply3(const double* __restrict__ a, int64_t N, int fun,
+                                                double* __restrict__ result, double* __restrict__ count) {
+    __shared__ double sv[256];
+    __shared__ double sn[256];
+    const int64_t k = blockIdx.x;
+    const double* x = a + k * N;
+    double v = fun == 2 ? -INFINITY : (fun == 3 ? INFINITY : 0.0), n = 0.0;
+    for (int64_t i = threadIdx.x; i < N; i += 256) {
+        const double q = x[i];
+        if (isnan(q)) continue;
+        n += 1.0;
+        if (fun < 2) v += q;
+        else if (fun == 2) { if (q > v) v = q; }
+        else { if (q < v) v = q; }
+    }
+    sv[threadIdx.x] = v; sn[threadIdx.x] = n;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            const double o = sv[threadIdx.x + w];
+            if (fun < 2) sv[threadIdx.x] += o;
+            else if (fun == 2) { if (o > sv[threadIdx.x]) sv[threadIdx.x] = o; }
+            else { if (o < sv[threadIdx.x]) sv[threadIdx.x] = o; }
+            sn[threadIdx.x] += sn[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double r = sv[0];
+        if (fun == 0) r = sn[0] > 0 ? r / sn[0] : NAN;
+        result[k] = r;
+        if (count) count[k] = sn[0];
+    }
+}
+
 // ---- host side -------------------------------------------------------------------------------------
 #define S_TRY(expr)                                                                          \
     do {                                                                                     \
@@ -941,6 +978,27 @@ int run_snowdriver(const mcf_snowdriver_in* din, mcf_snowdriver_out* out, int32_
 
 extern "C" int mcf_snowmodel1(const mcf_snowdriver_in* in, mcf_snowdriver_out* out, int32_t device) {
     return run_snowdriver(in, out, device);
+}
+
+extern "C" int mcf_applycpp3(const double* a, int64_t rows, int64_t cols, int64_t tsteps, int32_t fun, double* result,
+                             double* count, int32_t device) {
+    if (!a || !result || rows <= 0 || cols <= 0 || tsteps <= 0 || tsteps > (1 << 30) || fun < 0 || fun > 3)
+        return mcf::api_fail(MCF_ERR_ARG, "bad applycpp3 argument");
+    int rc;
+    if ((rc = pick_device(device))) return rc;
+    const int64_t N = rows * cols;
+    if ((rc = check_room(N * tsteps * 8))) return rc;
+    Bufs b;
+    const double* d_a;
+    double *d_r, *d_c = nullptr;
+    UP(d_a, a, N * tsteps);
+    if ((rc = b.alloc((void**)&d_r, tsteps * 8))) return rc;
+    if (count && (rc = b.alloc((void**)&d_c, tsteps * 8))) return rc;
+    hipLaunchKernelGGL(k_apply3, dim3((unsigned)tsteps), dim3(256), 0, nullptr, d_a, N, (int)fun, d_r, d_c);
+    S_TRY(hipGetLastError());
+    S_TRY(hipMemcpy(result, d_r, (size_t)tsteps * 8, hipMemcpyDeviceToHost));
+    if (count) S_TRY(hipMemcpy(count, d_c, (size_t)tsteps * 8, hipMemcpyDeviceToHost));
+    return MCF_OK;
 }
 
 extern "C" int32_t mcf_snowenv_from_name(const char* name) {

@@ -55,3 +55,37 @@ def allreduce_sum(value: float, device=None) -> float:
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def allreduce_apply3(local, local_count, fun_name: str, device=None):
+    """Raster-wide applycpp3 (src/microclimfCpp.cpp:5553-5588) from per-rank row-block partials:
+    `local` is the rank's result of applycpp3(block, "sum" | "max" | "min") and `local_count` its
+    non-NA counts; "mean" is formed from the all-reduced sum and count (pass the local SUM).  One
+    all-reduce of a [tsteps] (or [2, tsteps]) fp64 tensor."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    local = np.asarray(local, dtype=np.float64)
+    cnt = np.asarray(local_count, dtype=np.float64)
+    active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if fun_name in ("mean", "sum"):
+        t = np.stack([local, cnt])
+        if active:
+            if device is None:
+                device = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            tt = torch.from_numpy(t).to(device)
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            t = tt.cpu().numpy()
+        if fun_name == "sum":
+            return t[0]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return np.where(t[1] > 0, t[0] / t[1], np.nan)
+    if fun_name not in ("max", "min"):
+        raise ValueError("Unknown function name")
+    if not active:
+        return local
+    if device is None:
+        device = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    tt = torch.from_numpy(local.copy()).to(device)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX if fun_name == "max" else dist.ReduceOp.MIN)
+    return tt.cpu().numpy()

@@ -220,3 +220,65 @@ def snowmodel1_chunks(obstime, climdata, pointm, vegp, other, snowenv, dtm, res,
         setattr(out, f, a.ctypes.data_as(_abi.c_double_p))
     _abi.check(lib.mcf_snowmodel1(C.byref(din), C.byref(out), device))
     return arrays
+
+
+APPLY_FUNS = {"mean": 0, "sum": 1, "max": 2, "min": 3}
+
+
+def applycpp3(a, fun_name: str, *, device: int = 0, with_count: bool = False):
+    """Reduction over space per time step, NA skipped: drop-in for the reference's applycpp3
+    (src/microclimfCpp.cpp:5553-5588).  `with_count=True` also returns the non-NA cell counts
+    (what a row-block rank contributes to a raster-wide mean, see distributed.allreduce_apply3)."""
+    if fun_name not in APPLY_FUNS:
+        raise ValueError("Unknown function name")           # the reference's stop() message
+    lib = _abi.load()
+    arr = np.asfortranarray(np.asarray(a, dtype=np.float64))
+    if arr.ndim != 3:
+        raise ValueError("applycpp3 needs a [rows, cols, tsteps] array")
+    R, Cc, T = arr.shape
+    res = np.empty(T)
+    cnt = np.empty(T) if with_count else None
+    _abi.check(lib.mcf_applycpp3(arr.ctypes.data_as(_abi.c_double_p), R, Cc, T, APPLY_FUNS[fun_name],
+                                 res.ctypes.data_as(_abi.c_double_p),
+                                 cnt.ctypes.data_as(_abi.c_double_p) if with_count else None, device))
+    return (res, cnt) if with_count else res
+
+
+def snowdaysfun(maxsnowdepth, minsnowdepth) -> dict:
+    """Host-side mirror of the reference's snowdaysfun (src/microclimfCpp.cpp:5531-5550): a day is a
+    snow day if any hour has snow somewhere (max > 0) and a no-snow day if any hour has a snow-free
+    cell (min == 0); a day can be both."""
+    mx = np.asarray(maxsnowdepth, dtype=np.float64)
+    mn = np.asarray(minsnowdepth, dtype=np.float64)
+    days = mx.size // 24
+    with np.errstate(invalid="ignore"):
+        snow = (mx[:days * 24].reshape(days, 24) > 0.0).any(axis=1)
+        nosnow = (mn[:days * 24].reshape(days, 24) == 0.0).any(axis=1)
+    return {"snowdays": snow.astype(np.int32), "nosnowdays": nosnow.astype(np.int32)}
+
+
+def merge_snow_outputs(moutn: Mapping, mouts: Mapping, snowdays, nosnowdays, rows: int, cols: int) -> dict:
+    """Step (5) of `.runmicrosnow1/2` (R/internal.R:3633-3656): days with snow anywhere take the snow
+    microclimate (`mouts`, which already carries the no-snow solver's values on its snow-free cell-steps),
+    the other days the no-snow solver's output (`moutn`).  `snowdays` / `nosnowdays` are 1-based day
+    numbers as in R; `moutn` covers `nosnowdays` in order, `mouts` covers `snowdays` in order."""
+    snowdays = np.asarray(snowdays, dtype=np.int64)
+    nosnowdays = np.asarray(nosnowdays, dtype=np.int64)
+    if nosnowdays.size == 0:
+        return dict(mouts)
+    if snowdays.size == 0:
+        return dict(moutn)
+    tdays = np.unique(np.concatenate([snowdays, nosnowdays]))
+    nosnow = np.setdiff1d(tdays, snowdays)
+    s1 = np.repeat(np.isin(nosnowdays, nosnow), 24)
+    hours = np.arange(24)
+    nosnowh = (np.repeat((nosnow - 1) * 24, 24) + np.tile(hours, nosnow.size)).astype(np.int64)
+    snowh = (np.repeat((snowdays - 1) * 24, 24) + np.tile(hours, snowdays.size)).astype(np.int64)
+    n = nosnowh.size + snowh.size
+    out = {}
+    for k, v in moutn.items():
+        a = np.full((rows, cols, n), np.nan, order="F")
+        a[:, :, nosnowh] = np.asarray(v)[:, :, s1]
+        a[:, :, snowh] = np.asarray(mouts[k])
+        out[k] = a
+    return out

@@ -388,6 +388,80 @@ SEXP mcfhip_gridmicrosnow2(SEXP reqhgt, SEXP obstime, SEXP climdata, SEXP snowm,
     return run_microsnow(1, reqhgt, obstime, climdata, snowm, micro, vegp, other, mat, out);
 }
 
+/* _microclimf_applycpp3 (src/microclimfCpp.cpp:5553-5588): (a [rows,cols,tsteps], fun_name) -> numeric(tsteps) */
+SEXP mcfhip_applycpp3(SEXP a, SEXP fun_name) {
+    int np = 0;
+    SEXP dim = getAttrib(a, R_DimSymbol);
+    if (TYPEOF(dim) != INTSXP || LENGTH(dim) != 3) Rf_error("mcfhip: applycpp3 needs a 3-D array");
+    const char *fn = CHAR(asChar(fun_name));
+    int fun = !strcmp(fn, "mean") ? MCF_APPLY_MEAN : !strcmp(fn, "sum") ? MCF_APPLY_SUM
+            : !strcmp(fn, "max") ? MCF_APPLY_MAX : !strcmp(fn, "min") ? MCF_APPLY_MIN : -1;
+    if (fun < 0) Rf_error("Unknown function name");
+    const double *pa = dbl(a, &np);
+    SEXP ans = PROTECT(allocVector(REALSXP, INTEGER(dim)[2])); ++np;
+    int rc = mcf_applycpp3(pa, INTEGER(dim)[0], INTEGER(dim)[1], INTEGER(dim)[2], fun, REAL(ans), NULL, 0);
+    if (rc != MCF_OK) raise_last(rc, np);
+    UNPROTECT(np);
+    return ans;
+}
+/* the `for (day in 1:n5days)` loop of .snowmodel1 (R/internal.R:2563-2617) in one call */
+SEXP mcfhip_snowmodel1(SEXP obstime, SEXP weather, SEXP pointm, SEXP vegp, SEXP other, SEXP snowenv, SEXP dtm,
+                       SEXP res, SEXP tfact) {
+    int np = 0;
+    mcf_snowdriver_in din;
+    memset(&din, 0, sizeof din);
+    mcf_snow_inputs *in = &din.base;
+    /* fill_snow() wants the terrain members the loop recomputes: take what the driver needs by hand */
+    SEXP dim = getAttrib(elt(vegp, "pai", NULL), R_DimSymbol);
+    if (TYPEOF(dim) != INTSXP || LENGTH(dim) != 2) Rf_error("mcfhip: vegp$pai must be a matrix");
+    in->rows = INTEGER(dim)[0]; in->cols = INTEGER(dim)[1];
+    in->tsteps = XLENGTH(elt(obstime, "year", NULL));
+    in->obstime.year = intcol(elt(obstime, "year", NULL), &np);
+    in->obstime.month = intcol(elt(obstime, "month", NULL), &np);
+    in->obstime.day = intcol(elt(obstime, "day", NULL), &np);
+    in->obstime.hour = dbl(elt(obstime, "hour", NULL), &np);
+    static const char *cn[9] = {"temp", "relhum", "pres", "swdown", "difrad", "lwdown", "windspeed", "winddir",
+                                "precip"};
+    const double **cp = (const double **)&in->clim;
+    for (int i = 0; i < 9; ++i) cp[i] = dbl(elt(weather, cn[i], NULL), &np);
+    static const char *pn[5] = {"Gp", "Tc", "RswabsG", "RlwabsG", "umu"};
+    const double **pp = (const double **)&in->pointm;
+    for (int i = 0; i < 5; ++i) pp[i] = dbl(elt(pointm, pn[i], NULL), &np);
+    static const char *vn[4] = {"pai", "hgt", "leaft", "clump"};
+    const double **vp = (const double **)&in->vegp;
+    for (int i = 0; i < 4; ++i) vp[i] = dbl(elt(vegp, vn[i], NULL), &np);
+    in->other.lat = asReal(elt(other, "lat", NULL));
+    in->other.lon = asReal(elt(other, "lon", NULL));
+    in->other.zref = asReal(elt(other, "zref", NULL));
+    in->other.isnowdc = dbl(elt(other, "isnowdc", NULL), &np);
+    in->other.isnowdg = dbl(elt(other, "isnowdg", NULL), &np);
+    in->other.isnowac = intcol(elt(other, "isnowac", NULL), &np);
+    in->other.isnowag = intcol(elt(other, "isnowag", NULL), &np);
+    in->snowenv = mcf_snowenv_from_name(CHAR(asChar(snowenv)));
+    din.dtm = dbl(dtm, &np);
+    din.res = asReal(res);
+    din.tfact = asReal(tfact);
+    static const char *on[5] = {"Tc", "Tg", "groundsnowdepth", "totalSWE", "snowden"};
+    mcf_snowdriver_out res5;
+    double **rp = (double **)&res5;
+    SEXP ans = PROTECT(allocVector(VECSXP, 5)); ++np;
+    SEXP nms = PROTECT(allocVector(STRSXP, 5)); ++np;
+    for (int v = 0; v < 5; ++v) {
+        SEXP a = PROTECT(allocVector(REALSXP, (R_xlen_t)in->rows * in->cols * in->tsteps)); ++np;
+        SEXP d = PROTECT(allocVector(INTSXP, 3)); ++np;
+        INTEGER(d)[0] = (int)in->rows; INTEGER(d)[1] = (int)in->cols; INTEGER(d)[2] = (int)in->tsteps;
+        setAttrib(a, R_DimSymbol, d);
+        SET_VECTOR_ELT(ans, v, a);
+        SET_STRING_ELT(nms, v, mkChar(on[v]));
+        rp[v] = REAL(a);
+    }
+    setAttrib(ans, R_NamesSymbol, nms);
+    int rc = mcf_snowmodel1(&din, &res5, 0);
+    if (rc != MCF_OK) raise_last(rc, np);
+    UNPROTECT(np);
+    return ans;
+}
+
 static const R_CallMethodDef CallEntries[] = {
     {"mcfhip_runmicro1", (DL_FUNC)&mcfhip_runmicro1, 15},
     {"mcfhip_runmicro2", (DL_FUNC)&mcfhip_runmicro2, 15},
@@ -399,6 +473,8 @@ static const R_CallMethodDef CallEntries[] = {
     {"mcfhip_gridmodelsnow2", (DL_FUNC)&mcfhip_gridmodelsnow2, 6},
     {"mcfhip_gridmicrosnow1", (DL_FUNC)&mcfhip_gridmicrosnow1, 9},
     {"mcfhip_gridmicrosnow2", (DL_FUNC)&mcfhip_gridmicrosnow2, 9},
+    {"mcfhip_applycpp3", (DL_FUNC)&mcfhip_applycpp3, 2},
+    {"mcfhip_snowmodel1", (DL_FUNC)&mcfhip_snowmodel1, 9},
     {NULL, NULL, 0}};
 
 void R_init_mcfhip_glue(DllInfo *dll) {

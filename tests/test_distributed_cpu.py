@@ -15,7 +15,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from microclimf_amd import synthetic
-from microclimf_amd.distributed import allreduce_max, allreduce_twi_mean, row_block
+from microclimf_amd.distributed import allreduce_apply3, allreduce_max, allreduce_twi_mean, row_block
 
 ROWS, COLS, T = 13, 7, 48
 
@@ -90,3 +90,69 @@ def test_two_ranks_gloo_equal_single_process(oracle):
         assert tmax == 2.0
         for k, v in res.items():
             np.testing.assert_allclose(v, want[k][row0:row0 + rows], rtol=1e-12, atol=1e-12, err_msg=f"{k} rank {rank}")
+
+
+def _apply3_numpy(a, fun):
+    """applycpp3 (cpp:5553-5588) in numpy: NA-skipping reduction over space per time step."""
+    with np.errstate(invalid="ignore", all="ignore"):
+        flat = a.reshape(-1, a.shape[2], order="F")
+        ok = ~np.isnan(flat)
+        if fun == "sum":
+            return np.where(ok, flat, 0.0).sum(axis=0), ok.sum(axis=0).astype(float)
+        if fun == "max":
+            return np.where(ok, flat, -np.inf).max(axis=0), ok.sum(axis=0).astype(float)
+        return np.where(ok, flat, np.inf).min(axis=0), ok.sum(axis=0).astype(float)
+
+
+def _apply3_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        swe = _swe_field()
+        row0, rows = row_block(rank, world, swe.shape[0])
+        blk = swe[row0:row0 + rows]
+        out = {}
+        for fun in ("sum", "max", "min"):
+            loc, cnt = _apply3_numpy(blk, fun)            # stands in for mcf_applycpp3 on the rank's GPU
+            out[fun] = allreduce_apply3(loc, cnt, fun)
+        loc, cnt = _apply3_numpy(blk, "sum")
+        out["mean"] = allreduce_apply3(loc, cnt, "mean")
+        q.put((rank, out))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _swe_field():
+    rng = np.random.default_rng(5)
+    swe = np.asfortranarray(np.maximum(rng.normal(2.0, 3.0, (11, 6, 30)), 0.0))
+    swe[2, 3, :] = np.nan
+    swe[:, :, 7] = np.nan                 # an all-NA step: max -Inf, min +Inf, mean NaN
+    swe[:, :, 12] = 0.0
+    return swe
+
+
+def test_applycpp3_partials_combine_over_two_ranks():
+    """the snow branch's per-step min / max of totalSWE over space (R/internal.R:3592-3593) for a
+    row-tiled raster: per-rank partials + one all-reduce equal the single-process reduction"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_apply3_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    swe = _swe_field()
+    want = {f: _apply3_numpy(swe, f)[0] for f in ("sum", "max", "min")}
+    s, n = _apply3_numpy(swe, "sum")
+    with np.errstate(invalid="ignore", divide="ignore"):
+        want["mean"] = np.where(n > 0, s / n, np.nan)
+    for rank, out in got:
+        for f in want:
+            assert np.allclose(out[f], want[f], rtol=1e-13, equal_nan=True), (rank, f)
+    assert np.isneginf(want["max"][7]) and np.isposinf(want["min"][7]) and np.isnan(want["mean"][7])

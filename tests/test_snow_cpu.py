@@ -153,3 +153,24 @@ def test_tpicalc_oracle_properties():
     want = np.exp((np.nanmean(dtm) - dtm) * 0.02)
     want = want / np.nanmean(want)
     assert np.allclose(t2[ok], want[ok], rtol=1e-12)
+
+
+def test_snowdaysfun_and_merge():
+    """snowdaysfun (cpp:5531-5550) and the day merge of `.runmicrosnow1` (R/internal.R:3633-3656)"""
+    from microclimf_amd.snow import merge_snow_outputs, snowdaysfun
+    mx = np.zeros(96)
+    mn = np.zeros(96)
+    mx[24:72] = 1.0            # days 2 and 3 have snow somewhere
+    mn[48:72] = 0.5            # on day 3 every cell is snow-covered
+    sd = snowdaysfun(mx, mn)
+    assert list(sd["snowdays"]) == [0, 1, 1, 0] and list(sd["nosnowdays"]) == [1, 1, 0, 1]
+    snowdays = np.flatnonzero(sd["snowdays"]) + 1            # R's 1-based day numbers: 2, 3
+    nosnowdays = np.flatnonzero(sd["nosnowdays"]) + 1        # 1, 2, 4
+    R, Cc = 2, 3
+    moutn = {"Tz": np.asfortranarray(np.arange(R * Cc * 72, dtype=float).reshape((R, Cc, 72), order="F"))}
+    mouts = {"Tz": np.asfortranarray(-1.0 - np.arange(R * Cc * 48, dtype=float).reshape((R, Cc, 48), order="F"))}
+    m = merge_snow_outputs(moutn, mouts, snowdays, nosnowdays, R, Cc)["Tz"]
+    assert m.shape == (R, Cc, 96)
+    assert np.array_equal(m[:, :, 0:24], moutn["Tz"][:, :, 0:24])       # day 1: no-snow model
+    assert np.array_equal(m[:, :, 24:72], mouts["Tz"])                  # days 2-3: snow model (day 2's no-snow run dropped)
+    assert np.array_equal(m[:, :, 72:96], moutn["Tz"][:, :, 48:72])     # day 4: third no-snow day

@@ -144,6 +144,28 @@ def test_snowmodel1_rejects_zero_aggregation_factor():
                           500.0, chunk_steps=48)
 
 
+@pytest.mark.parametrize("fun", ["mean", "sum", "max", "min"])
+def test_applycpp3_matches_numpy(fun):
+    from microclimf_amd.snow import applycpp3
+    rng = np.random.default_rng(11)
+    a = np.asfortranarray(np.maximum(rng.normal(1.0, 2.0, (37, 29, 50)), 0.0))
+    a[rng.random(a.shape) < 0.05] = np.nan
+    a[:, :, 9] = np.nan
+    a[:, :, 20] = 0.0
+    got, cnt = applycpp3(a, fun, with_count=True)
+    flat = a.reshape(-1, 50, order="F")
+    ok = ~np.isnan(flat)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        want = {"sum": np.where(ok, flat, 0).sum(0), "mean": np.where(ok, flat, 0).sum(0) / ok.sum(0),
+                "max": np.where(ok, flat, -np.inf).max(0), "min": np.where(ok, flat, np.inf).min(0)}[fun]
+    assert np.array_equal(cnt, ok.sum(0))
+    if fun in ("max", "min"):
+        assert np.array_equal(got, want)                  # exact: selections only
+    else:
+        assert np.allclose(got, want, rtol=1e-13, equal_nan=True)
+    assert (np.isnan(got[9]) if fun == "mean" else True)
+
+
 def test_snow_entry_points_reject_bad_arguments():
     lib = _abi.load()
     sw, _ = build_snow("prairie_short")

@@ -25,8 +25,11 @@ def main():
     ap.add_argument("--array-forcing", action="store_true")
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--reqhgt", type=float, default=0.05)
+    ap.add_argument("--driver", action="store_true", help="time mcf_snowmodel1 (the 5-day chunk loop) instead")
     a = ap.parse_args()
     af = a.array_forcing
+    if a.driver:
+        return driver(a)
     sw = synthetic.snow_workload(a.rows, a.cols, a.tsteps, array_forcing=af, cold=3.0, zref=3.5)
     fn = gridmodelsnow2 if af else gridmodelsnow1
     args = (sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"], sw["other"], sw["snowenv"])
@@ -69,6 +72,29 @@ def main():
             print(f"  micro {k}: max scaled error {e:.3e}")
             worst = max(worst, e)
         print(f"worst scaled error {worst:.3e}")
+
+
+def driver(a):
+    from microclimf_amd.snow import snowmodel1_chunks
+    sw = synthetic.snow_workload(a.rows, a.cols, a.tsteps, cold=3.0, zref=3.5)
+    _, _, dtm = synthetic.rasters(a.rows, a.cols)
+    dtm = np.where(np.isnan(sw["vegp"]["hgt"]), np.nan, dtm)
+    args = (sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"], sw["other"], sw["snowenv"], dtm, 1.0, 0.02)
+    snowmodel1_chunks(*args)
+    t = time.time()
+    r = snowmodel1_chunks(*args)
+    dt = time.time() - t
+    n = a.rows * a.cols * a.tsteps
+    print(f"snowmodel1 chunk loop: {a.rows}x{a.cols}x{a.tsteps} end-to-end {dt:.3f} s = {n / dt:.3e} cell-steps/s")
+    if a.check:
+        from oracle import snowdriver_oracle as SD
+        t = time.time()
+        w = SD.snowmodel1_chunks(*args)
+        print(f"oracle chunk loop: {time.time() - t:.3f} s (numpy terrain + C snow model, 1 core)")
+        for k in w:
+            assert np.array_equal(np.isnan(r[k]), np.isnan(w[k])), k
+            f = np.isfinite(w[k])
+            print(f"  {k}: max scaled error {float(np.max(np.abs(r[k][f] - w[k][f]) / (1 + np.abs(w[k][f])))):.3e}")
 
 
 if __name__ == "__main__":
