@@ -197,6 +197,14 @@ int mcf_plan_sync(mcf_plan *plan);
  * step `step0` within the slot) to host memory. */
 int mcf_plan_fetch(mcf_plan *plan, int32_t slot, int32_t var, int64_t step0,
                    int64_t nsteps, double *host_dst);
+/* The same, packed as `writetonc` stores it (R/dataprep.R:1064-1069 `atonc`, :1158-1167): int32
+ * round-half-even(value * scale), transposed per step to [cols, rows] (east fastest), NA ->
+ * NA_integer_ (INT32_MIN; ncvar_put writes the variable's missval -9999 for it).  writetonc's scales:
+ * 100 for Tz, tleaf, soilm, windspeed; 1 for relhum and the radiation terms.  Halves the bytes that
+ * cross PCIe and arrives in the file's layout.  `kernel_ms` (optional) receives the device time of the
+ * pack kernel. */
+int mcf_plan_fetch_packed(mcf_plan *plan, int32_t slot, int32_t var, int64_t step0, int64_t nsteps,
+                          double scale, int32_t *host_dst, float *kernel_ms);
 /* Device address of a ring slot variable (for device-side consumers). */
 int mcf_plan_slot_ptr(mcf_plan *plan, int32_t slot, int32_t var, void **dev_ptr);
 

@@ -192,6 +192,24 @@ class Plan:
                                             a.ctypes.data_as(_abi.c_double_p)))
         return a
 
+    # writetonc's scale per variable (R/dataprep.R:1158-1167): x100 for temperatures, soil moisture, wind
+    NC_SCALE = {"Tz": 100.0, "tleaf": 100.0, "relhum": 1.0, "soilm": 100.0, "windspeed": 100.0, "Rdirdown": 1.0,
+                "Rdifdown": 1.0, "Rlwdown": 1.0, "Rswup": 1.0, "Rlwup": 1.0}
+
+    def fetch_packed(self, slot: int, var, step0: int, nsteps: int, scale: float | None = None,
+                     timing: bool = False):
+        """`writetonc`-packed fetch: int32 [cols, rows, nsteps] (east fastest) = round(value * scale),
+        NA -> INT32_MIN (R's NA_integer_).  Returns the array (and the pack kernel's ms with timing)."""
+        v = _abi.OUT_NAMES.index(var) if isinstance(var, str) else int(var)
+        if scale is None:
+            scale = self.NC_SCALE[_abi.OUT_NAMES[v]]
+        a = np.empty((self.cols, self.rows, nsteps), dtype=np.int32, order="F")
+        ms = C.c_float()
+        _abi.check(self._lib.mcf_plan_fetch_packed(self._p, slot, v, step0, nsteps, float(scale),
+                                                   a.ctypes.data_as(_abi.c_int32_p),
+                                                   C.byref(ms) if timing else None))
+        return (a, ms.value) if timing else a
+
     def timer_start(self):
         _abi.check(self._lib.mcf_plan_timer_start(self._p))
 

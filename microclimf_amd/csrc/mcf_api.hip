@@ -98,6 +98,9 @@ struct mcf_plan {
     double ktotal_ms = 0;
     int64_t klaunches = 0;
     int64_t valid_cells = 0;
+    // packed sink staging
+    int32_t* d_pack = nullptr;
+    int64_t pack_elems = 0;
 };
 
 namespace {
@@ -552,6 +555,33 @@ int mcf_plan_fetch(mcf_plan* p, int32_t slot, int32_t var, int64_t step0, int64_
     const double* src = p->d_ring + ((int64_t)slot * p->nvars + p->var_slot[var]) * (p->N * cap_steps) + p->N * step0;
     HIP_TRY(hipMemcpyAsync(host_dst, src, (size_t)(p->N * nsteps) * 8, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
+    return MCF_OK;
+}
+
+int mcf_plan_fetch_packed(mcf_plan* p, int32_t slot, int32_t var, int64_t step0, int64_t nsteps, double scale,
+                          int32_t* host_dst, float* kernel_ms) {
+    if (!p || !host_dst) return fail(MCF_ERR_ARG, "null argument");
+    if (slot < 0 || slot >= p->ring_slots || var < 0 || var >= MCF_NOUT) return fail(MCF_ERR_ARG, "bad slot/var");
+    if (p->var_slot[var] < 0) return fail(MCF_ERR_ARG, "variable was not requested in out[]");
+    const int64_t cap_steps = (int64_t)p->ring_days * 24;
+    if (step0 < 0 || nsteps < 0 || step0 + nsteps > cap_steps) return fail(MCF_ERR_ARG, "step range out of slot");
+    if (nsteps > 65535) return fail(MCF_ERR_ARG, "at most 65535 steps per packed fetch");
+    HIP_TRY(hipSetDevice(p->device));
+    if (p->pack_elems < p->N * nsteps) {
+        int rc;
+        void* q;
+        if ((rc = dalloc(p, &q, p->N * nsteps * 4))) return rc;     // earlier (smaller) buffers are released with the plan
+        p->d_pack = (int32_t*)q;
+        p->pack_elems = p->N * nsteps;
+    }
+    const double* src = p->d_ring + ((int64_t)slot * p->nvars + p->var_slot[var]) * (p->N * cap_steps) + p->N * step0;
+    if (kernel_ms) HIP_TRY(hipEventRecord(p->ev0, p->stream));
+    mcf::launch_pack_transpose(src, p->rows, p->cols, nsteps, scale, p->d_pack, p->stream);
+    HIP_TRY(hipGetLastError());
+    if (kernel_ms) HIP_TRY(hipEventRecord(p->ev1, p->stream));
+    HIP_TRY(hipMemcpyAsync(host_dst, p->d_pack, (size_t)(p->N * nsteps) * 4, hipMemcpyDeviceToHost, p->stream));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, p->ev0, p->ev1));
     return MCF_OK;
 }
 

@@ -792,8 +792,47 @@ void launch_selftest_math(int kind, const double* x, const double* y, double* ou
 }
 
 // ------------------------------------------------------------------------------------
+// writetonc's array conversion `atonc` (R/dataprep.R:1064-1069) as an on-device sink: per time step
+// transpose [rows, cols] -> [cols, rows] (aperm(a, c(2,1,3)): east becomes the fastest index),
+// round(a * rd) half-to-even, as.integer (NA -> NA_integer_ = INT_MIN, which ncvar_put writes as the
+// file's missval).  32 x 32 tiles through LDS so that both the fp64 loads (along rows) and the int32
+// stores (along cols) are coalesced; 12 B of HBM traffic per element.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_transpose(const double* __restrict__ src, int64_t rows, int64_t cols,
+                                                        double scale, int32_t* __restrict__ dst) {
+    __shared__ int32_t tile[32][33];
+    const int64_t N = rows * cols;
+    const double* in = src + (int64_t)blockIdx.z * N;
+    int32_t* out = dst + (int64_t)blockIdx.z * N;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int64_t r0 = (int64_t)blockIdx.x * 32, c0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t r = r0 + tx, c = c0 + j;
+        int32_t v = INT32_MIN;
+        if (r < rows && c < cols) {
+            const double x = rint(in[r + rows * c] * scale);
+            if (x > -2147483648.0 && x < 2147483648.0) v = (int32_t)x;   // NaN and out-of-range -> NA_integer_
+        }
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t c = c0 + tx, r = r0 + j;
+        if (r < rows && c < cols) out[c + cols * r] = tile[tx][j];
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------
+void launch_pack_transpose(const double* src, int64_t rows, int64_t cols, int64_t nsteps, double scale, int32_t* dst,
+                           hipStream_t s) {
+    if (nsteps <= 0) return;
+    dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32), (unsigned)nsteps);
+    hipLaunchKernelGGL(k_pack_transpose, grid, dim3(256), 0, s, src, rows, cols, scale, dst);
+}
 void launch_fill(double* p, int64_t n, double v, hipStream_t s) {
     if (n <= 0) return;
     int64_t blocks = (n + 255) / 256;

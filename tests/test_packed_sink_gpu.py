@@ -1,0 +1,56 @@
+"""The writetonc-packed output sink: mcf_plan_fetch_packed against a numpy
+restatement of `atonc` (R/dataprep.R:1064-1069): aperm(a, c(2,1,3)); round(a * rd, 0) (half to even);
+as.integer (NA -> NA_integer_).  Integer output: the comparison is bit-exact."""
+import numpy as np
+import pytest
+
+from microclimf_amd import synthetic
+from microclimf_amd.api import Plan
+
+pytestmark = pytest.mark.gpu
+NA_INT = np.iinfo(np.int32).min
+
+
+def atonc(a, rd):
+    with np.errstate(invalid="ignore"):
+        x = np.rint(np.transpose(a, (1, 0, 2)) * rd)          # numpy rint = round half to even, as R's round(x, 0)
+    out = np.full(x.shape, NA_INT, dtype=np.int32)
+    ok = np.isfinite(x) & (np.abs(x) < 2147483648.0)
+    out[ok] = x[ok].astype(np.int32)
+    return np.asfortranarray(out)
+
+
+@pytest.mark.parametrize("rows,cols", [(37, 29), (64, 32), (5, 70)])
+def test_packed_fetch_is_atonc_of_plain_fetch(rows, cols):
+    a = synthetic.workload(rows, cols, 72, reqhgt=0.05, variety=True, start_doy=120, na_frac=0.05)
+    with Plan(a["obstime"], a["climdata"], a["pointm"], a["vegp"], a["soilc"], a["reqhgt"], a["zref"], a["lat"],
+              a["lon"], a["Sminp"], a["Smaxp"], a["tfact"], True, a["mat"], a["out"], ring_days=3) as p:
+        p.run_days(0, 3)
+        p.sync()
+        for var in ("Tz", "tleaf", "relhum", "soilm", "windspeed", "Rdirdown", "Rlwup"):
+            plain = p.fetch(0, var, 0, 72)
+            packed = p.fetch_packed(0, var, 0, 72)
+            assert packed.dtype == np.int32 and packed.shape == (cols, rows, 72)
+            want = atonc(plain, Plan.NC_SCALE[var])
+            assert np.array_equal(packed, want), var
+            assert (packed[np.isnan(np.transpose(plain, (1, 0, 2)))] == NA_INT).all()
+        # a sub-range of steps and an explicit scale
+        part = p.fetch_packed(0, "Tz", 24, 30, scale=10.0)
+        assert np.array_equal(part, atonc(p.fetch(0, "Tz", 24, 30), 10.0))
+
+
+def test_packed_fetch_round_half_even_and_range():
+    """ties round to even (R >= 4.0 round()), values beyond int32 become NA like as.integer()"""
+    a = synthetic.workload(8, 8, 24, reqhgt=0.05, na_frac=0.0)
+    with Plan(a["obstime"], a["climdata"], a["pointm"], a["vegp"], a["soilc"], a["reqhgt"], a["zref"], a["lat"],
+              a["lon"], a["Sminp"], a["Smaxp"], a["tfact"], True, a["mat"], a["out"], ring_days=1) as p:
+        p.run_days(0, 1)
+        p.sync()
+        plain = p.fetch(0, "Rlwdown", 0, 24)
+        huge = p.fetch_packed(0, "Rlwdown", 0, 24, scale=1e8)          # ~3e10 > 2^31
+        assert (huge == NA_INT).all()
+        # scale chosen so that value * scale lands exactly on .5 for one element
+        v = plain[3, 4, 7]
+        s = 2.5 / v
+        got = p.fetch_packed(0, "Rlwdown", 0, 24, scale=s)[4, 3, 7]
+        assert got == int(np.rint(v * s))
