@@ -23,6 +23,10 @@
 
 #include "mcf_kernels.h"
 
+#ifndef MCF_FDIV_NR2
+#define MCF_FDIV_NR2 0   // 1: second Newton step on the reciprocal inside fdiv (not needed, see fdiv)
+#endif
+
 namespace mcf {
 
 constexpr double kPi = 3.14159265358979323846;     // cpp:14
@@ -120,7 +124,13 @@ __device__ __forceinline__ double frcp(double b) {           // 1/b, b finite no
     return r;
 }
 __device__ __forceinline__ double fdiv(double a, double b) {  // a/b, b finite normal non-zero
-    double r = frcp(b);
+    // v_rcp_f64 delivers ~23 bits; ONE Newton step (46 bits, relative error e) is enough here because the
+    // quotient correction below is itself a Newton step on q: q' = (a/b)(1 - e^2)
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+#if MCF_FDIV_NR2
+    r = fma(fma(-b, r, 1.0), r, r);
+#endif
     double q = a * r;
     return fma(fma(-b, q, a), r, q);
 }
