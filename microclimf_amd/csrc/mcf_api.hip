@@ -17,6 +17,7 @@
 
 #include "../../include/mcf.h"
 #include "mcf_kernels.h"
+#include "mcf_hostpipe.hpp"
 
 namespace {
 
@@ -101,6 +102,10 @@ struct mcf_plan {
     // packed sink staging
     int32_t* d_pack = nullptr;
     int64_t pack_elems = 0;
+    // device -> pageable host copies of large results (mcf_hostpipe.hpp)
+    mcf::HostPipe* pipe = nullptr;
+    hipEvent_t ev_pipe = nullptr;
+    bool pipe_failed = false;
 };
 
 namespace {
@@ -217,6 +222,8 @@ void mcf_plan_destroy(mcf_plan* p) {
     if (p->stream) hipStreamSynchronize(p->stream);
     for (auto& e : p->kev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (void* a : p->allocs) hipFree(a);
+    delete p->pipe;
+    if (p->ev_pipe) hipEventDestroy(p->ev_pipe);
     if (p->ev0) hipEventDestroy(p->ev0);
     if (p->ev1) hipEventDestroy(p->ev1);
     if (p->stream) hipStreamDestroy(p->stream);
@@ -553,7 +560,25 @@ int mcf_plan_fetch(mcf_plan* p, int32_t slot, int32_t var, int64_t step0, int64_
     if (step0 < 0 || nsteps < 0 || step0 + nsteps > cap_steps) return fail(MCF_ERR_ARG, "step range out of slot");
     HIP_TRY(hipSetDevice(p->device));
     const double* src = p->d_ring + ((int64_t)slot * p->nvars + p->var_slot[var]) * (p->N * cap_steps) + p->N * step0;
-    HIP_TRY(hipMemcpyAsync(host_dst, src, (size_t)(p->N * nsteps) * 8, hipMemcpyDeviceToHost, p->stream));
+    const size_t bytes = (size_t)(p->N * nsteps) * 8;
+    // large results: pinned ring + host copy threads instead of hipMemcpy's single-threaded staging
+    static const bool no_pipe = getenv("MCF_NO_HOSTPIPE") != nullptr;
+    if (bytes >= ((size_t)64 << 20) && !no_pipe && !p->pipe_failed) {
+        if (!p->pipe) {
+            p->pipe = new mcf::HostPipe();
+            if (!p->pipe->init() || hipEventCreateWithFlags(&p->ev_pipe, hipEventDisableTiming) != hipSuccess) {
+                delete p->pipe;
+                p->pipe = nullptr;
+                p->pipe_failed = true;
+            }
+        }
+        if (p->pipe) {
+            HIP_TRY(hipEventRecord(p->ev_pipe, p->stream));
+            HIP_TRY(p->pipe->copy(host_dst, src, bytes, p->ev_pipe));
+            return MCF_OK;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(host_dst, src, bytes, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     return MCF_OK;
 }
