@@ -3,8 +3,8 @@
 // The one-shot entry points hand results back into caller-owned pageable memory (R vectors, numpy
 // arrays).  hipMemcpy stages such copies through an internal pinned buffer with a single-threaded
 // CPU copy (measured 25 GB/s on the MI355X box), which bounds mcf_runmicro1..4 end to end: the solver
-// produces 10 GB of results in 8 ms and they take 0.41 s to come back (0.31 s through this pipe).  HostPipe keeps the DMA engine
-// busy instead: results stream into a ring of pinned pieces with hipMemcpyAsync on a dedicated copy
+// produces 10 GB of results in 8 ms and they take 0.41 s to come back (0.31 s through this pipe).
+// HostPipe keeps the DMA engine busy instead: results stream into a ring of pinned pieces with hipMemcpyAsync on a dedicated copy
 // stream while a small pool of host threads copies finished pieces into the destination (each thread
 // a contiguous slice, so first-touch page faults of a fresh destination are spread over the threads).
 #pragma once

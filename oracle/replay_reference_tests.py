@@ -44,6 +44,7 @@ class PointSnowOut(C.Structure):
         + [("mxdif", C.c_double), ("iters", C.c_int)]
 
 
+LAST_POINTSNOW = {}     # output of the last replay (frozen in tests/golden/pointmodelsnow_test.npz)
 SNOWENV = {"Alpine": 0, "Maritime": 1, "Prairie": 2, "Tundra": 3, "Taiga": 4}
 
 
@@ -288,6 +289,8 @@ def replay_pointmodelsnow_test():
     vegp = np.array([2, 0.5, 0.05, 0])          # pai, hgt, ltra, clump
     other = np.array([0, 180, 50, -5, 2, 0, 0])  # slope, aspect, lat, lon, zref, isnowd, isnowa
     pm = pointmodelsnow(obst, clim, vegp, other, "Taiga")
+    LAST_POINTSNOW.clear()
+    LAST_POINTSNOW.update({k: np.array(v) for k, v in pm.items()})
     Tc, Tg, sdepc, sdepg, sdenc, sdeng = (pm[k] for k in ("Tc", "Tg", "sdepc", "sdepg", "sdenc", "sdeng"))
     # :52-74 (R indices are 1-based: sdepc[n] is element n-1 here)
     nums = np.concatenate([Tc, Tg, sdepc, sdepg, sdenc, sdeng])

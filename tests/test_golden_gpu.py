@@ -24,3 +24,25 @@ def test_hip_reproduces_golden(name):
             continue
         err = np.abs(got[k][fin] - w[fin]) / (1 + np.abs(w[fin]))
         assert err.max() <= 1e-6, (k, err.max())     # acceptance bar is 1e-4
+
+
+from golden_util import SNOW_CASES, load_snow  # noqa: E402
+from microclimf_amd import synthetic  # noqa: E402
+from microclimf_amd.snow import gridmicrosnow1, gridmicrosnow2, gridmodelsnow1, gridmodelsnow2  # noqa: E402
+
+
+@pytest.mark.parametrize("name", SNOW_CASES)
+def test_hip_snow_reproduces_golden(name):
+    sw, af, reqhgt, mat, micro, smod, mout = load_snow(name)
+    got = (gridmodelsnow2 if af else gridmodelsnow1)(sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"],
+                                                     sw["other"], sw["snowenv"])
+    snowm, _ = synthetic.microsnow_inputs(sw, smod)
+    gm = (gridmicrosnow2 if af else gridmicrosnow1)(reqhgt, sw["obstime"], sw["climdata"], snowm, micro, sw["vegp"],
+                                                    sw["other"], mat, [1] * 10)
+    for res, want in ((got, smod), (gm, mout)):
+        for k, w in want.items():
+            assert np.array_equal(np.isnan(res[k]), np.isnan(w)), k
+            fin = np.isfinite(w)
+            if fin.any():
+                err = np.abs(res[k][fin] - w[fin]) / (1 + np.abs(w[fin]))
+                assert err.max() <= 1e-6, (k, err.max())
