@@ -20,6 +20,15 @@
 #ifndef MCF_HOUR_PERMUTE
 #define MCF_HOUR_PERMUTE 1
 #endif
+#ifndef MCF_LANES21
+#define MCF_LANES21 1
+#endif
+#ifndef MCF_REDUCE_MINMAX
+#define MCF_REDUCE_MINMAX 1
+#endif
+#ifndef MCF_OPAQUE_OUTSEL
+#define MCF_OPAQUE_OUTSEL 1
+#endif
 #ifndef MCF_XCD_REMAP
 #define MCF_XCD_REMAP 1
 #endif
@@ -356,7 +365,22 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? 3 : MCF_WAVES_PER_EU) void
     __shared__ double s_dd[BG ? 24 * CPB : 1];
 
     const int tid = threadIdx.x;
-    const int cl = tid % CPB;
+    int cl = tid % CPB;
+    bool lane_on = tid < CPB * 24;
+#if MCF_LANES21
+    // CPB = 21: with cell = t % 21 a 16-lane group (the unit in which ds_read_b64 resolves banks) straddles two
+    // hours in 15 of 21 cases and then holds cells {16..20, 0..10}: cells k and 16+k fall in the same bank pair
+    // (2-way conflicts on every per-cell table read; SQ_LDS_BANK_CONFLICT = 13 % of the kernel's cycles).  Each
+    // wave therefore takes 3 hours as three full groups (cells 0..15 of one hour each) plus one group holding
+    // cells 16..20 of the same three hours (15 lanes, one idle): 16 distinct consecutive addresses, or 5 distinct
+    // ones read by 3 lanes each — conflict-free — and the same 168-B row segment per hour in the stores.
+    int hr21 = 0;
+    if (CPB == 21) {
+        const int w = tid >> 6, l = tid & 63;
+        if (l < 48) { cl = l & 15; hr21 = 3 * w + (l >> 4); }
+        else { const int j = l - 48; cl = 16 + (j % 5); hr21 = 3 * w + (j / 5); lane_on = j < 15; if (!lane_on) { cl = 20; hr21 = 3 * w + 2; } }
+    }
+#endif
 #if MCF_HOUR_PERMUTE
     // Waves w, w+4, w+8 of a workgroup share a SIMD.  Daytime waves carry the short-wave block
     // (about twice the work of a night wave), so hour groups are dealt to waves so that every
@@ -377,6 +401,9 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? 3 : MCF_WAVES_PER_EU) void
     int hr = tid / CPB;
     if (hr > 23) hr = 23;
 #endif
+#if MCF_LANES21
+    if (CPB == 21) hr = hr21;
+#endif
     const int64_t N = a.N;
 #if MCF_XCD_REMAP
     // Workgroups are dealt round-robin to the 8 XCDs (b and b+8 share one, each XCD has its own
@@ -392,7 +419,7 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? 3 : MCF_WAVES_PER_EU) void
     const int64_t c0 = (int64_t)blockIdx.x * CPB;
 #endif
     const int64_t c = c0 + cl;
-    const bool in_grid = tid < CPB * 24 && c < N;   // lanes past CPB*24 only help staging and keep the barriers
+    const bool in_grid = lane_on && c < N;   // the other lanes only help staging and keep the barriers
 
     // ---- stage the tile's direction tables and the first day's time table in LDS
     for (int q = tid; q < kCellDirs * CPB; q += NT) {
@@ -440,8 +467,18 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? 3 : MCF_WAVES_PER_EU) void
         }
         const int64_t kl = (int64_t)dl * 24 + hr;            // step within the slot
         const int64_t oidx = c + N * (a.slot_step0 + kl);
+#if MCF_OPAQUE_OUTSEL
+        // Left alone, hipcc hoists a 64-bit "variable v is requested" mask and a 64-bit slab pointer per
+        // output variable out of the day loop: 40 SGPRs that do not fit and are spilled to VGPR lanes
+        // (v_readlane + hazard nops around every store).  Making the selector opaque once per day keeps two
+        // SGPRs live instead; slab index and address are re-derived by a handful of SALU ops per store.
+        uint64_t osel = a.out_sel;
+        asm volatile("" : "+s"(osel));
+#else
+        const uint64_t osel = a.out_sel;
+#endif
         auto put = [&](int v, double val) {
-            unsigned sel = (unsigned)(a.out_sel >> (4 * v)) & 15u;
+            unsigned sel = (unsigned)(osel >> (4 * v)) & 15u;
 #if MCF_EXPERIMENT_NOSTORE
             if (sel != 15u && val == 1.2345e300) a.out_base[(int64_t)sel * a.out_stride + oidx] = val;
 #else
@@ -524,9 +561,18 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? 3 : MCF_WAVES_PER_EU) void
 #pragma unroll
             for (int hh = 0; hh < 24; ++hh) {
                 double tg = rt[hh * CPB], rv = rr[hh * CPB];
+#if MCF_REDUCE_MINMAX
+                // `if (Rmx < rv) Rmx = rv` with a finite start value ignores a NaN rv, exactly what v_max_f64
+                // does (the accumulator is never NaN, rv is never a signalling NaN: it was just computed):
+                // one VALU instruction instead of a compare and two 32-bit selects, 72 x per cell-step
+                asm("v_max_f64 %0, %0, %1" : "+v"(Rmx) : "v"(rv));
+                asm("v_max_f64 %0, %0, %1" : "+v"(tmx) : "v"(tg));
+                asm("v_min_f64 %0, %0, %1" : "+v"(tmn) : "v"(tg));
+#else
                 if (Rmx < rv) Rmx = rv;
                 if (tmx < tg) tmx = tg;
                 if (tmn > tg) tmn = tg;
+#endif
             }
             const double dtr = tmx - tmn;
             Pass2Out p2{};
