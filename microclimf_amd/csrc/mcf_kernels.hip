@@ -20,6 +20,9 @@
 #ifndef MCF_HOUR_PERMUTE
 #define MCF_HOUR_PERMUTE 1
 #endif
+#ifndef MCF_WAVE_PREREDUCE
+#define MCF_WAVE_PREREDUCE 1
+#endif
 #ifndef MCF_LANES21
 #define MCF_LANES21 1
 #endif
@@ -361,7 +364,9 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? 3 : MCF_WAVES_PER_EU) void
     __shared__ double s_cell[CF_COUNT * CPB];
     __shared__ double s_dirs[kCellDirs * CPB];
     __shared__ double s_time[AF ? 1 : 3 * TF_COUNT * 24];
-    __shared__ double s_red[2][2][24 * CPB];
+    // day-reduction staging: per (hour, cell) values, or — 21-cell tiles — per (wave, cell) partial extremes
+    constexpr bool PRE = (CPB == 21) && MCF_LANES21 && MCF_WAVE_PREREDUCE;
+    __shared__ double s_red[2][PRE ? 3 : 2][(PRE ? 8 : 24) * CPB];
     __shared__ double s_dd[BG ? 24 * CPB : 1];
 
     const int tid = threadIdx.x;
@@ -520,13 +525,15 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? 3 : MCF_WAVES_PER_EU) void
 #endif
         Carry cy;
         Pass1Out p1;
-        double* red_t = &s_red[dl & 1][0][hr * CPB + cl];
-        double* red_r = &s_red[dl & 1][1][hr * CPB + cl];
+        double* red_t = &s_red[dl & 1][0][PRE ? 0 : hr * CPB + cl];
+        double* red_r = &s_red[dl & 1][1][PRE ? 0 : hr * CPB + cl];
         if (valid) {
             if (AF) pass1(C, TR, g, flags, dTmx, cy, p1);
             else pass1(C, TL, g, flags, dTmx, cy, p1);
-            *red_t = p1.Tg0;
-            *red_r = p1.absRnet;
+            if (!PRE) {
+                *red_t = p1.Tg0;
+                *red_r = p1.absRnet;
+            }
             put(3, cy.soilm);     // soilm      cpp:2227
             put(4, p1.uz);        // windspeed  cpp:2253
             put(5, cy.Rbdown);    // Rdirdown   cpp:2242
@@ -538,6 +545,32 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? 3 : MCF_WAVES_PER_EU) void
             put(5, NA);
             put(6, NA);
             put(8, NA);
+        }
+        if (PRE) {
+            // The three hour lanes of a cell inside this wave (lanes l, l+16, l+32, or 48+j, 48+j+5, 48+j+10) first
+            // combine their values through the crossbar, and one of them stores the wave's partial extremes:
+            // 8 partials per cell instead of 24 values for every lane to walk after the barrier.  max / min with
+            // NaN-ignoring v_max_f64 / v_min_f64 are order-independent, so this equals the hour-ordered scan.
+            const int l = tid & 63;
+            int q1, q2;
+            if (l < 48) { q1 = l + 16; q1 -= q1 >= 48 ? 48 : 0; q2 = l + 32; q2 -= q2 >= 48 ? 48 : 0; }
+            else if (l < 63) { const int j = l - 48; q1 = 48 + (j + 5) % 15; q2 = 48 + (j + 10) % 15; }
+            else { q1 = l; q2 = l; }
+            const double xt = valid ? p1.Tg0 : 0.0, xr = valid ? p1.absRnet : 0.0;
+            const double t1 = __shfl(xt, q1), t2 = __shfl(xt, q2), r1 = __shfl(xr, q1), r2 = __shfl(xr, q2);
+            double tmx3 = xt, tmn3 = xt, rmx3 = xr;
+            asm("v_max_f64 %0, %0, %1" : "+v"(tmx3) : "v"(t1));
+            asm("v_max_f64 %0, %0, %1" : "+v"(tmx3) : "v"(t2));
+            asm("v_min_f64 %0, %0, %1" : "+v"(tmn3) : "v"(t1));
+            asm("v_min_f64 %0, %0, %1" : "+v"(tmn3) : "v"(t2));
+            asm("v_max_f64 %0, %0, %1" : "+v"(rmx3) : "v"(r1));
+            asm("v_max_f64 %0, %0, %1" : "+v"(rmx3) : "v"(r2));
+            if (valid && (l < 16 || (l >= 48 && l < 53))) {
+                const int wv = tid >> 6;
+                s_red[dl & 1][0][wv * CPB + cl] = tmx3;
+                s_red[dl & 1][1][wv * CPB + cl] = tmn3;
+                s_red[dl & 1][PRE ? 2 : 0][wv * CPB + cl] = rmx3;
+            }
         }
         if (stage) {
             double* dst = s_time + ((dl + 1) % 3) * (TF_COUNT * 24);
@@ -558,8 +591,18 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? 3 : MCF_WAVES_PER_EU) void
             double Rmx = -999.9, tmx = -999.0, tmn = 999.0;
             const double* rt = &s_red[dl & 1][0][cl];
             const double* rr = &s_red[dl & 1][1][cl];
+            if (PRE) {
+                const double* rq = &s_red[dl & 1][PRE ? 2 : 0][cl];
 #pragma unroll
-            for (int hh = 0; hh < 24; ++hh) {
+                for (int wv = 0; wv < 8; ++wv) {
+                    const double a1 = rt[wv * CPB], a2 = rr[wv * CPB], a3 = rq[wv * CPB];
+                    asm("v_max_f64 %0, %0, %1" : "+v"(tmx) : "v"(a1));
+                    asm("v_min_f64 %0, %0, %1" : "+v"(tmn) : "v"(a2));
+                    asm("v_max_f64 %0, %0, %1" : "+v"(Rmx) : "v"(a3));
+                }
+            }
+#pragma unroll
+            for (int hh = 0; hh < (PRE ? 0 : 24); ++hh) {
                 double tg = rt[hh * CPB], rv = rr[hh * CPB];
 #if MCF_REDUCE_MINMAX
                 // `if (Rmx < rv) Rmx = rv` with a finite start value ignores a NaN rv, exactly what v_max_f64
