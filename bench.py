@@ -104,6 +104,11 @@ def main():
     rows, cols, T = args.rows, args.cols, args.tsteps
     ndays = T // 24
     af = args.array_forcing
+    # the output ring (and, with array forcing, the forcing slabs) must fit the GPU: shrink the days per slot
+    # until slots x days x 24 h x cells x 8 B x (10 outputs [+ 15 forcing arrays]) stays under 160 GB
+    per_day = rows * cols * 24 * 8 * (10 + (15 if af else 0))
+    while args.ring_days > 1 and args.ring_slots * args.ring_days * per_day > 160e9:
+        args.ring_days -= 1
     if af:
         T = min(T, args.ring_days * args.ring_slots * 24)
         ndays = T // 24
