@@ -20,6 +20,9 @@
 #ifndef MCF_HOUR_PERMUTE
 #define MCF_HOUR_PERMUTE 1
 #endif
+#ifndef MCF_HOUR_ROTATE
+#define MCF_HOUR_ROTATE 1
+#endif
 #ifndef MCF_WAVE_PREREDUCE
 #define MCF_WAVE_PREREDUCE 1
 #endif
@@ -407,7 +410,18 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? 3 : MCF_WAVES_PER_EU) void
     if (hr > 23) hr = 23;
 #endif
 #if MCF_LANES21
-    if (CPB == 21) hr = hr21;
+    if (CPB == 21) {
+        hr = hr21;
+#if MCF_HOUR_ROTATE
+        // Waves w and w+4 of a workgroup share a SIMD and sit 12 hours apart: a day and a night wave at the
+        // equinox, but two day waves (hours 6-8 and 18-20) on one SIMD in summer and two night waves in winter.
+        // Two workgroups are resident per CU; shifting every other one by six hours puts the complementary
+        // pattern on the same SIMDs.  Workgroups q and q+32 of an XCD's dispatch sequence tend to share a CU.
+        const int rot = (int)((blockIdx.x >> 8) & 1);
+        hr = hr + 6 * rot;
+        hr -= hr >= 24 ? 24 : 0;
+#endif
+    }
 #endif
     const int64_t N = a.N;
 #if MCF_XCD_REMAP
