@@ -131,10 +131,11 @@ def run_bioclim(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, 
 
 
 # ---- snow branch (snow_oracle.c) ----
-def run_snowmodel(obstime, climdata, pointm, vegp, other, snowenv, array_forcing=False):
-    """Oracle for gridmodelsnow1 (array_forcing=False) / gridmodelsnow2 (True)."""
+def run_snowmodel(obstime, climdata, pointm, vegp, other, snowenv, array_forcing=False, lib=None):
+    """Oracle for gridmodelsnow1 (array_forcing=False) / gridmodelsnow2 (True).  `lib`: another build
+    of the oracle (the gcov-instrumented one)."""
     from microclimf_amd import snow as S
-    lib = load()
+    lib = lib or load()
     m = S.marshal_snow(obstime, climdata, vegp, other, array_forcing, pointm=pointm, snowenv=snowenv)
     out, arrays = S.alloc_snowmodel_out(m)
     lib.orc_gridmodelsnow.restype = C.c_int
@@ -145,10 +146,10 @@ def run_snowmodel(obstime, climdata, pointm, vegp, other, snowenv, array_forcing
     return arrays
 
 
-def run_microsnow(reqhgt, obstime, climdata, snowm, micro, vegp, other, mat, out, array_forcing=False):
+def run_microsnow(reqhgt, obstime, climdata, snowm, micro, vegp, other, mat, out, array_forcing=False, lib=None):
     """Oracle for gridmicrosnow1 / gridmicrosnow2; returns updated copies of the requested fields."""
     from microclimf_amd import snow as S
-    lib = load()
+    lib = lib or load()
     m = S.marshal_snow(obstime, climdata, vegp, other, array_forcing, micro=True)
     sm = S.marshal_snowm(m, snowm)
     sel, outs, arrays = S.marshal_micro(m, micro, out)

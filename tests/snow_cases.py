@@ -15,12 +15,59 @@ SNOW_CASES = {
     "array_5day": (dict(rows=10, cols=8, tsteps=120, cold=3.0, zref=3.5), True),
     "array_partial_day": (dict(rows=6, cols=7, tsteps=53, cold=2.0, zref=3.5, snowenv="Tundra"), True),
     "array_thaw": (dict(rows=7, cols=6, tsteps=96, cold=-1.0, zref=3.5, start_doy=75), True),
+    # twilight short wave (zenith > 90 with Rsw > 0, cpp:3795), beam above the solar constant (cpp:3800), ground heat
+    # flux beyond the day's |Rnet| (cpp:4353-4354), leap year (cpp:4984)
+    "bright_leap": (dict(rows=8, cols=7, tsteps=72, cold=3.0, zref=3.5, year=2024, start_doy=58, tweak="bright"), False),
+    "array_bright": (dict(rows=6, cols=6, tsteps=48, cold=3.0, zref=3.5, year=2000, tweak="bright"), True),
+    # NaN terrain / snow state on cells with vegetation: the is_na(si) fallback (cpp:5002 / 5161), meanDsnow's NA (cpp:4723)
+    "nan_inputs": (dict(rows=7, cols=6, tsteps=72, cold=3.0, zref=3.5, tweak="nan"), False),
+    "array_nan_inputs": (dict(rows=6, cols=5, tsteps=48, cold=3.0, zref=3.5, tweak="nan"), True),
 }
+
+
+MICRO_HEIGHTS = (0.0, 0.05, 1.0, 2.5, -8.0)   # sensor heights of the snow-microclimate parity tests (-8 m: nb > hiy)
 
 
 def build_snow(name):
     kw, af = SNOW_CASES[name]
-    return synthetic.snow_workload(array_forcing=af, **kw), af
+    kw = dict(kw)
+    tweak = kw.pop("tweak", None)
+    sw = synthetic.snow_workload(array_forcing=af, **kw)
+    if tweak == "bright":
+        c, p = sw["climdata"], sw["pointm"]
+        c["swdown"] = np.asfortranarray(np.maximum(c["swdown"] * 1.7, 0.8))     # never dark, strong beam at low sun
+        c["difrad"] = np.asfortranarray(np.minimum(c["difrad"] * 0.3 + 0.5, c["swdown"]))
+        p["Gp"] = np.asfortranarray(p["Gp"] * 25.0)
+        v = sw["vegp"]                                                           # extreme canopy optics
+        rr, cc = v["pai"].shape
+        ii = np.arange(rr * cc, dtype=np.uint64).reshape((rr, cc), order="F")
+        v["leaft"] = 0.02 + 0.9 * synthetic.uniform(201, ii)
+        v["clump"] = np.where(synthetic.uniform(202, ii) < 0.3, 0.0, 0.97 * synthetic.uniform(203, ii))
+    elif tweak == "nan":
+        hgt = sw["vegp"]["hgt"]
+        ok = np.argwhere(~np.isnan(hgt))
+        (i2, j2) = ok[len(ok) // 2]
+        sw["other"]["slope"] = sw["other"]["slope"].copy()
+        for (i1, j1) in ok[1::7]:
+            sw["other"]["slope"][i1, j1] = np.nan
+        sw["nan_state_cell"] = (int(i2), int(j2))          # microsnow_state() pokes NaN into snowm here
+    return sw, af
+
+
+def microsnow_state(sw, smod):
+    """snowm / micro of a case (synthetic.microsnow_inputs) with the case's NaN pokes applied."""
+    snowm, micro = synthetic.microsnow_inputs(sw, smod)
+    if "nan_state_cell" in sw:
+        i, j = sw["nan_state_cell"]
+        snowm = {k: v.copy() for k, v in snowm.items()}
+        snowm["snowden"][i, j, :] = np.nan
+        snowm["Tg"][i, j, 0] = np.nan
+    return snowm, micro
+
+
+def model_args(sw):
+    """the keyword arguments of oracle.run_snowmodel / the positional ones of gridmodelsnow*"""
+    return {k: sw[k] for k in ("obstime", "climdata", "pointm", "vegp", "other", "snowenv")}
 
 
 def assert_close(got, want, tol, what=""):

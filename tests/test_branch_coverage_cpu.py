@@ -48,3 +48,45 @@ def test_parity_cases_flip_every_branch(tmp_path):
     # the allowlist must not rot: every entry still matches a one-sided line
     stale = [k for k in ONE_SIDED_OK if not any(k in src for _, src, _ in one_sided)]
     assert not stale, f"allowlist entries that no longer apply: {stale}"
+
+
+# ---- the snow branch (oracle/snow_oracle.c under tests/snow_cases.py) --------------------------------------
+SNOW_ONE_SIDED_OK = {
+    "if (cis > prec) cis = prec": "cpp:3737: I1*0.678 <= 0.678*Cp*prec < prec for a non-negative load Li",
+    "if (out.cis > clim.prec)": "cpp:3934: repeats the clamp canopysnowintCpp has applied already",
+    "snowenv < 0 || snowenv > 4": "range guard of the oracle's enum (unknown names map to 0 before the call)",
+    "if (alb[i] < 0.1)": "cpp:3768: needs more than 1000 days without snowfall",
+    "if (si < 0.0) si = 0.0;": "cpp:3796: solarindexCpp has clamped already (cpp:100)",
+    "if (Rddm > 1.0)": "cpp:3815: not reached over the optical parameter space sampled by the 'bright' cases",
+    "if (Rddm < 0.0)": "cpp:3816: idem",
+    "if (Rdbm > 1.0)": "cpp:3820: idem",
+    "if (Rbgm > 1.0)": "cpp:3824: a convex combination of 1 and exp(-kd*pait) <= 1",
+    "if (Rbgm < 0.0)": "cpp:3825: idem, >= 0",
+    "if (mu > 1.0) mu = 1.0": "cpp:3911: exp(-pai) > 1 needs a negative plant area index",
+    "if (wgtg < 0.0)": "cpp:3927: a ratio of two non-negative depths",
+    "if (hgts > 0.0) paias": "cpp:4801: the in-canopy branch is only entered with reqhgt < hgts, hence hgts > 0",
+    "const int hiy =": "cpp:4984: a year divisible by 100 but not by 400 (2100) is not sampled",
+    # pointmodelsnow (cpp:4000-4169) is restated only to replay the reference's test, it is not on the grid path
+    "if (zm < 0.001) zm = 0.001": "pointmodelsnow only",
+    "if (fabs(H[i]) < 0.1)": "pointmodelsnow only",
+    "if (psim[i] <": "pointmodelsnow only",
+    "if (psih[i] <": "pointmodelsnow only",
+    "if (psim[i] >": "pointmodelsnow only",
+    "if (psih[i] >": "pointmodelsnow only",
+    "if (iter > maxiter)": "pointmodelsnow only",
+    # API guards of the oracle: the tests always request every output
+    "if (out->": "oracle API guard",
+    "if (outsel[": "oracle API guard",
+    "if (arr3[v])": "oracle API guard",
+    "if (arr2[v])": "oracle API guard",
+}
+
+
+def test_snow_cases_flip_every_branch(tmp_path):
+    import oracle_branch_coverage as cov
+    total, one_sided = cov.measure_snow(tmp_path)
+    assert total >= 150
+    unexplained = [(no, src) for no, src, _ in one_sided if not any(k in src for k in SNOW_ONE_SIDED_OK)]
+    assert not unexplained, "branches taken one way only:\n" + "\n".join(f"  snow_oracle.c:{n}: {s}" for n, s in unexplained)
+    stale = [k for k in SNOW_ONE_SIDED_OK if not any(k in src for _, src, _ in one_sided)]
+    assert not stale, f"allowlist entries that no longer apply: {stale}"

@@ -7,7 +7,7 @@ import pytest
 
 from microclimf_amd import _abi, synthetic
 from oracle import replay_reference_tests as RT
-from snow_cases import SNOW_CASES, assert_close, build_snow
+from snow_cases import MICRO_HEIGHTS, SNOW_CASES, assert_close, build_snow, microsnow_state, model_args
 
 NA_BITS = 0x7FF00000000007A2
 
@@ -45,7 +45,7 @@ def test_snowenv_names():
 @pytest.mark.parametrize("name", ["alpine_5day", "array_5day"])
 def test_snowmodel_oracle_invariants(oracle, name):
     sw, af = build_snow(name)
-    r = oracle.run_snowmodel(**sw, array_forcing=af)
+    r = oracle.run_snowmodel(**model_args(sw), array_forcing=af)
     hgt = sw["vegp"]["hgt"]
     na = np.isnan(hgt)
     for k in ("Tc", "Tg", "sdepc", "sdepg", "sden"):
@@ -107,7 +107,7 @@ def test_model1_equals_model2_on_broadcast_forcing(oracle):
 @pytest.mark.parametrize("reqhgt", [0.05, 1.0])
 def test_microsnow_oracle_invariants(oracle, name, reqhgt):
     sw, af = build_snow(name)
-    smod = oracle.run_snowmodel(**sw, array_forcing=af)
+    smod = oracle.run_snowmodel(**model_args(sw), array_forcing=af)
     snowm, micro = synthetic.microsnow_inputs(sw, smod)
     out = [1] * 10
     mo = oracle.run_microsnow(reqhgt, sw["obstime"], sw["climdata"], snowm, micro, sw["vegp"], sw["other"], 3.0,
@@ -130,7 +130,7 @@ def test_microsnow_oracle_invariants(oracle, name, reqhgt):
 
 def test_out_mask_only_touches_requested(oracle):
     sw, af = build_snow("alpine_5day")
-    smod = oracle.run_snowmodel(**sw, array_forcing=af)
+    smod = oracle.run_snowmodel(**model_args(sw), array_forcing=af)
     snowm, micro = synthetic.microsnow_inputs(sw, smod)
     out = [1, 0, 1, 0, 0, 0, 0, 0, 0, 1]
     mo = oracle.run_microsnow(0.05, sw["obstime"], sw["climdata"], snowm, micro, sw["vegp"], sw["other"], 3.0, out)

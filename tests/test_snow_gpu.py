@@ -9,7 +9,7 @@ import pytest
 
 from microclimf_amd import _abi, synthetic
 from microclimf_amd.snow import gridmicrosnow1, gridmicrosnow2, gridmodelsnow1, gridmodelsnow2, marshal_snow
-from snow_cases import SNOW_CASES, assert_close, build_snow
+from snow_cases import MICRO_HEIGHTS, SNOW_CASES, assert_close, build_snow, microsnow_state, model_args
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-6
@@ -24,7 +24,7 @@ def run_model(sw, af):
 @pytest.mark.parametrize("name", sorted(SNOW_CASES))
 def test_snowmodel_matches_oracle(oracle, name):
     sw, af = build_snow(name)
-    want = oracle.run_snowmodel(**sw, array_forcing=af)
+    want = oracle.run_snowmodel(**model_args(sw), array_forcing=af)
     got = run_model(sw, af)
     assert list(got) == ["Tc", "Tg", "sdepc", "sdepg", "sden", "agec", "ageg", "meltc", "meltg"]   # cpp:4413-4421
     for k in ("Tc", "Tg", "sdepc", "sdepg", "sden", "meltc", "meltg"):
@@ -75,13 +75,13 @@ def test_snowmodel_chunks_chain_like_the_r_driver(oracle):
         assert_close(g2[k], o2[k], TOL, k)
 
 
-@pytest.mark.parametrize("reqhgt", [0.0, 0.05, 1.0, 2.5])
+@pytest.mark.parametrize("reqhgt", MICRO_HEIGHTS)
 @pytest.mark.parametrize("name", ["alpine_5day", "maritime_partial_day", "veg_above_zref", "array_5day",
-                                  "array_partial_day"])
+                                  "array_partial_day", "bright_leap", "array_bright", "nan_inputs", "array_nan_inputs"])
 def test_microsnow_matches_oracle(oracle, name, reqhgt):
     sw, af = build_snow(name)
-    smod = oracle.run_snowmodel(**sw, array_forcing=af)
-    snowm, micro = synthetic.microsnow_inputs(sw, smod)
+    smod = oracle.run_snowmodel(**model_args(sw), array_forcing=af)
+    snowm, micro = microsnow_state(sw, smod)
     out = [1] * 10
     args = (reqhgt, sw["obstime"], sw["climdata"], snowm, micro, sw["vegp"], sw["other"], 3.0, out)
     want = oracle.run_microsnow(*args, array_forcing=af)
@@ -96,7 +96,7 @@ def test_microsnow_matches_oracle(oracle, name, reqhgt):
 
 def test_microsnow_out_mask(oracle):
     sw, af = build_snow("alpine_5day")
-    smod = oracle.run_snowmodel(**sw, array_forcing=af)
+    smod = oracle.run_snowmodel(**model_args(sw), array_forcing=af)
     snowm, micro = synthetic.microsnow_inputs(sw, smod)
     out = [1, 0, 1, 0, 0, 1, 0, 0, 0, 1]
     args = (0.05, sw["obstime"], sw["climdata"], snowm, micro, sw["vegp"], sw["other"], 3.0, out)

@@ -40,6 +40,40 @@ def measure(workdir: Path):
     return parse(workdir / "mcf_oracle.c.gcov")
 
 
+def measure_snow(workdir: Path):
+    """The same for oracle/snow_oracle.c under tests/snow_cases.py (snowpack model, snow microclimate at
+    several sensor heights) and the replayed test-pointmodelsnow.R."""
+    import snow_cases as SC
+    from microclimf_amd import synthetic
+    from oracle import oracle as O
+    from oracle import replay_reference_tests as RT
+
+    src = ROOT / "oracle" / "oracle_unit.c"
+    lib_path = workdir / "libcovs.so"
+    subprocess.run(["gcc", "-O0", "--coverage", "-DORC_COVERAGE", "-fPIC", "-shared", "-std=c99", "-o", str(lib_path), str(src), "-lm"],
+                   check=True, cwd=workdir)
+    lib = C.CDLL(str(lib_path))
+    for name in SC.SNOW_CASES:
+        sw, af = SC.build_snow(name)
+        smod = O.run_snowmodel(**SC.model_args(sw), array_forcing=af, lib=lib)
+        snowm, micro = SC.microsnow_state(sw, smod)
+        for reqhgt in SC.MICRO_HEIGHTS:
+            O.run_microsnow(reqhgt, sw["obstime"], sw["climdata"], snowm, micro, sw["vegp"], sw["other"], 3.0, [1] * 10,
+                            array_forcing=af, lib=lib)
+    lib.orc_satvap.restype = C.c_double
+    lib.orc_satvap.argtypes = [C.c_double]
+    saved = O._lib
+    O._lib = lib                                   # the replay goes through oracle.load()
+    try:
+        RT.replay_pointmodelsnow_test()
+    finally:
+        O._lib = saved
+    lib.orc_cov_dump()
+    subprocess.run(["gcov", "-b", "-c", "-o", str(workdir / "libcovs.so-oracle_unit.gcno"), str(src)],
+                   check=True, cwd=workdir, capture_output=True)
+    return parse(workdir / "snow_oracle.c.gcov")
+
+
 def parse(gcov_file: Path):
     """-> (lines_with_branches, one_sided): one_sided = [(lineno, source, [counts])] for executed
     lines where some branch outcome was never taken."""
@@ -72,3 +106,8 @@ if __name__ == "__main__":
     print(f"{total} source lines with conditional branches, {len(one)} taken one way only:")
     for no, src, br in one:
         print(f"  mcf_oracle.c:{no}: {src[:110]}   {br}")
+    with tempfile.TemporaryDirectory() as d:
+        total, one = measure_snow(Path(d))
+    print(f"snow_oracle.c: {total} source lines with conditional branches, {len(one)} taken one way only:")
+    for no, src, br in one:
+        print(f"  snow_oracle.c:{no}: {src[:110]}   {br}")
