@@ -110,6 +110,20 @@ struct mcf_plan {
 
 namespace {
 
+// lazily sets up the pinned ring + host copy threads of a plan; false: unavailable (callers fall back to hipMemcpy)
+bool ensure_pipe(mcf_plan* p) {
+    if (p->pipe) return true;
+    if (p->pipe_failed) return false;
+    p->pipe = new mcf::HostPipe();
+    if (!p->pipe->init() || hipEventCreateWithFlags(&p->ev_pipe, hipEventDisableTiming) != hipSuccess) {
+        delete p->pipe;
+        p->pipe = nullptr;
+        p->pipe_failed = true;
+        return false;
+    }
+    return true;
+}
+
 int dalloc(mcf_plan* p, void** ptr, int64_t nbytes) {
     if (nbytes <= 0) nbytes = 8;
     hipError_t e = hipMalloc(ptr, (size_t)nbytes);
@@ -462,8 +476,8 @@ int mcf_plan_upload_forcing_days(mcf_plan* p, const mcf_grid_inputs* in, int32_t
     for (int f = 0; f < 15; ++f) {
         if (!raw[f]) return fail(MCF_ERR_ARG, std::string("missing forcing array: ") + kRawNames[f]);
         double* dst = p->d_force + ((int64_t)slot * 15 + f) * cap;
-        HIP_TRY(hipMemcpyAsync(dst, raw[f] + N * (int64_t)day0 * 24, (size_t)n * 8, hipMemcpyHostToDevice,
-                               p->stream));
+        const double* src = raw[f] + N * (int64_t)day0 * 24;
+        HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n * 8, hipMemcpyHostToDevice, p->stream));
     }
     p->force_day0[slot] = day0;
     p->force_ndays[slot] = ndays;
@@ -563,20 +577,10 @@ int mcf_plan_fetch(mcf_plan* p, int32_t slot, int32_t var, int64_t step0, int64_
     const size_t bytes = (size_t)(p->N * nsteps) * 8;
     // large results: pinned ring + host copy threads instead of hipMemcpy's single-threaded staging
     static const bool no_pipe = getenv("MCF_NO_HOSTPIPE") != nullptr;
-    if (bytes >= ((size_t)64 << 20) && !no_pipe && !p->pipe_failed) {
-        if (!p->pipe) {
-            p->pipe = new mcf::HostPipe();
-            if (!p->pipe->init() || hipEventCreateWithFlags(&p->ev_pipe, hipEventDisableTiming) != hipSuccess) {
-                delete p->pipe;
-                p->pipe = nullptr;
-                p->pipe_failed = true;
-            }
-        }
-        if (p->pipe) {
-            HIP_TRY(hipEventRecord(p->ev_pipe, p->stream));
-            HIP_TRY(p->pipe->copy(host_dst, src, bytes, p->ev_pipe));
-            return MCF_OK;
-        }
+    if (bytes >= ((size_t)64 << 20) && !no_pipe && ensure_pipe(p)) {
+        HIP_TRY(hipEventRecord(p->ev_pipe, p->stream));
+        HIP_TRY(p->pipe->copy(host_dst, src, bytes, p->ev_pipe));
+        return MCF_OK;
     }
     HIP_TRY(hipMemcpyAsync(host_dst, src, bytes, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
