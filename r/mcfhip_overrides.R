@@ -29,6 +29,16 @@ mcfhip_enable <- function(glue = "r/mcfhip_glue.so") {
                   Sminp, Smaxp, tfact, complete, mat, out)
     .Call("mcfhip_runmicro4", dfsel, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons,
           Sminp, Smaxp, tfact, complete, mat, out)
+  # fused bioclim sink (R/RcppExports.R runbioclim1Cpp / runbioclim2Cpp, src/microclimfCpp.cpp:3563-3616)
+  for (nm in c("runbioclim1Cpp", "runbioclim2Cpp")) local({
+    sym <- paste0("mcfhip_", sub("Cpp$", "", nm))
+    utils::assignInNamespace(nm, function(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, long, Sminp,
+                                          Smaxp, tfact, mat, out, wetq, dryq, hotq, colq, air)
+      .Call(sym, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, long, Sminp, Smaxp, tfact, mat, out,
+            wetq, dryq, hotq, colq, air), ns = "microclimf")
+  })
+  utils::assignInNamespace("applycpp3", function(a, fun_name) .Call("mcfhip_applycpp3", a, fun_name),
+                           ns = "microclimf")
   # snow branch (R/RcppExports.R:108-114, 124-130; called at R/internal.R:2587 and 3625)
   for (nm in c("gridmodelsnow1", "gridmodelsnow2")) local({
     sym <- paste0("mcfhip_", nm)
