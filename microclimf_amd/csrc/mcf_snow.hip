@@ -548,6 +548,20 @@ __global__ __launch_bounds__(256) void k_apply3(const double* __restrict__ a, in
         }                                                                                    \
     } while (0)
 
+struct Events {   // timing events released on every exit path
+    std::vector<hipEvent_t> e;
+    ~Events() { for (hipEvent_t x : e) (void)hipEventDestroy(x); }
+    hipError_t make(int n) {
+        for (int i = 0; i < n; ++i) {
+            hipEvent_t x;
+            hipError_t r = hipEventCreate(&x);
+            if (r != hipSuccess) return r;
+            e.push_back(x);
+        }
+        return hipSuccess;
+    }
+};
+
 struct Bufs {
     std::vector<void*> p;
     int64_t bytes = 0;
@@ -725,20 +739,19 @@ int run_snowmodel(const mcf_snow_inputs* in, mcf_snowmodel_out* out, int32_t dev
     for (int v = 0; v < 4; ++v)
         if (host2[v] && (rc = b.alloc((void**)dev2[v], N * 8))) return rc;
     const unsigned grid = (unsigned)((N + 255) / 256);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    Events evs;
     const bool timing = getenv("MCF_TIMING") != nullptr;
-    if (timing) { S_TRY(hipEventCreate(&e0)); S_TRY(hipEventCreate(&e1)); S_TRY(hipEventRecord(e0, nullptr)); }
+    if (timing) { S_TRY(evs.make(2)); S_TRY(hipEventRecord(evs.e[0], nullptr)); }
     if (af) hipLaunchKernelGGL(k_snowmodel<true>, dim3(grid), dim3(256), 0, nullptr, a);
     else hipLaunchKernelGGL(k_snowmodel<false>, dim3(grid), dim3(256), 0, nullptr, a);
     S_TRY(hipGetLastError());
     if (timing) {
-        S_TRY(hipEventRecord(e1, nullptr));
-        S_TRY(hipEventSynchronize(e1));
+        S_TRY(hipEventRecord(evs.e[1], nullptr));
+        S_TRY(hipEventSynchronize(evs.e[1]));
         float ms = 0;
-        S_TRY(hipEventElapsedTime(&ms, e0, e1));
+        S_TRY(hipEventElapsedTime(&ms, evs.e[0], evs.e[1]));
         fprintf(stderr, "[mcf] k_snowmodel<%d>: %lld cells x %d steps in %.3f ms (%.3e cell-steps/s)\n", (int)af,
                 (long long)N, T, ms, (double)NT / (ms * 1e-3));
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     }
     for (int v = 0; v < 5; ++v)
         if (host3[v]) S_TRY(hipMemcpy(host3[v], *dev3[v], (size_t)NT * 8, hipMemcpyDeviceToHost));
@@ -870,6 +883,7 @@ int run_snowdriver(const mcf_snowdriver_in* din, mcf_snowdriver_out* out, int32_
     if ((rc = b.alloc((void**)&d_hor, 24 * N * 8))) return rc;
     if ((rc = b.alloc((void**)&d_tpic, N * 8))) return rc;
     if ((rc = b.alloc((void**)&d_mean2, 16))) return rc;
+    if ((rc = b.alloc((void**)&d_cm, N * 8))) return rc;      // .tpicalc's coarse grid (at most one block per cell)
     a.slope = d_slope; a.aspect = d_aspect; a.skyview = d_svf; a.wsa = d_wsa; a.hor = d_hor;
     a.isnowdc = d_isnowdc; a.isnowdg = d_isnowdg; a.isnowac = d_ac; a.isnowag = d_ag;
     const StepRow* rows_tab;
@@ -904,8 +918,9 @@ int run_snowdriver(const mcf_snowdriver_in* din, mcf_snowdriver_out* out, int32_
     const int64_t me = std::min(rows, cols);
     const bool timing = getenv("MCF_TIMING") != nullptr;
     double t_terrain = 0, t_model = 0, t_redist = 0, t_copy = 0;
-    hipEvent_t ev[5];
-    if (timing) for (auto& e : ev) S_TRY(hipEventCreate(&e));
+    Events evs;
+    if (timing) S_TRY(evs.make(5));
+    hipEvent_t* ev = evs.e.data();
     for (int ch = 0; ch < nchunks; ++ch) {
         const int k0 = ch * chunk, ns = std::min(chunk, T - k0);
         if (timing) S_TRY(hipEventRecord(ev[0], nullptr));
@@ -931,9 +946,7 @@ int run_snowdriver(const mcf_snowdriver_in* din, mcf_snowdriver_out* out, int32_
         if (!(afd >= 1.0)) return mcf::api_fail(MCF_ERR_ARG, "snow driver: aggregation factor round(10*sqrt(mean wind)/res) is 0 (terra::aggregate fails)");
         const int af = (int)std::min(afd, 1e9);
         if ((double)af < me / 2.0) {
-            const int64_t nI = (rows + af - 1) / af, nJ = (cols + af - 1) / af;
-            if (d_cm) { (void)hipFree(d_cm); d_cm = nullptr; }
-            S_TRY(hipMalloc((void**)&d_cm, (size_t)(nI * nJ * 8)));
+            const int64_t nI = (rows + af - 1) / af, nJ = (cols + af - 1) / af;   // nI * nJ <= N
             hipLaunchKernelGGL(k_tpi_coarse, dim3((unsigned)((nI * nJ + 255) / 256)), dim3(256), 0, nullptr, d_dtms, rows,
                                cols, af, nI, nJ, d_cm);
             hipLaunchKernelGGL(k_tpi_fine, dim3(gridN), dim3(256), 0, nullptr, d_dtms, rows, cols, af, nI, nJ, d_cm,
@@ -964,12 +977,10 @@ int run_snowdriver(const mcf_snowdriver_in* din, mcf_snowdriver_out* out, int32_
             S_TRY(hipEventElapsedTime(&ms, ev[3], ev[4])); t_copy += ms;
         }
     }
-    if (d_cm) (void)hipFree(d_cm);
     S_TRY(hipDeviceSynchronize());
     if (timing) {
         fprintf(stderr, "[mcf] snowmodel1: %d chunks of %d steps, %lld cells: terrain %.2f ms, gridmodelsnow %.2f ms, "
                 "tpi+redistribute %.2f ms, D2H %.2f ms\n", nchunks, chunk, (long long)N, t_terrain, t_model, t_redist, t_copy);
-        for (auto& e : ev) (void)hipEventDestroy(e);
     }
     return MCF_OK;
 }
