@@ -381,6 +381,33 @@ typedef struct mcf_snowdriver_out {
 } mcf_snowdriver_out;
 int mcf_snowmodel1(const mcf_snowdriver_in *in, mcf_snowdriver_out *out, int32_t device);
 
+/* The same loop one step at a time, for a row block of a tiled raster (one plan per rank): between the
+ * steps the caller exchanges what couples the blocks — halo rows of the snow surface for the terrain
+ * stencil and .tpicalc's block means (point-to-point), and two raster-wide means as (sum, count)
+ * all-reduces.  mcf_snowmodel1 is this sequence with one block.  `in->base` and `in->dtm` describe the own
+ * rows; row0 / rows_total place them (rows_total = 0: the block is the raster).  Per chunk c:
+ *   mcf_snowplan_surface()          own rows of dtm + ground snow depth          -> halo exchange
+ *   mcf_snowplan_surface_partial()  (sum, count) of it over non-NA cells         -> all-reduce (only used when
+ *                                   round(10*sqrt(mean wind)/res) >= min(dim)/2, .tpicalc's fallback)
+ *   mcf_snowplan_prepare_chunk(c, ext, hn, hs, surface_mean, &s, &n)
+ *                                   ext = [hn + rows + hs, cols] surface with halos (NULL, 0, 0: no
+ *                                   neighbours); terrain refresh + tpic; returns the partial (sum, count)
+ *                                   of tpic                                       -> all-reduce
+ *   mcf_snowplan_run_chunk(c, tpic_mean, out)   gridmodelsnow1 on the chunk, redistribution, hand-over;
+ *                                   copies the chunk into the block's [rows, cols, tsteps] host arrays
+ * Halo needed: 100 + 2.5 s rows (s = 10 if res <= 100 else 1) and whole af x af blocks around the own
+ * rows, or every row up to the raster edge; checked. */
+typedef struct mcf_snowplan mcf_snowplan;
+int mcf_snowplan_create(const mcf_snowdriver_in *in, int64_t row0, int64_t rows_total, int32_t device,
+                        mcf_snowplan **plan);
+void mcf_snowplan_destroy(mcf_snowplan *plan);
+int32_t mcf_snowplan_chunks(const mcf_snowplan *plan);
+int mcf_snowplan_surface(mcf_snowplan *plan, double *host_own);
+int mcf_snowplan_surface_partial(mcf_snowplan *plan, double *sum, double *count);
+int mcf_snowplan_prepare_chunk(mcf_snowplan *plan, int32_t chunk, const double *ext, int32_t halo_north,
+                               int32_t halo_south, double surface_mean, double *tpic_sum, double *tpic_count);
+int mcf_snowplan_run_chunk(mcf_snowplan *plan, int32_t chunk, double tpic_mean, mcf_snowdriver_out *out);
+
 /* applycpp3 (src/microclimfCpp.cpp:5553-5588; `.runmicrosnow1/2` use it on totalSWE, R/internal.R:3592-3593):
  * reduction of a [rows,cols,tsteps] array over space, per time step, skipping NA.  fun: 0 mean, 1 sum,
  * 2 max, 3 min (max / min of an all-NA step: -Inf / +Inf, mean: NaN).  `count` (optional, [tsteps])

@@ -143,6 +143,8 @@ EXPORTS = (
     "mcf_precompute_terrain", "mcf_runbioclim1", "mcf_runbioclim2",
     "mcf_snowenv_from_name", "mcf_gridmodelsnow1", "mcf_gridmodelsnow2", "mcf_gridmicrosnow1",
     "mcf_gridmicrosnow2", "mcf_snowmodel1", "mcf_applycpp3",
+    "mcf_snowplan_create", "mcf_snowplan_destroy", "mcf_snowplan_chunks", "mcf_snowplan_surface",
+    "mcf_snowplan_surface_partial", "mcf_snowplan_prepare_chunk", "mcf_snowplan_run_chunk",
 )
 
 _lib = None
@@ -224,6 +226,21 @@ def load() -> C.CDLL:
     lib.mcf_applycpp3.restype = C.c_int
     lib.mcf_applycpp3.argtypes = [c_double_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, c_double_p, c_double_p,
                                   C.c_int32]
+    lib.mcf_snowplan_create.restype = C.c_int
+    lib.mcf_snowplan_create.argtypes = [C.POINTER(SnowDriverIn), C.c_int64, C.c_int64, C.c_int32, C.POINTER(P)]
+    lib.mcf_snowplan_destroy.restype = None
+    lib.mcf_snowplan_destroy.argtypes = [P]
+    lib.mcf_snowplan_chunks.restype = C.c_int32
+    lib.mcf_snowplan_chunks.argtypes = [P]
+    lib.mcf_snowplan_surface.restype = C.c_int
+    lib.mcf_snowplan_surface.argtypes = [P, c_double_p]
+    lib.mcf_snowplan_surface_partial.restype = C.c_int
+    lib.mcf_snowplan_surface_partial.argtypes = [P, c_double_p, c_double_p]
+    lib.mcf_snowplan_prepare_chunk.restype = C.c_int
+    lib.mcf_snowplan_prepare_chunk.argtypes = [P, C.c_int32, c_double_p, C.c_int32, C.c_int32, C.c_double, c_double_p,
+                                               c_double_p]
+    lib.mcf_snowplan_run_chunk.restype = C.c_int
+    lib.mcf_snowplan_run_chunk.argtypes = [P, C.c_int32, C.c_double, C.POINTER(SnowDriverOut)]
     lib.mcf_snowmodel1.restype = C.c_int
     lib.mcf_snowmodel1.argtypes = [C.POINTER(SnowDriverIn), C.POINTER(SnowDriverOut), C.c_int32]
     lib.mcf_precompute_terrain.restype = C.c_int

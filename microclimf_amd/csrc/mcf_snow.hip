@@ -422,45 +422,51 @@ __global__ __launch_bounds__(1024) void k_sumcount(const double* __restrict__ x,
     }
     if (threadIdx.x == 0) { out2[0] = ss[0]; out2[1] = sc[0]; }
 }
-// .tpicalc (int:2471-2485), coarse part: aggregate(dtm, af, na.rm = TRUE) — af x af block means from the
-// top-left corner over the non-NA cells
-__global__ __launch_bounds__(256) void k_tpi_coarse(const double* __restrict__ z, int64_t rows, int64_t cols, int af,
-                                                    int64_t nI, int64_t nJ, double* __restrict__ cm) {
+// .tpicalc (int:2471-2485) on a row block of the raster.  `z` is the block's surface (dtm + ground snow) with
+// `hn` halo rows above: row b of z is global row row0 - hn + b; RB rows in all.
+struct TpiGeo {
+    int64_t rows, cols, RB, hn, row0, rows_total;
+    int af;
+    int64_t I0, nI, nJ, NItot;   // coarse rows [I0, I0 + nI) are held, NItot in the whole raster
+};
+// coarse part: aggregate(dtm, af, na.rm = TRUE) — af x af block means from the raster's top-left corner
+// over the non-NA cells
+__global__ __launch_bounds__(256) void k_tpi_coarse(const double* __restrict__ z, TpiGeo g, double* __restrict__ cm) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nI * nJ) return;
-    const int64_t I = q % nI, J = q / nI;
-    const int64_t ra = I * af, rb = min(ra + af, rows), ca = J * af, cb = min(ca + af, cols);
+    if (q >= g.nI * g.nJ) return;
+    const int64_t Il = q % g.nI, J = q / g.nI;
+    const int64_t ra = (g.I0 + Il) * g.af, rb = min(ra + g.af, g.rows_total), ca = J * g.af, cb = min(ca + g.af, g.cols);
     double s = 0.0, n = 0.0;
     for (int64_t c = ca; c < cb; ++c)
         for (int64_t r = ra; r < rb; ++r) {
-            const double v = z[r + rows * c];
+            const double v = z[(r - (g.row0 - g.hn)) + g.RB * c];
             if (!isnan(v)) { s += v; n += 1.0; }
         }
     cm[q] = s / n;   // 0/0 = NaN for an all-NA block
 }
-// .tpicalc, fine part: resample (bilinear between block centres, clamped) or the raster mean, then
+// fine part: resample (bilinear between block centres, clamped) or the raster mean, then
 // tpic = exp((dtmc - dtm) * tfact) with its two clamps (`tpic[tpic < 0.05] <- 0.1` sic)
-__global__ __launch_bounds__(256) void k_tpi_fine(const double* __restrict__ z, int64_t rows, int64_t cols, int af,
-                                                  int64_t nI, int64_t nJ, const double* __restrict__ cm,
-                                                  const double* __restrict__ mean2, double tfact,
-                                                  double* __restrict__ tpic) {
+__global__ __launch_bounds__(256) void k_tpi_fine(const double* __restrict__ z, TpiGeo g, const double* __restrict__ cm,
+                                                  double surface_mean, double tfact, double* __restrict__ tpic) {
     const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (cell >= rows * cols) return;
+    if (cell >= g.rows * g.cols) return;
+    const int64_t r = cell % g.rows, c = cell / g.rows;
+    const double z0 = z[(g.hn + r) + g.RB * c];
     double zc;
     if (cm) {
-        const int64_t r = cell % rows, c = cell / rows;
-        const double tr = ((double)r - (af - 1) / 2.0) / af, tcc = ((double)c - (af - 1) / 2.0) / af;
+        const int af = g.af;
+        const double tr = ((double)(g.row0 + r) - (af - 1) / 2.0) / af, tcc = ((double)c - (af - 1) / 2.0) / af;
         const int64_t i0 = (int64_t)floor(tr), j0 = (int64_t)floor(tcc);
         const double wr = tr - (double)i0, wc = tcc - (double)j0;
-        const int64_t ia = min(max(i0, (int64_t)0), nI - 1), ib = min(max(i0 + 1, (int64_t)0), nI - 1);
-        const int64_t ja = min(max(j0, (int64_t)0), nJ - 1), jb = min(max(j0 + 1, (int64_t)0), nJ - 1);
-        const double top = cm[ia + nI * ja] * (1 - wc) + cm[ia + nI * jb] * wc;
-        const double bot = cm[ib + nI * ja] * (1 - wc) + cm[ib + nI * jb] * wc;
+        const int64_t ia = min(max(i0, (int64_t)0), g.NItot - 1) - g.I0, ib = min(max(i0 + 1, (int64_t)0), g.NItot - 1) - g.I0;
+        const int64_t ja = min(max(j0, (int64_t)0), g.nJ - 1), jb = min(max(j0 + 1, (int64_t)0), g.nJ - 1);
+        const double top = cm[ia + g.nI * ja] * (1 - wc) + cm[ia + g.nI * jb] * wc;
+        const double bot = cm[ib + g.nI * ja] * (1 - wc) + cm[ib + g.nI * jb] * wc;
         zc = top * (1 - wr) + bot * wr;
     } else {
-        zc = z[cell] * 0 + mean2[0] / mean2[1];   // dtm * 0 + mean(dtm, na.rm = TRUE)
+        zc = z0 * 0 + surface_mean;   // dtm * 0 + mean(dtm, na.rm = TRUE)
     }
-    double t = exp((zc - z[cell]) * tfact);
+    double t = exp((zc - z0) * tfact);
     if (t < 0.05) t = 0.1;
     if (t > 10) t = 10;
     tpic[cell] = t;
@@ -471,7 +477,8 @@ struct RedistArgs {
     int64_t N;
     int nsteps;
     const double* hgt;
-    const double *dtm, *tpic, *tpimean2, *isnowdg, *sden, *agec, *ageg;
+    const double *dtm, *tpic, *isnowdg, *sden, *agec, *ageg;
+    double tpimean;                 // mean(tpic, na.rm = TRUE) over the whole raster
     double *sdepc, *sdepg;          // in: smod$sdepc / sdepg, out: swe / snowdepg   [N][nsteps]
     double *isnowdc, *dtms;         // state for the next chunk
     int32_t *isnowac, *isnowag;
@@ -479,7 +486,7 @@ struct RedistArgs {
 __global__ __launch_bounds__(256) void k_snow_redistribute(RedistArgs a) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.N) return;
-    const double tpi = a.tpic[c] / (a.tpimean2[0] / a.tpimean2[1]);   // tpic / mean(tpic, na.rm = TRUE)
+    const double tpi = a.tpic[c] / a.tpimean;   // tpic / mean(tpic, na.rm = TRUE)
     const double asd = a.isnowdg[c], asc = a.isnowdc[c];
     double tot = 0.0, gd = 0.0;
     for (int k = 0; k < a.nsteps; ++k) {
@@ -844,59 +851,104 @@ int run_microsnow(const mcf_snow_inputs* in, const mcf_snowm* sm, double reqhgt,
     return MCF_OK;
 }
 
-int run_snowdriver(const mcf_snowdriver_in* din, mcf_snowdriver_out* out, int32_t device) {
+// (the chunk loop lives in mcf_snowplan below)
+
+}  // namespace
+
+// ---- .snowmodel1's chunk loop as a stepwise, device-resident plan (one per rank's row block) ---------------
+struct mcf_snowplan {
+    int device = 0;
+    int64_t rows = 0, cols = 0, N = 0, row0 = 0, rows_total = 0;
+    int T = 0, chunk = 120, nchunks = 1, ss = 10;
+    double res = 1.0, tfact = 0.02, zref = 2.0;
+    Bufs b;
+    ModelArgs a;
+    const StepRow* rows_tab = nullptr;
+    const double *d_dtm = nullptr, *d_isnowdg = nullptr;
+    double *d_isnowdc = nullptr, *d_dtms = nullptr, *d_slope = nullptr, *d_aspect = nullptr, *d_svf = nullptr,
+           *d_wsa = nullptr, *d_hor = nullptr, *d_tpic = nullptr, *d_mean2 = nullptr, *d_cm = nullptr, *d_ext = nullptr;
+    int64_t ext_cap = 0, cm_cap = 0;
+    int32_t *d_ac = nullptr, *d_ag = nullptr;
+    std::vector<double> wind;
+    int prepared = -1;
+    double t_terrain = 0, t_model = 0;   // ms, MCF_TIMING
+};
+
+namespace {
+
+int chunk_af(const mcf_snowplan* sp, int ch, int* af) {   // int:2589-2590
+    const int k0 = ch * sp->chunk, ns = std::min(sp->chunk, sp->T - k0);
+    double wsum = 0.0;
+    for (int k = 0; k < ns; ++k) wsum += sp->wind[k0 + k];
+    const double tpr = 10 * sqrt(wsum / ns);
+    const double afd = nearbyint(tpr / sp->res);          // R's round(x, 0): half to even
+    if (!(afd >= 1.0))
+        return mcf::api_fail(MCF_ERR_ARG, "snow driver: aggregation factor round(10*sqrt(mean wind)/res) is 0 (terra::aggregate fails)");
+    *af = (int)std::min(afd, 1e9);
+    return MCF_OK;
+}
+
+}  // namespace
+
+extern "C" int mcf_snowplan_create(const mcf_snowdriver_in* din, int64_t row0, int64_t rows_total, int32_t device,
+                                   mcf_snowplan** out) {
     int rc;
     if (!din || !out) return mcf::api_fail(MCF_ERR_ARG, "null snow driver argument");
     const mcf_snow_inputs* in = &din->base;
     if ((rc = common_checks(in))) return rc;
-    if (in->array_forcing) return mcf::api_fail(MCF_ERR_ARG, "mcf_snowmodel1 takes data.frame (vector) climate");
+    if (in->array_forcing) return mcf::api_fail(MCF_ERR_ARG, "the snow driver takes data.frame (vector) climate");
     if (!din->dtm || !(din->res > 0)) return mcf::api_fail(MCF_ERR_ARG, "snow driver needs dtm and res > 0");
+    if (!in->clim.windspeed) return mcf::api_fail(MCF_ERR_ARG, "null input: windspeed");
+    if (rows_total <= 0) { rows_total = in->rows; row0 = 0; }
+    if (row0 < 0 || row0 + in->rows > rows_total) return mcf::api_fail(MCF_ERR_ARG, "block outside the raster");
     if ((rc = pick_device(device))) return rc;
-    const int64_t rows = in->rows, cols = in->cols, N = rows * cols;
-    const int T = (int)in->tsteps;
-    const int chunk = din->chunk_steps > 0 ? din->chunk_steps : 120;
-    if (chunk % 24) return mcf::api_fail(MCF_ERR_ARG, "snow driver: chunk_steps must be whole days");
-    int nchunks = T / chunk;             // `for (day in 1:n5days)`: 1:x truncates, and 1:0.4 still runs once
-    if (nchunks < 1) nchunks = 1;
-    Bufs b;
-    ModelArgs a;
+    mcf_snowplan* sp = new mcf_snowplan();
+    struct Guard { mcf_snowplan* p; ~Guard() { delete p; } } guard{sp};
+    sp->device = device;
+    sp->rows = in->rows; sp->cols = in->cols; sp->N = in->rows * in->cols; sp->row0 = row0; sp->rows_total = rows_total;
+    sp->T = (int)in->tsteps;
+    sp->chunk = din->chunk_steps > 0 ? din->chunk_steps : 120;
+    if (sp->chunk % 24) return mcf::api_fail(MCF_ERR_ARG, "snow driver: chunk_steps must be whole days");
+    sp->nchunks = std::max(1, sp->T / sp->chunk);   // `for (day in 1:n5days)`: 1:x truncates, and 1:0.4 still runs once
+    sp->res = din->res; sp->tfact = din->tfact; sp->zref = in->other.zref;
+    sp->ss = din->res <= 100 ? 10 : 1;              // int:2577-2578
+    sp->wind.assign(in->clim.windspeed, in->clim.windspeed + sp->T);
+    const int64_t N = sp->N;
+    const int T = sp->T;
+    Bufs& b = sp->b;
+    ModelArgs& a = sp->a;
     memset(&a, 0, sizeof a);
-    a.N = N; a.zref = in->other.zref;
+    a.N = N; a.zref = sp->zref;
     snow_density_params(in->snowenv, a.sdp);
     UP(a.pai, in->vegp.pai, N);
     UP(a.hgt, in->vegp.hgt, N);
     UP(a.leaft, in->vegp.leaft, N);
     UP(a.clump, in->vegp.clump, N);
-    const double *d_dtm, *d_isnowdg;
-    double *d_isnowdc, *d_dtms, *d_slope, *d_aspect, *d_svf, *d_wsa, *d_hor, *d_tpic, *d_mean2, *d_cm = nullptr;
-    int32_t *d_ac, *d_ag;
-    UP(d_dtm, din->dtm, N);
-    UP(d_isnowdg, in->other.isnowdg, N);
-    { const double* t; UP(t, in->other.isnowdc, N); d_isnowdc = const_cast<double*>(t); }
-    { const int32_t* t; UP(t, in->other.isnowac, N); d_ac = const_cast<int32_t*>(t); }
-    { const int32_t* t; UP(t, in->other.isnowag, N); d_ag = const_cast<int32_t*>(t); }
-    if ((rc = b.alloc((void**)&d_dtms, N * 8))) return rc;
-    if ((rc = b.alloc((void**)&d_slope, N * 8))) return rc;
-    if ((rc = b.alloc((void**)&d_aspect, N * 8))) return rc;
-    if ((rc = b.alloc((void**)&d_svf, N * 8))) return rc;
-    if ((rc = b.alloc((void**)&d_wsa, 8 * N * 8))) return rc;
-    if ((rc = b.alloc((void**)&d_hor, 24 * N * 8))) return rc;
-    if ((rc = b.alloc((void**)&d_tpic, N * 8))) return rc;
-    if ((rc = b.alloc((void**)&d_mean2, 16))) return rc;
-    if ((rc = b.alloc((void**)&d_cm, N * 8))) return rc;      // .tpicalc's coarse grid (at most one block per cell)
-    a.slope = d_slope; a.aspect = d_aspect; a.skyview = d_svf; a.wsa = d_wsa; a.hor = d_hor;
-    a.isnowdc = d_isnowdc; a.isnowdg = d_isnowdg; a.isnowac = d_ac; a.isnowag = d_ag;
-    const StepRow* rows_tab;
+    UP(sp->d_dtm, din->dtm, N);
+    UP(sp->d_isnowdg, in->other.isnowdg, N);
+    { const double* t; UP(t, in->other.isnowdc, N); sp->d_isnowdc = const_cast<double*>(t); }
+    { const int32_t* t; UP(t, in->other.isnowac, N); sp->d_ac = const_cast<int32_t*>(t); }
+    { const int32_t* t; UP(t, in->other.isnowag, N); sp->d_ag = const_cast<int32_t*>(t); }
+    if ((rc = b.alloc((void**)&sp->d_dtms, N * 8))) return rc;
+    if ((rc = b.alloc((void**)&sp->d_slope, N * 8))) return rc;
+    if ((rc = b.alloc((void**)&sp->d_aspect, N * 8))) return rc;
+    if ((rc = b.alloc((void**)&sp->d_svf, N * 8))) return rc;
+    if ((rc = b.alloc((void**)&sp->d_wsa, 8 * N * 8))) return rc;
+    if ((rc = b.alloc((void**)&sp->d_hor, 24 * N * 8))) return rc;
+    if ((rc = b.alloc((void**)&sp->d_tpic, N * 8))) return rc;
+    if ((rc = b.alloc((void**)&sp->d_mean2, 16))) return rc;
+    a.slope = sp->d_slope; a.aspect = sp->d_aspect; a.skyview = sp->d_svf; a.wsa = sp->d_wsa; a.hor = sp->d_hor;
+    a.isnowdc = sp->d_isnowdc; a.isnowdg = sp->d_isnowdg; a.isnowac = sp->d_ac; a.isnowag = sp->d_ag;
     const DateRow2* dates_unused;
     const double* mx_unused;
-    if ((rc = build_step_tables(b, in, false, true, true, &rows_tab, &dates_unused, &mx_unused))) return rc;
+    if ((rc = build_step_tables(b, in, false, true, true, &sp->rows_tab, &dates_unused, &mx_unused))) return rc;
     {   // albedo per chunk (overrides the whole-series scan of build_step_tables)
         const double* d_prec;
         UP(d_prec, in->clim.precip, T);
-        hipLaunchKernelGGL(k_snow_alb_chunks, dim3((unsigned)((nchunks + 63) / 64)), dim3(64), 0, nullptr,
-                           const_cast<StepRow*>(rows_tab), d_prec, T, chunk, nchunks);
+        hipLaunchKernelGGL(k_snow_alb_chunks, dim3((unsigned)((sp->nchunks + 63) / 64)), dim3(64), 0, nullptr,
+                           const_cast<StepRow*>(sp->rows_tab), d_prec, T, sp->chunk, sp->nchunks);
     }
-    const int64_t CN = (int64_t)chunk * N;
+    const int64_t CN = (int64_t)sp->chunk * N;
     if ((rc = b.alloc((void**)&a.Tc, CN * 8))) return rc;
     if ((rc = b.alloc((void**)&a.Tg, CN * 8))) return rc;
     if ((rc = b.alloc((void**)&a.sdepc, CN * 8))) return rc;
@@ -904,91 +956,179 @@ int run_snowdriver(const mcf_snowdriver_in* din, mcf_snowdriver_out* out, int32_
     if ((rc = b.alloc((void**)&a.sden, CN * 8))) return rc;
     if ((rc = b.alloc((void**)&a.agec, N * 8))) return rc;
     if ((rc = b.alloc((void**)&a.ageg, N * 8))) return rc;
-    const unsigned gridN = (unsigned)((N + 255) / 256);
-    // steps that no chunk covers stay NA (R pre-fills its arrays with NA, int:2554-2558)
-    double* hostv[5] = {out->Tc, out->Tg, out->groundsnowdepth, out->totalSWE, out->snowden};
-    {
-        union { uint64_t u; double d; } na; na.u = kNaRealBits;
-        const int covered = std::min(T, nchunks * chunk);
-        for (double* h : hostv)
-            if (h) for (int64_t q = (int64_t)covered * N; q < (int64_t)T * N; ++q) h[q] = na.d;
-    }
-    hipLaunchKernelGGL(k_add_snow, dim3(gridN), dim3(256), 0, nullptr, d_dtm, d_isnowdg, 1.0, N, d_dtms);   // int:2562
-    const int ss = din->res <= 100 ? 10 : 1;                                                                 // int:2577-2578
-    const int64_t me = std::min(rows, cols);
-    const bool timing = getenv("MCF_TIMING") != nullptr;
-    double t_terrain = 0, t_model = 0, t_redist = 0, t_copy = 0;
-    Events evs;
-    if (timing) S_TRY(evs.make(5));
-    hipEvent_t* ev = evs.e.data();
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int k0 = ch * chunk, ns = std::min(chunk, T - k0);
-        if (timing) S_TRY(hipEventRecord(ev[0], nullptr));
-        // terrain of dtm + snow (int:2566-2580)
-        mcf::TerrainDev td;
-        memset(&td, 0, sizeof td);
-        td.rows = rows; td.cols = cols; td.d_dtm = d_dtms; td.res = din->res; td.zref = in->other.zref; td.agg = ss;
-        td.aspect_na = 180.0;
-        td.d_slope = d_slope; td.d_aspect = d_aspect; td.d_hor = d_hor; td.d_svfa = d_svf; td.d_wsa = d_wsa;
-        if ((rc = mcf::terrain_device(td))) return rc;
-        hipLaunchKernelGGL(k_mask2, dim3(gridN), dim3(256), 0, nullptr, d_dtm, N, d_slope, d_aspect);
-        if (timing) S_TRY(hipEventRecord(ev[1], nullptr));
-        // gridmodelsnow1 on the chunk (int:2587)
-        a.rows = rows_tab + k0;
-        a.tsteps = ns;
-        hipLaunchKernelGGL(k_snowmodel<false>, dim3(gridN), dim3(256), 0, nullptr, a);
-        if (timing) S_TRY(hipEventRecord(ev[2], nullptr));
-        // topographic positioning index (int:2589-2592, 2471-2485)
-        double wsum = 0.0;
-        for (int k = 0; k < ns; ++k) wsum += in->clim.windspeed[k0 + k];
-        const double tpr = 10 * sqrt(wsum / ns);
-        const double afd = nearbyint(tpr / din->res);          // R's round(x, 0): half to even
-        if (!(afd >= 1.0)) return mcf::api_fail(MCF_ERR_ARG, "snow driver: aggregation factor round(10*sqrt(mean wind)/res) is 0 (terra::aggregate fails)");
-        const int af = (int)std::min(afd, 1e9);
-        if ((double)af < me / 2.0) {
-            const int64_t nI = (rows + af - 1) / af, nJ = (cols + af - 1) / af;   // nI * nJ <= N
-            hipLaunchKernelGGL(k_tpi_coarse, dim3((unsigned)((nI * nJ + 255) / 256)), dim3(256), 0, nullptr, d_dtms, rows,
-                               cols, af, nI, nJ, d_cm);
-            hipLaunchKernelGGL(k_tpi_fine, dim3(gridN), dim3(256), 0, nullptr, d_dtms, rows, cols, af, nI, nJ, d_cm,
-                               d_mean2, din->tfact, d_tpic);
-        } else {
-            hipLaunchKernelGGL(k_sumcount, dim3(1), dim3(1024), 0, nullptr, d_dtms, N, d_mean2);
-            hipLaunchKernelGGL(k_tpi_fine, dim3(gridN), dim3(256), 0, nullptr, d_dtms, rows, cols, af, (int64_t)0,
-                               (int64_t)0, (const double*)nullptr, d_mean2, din->tfact, d_tpic);
-        }
-        hipLaunchKernelGGL(k_sumcount, dim3(1), dim3(1024), 0, nullptr, d_tpic, N, d_mean2);
-        RedistArgs ra;
-        ra.N = N; ra.nsteps = ns; ra.hgt = a.hgt; ra.dtm = d_dtm; ra.tpic = d_tpic; ra.tpimean2 = d_mean2;
-        ra.isnowdg = d_isnowdg; ra.sden = a.sden; ra.agec = a.agec; ra.ageg = a.ageg; ra.sdepc = a.sdepc;
-        ra.sdepg = a.sdepg; ra.isnowdc = d_isnowdc; ra.dtms = d_dtms; ra.isnowac = d_ac; ra.isnowag = d_ag;
-        hipLaunchKernelGGL(k_snow_redistribute, dim3(gridN), dim3(256), 0, nullptr, ra);
-        S_TRY(hipGetLastError());
-        if (timing) S_TRY(hipEventRecord(ev[3], nullptr));
-        double* devv[5] = {a.Tc, a.Tg, a.sdepg, a.sdepc, a.sden};
-        for (int v = 0; v < 5; ++v)
-            if (hostv[v]) S_TRY(hipMemcpy(hostv[v] + (int64_t)k0 * N, devv[v], (size_t)ns * N * 8, hipMemcpyDeviceToHost));
-        if (timing) {
-            S_TRY(hipEventRecord(ev[4], nullptr));
-            S_TRY(hipEventSynchronize(ev[4]));
-            float ms;
-            S_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); t_terrain += ms;
-            S_TRY(hipEventElapsedTime(&ms, ev[1], ev[2])); t_model += ms;
-            S_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); t_redist += ms;
-            S_TRY(hipEventElapsedTime(&ms, ev[3], ev[4])); t_copy += ms;
-        }
-    }
+    hipLaunchKernelGGL(k_add_snow, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, nullptr, sp->d_dtm, sp->d_isnowdg, 1.0,
+                       N, sp->d_dtms);   // int:2562
+    S_TRY(hipGetLastError());
     S_TRY(hipDeviceSynchronize());
-    if (timing) {
-        fprintf(stderr, "[mcf] snowmodel1: %d chunks of %d steps, %lld cells: terrain %.2f ms, gridmodelsnow %.2f ms, "
-                "tpi+redistribute %.2f ms, D2H %.2f ms\n", nchunks, chunk, (long long)N, t_terrain, t_model, t_redist, t_copy);
+    guard.p = nullptr;
+    *out = sp;
+    return MCF_OK;
+}
+extern "C" void mcf_snowplan_destroy(mcf_snowplan* sp) {
+    if (!sp) return;
+    (void)hipSetDevice(sp->device);
+    delete sp;
+}
+extern "C" int32_t mcf_snowplan_chunks(const mcf_snowplan* sp) { return sp ? sp->nchunks : 0; }
+extern "C" int mcf_snowplan_surface(mcf_snowplan* sp, double* host_own) {
+    if (!sp || !host_own) return mcf::api_fail(MCF_ERR_ARG, "null argument");
+    S_TRY(hipSetDevice(sp->device));
+    S_TRY(hipMemcpy(host_own, sp->d_dtms, (size_t)sp->N * 8, hipMemcpyDeviceToHost));
+    return MCF_OK;
+}
+extern "C" int mcf_snowplan_surface_partial(mcf_snowplan* sp, double* sum, double* count) {
+    if (!sp || !sum || !count) return mcf::api_fail(MCF_ERR_ARG, "null argument");
+    S_TRY(hipSetDevice(sp->device));
+    hipLaunchKernelGGL(k_sumcount, dim3(1), dim3(1024), 0, nullptr, sp->d_dtms, sp->N, sp->d_mean2);
+    double h[2];
+    S_TRY(hipMemcpy(h, sp->d_mean2, 16, hipMemcpyDeviceToHost));
+    *sum = h[0]; *count = h[1];
+    return MCF_OK;
+}
+extern "C" int mcf_snowplan_prepare_chunk(mcf_snowplan* sp, int32_t ch, const double* ext, int32_t hn, int32_t hs,
+                                          double surface_mean, double* tpic_sum, double* tpic_count) {
+    if (!sp || !tpic_sum || !tpic_count) return mcf::api_fail(MCF_ERR_ARG, "null argument");
+    if (ch < 0 || ch >= sp->nchunks) return mcf::api_fail(MCF_ERR_ARG, "chunk out of range");
+    if (hn < 0 || hs < 0 || (!ext && (hn || hs))) return mcf::api_fail(MCF_ERR_ARG, "bad halo");
+    S_TRY(hipSetDevice(sp->device));
+    int rc, af;
+    if ((rc = chunk_af(sp, ch, &af))) return rc;
+    const int64_t rows = sp->rows, cols = sp->cols, N = sp->N, RB = hn + rows + hs;
+    const double* d_z = sp->d_dtms;
+    if (ext) {
+        if (sp->ext_cap < RB * cols) {
+            if ((rc = sp->b.alloc((void**)&sp->d_ext, RB * cols * 8))) return rc;
+            sp->ext_cap = RB * cols;
+        }
+        S_TRY(hipMemcpy(sp->d_ext, ext, (size_t)(RB * cols) * 8, hipMemcpyHostToDevice));
+        d_z = sp->d_ext;
     }
+    const int64_t me = std::min(sp->rows_total, cols);
+    const bool coarse = (double)af < me / 2.0;
+    TpiGeo g;
+    g.rows = rows; g.cols = cols; g.RB = RB; g.hn = hn; g.row0 = sp->row0; g.rows_total = sp->rows_total; g.af = af;
+    g.NItot = (sp->rows_total + af - 1) / af; g.nJ = (cols + af - 1) / af;
+    auto clampI = [&](int64_t i) { return std::min<int64_t>(std::max<int64_t>(i, 0), g.NItot - 1); };
+    g.I0 = clampI((int64_t)floor(((double)sp->row0 - (af - 1) / 2.0) / af));
+    const int64_t I1 = clampI((int64_t)floor(((double)(sp->row0 + rows - 1) - (af - 1) / 2.0) / af) + 1);
+    g.nI = I1 - g.I0 + 1;
+    // halo rows this chunk needs (or every row up to the raster edge): the terrain stencil and, for the tpi,
+    // whole af x af blocks around the own rows
+    const int64_t avail_n = sp->row0, avail_s = sp->rows_total - sp->row0 - rows;
+    int64_t need_n = 100 + 2 * sp->ss + sp->ss / 2, need_s = need_n;
+    if (coarse) {
+        need_n = std::max(need_n, sp->row0 - g.I0 * af);
+        need_s = std::max(need_s, std::min<int64_t>((I1 + 1) * af, sp->rows_total) - (sp->row0 + rows));
+    }
+    if (hn < std::min(need_n, avail_n) || hs < std::min(need_s, avail_s)) {
+        char m[200];
+        snprintf(m, sizeof m, "snow plan: chunk %d needs %lld / %lld halo rows north / south (or all rows up to the raster edge)",
+                 ch, (long long)need_n, (long long)need_s);
+        return mcf::api_fail(MCF_ERR_ARG, m);
+    }
+    const bool timing = getenv("MCF_TIMING") != nullptr;
+    Events evs;
+    if (timing) { S_TRY(evs.make(2)); S_TRY(hipEventRecord(evs.e[0], nullptr)); }
+    // terrain of dtm + snow (int:2566-2580)
+    mcf::TerrainDev td;
+    memset(&td, 0, sizeof td);
+    td.rows = rows; td.cols = cols; td.halo_north = hn; td.halo_south = hs; td.row0 = sp->row0; td.rows_total = sp->rows_total;
+    td.d_dtm = d_z; td.res = sp->res; td.zref = sp->zref; td.agg = sp->ss; td.aspect_na = 180.0;
+    td.d_slope = sp->d_slope; td.d_aspect = sp->d_aspect; td.d_hor = sp->d_hor; td.d_svfa = sp->d_svf; td.d_wsa = sp->d_wsa;
+    if ((rc = mcf::terrain_device(td))) return rc;
+    const unsigned gridN = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(k_mask2, dim3(gridN), dim3(256), 0, nullptr, sp->d_dtm, N, sp->d_slope, sp->d_aspect);
+    // topographic positioning index (int:2589-2592, 2471-2485)
+    if (coarse) {
+        if (sp->cm_cap < g.nI * g.nJ) {
+            if ((rc = sp->b.alloc((void**)&sp->d_cm, g.nI * g.nJ * 8))) return rc;
+            sp->cm_cap = g.nI * g.nJ;
+        }
+        hipLaunchKernelGGL(k_tpi_coarse, dim3((unsigned)((g.nI * g.nJ + 255) / 256)), dim3(256), 0, nullptr, d_z, g, sp->d_cm);
+        hipLaunchKernelGGL(k_tpi_fine, dim3(gridN), dim3(256), 0, nullptr, d_z, g, (const double*)sp->d_cm, 0.0, sp->tfact,
+                           sp->d_tpic);
+    } else {
+        hipLaunchKernelGGL(k_tpi_fine, dim3(gridN), dim3(256), 0, nullptr, d_z, g, (const double*)nullptr, surface_mean,
+                           sp->tfact, sp->d_tpic);
+    }
+    hipLaunchKernelGGL(k_sumcount, dim3(1), dim3(1024), 0, nullptr, sp->d_tpic, N, sp->d_mean2);
+    S_TRY(hipGetLastError());
+    double h[2];
+    S_TRY(hipMemcpy(h, sp->d_mean2, 16, hipMemcpyDeviceToHost));
+    *tpic_sum = h[0]; *tpic_count = h[1];
+    if (timing) {
+        S_TRY(hipEventRecord(evs.e[1], nullptr));
+        S_TRY(hipEventSynchronize(evs.e[1]));
+        float ms = 0;
+        S_TRY(hipEventElapsedTime(&ms, evs.e[0], evs.e[1]));
+        sp->t_terrain += ms;
+    }
+    sp->prepared = ch;
+    return MCF_OK;
+}
+extern "C" int mcf_snowplan_run_chunk(mcf_snowplan* sp, int32_t ch, double tpic_mean, mcf_snowdriver_out* out) {
+    if (!sp || !out) return mcf::api_fail(MCF_ERR_ARG, "null argument");
+    if (ch != sp->prepared) return mcf::api_fail(MCF_ERR_STATE, "snow plan: run_chunk needs prepare_chunk of the same chunk first");
+    S_TRY(hipSetDevice(sp->device));
+    const int64_t N = sp->N;
+    const int k0 = ch * sp->chunk, ns = std::min(sp->chunk, sp->T - k0);
+    const unsigned gridN = (unsigned)((N + 255) / 256);
+    const bool timing = getenv("MCF_TIMING") != nullptr;
+    Events evs;
+    if (timing) { S_TRY(evs.make(2)); S_TRY(hipEventRecord(evs.e[0], nullptr)); }
+    ModelArgs a = sp->a;
+    a.rows = sp->rows_tab + k0;            // gridmodelsnow1 on the chunk (int:2587)
+    a.tsteps = ns;
+    hipLaunchKernelGGL(k_snowmodel<false>, dim3(gridN), dim3(256), 0, nullptr, a);
+    RedistArgs ra;
+    ra.N = N; ra.nsteps = ns; ra.hgt = a.hgt; ra.dtm = sp->d_dtm; ra.tpic = sp->d_tpic; ra.tpimean = tpic_mean;
+    ra.isnowdg = sp->d_isnowdg; ra.sden = a.sden; ra.agec = a.agec; ra.ageg = a.ageg; ra.sdepc = a.sdepc;
+    ra.sdepg = a.sdepg; ra.isnowdc = sp->d_isnowdc; ra.dtms = sp->d_dtms; ra.isnowac = sp->d_ac; ra.isnowag = sp->d_ag;
+    hipLaunchKernelGGL(k_snow_redistribute, dim3(gridN), dim3(256), 0, nullptr, ra);
+    S_TRY(hipGetLastError());
+    if (timing) {
+        S_TRY(hipEventRecord(evs.e[1], nullptr));
+        S_TRY(hipEventSynchronize(evs.e[1]));
+        float ms = 0;
+        S_TRY(hipEventElapsedTime(&ms, evs.e[0], evs.e[1]));
+        sp->t_model += ms;
+    }
+    double* hostv[5] = {out->Tc, out->Tg, out->groundsnowdepth, out->totalSWE, out->snowden};
+    double* devv[5] = {a.Tc, a.Tg, a.sdepg, a.sdepc, a.sden};
+    for (int v = 0; v < 5; ++v)
+        if (hostv[v]) S_TRY(hipMemcpy(hostv[v] + (int64_t)k0 * N, devv[v], (size_t)ns * N * 8, hipMemcpyDeviceToHost));
+    if (ch == sp->nchunks - 1) {   // steps that no chunk covers stay NA (R pre-fills its arrays, int:2554-2558)
+        union { uint64_t u; double d; } na; na.u = kNaRealBits;
+        const int covered = std::min(sp->T, sp->nchunks * sp->chunk);
+        for (double* h : hostv)
+            if (h) for (int64_t q = (int64_t)covered * N; q < (int64_t)sp->T * N; ++q) h[q] = na.d;
+    }
+    sp->prepared = -1;
     return MCF_OK;
 }
 
-}  // namespace
-
 extern "C" int mcf_snowmodel1(const mcf_snowdriver_in* in, mcf_snowdriver_out* out, int32_t device) {
-    return run_snowdriver(in, out, device);
+    if (!out) return mcf::api_fail(MCF_ERR_ARG, "null snow driver argument");
+    mcf_snowplan* sp = nullptr;
+    int rc = mcf_snowplan_create(in, 0, 0, device, &sp);
+    if (rc) return rc;
+    struct Guard { mcf_snowplan* p; ~Guard() { mcf_snowplan_destroy(p); } } guard{sp};
+    const int64_t me = std::min(sp->rows_total, sp->cols);
+    for (int ch = 0; ch < sp->nchunks; ++ch) {
+        int af;
+        if ((rc = chunk_af(sp, ch, &af))) return rc;
+        double mean = 0.0, s = 0.0, n = 0.0;
+        if (!((double)af < me / 2.0)) {            // .tpicalc's raster-mean branch
+            if ((rc = mcf_snowplan_surface_partial(sp, &s, &n))) return rc;
+            mean = s / n;
+        }
+        if ((rc = mcf_snowplan_prepare_chunk(sp, ch, nullptr, 0, 0, mean, &s, &n))) return rc;
+        if ((rc = mcf_snowplan_run_chunk(sp, ch, s / n, out))) return rc;
+    }
+    if (getenv("MCF_TIMING"))
+        fprintf(stderr, "[mcf] snowmodel1: %d chunks of %d steps, %lld cells: terrain + tpi %.2f ms, gridmodelsnow + "
+                "redistribute %.2f ms\n", sp->nchunks, sp->chunk, (long long)sp->N, sp->t_terrain, sp->t_model);
+    return MCF_OK;
 }
 
 extern "C" int mcf_applycpp3(const double* a, int64_t rows, int64_t cols, int64_t tsteps, int32_t fun, double* result,

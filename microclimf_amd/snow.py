@@ -282,3 +282,96 @@ def merge_snow_outputs(moutn: Mapping, mouts: Mapping, snowdays, nosnowdays, row
         a[:, :, snowh] = np.asarray(mouts[k])
         out[k] = a
     return out
+
+
+class SnowPlan:
+    """One rank's row block of `.snowmodel1`'s chunk loop, resident on the device (include/mcf.h
+    mcf_snowplan_*).  Arguments as snowmodel1_chunks, for the block's own rows; `row0` / `rows_total`
+    place the block in the raster."""
+
+    def __init__(self, obstime, climdata, pointm, vegp, other, snowenv, dtm, res, tfact=0.02, *, chunk_steps=120,
+                 row0=0, rows_total=0, device=0):
+        self._lib = _abi.load()
+        R, Cc = np.shape(vegp["pai"])
+        oth = dict(other)
+        for k, shp in (("slope", (R, Cc)), ("aspect", (R, Cc)), ("skyview", (R, Cc)), ("wsa", (R, Cc, 8)),
+                       ("hor", (R, Cc, 24))):
+            oth.setdefault(k, np.zeros(shp))
+        self._m = marshal_snow(obstime, climdata, vegp, oth, False, pointm=pointm, snowenv=snowenv)
+        din = _abi.SnowDriverIn()
+        din.base = self._m.inputs
+        din.dtm = self._m.f64(dtm, (R, Cc), "dtm")
+        din.res, din.tfact, din.chunk_steps = float(res), float(tfact), int(chunk_steps)
+        self._p = C.c_void_p()
+        _abi.check(self._lib.mcf_snowplan_create(C.byref(din), int(row0), int(rows_total), device, C.byref(self._p)))
+        self.rows, self.cols, self.tsteps = R, Cc, self._m.tsteps
+        self.chunks = int(self._lib.mcf_snowplan_chunks(self._p))
+        self._out = _abi.SnowDriverOut()
+        self.result = {}
+        for f in _abi.SNOWDRIVER_OUT:
+            a = np.empty((R, Cc, self.tsteps), dtype=np.float64, order="F")
+            self.result[f] = a
+            setattr(self._out, f, a.ctypes.data_as(_abi.c_double_p))
+
+    def close(self):
+        if getattr(self, "_p", None) is not None and self._p.value:
+            self._lib.mcf_snowplan_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def surface(self) -> np.ndarray:
+        a = np.empty((self.rows, self.cols), dtype=np.float64, order="F")
+        _abi.check(self._lib.mcf_snowplan_surface(self._p, a.ctypes.data_as(_abi.c_double_p)))
+        return a
+
+    def surface_partial(self):
+        s, n = C.c_double(), C.c_double()
+        _abi.check(self._lib.mcf_snowplan_surface_partial(self._p, C.byref(s), C.byref(n)))
+        return s.value, n.value
+
+    def prepare_chunk(self, chunk: int, ext=None, halo_north: int = 0, halo_south: int = 0, surface_mean: float = 0.0):
+        s, n = C.c_double(), C.c_double()
+        p = None
+        if ext is not None:
+            e = np.asfortranarray(np.asarray(ext, dtype=np.float64))
+            if e.shape != (halo_north + self.rows + halo_south, self.cols):
+                raise ValueError("ext must be [halo_north + rows + halo_south, cols]")
+            p = e.ctypes.data_as(_abi.c_double_p)
+        _abi.check(self._lib.mcf_snowplan_prepare_chunk(self._p, int(chunk), p, int(halo_north), int(halo_south),
+                                                        float(surface_mean), C.byref(s), C.byref(n)))
+        return s.value, n.value
+
+    def run_chunk(self, chunk: int, tpic_mean: float):
+        _abi.check(self._lib.mcf_snowplan_run_chunk(self._p, int(chunk), float(tpic_mean), C.byref(self._out)))
+
+
+def snowmodel1_chunks_tiled(plan, rank: int, world: int, *, exchange=None, allreduce=None) -> dict:
+    """Drives one rank's SnowPlan through the chunk loop of a row-tiled raster: per chunk a halo exchange of
+    the snow surface (terrain.exchange_halo, point-to-point between neighbouring ranks) and two (sum, count)
+    all-reduces (the raster means of the surface and of tpic).  `exchange` / `allreduce` are injectable for
+    tests; the defaults use torch.distributed (RCCL when the backend is nccl)."""
+    from .terrain import exchange_halo
+    from .distributed import allreduce_twi_mean
+    if exchange is None:
+        exchange = lambda blk: exchange_halo(blk, rank, world)          # noqa: E731
+    if allreduce is None:
+        allreduce = allreduce_twi_mean                                    # (sum, count) -> global mean
+    for ch in range(plan.chunks):
+        surf = plan.surface()
+        ext, hn, hs = exchange(surf)
+        s, n = plan.surface_partial()
+        smean = allreduce(s, n)
+        ts, tn = plan.prepare_chunk(ch, ext if (hn or hs) else None, hn, hs, smean)
+        plan.run_chunk(ch, allreduce(ts, tn))
+    return plan.result

@@ -156,3 +156,78 @@ def test_applycpp3_partials_combine_over_two_ranks():
         for f in want:
             assert np.allclose(out[f], want[f], rtol=1e-13, equal_nan=True), (rank, f)
     assert np.isneginf(want["max"][7]) and np.isposinf(want["min"][7]) and np.isnan(want["mean"][7])
+
+
+class _FakeSnowPlan:
+    """Stands in for microclimf_amd.snow.SnowPlan (which needs a GPU): a surface that changes per chunk, the
+    same partial sums, and checks that the halo rows handed to prepare_chunk are the neighbours' rows."""
+
+    def __init__(self, rank, world, rows_total, cols, chunks):
+        self.rank, self.world, self.cols, self.chunks = rank, world, cols, chunks
+        self.row0, self.rows = row_block(rank, world, rows_total)
+        self.rows_total = rows_total
+        self.t = 0
+        self.means = []
+        self.result = {"log": self.means}
+
+    def _global(self):
+        i = np.arange(self.rows_total, dtype=np.float64)[:, None]
+        j = np.arange(self.cols, dtype=np.float64)[None, :]
+        return 100 + np.sin(i / 7.0) * 5 + j * 0.1 + self.t
+
+    def surface(self):
+        return np.asfortranarray(self._global()[self.row0:self.row0 + self.rows])
+
+    def surface_partial(self):
+        s = self.surface()
+        return float(s.sum()), float(s.size)
+
+    def prepare_chunk(self, ch, ext, hn, hs, smean):
+        g = self._global()
+        want = g[self.row0 - hn:self.row0 + self.rows + hs]
+        assert ext is not None and np.array_equal(np.asarray(ext), want), "halo rows are not the neighbours' rows"
+        assert abs(smean - g.mean()) < 1e-12
+        t = np.exp((smean - self.surface()) * 0.02)
+        return float(t.sum()), float(t.size)
+
+    def run_chunk(self, ch, tmean):
+        self.means.append(tmean)
+        self.t += 1
+
+
+def _snowtile_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from microclimf_amd.snow import snowmodel1_chunks_tiled
+        plan = _FakeSnowPlan(rank, world, 301, 9, 3)
+        res = snowmodel1_chunks_tiled(plan, rank, world)
+        q.put((rank, list(res["log"])))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_snow_chunk_loop_collectives_over_two_ranks():
+    """snowmodel1_chunks_tiled: per chunk one point-to-point halo exchange of the snow surface and two (sum, count)
+    all-reduces; both ranks end up with the raster-wide tpic mean of every chunk"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_snowtile_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = _FakeSnowPlan(0, 1, 301, 9, 3)
+    want = []
+    for _ in range(3):
+        g = ref._global()
+        want.append(float(np.exp((g.mean() - g) * 0.02).mean()))
+        ref.t += 1
+    for rank in range(world):
+        assert np.allclose(got[rank], want, rtol=1e-13), rank

@@ -136,6 +136,53 @@ def test_snowmodel1_chunk_loop_matches_oracle(oracle, case):
         assert (got["Tc"][:, :, covered:].view(np.uint64) == NA_BITS).all()
 
 
+@pytest.mark.parametrize("rows,cols,split", [(300, 40, 150), (290, 30, 160)])
+def test_snowplan_two_row_blocks_equal_the_whole_raster(rows, cols, split):
+    """the tiled chunk loop on one GPU: two SnowPlans (north / south row blocks) that exchange surface halos and
+    add their (sum, count) partials by hand reproduce the single-plan run of the whole raster (cols = 30 takes
+    .tpicalc's raster-mean branch: af = 17 >= min(dim) / 2)"""
+    from microclimf_amd.snow import SnowPlan, snowmodel1_chunks
+    sw, dtm = _driver_case(rows, cols, 240)
+    args = (sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"], sw["other"], sw["snowenv"])
+    whole = snowmodel1_chunks(*args, dtm, 1.0, 0.02)
+
+    def block(sl):
+        veg = {k: v[sl] for k, v in sw["vegp"].items()}
+        oth = {k: (v[sl] if isinstance(v, np.ndarray) and v.ndim >= 2 else v) for k, v in sw["other"].items()}
+        return SnowPlan(sw["obstime"], sw["climdata"], sw["pointm"], veg, oth, sw["snowenv"], dtm[sl], 1.0, 0.02,
+                        row0=sl.start, rows_total=rows)
+
+    H = 128
+    with block(slice(0, split)) as pa, block(slice(split, rows)) as pb:
+        assert pa.chunks == pb.chunks == 2
+        for ch in range(pa.chunks):
+            sa, sb = pa.surface(), pb.surface()
+            (s1, n1), (s2, n2) = pa.surface_partial(), pb.surface_partial()
+            smean = (s1 + s2) / (n1 + n2)
+            ta = pa.prepare_chunk(ch, np.concatenate([sa, sb[:H]], axis=0), 0, min(H, rows - split), smean)
+            tb = pb.prepare_chunk(ch, np.concatenate([sa[-H:], sb], axis=0), min(H, split), 0, smean)
+            tmean = (ta[0] + tb[0]) / (ta[1] + tb[1])
+            pa.run_chunk(ch, tmean)
+            pb.run_chunk(ch, tmean)
+        for k, w in whole.items():
+            got = np.concatenate([pa.result[k], pb.result[k]], axis=0)
+            assert_close(got, w, 1e-9, k)
+
+
+def test_snowplan_checks_halo_and_order():
+    from microclimf_amd.snow import SnowPlan
+    sw, dtm = _driver_case(200, 24, 48)
+    sl = slice(0, 100)
+    veg = {k: v[sl] for k, v in sw["vegp"].items()}
+    oth = {k: (v[sl] if isinstance(v, np.ndarray) and v.ndim >= 2 else v) for k, v in sw["other"].items()}
+    with SnowPlan(sw["obstime"], sw["climdata"], sw["pointm"], veg, oth, sw["snowenv"], dtm[sl], 1.0, 0.02,
+                  chunk_steps=48, row0=0, rows_total=200) as p:
+        with pytest.raises(_abi.McfError, match="halo rows"):
+            p.prepare_chunk(0)                                  # a southern neighbour exists: halo required
+        with pytest.raises(_abi.McfError, match="prepare_chunk"):
+            p.run_chunk(0, 1.0)
+
+
 def test_snowmodel1_rejects_zero_aggregation_factor():
     from microclimf_amd.snow import snowmodel1_chunks
     sw, dtm = _driver_case(12, 12, 48)
