@@ -20,6 +20,9 @@
 #ifndef MCF_HOUR_PERMUTE
 #define MCF_HOUR_PERMUTE 1
 #endif
+#ifndef MCF_AF_WAVES
+#define MCF_AF_WAVES 3   // waves per SIMD the array-forcing kernels are built for (168 VGPRs)
+#endif
 #ifndef MCF_HOUR_ROTATE
 #define MCF_HOUR_ROTATE 1
 #endif
@@ -362,7 +365,7 @@ constexpr int solve_threads(int cpb) { return ((cpb * 24 + 255) / 256) * 256; }
 template <int CPB, bool AF, bool BG>
 // array forcing keeps ~17 more doubles live per lane (forcing values instead of an LDS table):
 // it is built for 3 waves/SIMD (168 VGPRs, no scratch) and run with 32-cell workgroups
-__global__ __launch_bounds__(solve_threads(CPB), AF ? 3 : MCF_WAVES_PER_EU) void k_solve(SolveArgs a) {
+__global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_PER_EU) void k_solve(SolveArgs a) {
     constexpr int NT = solve_threads(CPB);
     __shared__ double s_cell[CF_COUNT * CPB];
     __shared__ double s_dirs[kCellDirs * CPB];
