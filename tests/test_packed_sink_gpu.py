@@ -54,3 +54,23 @@ def test_packed_fetch_round_half_even_and_range():
         s = 2.5 / v
         got = p.fetch_packed(0, "Rlwdown", 0, 24, scale=s)[4, 3, 7]
         assert got == int(np.rint(v * s))
+
+
+def test_large_fetch_through_the_host_pipe_is_bitwise_the_plain_copy():
+    """fetches of >= 64 MB go through the pinned ring + host copy threads (mcf_hostpipe.hpp); smaller ones through
+    a plain hipMemcpy: the same slot fetched both ways must be bit-identical, including odd tail sizes"""
+    rows, cols, T = 500, 517, 48
+    a = synthetic.workload(rows, cols, T, reqhgt=0.05, start_doy=100, out=[1, 0, 0, 1, 0, 0, 0, 0, 0, 0])
+    with Plan(a["obstime"], a["climdata"], a["pointm"], a["vegp"], a["soilc"], a["reqhgt"], a["zref"], a["lat"],
+              a["lon"], a["Sminp"], a["Smaxp"], a["tfact"], True, a["mat"], a["out"], ring_days=2) as p:
+        p.run_days(0, 2)
+        p.sync()
+        for var in ("Tz", "soilm"):
+            big = p.fetch(0, var, 0, T)                                   # 99 MB: host pipe
+            assert big.nbytes >= 64 << 20
+            parts = [p.fetch(0, var, k, 8) for k in range(0, T, 8)]       # 16.5 MB each: plain copies
+            assert parts[0].nbytes < 64 << 20
+            small = np.concatenate(parts, axis=2)
+            assert np.array_equal(big.view(np.uint64), small.view(np.uint64)), var
+            odd = p.fetch(0, var, 3, 41)                                   # 84.8 MB, not a multiple of the piece size
+            assert np.array_equal(odd.view(np.uint64), small[:, :, 3:44].view(np.uint64)), var
