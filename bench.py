@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--ring-slots", type=int, default=2)
     ap.add_argument("--cells-per-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=str, default="96x96x720")
+    ap.add_argument("--cpu-sample", type=str, default="144x144x720")
     ap.add_argument("--terrain", choices=["random", "device"], default="random",
                     help="'device': slope/aspect/hor/svfa/wsa come from mcf_precompute_terrain run on the "
                          "synthetic DTM (BASELINE.json configs[2]); 'random': SURVEY 8d's random terrain inputs")
