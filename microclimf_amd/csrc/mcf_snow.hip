@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/mcf.h"
+#include "mcf_hostpipe.hpp"
 #include "mcf_snow_device.hpp"
 #include "mcf_terrain.h"
 
@@ -595,6 +596,24 @@ struct Bufs {
         return MCF_OK;
     }
 };
+// device -> caller-owned pageable memory; large results through the pinned ring + copy threads (mcf_hostpipe.hpp)
+struct Downloader {
+    mcf::HostPipe pipe;
+    bool tried = false, ok = false;
+    hipError_t get(void* dst, const void* dev, size_t bytes) {
+        static const bool no_pipe = getenv("MCF_NO_HOSTPIPE") != nullptr;
+        if (bytes >= ((size_t)64 << 20) && !no_pipe) {
+            if (!tried) { tried = true; ok = pipe.init(); }
+            if (ok) {
+                hipError_t e = hipDeviceSynchronize();      // the producers ran on the null stream
+                if (e != hipSuccess) return e;
+                return pipe.copy(dst, dev, bytes, nullptr);
+            }
+        }
+        return hipMemcpy(dst, dev, bytes, hipMemcpyDeviceToHost);
+    }
+};
+
 #define UP(dst, src, n) do { if ((rc = b.up(&(dst), (src), (n), #src))) return rc; } while (0)
 
 int pick_device(int32_t device) {
@@ -760,8 +779,9 @@ int run_snowmodel(const mcf_snow_inputs* in, mcf_snowmodel_out* out, int32_t dev
         fprintf(stderr, "[mcf] k_snowmodel<%d>: %lld cells x %d steps in %.3f ms (%.3e cell-steps/s)\n", (int)af,
                 (long long)N, T, ms, (double)NT / (ms * 1e-3));
     }
+    Downloader dl;
     for (int v = 0; v < 5; ++v)
-        if (host3[v]) S_TRY(hipMemcpy(host3[v], *dev3[v], (size_t)NT * 8, hipMemcpyDeviceToHost));
+        if (host3[v]) S_TRY(dl.get(host3[v], *dev3[v], (size_t)NT * 8));
     for (int v = 0; v < 4; ++v)
         if (host2[v]) S_TRY(hipMemcpy(host2[v], *dev2[v], (size_t)N * 8, hipMemcpyDeviceToHost));
     S_TRY(hipDeviceSynchronize());
@@ -845,8 +865,9 @@ int run_microsnow(const mcf_snow_inputs* in, const mcf_snowm* sm, double reqhgt,
         hipLaunchKernelGGL(k_microsnow<false>, dim3(gridD), dim3(256), 0, nullptr, a);
     }
     S_TRY(hipGetLastError());
+    Downloader dl;
     for (int v = 0; v < MCF_NOUT; ++v)
-        if (outsel[v]) S_TRY(hipMemcpy(micro->var[v], a.out[v], (size_t)NT * 8, hipMemcpyDeviceToHost));
+        if (outsel[v]) S_TRY(dl.get(micro->var[v], a.out[v], (size_t)NT * 8));
     S_TRY(hipDeviceSynchronize());
     return MCF_OK;
 }
@@ -870,6 +891,7 @@ struct mcf_snowplan {
     int64_t ext_cap = 0, cm_cap = 0;
     int32_t *d_ac = nullptr, *d_ag = nullptr;
     std::vector<double> wind;
+    Downloader dl;
     int prepared = -1;
     double t_terrain = 0, t_model = 0;   // ms, MCF_TIMING
 };
@@ -1096,7 +1118,7 @@ extern "C" int mcf_snowplan_run_chunk(mcf_snowplan* sp, int32_t ch, double tpic_
     double* hostv[5] = {out->Tc, out->Tg, out->groundsnowdepth, out->totalSWE, out->snowden};
     double* devv[5] = {a.Tc, a.Tg, a.sdepg, a.sdepc, a.sden};
     for (int v = 0; v < 5; ++v)
-        if (hostv[v]) S_TRY(hipMemcpy(hostv[v] + (int64_t)k0 * N, devv[v], (size_t)ns * N * 8, hipMemcpyDeviceToHost));
+        if (hostv[v]) S_TRY(sp->dl.get(hostv[v] + (int64_t)k0 * N, devv[v], (size_t)ns * N * 8));
     if (ch == sp->nchunks - 1) {   // steps that no chunk covers stay NA (R pre-fills its arrays, int:2554-2558)
         union { uint64_t u; double d; } na; na.u = kNaRealBits;
         const int covered = std::min(sp->T, sp->nchunks * sp->chunk);
