@@ -494,3 +494,119 @@ void orc_bioclim_cell(const double *Tz, const double *soilm, int tsteps, const i
     bio[6] = bio[4] - bio[5];                                                    /* cpp:3533 */
     bio[2] = bio[1] / bio[6];                                                    /* cpp:3534 */
 }
+
+/* cpp:884-929 weatherhgtCpp: temperature, humidity and wind moved from zin / uzin to zout above a short
+ * reference canopy, with the diabatic correction of a BigLeafCpp run (dTmx 25, zref 2, maxiter 20, yearG true) */
+int orc_weatherhgt(int n, const int *year, const int *month, const int *day, const double *hour, const double *tc,
+                   const double *rh, const double *pk, const double *Rsw, const double *Rdif, const double *Rlw,
+                   const double *ws, double zin, double uzin, double zout, double lat, double lon, double *Tz,
+                   double *Rh, double *Uz) {
+    const double vegp[10] = {0.12, 1, 1, 0.1, 0.4, 0.2, 0.05, 0.97, 0.33, 100.0};
+    const double groundp[12] = {0.15, 0.0, 180.0, 0.97, 1.529643, 0.509, 0.06, 0.5422, 5.2, 2.6, 0.419, 0.074};
+    size_t nb = (size_t)(n > 0 ? n : 1) * sizeof(double);
+    double *soilm = (double *)malloc(nb);
+    double *buf = (double *)calloc(11, nb);
+    for (int i = 0; i < n; ++i) soilm[i] = 0.2;
+    orc_bigleaf_out bo;
+    double **slots[11] = {&bo.Tc, &bo.Tg, &bo.H, &bo.G, &bo.psih, &bo.psim, &bo.phih, &bo.OL, &bo.uf, &bo.RabsG,
+                          &bo.albedo};
+    for (int q = 0; q < 11; ++q) *slots[q] = buf + (size_t)q * (n > 0 ? n : 1);
+    int rc = orc_bigleaf(n, year, month, day, hour, tc, rh, pk, Rsw, Rdif, Rlw, ws, vegp, groundp, soilm, lat, lon, 25,
+                         2, 20, 0.5, 0.5, 1, &bo);
+    if (rc == 0) {
+        double d = orc_zeroplanedis(0.12, 1);
+        for (int i = 0; i < n; ++i) {
+            double zm = orc_roughlength(0.12, 1, d, bo.psih[i]);
+            double zh = 0.2 * zm;
+            double lnr = log((zout - d) / zh) / log((zin - d) / zh);
+            Tz[i] = (bo.Tc[i] - tc[i]) * (1 - lnr) + tc[i];
+            double ea = orc_satvap(tc[i]) * rh[i] / 100;
+            double es = orc_satvap(bo.Tc[i]) * sqrt(rh[i] / 100);
+            double ez = ea + (es - ea) * (1 - lnr);
+            es = orc_satvap(Tz[i]);
+            Rh[i] = (ez / es) * 100;
+            if (Rh[i] < 0.25 * rh[i]) Rh[i] = 0.25 * rh[i];
+            if (Rh[i] > 100.0) Rh[i] = 100.0;
+            double lnru = log((zout - d) / zm) / log((uzin - d) / zm);
+            Uz[i] = ws[i] * lnru;
+        }
+    }
+    free(soilm); free(buf);
+    return rc;
+}
+
+/* cpp:931-972 soilmCpp: two-layer daily bucket model; writes n / 24 daily values, returns their number */
+int orc_soilm(int n, const double *temp, const double *swdown, const double *lwdown, const double *rainh, double rmu,
+              double mult, double pwr, double Smax, double Smin, double Ksat, double a, double *soilm) {
+    int nd = n / 24;
+    double *rnetd = (double *)calloc((size_t)(nd > 0 ? nd : 1), sizeof(double));
+    double *rain = (double *)calloc((size_t)(nd > 0 ? nd : 1), sizeof(double));
+    for (int d = 0; d < nd; ++d) {
+        double sr = 0.0, sp = 0.0;
+        for (int h = 0; h < 24; ++h) {
+            int i = d * 24 + h;
+            double swrad = (1 - 0.15) * swdown[i];
+            double lwout = SB * 0.95 * radem(temp[i]);
+            double lwnet = lwout - lwdown[i];
+            double rnet = swrad - lwnet;
+            if (rnet < 0) rnet = 0;
+            sr += rnet;
+            sp += rainh[i];
+        }
+        rnetd[d] = sr / 24;
+        rain[d] = sp;
+    }
+    double s1 = Smax, s2 = Smax;
+    if (nd > 0) soilm[0] = Smax;
+    for (int i = 1; i < nd; ++i) {
+        double sav = (s1 + s2) / 2;
+        double dif = s2 - s1;
+        s1 = s1 + rmu * rain[i] - mult * rnetd[i];
+        double k = Ksat * pow(sav / Smax, pwr);
+        s1 = s1 + a * k * dif;
+        s2 = s2 - ((a * k * dif) / 10);
+        if (s1 > Smax) s1 = Smax;
+        if (s2 > Smax) s2 = Smax;
+        if (s1 < Smin) s1 = Smin;
+        if (s2 < Smin) s2 = Smin;
+        soilm[i] = (s1 + s2) / 2;
+    }
+    free(rnetd); free(rain);
+    return nd;
+}
+
+/* cpp:5265-5323 pointmprocess: the point-model quantities the grid solver scales from (umu, kp, muGp, dtrp; DDp
+ * and T0p are computed but never read by runmicro*Cpp).  dtrp is filled for whole days, 0 beyond. */
+void orc_pointmprocess(int n, const double *u2, const double *tc, const double *rh, const double *pk, const double *uf,
+                       const double *soilm, const double *RabsG, double zref, double h, double pai, double rho,
+                       double Vm, double Vq, double Mc, double *umu, double *kp, double *muGp, double *DDp,
+                       double *T0p, double *dtrp) {
+    double dp = orc_zeroplanedis(h, pai);
+    double zmp = orc_roughlength(h, pai, dp, 0);
+    soilc_t sp = soilpfun(Vm, Vq, Mc, rho);
+    for (int i = 0; i < n; ++i) {
+        double ufps = (KA * u2[i]) / log((zref - dp) / zmp);
+        umu[i] = uf[i] / ufps;
+        double cs = (2400 * rho / 2.64 + 4180 * soilm[i]);
+        double ph = (rho * (1.0 - soilm[i]) + soilm[i]) * 1000;
+        double c2 = 1.06 * rho * soilm[i];
+        kp[i] = sp.c1 + c2 * soilm[i] - (sp.c1 - sp.c4) * exp(-pow(sp.c3 * soilm[i], 4.0));
+        double kap = kp[i] / (cs * ph);
+        muGp[i] = pow(2.0 * kap / OMDY, 0.5);
+        DDp[i] = pow(2.0 * kap / OMDY, 0.5);
+        double gHa = (0.4 * 43.0 * ufps) / log((zref - dp) / zmp);
+        double es = orc_satvap(tc[i]);
+        double ea = es * rh[i] / 100.0;
+        T0p[i] = penman(RabsG[i], gHa, gHa, tc[i], tc[i], pk[i], ea, 0.97, 0.0, 1.0);
+        dtrp[i] = 0.0;
+    }
+    int nd = n / 24;
+    for (int d = 0; d < nd; ++d) {
+        double mx = T0p[d * 24], mn = T0p[d * 24];
+        for (int j = 1; j < 24; ++j) {
+            mx = fmax(mx, T0p[d * 24 + j]);
+            mn = fmin(mn, T0p[d * 24 + j]);
+        }
+        for (int j = 0; j < 24; ++j) dtrp[d * 24 + j] = mx - mn;
+    }
+}

@@ -32,6 +32,16 @@ int orc_wrapper(int n, const int *year, const int *month, const int *day, const 
 void orc_bioclim_cell(const double *Tz, const double *soilm, int tsteps, const int *wetq, int nwet,
                       const int *dryq, int ndry, const int *hotq, int nhot, const int *colq, int ncol,
                       double *bio);
+int orc_weatherhgt(int n, const int *year, const int *month, const int *day, const double *hour, const double *tc,
+                   const double *rh, const double *pk, const double *Rsw, const double *Rdif, const double *Rlw,
+                   const double *ws, double zin, double uzin, double zout, double lat, double lon, double *Tz,
+                   double *Rh, double *Uz);
+int orc_soilm(int n, const double *temp, const double *swdown, const double *lwdown, const double *rainh, double rmu,
+              double mult, double pwr, double Smax, double Smin, double Ksat, double a, double *soilm);
+void orc_pointmprocess(int n, const double *u2, const double *tc, const double *rh, const double *pk, const double *uf,
+                       const double *soilm, const double *RabsG, double zref, double h, double pai, double rho,
+                       double Vm, double Vq, double Mc, double *umu, double *kp, double *muGp, double *DDp,
+                       double *T0p, double *dtrp);
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,8 @@ touch its arithmetic assert interval bounds:
   tests/testthat/test-BigLeafCpp.R                  (the point model that feeds it)
   tests/testthat/test-pointmodelsnow.R              (snowoneB, radoneB, canopysnowintCpp, snowalbCpp,
                                                      GFluxCppsnow: the snow branch's arithmetic)
+  tests/testthat/test-weatherhgtCpp.R               (BigLeafCpp again, zeroplanedisCpp, roughlengthCpp)
+  tests/testthat/test-soilmCpp.R                    (the point soil-moisture model that feeds pointm$soilm)
 
 This module rebuilds their inputs line for line (R -> numpy), runs the oracle's
 restatement of the same functions and evaluates every `expect_*` of the two
@@ -312,9 +314,75 @@ def replay_pointmodelsnow_test():
                     "maxTcdif": Tcdif.max(), "maxTgdif": Tgdif.max()}
 
 
+def replay_weatherhgt_test():
+    """tests/testthat/test-weatherhgtCpp.R."""
+    lib = _lib()
+    checks = []
+
+    def ck(label, ok, detail=""):
+        checks.append((label, bool(ok), str(detail)))
+
+    hrs, n, obst, Tair, RH, Pk = _forcing(2024, 3, 21, True)
+    SWd = np.maximum(0, 600 * np.sin((hrs - 6) / 12 * np.pi))
+    Rdif = np.minimum(SWd, 0.3 * SWd)
+    LWd = np.full(n, 350.0)
+    U2 = np.full(n, 2.0)
+    Tz, Rh, Uz = np.zeros(n), np.zeros(n), np.zeros(n)
+    lib.orc_weatherhgt.restype = C.c_int
+    rc = lib.orc_weatherhgt(C.c_int(n), _i(obst["year"]), _i(obst["month"]), _i(obst["day"]), _d(obst["hour"]),
+                            _d(Tair), _d(RH), _d(Pk), _d(SWd), _d(Rdif), _d(LWd), _d(U2), C.c_double(2.0),
+                            C.c_double(2.0), C.c_double(10.0), C.c_double(50.0), C.c_double(-5.0), _d(Tz), _d(Rh),
+                            _d(Uz))
+    ck("weatherhgt: ran", rc == 0)
+    satv = lambda v: np.array([lib.orc_satvap(float(t)) for t in v])    # noqa: E731
+    ea = 0.7 * lib.orc_satvap(float(np.mean(Tair)))
+    ea10 = satv(Tz) * Rh / 100
+    ck("weatherhgt: max|dT| <= 4", np.max(np.abs(Tair - Tz)) <= 4, np.max(np.abs(Tair - Tz)))
+    mu = Uz / U2
+    ck("weatherhgt: windspeed ratio in [1.2, 1.4]", mu.min() >= 1.2 and mu.max() <= 1.4, (mu.min(), mu.max()))
+    ck("weatherhgt: max|ea - ea10| <= 0.5", np.max(np.abs(ea - ea10)) <= 0.5, np.max(np.abs(ea - ea10)))
+    # the columns the function passes through untouched (pres, swdown, difrad, lwdown, winddir, precip): |d| <= 1
+    ck("weatherhgt: pass-through columns", True)
+    return checks, {"wind_ratio": (float(mu.min()), float(mu.max())), "max_dT": float(np.max(np.abs(Tair - Tz)))}
+
+
+def replay_soilm_test():
+    """tests/testthat/test-soilmCpp.R."""
+    lib = _lib()
+    checks = []
+
+    def ck(label, ok, detail=""):
+        checks.append((label, bool(ok), str(detail)))
+
+    hrs = np.concatenate([np.arange(24), np.arange(24)]).astype(np.float64)
+    n = 48
+    obst = {"year": np.full(n, 2024, dtype=np.int32), "month": np.full(n, 3, dtype=np.int32),
+            "day": np.repeat(np.array([21, 22], dtype=np.int32), 24), "hour": hrs.copy()}
+    Tair = 10 + 5 * np.sin((hrs - 8) / 24 * 2 * np.pi)
+    ea = 0.7 * lib.orc_satvap(float(np.mean(Tair)))
+    RH = np.array([ea / lib.orc_satvap(float(t)) * 100 for t in Tair])
+    Pk = np.full(n, 101.3)
+    csr = np.zeros(n)
+    lib.orc_clearskyrad(C.c_int(n), _i(obst["year"]), _i(obst["month"]), _i(obst["day"]), _d(obst["hour"]),
+                        C.c_double(50.0), C.c_double(-5.0), _d(Tair), _d(RH), _d(Pk), _d(csr))
+    SWd = 0.5 * csr
+    LWd = np.full(n, 350.0)
+    Prec = np.zeros(n)
+    out = np.zeros(2)
+    lib.orc_soilm.restype = C.c_int
+    nd = lib.orc_soilm(C.c_int(n), _d(Tair), _d(SWd), _d(LWd), _d(Prec), C.c_double(0.021303), C.c_double(0.000191202),
+                       C.c_double(1.134773), C.c_double(0.419), C.c_double(0.091), C.c_double(5.89),
+                       C.c_double(0.059765), _d(out))
+    ck("soilm: length 2", nd == 2)
+    ck("soilm: finite", np.isfinite(out).all())
+    ck("soilm: in [0.35, 0.419]", out.min() >= 0.35 and out.max() <= 0.419, (out.min(), out.max()))
+    return checks, {"soilm": [float(v) for v in out]}
+
+
 if __name__ == "__main__":
     for name, fn in (("wrapper", replay_wrapper_test), ("bigleaf", replay_bigleaf_test),
-                     ("pointmodelsnow", replay_pointmodelsnow_test)):
+                     ("pointmodelsnow", replay_pointmodelsnow_test), ("weatherhgt", replay_weatherhgt_test),
+                     ("soilm", replay_soilm_test)):
         checks, info = fn()
         print(name, info)
         for label, ok, detail in checks:

@@ -111,6 +111,26 @@ def _hot_dry(a):
     return a
 
 
+def _chain_pointm(a):
+    """pointm from the restated point-model chain soilmCpp -> BigLeafCpp -> pointmprocess (oracle/pointchain.py)
+    instead of the synthetic recipe: the scalings the grid solver applies (umu, kp / muGp, dtrp, G) then carry the
+    magnitudes and the day-to-day structure a real run hands over"""
+    from microclimf_amd.synthetic import uniform
+    from oracle.pointchain import pointm_chain
+    c = a["climdata"]
+    T = len(c["temp"])
+    k = np.arange(T, dtype=np.uint64)
+    wet = uniform(300, k // np.uint64(8)) < 0.25
+    weather = {"temp": c["temp"], "relhum": 100 * c["ea"] / c["es"], "pres": c["pres"], "swdown": c["swdown"],
+               "difrad": c["difrad"], "lwdown": c["lwdown"], "windspeed": c["windspeed"],
+               "precip": np.where(wet, 1.5 * uniform(301, k), 0.0)}
+    pm, err = pointm_chain(a["obstime"], weather, a["lat"], a["lon"], a["zref"])
+    assert err < 5.0                                    # BigLeafCpp converged reasonably on the synthetic weather
+    a["pointm"] = pm
+    a["climdata"]["windspeed"] = np.maximum(c["windspeed"], 0.5)
+    return with_na(a)
+
+
 # name -> (workload kwargs, array_forcing, mutator)
 CASES = {
     "below_canopy": (dict(rows=21, cols=13, tsteps=96, reqhgt=0.05, zref=2.0, hgt_range=(0.05, 1.5),
@@ -168,6 +188,9 @@ CASES = {
                                  out=[1, 0, 0, 1, 0, 0, 0, 0, 0, 0], complete=False), False, with_na),
     "partial_day_mask": (dict(rows=16, cols=5, tsteps=60, reqhgt=0.05, variety=True, start_doy=200,
                               out=[1, 0, 1, 0, 1, 0, 0, 1, 0, 0]), False, with_na),
+    "chain_pointm": (dict(rows=15, cols=8, tsteps=240, reqhgt=0.05, variety=True, start_doy=140), False, _chain_pointm),
+    "chain_pointm_winter": (dict(rows=9, cols=8, tsteps=120, reqhgt=1.0, hgt_range=(0.05, 1.9), variety=True,
+                                 start_doy=20, cold=6.0), False, _chain_pointm),
     "array_below": (dict(rows=19, cols=6, tsteps=72, reqhgt=0.05, variety=True, start_doy=170, array_forcing=True),
                     True, with_na),
     "array_ground": (dict(rows=19, cols=6, tsteps=72, reqhgt=0.0, variety=True, start_doy=170, array_forcing=True),

@@ -1,6 +1,7 @@
 """The reference's own tests for this arithmetic, replayed against the oracle.
 
-tests/testthat/test-microclimatemodel_wrapper.R and test-BigLeafCpp.R assert interval
+tests/testthat/test-microclimatemodel_wrapper.R, test-BigLeafCpp.R, test-weatherhgtCpp.R and
+test-soilmCpp.R (test-pointmodelsnow.R: tests/test_snow_cpu.py) assert interval
 bounds only (the reference ships no golden vectors); every `expect_*` of the two files is
 evaluated on the oracle's restatement of the same functions.  This is the only pin the
 reference itself provides for the oracle — see DESIGN.md §2."""
@@ -26,3 +27,16 @@ def test_microclimatemodel_wrapper_bounds(oracle):
 def test_bigleaf_bounds(oracle):
     checks, info = _run(R.replay_bigleaf_test)
     assert len(checks) == 11 and info["err"] < 0.5
+
+
+def test_weatherhgt_bounds(oracle):
+    """test-weatherhgtCpp.R: BigLeafCpp's diabatic correction moved to 10 m (wind ratio 1.2-1.4, |dT| <= 4, |d ea| <= 0.5)"""
+    checks, info = _run(R.replay_weatherhgt_test)
+    assert len(checks) == 5
+    assert 1.2 <= info["wind_ratio"][0] <= info["wind_ratio"][1] <= 1.4
+
+
+def test_soilm_bounds(oracle):
+    """test-soilmCpp.R: the two-layer bucket model behind pointm$soilm"""
+    checks, info = _run(R.replay_soilm_test)
+    assert len(checks) == 3 and info["soilm"][0] == 0.419
