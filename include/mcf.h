@@ -412,7 +412,7 @@ int mcf_snowplan_run_chunk(mcf_snowplan *plan, int32_t chunk, double tpic_mean, 
  * reduction of a [rows,cols,tsteps] array over space, per time step, skipping NA.  fun: 0 mean, 1 sum,
  * 2 max, 3 min (max / min of an all-NA step: -Inf / +Inf, mean: NaN).  `count` (optional, [tsteps])
  * receives the number of non-NA cells so that row blocks of a tiled raster can be combined: sum and
- * count add, max / min combine by max / min (microclimf_amd/distributed.py). */
+ * count add, max / min combine by max / min (microclimf_amd/distributed.py).  At most 65535 steps per call. */
 enum { MCF_APPLY_MEAN = 0, MCF_APPLY_SUM = 1, MCF_APPLY_MAX = 2, MCF_APPLY_MIN = 3 };
 int mcf_applycpp3(const double *a, int64_t rows, int64_t cols, int64_t tsteps, int32_t fun, double *result,
                   double *count, int32_t device);

@@ -311,7 +311,7 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
 
     // ---- the one global reduction: mean of log(twi)/tfact, cpp:993-1004
     void* tmp = nullptr;
-    if ((rc = dalloc(p, &tmp, 16))) return rc;
+    if ((rc = dalloc(p, &tmp, (int64_t)mcf::twi_scratch_doubles() * 8))) return rc;
     p->d_twi2 = (double*)tmp;
     mcf::launch_twi_partial(p->d_soil[11], N, opt->tfact, p->d_twi2, p->stream);
     double h2[2];

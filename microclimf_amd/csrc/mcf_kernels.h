@@ -102,7 +102,9 @@ void launch_bioclim(const BioclimArgs& a, hipStream_t s);
 void launch_fill(double* p, int64_t n, double v, hipStream_t s);
 void launch_pack_transpose(const double* src, int64_t rows, int64_t cols, int64_t nsteps, double scale, int32_t* dst,
                            hipStream_t s);
+// out2: twi_scratch_doubles() doubles; [0] = sum, [1] = count on completion
 void launch_twi_partial(const double* twi, int64_t n, double tfact, double* out2, hipStream_t s);
+int twi_scratch_doubles();
 void launch_cell_setup(const CellSetupArgs& a, hipStream_t s);
 void launch_time_setup(const TimeSetupArgs& a, hipStream_t s);
 void launch_date_setup(const DateSetupArgs& a, hipStream_t s);

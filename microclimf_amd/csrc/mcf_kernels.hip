@@ -55,13 +55,15 @@ __global__ void k_fill(double* __restrict__ p, int64_t n, double v) {
 }
 
 // ------------------------------------------------------------------------------------
-// Deterministic single-block reduction: fixed strided partials, then an LDS tree.
-__global__ __launch_bounds__(1024) void k_twi_partial(const double* __restrict__ twi, int64_t n, double tfact,
-                                                      double* __restrict__ out /* [2]: sum, count */) {
-    __shared__ double ssum[1024];
-    __shared__ double scnt[1024];
+// Deterministic two-stage reduction: kTwiParts workgroups reduce fixed strided subsets with a fixed-shape LDS
+// tree into out[2 + 2p], a single lane then adds the partials in order into out[0..1].
+constexpr int kTwiParts = 128;
+__global__ __launch_bounds__(256) void k_twi_partial(const double* __restrict__ twi, int64_t n, double tfact,
+                                                     double* __restrict__ out /* [2 + 2*kTwiParts] */) {
+    __shared__ double ssum[256];
+    __shared__ double scnt[256];
     double s = 0.0, c = 0.0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)kTwiParts * 256) {
         double v = twi[i];
         if (!isnan(v)) {
             s += log(v) / tfact;
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(1024) void k_twi_partial(const double* __restrict__
     ssum[threadIdx.x] = s;
     scnt[threadIdx.x] = c;
     __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
+    for (int w = 128; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) {
             ssum[threadIdx.x] += ssum[threadIdx.x + w];
             scnt[threadIdx.x] += scnt[threadIdx.x + w];
@@ -79,9 +81,16 @@ __global__ __launch_bounds__(1024) void k_twi_partial(const double* __restrict__
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        out[0] = ssum[0];
-        out[1] = scnt[0];
+        out[2 + 2 * blockIdx.x] = ssum[0];
+        out[3 + 2 * blockIdx.x] = scnt[0];
     }
+}
+__global__ void k_twi_finish(double* __restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double s = 0.0, c = 0.0;
+    for (int p = 0; p < kTwiParts; ++p) { s += out[2 + 2 * p]; c += out[3 + 2 * p]; }
+    out[0] = s;
+    out[1] = c;
 }
 
 // ------------------------------------------------------------------------------------
@@ -946,7 +955,8 @@ void launch_fill(double* p, int64_t n, double v, hipStream_t s) {
     hipLaunchKernelGGL(k_fill, dim3((unsigned)blocks), dim3(256), 0, s, p, n, v);
 }
 void launch_twi_partial(const double* twi, int64_t n, double tfact, double* out2, hipStream_t s) {
-    hipLaunchKernelGGL(k_twi_partial, dim3(1), dim3(1024), 0, s, twi, n, tfact, out2);
+    hipLaunchKernelGGL(k_twi_partial, dim3(kTwiParts), dim3(256), 0, s, twi, n, tfact, out2);
+    hipLaunchKernelGGL(k_twi_finish, dim3(1), dim3(64), 0, s, out2);
 }
 void launch_cell_setup(const CellSetupArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_cell_setup, dim3((unsigned)((a.N + 255) / 256)), dim3(256), 0, s, a);
@@ -982,6 +992,7 @@ static void launch_solve_cpb(const SolveArgs& a, bool af, bool bg, hipStream_t s
         else hipLaunchKernelGGL((k_solve<CPB, false, false>), grid, block, 0, s, a);
     }
 }
+int twi_scratch_doubles() { return 2 + 2 * kTwiParts; }
 int cell_field_count() { return CF_COUNT; }
 int time_field_count() { return TF_COUNT; }
 // mincondCpp (cpp:1321-1328): for a fixed stomatal resistance rs, Hlf and Hf are constants and

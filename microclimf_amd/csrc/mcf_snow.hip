@@ -406,22 +406,35 @@ __global__ __launch_bounds__(256) void k_mask2(const double* __restrict__ dtm, i
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < N && isnan(dtm[c])) { a[c] = na_real(); b[c] = na_real(); }
 }
-// deterministic (sum, count) of the non-NaN entries of x, one workgroup
-__global__ __launch_bounds__(1024) void k_sumcount(const double* __restrict__ x, int64_t N, double* __restrict__ out2) {
-    __shared__ double ss[1024];
-    __shared__ double sc[1024];
+// deterministic (sum, count) of the non-NaN entries of x: kSumParts workgroups reduce fixed strided subsets with a
+// fixed-shape tree, workgroup 0 of a second launch adds the partials in order (same result on every run)
+constexpr int kSumParts = 128;
+__global__ __launch_bounds__(256) void k_sumcount_part(const double* __restrict__ x, int64_t N, double* __restrict__ ws) {
+    __shared__ double ss[256];
+    __shared__ double sc[256];
     double s = 0.0, n = 0.0;
-    for (int64_t i = threadIdx.x; i < N; i += 1024) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)kSumParts * 256) {
         const double v = x[i];
         if (!isnan(v)) { s += v; n += 1.0; }
     }
     ss[threadIdx.x] = s; sc[threadIdx.x] = n;
     __syncthreads();
-    for (int w = 512; w > 0; w >>= 1) {
+    for (int w = 128; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) { ss[threadIdx.x] += ss[threadIdx.x + w]; sc[threadIdx.x] += sc[threadIdx.x + w]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out2[0] = ss[0]; out2[1] = sc[0]; }
+    if (threadIdx.x == 0) { ws[2 * blockIdx.x] = ss[0]; ws[2 * blockIdx.x + 1] = sc[0]; }
+}
+__global__ void k_sumcount_fin(const double* __restrict__ ws, double* __restrict__ out2) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    double s = 0.0, n = 0.0;
+    for (int p = 0; p < kSumParts; ++p) { s += ws[2 * p]; n += ws[2 * p + 1]; }
+    out2[0] = s; out2[1] = n;
+}
+// ws: 2 * kSumParts doubles of scratch
+void launch_sumcount(const double* x, int64_t N, double* ws, double* out2) {
+    hipLaunchKernelGGL(k_sumcount_part, dim3(kSumParts), dim3(256), 0, nullptr, x, N, ws);
+    hipLaunchKernelGGL(k_sumcount_fin, dim3(1), dim3(64), 0, nullptr, ws, out2);
 }
 // .tpicalc (int:2471-2485) on a row block of the raster.  `z` is the block's surface (dtm + ground snow) with
 // `hn` halo rows above: row b of z is global row row0 - hn + b; RB rows in all.
@@ -507,41 +520,52 @@ __global__ __launch_bounds__(256) void k_snow_redistribute(RedistArgs a) {
     if (!isnan(a.ageg[c])) a.isnowag[c] = (int32_t)a.ageg[c];
 }
 
-// applycpp3 (cpp:5553-5588): one workgroup per time step, lanes stride over the cells (coalesced),
-// fixed-shape tree in LDS -> deterministic; NaN cells are skipped
-__global__ __launch_bounds__(256) void k_apply3(const double* __restrict__ a, int64_t N, int fun,
-                                                double* __restrict__ result, double* __restrict__ count) {
+// applycpp3 (cpp:5553-5588): `parts` workgroups per time step stream fixed strided subsets of the cells (coalesced),
+// fixed-shape tree in LDS, partials combined in order by a second kernel -> deterministic; NaN cells are skipped
+__device__ __forceinline__ double apply3_combine(int fun, double a, double b) {
+    if (fun < 2) return a + b;
+    if (fun == 2) return b > a ? b : a;
+    return b < a ? b : a;
+}
+__global__ __launch_bounds__(256) void k_apply3_part(const double* __restrict__ a, int64_t N, int fun, int parts,
+                                                     double* __restrict__ ws /* [tsteps][parts][2] */) {
     __shared__ double sv[256];
     __shared__ double sn[256];
-    const int64_t k = blockIdx.x;
+    const int64_t k = blockIdx.y;
     const double* x = a + k * N;
     double v = fun == 2 ? -INFINITY : (fun == 3 ? INFINITY : 0.0), n = 0.0;
-    for (int64_t i = threadIdx.x; i < N; i += 256) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)parts * 256) {
         const double q = x[i];
         if (isnan(q)) continue;
         n += 1.0;
-        if (fun < 2) v += q;
-        else if (fun == 2) { if (q > v) v = q; }
-        else { if (q < v) v = q; }
+        v = apply3_combine(fun, v, q);
     }
     sv[threadIdx.x] = v; sn[threadIdx.x] = n;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) {
-            const double o = sv[threadIdx.x + w];
-            if (fun < 2) sv[threadIdx.x] += o;
-            else if (fun == 2) { if (o > sv[threadIdx.x]) sv[threadIdx.x] = o; }
-            else { if (o < sv[threadIdx.x]) sv[threadIdx.x] = o; }
+            sv[threadIdx.x] = apply3_combine(fun, sv[threadIdx.x], sv[threadIdx.x + w]);
             sn[threadIdx.x] += sn[threadIdx.x + w];
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        double r = sv[0];
-        if (fun == 0) r = sn[0] > 0 ? r / sn[0] : NAN;
-        result[k] = r;
-        if (count) count[k] = sn[0];
+        ws[2 * (k * parts + blockIdx.x)] = sv[0];
+        ws[2 * (k * parts + blockIdx.x) + 1] = sn[0];
     }
+}
+__global__ __launch_bounds__(256) void k_apply3_fin(const double* __restrict__ ws, int64_t tsteps, int fun, int parts,
+                                                    double* __restrict__ result, double* __restrict__ count) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= tsteps) return;
+    double v = fun == 2 ? -INFINITY : (fun == 3 ? INFINITY : 0.0), n = 0.0;
+    for (int p = 0; p < parts; ++p) {
+        v = apply3_combine(fun, v, ws[2 * (k * parts + p)]);
+        n += ws[2 * (k * parts + p) + 1];
+    }
+    if (fun == 0) v = n > 0 ? v / n : NAN;
+    result[k] = v;
+    if (count) count[k] = n;
 }
 
 // ---- host side -------------------------------------------------------------------------------------
@@ -887,7 +911,8 @@ struct mcf_snowplan {
     const StepRow* rows_tab = nullptr;
     const double *d_dtm = nullptr, *d_isnowdg = nullptr;
     double *d_isnowdc = nullptr, *d_dtms = nullptr, *d_slope = nullptr, *d_aspect = nullptr, *d_svf = nullptr,
-           *d_wsa = nullptr, *d_hor = nullptr, *d_tpic = nullptr, *d_mean2 = nullptr, *d_cm = nullptr, *d_ext = nullptr;
+           *d_wsa = nullptr, *d_hor = nullptr, *d_tpic = nullptr, *d_mean2 = nullptr, *d_cm = nullptr, *d_ext = nullptr,
+           *d_sumws = nullptr;
     int64_t ext_cap = 0, cm_cap = 0;
     int32_t *d_ac = nullptr, *d_ag = nullptr;
     std::vector<double> wind;
@@ -959,6 +984,7 @@ extern "C" int mcf_snowplan_create(const mcf_snowdriver_in* din, int64_t row0, i
     if ((rc = b.alloc((void**)&sp->d_hor, 24 * N * 8))) return rc;
     if ((rc = b.alloc((void**)&sp->d_tpic, N * 8))) return rc;
     if ((rc = b.alloc((void**)&sp->d_mean2, 16))) return rc;
+    if ((rc = b.alloc((void**)&sp->d_sumws, 2 * kSumParts * 8))) return rc;
     a.slope = sp->d_slope; a.aspect = sp->d_aspect; a.skyview = sp->d_svf; a.wsa = sp->d_wsa; a.hor = sp->d_hor;
     a.isnowdc = sp->d_isnowdc; a.isnowdg = sp->d_isnowdg; a.isnowac = sp->d_ac; a.isnowag = sp->d_ag;
     const DateRow2* dates_unused;
@@ -1001,7 +1027,7 @@ extern "C" int mcf_snowplan_surface(mcf_snowplan* sp, double* host_own) {
 extern "C" int mcf_snowplan_surface_partial(mcf_snowplan* sp, double* sum, double* count) {
     if (!sp || !sum || !count) return mcf::api_fail(MCF_ERR_ARG, "null argument");
     S_TRY(hipSetDevice(sp->device));
-    hipLaunchKernelGGL(k_sumcount, dim3(1), dim3(1024), 0, nullptr, sp->d_dtms, sp->N, sp->d_mean2);
+    launch_sumcount(sp->d_dtms, sp->N, sp->d_sumws, sp->d_mean2);
     double h[2];
     S_TRY(hipMemcpy(h, sp->d_mean2, 16, hipMemcpyDeviceToHost));
     *sum = h[0]; *count = h[1];
@@ -1073,7 +1099,7 @@ extern "C" int mcf_snowplan_prepare_chunk(mcf_snowplan* sp, int32_t ch, const do
         hipLaunchKernelGGL(k_tpi_fine, dim3(gridN), dim3(256), 0, nullptr, d_z, g, (const double*)nullptr, surface_mean,
                            sp->tfact, sp->d_tpic);
     }
-    hipLaunchKernelGGL(k_sumcount, dim3(1), dim3(1024), 0, nullptr, sp->d_tpic, N, sp->d_mean2);
+    launch_sumcount(sp->d_tpic, N, sp->d_sumws, sp->d_mean2);
     S_TRY(hipGetLastError());
     double h[2];
     S_TRY(hipMemcpy(h, sp->d_mean2, 16, hipMemcpyDeviceToHost));
@@ -1155,7 +1181,7 @@ extern "C" int mcf_snowmodel1(const mcf_snowdriver_in* in, mcf_snowdriver_out* o
 
 extern "C" int mcf_applycpp3(const double* a, int64_t rows, int64_t cols, int64_t tsteps, int32_t fun, double* result,
                              double* count, int32_t device) {
-    if (!a || !result || rows <= 0 || cols <= 0 || tsteps <= 0 || tsteps > (1 << 30) || fun < 0 || fun > 3)
+    if (!a || !result || rows <= 0 || cols <= 0 || tsteps <= 0 || tsteps > 65535 || fun < 0 || fun > 3)
         return mcf::api_fail(MCF_ERR_ARG, "bad applycpp3 argument");
     int rc;
     if ((rc = pick_device(device))) return rc;
@@ -1167,7 +1193,15 @@ extern "C" int mcf_applycpp3(const double* a, int64_t rows, int64_t cols, int64_
     UP(d_a, a, N * tsteps);
     if ((rc = b.alloc((void**)&d_r, tsteps * 8))) return rc;
     if (count && (rc = b.alloc((void**)&d_c, tsteps * 8))) return rc;
-    hipLaunchKernelGGL(k_apply3, dim3((unsigned)tsteps), dim3(256), 0, nullptr, d_a, N, (int)fun, d_r, d_c);
+    // enough workgroups to keep the memory system busy whatever the ratio of cells to steps
+    int parts = (int)std::min<int64_t>(64, std::max<int64_t>(1, N / 16384));
+    if (tsteps * parts < 2048) parts = (int)std::min<int64_t>(64, std::max<int64_t>(parts, (2048 + tsteps - 1) / tsteps));
+    double* d_ws;
+    if ((rc = b.alloc((void**)&d_ws, tsteps * parts * 16))) return rc;
+    hipLaunchKernelGGL(k_apply3_part, dim3((unsigned)parts, (unsigned)tsteps), dim3(256), 0, nullptr, d_a, N, (int)fun, parts,
+                       d_ws);
+    hipLaunchKernelGGL(k_apply3_fin, dim3((unsigned)((tsteps + 255) / 256)), dim3(256), 0, nullptr, d_ws, tsteps, (int)fun,
+                       parts, d_r, d_c);
     S_TRY(hipGetLastError());
     S_TRY(hipMemcpy(result, d_r, (size_t)tsteps * 8, hipMemcpyDeviceToHost));
     if (count) S_TRY(hipMemcpy(count, d_c, (size_t)tsteps * 8, hipMemcpyDeviceToHost));

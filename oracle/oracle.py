@@ -41,8 +41,11 @@ class Kstruct(C.Structure):
 def load() -> C.CDLL:
     global _lib
     if _lib is None:
-        build()
-        lib = C.CDLL(str(LIB_PATH))
+        import os
+        alt = os.environ.get("MCF_ORACLE_LIB")       # e.g. an AddressSanitizer build (CPU only)
+        if not alt:
+            build()
+        lib = C.CDLL(alt or str(LIB_PATH))
         lib.orc_run_grid.restype = C.c_int
         lib.orc_run_grid.argtypes = [C.POINTER(_abi.GridInputs), C.POINTER(_abi.Options),
                                      C.POINTER(_abi.Outputs)]

@@ -3,6 +3,8 @@
 restatements (oracle/pointmodel.c).  Used to give parity cases point-model inputs that come from the physics
 instead of the SURVEY §8d synthetic recipe.  One deliberate simplification, because it only shapes a test
 input: R expands the daily soil moisture with stats::spline (FMM cubic); here it is interpolated linearly.
+BigLeafCpp runs with yearG = FALSE: its annual ground-heat-flux cycle takes a 91-day circular mean (mayCpp ->
+maCpp, cpp:561-594) that indexes out of bounds for series shorter than 91 days, in the reference as in the oracle.
 """
 from __future__ import annotations
 
@@ -47,7 +49,7 @@ def pointm_chain(obstime, weather, lat, lon, zref=2.0, vegp_p=VEGP_P, groundp_p=
             "day": np.ascontiguousarray(obstime["day"], dtype=np.int32),
             "hour": np.ascontiguousarray(obstime["hour"], dtype=np.float64)}
     bl = bigleaf(obst, w, np.ascontiguousarray(vegp_p), np.ascontiguousarray(groundp_p), np.ascontiguousarray(soilm),
-                 float(lat), float(lon), 25.0, float(zref), int(maxiter), 0.5, 0.5, 0.1, True)
+                 float(lat), float(lon), 25.0, float(zref), int(maxiter), 0.5, 0.5, 0.1, False)
     out = {k: np.zeros(n) for k in ("umu", "kp", "muGp", "DDp", "T0p", "dtrp")}
     lib.orc_pointmprocess.restype = None
     lib.orc_pointmprocess(C.c_int(n), _d(w["windspeed"]), _d(w["temp"]), _d(w["relhum"]), _d(w["pres"]), _d(bl["uf"]),
