@@ -23,6 +23,9 @@
 
 #include "mcf_kernels.h"
 
+#ifndef MCF_EXPERIMENT_SALU
+#define MCF_EXPERIMENT_SALU 0
+#endif
 #ifndef MCF_FDIV_NR2
 #define MCF_FDIV_NR2 0   // 1: second Newton step on the reciprocal inside fdiv (not needed, see fdiv)
 #endif
@@ -155,10 +158,47 @@ __device__ __forceinline__ double fsqrt(double x) {           // sqrt(x), x fini
 // exp(x): Cody-Waite reduction + degree-11 minimax polynomial on [-ln2/2, ln2/2].
 // No overflow/underflow branches: v_cvt_i32_f64 saturates and v_ldexp_f64 saturates to
 // inf / flushes to 0 by itself, so very negative arguments return exactly 0.
-__device__ __forceinline__ double fexp(double x) {
+//
+// The coefficients are carried in a MathK: k_solve pins them into SGPR pairs once, in front of the day loop
+// (MathK::pin), so that the ~25 exp and ~7 log evaluations of a cell-step share them.  Rematerialised at every
+// call (22 + 14 s_mov_b32 each) they made up ~70 % of the kernel's scalar instructions, and the scalar issue slots
+// they take from their own wave cost 9 % of the run time (measured by doubling them).
+struct MathK {
+    double e[12];   // exp: 1/ln2, -ln2_hi, -ln2_lo, c10 .. c2
+    double l[7];    // log: Lg4, Lg5, Lg2, Lg3, Lg1, ln2_lo, ln2_hi
+    __device__ __forceinline__ void set() {
+        e[0] = 0x1.71547652b82fep+0; e[1] = -0x1.62e42fefa39efp-1; e[2] = -0x1.abc9e3b39803fp-56;
+        e[3] = 0x1.28af3fca7ab0cp-22; e[4] = 0x1.71dee623fde64p-19; e[5] = 0x1.a01997c89e6b0p-16;
+        e[6] = 0x1.a01a014761f6ep-13; e[7] = 0x1.6c16c1852b7b0p-10; e[8] = 0x1.1111111122322p-7;
+        e[9] = 0x1.55555555502a1p-5; e[10] = 0x1.5555555555511p-3; e[11] = 0x1.000000000000bp-1;
+        l[0] = 2.222219843214978396e-01; l[1] = 1.818357216161805012e-01; l[2] = 3.999999999940941908e-01;
+        l[3] = 2.857142874366239149e-01; l[4] = 6.666666666666735130e-01; l[5] = 1.90821492927058770002e-10;
+        l[6] = 6.93147180369123816490e-01;
+    }
+    // makes the values opaque SGPR residents: the compiler can no longer re-create them from literals
+    __device__ __forceinline__ void pin(bool with_log) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) asm volatile("" : "+s"(e[i]));
+        if (with_log) {
+#pragma unroll
+            for (int i = 0; i < 7; ++i) asm volatile("" : "+s"(l[i]));
+        }
+    }
+};
+__device__ __forceinline__ double fexp(double x, const MathK& K) {
     double n, r, p, out;
     int t;
     const double c11 = 0x1.ade156a5dcb37p-26;
+#if MCF_EXPERIMENT_SALU
+    {   // timing experiment only: 22 extra scalar moves per exp (as many as its coefficients cost)
+        int dummy;
+        asm volatile("s_mov_b32 %0, 1\n\ts_mov_b32 %0, 2\n\ts_mov_b32 %0, 3\n\ts_mov_b32 %0, 4\n\ts_mov_b32 %0, 5\n\t"
+                     "s_mov_b32 %0, 6\n\ts_mov_b32 %0, 7\n\ts_mov_b32 %0, 8\n\ts_mov_b32 %0, 9\n\ts_mov_b32 %0, 10\n\t"
+                     "s_mov_b32 %0, 11\n\ts_mov_b32 %0, 12\n\ts_mov_b32 %0, 13\n\ts_mov_b32 %0, 14\n\ts_mov_b32 %0, 15\n\t"
+                     "s_mov_b32 %0, 16\n\ts_mov_b32 %0, 17\n\ts_mov_b32 %0, 18\n\ts_mov_b32 %0, 19\n\ts_mov_b32 %0, 20\n\t"
+                     "s_mov_b32 %0, 21\n\ts_mov_b32 %0, 22" : "=s"(dummy));
+    }
+#endif
     asm("v_mul_f64 %0, %5, %6\n\t"
         "v_rndne_f64 %0, %0\n\t"
         "v_fma_f64 %1, %0, %7, %5\n\t"
@@ -177,15 +217,13 @@ __device__ __forceinline__ double fexp(double x) {
         "v_cvt_i32_f64 %3, %0\n\t"
         "v_ldexp_f64 %4, %2, %3"
         : "=&v"(n), "=&v"(r), "=&v"(p), "=&v"(t), "=v"(out)
-        : "v"(x), "s"(0x1.71547652b82fep+0), "s"(-0x1.62e42fefa39efp-1), "s"(-0x1.abc9e3b39803fp-56),
-          "v"(c11), "s"(0x1.28af3fca7ab0cp-22), "s"(0x1.71dee623fde64p-19), "s"(0x1.a01997c89e6b0p-16),
-          "s"(0x1.a01a014761f6ep-13), "s"(0x1.6c16c1852b7b0p-10), "s"(0x1.1111111122322p-7),
-          "s"(0x1.55555555502a1p-5), "s"(0x1.5555555555511p-3), "s"(0x1.000000000000bp-1));
+        : "v"(x), "s"(K.e[0]), "s"(K.e[1]), "s"(K.e[2]), "v"(c11), "s"(K.e[3]), "s"(K.e[4]), "s"(K.e[5]), "s"(K.e[6]),
+          "s"(K.e[7]), "s"(K.e[8]), "s"(K.e[9]), "s"(K.e[10]), "s"(K.e[11]));
     return out;
 }
 // log(x) for finite normal x > 0: m in [sqrt(1/2), sqrt(2)), s = f/(2+f), the
 // classic 7-term series in s^2 with the hi/lo split of ln2.
-__device__ __forceinline__ double flog(double x) {
+__device__ __forceinline__ double flog(double x, const MathK& K) {
     double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
     int e = __builtin_amdgcn_frexp_exp(x);
     const int lo = m < 0.70710678118654752440 ? 1 : 0;
@@ -213,22 +251,21 @@ __device__ __forceinline__ double flog(double x) {
         "v_add_f64 %2, %2, -%7\n\t"             // (...) - f
         "v_fma_f64 %4, %8, %17, -%2"              // dk*ln2_hi - (...)
         : "=&v"(z), "=&v"(w), "=&v"(t1), "=&v"(t2), "=v"(out)
-        : "v"(s), "v"(hfsq), "v"(f), "v"(dk), "v"(lg6), "s"(2.222219843214978396e-01), "v"(lg7),
-          "s"(1.818357216161805012e-01), "s"(3.999999999940941908e-01), "s"(2.857142874366239149e-01),
-          "s"(6.666666666666735130e-01), "s"(1.90821492927058770002e-10), "s"(6.93147180369123816490e-01));
+        : "v"(s), "v"(hfsq), "v"(f), "v"(dk), "v"(lg6), "s"(K.l[0]), "v"(lg7), "s"(K.l[1]), "s"(K.l[2]), "s"(K.l[3]),
+          "s"(K.l[4]), "s"(K.l[5]), "s"(K.l[6]));
     return out;
 }
 // pow(x, y) for the positive-base uses on this path, as exp(y*log(x)); the
 // relative error (|y log x| * 2^-52) is far below the 1e-4 acceptance bar.
-__device__ __forceinline__ double powxy(double x, double y) { return fexp(y * flog(x)); }
+__device__ __forceinline__ double powxy(double x, double y, const MathK& K) { return fexp(y * flog(x, K), K); }
 __device__ __forceinline__ double sq(double x) { return x * x; }
 __device__ __forceinline__ double pow4(double x) { double x2 = x * x; return x2 * x2; }
 
 // cpp:480-490 satvapCpp
-__device__ __forceinline__ double satvap(double tc) {
+__device__ __forceinline__ double satvap(double tc, const MathK& K) {
     double a = tc > 0 ? 17.27 : 21.875;
     double b = tc > 0 ? 237.3 : 265.5;
-    return 0.61078 * fexp(fdiv(a * tc, tc + b));
+    return 0.61078 * fexp(fdiv(a * tc, tc + b), K);
 }
 // cpp:24-26 with the 0.97*sb factor every caller applies
 __device__ __forceinline__ double lw_emit(double tc) { return 0.97 * kSb * pow4(tc + 273.15); }
@@ -298,6 +335,8 @@ struct TimeVals {
 
 // Fills the derived TF_ fields of `t` from its raw fields and the solar position.
 __device__ inline void derive_time(TimeVals& t, const SolPos& sp, int windex) {
+    MathK K;
+    K.set();
     const double tc = t.v[TF_TC];
     const double zenr = sp.zenr;
     t.v[TF_ZEND] = sp.zend;
@@ -319,7 +358,7 @@ __device__ inline void derive_time(TimeVals& t, const SolPos& sp, int windex) {
     t.v[TF_TANB] = tb;
     t.v[TF_TAN2B] = tb * tb;
     t.v[TF_INV2COSB] = 1.0 / (2.0 * cb);
-    t.v[TF_DE] = satvap(tc + 0.5) - satvap(tc - 0.5);                       // cpp:1223
+    t.v[TF_DE] = satvap(tc + 0.5, K) - satvap(tc - 0.5, K);                       // cpp:1223
     double tk = tc + 273.15;
     t.v[TF_GHRRAD] = (4 * 0.97 * kSb * (tk * tk * tk)) / 29.3;               // cpp:1224
     t.v[TF_REM] = lw_emit(tc);                                              // cpp:1225, 1167
@@ -350,7 +389,7 @@ __device__ inline void derive_time(TimeVals& t, const SolPos& sp, int windex) {
 // Differences to the literal evaluation are rounding-level (1e-16 relative).
 struct DateRow { double sindec, cosdec, cosA, sinA; };
 __device__ __forceinline__ void derive_time_af(TimeVals& t, const DateRow& dr, double sinlat, double coslat,
-                                               double cosB, double sinB, int windex) {
+                                               double cosB, double sinB, int windex, const MathK& K) {
     const double ctt = dr.cosA * cosB - dr.sinA * sinB;
     const double stt = dr.sinA * cosB + dr.cosA * sinB;
     const double coh = dr.sindec * sinlat + dr.cosdec * coslat * ctt;          // cpp:56
@@ -408,7 +447,7 @@ __device__ __forceinline__ void derive_time_af(TimeVals& t, const DateRow& dr, d
     t.v[TF_IDX] = (double)(sindex | (windex << 5) | (ksat << 8));
     // Penman-Monteith operands (cpp:1220-1247) and beam normalisation (cpp:1122-1124)
     const double tc = t.v[TF_TC];
-    t.v[TF_DE] = satvap(tc + 0.5) - satvap(tc - 0.5);
+    t.v[TF_DE] = satvap(tc + 0.5, K) - satvap(tc - 0.5, K);
     const double tk = tc + 273.15;
     t.v[TF_GHRRAD] = (4 * 0.97 * kSb * (tk * tk * tk)) * (1.0 / 29.3);
     t.v[TF_REM] = lw_emit(tc);
@@ -485,7 +524,7 @@ __device__ __forceinline__ double pm_temperature(double num, double den, double 
 // ---------------------------------------------------------------------------------
 template <class CL, class TM>
 __device__ __forceinline__ void pass1(const CL& C, const TM& T, const Globals& g, int flags, double dTmx,
-                                      Carry& cy, Pass1Out& o) {
+                                      Carry& cy, Pass1Out& o, const MathK& K) {
     // ---- section A operands: soil moisture spread + branch selectors
     double t_idx = T(TF_IDX), rsw = T(TF_RSW), rdif = T(TF_RDIF), t_soilmp = T(TF_SOILMP);
     double c_smin = C(CF_SMIN), c_invrge = C(CF_INVRGE), c_eta = C(CF_ETA), c_rge = C(CF_RGE);
@@ -534,7 +573,7 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const Globals& g
             double sig = kd * kd + c_gma2 - c_agm2;
             double ss = 0.5 * (om * kd + c_jdel);           // 0.5*(om + J*del/kd)*kd
             double sstr = om * kd - ss;
-            double S2 = fexp(-kd * c_pait);
+            double S2 = fexp(-kd * c_pait, K);
             double isig = frcp(sig);
             double p5 = -ss * (agm - kd) - gma * sstr;
             double p5s = p5 * isig;
@@ -557,10 +596,10 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const Globals& g
             pin(c_logclump, c_loggi, amx, trdn, trdu, c_ehp, c_paiaa, emhpa, ehpa, c_rddng, c_albd, c_rddnz,
                 c_rdupz, Rbeam, Rb);
             // gap transmissions, cpp:1095-1100
-            double trbn = fexp(Kc * c_logclump);
+            double trbn = fexp(Kc * c_logclump, K);
             if (trbn > 0.999) trbn = 0.999;
             if (trbn < 0.0) trbn = 0.0;
-            double trb = fexp(Kc * c_loggi);
+            double trb = fexp(Kc * c_loggi, K);
             if (trb > 0.999) trb = 0.999;
             if (trb < 0.0) trb = 0.0;
             double albb = (1.0 - trdn * trbn) * (p5s + p6 + p7) + trdn * trbn * gref;      // cpp:1102
@@ -569,7 +608,7 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const Globals& g
             double Rdbdn_g = (1.0 - trbn) * (p8s * S2 + p9 * S1 + p10 * c_ehp);            // cpp:1106
             if (Rdbdn_g > amx) Rdbdn_g = amx;
             if (Rdbdn_g < 0.0) Rdbdn_g = 0.0;
-            double S2a = fexp(-kd * c_paiaa);
+            double S2a = fexp(-kd * c_paiaa, K);
             double Rdbup_z = (1.0 - trdu * trbn) * (p5s * S2a + p6 * emhpa + p7 * ehpa) + trdu * trbn * gref;
             if (Rdbup_z > amx) Rdbup_z = amx;
             if (Rdbup_z < 0.0) Rdbup_z = 0.0;
@@ -628,8 +667,8 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const Globals& g
     o.uz = uz;
     // --- soil surface temperature with G = 0, cpp:1262-1275 ------------------------------
     const double radabs = radGsw + radGlw;
-    double matric = -c_abspsie * powxy(soilm * c_invsmax, -c_soilb);
-    double surfwet = fexp(matric * t_wfac);
+    double matric = -c_abspsie * powxy(soilm * c_invsmax, -c_soilb, K);
+    double surfwet = fexp(matric * t_wfac, K);
     if (surfwet > 1.0) surfwet = 1.0;
     const double m = t_lapk * gHa;
     const double num0 = radabs - t_rem - m * (t_es - t_ea) * surfwet;
@@ -646,10 +685,10 @@ struct Stom {
     double gsmax, rsmx, inv02rsmx, gs2;
 };
 // cpp:442-458 stomcondCpp with the soil-water factor `gs2 = mu*gsmax` passed in.
-__device__ __forceinline__ double stomcond(double Rswabs, const Stom& s) {
+__device__ __forceinline__ double stomcond(double Rswabs, const Stom& s, const MathK& K) {
     if (Rswabs <= 0.0) return 0.0;
     double gs = s.gsmax;          // light-saturated (Rswabs >= Rsmx): 2^0 = 1
-    if (Rswabs < s.rsmx) gs = s.gsmax * fexp(-(s.rsmx - Rswabs) * s.inv02rsmx * 0.693147180559945309417);
+    if (Rswabs < s.rsmx) gs = s.gsmax * fexp(-(s.rsmx - Rswabs) * s.inv02rsmx * 0.693147180559945309417, K);
     if (gs > s.gs2) gs = s.gs2;
     return gs;
 }
@@ -657,10 +696,10 @@ __device__ __forceinline__ double stomcond(double Rswabs, const Stom& s) {
 // cpp:1316-1331 mincondCpp: gmin = max(0.0463*(|Hf*Rnet|/leafd)^0.2, 0.05).  The two calls of a
 // cell-step share Rnet and leafd, so (|Rnet|/leafd)^0.2 is evaluated once (`a02`) and each call
 // supplies |Hf|^0.2 (`hf02`).
-__device__ __forceinline__ double mincond_a02(double Rnet, double invleafd) {
+__device__ __forceinline__ double mincond_a02(double Rnet, double invleafd, const MathK& K) {
     double arg = fabs(Rnet) * invleafd;
     if (arg < 1e-300) arg = 1e-300;      // pow(0, 0.2) = 0 and tiny values end in the 0.05 floor alike
-    return powxy(arg, 0.2);
+    return powxy(arg, 0.2, K);
 }
 __device__ __forceinline__ double mincond_gmin(double hf02, double a02) {
     double gmin = 0.0463 * (hf02 * a02);
@@ -679,7 +718,7 @@ struct Pass2Out {
 template <class CL, class TM>
 __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g, int flags, double dTmx,
                                       const Carry& cy, double dtr, double Rmx, bool above_ground,
-                                      Pass2Out& o) {
+                                      Pass2Out& o, const MathK& K) {
     const double soilm = cy.soilm;
     // ---- section A operands: soil conductivity, ground heat flux, ground temperature
     double rho = C(CF_RHO), c_csa = C(CF_CSA), c_c1 = C(CF_C1), c_c1mc4 = C(CF_C1MC4), c_c3 = C(CF_C3);
@@ -689,7 +728,7 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
     double cs = c_csa + 4180.0 * soilm;
     double ph = (rho * (1.0 - soilm) + soilm) * 1000.0;
     double c2 = 1.06 * rho * soilm;
-    double ksoil = c_c1 + c2 * soilm - c_c1mc4 * fexp(-pow4(c_c3 * soilm));
+    double ksoil = c_c1 + c2 * soilm - c_c1mc4 * fexp(-pow4(c_c3 * soilm), K);
     double kap = fdiv(ksoil, cs * ph);
     double DD = fsqrt(kap * (2.0 / kOmdy));
     // --- ground heat flux and ground temperature, cpp:1277-1296 ------------------------------
@@ -712,11 +751,11 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
     const double uf = cy.uf;
     double gHa = uf * c_ghafac;
     if (gHa < 0.0001) gHa = 0.0001;
-    const double esTg = satvap(Tg);
+    const double esTg = satvap(Tg, K);
     double eT = esTg - ea;
     if (eT < 0.001) eT = 0.001;
-    double plf = 0.8753 - 1.7126 * flog(eT);
-    double gwet = frcp(1.0 + fexp(-plf));
+    double plf = 0.8753 - 1.7126 * flog(eT, K);
+    double gwet = frcp(1.0 + fexp(-plf, K));
     const double surfwet = (soilm - c_smin) * c_invrge;
     if (surfwet > gwet) gwet = surfwet;
     // canopy conductance, cpp:1425-1428 + 460-477
@@ -737,9 +776,9 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
         double thetan = c_rat * soilm + c_ratc;
         double Se = thetan * c_invsmax;
         if (Se > 1.0) Se = 1.0;
-        double psiw = -c_abspsie * powxy(Se, -c_soilb) * 0.01;
+        double psiw = -c_abspsie * powxy(Se, -c_soilb, K) * 0.01;
         if (psiw < c_psiw0) psiw = c_psiw0;
-        double mu = 1.0 - (fexp(-c_kk * psiw) - 1.0) * c_mudeninv;
+        double mu = 1.0 - (fexp(-c_kk * psiw, K) - 1.0) * c_mudeninv;
         st.gs2 = mu * st.gsmax;
         have_gs2 = true;
     };
@@ -753,7 +792,7 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
             if (flags & (FL_XONE | FL_XINF | FL_XZERO))
                 kb = (flags & FL_XONE) ? T(TF_INV2COSB) : (flags & FL_XINF) ? 1.0 : T(TF_TANB);
             if (kb > 6000.0) kb = 6000.0;
-            P_sun = fdiv(1.0 - fexp(-kb * c_pai), kb);
+            P_sun = fdiv(1.0 - fexp(-kb * c_pai, K), kb);
         }
         double P_shade = c_pai - P_sun;
         double Rshade_abs = rdif * c_shadefac;
@@ -761,8 +800,8 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
         double gs_sun = 0.0, gs_shade = 0.0;
         if (!(Rsun_abs <= 0.0) || !(Rshade_abs <= 0.0)) {
             load_stom();
-            gs_sun = stomcond(Rsun_abs, st);
-            gs_shade = stomcond(Rshade_abs, st);
+            gs_sun = stomcond(Rsun_abs, st, K);
+            gs_shade = stomcond(Rshade_abs, st, K);
         }
         gS = gs_sun * P_sun + gs_shade * P_shade;
     }
@@ -773,7 +812,7 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
     const double mC = lapk * gV;
     const double Tcan = pm_temperature(Rabs - rem - mC * (es - ea) * surfwet - G,
                                        29.3 * (gHa + ghr) + mC * De, dTmx, tc, tdew);
-    const double esTcan = satvap(Tcan);
+    const double esTcan = satvap(Tcan, K);
     double ez;
     if (!(flags & FL_BELOW)) {
         // above canopy: log profile, cpp:1298-1313 / 1434-1441
@@ -802,7 +841,7 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
         const double leafabs = (lit ? c_hom * cy.X : 0.0) + lwabs;   // radLsw + lwabs
         double gh = 0.135 * fsqrt(uz * invleafd) * 1.4;
         const double RnetL = leafabs - lwcan;                // cpp:1319 with tc = Tcan
-        const double a02 = mincond_a02(RnetL, invleafd);
+        const double a02 = mincond_a02(RnetL, invleafd, K);
         double gmin = mincond_gmin(g.hf0p, a02);             // mincondCpp(leafabs, 999.99, Tcan, leafd)
         if (gh < gmin) gh = gmin;
         double gVl = gh;
@@ -812,14 +851,14 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
             double gs = 0.0;
             if (PARabs > 0.0) {
                 if (!have_gs2) load_stom();
-                gs = stomcond(PARabs, st);
+                gs = stomcond(PARabs, st, K);
             }
             // rs = min(1/gs, 500) (500 when gs <= 0), Hlf = 1.09767*rs^0.2672778,
             // Hf = -1/(1 + exp(2 - Hlf)), cpp:1321-1325; |Hf|^0.2 = exp(-0.2*log(1 + exp(2 - Hlf)))
             double hf02 = g.hf500p;                           // rs = 500: a constant (night, closed stomata)
             if (gs > 0.002) {
-                double Hlf = 1.09767 * fexp(-0.2672778 * flog(gs));
-                hf02 = fexp(-0.2 * flog(1.0 + fexp(2.0 - Hlf)));
+                double Hlf = 1.09767 * fexp(-0.2672778 * flog(gs, K), K);
+                hf02 = fexp(-0.2 * flog(1.0 + fexp(2.0 - Hlf, K), K), K);
             }
             gmin = mincond_gmin(hf02, a02);                   // mincondCpp(leafabs, gs, Tcan, leafd)
             if (gh < gmin) gh = gmin;
@@ -828,7 +867,7 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
         const double mL = lapk * gVl;
         const double tleaf = pm_temperature(leafabs - rem - mL * (es - ea) * surfwet - 0.0,
                                             29.3 * (gh + ghr) + mL * De, dTmx, tc, tdew);
-        const double esTl = satvap(tleaf);
+        const double esTl = satvap(tleaf, K);
         const double HL = 29.3 * gh * (tleaf - tc);                       // cpp:1242
         const double LL = mL * (esTl - ea) * surfwet;                     // cpp:1243
         o.tleaf = tleaf;
@@ -882,7 +921,7 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
             ez = (near + farg) * invmu;
         }
     }
-    double rh = fdiv(ez, satvap(o.Tz)) * 100.0;
+    double rh = fdiv(ez, satvap(o.Tz, K)) * 100.0;
     if (rh > 100.0) rh = 100.0;
     o.rh = rh;
     // clamp Tz to the source temperatures +-2, cpp:1467-1470

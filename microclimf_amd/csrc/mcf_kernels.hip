@@ -20,6 +20,9 @@
 #ifndef MCF_HOUR_PERMUTE
 #define MCF_HOUR_PERMUTE 1
 #endif
+#ifndef MCF_PIN_MATHK
+#define MCF_PIN_MATHK 2   // 0: literals re-created at every exp/log, 1: exp coefficients pinned, 2: exp and log
+#endif
 #ifndef MCF_AF_WAVES
 #define MCF_AF_WAVES 3   // waves per SIMD the array-forcing kernels are built for (168 VGPRs)
 #endif
@@ -474,6 +477,11 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
     if (AF && in_grid) dTmx = -0.6273 * a.mxtc[c] + 49.79;   // cpp:1236 with the per-cell mxtc
     // TVaboveground (cpp:2272) is only evaluated when one of its outputs was requested
     const bool need_tv = g.reqhgt >= 0.0 && a.need_tv != 0;
+    MathK MK;
+    MK.set();
+#if MCF_PIN_MATHK
+    MK.pin(MCF_PIN_MATHK > 1);   // exp (and log) coefficients resident in SGPRs for the whole day loop
+#endif
     const double NA = na_real();
 
     for (int dl = 0; dl < a.ndays; ++dl) {
@@ -540,7 +548,7 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
             tv.v[TF_UMU] = a.af_base[(int64_t)TF_UMU * a.af_stride + fidx];
             const int64_t kabs = (int64_t)dabs * 24 + hr;
             DateRow dr{a.dt[4 * kabs + 0], a.dt[4 * kabs + 1], a.dt[4 * kabs + 2], a.dt[4 * kabs + 3]};
-            derive_time_af(tv, dr, C(CF_SINLAT), C(CF_COSLAT), C(CF_COSB), C(CF_SINB), a.windex[kabs]);
+            derive_time_af(tv, dr, C(CF_SINLAT), C(CF_COSLAT), C(CF_COSB), C(CF_SINB), a.windex[kabs], MK);
         }
         TimeLds TL{s_time + (AF ? 0 : (dl % 3) * (TF_COUNT * 24)) + hr};
         TimeReg TR{&tv};
@@ -554,8 +562,8 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
         double* red_t = &s_red[dl & 1][0][PRE ? 0 : hr * CPB + cl];
         double* red_r = &s_red[dl & 1][1][PRE ? 0 : hr * CPB + cl];
         if (valid) {
-            if (AF) pass1(C, TR, g, flags, dTmx, cy, p1);
-            else pass1(C, TL, g, flags, dTmx, cy, p1);
+            if (AF) pass1(C, TR, g, flags, dTmx, cy, p1, MK);
+            else pass1(C, TL, g, flags, dTmx, cy, p1, MK);
             if (!PRE) {
                 *red_t = p1.Tg0;
                 *red_r = p1.absRnet;
@@ -650,8 +658,8 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
                                      a.af_base[(int64_t)TF_MUGP * a.af_stride + fidx],
                                      a.af_base[(int64_t)TF_DTRP * a.af_stride + fidx],
                                      a.af_base[(int64_t)TF_KP * a.af_stride + fidx]);
-            if (AF) pass2(C, TR, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2);
-            else pass2(C, TL, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2);
+            if (AF) pass2(C, TR, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2, MK);
+            else pass2(C, TL, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2, MK);
             if (BG) {
                 a.tgser[c + N * ((int64_t)dabs * 24 + hr)] = p2.Tg;
                 s_dd[hr * CPB + cl] = p2.DD;
@@ -890,14 +898,16 @@ __global__ void k_selftest_math(int kind, const double* __restrict__ x, const do
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double a = x[i], b = y ? y[i] : 0.0, r;
+    MathK K;
+    K.set();
     switch (kind) {
-        case 0: r = fexp(a); break;
-        case 1: r = flog(a); break;
+        case 0: r = fexp(a, K); break;
+        case 1: r = flog(a, K); break;
         case 2: r = fdiv(a, b); break;
         case 3: r = fsqrt(a); break;
         case 4: r = frcp(a); break;
-        case 5: r = satvap(a); break;
-        default: r = powxy(a, b); break;
+        case 5: r = satvap(a, K); break;
+        default: r = powxy(a, b, K); break;
     }
     out[i] = r;
 }
