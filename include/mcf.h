@@ -417,6 +417,38 @@ enum { MCF_APPLY_MEAN = 0, MCF_APPLY_SUM = 1, MCF_APPLY_MAX = 2, MCF_APPLY_MIN =
 int mcf_applycpp3(const double *a, int64_t rows, int64_t cols, int64_t tsteps, int32_t fun, double *result,
                   double *count, int32_t device);
 
+/* ---- host-side point model ---------------------------------------------------------
+ * The O(tsteps) serial series that produce the grid solver's `pointm` in the reference:
+ *   mcf_soilm()          soilmCpp        src/microclimfCpp.cpp:931-972   (_microclimf_soilmCpp)
+ *   mcf_bigleaf()        BigLeafCpp      src/microclimfCpp.cpp:710-881   (_microclimf_BigLeafCpp)
+ *   mcf_pointmprocess()  pointmprocess   src/microclimfCpp.cpp:5265-5323 (_microclimf_pointmprocess)
+ *   mcf_weatherhgt()     weatherhgtCpp   src/microclimfCpp.cpp:884-929   (_microclimf_weatherhgtCpp)
+ * as `runpointmodel` chains them (R/Cppwrappers.R:119-138).  They run on the HOST, as in the reference: one
+ * point, iterated over the whole series with running means — nothing to parallelise and not part of the GPU hot
+ * path (which has no CPU implementation).  vegp / groundp are read positionally as the reference does:
+ * vegp = (h, pai, x, clump, lref, ltra, leafd, em, gsmax, q50), groundp = (gref, slope, aspect, em, rho, Vm, Vq,
+ * Mc, b, psi_e, Smax, Smin).  One guard the reference lacks: its circular means index outside their arrays when
+ * the window is longer than the series; mcf_bigleaf rejects yearG for 2..89 days and series under 6 steps. */
+typedef struct mcf_point_weather {
+    const double *temp, *relhum, *pres, *swdown, *difrad, *lwdown, *windspeed, *precip; /* [n]; precip: soilm only */
+} mcf_point_weather;
+typedef struct mcf_bigleaf_out { /* caller-allocated [n] each (src/microclimfCpp.cpp:867-879) */
+    double *Tc, *Tg, *H, *G, *psih, *psim, *phih, *OL, *uf, *RabsG, *albedo;
+    double err;
+    int32_t iters;
+} mcf_bigleaf_out;
+int mcf_bigleaf(int64_t n, const mcf_obstime *obstime, const mcf_point_weather *weather, const double *vegp,
+                const double *groundp, const double *soilm, double lat, double lon, double dTmx, double zref,
+                int32_t maxiter, double bwgt, double tol, int32_t yearG, mcf_bigleaf_out *out);
+int mcf_soilm(int64_t n, const mcf_point_weather *weather, double rmu, double mult, double pwr, double Smax,
+              double Smin, double Ksat, double a, double *soilm_days /* [n / 24] */, int64_t *ndays);
+int mcf_pointmprocess(int64_t n, const double *windspeed, const double *tc, const double *rh, const double *pk,
+                      const double *uf, const double *soilm, const double *RabsG, double zref, double h, double pai,
+                      double rho, double Vm, double Vq, double Mc, double *umu, double *kp, double *muGp,
+                      double *DDp, double *T0p, double *dtrp);
+int mcf_weatherhgt(int64_t n, const mcf_obstime *obstime, const mcf_point_weather *weather, double zin, double uzin,
+                   double zout, double lat, double lon, double *temp, double *relhum, double *windspeed);
+
 /* Diagnostics: evaluate one of the solver's lean device elementary functions
  * elementwise on host arrays (kind 0 exp, 1 log, 2 x/y, 3 sqrt, 4 1/x, 5 satvap
  * (cpp:480-490), 6 x^y); used by tests to bound their error against libm. */

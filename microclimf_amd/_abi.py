@@ -120,6 +120,15 @@ class SnowInputs(C.Structure):
                 ("vegp", SnowVegp), ("other", SnowOther)]
 
 
+POINT_WEATHER_FIELDS = ("temp", "relhum", "pres", "swdown", "difrad", "lwdown", "windspeed", "precip")
+PointWeather = _ptr_struct("PointWeather", POINT_WEATHER_FIELDS)
+BIGLEAF_FIELDS = ("Tc", "Tg", "H", "G", "psih", "psim", "phih", "OL", "uf", "RabsG", "albedo")
+
+
+class BigLeafOut(C.Structure):
+    _fields_ = [(k, c_double_p) for k in BIGLEAF_FIELDS] + [("err", C.c_double), ("iters", C.c_int32)]
+
+
 class SnowDriverIn(C.Structure):
     _fields_ = [("base", SnowInputs), ("dtm", c_double_p), ("res", C.c_double), ("tfact", C.c_double),
                 ("chunk_steps", C.c_int32), ("reserved", C.c_int32)]
@@ -145,6 +154,7 @@ EXPORTS = (
     "mcf_gridmicrosnow2", "mcf_snowmodel1", "mcf_applycpp3",
     "mcf_snowplan_create", "mcf_snowplan_destroy", "mcf_snowplan_chunks", "mcf_snowplan_surface",
     "mcf_snowplan_surface_partial", "mcf_snowplan_prepare_chunk", "mcf_snowplan_run_chunk",
+    "mcf_bigleaf", "mcf_soilm", "mcf_pointmprocess", "mcf_weatherhgt",
 )
 
 _lib = None
@@ -223,6 +233,16 @@ def load() -> C.CDLL:
     for fn in (lib.mcf_gridmicrosnow1, lib.mcf_gridmicrosnow2):
         fn.restype = C.c_int
         fn.argtypes = [SI, C.POINTER(Snowm), C.c_double, C.c_double, C.POINTER(C.c_int32 * NOUT), OU, C.c_int32]
+    PW, OT = C.POINTER(PointWeather), C.POINTER(Obstime)
+    lib.mcf_bigleaf.restype = C.c_int
+    lib.mcf_bigleaf.argtypes = [C.c_int64, OT, PW, c_double_p, c_double_p, c_double_p, C.c_double, C.c_double, C.c_double,
+                                C.c_double, C.c_int32, C.c_double, C.c_double, C.c_int32, C.POINTER(BigLeafOut)]
+    lib.mcf_soilm.restype = C.c_int
+    lib.mcf_soilm.argtypes = [C.c_int64, PW] + [C.c_double] * 7 + [c_double_p, C.POINTER(C.c_int64)]
+    lib.mcf_pointmprocess.restype = C.c_int
+    lib.mcf_pointmprocess.argtypes = [C.c_int64] + [c_double_p] * 7 + [C.c_double] * 7 + [c_double_p] * 6
+    lib.mcf_weatherhgt.restype = C.c_int
+    lib.mcf_weatherhgt.argtypes = [C.c_int64, OT, PW] + [C.c_double] * 5 + [c_double_p] * 3
     lib.mcf_applycpp3.restype = C.c_int
     lib.mcf_applycpp3.argtypes = [c_double_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, c_double_p, c_double_p,
                                   C.c_int32]

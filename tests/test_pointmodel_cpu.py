@@ -1,0 +1,94 @@
+"""The host-side point model of libmcfhip (mcf_pointmodel.cpp) against the oracle's restatement
+(oracle/pointmodel.c) on the inputs of the reference's own tests and on the synthetic weather.  Both are host code;
+no GPU is involved.  Same algorithm in the same evaluation order: agreement to rounding (1e-11 asserted)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from microclimf_amd import pointmodel as PM
+from microclimf_amd import synthetic
+from oracle import pointchain
+from oracle import replay_reference_tests as RT
+
+DP = C.POINTER(C.c_double)
+
+
+def _test_inputs():
+    hrs, n, obst, Tair, RH, Pk = RT._forcing(2024, 3, 21, True)
+    SWd = np.maximum(0, 600 * np.sin((hrs - 6) / 12 * np.pi))
+    clim = {"temp": Tair, "relhum": RH, "pres": Pk, "swdown": SWd, "difrad": np.minimum(SWd, 0.3 * SWd),
+            "lwdown": np.full(n, 350.0), "windspeed": np.full(n, 2.0), "precip": np.zeros(n)}
+    return obst, clim, n
+
+
+def test_bigleaf_equals_oracle_on_the_reference_test_inputs(oracle):
+    obst, clim, n = _test_inputs()
+    vegp = np.array([0.5, 2.0, 1.0, 0.1, 0.4, 0.2, 0.05, 0.97, 0.33, 100])
+    groundp = np.array([0.15, 0, 180, 0.97, 1.53, 0.509, 0.06, 0.5422, 5.2, -5.6, 0.42, 0.074])
+    want = RT.bigleaf(obst, clim, vegp, groundp, np.full(n, 0.3), 50.0, -5.0, 25, 2, 50, 0.5, 0.5, 0.1, False)
+    got = PM.BigLeafCpp(obst, clim, vegp, groundp, np.full(n, 0.3), 50.0, -5.0, 25, 2, 50, 0.5, 0.5, 0.1, False)
+    assert got["iters"] == want["iters"]
+    assert got["err"] == pytest.approx(want["err"], abs=1e-11)
+    for k in ("Tc", "Tg", "H", "G", "psih", "psim", "phih", "OL", "uf", "RabsG", "albedo"):
+        np.testing.assert_allclose(got[k], want[k], rtol=1e-11, atol=1e-11, err_msg=k)
+    # and the reference's own bounds (test-BigLeafCpp.R) hold for the product as they do for the oracle
+    assert got["err"] < 0.5 and got["Tc"].max() <= clim["temp"].max() + 10
+
+
+def test_weatherhgt_and_soilm_equal_oracle(oracle):
+    lib = oracle.load()
+    obst, clim, n = _test_inputs()
+    got = PM.weatherhgtCpp(obst, clim, 2, 2, 10, 50, -5)
+    Tz, Rh, Uz = np.zeros(n), np.zeros(n), np.zeros(n)
+    d = lambda a: a.ctypes.data_as(DP)                                                  # noqa: E731
+    i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))                                  # noqa: E731
+    lib.orc_weatherhgt(C.c_int(n), i(obst["year"]), i(obst["month"]), i(obst["day"]), d(obst["hour"]), d(clim["temp"]),
+                       d(clim["relhum"]), d(clim["pres"]), d(clim["swdown"]), d(clim["difrad"]), d(clim["lwdown"]),
+                       d(clim["windspeed"]), C.c_double(2.0), C.c_double(2.0), C.c_double(10.0), C.c_double(50.0),
+                       C.c_double(-5.0), d(Tz), d(Rh), d(Uz))
+    np.testing.assert_allclose(got["temp"], Tz, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(got["relhum"], Rh, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(got["windspeed"], Uz, rtol=1e-11, atol=1e-11)
+    ratio = got["windspeed"] / clim["windspeed"]
+    assert 1.2 <= ratio.min() and ratio.max() <= 1.4                                   # test-weatherhgtCpp.R
+    assert np.array_equal(got["swdown"], clim["swdown"]) and got["swdown"] is not clim["swdown"]
+    # soilmCpp on two days (test-soilmCpp.R's call)
+    c2 = {k: np.concatenate([v, v]) for k, v in clim.items()}
+    p = pointchain.SOILM_PARAMS
+    sm = PM.soilmCpp(c2, p["rmu"], p["mult"], p["pwr"], p["Smax"], p["Smin"], p["Ksat"], p["a"])
+    want = np.zeros(2)
+    lib.orc_soilm.restype = C.c_int
+    lib.orc_soilm(C.c_int(2 * n), d(c2["temp"]), d(c2["swdown"]), d(c2["lwdown"]), d(c2["precip"]), C.c_double(p["rmu"]),
+                  C.c_double(p["mult"]), C.c_double(p["pwr"]), C.c_double(p["Smax"]), C.c_double(p["Smin"]),
+                  C.c_double(p["Ksat"]), C.c_double(p["a"]), d(want))
+    assert len(sm) == 2 and np.allclose(sm, want, rtol=1e-13) and 0.35 <= sm.min() and sm.max() <= 0.419
+
+
+def test_chain_to_pointm_equals_oracle_chain(oracle):
+    """weather -> soilmCpp -> BigLeafCpp -> pointmprocess -> pointm, product against oracle/pointchain.py"""
+    a = synthetic.workload(4, 4, 240, reqhgt=0.05, start_doy=140)
+    c = a["climdata"]
+    T = len(c["temp"])
+    weather = {"temp": c["temp"], "relhum": 100 * c["ea"] / c["es"], "pres": c["pres"], "swdown": c["swdown"],
+               "difrad": c["difrad"], "lwdown": c["lwdown"], "windspeed": c["windspeed"],
+               "precip": np.where(np.arange(T) % 17 == 0, 1.0, 0.0)}
+    want, werr = pointchain.pointm_chain(a["obstime"], weather, a["lat"], a["lon"], a["zref"])
+    got = PM.runpointmodel_chain(a["obstime"], weather, pointchain.VEGP_P, pointchain.GROUNDP_P, a["lat"], a["lon"],
+                                 a["zref"], soilparams=pointchain.SOILM_PARAMS, yearG=False)
+    assert got["bigleaf"]["err"] == pytest.approx(werr, abs=1e-10)
+    for k, w in want.items():
+        np.testing.assert_allclose(got["pointm"][k], w, rtol=1e-10, atol=1e-10, err_msg=k)
+
+
+def test_guards_against_the_reference_out_of_bounds_means():
+    from microclimf_amd import _abi
+    obst, clim, n = _test_inputs()
+    vegp = np.array([0.5, 2.0, 1.0, 0.1, 0.4, 0.2, 0.05, 0.97, 0.33, 100])
+    groundp = np.array([0.15, 0, 180, 0.97, 1.53, 0.509, 0.06, 0.5422, 5.2, -5.6, 0.42, 0.074])
+    ob5 = {k: np.tile(v, 5) for k, v in obst.items()}
+    cl5 = {k: np.tile(v, 5) for k, v in clim.items()}
+    with pytest.raises(_abi.McfError, match="yearG"):
+        PM.BigLeafCpp(ob5, cl5, vegp, groundp, np.full(5 * n, 0.3), 50.0, -5.0, yearG=True)      # 5 days: 91-day mean
+    r = PM.BigLeafCpp(obst, clim, vegp, groundp, np.full(n, 0.3), 50.0, -5.0, yearG=True)       # one day is fine
+    assert np.isfinite(r["Tc"]).all()
