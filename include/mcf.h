@@ -205,6 +205,46 @@ int mcf_plan_fetch(mcf_plan *plan, int32_t slot, int32_t var, int64_t step0,
  * pack kernel. */
 int mcf_plan_fetch_packed(mcf_plan *plan, int32_t slot, int32_t var, int64_t step0, int64_t nsteps,
                           double scale, int32_t *host_dst, float *kernel_ms);
+/* ---- writetonc sink ---------------------------------------------------------------------
+ * Replaces `writetonc(mout, fileout, dtm, reqhgt, vars)` (R/dataprep.R:1063-1260; called per tile by
+ * runmicro_big, R/Cppwrappers.R:531): the solver's outputs as int32 (x100 for Tz, tleaf, soilm,
+ * windspeed; x1 for relhum and the radiation terms; round half even; NA -> missval -9999) on the
+ * dimensions east, north, time, with writetonc's variable names, long names, units, `crs` variable and
+ * time attributes.  File format: netCDF classic, 64-bit offsets, `time` as the record dimension,
+ * uncompressed (the reference writes netCDF-4/deflate through ncdf4; every netCDF reader opens both;
+ * see mcf_ncfile.hpp).  The dataset keeps writetonc's orientation: north[i] belongs to raster row i,
+ * with `north` the ASCENDING northings of dataprep.R:1073 (the reference does not flip the rows).
+ *
+ * `vars[v]` selects solver output v (MCF_OUT order); writetonc defines Tz, tleaf, relhum, soilm,
+ * windspeed and the five radiation terms for reqhgt > 0, Tz, soilm and radiation for reqhgt == 0, Tz and
+ * soilm below ground — anything else is MCF_ERR_ARG.  `reference_puts_only` = 1 reproduces the file the
+ * reference really produces: its `ncvar_put` guards test names ("raddir", …) that never occur in `vars`
+ * (dataprep.R:1163-1167) and the soilm put refers to an undefined object (:1161), so those variables
+ * are defined but hold missval throughout; 0 writes what was evidently meant. */
+typedef struct mcf_nc_spec {
+    int32_t rows, cols;          /* raster rows (= length of north), columns (= length of east) */
+    int64_t nsteps;
+    const double *east;          /* [cols]  seq(xmin + res/2, xmax - res/2, res)                 */
+    const double *north;         /* [rows]  seq(ymin + res/2, ymax - res/2, res)                 */
+    const double *time_hours;    /* [nsteps] hours since 1970-01-01 00:00                        */
+    const char *crs_wkt;         /* crs(dtm); may be NULL                                        */
+    double reqhgt;
+    int32_t vars[MCF_NOUT];
+    int32_t reference_puts_only;
+} mcf_nc_spec;
+typedef struct mcf_ncfile mcf_ncfile;
+/* Host only (no device needed): create the file with header, coordinates and room for every record. */
+int mcf_nc_create(const char *path, const mcf_nc_spec *spec, mcf_ncfile **nc);
+/* Host only: records [step0, step0+nsteps) from host arrays; vars[v] = [rows, cols, nsteps] column-major
+ * doubles as mcf_runmicro1..4 return them (NULL for variables the file does not hold). */
+int mcf_nc_write_host(mcf_ncfile *nc, int64_t step0, int64_t nsteps, const double *const vars[MCF_NOUT]);
+/* Records [file_step0, file_step0+nsteps) straight from a plan's ring slot: packed, transposed and
+ * byte-ordered on the device (k_pack_nc, 4 B per value over PCIe instead of 8), written to the file
+ * while the next piece is being packed and copied. */
+int mcf_nc_write_plan(mcf_ncfile *nc, mcf_plan *plan, int32_t slot, int64_t slot_step0, int64_t file_step0,
+                      int64_t nsteps, float *kernel_ms);
+int mcf_nc_close(mcf_ncfile *nc);
+
 /* Device address of a ring slot variable (for device-side consumers). */
 int mcf_plan_slot_ptr(mcf_plan *plan, int32_t slot, int32_t var, void **dev_ptr);
 

@@ -129,6 +129,12 @@ class BigLeafOut(C.Structure):
     _fields_ = [(k, c_double_p) for k in BIGLEAF_FIELDS] + [("err", C.c_double), ("iters", C.c_int32)]
 
 
+class NcSpec(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("nsteps", C.c_int64), ("east", c_double_p),
+                ("north", c_double_p), ("time_hours", c_double_p), ("crs_wkt", C.c_char_p), ("reqhgt", C.c_double),
+                ("vars", C.c_int32 * 10), ("reference_puts_only", C.c_int32)]
+
+
 class SnowDriverIn(C.Structure):
     _fields_ = [("base", SnowInputs), ("dtm", c_double_p), ("res", C.c_double), ("tfact", C.c_double),
                 ("chunk_steps", C.c_int32), ("reserved", C.c_int32)]
@@ -155,6 +161,7 @@ EXPORTS = (
     "mcf_snowplan_create", "mcf_snowplan_destroy", "mcf_snowplan_chunks", "mcf_snowplan_surface",
     "mcf_snowplan_surface_partial", "mcf_snowplan_prepare_chunk", "mcf_snowplan_run_chunk",
     "mcf_bigleaf", "mcf_soilm", "mcf_pointmprocess", "mcf_weatherhgt",
+    "mcf_nc_create", "mcf_nc_write_host", "mcf_nc_write_plan", "mcf_nc_close",
 )
 
 _lib = None
@@ -243,6 +250,15 @@ def load() -> C.CDLL:
     lib.mcf_pointmprocess.argtypes = [C.c_int64] + [c_double_p] * 7 + [C.c_double] * 7 + [c_double_p] * 6
     lib.mcf_weatherhgt.restype = C.c_int
     lib.mcf_weatherhgt.argtypes = [C.c_int64, OT, PW] + [C.c_double] * 5 + [c_double_p] * 3
+    lib.mcf_nc_create.restype = C.c_int
+    lib.mcf_nc_create.argtypes = [C.c_char_p, C.POINTER(NcSpec), C.POINTER(C.c_void_p)]
+    lib.mcf_nc_write_host.restype = C.c_int
+    lib.mcf_nc_write_host.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(c_double_p * 10)]
+    lib.mcf_nc_write_plan.restype = C.c_int
+    lib.mcf_nc_write_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
+                                      C.POINTER(C.c_float)]
+    lib.mcf_nc_close.restype = C.c_int
+    lib.mcf_nc_close.argtypes = [C.c_void_p]
     lib.mcf_applycpp3.restype = C.c_int
     lib.mcf_applycpp3.argtypes = [c_double_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, c_double_p, c_double_p,
                                   C.c_int32]

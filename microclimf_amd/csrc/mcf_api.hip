@@ -12,12 +12,14 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <future>
 #include <string>
 #include <vector>
 
 #include "../../include/mcf.h"
 #include "mcf_kernels.h"
 #include "mcf_hostpipe.hpp"
+#include "mcf_ncfile.hpp"
 
 namespace {
 
@@ -216,6 +218,69 @@ int ensure_cells(mcf_plan* p) {
   }
     p->cells_ready = true;
     return MCF_OK;
+}
+
+}  // namespace
+
+// ---- writetonc sink (R/dataprep.R:1063-1260) -------------------------------------------------------------------
+struct mcf_ncfile {
+    mcf::NcFile f;
+    int var_of[MCF_NOUT];        // file variable index of solver output v, or -1
+    int out_of[MCF_NOUT];        // solver output of file variable k
+    double scale[MCF_NOUT];      // per file variable
+    int fill_only[MCF_NOUT];
+    std::vector<uint8_t> stage[2];
+};
+
+namespace {
+
+std::string r_number(double x) {   // as.character(<double>): 15 significant digits
+    char b[64];
+    snprintf(b, sizeof b, "%.15g", x);
+    return b;
+}
+
+// variables writetonc defines for a height, with its long names and units (dataprep.R:1097-1157, 1180-1214, 1234-1244)
+bool nc_var_def(int v, double reqhgt, mcf::NcVarDef* d, double* scale, bool* put_by_reference) {
+    static const char* names[MCF_NOUT] = {"Tz", "tleaf", "relhum", "soilm", "windspeed", "Rdirdown", "Rdifdown",
+                                          "Rlwdown", "Rswup", "Rlwup"};
+    static const char* radlong[5] = {"Downward direct shortwave radiation", "Downward diffuse shortwave radiation",
+                                     "Downward longwave radiation", "Upward shortwave radiation", "Upward longwave radiation"};
+    d->name = names[v];
+    *put_by_reference = true;
+    const std::string h = r_number(fabs(reqhgt));
+    if (v >= 5) {
+        if (reqhgt < 0) return false;
+        d->long_name = radlong[v - 5]; d->units = "W/m^2"; *scale = 1;
+        *put_by_reference = false;   // `if ("raddir" %in% vars)` never holds for the documented names (dataprep.R:1163-1167)
+        return true;
+    }
+    switch (v) {
+    case 0:
+        d->long_name = reqhgt > 0 ? "Air temperature at height " + h + " m"
+                     : reqhgt == 0 ? std::string("Soil surface temperature") : "Soil temperature at depth " + h + " m";
+        d->units = "deg C x 100"; *scale = 100; return true;
+    case 1:
+        if (!(reqhgt > 0)) return false;
+        d->long_name = "Leaf temperature at height " + h + " m"; d->units = "deg C x 100"; *scale = 100; return true;
+    case 2:
+        if (!(reqhgt > 0)) return false;
+        d->long_name = "Relative humidity at height " + h + " m"; d->units = "Percentage"; *scale = 1; return true;
+    case 3:
+        d->long_name = "Soil surface moisture";
+        d->units = reqhgt < 0 ? "Percentage volume" : "Volume percentage soil moisture in top 10 cm of soil";
+        *scale = 100;
+        *put_by_reference = false;   // `ncvar_put(nccew, …)`: an undefined object, the put is an R error (dataprep.R:1161)
+        return true;
+    default:
+        if (!(reqhgt > 0)) return false;
+        d->long_name = "Wind speed at height " + h + " m"; d->units = "m/s x 100"; *scale = 100; return true;
+    }
+}
+
+inline int32_t nc_pack(double x, double scale) {
+    const double q = rint(x * scale);
+    return (q > -2147483648.0 && q < 2147483648.0) ? (int32_t)q : mcf::NcFile::kMissval;
 }
 
 }  // namespace
@@ -611,6 +676,148 @@ int mcf_plan_fetch_packed(mcf_plan* p, int32_t slot, int32_t var, int64_t step0,
     HIP_TRY(hipMemcpyAsync(host_dst, p->d_pack, (size_t)(p->N * nsteps) * 4, hipMemcpyDeviceToHost, p->stream));
     HIP_TRY(hipStreamSynchronize(p->stream));
     if (kernel_ms) HIP_TRY(hipEventElapsedTime(kernel_ms, p->ev0, p->ev1));
+    return MCF_OK;
+}
+
+int mcf_nc_create(const char* path, const mcf_nc_spec* sp, mcf_ncfile** out) {
+    if (!path || !sp || !out) return fail(MCF_ERR_ARG, "null argument");
+    if (sp->rows <= 0 || sp->cols <= 0 || sp->nsteps < 0 || !sp->east || !sp->north || (sp->nsteps > 0 && !sp->time_hours))
+        return fail(MCF_ERR_ARG, "mcf_nc_create: bad dimensions or null coordinate vector");
+    mcf_ncfile* nc = new mcf_ncfile();
+    std::vector<mcf::NcVarDef> defs;
+    for (int v = 0; v < MCF_NOUT; ++v) {
+        nc->var_of[v] = -1;
+        if (!sp->vars[v]) continue;
+        mcf::NcVarDef d;
+        double sc;
+        bool put;
+        if (!nc_var_def(v, sp->reqhgt, &d, &sc, &put)) {
+            delete nc;
+            return fail(MCF_ERR_ARG, "mcf_nc_create: writetonc defines no variable '" + d.name + "' at this reqhgt");
+        }
+        const int k = (int)defs.size();
+        nc->var_of[v] = k; nc->out_of[k] = v; nc->scale[k] = sc;
+        nc->fill_only[k] = (sp->reference_puts_only && !put) ? 1 : 0;
+        defs.push_back(d);
+    }
+    if (defs.empty()) { delete nc; return fail(MCF_ERR_ARG, "mcf_nc_create: no variable selected"); }
+    const std::string e = nc->f.create(path, sp->rows, sp->cols, sp->nsteps, sp->east, sp->north, sp->time_hours,
+                                       sp->crs_wkt, defs);
+    if (!e.empty()) { delete nc; return fail(MCF_ERR_ARG, "mcf_nc_create: " + e); }
+    *out = nc;
+    return MCF_OK;
+}
+
+int mcf_nc_close(mcf_ncfile* nc) {
+    if (!nc) return MCF_OK;
+    const std::string e = nc->f.close();
+    delete nc;
+    return e.empty() ? MCF_OK : fail(MCF_ERR_ARG, "mcf_nc_close: " + e);
+}
+
+int mcf_nc_write_host(mcf_ncfile* nc, int64_t step0, int64_t nsteps, const double* const vars[MCF_NOUT]) {
+    if (!nc || !vars) return fail(MCF_ERR_ARG, "null argument");
+    if (step0 < 0 || nsteps < 0 || step0 + nsteps > nc->f.nsteps) return fail(MCF_ERR_ARG, "mcf_nc_write_host: step range outside the file");
+    const int64_t R = nc->f.rows, C = nc->f.cols, N = R * C, rb = nc->f.rec_bytes;
+    for (int k = 0; k < nc->f.nvars; ++k)
+        if (!nc->fill_only[k] && !vars[nc->out_of[k]]) return fail(MCF_ERR_ARG, "mcf_nc_write_host: a variable of the file is missing");
+    const int64_t piece = std::max<int64_t>(1, ((int64_t)64 << 20) / rb);
+    std::vector<uint8_t>& st = nc->stage[0];
+    for (int64_t s0 = 0; s0 < nsteps; s0 += piece) {
+        const int64_t n = std::min(piece, nsteps - s0);
+        st.resize((size_t)(n * rb));
+        for (int64_t s = 0; s < n; ++s)
+            for (int k = 0; k < nc->f.nvars; ++k) {
+                uint8_t* dst = st.data() + s * rb + 8 + (int64_t)k * N * 4;
+                const double* src = nc->fill_only[k] ? nullptr : vars[nc->out_of[k]] + (s0 + s) * N;
+                for (int64_t r = 0; r < R; ++r)
+                    for (int64_t c = 0; c < C; ++c)
+                        mcf::NcFile::store_i32(dst + 4 * (c + C * r), src ? nc_pack(src[r + R * c], nc->scale[k]) : mcf::NcFile::kMissval);
+            }
+        const std::string e = nc->f.write_records(step0 + s0, n, st.data());
+        if (!e.empty()) return fail(MCF_ERR_ARG, "mcf_nc_write_host: " + e);
+    }
+    return MCF_OK;
+}
+
+int mcf_nc_write_plan(mcf_ncfile* nc, mcf_plan* p, int32_t slot, int64_t slot_step0, int64_t file_step0, int64_t nsteps,
+                      float* kernel_ms) {
+    if (!nc || !p) return fail(MCF_ERR_ARG, "null argument");
+    if (nc->f.rows != p->rows || nc->f.cols != p->cols) return fail(MCF_ERR_ARG, "mcf_nc_write_plan: the file's grid is not the plan's");
+    if (slot < 0 || slot >= p->ring_slots) return fail(MCF_ERR_ARG, "bad slot");
+    const int64_t cap_steps = (int64_t)p->ring_days * 24;
+    if (slot_step0 < 0 || nsteps < 0 || slot_step0 + nsteps > cap_steps) return fail(MCF_ERR_ARG, "step range out of slot");
+    if (file_step0 < 0 || file_step0 + nsteps > nc->f.nsteps) return fail(MCF_ERR_ARG, "mcf_nc_write_plan: step range outside the file");
+    mcf::PackNcArgs a{};
+    a.nv = nc->f.nvars; a.missval = mcf::NcFile::kMissval; a.rows = p->rows; a.cols = p->cols;
+    a.rec_words = nc->f.rec_bytes / 4;
+    for (int k = 0; k < a.nv; ++k) {
+        const int v = nc->out_of[k];
+        a.scale[k] = nc->scale[k];
+        a.fill_only[k] = nc->fill_only[k];
+        if (a.fill_only[k]) { a.src[k] = p->d_ring; continue; }   // never read
+        if (p->var_slot[v] < 0) return fail(MCF_ERR_ARG, "mcf_nc_write_plan: a variable of the file was not requested in out[]");
+        a.src[k] = p->d_ring + ((int64_t)slot * p->nvars + p->var_slot[v]) * (p->N * cap_steps) + p->N * slot_step0;
+    }
+    HIP_TRY(hipSetDevice(p->device));
+    const int64_t rb = nc->f.rec_bytes;
+    int64_t piece = std::min<int64_t>(65535 / a.nv, std::max<int64_t>(1, ((int64_t)256 << 20) / rb));
+    piece = std::min(piece, std::max<int64_t>(nsteps, 1));
+    if (p->pack_elems < piece * (rb / 4)) {
+        int rc;
+        void* q;
+        if ((rc = dalloc(p, &q, piece * rb))) return rc;
+        p->d_pack = (int32_t*)q;
+        p->pack_elems = piece * (rb / 4);
+    }
+    a.dst = p->d_pack;
+    static const bool no_pipe = getenv("MCF_NO_HOSTPIPE") != nullptr;
+    std::future<std::string> pending;            // the previous piece going to disk while this one is packed and copied
+    float kms = 0;
+    int rc = MCF_OK;
+    std::string werr;
+    for (int64_t s0 = 0, i = 0; s0 < nsteps && rc == MCF_OK; s0 += piece, ++i) {
+        const int64_t n = std::min(piece, nsteps - s0);
+        std::vector<uint8_t>& st = nc->stage[i & 1];
+        mcf::PackNcArgs b = a;
+        for (int k = 0; k < a.nv; ++k) b.src[k] = a.src[k] + (a.fill_only[k] ? 0 : s0 * p->N);
+        hipError_t e = hipSuccess;
+        if (kernel_ms) e = hipEventRecord(p->ev0, p->stream);
+        mcf::launch_pack_nc(b, n, p->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess && kernel_ms) e = hipEventRecord(p->ev1, p->stream);
+        // stage[i & 1] was handed to the writer two pieces ago: that write has been joined (below) before piece i-1 began
+        st.resize((size_t)(n * rb));
+        const size_t bytes = (size_t)(n * rb);
+        if (e == hipSuccess) {
+            if (bytes >= ((size_t)64 << 20) && !no_pipe && ensure_pipe(p)) {
+                e = hipEventRecord(p->ev_pipe, p->stream);
+                if (e == hipSuccess) e = p->pipe->copy(st.data(), p->d_pack, bytes, p->ev_pipe);
+            } else {
+                e = hipMemcpyAsync(st.data(), p->d_pack, bytes, hipMemcpyDeviceToHost, p->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+            }
+        }
+        if (e == hipSuccess && kernel_ms) {
+            float ms = 0;
+            e = hipEventElapsedTime(&ms, p->ev0, p->ev1);
+            kms += ms;
+        }
+        if (pending.valid()) werr = pending.get();
+        if (e != hipSuccess) { rc = fail(MCF_ERR_HIP, std::string("mcf_nc_write_plan: ") + hipGetErrorString(e)); break; }
+        if (!werr.empty()) break;
+        mcf::NcFile* f = &nc->f;
+        uint8_t* data = st.data();
+        const int64_t fs = file_step0 + s0;
+        pending = std::async(std::launch::async, [f, fs, n, data] { return f->write_records(fs, n, data); });
+    }
+    if (pending.valid()) {
+        const std::string e2 = pending.get();
+        if (werr.empty()) werr = e2;
+    }
+    if (rc != MCF_OK) return rc;
+    if (!werr.empty()) return fail(MCF_ERR_ARG, "mcf_nc_write_plan: " + werr);
+    if (kernel_ms) *kernel_ms = kms;
     return MCF_OK;
 }
 

@@ -100,6 +100,18 @@ struct BioclimArgs {
 };
 void launch_bioclim(const BioclimArgs& a, hipStream_t s);
 void launch_fill(double* p, int64_t n, double v, hipStream_t s);
+struct PackNcArgs {
+    const double* src[10];   // first step of each variable, [rows, cols, steps] column-major
+    double scale[10];
+    int32_t fill_only[10];
+    int32_t nv;
+    int32_t missval;
+    int64_t rows, cols;
+    int64_t rec_words;       // record length in 4-byte words (2 + nv * rows * cols)
+    int32_t* dst;            // first record
+};
+// at most 65535 / nv steps per launch
+void launch_pack_nc(const PackNcArgs& a, int64_t nsteps, hipStream_t s);
 void launch_pack_transpose(const double* src, int64_t rows, int64_t cols, int64_t nsteps, double scale, int32_t* dst,
                            hipStream_t s);
 // out2: twi_scratch_doubles() doubles; [0] = sum, [1] = count on completion

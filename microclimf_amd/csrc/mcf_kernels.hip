@@ -950,8 +950,47 @@ __global__ __launch_bounds__(256) void k_pack_transpose(const double* __restrict
 }
 
 // ------------------------------------------------------------------------------------
+// NetCDF record sink (mcf_ncfile.hpp): the same transpose + round as k_pack_transpose for up to MCF_NOUT variables
+// at once, written where the classic-format file wants them — record `step` = [8 B time | var0[rows][cols] | var1 …],
+// big-endian int32, NA / out-of-range -> the file's missval.  blockIdx.z = step * nv + v.  `fill_only[v]`: the
+// variable is defined in the file but never put by writetonc (R/dataprep.R:1163-1167), so it holds missval.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_nc(PackNcArgs a) {
+    __shared__ int32_t tile[32][33];
+    const int step = blockIdx.z / a.nv, v = blockIdx.z - step * a.nv;
+    const int64_t N = a.rows * a.cols;
+    const double* in = a.src[v] + (int64_t)step * N;
+    int32_t* out = a.dst + (int64_t)step * a.rec_words + 2 + (int64_t)v * N;
+    const double scale = a.scale[v];
+    const bool fill = a.fill_only[v] != 0;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t r0 = (int64_t)blockIdx.x * 32, c0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t r = r0 + tx, c = c0 + j;
+        int32_t q = a.missval;
+        if (!fill && r < a.rows && c < a.cols) {
+            const double x = rint(in[r + a.rows * c] * scale);
+            if (x > -2147483648.0 && x < 2147483648.0) q = (int32_t)x;
+        }
+        tile[j][tx] = (int32_t)__builtin_bswap32((uint32_t)q);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t c = c0 + tx, r = r0 + j;
+        if (r < a.rows && c < a.cols) out[c + a.cols * r] = tile[tx][j];
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------
+void launch_pack_nc(const PackNcArgs& a, int64_t nsteps, hipStream_t s) {
+    if (nsteps <= 0 || a.nv <= 0) return;
+    dim3 grid((unsigned)((a.rows + 31) / 32), (unsigned)((a.cols + 31) / 32), (unsigned)(nsteps * a.nv));
+    hipLaunchKernelGGL(k_pack_nc, grid, dim3(256), 0, s, a);
+}
 void launch_pack_transpose(const double* src, int64_t rows, int64_t cols, int64_t nsteps, double scale, int32_t* dst,
                            hipStream_t s) {
     if (nsteps <= 0) return;

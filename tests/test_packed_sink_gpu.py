@@ -74,3 +74,62 @@ def test_large_fetch_through_the_host_pipe_is_bitwise_the_plain_copy():
             assert np.array_equal(big.view(np.uint64), small.view(np.uint64)), var
             odd = p.fetch(0, var, 3, 41)                                   # 84.8 MB, not a multiple of the piece size
             assert np.array_equal(odd.view(np.uint64), small[:, :, 3:44].view(np.uint64)), var
+
+
+# ---- the writetonc file sink: records packed and byte-ordered on the device (k_pack_nc) --------------------------
+def _nc_inputs(rows, cols, T):
+    from microclimf_amd import ncsink
+    east, north = ncsink.coords_from_extent(0.0, cols * 5.0, 100.0, 100.0 + rows * 5.0, 5.0)
+    return ncsink, east, north, 473352.0 + np.arange(T)
+
+
+@pytest.mark.parametrize("rows,cols,puts_only", [(37, 29, False), (64, 32, True), (5, 70, False)])
+def test_nc_file_from_the_device_ring_is_bytewise_the_host_written_file(rows, cols, puts_only, tmp_path):
+    """two routes to the same file: device ring -> k_pack_nc -> records (chunks of 1 and 2 days, second chunk first),
+    and plain fp64 fetch -> mcf_nc_write_host (itself checked against scipy + numpy in tests/test_ncsink_cpu.py)"""
+    T = 72
+    ncsink, east, north, hours = _nc_inputs(rows, cols, T)
+    a = synthetic.workload(rows, cols, T, reqhgt=0.05, variety=True, start_doy=120, na_frac=0.05)
+    names = ncsink.default_vars(0.05) + ("soilm",)
+    with Plan(a["obstime"], a["climdata"], a["pointm"], a["vegp"], a["soilc"], a["reqhgt"], a["zref"], a["lat"],
+              a["lon"], a["Sminp"], a["Smaxp"], a["tfact"], True, a["mat"], a["out"], ring_days=3) as p:
+        p.run_days(0, 3)
+        p.sync()
+        with ncsink.NcWriter(tmp_path / "dev.nc", rows, cols, hours, east, north, 0.05, names, "wkt", puts_only) as w:
+            ms = w.write_plan(p, 0, 24, 24, 48, timing=True)
+            w.write_plan(p, 0, 0, 0, 24)
+            assert ms > 0
+        with ncsink.NcWriter(tmp_path / "host.nc", rows, cols, hours, east, north, 0.05, names, "wkt", puts_only) as w:
+            w.write_host(0, {k: p.fetch(0, k, 0, T) for k in names})
+        tz = p.fetch(0, "Tz", 0, T)
+    dev, host = (tmp_path / "dev.nc").read_bytes(), (tmp_path / "host.nc").read_bytes()
+    assert len(dev) == len(host) and dev == host
+    from scipy.io import netcdf_file
+    f = netcdf_file(str(tmp_path / "dev.nc"), "r", mmap=False)
+    got = np.transpose(f.variables["Tz"][:], (2, 1, 0))
+    want = atonc(tz, 100.0)
+    want[want == NA_INT] = -9999
+    assert np.array_equal(got, want)
+    if puts_only:
+        assert (f.variables["Rswup"][:] == -9999).all() and (f.variables["soilm"][:] == -9999).all()
+    else:
+        assert (f.variables["Rlwup"][:] != -9999).any()
+    f.close()
+
+
+def test_nc_sink_needs_the_files_variables_in_the_plan(tmp_path):
+    from microclimf_amd import _abi
+    ncsink, east, north, hours = _nc_inputs(8, 8, 24)
+    a = synthetic.workload(8, 8, 24, reqhgt=0.05, out=[1, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    with Plan(a["obstime"], a["climdata"], a["pointm"], a["vegp"], a["soilc"], a["reqhgt"], a["zref"], a["lat"],
+              a["lon"], a["Sminp"], a["Smaxp"], a["tfact"], True, a["mat"], a["out"], ring_days=1) as p:
+        p.run_days(0, 1)
+        p.sync()
+        with ncsink.NcWriter(tmp_path / "a.nc", 8, 8, hours, east, north, 0.05, ("Tz", "tleaf")) as w:
+            with pytest.raises(_abi.McfError, match="not requested"):
+                w.write_plan(p, 0, 0, 0, 24)
+        with ncsink.NcWriter(tmp_path / "b.nc", 8, 9, hours, np.arange(9.0), north, 0.05, ("Tz",)) as w:
+            with pytest.raises(_abi.McfError, match="grid"):
+                w.write_plan(p, 0, 0, 0, 24)
+        with ncsink.NcWriter(tmp_path / "c.nc", 8, 8, hours, east, north, 0.05, ("Tz",)) as w:
+            w.write_plan(p, 0, 0, 0, 24)                                    # Tz alone is fine
