@@ -34,8 +34,11 @@
  *      decides what (if anything) is copied back.  bench.py and multi-GPU row
  *      tiling use this level.
  *
- * There is no CPU fallback: every entry point fails with MCF_ERR_NO_DEVICE when
- * no HIP device is usable.
+ * There is no CPU fallback: every solver / kernel entry point fails with
+ * MCF_ERR_NO_DEVICE when no HIP device is usable.  Host-side by nature, as in the
+ * reference, and therefore usable without a device: the one-point time-series model
+ * (mcf_bigleaf, mcf_soilm, mcf_pointmprocess, mcf_weatherhgt) and the file side of
+ * the writetonc sink (mcf_nc_create, mcf_nc_write_host, mcf_nc_close).
  */
 #ifndef MCF_H
 #define MCF_H

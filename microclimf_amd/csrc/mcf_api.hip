@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <future>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -229,7 +230,13 @@ struct mcf_ncfile {
     int out_of[MCF_NOUT];        // solver output of file variable k
     double scale[MCF_NOUT];      // per file variable
     int fill_only[MCF_NOUT];
-    std::vector<uint8_t> stage[2];
+    // staging of records on their way to the file; plain arrays, not vectors: no zero-fill of memory about to be overwritten
+    std::unique_ptr<uint8_t[]> stage[2];
+    size_t stage_bytes[2] = {0, 0};
+    uint8_t* staging(int i, size_t n) {
+        if (stage_bytes[i] < n) { stage[i].reset(new uint8_t[n]); stage_bytes[i] = n; }
+        return stage[i].get();
+    }
 };
 
 namespace {
@@ -722,19 +729,18 @@ int mcf_nc_write_host(mcf_ncfile* nc, int64_t step0, int64_t nsteps, const doubl
     for (int k = 0; k < nc->f.nvars; ++k)
         if (!nc->fill_only[k] && !vars[nc->out_of[k]]) return fail(MCF_ERR_ARG, "mcf_nc_write_host: a variable of the file is missing");
     const int64_t piece = std::max<int64_t>(1, ((int64_t)64 << 20) / rb);
-    std::vector<uint8_t>& st = nc->stage[0];
     for (int64_t s0 = 0; s0 < nsteps; s0 += piece) {
         const int64_t n = std::min(piece, nsteps - s0);
-        st.resize((size_t)(n * rb));
+        uint8_t* st = nc->staging(0, (size_t)(n * rb));
         for (int64_t s = 0; s < n; ++s)
             for (int k = 0; k < nc->f.nvars; ++k) {
-                uint8_t* dst = st.data() + s * rb + 8 + (int64_t)k * N * 4;
+                uint8_t* dst = st + s * rb + 8 + (int64_t)k * N * 4;
                 const double* src = nc->fill_only[k] ? nullptr : vars[nc->out_of[k]] + (s0 + s) * N;
                 for (int64_t r = 0; r < R; ++r)
                     for (int64_t c = 0; c < C; ++c)
                         mcf::NcFile::store_i32(dst + 4 * (c + C * r), src ? nc_pack(src[r + R * c], nc->scale[k]) : mcf::NcFile::kMissval);
             }
-        const std::string e = nc->f.write_records(step0 + s0, n, st.data());
+        const std::string e = nc->f.write_records(step0 + s0, n, st);
         if (!e.empty()) return fail(MCF_ERR_ARG, "mcf_nc_write_host: " + e);
     }
     return MCF_OK;
@@ -778,7 +784,6 @@ int mcf_nc_write_plan(mcf_ncfile* nc, mcf_plan* p, int32_t slot, int64_t slot_st
     std::string werr;
     for (int64_t s0 = 0, i = 0; s0 < nsteps && rc == MCF_OK; s0 += piece, ++i) {
         const int64_t n = std::min(piece, nsteps - s0);
-        std::vector<uint8_t>& st = nc->stage[i & 1];
         mcf::PackNcArgs b = a;
         for (int k = 0; k < a.nv; ++k) b.src[k] = a.src[k] + (a.fill_only[k] ? 0 : s0 * p->N);
         hipError_t e = hipSuccess;
@@ -787,14 +792,14 @@ int mcf_nc_write_plan(mcf_ncfile* nc, mcf_plan* p, int32_t slot, int64_t slot_st
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess && kernel_ms) e = hipEventRecord(p->ev1, p->stream);
         // stage[i & 1] was handed to the writer two pieces ago: that write has been joined (below) before piece i-1 began
-        st.resize((size_t)(n * rb));
         const size_t bytes = (size_t)(n * rb);
+        uint8_t* st = nc->staging((int)(i & 1), bytes);
         if (e == hipSuccess) {
             if (bytes >= ((size_t)64 << 20) && !no_pipe && ensure_pipe(p)) {
                 e = hipEventRecord(p->ev_pipe, p->stream);
-                if (e == hipSuccess) e = p->pipe->copy(st.data(), p->d_pack, bytes, p->ev_pipe);
+                if (e == hipSuccess) e = p->pipe->copy(st, p->d_pack, bytes, p->ev_pipe);
             } else {
-                e = hipMemcpyAsync(st.data(), p->d_pack, bytes, hipMemcpyDeviceToHost, p->stream);
+                e = hipMemcpyAsync(st, p->d_pack, bytes, hipMemcpyDeviceToHost, p->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
             }
         }
@@ -807,7 +812,7 @@ int mcf_nc_write_plan(mcf_ncfile* nc, mcf_plan* p, int32_t slot, int64_t slot_st
         if (e != hipSuccess) { rc = fail(MCF_ERR_HIP, std::string("mcf_nc_write_plan: ") + hipGetErrorString(e)); break; }
         if (!werr.empty()) break;
         mcf::NcFile* f = &nc->f;
-        uint8_t* data = st.data();
+        uint8_t* data = st;
         const int64_t fs = file_step0 + s0;
         pending = std::async(std::launch::async, [f, fs, n, data] { return f->write_records(fs, n, data); });
     }
