@@ -19,6 +19,45 @@ def row_block(rank: int, world: int, rows_total: int):
     return row0, rows
 
 
+def balanced_row_blocks(valid_per_row, world: int, multiple: int = 10):
+    """[(row0, rows)] per rank: contiguous row blocks holding about the same number of VALID cells (non-NA `hgt`),
+    the solver's unit of work — NA cells cost nothing, so equal row counts leave ranks idle on rasters with sea or
+    no-data areas.  Interior boundaries fall on multiples of `multiple` rows (10 keeps the wind-shelter
+    pre-compute's 10 x 10 aggregation blocks inside one tile, R/internal.R:980); every rank gets at least one such
+    group while there are enough rows."""
+    import numpy as np
+    w = np.asarray(valid_per_row, dtype=np.float64)
+    rows_total = len(w)
+    if world < 1 or multiple < 1:
+        raise ValueError("world and multiple must be >= 1")
+    ngroups = -(-rows_total // multiple)
+    if ngroups < world:                       # fewer groups than ranks: fall back to single rows
+        if multiple > 1:
+            return balanced_row_blocks(w, world, 1)
+        return [row_block(r, world, rows_total) for r in range(world)]
+    gw = np.add.reduceat(w, np.arange(0, rows_total, multiple))
+    cum = np.concatenate([[0.0], np.cumsum(gw)])
+    total = cum[-1]
+    cuts = [0]
+    for r in range(1, world):
+        if total > 0:
+            g = int(np.searchsorted(cum, total * r / world, side="left"))
+            # the nearer of the two neighbouring group boundaries
+            if g > 0 and abs(cum[g - 1] - total * r / world) <= abs(cum[min(g, ngroups)] - total * r / world):
+                g -= 1
+        else:
+            g = ngroups * r // world
+        g = min(max(g, cuts[-1] + 1), ngroups - (world - r))      # strictly increasing, leave a group for each later rank
+        cuts.append(g)
+    cuts.append(ngroups)
+    out = []
+    for r in range(world):
+        row0 = cuts[r] * multiple
+        row1 = min(cuts[r + 1] * multiple, rows_total)
+        out.append((row0, row1 - row0))
+    return out
+
+
 def allreduce_twi_mean(local_sum: float, local_count: float, device=None) -> float:
     """Global mean from per-rank partial (sum, count); a no-op without an initialised
     process group."""

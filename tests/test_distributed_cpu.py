@@ -51,6 +51,30 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def test_balanced_row_blocks_follow_the_valid_cells():
+    from microclimf_amd.distributed import balanced_row_blocks
+    rng = np.random.default_rng(5)
+    valid = np.full(1030, 1024.0)
+    valid[:400] = 0                                   # sea in the north
+    valid[400:520] = rng.integers(0, 300, 120)        # a ragged coast
+    for world in (1, 2, 3, 8):
+        blocks = balanced_row_blocks(valid, world)
+        assert blocks[0][0] == 0 and sum(n for _, n in blocks) == 1030
+        for (a, n), (b, _) in zip(blocks, blocks[1:]):
+            assert a + n == b and n > 0 and b % 10 == 0
+        work = np.array([valid[a:a + n].sum() for a, n in blocks])
+        assert work.max() <= valid.sum() / world + 10 * 1024          # within one 10-row group of the ideal share
+    eq = np.array([valid[a:a + n].sum() for a, n in [row_block(r, 8, 1030) for r in range(8)]])
+    bal = np.array([valid[a:a + n].sum() for a, n in balanced_row_blocks(valid, 8)])
+    assert bal.max() < 0.75 * eq.max()                                 # equal rows would leave three ranks idle
+    # degenerate inputs: all-NA raster, fewer row groups than ranks, fewer rows than ranks
+    assert [n for _, n in balanced_row_blocks(np.zeros(80), 4)] == [20, 20, 20, 20]
+    b = balanced_row_blocks(np.ones(25), 4)
+    assert sum(n for _, n in b) == 25 and all(n > 0 for _, n in b)
+    b = balanced_row_blocks(np.ones(3), 4)
+    assert sum(n for _, n in b) == 3
+
+
 def test_row_block_partition():
     for world in (1, 2, 3, 8):
         blocks = [row_block(r, world, 1030) for r in range(world)]
