@@ -201,6 +201,9 @@ def workload(rows: int, cols: int, tsteps: int, reqhgt: float = 0.05, zref: floa
     """Positional-argument dict for runmicro1Cpp / runmicro2Cpp."""
     obstime, climdata, pointm = forcing_vectors(tsteps, lat, lon, year, start_doy, seed, cold)
     vegp, soilc, _ = rasters(rows, cols, row0, rows_total, seed, reqhgt, hgt_range, na_frac=na_frac, variety=variety)
+    # column-major like the R matrices / arrays the reference receives (marshal() then takes them without a copy)
+    vegp = {k: np.asfortranarray(v) for k, v in vegp.items()}
+    soilc = {k: np.asfortranarray(v) for k, v in soilc.items()}
     args = dict(obstime=obstime, climdata=climdata, pointm=pointm, vegp=vegp, soilc=soilc,
                 reqhgt=reqhgt, zref=zref, lat=lat, lon=lon, Sminp=0.074, Smaxp=0.42, tfact=1.5,
                 complete=complete, mat=10.0, out=[True] * 10 if out is None else list(out))
