@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--terrain", choices=["random", "device"], default="random",
                     help="'device': slope/aspect/hor/svfa/wsa come from mcf_precompute_terrain run on the "
                          "synthetic DTM (BASELINE.json configs[2]); 'random': SURVEY 8d's random terrain inputs")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="'weak' (default): --rows rows PER GPU; 'strong': --rows is the whole raster, dealt to the ranks "
+                         "in row blocks (e.g. --rows 8192 --cols 8192 --scaling strong --gpus 8 = BASELINE.json configs[3])")
     ap.add_argument("--array-forcing", action="store_true",
                     help="secondary measurement: runmicro2Cpp geometry; ring_slots x ring_days days of forcing are "
                          "resident in HBM and solved repeatedly (a year of array forcing, 1.1 TB at 1024^2, "
@@ -102,6 +105,11 @@ def main():
     from microclimf_amd.distributed import allreduce_max, allreduce_sum, allreduce_twi_mean
 
     rows, cols, T = args.rows, args.cols, args.tsteps
+    row0, rows_total = rank * rows, rows * world
+    if args.scaling == "strong":
+        from microclimf_amd.distributed import row_block
+        rows_total = args.rows
+        row0, rows = row_block(rank, world, rows_total)
     ndays = T // 24
     af = args.array_forcing
     # the output ring (and, with array forcing, the forcing slabs) must fit the GPU: shrink the days per slot
@@ -112,14 +120,14 @@ def main():
     if af:
         T = min(T, args.ring_days * args.ring_slots * 24)
         ndays = T // 24
-    a = synthetic.workload(rows, cols, T, reqhgt=args.reqhgt, row0=rank * rows, rows_total=rows * world,
+    a = synthetic.workload(rows, cols, T, reqhgt=args.reqhgt, row0=row0, rows_total=rows_total,
                            array_forcing=af, start_doy=152 if af else 1)
     terrain_s = None
     if args.terrain == "device":
         from microclimf_amd.terrain import precompute_terrain_tiled
-        _, _, dtm = synthetic.rasters(rows, cols, rank * rows, rows * world, reqhgt=args.reqhgt)
+        _, _, dtm = synthetic.rasters(rows, cols, row0, rows_total, reqhgt=args.reqhgt)
         tt0 = time.perf_counter()
-        ter = precompute_terrain_tiled(dtm, 1.0, a["zref"], rank, world, rank * rows, rows * world,
+        ter = precompute_terrain_tiled(dtm, 1.0, a["zref"], rank, world, row0, rows_total,
                                        device=local_rank)
         terrain_s = time.perf_counter() - tt0
         a["soilc"].update(ter)
@@ -182,10 +190,11 @@ def main():
         line = {
             "metric": "cell-steps/s", "value": value, "unit": "cell-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": (f"{rows}x{cols} synthetic DTM per GPU, {T} hourly steps, "
+                "workload": ((f"{rows}x{cols} synthetic DTM per GPU" if args.scaling == "weak" else
+                              f"{rows_total}x{cols} synthetic DTM over {world} GPU(s)") + f", {T} hourly steps, "
                              + ("array forcing (runmicro2Cpp geometry), forcing resident in HBM, "
                                 if af else "vector forcing (runmicro1Cpp geometry), ")
                              + f"reqhgt={args.reqhgt}, no snow"
