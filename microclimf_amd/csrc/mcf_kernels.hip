@@ -798,8 +798,11 @@ __global__ __launch_bounds__(64) void k_belowground(BelowArgs a) {
             }
         }
     }
-    if (blend_year && !(nb < a.hiy))
-        for (int i = nd * 24; i < m; ++i) z[N * i] = a.mat;
+    // Steps past the last whole day: the reference indexes its day statistics (vectors of nd*24 elements,
+    // cpp:517-519) with them, a read past the end.  With zeros there (what the oracle's zero-filled arrays give)
+    // rat = 0/0, so every blend that uses Tzd is NaN; only the `mat` branch has a defined value.
+    for (int i = nd * 24; i < m; ++i)
+        z[N * i] = (blend_year && !(nb < a.hiy)) ? a.mat : __longlong_as_double(0x7FF8000000000000LL);
 }
 
 // ------------------------------------------------------------------------------------

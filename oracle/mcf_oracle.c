@@ -832,6 +832,8 @@ void orc_tbelowground(double reqhgt, const double *Tg, const double *Tgp, const 
         }
         return;
     }
+    /* hourtodayCpp returns (tsteps/24)*24 elements (cpp:517-519) and cpp:1501-1515 index them up to tsteps: with a
+     * ragged last day the reference reads past the end.  Zero-filled full-length arrays here: the tail's rat is 0/0. */
     size_t nb_ = (size_t)(tsteps > 0 ? tsteps : 1) * sizeof(double);
     double *Tzd = (double *)calloc(1, nb_), *Tbpd = (double *)calloc(1, nb_);
     double *gmx = (double *)calloc(1, nb_), *gmn = (double *)calloc(1, nb_), *gme = (double *)calloc(1, nb_);
