@@ -84,3 +84,59 @@ def test_random_plan_schedules_equal_the_one_shot_call(i):
                 want = ref[k][:, :, d0 * 24 + s0:d0 * 24 + s0 + n]
                 assert np.array_equal(got.view(np.uint64), np.asfortranarray(want).view(np.uint64)), k   # bit for bit
             slot = (slot + 1) % slots
+
+
+@pytest.mark.parametrize("i", range(12))
+def test_random_bioclim_selection(oracle, i):
+    from microclimf_amd.api import runbioclim1Cpp, runbioclim2Cpp
+    rng = np.random.default_rng(6600 + i)
+    nq = [int(rng.integers(1, 4)) * 24 for _ in range(4)]                    # quarter lengths (the divisor stays 72, cpp:3325)
+    T = 336 + sum(nq)
+    af = bool(rng.random() < 0.3)
+    a = synthetic.workload(int(rng.integers(1, 16)), int(rng.integers(1, 16)), T, reqhgt=float(rng.choice([0.05, 1.0])),
+                           variety=True, start_doy=int(rng.integers(1, 300)), array_forcing=af,
+                           na_frac=float(rng.choice([0.0, 0.1])), seed=int(rng.integers(1, 1 << 30)))
+    for k in ("complete", "out"):
+        a.pop(k)
+    edges = 336 + np.concatenate([[0], np.cumsum(nq)])
+    q = [np.arange(edges[j], edges[j + 1]) for j in range(4)]
+    out = [int(b) for b in rng.random(19) < 0.5]
+    if not any(out):
+        out[0] = 1
+    air = bool(rng.random() < 0.5)
+    kw = dict(out=out, wetq=q[0], dryq=q[1], hotq=q[2], colq=q[3], air=air)
+    want = oracle.run_bioclim(**a, **kw, array_forcing=af)
+    if af:
+        a["lats"], a["lons"] = a.pop("lat"), a.pop("lon")
+        got = runbioclim2Cpp(**a, **kw)
+    else:
+        got = runbioclim1Cpp(**a, **kw)
+    assert list(got) == [f"bio{j + 1}" for j in range(19) if out[j]]
+    for k, w in want.items():
+        assert np.array_equal(np.isnan(got[k]), np.isnan(w)), k
+        np.testing.assert_allclose(got[k], w, rtol=1e-9, atol=1e-9, err_msg=k)
+
+
+@pytest.mark.parametrize("i", range(10))
+def test_random_nc_files_device_route_equals_host_route(i, tmp_path):
+    from microclimf_amd import ncsink
+    rng = np.random.default_rng(7700 + i)
+    rows, cols, days = int(rng.integers(1, 70)), int(rng.integers(1, 70)), int(rng.integers(1, 5))
+    reqhgt = float(rng.choice([0.05, 1.0, 0.0]))
+    allowed = ncsink.DEFAULT_VARS_ABOVE + ("soilm",) if reqhgt > 0 else ncsink.DEFAULT_VARS_SURFACE
+    names = tuple(v for v in allowed if rng.random() < 0.6) or ("Tz",)
+    a = synthetic.workload(rows, cols, days * 24, reqhgt=reqhgt, variety=True, start_doy=int(rng.integers(1, 350)),
+                           na_frac=float(rng.choice([0.0, 0.2])), seed=int(rng.integers(1, 1 << 30)))
+    east, north = ncsink.coords_from_extent(0.0, cols * 3.0, -50.0, -50.0 + rows * 3.0, 3.0)
+    hours = ncsink.hours_since_epoch(a["obstime"])
+    puts = bool(rng.random() < 0.3)
+    with Plan(**a, ring_days=days) as p:
+        p.run_days(0, days)
+        p.sync()
+        with ncsink.NcWriter(tmp_path / "d.nc", rows, cols, hours, east, north, reqhgt, names, "x", puts) as w:
+            cut = int(rng.integers(0, days * 24 + 1))
+            w.write_plan(p, 0, cut, cut, days * 24 - cut)
+            w.write_plan(p, 0, 0, 0, cut)
+        with ncsink.NcWriter(tmp_path / "h.nc", rows, cols, hours, east, north, reqhgt, names, "x", puts) as w:
+            w.write_host(0, {k: p.fetch(0, k, 0, days * 24) for k in names})
+    assert (tmp_path / "d.nc").read_bytes() == (tmp_path / "h.nc").read_bytes()
