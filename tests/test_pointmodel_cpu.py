@@ -92,3 +92,36 @@ def test_guards_against_the_reference_out_of_bounds_means():
         PM.BigLeafCpp(ob5, cl5, vegp, groundp, np.full(5 * n, 0.3), 50.0, -5.0, yearG=True)      # 5 days: 91-day mean
     r = PM.BigLeafCpp(obst, clim, vegp, groundp, np.full(n, 0.3), 50.0, -5.0, yearG=True)       # one day is fine
     assert np.isfinite(r["Tc"]).all()
+
+
+@pytest.mark.parametrize("i", range(12))
+def test_random_point_model_inputs_equal_oracle(oracle, i):
+    """random sites, canopies, soils and weather (1 - 6 days, and whole-year-like >= 90-day series with yearG)"""
+    rng = np.random.default_rng(8800 + i)
+    days = int(rng.choice([1, 2, 3, 6])) if i % 4 else 95
+    yearG = days >= 90 or days == 1
+    a = synthetic.workload(2, 2, days * 24, reqhgt=0.05, start_doy=int(rng.integers(1, 250)),
+                           lat=float(rng.choice([-40.0, 10.0, 50.0, 65.0])), lon=float(rng.choice([-5.0, 120.0])),
+                           cold=float(rng.choice([0.0, 10.0])), seed=int(rng.integers(1, 1 << 30)))
+    c = a["climdata"]
+    n = days * 24
+    clim = {"temp": c["temp"], "relhum": np.clip(100 * c["ea"] / c["es"], 5, 100), "pres": c["pres"], "swdown": c["swdown"],
+            "difrad": c["difrad"], "lwdown": c["lwdown"], "windspeed": np.maximum(c["windspeed"], 0.5),
+            "precip": np.where(rng.random(n) < 0.1, rng.uniform(0, 5, n), 0.0)}
+    hgt = float(rng.uniform(0.1, 1.8))
+    vegp = np.array([hgt, rng.uniform(0.2, 4), rng.uniform(0.5, 2), rng.uniform(0, 0.5), rng.uniform(0.3, 0.45),
+                     rng.uniform(0.1, 0.25), rng.uniform(0.01, 0.1), 0.97, rng.uniform(0.2, 0.4), 100.0])
+    groundp = np.array([rng.uniform(0.1, 0.2), rng.uniform(0, 20), rng.uniform(0, 360), 0.97, 1.53, 0.509, 0.06, 0.5422,
+                        5.2, -5.6, 0.42, 0.074])
+    soilm = rng.uniform(0.1, 0.4, n)
+    zref = float(hgt + rng.uniform(0.3, 2.0))
+    args = (a["obstime"], clim, vegp, groundp, soilm, a["lat"], a["lon"], 25.0, zref, int(rng.choice([20, 100])), 0.5, 0.5,
+            0.1, yearG)
+    want = RT.bigleaf(*args)
+    got = PM.BigLeafCpp(*args)
+    assert got["iters"] == want["iters"]
+    for k in ("Tc", "Tg", "H", "G", "psih", "psim", "phih", "OL", "uf", "RabsG", "albedo"):
+        np.testing.assert_allclose(got[k], want[k], rtol=1e-10, atol=1e-10, err_msg=k)
+    # height adjustment of the same weather
+    wh = PM.weatherhgtCpp(a["obstime"], clim, zref, zref, zref + 8.0, a["lat"], a["lon"])
+    assert np.isfinite(wh["temp"]).all() and (wh["windspeed"] >= clim["windspeed"] - 1e-12).all()

@@ -56,3 +56,31 @@ def test_random_snow_configuration(oracle, i):
     for k in mwant:
         assert_close(mgot[k], mwant[k], TOL, f"{i}:{reqhgt}:{k}")
         assert np.array_equal(mgot[k][~covered], micro[k][~covered]), k
+
+
+@pytest.mark.parametrize("i", range(10))
+def test_random_snow_driver_cases(oracle, i):
+    """`.snowmodel1`'s chunk loop on the device against its oracle for random rasters, resolutions and chunk lengths
+    (at most three chunks: over long series the reference's hand-over amplifies rounding residue)"""
+    from microclimf_amd.snow import applycpp3, snowmodel1_chunks
+    from oracle import snowdriver_oracle as SD
+    rng = np.random.default_rng(9900 + i)
+    rows, cols = int(rng.integers(12, 60)), int(rng.integers(12, 60))
+    chunk = int(rng.choice([24, 48, 120]))
+    T = chunk * int(rng.integers(1, 4)) + int(rng.choice([0, 0, 10]))
+    sw = synthetic.snow_workload(rows, cols, T, cold=float(rng.choice([2.0, 3.0, 6.0])), zref=3.5,
+                                 snowenv=str(rng.choice(ENVS[:5])), start_doy=int(rng.choice([5, 40, 340])),
+                                 seed=int(rng.integers(1, 1 << 30)))
+    _, _, dtm = synthetic.rasters(rows, cols)
+    dtm = np.where(np.isnan(sw["vegp"]["hgt"]), np.nan, dtm * float(rng.choice([0.5, 1.0, 3.0])))
+    args = (sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"], sw["other"], sw["snowenv"], dtm,
+            float(rng.choice([1.0, 2.0, 10.0])), float(rng.choice([0.02, 0.05])))
+    want = SD.snowmodel1_chunks(*args, chunk_steps=chunk)
+    got = snowmodel1_chunks(*args, chunk_steps=chunk)
+    for k in want:
+        assert_close(got[k], want[k], TOL, f"{i}:{k}")
+    # applycpp3 over the result, as .runmicrosnow uses it (R/internal.R:3592-3593)
+    for fun in ("max", "min", "mean", "sum"):
+        swe = np.nan_to_num(got["totalSWE"], nan=0.0)
+        ref = getattr(np, fun)(swe.reshape(-1, swe.shape[2]), axis=0)
+        np.testing.assert_allclose(applycpp3(np.asfortranarray(swe), fun), ref, rtol=1e-12, atol=1e-12)
