@@ -39,12 +39,14 @@ def run_to_nc(inputs: Mapping, fileout: str, dtm: Mapping, *, vars: Sequence[str
     from . import _abi
     a["out"] = [1 if n in names else 0 for n in _abi.OUT_NAMES]
     t_solve = t_write = 0.0
+    t_begin = time.perf_counter()
     with Plan(**a, ring_days=days_per_chunk, ring_slots=1, device=device, array_forcing=array_forcing) as plan:
         if twi_mean is not None:
             plan.set_twi_mean(twi_mean)
         rows, cols = plan.rows, plan.cols
         with ncsink.NcWriter(fileout, rows, cols, hours[:ndays * 24], east, north, reqhgt, names, dtm.get("crs", ""),
                              reference_puts_only) as nc:
+            t_setup = time.perf_counter() - t_begin
             for d0 in range(0, ndays, days_per_chunk):
                 nd = min(days_per_chunk, ndays - d0)
                 t0 = time.perf_counter()
@@ -56,6 +58,9 @@ def run_to_nc(inputs: Mapping, fileout: str, dtm: Mapping, *, vars: Sequence[str
                 nc.write_plan(plan, 0, 0, d0 * 24, nd * 24)
                 t_write += time.perf_counter() - t1
                 t_solve += t1 - t0
+            t_loop_end = time.perf_counter()
+        t_close_file = time.perf_counter() - t_loop_end
         valid = plan.valid_cells
     return {"rows": rows, "cols": cols, "steps": ndays * 24, "vars": names, "valid_cells": int(valid),
-            "solve_s": t_solve, "write_s": t_write, "values": rows * cols * ndays * 24 * len(names)}
+            "solve_s": t_solve, "write_s": t_write, "setup_s": t_setup, "close_file_s": t_close_file,
+            "total_s": time.perf_counter() - t_begin, "values": rows * cols * ndays * 24 * len(names)}
