@@ -51,3 +51,17 @@ def test_random_configuration(oracle, i):
     else:
         got = runmicro1Cpp(**a, **extra)
     compare(got, want)
+
+
+@pytest.mark.parametrize("af,reqhgt", [(False, 0.05), (True, 0.6), (False, -0.05)])
+def test_medium_raster_against_the_oracle(oracle, af, reqhgt):
+    """~900 workgroups: more than one XCD round and both hour rotations of the tile schedule (blockIdx >> 8), which the
+    small cases above never reach, compared value by value"""
+    a = synthetic.workload(160, 120, 72, reqhgt=reqhgt, variety=True, start_doy=200, array_forcing=af, na_frac=0.03)
+    want = oracle.run_grid(**a, array_forcing=af)
+    if af:
+        a["lats"], a["lons"] = a.pop("lat"), a.pop("lon")
+        got = runmicro2Cpp(**a)
+    else:
+        got = runmicro1Cpp(**a)
+    compare(got, want)
