@@ -84,3 +84,21 @@ def test_random_snow_driver_cases(oracle, i):
         swe = np.nan_to_num(got["totalSWE"], nan=0.0)
         ref = getattr(np, fun)(swe.reshape(-1, swe.shape[2]), axis=0)
         np.testing.assert_allclose(applycpp3(np.asfortranarray(swe), fun), ref, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("af", [False, True])
+def test_medium_snow_raster_against_the_oracle(oracle, af):
+    """tens of workgroups per kernel instead of the two or three of the small cases"""
+    sw = synthetic.snow_workload(150, 110, 96, cold=3.0, zref=3.5, array_forcing=af, na_frac=0.03)
+    want = oracle.run_snowmodel(**model_args(sw), array_forcing=af)
+    got = (gridmodelsnow2 if af else gridmodelsnow1)(sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"],
+                                                      sw["other"], sw["snowenv"])
+    for k in ("Tc", "Tg", "sdepc", "sdepg", "sden", "meltc", "meltg", "agec", "ageg"):
+        assert_close(got[k], want[k], TOL, k)
+    snowm, micro = synthetic.microsnow_inputs(sw, want)
+    for reqhgt in (0.05, 2.5):
+        args = (reqhgt, sw["obstime"], sw["climdata"], snowm, micro, sw["vegp"], sw["other"], 3.0, [1] * 10)
+        mwant = oracle.run_microsnow(*args, array_forcing=af)
+        mgot = (gridmicrosnow2 if af else gridmicrosnow1)(*args)
+        for k in mwant:
+            assert_close(mgot[k], mwant[k], TOL, f"{reqhgt}:{k}")
