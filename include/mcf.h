@@ -38,7 +38,8 @@
  * MCF_ERR_NO_DEVICE when no HIP device is usable.  Host-side by nature, as in the
  * reference, and therefore usable without a device: the one-point time-series model
  * (mcf_bigleaf, mcf_soilm, mcf_pointmprocess, mcf_weatherhgt) and the file side of
- * the writetonc sink (mcf_nc_create, mcf_nc_write_host, mcf_nc_close).
+ * the writetonc sink (mcf_nc_create, mcf_nc_write_host, mcf_nc_close), and the
+ * flow-accumulation sweep behind soilc$twi (mcf_flowacc, mcf_topidx).
  */
 #ifndef MCF_H
 #define MCF_H
@@ -491,6 +492,15 @@ int mcf_pointmprocess(int64_t n, const double *windspeed, const double *tc, cons
                       double *DDp, double *T0p, double *dtrp);
 int mcf_weatherhgt(int64_t n, const mcf_obstime *obstime, const mcf_point_weather *weather, double zin, double uzin,
                    double zout, double lat, double lon, double *temp, double *relhum, double *windspeed);
+
+/* ---- topographic wetness index (soilc$twi) ------------------------------------------------
+ * mcf_flowacc replaces _microclimf_flowaccCpp (src/microclimfCpp.cpp:5368-5408, with flowdirCpp :5326-5366),
+ * mcf_topidx the R function `.topidx` around it (R/internal.R:861-874).  Host code as in the reference: one
+ * elevation-ordered sweep over the whole raster, run once per raster (see mcf_hydro.cpp for the reference
+ * behaviours kept: self-pointing pits, the 9999.99 m ceiling, tie order, NA cells = -2147483648 in `fa`).
+ * `dtm`, `fa`, `twi`: [rows, cols] column-major; NaN = NA. */
+int mcf_flowacc(int64_t rows, int64_t cols, const double *dtm, double *fa);
+int mcf_topidx(int64_t rows, int64_t cols, const double *dtm, double xres, double yres, double *twi);
 
 /* Diagnostics: evaluate one of the solver's lean device elementary functions
  * elementwise on host arrays (kind 0 exp, 1 log, 2 x/y, 3 sqrt, 4 1/x, 5 satvap

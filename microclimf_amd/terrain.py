@@ -94,3 +94,23 @@ def precompute_terrain_tiled(block, res, zref, rank, world, row0, rows_total, *,
     ext, hn, hs = exchange_halo(np.asarray(block, dtype=np.float64), rank, world)
     return compute(ext, res, zref, agg=agg, halo_north=hn, halo_south=hs, row0=row0,
                    rows_total=rows_total, what=what, device=device)
+
+
+def flowaccCpp(dm) -> np.ndarray:
+    """Drop-in for flowaccCpp (src/microclimfCpp.cpp:5368-5408): flow accumulation of an elevation matrix (host)."""
+    lib = _abi.load()
+    z = np.asfortranarray(np.asarray(dm, dtype=np.float64))
+    fa = np.empty(z.shape, dtype=np.float64, order="F")
+    _abi.check(lib.mcf_flowacc(z.shape[0], z.shape[1], z.ctypes.data_as(_abi.c_double_p), fa.ctypes.data_as(_abi.c_double_p)))
+    return fa
+
+
+def topidx(dtm, res) -> np.ndarray:
+    """`.topidx(dtm)` (R/internal.R:861-874): the topographic wetness index the solver takes as soilc$twi (host)."""
+    lib = _abi.load()
+    z = np.asfortranarray(np.asarray(dtm, dtype=np.float64))
+    xres, yres = (res, res) if np.isscalar(res) else res
+    twi = np.empty(z.shape, dtype=np.float64, order="F")
+    _abi.check(lib.mcf_topidx(z.shape[0], z.shape[1], z.ctypes.data_as(_abi.c_double_p), float(xres), float(yres),
+                              twi.ctypes.data_as(_abi.c_double_p)))
+    return twi
