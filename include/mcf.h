@@ -492,6 +492,8 @@ int mcf_pointmprocess(int64_t n, const double *windspeed, const double *tc, cons
                       double *DDp, double *T0p, double *dtrp);
 int mcf_weatherhgt(int64_t n, const mcf_obstime *obstime, const mcf_point_weather *weather, double zin, double uzin,
                    double zout, double lat, double lon, double *temp, double *relhum, double *windspeed);
+/* manCpp (src/microclimfCpp.cpp:597-627): circular trailing mean, via daily means for windows beyond 48 steps. */
+int mcf_man(int64_t n, const double *x, int32_t window, double *out);
 
 /* ---- topographic wetness index (soilc$twi) ------------------------------------------------
  * mcf_flowacc replaces _microclimf_flowaccCpp (src/microclimfCpp.cpp:5368-5408, with flowdirCpp :5326-5366),

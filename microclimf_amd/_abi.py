@@ -160,7 +160,7 @@ EXPORTS = (
     "mcf_gridmicrosnow2", "mcf_snowmodel1", "mcf_applycpp3",
     "mcf_snowplan_create", "mcf_snowplan_destroy", "mcf_snowplan_chunks", "mcf_snowplan_surface",
     "mcf_snowplan_surface_partial", "mcf_snowplan_prepare_chunk", "mcf_snowplan_run_chunk",
-    "mcf_bigleaf", "mcf_soilm", "mcf_pointmprocess", "mcf_weatherhgt",
+    "mcf_bigleaf", "mcf_soilm", "mcf_pointmprocess", "mcf_weatherhgt", "mcf_man",
     "mcf_nc_create", "mcf_nc_write_host", "mcf_nc_write_plan", "mcf_nc_close",
     "mcf_flowacc", "mcf_topidx",
 )
@@ -251,6 +251,8 @@ def load() -> C.CDLL:
     lib.mcf_pointmprocess.argtypes = [C.c_int64] + [c_double_p] * 7 + [C.c_double] * 7 + [c_double_p] * 6
     lib.mcf_weatherhgt.restype = C.c_int
     lib.mcf_weatherhgt.argtypes = [C.c_int64, OT, PW] + [C.c_double] * 5 + [c_double_p] * 3
+    lib.mcf_man.restype = C.c_int
+    lib.mcf_man.argtypes = [C.c_int64, c_double_p, C.c_int32, c_double_p]
     lib.mcf_flowacc.restype = C.c_int
     lib.mcf_flowacc.argtypes = [C.c_int64, C.c_int64, c_double_p, c_double_p]
     lib.mcf_topidx.restype = C.c_int

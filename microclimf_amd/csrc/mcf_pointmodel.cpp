@@ -628,3 +628,29 @@ extern "C" int mcf_weatherhgt(int64_t n64, const mcf_obstime* t, const mcf_point
     }
     return MCF_OK;
 }
+
+// manCpp, cpp:597-627: circular trailing mean over `window` steps; windows beyond 48 h go through daily means
+// (window / 24 days) and a 24-h mean of the result.  Used by `.soilbelowT` (R/internal.R:169-185).
+extern "C" int mcf_man(int64_t n64, const double* x, int32_t window, double* out) {
+    if (n64 <= 0 || n64 > INT32_MAX || !x || !out || window < 1) return mcf::api_fail(MCF_ERR_ARG, "mcf_man: bad length, window or null argument");
+    const int m = (int)n64;
+    Vec xv(x, x + m), z((size_t)m);
+    if (window <= 48) {
+        moving_mean(xv, window, z);
+    } else {
+        const size_t nd = (size_t)m / 24;
+        if (nd == 0 || window / 24 < 1) return mcf::api_fail(MCF_ERR_ARG, "mcf_man: a window beyond 48 steps needs at least one whole day");
+        Vec d(nd), y(nd), zz((size_t)m, 0.0);
+        for (size_t i = 0; i < nd; ++i) {
+            double sum = 0.0;
+            for (int j = 0; j < 24; ++j) sum += xv[i * 24 + j];
+            d[i] = sum / 24.0;
+        }
+        moving_mean(d, window / 24, y);
+        for (size_t i = 0; i < nd; ++i)
+            for (int j = 0; j < 24; ++j) zz[i * 24 + j] = y[i];
+        moving_mean(zz, 24, z);
+    }
+    for (int i = 0; i < m; ++i) out[i] = z[(size_t)i];
+    return MCF_OK;
+}

@@ -1,0 +1,358 @@
+"""Host-side mirror of the reference's user-level calls for data.frame weather — `runpointmodel()`
+(R/Cppwrappers.R:59-139) and `runmicro()` → `.runmicronosnow` → `.runmodel1Cpp` / `.runmodel3Cpp`
+(R/Cppwrappers.R:376-397, R/internal.R:3290-3349, 1065-1169, 1345-1459) — for hosts without R.
+
+In an R session these R functions keep running unchanged above the C ABI.  Here every step they take
+between the user's rasters and the solver call is restated with numpy on top of libmcfhip's own producers:
+
+    step of the reference                          here
+    ---------------------------------------------  -----------------------------------------------------
+    soilmCpp, BigLeafCpp, pointmprocess, manCpp     libmcfhip, host C++ (pointmodel.py)
+    terra::terrain, .horizon, .windsheltera         mcf_precompute_terrain (device kernels, terrain.py)
+    .topidx / flowaccCpp                            mcf_topidx (host C++)
+    runmicro1Cpp / runmicro3Cpp                     mcf_runmicro1 / mcf_runmicro3 (the hot path)
+    .sortvegp, .soilinit, .foliageden, .satvap ...  numpy, below, citing the R lines they follow
+
+Rasters are numpy arrays `[rows, cols]` (or `[rows, cols, layers]`), row 0 = northern edge as in terra; what a
+SpatRaster carries besides values is passed as `dtm = {"z": array, "res": xres | (xres, yres), "lat": ., "long": .}`
+(the reference gets lat / long from the CRS through sf/PROJ, `.latlongfromraster`, R/internal.R:61-69).
+`checkinputs()` (R/dataprep.R) is not mirrored: inputs are taken as checked (`runchecks = FALSE`).
+"""
+from __future__ import annotations
+
+from typing import Mapping, Sequence
+
+import numpy as np
+
+from . import api, pointmodel, terrain
+from .soil_tables import SOILPARAMETERS, SOILPARAMSP
+from .synthetic import dewpoint_R as _dewpoint, satvap_R as _satvap   # .satvap / .dewpoint, R/internal.R:501-521
+
+WEATHER = ("temp", "relhum", "pres", "swdown", "difrad", "lwdown", "windspeed", "winddir", "precip")
+
+
+# ---- small R helpers --------------------------------------------------------------------------------------------
+def getmode(v):
+    """`.getmode` (R/internal.R:107-111): most frequent non-NA value, the first seen on ties."""
+    v = np.asarray(v, dtype=np.float64).ravel(order="F")
+    v = v[~np.isnan(v)]
+    if v.size == 0:
+        return np.nan
+    u, first, counts = np.unique(v, return_index=True, return_counts=True)
+    order = np.argsort(first)                      # unique() in R keeps first-appearance order
+    return float(u[order][np.argmax(counts[order])])
+
+
+def r_round(x):
+    """R's round(x, 0): half to even"""
+    return np.rint(x)
+
+
+def layer_index(nr: int, n: int):
+    """`s <- round(seq(0.50001, nr + 0.5, length.out = n), 0)` clipped to 1..nr (R/internal.R:188-191); 1-based"""
+    s = r_round(np.linspace(0.50001, nr + 0.5, n)) if n > 1 else r_round(np.array([0.50001]))
+    return np.clip(s, 1, nr).astype(int)
+
+
+def as3d(a):
+    a = np.asarray(a, dtype=np.float64)
+    return a[:, :, None] if a.ndim == 2 else a
+
+
+def intr(a, n: int, subs):
+    """`.intr` (R/internal.R:187-195): pick, for each of `n` time steps, the nearest of the raster's layers"""
+    a = as3d(a)
+    s = layer_index(a.shape[2], n)[np.asarray(subs) - 1]
+    return a[:, :, s - 1]
+
+
+def spline_fmm(y, n: int):
+    """`stats::spline(y, n = n)$y` for x = 1..length(y): the cubic spline of Forsythe, Malcolm & Moler (1977), whose
+    end conditions fit cubics through the first and the last four points, evaluated at `n` equally spaced abscissae
+    (R's default `method = "fmm"`, `xmin = min(x)`, `xmax = max(x)`)."""
+    y = np.asarray(y, dtype=np.float64)
+    m = len(y)
+    x = np.arange(1.0, m + 1.0)
+    xo = np.linspace(1.0, float(m), n)
+    if m < 2:
+        return np.full(n, y[0] if m else np.nan)
+    b, c, d = np.zeros(m), np.zeros(m), np.zeros(m)
+    if m < 3:
+        b[:] = (y[1] - y[0]) / (x[1] - x[0])
+    else:
+        d[0] = x[1] - x[0]
+        c[1] = (y[1] - y[0]) / d[0]
+        for i in range(1, m - 1):
+            d[i] = x[i + 1] - x[i]
+            b[i] = 2.0 * (d[i - 1] + d[i])
+            c[i + 1] = (y[i + 1] - y[i]) / d[i]
+            c[i] = c[i + 1] - c[i]
+        b[0], b[m - 1] = -d[0], -d[m - 2]
+        c[0] = c[m - 1] = 0.0
+        if m > 3:
+            c[0] = c[2] / (x[3] - x[1]) - c[1] / (x[2] - x[0])
+            c[m - 1] = c[m - 2] / (x[m - 1] - x[m - 3]) - c[m - 3] / (x[m - 2] - x[m - 4])
+            c[0] = c[0] * d[0] * d[0] / (x[3] - x[0])
+            c[m - 1] = -c[m - 1] * d[m - 2] * d[m - 2] / (x[m - 1] - x[m - 4])
+        for i in range(1, m):                       # Gaussian elimination
+            t = d[i - 1] / b[i - 1]
+            b[i] = b[i] - t * d[i - 1]
+            c[i] = c[i] - t * c[i - 1]
+        c[m - 1] = c[m - 1] / b[m - 1]              # back substitution
+        for i in range(m - 2, -1, -1):
+            c[i] = (c[i] - d[i] * c[i + 1]) / b[i]
+        b[m - 1] = (y[m - 1] - y[m - 2]) / d[m - 2] + d[m - 2] * (c[m - 2] + 2.0 * c[m - 1])
+        for i in range(m - 1):
+            b[i] = (y[i + 1] - y[i]) / d[i] - d[i] * (c[i + 1] + 2.0 * c[i])
+            d[i] = (c[i + 1] - c[i]) / d[i]
+            c[i] = 3.0 * c[i]
+        c[m - 1] = 3.0 * c[m - 1]
+        d[m - 1] = d[m - 2]
+    i = np.clip(np.searchsorted(x, xo, side="right") - 1, 0, m - 1)
+    dx = xo - x[i]
+    return y[i] + dx * (b[i] + dx * (c[i] + dx * d[i]))
+
+
+# ---- vegetation -------------------------------------------------------------------------------------------------
+VEG_KEYS = ("hgt", "pai", "x", "gsmax", "leafr", "clump", "leafd", "leaft")
+
+
+def vegpdmx(vegp) -> int:
+    """`.vegpdmx` (R/internal.R:197-208)"""
+    return max(as3d(vegp[k]).shape[2] for k in VEG_KEYS)
+
+
+def sortvegp_point(vegp) -> np.ndarray:
+    """`.sortvegp(vegp, method = "P")` (R/internal.R:229-239): the point model's vegetation vector"""
+    m = {k: float(np.nanmean(np.asarray(vegp[k], dtype=np.float64))) for k in VEG_KEYS}
+    return np.array([m["hgt"], m["pai"], m["x"], m["clump"], m["leafr"], m["leaft"], m["leafd"], 0.97, m["gsmax"], 100.0])
+
+
+def sortvegp_grid(vegp, n: int, subs):
+    """`.sortvegp(vegp, method = "C", n, subs)` (R/internal.R:249-273): every variable expanded to the layers of the
+    variable with most layers, and `lsubs`, the layer of each time step with whole days never split"""
+    subs = np.asarray(subs)
+    dmx = vegpdmx(vegp)
+    s = layer_index(dmx, n)
+    first = []
+    for v in s[subs - 1]:                              # unique(s[subs]) keeps first-appearance order
+        if v not in first:
+            first.append(int(v))
+    out = {k: intr(vegp[k], dmx, np.array(first)) for k in VEG_KEYS}
+    ss = s[subs - 1]
+    if len(ss) % 24:
+        raise ValueError("the grid model needs whole days (matrix(s, ncol = 24) in .sortvegp)")
+    sdd = np.array([getmode(row) for row in ss.reshape(-1, 24)]).astype(int)
+    out["lsubs"] = np.repeat(sdd, 24)
+    return out
+
+
+def foliageden(z, hgt, pai, paia=None, shape: float = 1.5, rate: float | None = None):
+    """`.foliageden` (R/internal.R:937-946): gamma-shaped foliage profile -> leaf density at z and plant area above z"""
+    from scipy.stats import gamma
+    rate = shape / 7 if rate is None else rate
+    g = gamma(a=shape, scale=1.0 / rate)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        x = ((hgt - z) / hgt) * 10
+        td = g.cdf(10)
+        rfd = g.pdf(x) / td
+        tdf = (pai / hgt) * rfd * 10
+        if paia is None:
+            paia = g.cdf(x) * (pai / td)
+    return tdf, paia
+
+
+def cleanvars(vegp, soilc, dtm_z):
+    """`.cleanvars` (R/internal.R:1020-1063): one NA mask for everything; zero pai where pai or hgt is zero or a
+    vegetation parameter is missing.  (`.cleanr(vegp$hgt, 0)` there sets cell 0 — nothing — so hgt keeps its values.)"""
+    veg = {k: as3d(vegp[k]).copy() for k in VEG_KEYS}
+    soil = {k: np.asarray(v, dtype=np.float64).copy() for k, v in soilc.items()}
+    z = np.asarray(dtm_z, dtype=np.float64).copy()
+    na = (np.isnan(veg["pai"][:, :, 0]) | np.isnan(veg["hgt"][:, :, 0]) | np.isnan(soil["soiltype"])
+          | np.isnan(soil["groundr"]) | np.isnan(z))
+    for k in VEG_KEYS:
+        veg[k][na] = np.nan
+    for k in ("soiltype", "groundr"):
+        soil[k][na] = np.nan
+    z[na] = np.nan
+    with np.errstate(invalid="ignore"):
+        zero = (veg["pai"][:, :, 0] == 0) | (veg["hgt"][:, :, 0] == 0)
+    for k in ("gsmax", "leafr", "clump", "leafd", "leaft"):
+        zero |= np.isnan(veg[k][:, :, 0])
+    veg["pai"][zero] = 0.0
+    veg["pai"][na] = np.nan                              # mask(vegp$pai, dtm)
+    veg["hgt"][na] = np.nan
+    return veg, soil, z
+
+
+# ---- soil -------------------------------------------------------------------------------------------------------
+def soilinit(soilc) -> dict:
+    """`.soilinit` (R/internal.R:304-336): per-cell soil constants from the soil type unless given explicitly"""
+    st = np.asarray(soilc["soiltype"], dtype=np.float64)
+    num = np.array(SOILPARAMETERS["Number"])
+    out = {}
+    for name, col in (("rho", "rho"), ("Vm", "Vm"), ("Vq", "Vq"), ("Mc", "Mc"), ("psi_e", "psi_e"), ("soilb", "b"),
+                      ("Smax", "Smax"), ("Smin", "Smin")):
+        if col in soilc:
+            out[name] = np.asarray(soilc[col], dtype=np.float64)
+            continue
+        a = np.full(st.shape, np.nan)
+        tab = np.array(SOILPARAMETERS[col])
+        for u in np.unique(st[~np.isnan(st)]):
+            a[st == u] = tab[num == u][0]
+        out[name] = a
+    return out
+
+
+def sortsoilc_point(soilc) -> np.ndarray:
+    """`.sortsoilc(soilc, "P")` (R/internal.R:338-357): the point model's ground vector (BigLeafCpp reads 12 entries)"""
+    sl = soilinit(soilc)
+    sn = int(getmode(soilc["soiltype"]))
+    return np.array([getmode(soilc["groundr"]), 0.0, 180.0, 0.97, getmode(sl["rho"]), getmode(sl["Vm"]), getmode(sl["Vq"]),
+                     getmode(sl["Mc"]), getmode(sl["soilb"]), getmode(sl["psi_e"]), getmode(sl["Smax"]), getmode(sl["Smin"]),
+                     SOILPARAMSP["alpha"][sn - 1], SOILPARAMSP["n"][sn - 1], SOILPARAMSP["Ksat"][sn - 1]])
+
+
+# ---- runpointmodel ----------------------------------------------------------------------------------------------
+def soilbelowT(dfo: Mapping, reqhgt: float) -> np.ndarray:
+    """`.soilbelowT` (R/internal.R:169-185)"""
+    n = -118.35 * reqhgt / dfo["DDp"]
+    nmn, nmx = int(np.floor(n.min())), int(np.ceil(n.max()))
+    Tnmn, Tnmx = pointmodel.manCpp(dfo["Tg"], nmn), pointmodel.manCpp(dfo["Tg"], nmx)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        wgt = (n - nmn) / (nmx - nmn)
+    Tb = wgt * Tnmx + (1 - wgt) * Tnmn
+    wgt2 = 0.041596 * (reqhgt / np.mean(dfo["DDp"])) + 0.87142
+    return wgt2 * Tb + (1 - wgt2) * np.mean(dfo["Tg"])
+
+
+def runpointmodel(weather: Mapping, reqhgt: float, dtm: Mapping, vegp: Mapping, soilc: Mapping, *, zref: float = 2.0,
+                  windhgt: float | None = None, soilm=None, matemp: float | None = None, dTmx: float = 25.0,
+                  maxiter: int = 20, yearG: bool = True, lat: float | None = None, long: float | None = None) -> dict:
+    """`runpointmodel(weather, reqhgt, dtm, vegp, soilc, ...)` (R/Cppwrappers.R:59-139).  `weather`: the columns of the
+    reference's `climdata` plus `obstime = {year, month, day, hour}` in place of the POSIX `obs_time`."""
+    w = {k: np.array(weather[k], dtype=np.float64, copy=True) for k in WEATHER if k in weather}
+    obstime = {k: np.asarray(weather["obstime"][k]) for k in ("year", "month", "day", "hour")}
+    n = len(w["temp"])
+    windhgt = zref if windhgt is None else windhgt
+    if matemp is None:
+        matemp = float(np.mean(w["temp"]))
+    if zref != windhgt:
+        w["windspeed"] = w["windspeed"] * np.log(67.8 * zref - 5.42) / np.log(67.8 * windhgt - 5.42)
+    if n < 8760:
+        yearG = False
+    vegp_p, groundp_p = sortvegp_point(vegp), sortsoilc_point(soilc)
+    mxhgt = float(np.nanmax(np.asarray(vegp["hgt"], dtype=np.float64)))
+    zout = mxhgt if mxhgt > 2 else 2.0
+    lat = dtm["lat"] if lat is None else lat
+    long = dtm["long"] if long is None else long
+    if zout > zref:
+        w2 = pointmodel.weatherhgtCpp(obstime, w, zref, zout, zout, lat, long)
+        if not np.isnan(np.mean(w2["temp"])):
+            w = w2
+        zref = zout
+    w["windspeed"] = np.maximum(w["windspeed"], 0.5)
+    if soilm is None:
+        ii = int(getmode(soilc["soiltype"])) - 1
+        p = SOILPARAMSP
+        sd = pointmodel.soilmCpp(w, p["rmu"][ii], p["mult"][ii], p["pwr"][ii], p["Smax"][ii], p["Smin"][ii], p["Ksat"][ii],
+                                 p["a"][ii])
+        soilm = spline_fmm(sd, n)
+    soilm = np.asarray(soilm, dtype=np.float64)
+    bl = pointmodel.BigLeafCpp(obstime, w, vegp_p, groundp_p, soilm, lat, long, dTmx, zref, maxiter, 0.5, 0.5, 0.1, yearG)
+    pp = pointmodel.pointmprocess({"windspeed": w["windspeed"], "tc": w["temp"], "rh": w["relhum"], "pk": w["pres"],
+                                   "uf": bl["uf"], "soilm": soilm, "RabsG": bl["RabsG"]},
+                                  zref, vegp_p[0], vegp_p[1], groundp_p[4], groundp_p[5], groundp_p[6], groundp_p[7])
+    dfo = dict(pp)
+    dfo.update(G=bl["G"], soilm=soilm, Tg=bl["Tg"], Tc=bl["Tc"])
+    Tbz = soilbelowT(dfo, reqhgt) if reqhgt < 0 else None
+    return {"weather": w, "obstime": obstime, "dfo": dfo, "Tbz": Tbz, "lat": lat, "long": long, "zref": zref,
+            "subs": np.arange(1, n + 1), "ntme": n, "matemp": matemp, "bigleaf_err": bl["err"]}
+
+
+# ---- runmicro ---------------------------------------------------------------------------------------------------
+def prepare_grid_inputs(micropoint: Mapping, reqhgt: float, vegp: Mapping, soilc: Mapping, dtm: Mapping, *, pai_a=None,
+                        out: Sequence = (1,) * 10, slr=None, apr=None, hor=None, twi=None, wsa=None, svf=None,
+                        device: int = 0) -> dict:
+    """Everything `.runmodel1Cpp` / `.runmodel3Cpp` do before calling the solver (R/internal.R:1067-1166 / 1347-1456):
+    returns the keyword arguments of runmicro1Cpp, plus `dfsel` when the vegetation varies in time."""
+    res = dtm["res"]
+    xres, yres = (res, res) if np.isscalar(res) else res
+    veg, soil, z = cleanvars(vegp, soilc, dtm["z"])
+    w = micropoint["weather"]
+    clim = {k: np.asarray(w[k], dtype=np.float64) for k in ("temp", "pres", "swdown", "difrad", "lwdown", "windspeed", "winddir")}
+    clim["es"] = _satvap(clim["temp"])
+    clim["ea"] = clim["es"] * np.asarray(w["relhum"], dtype=np.float64) / 100
+    clim["tdew"] = _dewpoint(clim["ea"], clim["temp"])
+    dfo = micropoint["dfo"]
+    nt = len(clim["temp"])
+    pointm = {k: np.asarray(dfo[k], dtype=np.float64) for k in ("soilm", "Tg", "T0p", "G", "DDp", "umu", "kp", "muGp", "dtrp")}
+    pointm["Tbp"] = np.asarray(micropoint["Tbz"], dtype=np.float64) if reqhgt < 0 else np.zeros(nt)
+    n, subs = micropoint["ntme"], micropoint["subs"]
+    sv = sortvegp_grid(veg, n, subs)
+    lsubs = sv.pop("lsubs")
+    with np.errstate(invalid="ignore"):
+        sv["hgt"][sv["pai"] == 0] = 0.0
+        sv["pai"][sv["hgt"] == 0] = 0.0
+    if pai_a is not None:
+        pai_a = intr(pai_a, n, subs)
+    sv["leafden"], sv["paia"] = foliageden(reqhgt, sv["hgt"], sv["pai"], pai_a)
+    layers = sv["pai"].shape[2]
+    dfsel = None
+    if layers > 1:                                                       # R/internal.R:1391-1399
+        lyr = []
+        for v in lsubs:
+            if v not in lyr:
+                lyr.append(int(v))
+        st, ed = [], []
+        for v in lyr:
+            s = np.nonzero(lsubs == v)[0] + 1                            # 1-based positions
+            st.append(int(np.floor(s[0] / 24) * 24))
+            ed.append(int(np.floor(s[-1] / 24) * 24 - 1))
+        dfsel = {"lyr": np.arange(1, len(lyr) + 1), "st": np.array(st), "ed": np.array(ed)}
+    else:
+        sv = {k: v[:, :, 0] for k, v in sv.items()}
+    sl = soilinit(soil)
+    sc = {"gref": soil["groundr"], "Smin": sl["Smin"], "Smax": sl["Smax"], "soilb": sl["soilb"], "Psie": sl["psi_e"],
+          "Vq": sl["Vq"], "Vm": sl["Vm"], "Mc": sl["Mc"], "rho": sl["rho"]}
+    na = np.isnan(z)
+    need = [k for k, v in (("slope", slr), ("aspect", apr), ("hor", hor), ("svfa", svf), ("wsa", wsa)) if v is None]
+    ter = terrain.precompute_terrain(z, xres, micropoint["zref"], what=tuple(need), device=device) if need else {}
+    for k, given in (("slope", slr), ("aspect", apr)):
+        a = np.array(ter[k] if given is None else given, dtype=np.float64, copy=True)
+        a[np.isnan(a)] = 0.0
+        a[na] = np.nan
+        sc[k] = a
+    t = np.array(terrain.topidx(z, (xres, yres)) if twi is None else twi, dtype=np.float64, copy=True)
+    t[np.isnan(t)] = 1.0
+    t[na] = np.nan
+    sc["twi"] = t
+    sc["hor"] = ter["hor"] if hor is None else np.asarray(hor, dtype=np.float64)
+    sc["svfa"] = ter["svfa"] if svf is None else np.asarray(svf, dtype=np.float64)
+    sc["wsa"] = ter["wsa"] if wsa is None else np.asarray(wsa, dtype=np.float64)
+    out = [int(bool(v)) for v in out]
+    if reqhgt == 0:
+        out = [a * b for a, b in zip((1, 0, 0, 1, 0, 1, 1, 1, 1, 1), out)]
+    if reqhgt < 0:
+        out = [a * b for a, b in zip((1, 0, 0, 1, 0, 0, 0, 0, 0, 0), out)]
+    args = dict(obstime=micropoint["obstime"], climdata=clim, pointm=pointm, vegp=sv, soilc=sc, reqhgt=float(reqhgt),
+                zref=float(micropoint["zref"]), lat=float(micropoint["lat"]), lon=float(micropoint["long"]),
+                Sminp=getmode(sc["Smin"]), Smaxp=getmode(sc["Smax"]), tfact=1.5, complete=len(subs) == n,
+                mat=float(micropoint["matemp"]), out=out)
+    if dfsel is not None:
+        args["dfsel"] = dfsel
+    return args
+
+
+def runmicro(micropoint: Mapping, reqhgt: float, vegp: Mapping, soilc: Mapping, dtm: Mapping, *, pai_a=None,
+             tfact: float = 1.5, out: Sequence = (1,) * 10, slr=None, apr=None, hor=None, twi=None, wsa=None, svf=None,
+             device: int = 0) -> dict:
+    """`runmicro(micropoint, reqhgt, vegp, soilc, dtm, ...)` for data.frame weather without snow: time-invariant
+    vegetation goes to runmicro1Cpp, layered vegetation to runmicro3Cpp (R/internal.R:3332-3346)."""
+    a = prepare_grid_inputs(micropoint, reqhgt, vegp, soilc, dtm, pai_a=pai_a, out=out, slr=slr, apr=apr, hor=hor, twi=twi,
+                            wsa=wsa, svf=svf, device=device)
+    a["tfact"] = float(tfact)
+    dfsel = a.pop("dfsel", None)
+    if dfsel is None:
+        return api.runmicro1Cpp(**a, device=device)
+    return api.runmicro3Cpp(dfsel, **a, device=device)

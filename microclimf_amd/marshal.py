@@ -64,9 +64,11 @@ def marshal(obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Mapping,
     else:                       # runmicro3Cpp/4Cpp: vegetation arrays are [rows, cols, layers]
         if hgt.ndim != 3:
             raise ValueError("vegp$hgt must be a rows x cols x layers array")
-        L = hgt.shape[2]
-        if len(np.asarray(dfsel["st"])) != L:
-            raise ValueError("dfsel must have one row per vegetation layer")
+        # the reference walks dfsel's rows and indexes layer `row` of the arrays (cpp:2632, 2771): arrays may be
+        # deeper than dfsel (`.runmodel3Cpp` renumbers the layers it uses, R/internal.R:1399) — the first L are read
+        L = len(np.asarray(dfsel["st"]))
+        if hgt.shape[2] < L:
+            raise ValueError("dfsel has more rows than the vegetation arrays have layers")
     R, Cc = hgt.shape[:2]
     T = len(np.asarray(obstime["year"]))
     m.rows, m.cols, m.tsteps = R, Cc, T
@@ -94,7 +96,13 @@ def marshal(obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Mapping,
             src = np.full(fshape, float(src))
         setattr(gi.pointm, f, m._f64(src, fshape, f"pointm${f}"))
     for f in _abi.VEGP_FIELDS:
-        setattr(gi.vegp, f, m._f64(vegp[f], (R, Cc) if dfsel is None else (R, Cc, L), f"vegp${f}"))
+        src = vegp[f]
+        if dfsel is not None:
+            src = np.asfortranarray(np.asarray(src, dtype=np.float64))
+            if src.ndim != 3 or src.shape[2] < L:
+                raise ValueError(f"vegp${f}: expected [rows, cols, >= {L} layers]")
+            src = src[:, :, :L]            # a contiguous prefix in column-major order: no copy
+        setattr(gi.vegp, f, m._f64(src, (R, Cc) if dfsel is None else (R, Cc, L), f"vegp${f}"))
     if dfsel is None:
         gi.veg_layers = 0
         gi.lyr_st = gi.lyr_ed = None

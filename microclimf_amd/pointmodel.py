@@ -114,6 +114,15 @@ def weatherhgtCpp(obstime, climdata, zin, uzin, zout, lat, lon) -> dict:
     return out
 
 
+def manCpp(x, n: int) -> np.ndarray:
+    """Drop-in for manCpp (src/microclimfCpp.cpp:597-627)."""
+    lib = _abi.load()
+    v = _vec(x)
+    out = np.zeros(len(v))
+    _abi.check(lib.mcf_man(len(v), v.ctypes.data_as(_abi.c_double_p), int(n), out.ctypes.data_as(_abi.c_double_p)))
+    return out
+
+
 def runpointmodel_chain(obstime, weather, vegp_p, groundp_p, lat, lon, zref=2.0, soilparams=None, soilm=None,
                         dTmx=25.0, maxiter=100, yearG=True) -> dict:
     """The chain of `runpointmodel` (R/Cppwrappers.R:117-138) from a weather table to the grid solver's `pointm`:

@@ -1,0 +1,98 @@
+"""The host-side front end (microclimf_amd/frontend.py: runpointmodel / the preparation of runmicro) on the reference's
+bundled example data and on constructed inputs.  No device: the terrain inputs come from the numpy terrain oracle and
+the solver is the oracle, which checks that what the front end hands over is a well-formed solver call."""
+import numpy as np
+import pytest
+
+from bundled import load
+from microclimf_amd import frontend as F
+from oracle import terrain_oracle as TO
+
+
+def test_r_helpers():
+    assert F.getmode([3, 1, 1, 3, 2]) == 3                     # ties: first seen
+    assert F.getmode([np.nan, 2, 2, 5]) == 2
+    assert list(F.layer_index(12, 8760)[[0, 729, 730, 8759]]) == [1, 1, 2, 12]      # 12 equal spans of 730 h, not months
+    assert list(F.layer_index(1, 10)) == [1] * 10
+    # the FMM spline reproduces cubics exactly and interpolates its knots
+    x = np.arange(1.0, 9.0)
+    y = 0.3 * x ** 3 - 2 * x ** 2 + x - 4
+    xo = np.linspace(1, 8, 50)
+    np.testing.assert_allclose(F.spline_fmm(y, 50), 0.3 * xo ** 3 - 2 * xo ** 2 + xo - 4, rtol=1e-12, atol=1e-12)
+    yy = np.array([0.3, 0.35, 0.31, 0.4, 0.38, 0.33, 0.36])
+    s = F.spline_fmm(yy, 7 * 24 - 23)                                   # knots fall on every 24th output
+    np.testing.assert_allclose(s[::24], yy, rtol=0, atol=1e-14)
+    np.testing.assert_allclose(F.spline_fmm([1.0, 3.0], 5), [1, 1.5, 2, 2.5, 3])
+    np.testing.assert_allclose(F.spline_fmm([1.0, 3.0, 2.0], 3), [1, 3, 2], atol=1e-14)
+
+
+def test_foliageden_matches_the_gamma_profile():
+    hgt, pai = np.array([[2.0, 0.5, 0.0]]), np.array([[3.0, 1.0, 0.0]])
+    with np.errstate(all="ignore"):
+        ld, pa = F.foliageden(0.25, hgt, pai)
+    # plant area above the ground is the whole pai; above the canopy top nothing
+    _, full = F.foliageden(0.0, hgt[:, :2], pai[:, :2])
+    np.testing.assert_allclose(full, pai[:, :2], rtol=1e-12)
+    _, none = F.foliageden(5.0, hgt[:, :2], pai[:, :2])
+    assert (none == 0).all()
+    assert 0 < pa[0, 0] < 3.0 and 0 < pa[0, 1] < 1.0 and pa[0, 2] == 0 and np.isnan(ld[0, 2])
+    # leaf density integrates to pai over the canopy height
+    z = np.linspace(0, 2.0, 20001)
+    dens = F.foliageden(z, np.full_like(z, 2.0), np.full_like(z, 3.0))[0]
+    assert abs(np.trapezoid(dens, z) - 3.0) < 1e-4
+
+
+def test_sortvegp_deals_whole_days_to_layers():
+    _, vegp, _, _ = load(24)
+    sv = F.sortvegp_grid({k: F.as3d(v) for k, v in vegp.items()}, 8760, np.arange(1, 8761))
+    assert sv["pai"].shape == (50, 50, 12) and sv["hgt"].shape == (50, 50, 12)      # hgt repeated over the layers
+    ls = sv["lsubs"]
+    assert ls.shape == (8760,) and (ls.reshape(-1, 24) == ls.reshape(-1, 24)[:, :1]).all()
+    assert list(np.unique(ls)) == list(range(1, 13)) and (np.diff(ls) >= 0).all()
+
+
+def test_runpointmodel_on_the_bundled_year_and_the_oracle_chain(oracle):
+    """the same chain through the oracle's C restatement (oracle/pointmodel.c) gives the same pointm"""
+    from oracle import replay_reference_tests as RT
+    weather, vegp, soilc, dtm = load()
+    mp = F.runpointmodel(weather, 0.05, dtm, vegp, soilc)
+    assert mp["zref"] == 2.0 and mp["bigleaf_err"] < 2.0 and len(mp["dfo"]["Tg"]) == 8760
+    assert 0.09 <= mp["dfo"]["soilm"].min() and mp["dfo"]["soilm"].max() <= 0.42
+    w = mp["weather"]
+    want = RT.bigleaf(mp["obstime"], w, F.sortvegp_point(vegp), F.sortsoilc_point(soilc), mp["dfo"]["soilm"], mp["lat"],
+                      mp["long"], 25.0, 2.0, 20, 0.5, 0.5, 0.1, True)
+    for k in ("Tg", "G", "Tc"):
+        np.testing.assert_allclose(mp["dfo"][k], want[k], rtol=1e-10, atol=1e-10, err_msg=k)
+    # below ground: Tbz is a damped, lagged copy of Tg
+    mpb = F.runpointmodel(weather, -0.1, dtm, vegp, soilc)
+    assert mpb["Tbz"].shape == (8760,) and np.ptp(mpb["Tbz"]) < np.ptp(mpb["dfo"]["Tg"])
+
+
+@pytest.mark.parametrize("reqhgt,layered", [(0.05, True), (1.0, False), (0.0, True), (-0.1, False)])
+def test_prepared_call_runs_through_the_oracle(oracle, reqhgt, layered):
+    weather, vegp, soilc, dtm = load(96)
+    if not layered:
+        vegp = {k: (v[:, :, 5] if v.ndim == 3 else v) for k, v in vegp.items()}
+    mp = F.runpointmodel(weather, reqhgt, dtm, vegp, soilc)
+    z = F.cleanvars(vegp, soilc, dtm["z"])[2]
+    ter = TO.terrain(z, dtm["res"], mp["zref"])
+    a = F.prepare_grid_inputs(mp, reqhgt, vegp, soilc, dtm, slr=ter["slope"], apr=ter["aspect"], hor=ter["hor"],
+                              svf=ter["svfa"], wsa=ter["wsa"])
+    assert ("dfsel" in a) == layered
+    na = np.isnan(z)
+    assert na.sum() >= 128 and np.array_equal(np.isnan(a["soilc"]["twi"]), na) and (a["soilc"]["twi"][~na] >= 1).all()
+    assert a["complete"] and a["Sminp"] == 0.091 and a["Smaxp"] == 0.419                 # clay loam is the modal soil
+    if layered:
+        # the 12 layers are spread over the series whatever its length (n = length(tmeorig), R/internal.R:1381-1383):
+        # 8 hours each here, one per day after the whole-day rule; dflyr$lyr is renumbered 1..4 (R/internal.R:1399), so
+        # the solver reads the FIRST four layers of the 12 kept — the reference's behaviour when layers are skipped
+        assert list(a["dfsel"]["st"]) == [0, 24, 48, 72] and list(a["dfsel"]["ed"]) == [23, 47, 71, 95]
+        assert list(a["dfsel"]["lyr"]) == [1, 2, 3, 4] and a["vegp"]["pai"].shape == (50, 50, 12)
+    got = oracle.run_grid(**a)
+    tz = got["Tz"]
+    assert np.array_equal(np.isnan(tz[:, :, 0]), na)
+    assert np.nanmin(tz) > -15 and np.nanmax(tz) < 45
+    if reqhgt > 0:
+        assert np.nanmax(got["relhum"]) <= 100 and np.nanmin(got["windspeed"]) >= 0
+    else:
+        assert "tleaf" not in got and "relhum" not in got                                  # out masks of R/internal.R:1159-1166
