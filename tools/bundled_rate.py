@@ -1,0 +1,31 @@
+"""End-to-end wall time of BASELINE.json configs[0] — runpointmodel() + runmicro() on the reference's bundled example data
+(50 x 50 cells, 12 pai layers, 8760 hourly steps) through the host front end: python tools/bundled_rate.py"""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+from bundled import load  # noqa: E402
+from microclimf_amd import frontend as F  # noqa: E402
+
+weather, vegp, soilc, dtm = load()
+w96 = load(96)
+mp = F.runpointmodel(w96[0], 0.05, dtm, vegp, soilc)
+F.runmicro(mp, 0.05, vegp, soilc, dtm)                       # warm-up: library load, first kernels
+for reqhgt in (0.05, 1.0, 0.0):
+    t0 = time.perf_counter()
+    mp = F.runpointmodel(weather, reqhgt, dtm, vegp, soilc)
+    t1 = time.perf_counter()
+    a = F.prepare_grid_inputs(mp, reqhgt, vegp, soilc, dtm)
+    t2 = time.perf_counter()
+    out = F.runmicro(mp, reqhgt, vegp, soilc, dtm)
+    t3 = time.perf_counter()
+    valid = int((~np.isnan(a["vegp"]["hgt"][:, :, 0])).sum())
+    print(f"reqhgt {reqhgt}: runpointmodel {t1 - t0:.3f} s, input preparation (terrain on the device, wetness index, vegetation "
+          f"layers) {t2 - t1:.3f} s, runmicro incl. the same preparation {t3 - t2:.3f} s; {valid} cells x 8760 h, "
+          f"{len(out)} outputs = {sum(v.nbytes for v in out.values()) / 1e9:.2f} GB; whole chain {t1 - t0 + t3 - t2:.2f} s = "
+          f"{valid * 8760 / (t1 - t0 + t3 - t2):.3e} cell-steps/s end to end")
