@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="'weak' (default): --rows rows PER GPU; 'strong': --rows is the whole raster, dealt to the ranks "
                          "in row blocks (e.g. --rows 8192 --cols 8192 --scaling strong --gpus 8 = BASELINE.json configs[3])")
+    ap.add_argument("--coarse", type=str, default="",
+                    help="secondary measurement: CRxCC, e.g. 8x8 — `.runmodel2Cpp` geometry with the coarse climate / point-model "
+                         "arrays interpolated inside the solver (mcf.h array_forcing == 2): the whole year is resident")
     ap.add_argument("--array-forcing", action="store_true",
                     help="secondary measurement: runmicro2Cpp geometry; ring_slots x ring_days days of forcing are "
                          "resident in HBM and solved repeatedly (a year of array forcing, 1.1 TB at 1024^2, "
@@ -112,6 +115,7 @@ def main():
         row0, rows = row_block(rank, world, rows_total)
     ndays = T // 24
     af = args.array_forcing
+    coarse = tuple(int(v) for v in args.coarse.split("x")) if args.coarse else None
     # the output ring (and, with array forcing, the forcing slabs) must fit the GPU: shrink the days per slot
     # until slots x days x 24 h x cells x 8 B x (10 outputs [+ 15 forcing arrays]) stays under 160 GB
     per_day = rows * cols * 24 * 8 * (10 + (15 if af else 0))
@@ -120,8 +124,14 @@ def main():
     if af:
         T = min(T, args.ring_days * args.ring_slots * 24)
         ndays = T // 24
-    a = synthetic.workload(rows, cols, T, reqhgt=args.reqhgt, row0=row0, rows_total=rows_total,
-                           array_forcing=af, start_doy=152 if af else 1)
+    cpos = None
+    if coarse:
+        a, rp, cp = synthetic.coarse_workload(rows, cols, T, coarse[0], coarse[1], reqhgt=args.reqhgt, row0=row0,
+                                              rows_total=rows_total)
+        cpos = {"rowpos": rp, "colpos": cp}
+    else:
+        a = synthetic.workload(rows, cols, T, reqhgt=args.reqhgt, row0=row0, rows_total=rows_total,
+                               array_forcing=af, start_doy=152 if af else 1)
     terrain_s = None
     if args.terrain == "device":
         from microclimf_amd.terrain import precompute_terrain_tiled
@@ -133,7 +143,7 @@ def main():
         a["soilc"].update(ter)
     n_out = 10
     plan = Plan(**a, ring_days=args.ring_days, ring_slots=args.ring_slots, device=local_rank,
-                cells_per_block=args.cells_per_block, array_forcing=af)
+                cells_per_block=args.cells_per_block, array_forcing=af, coarse=cpos)
     if af:
         for sl, d0 in enumerate(range(0, ndays, args.ring_days)):
             plan.upload_forcing_days(d0, min(args.ring_days, ndays - d0), sl)
@@ -180,7 +190,7 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         traffic = None
         tf = ROOT / "profiles" / "traffic.json"
-        if tf.exists():
+        if tf.exists() and not coarse and not af:
             try:
                 tj = json.loads(tf.read_text())
                 if tj.get("rows") == rows and tj.get("cols") == cols and tj.get("ring_days") == args.ring_days:
@@ -195,10 +205,12 @@ def main():
             "config": {
                 "workload": ((f"{rows}x{cols} synthetic DTM per GPU" if args.scaling == "weak" else
                               f"{rows_total}x{cols} synthetic DTM over {world} GPU(s)") + f", {T} hourly steps, "
-                             + ("array forcing (runmicro2Cpp geometry), forcing resident in HBM, "
+                             + (f"coarse array forcing ({coarse[0]}x{coarse[1]} climate grid interpolated in the solver, "
+                                "`.runmodel2Cpp` geometry), whole series resident, " if coarse else
+                                "array forcing (runmicro2Cpp geometry), forcing resident in HBM, "
                                 if af else "vector forcing (runmicro1Cpp geometry), ")
                              + f"reqhgt={args.reqhgt}, no snow"
-                             + ("" if af else (" [BASELINE.json configs[1]]" if (rows, cols) == (1024, 1024) else
+                             + ("" if (af or coarse) else (" [BASELINE.json configs[1]]" if (rows, cols) == (1024, 1024) else
                                                " [BASELINE.json configs[2]]" if (rows, cols) == (4096, 4096)
                                                else ""))),
                 "rows_per_gpu": rows, "cols": cols, "tsteps": T, "outputs": n_out,

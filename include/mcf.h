@@ -120,7 +120,7 @@ typedef struct mcf_soilc {
 
 typedef struct mcf_grid_inputs {
     int64_t rows, cols, tsteps;
-    int32_t array_forcing; /* 0: runmicro1Cpp/3Cpp geometry, 1: runmicro2Cpp/4Cpp geometry */
+    int32_t array_forcing; /* 0: runmicro1Cpp/3Cpp geometry, 1: runmicro2Cpp/4Cpp geometry, 2: coarse arrays (below) */
     int32_t veg_layers;    /* 0 or 1: static vegetation; >1: runmicro3Cpp/4Cpp `dfsel` layers    */
     mcf_obstime obstime;
     mcf_climate clim;
@@ -132,6 +132,21 @@ typedef struct mcf_grid_inputs {
     /* dfsel of runmicro3Cpp/4Cpp (src/microclimfCpp.cpp:2629-2640): layer l drives the steps
      * lyr_st[l] .. lyr_ed[l] (0-based, whole days); NULL when veg_layers <= 1 */
     const int32_t *lyr_st, *lyr_ed;
+    /* array_forcing == 2 — COARSE array forcing, the MI355X-native form of `.runmodel2Cpp` (R/internal.R:1175-1343):
+     * the reference resamples every coarse climate / point-model variable to the fine raster (`.cca` ->
+     * terra::resample, bilinear; R/internal.R:523-542, 1224-1277) and hands runmicro2Cpp full [rows,cols,T] arrays —
+     * 120 B per cell-step to upload, hold and read back, the reason a tile is capped at 2e7 cell-steps
+     * (R/Cppwrappers.R:469).  Here the coarse arrays stay coarse: clim.{tc,pk,swdown,difrad,lwdown,windspeed},
+     * coarse_relhum, coarse_winddir and pointm.{soilm,G,umu,kp,muGp,dtrp} are [coarse_rows, coarse_cols, tsteps]; the
+     * solver interpolates them bilinearly per cell-step and derives es, ea, tdew (.satvap, .dewpoint after
+     * interpolating temp and relhum), wind speed (from interpolated u, v components) and the raster-mean wind
+     * direction exactly where `.runmodel2Cpp` does (altcorrect = 0).  clim.es, ea, tdew, winddir are ignored.
+     * coarse_rowpos[i] / coarse_colpos[j]: position of raster row i / column j in units of coarse rows / columns,
+     * 0 = centre of the first coarse row / column, clamped by the caller to [0, coarse_rows-1] / [0, coarse_cols-1]
+     * (edge replication).  reqhgt < 0 needs complete = 1 in this mode. */
+    int32_t coarse_rows, coarse_cols;
+    const double *coarse_rowpos, *coarse_colpos;
+    const double *coarse_relhum, *coarse_winddir;
 } mcf_grid_inputs;
 
 typedef struct mcf_options {

@@ -50,7 +50,10 @@ class GridInputs(C.Structure):
                 ("vegp", Vegp), ("soilc", Soilc),
                 ("lat", C.c_double), ("lon", C.c_double),
                 ("lats", c_double_p), ("lons", c_double_p),
-                ("lyr_st", c_int32_p), ("lyr_ed", c_int32_p)]
+                ("lyr_st", c_int32_p), ("lyr_ed", c_int32_p),
+                ("coarse_rows", C.c_int32), ("coarse_cols", C.c_int32),
+                ("coarse_rowpos", c_double_p), ("coarse_colpos", c_double_p),
+                ("coarse_relhum", c_double_p), ("coarse_winddir", c_double_p)]
 
 
 class Options(C.Structure):

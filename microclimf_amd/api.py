@@ -24,10 +24,10 @@ from .marshal import Marshalled, alloc_outputs, marshal
 
 
 def _run(fn_name, array_forcing, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon,
-         Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block, dfsel=None):
+         Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block, dfsel=None, coarse=None):
     lib = _abi.load()
     m = marshal(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp,
-                tfact, complete, mat, out, array_forcing, device, days_per_chunk, cells_per_block, dfsel)
+                tfact, complete, mat, out, array_forcing, device, days_per_chunk, cells_per_block, dfsel, coarse)
     outs, arrays = alloc_outputs(m)
     _abi.check(getattr(lib, fn_name)(C.byref(m.inputs), C.byref(m.options), C.byref(outs)))
     return arrays
@@ -53,6 +53,30 @@ def runmicro2Cpp(obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Map
     Drop-in for the reference's runmicro2Cpp (src/microclimfCpp.cpp:2340-2621)."""
     return _run("mcf_runmicro2", True, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons,
                 Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block)
+
+
+def coarse_positions(n_fine: int, n_coarse: int):
+    """Position of each of `n_fine` equally spaced fine cells in units of `n_coarse` coarse cells covering the same
+    extent (0 = centre of the first coarse cell), clamped to the coarse centres (edge replication)."""
+    pos = (np.arange(n_fine) + 0.5) * (n_coarse / n_fine) - 0.5
+    return np.clip(pos, 0.0, n_coarse - 1.0)
+
+
+def runmicro2Cpp_coarse(obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Mapping, soilc: Mapping,
+                        reqhgt: float, zref: float, lats, lons, Sminp: float, Smaxp: float, tfact: float,
+                        complete: bool, mat: float, out: Sequence, *, rowpos=None, colpos=None, device: int = 0,
+                        days_per_chunk: int = 0) -> dict:
+    """`.runmodel2Cpp` with the resampling fused into the solver (include/mcf.h, array_forcing == 2): `climdata` =
+    {temp, relhum, pres, swdown, difrad, lwdown, windspeed, winddir} and `pointm` = {soilm, Gp, umu, kp, muGp, dtrp} as
+    COARSE arrays [coarse_rows, coarse_cols, tsteps] — what `.cca(..., dtmc, dtmc)` gives before `resample` — instead of
+    the full-resolution arrays runmicro2Cpp takes.  `rowpos` / `colpos`: see `coarse_positions` (default: the coarse
+    grid covers the raster's extent)."""
+    R, Cc = np.shape(vegp["hgt"])[:2]
+    cr, cc = np.shape(climdata["temp"])[:2]
+    coarse = {"rowpos": coarse_positions(R, cr) if rowpos is None else rowpos,
+              "colpos": coarse_positions(Cc, cc) if colpos is None else colpos}
+    return _run("mcf_runmicro2", True, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons,
+                Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, 0, None, coarse)
 
 
 def runmicro3Cpp(dfsel: Mapping, obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Mapping,
@@ -128,17 +152,17 @@ class Plan:
 
     def __init__(self, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp,
                  tfact, complete, mat, out, *, array_forcing=False, ring_days=1, ring_slots=1,
-                 device=0, cells_per_block=0, dfsel=None):
+                 device=0, cells_per_block=0, dfsel=None, coarse=None):
         self._lib = _abi.load()
         self._m: Marshalled = marshal(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon,
-                                      Sminp, Smaxp, tfact, complete, mat, out, array_forcing, device,
-                                      0, cells_per_block, dfsel)
+                                      Sminp, Smaxp, tfact, complete, mat, out, array_forcing or coarse is not None, device,
+                                      0, cells_per_block, dfsel, coarse)
         self._p = C.c_void_p()
         _abi.check(self._lib.mcf_plan_create(C.byref(self._m.inputs), C.byref(self._m.options),
                                              int(ring_days), int(ring_slots), C.byref(self._p)))
         self.rows, self.cols, self.tsteps = self._m.rows, self._m.cols, self._m.tsteps
         self.ndays = self.tsteps // 24
-        self.array_forcing = bool(array_forcing)
+        self.array_forcing = bool(array_forcing) or coarse is not None
 
     def close(self):
         if getattr(self, "_p", None) is not None and self._p.value:

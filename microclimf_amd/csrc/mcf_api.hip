@@ -62,6 +62,9 @@ struct mcf_plan {
     int64_t rows = 0, cols = 0, N = 0, tsteps = 0;
     int ndays = 0;
     bool af = false, bg = false;
+    bool coarse = false;                 // array_forcing == 2: coarse arrays interpolated in the solver
+    int crows = 0, ccols = 0;
+    const double *d_crowpos = nullptr, *d_ccolpos = nullptr;
     int cpb = 16;
     int layers = 1;
     int32_t* d_daylayer = nullptr;
@@ -210,6 +213,7 @@ int ensure_cells(mcf_plan* p) {
     a.rho = p->d_soil[8]; a.slope = p->d_soil[9]; a.aspect = p->d_soil[10]; a.twi = p->d_soil[11];
     a.svfa = p->d_soil[12];
     a.lats = p->d_lats; a.lons = p->d_lons; a.lat = p->lat; a.lon = p->lon;
+    a.crowpos = p->d_crowpos; a.ccolpos = p->d_ccolpos; a.rows = p->rows;
     a.tfact = p->opt.tfact;
     a.twi_mean = p->twi_mean;
     a.g = p->g;
@@ -333,7 +337,22 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
     p->rows = in->rows; p->cols = in->cols; p->N = in->rows * in->cols; p->tsteps = in->tsteps;
     p->ndays = (int)(in->tsteps / 24);                       // cpp:2116 truncation
     p->af = in->array_forcing != 0;
+    p->coarse = in->array_forcing == 2;
     p->bg = opt->reqhgt < 0.0;
+    if (p->coarse) {
+        if (in->coarse_rows < 1 || in->coarse_cols < 1 || !in->coarse_rowpos || !in->coarse_colpos || !in->coarse_relhum ||
+            !in->coarse_winddir)
+            return fail(MCF_ERR_ARG, "coarse array forcing needs coarse_rows/cols, coarse_rowpos/colpos, coarse_relhum and coarse_winddir");
+        if ((int64_t)in->coarse_rows * in->coarse_cols > INT32_MAX / 2) return fail(MCF_ERR_ARG, "coarse grid too large");
+        if (p->bg && !opt->complete) return fail(MCF_ERR_ARG, "coarse array forcing: reqhgt < 0 needs complete = 1");
+        for (int64_t i = 0; i < in->rows; ++i)
+            if (!(in->coarse_rowpos[i] >= 0.0 && in->coarse_rowpos[i] <= in->coarse_rows - 1))
+                return fail(MCF_ERR_ARG, "coarse_rowpos must lie in [0, coarse_rows - 1]");
+        for (int64_t j = 0; j < in->cols; ++j)
+            if (!(in->coarse_colpos[j] >= 0.0 && in->coarse_colpos[j] <= in->coarse_cols - 1))
+                return fail(MCF_ERR_ARG, "coarse_colpos must lie in [0, coarse_cols - 1]");
+        p->crows = in->coarse_rows; p->ccols = in->coarse_cols;
+    }
     // vector forcing: two 8-wave workgroups per CU (21 cells); array forcing: one 12-wave workgroup
     p->cpb = opt->cells_per_block ? opt->cells_per_block : (in->array_forcing ? 32 : 21);
     p->layers = in->veg_layers > 1 ? in->veg_layers : 1;
@@ -365,6 +384,10 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
     if (p->af) {
         if ((rc = upload(p, in->lats, N, &p->d_lats, "lats"))) return rc;
         if ((rc = upload(p, in->lons, N, &p->d_lons, "lons"))) return rc;
+    }
+    if (p->coarse) {
+        if ((rc = upload(p, in->coarse_rowpos, in->rows, &p->d_crowpos, "coarse_rowpos"))) return rc;
+        if ((rc = upload(p, in->coarse_colpos, in->cols, &p->d_ccolpos, "coarse_colpos"))) return rc;
     }
     int64_t nvalid = 0;
     for (int64_t c = 0; c < N; ++c) nvalid += !std::isnan(in->vegp.hgt[c]);
@@ -412,8 +435,29 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
     const double* raw[15];
     clim_ptrs(in, raw);
     for (int f = 0; f < 15; ++f)
-        if (T > 0 && !raw[f]) return fail(MCF_ERR_ARG, std::string("missing forcing array: ") + kRawNames[f]);
-    if (T > 0 && !in->clim.winddir) return fail(MCF_ERR_ARG, "missing forcing array: winddir");
+        if (T > 0 && !raw[f] && !(p->coarse && f >= 1 && f <= 3))     // es, ea, tdew are derived in coarse mode
+            return fail(MCF_ERR_ARG, std::string("missing forcing array: ") + kRawNames[f]);
+    if (T > 0 && !p->coarse && !in->clim.winddir) return fail(MCF_ERR_ARG, "missing forcing array: winddir");
+    // coarse mode: wind components per coarse cell and the raster-mean direction per step (R/internal.R:1255-1264)
+    std::vector<double> cwu, cwv, cwd;
+    if (p->coarse && T > 0) {
+        const int64_t cN = (int64_t)p->crows * p->ccols;
+        cwu.resize((size_t)(cN * T)); cwv.resize((size_t)(cN * T)); cwd.resize((size_t)T);
+        for (int64_t k = 0; k < T; ++k) {
+            double su = 0, sv = 0;
+            int64_t nu = 0, nv = 0;
+            for (int64_t q = 0; q < cN; ++q) {
+                const double u2 = in->clim.windspeed[q + cN * k], wd = in->coarse_winddir[q + cN * k] * M_PI / 180.0;
+                const double u = u2 * cos(wd), v = u2 * sin(wd);
+                cwu[(size_t)(q + cN * k)] = u; cwv[(size_t)(q + cN * k)] = v;
+                if (!std::isnan(u)) { su += u; ++nu; }               // apply(wu, 3, mean, na.rm = TRUE)
+                if (!std::isnan(v)) { sv += v; ++nv; }
+            }
+            double d = fmod(atan2(sv / (double)nv, su / (double)nu) * 180.0 / M_PI, 360.0);
+            if (d < 0) d += 360.0;                                    // R's %% takes the sign of the divisor
+            cwd[(size_t)k] = d;
+        }
+    }
     std::vector<void*> temps;   // freed after setup
     auto up_tmp = [&](const void* host, int64_t nbytes, void** dev) -> int {
         if (nbytes <= 0) nbytes = 8;
@@ -429,7 +473,7 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
         if ((rc = up_tmp(in->obstime.month, T * 4, &dm))) return rc;
         if ((rc = up_tmp(in->obstime.day, T * 4, &dd))) return rc;
         if ((rc = up_tmp(in->obstime.hour, T * 8, &dh))) return rc;
-        if ((rc = up_tmp(in->clim.winddir, T * 8, &dw))) return rc;
+        if ((rc = up_tmp(p->coarse ? cwd.data() : in->clim.winddir, T * 8, &dw))) return rc;
     }
     if (!p->af) {
         double mxtc = -273.15;                                           // cpp:2159-2168
@@ -469,6 +513,30 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
             mcf::launch_date_setup(da, p->stream);
             HIP_TRY(hipGetLastError());
         }
+        if (p->coarse) {
+            // the whole series of the 15 coarse slabs stays resident: [15][crows*ccols][T]
+            const int64_t cN = (int64_t)p->crows * p->ccols, slab = cN * std::max<int64_t>(T, 1);
+            if ((rc = dalloc(p, &tmp, 15 * slab * 8))) return rc;
+            p->d_force = (double*)tmp;
+            const double* src[15];
+            for (int f = 0; f < 15; ++f) src[f] = raw[f];
+            src[1] = in->coarse_relhum;                  // slot TF_ES
+            src[2] = cwv.data();                         // slot TF_EA: v component
+            src[3] = nullptr;                            // slot TF_TDEW unused
+            src[8] = cwu.data();                         // slot TF_U2: u component
+            for (int f = 0; f < 15 && T > 0; ++f)
+                if (src[f]) HIP_TRY(hipMemcpyAsync(p->d_force + f * slab, src[f], (size_t)(cN * T * 8), hipMemcpyHostToDevice, p->stream));
+            if (T > 0) {
+                mcf::launch_mxtc_coarse(p->d_force, p->crows, p->ccols, (int)T, p->d_crowpos, p->d_ccolpos, p->rows, N,
+                                        p->d_mxtc, p->stream);
+                HIP_TRY(hipGetLastError());
+            } else {
+                mcf::launch_fill(p->d_mxtc, N, -273.15, p->stream);
+            }
+            HIP_TRY(hipStreamSynchronize(p->stream));    // cwu / cwv are about to go out of scope
+            p->force_day0.assign(ring_slots, 0);
+            p->force_ndays.assign(ring_slots, p->ndays);
+        } else {
         // per-cell max air temperature over the WHOLE series (cpp:2467-2471), streamed in slabs
         mcf::launch_fill(p->d_mxtc, N, -273.15, p->stream);
         int64_t slab_steps = std::max<int64_t>(1, std::min<int64_t>(T, (int64_t)(256LL << 20) / (N * 8)));
@@ -489,6 +557,7 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
         p->d_force = (double*)tmp;
         p->force_day0.assign(ring_slots, -1);
         p->force_ndays.assign(ring_slots, 0);
+        }
     }
 
     // ---- output ring
@@ -538,6 +607,7 @@ int mcf_plan_set_twi_mean(mcf_plan* p, double mean) {
 int mcf_plan_upload_forcing_days(mcf_plan* p, const mcf_grid_inputs* in, int32_t day0, int32_t ndays, int32_t slot) {
     if (!p || !in) return fail(MCF_ERR_ARG, "null argument");
     if (!p->af) return fail(MCF_ERR_STATE, "plan uses vector forcing");
+    if (p->coarse) return MCF_OK;            // the coarse series is resident since mcf_plan_create
     if (slot < 0 || slot >= p->ring_slots) return fail(MCF_ERR_ARG, "slot out of range");
     if (day0 < 0 || ndays < 1 || ndays > p->ring_days || day0 + ndays > p->ndays)
         return fail(MCF_ERR_ARG, "day range out of bounds");
@@ -569,7 +639,13 @@ int mcf_plan_run_days(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot) {
     a.cellc = p->d_cellc; a.hor = p->d_hor; a.wsa = p->d_wsa; a.tt = p->d_tt;
     a.daylayer = p->d_daylayer;
     const int64_t cap = p->N * (int64_t)p->ring_days * 24;
-    if (p->af) {
+    if (p->af && p->coarse) {
+        a.af_base = p->d_force;
+        a.af_stride = (int64_t)p->crows * p->ccols * std::max<int64_t>(p->tsteps, 1);
+        a.crows = p->crows; a.ccols = p->ccols;
+        a.dt = p->d_dt; a.windex = p->d_windex; a.mxtc = p->d_mxtc;
+        a.force_step0 = 0;
+    } else if (p->af) {
         if (p->force_day0[slot] != day0 || p->force_ndays[slot] < ndays)
             return fail(MCF_ERR_STATE, "forcing for these days has not been uploaded to this slot");
         a.af_base = p->d_force + (int64_t)slot * 15 * cap;

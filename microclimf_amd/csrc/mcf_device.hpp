@@ -92,6 +92,8 @@ enum CellField : int {
     // array forcing: per-cell solar geometry (cpp:2497): latitude and the longitude part B of the
     // hour angle tt = A(time) + B(cell), B = 0.261799*4*lon/60 (cpp:44, 54)
     CF_SINLAT, CF_COSLAT, CF_COSB, CF_SINB,
+    // coarse array forcing: the cell's position in the coarse grid (rows, columns)
+    CF_CROWPOS, CF_CCOLPOS,
     CF_COUNT
 };
 constexpr int kCellDirs = 32;  // 24 horizon + 8 wind-shelter values follow the CF_ rows
@@ -468,6 +470,42 @@ __device__ __forceinline__ void derive_time_af(TimeVals& t, const DateRow& dr, d
     t.v[TF_RBEAM] = rbeam;
     t.v[TF_RB] = rbeam * coh;
 }
+// ---- coarse array forcing (mcf_grid_inputs.array_forcing == 2) ------------------------------------------------
+// Bilinear tap into a coarse [crows, ccols] field: the four neighbours and weights of one raster cell, from its
+// position in coarse-grid units (clamped by the host, so that r1 / c1 fall back onto r0 / c0 at the far edges).
+struct CoarseTap {
+    int i00, i01, i10, i11;
+    double wx, wy;
+    __device__ __forceinline__ CoarseTap(double rowpos, double colpos, int crows, int ccols) {
+        const double fr = floor(rowpos), fc = floor(colpos);
+        const int r0 = (int)fr, c0 = (int)fc;
+        const int r1 = r0 + 1 < crows ? r0 + 1 : r0, c1 = c0 + 1 < ccols ? c0 + 1 : c0;
+        wy = rowpos - fr;
+        wx = colpos - fc;
+        i00 = r0 + crows * c0; i01 = r0 + crows * c1; i10 = r1 + crows * c0; i11 = r1 + crows * c1;
+    }
+    // p: the field at one time step
+    __device__ __forceinline__ double operator()(const double* __restrict__ p) const {
+        const double top = (1.0 - wx) * p[i00] + wx * p[i01];
+        const double bot = (1.0 - wx) * p[i10] + wx * p[i11];
+        return (1.0 - wy) * top + wy * bot;
+    }
+};
+// `.satvap` and `.dewpoint` of the R side (R/internal.R:501-521), which `.runmodel2Cpp` applies to the resampled
+// temperature and humidity (R/internal.R:1230-1232); NOT satvapCpp / dewpointCpp (other ice threshold, other constants).
+__device__ __forceinline__ double satvap_r(double tc, const MathK& K) {
+    const double a = tc < 0.0 ? 21.875 : 17.27, b = tc < 0.0 ? 265.5 : 237.3;
+    return 0.61078 * fexp(fdiv(a * tc, tc + b), K);
+}
+__device__ __forceinline__ double dewpoint_r(double ea, double tc, const MathK& K) {
+    if (!(ea > 0.0)) return -273.15;                       // log(0) = -Inf in R: 1/Inf - 273.15
+    const double lw = flog(ea * (1.0 / 0.6112), K), li = flog(ea * (1.0 / 0.61078), K);
+    const double L = 2.501e6 - 2340.0 * tc;
+    const double tdew = frcp(1.0 / 273.15 - fdiv(461.5, L) * lw) - 273.15;
+    const double tfrost = frcp(1.0 / 273.15 - (461.5 / 2.834e6) * li) - 273.15;
+    return tdew < 0.0 ? tfrost : tdew;
+}
+
 // second half, evaluated in front of pass 2 (keeps these out of the registers during pass 1)
 __device__ __forceinline__ void derive_time_af_pass2(TimeVals& t, double gp, double mugp, double dtrp, double kp) {
     const double mu = latent(t.v[TF_TC]) * (43.0 * frcp(t.v[TF_PK]));          // cpp:1245

@@ -23,6 +23,8 @@ struct CellSetupArgs {
     // soilc
     const double *Smin, *Smax, *gref, *soilb, *Psie, *Vq, *Vm, *Mc, *rho, *slope, *aspect, *twi, *svfa;
     const double *lats, *lons;  // array forcing, else null
+    const double *crowpos, *ccolpos;  // coarse array forcing: [rows], [cols]; else null
+    int64_t rows;
     double lat, lon;
     double tfact, twi_mean;
     Globals g;
@@ -62,6 +64,8 @@ struct SolveArgs {
     const int32_t* windex;  // [tsteps]
     const double* mxtc;     // [N]
     int64_t force_step0;    // first step of this launch inside the forcing slabs
+    // coarse array forcing (af_base = [15][crows*ccols][tsteps], whole series resident): crows > 0
+    int32_t crows, ccols;
     // outputs: enabled variables are consecutive slabs [N][slot steps] from out_base;
     // out_sel packs, 4 bits per variable, the slab index of variable v (15 = not requested)
     double* out_base;
@@ -100,6 +104,9 @@ struct BioclimArgs {
 };
 void launch_bioclim(const BioclimArgs& a, hipStream_t s);
 void launch_fill(double* p, int64_t n, double v, hipStream_t s);
+// per-cell maximum over time of the bilinearly interpolated coarse temperature [crows*ccols][tsteps]
+void launch_mxtc_coarse(const double* tc, int crows, int ccols, int tsteps, const double* rowpos, const double* colpos,
+                        int64_t rows, int64_t N, double* mx, hipStream_t s);
 struct PackNcArgs {
     const double* src[10];   // first step of each variable, [rows, cols, steps] column-major
     double scale[10];

@@ -285,6 +285,8 @@ __global__ __launch_bounds__(256) void k_cell_setup(CellSetupArgs a) {
         const double B = 0.261799 * ((4.0 * (a.lons ? a.lons[c] : a.lon)) / 60.0);   // cpp:44, 54
         put(CF_COSB, cos(B));
         put(CF_SINB, sin(B));
+        put(CF_CROWPOS, a.crowpos ? a.crowpos[c % a.rows] : 0.0);
+        put(CF_CCOLPOS, a.ccolpos ? a.ccolpos[c / a.rows] : 0.0);
     }
     // ---- canopy conductance operands for the saturated (degrees) cankCpp call, cpp:1425, 466-469
     {
@@ -364,6 +366,22 @@ __global__ __launch_bounds__(256) void k_mxtc(const double* __restrict__ tc, int
     mx[c] = m;
 }
 
+// coarse array forcing: the same maximum over the interpolated series (the coarse field is L2-resident)
+__global__ __launch_bounds__(256) void k_mxtc_coarse(const double* __restrict__ tc, int crows, int ccols, int nsteps,
+                                                     const double* __restrict__ rowpos, const double* __restrict__ colpos,
+                                                     int64_t rows, int64_t N, double* __restrict__ mx) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    const CoarseTap tap(rowpos[c % rows], colpos[c / rows], crows, ccols);
+    const int64_t cN = (int64_t)crows * ccols;
+    double m = -273.15;
+    for (int k = 0; k < nsteps; ++k) {
+        const double v = tap(tc + cN * k);
+        if (v > m) m = v;
+    }
+    mx[c] = m;
+}
+
 // ------------------------------------------------------------------------------------
 // The solver.  Workgroup = CPB cells x 24 hours; thread t -> cell t % CPB, hour t / CPB,
 // so the lanes of a wave are CPB consecutive raster rows (coalesced stores of
@@ -374,7 +392,7 @@ __global__ __launch_bounds__(256) void k_mxtc(const double* __restrict__ tc, int
 // threads per workgroup: CPB*24 lanes rounded up to whole waves on all four SIMDs
 constexpr int solve_threads(int cpb) { return ((cpb * 24 + 255) / 256) * 256; }
 
-template <int CPB, bool AF, bool BG>
+template <int CPB, int AF, bool BG>   // AF: 0 vector forcing, 1 array forcing, 2 coarse array forcing
 // array forcing keeps ~17 more doubles live per lane (forcing values instead of an LDS table):
 // it is built for 3 waves/SIMD (168 VGPRs, no scratch) and run with 32-cell workgroups
 __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_PER_EU) void k_solve(SolveArgs a) {
@@ -543,10 +561,25 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
         TimeVals tv;
         const int64_t fidx = c + N * (a.force_step0 + kl);
         if (AF && valid) {
+            const int64_t kabs = (int64_t)dabs * 24 + hr;
+            if (AF == 2) {
+                // coarse arrays: interpolate, then derive what `.runmodel2Cpp` derives after resampling
+                // (slot TF_ES carries relhum, TF_U2 / TF_EA the wind components u, v)
+                const CoarseTap tap(C(CF_CROWPOS), C(CF_CCOLPOS), a.crows, a.ccols);
+                const double* q = a.af_base + (int64_t)a.crows * a.ccols * kabs;
+                auto at = [&](int f) { return tap(q + (int64_t)f * a.af_stride); };
+                const double tc = at(TF_TC), rh = at(TF_ES), wu = at(TF_U2), wv = at(TF_EA);
+                const double es = satvap_r(tc, MK), ea = es * rh / 100.0;
+                tv.v[TF_TC] = tc; tv.v[TF_ES] = es; tv.v[TF_EA] = ea; tv.v[TF_TDEW] = dewpoint_r(ea, tc, MK);
+                tv.v[TF_PK] = at(TF_PK); tv.v[TF_RSW] = at(TF_RSW); tv.v[TF_RDIF] = at(TF_RDIF); tv.v[TF_RLW] = at(TF_RLW);
+                const double s2 = wu * wu + wv * wv;
+                tv.v[TF_U2] = s2 > 0.0 ? fsqrt(s2) : 0.0;
+                tv.v[TF_SOILMP] = at(TF_SOILMP); tv.v[TF_UMU] = at(TF_UMU);
+            } else {
             // TF_TC .. TF_SOILMP and TF_UMU feed pass 1; Gp, kp, muGp, dtrp are reloaded for pass 2
             for (int f = 0; f < 10; ++f) tv.v[f] = a.af_base[(int64_t)f * a.af_stride + fidx];
             tv.v[TF_UMU] = a.af_base[(int64_t)TF_UMU * a.af_stride + fidx];
-            const int64_t kabs = (int64_t)dabs * 24 + hr;
+            }
             DateRow dr{a.dt[4 * kabs + 0], a.dt[4 * kabs + 1], a.dt[4 * kabs + 2], a.dt[4 * kabs + 3]};
             derive_time_af(tv, dr, C(CF_SINLAT), C(CF_COSLAT), C(CF_COSB), C(CF_SINB), a.windex[kabs], MK);
         }
@@ -653,11 +686,19 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
             }
             const double dtr = tmx - tmn;
             Pass2Out p2{};
-            if (AF)
-                derive_time_af_pass2(tv, a.af_base[(int64_t)TF_GP * a.af_stride + fidx],
-                                     a.af_base[(int64_t)TF_MUGP * a.af_stride + fidx],
-                                     a.af_base[(int64_t)TF_DTRP * a.af_stride + fidx],
-                                     a.af_base[(int64_t)TF_KP * a.af_stride + fidx]);
+            if (AF) {
+                if (AF == 2) {
+                    const CoarseTap tap(C(CF_CROWPOS), C(CF_CCOLPOS), a.crows, a.ccols);
+                    const double* q = a.af_base + (int64_t)a.crows * a.ccols * ((int64_t)dabs * 24 + hr);
+                    derive_time_af_pass2(tv, tap(q + (int64_t)TF_GP * a.af_stride), tap(q + (int64_t)TF_MUGP * a.af_stride),
+                                         tap(q + (int64_t)TF_DTRP * a.af_stride), tap(q + (int64_t)TF_KP * a.af_stride));
+                } else {
+                    derive_time_af_pass2(tv, a.af_base[(int64_t)TF_GP * a.af_stride + fidx],
+                                         a.af_base[(int64_t)TF_MUGP * a.af_stride + fidx],
+                                         a.af_base[(int64_t)TF_DTRP * a.af_stride + fidx],
+                                         a.af_base[(int64_t)TF_KP * a.af_stride + fidx]);
+                }
+            }
             if (AF) pass2(C, TR, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2, MK);
             else pass2(C, TL, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2, MK);
             if (BG) {
@@ -1000,6 +1041,11 @@ void launch_pack_transpose(const double* src, int64_t rows, int64_t cols, int64_
     dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32), (unsigned)nsteps);
     hipLaunchKernelGGL(k_pack_transpose, grid, dim3(256), 0, s, src, rows, cols, scale, dst);
 }
+void launch_mxtc_coarse(const double* tc, int crows, int ccols, int tsteps, const double* rowpos, const double* colpos,
+                        int64_t rows, int64_t N, double* mx, hipStream_t s) {
+    hipLaunchKernelGGL(k_mxtc_coarse, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, tc, crows, ccols, tsteps, rowpos,
+                       colpos, rows, N, mx);
+}
 void launch_fill(double* p, int64_t n, double v, hipStream_t s) {
     if (n <= 0) return;
     int64_t blocks = (n + 255) / 256;
@@ -1037,12 +1083,24 @@ static void launch_solve_cpb(const SolveArgs& a, bool af, bool bg, hipStream_t s
     dim3 grid((unsigned)((a.N + CPB - 1) / CPB)), block(solve_threads(CPB));
 #endif
     if (af) {
-        if (bg) hipLaunchKernelGGL((k_solve<CPB, true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_solve<CPB, true, false>), grid, block, 0, s, a);
+        if (bg) hipLaunchKernelGGL((k_solve<CPB, 1, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_solve<CPB, 1, false>), grid, block, 0, s, a);
     } else {
-        if (bg) hipLaunchKernelGGL((k_solve<CPB, false, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_solve<CPB, false, false>), grid, block, 0, s, a);
+        if (bg) hipLaunchKernelGGL((k_solve<CPB, 0, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_solve<CPB, 0, false>), grid, block, 0, s, a);
     }
+}
+// coarse array forcing is built for the array-forcing geometry (32 cells per workgroup) only
+static void launch_solve_coarse(const SolveArgs& a, bool bg, hipStream_t s) {
+    constexpr int CPB = 32;
+#if MCF_XCD_REMAP
+    const int64_t ntiles = (a.N + CPB - 1) / CPB;
+    dim3 grid((unsigned)(8 * ((ntiles + 7) / 8))), block(solve_threads(CPB));
+#else
+    dim3 grid((unsigned)((a.N + CPB - 1) / CPB)), block(solve_threads(CPB));
+#endif
+    if (bg) hipLaunchKernelGGL((k_solve<CPB, 2, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_solve<CPB, 2, false>), grid, block, 0, s, a);
 }
 int twi_scratch_doubles() { return 2 + 2 * kTwiParts; }
 int cell_field_count() { return CF_COUNT; }
@@ -1057,6 +1115,7 @@ double hf_pow02(double rs) {
 
 void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, hipStream_t s) {
     if (a.N <= 0 || a.ndays <= 0) return;
+    if (a.crows > 0) { launch_solve_coarse(a, bg, s); return; }
     if (cells_per_block == 32) launch_solve_cpb<32>(a, af, bg, s);
     else if (cells_per_block == 21) launch_solve_cpb<21>(a, af, bg, s);
     else if (cells_per_block == 42) launch_solve_cpb<42>(a, af, bg, s);

@@ -54,7 +54,11 @@ def marshal(obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Mapping,
             soilc: Mapping, reqhgt: float, zref: float, lat, lon, Sminp: float,
             Smaxp: float, tfact: float, complete: bool, mat: float,
             out: Sequence, array_forcing: bool, device: int = 0,
-            days_per_chunk: int = 0, cells_per_block: int = 0, dfsel: Mapping | None = None) -> Marshalled:
+            days_per_chunk: int = 0, cells_per_block: int = 0, dfsel: Mapping | None = None,
+            coarse: Mapping | None = None) -> Marshalled:
+    """`coarse` = {"rowpos": [rows], "colpos": [cols]} switches to coarse array forcing (mcf.h, array_forcing == 2):
+    climdata = {temp, relhum, pres, swdown, difrad, lwdown, windspeed, winddir} and pointm are then
+    [coarse_rows, coarse_cols, tsteps] arrays."""
     m = Marshalled()
     hgt = np.asarray(vegp["hgt"], dtype=np.float64)
     if dfsel is None:
@@ -74,15 +78,29 @@ def marshal(obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Mapping,
     m.rows, m.cols, m.tsteps = R, Cc, T
     gi = m.inputs
     gi.rows, gi.cols, gi.tsteps = R, Cc, T
-    gi.array_forcing = 1 if array_forcing else 0
+    gi.array_forcing = 2 if coarse is not None else 1 if array_forcing else 0
+    cshape = None
+    if coarse is not None:
+        t0 = np.asarray(_get(climdata, "temp", "tc"))
+        if t0.ndim != 3 or t0.shape[2] != T:
+            raise ValueError("coarse climate arrays must be [coarse_rows, coarse_cols, tsteps]")
+        cshape = t0.shape
+        gi.coarse_rows, gi.coarse_cols = int(cshape[0]), int(cshape[1])
+        gi.coarse_rowpos = m._f64(coarse["rowpos"], (R,), "coarse$rowpos")
+        gi.coarse_colpos = m._f64(coarse["colpos"], (Cc,), "coarse$colpos")
+        gi.coarse_relhum = m._f64(climdata["relhum"], cshape, "climdata$relhum")
+        gi.coarse_winddir = m._f64(climdata["winddir"], cshape, "climdata$winddir")
     gi.obstime.year = m._i32(obstime["year"], T, "obstime$year")
     gi.obstime.month = m._i32(obstime["month"], T, "obstime$month")
     gi.obstime.day = m._i32(obstime["day"], T, "obstime$day")
     gi.obstime.hour = m._f64(obstime["hour"], (T,), "obstime$hour")
-    fshape = (R, Cc, T) if array_forcing else (T,)
+    fshape = cshape if coarse is not None else (R, Cc, T) if array_forcing else (T,)
     # climdata: data.frame names (1Cpp) or list names (2Cpp)
     names = {"tc": ("temp", "tc"), "pk": ("pres", "pk")}
     for f in _abi.CLIM_FIELDS:
+        if coarse is not None and f in ("es", "ea", "tdew", "winddir"):     # derived inside the solver
+            setattr(gi.clim, f, None)
+            continue
         src = _get(climdata, *names.get(f, (f,)))
         shape = (T,) if f == "winddir" else fshape
         setattr(gi.clim, f, m._f64(src, shape, f"climdata${f}"))

@@ -342,3 +342,26 @@ def microsnow_inputs(sw: dict, smod: dict, seed=SEED):
     micro = {nm: np.asfortranarray((1000.0 * (v + 1) + uniform(100 + v, base, seed)).reshape((R, Cc, T), order="F"))
              for v, nm in enumerate(names)}
     return snowm, micro
+
+
+def coarse_workload(rows: int, cols: int, tsteps: int, crows: int, ccols: int, reqhgt: float = 0.05, seed=SEED, **kw):
+    """Inputs of the coarse array-forcing mode (include/mcf.h, array_forcing == 2): fine rasters as `workload`, climate
+    and point-model arrays on a [crows, ccols] grid covering the same extent (what `.runmodel2Cpp` holds before it
+    resamples).  Returns (args for runmicro2Cpp_coarse, rowpos, colpos)."""
+    fine = workload(rows, cols, tsteps, reqhgt=reqhgt, seed=seed, array_forcing=False, **kw)
+    kw2 = {k: v for k, v in kw.items() if k in ("start_doy", "cold", "lat", "lon", "year")}
+    co = workload(crows, ccols, tsteps, reqhgt=reqhgt, seed=seed, array_forcing=True, **kw2)
+    c = co["climdata"]
+    i = np.arange(crows * ccols, dtype=np.uint64).reshape((crows, ccols), order="F")[:, :, None]
+    k = (np.arange(tsteps, dtype=np.uint64) * np.uint64(crows * ccols))[None, None, :]
+    wd = (c["winddir"][None, None, :] + 40.0 * (uniform(71, i + k, seed) - 0.5)) % 360.0
+    clim = {"temp": c["tc"], "relhum": np.asfortranarray(np.clip(100 * c["ea"] / c["es"], 5, 100)), "pres": c["pk"],
+            "swdown": c["swdown"], "difrad": c["difrad"], "lwdown": c["lwdown"], "windspeed": c["windspeed"],
+            "winddir": np.asfortranarray(wd)}
+    fi = (np.arange(rows, dtype=np.float64))[:, None]
+    fj = (np.arange(cols, dtype=np.float64))[None, :]
+    args = dict(fine)
+    args.update(climdata=clim, pointm=co["pointm"],
+                lat=fine["lat"] + 0.01 * (fi / max(rows, 1)) + 0 * fj, lon=fine["lon"] + 0.01 * (fj / max(cols, 1)) + 0 * fi)
+    pos = lambda n, m: np.clip((np.arange(n) + 0.5) * (m / n) - 0.5, 0.0, m - 1.0)       # noqa: E731
+    return args, pos(rows, crows), pos(cols, ccols)

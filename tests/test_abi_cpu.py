@@ -35,7 +35,31 @@ def test_struct_layout_matches_header():
     assert C.sizeof(_abi.Pointm) == 8 * 8
     assert C.sizeof(_abi.Vegp) == 10 * 8
     assert C.sizeof(_abi.Soilc) == 15 * 8
-    assert C.sizeof(_abi.GridInputs) == 3 * 8 + 8 + (4 + 10 + 8 + 10 + 15) * 8 + 2 * 8 + 2 * 8 + 2 * 8
+    assert C.sizeof(_abi.GridInputs) == 3 * 8 + 8 + (4 + 10 + 8 + 10 + 15) * 8 + 2 * 8 + 2 * 8 + 2 * 8 + 8 + 4 * 8
+
+
+def test_ctypes_structs_agree_with_the_compiled_header(tmp_path):
+    """sizeof / offsetof from gcc on include/mcf.h against the ctypes mirrors"""
+    import subprocess
+    root = Path(__file__).resolve().parents[1]
+    probes = {"mcf_grid_inputs": (_abi.GridInputs, ["tsteps", "array_forcing", "veg_layers", "clim", "soilc", "lat", "lats",
+                                                    "lyr_ed", "coarse_rows", "coarse_cols", "coarse_rowpos", "coarse_winddir"]),
+              "mcf_options": (_abi.Options, ["tfact", "complete", "out", "device", "cells_per_block"]),
+              "mcf_nc_spec": (_abi.NcSpec, ["nsteps", "east", "crs_wkt", "reqhgt", "vars", "reference_puts_only"])}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "mcf.h"', 'int main(void) {']
+    for name, (_, fields) in probes.items():
+        src.append(f'printf("{name} %zu\\n", sizeof({name}));')
+        for f in fields:
+            src.append(f'printf("{name}.{f} %zu\\n", offsetof({name}, {f}));')
+    src.append('return 0; }')
+    (tmp_path / "probe.c").write_text("\n".join(src))
+    subprocess.run(["gcc", "-I", str(root / "include"), "-o", str(tmp_path / "probe"), str(tmp_path / "probe.c")], check=True)
+    out = subprocess.run([str(tmp_path / "probe")], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = dict(line.split() for line in out if line)
+    for name, (cls, fields) in probes.items():
+        assert int(got[name]) == C.sizeof(cls), name
+        for f in fields:
+            assert int(got[f"{name}.{f}"]) == getattr(cls, f).offset, f"{name}.{f}"
     assert C.sizeof(_abi.Options) == 6 * 8 + 4 + 40 + 3 * 4
     assert C.sizeof(_abi.Outputs) == 80
 

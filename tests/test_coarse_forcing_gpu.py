@@ -1,0 +1,72 @@
+"""Coarse array forcing (include/mcf.h, array_forcing == 2): `.runmodel2Cpp`'s resampling of coarse climate and
+point-model arrays fused into the solver, against the reference's order of work — expand to full resolution
+(oracle/coarse_oracle.py), then the array-forcing oracle."""
+import numpy as np
+import pytest
+
+from microclimf_amd import synthetic
+from microclimf_amd.api import Plan, runmicro2Cpp, runmicro2Cpp_coarse
+from oracle import coarse_oracle as CO
+from test_parity_gpu import compare
+
+pytestmark = pytest.mark.gpu
+ARGS = ("obstime", "climdata", "pointm", "vegp", "soilc", "reqhgt", "zref", "lat", "lon", "Sminp", "Smaxp", "tfact",
+        "complete", "mat", "out")
+
+
+def expanded(a, rp, cp):
+    clim, pm = CO.expand(a["climdata"], a["pointm"], rp, cp)
+    b = dict(a)
+    b.update(climdata=clim, pointm=pm)
+    return b
+
+
+@pytest.mark.parametrize("rows,cols,cr,cc,reqhgt", [(37, 29, 5, 4, 0.05), (64, 40, 2, 3, 1.0), (20, 33, 1, 1, 0.05),
+                                                     (31, 18, 31, 18, 0.0), (26, 26, 4, 4, -0.1)])
+def test_coarse_forcing_matches_expand_then_solve(oracle, rows, cols, cr, cc, reqhgt):
+    a, rp, cp = synthetic.coarse_workload(rows, cols, 72, cr, cc, reqhgt=reqhgt, variety=True, start_doy=170, na_frac=0.03)
+    got = runmicro2Cpp_coarse(*[a[k] for k in ARGS], rowpos=rp, colpos=cp)
+    b = expanded(a, rp, cp)
+    want = oracle.run_grid(**b, array_forcing=True)
+    compare(got, want)
+    # and the device's own array-forcing path given the expanded arrays
+    full = runmicro2Cpp(*[b[k] for k in ARGS])
+    for k in want:
+        np.testing.assert_allclose(got[k], full[k], rtol=1e-9, atol=1e-9, err_msg=k)
+
+
+def test_identity_grid_equals_plain_array_forcing_bitwise_inputs(oracle):
+    """a coarse grid as fine as the raster interpolates nothing: positions are integers, weights 0"""
+    a, rp, cp = synthetic.coarse_workload(24, 16, 48, 24, 16, variety=True, start_doy=100)
+    assert np.array_equal(rp, np.arange(24.0)) and np.array_equal(cp, np.arange(16.0))
+    b = expanded(a, rp, cp)
+    assert np.array_equal(b["climdata"]["tc"], a["climdata"]["temp"])
+    compare(runmicro2Cpp_coarse(*[a[k] for k in ARGS]), oracle.run_grid(**b, array_forcing=True))
+
+
+def test_plan_keeps_the_coarse_series_resident_and_needs_no_uploads(oracle):
+    a, rp, cp = synthetic.coarse_workload(40, 30, 120, 3, 3, variety=True, start_doy=200)
+    want = oracle.run_grid(**expanded(a, rp, cp), array_forcing=True)
+    with Plan(**a, ring_days=2, ring_slots=2, coarse={"rowpos": rp, "colpos": cp}) as p:
+        slot = 0
+        for d0 in (0, 2, 4):
+            nd = min(2, 5 - d0)
+            p.run_days(d0, nd, slot)                 # no upload_forcing_days
+            p.sync()
+            for k in ("Tz", "relhum", "Rswup"):
+                got = p.fetch(slot, k, 0, nd * 24)
+                w = want[k][:, :, d0 * 24:(d0 + nd) * 24]
+                assert np.array_equal(np.isnan(got), np.isnan(w))
+                assert np.nanmax(np.abs(got - w) / (1 + np.abs(w))) < 1e-6, k
+            slot ^= 1
+
+
+def test_coarse_mode_argument_checks():
+    from microclimf_amd import McfError
+    a, rp, cp = synthetic.coarse_workload(12, 12, 24, 3, 3)
+    with pytest.raises(McfError, match="coarse_rowpos"):
+        runmicro2Cpp_coarse(*[a[k] for k in ARGS], rowpos=rp + 5.0, colpos=cp)
+    a2, rp2, cp2 = synthetic.coarse_workload(12, 12, 48, 3, 3, reqhgt=-0.1, complete=False)
+    a2["pointm"] = dict(a2["pointm"], Tg=a2["pointm"]["soilm"], Tbp=a2["pointm"]["soilm"])
+    with pytest.raises(McfError, match="complete"):
+        runmicro2Cpp_coarse(*[a2[k] for k in ARGS], rowpos=rp2, colpos=cp2)
