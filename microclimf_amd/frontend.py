@@ -228,7 +228,8 @@ def soilbelowT(dfo: Mapping, reqhgt: float) -> np.ndarray:
 
 def runpointmodel(weather: Mapping, reqhgt: float, dtm: Mapping, vegp: Mapping, soilc: Mapping, *, zref: float = 2.0,
                   windhgt: float | None = None, soilm=None, matemp: float | None = None, dTmx: float = 25.0,
-                  maxiter: int = 20, yearG: bool = True, lat: float | None = None, long: float | None = None) -> dict:
+                  maxiter: int = 20, yearG: bool = True, lat: float | None = None, long: float | None = None,
+                  vegp_p=None, groundp_p=None, soiltype: int | None = None, mxhgt: float | None = None) -> dict:
     """`runpointmodel(weather, reqhgt, dtm, vegp, soilc, ...)` (R/Cppwrappers.R:59-139).  `weather`: the columns of the
     reference's `climdata` plus `obstime = {year, month, day, hour}` in place of the POSIX `obs_time`."""
     w = {k: np.array(weather[k], dtype=np.float64, copy=True) for k in WEATHER if k in weather}
@@ -241,8 +242,10 @@ def runpointmodel(weather: Mapping, reqhgt: float, dtm: Mapping, vegp: Mapping, 
         w["windspeed"] = w["windspeed"] * np.log(67.8 * zref - 5.42) / np.log(67.8 * windhgt - 5.42)
     if n < 8760:
         yearG = False
-    vegp_p, groundp_p = sortvegp_point(vegp), sortsoilc_point(soilc)
-    mxhgt = float(np.nanmax(np.asarray(vegp["hgt"], dtype=np.float64)))
+    vegp_p = sortvegp_point(vegp) if vegp_p is None else np.asarray(vegp_p, dtype=np.float64)
+    groundp_p = sortsoilc_point(soilc) if groundp_p is None else np.asarray(groundp_p, dtype=np.float64)
+    if mxhgt is None:
+        mxhgt = float(np.nanmax(np.asarray(vegp["hgt"], dtype=np.float64)))
     zout = mxhgt if mxhgt > 2 else 2.0
     lat = dtm["lat"] if lat is None else lat
     long = dtm["long"] if long is None else long
@@ -253,7 +256,7 @@ def runpointmodel(weather: Mapping, reqhgt: float, dtm: Mapping, vegp: Mapping, 
         zref = zout
     w["windspeed"] = np.maximum(w["windspeed"], 0.5)
     if soilm is None:
-        ii = int(getmode(soilc["soiltype"])) - 1
+        ii = (int(getmode(soilc["soiltype"])) if soiltype is None else int(soiltype)) - 1
         p = SOILPARAMSP
         sd = pointmodel.soilmCpp(w, p["rmu"][ii], p["mult"][ii], p["pwr"][ii], p["Smax"][ii], p["Smin"][ii], p["Ksat"][ii],
                                  p["a"][ii])
@@ -356,3 +359,104 @@ def runmicro(micropoint: Mapping, reqhgt: float, vegp: Mapping, soilc: Mapping, 
     if dfsel is None:
         return api.runmicro1Cpp(**a, device=device)
     return api.runmicro3Cpp(dfsel, **a, device=device)
+
+
+# ---- array weather: runpointmodela() and runmicro() -> .runmodel2Cpp / .runmodel4Cpp ------------------------------
+def block_reduce(a, crows: int, ccols: int, how: str = "mean"):
+    """A fine raster [rows, cols(, layers)] summarised per coarse cell (the fine cells whose centres fall in it):
+    stands for `.resampler(r2, r)` = terra aggregate + resample (R/internal.R:358-380; terra semantics unpinned)."""
+    a = as3d(a)
+    R, Cc, L = a.shape
+    ri = np.minimum((np.arange(R) + 0.5) * crows / R, crows - 1).astype(int)
+    ci = np.minimum((np.arange(Cc) + 0.5) * ccols / Cc, ccols - 1).astype(int)
+    out = np.full((crows, ccols, L), np.nan)
+    for i in range(crows):
+        for j in range(ccols):
+            blk = a[np.ix_(ri == i, ci == j)].reshape(-1, L)
+            for l in range(L):
+                v = blk[:, l]
+                v = v[~np.isnan(v)]
+                if v.size:
+                    out[i, j, l] = getmode(v) if how == "mode" else v.mean()
+    return out
+
+
+def runpointmodela(climarray: Mapping, obstime: Mapping, reqhgt: float, dtm: Mapping, vegp: Mapping, soilc: Mapping, *,
+                   lats, lons, matemp: float | None = None, zref: float = 2.0, windhgt: float = 2.0, soilm=None,
+                   dTmx: float = 25.0, maxiter: int = 20, yearG: bool = True) -> list:
+    """`runpointmodela(climarrayr, tme, reqhgt, dtm, vegp, soilc, ...)` (R/Cppwrappers.R:208-263): the point model once
+    per cell of the coarse climate grid.  `climarray[k]`: [crows, ccols, T]; `lats`, `lons`: [crows, ccols] (the reference
+    takes them from the climate raster's CRS).  Returns the row-major list of micropoints (None where the cell has no
+    data), as the reference's `pointo`."""
+    cr, cc, T = np.shape(climarray["temp"])
+    mxhgt = float(np.nanmax(np.asarray(vegp["hgt"], dtype=np.float64)))
+    wdir = np.array([getmode(np.asarray(climarray["winddir"])[:, :, k]) for k in range(T)])
+    vc = {k: block_reduce(vegp[k], cr, cc) for k in VEG_KEYS}
+    st = block_reduce(soilc["soiltype"], cr, cc, "mode")[:, :, 0]
+    soiltype = int(getmode(st))
+    gr = float(np.nanmean(np.asarray(soilc["groundr"], dtype=np.float64)))
+    P = SOILPARAMETERS
+    out = []
+    for i in range(cr):
+        for j in range(cc):
+            if np.isnan(climarray["temp"][i, j, 0]) or np.isnan(vc["hgt"][i, j, 0]):
+                out.append(None)
+                continue
+            w = {k: np.asarray(climarray[k])[i, j, :] for k in WEATHER if k != "winddir"}
+            w["winddir"] = wdir
+            w["obstime"] = obstime
+            m = {k: float(np.mean(vc[k][i, j, :])) for k in VEG_KEYS}                                   # .tovp
+            vegp_p = np.array([m["hgt"], m["pai"], m["x"], m["clump"], m["leafr"], m["leaft"], m["leafd"], 0.97, m["gsmax"], 100.0])
+            sn = int(st[i, j]) - 1                                                                       # .togp
+            groundp_p = np.array([gr, 0.0, 180.0, 0.97, P["rho"][sn], P["Vm"][sn], P["Vq"][sn], P["Mc"][sn], P["b"][sn],
+                                  P["psi_e"][sn], P["Smax"][sn], P["Smin"][sn], P["Smin"][sn], P["Smin"][sn], P["Smin"][sn]])
+            out.append(runpointmodel(w, reqhgt, dtm, vegp, soilc, zref=zref, windhgt=windhgt,
+                                     soilm=None if soilm is None else np.asarray(soilm)[i, j, :], matemp=matemp, dTmx=dTmx,
+                                     maxiter=maxiter, yearG=yearG, lat=float(lats[i, j]), long=float(lons[i, j]),
+                                     vegp_p=vegp_p, groundp_p=groundp_p, soiltype=soiltype, mxhgt=mxhgt))
+    return out
+
+
+def prepare_grid_inputs_array(micropointa: Sequence, crows: int, ccols: int, reqhgt: float, vegp: Mapping, soilc: Mapping,
+                              dtm: Mapping, *, lats, lons, pai_a=None, out: Sequence = (1,) * 10, slr=None, apr=None,
+                              hor=None, twi=None, wsa=None, svf=None, device: int = 0) -> dict:
+    """What `.runmodel2Cpp` / `.runmodel4Cpp` prepare (R/internal.R:1175-1343), altcorrect = 0, with the climate and
+    point-model variables left on the coarse grid: the solver interpolates them (array_forcing == 2).  `lats`, `lons`:
+    [rows, cols] of the fine raster (`.latslonsfromr(dtm)`).  Cells of the coarse grid without a micropoint are not
+    supported (the reference fills them with NA and lets `resample` look around them)."""
+    if any(m is None for m in micropointa):
+        raise ValueError("every coarse cell needs a micropoint")
+    first = micropointa[0]
+    base = prepare_grid_inputs(first, reqhgt, vegp, soilc, dtm, pai_a=pai_a, out=out, slr=slr, apr=apr, hor=hor, twi=twi,
+                               wsa=wsa, svf=svf, device=device)
+    T = len(first["weather"]["temp"])
+
+    def grid(get):
+        a = np.empty((crows, ccols, T), order="F")
+        for k, m in enumerate(micropointa):
+            a[k // ccols, k % ccols, :] = get(m)
+        return a
+    clim = {k: grid(lambda m, k=k: m["weather"][k]) for k in ("temp", "relhum", "pres", "swdown", "difrad", "lwdown",
+                                                                "windspeed", "winddir")}
+    pm = {"soilm": "soilm", "Gp": "G", "umu": "umu", "kp": "kp", "muGp": "muGp", "dtrp": "dtrp"}
+    pointm = {k: grid(lambda m, v=v: m["dfo"][v]) for k, v in pm.items()}
+    base.update(climdata=clim, pointm=pointm, lat=np.asfortranarray(lats, dtype=np.float64),
+                lon=np.asfortranarray(lons, dtype=np.float64), zref=float(first["zref"]),
+                mat=float(np.mean([m["matemp"] for m in micropointa])))
+    return base
+
+
+def runmicro_array(micropointa: Sequence, crows: int, ccols: int, reqhgt: float, vegp: Mapping, soilc: Mapping, dtm: Mapping,
+                   *, lats, lons, tfact: float = 1.5, device: int = 0, **kw) -> dict:
+    """`runmicro()` for a list of micropoints from `runpointmodela` (array weather, no snow, altcorrect = 0)."""
+    if reqhgt < 0:
+        raise ValueError("coarse array forcing below ground needs the per-cell point-model series: not mirrored")
+    a = prepare_grid_inputs_array(micropointa, crows, ccols, reqhgt, vegp, soilc, dtm, lats=lats, lons=lons, device=device, **kw)
+    a["tfact"] = float(tfact)
+    dfsel = a.pop("dfsel", None)
+    R, Cc = a["vegp"]["hgt"].shape[:2]
+    coarse = {"rowpos": api.coarse_positions(R, crows), "colpos": api.coarse_positions(Cc, ccols)}
+    order = ("obstime", "climdata", "pointm", "vegp", "soilc", "reqhgt", "zref", "lat", "lon", "Sminp", "Smaxp", "tfact",
+             "complete", "mat", "out")
+    fn = "mcf_runmicro2" if dfsel is None else "mcf_runmicro4"
+    return api._run(fn, True, *[a[k] for k in order], device, 0, 0, dfsel, coarse)

@@ -53,3 +53,41 @@ def test_bundled_month_other_heights(oracle, reqhgt, static):
     assert list(got) == (["Tz", "tleaf", "relhum", "soilm", "windspeed", "Rdirdown", "Rdifdown", "Rlwdown", "Rswup", "Rlwup"]
                          if reqhgt > 0 else ["Tz", "soilm", "Rdirdown", "Rdifdown", "Rlwdown", "Rswup", "Rlwup"]
                          if reqhgt == 0 else ["Tz", "soilm"])
+
+
+@pytest.mark.parametrize("layered", [False, True])
+def test_array_weather_chain_on_the_bundled_site(oracle, layered):
+    """runpointmodela -> runmicro with a 2 x 3 grid of (perturbed) climate cells over the bundled site: the point model per
+    coarse cell, the coarse arrays interpolated inside the solver, against expand-then-solve through the oracle"""
+    from oracle import coarse_oracle as CO
+    from microclimf_amd import api
+    weather, vegp, soilc, dtm = load(10 * 24)
+    if not layered:
+        vegp = {k: (v[:, :, 6] if v.ndim == 3 else v) for k, v in vegp.items()}
+    cr, cc, T = 2, 3, 240
+    rng = np.random.default_rng(4)
+    climarray = {}
+    for k in F.WEATHER:
+        base = np.broadcast_to(weather[k][None, None, :], (cr, cc, T)).copy()
+        if k == "temp":
+            base += rng.uniform(-1.5, 1.5, (cr, cc, 1))
+        elif k in ("swdown", "difrad", "windspeed", "precip"):
+            base *= rng.uniform(0.9, 1.1, (cr, cc, 1))
+        elif k == "winddir":
+            base = (base + rng.integers(-1, 2, (cr, cc, T)) * 10.0) % 360
+        climarray[k] = np.asfortranarray(base)
+    climarray["difrad"] = np.minimum(climarray["difrad"], climarray["swdown"])
+    clat = dtm["lat"] + 1e-4 * np.arange(cr)[:, None] + 0 * np.arange(cc)[None, :]
+    clon = dtm["long"] + 1e-4 * np.arange(cc)[None, :] + 0 * np.arange(cr)[:, None]
+    mpa = F.runpointmodela(climarray, weather["obstime"], 0.05, dtm, vegp, soilc, lats=clat, lons=clon)
+    assert len(mpa) == cr * cc and all(m is not None for m in mpa)
+    assert abs(mpa[0]["dfo"]["Tg"].mean() - mpa[-1]["dfo"]["Tg"].mean()) > 1e-3        # the cells differ
+    lats = dtm["lat"] + 9e-6 * np.arange(50)[::-1, None] + 0 * np.arange(50)[None, :]
+    lons = dtm["long"] + 1.4e-5 * np.arange(50)[None, :] + 0 * np.arange(50)[:, None]
+    got = F.runmicro_array(mpa, cr, cc, 0.05, vegp, soilc, dtm, lats=lats, lons=lons)
+    a = F.prepare_grid_inputs_array(mpa, cr, cc, 0.05, vegp, soilc, dtm, lats=lats, lons=lons)
+    assert ("dfsel" in a) == layered
+    clim, pm = CO.expand(a["climdata"], a["pointm"], api.coarse_positions(50, cr), api.coarse_positions(50, cc))
+    b = dict(a)
+    b.update(climdata=clim, pointm=pm)
+    compare(got, oracle.run_grid(**b, array_forcing=True))
