@@ -70,3 +70,22 @@ def test_coarse_mode_argument_checks():
     a2["pointm"] = dict(a2["pointm"], Tg=a2["pointm"]["soilm"], Tbp=a2["pointm"]["soilm"])
     with pytest.raises(McfError, match="complete"):
         runmicro2Cpp_coarse(*[a2[k] for k in ARGS], rowpos=rp2, colpos=cp2)
+
+
+@pytest.mark.parametrize("i", range(24))
+def test_random_coarse_configurations(oracle, i):
+    rng = np.random.default_rng(12000 + i)
+    rows, cols = int(rng.integers(1, 45)), int(rng.integers(1, 45))
+    cr, cc = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+    T = int(rng.integers(1, 4)) * 24 + int(rng.choice([0, 0, 7]))
+    reqhgt = float(rng.choice([0.02, 0.05, 0.6, 1.9, 0.0, -0.08]))
+    out = [int(b) for b in rng.random(10) < 0.6]
+    out[0] = 1
+    a, rp, cp = synthetic.coarse_workload(rows, cols, T, cr, cc, reqhgt=reqhgt, variety=bool(rng.random() < 0.7),
+                                          start_doy=int(rng.integers(1, 350)), cold=float(rng.choice([0.0, 12.0])),
+                                          na_frac=float(rng.choice([0.0, 0.05])), out=out, seed=int(rng.integers(1, 1 << 30)))
+    if rng.random() < 0.3:                       # a climate grid that covers more than the raster: positions inside one cell
+        rp = np.clip(rp * 0.3 + 0.2 * (cr - 1), 0, cr - 1)
+        cp = np.clip(cp * 0.5, 0, cc - 1)
+    got = runmicro2Cpp_coarse(*[a[k] for k in ARGS], rowpos=rp, colpos=cp, days_per_chunk=int(rng.choice([0, 1])) if reqhgt >= 0 else 0)
+    compare(got, oracle.run_grid(**expanded(a, rp, cp), array_forcing=True))

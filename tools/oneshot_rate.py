@@ -14,7 +14,8 @@ from microclimf_amd.api import runmicro1Cpp   # noqa: E402
 from microclimf_amd.api import runmicro2Cpp   # noqa: E402
 
 af = "--af" in sys.argv                        # array climate: the 15 forcing arrays cross PCIe too
-argv = [v for v in sys.argv[1:] if v != "--af"]
+coarse = "--coarse" in sys.argv                # coarse array climate (8 x 8), interpolated inside the solver
+argv = [v for v in sys.argv[1:] if v not in ("--af", "--coarse")]
 rows, cols, T = (int(v) for v in (argv[0:3] or (512, 512, 240)))
 for out in ([1] * 10, [1] + [0] * 9):
     a = synthetic.workload(rows, cols, T, reqhgt=0.05, out=out, array_forcing=af)
@@ -22,6 +23,13 @@ for out in ([1] * 10, [1] + [0] * 9):
     fn = runmicro1Cpp
     if af:
         fn = runmicro2Cpp
+        for d in (a, w):
+            d["lats"], d["lons"] = d.pop("lat"), d.pop("lon")
+    if coarse:
+        from microclimf_amd.api import runmicro2Cpp_coarse
+        a, rp, cp = synthetic.coarse_workload(rows, cols, T, 8, 8, reqhgt=0.05, out=out)
+        w, _, _ = synthetic.coarse_workload(64, 64, 48, 8, 8, reqhgt=0.05, out=out)
+        fn = runmicro2Cpp_coarse
         for d in (a, w):
             d["lats"], d["lons"] = d.pop("lat"), d.pop("lon")
     fn(**w)                                    # warm up
