@@ -147,6 +147,13 @@ typedef struct mcf_grid_inputs {
     int32_t coarse_rows, coarse_cols;
     const double *coarse_rowpos, *coarse_colpos;
     const double *coarse_relhum, *coarse_winddir;
+    /* `.runmodel2Cpp`'s altcorrect (R/internal.R:1233-1251): 0 none; 1 fixed lapse rate 5 K/km; 2 humidity-dependent
+     * lapse rate (`.lapserate`, R/internal.R:545-550).  With 1 or 2: coarse_dtm [coarse_rows, coarse_cols] (elevation
+     * of the climate cells, NA read as 0) and fine_dtm [rows, cols]; pressure goes to sea level on the coarse grid and
+     * back up on the fine one, temperature moves by lapse rate x (interpolated coarse elevation - fine elevation);
+     * es, ea, tdew come from the UNcorrected temperature, as in the reference. */
+    int32_t coarse_altcorrect;
+    const double *coarse_dtm, *fine_dtm;
 } mcf_grid_inputs;
 
 typedef struct mcf_options {

@@ -53,7 +53,8 @@ class GridInputs(C.Structure):
                 ("lyr_st", c_int32_p), ("lyr_ed", c_int32_p),
                 ("coarse_rows", C.c_int32), ("coarse_cols", C.c_int32),
                 ("coarse_rowpos", c_double_p), ("coarse_colpos", c_double_p),
-                ("coarse_relhum", c_double_p), ("coarse_winddir", c_double_p)]
+                ("coarse_relhum", c_double_p), ("coarse_winddir", c_double_p),
+                ("coarse_altcorrect", C.c_int32), ("coarse_dtm", c_double_p), ("fine_dtm", c_double_p)]
 
 
 class Options(C.Structure):

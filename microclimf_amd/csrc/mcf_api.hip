@@ -65,6 +65,8 @@ struct mcf_plan {
     bool coarse = false;                 // array_forcing == 2: coarse arrays interpolated in the solver
     int crows = 0, ccols = 0;
     const double *d_crowpos = nullptr, *d_ccolpos = nullptr;
+    int altcorrect = 0;
+    const double *d_elevd = nullptr, *d_pkfac = nullptr;
     int cpb = 16;
     int layers = 1;
     int32_t* d_daylayer = nullptr;
@@ -214,6 +216,7 @@ int ensure_cells(mcf_plan* p) {
     a.svfa = p->d_soil[12];
     a.lats = p->d_lats; a.lons = p->d_lons; a.lat = p->lat; a.lon = p->lon;
     a.crowpos = p->d_crowpos; a.ccolpos = p->d_ccolpos; a.rows = p->rows;
+    a.elevd = p->d_elevd; a.pkfac = p->d_pkfac;
     a.tfact = p->opt.tfact;
     a.twi_mean = p->twi_mean;
     a.g = p->g;
@@ -352,6 +355,10 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
             if (!(in->coarse_colpos[j] >= 0.0 && in->coarse_colpos[j] <= in->coarse_cols - 1))
                 return fail(MCF_ERR_ARG, "coarse_colpos must lie in [0, coarse_cols - 1]");
         p->crows = in->coarse_rows; p->ccols = in->coarse_cols;
+        p->altcorrect = in->coarse_altcorrect;
+        if (p->altcorrect < 0 || p->altcorrect > 2) return fail(MCF_ERR_ARG, "coarse_altcorrect must be 0, 1 or 2");
+        if (p->altcorrect && (!in->coarse_dtm || !in->fine_dtm))
+            return fail(MCF_ERR_ARG, "altitude correction needs coarse_dtm and fine_dtm");
     }
     // vector forcing: two 8-wave workgroups per CU (21 cells); array forcing: one 12-wave workgroup
     p->cpb = opt->cells_per_block ? opt->cells_per_block : (in->array_forcing ? 32 : 21);
@@ -385,9 +392,40 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
         if ((rc = upload(p, in->lats, N, &p->d_lats, "lats"))) return rc;
         if ((rc = upload(p, in->lons, N, &p->d_lons, "lons"))) return rc;
     }
+    std::vector<double> cpk_sea;     // coarse pressure reduced to sea level (altitude correction)
     if (p->coarse) {
         if ((rc = upload(p, in->coarse_rowpos, in->rows, &p->d_crowpos, "coarse_rowpos"))) return rc;
         if ((rc = upload(p, in->coarse_colpos, in->cols, &p->d_ccolpos, "coarse_colpos"))) return rc;
+        if (p->altcorrect) {
+            // R/internal.R:1236-1241: psl = pk / ((293 - 0.0065 zc) / 293)^5.26 on the coarse grid, back up with the
+            // fine elevation after resampling; elevd = resample(dtmc) - dtm
+            const int cr = p->crows, cc = p->ccols;
+            std::vector<double> zc((size_t)cr * cc), elevd((size_t)N), pkfac((size_t)N);
+            for (size_t q = 0; q < zc.size(); ++q) zc[q] = std::isnan(in->coarse_dtm[q]) ? 0.0 : in->coarse_dtm[q];
+            for (int64_t j = 0; j < in->cols; ++j) {
+                const double cp = in->coarse_colpos[j], fc = floor(cp), wx = cp - fc;
+                const int c0 = (int)fc, c1 = c0 + 1 < cc ? c0 + 1 : c0;
+                for (int64_t i = 0; i < in->rows; ++i) {
+                    const double rp = in->coarse_rowpos[i], fr = floor(rp), wy = rp - fr;
+                    const int r0 = (int)fr, r1 = r0 + 1 < cr ? r0 + 1 : r0;
+                    const double top = (1.0 - wx) * zc[(size_t)(r0 + cr * c0)] + wx * zc[(size_t)(r0 + cr * c1)];
+                    const double bot = (1.0 - wx) * zc[(size_t)(r1 + cr * c0)] + wx * zc[(size_t)(r1 + cr * c1)];
+                    const double z = in->fine_dtm[i + in->rows * j];
+                    elevd[(size_t)(i + in->rows * j)] = ((1.0 - wy) * top + wy * bot) - z;
+                    pkfac[(size_t)(i + in->rows * j)] = pow((293.0 - 0.0065 * z) / 293.0, 5.26);
+                }
+            }
+            if ((rc = upload(p, elevd.data(), N, &p->d_elevd, "elevd"))) return rc;
+            if ((rc = upload(p, pkfac.data(), N, &p->d_pkfac, "pkfac"))) return rc;
+            HIP_TRY(hipStreamSynchronize(p->stream));
+            if (in->tsteps > 0 && in->clim.pk) {
+                const int64_t cN = (int64_t)cr * cc;
+                cpk_sea.resize((size_t)(cN * in->tsteps));
+                for (int64_t k = 0; k < in->tsteps; ++k)
+                    for (int64_t q = 0; q < cN; ++q)
+                        cpk_sea[(size_t)(q + cN * k)] = in->clim.pk[q + cN * k] / pow((293.0 - 0.0065 * zc[(size_t)q]) / 293.0, 5.26);
+            }
+        }
     }
     int64_t nvalid = 0;
     for (int64_t c = 0; c < N; ++c) nvalid += !std::isnan(in->vegp.hgt[c]);
@@ -523,12 +561,13 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
             src[1] = in->coarse_relhum;                  // slot TF_ES
             src[2] = cwv.data();                         // slot TF_EA: v component
             src[3] = nullptr;                            // slot TF_TDEW unused
+            if (p->altcorrect) src[4] = cpk_sea.data();  // slot TF_PK: sea-level pressure
             src[8] = cwu.data();                         // slot TF_U2: u component
             for (int f = 0; f < 15 && T > 0; ++f)
                 if (src[f]) HIP_TRY(hipMemcpyAsync(p->d_force + f * slab, src[f], (size_t)(cN * T * 8), hipMemcpyHostToDevice, p->stream));
             if (T > 0) {
-                mcf::launch_mxtc_coarse(p->d_force, p->crows, p->ccols, (int)T, p->d_crowpos, p->d_ccolpos, p->rows, N,
-                                        p->d_mxtc, p->stream);
+                mcf::launch_mxtc_coarse(p->d_force, slab, p->crows, p->ccols, (int)T, p->d_crowpos, p->d_ccolpos, p->rows, N,
+                                        p->altcorrect, p->d_elevd, p->d_pkfac, p->d_mxtc, p->stream);
                 HIP_TRY(hipGetLastError());
             } else {
                 mcf::launch_fill(p->d_mxtc, N, -273.15, p->stream);
@@ -643,6 +682,7 @@ int mcf_plan_run_days(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot) {
         a.af_base = p->d_force;
         a.af_stride = (int64_t)p->crows * p->ccols * std::max<int64_t>(p->tsteps, 1);
         a.crows = p->crows; a.ccols = p->ccols;
+        a.altcorrect = p->altcorrect;
         a.dt = p->d_dt; a.windex = p->d_windex; a.mxtc = p->d_mxtc;
         a.force_step0 = 0;
     } else if (p->af) {

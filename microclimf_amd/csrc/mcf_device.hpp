@@ -94,6 +94,8 @@ enum CellField : int {
     CF_SINLAT, CF_COSLAT, CF_COSB, CF_SINB,
     // coarse array forcing: the cell's position in the coarse grid (rows, columns)
     CF_CROWPOS, CF_CCOLPOS,
+    // ... and its altitude correction: interpolated coarse elevation - own elevation; sea-level -> own-level pressure factor
+    CF_ELEVD, CF_PKFAC,
     CF_COUNT
 };
 constexpr int kCellDirs = 32;  // 24 horizon + 8 wind-shelter values follow the CF_ rows
@@ -496,6 +498,12 @@ struct CoarseTap {
 __device__ __forceinline__ double satvap_r(double tc, const MathK& K) {
     const double a = tc < 0.0 ? 21.875 : 17.27, b = tc < 0.0 ? 265.5 : 237.3;
     return 0.61078 * fexp(fdiv(a * tc, tc + b), K);
+}
+// `.lapserate` (R/internal.R:545-550): moist adiabatic lapse rate, K per m
+__device__ __forceinline__ double lapserate_r(double tc, double ea, double pk) {
+    const double rv = fdiv(0.622 * ea, pk - ea), tk = tc + 273.15;
+    return fdiv(9.8076 * (1.0 + fdiv(2501000.0 * rv, 287.0 * tk)),
+                1003.5 + fdiv(0.622 * 2501000.0 * 2501000.0 * rv, 287.0 * (tk * tk)));
 }
 __device__ __forceinline__ double dewpoint_r(double ea, double tc, const MathK& K) {
     if (!(ea > 0.0)) return -273.15;                       // log(0) = -Inf in R: 1/Inf - 273.15

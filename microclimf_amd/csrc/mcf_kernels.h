@@ -24,6 +24,7 @@ struct CellSetupArgs {
     const double *Smin, *Smax, *gref, *soilb, *Psie, *Vq, *Vm, *Mc, *rho, *slope, *aspect, *twi, *svfa;
     const double *lats, *lons;  // array forcing, else null
     const double *crowpos, *ccolpos;  // coarse array forcing: [rows], [cols]; else null
+    const double *elevd, *pkfac;      // coarse array forcing with altitude correction: [N]; else null
     int64_t rows;
     double lat, lon;
     double tfact, twi_mean;
@@ -66,6 +67,7 @@ struct SolveArgs {
     int64_t force_step0;    // first step of this launch inside the forcing slabs
     // coarse array forcing (af_base = [15][crows*ccols][tsteps], whole series resident): crows > 0
     int32_t crows, ccols;
+    int32_t altcorrect;     // 0, 1 (fixed lapse rate), 2 (humidity-dependent)
     // outputs: enabled variables are consecutive slabs [N][slot steps] from out_base;
     // out_sel packs, 4 bits per variable, the slab index of variable v (15 = not requested)
     double* out_base;
@@ -105,8 +107,10 @@ struct BioclimArgs {
 void launch_bioclim(const BioclimArgs& a, hipStream_t s);
 void launch_fill(double* p, int64_t n, double v, hipStream_t s);
 // per-cell maximum over time of the bilinearly interpolated coarse temperature [crows*ccols][tsteps]
-void launch_mxtc_coarse(const double* tc, int crows, int ccols, int tsteps, const double* rowpos, const double* colpos,
-                        int64_t rows, int64_t N, double* mx, hipStream_t s);
+// `force`: the 15 coarse slabs (stride elements apart); elevd / pkfac null without altitude correction
+void launch_mxtc_coarse(const double* force, int64_t stride, int crows, int ccols, int tsteps, const double* rowpos,
+                        const double* colpos, int64_t rows, int64_t N, int altcorrect, const double* elevd,
+                        const double* pkfac, double* mx, hipStream_t s);
 struct PackNcArgs {
     const double* src[10];   // first step of each variable, [rows, cols, steps] column-major
     double scale[10];

@@ -287,6 +287,8 @@ __global__ __launch_bounds__(256) void k_cell_setup(CellSetupArgs a) {
         put(CF_SINB, sin(B));
         put(CF_CROWPOS, a.crowpos ? a.crowpos[c % a.rows] : 0.0);
         put(CF_CCOLPOS, a.ccolpos ? a.ccolpos[c / a.rows] : 0.0);
+        put(CF_ELEVD, a.elevd ? a.elevd[c] : 0.0);
+        put(CF_PKFAC, a.pkfac ? a.pkfac[c] : 1.0);
     }
     // ---- canopy conductance operands for the saturated (degrees) cankCpp call, cpp:1425, 466-469
     {
@@ -366,17 +368,29 @@ __global__ __launch_bounds__(256) void k_mxtc(const double* __restrict__ tc, int
     mx[c] = m;
 }
 
-// coarse array forcing: the same maximum over the interpolated series (the coarse field is L2-resident)
-__global__ __launch_bounds__(256) void k_mxtc_coarse(const double* __restrict__ tc, int crows, int ccols, int nsteps,
-                                                     const double* __restrict__ rowpos, const double* __restrict__ colpos,
-                                                     int64_t rows, int64_t N, double* __restrict__ mx) {
+// coarse array forcing: the same maximum over the interpolated (and altitude-corrected) series; the coarse fields are
+// L2-resident
+__global__ __launch_bounds__(256) void k_mxtc_coarse(const double* __restrict__ force, int64_t stride, int crows, int ccols,
+                                                     int nsteps, const double* __restrict__ rowpos,
+                                                     const double* __restrict__ colpos, int64_t rows, int64_t N,
+                                                     int altcorrect, const double* __restrict__ elevd,
+                                                     const double* __restrict__ pkfac, double* __restrict__ mx) {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= N) return;
     const CoarseTap tap(rowpos[c % rows], colpos[c / rows], crows, ccols);
     const int64_t cN = (int64_t)crows * ccols;
+    MathK MK;
+    MK.set();
+    const double ed = altcorrect ? elevd[c] : 0.0, pf = altcorrect ? pkfac[c] : 1.0;
     double m = -273.15;
     for (int k = 0; k < nsteps; ++k) {
-        const double v = tap(tc + cN * k);
+        const double* q = force + cN * k;
+        double v = tap(q + (int64_t)TF_TC * stride);
+        if (altcorrect == 1) v += 0.005 * ed;
+        if (altcorrect == 2) {
+            const double ea = satvap_r(v, MK) * tap(q + (int64_t)TF_ES * stride) / 100.0;
+            v += lapserate_r(v, ea, tap(q + (int64_t)TF_PK * stride) * pf) * ed;
+        }
         if (v > m) m = v;
     }
     mx[c] = m;
@@ -568,10 +582,15 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
                 const CoarseTap tap(C(CF_CROWPOS), C(CF_CCOLPOS), a.crows, a.ccols);
                 const double* q = a.af_base + (int64_t)a.crows * a.ccols * kabs;
                 auto at = [&](int f) { return tap(q + (int64_t)f * a.af_stride); };
-                const double tc = at(TF_TC), rh = at(TF_ES), wu = at(TF_U2), wv = at(TF_EA);
+                double tc = at(TF_TC);
+                const double rh = at(TF_ES), wu = at(TF_U2), wv = at(TF_EA);
                 const double es = satvap_r(tc, MK), ea = es * rh / 100.0;
-                tv.v[TF_TC] = tc; tv.v[TF_ES] = es; tv.v[TF_EA] = ea; tv.v[TF_TDEW] = dewpoint_r(ea, tc, MK);
-                tv.v[TF_PK] = at(TF_PK); tv.v[TF_RSW] = at(TF_RSW); tv.v[TF_RDIF] = at(TF_RDIF); tv.v[TF_RLW] = at(TF_RLW);
+                const double pk = at(TF_PK) * C(CF_PKFAC);
+                tv.v[TF_ES] = es; tv.v[TF_EA] = ea; tv.v[TF_TDEW] = dewpoint_r(ea, tc, MK);   // from the uncorrected tc
+                if (a.altcorrect == 1) tc += 0.005 * C(CF_ELEVD);
+                if (a.altcorrect == 2) tc += lapserate_r(tc, ea, pk) * C(CF_ELEVD);
+                tv.v[TF_TC] = tc;
+                tv.v[TF_PK] = pk; tv.v[TF_RSW] = at(TF_RSW); tv.v[TF_RDIF] = at(TF_RDIF); tv.v[TF_RLW] = at(TF_RLW);
                 const double s2 = wu * wu + wv * wv;
                 tv.v[TF_U2] = s2 > 0.0 ? fsqrt(s2) : 0.0;
                 tv.v[TF_SOILMP] = at(TF_SOILMP); tv.v[TF_UMU] = at(TF_UMU);
@@ -1041,10 +1060,11 @@ void launch_pack_transpose(const double* src, int64_t rows, int64_t cols, int64_
     dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32), (unsigned)nsteps);
     hipLaunchKernelGGL(k_pack_transpose, grid, dim3(256), 0, s, src, rows, cols, scale, dst);
 }
-void launch_mxtc_coarse(const double* tc, int crows, int ccols, int tsteps, const double* rowpos, const double* colpos,
-                        int64_t rows, int64_t N, double* mx, hipStream_t s) {
-    hipLaunchKernelGGL(k_mxtc_coarse, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, tc, crows, ccols, tsteps, rowpos,
-                       colpos, rows, N, mx);
+void launch_mxtc_coarse(const double* force, int64_t stride, int crows, int ccols, int tsteps, const double* rowpos,
+                        const double* colpos, int64_t rows, int64_t N, int altcorrect, const double* elevd,
+                        const double* pkfac, double* mx, hipStream_t s) {
+    hipLaunchKernelGGL(k_mxtc_coarse, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, force, stride, crows, ccols, tsteps,
+                       rowpos, colpos, rows, N, altcorrect, elevd, pkfac, mx);
 }
 void launch_fill(double* p, int64_t n, double v, hipStream_t s) {
     if (n <= 0) return;

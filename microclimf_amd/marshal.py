@@ -90,6 +90,10 @@ def marshal(obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Mapping,
         gi.coarse_colpos = m._f64(coarse["colpos"], (Cc,), "coarse$colpos")
         gi.coarse_relhum = m._f64(climdata["relhum"], cshape, "climdata$relhum")
         gi.coarse_winddir = m._f64(climdata["winddir"], cshape, "climdata$winddir")
+        gi.coarse_altcorrect = int(coarse.get("altcorrect", 0))
+        if gi.coarse_altcorrect:
+            gi.coarse_dtm = m._f64(coarse["dtmc"], cshape[:2], "coarse$dtmc")
+            gi.fine_dtm = m._f64(coarse["dtm"], (R, Cc), "coarse$dtm")
     gi.obstime.year = m._i32(obstime["year"], T, "obstime$year")
     gi.obstime.month = m._i32(obstime["month"], T, "obstime$month")
     gi.obstime.day = m._i32(obstime["day"], T, "obstime$day")

@@ -35,7 +35,7 @@ def test_struct_layout_matches_header():
     assert C.sizeof(_abi.Pointm) == 8 * 8
     assert C.sizeof(_abi.Vegp) == 10 * 8
     assert C.sizeof(_abi.Soilc) == 15 * 8
-    assert C.sizeof(_abi.GridInputs) == 3 * 8 + 8 + (4 + 10 + 8 + 10 + 15) * 8 + 2 * 8 + 2 * 8 + 2 * 8 + 8 + 4 * 8
+    assert C.sizeof(_abi.GridInputs) == 3 * 8 + 8 + (4 + 10 + 8 + 10 + 15) * 8 + 2 * 8 + 2 * 8 + 2 * 8 + 8 + 4 * 8 + 8 + 2 * 8
 
 
 def test_ctypes_structs_agree_with_the_compiled_header(tmp_path):
@@ -43,7 +43,8 @@ def test_ctypes_structs_agree_with_the_compiled_header(tmp_path):
     import subprocess
     root = Path(__file__).resolve().parents[1]
     probes = {"mcf_grid_inputs": (_abi.GridInputs, ["tsteps", "array_forcing", "veg_layers", "clim", "soilc", "lat", "lats",
-                                                    "lyr_ed", "coarse_rows", "coarse_cols", "coarse_rowpos", "coarse_winddir"]),
+                                                    "lyr_ed", "coarse_rows", "coarse_cols", "coarse_rowpos", "coarse_winddir",
+                                                    "coarse_altcorrect", "coarse_dtm", "fine_dtm"]),
               "mcf_options": (_abi.Options, ["tfact", "complete", "out", "device", "cells_per_block"]),
               "mcf_nc_spec": (_abi.NcSpec, ["nsteps", "east", "crs_wkt", "reqhgt", "vars", "reference_puts_only"])}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "mcf.h"', 'int main(void) {']

@@ -89,3 +89,24 @@ def test_random_coarse_configurations(oracle, i):
         cp = np.clip(cp * 0.5, 0, cc - 1)
     got = runmicro2Cpp_coarse(*[a[k] for k in ARGS], rowpos=rp, colpos=cp, days_per_chunk=int(rng.choice([0, 1])) if reqhgt >= 0 else 0)
     compare(got, oracle.run_grid(**expanded(a, rp, cp), array_forcing=True))
+
+
+@pytest.mark.parametrize("altcorrect", [1, 2])
+@pytest.mark.parametrize("rows,cols,cr,cc", [(33, 27, 3, 4), (40, 40, 1, 2)])
+def test_altitude_correction_is_fused_too(oracle, altcorrect, rows, cols, cr, cc):
+    """`.runmodel2Cpp`'s altcorrect (R/internal.R:1233-1251): pressure through sea level, temperature by a fixed or a
+    humidity-dependent lapse rate times the elevation difference to the (interpolated) climate cell; es / ea / tdew stay
+    those of the uncorrected temperature"""
+    a, rp, cp = synthetic.coarse_workload(rows, cols, 72, cr, cc, reqhgt=0.05, variety=True, start_doy=150, na_frac=0.02)
+    _, _, z = synthetic.rasters(rows, cols)
+    z = 300.0 + 8.0 * (z - np.nanmean(z))                                  # a few hundred metres of relief
+    rng = np.random.default_rng(3)
+    zc = 350.0 + 200.0 * rng.random((cr, cc))
+    zc[0, 0] = np.nan                                                       # dtmc[is.na(dtmc)] <- 0
+    got = runmicro2Cpp_coarse(*[a[k] for k in ARGS], rowpos=rp, colpos=cp, altcorrect=altcorrect, dtmc=zc, dtm=z)
+    clim, pm = CO.expand(a["climdata"], a["pointm"], rp, cp, altcorrect, zc, z)
+    b = dict(a)
+    b.update(climdata=clim, pointm=pm)
+    compare(got, oracle.run_grid(**b, array_forcing=True))
+    plain = runmicro2Cpp_coarse(*[a[k] for k in ARGS], rowpos=rp, colpos=cp)
+    assert np.nanmax(np.abs(got["Tz"] - plain["Tz"])) > 0.3                  # the correction does something
