@@ -140,7 +140,7 @@ typedef struct mcf_grid_inputs {
      * coarse_relhum, coarse_winddir and pointm.{soilm,G,umu,kp,muGp,dtrp} are [coarse_rows, coarse_cols, tsteps]; the
      * solver interpolates them bilinearly per cell-step and derives es, ea, tdew (.satvap, .dewpoint after
      * interpolating temp and relhum), wind speed (from interpolated u, v components) and the raster-mean wind
-     * direction exactly where `.runmodel2Cpp` does (altcorrect = 0).  clim.es, ea, tdew, winddir are ignored.
+     * direction exactly where `.runmodel2Cpp` does.  clim.es, ea, tdew, winddir are ignored.
      * coarse_rowpos[i] / coarse_colpos[j]: position of raster row i / column j in units of coarse rows / columns,
      * 0 = centre of the first coarse row / column, clamped by the caller to [0, coarse_rows-1] / [0, coarse_cols-1]
      * (edge replication).  reqhgt < 0 needs complete = 1 in this mode. */

@@ -420,8 +420,9 @@ def runpointmodela(climarray: Mapping, obstime: Mapping, reqhgt: float, dtm: Map
 def prepare_grid_inputs_array(micropointa: Sequence, crows: int, ccols: int, reqhgt: float, vegp: Mapping, soilc: Mapping,
                               dtm: Mapping, *, lats, lons, pai_a=None, out: Sequence = (1,) * 10, slr=None, apr=None,
                               hor=None, twi=None, wsa=None, svf=None, device: int = 0) -> dict:
-    """What `.runmodel2Cpp` / `.runmodel4Cpp` prepare (R/internal.R:1175-1343), altcorrect = 0, with the climate and
-    point-model variables left on the coarse grid: the solver interpolates them (array_forcing == 2).  `lats`, `lons`:
+    """What `.runmodel2Cpp` / `.runmodel4Cpp` prepare (R/internal.R:1175-1343) with the climate and
+    point-model variables left on the coarse grid: the solver interpolates them (array_forcing == 2; the altitude
+    correction is applied there too, see runmicro_array).  `lats`, `lons`:
     [rows, cols] of the fine raster (`.latslonsfromr(dtm)`).  Cells of the coarse grid without a micropoint are not
     supported (the reference fills them with NA and lets `resample` look around them)."""
     if any(m is None for m in micropointa):
@@ -447,8 +448,9 @@ def prepare_grid_inputs_array(micropointa: Sequence, crows: int, ccols: int, req
 
 
 def runmicro_array(micropointa: Sequence, crows: int, ccols: int, reqhgt: float, vegp: Mapping, soilc: Mapping, dtm: Mapping,
-                   *, lats, lons, tfact: float = 1.5, device: int = 0, **kw) -> dict:
-    """`runmicro()` for a list of micropoints from `runpointmodela` (array weather, no snow, altcorrect = 0)."""
+                   *, lats, lons, tfact: float = 1.5, altcorrect: int = 0, dtmc=None, device: int = 0, **kw) -> dict:
+    """`runmicro()` for a list of micropoints from `runpointmodela` (array weather, no snow).  `altcorrect` 1 / 2 with
+    `dtmc` [crows, ccols], the elevations of the climate cells: the lapse-rate correction of R/internal.R:1233-1251."""
     if reqhgt < 0:
         raise ValueError("coarse array forcing below ground needs the per-cell point-model series: not mirrored")
     a = prepare_grid_inputs_array(micropointa, crows, ccols, reqhgt, vegp, soilc, dtm, lats=lats, lons=lons, device=device, **kw)
@@ -456,6 +458,8 @@ def runmicro_array(micropointa: Sequence, crows: int, ccols: int, reqhgt: float,
     dfsel = a.pop("dfsel", None)
     R, Cc = a["vegp"]["hgt"].shape[:2]
     coarse = {"rowpos": api.coarse_positions(R, crows), "colpos": api.coarse_positions(Cc, ccols)}
+    if altcorrect:
+        coarse.update(altcorrect=int(altcorrect), dtmc=dtmc, dtm=cleanvars(vegp, soilc, dtm["z"])[2])
     order = ("obstime", "climdata", "pointm", "vegp", "soilc", "reqhgt", "zref", "lat", "lon", "Sminp", "Smaxp", "tfact",
              "complete", "mat", "out")
     fn = "mcf_runmicro2" if dfsel is None else "mcf_runmicro4"
