@@ -236,6 +236,19 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # second roof ("both fractions must be reported"): fp64 VALU issue slots.  Instructions per cell-step
+        # come from the committed PMC summary of this kernel (SQ_INSTS_VALU); the peak is one wave-instruction per
+        # 4 cycles per SIMD at the 2.4 GHz nominal clock (256 CUs x 4 SIMDs)
+        valu = None
+        pf = ROOT / "profiles" / "r01h_pmc_summary.json"
+        if pf.exists() and not coarse and not af:
+            try:
+                pj = json.loads(pf.read_text())
+                per_cs = pj["per_launch_mean"]["SQ_INSTS_VALU"] * 64.0 / (1038103 * 120)
+                valu = {"insts_per_cell_step": per_cs, "frac_of_issue_peak": per_cs * (value / world) / 64.0 / (1024 * 2.4e9 / 4),
+                        "busy_fraction_measured": pj.get("valu_busy_fraction"), "source": "profiles/r01h_pmc_summary.json"}
+            except Exception:
+                valu = None
         line = {
             "metric": "cell-steps/s", "value": value, "unit": "cell-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -263,6 +276,7 @@ def main():
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": "k_solve", "avg_launch_ms": avg_ms, "launches": int(klaunches),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "valu": valu,
                          "note": "fp64 VALU (software transcendentals) is the binding roof, see DESIGN.md"},
         }
         if cpu_first is not None:
