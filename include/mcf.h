@@ -306,6 +306,13 @@ int mcf_runbioclim1(const mcf_grid_inputs *in, const mcf_options *opt, const mcf
                     mcf_bioclim_out *out);
 int mcf_runbioclim2(const mcf_grid_inputs *in, const mcf_options *opt, const mcf_bioclim_sel *sel,
                     mcf_bioclim_out *out);
+/* The time-varying-vegetation variants _microclimf_runbioclim3Cpp / 4Cpp (src/microclimfCpp.cpp:3620-3658 /
+ * 3660-3700): vegetation arrays [rows, cols, 14] (deeper arrays: the first 14 layers) with the reference's fixed
+ * dfsel of fourteen one-day layers; steps past the 336th belong to no layer and stay NA there too. */
+int mcf_runbioclim3(const mcf_grid_inputs *in, const mcf_options *opt, const mcf_bioclim_sel *sel,
+                    mcf_bioclim_out *out);
+int mcf_runbioclim4(const mcf_grid_inputs *in, const mcf_options *opt, const mcf_bioclim_sel *sel,
+                    mcf_bioclim_out *out);
 
 /* ---- terrain pre-compute (the solver's terrain inputs, built on the device) ------
  * Restates the R-side arithmetic of the reference's marshaller (R/internal.R):

@@ -159,7 +159,7 @@ EXPORTS = (
     "mcf_plan_belowground", "mcf_plan_sync", "mcf_plan_fetch", "mcf_plan_fetch_packed", "mcf_plan_slot_ptr",
     "mcf_plan_timer_start", "mcf_plan_timer_stop", "mcf_plan_kernel_timing",
     "mcf_plan_kernel_stats", "mcf_plan_valid_cells", "mcf_plan_bytes", "mcf_selftest_math",
-    "mcf_precompute_terrain", "mcf_runbioclim1", "mcf_runbioclim2",
+    "mcf_precompute_terrain", "mcf_runbioclim1", "mcf_runbioclim2", "mcf_runbioclim3", "mcf_runbioclim4",
     "mcf_snowenv_from_name", "mcf_gridmodelsnow1", "mcf_gridmodelsnow2", "mcf_gridmicrosnow1",
     "mcf_gridmicrosnow2", "mcf_snowmodel1", "mcf_applycpp3",
     "mcf_snowplan_create", "mcf_snowplan_destroy", "mcf_snowplan_chunks", "mcf_snowplan_surface",
@@ -233,7 +233,7 @@ def load() -> C.CDLL:
     lib.mcf_plan_bytes.argtypes = [P]
     lib.mcf_selftest_math.restype = C.c_int
     lib.mcf_selftest_math.argtypes = [C.c_int32, c_double_p, c_double_p, c_double_p, C.c_int64, C.c_int32]
-    for fn in (lib.mcf_runbioclim1, lib.mcf_runbioclim2):
+    for fn in (lib.mcf_runbioclim1, lib.mcf_runbioclim2, lib.mcf_runbioclim3, lib.mcf_runbioclim4):
         fn.restype = C.c_int
         fn.argtypes = [GI, OP, C.POINTER(BioclimSel), C.POINTER(BioclimOut)]
     lib.mcf_snowenv_from_name.restype = C.c_int32

@@ -102,11 +102,14 @@ def runmicro4Cpp(dfsel: Mapping, obstime: Mapping, climdata: Mapping, pointm: Ma
                 Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block, dfsel)
 
 
+BIOCLIM_DFSEL = {"lyr": np.arange(1, 15), "st": np.arange(14) * 24, "ed": np.arange(14) * 24 + 23}   # cpp:3634-3646
+
+
 def _bioclim(fn_name, array_forcing, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp,
-             Smaxp, tfact, mat, out, wetq, dryq, hotq, colq, air, device):
+             Smaxp, tfact, mat, out, wetq, dryq, hotq, colq, air, device, layered=False):
     lib = _abi.load()
     m = marshal(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact, True, mat,
-                [1] * 10, array_forcing, device)
+                [1] * 10, array_forcing, device, dfsel=BIOCLIM_DFSEL if layered else None)
     sel = _abi.BioclimSel()
     keep = []
     for name, q in (("wet", wetq), ("dry", dryq), ("hot", hotq), ("col", colq)):
@@ -251,3 +254,18 @@ class Plan:
         ms, n = C.c_double(), C.c_int64()
         _abi.check(self._lib.mcf_plan_kernel_stats(self._p, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+def runbioclim3Cpp(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact, mat, out,
+                   wetq, dryq, hotq, colq, air, *, device: int = 0) -> dict:
+    """Drop-in for runbioclim3Cpp (src/microclimfCpp.cpp:3620-3658): vegetation arrays [rows, cols, 14], one layer per
+    selected day (twelve monthly days, the hottest, the coldest); steps past the 336th stay NA as in the reference."""
+    return _bioclim("mcf_runbioclim3", False, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon,
+                    Sminp, Smaxp, tfact, mat, out, wetq, dryq, hotq, colq, air, device, True)
+
+
+def runbioclim4Cpp(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons, Sminp, Smaxp, tfact, mat, out,
+                   wetq, dryq, hotq, colq, air, *, device: int = 0) -> dict:
+    """Drop-in for runbioclim4Cpp (src/microclimfCpp.cpp:3660-3700), array climate."""
+    return _bioclim("mcf_runbioclim4", True, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons,
+                    Sminp, Smaxp, tfact, mat, out, wetq, dryq, hotq, colq, air, device, True)

@@ -1015,9 +1015,22 @@ int mcf_selftest_math(int32_t kind, const double* x, const double* y, double* ou
     return MCF_OK;
 }
 
-static int run_bioclim(const mcf_grid_inputs* in, const mcf_options* opt_in, const mcf_bioclim_sel* sel,
-                       mcf_bioclim_out* out, int want_af) {
-    if (!sel || !out) return fail(MCF_ERR_ARG, "null bioclim argument");
+static int run_bioclim(const mcf_grid_inputs* in_caller, const mcf_options* opt_in, const mcf_bioclim_sel* sel,
+                       mcf_bioclim_out* out, int want_af, int layered = 0) {
+    if (!sel || !out || !in_caller) return fail(MCF_ERR_ARG, "null bioclim argument");
+    // runbioclim3Cpp / 4Cpp (cpp:3620-3658 / 3660-3700): vegetation arrays [rows, cols, >= 14] and a fixed dfsel of
+    // fourteen one-day layers — the twelve monthly days, the hottest and the coldest day; later steps (the quarter
+    // days) belong to no layer and stay NA, as in the reference
+    static const int32_t kSt[14] = {0, 24, 48, 72, 96, 120, 144, 168, 192, 216, 240, 264, 288, 312};
+    static const int32_t kEd[14] = {23, 47, 71, 95, 119, 143, 167, 191, 215, 239, 263, 287, 311, 335};
+    mcf_grid_inputs in_l;
+    if (layered) {
+        in_l = *in_caller;
+        in_l.veg_layers = 14;
+        in_l.lyr_st = kSt;
+        in_l.lyr_ed = kEd;
+    }
+    const mcf_grid_inputs* in = layered ? &in_l : in_caller;
     int rc = check_inputs(in, opt_in);
     if (rc) return rc;
     if ((in->array_forcing != 0) != (want_af != 0)) return fail(MCF_ERR_ARG, "forcing geometry does not match the entry point");
@@ -1070,6 +1083,12 @@ static int run_bioclim(const mcf_grid_inputs* in, const mcf_options* opt_in, con
 }
 int mcf_runbioclim1(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_bioclim_sel* sel, mcf_bioclim_out* out) {
     return run_bioclim(in, opt, sel, out, 0);
+}
+int mcf_runbioclim3(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_bioclim_sel* sel, mcf_bioclim_out* out) {
+    return run_bioclim(in, opt, sel, out, 0, 1);
+}
+int mcf_runbioclim4(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_bioclim_sel* sel, mcf_bioclim_out* out) {
+    return run_bioclim(in, opt, sel, out, 1, 1);
 }
 int mcf_runbioclim2(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_bioclim_sel* sel, mcf_bioclim_out* out) {
     return run_bioclim(in, opt, sel, out, 1);

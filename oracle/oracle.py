@@ -103,7 +103,7 @@ def satvap(tc):
 
 
 def run_bioclim(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact, mat,
-                out, wetq, dryq, hotq, colq, air, array_forcing=False):
+                out, wetq, dryq, hotq, colq, air, array_forcing=False, dfsel=None):
     """Oracle for runbioclim1Cpp / runbioclim2Cpp (cpp:3563-3616): the grid oracle with the reference's
     output mask, then runbioclimCpp's reductions cell by cell."""
     lib = load()
@@ -111,7 +111,7 @@ def run_bioclim(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, 
     mask[0 if air else 1] = 1
     mask[3] = 1
     res = run_grid(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact,
-                   True, mat, mask, array_forcing)
+                   True, mat, mask, array_forcing, dfsel=dfsel)
     tz = res["Tz" if air else "tleaf"]
     sm = res["soilm"]
     R, Cc, T = tz.shape

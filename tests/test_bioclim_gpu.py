@@ -57,3 +57,28 @@ def test_runbioclim_rejects_short_series():
         a.pop(k)
     with pytest.raises(McfError, match="336"):
         runbioclim1Cpp(**a, out=[1] * 19, wetq=[0], dryq=[0], hotq=[0], colq=[0], air=True)
+
+
+@pytest.mark.parametrize("af", [False, True])
+def test_runbioclim3_and_4_layered_vegetation(oracle, af):
+    """runbioclim3Cpp / 4Cpp: fourteen one-day vegetation layers (cpp:3634-3646); the quarter days lie past the last
+    layer, so the quarter statistics see NA exactly as in the reference"""
+    from microclimf_amd.api import BIOCLIM_DFSEL, runbioclim3Cpp, runbioclim4Cpp
+    a = synthetic.workload(9, 6, T, reqhgt=0.05, variety=True, start_doy=100, array_forcing=af)
+    a["vegp"]["hgt"][2, 1] = np.nan
+    a = synthetic.layered(a, 14)
+    a.pop("dfsel")
+    for k in ("complete", "out"):
+        a.pop(k)
+    wq, dq, hq, cq = quarters()
+    out = [1] * 19
+    want = oracle.run_bioclim(**a, out=out, wetq=wq, dryq=dq, hotq=hq, colq=cq, air=True, array_forcing=af, dfsel=BIOCLIM_DFSEL)
+    if af:
+        a["lats"], a["lons"] = a.pop("lat"), a.pop("lon")
+        got = runbioclim4Cpp(**a, out=out, wetq=wq, dryq=dq, hotq=hq, colq=cq, air=True)
+    else:
+        got = runbioclim3Cpp(**a, out=out, wetq=wq, dryq=dq, hotq=hq, colq=cq, air=True)
+    for k, w in want.items():
+        assert np.array_equal(np.isnan(got[k]), np.isnan(w)), k
+        np.testing.assert_allclose(got[k], w, rtol=1e-9, atol=1e-9, err_msg=k)
+    assert np.isfinite(got["bio1"][0, 0]) and np.isnan(got["bio1"][2, 1])
