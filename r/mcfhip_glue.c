@@ -178,7 +178,7 @@ SEXP mcfhip_runmicro4(SEXP dfsel, SEXP obstime, SEXP climdata, SEXP pointm, SEXP
 
 /* _microclimf_runbioclim1Cpp / 2Cpp (src/microclimfCpp.cpp:3563-3616): 19 arguments; returns the list
  * bio1..bio19 (requested ones) of [rows, cols] matrices.  Solver and reductions stay on the device. */
-static SEXP run_bioclim(int array_forcing, SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc,
+static SEXP run_bioclim(int array_forcing, int layered, SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc,
                         SEXP reqhgt, SEXP zref, SEXP lat, SEXP lon, SEXP Sminp, SEXP Smaxp, SEXP tfact, SEXP mat,
                         SEXP out, SEXP wetq, SEXP dryq, SEXP hotq, SEXP colq, SEXP air) {
     int np = 0;
@@ -214,7 +214,9 @@ static SEXP run_bioclim(int array_forcing, SEXP obstime, SEXP climdata, SEXP poi
         ++k;
     }
     setAttrib(ans, R_NamesSymbol, nms);
-    int rc = array_forcing ? mcf_runbioclim2(&in, &opt, &sel, &bo) : mcf_runbioclim1(&in, &opt, &sel, &bo);
+    /* layered (runbioclim3Cpp / 4Cpp): vegp holds [rows, cols, 14] arrays; the library installs the fixed dfsel */
+    int rc = layered ? (array_forcing ? mcf_runbioclim4(&in, &opt, &sel, &bo) : mcf_runbioclim3(&in, &opt, &sel, &bo))
+                     : (array_forcing ? mcf_runbioclim2(&in, &opt, &sel, &bo) : mcf_runbioclim1(&in, &opt, &sel, &bo));
     if (rc != MCF_OK) {
         char msg[600];
         strncpy(msg, mcf_last_error(), sizeof msg - 1); msg[sizeof msg - 1] = 0;
@@ -227,13 +229,26 @@ static SEXP run_bioclim(int array_forcing, SEXP obstime, SEXP climdata, SEXP poi
 SEXP mcfhip_runbioclim1(SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc, SEXP reqhgt, SEXP zref,
                         SEXP lat, SEXP lon, SEXP Sminp, SEXP Smaxp, SEXP tfact, SEXP mat, SEXP out, SEXP wetq,
                         SEXP dryq, SEXP hotq, SEXP colq, SEXP air) {
-    return run_bioclim(0, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact, mat, out,
+    return run_bioclim(0, 0, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact, mat, out,
                        wetq, dryq, hotq, colq, air);
 }
 SEXP mcfhip_runbioclim2(SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc, SEXP reqhgt, SEXP zref,
                         SEXP lats, SEXP lons, SEXP Sminp, SEXP Smaxp, SEXP tfact, SEXP mat, SEXP out, SEXP wetq,
                         SEXP dryq, SEXP hotq, SEXP colq, SEXP air) {
-    return run_bioclim(1, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons, Sminp, Smaxp, tfact, mat,
+    return run_bioclim(1, 0, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons, Sminp, Smaxp, tfact, mat,
+                       out, wetq, dryq, hotq, colq, air);
+}
+/* _microclimf_runbioclim3Cpp / 4Cpp (src/microclimfCpp.cpp:3620-3700): the same with 14-layer vegetation */
+SEXP mcfhip_runbioclim3(SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc, SEXP reqhgt, SEXP zref,
+                        SEXP lat, SEXP lon, SEXP Sminp, SEXP Smaxp, SEXP tfact, SEXP mat, SEXP out, SEXP wetq,
+                        SEXP dryq, SEXP hotq, SEXP colq, SEXP air) {
+    return run_bioclim(0, 1, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact, mat, out,
+                       wetq, dryq, hotq, colq, air);
+}
+SEXP mcfhip_runbioclim4(SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP soilc, SEXP reqhgt, SEXP zref,
+                        SEXP lats, SEXP lons, SEXP Sminp, SEXP Smaxp, SEXP tfact, SEXP mat, SEXP out, SEXP wetq,
+                        SEXP dryq, SEXP hotq, SEXP colq, SEXP air) {
+    return run_bioclim(1, 1, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons, Sminp, Smaxp, tfact, mat,
                        out, wetq, dryq, hotq, colq, air);
 }
 
@@ -469,6 +484,8 @@ static const R_CallMethodDef CallEntries[] = {
     {"mcfhip_runmicro4", (DL_FUNC)&mcfhip_runmicro4, 16},
     {"mcfhip_runbioclim1", (DL_FUNC)&mcfhip_runbioclim1, 19},
     {"mcfhip_runbioclim2", (DL_FUNC)&mcfhip_runbioclim2, 19},
+    {"mcfhip_runbioclim3", (DL_FUNC)&mcfhip_runbioclim3, 19},
+    {"mcfhip_runbioclim4", (DL_FUNC)&mcfhip_runbioclim4, 19},
     {"mcfhip_gridmodelsnow1", (DL_FUNC)&mcfhip_gridmodelsnow1, 6},
     {"mcfhip_gridmodelsnow2", (DL_FUNC)&mcfhip_gridmodelsnow2, 6},
     {"mcfhip_gridmicrosnow1", (DL_FUNC)&mcfhip_gridmicrosnow1, 9},

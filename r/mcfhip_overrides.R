@@ -29,8 +29,8 @@ mcfhip_enable <- function(glue = "r/mcfhip_glue.so") {
                   Sminp, Smaxp, tfact, complete, mat, out)
     .Call("mcfhip_runmicro4", dfsel, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons,
           Sminp, Smaxp, tfact, complete, mat, out)
-  # fused bioclim sink (R/RcppExports.R runbioclim1Cpp / runbioclim2Cpp, src/microclimfCpp.cpp:3563-3616)
-  for (nm in c("runbioclim1Cpp", "runbioclim2Cpp")) local({
+  # fused bioclim sink (R/RcppExports.R runbioclim1Cpp .. runbioclim4Cpp, src/microclimfCpp.cpp:3563-3700)
+  for (nm in c("runbioclim1Cpp", "runbioclim2Cpp", "runbioclim3Cpp", "runbioclim4Cpp")) local({
     sym <- paste0("mcfhip_", sub("Cpp$", "", nm))
     utils::assignInNamespace(nm, function(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, long, Sminp,
                                           Smaxp, tfact, mat, out, wetq, dryq, hotq, colq, air)
