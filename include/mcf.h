@@ -521,6 +521,18 @@ int mcf_pointmprocess(int64_t n, const double *windspeed, const double *tc, cons
                       double *DDp, double *T0p, double *dtrp);
 int mcf_weatherhgt(int64_t n, const mcf_obstime *obstime, const mcf_point_weather *weather, double zin, double uzin,
                    double zout, double lat, double lon, double *temp, double *relhum, double *windspeed);
+/* _microclimf_pointmodelsnow (src/microclimfCpp.cpp:4000-4169; called by `.snowmodel1`, R/internal.R:2536): the snow
+ * branch's point model.  vegp = (pai, hgt, ltra, clump), other = (slope, aspect, lat, lon, zref, initial depth,
+ * initial age); snowenv: MCF_SNOWENV_*; the reference's defaults are tol = 0.5, maxiter = 100.  Outputs: [n] each,
+ * sdepc / sdepg [n + 1] (the depth after the last step is kept, as in the reference).  Host code. */
+typedef struct mcf_pointsnow_out {
+    double *Tc, *Tg, *sdepc, *sdepg, *sdenc, *sdeng, *G, *RswabsG, *RlwabsG, *tr, *umu, *sublmelt, *tempmelt, *rainmelt,
+        *sstemp;
+    double mxdif;
+    int32_t iters;
+} mcf_pointsnow_out;
+int mcf_pointmodelsnow(int64_t n, const mcf_obstime *obstime, const mcf_point_weather *weather, const double *vegp,
+                       const double *other, int32_t snowenv, double tol, double maxiter, mcf_pointsnow_out *out);
 /* manCpp (src/microclimfCpp.cpp:597-627): circular trailing mean, via daily means for windows beyond 48 steps. */
 int mcf_man(int64_t n, const double *x, int32_t window, double *out);
 

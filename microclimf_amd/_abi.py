@@ -139,6 +139,14 @@ class NcSpec(C.Structure):
                 ("vars", C.c_int32 * 10), ("reference_puts_only", C.c_int32)]
 
 
+POINTSNOW_FIELDS = ("Tc", "Tg", "sdepc", "sdepg", "sdenc", "sdeng", "G", "RswabsG", "RlwabsG", "tr", "umu", "sublmelt",
+                    "tempmelt", "rainmelt", "sstemp")
+
+
+class PointSnowOut(C.Structure):
+    _fields_ = [(k, c_double_p) for k in POINTSNOW_FIELDS] + [("mxdif", C.c_double), ("iters", C.c_int32)]
+
+
 class SnowDriverIn(C.Structure):
     _fields_ = [("base", SnowInputs), ("dtm", c_double_p), ("res", C.c_double), ("tfact", C.c_double),
                 ("chunk_steps", C.c_int32), ("reserved", C.c_int32)]
@@ -164,7 +172,7 @@ EXPORTS = (
     "mcf_gridmicrosnow2", "mcf_snowmodel1", "mcf_applycpp3",
     "mcf_snowplan_create", "mcf_snowplan_destroy", "mcf_snowplan_chunks", "mcf_snowplan_surface",
     "mcf_snowplan_surface_partial", "mcf_snowplan_prepare_chunk", "mcf_snowplan_run_chunk",
-    "mcf_bigleaf", "mcf_soilm", "mcf_pointmprocess", "mcf_weatherhgt", "mcf_man",
+    "mcf_bigleaf", "mcf_soilm", "mcf_pointmprocess", "mcf_weatherhgt", "mcf_man", "mcf_pointmodelsnow",
     "mcf_nc_create", "mcf_nc_write_host", "mcf_nc_write_plan", "mcf_nc_close",
     "mcf_flowacc", "mcf_topidx",
 )
@@ -255,6 +263,9 @@ def load() -> C.CDLL:
     lib.mcf_pointmprocess.argtypes = [C.c_int64] + [c_double_p] * 7 + [C.c_double] * 7 + [c_double_p] * 6
     lib.mcf_weatherhgt.restype = C.c_int
     lib.mcf_weatherhgt.argtypes = [C.c_int64, OT, PW] + [C.c_double] * 5 + [c_double_p] * 3
+    lib.mcf_pointmodelsnow.restype = C.c_int
+    lib.mcf_pointmodelsnow.argtypes = [C.c_int64, C.POINTER(Obstime), C.POINTER(PointWeather), c_double_p, c_double_p,
+                                       C.c_int32, C.c_double, C.c_double, C.POINTER(PointSnowOut)]
     lib.mcf_man.restype = C.c_int
     lib.mcf_man.argtypes = [C.c_int64, c_double_p, C.c_int32, c_double_p]
     lib.mcf_flowacc.restype = C.c_int

@@ -654,3 +654,247 @@ extern "C" int mcf_man(int64_t n64, const double* x, int32_t window, double* out
     for (int i = 0; i < m; ++i) out[i] = z[(size_t)i];
     return MCF_OK;
 }
+
+// =====================================================================================================================
+// pointmodelsnow, cpp:4000-4169 (with canopysnowintCpp 3713-3739, snowdenp 3741-3749, snowalbCpp 3752-3771, radoneB
+// 3773-3833, snowoneB 3835-3972, GFluxCppsnow 3974-3997): the snow branch's point model — one snowpack under a canopy,
+// stepped through the series and relaxed until canopy and ground snow temperatures settle.  It feeds `.snowmodel1`
+// (R/internal.R:2536-2541) with Gp, Tc, RswabsG, RlwabsG, umu and the pack depth that `.sortl` averages vegetation by.
+// Host code, as in the reference: a serial recurrence in time inside an outer relaxation.
+// =====================================================================================================================
+namespace {
+
+struct SnowDen { double a, b, c, d; };
+SnowDen snow_density_params(int env) {                       // snowdenp
+    static const SnowDen tab[5] = {{0.5975, 0.2237, 0.0012, 0.0038}, {0.5979, 0.2578, 0.001, 0.0038},
+                                   {0.594, 0.2332, 0.0016, 0.0031}, {0.363, 0.2425, 0.0029, 0.0049}, {0.217, 0.217, 0.0, 0.0}};
+    return tab[(env < 0 || env > 4) ? 0 : env];
+}
+double snow_density(const SnowDen& p, double depth, double age_hours) {
+    return ((p.a - p.b) * (1.0 - exp(-p.c * depth / 100.0 - p.d * age_hours / 24.0)) + p.b) * 1000.0;
+}
+// the age clock counts HOURS since snowfall; `hs / 24` is an integer division in the reference (whole days)
+void snow_albedo(const double* prec, size_t n, Vec& alb) {
+    int hs = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (i > 0) hs = prec[i] > 0 ? 0 : hs + 1;
+        double a = (-9.8740 * log((double)(hs / 24)) + 78.3434) / 100.0;
+        alb[i] = a > 0.95 ? 0.95 : a < 0.1 ? 0.1 : a;
+    }
+}
+double canopy_snow_interception(double hgt, double pai, double uf, double prec, double tc, double Li) {
+    if (hgt < 0.001) hgt = 0.001;
+    if (pai < 0.001) pai = 0.001;
+    const double Be = sqrt(0.003 + (0.2 * pai) / 2.0), uh = uf / Be;
+    const double Lc = pow(0.25 * (pai / hgt), -1.0), Lm = 2.0 * pow(Be, 3.0) * Lc, k1 = Be / Lm;
+    double uzm = (uh / (hgt * k1)) * (1 - exp(-k1 * hgt));
+    if (uzm < uf) uzm = uf;
+    const double rhos = 67.92 + 51.25 * exp(tc / 2.59);
+    const double Lstr = 6.2 * (0.26 + 46 / rhos) * pai;
+    const double kc = 1.0 / (2.0 * cos(atan(uzm / 0.8)));
+    const double Cp = 1.0 - exp(-kc * pai);
+    const double cis = (Lstr - Li) * (1.0 - exp(-(Cp / Lstr) * prec)) * 0.678;
+    return cis > prec ? prec : cis;
+}
+
+struct SnowStepIn {
+    int year, month, day;
+    double hour, tc, ea, pk, u2, Rsw, Rdif, Rlw, prec, Tci, te;
+    double pai, hgt, ltra, clump;                              // vegetation of the site
+    double alb, sdenc, sdeng, sdepc, sdepg, agec, ageg;        // pack
+    double slope, aspect, lat, lon, zref, psim, psih, G;
+};
+struct SnowStepOut {
+    double Tc, Tg, mSc, mMc, mRc, uf, gHa, RswabsG, RlwabsG, tr, Tcp, agec, ageg, sdenc, sdeng, sdepc, sdepg, pai, hgt;
+};
+struct SnowRad { double RabsC, RswabsG, RlwabsG, tr; };
+
+SnowRad snow_radiation(const SnowStepIn& q, double pai, double hgt, double ltra) {      // radoneB
+    SnowRad o{};
+    const double RlwabsC = 0.97 * q.Rlw, cld = q.clump * q.clump, pait = pai / (1.0 - q.clump);
+    o.RlwabsG = RlwabsC;
+    o.tr = (1.0 - cld) * exp(-pait) + cld;
+    if (hgt > 0.0) o.RlwabsG = 0.97 * (o.tr * q.Rlw + (1.0 - o.tr) * 0.97 * kSb * radem(q.Tci));
+    o.RabsC = RlwabsC;
+    if (q.Rsw > 0.0) {
+        const Sun sp = sun_position(q.lat, q.lon, q.year, q.month, q.day, q.hour);
+        double si = solar_index(q.slope, q.aspect, sp.zend, sp.azid);
+        if (si < 0.0) si = 0.0;
+        const double cosz = cos(sp.zenr);
+        double Rbeam = (q.Rsw - q.Rdif) / cosz;
+        if (Rbeam > 1352.2) Rbeam = 1352.2;
+        const double RswabsC = (1.0 - q.alb) * (q.Rdif + Rbeam * cosz);
+        o.RabsC = RswabsC + RlwabsC;
+        o.RswabsG = RswabsC;
+        if (hgt > 0.0) {
+            if (q.alb + ltra > 0.999) ltra = 0.999 - q.alb;
+            const Dif f = two_stream_dif(pait, 1.0, q.alb, ltra, q.alb);
+            const Ext kp = canopy_k(sp.zenr, 1.0, si);
+            const Dir r = two_stream_dir(pait, f, q.alb, kp.kd);
+            const double clb = pow(q.clump, kp.Kc);
+            double Rddm = (1.0 - cld) * (f.p3 * exp(-f.h * pait) + f.p4 * exp(f.h * pait)) + cld;
+            Rddm = Rddm > 1.0 ? 1.0 : Rddm < 0.0 ? 0.0 : Rddm;
+            double Rdbm = (1.0 - clb) * ((r.p8 / r.sig) * exp(-kp.kd * pait) + r.p9 * exp(-f.h * pait) + r.p10 * exp(f.h * pait));
+            Rdbm = Rdbm > 1.0 ? 1.0 : Rdbm < 0.0 ? 0.0 : Rdbm;
+            double Rbgm = (1.0 - clb) * exp(-kp.kd * pait) + clb;
+            Rbgm = Rbgm > 1.0 ? 1.0 : Rbgm < 0.0 ? 0.0 : Rbgm;
+            o.RswabsG = (1.0 - q.alb) * (Rdbm * Rbeam * cosz) + Rddm * q.Rdif + (1.0 - q.alb) * (Rbgm * Rbeam * 0.5);
+        }
+    }
+    return o;
+}
+
+double latent_molar(double t) { return t < 0.0 ? 51078.69 - 4.338 * t - 0.06367 * t * t : 45068.7 - 42.8428 * t; }
+
+SnowStepOut snow_step(const SnowStepIn& q, const SnowDen& sd) {                       // snowoneB with umu = 1
+    SnowStepOut o{};
+    const double pai = q.hgt > q.sdepg ? q.pai * (q.hgt - q.sdepg) / q.hgt : 0.0;
+    double hgt = q.hgt - q.sdepg;
+    if (hgt < 0.0) hgt = 0.0;
+    const double zi = (q.sdepg > 0.0 && hgt > 0.0) ? ((q.sdepc - q.sdepg) * q.sdenc) / (hgt * 1000.0) : 0.0;
+    const SnowRad rad = snow_radiation(q, pai, hgt, q.ltra * exp(-10.1 * zi));
+    double d = 0.0, zm = 0.005;
+    if (hgt > 0.0) { d = zeroplane(hgt, pai); zm = roughlength(hgt, pai, d, q.psih); }
+    if (zm < 0.0009) zm = 0.0009;
+    o.hgt = hgt; o.pai = pai;
+    o.uf = (kKa * q.u2) / (log((q.zref - d) / zm) + q.psim);
+    o.gHa = g_turb(o.uf, d, zm, q.zref, phair(q.tc, q.pk), q.psih, 0.03);
+    o.Tc = penman(rad.RabsC, o.gHa, o.gHa, q.tc, q.te, q.pk, q.ea, 0.97, q.G, 1.0);
+    o.Tg = penman(rad.RswabsG + rad.RlwabsG, o.gHa, o.gHa, q.tc, q.te, q.pk, q.ea, 0.97, q.G, 1.0);
+    const double tdew = dewpoint(q.ea);
+    if (o.Tc < tdew) o.Tc = tdew;
+    if (o.Tg < tdew) o.Tg = tdew;
+    // whole pack: sublimation, temperature melt, rain melt (m of water equivalent per hour)
+    double la = latent_molar(o.Tc);
+    o.mSc = ((la * (o.gHa / q.pk) * (satvap(o.Tc) - q.ea)) / (la / 0.018015)) * 3.6;
+    o.Tcp = o.Tc;
+    if (o.Tc > 0.0) {
+        o.mMc = ((583.3 * o.Tc * (q.sdepc * (q.sdenc / 1000))) / 334000.0) * 3.6;
+        if (q.sdepc > 0.0) o.Tc = 0.0;
+    }
+    if (q.tc > 0.0) o.mRc = 0.0125 * q.tc * q.prec / 1000;
+    // ground pack
+    la = latent_molar(o.Tg);
+    double mu = exp(-pai);
+    if (mu > 1.0) mu = 1.0;
+    const double mSg = ((la * (o.gHa / q.pk) * (satvap(o.Tg) - q.ea) * mu) / (la / 0.018015)) * 3.6;
+    double mMg = 0.0;
+    if (o.Tg > 0.0) {
+        mMg = ((583.3 * o.Tg * (q.sdepg * (q.sdeng / 1000.0))) / 334000.0) * 3.6;
+        if (q.sdepg > 0.0) o.Tg = 0.0;
+    }
+    double Li = 0.0;
+    if (q.sdepc > 0.0) {
+        double wg = q.sdepg / q.sdepc;
+        wg = wg < 0.0 ? 0.0 : wg > 1.0 ? 1.0 : wg;
+        Li = (q.sdepc - q.sdepg) * (wg * q.sdeng + (1.0 - wg) * q.sdenc);
+    }
+    if (Li < 0.0) Li = 0.0;
+    double cis = canopy_snow_interception(hgt, pai, o.uf, q.prec, q.tc, Li);
+    if (cis > q.prec) cis = q.prec;
+    const double mRg = q.tc > 0.0 ? 0.0125 * q.tc * (q.prec - cis) / 1000.0 : 0.0;
+    const double snowc = q.tc > 2.0 ? 0.0 : q.prec, snowg = q.tc > 2.0 ? 0.0 : q.prec - cis;
+    const double swec = snowc / 1000.0 - o.mSc - o.mMc - o.mRc, sweg = snowg / 1000.0 - mSg - mMg - mRg;
+    o.agec = q.agec + 1.0; o.ageg = q.ageg + 1.0;
+    o.sdenc = snow_density(sd, q.sdepc, o.agec);
+    o.sdeng = snow_density(sd, q.sdepg, o.ageg);
+    o.sdepc = q.sdepc + (swec * 1000.0) / o.sdenc;
+    o.sdepg = q.sdepg + (sweg * 1000.0) / o.sdeng;
+    if (o.sdepc < 0.0) { o.sdepc = 0.0; o.agec = 0.0; }
+    if (o.sdepg < 0.0) { o.sdepg = 0.0; o.ageg = 0.0; }
+    o.RswabsG = rad.RswabsG; o.RlwabsG = rad.RlwabsG; o.tr = rad.tr;
+    return o;
+}
+
+void snow_ground_flux(const double* Ts, const double* den, size_t n, Vec& G) {          // GFluxCppsnow
+    Vec Gmu(n), dT(n), Td(n, 0.0), Gmud(n), t(Ts, Ts + n);
+    hour_to_day(t, MEAN, Td);
+    for (size_t i = 0; i < n; ++i) {
+        const double k = 0.0442 * exp(5.181 * den[i] / 1000), kap = k / (den[i] * 2090);
+        Gmu[i] = sqrt(2.0) * (k / sqrt(2.0 * kap / kOmdy)) * 0.5;
+        dT[i] = Ts[i] - Td[i];
+    }
+    moving_mean(Gmu, 6, Gmud);
+    moving_mean(dT, 6, G);
+    for (size_t i = 0; i < n; ++i) G[i] = G[i] * Gmud[i] * 1.1171;
+}
+
+}  // namespace
+
+extern "C" int mcf_pointmodelsnow(int64_t n64, const mcf_obstime* t, const mcf_point_weather* w, const double* vegp,
+                                  const double* other, int32_t snowenv, double tol, double maxiter, mcf_pointsnow_out* o) {
+    if (!t || !w || !vegp || !other || !o) return mcf::api_fail(MCF_ERR_ARG, "mcf_pointmodelsnow: null argument");
+    int rc = check_series(t, w, n64, true);
+    if (rc) return rc;
+    const size_t n = (size_t)n64;
+    double* outs[] = {o->Tc, o->Tg, o->sdenc, o->sdeng, o->G, o->RswabsG, o->RlwabsG, o->tr, o->umu, o->sublmelt, o->tempmelt,
+                      o->rainmelt, o->sstemp, o->sdepc, o->sdepg};
+    for (double* q : outs)
+        if (!q) return mcf::api_fail(MCF_ERR_ARG, "mcf_pointmodelsnow: null output vector");
+    Vec ea(n), te(w->temp, w->temp + n), salb(n), psih(n, 0.0), psim(n, 0.0), G(n), Tco(n), Tgo(n);
+    for (size_t i = 0; i < n; ++i) ea[i] = satvap(w->temp[i]) * w->relhum[i] / 100.0;
+    const double slope = other[0], aspect = other[1], lat = other[2], lon = other[3], zref = other[4], isnowd = other[5],
+                 isnowa = other[6];
+    snow_albedo(w->precip, n, salb);
+    const SnowDen sd = snow_density_params(snowenv);
+    for (size_t i = 0; i < n; ++i) {
+        o->sdenc[i] = o->sdeng[i] = snow_density(sd, isnowd, 0.0);
+        o->Tc[i] = o->Tg[i] = w->temp[i];
+    }
+    snow_ground_flux(w->temp, o->sdenc, n, G);
+    double tst = 100.0, mxdif = 0.0;
+    int iter = 0;
+    while (tst > tol) {
+        double agec = (double)(int)isnowa, ageg = (double)(int)isnowa;       // `int snowagec = isnowa`
+        o->sdepc[0] = isnowd;
+        o->sdepg[0] = isnowd * 0.5;
+        for (size_t i = 0; i < n; ++i) { Tco[i] = o->Tc[i]; Tgo[i] = o->Tg[i]; }
+        mxdif = 0.0;
+        for (size_t i = 0; i < n; ++i) {
+            SnowStepIn q{};
+            q.year = t->year[i]; q.month = t->month[i]; q.day = t->day[i]; q.hour = t->hour[i];
+            q.tc = w->temp[i]; q.ea = ea[i]; q.pk = w->pres[i]; q.u2 = w->windspeed[i]; q.prec = w->precip[i];
+            q.Rsw = w->swdown[i]; q.Rdif = w->difrad[i]; q.Rlw = w->lwdown[i]; q.Tci = o->Tc[i]; q.te = te[i];
+            q.pai = vegp[0]; q.hgt = vegp[1]; q.ltra = vegp[2]; q.clump = vegp[3];
+            q.alb = salb[i]; q.sdenc = o->sdenc[i]; q.sdeng = o->sdeng[i]; q.sdepc = o->sdepc[i]; q.sdepg = o->sdepg[i];
+            q.agec = agec; q.ageg = ageg;
+            q.slope = slope; q.aspect = aspect; q.lat = lat; q.lon = lon; q.zref = zref;
+            q.psim = psim[i]; q.psih = psih[i]; q.G = G[i];
+            const SnowStepOut s = snow_step(q, sd);
+            agec = (double)(int)s.agec; ageg = (double)(int)s.ageg;
+            o->sdepc[i + 1] = s.sdepc;
+            o->sdepg[i + 1] = s.sdepg;
+            o->Tc[i] = 0.5 * Tco[i] + 0.5 * s.Tc;
+            o->Tg[i] = 0.5 * Tgo[i] + 0.5 * s.Tg;
+            mxdif = fmax(mxdif, fmax(fabs(o->Tc[i] - Tco[i]), fabs(o->Tg[i] - Tgo[i])));
+            // stability of the surface layer for the next pass
+            const double cp = cpair(w->temp[i]), ph = phair(w->temp[i], w->pres[i]);
+            double H = cp * s.gHa * (o->Tc[i] - w->temp[i]);
+            const double d = zeroplane(s.hgt, s.pai);
+            double zm = roughlength(s.hgt, s.pai, d, psih[i]);
+            if (zm < 0.001) zm = 0.001;
+            if (fabs(H) < 0.1) H = 0.1;
+            const double LL = (ph * cp * pow(s.uf, 3.0) * (w->temp[i] + 273.15)) / (-kKa * 9.81 * H);
+            psim[i] = psi_m(zm / LL) - psi_m((zref - d) / LL);
+            psih[i] = psi_h((0.2 * zm) / LL) - psi_h((zref - d) / LL);
+            const double Belim = 0.4 / sqrt(0.003 + (0.2 * s.pai) / 2.0);
+            const double ln1 = log((zref - d) / zm), ln2 = log((zref - d) / (0.2 * zm));
+            if (psim[i] < -0.9 * ln1) psim[i] = -0.9 * ln1;
+            if (psih[i] < -0.9 * ln2) psih[i] = -0.9 * ln2;
+            if (psim[i] > 0.9 * ln1) psim[i] = 0.9 * ln1;
+            if (psih[i] > 0.9 * ln2) psih[i] = 0.9 * ln2;
+            if (psih[i] > 0.9 * Belim) psih[i] = 0.9 * Belim;
+            o->RswabsG[i] = s.RswabsG; o->RlwabsG[i] = s.RlwabsG; o->tr[i] = s.tr;
+            o->umu[i] = s.uf / ((0.4 * w->windspeed[i]) / log((zref - d) / zm));
+            te[i] = (o->Tc[i] + w->temp[i]) / 2.0;
+            o->sublmelt[i] = s.mSc; o->tempmelt[i] = s.mMc; o->rainmelt[i] = s.mRc; o->sstemp[i] = s.Tcp;
+        }
+        snow_ground_flux(o->Tg, o->sdenc, n, G);
+        tst = mxdif;
+        if (++iter > maxiter) tst = 0;
+    }
+    for (size_t i = 0; i < n; ++i) o->G[i] = G[i];
+    o->mxdif = mxdif;
+    o->iters = iter;
+    return MCF_OK;
+}

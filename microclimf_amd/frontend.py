@@ -464,3 +464,78 @@ def runmicro_array(micropointa: Sequence, crows: int, ccols: int, reqhgt: float,
              "complete", "mat", "out")
     fn = "mcf_runmicro2" if dfsel is None else "mcf_runmicro4"
     return api._run(fn, True, *[a[k] for k in order], device, 0, 0, dfsel, coarse)
+
+
+# ---- snow: runsnowmodel() -> .snowmodel1 --------------------------------------------------------------------------
+def cleanvegp(vegp):
+    """`.cleanvegp` (R/internal.R:121-139): no plant area on zero-height cells and the other way round, so that the
+    snow model does not return NAs"""
+    veg = {k: as3d(vegp[k]).copy() for k in VEG_KEYS}
+    hm = veg["hgt"][:, :, 0]
+    for l in range(veg["pai"].shape[2]):
+        pm = veg["pai"][:, :, l]
+        with np.errstate(invalid="ignore"):
+            hm[(pm == 0) & (hm > 0)] = 0
+            pm[(hm == 0) & (pm > 0)] = 0
+    return {k: (v[:, :, 0] if np.ndim(vegp[k]) == 2 else v) for k, v in veg.items()}
+
+
+def sortl(vegp, sdep):
+    """`.sortl` (R/internal.R:2388-2419): pai, hgt, leaft, clump averaged over the layers in force while snow lies
+    (weights = number of snow-covered steps each layer serves); single-layer variables pass through"""
+    sdep = np.asarray(sdep, dtype=np.float64)
+    out = {}
+    for k in ("pai", "hgt", "leaft", "clump"):
+        a = as3d(vegp[k])
+        dmx = a.shape[2]
+        if dmx == 1:
+            out[k] = a[:, :, 0]
+            continue
+        s = layer_index(dmx, len(sdep))
+        sel = np.nonzero(sdep > 0)[0]
+        s = s[sel] if len(sel) else s[:1]
+        num, fre = np.unique(s, return_counts=True)
+        # the reference sums a[,,j] * fre[j] with j = 1..length(num) — the FIRST layers, not layers `num`
+        m = np.zeros(a.shape[:2])
+        for j in range(len(num)):
+            m = m + a[:, :, j] * fre[j]
+        out[k] = m / fre.sum()
+    return out
+
+
+def runsnowmodel(weather: Mapping, micropoint: Mapping, vegp: Mapping, soilc: Mapping, dtm: Mapping, *,
+                 snowenv: str = "Taiga", snowinitd=0.0, snowinita=0.0, stfact: float = 0.01, device: int = 0) -> dict:
+    """`runsnowmodel(weather, micropoint, vegp, soilc, dtm, ...)` for data.frame weather and a complete (not subset)
+    micropoint (R/Cppwrappers.R:717-731 -> `.snowmodel1`, R/internal.R:2498-2619): weather height adjustment, the
+    snow point model (host C++), `.sortl`, then the 5-day chunk loop on the device (terrain refresh from dtm + snow,
+    gridmodelsnow1, `.tpicalc` redistribution, hand-over).  Returns Tc, Tg, groundsnowdepth, totalSWE, snowden, umu."""
+    from . import snow as S
+    vegp = cleanvegp(vegp)
+    w = {k: np.array(weather[k], dtype=np.float64, copy=True) for k in WEATHER if k in weather}
+    tme = weather["obstime"]
+    obstime = {k: np.asarray(tme[k]) for k in ("year", "month", "day", "hour")}
+    zref = float(micropoint["zref"])                                   # runsnowmodel passes micropoint$zref twice
+    lat, long = float(micropoint["lat"]), float(micropoint["long"])
+    z = np.asarray(dtm["z"], dtype=np.float64)
+    hmax = float(np.nanmax(np.asarray(vegp["hgt"], dtype=np.float64)))
+    if hmax > zref:                                                    # R/internal.R:2509-2526
+        w.update({k: v for k, v in pointmodel.weatherhgtCpp(obstime, w, zref, zref, hmax, lat, long).items() if k in w})
+        zref = hmax
+    vp = sortvegp_point(vegp)                                          # (hgt, pai, x, clump, leafr, leaft, ...)
+    vegpp = np.array([vp[1], vp[0], vp[5], vp[3]])                     # c(vegpp[2], vegpp[1], vegpp[6], vegpp[4])
+    sdep = z * 0 + snowinitd
+    sage = z * 0 + snowinita
+    other_p = [0.0, 0.0, lat, long, zref, float(np.nanmean(sdep)), float(np.nanmean(sage))]
+    hour_int = {**obstime, "hour": np.floor(np.asarray(obstime["hour"], dtype=np.float64))}   # `hour = tme$hour`
+    pmod = pointmodel.pointmodelsnow(hour_int, w, vegpp, other_p, snowenv)
+    n = len(w["temp"])
+    pointm = {"Gp": pmod["G"], "Tc": pmod["Tc"], "RswabsG": pmod["RswabsG"], "RlwabsG": pmod["RlwabsG"], "umu": pmod["umu"],
+              "tr": pmod["tr"]}
+    vg = sortl(vegp, pmod["sdepc"][:n])
+    other = {"zref": zref, "lat": lat, "lon": long, "isnowdc": sdep, "isnowac": sage, "isnowdg": sdep * 0.5, "isnowag": sage}
+    res = dtm["res"]
+    xres = res if np.isscalar(res) else res[0]
+    clim = {k: w[k] for k in ("temp", "relhum", "pres", "swdown", "difrad", "lwdown", "windspeed", "winddir", "precip")}
+    out = S.snowmodel1_chunks(hour_int, clim, pointm, vg, other, snowenv, z, xres, stfact, device=device)
+    out["umu"] = pmod["umu"]
+    return out

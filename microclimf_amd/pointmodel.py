@@ -114,6 +114,29 @@ def weatherhgtCpp(obstime, climdata, zin, uzin, zout, lat, lon) -> dict:
     return out
 
 
+def pointmodelsnow(obstime, climdata, vegp, other, snowenv, tol: float = 0.5, maxiter: float = 100) -> dict:
+    """Drop-in for pointmodelsnow (src/microclimfCpp.cpp:4000-4169): vegp = (pai, hgt, ltra, clump), other = (slope,
+    aspect, lat, lon, zref, initial snow depth, initial snow age), snowenv a name as in the reference."""
+    lib = _abi.load()
+    n = len(np.asarray(climdata["temp"]))
+    t, k1 = _obstime(obstime, n)
+    w, k2 = _weather(climdata, n, True)
+    vp, ot = _vec(vegp), _vec(other)
+    if vp.size < 4 or ot.size < 7:
+        raise ValueError("vegp needs 4 and other 7 entries")
+    out = _abi.PointSnowOut()
+    res = {}
+    for f in _abi.POINTSNOW_FIELDS:
+        res[f] = np.zeros(n + 1 if f in ("sdepc", "sdepg") else n)
+        setattr(out, f, res[f].ctypes.data_as(_abi.c_double_p))
+    env = lib.mcf_snowenv_from_name(str(snowenv).encode())
+    _abi.check(lib.mcf_pointmodelsnow(n, C.byref(t), C.byref(w), vp.ctypes.data_as(_abi.c_double_p),
+                                      ot.ctypes.data_as(_abi.c_double_p), env, float(tol), float(maxiter), C.byref(out)))
+    res["mxdif"] = out.mxdif
+    res["iters"] = out.iters
+    return res
+
+
 def manCpp(x, n: int) -> np.ndarray:
     """Drop-in for manCpp (src/microclimfCpp.cpp:597-627)."""
     lib = _abi.load()

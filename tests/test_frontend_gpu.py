@@ -91,3 +91,36 @@ def test_array_weather_chain_on_the_bundled_site(oracle, layered):
     b = dict(a)
     b.update(climdata=clim, pointm=pm)
     compare(got, oracle.run_grid(**b, array_forcing=True))
+
+
+def test_runsnowmodel_on_the_bundled_site_made_colder(oracle):
+    """the reference's own example (R/Cppwrappers.R:701-704): `climdata$temp - 8`, runpointmodel, runsnowmodel — here for
+    the first 30 days against the oracle chain (pointmodelsnow in C, the chunk loop in numpy + C); over longer series the
+    reference's hand-over between chunks amplifies rounding residue in a few cells"""
+    from oracle import replay_reference_tests as RT
+    from oracle import snowdriver_oracle as SD
+    weather, vegp, soilc, dtm = load(30 * 24)
+    weather = dict(weather, temp=weather["temp"] - 8.0)
+    mp = F.runpointmodel(weather, 0.05, dtm, vegp, soilc)
+    got = F.runsnowmodel(weather, mp, vegp, soilc, dtm)
+    assert list(got) == ["Tc", "Tg", "groundsnowdepth", "totalSWE", "snowden", "umu"]
+    # the same chain through the oracle
+    vg = F.cleanvegp(vegp)
+    vp = F.sortvegp_point(vg)
+    z = np.asarray(dtm["z"])
+    obst = {k: np.asarray(v) for k, v in weather["obstime"].items()}
+    w = {k: np.asarray(weather[k], dtype=np.float64) for k in F.WEATHER}
+    pm = RT.pointmodelsnow(obst, w, np.array([vp[1], vp[0], vp[5], vp[3]]), np.array([0, 0, mp["lat"], mp["long"], mp["zref"], 0, 0]),
+                           "Taiga")
+    n = len(w["temp"])
+    pointm = {"Gp": pm["G"], "Tc": pm["Tc"], "RswabsG": pm["RswabsG"], "RlwabsG": pm["RlwabsG"], "umu": pm["umu"], "tr": pm["tr"]}
+    other = {"zref": mp["zref"], "lat": mp["lat"], "lon": mp["long"], "isnowdc": z * 0, "isnowac": z * 0, "isnowdg": z * 0,
+             "isnowag": z * 0}
+    want = SD.snowmodel1_chunks(obst, w, pointm, F.sortl(vg, pm["sdepc"][:n]), other, "Taiga", z, dtm["res"], 0.01)
+    np.testing.assert_allclose(got["umu"], pm["umu"], rtol=1e-10)
+    for k in want:
+        g, x = got[k], want[k]
+        assert np.array_equal(np.isnan(g), np.isnan(x)), k
+        err = np.nanmax(np.abs(g - x) / (1 + np.abs(x)))
+        assert err < 1e-6, (k, err)
+    assert np.nanmax(got["groundsnowdepth"]) > 0.01                      # it does snow at -8 degC

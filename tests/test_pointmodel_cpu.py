@@ -125,3 +125,72 @@ def test_random_point_model_inputs_equal_oracle(oracle, i):
     # height adjustment of the same weather
     wh = PM.weatherhgtCpp(a["obstime"], clim, zref, zref, zref + 8.0, a["lat"], a["lon"])
     assert np.isfinite(wh["temp"]).all() and (wh["windspeed"] >= clim["windspeed"] - 1e-12).all()
+
+
+def _snow_test_inputs(oracle):
+    """the inputs of tests/testthat/test-pointmodelsnow.R as oracle/replay_reference_tests.py rebuilds them"""
+    RT.replay_pointmodelsnow_test()
+    lib = oracle.load()
+    hrs = np.arange(24.0)
+    n = 24
+    obst = {"year": np.full(n, 2024, dtype=np.int32), "month": np.full(n, 3, dtype=np.int32),
+            "day": np.full(n, 21, dtype=np.int32), "hour": hrs.copy()}
+    Tair = -5 + 5 * np.sin((hrs - 8) / 24 * 2 * np.pi)
+    lib.orc_satvap.restype = C.c_double
+    lib.orc_satvap.argtypes = [C.c_double]
+    ea = 0.7 * lib.orc_satvap(float(np.mean(Tair)))
+    RH = np.array([ea / lib.orc_satvap(float(t)) * 100 for t in Tair])
+    return obst, Tair, RH, n
+
+
+def test_pointmodelsnow_equals_oracle_on_the_reference_test(oracle):
+    want = dict(RT.LAST_POINTSNOW) if RT.LAST_POINTSNOW else None
+    obst, Tair, RH, n = _snow_test_inputs(oracle)
+    want = dict(RT.LAST_POINTSNOW)
+    # the replay's radiation inputs are not kept: rebuild the same weather through the oracle's helpers
+    lib = oracle.load()
+    Pk = np.full(n, 101.3)
+    csr, zen, azi, si = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)
+    d = lambda a: a.ctypes.data_as(DP)                                                  # noqa: E731
+    i = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))                                  # noqa: E731
+    lib.orc_clearskyrad.restype = None
+    lib.orc_clearskyrad.argtypes = None
+    lib.orc_clearskyrad(C.c_int(n), i(obst["year"]), i(obst["month"]), i(obst["day"]), d(obst["hour"]), C.c_double(50.0),
+                        C.c_double(-5.0), d(Tair), d(RH), d(Pk), d(csr))
+    lib.orc_solpositionv.restype = None
+    lib.orc_solpositionv(C.c_int(n), i(obst["year"]), i(obst["month"]), i(obst["day"]), d(obst["hour"]), C.c_double(50.0),
+                         C.c_double(-5.0), C.c_double(0.0), C.c_double(180.0), d(zen), d(azi), d(si))
+    SWd = 0.5 * csr
+    clim = {"temp": Tair, "relhum": RH, "pres": Pk, "swdown": SWd, "difrad": SWd - 0.3 * csr * si, "lwdown": np.full(n, 350.0),
+            "windspeed": np.full(n, 2.0), "precip": np.full(n, 1.0)}
+    got = PM.pointmodelsnow(obst, clim, [2, 0.5, 0.05, 0], [0, 180, 50, -5, 2, 0, 0], "Taiga")
+    assert got["iters"] == want["iters"]
+    for k in ("Tc", "Tg", "sdepc", "sdepg", "sdenc", "sdeng", "G", "RswabsG", "RlwabsG", "tr", "umu", "sublmelt", "tempmelt",
+              "rainmelt", "sstemp"):
+        np.testing.assert_allclose(got[k], want[k], rtol=1e-10, atol=1e-10, err_msg=k)
+    # test-pointmodelsnow.R's own bounds hold for the product as they do for the oracle
+    assert np.isfinite(got["Tc"]).all() and (got["sdepc"] >= 0).all() and got["sdepc"][-1] > 0
+
+
+@pytest.mark.parametrize("i", range(8))
+def test_random_snow_point_series_equal_oracle(oracle, i):
+    rng = np.random.default_rng(9300 + i)
+    days = int(rng.integers(1, 12))
+    a = synthetic.workload(2, 2, days * 24, reqhgt=0.05, start_doy=int(rng.choice([5, 40, 340])),
+                           lat=float(rng.choice([46.0, 57.0, 68.0])), cold=float(rng.choice([4.0, 9.0, 14.0])),
+                           seed=int(rng.integers(1, 1 << 30)))
+    c = a["climdata"]
+    n = days * 24
+    clim = {"temp": c["temp"], "relhum": np.clip(100 * c["ea"] / c["es"], 5, 100), "pres": c["pres"], "swdown": c["swdown"],
+            "difrad": c["difrad"], "lwdown": c["lwdown"], "windspeed": np.maximum(c["windspeed"], 0.5),
+            "precip": np.where(rng.random(n) < 0.2, rng.uniform(0, 3, n), 0.0)}
+    hgt = float(rng.choice([0.0, 0.3, 1.5, 3.0]))
+    vegp = [float(rng.uniform(0.2, 3)) if hgt > 0 else 0.0, hgt, float(rng.uniform(0.02, 0.3)), float(rng.uniform(0, 0.5))]
+    other = [float(rng.uniform(0, 20)), float(rng.uniform(0, 360)), a["lat"], a["lon"], hgt + 2.0, float(rng.uniform(0, 0.6)),
+             float(rng.integers(0, 200))]
+    env = str(rng.choice(["Alpine", "Maritime", "Prairie", "Tundra", "Taiga", "Ephemeral"]))
+    want = RT.pointmodelsnow(a["obstime"], clim, np.array(vegp), np.array(other), env, 0.5, 30)
+    got = PM.pointmodelsnow(a["obstime"], clim, vegp, other, env, 0.5, 30)
+    assert got["iters"] == want["iters"]
+    for k in ("Tc", "Tg", "sdepc", "sdepg", "sdenc", "G", "RswabsG", "RlwabsG", "tr", "umu", "sublmelt", "tempmelt", "rainmelt"):
+        np.testing.assert_allclose(got[k], want[k], rtol=1e-9, atol=1e-9, err_msg=k)
