@@ -34,7 +34,9 @@ class SnowMarshalled:
 
     def i32(self, a, shape, name):
         # Rcpp's as<IntegerVector/IntegerMatrix>() truncates doubles towards zero
-        arr = np.asfortranarray(np.trunc(np.asarray(a, dtype=np.float64)).astype(np.int32))
+        # (NA cells: NA_integer_, as Rcpp's conversion gives)
+        v = np.trunc(np.asarray(a, dtype=np.float64))
+        arr = np.asfortranarray(np.where(np.isnan(v), float(np.iinfo(np.int32).min), v).astype(np.int32))
         if tuple(arr.shape) != tuple(shape):
             raise ValueError(f"{name}: expected shape {tuple(shape)}, got {arr.shape}")
         self._keep.append(arr)

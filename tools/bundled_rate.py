@@ -29,3 +29,16 @@ for reqhgt in (0.05, 1.0, 0.0):
           f"layers) {t2 - t1:.3f} s, runmicro incl. the same preparation {t3 - t2:.3f} s; {valid} cells x 8760 h, "
           f"{len(out)} outputs = {sum(v.nbytes for v in out.values()) / 1e9:.2f} GB; whole chain {t1 - t0 + t3 - t2:.2f} s = "
           f"{valid * 8760 / (t1 - t0 + t3 - t2):.3e} cell-steps/s end to end")
+
+# the reference's snow example (R/Cppwrappers.R:701-704: "takes ~90 seconds"): climdata$temp - 8, runsnowmodel for the year
+wc = dict(weather, temp=weather["temp"] - 8.0)
+mpc = F.runpointmodel(wc, 0.05, dtm, vegp, soilc)
+F.runsnowmodel({k: (v[:240] if k != "obstime" else {q: x[:240] for q, x in v.items()}) for k, v in wc.items()},
+               F.runpointmodel({k: (v[:240] if k != "obstime" else {q: x[:240] for q, x in v.items()}) for k, v in wc.items()},
+                               0.05, dtm, vegp, soilc), vegp, soilc, dtm)          # warm-up
+t0 = time.perf_counter()
+sm = F.runsnowmodel(wc, mpc, vegp, soilc, dtm)
+dt = time.perf_counter() - t0
+d = np.nanmean(sm["groundsnowdepth"], axis=(0, 1))
+print(f"runsnowmodel, bundled site at -8 K, 8760 h (73 five-day chunks): {dt:.2f} s; mean ground snow depth peaks at "
+      f"{d.max():.3f} m on step {int(d.argmax())}, {int((d > 0).sum())} h with snow")
