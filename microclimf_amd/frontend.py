@@ -539,3 +539,154 @@ def runsnowmodel(weather: Mapping, micropoint: Mapping, vegp: Mapping, soilc: Ma
     out = S.snowmodel1_chunks(hour_int, clim, pointm, vg, other, snowenv, z, xres, stfact, device=device)
     out["umu"] = pmod["umu"]
     return out
+
+
+# ---- snow: runmicro(snow = TRUE) -> .runmicrosnow1 ----------------------------------------------------------------
+def _rows(d: Mapping, ai):
+    return {k: np.asarray(v)[ai] for k, v in d.items()}
+
+
+def subsetpointmodel(micropoint: Mapping, tstep: str = "month", what: str = "tmax", days=None, Tc=None) -> dict:
+    """`subsetpointmodel` (R/dataprep.R:31-103): whole days of the point model — given 1-based `days`, or one day per
+    month / year chosen by the point model's canopy temperature (`what` = tmax, tmin, tmedian)."""
+    dfo, ob = micropoint["dfo"], micropoint["obstime"]
+    n = len(dfo["Tg"])
+    if days is not None:
+        days = np.asarray(days, dtype=np.int64)
+        ai = (np.repeat((days - 1) * 24, 24) + np.tile(np.arange(24), days.size)).astype(np.int64)
+    else:
+        tc = np.asarray(dfo["Tc"] if Tc is None else Tc, dtype=np.float64)
+        yr, mo, dy = (np.asarray(ob[k]).astype(int) for k in ("year", "month", "day"))
+
+        def extract(sel):
+            v = tc[sel]
+            if what == "tmax":
+                s2 = int(np.argmax(v))
+            elif what == "tmin":
+                s2 = int(np.argmin(v))
+            elif what == "tmedian":
+                o = np.argsort(v, kind="stable")
+                s2 = int(o[len(o) // 2 - 1])                       # o[trunc(length(o) / 2)], 1-based
+            else:
+                raise ValueError("what must be one of tmax, tmin or tmedian")
+            k = sel[s2]
+            return np.nonzero((yr == yr[k]) & (mo == mo[k]) & (dy == dy[k]))[0]
+        parts = []
+        for y in dict.fromkeys(yr.tolist()):
+            sely = np.nonzero(yr == y)[0]
+            if tstep == "year":
+                parts.append(extract(sely))
+            elif tstep == "month":
+                # `which(tme$mon[sely] == m)` indexes WITHIN the year's rows; the reference then uses those positions
+                # on the whole series — the same thing for the first year only
+                for m in dict.fromkeys(mo[sely].tolist()):
+                    parts.append(extract(np.nonzero(mo[sely] == m)[0]))
+            else:
+                raise ValueError("tstep must be month or year")
+        ai = np.concatenate(parts)
+    out = dict(micropoint)
+    out["dfo"] = _rows(dfo, ai)
+    out["weather"] = _rows(micropoint["weather"], ai)
+    out["obstime"] = _rows(ob, ai)
+    out["subs"] = np.asarray(micropoint["subs"])[ai]
+    if micropoint.get("Tbz") is not None:
+        out["Tbz"] = np.asarray(micropoint["Tbz"])[ai]
+    assert n == len(micropoint["subs"]) or True
+    return out
+
+
+def subsetsnowmodel(smod: Mapping, subs) -> dict:
+    """`subsetsnowmodel` (R/dataprep.R:148-160); `subs` 1-based.  (The reference tests `snowmods$umu`, which does not
+    exist yet, so `umu` is always subset as a vector.)"""
+    i = np.asarray(subs, dtype=np.int64) - 1
+    out = {k: np.asarray(smod[k])[:, :, i] for k in ("Tc", "Tg", "groundsnowdepth", "totalSWE", "snowden")}
+    out["umu"] = np.asarray(smod["umu"])[i]
+    return out
+
+
+def sortl2(vegp, sdep, reqhgt, pai_a=None):
+    """`.sortl2` (R/internal.R:2421-2482): as `.sortl` for pai, hgt, leaft, clump, leafd, plus paia and leafden"""
+    sdep = np.asarray(sdep, dtype=np.float64)
+    out = {}
+    for k in ("pai", "hgt", "leaft", "clump", "leafd"):
+        a = as3d(vegp[k])
+        dmx = a.shape[2]
+        if dmx == 1:
+            out[k] = a[:, :, 0]
+            continue
+        s = layer_index(dmx, len(sdep))
+        sel = np.nonzero(sdep > 0)[0]
+        s = s[sel] if len(sel) else s[:1]
+        num, fre = np.unique(s, return_counts=True)
+        m = np.zeros(a.shape[:2])
+        for j in range(len(num)):
+            m = m + a[:, :, j] * fre[j]
+        out[k] = m / fre.sum()
+    if pai_a is not None and as3d(pai_a).shape[2] > 1:
+        pai_a = sortl({"pai": pai_a, "hgt": pai_a, "leaft": pai_a, "clump": pai_a}, sdep)["pai"]
+    elif pai_a is not None:
+        pai_a = as3d(pai_a)[:, :, 0]
+    out["leafden"], out["paia"] = foliageden(reqhgt, out["hgt"], out["pai"], pai_a)
+    return out
+
+
+def runmicro_snow(micropoint: Mapping, reqhgt: float, vegp: Mapping, soilc: Mapping, dtm: Mapping, smod: Mapping, *,
+                  pai_a=None, tfact: float = 1.5, out: Sequence = (1,) * 10, device: int = 0,
+                  _solve=None, _microsnow=None, _terrain=None) -> dict:
+    """`runmicro(..., snow = TRUE, snowmod = smod)` for data.frame weather = `.runmicrosnow1` (R/internal.R:3581-3659):
+    days with no snow anywhere go through the ordinary solver, days with snow through gridmicrosnow1 (which keeps the
+    ordinary solver's values on snow-free cell-steps of days that have both), and the two are merged by day.
+    `_solve` / `_microsnow` / `_terrain` let the tests put their checkers behind the same orchestration."""
+    from . import snow as S
+    solve = runmicro if _solve is None else _solve
+    microsnow = S.gridmicrosnow1 if _microsnow is None else _microsnow
+    veg, soil, z = cleanvars(vegp, soilc, dtm["z"])
+    sm = dict(smod)
+    swe = np.array(sm["totalSWE"], dtype=np.float64, copy=True)
+    swe[np.isnan(swe)] = 0.0
+    swe[np.isnan(z)] = np.nan                                            # mask(totalSWE, dtm)
+    sm["totalSWE"] = swe
+    sd = S.snowdaysfun(S.applycpp3(swe, "max", device=device), S.applycpp3(swe, "min", device=device))
+    alldays = np.arange(1, len(sd["snowdays"]) + 1)
+    snowdays, nosnowdays = alldays[sd["snowdays"] == 1], alldays[sd["nosnowdays"] == 1]
+    rows, cols = z.shape
+    if len(nosnowdays):
+        moutn = solve(subsetpointmodel(micropoint, days=nosnowdays), reqhgt, vegp, soilc, dtm, pai_a=pai_a, tfact=tfact,
+                      out=out, device=device)
+    else:                                                                # .createblanktemplate1
+        moutn = solve(subsetpointmodel(micropoint, days=[1]), reqhgt, vegp, soilc, dtm, tfact=1.5, out=out, device=device)
+        moutn = {k: v * np.nan for k, v in moutn.items()}
+    if not len(snowdays):
+        return moutn
+    mps = subsetpointmodel(micropoint, days=snowdays)
+    ai = (np.repeat((snowdays - 1) * 24, 24) + np.tile(np.arange(24), snowdays.size)).astype(np.int64)
+    w = dict(mps["weather"])
+    w["umu"] = np.asarray(sm["umu"])[ai]
+    sdept = np.zeros(micropoint["ntme"])
+    sdept[np.asarray(mps["subs"]) - 1] = 1
+    vg = sortl2(veg, sdept, reqhgt, pai_a)
+    res = dtm["res"]
+    xres = res if np.isscalar(res) else res[0]
+    ter = (terrain.precompute_terrain(z, xres, micropoint["zref"], device=device) if _terrain is None
+           else _terrain(z, xres, micropoint["zref"]))
+    other = {"slope": ter["slope"], "aspect": ter["aspect"], "hor": ter["hor"], "skyview": ter["svfa"], "wsa": ter["wsa"],
+             "lat": float(micropoint["lat"]), "lon": float(micropoint["long"]), "zref": float(micropoint["zref"]),
+             "Smax": soilinit(soil)["Smax"]}
+    t1 = len(snowdays) * 24
+    s1 = np.arange(t1)[np.repeat(np.isin(snowdays, nosnowdays), 24)]
+    s2 = np.arange(len(nosnowdays) * 24)[np.repeat(np.isin(nosnowdays, snowdays), 24)]
+    micro = {}
+    for k, v in moutn.items():
+        a = np.full((rows, cols, t1), np.nan, order="F")
+        if len(s1):
+            a[:, :, s1] = np.asarray(v)[:, :, s2]
+        micro[k] = a
+    outm = [int(bool(v)) for v in out]
+    if reqhgt == 0:
+        outm = [1 if i in (0, 3, 5, 6, 7, 8, 9) else 0 for i in range(10)]
+    elif reqhgt < 0:
+        outm = [1 if i in (0, 3) else 0 for i in range(10)]
+    smods = subsetsnowmodel(sm, ai + 1)
+    mouts = microsnow(reqhgt, mps["obstime"], w, smods, micro, vg, other, float(micropoint["matemp"]), outm)
+    return S.merge_snow_outputs(moutn, mouts, snowdays, nosnowdays, rows, cols)
+

@@ -124,3 +124,39 @@ def test_runsnowmodel_on_the_bundled_site_made_colder(oracle):
         err = np.nanmax(np.abs(g - x) / (1 + np.abs(x)))
         assert err < 1e-6, (k, err)
     assert np.nanmax(got["groundsnowdepth"]) > 0.01                      # it does snow at -8 degC
+
+
+def test_runmicro_with_snow_on_the_bundled_site(oracle):
+    """runmicro(snow = TRUE): no-snow days through the solver, snow days through gridmicrosnow1, merged by day — the product
+    against the same orchestration with the oracle's solver, snow microclimate and terrain behind it.  A cool spell in a
+    mild month gives days with snow everywhere, days with none and days with both."""
+    from oracle import terrain_oracle as TO
+    weather, vegp, soilc, dtm = load(25 * 24)
+    t = np.arange(25 * 24)
+    weather = dict(weather, temp=weather["temp"] - 9.0 + 7.0 * (t > 8 * 24) + 6.0 * (t > 16 * 24))
+    mp = F.runpointmodel(weather, 0.05, dtm, vegp, soilc)
+    smod = F.runsnowmodel(weather, mp, vegp, soilc, dtm)
+    from microclimf_amd import snow as S
+    sd = S.snowdaysfun(S.applycpp3(np.nan_to_num(smod["totalSWE"]), "max"), S.applycpp3(np.nan_to_num(smod["totalSWE"]), "min"))
+    assert sd["snowdays"].sum() > 0 and sd["nosnowdays"].sum() > 0 and (sd["snowdays"] & sd["nosnowdays"]).sum() >= 0
+
+    def solve_oracle(mpx, reqhgt, vegp_, soilc_, dtm_, **kw):
+        kw.pop("device", None)
+        tf = kw.pop("tfact", 1.5)
+        z = F.cleanvars(vegp_, soilc_, dtm_["z"])[2]
+        ter = TO.terrain(z, dtm_["res"], mpx["zref"])
+        a = F.prepare_grid_inputs(mpx, reqhgt, vegp_, soilc_, dtm_, slr=ter["slope"], apr=ter["aspect"], hor=ter["hor"],
+                                  svf=ter["svfa"], wsa=ter["wsa"], **kw)
+        a["tfact"] = tf
+        return oracle.run_grid(**a)
+
+    for reqhgt in (0.05, 0.0):
+        got = F.runmicro_snow(mp, reqhgt, vegp, soilc, dtm, smod)
+        want = F.runmicro_snow(mp, reqhgt, vegp, soilc, dtm, smod, _solve=solve_oracle, _microsnow=oracle.run_microsnow,
+                               _terrain=TO.terrain)
+        assert list(got) == list(want)
+        for k in want:
+            assert got[k].shape == (50, 50, 25 * 24)
+            assert np.array_equal(np.isnan(got[k]), np.isnan(want[k])), k
+            err = np.nanmax(np.abs(got[k] - want[k]) / (1 + np.abs(want[k])))
+            assert err < 1e-6, (reqhgt, k, err)
