@@ -96,3 +96,26 @@ def test_prepared_call_runs_through_the_oracle(oracle, reqhgt, layered):
         assert np.nanmax(got["relhum"]) <= 100 and np.nanmin(got["windspeed"]) >= 0
     else:
         assert "tleaf" not in got and "relhum" not in got                                  # out masks of R/internal.R:1159-1166
+
+
+def test_subsetpointmodel_picks_whole_days():
+    weather, vegp, soilc, dtm = load()
+    mp = F.runpointmodel(weather, 0.05, dtm, vegp, soilc)
+    sub = F.subsetpointmodel(mp)                                        # one day per month, the hottest by canopy temperature
+    assert len(sub["dfo"]["Tg"]) == 288 and len(sub["weather"]["temp"]) == 288 and len(sub["subs"]) == 288
+    subs = sub["subs"].reshape(12, 24)
+    assert (np.diff(subs, axis=1) == 1).all() and ((subs[:, 0] - 1) % 24 == 0).all()
+    months = np.asarray(sub["obstime"]["month"]).reshape(12, 24)
+    assert (months == np.arange(1, 13)[:, None]).all()
+    tc = mp["dfo"]["Tc"]
+    for m in range(12):
+        in_month = np.asarray(mp["obstime"]["month"]) == m + 1
+        assert tc[subs[m] - 1].max() == tc[in_month].max()
+    assert sub["ntme"] == 8760 and mp["ntme"] == 8760                 # tmeorig keeps its length: `complete` turns FALSE
+    cold = F.subsetpointmodel(mp, what="tmin")
+    assert cold["dfo"]["Tc"].min() == tc.min()
+    by_day = F.subsetpointmodel(mp, days=[3, 200])
+    assert list(by_day["subs"][[0, 23, 24]]) == [49, 72, 4777]
+    a = F.prepare_grid_inputs(sub, 0.05, vegp, soilc, dtm, slr=np.zeros((50, 50)), apr=np.zeros((50, 50)),
+                              hor=np.zeros((50, 50, 24)), svf=np.ones((50, 50)), wsa=np.ones((50, 50, 8)))
+    assert not a["complete"] and len(a["dfsel"]["st"]) == 12 and a["dfsel"]["ed"][-1] == 287

@@ -42,3 +42,12 @@ dt = time.perf_counter() - t0
 d = np.nanmean(sm["groundsnowdepth"], axis=(0, 1))
 print(f"runsnowmodel, bundled site at -8 K, 8760 h (73 five-day chunks): {dt:.2f} s; mean ground snow depth peaks at "
       f"{d.max():.3f} m on step {int(d.argmax())}, {int((d > 0).sum())} h with snow")
+
+# the reference's runmicro() example (R/Cppwrappers.R:355-362, "takes ~20 seconds" for two calls): the point model subset
+# to the hottest day of each month, then runmicro at 5 cm and at 1 m
+mps = F.subsetpointmodel(F.runpointmodel(weather, 0.05, dtm, vegp, soilc))
+t0 = time.perf_counter()
+o1 = F.runmicro(mps, 0.05, vegp, soilc, dtm)
+o2 = F.runmicro(mps, 1.0, vegp, soilc, dtm)
+print(f"two runmicro() calls on the monthly subset (50 x 50 cells x 288 h each, incl. terrain / wetness-index preparation): "
+      f"{time.perf_counter() - t0:.3f} s")
