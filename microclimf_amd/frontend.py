@@ -690,3 +690,98 @@ def runmicro_snow(micropoint: Mapping, reqhgt: float, vegp: Mapping, soilc: Mapp
     mouts = microsnow(reqhgt, mps["obstime"], w, smods, micro, vg, other, float(micropoint["matemp"]), outm)
     return S.merge_snow_outputs(moutn, mouts, snowdays, nosnowdays, rows, cols)
 
+
+
+# ---- runbioclim() -> .runbioclim1 / .runbioclim3 ------------------------------------------------------------------
+def biosel(obstime: Mapping, tc) -> dict:
+    """`.biosel` (R/internal.R:1690-1729): the fourteen days a bioclim run models — for each month the day of median
+    daily-mean temperature, then the hottest and the coldest day (of the median year when there are several).
+    `seld`: 1-based day numbers, `selh`: 0-based hour indices."""
+    tcd = np.asarray(tc, dtype=np.float64).reshape(-1, 24).mean(axis=1)
+    mon = np.asarray(obstime["month"]).astype(int).reshape(-1, 24)[:, 12]       # the day's mean time falls on the day itself
+    yr = np.asarray(obstime["year"]).astype(int).reshape(-1, 24)[:, 12]
+    sel = []
+    for m in range(1, 13):
+        s = np.nonzero(mon == m)[0]
+        o = np.argsort(tcd[s], kind="stable")
+        sel.append(s[0] + o[len(o) // 2 - 1])                                   # s[1] - 1 + o[trunc(length(o) / 2)]
+    mx, mn = [], []
+    for y in dict.fromkeys(yr.tolist()):
+        s = np.nonzero(yr == y)[0]
+        mx.append(s[0] + int(np.argmax(tcd[s])))
+        mn.append(s[0] + int(np.argmin(tcd[s])))
+    mx = np.array(mx)[np.argsort(tcd[mx], kind="stable")]
+    mn = np.array(mn)[np.argsort(tcd[mn], kind="stable")]
+    k = len(mx) // 2                                                            # element trunc(n / 2) + 1, 1-based
+    seld = np.array(sel + [mx[k], mn[k]]) + 1
+    selh = (np.repeat((seld - 1) * 24, 24) + np.tile(np.arange(24), seld.size)).astype(np.int64)
+    return {"seld": seld, "selh": selh}
+
+
+def _quarter(values, months, how):
+    """which.max / which.min of the circular three-month mean of the monthly aggregate (R/internal.R:1797-1802)"""
+    ms = sorted(set(months.tolist()))
+    agg = np.array([how(values[months == m]) for m in ms])
+    sm = (np.roll(agg, 1) + agg + np.roll(agg, -1)) / 3
+    return sm
+
+
+def runbioclim(climdata: Mapping, reqhgt: float, vegp: Mapping, soilc: Mapping, dtm: Mapping, *, temp: str = "air",
+               zref: float = 2.0, windhgt: float | None = None, soilm=None, pai_a=None, tfact: float = 1.5,
+               out: Sequence = (1,) * 19, vegpisannual: bool = True, device: int = 0, _bioclim=None, _terrain=None) -> dict:
+    """`runbioclim(climdata, reqhgt, vegp, soilc, dtm, ...)` for data.frame weather (R/Cppwrappers.R:628-651 ->
+    `.runbioclim1` / `.runbioclim3`, R/internal.R:1776-1880 / 2083-2200): fourteen days are modelled (`biosel`) and the
+    19 bioclim variables reduced from them on the device (mcf_runbioclim1 / 3).  Returns {bio1.. : [rows, cols]}."""
+    ob_all = {k: np.asarray(climdata["obstime"][k]) for k in ("year", "month", "day", "hour")}
+    mon_all = ob_all["month"].astype(int)
+    t_all, p_all = np.asarray(climdata["temp"], dtype=np.float64), np.asarray(climdata["precip"], dtype=np.float64)
+    pq = _quarter(p_all, mon_all, np.nanmean)
+    tq = _quarter(t_all, mon_all, np.nansum)
+    wq, dq, hq, cq = int(np.argmax(pq)) + 1, int(np.argmin(pq)) + 1, int(np.argmax(tq)) + 1, int(np.argmin(tq)) + 1
+    sel = biosel(ob_all, t_all)
+    w2 = {k: np.asarray(climdata[k])[sel["selh"]] for k in WEATHER}
+    w2["obstime"] = {k: v[sel["selh"]] for k, v in ob_all.items()}
+    veg, soil, z = cleanvars(vegp, soilc, dtm["z"])
+    mp = runpointmodel(w2, reqhgt, dtm, vegp, soilc, zref=zref, windhgt=windhgt, soilm=soilm, yearG=False)
+    layered = vegpdmx(veg) > 1
+    ter_kw = {}
+    if _terrain is not None:
+        t = _terrain(z, dtm["res"] if np.isscalar(dtm["res"]) else dtm["res"][0], mp["zref"])
+        ter_kw = dict(slr=t["slope"], apr=t["aspect"], hor=t["hor"], svf=t["svfa"], wsa=t["wsa"])
+    static = {k: as3d(v)[:, :, 0] for k, v in veg.items()} if layered else vegp
+    a = prepare_grid_inputs(mp, reqhgt, static, soilc, dtm, pai_a=None if layered else pai_a, device=device, **ter_kw)
+    if layered:                                                                 # .sortvegp2
+        n = len(t_all)
+        seld = sel["seld"] % 365 if vegpisannual else sel["seld"]
+        nd = 365 if vegpisannual else int(round(n / 24))
+        v14 = {}
+        for k in VEG_KEYS:
+            arr = as3d(veg[k])
+            dmx = arr.shape[2]
+            if dmx == 1:
+                v14[k] = np.repeat(arr, 14, axis=2)
+            else:
+                sidx = layer_index(dmx, nd)
+                sidx = np.concatenate([sidx, sidx[-1:]])
+                v14[k] = arr[:, :, sidx[np.clip(seld, 1, len(sidx)) - 1] - 1]      # (seld = 0 would drop the day in R)
+        with np.errstate(invalid="ignore"):
+            pass
+        pa = None if pai_a is None else intr(pai_a, mp["ntme"], mp["subs"])
+        v14["leafden"], v14["paia"] = foliageden(reqhgt, v14["hgt"], v14["pai"], pa)
+        a["vegp"] = v14
+    mon2 = np.asarray(w2["obstime"]["month"]).astype(int)
+
+    def selq(iq):                                                               # .getselq(iq, tme) - 1
+        imn, imx = (12 if iq == 1 else iq - 1), (1 if iq == 12 else iq + 1)
+        return np.sort(np.concatenate([np.nonzero(mon2 == m)[0] for m in (imn, iq, imx)]))
+    args = {k: a[k] for k in ("obstime", "climdata", "pointm", "vegp", "soilc", "reqhgt", "zref", "lat", "lon", "Sminp", "Smaxp")}
+    kw = dict(tfact=float(tfact), mat=a["mat"], out=[int(bool(v)) for v in out], wetq=selq(wq), dryq=selq(dq), hotq=selq(hq),
+              colq=selq(cq), air=(temp == "air"))
+    if _bioclim is not None:
+        return _bioclim(layered, args, kw)
+    fn = api.runbioclim3Cpp if layered else api.runbioclim1Cpp
+    res = fn(**args, **kw, device=device)
+    na = np.isnan(z)
+    for v in res.values():
+        v[na] = np.nan                                                          # mask(bior, dtm)
+    return res

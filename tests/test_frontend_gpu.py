@@ -160,3 +160,28 @@ def test_runmicro_with_snow_on_the_bundled_site(oracle):
             assert np.array_equal(np.isnan(got[k]), np.isnan(want[k])), k
             err = np.nanmax(np.abs(got[k] - want[k]) / (1 + np.abs(want[k])))
             assert err < 1e-6, (reqhgt, k, err)
+
+
+@pytest.mark.parametrize("layered,temp", [(True, "air"), (False, "leaf")])
+def test_runbioclim_on_the_bundled_site(oracle, layered, temp):
+    """runbioclim(): fourteen modelled days -> nineteen bioclim layers, fused on the device, against the oracle's solver +
+    runbioclimCpp restatement on the same prepared call"""
+    from microclimf_amd.api import BIOCLIM_DFSEL
+    from oracle import terrain_oracle as TO
+    weather, vegp, soilc, dtm = load()
+    if not layered:
+        vegp = {k: (v[:, :, 6] if v.ndim == 3 else v) for k, v in vegp.items()}
+    sel = F.biosel(weather["obstime"], weather["temp"])
+    assert len(sel["seld"]) == 14 and len(set(np.asarray(weather["obstime"]["month"])[sel["selh"][::24][:12]])) == 12
+
+    def oracle_bioclim(lay, args, kw):
+        return oracle.run_bioclim(**args, **kw, dfsel=BIOCLIM_DFSEL if lay else None)
+    got = F.runbioclim(weather, 0.05, vegp, soilc, dtm, temp=temp)
+    want = F.runbioclim(weather, 0.05, vegp, soilc, dtm, temp=temp, _bioclim=oracle_bioclim, _terrain=TO.terrain)
+    assert list(got) == [f"bio{i}" for i in range(1, 20)]
+    na = np.isnan(F.cleanvars(vegp, soilc, dtm["z"])[2])
+    for k, w in want.items():
+        w = np.where(na, np.nan, w)
+        assert np.array_equal(np.isnan(got[k]), np.isnan(w)), k
+        np.testing.assert_allclose(got[k], w, rtol=1e-8, atol=1e-8, err_msg=k)
+    assert 5 < np.nanmean(got["bio1"]) < 25 and np.nanmin(got["bio5"]) > np.nanmax(got["bio6"])   # warmest > coldest
