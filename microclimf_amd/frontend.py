@@ -764,8 +764,6 @@ def runbioclim(climdata: Mapping, reqhgt: float, vegp: Mapping, soilc: Mapping, 
                 sidx = layer_index(dmx, nd)
                 sidx = np.concatenate([sidx, sidx[-1:]])
                 v14[k] = arr[:, :, sidx[np.clip(seld, 1, len(sidx)) - 1] - 1]      # (seld = 0 would drop the day in R)
-        with np.errstate(invalid="ignore"):
-            pass
         pa = None if pai_a is None else intr(pai_a, mp["ntme"], mp["subs"])
         v14["leafden"], v14["paia"] = foliageden(reqhgt, v14["hgt"], v14["pai"], pa)
         a["vegp"] = v14

@@ -51,3 +51,9 @@ o1 = F.runmicro(mps, 0.05, vegp, soilc, dtm)
 o2 = F.runmicro(mps, 1.0, vegp, soilc, dtm)
 print(f"two runmicro() calls on the monthly subset (50 x 50 cells x 288 h each, incl. terrain / wetness-index preparation): "
       f"{time.perf_counter() - t0:.3f} s")
+
+# runbioclim() on the bundled year (vignettes/running-microclimf.Rmd:648: "~20 seconds")
+F.runbioclim(weather, 0.05, vegp, soilc, dtm)
+t0 = time.perf_counter()
+b = F.runbioclim(weather, 0.05, vegp, soilc, dtm)
+print(f"runbioclim(), 19 layers from 14 modelled days: {time.perf_counter() - t0:.3f} s; bio1 mean {np.nanmean(b['bio1']):.2f} degC")
