@@ -550,7 +550,6 @@ def subsetpointmodel(micropoint: Mapping, tstep: str = "month", what: str = "tma
     """`subsetpointmodel` (R/dataprep.R:31-103): whole days of the point model — given 1-based `days`, or one day per
     month / year chosen by the point model's canopy temperature (`what` = tmax, tmin, tmedian)."""
     dfo, ob = micropoint["dfo"], micropoint["obstime"]
-    n = len(dfo["Tg"])
     if days is not None:
         days = np.asarray(days, dtype=np.int64)
         ai = (np.repeat((days - 1) * 24, 24) + np.tile(np.arange(24), days.size)).astype(np.int64)
@@ -591,7 +590,6 @@ def subsetpointmodel(micropoint: Mapping, tstep: str = "month", what: str = "tma
     out["subs"] = np.asarray(micropoint["subs"])[ai]
     if micropoint.get("Tbz") is not None:
         out["Tbz"] = np.asarray(micropoint["Tbz"])[ai]
-    assert n == len(micropoint["subs"]) or True
     return out
 
 
