@@ -26,7 +26,7 @@ import numpy as np
 
 from . import api, pointmodel, terrain
 from .soil_tables import SOILPARAMETERS, SOILPARAMSP
-from .synthetic import dewpoint_R as _dewpoint, satvap_R as _satvap   # .satvap / .dewpoint, R/internal.R:501-521
+from .rformulas import dewpoint_R as _dewpoint, satvap_R as _satvap   # .satvap / .dewpoint, R/internal.R:501-521
 
 WEATHER = ("temp", "relhum", "pres", "swdown", "difrad", "lwdown", "windspeed", "winddir", "precip")
 

@@ -35,24 +35,7 @@ def normal(field: int, idx: np.ndarray, seed: int = SEED) -> np.ndarray:
 
 
 # ---- R-side derived climate variables (R/internal.R:501-521) -----------------
-def satvap_R(tc):
-    tc = np.asarray(tc, dtype=np.float64)
-    es = 0.61078 * np.exp(17.27 * tc / (tc + 237.3))
-    ei = 0.61078 * np.exp(21.875 * tc / (tc + 265.5))
-    return np.where(tc < 0, ei, es)
-
-
-def dewpoint_R(ea, tc):
-    ea = np.asarray(ea, dtype=np.float64)
-    e0 = 611.2 / 1000
-    L = (2.501e6) - (2340 * tc)
-    it = 1 / 273.15 - (461.5 / L) * np.log(ea / e0)
-    tdew = 1 / it - 273.15
-    e0 = 610.78 / 1000
-    L = 2.834e6
-    it = 1 / 273.15 - (461.5 / L) * np.log(ea / e0)
-    tfrost = 1 / it - 273.15
-    return np.where(tdew < 0, tfrost, tdew)
+from .rformulas import dewpoint_R, satvap_R  # noqa: E402,F401  (the R-side formulas, also used by frontend.py)
 
 
 def solar_zenith_cos(lat, lon, year, month, day, hour):
