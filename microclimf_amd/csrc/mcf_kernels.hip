@@ -23,6 +23,10 @@
 #ifndef MCF_PIN_MATHK
 #define MCF_PIN_MATHK 2   // 0: literals re-created at every exp/log, 1: exp coefficients pinned, 2: exp and log
 #endif
+#ifndef MCF_NT_STORES
+#define MCF_NT_STORES 0   // 1 (experiment): non-temporal output stores — 13 % SLOWER same-box (6.87 vs 5.99 ms per launch):
+                          // the L2 no longer merges the partial lines neighbouring tiles write
+#endif
 #ifndef MCF_AF_WAVES
 #define MCF_AF_WAVES 3   // waves per SIMD the array-forcing kernels are built for (168 VGPRs)
 #endif
@@ -553,7 +557,11 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
 #if MCF_EXPERIMENT_NOSTORE
             if (sel != 15u && val == 1.2345e300) a.out_base[(int64_t)sel * a.out_stride + oidx] = val;
 #else
+#if MCF_NT_STORES
+            if (sel != 15u) __builtin_nontemporal_store(val, &a.out_base[(int64_t)sel * a.out_stride + oidx]);
+#else
             if (sel != 15u) a.out_base[(int64_t)sel * a.out_stride + oidx] = val;
+#endif
 #endif
         };
         // issue the loads of the next day's table rows now; they land in LDS after pass 1
