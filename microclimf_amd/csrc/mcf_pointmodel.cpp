@@ -635,11 +635,15 @@ extern "C" int mcf_man(int64_t n64, const double* x, int32_t window, double* out
     if (n64 <= 0 || n64 > INT32_MAX || !x || !out || window < 1) return mcf::api_fail(MCF_ERR_ARG, "mcf_man: bad length, window or null argument");
     const int m = (int)n64;
     Vec xv(x, x + m), z((size_t)m);
+    // the reference's circular index (i - j + m) % m leaves the array when the window is longer than the series
+    // (cpp:561-572); such calls are refused here
     if (window <= 48) {
+        if (window > m) return mcf::api_fail(MCF_ERR_ARG, "mcf_man: the window is longer than the series");
         moving_mean(xv, window, z);
     } else {
         const size_t nd = (size_t)m / 24;
-        if (nd == 0 || window / 24 < 1) return mcf::api_fail(MCF_ERR_ARG, "mcf_man: a window beyond 48 steps needs at least one whole day");
+        if (nd == 0 || (size_t)(window / 24) > nd || m < 24)
+            return mcf::api_fail(MCF_ERR_ARG, "mcf_man: the window is longer than the series");
         Vec d(nd), y(nd), zz((size_t)m, 0.0);
         for (size_t i = 0; i < nd; ++i) {
             double sum = 0.0;

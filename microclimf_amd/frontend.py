@@ -218,6 +218,10 @@ def soilbelowT(dfo: Mapping, reqhgt: float) -> np.ndarray:
     """`.soilbelowT` (R/internal.R:169-185)"""
     n = -118.35 * reqhgt / dfo["DDp"]
     nmn, nmx = int(np.floor(n.min())), int(np.ceil(n.max()))
+    # manCpp's circular mean reads outside its array when the window exceeds the series (the reference then returns
+    # whatever lies there); windows are capped at the whole days available
+    cap = max(24 * (len(n) // 24), 1) if len(n) >= 48 else len(n)
+    nmn, nmx = max(1, min(nmn, cap)), max(1, min(nmx, cap))
     Tnmn, Tnmx = pointmodel.manCpp(dfo["Tg"], nmn), pointmodel.manCpp(dfo["Tg"], nmx)
     with np.errstate(invalid="ignore", divide="ignore"):
         wgt = (n - nmn) / (nmx - nmn)

@@ -194,3 +194,16 @@ def test_random_snow_point_series_equal_oracle(oracle, i):
     assert got["iters"] == want["iters"]
     for k in ("Tc", "Tg", "sdepc", "sdepg", "sdenc", "G", "RswabsG", "RlwabsG", "tr", "umu", "sublmelt", "tempmelt", "rainmelt"):
         np.testing.assert_allclose(got[k], want[k], rtol=1e-9, atol=1e-9, err_msg=k)
+
+
+def test_man_refuses_windows_longer_than_the_series():
+    """the reference's circular index leaves the array there (cpp:561-572; found by tools/host_sanitizers.sh)"""
+    from microclimf_amd import _abi
+    x = np.arange(48.0)
+    assert PM.manCpp(x, 48)[-1] == pytest.approx(x.mean())
+    for win in (49, 72, 500):
+        with pytest.raises(_abi.McfError, match="longer than the series"):
+            PM.manCpp(x, win)
+    with pytest.raises(_abi.McfError, match="longer than the series"):
+        PM.manCpp(np.arange(10.0), 11)
+    assert np.isfinite(PM.manCpp(np.arange(240.0), 100)).all()          # 4-day mean of daily means: fine

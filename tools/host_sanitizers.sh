@@ -1,0 +1,60 @@
+#!/bin/bash
+# CPU-only: the host-side C++ of libmcfhip (point models, flow accumulation, netCDF file layer) built with
+# AddressSanitizer + UBSan — without the HIP parts — and driven over the reference-test inputs, random series and
+# rasters.  (GPU sanitizers are not available on the pool; this covers the code of the product that runs on the host.)
+set -e
+cd "$(dirname "$0")/.."
+cat > /tmp/mcf_host_stub.cpp <<'CPP'
+#include <string>
+namespace mcf { int api_fail(int code, const std::string&) { return code; } }
+CPP
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -ffp-contract=off -fPIC -shared \
+    -o /tmp/libmcfhost_asan.so microclimf_amd/csrc/mcf_pointmodel.cpp microclimf_amd/csrc/mcf_hydro.cpp /tmp/mcf_host_stub.cpp
+export LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0
+python - <<'PY'
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from microclimf_amd import _abi, pointmodel as PM, terrain as TR, synthetic
+lib = C.CDLL("/tmp/libmcfhost_asan.so")
+for name in ("mcf_bigleaf", "mcf_soilm", "mcf_pointmprocess", "mcf_weatherhgt", "mcf_man", "mcf_pointmodelsnow", "mcf_flowacc",
+             "mcf_topidx", "mcf_snowenv_from_name"):
+    if not hasattr(lib, name) and name != "mcf_snowenv_from_name":
+        raise SystemExit(f"{name} missing from the host build")
+# route the Python mirrors to the sanitizer build: give the ctypes handle the prototypes _abi sets up
+real = _abi.load()
+for name in ("mcf_bigleaf", "mcf_soilm", "mcf_pointmprocess", "mcf_weatherhgt", "mcf_man", "mcf_pointmodelsnow", "mcf_flowacc",
+             "mcf_topidx"):
+    f = getattr(lib, name)
+    f.restype, f.argtypes = getattr(real, name).restype, getattr(real, name).argtypes
+    setattr(real, name, f)                       # later calls through _abi.load() hit the ASan build
+from bundled import load
+from microclimf_amd import frontend as F
+weather, vegp, soilc, dtm = load()
+mp = F.runpointmodel(weather, -0.1, dtm, vegp, soilc)                      # BigLeaf, soilm, pointmprocess, man on the year
+cold = dict(weather, temp=weather["temp"] - 8.0)
+pm = PM.pointmodelsnow(cold["obstime"], cold, [1.0, 0.5, 0.1, 0.2], [5, 180, 50, -5, 2, 0.1, 12], "Taiga", 0.5, 20)
+rng = np.random.default_rng(0)
+for shape in ((1, 1), (1, 40), (37, 1), (50, 50), (64, 33)):
+    z = rng.uniform(0, 100, shape)
+    z[rng.random(shape) < 0.05] = np.nan
+    TR.flowaccCpp(z)
+    if min(shape) >= 1:
+        TR.topidx(z, 2.0)
+TR.flowaccCpp(np.full((5, 5), np.nan)); TR.topidx(dtm["z"], 1.0)
+for days in (1, 2, 6, 95):
+    a = synthetic.workload(2, 2, days * 24, reqhgt=0.05)
+    c = a["climdata"]
+    w = {"temp": c["temp"], "relhum": 100 * c["ea"] / c["es"], "pres": c["pres"], "swdown": c["swdown"], "difrad": c["difrad"],
+         "lwdown": c["lwdown"], "windspeed": np.maximum(c["windspeed"], 0.5), "precip": np.zeros(days * 24)}
+    PM.BigLeafCpp(a["obstime"], w, F.sortvegp_point(vegp), F.sortsoilc_point(soilc), np.full(days * 24, 0.3), 50.0, -5.0,
+                  yearG=days >= 90 or days == 1)
+    PM.weatherhgtCpp(a["obstime"], w, 2, 2, 10, 50, -5)
+    PM.pointmodelsnow(a["obstime"], w, [2, 0.5, 0.05, 0], [0, 180, 50, -5, 2, 0, 0], "Alpine", 0.5, 10)
+    for win in (1, 5, 24, 48, 49, 100):
+        try:
+            PM.manCpp(c["temp"], win)
+        except _abi.McfError:
+            assert win > days * 24 or win // 24 > days            # refused: the window is longer than the series
+print("host-side C++ through ASan + UBSan: clean")
+PY
