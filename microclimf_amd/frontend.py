@@ -223,9 +223,11 @@ def soilbelowT(dfo: Mapping, reqhgt: float) -> np.ndarray:
     cap = max(24 * (len(n) // 24), 1) if len(n) >= 48 else len(n)
     nmn, nmx = max(1, min(nmn, cap)), max(1, min(nmx, cap))
     Tnmn, Tnmx = pointmodel.manCpp(dfo["Tg"], nmn), pointmodel.manCpp(dfo["Tg"], nmx)
-    with np.errstate(invalid="ignore", divide="ignore"):
-        wgt = (n - nmn) / (nmx - nmn)
-    Tb = wgt * Tnmx + (1 - wgt) * Tnmn
+    if nmx == nmn:                                  # capped windows: one mean serves both
+        Tb = Tnmn
+    else:
+        wgt = np.clip((n - nmn) / (nmx - nmn), 0.0, 1.0)
+        Tb = wgt * Tnmx + (1 - wgt) * Tnmn
     wgt2 = 0.041596 * (reqhgt / np.mean(dfo["DDp"])) + 0.87142
     return wgt2 * Tb + (1 - wgt2) * np.mean(dfo["Tg"])
 
