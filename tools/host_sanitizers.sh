@@ -58,3 +58,37 @@ for days in (1, 2, 6, 95):
             assert win > days * 24 or win // 24 > days            # refused: the window is longer than the series
 print("host-side C++ through ASan + UBSan: clean")
 PY
+# the netCDF file layer (header-only, with its writer threads): ASan + UBSan, then ThreadSanitizer
+unset LD_PRELOAD
+cat > /tmp/mcf_nc_harness.cpp <<'CPP'
+#include "mcf_ncfile.hpp"
+#include <cstdio>
+int main() {
+    const int64_t rows = 300, cols = 200, T = 48;
+    std::vector<double> east(cols), north(rows), hours(T);
+    for (int i = 0; i < cols; ++i) east[i] = i + 0.5;
+    for (int i = 0; i < rows; ++i) north[i] = i + 0.5;
+    for (int i = 0; i < T; ++i) hours[i] = 400000.0 + i;
+    std::vector<mcf::NcVarDef> vars = {{"Tz", "Air temperature at height 0.05 m", "deg C x 100"},
+                                       {"relhum", "Relative humidity at height 0.05 m", "Percentage"},
+                                       {"Rswup", "Upward shortwave radiation", "W/m^2"}};
+    mcf::NcFile f;
+    std::string e = f.create("/tmp/mcf_nc_harness.nc", rows, cols, T, east.data(), north.data(), hours.data(), "wkt", vars);
+    if (!e.empty()) { fprintf(stderr, "%s\n", e.c_str()); return 1; }
+    std::vector<uint8_t> recs((size_t)(T * f.rec_bytes), 7);          // 48 records of 720 KB: the threaded write path
+    for (int pass = 0; pass < 2; ++pass) {
+        e = f.write_records(pass ? 0 : 24, 24, recs.data());
+        if (!e.empty()) { fprintf(stderr, "%s\n", e.c_str()); return 1; }
+    }
+    e = f.write_records(0, T, recs.data());
+    if (!e.empty() || !f.write_records(40, 20, recs.data()).size()) { fprintf(stderr, "range check failed\n"); return 1; }
+    e = f.close();
+    remove("/tmp/mcf_nc_harness.nc");
+    return e.empty() ? 0 : 1;
+}
+CPP
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -Imicroclimf_amd/csrc -pthread -o /tmp/mcf_nc_asan /tmp/mcf_nc_harness.cpp
+MCF_NC_WRITE_THREADS=4 /tmp/mcf_nc_asan
+g++ -O1 -g -std=c++17 -fsanitize=thread -Imicroclimf_amd/csrc -pthread -o /tmp/mcf_nc_tsan /tmp/mcf_nc_harness.cpp
+MCF_NC_WRITE_THREADS=4 /tmp/mcf_nc_tsan
+echo "netCDF file layer through ASan + UBSan and TSan: clean"
