@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define MCF_ABI_VERSION 1
+#define MCF_ABI_VERSION 2   /* 2: mcf_grid_inputs grew the coarse-forcing fields */
 
 /* Output variables, in the order of the reference's returned list
  * (src/microclimfCpp.cpp:2326-2335) and of its `out` logical(10). */

@@ -177,6 +177,7 @@ EXPORTS = (
     "mcf_flowacc", "mcf_topidx",
 )
 
+ABI_VERSION = 2     # include/mcf.h MCF_ABI_VERSION this mirror was written against
 _lib = None
 
 
@@ -303,7 +304,7 @@ def load() -> C.CDLL:
     lib.mcf_snowmodel1.argtypes = [C.POINTER(SnowDriverIn), C.POINTER(SnowDriverOut), C.c_int32]
     lib.mcf_precompute_terrain.restype = C.c_int
     lib.mcf_precompute_terrain.argtypes = [C.POINTER(TerrainIn), C.POINTER(TerrainOut), C.c_int32]
-    if lib.mcf_abi_version() != 1:
+    if lib.mcf_abi_version() != ABI_VERSION:
         raise McfError("libmcfhip ABI version mismatch")
     _lib = lib
     return lib

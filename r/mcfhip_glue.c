@@ -495,6 +495,8 @@ static const R_CallMethodDef CallEntries[] = {
     {NULL, NULL, 0}};
 
 void R_init_mcfhip_glue(DllInfo *dll) {
+    if (mcf_abi_version() != MCF_ABI_VERSION)      /* the glue was compiled against another include/mcf.h */
+        Rf_error("mcfhip: libmcfhip ABI version %d, glue built for %d", mcf_abi_version(), MCF_ABI_VERSION);
     R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);
     R_useDynamicSymbols(dll, FALSE);
 }

@@ -25,7 +25,7 @@ def test_header_symbols_are_exported():
     lib = C.CDLL(str(_abi.LIB_PATH))
     for name in declared:
         assert hasattr(lib, name), f"libmcfhip.so does not export {name}"
-    assert lib.mcf_abi_version() == 1
+    assert lib.mcf_abi_version() == _abi.ABI_VERSION == int(re.search(r"#define MCF_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_struct_layout_matches_header():
