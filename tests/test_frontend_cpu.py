@@ -119,3 +119,16 @@ def test_subsetpointmodel_picks_whole_days():
     a = F.prepare_grid_inputs(sub, 0.05, vegp, soilc, dtm, slr=np.zeros((50, 50)), apr=np.zeros((50, 50)),
                               hor=np.zeros((50, 50, 24)), svf=np.ones((50, 50)), wsa=np.ones((50, 50, 8)))
     assert not a["complete"] and len(a["dfsel"]["st"]) == 12 and a["dfsel"]["ed"][-1] == 287
+
+
+def test_tall_vegetation_lifts_the_reference_height():
+    """runpointmodel's weather height adjustment (R/Cppwrappers.R:93-116): vegetation above 2 m moves zref to the canopy top
+    and carries temperature, humidity and wind there with weatherhgtCpp"""
+    weather, vegp, soilc, dtm = load(10 * 24)
+    tall = dict(vegp, hgt=np.where(np.isnan(vegp["hgt"]), np.nan, vegp["hgt"] * 4.0))      # up to 8 m
+    mp = F.runpointmodel(weather, 0.05, dtm, tall, soilc)
+    assert mp["zref"] == pytest.approx(np.nanmax(tall["hgt"])) and mp["zref"] > 2.0
+    assert np.isfinite(mp["weather"]["temp"]).all() and not np.allclose(mp["weather"]["temp"], weather["temp"])
+    assert (mp["weather"]["windspeed"] >= np.maximum(weather["windspeed"], 0.5) - 1e-9).all()   # wind grows with height
+    low = F.runpointmodel(weather, 0.05, dtm, vegp, soilc)
+    assert low["zref"] == 2.0 and np.array_equal(low["weather"]["temp"], weather["temp"])
