@@ -287,6 +287,9 @@ def prepare_grid_inputs(micropoint: Mapping, reqhgt: float, vegp: Mapping, soilc
     returns the keyword arguments of runmicro1Cpp, plus `dfsel` when the vegetation varies in time."""
     res = dtm["res"]
     xres, yres = (res, res) if np.isscalar(res) else res
+    if xres != yres:
+        raise ValueError("the horizon / wind-shelter pre-compute works on z / res with one resolution, as the reference's "
+                         ".horizon does (R/internal.R:909-925): square cells only")
     veg, soil, z = cleanvars(vegp, soilc, dtm["z"])
     w = micropoint["weather"]
     clim = {k: np.asarray(w[k], dtype=np.float64) for k in ("temp", "pres", "swdown", "difrad", "lwdown", "windspeed", "winddir")}
