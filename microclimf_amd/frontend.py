@@ -790,3 +790,69 @@ def runbioclim(climdata: Mapping, reqhgt: float, vegp: Mapping, soilc: Mapping, 
     for v in res.values():
         v[na] = np.nan                                                          # mask(bior, dtm)
     return res
+
+
+# ---- runmicro_big(): tiles of a large raster, one netCDF file each ---------------------------------------------------
+def tile_size(nt: int, toverlap: int = 0) -> int:
+    """the reference's automatic tile size (R/Cppwrappers.R:469-471): about 2e7 cell-steps per tile"""
+    osize = np.sqrt(20000000 / nt) - 2 * toverlap
+    sizeo = np.array([10, 20, 50, 100, 200, 500, 1000, 2000])
+    return int(sizeo[np.argmin(np.abs(osize - sizeo))])
+
+
+def tile_window(rw: int, cl: int, rows: int, cols: int, tilesize: int, toverlap: int):
+    """`.croprast` (R/internal.R:1663-1676) in cell indices for unit-free overlap (the reference subtracts `toverlap` in
+    map units): rows [r0, r1), cols [c0, c1) of tile (rw, cl), 1-based tile numbers, clipped to the raster"""
+    r0, r1 = max((rw - 1) * tilesize - toverlap, 0), min(rw * tilesize + toverlap, rows)
+    c0, c1 = max((cl - 1) * tilesize - toverlap, 0), min(cl * tilesize + toverlap, cols)
+    return r0, r1, c0, c1
+
+
+def runmicro_big(micropoint: Mapping, reqhgt: float, pathout: str, vegp: Mapping, soilc: Mapping, dtm: Mapping, *,
+                 tilesize: int | None = None, toverlap: int = 0, pai_a=None, tfact: float = 1.5,
+                 vars: Sequence[str] | None = None, days_per_chunk: int = 5, device: int = 0) -> list:
+    """`runmicro_big(micropoint, reqhgt, pathout, vegp, soilc, dtm, ..., writeasnc = TRUE)` for data.frame weather
+    (R/Cppwrappers.R:446-541): slope, aspect, wetness index, horizons, sky view and wind shelter once for the WHOLE raster
+    (wind shelter from the surface model dtm + hgt at 8 m, as there), then tile by tile the solver and
+    `microut/area_RR_CC.nc`.  Each tile is solved in day chunks straight into its file (`pipeline.run_to_nc`): no tile's
+    output ever exists on the host, and the tile size is only a file layout — the default keeps the reference's.
+    `dtm` needs "xmin", "ymax" besides "z" / "res" / "lat" / "long" for the files' coordinates.  Returns the files written.
+    (In the reference this function stops at an undefined `svfi`, R/Cppwrappers.R:520; what it sets out to do is done.)"""
+    import os
+    from . import pipeline
+    if reqhgt < 0:
+        raise ValueError("below ground the whole series has to be resident: use runmicro() per tile and writetonc()")
+    z_all = np.asarray(dtm["z"], dtype=np.float64)
+    rows, cols = z_all.shape
+    res = dtm["res"] if np.isscalar(dtm["res"]) else dtm["res"][0]
+    nt = len(micropoint["weather"]["temp"])
+    ts = tile_size(nt, toverlap) if tilesize is None else int(tilesize)
+    os.makedirs(os.path.join(pathout, "microut"), exist_ok=True)
+    # universal variables, R/Cppwrappers.R:482-499
+    ter = terrain.precompute_terrain(z_all, res, micropoint["zref"], what=("slope", "aspect", "hor", "svfa"), device=device)
+    slr, apr = ter["slope"], ter["aspect"]
+    slr[np.isnan(z_all)] = np.nan
+    apr[np.isnan(z_all)] = np.nan
+    twi = terrain.topidx(z_all, res)
+    dsm = z_all + np.nan_to_num(as3d(vegp["hgt"])[:, :, 0], nan=0.0)
+    wsa = terrain.precompute_terrain(dsm, res, 8.0, what=("wsa",), device=device)["wsa"]
+    written = []
+    for rw in range(1, -(-rows // ts) + 1):
+        for cl in range(1, -(-cols // ts) + 1):
+            r0, r1, c0, c1 = tile_window(rw, cl, rows, cols, ts, toverlap)
+            zi = z_all[r0:r1, c0:c1]
+            if np.count_nonzero(~np.isnan(zi)) <= 1:
+                continue
+            crop = lambda a: np.asarray(a)[r0:r1, c0:c1]                           # noqa: E731
+            dtmi = dict(dtm, z=zi)
+            a = prepare_grid_inputs(micropoint, reqhgt, {k: crop(v) for k, v in vegp.items()},
+                                    {k: crop(v) for k, v in soilc.items()}, dtmi, pai_a=None if pai_a is None else crop(pai_a),
+                                    slr=crop(slr), apr=crop(apr), hor=crop(ter["hor"]), twi=crop(twi), wsa=crop(wsa),
+                                    svf=crop(ter["svfa"]), device=device)
+            a["tfact"] = float(tfact)
+            fo = os.path.join(pathout, "microut", f"area_{rw:02d}_{cl:02d}.nc")
+            ext = {"xmin": dtm["xmin"] + c0 * res, "xmax": dtm["xmin"] + c1 * res, "ymin": dtm["ymax"] - r1 * res,
+                   "ymax": dtm["ymax"] - r0 * res, "res": res, "crs": dtm.get("crs", "")}
+            pipeline.run_to_nc(a, fo, ext, vars=vars, days_per_chunk=days_per_chunk, device=device)
+            written.append(fo)
+    return written

@@ -20,7 +20,8 @@ def run_to_nc(inputs: Mapping, fileout: str, dtm: Mapping, *, vars: Sequence[str
               days_per_chunk: int = 5, device: int = 0, array_forcing: bool = False,
               reference_puts_only: bool = False, twi_mean: float | None = None) -> dict:
     """`inputs`: the 15 arguments of runmicro1Cpp / runmicro2Cpp by name (as `synthetic.workload` returns them);
-    `dtm`: {"xmin","xmax","ymin","ymax","res"[, "crs"]} of the tile.  Variables default to writetonc's for the height.
+    with "dfsel" added for time-varying vegetation (runmicro3Cpp); `dtm`: {"xmin","xmax","ymin","ymax","res"[, "crs"]} of
+    the tile.  Variables default to writetonc's for the height.
     `twi_mean`: the raster-wide mean of log(twi)/tfact when this tile is part of a larger raster
     (`distributed.allreduce_twi_mean`).  Returns timings and sizes."""
     reqhgt = float(inputs["reqhgt"])

@@ -185,3 +185,42 @@ def test_runbioclim_on_the_bundled_site(oracle, layered, temp):
         assert np.array_equal(np.isnan(got[k]), np.isnan(w)), k
         np.testing.assert_allclose(got[k], w, rtol=1e-8, atol=1e-8, err_msg=k)
     assert 5 < np.nanmean(got["bio1"]) < 25 and np.nanmin(got["bio5"]) > np.nanmax(got["bio6"])   # warmest > coldest
+
+
+def test_runmicro_big_writes_one_file_per_tile(oracle, tmp_path):
+    """runmicro_big(): universal terrain once, then every tile solved in day chunks straight into microut/area_RR_CC.nc — the
+    files against the oracle on the same prepared tile call, packed as writetonc packs"""
+    from scipy.io import netcdf_file
+    from microclimf_amd import terrain
+    weather, vegp, soilc, dtm = load(4 * 24)
+    dtm = dict(dtm, xmin=float(dtm["extent"][0]), ymax=float(dtm["extent"][3]))
+    mp = F.runpointmodel(weather, 0.05, dtm, vegp, soilc)
+    files = F.runmicro_big(mp, 0.05, str(tmp_path), vegp, soilc, dtm, tilesize=20, toverlap=3, vars=("Tz", "relhum", "Rswup"),
+                           days_per_chunk=3)
+    assert [f.split("/")[-1] for f in files] == [f"area_{r:02d}_{c:02d}.nc" for r in (1, 2, 3) for c in (1, 2, 3)]
+    assert F.tile_size(8760) == 50 and F.tile_size(288) == 200                      # the reference's automatic sizes
+    # one interior tile and one corner tile against the oracle
+    z = np.asarray(dtm["z"])
+    ter = terrain.precompute_terrain(z, dtm["res"], mp["zref"], what=("slope", "aspect", "hor", "svfa"))
+    twi = terrain.topidx(z, dtm["res"])
+    wsa = terrain.precompute_terrain(z + np.nan_to_num(vegp["hgt"], nan=0.0), dtm["res"], 8.0, what=("wsa",))["wsa"]
+    for rw, cl in ((2, 2), (3, 1)):
+        r0, r1, c0, c1 = F.tile_window(rw, cl, 50, 50, 20, 3)
+        crop = lambda a: np.asarray(a)[r0:r1, c0:c1]                               # noqa: E731
+        slr, apr = ter["slope"].copy(), ter["aspect"].copy()
+        slr[np.isnan(z)] = np.nan
+        apr[np.isnan(z)] = np.nan
+        a = F.prepare_grid_inputs(mp, 0.05, {k: crop(v) for k, v in vegp.items()}, {k: crop(v) for k, v in soilc.items()},
+                                  dict(dtm, z=crop(z)), slr=crop(slr), apr=crop(apr), hor=crop(ter["hor"]), twi=crop(twi),
+                                  wsa=crop(wsa), svf=crop(ter["svfa"]))
+        want = oracle.run_grid(**a)
+        f = netcdf_file(str(tmp_path / "microut" / f"area_{rw:02d}_{cl:02d}.nc"), "r", mmap=False)
+        assert f.variables["Tz"].shape == (96, r1 - r0, c1 - c0)
+        assert f.variables["east"][0] == dtm["xmin"] + c0 + 0.5
+        for k, sc in (("Tz", 100), ("relhum", 1), ("Rswup", 1)):
+            got = np.transpose(f.variables[k][:], (2, 1, 0)).astype(np.int64)
+            with np.errstate(invalid="ignore"):
+                w = np.rint(np.transpose(want[k], (1, 0, 2)) * sc)
+            w = np.where(np.isfinite(w), w, -9999).astype(np.int64)
+            assert np.abs(got - w).max() <= 1 and (got != w).mean() < 1e-3, (rw, cl, k)
+        f.close()
