@@ -810,13 +810,16 @@ def tile_window(rw: int, cl: int, rows: int, cols: int, tilesize: int, toverlap:
 
 def runmicro_big(micropoint: Mapping, reqhgt: float, pathout: str, vegp: Mapping, soilc: Mapping, dtm: Mapping, *,
                  tilesize: int | None = None, toverlap: int = 0, pai_a=None, tfact: float = 1.5,
-                 vars: Sequence[str] | None = None, days_per_chunk: int = 5, device: int = 0) -> list:
+                 vars: Sequence[str] | None = None, days_per_chunk: int = 5, device: int = 0, rank: int = 0,
+                 world: int = 1) -> list:
     """`runmicro_big(micropoint, reqhgt, pathout, vegp, soilc, dtm, ..., writeasnc = TRUE)` for data.frame weather
     (R/Cppwrappers.R:446-541): slope, aspect, wetness index, horizons, sky view and wind shelter once for the WHOLE raster
     (wind shelter from the surface model dtm + hgt at 8 m, as there), then tile by tile the solver and
     `microut/area_RR_CC.nc`.  Each tile is solved in day chunks straight into its file (`pipeline.run_to_nc`): no tile's
     output ever exists on the host, and the tile size is only a file layout — the default keeps the reference's.
     `dtm` needs "xmin", "ymax" besides "z" / "res" / "lat" / "long" for the files' coordinates.  Returns the files written.
+    With `world` > 1 (one process per GPU) the tiles are dealt round-robin: tile k goes to rank k % world; the universal
+    variables are computed by every rank (seconds), no exchange is needed.
     (In the reference this function stops at an undefined `svfi`, R/Cppwrappers.R:520; what it sets out to do is done.)"""
     import os
     from . import pipeline
@@ -837,11 +840,15 @@ def runmicro_big(micropoint: Mapping, reqhgt: float, pathout: str, vegp: Mapping
     dsm = z_all + np.nan_to_num(as3d(vegp["hgt"])[:, :, 0], nan=0.0)
     wsa = terrain.precompute_terrain(dsm, res, 8.0, what=("wsa",), device=device)["wsa"]
     written = []
+    k_tile = 0
     for rw in range(1, -(-rows // ts) + 1):
         for cl in range(1, -(-cols // ts) + 1):
             r0, r1, c0, c1 = tile_window(rw, cl, rows, cols, ts, toverlap)
             zi = z_all[r0:r1, c0:c1]
             if np.count_nonzero(~np.isnan(zi)) <= 1:
+                continue
+            k_tile += 1
+            if (k_tile - 1) % world != rank:
                 continue
             crop = lambda a: np.asarray(a)[r0:r1, c0:c1]                           # noqa: E731
             dtmi = dict(dtm, z=zi)

@@ -199,6 +199,14 @@ def test_runmicro_big_writes_one_file_per_tile(oracle, tmp_path):
                            days_per_chunk=3)
     assert [f.split("/")[-1] for f in files] == [f"area_{r:02d}_{c:02d}.nc" for r in (1, 2, 3) for c in (1, 2, 3)]
     assert F.tile_size(8760) == 50 and F.tile_size(288) == 200                      # the reference's automatic sizes
+    # dealt to two ranks: disjoint, complete, byte-identical files
+    parts = [F.runmicro_big(mp, 0.05, str(tmp_path / f"r{r}"), vegp, soilc, dtm, tilesize=20, toverlap=3, vars=("Tz", "relhum", "Rswup"),
+                            days_per_chunk=3, rank=r, world=2) for r in (0, 1)]
+    names = [sorted(f.split("/")[-1] for f in p) for p in parts]
+    assert len(names[0]) == 5 and len(names[1]) == 4 and sorted(names[0] + names[1]) == sorted(f.split("/")[-1] for f in files)
+    for p in parts:
+        for f in p:
+            assert open(f, "rb").read() == open(str(tmp_path / "microut" / f.split("/")[-1]), "rb").read()
     # one interior tile and one corner tile against the oracle
     z = np.asarray(dtm["z"])
     ter = terrain.precompute_terrain(z, dtm["res"], mp["zref"], what=("slope", "aspect", "hor", "svfa"))
