@@ -1,0 +1,36 @@
+"""A whole year value by value: the HIP path against the oracle on 96 x 96 cells x 8760 h (8 x 10^7 cell-steps, all ten
+outputs; the oracle needs about a minute on one core).  python tools/year_parity.py [--rows 96 --cols 96]"""
+import argparse
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from microclimf_amd import synthetic  # noqa: E402
+from microclimf_amd.api import runmicro1Cpp  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", type=int, default=96)
+ap.add_argument("--cols", type=int, default=96)
+ap.add_argument("--reqhgt", type=float, default=0.05)
+a = ap.parse_args()
+w = synthetic.workload(a.rows, a.cols, 8760, reqhgt=a.reqhgt, variety=True, na_frac=0.02)
+t0 = time.perf_counter()
+got = runmicro1Cpp(**w)
+t1 = time.perf_counter()
+want = O.run_grid(**w)
+t2 = time.perf_counter()
+print(f"{a.rows} x {a.cols} x 8760, reqhgt {a.reqhgt}: HIP one-shot {t1 - t0:.2f} s, oracle {t2 - t1:.1f} s")
+worst = 0.0
+for k, x in want.items():
+    g = got[k]
+    assert np.array_equal(np.isnan(g), np.isnan(x)), k
+    fin = np.isfinite(x)
+    e = float((np.abs(g[fin] - x[fin]) / (1 + np.abs(x[fin]))).max()) if fin.any() else 0.0
+    worst = max(worst, e)
+    print(f"  {k:10s} max scaled |HIP - oracle| = {e:.3e} over {int(fin.sum())} values")
+print(f"worst {worst:.3e}")
+assert worst < 1e-6
