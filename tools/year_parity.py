@@ -16,14 +16,31 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=96)
 ap.add_argument("--cols", type=int, default=96)
 ap.add_argument("--reqhgt", type=float, default=0.05)
+ap.add_argument("--coarse", type=str, default="", help="CRxCC: coarse array forcing against expand-then-solve through the oracle")
 a = ap.parse_args()
-w = synthetic.workload(a.rows, a.cols, 8760, reqhgt=a.reqhgt, variety=True, na_frac=0.02)
-t0 = time.perf_counter()
-got = runmicro1Cpp(**w)
-t1 = time.perf_counter()
-want = O.run_grid(**w)
-t2 = time.perf_counter()
-print(f"{a.rows} x {a.cols} x 8760, reqhgt {a.reqhgt}: HIP one-shot {t1 - t0:.2f} s, oracle {t2 - t1:.1f} s")
+if a.coarse:
+    from microclimf_amd.api import runmicro2Cpp_coarse
+    from oracle import coarse_oracle as CO
+    cr, cc = (int(v) for v in a.coarse.split("x"))
+    w, rp, cp = synthetic.coarse_workload(a.rows, a.cols, 8760, cr, cc, reqhgt=a.reqhgt, variety=True, na_frac=0.02)
+    order = ("obstime", "climdata", "pointm", "vegp", "soilc", "reqhgt", "zref", "lat", "lon", "Sminp", "Smaxp", "tfact", "complete",
+             "mat", "out")
+    t0 = time.perf_counter()
+    got = runmicro2Cpp_coarse(*[w[k] for k in order], rowpos=rp, colpos=cp)
+    t1 = time.perf_counter()
+    clim, pm = CO.expand(w["climdata"], w["pointm"], rp, cp)
+    b = dict(w)
+    b.update(climdata=clim, pointm=pm)
+    want = O.run_grid(**b, array_forcing=True)
+    t2 = time.perf_counter()
+else:
+    w = synthetic.workload(a.rows, a.cols, 8760, reqhgt=a.reqhgt, variety=True, na_frac=0.02)
+    t0 = time.perf_counter()
+    got = runmicro1Cpp(**w)
+    t1 = time.perf_counter()
+    want = O.run_grid(**w)
+    t2 = time.perf_counter()
+print(f"{a.rows} x {a.cols} x 8760, reqhgt {a.reqhgt}{', coarse ' + a.coarse if a.coarse else ''}: HIP one-shot {t1 - t0:.2f} s, oracle {t2 - t1:.1f} s")
 worst = 0.0
 for k, x in want.items():
     g = got[k]
