@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--cols", type=int, default=1024)
     ap.add_argument("--tsteps", type=int, default=8760)
     ap.add_argument("--reqhgt", type=float, default=0.05)
-    ap.add_argument("--ring-days", type=int, default=5)
+    ap.add_argument("--ring-days", type=int, default=10)
     ap.add_argument("--ring-slots", type=int, default=2)
     ap.add_argument("--cells-per-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -247,13 +247,17 @@ def main():
         # come from the committed PMC summary of this kernel (SQ_INSTS_VALU); the peak is one wave-instruction per
         # 4 cycles per SIMD at the 2.4 GHz nominal clock (256 CUs x 4 SIMDs)
         valu = None
-        pf = ROOT / "profiles" / "r01h_pmc_summary.json"
-        if pf.exists() and not coarse and not af:
+        try:
+            ptag = json.loads(tf.read_text()).get("tag") if tf.exists() else None
+        except Exception:
+            ptag = None
+        pf = ROOT / "profiles" / f"{ptag}_pmc_summary.json"
+        if ptag and pf.exists() and not coarse and not af:
             try:
                 pj = json.loads(pf.read_text())
-                per_cs = pj["per_launch_mean"]["SQ_INSTS_VALU"] * 64.0 / (1038103 * 120)
+                per_cs = pj["per_launch_mean"]["SQ_INSTS_VALU"] * 64.0 / pj.get("cell_steps_per_launch", 1038103 * 120)
                 valu = {"insts_per_cell_step": per_cs, "frac_of_issue_peak": per_cs * (value / world) / 64.0 / (1024 * 2.4e9 / 4),
-                        "busy_fraction_measured": pj.get("valu_busy_fraction"), "source": "profiles/r01h_pmc_summary.json"}
+                        "busy_fraction_measured": pj.get("valu_busy_fraction"), "source": f"profiles/{ptag}_pmc_summary.json"}
             except Exception:
                 valu = None
         line = {

@@ -40,14 +40,26 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc"):
     ds = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(kt))
           if "k_solve" in r["Kernel_Name"]]
     dur[d] = sum(ds) / len(ds)
-summary = {"kernel": "k_solve<21,false,false>", "per_launch_mean": pmc, "avg_launch_ms_under_pmc": dur,
-           "command": "python3 bench.py --tsteps 1200 --steps 1 --warmup 0 --no-cpu-baseline (5-day launches)"}
+# days per launch: from the bench line written during the profiled run ("HBM ring (2 slots x N days)")
+import re
+ring_days, valid_cells = 5, 1038103
+bj = dst / f"{tag}_bench_under_rocprof.json"
+if bj.exists():
+    try:
+        cfg = json.loads(bj.read_text())["config"]
+        ring_days = int(re.search(r"x (\d+) days", cfg["sink"]).group(1))
+        valid_cells = int(cfg["valid_cells"])
+    except Exception:
+        pass
+summary = {"kernel": "k_solve<21,0,false>", "per_launch_mean": pmc, "avg_launch_ms_under_pmc": dur,
+           "ring_days": ring_days, "cell_steps_per_launch": valid_cells * ring_days * 24,
+           "command": f"python3 bench.py --tsteps 1200 --steps 1 --warmup 0 --no-cpu-baseline ({ring_days}-day launches)"}
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     fetch_b = pmc["FETCH_SIZE"] * 1024 * 2       # gfx950: FETCH_SIZE reports half of a coalesced stream
     write_b = pmc["WRITE_SIZE"] * 1024
     summary["hbm_bytes_per_launch"] = {"read": fetch_b, "write": write_b, "total": fetch_b + write_b}
     (dst / "traffic.json").write_text(json.dumps({
-        "rows": 1024, "cols": 1024, "ring_days": 5, "tag": tag,
+        "rows": 1024, "cols": 1024, "ring_days": ring_days, "tag": tag,
         "hbm_bytes_per_launch": fetch_b + write_b, "read_bytes": fetch_b, "write_bytes": write_b,
         "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KB -> B; FETCH_SIZE x2 (gfx950)"},
         indent=1))
