@@ -132,3 +132,17 @@ def test_tall_vegetation_lifts_the_reference_height():
     assert (mp["weather"]["windspeed"] >= np.maximum(weather["windspeed"], 0.5) - 1e-9).all()   # wind grows with height
     low = F.runpointmodel(weather, 0.05, dtm, vegp, soilc)
     assert low["zref"] == 2.0 and np.array_equal(low["weather"]["temp"], weather["temp"])
+
+
+def test_known_answer_from_the_reference_vignette_hottest_hour():
+    """vignettes/running-microclimf.Rmd:121 — "Plot air temperatures on hottest hour in micropoint (2017-06-20 13:00:00 UTC)":
+    `mout_mx$Tz[,,134]` of the `tstep = "month", what = "tmax"` subset.  The point model (BigLeafCpp's canopy temperature)
+    and subsetpointmodel reproduce that date and hour on the bundled data — a published answer of the reference itself."""
+    weather, vegp, soilc, dtm = load()
+    mp = F.runpointmodel(weather, 0.05, dtm, vegp, soilc)
+    mx = F.subsetpointmodel(mp, tstep="month", what="tmax")
+    ob = mx["obstime"]
+    k = 133
+    assert (int(ob["year"][k]), int(ob["month"][k]), int(ob["day"][k]), int(ob["hour"][k])) == (2017, 6, 20, 13)
+    tc = mx["dfo"]["Tc"]
+    assert int(np.argmax(tc)) == k                                       # and it is the hottest hour of the whole subset

@@ -232,3 +232,21 @@ def test_runmicro_big_writes_one_file_per_tile(oracle, tmp_path):
             w = np.where(np.isfinite(w), w, -9999).astype(np.int64)
             assert np.abs(got - w).max() <= 1 and (got != w).mean() < 1e-3, (rw, cl, k)
         f.close()
+
+
+def test_vignette_quick_start_maps_match_the_published_figure():
+    """vignettes/images/image1a.png of the reference: air temperature 5 cm above ground on the hottest hour (colour scale
+    about 26 .. 53 degC) and the mean of the monthly maximum and minimum days (about 10.2 .. 14.1 degC), with the no-data
+    block in the south-west corner — the quick start of vignettes/running-microclimf.Rmd:113-126 run through the front end"""
+    weather, vegp, soilc, dtm = load()
+    mp = F.runpointmodel(weather, 0.05, dtm, vegp, soilc)
+    mx, mn = F.subsetpointmodel(mp, what="tmax"), F.subsetpointmodel(mp, what="tmin")
+    tmx, tmn = F.runmicro(mx, 0.05, vegp, soilc, dtm)["Tz"], F.runmicro(mn, 0.05, vegp, soilc, dtm)["Tz"]
+    hot = tmx[:, :, 133]
+    mairt = ((tmn + tmx) / 2).mean(axis=2)
+    assert 24.0 < np.nanmin(hot) < 28.0 and 51.0 < np.nanmax(hot) < 55.0
+    assert 9.8 < np.nanmin(mairt) < 10.6 and 13.8 < np.nanmax(mairt) < 14.3
+    na = np.isnan(hot)
+    assert na.sum() == 128 and na[38:, :12].mean() > 0.8                  # the white block of the figure
+    # the shaded gully of the figure (x about 18..22, y about 3..17) is the coolest part of the hot map
+    assert np.nanmean(hot[33:47, 18:22]) < np.nanmean(hot) - 4.0
