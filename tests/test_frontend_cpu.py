@@ -146,3 +146,10 @@ def test_known_answer_from_the_reference_vignette_hottest_hour():
     assert (int(ob["year"][k]), int(ob["month"][k]), int(ob["day"][k]), int(ob["hour"][k])) == (2017, 6, 20, 13)
     tc = mx["dfo"]["Tc"]
     assert int(np.argmax(tc)) == k                                       # and it is the hottest hour of the whole subset
+    # vignettes/images/image1b.png (the point model's Tc and Tg over 2017, axis -5 .. 50): the canopy trace peaks just
+    # above 50 degC in late June and dips to about -1.7 degC in early February
+    full = mp["dfo"]["Tc"]
+    assert 50.0 < full.max() < 51.5 and -2.2 < full.min() < -1.2
+    mon = np.asarray(mp["obstime"]["month"])
+    assert mon[int(np.argmax(full))] == 6 and mon[int(np.argmin(full))] in (1, 2)
+    assert mp["dfo"]["Tg"].max() < full.max()                           # the ground trace stays under the canopy trace

@@ -250,3 +250,20 @@ def test_vignette_quick_start_maps_match_the_published_figure():
     assert na.sum() == 128 and na[38:, :12].mean() > 0.8                  # the white block of the figure
     # the shaded gully of the figure (x about 18..22, y about 3..17) is the coolest part of the hot map
     assert np.nanmean(hot[33:47, 18:22]) < np.nanmean(hot) - 4.0
+
+
+def test_vignette_bioclim_map_matches_the_published_figure():
+    """vignettes/images/image11.png: `runbioclim(climdata, 0.05, vegp, soilc, dtm, temp = "air")[[12]]` — soil moisture
+    between about 0.389 and 0.419 (the modal soil's Smax), dry hill tops, and the uniform band along the raster edge where
+    `.topidx` replaces the undefined edge slopes by their median"""
+    weather, vegp, soilc, dtm = load()
+    b12 = F.runbioclim(weather, 0.05, vegp, soilc, dtm, temp="air")["bio12"]
+    assert 0.386 < np.nanmin(b12) < 0.392 and 0.4180 < np.nanmax(b12) <= 0.4190
+    assert np.isnan(b12).sum() == 128
+    # the driest spots of the figure are three hill tops: near (x, y) = (169507, 12522), (169496, 12489), (169494, 12479)
+    r, c = np.unravel_index(np.nanargmin(np.where(np.isnan(b12), 9, b12)), b12.shape)
+    assert any(abs(r - rr) <= 4 and abs(c - cc) <= 4 for rr, cc in ((2, 32), (35, 21), (45, 19))), (r, c)
+    for rr, cc in ((2, 32), (35, 21), (45, 19)):
+        assert np.nanmin(b12[max(rr - 3, 0):rr + 4, cc - 3:cc + 4]) < 0.398                 # each of them is dry
+    edge = np.concatenate([b12[0, 15:], b12[15:38, -1]])
+    assert np.nanstd(edge) < 0.004 and abs(np.nanmean(edge) - 0.4065) < 0.004     # the green band
