@@ -267,3 +267,25 @@ def test_vignette_bioclim_map_matches_the_published_figure():
         assert np.nanmin(b12[max(rr - 3, 0):rr + 4, cc - 3:cc + 4]) < 0.398                 # each of them is dry
     edge = np.concatenate([b12[0, 15:], b12[15:38, -1]])
     assert np.nanstd(edge) < 0.004 and abs(np.nanmean(edge) - 0.4065) < 0.004     # the green band
+
+
+def test_vignette_snow_curves_match_the_published_figure():
+    """vignettes/images/image14a.png (running-microclimf.Rmd:685-703): `climdata$temp - 12`, `runsnowmodel(..., snowenv =
+    "Maritime")` over 2017 — mean snow water equivalent peaking near 190 mm and mean depth near 0.53 m in early April, the
+    pack gone by early June, and about 115 mm / 0.34 m again on 31 December"""
+    weather, vegp, soilc, dtm = load()
+    cold = dict(weather, temp=weather["temp"] - 12.0)
+    mp = F.runpointmodel(cold, 0.05, dtm, vegp, soilc)
+    smod = F.runsnowmodel(cold, mp, vegp, soilc, dtm, snowenv="Maritime")
+    with np.errstate(invalid="ignore", divide="ignore"):
+        swe = np.nanmean(smod["totalSWE"], axis=(0, 1))
+        depth = np.nanmean(smod["totalSWE"] / smod["snowden"], axis=(0, 1))
+    ob = weather["obstime"]
+    k = int(np.argmax(swe))
+    assert 180 < swe[k] < 200 and (int(ob["month"][k]), int(ob["day"][k])) in [(3, d) for d in range(28, 32)] + [(4, d) for d in range(1, 9)]
+    assert 0.50 < np.nanmax(depth) < 0.57
+    assert 105 < swe[-1] < 120 and 0.31 < depth[-1] < 0.36
+    june = (ob["month"] == 6) & (ob["day"] >= 10) & (ob["day"] <= 25)
+    assert swe[june].max() < 5.0                                           # bare ground in mid June
+    may1 = int(np.nonzero((ob["month"] == 5) & (ob["day"] == 1))[0][0])
+    assert 70 < swe[may1] < 110                                            # the melt shoulder of the published curve
