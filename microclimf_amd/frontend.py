@@ -514,8 +514,9 @@ def sortl(vegp, sdep):
 
 def runsnowmodel(weather: Mapping, micropoint: Mapping, vegp: Mapping, soilc: Mapping, dtm: Mapping, *,
                  snowenv: str = "Taiga", snowinitd=0.0, snowinita=0.0, stfact: float = 0.01, device: int = 0) -> dict:
-    """`runsnowmodel(weather, micropoint, vegp, soilc, dtm, ...)` for data.frame weather and a complete (not subset)
-    micropoint (R/Cppwrappers.R:717-731 -> `.snowmodel1`, R/internal.R:2498-2619): weather height adjustment, the
+    """`runsnowmodel(weather, micropoint, vegp, soilc, dtm, ..., method = "slow")` for data.frame weather
+    (R/Cppwrappers.R:717-731 -> `.snowmodel1`, R/internal.R:2498-2619; `weather` is always the complete hourly series, a
+    subset micropoint only selects which steps come back): weather height adjustment, the
     snow point model (host C++), `.sortl`, then the 5-day chunk loop on the device (terrain refresh from dtm + snow,
     gridmodelsnow1, `.tpicalc` redistribution, hand-over).  Returns Tc, Tg, groundsnowdepth, totalSWE, snowden, umu."""
     from . import snow as S
@@ -547,6 +548,8 @@ def runsnowmodel(weather: Mapping, micropoint: Mapping, vegp: Mapping, soilc: Ma
     clim = {k: w[k] for k in ("temp", "relhum", "pres", "swdown", "difrad", "lwdown", "windspeed", "winddir", "precip")}
     out = S.snowmodel1_chunks(hour_int, clim, pointm, vg, other, snowenv, z, xres, stfact, device=device)
     out["umu"] = pmod["umu"]
+    if len(micropoint["subs"]) != micropoint["ntme"]:                  # method = "slow": the full model, then its subset
+        out = subsetsnowmodel(out, micropoint["subs"])
     return out
 
 
