@@ -289,3 +289,32 @@ def test_vignette_snow_curves_match_the_published_figure():
     assert swe[june].max() < 5.0                                           # bare ground in mid June
     may1 = int(np.nonzero((ob["month"] == 5) & (ob["day"] == 1))[0][0])
     assert 70 < swe[may1] < 110                                            # the melt shoulder of the published curve
+
+
+def test_vignette_component_maps_match_the_published_colour_scales():
+    """vignettes/images/image2, 3b, 4, 5 (running-microclimf.Rmd:322-395; drawn there with the R-language model path on
+    the monthly-maximum subset): soil moisture 0.13 .. 0.41 on the hottest hour, downward short wave ~50 .. 950 and upward
+    ~10 .. 285 W/m2 at 10:00 on 20 June, wind speed ~0.15 .. 3.15 m/s at step 100, soil surface temperature ~25 .. 59 degC"""
+    weather, vegp, soilc, dtm = load()
+    mx = F.subsetpointmodel(F.runpointmodel(weather, 0.05, dtm, vegp, soilc), what="tmax")
+    m = F.runmicro(mx, 0.05, vegp, soilc, dtm)
+    tg = F.runmicro(mx, 0.0, vegp, soilc, dtm)["Tz"][:, :, 133]
+    with np.errstate(invalid="ignore"):
+        down = (m["Rdirdown"] + m["Rdifdown"])[:, :, 130]
+    rng = lambda a: (float(np.nanmin(a)), float(np.nanmax(a)))          # noqa: E731
+    lo, hi = rng(m["soilm"][:, :, 133])
+    assert 0.125 < lo < 0.145 and 0.40 < hi < 0.42
+    lo, hi = rng(down)
+    assert 30 < lo < 70 and 940 < hi < 955
+    lo, hi = rng(m["Rswup"][:, :, 130])
+    assert 5 < lo < 20 and 278 < hi < 292
+    lo, hi = rng(m["windspeed"][:, :, 99])
+    assert 0.12 < lo < 0.20 and 3.10 < hi < 3.20
+    lo, hi = rng(tg)
+    assert 24.0 < lo < 26.5 and 58.0 < hi < 60.5
+    # the sheltered valley of image4 runs from the lower left to the upper right; the north-west and south-east corners are exposed
+    ws = m["windspeed"][:, :, 99]
+    assert np.nanmean(ws[:8, :15]) > 2.5 and np.nanmean(ws[40:, 35:]) > 2.5 and np.nanmean(ws[22:30, 18:28]) < 0.8
+    # the drainage lines of image2 are the wettest cells: far above the median soil moisture
+    sm = m["soilm"][:, :, 133]
+    assert np.nanpercentile(sm, 97) > 0.35 > np.nanmedian(sm) + 0.1
