@@ -318,3 +318,80 @@ def test_vignette_component_maps_match_the_published_colour_scales():
     # the drainage lines of image2 are the wettest cells: far above the median soil moisture
     sm = m["soilm"][:, :, 133]
     assert np.nanpercentile(sm, 97) > 0.35 > np.nanmedian(sm) + 0.1
+
+
+def _flat_uniform_site(pai, hgt):
+    """`aggregate(rast(dtmcaerth), 10) * 0` with the uniform vegp2 / soilc2 of running-microclimf.Rmd:408-419, 440-451"""
+    _, _, soilc, dtm = load()
+    one = np.ones((5, 5))
+    assert np.all(soilc["soiltype"][~np.isnan(soilc["soiltype"])] == 7)        # so the aggregated soil type is 7 as well
+    vegp2 = {"pai": pai * one, "hgt": hgt * one, "x": one, "gsmax": 0.1 * one, "leafr": 0.3 * one, "clump": 0 * one,
+             "leafd": 0.05 * one, "leaft": 0.15 * one}
+    return {"z": 0 * one, "res": 10.0, "lat": dtm["lat"], "long": dtm["long"]}, vegp2, {"soiltype": 7 * one, "groundr": 0.15 * one}
+
+
+def test_vignette_above_canopy_profile_matches_the_published_figure():
+    """vignettes/images/image7.png (running-microclimf.Rmd:408-432): the logarithmic temperature profile over a 5 mm sward
+    in entry 132 of the monthly-tmax subset; the seven plotted points read off the figure to about 0.1 degC"""
+    weather = load()[0]
+    dem, vegp2, soilc2 = _flat_uniform_site(0.05, 0.005)
+    mp = F.subsetpointmodel(F.runpointmodel(weather, 0.05, dem, vegp2, soilc2), tstep="month", what="tmax")
+    published = {0.01: 43.4, 0.02: 40.8, 0.05: 37.6, 0.1: 35.2, 0.2: 32.8, 0.5: 29.7, 1.0: 27.3}
+    for h, want in published.items():
+        got = F.runmicro(mp, h, vegp2, soilc2, dem)["Tz"][1, 1, 131]
+        assert abs(got - want) < 0.15, (h, got, want)
+
+
+def test_vignette_below_canopy_profile_matches_the_published_figure():
+    """vignettes/images/image8.png (running-microclimf.Rmd:440-466): the profile under a 10 m canopy of pai 3 — 18.1 degC at
+    0.1 m, a bulge to just under 25 degC near 3 m, 24.1 at 6.3 m and 20.8 at the canopy top.  The figure was drawn with the
+    R-language `aboveground`; the compiled path this package replaces peaks 0.1 degC lower."""
+    weather = load()[0]
+    dem, vegp2, soilc2 = _flat_uniform_site(3.0, 10.0)
+    mp = F.subsetpointmodel(F.runpointmodel(weather, 10.0, dem, vegp2, soilc2), tstep="month", what="tmax")
+    heights = 10 ** (np.arange(-10, 11) / 10)
+    t = np.array([F.runmicro(mp, float(h), vegp2, soilc2, dem)["Tz"][1, 1, 131] for h in heights])
+    assert abs(t[0] - 18.1) < 0.15 and abs(t[-1] - 20.8) < 0.15 and abs(t[18] - 24.1) < 0.15
+    k = int(np.argmax(t))
+    assert 2.5 <= heights[k] <= 4.0 and 24.7 < t[k] < 25.0
+    assert np.all(np.diff(t[:k + 1]) > 0) and np.all(np.diff(t[k:]) < 0)
+
+
+def test_vignette_soil_temperature_curves_match_the_published_figure():
+    """vignettes/images/image9.png (running-microclimf.Rmd:470-494): a year of soil temperature under the same canopy at
+    5 cm (about 2.7 .. 18.6 degC), 20 cm (5.0 .. 15.4) and 1 m depth (6.8 .. 14.3, one smooth wave peaking in mid-August)"""
+    weather = load()[0]
+    dem, vegp2, soilc2 = _flat_uniform_site(3.0, 10.0)
+    published = {-0.05: (2.7, 18.6), -0.2: (5.0, 15.4), -1.0: (6.8, 14.3)}
+    peak = {}
+    for depth, (lo, hi) in published.items():
+        mp = F.runpointmodel(weather, depth, dem, vegp2, soilc2)
+        t = F.runmicro(mp, depth, vegp2, soilc2, dem)["Tz"][1, 1, :]
+        assert abs(t.min() - lo) < 0.25 and abs(t.max() - hi) < 0.25, (depth, t.min(), t.max())
+        peak[depth] = int(np.argmax(t))
+    assert 5000 < peak[-1.0] < 5700 and peak[-0.05] < peak[-0.2] < peak[-1.0]      # the deeper, the later
+
+
+def test_vignette_air_temperature_map_and_its_netcdf_copy_match_the_published_figures(tmp_path):
+    """vignettes/images/image6.png (Rmd:392-397: Tz[,,134] of the monthly-tmax subset, colour scale 25 .. 54 degC) and
+    image10.png (Rmd:540-549: the run written by writetonc, layer 12 read back and divided by 100, scale 7.2 .. 19.4 degC,
+    the slope facing the low January sun in the upper left warm and the scarp's shadow through the middle cold)"""
+    from scipy.io import netcdf_file
+    from microclimf_amd.ncsink import writetonc
+    weather, vegp, soilc, dtm = load()
+    mp = F.subsetpointmodel(F.runpointmodel(weather, 0.05, dtm, vegp, soilc), tstep="month", what="tmax")
+    mout = dict(F.runmicro(mp, 0.05, vegp, soilc, dtm))
+    t6 = mout["Tz"][:, :, 133]
+    assert 24.5 < np.nanmin(t6) < 26.0 and 53.0 < np.nanmax(t6) < 54.5
+    mout["tme"] = mp["obstime"]
+    xmin, xmax, ymin, ymax = dtm["extent"]
+    f = str(tmp_path / "modelout.nc")
+    writetonc(mout, f, {"xmin": xmin, "xmax": xmax, "ymin": ymin, "ymax": ymax, "res": dtm["res"]}, 0.05)
+    with netcdf_file(f, "r", mmap=False) as nc:
+        v = nc.variables["Tz"]
+        lay = np.array(v.data[11], dtype=np.float64)
+        lay[lay == v._FillValue] = np.nan
+    lay /= 100
+    assert np.isnan(lay).sum() == np.isnan(dtm["z"]).sum() > 0
+    assert 7.0 < np.nanmin(lay) < 7.6 and 19.2 < np.nanmax(lay) < 19.6
+    assert np.nanmean(lay[10:25, 0:20]) > 13.0 and np.nanmean(lay[20:45, 20:30]) < 10.0
