@@ -533,6 +533,18 @@ typedef struct mcf_pointsnow_out {
 } mcf_pointsnow_out;
 int mcf_pointmodelsnow(int64_t n, const mcf_obstime *obstime, const mcf_point_weather *weather, const double *vegp,
                        const double *other, int32_t snowenv, double tol, double maxiter, mcf_pointsnow_out *out);
+/* ---- fast snow method for subset runs (R/internal.R:2627-2776 `.snowmodelq1`): its three kernels of arithmetic ----
+ * mcf_canintfrac replaces _microclimf_canintfrac (src/microclimfCpp.cpp:5417-5450): frac = canopysnowintCpp(hgt, pai,
+ *   uf, prec, tc, Li) / prec per cell, 0.5 everywhere when prec is not > 0, NaN where hgt is NA.  Host code.
+ * mcf_meltmu replaces _microclimf_meltmu (:5454-5492): per cell sum over the n steps of max(0, (stemp - tc) * skyview +
+ *   tc) over sum of max(0, stemp); 1 everywhere when the denominator is 0; NaN where skyview is NA.  Host code.
+ * mcf_tpicalc replaces `.tpicalc` (R/internal.R:2483-2496) on the device: exp((aggregate(dtm, af, na.rm) resampled
+ *   bilinearly - dtm) * tfact), or the raster mean in place of the aggregate when af >= min(dim) / 2, values below 0.05
+ *   set to 0.1 and above 10 to 10 as in the reference, divided by the raster mean.  [rows, cols] column-major. */
+int mcf_canintfrac(int64_t cells, const double *hgt, const double *pai, double uf, double prec, double tc, double Li,
+                   double *frac);
+int mcf_meltmu(int64_t cells, const double *skyview, int64_t n, const double *stemp, const double *tc, double *mu);
+int mcf_tpicalc(int64_t rows, int64_t cols, const double *dtm, int32_t af, double tfact, double *tpic, int32_t device);
 /* manCpp (src/microclimfCpp.cpp:597-627): circular trailing mean, via daily means for windows beyond 48 steps. */
 int mcf_man(int64_t n, const double *x, int32_t window, double *out);
 

@@ -902,3 +902,34 @@ extern "C" int mcf_pointmodelsnow(int64_t n64, const mcf_obstime* t, const mcf_p
     o->iters = iter;
     return MCF_OK;
 }
+
+// canintfrac (src/microclimfCpp.cpp:5417-5450): the share of a typical snowfall the canopy of each cell holds back
+extern "C" int mcf_canintfrac(int64_t cells, const double* hgt, const double* pai, double uf, double prec, double tc, double Li,
+                              double* frac) {
+    if (cells <= 0 || !hgt || !pai || !frac) return mcf::api_fail(MCF_ERR_ARG, "mcf_canintfrac: null argument or no cells");
+    for (int64_t i = 0; i < cells; ++i) {
+        if (isnan(hgt[i])) frac[i] = NAN;
+        else frac[i] = prec > 0.0 ? canopy_snow_interception(hgt[i], pai[i], uf, prec, tc, Li) / prec : 0.5;   // NaN prec: 0.5 too
+    }
+    return MCF_OK;
+}
+// meltmu (src/microclimfCpp.cpp:5454-5492): degree hours of the snow surface with each cell's sky view scaling its
+// departure from air temperature, over the degree hours of the point model's surface
+extern "C" int mcf_meltmu(int64_t cells, const double* skyview, int64_t n, const double* stemp, const double* tc, double* mu) {
+    if (cells <= 0 || n < 0 || !skyview || !mu || (n > 0 && (!stemp || !tc)))
+        return mcf::api_fail(MCF_ERR_ARG, "mcf_meltmu: null argument or no cells");
+    double dhp = 0.0;
+    for (int64_t k = 0; k < n; ++k)
+        if (stemp[k] > 0.0) dhp += stemp[k];
+    for (int64_t i = 0; i < cells; ++i) {
+        if (!(dhp > 0.0)) { mu[i] = 1.0; continue; }          // NA cells included, as in the reference
+        if (isnan(skyview[i])) { mu[i] = NAN; continue; }
+        double dhm = 0.0;
+        for (int64_t k = 0; k < n; ++k) {
+            const double s2 = (stemp[k] - tc[k]) * skyview[i] + tc[k];
+            if (s2 > 0.0) dhm += s2;
+        }
+        mu[i] = dhm / dhp;
+    }
+    return MCF_OK;
+}

@@ -1213,6 +1213,46 @@ extern "C" int mcf_applycpp3(const double* a, int64_t rows, int64_t cols, int64_
     return MCF_OK;
 }
 
+// k_tpi_fine's result divided by its raster mean
+__global__ __launch_bounds__(256) void k_scale_by_mean(double* __restrict__ x, int64_t N, const double* __restrict__ sumcount) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) x[i] /= sumcount[0] / sumcount[1];
+}
+extern "C" int mcf_tpicalc(int64_t rows, int64_t cols, const double* dtm, int32_t af, double tfact, double* tpic, int32_t device) {
+    if (!dtm || !tpic || rows <= 0 || cols <= 0) return mcf::api_fail(MCF_ERR_ARG, "mcf_tpicalc: null argument or empty raster");
+    if (af < 1) return mcf::api_fail(MCF_ERR_ARG, "mcf_tpicalc: aggregation factor below 1 (terra::aggregate fails)");
+    int rc;
+    if ((rc = pick_device(device))) return rc;
+    const int64_t N = rows * cols;
+    if ((rc = check_room(N * 24))) return rc;
+    Bufs b;
+    const double* d_z;
+    double *d_t, *d_ws, *d_m2, *d_cm = nullptr;
+    UP(d_z, dtm, N);
+    if ((rc = b.alloc((void**)&d_t, N * 8))) return rc;
+    if ((rc = b.alloc((void**)&d_ws, 2 * kSumParts * 8))) return rc;
+    if ((rc = b.alloc((void**)&d_m2, 16))) return rc;
+    TpiGeo g;
+    g.rows = rows; g.cols = cols; g.RB = rows; g.hn = 0; g.row0 = 0; g.rows_total = rows; g.af = af;
+    g.NItot = (rows + af - 1) / af; g.nJ = (cols + af - 1) / af; g.I0 = 0; g.nI = g.NItot;
+    const unsigned gridN = (unsigned)((N + 255) / 256);
+    if ((double)af < std::min(rows, cols) / 2.0) {
+        if ((rc = b.alloc((void**)&d_cm, g.nI * g.nJ * 8))) return rc;
+        hipLaunchKernelGGL(k_tpi_coarse, dim3((unsigned)((g.nI * g.nJ + 255) / 256)), dim3(256), 0, nullptr, d_z, g, d_cm);
+        hipLaunchKernelGGL(k_tpi_fine, dim3(gridN), dim3(256), 0, nullptr, d_z, g, (const double*)d_cm, 0.0, tfact, d_t);
+    } else {
+        launch_sumcount(d_z, N, d_ws, d_m2);
+        double h[2];
+        S_TRY(hipMemcpy(h, d_m2, 16, hipMemcpyDeviceToHost));
+        hipLaunchKernelGGL(k_tpi_fine, dim3(gridN), dim3(256), 0, nullptr, d_z, g, (const double*)nullptr, h[0] / h[1], tfact, d_t);
+    }
+    launch_sumcount(d_t, N, d_ws, d_m2);
+    hipLaunchKernelGGL(k_scale_by_mean, dim3(gridN), dim3(256), 0, nullptr, d_t, N, (const double*)d_m2);
+    S_TRY(hipGetLastError());
+    S_TRY(hipMemcpy(tpic, d_t, (size_t)N * 8, hipMemcpyDeviceToHost));
+    return MCF_OK;
+}
+
 extern "C" int32_t mcf_snowenv_from_name(const char* name) {
     if (!name) return MCF_SNOWENV_ALPINE;
     if (!strcmp(name, "Maritime")) return MCF_SNOWENV_MARITIME;

@@ -513,18 +513,31 @@ def sortl(vegp, sdep):
 
 
 def runsnowmodel(weather: Mapping, micropoint: Mapping, vegp: Mapping, soilc: Mapping, dtm: Mapping, *,
-                 snowenv: str = "Taiga", snowinitd=0.0, snowinita=0.0, stfact: float = 0.01, device: int = 0) -> dict:
-    """`runsnowmodel(weather, micropoint, vegp, soilc, dtm, ..., method = "slow")` for data.frame weather
-    (R/Cppwrappers.R:717-731 -> `.snowmodel1`, R/internal.R:2498-2619; `weather` is always the complete hourly series, a
-    subset micropoint only selects which steps come back): weather height adjustment, the
-    snow point model (host C++), `.sortl`, then the 5-day chunk loop on the device (terrain refresh from dtm + snow,
-    gridmodelsnow1, `.tpicalc` redistribution, hand-over).  Returns Tc, Tg, groundsnowdepth, totalSWE, snowden, umu."""
+                 snowenv: str = "Taiga", method: str = "fast", snowinitd=0.0, snowinita=0.0, zref: float = 2.0,
+                 windhgt: float | None = None, stfact: float = 0.01, device: int = 0) -> dict:
+    """`runsnowmodel(weather, micropoint, vegp, soilc, dtm, ...)` for data.frame weather (R/Cppwrappers.R:717-735);
+    `weather` is always the complete hourly series.  A complete micropoint runs `.snowmodel1` (R/internal.R:2498-2619)
+    at the point model's reference height: weather height adjustment, the snow point model (host C++), `.sortl`, the
+    5-day chunk loop on the device (terrain refresh from dtm + snow, gridmodelsnow1, `.tpicalc` redistribution,
+    hand-over).  A subset micropoint runs, at `zref` / `windhgt`, either that and its subset (`method = "slow"`) or
+    `.snowmodelq1` (:2627-2776, `method = "fast"`, the reference's default): the point model over every hour, the grid
+    model on the selected days only, the pack carried between them by the point model's balance.
+    Returns Tc, Tg, groundsnowdepth, totalSWE, snowden, umu."""
     from . import snow as S
+    if method not in ("fast", "slow"):
+        raise ValueError('method is "fast" or "slow"')
     vegp = cleanvegp(vegp)
     w = {k: np.array(weather[k], dtype=np.float64, copy=True) for k in WEATHER if k in weather}
     tme = weather["obstime"]
     obstime = {k: np.asarray(tme[k]) for k in ("year", "month", "day", "hour")}
-    zref = float(micropoint["zref"])                                   # runsnowmodel passes micropoint$zref twice
+    subset = len(micropoint["subs"]) != micropoint["ntme"]
+    if subset:
+        zref = float(zref)
+        windhgt = zref if windhgt is None else float(windhgt)
+    else:
+        zref = windhgt = float(micropoint["zref"])                     # runsnowmodel passes micropoint$zref twice
+    if zref != windhgt:                                                # R/internal.R:2505-2507, 2636-2638
+        w["windspeed"] = w["windspeed"] * np.log(67.8 * zref - 5.42) / np.log(67.8 * windhgt - 5.42)
     lat, long = float(micropoint["lat"]), float(micropoint["long"])
     z = np.asarray(dtm["z"], dtype=np.float64)
     hmax = float(np.nanmax(np.asarray(vegp["hgt"], dtype=np.float64)))
@@ -537,18 +550,29 @@ def runsnowmodel(weather: Mapping, micropoint: Mapping, vegp: Mapping, soilc: Ma
     sage = z * 0 + snowinita
     other_p = [0.0, 0.0, lat, long, zref, float(np.nanmean(sdep)), float(np.nanmean(sage))]
     hour_int = {**obstime, "hour": np.floor(np.asarray(obstime["hour"], dtype=np.float64))}   # `hour = tme$hour`
-    pmod = pointmodel.pointmodelsnow(hour_int, w, vegpp, other_p, snowenv)
+    fast = subset and method == "fast"
+    pmod = pointmodel.pointmodelsnow(hour_int, w, vegpp, other_p, snowenv, maxiter=20 if fast else 100)
     n = len(w["temp"])
     pointm = {"Gp": pmod["G"], "Tc": pmod["Tc"], "RswabsG": pmod["RswabsG"], "RlwabsG": pmod["RlwabsG"], "umu": pmod["umu"],
               "tr": pmod["tr"]}
     vg = sortl(vegp, pmod["sdepc"][:n])
-    other = {"zref": zref, "lat": lat, "lon": long, "isnowdc": sdep, "isnowac": sage, "isnowdg": sdep * 0.5, "isnowag": sage}
     res = dtm["res"]
     xres = res if np.isscalar(res) else res[0]
     clim = {k: w[k] for k in ("temp", "relhum", "pres", "swdown", "difrad", "lwdown", "windspeed", "winddir", "precip")}
+    if fast:
+        subs = np.asarray(micropoint["subs"], dtype=np.int64)          # 1-based positions, as in the reference
+        ai = subs - 1
+        vg["leaft"] = np.where(np.isnan(vg["leaft"]), 0.01, vg["leaft"])
+        other = {"zref": zref, "lat": lat, "lon": long, "isnowdc": snowinitd * z, "isnowac": sage, "isnowag": sage}
+        out = S.snowmodelq1_days(_rows(hour_int, ai), _rows(clim, ai), _rows(pointm, ai), pmod, w["temp"],
+                                 np.where(w["temp"] > 2, 0.0, w["precip"]), subs, vg, other, snowenv, z, xres, stfact,
+                                 device=device)
+        out["umu"] = pmod["umu"][ai]
+        return out
+    other = {"zref": zref, "lat": lat, "lon": long, "isnowdc": sdep, "isnowac": sage, "isnowdg": sdep * 0.5, "isnowag": sage}
     out = S.snowmodel1_chunks(hour_int, clim, pointm, vg, other, snowenv, z, xres, stfact, device=device)
     out["umu"] = pmod["umu"]
-    if len(micropoint["subs"]) != micropoint["ntme"]:                  # method = "slow": the full model, then its subset
+    if subset:                                                         # method = "slow": the full model, then its subset
         out = subsetsnowmodel(out, micropoint["subs"])
     return out
 

@@ -224,6 +224,123 @@ def snowmodel1_chunks(obstime, climdata, pointm, vegp, other, snowenv, dtm, res,
     return arrays
 
 
+def canintfrac(hgt, pai, uf: float, prec: float, tc: float, Li: float = 0.0) -> np.ndarray:
+    """`canintfrac` (src/microclimfCpp.cpp:5417-5450): the canopy's share of a snowfall of `prec` mm per cell (host code)"""
+    lib = _abi.load()
+    h = np.asfortranarray(np.asarray(hgt, dtype=np.float64))
+    p = np.asfortranarray(np.asarray(pai, dtype=np.float64))
+    if h.shape != p.shape:
+        raise ValueError("hgt and pai differ in shape")
+    out = np.empty(h.shape, dtype=np.float64, order="F")
+    _abi.check(lib.mcf_canintfrac(C.c_int64(h.size), h.ctypes.data_as(_abi.c_double_p), p.ctypes.data_as(_abi.c_double_p),
+                                  C.c_double(uf), C.c_double(prec), C.c_double(tc), C.c_double(Li),
+                                  out.ctypes.data_as(_abi.c_double_p)))
+    return out
+
+
+def meltmu(skyview, stemp, tc) -> np.ndarray:
+    """`meltmu` (src/microclimfCpp.cpp:5454-5492): per-cell multiplier of the point model's temperature melt (host code)"""
+    lib = _abi.load()
+    sv = np.asfortranarray(np.asarray(skyview, dtype=np.float64))
+    st = np.ascontiguousarray(stemp, dtype=np.float64)
+    ta = np.ascontiguousarray(tc, dtype=np.float64)
+    if st.shape != ta.shape or st.ndim != 1:
+        raise ValueError("stemp and tc must be vectors of one length")
+    out = np.empty(sv.shape, dtype=np.float64, order="F")
+    _abi.check(lib.mcf_meltmu(C.c_int64(sv.size), sv.ctypes.data_as(_abi.c_double_p), C.c_int64(st.size),
+                              st.ctypes.data_as(_abi.c_double_p), ta.ctypes.data_as(_abi.c_double_p),
+                              out.ctypes.data_as(_abi.c_double_p)))
+    return out
+
+
+def tpicalc(af: int, dtm, tfact: float, *, device: int = 0) -> np.ndarray:
+    """`.tpicalc(af, min(dim), dtm, tfact)` (R/internal.R:2483-2496) on the device"""
+    lib = _abi.load()
+    z = np.asfortranarray(np.asarray(dtm, dtype=np.float64))
+    out = np.empty(z.shape, dtype=np.float64, order="F")
+    _abi.check(lib.mcf_tpicalc(C.c_int64(z.shape[0]), C.c_int64(z.shape[1]), z.ctypes.data_as(_abi.c_double_p), C.c_int32(int(af)),
+                               C.c_double(tfact), out.ctypes.data_as(_abi.c_double_p), C.c_int32(device)))
+    return out
+
+
+def r_colon(a: int, b: int) -> np.ndarray:
+    """R's `a:b` (counts down when a > b) as 0-based indices of 1-based positions"""
+    return (np.arange(a, b + 1) if a <= b else np.arange(a, b - 1, -1)) - 1
+
+
+def snowmodelq1_days(obstime, climdata, pointm, pmod, temp_all, snow_all, subs, vegp, other, snowenv, dtm, res, tfact=0.02, *,
+                     device: int = 0) -> dict:
+    """The day loop of the reference's fast snow method `.snowmodelq1` (R/internal.R:2690-2776).  `obstime`, `climdata`,
+    `pointm`: the selected hours only (whole days); `pmod`: pointmodelsnow's output over the whole series with `temp_all`
+    (air temperature) and `snow_all` (precipitation of the hours at or below 2 degC) beside it; `subs`: 1-based positions of
+    the selected hours; `vegp`: `.sortl`'s means; `other`: zref, lat, lon, isnowdc, isnowac, isnowag.  Between two selected
+    days the pack of every cell moves by the point model's balance, its temperature melt scaled by `meltmu`; each selected
+    day runs gridmodelsnow1 on the device over terrain of the bare dtm and spreads the ground-snow change by `.tpicalc`.
+    Reference behaviours kept: the ground depths stacked on the dtm for the position index are still zero when they are
+    read (:2750), snow ages are not handed on, and a first selected day that is the first day of the series fails (`sbtn`
+    undefined there)."""
+    from . import terrain as T
+    z = np.asarray(dtm, dtype=np.float64)
+    subs = np.asarray(subs, dtype=np.int64)
+    n = subs.size
+    if n % 24 or n == 0:
+        raise ValueError("the fast snow method works on whole selected days")
+    if subs[0] - 1 <= 1:
+        raise ValueError("the fast snow method cannot start on the first day of the series (the reference fails there: "
+                         "`sbtn` not found)")
+    R, Cc = z.shape
+    zref = float(other["zref"])
+    oth = dict(other)
+    oth.update(T.snow_terrain(z, res, zref, device=device))
+    temp_s = np.asarray(climdata["temp"], dtype=np.float64)
+    wind_s = np.asarray(climdata["windspeed"], dtype=np.float64)
+    snow_all = np.asarray(snow_all, dtype=np.float64)
+    pos = snow_all[snow_all > 0]
+    msnow = float(pos.mean()) if pos.size else float("nan")
+    intfrac = canintfrac(vegp["hgt"], vegp["pai"], 2.0, msnow, float(temp_s.mean()), 0.0)
+    isnowdc = np.array(oth["isnowdc"], dtype=np.float64)
+    isnowdg = (1 - intfrac) * isnowdc
+    out = {k: np.full((R, Cc, n), np.nan, order="F") for k in ("Tc", "Tg", "sdepc", "snowden")}
+    out["sdepg"] = np.zeros((R, Cc, n), order="F")
+    pai = np.asarray(vegp["pai"], dtype=np.float64)
+    ped = 0
+    with np.errstate(invalid="ignore"):
+        for day in range(n // 24):
+            sl = slice(day * 24, day * 24 + 24)
+            first = int(subs[day * 24])
+            if first - 1 > 1:
+                sbtn = r_colon(ped + 1, first - 1)
+                mu = meltmu(oth["skyview"], pmod["sstemp"][sbtn], np.asarray(temp_all)[sbtn])
+                melt = pmod["sublmelt"][sbtn].sum() + pmod["rainmelt"][sbtn].sum() + mu * pmod["tempmelt"][sbtn].sum()
+                fall = (snow_all[sbtn] / 1000).sum()
+                balancec, balanceg = fall - melt, (1 - intfrac) * fall - np.exp(-pai) * melt
+            else:
+                balancec = balanceg = 0.0                          # sbtn of the day before stays in force
+            isnowdc = isnowdc + balancec * (1000 / pmod["sdenc"][sbtn].mean())
+            isnowdg = isnowdg + balanceg * (1000 / pmod["sdeng"][sbtn].mean())
+            isnowdc[isnowdc < 0] = 0
+            isnowdg[isnowdg < 0] = 0
+            oth["isnowdc"], oth["isnowdg"] = isnowdc, isnowdg
+            smod = gridmodelsnow1({k: np.asarray(v)[sl] for k, v in obstime.items()},
+                                  {k: np.asarray(v)[sl] for k, v in climdata.items()},
+                                  {k: np.asarray(v)[sl] for k, v in pointm.items()}, vegp, oth, snowenv, device=device)
+            dsnow = smod["sdepc"] - isnowdc[:, :, None]
+            dsnowg = smod["sdepg"] - isnowdg[:, :, None]
+            af = int(np.round(10 * wind_s[sl].mean() ** 0.5 / res))    # half to even, like R's round
+            tpi = tpicalc(af, z, tfact, device=device)
+            dsnowg2 = dsnowg * tpi[:, :, None]
+            sdc = (dsnow - dsnowg) + dsnowg2 + isnowdc[:, :, None]
+            sdg = dsnowg2 + isnowdg[:, :, None]
+            sdc[sdc < 0] = 0
+            sdg[sdg < 0] = 0
+            out["Tc"][:, :, sl], out["Tg"][:, :, sl], out["snowden"][:, :, sl] = smod["Tc"], smod["Tg"], smod["sden"]
+            out["sdepc"][:, :, sl], out["sdepg"][:, :, sl] = sdc, sdg
+            ped = int(subs[day * 24 + 23])
+            isnowdc, isnowdg = sdc[:, :, 23].copy(), sdg[:, :, 23].copy()
+        swe = out["sdepc"] * out["snowden"]
+    return {"Tc": out["Tc"], "Tg": out["Tg"], "groundsnowdepth": out["sdepg"], "totalSWE": swe, "snowden": out["snowden"]}
+
+
 APPLY_FUNS = {"mean": 0, "sum": 1, "max": 2, "min": 3}
 
 

@@ -47,6 +47,22 @@ def precompute_terrain(dtm, res: float, zref: float, *, agg: int = 10, halo_nort
     return res_arrays
 
 
+def snow_terrain(dtm, res: float, zref: float, *, device: int = 0) -> dict:
+    """The terrain block of `.snowmodelq1` (R/internal.R:2690-2706): as the marshaller's, but terra's NA aspects (raster
+    edge, NA neighbour) become 180 and slope / aspect are masked by the dtm."""
+    z = np.asarray(dtm, dtype=np.float64)
+    t = precompute_terrain(z, res, zref, agg=10 if res <= 100 else 1, device=device)
+    pad = np.pad(z, 1, constant_values=np.nan)
+    na = np.zeros(z.shape, dtype=bool)
+    for dr in (0, 1, 2):
+        for dc in (0, 1, 2):
+            if (dr, dc) != (1, 1):
+                na |= np.isnan(pad[dr:dr + z.shape[0], dc:dc + z.shape[1]])
+    hole = np.isnan(z)
+    return {"slope": np.where(hole, np.nan, t["slope"]), "aspect": np.where(hole, np.nan, np.where(na, 180.0, t["aspect"])),
+            "hor": t["hor"], "skyview": t["svfa"], "wsa": t["wsa"]}
+
+
 def exchange_halo(block: np.ndarray, rank: int, world: int, halo: int = HALO, device=None):
     """Returns (extended block, halo_north, halo_south): up to `halo` rows from each neighbouring
     rank's block (row blocks are ordered north to south by rank).  Point-to-point

@@ -395,3 +395,20 @@ def test_vignette_air_temperature_map_and_its_netcdf_copy_match_the_published_fi
     assert np.isnan(lay).sum() == np.isnan(dtm["z"]).sum() > 0
     assert 7.0 < np.nanmin(lay) < 7.6 and 19.2 < np.nanmax(lay) < 19.6
     assert np.nanmean(lay[10:25, 0:20]) > 13.0 and np.nanmean(lay[20:45, 20:30]) < 10.0
+
+
+def test_vignette_subset_snow_depth_steps_match_the_published_figure():
+    """vignettes/images/image14p.png, the blue curve (running-microclimf.Rmd:663-683): climdata$temp - 12, the point model
+    subset to each month's coldest day, `runsnowmodel(method = "slow")` with the default snow environment; raster-mean
+    depth = totalSWE / snowden on the 12 selected days as read off the figure (to about 0.01 m)"""
+    weather, vegp, soilc, dtm = load()
+    cold = dict(weather, temp=weather["temp"] - 12.0)
+    mp = F.subsetpointmodel(F.runpointmodel(cold, 0.05, dtm, vegp, soilc), tstep="month", what="tmin")
+    smod = F.runsnowmodel(cold, mp, vegp, soilc, dtm, method="slow")
+    with np.errstate(invalid="ignore", divide="ignore"):
+        depth = np.nanmean(smod["totalSWE"] / smod["snowden"], axis=(0, 1))
+    assert depth.size == 288
+    start = [0.022, 0.35, 0.64, 0.485, 0.205, 0.003, 0.078, 0.0, 0.025, 0.01, 0.095, 0.375]
+    for m, want in enumerate(start):
+        assert abs(depth[m * 24] - want) < 0.012, (m + 1, depth[m * 24], want)
+    assert abs(depth[3 * 24 - 1] - 0.68) < 0.012 and abs(depth[7 * 24 - 1] - 0.055) < 0.012      # March builds, July melts
