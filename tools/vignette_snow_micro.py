@@ -14,7 +14,7 @@ from microclimf_amd import frontend as F  # noqa: E402
 weather, vegp, soilc, dtm = load()
 cold = dict(weather, temp=weather["temp"] - 12.0)
 mp = F.subsetpointmodel(F.runpointmodel(cold, 0.05, dtm, vegp, soilc), tstep="month", what=(sys.argv[1] if len(sys.argv) > 1 else "tmin"))
-smod = F.runsnowmodel(cold, mp, vegp, soilc, dtm, snowenv="Maritime")
+smod = F.runsnowmodel(cold, mp, vegp, soilc, dtm, snowenv="Maritime", method="slow")
 m1 = F.runmicro_snow(mp, 0.05, vegp, soilc, dtm, smod)
 m2 = F.runmicro(mp, 0.05, vegp, soilc, dtm)
 with np.errstate(invalid="ignore"):
