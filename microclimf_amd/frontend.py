@@ -577,6 +577,71 @@ def runsnowmodel(weather: Mapping, micropoint: Mapping, vegp: Mapping, soilc: Ma
     return out
 
 
+def runsnowmodela(climarray: Mapping, obstime: Mapping, micropointa: Sequence, vegp: Mapping, soilc: Mapping, dtm: Mapping, *,
+                  dtmc, lats_c, lons_c, lats, lons, altcorrect: int = 0, snowenv: str = "Taiga", method: str = "fast",
+                  snowinitd: float = 0.0, snowinita: float = 0.0, zref: float = 2.0, windhgt: float | None = None,
+                  stfact: float = 0.01, device: int = 0) -> dict:
+    """`runsnowmodel(climarrayr, micropointa, vegp, soilc, dtm, dtmc, tme, altcorrect, ...)` for array weather
+    (R/Cppwrappers.R:735-757 -> `.snowmodel2`, R/internal.R:2777-3013): the snow point model (host C++) once per cell of
+    the climate grid, then `snow.snowmodel2_chunks`.  `climarray[k]`: [crows, ccols, T]; `dtmc`, `lats_c`, `lons_c`:
+    [crows, ccols] of the climate grid; `lats`, `lons`: [rows, cols] of the fine raster.  A subset micropoint list with
+    `method = "slow"` runs the whole series and subsets it (here `umu` too along time; the reference indexes the array as
+    a vector there); `method = "fast"` (`.snowmodelq2`) is not mirrored.  As in the reference every climate cell needs
+    data, and vegetation taller than `zref` fails (`.snowmodel2` stops at R/internal.R:2838, `climdfr` not found)."""
+    from . import snow as S
+    vegp = cleanvegp(vegp)
+    if any(m is None for m in micropointa):
+        raise ValueError("every coarse cell needs a micropoint")
+    last = micropointa[-1]                                            # the reference's loop keeps the last one's subs
+    subset = len(last["subs"]) != last["ntme"]
+    if subset:
+        if method == "fast":
+            raise NotImplementedError('the fast array snow method (`.snowmodelq2`) is not mirrored: use method = "slow"')
+        zref = float(zref)
+        windhgt = zref if windhgt is None else float(windhgt)
+    else:
+        zref = windhgt = float(micropointa[0]["zref"])
+    cr, cc, T = np.shape(climarray["temp"])
+    z = np.asarray(dtm["z"], dtype=np.float64)
+    R, Cc = z.shape
+    if float(np.nanmax(np.asarray(vegp["hgt"], dtype=np.float64))) > zref:
+        raise ValueError("the array snow model needs zref at or above the tallest vegetation (the reference fails there)")
+    wdir = np.array([getmode(np.asarray(climarray["winddir"])[:, :, k]) for k in range(T)])
+    vc = {k: block_reduce(vegp[k], cr, cc) for k in ("pai", "hgt", "leaft", "clump")}
+    if np.isnan(np.asarray(climarray["temp"])[:, :, 0]).any() or np.isnan(vc["hgt"][:, :, 0]).any():
+        raise ValueError("every coarse cell needs climate data and vegetation")
+    ob = {k: np.asarray(obstime[k]) for k in ("year", "month", "day", "hour")}
+    clim_c = {k: np.array(climarray[k], dtype=np.float64, order="F", copy=True) for k in WEATHER if k != "winddir"}
+    if zref != windhgt:
+        clim_c["windspeed"] *= np.log(67.8 * zref - 5.42) / np.log(67.8 * windhgt - 5.42)
+    clim_c["winddir"] = wdir
+    pn = {"Gp": "G", "Tc": "Tc", "RswabsG": "RswabsG", "RlwabsG": "RlwabsG", "umu": "umu", "tr": "tr", "sdepc": "sdepc"}
+    pointm_c = {k: np.empty((cr, cc, T), order="F") for k in pn}
+    for i in range(cr):
+        for j in range(cc):
+            w = {k: clim_c[k][i, j, :] for k in clim_c if k != "winddir"}
+            w["winddir"] = wdir
+            vegpp = [float(np.mean(vc[k][i, j, :])) for k in ("pai", "hgt", "leaft", "clump")]          # `.tovp`
+            pmod = pointmodel.pointmodelsnow(ob, w, vegpp, [0.0, 0.0, float(lats_c[i, j]), float(lons_c[i, j]), zref, snowinitd,
+                                                            snowinita], snowenv, maxiter=10)
+            for k, v in pn.items():
+                pointm_c[k][i, j, :] = pmod[v][:T]
+    vg = sortl(vegp, np.max(pointm_c["sdepc"], axis=(0, 1)))
+    sdep = z * 0 + snowinitd
+    sage = z * 0 + snowinita
+    other = {"zref": zref, "lats": np.asarray(lats, dtype=np.float64), "lons": np.asarray(lons, dtype=np.float64),
+             "isnowdc": sdep, "isnowac": sage, "isnowdg": sdep * 0.5, "isnowag": sage}
+    res = dtm["res"]
+    xres = res if np.isscalar(res) else res[0]
+    out = S.snowmodel2_chunks(ob, clim_c, pointm_c, vg, other, snowenv, z, np.asarray(dtmc, dtype=np.float64), xres, stfact,
+                              rowpos=api.coarse_positions(R, cr), colpos=api.coarse_positions(Cc, cc), altcorrect=altcorrect,
+                              agg=10 if xres <= 100 and min(cr, cc) >= 10 else 1, device=device)
+    if subset:
+        i = np.asarray(last["subs"], dtype=np.int64) - 1
+        out = {k: v[:, :, i] for k, v in out.items()}
+    return out
+
+
 # ---- snow: runmicro(snow = TRUE) -> .runmicrosnow1 ----------------------------------------------------------------
 def _rows(d: Mapping, ai):
     return {k: np.asarray(v)[ai] for k, v in d.items()}

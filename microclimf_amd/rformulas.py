@@ -22,3 +22,28 @@ def dewpoint_R(ea, tc):
     it = 1 / 273.15 - (461.5 / L) * np.log(ea / e0)
     tfrost = 1 / it - 273.15
     return np.where(tdew < 0, tfrost, tdew)
+
+
+def lapserate_R(tc, ea, pk):
+    """`.lapserate` (R/internal.R:545-550): moist adiabatic lapse rate (K / m)"""
+    rv = 0.622 * ea / (pk - ea)
+    return 9.8076 * (1 + (2501000 * rv) / (287 * (tc + 273.15))) / (1003.5 + (0.622 * 2501000 ** 2 * rv) / (287 * (tc + 273.15) ** 2))
+
+
+def upsample_coarse(a, rowpos, colpos):
+    """`resample(.rast(a, dtmc), dtm)` for [crows, ccols(, T)] held on the host: bilinear between the four neighbouring
+    coarse cell centres, positions as `api.coarse_positions` gives them (edge replication) — the same taps the solver's
+    coarse array forcing uses on the device (mcf_device.hpp CoarseTap)."""
+    a = np.asarray(a, dtype=np.float64)
+    two = a.ndim == 2
+    if two:
+        a = a[:, :, None]
+    cr, cc = a.shape[:2]
+    fr, fc = np.floor(rowpos), np.floor(colpos)
+    r0, c0 = fr.astype(np.int64), fc.astype(np.int64)
+    r1, c1 = np.minimum(r0 + 1, cr - 1), np.minimum(c0 + 1, cc - 1)
+    wy, wx = (rowpos - fr)[:, None, None], (colpos - fc)[None, :, None]
+    top = (1.0 - wx) * a[np.ix_(r0, c0)] + wx * a[np.ix_(r0, c1)]
+    bot = (1.0 - wx) * a[np.ix_(r1, c0)] + wx * a[np.ix_(r1, c1)]
+    out = np.asfortranarray((1.0 - wy) * top + wy * bot)
+    return out[:, :, 0] if two else out

@@ -341,6 +341,84 @@ def snowmodelq1_days(obstime, climdata, pointm, pmod, temp_all, snow_all, subs, 
     return {"Tc": out["Tc"], "Tg": out["Tg"], "groundsnowdepth": out["sdepg"], "totalSWE": swe, "snowden": out["snowden"]}
 
 
+def snowmodel2_chunks(obstime, clim_c, pointm_c, vegp, other, snowenv, dtm, dtmc, res, tfact=0.02, *, rowpos, colpos,
+                      altcorrect: int = 0, agg: int = 10, chunk_steps: int = 120, device: int = 0) -> dict:
+    """The second half of the reference's `.snowmodel2` (R/internal.R:2862-3013): coarse climate and snow point-model
+    arrays [crows, ccols, T] brought to the fine raster chunk by chunk (bilinear, `.cca`; altitude correction 0 / 1 / 2 of
+    :2871-2890; wind from resampled components), then per 5-day chunk the terrain of dtm + ground snow, gridmodelsnow2
+    and `.tpicalc` on the device, the redistribution and the hand-over of depths and ages.  `clim_c`: temp, relhum, pres,
+    swdown, difrad, lwdown, precip, windspeed [crows, ccols, T] and winddir [T] (degrees, the same in every cell as `.todf`
+    makes it); `pointm_c`: Gp, Tc, RswabsG, RlwabsG, umu, tr; `vegp`: `.sortl`'s means; `other`: zref, lats, lons, isnowdc,
+    isnowdg, isnowac, isnowag.  Reference behaviours kept: `other$isnowdg` is never updated, the aggregation factor of the
+    position index is at least 2, `1:n5days` truncates."""
+    from . import terrain as T
+    from .rformulas import lapserate_R, satvap_R, upsample_coarse
+    z = np.asarray(dtm, dtype=np.float64)
+    R, Cc = z.shape
+    h = len(np.asarray(obstime["year"]))
+    nch = h // chunk_steps
+    if nch < 1:
+        raise ValueError("the array snow model needs at least one whole 5-day chunk")
+    hole = np.isnan(z)
+    zc = np.nan_to_num(np.asarray(dtmc, dtype=np.float64), nan=0.0)
+    wd = np.asarray(clim_c["winddir"], dtype=np.float64) * np.pi / 180
+    wu_c = np.asarray(clim_c["windspeed"], dtype=np.float64) * np.cos(wd)
+    wv_c = np.asarray(clim_c["windspeed"], dtype=np.float64) * np.sin(wd)
+    wuv, wvv = np.nanmean(wu_c, axis=(0, 1)), np.nanmean(wv_c, axis=(0, 1))
+    winddir = (np.arctan2(wvv, wuv) * 180 / np.pi) % 360
+    names = ("Tc", "Tg", "groundsnowdepth", "totalSWE", "snowden", "umu")
+    out = {k: np.full((R, Cc, h), np.nan, order="F") for k in names}
+    oth = dict(other)
+    vg = dict(vegp)
+    vg["leaft"] = np.where(np.isnan(vg["leaft"]), 0.001, vg["leaft"])
+    isnowdg = np.asarray(other["isnowdg"], dtype=np.float64)
+    dtms = z + isnowdg
+    sea = ((293 - 0.0065 * zc) / 293) ** 5.26
+    fine = ((293 - 0.0065 * z) / 293) ** 5.26
+    elevd = (upsample_coarse(zc, rowpos, colpos) - z)[:, :, None]
+    with np.errstate(invalid="ignore"):
+        for ch in range(nch):
+            sl = slice(ch * chunk_steps, min((ch + 1) * chunk_steps, h))
+            up = lambda a: upsample_coarse(np.asarray(a)[:, :, sl], rowpos, colpos)            # noqa: E731
+            cca = lambda a: np.where(hole[:, :, None], np.nan, up(a))                          # noqa: E731  `.cca`: masked
+            oth.update(T.snow_terrain(dtms, res, float(other["zref"]), agg=agg, mask=z, device=device))
+            temp, relhum = cca(clim_c["temp"]), cca(clim_c["relhum"])
+            if altcorrect == 0:
+                pres = up(clim_c["pres"])
+            else:
+                ea = satvap_R(temp) * relhum / 100
+                pres = up(np.asarray(clim_c["pres"])[:, :, :] / sea[:, :, None]) * fine[:, :, None]
+                lr = 5 / 1000 if altcorrect == 1 else lapserate_R(temp, ea, pres)
+                temp = lr * elevd + temp
+                relhum = (ea / satvap_R(temp)) * 100
+            relhum = np.where(relhum > 100, 100.0, relhum)
+            clim = {"temp": temp, "relhum": relhum, "pres": pres, "swdown": cca(clim_c["swdown"]), "difrad": cca(clim_c["difrad"]),
+                    "lwdown": cca(clim_c["lwdown"]), "precip": cca(clim_c["precip"]),
+                    "windspeed": np.sqrt(up(wu_c) ** 2 + up(wv_c) ** 2), "winddir": winddir[sl]}
+            pointm = {k: cca(pointm_c[k]) for k in ("Gp", "Tc", "RswabsG", "RlwabsG", "umu", "tr")}
+            smod = gridmodelsnow2({k: np.asarray(v)[sl] for k, v in obstime.items()}, clim, pointm, vg, oth, snowenv, device=device)
+            af = max(int(np.round(10 * np.mean(np.sqrt(wuv[sl] ** 2 + wvv[sl] ** 2)) ** 0.5 / res)), 2)
+            tpi = tpicalc(af, dtms, tfact, device=device)[:, :, None]
+            asd = isnowdg[:, :, None]
+            dsnow = smod["sdepg"] - asd
+            dsnow2 = np.where(dsnow < 0, dsnow, dsnow * tpi)
+            asc = np.asarray(oth["isnowdc"], dtype=np.float64)[:, :, None]
+            tot = asc + (smod["sdepc"] - asc - dsnow) + dsnow2
+            out["Tc"][:, :, sl], out["Tg"][:, :, sl], out["snowden"][:, :, sl] = smod["Tc"], smod["Tg"], smod["sden"]
+            out["totalSWE"][:, :, sl] = tot * smod["sden"]
+            out["groundsnowdepth"][:, :, sl] = asd + dsnow2
+            out["umu"][:, :, sl] = pointm["umu"]                       # `umu = pointm$umu`
+            oth["isnowdc"] = tot[:, :, -1]
+            oth["isnowac"], oth["isnowag"] = smod["agec"], smod["ageg"]
+            dtms = z + out["groundsnowdepth"][:, :, sl.stop - 1]
+    tail = slice(nch * chunk_steps, h)                                  # steps past the last whole chunk: only umu is filled
+    if tail.start < h:
+        out["umu"][:, :, tail] = upsample_coarse(np.asarray(pointm_c["umu"])[:, :, tail], rowpos, colpos)
+    for k in names:                                                     # `.cleansmod`
+        out[k][hole] = np.nan
+    return out
+
+
 APPLY_FUNS = {"mean": 0, "sum": 1, "max": 2, "min": 3}
 
 

@@ -47,18 +47,18 @@ def precompute_terrain(dtm, res: float, zref: float, *, agg: int = 10, halo_nort
     return res_arrays
 
 
-def snow_terrain(dtm, res: float, zref: float, *, device: int = 0) -> dict:
+def snow_terrain(dtm, res: float, zref: float, *, agg: int | None = None, mask=None, device: int = 0) -> dict:
     """The terrain block of `.snowmodelq1` (R/internal.R:2690-2706): as the marshaller's, but terra's NA aspects (raster
     edge, NA neighbour) become 180 and slope / aspect are masked by the dtm."""
     z = np.asarray(dtm, dtype=np.float64)
-    t = precompute_terrain(z, res, zref, agg=10 if res <= 100 else 1, device=device)
+    t = precompute_terrain(z, res, zref, agg=(10 if res <= 100 else 1) if agg is None else agg, device=device)
     pad = np.pad(z, 1, constant_values=np.nan)
     na = np.zeros(z.shape, dtype=bool)
     for dr in (0, 1, 2):
         for dc in (0, 1, 2):
             if (dr, dc) != (1, 1):
                 na |= np.isnan(pad[dr:dr + z.shape[0], dc:dc + z.shape[1]])
-    hole = np.isnan(z)
+    hole = np.isnan(z) if mask is None else np.isnan(np.asarray(mask, dtype=np.float64))     # `mask(slope, dtm)`
     return {"slope": np.where(hole, np.nan, t["slope"]), "aspect": np.where(hole, np.nan, np.where(na, 180.0, t["aspect"])),
             "hor": t["hor"], "skyview": t["svfa"], "wsa": t["wsa"]}
 

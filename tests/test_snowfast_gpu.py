@@ -91,3 +91,89 @@ def test_vignette_fast_snow_depth_steps_match_the_published_figure():
     for m, want in enumerate(start):
         assert abs(depth[m * 24] - want) < 0.015, (m + 1, depth[m * 24], want)
     assert abs(depth[3 * 24 - 1] - 0.605) < 0.015
+
+
+@pytest.mark.parametrize("altcorrect,subset", [(0, False), (2, False), (1, True)])
+def test_array_weather_snow_model_matches_the_oracle_chain(oracle, altcorrect, subset):
+    """`runsnowmodel()` with array weather (`.snowmodel2`): a 2 x 3 grid of perturbed cold climate cells over the bundled
+    site, 11 days (two 5-day chunks and a ragged day); the snow point model per climate cell, resampling, altitude
+    correction, terrain refresh, gridmodelsnow2, position index and hand-over against the oracle's pieces"""
+    from oracle import replay_reference_tests as RT
+    from oracle import snowarray_oracle as SA
+    from microclimf_amd import api
+    weather, vegp, soilc, dtm = load(11 * 24)
+    cr, cc, T = 2, 3, 11 * 24
+    rng = np.random.default_rng(9)
+    climarray = {}
+    for k in F.WEATHER:
+        base = np.broadcast_to(weather[k][None, None, :], (cr, cc, T)).copy()
+        if k == "temp":
+            base += -9.0 + rng.uniform(-1.5, 1.5, (cr, cc, 1))
+        elif k in ("swdown", "difrad", "windspeed", "precip"):
+            base *= rng.uniform(0.9, 1.1, (cr, cc, 1))
+        elif k == "winddir":
+            base = (base + rng.integers(-1, 2, (cr, cc, T)) * 10.0) % 360
+        climarray[k] = np.asfortranarray(base)
+    climarray["difrad"] = np.minimum(climarray["difrad"], climarray["swdown"])
+    clat = dtm["lat"] + 1e-4 * np.arange(cr)[:, None] + 0 * np.arange(cc)[None, :]
+    clon = dtm["long"] + 1e-4 * np.arange(cc)[None, :] + 0 * np.arange(cr)[:, None]
+    lats = dtm["lat"] + 9e-6 * np.arange(50)[::-1, None] + 0 * np.arange(50)[None, :]
+    lons = dtm["long"] + 1.4e-5 * np.arange(50)[None, :] + 0 * np.arange(50)[:, None]
+    z = np.asarray(dtm["z"])
+    dtmc = np.array([[np.nanmean(z[:25, :17]), np.nanmean(z[:25, 17:34]), np.nanmean(z[:25, 34:])],
+                     [np.nanmean(z[25:, :17]), np.nanmean(z[25:, 17:34]), np.nanmean(z[25:, 34:])]]) + 40.0
+    mpa = F.runpointmodela(climarray, weather["obstime"], 0.05, dtm, vegp, soilc, lats=clat, lons=clon)
+    if subset:
+        mpa = [F.subsetpointmodel(m, days=[2, 7, 8]) for m in mpa]
+    got = F.runsnowmodela(climarray, weather["obstime"], mpa, vegp, soilc, dtm, dtmc=dtmc, lats_c=clat, lons_c=clon, lats=lats,
+                          lons=lons, altcorrect=altcorrect, method="slow")
+    assert list(got) == ["Tc", "Tg", "groundsnowdepth", "totalSWE", "snowden", "umu"]
+    # the same through the oracle
+    vg = F.cleanvegp(vegp)
+    obst = {k: np.asarray(v) for k, v in weather["obstime"].items()}
+    wdir = np.array([F.getmode(climarray["winddir"][:, :, k]) for k in range(T)])
+    vc = {k: F.block_reduce(vg[k], cr, cc) for k in ("pai", "hgt", "leaft", "clump")}
+    clim_c = {k: np.array(climarray[k], copy=True) for k in F.WEATHER if k != "winddir"}
+    clim_c["winddir"] = wdir
+    names = {"Gp": "G", "Tc": "Tc", "RswabsG": "RswabsG", "RlwabsG": "RlwabsG", "umu": "umu", "tr": "tr", "sdepc": "sdepc"}
+    pointm_c = {k: np.empty((cr, cc, T)) for k in names}
+    for i in range(cr):
+        for j in range(cc):
+            w = {k: np.ascontiguousarray(clim_c[k][i, j, :]) for k in clim_c if k != "winddir"}
+            pm = RT.pointmodelsnow(obst, w, np.array([np.mean(vc[k][i, j, :]) for k in ("pai", "hgt", "leaft", "clump")]),
+                                   np.array([0, 0, clat[i, j], clon[i, j], 2.0, 0, 0]), "Taiga", maxiter=10)
+            for k, v in names.items():
+                pointm_c[k][i, j, :] = pm[v][:T]
+    other = {"zref": 2.0, "lats": lats, "lons": lons, "isnowdc": z * 0, "isnowac": z * 0, "isnowdg": z * 0, "isnowag": z * 0}
+    want = SA.snowmodel2_chunks(obst, clim_c, pointm_c, F.sortl(vg, np.max(pointm_c["sdepc"], axis=(0, 1))), other, "Taiga", z, dtmc,
+                                dtm["res"], 0.01, api.coarse_positions(50, cr), api.coarse_positions(50, cc), altcorrect=altcorrect,
+                                agg=1)
+    if subset:
+        i = np.asarray(mpa[0]["subs"]) - 1
+        want = {k: v[:, :, i] for k, v in want.items()}
+        assert got["Tc"].shape == (50, 50, 72)
+    for k in want:
+        g, x = got[k], want[k]
+        assert np.array_equal(np.isnan(g), np.isnan(x)), k
+        with np.errstate(invalid="ignore"):
+            err = np.nanmax(np.abs(g - x) / (1 + np.abs(x)))
+        assert err < 1e-6, (k, err)
+    assert np.nanmax(got["groundsnowdepth"]) > 0.005
+    if not subset:
+        assert np.all(np.isnan(got["Tc"][:, :, 240:])) and not np.all(np.isnan(got["umu"][:, :, 240:]))   # past the last chunk
+
+
+def test_array_weather_snow_model_refusals(oracle):
+    weather, vegp, soilc, dtm = load(6 * 24)
+    mp = F.runpointmodel(weather, 0.05, dtm, vegp, soilc)
+    sub = F.subsetpointmodel(mp, days=[2, 4])
+    one = np.ones((1, 2))
+    arr = {k: np.broadcast_to(weather[k][None, None, :], (1, 2, 144)).copy() for k in F.WEATHER}
+    kw = dict(dtmc=one * 50, lats_c=one * dtm["lat"], lons_c=one * dtm["long"], lats=np.full((50, 50), dtm["lat"]),
+              lons=np.full((50, 50), dtm["long"]))
+    with pytest.raises(NotImplementedError, match="snowmodelq2"):
+        F.runsnowmodela(arr, weather["obstime"], [sub, sub], vegp, soilc, dtm, **kw)
+    with pytest.raises(ValueError, match="tallest vegetation"):
+        F.runsnowmodela(arr, weather["obstime"], [sub, sub], vegp, soilc, dtm, method="slow", zref=1.0, **kw)
+    with pytest.raises(ValueError, match="needs a micropoint"):
+        F.runsnowmodela(arr, weather["obstime"], [mp, None], vegp, soilc, dtm, **kw)
