@@ -791,6 +791,100 @@ def runmicro_snow(micropoint: Mapping, reqhgt: float, vegp: Mapping, soilc: Mapp
 
 
 
+def runmicro_snow_array(micropointa: Sequence, crows: int, ccols: int, reqhgt: float, vegp: Mapping, soilc: Mapping,
+                        dtm: Mapping, smod: Mapping, *, dtmc, lats, lons, altcorrect: int = 0, pai_a=None, tfact: float = 1.5,
+                        out: Sequence = (1,) * 10, device: int = 0, _solve=None, _microsnow=None, _terrain=None) -> dict:
+    """`runmicro(..., snow = TRUE, snowmod = smod)` for array weather = `.runmicrosnow2` with `.prepsnowinputs2`
+    (R/internal.R:3661-3742, 3445-3579): as `runmicro_snow`, with the no-snow days through the coarse-array solver and
+    the snow days through gridmicrosnow2 on climate resampled to the fine raster (host numpy, as the reference does it in
+    R; relative humidity from resampled vapour pressure, kept within 20 .. 100 %).  Reference behaviour kept: `.sortl2`
+    sees no snow-covered step here (`micropoints$subs` of a list is NULL), so the vegetation layers are weighted as
+    without snow."""
+    from . import snow as S
+    from .rformulas import lapserate_R, satvap_R, upsample_coarse
+    if any(m is None for m in micropointa):
+        raise ValueError("every coarse cell needs a micropoint")
+    microsnow = S.gridmicrosnow2 if _microsnow is None else _microsnow
+
+    def solve(mpa, **kw):
+        if _solve is not None:
+            return _solve(mpa, reqhgt, **kw)
+        return runmicro_array(mpa, crows, ccols, reqhgt, vegp, soilc, dtm, lats=lats, lons=lons, altcorrect=altcorrect, dtmc=dtmc,
+                              device=device, **kw)
+    veg, soil, z = cleanvars(vegp, soilc, dtm["z"])
+    hole = np.isnan(z)
+    sm = dict(smod)
+    swe = np.array(sm["totalSWE"], dtype=np.float64, copy=True)
+    swe[np.isnan(swe)] = 0.0
+    swe[hole] = np.nan
+    sm["totalSWE"] = swe
+    sd = S.snowdaysfun(S.applycpp3(swe, "max", device=device), S.applycpp3(swe, "min", device=device))
+    alldays = np.arange(1, len(sd["snowdays"]) + 1)
+    snowdays, nosnowdays = alldays[sd["snowdays"] == 1], alldays[sd["nosnowdays"] == 1]
+    rows, cols = z.shape
+    if len(nosnowdays):
+        moutn = solve([subsetpointmodel(m, days=nosnowdays) for m in micropointa], pai_a=pai_a, tfact=tfact, out=out)
+    else:                                                                # .createblanktemplate2
+        moutn = {k: v * np.nan for k, v in solve([subsetpointmodel(m, days=[1]) for m in micropointa], tfact=1.5, out=out).items()}
+    if not len(snowdays):
+        return moutn
+    mps = [subsetpointmodel(m, days=snowdays) for m in micropointa]
+    h = len(snowdays) * 24
+    ai = (np.repeat((snowdays - 1) * 24, 24) + np.tile(np.arange(24), snowdays.size)).astype(np.int64)
+
+    def grid(get):
+        a = np.empty((crows, ccols, h), order="F")
+        for k, m in enumerate(mps):
+            a[k // ccols, k % ccols, :] = get(m)
+        return a
+    rowpos, colpos = api.coarse_positions(rows, crows), api.coarse_positions(cols, ccols)
+    up = lambda a: upsample_coarse(a, rowpos, colpos)                                          # noqa: E731
+    cca = lambda a: np.where(hole[:, :, None], np.nan, up(a))                                  # noqa: E731
+    wc = {k: grid(lambda m, k=k: m["weather"][k]) for k in WEATHER}
+    with np.errstate(invalid="ignore"):
+        ea = up(satvap_R(wc["temp"]) * (wc["relhum"] / 100))
+        temp = up(wc["temp"])
+        if altcorrect == 0:
+            pres = up(wc["pres"])
+        else:
+            zc = np.nan_to_num(np.asarray(dtmc, dtype=np.float64), nan=0.0)
+            pres = up(wc["pres"] / (((293 - 0.0065 * zc[:, :, None]) / 293) ** 5.26)) * (((293 - 0.0065 * z[:, :, None]) / 293) ** 5.26)
+            elevd = (up(zc) - z)[:, :, None]
+            temp = (5 / 1000 if altcorrect == 1 else lapserate_R(temp, ea, pres)) * elevd + temp
+        relhum = np.clip((ea / satvap_R(temp)) * 100, 20.0, 100.0)
+        wd = wc["winddir"] * np.pi / 180
+        wu, wv = wc["windspeed"] * np.cos(wd), wc["windspeed"] * np.sin(wd)
+        w = {"temp": temp, "relhum": relhum, "pres": pres, "swdown": cca(wc["swdown"]), "difrad": cca(wc["difrad"]),
+             "lwdown": cca(wc["lwdown"]), "windspeed": np.sqrt(up(wu) ** 2 + up(wv) ** 2),
+             "winddir": (np.arctan2(np.nanmean(wv, axis=(0, 1)), np.nanmean(wu, axis=(0, 1))) * 180 / np.pi) % 360,
+             "precip": cca(wc["precip"]), "umu": cca(grid(lambda m: m["dfo"]["umu"]))}
+    last = micropointa[-1]
+    vg = sortl2(veg, np.zeros(last["ntme"]), reqhgt, pai_a)
+    res = dtm["res"]
+    xres = res if np.isscalar(res) else res[0]
+    zref = float(last["zref"])
+    ter = terrain.precompute_terrain(z, xres, zref, device=device) if _terrain is None else _terrain(z, xres, zref)
+    other = {"slope": ter["slope"], "aspect": ter["aspect"], "hor": ter["hor"], "skyview": ter["svfa"], "wsa": ter["wsa"],
+             "lat": np.asarray(lats, dtype=np.float64), "lon": np.asarray(lons, dtype=np.float64), "zref": zref,
+             "Smax": soilinit(soil)["Smax"]}
+    s1 = np.arange(h)[np.repeat(np.isin(snowdays, nosnowdays), 24)]
+    s2 = np.arange(len(nosnowdays) * 24)[np.repeat(np.isin(nosnowdays, snowdays), 24)]
+    micro = {}
+    for k, v in moutn.items():
+        a = np.full((rows, cols, h), np.nan, order="F")
+        if len(s1):
+            a[:, :, s1] = np.asarray(v)[:, :, s2]
+        micro[k] = a
+    outm = [int(bool(v)) for v in out]
+    if reqhgt == 0:
+        outm = [1 if i in (0, 3, 5, 6, 7, 8, 9) else 0 for i in range(10)]
+    elif reqhgt < 0:
+        outm = [1 if i in (0, 3) else 0 for i in range(10)]
+    smods = {k: np.asfortranarray(np.asarray(sm[k])[:, :, ai]) for k in ("Tc", "Tg", "groundsnowdepth", "totalSWE", "snowden")}
+    mouts = microsnow(reqhgt, mps[0]["obstime"], w, smods, micro, vg, other, float(np.mean([m["matemp"] for m in micropointa])), outm)
+    return S.merge_snow_outputs(moutn, mouts, snowdays, nosnowdays, rows, cols)
+
+
 # ---- runbioclim() -> .runbioclim1 / .runbioclim3 ------------------------------------------------------------------
 def biosel(obstime: Mapping, tc) -> dict:
     """`.biosel` (R/internal.R:1690-1729): the fourteen days a bioclim run models — for each month the day of median

@@ -177,3 +177,63 @@ def test_array_weather_snow_model_refusals(oracle):
         F.runsnowmodela(arr, weather["obstime"], [sub, sub], vegp, soilc, dtm, method="slow", zref=1.0, **kw)
     with pytest.raises(ValueError, match="needs a micropoint"):
         F.runsnowmodela(arr, weather["obstime"], [mp, None], vegp, soilc, dtm, **kw)
+
+
+@pytest.mark.parametrize("altcorrect", [0, 2])
+def test_runmicro_with_snow_and_array_weather(oracle, altcorrect):
+    """`runmicro(snow = TRUE)` with array weather (`.runmicrosnow2`): a cold spell followed by a thaw over a 2 x 2 climate
+    grid — no-snow days through the coarse-array solver, snow days through gridmicrosnow2, merged by day; the product
+    against the same orchestration with the oracle's solver, snow microclimate and terrain behind it"""
+    from functools import partial
+    from oracle import coarse_oracle as CO
+    from oracle import terrain_oracle as TO
+    from microclimf_amd import api
+    weather, vegp, soilc, dtm = load(15 * 24)
+    cr, cc, T = 2, 2, 15 * 24
+    t = np.arange(T)
+    rng = np.random.default_rng(3)
+    climarray = {}
+    for k in F.WEATHER:
+        base = np.broadcast_to(weather[k][None, None, :], (cr, cc, T)).copy()
+        if k == "temp":
+            base += -9.0 + 8.0 * (t > 5 * 24) + 7.0 * (t > 10 * 24) + rng.uniform(-1.0, 1.0, (cr, cc, 1))
+        elif k in ("swdown", "difrad", "windspeed", "precip"):
+            base *= rng.uniform(0.9, 1.1, (cr, cc, 1))
+        climarray[k] = np.asfortranarray(base)
+    climarray["difrad"] = np.minimum(climarray["difrad"], climarray["swdown"])
+    clat = dtm["lat"] + 1e-4 * np.arange(cr)[:, None] + 0 * np.arange(cc)[None, :]
+    clon = dtm["long"] + 1e-4 * np.arange(cc)[None, :] + 0 * np.arange(cr)[:, None]
+    lats = dtm["lat"] + 9e-6 * np.arange(50)[::-1, None] + 0 * np.arange(50)[None, :]
+    lons = dtm["long"] + 1.4e-5 * np.arange(50)[None, :] + 0 * np.arange(50)[:, None]
+    z = np.asarray(dtm["z"])
+    dtmc = np.array([[np.nanmean(z[:25, :25]), np.nanmean(z[:25, 25:])], [np.nanmean(z[25:, :25]), np.nanmean(z[25:, 25:])]]) + 30.0
+    mpa = F.runpointmodela(climarray, weather["obstime"], 0.05, dtm, vegp, soilc, lats=clat, lons=clon)
+    smod = F.runsnowmodela(climarray, weather["obstime"], mpa, vegp, soilc, dtm, dtmc=dtmc, lats_c=clat, lons_c=clon, lats=lats,
+                           lons=lons, altcorrect=altcorrect)
+    sd = S.snowdaysfun(S.applycpp3(np.nan_to_num(smod["totalSWE"]), "max"), S.applycpp3(np.nan_to_num(smod["totalSWE"]), "min"))
+    assert sd["snowdays"].sum() > 0 and sd["nosnowdays"].sum() > 0
+
+    def solve_oracle(mpx, reqhgt, **kw):
+        tf = kw.pop("tfact", 1.5)
+        zz = F.cleanvars(vegp, soilc, dtm["z"])[2]
+        ter = TO.terrain(zz, dtm["res"], mpx[0]["zref"])
+        a = F.prepare_grid_inputs_array(mpx, cr, cc, reqhgt, vegp, soilc, dtm, lats=lats, lons=lons, slr=ter["slope"],
+                                        apr=ter["aspect"], hor=ter["hor"], svf=ter["svfa"], wsa=ter["wsa"], **kw)
+        a["tfact"] = tf
+        clim, pm = CO.expand(a["climdata"], a["pointm"], api.coarse_positions(50, cr), api.coarse_positions(50, cc),
+                             altcorrect=altcorrect, dtmc=dtmc, dtm=zz)
+        a.update(climdata=clim, pointm=pm)
+        return oracle.run_grid(**a, array_forcing=True)
+
+    kw = dict(dtmc=dtmc, lats=lats, lons=lons, altcorrect=altcorrect)
+    for reqhgt in (0.05, 0.0):
+        got = F.runmicro_snow_array(mpa, cr, cc, reqhgt, vegp, soilc, dtm, smod, **kw)
+        want = F.runmicro_snow_array(mpa, cr, cc, reqhgt, vegp, soilc, dtm, smod, _solve=solve_oracle,
+                                     _microsnow=partial(oracle.run_microsnow, array_forcing=True), _terrain=TO.terrain, **kw)
+        assert list(got) == list(want)
+        for k in want:
+            assert got[k].shape == (50, 50, T)
+            assert np.array_equal(np.isnan(got[k]), np.isnan(want[k])), k
+            with np.errstate(invalid="ignore"):
+                err = np.nanmax(np.abs(got[k] - want[k]) / (1 + np.abs(want[k])))
+            assert err < 1e-6, (reqhgt, k, err)
