@@ -544,6 +544,9 @@ int mcf_pointmodelsnow(int64_t n, const mcf_obstime *obstime, const mcf_point_we
 int mcf_canintfrac(int64_t cells, const double *hgt, const double *pai, double uf, double prec, double tc, double Li,
                    double *frac);
 int mcf_meltmu(int64_t cells, const double *skyview, int64_t n, const double *stemp, const double *tc, double *mu);
+/* mcf_meltmu2 replaces _microclimf_meltmu2 (:5495-5527, `.snowmodelq2`): the same with stemp / tc per cell, [cells, n]
+ * with the cell index fastest (an R array [rows, cols, n]); 0.5 where the denominator is 0.  Host code. */
+int mcf_meltmu2(int64_t cells, int64_t n, const double *mu, const double *stemp, const double *tc, double *out);
 int mcf_tpicalc(int64_t rows, int64_t cols, const double *dtm, int32_t af, double tfact, double *tpic, int32_t device);
 /* manCpp (src/microclimfCpp.cpp:597-627): circular trailing mean, via daily means for windows beyond 48 steps. */
 int mcf_man(int64_t n, const double *x, int32_t window, double *out);

@@ -172,7 +172,7 @@ EXPORTS = (
     "mcf_gridmicrosnow2", "mcf_snowmodel1", "mcf_applycpp3",
     "mcf_snowplan_create", "mcf_snowplan_destroy", "mcf_snowplan_chunks", "mcf_snowplan_surface",
     "mcf_snowplan_surface_partial", "mcf_snowplan_prepare_chunk", "mcf_snowplan_run_chunk",
-    "mcf_bigleaf", "mcf_soilm", "mcf_pointmprocess", "mcf_weatherhgt", "mcf_man", "mcf_pointmodelsnow", "mcf_canintfrac", "mcf_meltmu", "mcf_tpicalc",
+    "mcf_bigleaf", "mcf_soilm", "mcf_pointmprocess", "mcf_weatherhgt", "mcf_man", "mcf_pointmodelsnow", "mcf_canintfrac", "mcf_meltmu", "mcf_meltmu2", "mcf_tpicalc",
     "mcf_nc_create", "mcf_nc_write_host", "mcf_nc_write_plan", "mcf_nc_close",
     "mcf_flowacc", "mcf_topidx",
 )

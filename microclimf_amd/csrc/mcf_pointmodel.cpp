@@ -933,3 +933,20 @@ extern "C" int mcf_meltmu(int64_t cells, const double* skyview, int64_t n, const
     }
     return MCF_OK;
 }
+// meltmu2 (src/microclimfCpp.cpp:5495-5527): meltmu with per-cell series, stemp / tc [cells, n] with the cell index fastest
+extern "C" int mcf_meltmu2(int64_t cells, int64_t n, const double* mu, const double* stemp, const double* tc, double* out) {
+    if (cells <= 0 || n < 0 || !mu || !out || (n > 0 && (!stemp || !tc)))
+        return mcf::api_fail(MCF_ERR_ARG, "mcf_meltmu2: null argument or no cells");
+    for (int64_t i = 0; i < cells; ++i) {
+        if (isnan(mu[i])) { out[i] = NAN; continue; }
+        double dhp = 0.0, dhm = 0.0;
+        for (int64_t k = 0; k < n; ++k) {
+            const double st = stemp[i + cells * k], ta = tc[i + cells * k];
+            if (st > 0.0) dhp += st;
+            const double s2 = (st - ta) * mu[i] + ta;
+            if (s2 > 0.0) dhm += s2;
+        }
+        out[i] = dhp > 0.0 ? dhm / dhp : 0.5;
+    }
+    return MCF_OK;
+}

@@ -586,7 +586,7 @@ def runsnowmodela(climarray: Mapping, obstime: Mapping, micropointa: Sequence, v
     the climate grid, then `snow.snowmodel2_chunks`.  `climarray[k]`: [crows, ccols, T]; `dtmc`, `lats_c`, `lons_c`:
     [crows, ccols] of the climate grid; `lats`, `lons`: [rows, cols] of the fine raster.  A subset micropoint list with
     `method = "slow"` runs the whole series and subsets it (here `umu` too along time; the reference indexes the array as
-    a vector there); `method = "fast"` (`.snowmodelq2`) is not mirrored.  As in the reference every climate cell needs
+    a vector there); `method = "fast"` runs `.snowmodelq2` (R/internal.R:3017-3283) = `snow.snowmodelq2_days`.  As in the reference every climate cell needs
     data, and vegetation taller than `zref` fails (`.snowmodel2` stops at R/internal.R:2838, `climdfr` not found)."""
     from . import snow as S
     vegp = cleanvegp(vegp)
@@ -594,9 +594,10 @@ def runsnowmodela(climarray: Mapping, obstime: Mapping, micropointa: Sequence, v
         raise ValueError("every coarse cell needs a micropoint")
     last = micropointa[-1]                                            # the reference's loop keeps the last one's subs
     subset = len(last["subs"]) != last["ntme"]
+    if method not in ("fast", "slow"):
+        raise ValueError('method is "fast" or "slow"')
+    fast = subset and method == "fast"
     if subset:
-        if method == "fast":
-            raise NotImplementedError('the fast array snow method (`.snowmodelq2`) is not mirrored: use method = "slow"')
         zref = float(zref)
         windhgt = zref if windhgt is None else float(windhgt)
     else:
@@ -616,6 +617,8 @@ def runsnowmodela(climarray: Mapping, obstime: Mapping, micropointa: Sequence, v
         clim_c["windspeed"] *= np.log(67.8 * zref - 5.42) / np.log(67.8 * windhgt - 5.42)
     clim_c["winddir"] = wdir
     pn = {"Gp": "G", "Tc": "Tc", "RswabsG": "RswabsG", "RlwabsG": "RlwabsG", "umu": "umu", "tr": "tr", "sdepc": "sdepc"}
+    if fast:                                                          # `.snowmodelq2`: depth after the step, the melt terms
+        pn.update({k: k for k in ("sublmelt", "tempmelt", "rainmelt", "sstemp", "sdenc", "sdeng")})
     pointm_c = {k: np.empty((cr, cc, T), order="F") for k in pn}
     for i in range(cr):
         for j in range(cc):
@@ -625,16 +628,31 @@ def runsnowmodela(climarray: Mapping, obstime: Mapping, micropointa: Sequence, v
             pmod = pointmodel.pointmodelsnow(ob, w, vegpp, [0.0, 0.0, float(lats_c[i, j]), float(lons_c[i, j]), zref, snowinitd,
                                                             snowinita], snowenv, maxiter=10)
             for k, v in pn.items():
-                pointm_c[k][i, j, :] = pmod[v][:T]
+                pointm_c[k][i, j, :] = pmod[v][1:T + 1] if fast and k == "sdepc" else pmod[v][:T]
+    res = dtm["res"]
+    xres = res if np.isscalar(res) else res[0]
+    rowpos, colpos = api.coarse_positions(R, cr), api.coarse_positions(Cc, cc)
+    if fast:                                                          # R/internal.R:3017-3283
+        subs = np.asarray(last["subs"], dtype=np.int64)
+        ai = subs - 1
+        pm2_c = {k: pointm_c[k] for k in ("sublmelt", "tempmelt", "rainmelt", "sstemp", "sdenc", "sdeng")}
+        pm2_c["tc"] = clim_c["temp"]
+        pm2_c["snow"] = np.where(clim_c["temp"] > 2, 0.0, clim_c["precip"])
+        sel = lambda d: {k: (np.asarray(v)[ai] if np.ndim(v) == 1 else np.asfortranarray(np.asarray(v)[:, :, ai]))   # noqa: E731
+                         for k, v in d.items()}
+        pm_s = sel({k: pointm_c[k] for k in ("Gp", "Tc", "RswabsG", "RlwabsG", "umu", "tr", "sdepc")})
+        vg = sortl(vegp, np.max(pm_s["sdepc"], axis=(0, 1)))
+        other = {"zref": zref, "lats": np.asarray(lats, dtype=np.float64), "lons": np.asarray(lons, dtype=np.float64),
+                 "isnowdc": z * 0 + snowinitd, "isnowac": z * 0 + snowinita, "isnowag": z * 0 + snowinita}
+        return S.snowmodelq2_days(sel(ob), sel(clim_c), pm_s, pm2_c, subs, vg, other, snowenv, z, np.asarray(dtmc, dtype=np.float64),
+                                  xres, stfact, rowpos=rowpos, colpos=colpos, altcorrect=altcorrect, device=device)
     vg = sortl(vegp, np.max(pointm_c["sdepc"], axis=(0, 1)))
     sdep = z * 0 + snowinitd
     sage = z * 0 + snowinita
     other = {"zref": zref, "lats": np.asarray(lats, dtype=np.float64), "lons": np.asarray(lons, dtype=np.float64),
              "isnowdc": sdep, "isnowac": sage, "isnowdg": sdep * 0.5, "isnowag": sage}
-    res = dtm["res"]
-    xres = res if np.isscalar(res) else res[0]
     out = S.snowmodel2_chunks(ob, clim_c, pointm_c, vg, other, snowenv, z, np.asarray(dtmc, dtype=np.float64), xres, stfact,
-                              rowpos=api.coarse_positions(R, cr), colpos=api.coarse_positions(Cc, cc), altcorrect=altcorrect,
+                              rowpos=rowpos, colpos=colpos, altcorrect=altcorrect,
                               agg=10 if xres <= 100 and min(cr, cc) >= 10 else 1, device=device)
     if subset:
         i = np.asarray(last["subs"], dtype=np.int64) - 1

@@ -341,6 +341,126 @@ def snowmodelq1_days(obstime, climdata, pointm, pmod, temp_all, snow_all, subs, 
     return {"Tc": out["Tc"], "Tg": out["Tg"], "groundsnowdepth": out["sdepg"], "totalSWE": swe, "snowden": out["snowden"]}
 
 
+def _fine_snow_inputs(clim_c, pointm_c, sl, z, zc, rowpos, colpos, altcorrect, wu_c, wv_c, winddir):
+    """Steps `sl` of the coarse climate and snow point-model arrays on the fine raster, as `.snowmodel2` / `.snowmodelq2`
+    prepare them (R/internal.R:2862-2925, 3108-3170): `.cca` = bilinear and masked by the dtm, pressure and wind
+    components unmasked, altitude correction 0 / 1 / 2, relative humidity capped at 100"""
+    from .rformulas import lapserate_R, satvap_R, upsample_coarse
+    hole = np.isnan(z)
+    up = lambda a: upsample_coarse(np.asarray(a)[:, :, sl], rowpos, colpos)            # noqa: E731
+    cca = lambda a: np.where(hole[:, :, None], np.nan, up(a))                          # noqa: E731
+    temp, relhum = cca(clim_c["temp"]), cca(clim_c["relhum"])
+    if altcorrect == 0:
+        pres = up(clim_c["pres"])
+    else:
+        ea = satvap_R(temp) * relhum / 100
+        pres = up(np.asarray(clim_c["pres"]) / (((293 - 0.0065 * zc) / 293) ** 5.26)[:, :, None]) * (((293 - 0.0065 * z) / 293) ** 5.26)[:, :, None]
+        elevd = (upsample_coarse(zc, rowpos, colpos) - z)[:, :, None]
+        lr = 5 / 1000 if altcorrect == 1 else lapserate_R(temp, ea, pres)
+        temp = lr * elevd + temp
+        relhum = (ea / satvap_R(temp)) * 100
+    relhum = np.where(relhum > 100, 100.0, relhum)
+    clim = {"temp": temp, "relhum": relhum, "pres": pres, "swdown": cca(clim_c["swdown"]), "difrad": cca(clim_c["difrad"]),
+            "lwdown": cca(clim_c["lwdown"]), "precip": cca(clim_c["precip"]),
+            "windspeed": np.sqrt(up(wu_c) ** 2 + up(wv_c) ** 2), "winddir": winddir[sl]}
+    return clim, {k: cca(pointm_c[k]) for k in ("Gp", "Tc", "RswabsG", "RlwabsG", "umu", "tr")}
+
+
+def meltmu2(mu, stemp, tc) -> np.ndarray:
+    """`meltmu2` (src/microclimfCpp.cpp:5495-5527): as `meltmu` with the snow surface and air temperatures given per
+    cell [rows, cols, n]; 0.5 where the surface never thaws (host code)"""
+    lib = _abi.load()
+    m = np.asfortranarray(np.asarray(mu, dtype=np.float64))
+    st = np.asfortranarray(np.asarray(stemp, dtype=np.float64))
+    ta = np.asfortranarray(np.asarray(tc, dtype=np.float64))
+    if st.shape != ta.shape or st.shape[:2] != m.shape:
+        raise ValueError("stemp and tc must be [rows, cols, n] over mu's raster")
+    out = np.empty(m.shape, dtype=np.float64, order="F")
+    _abi.check(lib.mcf_meltmu2(C.c_int64(m.size), C.c_int64(st.shape[2]), m.ctypes.data_as(_abi.c_double_p),
+                               st.ctypes.data_as(_abi.c_double_p), ta.ctypes.data_as(_abi.c_double_p),
+                               out.ctypes.data_as(_abi.c_double_p)))
+    return out
+
+
+def snowmodelq2_days(obstime, clim_c, pointm_c, pm2_c, subs, vegp, other, snowenv, dtm, dtmc, res, tfact=0.02, *, rowpos, colpos,
+                     altcorrect: int = 0, device: int = 0) -> dict:
+    """The second half of the reference's fast array-weather snow method `.snowmodelq2` (R/internal.R:3108-3283).
+    `obstime`, `clim_c`, `pointm_c`: the selected hours (coarse arrays as for `snowmodel2_chunks`); `pm2_c`: coarse arrays
+    over the WHOLE series — sublmelt, tempmelt, rainmelt, snow, sstemp, tc, sdenc, sdeng; `subs`: 1-based positions of the
+    selected hours.  Between two selected days each cell's pack moves by the resampled point-model balance (`meltmu2`
+    scaling the temperature melt by sky view), each selected day runs gridmodelsnow2 on terrain of the bare dtm and
+    spreads the ground-snow change by `.tpicalc`.  Unlike `.snowmodelq1` a first selected day that is the first day of
+    the series is accepted (no adjustment then)."""
+    from . import terrain as T
+    from .rformulas import upsample_coarse
+    z = np.asarray(dtm, dtype=np.float64)
+    hole = np.isnan(z)
+    R, Cc = z.shape
+    subs = np.asarray(subs, dtype=np.int64)
+    n = subs.size
+    if n % 24 or n == 0:
+        raise ValueError("the fast snow method works on whole selected days")
+    zc = np.nan_to_num(np.asarray(dtmc, dtype=np.float64), nan=0.0)
+    wd = np.asarray(clim_c["winddir"], dtype=np.float64) * np.pi / 180
+    wu_c = np.asarray(clim_c["windspeed"], dtype=np.float64) * np.cos(wd)
+    wv_c = np.asarray(clim_c["windspeed"], dtype=np.float64) * np.sin(wd)
+    wuv, wvv = np.nanmean(wu_c, axis=(0, 1)), np.nanmean(wv_c, axis=(0, 1))
+    winddir = (np.arctan2(wvv, wuv) * 180 / np.pi) % 360
+    oth = dict(other)
+    oth.update(T.snow_terrain(z, res, float(other["zref"]), device=device))
+    vg = dict(vegp)
+    vg["leaft"] = np.where(np.isnan(vg["leaft"]), 0.01, vg["leaft"])
+    pai = np.asarray(vg["pai"], dtype=np.float64)
+    up = lambda a: upsample_coarse(a, rowpos, colpos)                                      # noqa: E731
+    cca = lambda a: np.where(hole[:, :, None], np.nan, up(a))                              # noqa: E731
+    snow_c = np.asarray(pm2_c["snow"], dtype=np.float64)
+    pos = snow_c[snow_c > 0]
+    msnow = float(pos.mean()) if pos.size else float("nan")
+    mtemp = float(np.nanmean(cca(pm2_c["tc"])))
+    intfrac = canintfrac(vg["hgt"], vg["pai"], 2.0, msnow, mtemp, 0.0)
+    isnowdc = np.array(oth["isnowdc"], dtype=np.float64)
+    isnowdg = (1 - intfrac) * isnowdc
+    names = ("Tc", "Tg", "sdepc", "snowden", "umu")
+    out = {k: np.full((R, Cc, n), np.nan, order="F") for k in names}
+    out["sdepg"] = np.zeros((R, Cc, n), order="F")
+    ped = 0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for day in range(n // 24):
+            sl = slice(day * 24, day * 24 + 24)
+            first = int(subs[day * 24])
+            if first - 1 > 1:
+                sbtn = r_colon(ped + 1, first - 1)
+                tot = lambda k: up(np.asarray(pm2_c[k])[:, :, sbtn].sum(axis=2))          # noqa: E731  `.resamplemelt`
+                mu = meltmu2(oth["skyview"], cca(np.asarray(pm2_c["sstemp"])[:, :, sbtn]), cca(np.asarray(pm2_c["tc"])[:, :, sbtn]))
+                melt = tot("sublmelt") + tot("rainmelt") + mu * tot("tempmelt")
+                fall = tot("snow") / 1000
+                isnowdc = isnowdc + (fall - melt) * (1000 / (tot("sdenc") / sbtn.size))
+                isnowdg = isnowdg + ((1 - intfrac) * fall - np.exp(-pai) * melt) * (1000 / (tot("sdeng") / sbtn.size))
+            isnowdc[isnowdc < 0] = 0
+            isnowdg[isnowdg < 0] = 0
+            oth["isnowdc"], oth["isnowdg"] = isnowdc, isnowdg
+            clim, pointm = _fine_snow_inputs(clim_c, pointm_c, sl, z, zc, rowpos, colpos, altcorrect, wu_c, wv_c, winddir)
+            smod = gridmodelsnow2({k: np.asarray(v)[sl] for k, v in obstime.items()}, clim, pointm, vg, oth, snowenv, device=device)
+            dsnow = smod["sdepc"] - isnowdc[:, :, None]
+            dsnowg = smod["sdepg"] - isnowdg[:, :, None]
+            af = int(np.round(10 * np.mean(np.sqrt(wuv[sl] ** 2 + wvv[sl] ** 2)) ** 0.5 / res))
+            tpi = tpicalc(af, z, tfact, device=device)
+            dsnowg2 = dsnowg * tpi[:, :, None]
+            sdc = (dsnow - dsnowg) + dsnowg2 + isnowdc[:, :, None]
+            sdg = dsnowg2 + isnowdg[:, :, None]
+            sdc[sdc < 0] = 0
+            sdg[sdg < 0] = 0
+            out["Tc"][:, :, sl], out["Tg"][:, :, sl], out["snowden"][:, :, sl] = smod["Tc"], smod["Tg"], smod["sden"]
+            out["sdepc"][:, :, sl], out["sdepg"][:, :, sl], out["umu"][:, :, sl] = sdc, sdg, pointm["umu"]
+            ped = int(subs[day * 24 + 23])
+            isnowdc, isnowdg = sdc[:, :, 23].copy(), sdg[:, :, 23].copy()
+        res_ = {"Tc": out["Tc"], "Tg": out["Tg"], "groundsnowdepth": out["sdepg"], "totalSWE": out["sdepc"] * out["snowden"],
+                "snowden": out["snowden"], "umu": out["umu"]}
+    for v in res_.values():                                             # `.cleansmod`
+        v[hole] = np.nan
+    return res_
+
+
 def snowmodel2_chunks(obstime, clim_c, pointm_c, vegp, other, snowenv, dtm, dtmc, res, tfact=0.02, *, rowpos, colpos,
                       altcorrect: int = 0, agg: int = 10, chunk_steps: int = 120, device: int = 0) -> dict:
     """The second half of the reference's `.snowmodel2` (R/internal.R:2862-3013): coarse climate and snow point-model
@@ -352,7 +472,7 @@ def snowmodel2_chunks(obstime, clim_c, pointm_c, vegp, other, snowenv, dtm, dtmc
     isnowdg, isnowac, isnowag.  Reference behaviours kept: `other$isnowdg` is never updated, the aggregation factor of the
     position index is at least 2, `1:n5days` truncates."""
     from . import terrain as T
-    from .rformulas import lapserate_R, satvap_R, upsample_coarse
+    from .rformulas import upsample_coarse
     z = np.asarray(dtm, dtype=np.float64)
     R, Cc = z.shape
     h = len(np.asarray(obstime["year"]))
@@ -373,29 +493,11 @@ def snowmodel2_chunks(obstime, clim_c, pointm_c, vegp, other, snowenv, dtm, dtmc
     vg["leaft"] = np.where(np.isnan(vg["leaft"]), 0.001, vg["leaft"])
     isnowdg = np.asarray(other["isnowdg"], dtype=np.float64)
     dtms = z + isnowdg
-    sea = ((293 - 0.0065 * zc) / 293) ** 5.26
-    fine = ((293 - 0.0065 * z) / 293) ** 5.26
-    elevd = (upsample_coarse(zc, rowpos, colpos) - z)[:, :, None]
     with np.errstate(invalid="ignore"):
         for ch in range(nch):
             sl = slice(ch * chunk_steps, min((ch + 1) * chunk_steps, h))
-            up = lambda a: upsample_coarse(np.asarray(a)[:, :, sl], rowpos, colpos)            # noqa: E731
-            cca = lambda a: np.where(hole[:, :, None], np.nan, up(a))                          # noqa: E731  `.cca`: masked
             oth.update(T.snow_terrain(dtms, res, float(other["zref"]), agg=agg, mask=z, device=device))
-            temp, relhum = cca(clim_c["temp"]), cca(clim_c["relhum"])
-            if altcorrect == 0:
-                pres = up(clim_c["pres"])
-            else:
-                ea = satvap_R(temp) * relhum / 100
-                pres = up(np.asarray(clim_c["pres"])[:, :, :] / sea[:, :, None]) * fine[:, :, None]
-                lr = 5 / 1000 if altcorrect == 1 else lapserate_R(temp, ea, pres)
-                temp = lr * elevd + temp
-                relhum = (ea / satvap_R(temp)) * 100
-            relhum = np.where(relhum > 100, 100.0, relhum)
-            clim = {"temp": temp, "relhum": relhum, "pres": pres, "swdown": cca(clim_c["swdown"]), "difrad": cca(clim_c["difrad"]),
-                    "lwdown": cca(clim_c["lwdown"]), "precip": cca(clim_c["precip"]),
-                    "windspeed": np.sqrt(up(wu_c) ** 2 + up(wv_c) ** 2), "winddir": winddir[sl]}
-            pointm = {k: cca(pointm_c[k]) for k in ("Gp", "Tc", "RswabsG", "RlwabsG", "umu", "tr")}
+            clim, pointm = _fine_snow_inputs(clim_c, pointm_c, sl, z, zc, rowpos, colpos, altcorrect, wu_c, wv_c, winddir)
             smod = gridmodelsnow2({k: np.asarray(v)[sl] for k, v in obstime.items()}, clim, pointm, vg, oth, snowenv, device=device)
             af = max(int(np.round(10 * np.mean(np.sqrt(wuv[sl] ** 2 + wvv[sl] ** 2)) ** 0.5 / res)), 2)
             tpi = tpicalc(af, dtms, tfact, device=device)[:, :, None]

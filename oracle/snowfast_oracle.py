@@ -148,3 +148,130 @@ def snowmodelq1_days(obstime, climdata, pointm, pmod, temp_all, snow_all, subs, 
             isnowdc = sdc[:, :, 23].copy()
             isnowdg = sdg[:, :, 23].copy()
     return {"Tc": Tc, "Tg": Tg, "groundsnowdepth": sdepg, "totalSWE": sdepc * sden, "snowden": sden}
+
+
+def meltmu2(mu, stemp, tc):
+    """cpp:5495-5527"""
+    mu = np.asarray(mu, dtype=np.float64)
+    stemp = np.asarray(stemp, dtype=np.float64)
+    tc = np.asarray(tc, dtype=np.float64)
+    out = np.empty(mu.shape)
+    for i, j in np.ndindex(mu.shape):
+        if np.isnan(mu[i, j]):
+            out[i, j] = np.nan
+            continue
+        dhp = dhm = 0.0
+        for k in range(stemp.shape[2]):
+            if stemp[i, j, k] > 0.0:
+                dhp += stemp[i, j, k]
+            s2 = (stemp[i, j, k] - tc[i, j, k]) * mu[i, j] + tc[i, j, k]
+            if s2 > 0.0:
+                dhm += s2
+        out[i, j] = dhm / dhp if dhp > 0.0 else 0.5
+    return out
+
+
+def snowmodelq2_days(obstime, clim_c, pointm_c, pm2_c, subs, vegp, other, snowenv, dtm, dtmc, res, tfact, rowpos, colpos,
+                     altcorrect=0):
+    """`.snowmodelq2`, R/internal.R:3108-3283 (arguments as microclimf_amd.snow.snowmodelq2_days)"""
+    from . import coarse_oracle as CO
+    dtm = np.asarray(dtm, dtype=np.float64)
+    R, Cc = dtm.shape
+    nanmask = np.isnan(dtm)
+    subs = np.asarray(subs, dtype=np.int64)
+    n = subs.size
+    zc = np.nan_to_num(np.asarray(dtmc, dtype=np.float64), nan=0.0)
+    zref = float(other["zref"])
+
+    def cca(a, mask=True):
+        f = CO.upsample(a, rowpos, colpos)
+        if mask:
+            f[nanmask] = np.nan
+        return f
+    temp = cca(clim_c["temp"])
+    relhum = cca(clim_c["relhum"])
+    if altcorrect == 0:
+        pres = cca(clim_c["pres"], False)
+    else:
+        ea = CO.satvap_R(temp) * relhum / 100
+        psl = cca(np.asarray(clim_c["pres"]) / (((293 - 0.0065 * zc[:, :, None]) / 293) ** 5.26), False)
+        pres = psl * (((293 - 0.0065 * dtm[:, :, None]) / 293) ** 5.26)
+        elevd = (CO.upsample(zc[:, :, None], rowpos, colpos)[:, :, 0] - dtm)[:, :, None]
+        tcdif = elevd * (5 / 1000) if altcorrect == 1 else CO.lapserate(temp, ea, pres) * elevd
+        temp = tcdif + temp
+        relhum = (ea / CO.satvap_R(temp)) * 100
+    with np.errstate(invalid="ignore"):
+        relhum[relhum > 100] = 100
+    wd = np.asarray(clim_c["winddir"], dtype=np.float64) * np.pi / 180
+    wu = np.asarray(clim_c["windspeed"]) * np.cos(wd)
+    wv = np.asarray(clim_c["windspeed"]) * np.sin(wd)
+    wuv, wvv = np.nanmean(wu, axis=(0, 1)), np.nanmean(wv, axis=(0, 1))
+    clim = {"temp": temp, "relhum": relhum, "pres": pres, "difrad": cca(clim_c["difrad"]), "swdown": cca(clim_c["swdown"]),
+            "lwdown": cca(clim_c["lwdown"]), "precip": cca(clim_c["precip"]),
+            "windspeed": np.sqrt(cca(wu, False) ** 2 + cca(wv, False) ** 2), "winddir": (np.arctan2(wvv, wuv) * 180 / np.pi) % 360}
+    pointm = {k: cca(pointm_c[k]) for k in ("Gp", "Tc", "RswabsG", "RlwabsG", "umu", "tr")}
+    sstemp_f, tc_f = cca(pm2_c["sstemp"]), cca(pm2_c["tc"])
+    vg = dict(vegp)
+    vg["leaft"] = np.where(np.isnan(vg["leaft"]), 0.01, vg["leaft"])
+    slope, aspect = TO.slope_aspect(dtm, res, aspect_na=180.0)
+    hor = TO.horizons24(dtm, res)
+    oth = dict(other)
+    oth.update(slope=np.where(nanmask, np.nan, slope), aspect=np.where(nanmask, np.nan, aspect), hor=hor, skyview=TO.skyview(hor),
+               wsa=TO.windsheltera(dtm, zref, 10 if res <= 100 else 1, res))
+    snow_c = np.asarray(pm2_c["snow"], dtype=np.float64)
+    pos = snow_c[snow_c > 0]
+    msnow = pos.mean() if pos.size else np.nan
+    mtemp = np.nanmean(tc_f)
+    intfrac = canintfrac(vg["hgt"], vg["pai"], 2, msnow, mtemp, 0)
+    isnowdc = np.array(other["isnowdc"], dtype=np.float64)
+    isnowdg = (1 - intfrac) * isnowdc
+    Tc = np.full((R, Cc, n), np.nan)
+    Tg = Tc.copy(); sdepc = Tc.copy(); sden = Tc.copy()
+    sdepg = np.zeros((R, Cc, n))
+    ped = 0
+
+    def resamplemelt(a, sbtn):
+        return CO.upsample(np.asarray(a)[:, :, sbtn].sum(axis=2)[:, :, None], rowpos, colpos)[:, :, 0]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for day in range(n // 24):
+            st = day * 24
+            s = slice(st, st + 24)
+            if subs[st] - 1 > 1:
+                sbtn = _colon(ped + 1, int(subs[st]) - 1)
+                mu = meltmu2(oth["skyview"], sstemp_f[:, :, sbtn], tc_f[:, :, sbtn])
+                melt = resamplemelt(pm2_c["sublmelt"], sbtn) + resamplemelt(pm2_c["rainmelt"], sbtn) + mu * resamplemelt(pm2_c["tempmelt"], sbtn)
+                snowsum = resamplemelt(pm2_c["snow"], sbtn)
+                balancec = snowsum / 1000 - melt
+                balanceg = (1 - intfrac) * snowsum / 1000 - np.exp(-np.asarray(vg["pai"])) * melt
+                sdec = resamplemelt(pm2_c["sdenc"], sbtn) / len(sbtn)
+                sdeg = resamplemelt(pm2_c["sdeng"], sbtn) / len(sbtn)
+                isnowdc = isnowdc + balancec * (1000 / sdec)
+                isnowdg = isnowdg + balanceg * (1000 / sdeg)
+            isnowdc[isnowdc < 0] = 0
+            isnowdg[isnowdg < 0] = 0
+            oth["isnowdc"], oth["isnowdg"] = isnowdc, isnowdg
+            c1 = {k: (np.asarray(v)[s] if k == "winddir" else np.asfortranarray(v[:, :, s])) for k, v in clim.items()}
+            p1 = {k: np.asfortranarray(v[:, :, s]) for k, v in pointm.items()}
+            smod = O.run_snowmodel({k: np.asarray(v)[s] for k, v in obstime.items()}, c1, p1, vg, oth, snowenv, array_forcing=True)
+            dsnow = smod["sdepc"] - isnowdc[:, :, None]
+            dsnowg = smod["sdepg"] - isnowdg[:, :, None]
+            dsnowc = dsnow - dsnowg
+            dtms = dtm + sdepg[:, :, st + 23]
+            wss = np.sqrt(wuv[s] ** 2 + wvv[s] ** 2)
+            af = int(np.round(10 * np.mean(wss) ** 0.5 / res))
+            tpi = SD.tpicalc(af, min(R, Cc), dtms, tfact)
+            dsnowg2 = dsnowg * tpi[:, :, None]
+            sdc = dsnowc + dsnowg2 + isnowdc[:, :, None]
+            sdg = dsnowg2 + isnowdg[:, :, None]
+            sdc[sdc < 0] = 0
+            sdg[sdg < 0] = 0
+            Tc[:, :, s] = smod["Tc"]; Tg[:, :, s] = smod["Tg"]; sden[:, :, s] = smod["sden"]
+            sdepc[:, :, s] = sdc
+            sdepg[:, :, s] = sdg
+            ped = int(subs[st + 23])
+            isnowdc = sdc[:, :, 23].copy()
+            isnowdg = sdg[:, :, 23].copy()
+        out = {"Tc": Tc, "Tg": Tg, "groundsnowdepth": sdepg, "totalSWE": sdepc * sden, "snowden": sden, "umu": pointm["umu"]}
+    for v in out.values():
+        v[nanmask] = np.nan
+    return out

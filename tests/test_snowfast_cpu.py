@@ -45,6 +45,20 @@ def test_meltmu_matches_the_oracle():
     assert np.all(S.meltmu(sv, stemp[:0], tc[:0]) == 1.0)
 
 
+def test_meltmu2_matches_the_oracle():
+    rng = np.random.default_rng(8)
+    mu = rng.uniform(0.3, 1.0, (5, 4))
+    mu[2, 2] = np.nan
+    stemp = rng.normal(0.3, 3.0, (5, 4, 60))
+    tc = stemp - rng.uniform(0.0, 4.0, (5, 4, 60))
+    stemp[0, 0, :] = -1.0                                # never thaws: 0.5 (cpp:5518-5520)
+    stemp[4, 3, 5] = np.nan                              # a masked step counts for nothing
+    got, want = S.meltmu2(mu, stemp, tc), SF.meltmu2(mu, stemp, tc)
+    np.testing.assert_allclose(got, want, rtol=1e-12, equal_nan=True)
+    assert np.isnan(got[2, 2]) and got[0, 0] == 0.5
+    np.testing.assert_allclose(S.meltmu2(mu, stemp[:, :, :0], tc[:, :, :0])[~np.isnan(mu)], 0.5)
+
+
 def test_r_colon_counts_down_like_R():
     assert list(S.r_colon(3, 6)) == [2, 3, 4, 5]
     assert list(S.r_colon(25, 24)) == [24, 23]          # two consecutive selected days: `(ped + 1):(subs[st] - 1)`

@@ -24,7 +24,7 @@ for name in ("mcf_bigleaf", "mcf_soilm", "mcf_pointmprocess", "mcf_weatherhgt", 
 # route the Python mirrors to the sanitizer build: give the ctypes handle the prototypes _abi sets up
 real = _abi.load()
 for name in ("mcf_bigleaf", "mcf_soilm", "mcf_pointmprocess", "mcf_weatherhgt", "mcf_man", "mcf_pointmodelsnow", "mcf_flowacc",
-             "mcf_topidx", "mcf_canintfrac", "mcf_meltmu"):
+             "mcf_topidx", "mcf_canintfrac", "mcf_meltmu", "mcf_meltmu2"):
     f = getattr(lib, name)
     f.restype, f.argtypes = getattr(real, name).restype, getattr(real, name).argtypes
     setattr(real, name, f)                       # later calls through _abi.load() hit the ASan build
@@ -62,6 +62,8 @@ for shape in ((1, 1), (3, 50), (50, 50)):                                 # the 
     for n in (0, 1, 24, 700):
         st = rng.normal(0, 3, n)
         S.meltmu(sv, st, st - 1.0)
+        st3 = rng.normal(0, 3, shape + (n,))
+        S.meltmu2(sv, st3, st3 - 1.0)
     for prec in (0.0, float("nan"), 0.3, 40.0):
         S.canintfrac(np.where(np.isnan(sv), np.nan, 10 * sv), 5 * sv, 2.0, prec, -4.0, 0.0)
 print("host-side C++ through ASan + UBSan: clean")
