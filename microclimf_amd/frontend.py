@@ -712,6 +712,16 @@ def subsetpointmodel(micropoint: Mapping, tstep: str = "month", what: str = "tma
     return out
 
 
+def subsetpointmodela(micropointa: Sequence, tstep: str = "month", what: str = "tmax", days=None) -> list:
+    """`subsetpointmodela` (R/dataprep.R:105-138): the same days for every cell of the climate grid — chosen, as there,
+    from the mean canopy temperature over the cells that have a point model"""
+    have = [m for m in micropointa if m is not None]
+    if days is None:
+        tc = np.mean([np.asarray(m["dfo"]["Tc"], dtype=np.float64) for m in have], axis=0)
+        return [None if m is None else subsetpointmodel(m, tstep, what, Tc=tc) for m in micropointa]
+    return [None if m is None else subsetpointmodel(m, days=days) for m in micropointa]
+
+
 def subsetsnowmodel(smod: Mapping, subs) -> dict:
     """`subsetsnowmodel` (R/dataprep.R:148-160); `subs` 1-based.  (The reference tests `snowmods$umu`, which does not
     exist yet, so `umu` is always subset as a vector.)"""
@@ -1012,10 +1022,11 @@ def tile_window(rw: int, cl: int, rows: int, cols: int, tilesize: int, toverlap:
     return r0, r1, c0, c1
 
 
-def runmicro_big(micropoint: Mapping, reqhgt: float, pathout: str, vegp: Mapping, soilc: Mapping, dtm: Mapping, *,
+def runmicro_big(micropoint, reqhgt: float, pathout: str, vegp: Mapping, soilc: Mapping, dtm: Mapping, *,
                  tilesize: int | None = None, toverlap: int = 0, pai_a=None, tfact: float = 1.5,
                  vars: Sequence[str] | None = None, days_per_chunk: int = 5, device: int = 0, rank: int = 0,
-                 world: int = 1) -> list:
+                 world: int = 1, crows: int | None = None, ccols: int | None = None, lats=None, lons=None, dtmc=None,
+                 altcorrect: int = 0) -> list:
     """`runmicro_big(micropoint, reqhgt, pathout, vegp, soilc, dtm, ..., writeasnc = TRUE)` for data.frame weather
     (R/Cppwrappers.R:446-541): slope, aspect, wetness index, horizons, sky view and wind shelter once for the WHOLE raster
     (wind shelter from the surface model dtm + hgt at 8 m, as there), then tile by tile the solver and
@@ -1024,7 +1035,11 @@ def runmicro_big(micropoint: Mapping, reqhgt: float, pathout: str, vegp: Mapping
     `dtm` needs "xmin", "ymax" besides "z" / "res" / "lat" / "long" for the files' coordinates.  Returns the files written.
     With `world` > 1 (one process per GPU) the tiles are dealt round-robin: tile k goes to rank k % world; the universal
     variables are computed by every rank (seconds), no exchange is needed.
-    (In the reference this function stops at an undefined `svfi`, R/Cppwrappers.R:520; what it sets out to do is done.)"""
+    (In the reference this function stops at an undefined `svfi`, R/Cppwrappers.R:520; what it sets out to do is done.)
+    Array weather (`runmicro_big(micropointa, ..., dtm, dtmc, altcorrect)`, vignette "Running the model over large
+    areas"): `micropoint` is `runpointmodela`'s list for a `crows` x `ccols` climate grid over the whole raster, `lats`,
+    `lons` [rows, cols]; every tile interpolates the coarse arrays inside the solver at its own place in that grid, so
+    tiles join without a seam in the forcing."""
     import os
     from . import pipeline
     if reqhgt < 0:
@@ -1032,11 +1047,15 @@ def runmicro_big(micropoint: Mapping, reqhgt: float, pathout: str, vegp: Mapping
     z_all = np.asarray(dtm["z"], dtype=np.float64)
     rows, cols = z_all.shape
     res = dtm["res"] if np.isscalar(dtm["res"]) else dtm["res"][0]
-    nt = len(micropoint["weather"]["temp"])
+    array = not isinstance(micropoint, Mapping)
+    if array and (crows is None or ccols is None or lats is None or lons is None or len(micropoint) != crows * ccols):
+        raise ValueError("array weather needs crows, ccols (matching the list of micropoints), lats and lons")
+    first = micropoint[0] if array else micropoint
+    nt = len(first["weather"]["temp"])
     ts = tile_size(nt, toverlap) if tilesize is None else int(tilesize)
     os.makedirs(os.path.join(pathout, "microut"), exist_ok=True)
     # universal variables, R/Cppwrappers.R:482-499
-    ter = terrain.precompute_terrain(z_all, res, micropoint["zref"], what=("slope", "aspect", "hor", "svfa"), device=device)
+    ter = terrain.precompute_terrain(z_all, res, first["zref"], what=("slope", "aspect", "hor", "svfa"), device=device)
     slr, apr = ter["slope"], ter["aspect"]
     slr[np.isnan(z_all)] = np.nan
     apr[np.isnan(z_all)] = np.nan
@@ -1056,14 +1075,21 @@ def runmicro_big(micropoint: Mapping, reqhgt: float, pathout: str, vegp: Mapping
                 continue
             crop = lambda a: np.asarray(a)[r0:r1, c0:c1]                           # noqa: E731
             dtmi = dict(dtm, z=zi)
-            a = prepare_grid_inputs(micropoint, reqhgt, {k: crop(v) for k, v in vegp.items()},
-                                    {k: crop(v) for k, v in soilc.items()}, dtmi, pai_a=None if pai_a is None else crop(pai_a),
-                                    slr=crop(slr), apr=crop(apr), hor=crop(ter["hor"]), twi=crop(twi), wsa=crop(wsa),
-                                    svf=crop(ter["svfa"]), device=device)
+            vegi, soili = {k: crop(v) for k, v in vegp.items()}, {k: crop(v) for k, v in soilc.items()}
+            pre = dict(pai_a=None if pai_a is None else crop(pai_a), slr=crop(slr), apr=crop(apr), hor=crop(ter["hor"]),
+                       twi=crop(twi), wsa=crop(wsa), svf=crop(ter["svfa"]), device=device)
+            if array:
+                a = prepare_grid_inputs_array(micropoint, crows, ccols, reqhgt, vegi, soili, dtmi, lats=crop(lats), lons=crop(lons),
+                                              **pre)
+                a["coarse"] = {"rowpos": api.coarse_positions(rows, crows)[r0:r1], "colpos": api.coarse_positions(cols, ccols)[c0:c1]}
+                if altcorrect:
+                    a["coarse"].update(altcorrect=int(altcorrect), dtmc=dtmc, dtm=cleanvars(vegi, soili, zi)[2])
+            else:
+                a = prepare_grid_inputs(micropoint, reqhgt, vegi, soili, dtmi, **pre)
             a["tfact"] = float(tfact)
             fo = os.path.join(pathout, "microut", f"area_{rw:02d}_{cl:02d}.nc")
             ext = {"xmin": dtm["xmin"] + c0 * res, "xmax": dtm["xmin"] + c1 * res, "ymin": dtm["ymax"] - r1 * res,
                    "ymax": dtm["ymax"] - r0 * res, "res": res, "crs": dtm.get("crs", "")}
-            pipeline.run_to_nc(a, fo, ext, vars=vars, days_per_chunk=days_per_chunk, device=device)
+            pipeline.run_to_nc(a, fo, ext, vars=vars, days_per_chunk=days_per_chunk, device=device, array_forcing=array)
             written.append(fo)
     return written

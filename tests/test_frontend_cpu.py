@@ -121,6 +121,20 @@ def test_subsetpointmodel_picks_whole_days():
     assert not a["complete"] and len(a["dfsel"]["st"]) == 12 and a["dfsel"]["ed"][-1] == 287
 
 
+def test_subsetpointmodela_picks_the_same_days_for_every_cell():
+    """`subsetpointmodela` (R/dataprep.R:114-133): the days come from the canopy temperature averaged over the cells"""
+    weather, vegp, soilc, dtm = load(90 * 24)
+    a = F.runpointmodel(weather, 0.05, dtm, vegp, soilc)
+    t = np.arange(90 * 24)
+    b = F.runpointmodel(dict(weather, temp=weather["temp"] + 6.0 * np.sin(t / 300.0)), 0.05, dtm, vegp, soilc)
+    got = F.subsetpointmodela([a, None, b], what="tmax")
+    assert got[1] is None and np.array_equal(got[0]["subs"], got[2]["subs"]) and len(got[0]["subs"]) == 72
+    mean_tc = (a["dfo"]["Tc"] + b["dfo"]["Tc"]) / 2
+    assert np.array_equal(got[0]["subs"], F.subsetpointmodel(a, what="tmax", Tc=mean_tc)["subs"])
+    by_day = F.subsetpointmodela([a, b], days=[2, 40])
+    assert all(list(m["subs"][[0, 24]]) == [25, 937] for m in by_day)
+
+
 def test_tall_vegetation_lifts_the_reference_height():
     """runpointmodel's weather height adjustment (R/Cppwrappers.R:93-116): vegetation above 2 m moves zref to the canopy top
     and carries temperature, humidity and wind there with weatherhgtCpp"""

@@ -412,3 +412,87 @@ def test_vignette_subset_snow_depth_steps_match_the_published_figure():
     for m, want in enumerate(start):
         assert abs(depth[m * 24] - want) < 0.012, (m + 1, depth[m * 24], want)
     assert abs(depth[3 * 24 - 1] - 0.68) < 0.012 and abs(depth[7 * 24 - 1] - 0.055) < 0.012      # March builds, July melts
+
+
+def test_runmicro_big_with_array_weather_joins_without_a_seam(oracle, tmp_path):
+    """`runmicro_big(micropointa, ..., dtm, dtmc, altcorrect)`: a 2 x 3 climate grid over the bundled site, tiles of 20 cells
+    with 3 cells of overlap; every tile's file equals the whole-raster `runmicro` with array weather on its window (the
+    tile interpolates the coarse arrays at its own place in the climate grid), packed as writetonc packs — wherever the
+    universal terrain makes the two calls the same problem"""
+    from scipy.io import netcdf_file
+    from microclimf_amd import terrain
+    weather, vegp, soilc, dtm = load(3 * 24)
+    dtm = dict(dtm, xmin=float(dtm["extent"][0]), ymax=float(dtm["extent"][3]))
+    cr, cc, T = 2, 3, 72
+    rng = np.random.default_rng(12)
+    climarray = {}
+    for k in F.WEATHER:
+        base = np.broadcast_to(weather[k][None, None, :], (cr, cc, T)).copy()
+        if k == "temp":
+            base += rng.uniform(-2.0, 2.0, (cr, cc, 1))
+        elif k in ("swdown", "difrad", "windspeed"):
+            base *= rng.uniform(0.9, 1.1, (cr, cc, 1))
+        climarray[k] = np.asfortranarray(base)
+    climarray["difrad"] = np.minimum(climarray["difrad"], climarray["swdown"])
+    clat = dtm["lat"] + 1e-4 * np.arange(cr)[:, None] + 0 * np.arange(cc)[None, :]
+    clon = dtm["long"] + 1e-4 * np.arange(cc)[None, :] + 0 * np.arange(cr)[:, None]
+    lats = dtm["lat"] + 9e-6 * np.arange(50)[::-1, None] + 0 * np.arange(50)[None, :]
+    lons = dtm["long"] + 1.4e-5 * np.arange(50)[None, :] + 0 * np.arange(50)[:, None]
+    z = np.asarray(dtm["z"])
+    dtmc = np.array([[np.nanmean(z[:25, :17]), np.nanmean(z[:25, 17:34]), np.nanmean(z[:25, 34:])],
+                     [np.nanmean(z[25:, :17]), np.nanmean(z[25:, 17:34]), np.nanmean(z[25:, 34:])]]) + 25.0
+    mpa = F.runpointmodela(climarray, weather["obstime"], 0.05, dtm, vegp, soilc, lats=clat, lons=clon)
+    kw = dict(crows=cr, ccols=cc, lats=lats, lons=lons, dtmc=dtmc, altcorrect=2)
+    files = F.runmicro_big(mpa, 0.05, str(tmp_path), vegp, soilc, dtm, tilesize=20, toverlap=3, vars=("Tz", "relhum", "windspeed"),
+                           days_per_chunk=2, **kw)
+    assert len(files) == 9
+    with pytest.raises(ValueError, match="crows"):
+        F.runmicro_big(mpa, 0.05, str(tmp_path / "x"), vegp, soilc, dtm, tilesize=20)
+    # the whole raster in one call with the same universal terrain
+    ter = terrain.precompute_terrain(z, dtm["res"], mpa[0]["zref"], what=("slope", "aspect", "hor", "svfa"))
+    slr, apr = ter["slope"].copy(), ter["aspect"].copy()
+    slr[np.isnan(z)] = np.nan
+    apr[np.isnan(z)] = np.nan
+    wsa = terrain.precompute_terrain(z + np.nan_to_num(vegp["hgt"], nan=0.0), dtm["res"], 8.0, what=("wsa",))["wsa"]
+    twi = terrain.topidx(z, dtm["res"])
+    whole = F.runmicro_array(mpa, cr, cc, 0.05, vegp, soilc, dtm, lats=lats, lons=lons, altcorrect=2, dtmc=dtmc, slr=slr, apr=apr,
+                             hor=ter["hor"], twi=twi, wsa=wsa, svf=ter["svfa"])
+    seen = np.zeros((50, 50), dtype=bool)
+    for rw in (1, 2, 3):
+        for cl in (1, 2, 3):
+            r0, r1, c0, c1 = F.tile_window(rw, cl, 50, 50, 20, 3)
+            f = netcdf_file(str(tmp_path / "microut" / f"area_{rw:02d}_{cl:02d}.nc"), "r", mmap=False)
+            for k, sc in (("Tz", 100), ("windspeed", 100)):
+                got = np.transpose(f.variables[k][:], (2, 1, 0)).astype(np.int64)     # [cols, rows, T] -> compare as [rows, cols, T]
+                got = np.transpose(got, (1, 0, 2))
+                with np.errstate(invalid="ignore"):
+                    w = np.rint(whole[k][r0:r1, c0:c1, :] * sc)
+                w = np.where(np.isfinite(w), w, -9999).astype(np.int64)
+                assert got.shape == w.shape
+                # a tile spreads soil moisture around its own mean wetness index (as in the reference), so air temperature may
+                # move by one count of 0.01 K in a few cells; wind speed does not depend on it
+                assert np.abs(got - w).max() <= 1 and (got != w).mean() < (3e-2 if k == "Tz" else 1e-3), (rw, cl, k)
+            f.close()
+            seen[r0:r1, c0:c1] = True
+    assert seen.all()
+    # one tile against the oracle on the same prepared tile call (its own wetness-index mean, its window of the climate grid)
+    from oracle import coarse_oracle as CO
+    from microclimf_amd import api
+    r0, r1, c0, c1 = F.tile_window(3, 3, 50, 50, 20, 3)
+    crop = lambda a: np.asarray(a)[r0:r1, c0:c1]                                   # noqa: E731
+    vegi, soili = {k: crop(v) for k, v in vegp.items()}, {k: crop(v) for k, v in soilc.items()}
+    a = F.prepare_grid_inputs_array(mpa, cr, cc, 0.05, vegi, soili, dict(dtm, z=crop(z)), lats=crop(lats), lons=crop(lons),
+                                    slr=crop(slr), apr=crop(apr), hor=crop(ter["hor"]), twi=crop(twi), wsa=crop(wsa),
+                                    svf=crop(ter["svfa"]))
+    clim, pm = CO.expand(a["climdata"], a["pointm"], api.coarse_positions(50, cr)[r0:r1], api.coarse_positions(50, cc)[c0:c1],
+                         altcorrect=2, dtmc=dtmc, dtm=F.cleanvars(vegi, soili, crop(z))[2])
+    a.update(climdata=clim, pointm=pm, tfact=1.5)
+    want = oracle.run_grid(**a, array_forcing=True)
+    f = netcdf_file(str(tmp_path / "microut" / "area_03_03.nc"), "r", mmap=False)
+    for k, sc in (("Tz", 100), ("relhum", 1), ("windspeed", 100)):
+        got = np.transpose(f.variables[k][:], (2, 1, 0)).astype(np.int64)
+        with np.errstate(invalid="ignore"):
+            w = np.rint(np.transpose(want[k], (1, 0, 2)) * sc)
+        w = np.where(np.isfinite(w), w, -9999).astype(np.int64)
+        assert np.abs(got - w).max() <= 1 and (got != w).mean() < 1e-3, k
+    f.close()
