@@ -54,6 +54,31 @@ for meth in ("slow", "fast"):
     print(f"runsnowmodel(method = \"{meth}\") on the monthly subset (12 days of 24 h returned): {dt:.2f} s; mean depth peaks at "
           f"{np.nanmax(d):.3f} m")
 
+# the array-weather routes on the same site: a 2 x 2 climate grid (the vignette's dummy arrays, Rmd:560-577), cold year
+cr = cc = 2
+arr = {k: np.asfortranarray(np.broadcast_to(wc[k][None, None, :], (cr, cc, len(wc[k]))).copy()) for k in F.WEATHER}
+cl = dtm["lat"] + 1e-4 * np.arange(cr)[:, None] + 0 * np.arange(cc)[None, :]
+co = dtm["long"] + 1e-4 * np.arange(cc)[None, :] + 0 * np.arange(cr)[:, None]
+la = dtm["lat"] + 9e-6 * np.arange(50)[::-1, None] + 0 * np.arange(50)[None, :]
+lo = dtm["long"] + 1.4e-5 * np.arange(50)[None, :] + 0 * np.arange(50)[:, None]
+zz = np.asarray(dtm["z"])
+dc = np.array([[np.nanmean(zz[:25, :25]), np.nanmean(zz[:25, 25:])], [np.nanmean(zz[25:, :25]), np.nanmean(zz[25:, 25:])]])
+t0 = time.perf_counter()
+mpa = F.runpointmodela(arr, wc["obstime"], 0.05, dtm, vegp, soilc, lats=cl, lons=co)
+t1 = time.perf_counter()
+sma = F.runsnowmodela(arr, wc["obstime"], mpa, vegp, soilc, dtm, dtmc=dc, lats_c=cl, lons_c=co, lats=la, lons=lo)
+t2 = time.perf_counter()
+mo = F.runmicro_snow_array(mpa, cr, cc, 0.05, vegp, soilc, dtm, sma, dtmc=dc, lats=la, lons=lo)
+t3 = time.perf_counter()
+mpas = F.subsetpointmodela(mpa)
+t4 = time.perf_counter()
+smf = F.runsnowmodela(arr, wc["obstime"], mpas, vegp, soilc, dtm, dtmc=dc, lats_c=cl, lons_c=co, lats=la, lons=lo, method="fast")
+t5 = time.perf_counter()
+print(f"array weather, 2 x 2 climate cells, 8760 h: runpointmodela {t1 - t0:.2f} s, runsnowmodel (.snowmodel2; resampling on the "
+      f"host, terrain / gridmodelsnow2 / position index on the device) {t2 - t1:.2f} s, runmicro(snow = TRUE) (.runmicrosnow2) "
+      f"{t3 - t2:.2f} s, Tz mean {np.nanmean(mo['Tz']):.2f} degC; on the monthly subset runsnowmodel(method = \"fast\") "
+      f"(.snowmodelq2) {t5 - t4:.2f} s")
+
 # the reference's runmicro() example (R/Cppwrappers.R:355-362, "takes ~20 seconds" for two calls): the point model subset
 # to the hottest day of each month, then runmicro at 5 cm and at 1 m
 mps = F.subsetpointmodel(F.runpointmodel(weather, 0.05, dtm, vegp, soilc))
