@@ -33,33 +33,53 @@ def test_tpicalc_refuses_what_terra_refuses():
         S.tpicalc(0, np.zeros((5, 5)), 0.01)
 
 
-def test_fast_method_matches_the_oracle_chain(oracle):
-    """50 days of the bundled site made colder, five selected days of which two are consecutive (R's `a:b` then counts
-    down); the product (`runsnowmodel(method = "fast")`) against the oracle's point model, terrain, grid model, position
-    index and day loop"""
+def _crop(vegp, soilc, dtm, r0, r1, c0, c1):
+    cut = lambda a: np.asarray(a)[r0:r1, c0:c1]                        # noqa: E731
+    return {k: cut(v) for k, v in vegp.items()}, {k: cut(v) for k, v in soilc.items()}, dict(dtm, z=cut(dtm["z"]))
+
+
+@pytest.mark.parametrize("case", [
+    dict(days=[4, 11, 12, 30, 47], window=(0, 50, 0, 50)),                                             # two consecutive days
+    dict(days=[3, 20, 44], window=(5, 28, 10, 47), snowenv="Alpine", snowinitd=0.002, snowinita=30.0, stfact=0.03),
+    dict(days=[6, 7, 8, 35], window=(20, 50, 0, 19), snowenv="Tundra", zref=3.0, windhgt=2.0),
+    dict(days=[10, 40], window=(12, 13, 0, 50), snowenv="Prairie", cold=-14.0),                        # a single row of cells
+])
+def test_fast_method_matches_the_oracle_chain(oracle, case):
+    """50 days of the bundled site made colder, a few selected days (consecutive ones too: R's `a:b` then counts down),
+    windows of the raster down to one row, snow environments, initial pack, other reference heights; the product
+    (`runsnowmodel(method = "fast")`) against the oracle's point model, terrain, grid model, position index and day loop"""
     from oracle import replay_reference_tests as RT
     from oracle import snowfast_oracle as SF
     weather, vegp, soilc, dtm = load(50 * 24)
-    weather = dict(weather, temp=weather["temp"] - 9.0)
-    mp = F.subsetpointmodel(F.runpointmodel(weather, 0.05, dtm, vegp, soilc), days=[4, 11, 12, 30, 47])
-    got = F.runsnowmodel(weather, mp, vegp, soilc, dtm)                  # the reference's default: method = "fast"
-    assert list(got) == ["Tc", "Tg", "groundsnowdepth", "totalSWE", "snowden", "umu"] and got["Tc"].shape == (50, 50, 120)
+    vegp, soilc, dtm = _crop(vegp, soilc, dtm, *case["window"])
+    weather = dict(weather, temp=weather["temp"] + case.get("cold", -9.0))
+    env, sd0, sa0 = case.get("snowenv", "Taiga"), case.get("snowinitd", 0.0), case.get("snowinita", 0.0)
+    zref, windhgt, stfact = case.get("zref", 2.0), case.get("windhgt", case.get("zref", 2.0)), case.get("stfact", 0.01)
+    mp = F.subsetpointmodel(F.runpointmodel(weather, 0.05, dtm, vegp, soilc), days=case["days"])
+    got = F.runsnowmodel(weather, mp, vegp, soilc, dtm, snowenv=env, snowinitd=sd0, snowinita=sa0, zref=zref, windhgt=windhgt,
+                         stfact=stfact)                                 # the reference's default: method = "fast"
+    z = np.asarray(dtm["z"])
+    n = 24 * len(case["days"])
+    assert list(got) == ["Tc", "Tg", "groundsnowdepth", "totalSWE", "snowden", "umu"] and got["Tc"].shape == z.shape + (n,)
     vg = F.cleanvegp(vegp)
     vp = F.sortvegp_point(vg)
-    z = np.asarray(dtm["z"])
     obst = {k: np.asarray(v) for k, v in weather["obstime"].items()}
-    w = {k: np.asarray(weather[k], dtype=np.float64) for k in F.WEATHER}
-    pm = RT.pointmodelsnow(obst, w, np.array([vp[1], vp[0], vp[5], vp[3]]), np.array([0, 0, mp["lat"], mp["long"], 2.0, 0, 0]),
-                           "Taiga", maxiter=20)
-    n = len(w["temp"])
+    w = {k: np.array(weather[k], dtype=np.float64) for k in F.WEATHER}
+    if zref != windhgt:
+        w["windspeed"] = w["windspeed"] * np.log(67.8 * zref - 5.42) / np.log(67.8 * windhgt - 5.42)
+    assert np.nanmax(vg["hgt"]) <= zref                                  # no weather height adjustment in these cases
+    sdep, sage = z * 0 + sd0, z * 0 + sa0
+    pm = RT.pointmodelsnow(obst, w, np.array([vp[1], vp[0], vp[5], vp[3]]),
+                           np.array([0, 0, mp["lat"], mp["long"], zref, np.nanmean(sdep), np.nanmean(sage)]), env, maxiter=20)
+    T = len(w["temp"])
     ai = np.asarray(mp["subs"]) - 1
     pointm = {"Gp": pm["G"], "Tc": pm["Tc"], "RswabsG": pm["RswabsG"], "RlwabsG": pm["RlwabsG"], "umu": pm["umu"], "tr": pm["tr"]}
-    vs = F.sortl(vg, pm["sdepc"][:n])
+    vs = F.sortl(vg, pm["sdepc"][:T])
     vs["leaft"] = np.where(np.isnan(vs["leaft"]), 0.01, vs["leaft"])
-    other = {"zref": 2.0, "lat": mp["lat"], "lon": mp["long"], "isnowdc": z * 0, "isnowac": z * 0, "isnowag": z * 0}
+    other = {"zref": zref, "lat": mp["lat"], "lon": mp["long"], "isnowdc": sd0 * z, "isnowac": sage, "isnowag": sage}
     rows = lambda d: {k: np.asarray(v)[ai] for k, v in d.items()}      # noqa: E731
     want = SF.snowmodelq1_days(rows(obst), rows(w), rows(pointm), pm, w["temp"], np.where(w["temp"] > 2, 0.0, w["precip"]),
-                               mp["subs"], vs, other, "Taiga", z, dtm["res"], 0.01)
+                               mp["subs"], vs, other, env, z, dtm["res"], stfact)
     np.testing.assert_allclose(got["umu"], pm["umu"][ai], rtol=1e-10)
     for k in want:
         g, x = got[k], want[k]
