@@ -496,3 +496,32 @@ def test_runmicro_big_with_array_weather_joins_without_a_seam(oracle, tmp_path):
         w = np.where(np.isfinite(w), w, -9999).astype(np.int64)
         assert np.abs(got - w).max() <= 1 and (got != w).mean() < 1e-3, k
     f.close()
+
+
+def test_vignette_runmicro_with_and_without_snow_matches_the_published_figure():
+    """vignettes/images/image14b.png (running-microclimf.Rmd:707-731): the monthly-minimum subset, `runsnowmodel(method =
+    "slow", snowenv = "Maritime")`, `runmicro` with and without snow; raster means of Tz and soil moisture read off the figure.
+    The text says `climdata$temp - 12`, but the figure is the - 8 K of the package's help-file examples: at - 8 K every
+    plotted month is met, at - 12 K none is (tools/probe_image14b.py, profiles/r01i_probe_image14b.txt)."""
+    weather, vegp, soilc, dtm = load()
+    cold = dict(weather, temp=weather["temp"] - 8.0)
+    mp = F.subsetpointmodel(F.runpointmodel(cold, 0.05, dtm, vegp, soilc), tstep="month", what="tmin")
+    smod = F.runsnowmodel(cold, mp, vegp, soilc, dtm, snowenv="Maritime", method="slow")
+    m1 = F.runmicro_snow(mp, 0.05, vegp, soilc, dtm, smod)
+    m2 = F.runmicro(mp, 0.05, vegp, soilc, dtm)
+    with np.errstate(invalid="ignore"):
+        tz1, tz2 = np.nanmean(m1["Tz"], axis=(0, 1)), np.nanmean(m2["Tz"], axis=(0, 1))
+        s1, s2 = np.nanmean(m1["soilm"], axis=(0, 1)), np.nanmean(m2["soilm"], axis=(0, 1))
+    red_t = {36: -0.5, 85: 11.0, 110: 14.0, 134: 27.5, 182: 22.5, 230: 8.0, 278: 5.5}
+    red_s = {60: 0.41, 85: 0.295, 134: 0.295, 182: 0.24, 205: 0.275, 230: 0.32, 254: 0.37, 278: 0.40}
+    blue_t = {36: -2.5, 85: 4.5, 110: 4.5, 134: 26.0, 182: 22.5, 205: 13.0, 230: 6.5, 254: 0.0, 278: 0.0}
+    blue_s = {60: 0.42, 110: 0.42, 134: 0.30, 182: 0.24, 197: 0.42, 205: 0.30, 220: 0.42, 230: 0.34, 254: 0.42, 278: 0.42}
+    for i, v in red_t.items():
+        assert abs(tz2[i - 1] - v) < 0.7, ("no snow", i, tz2[i - 1], v)
+    for i, v in blue_t.items():
+        assert abs(tz1[i - 1] - v) < 1.1, ("snow", i, tz1[i - 1], v)
+    for i, v in red_s.items():
+        assert abs(s2[i - 1] - v) < 0.012, ("no snow", i, s2[i - 1], v)
+    for i, v in blue_s.items():
+        assert abs(s1[i - 1] - v) < 0.012, ("snow", i, s1[i - 1], v)
+    assert int(np.argmax(tz2)) + 1 == 134 and abs(tz2.min() - -9.5) < 0.6      # the figure's extremes
