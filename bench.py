@@ -1,23 +1,36 @@
 #!/usr/bin/env python3
 """bench.py — cell-steps/s of the grid microclimate solver on MI355X.
 
-One "step" = one pass of the hot path (runmicro1Cpp geometry: vector forcing,
-reqhgt = 0.05 m, all 10 outputs) over the whole workload of a rank:
-BASELINE.json configs[1], a 1024 x 1024 synthetic DTM x 8760 hourly steps.
-Inputs are resident in HBM before the timed region; outputs go to a device ring
-(sink: HBM ring, no D2H) because one year of outputs (735 GB at 1024^2) does not
-fit HBM.  With --gpus N (launched by torch.distributed.run, one rank per GPU)
-the raster is row-tiled: every rank owns a 1024-row block of a (1024*N) x 1024
-raster (weak scaling); the only data-path collective is the all-reduce of the
-(sum, count) of log(twi)/tfact (src/microclimfCpp.cpp:993-1004) over RCCL.
+One "step" = one pass of the hot path (runmicro1Cpp geometry: vector forcing, reqhgt = 0.05 m, all 10
+outputs) over the whole workload of a rank: a simulated year (8760 hourly steps) of its raster block.
+Inputs are resident in HBM before the timed region; outputs go to a device ring ("HBM ring, no D2H")
+because a year of outputs (11.8 TB at 4096^2) fits nowhere.
 
-Prints ONE JSON line on rank 0.
+  --config 2 (default)  BASELINE.json configs[2]: 4096 x 4096 synthetic DTM per GPU, terrain inputs (slope, aspect,
+                        24 horizons, sky view, 8 wind-shelter maps) pre-computed ON THE DEVICE from the DTM
+  --config 1            configs[1]: 1024 x 1024, SURVEY 8d's random terrain inputs
+  --config 3            configs[3]: 8192 x 8192 dealt to 8 ranks in row blocks (strong scaling), device terrain with
+                        the +-128-row halo exchanged over RCCL; with fewer than 8 GPUs every rank runs its block of
+                        the 8-block partition (one rank's share), halo rows generated instead of exchanged
+  --config 4            configs[4]: 4096 x 4096 + the snow branch (see run_snow_config)
+
+With --gpus N > 1 and no WORLD_SIZE in the environment this process only LAUNCHES: it starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child before torch / HIP are imported and relays
+rank 0's JSON line (never re-executes a process that has touched the GPU).  Under an external torch.distributed.run
+(the driver's way) it is one rank.  The only data-path collective of the solver is the all-reduce of the (sum, count)
+of log(twi)/tfact (src/microclimfCpp.cpp:993-1004); the terrain pre-compute exchanges halo rows point-to-point.
+
+After the timed region (outside it) a sample of cells of the LAST ring slot is fetched (mcf_plan_fetch_cells) and
+compared with the CPU oracle run on exactly those cells: `verified`.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -27,40 +40,100 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+CONFIGS = {
+    1: dict(rows=1024, cols=1024, terrain="random", scaling="weak", share=0),
+    2: dict(rows=4096, cols=4096, terrain="device", scaling="weak", share=0),
+    3: dict(rows=8192, cols=8192, terrain="device", scaling="strong", share=8),
+    4: dict(rows=4096, cols=4096, terrain="device", scaling="strong", share=8),
+}
+KERNEL_SOURCES = ("microclimf_amd/csrc/mcf_kernels.hip", "microclimf_amd/csrc/mcf_device.hpp",
+                  "microclimf_amd/csrc/mcf_kernels.h", "microclimf_amd/csrc/Makefile")
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--rows", type=int, default=1024, help="rows per GPU")
-    ap.add_argument("--cols", type=int, default=1024)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
+                    help="BASELINE.json configs[N]; sets --rows/--cols/--terrain/--scaling unless given")
+    ap.add_argument("--rows", type=int, default=None, help="rows per GPU (weak) / of the whole raster (strong)")
+    ap.add_argument("--cols", type=int, default=None)
     ap.add_argument("--tsteps", type=int, default=8760)
     ap.add_argument("--reqhgt", type=float, default=0.05)
     ap.add_argument("--ring-days", type=int, default=10)
     ap.add_argument("--ring-slots", type=int, default=2)
     ap.add_argument("--cells-per-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (configs[1], array forcing, "
+                                                                 "coarse array forcing)")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--verify-cells", type=int, default=256)
     ap.add_argument("--cpu-sample", type=str, default="144x144x720")
-    ap.add_argument("--terrain", choices=["random", "device"], default="random",
-                    help="'device': slope/aspect/hor/svfa/wsa come from mcf_precompute_terrain run on the "
-                         "synthetic DTM (BASELINE.json configs[2]); 'random': SURVEY 8d's random terrain inputs")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="'weak' (default): --rows rows PER GPU; 'strong': --rows is the whole raster, dealt to the ranks "
-                         "in row blocks (e.g. --rows 8192 --cols 8192 --scaling strong --gpus 8 = BASELINE.json configs[3])")
+    ap.add_argument("--terrain", choices=["random", "device"], default=None,
+                    help="'device': slope/aspect/hor/svfa/wsa come from mcf_precompute_terrain run on the synthetic DTM; "
+                         "'random': SURVEY 8d's random terrain inputs")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="'weak': --rows rows PER GPU; 'strong': --rows is the whole raster, dealt to the ranks in row blocks")
+    ap.add_argument("--share", type=int, default=None,
+                    help="strong scaling only: partition the raster into this many row blocks even when fewer ranks run "
+                         "(rank r solves block r) — one rank's share of an 8-GPU job on a 1-GPU box")
     ap.add_argument("--coarse", type=str, default="",
-                    help="secondary measurement: CRxCC, e.g. 8x8 — `.runmodel2Cpp` geometry with the coarse climate / point-model "
-                         "arrays interpolated inside the solver (mcf.h array_forcing == 2): the whole year is resident")
+                    help="primary measurement in the `.runmodel2Cpp` geometry instead: CRxCC coarse climate grid interpolated "
+                         "inside the solver (mcf.h array_forcing == 2)")
     ap.add_argument("--array-forcing", action="store_true",
-                    help="secondary measurement: runmicro2Cpp geometry; ring_slots x ring_days days of forcing are "
-                         "resident in HBM and solved repeatedly (a year of array forcing, 1.1 TB at 1024^2, "
-                         "cannot be resident)")
-    return ap.parse_args()
+                    help="primary measurement in the runmicro2Cpp geometry instead; ring_slots x ring_days days of forcing "
+                         "are resident in HBM and solved repeatedly")
+    ap.add_argument("--stub", action="store_true",
+                    help="TEST ONLY (tests/test_bench_launcher_cpu.py): gloo backend, no GPU, a stand-in for the solver — "
+                         "exercises the rank fan-out, partition and collectives; the line carries \"stub\": true")
+    a = ap.parse_args(argv)
+    preset = CONFIGS[a.config]
+    for k, v in preset.items():
+        if getattr(a, k) is None:
+            setattr(a, k, v)
+    return a
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# N > 1 without an external launcher: fan out BEFORE anything touches the GPU
+# ----------------------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """Parent side of `bench.py --gpus N`: one child process group, one rank per GPU, rank 0's JSON line relayed."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(Path(__file__).resolve())] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        s = ln.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+        elif s:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    if p.returncode != 0 or line is None:
+        print(f"bench.py: the {args.gpus}-rank child exited with {p.returncode}" + ("" if line else " and printed no result"),
+              file=sys.stderr)
+        return p.returncode or 1
+    return 0
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baseline legs (the oracle as the thing timed: allowed for this leg only)
+# ----------------------------------------------------------------------------------------------------------------
 def cpu_baseline(args):
-    """The oracle (a scalar C restatement of the reference loop, kind 'port') timed on one
-    host core over a bounded sample of the same synthetic workload."""
+    """The oracle (a scalar C restatement of the reference loop, kind 'port') timed on one host core over a bounded
+    sample of the same synthetic workload."""
     from microclimf_amd import synthetic
     from oracle import oracle as O
     r, c, t = (int(v) for v in args.cpu_sample.split("x"))
@@ -105,10 +178,362 @@ def cpu_baseline_all_cores(args):
                       f"worker {busy:.1f} s, wall {wall:.1f} s incl. input generation"}
 
 
-def main():
-    args = parse()
+# ----------------------------------------------------------------------------------------------------------------
+# helpers
+# ----------------------------------------------------------------------------------------------------------------
+def kernel_hash() -> str:
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        h.update((ROOT / rel).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def committed_counters(rows, cols, ring_days):
+    """HBM traffic and VALU counters of k_solve from profiles/traffic.json — measured by rocprofv3 --pmc in separate
+    passes (tools/profile_round.sh), stamped with the hash of the kernel sources they were taken from.  A stamp that
+    does not match the sources being run means the counters are STALE: they are withheld and the line says so."""
+    tf = ROOT / "profiles" / "traffic.json"
+    if not tf.exists():
+        return None, None, "no profiles/traffic.json"
+    try:
+        tj = json.loads(tf.read_text())
+    except Exception as e:
+        return None, None, f"unreadable profiles/traffic.json: {e}"
+    entries = tj.get("entries", [tj])
+    for e in entries:
+        if e.get("rows") == rows and e.get("cols") == cols and e.get("ring_days") == ring_days:
+            if e.get("kernel_hash") != kernel_hash():
+                return None, None, (f"stale: counters of {e.get('tag')} were taken from kernel sources "
+                                    f"{e.get('kernel_hash')}, this run is {kernel_hash()}")
+            pf = ROOT / "profiles" / f"{e.get('tag')}_pmc_summary.json"
+            pj = json.loads(pf.read_text()) if pf.exists() else None
+            return e, pj, None
+    return None, None, f"no counters for {rows}x{cols} with {ring_days}-day launches"
+
+
+def fit_ring(args, cells, af):
+    """The output ring (and, with array forcing, the forcing slabs) must fit the GPU: shrink until
+    slots x days x 24 h x cells x 8 B x (10 outputs [+ 15 forcing arrays]) stays under 160 GB.  Longer launches first:
+    at 4096^2 one 4-day slot runs 11 % faster than two 2-day slots (the cell tables are re-read once per launch)."""
+    per_day = cells * 24 * 8 * (10 + (15 if af else 0))
+    slots, days = args.ring_slots, args.ring_days
+    while slots * days * per_day > 160e9 and (slots > 1 or days > 1):
+        if slots > 1 and not af:
+            slots -= 1
+        elif days > 1:
+            days -= 1
+        else:
+            break
+    return slots, days
+
+
+class Clock:
+    """Barrier + device synchronisation on both sides of the timed region, MAX over ranks."""
+
+    def __init__(self, use_dist, dist, torch):
+        self.use_dist, self.dist, self.torch = use_dist, dist, torch
+
+    def fence(self, plan=None):
+        if plan is not None:
+            plan.sync()
+        if self.torch is not None and self.torch.cuda.is_available():
+            self.torch.cuda.synchronize()
+        if self.use_dist:
+            self.dist.barrier()
+        if self.torch is not None and self.torch.cuda.is_available():
+            self.torch.cuda.synchronize()
+
+
+def timed_year(plan, ndays, ring_days, ring_slots, steps, warmup, clock):
+    """`warmup` untimed and `steps` timed passes over the series in launches of `ring_days` days into the ring.
+    Returns (seconds, kernel ms, launches, resident) — resident[(slot, day offset in slot)] = absolute day."""
+    resident = {}
+
+    def one_step():
+        slot = 0
+        for d0 in range(0, ndays, ring_days):
+            nd = min(ring_days, ndays - d0)
+            plan.run_days(d0, nd, slot)
+            for k in range(nd):
+                resident[(slot, k)] = d0 + k
+            slot = (slot + 1) % ring_slots
+
+    for _ in range(warmup):
+        one_step()
+    clock.fence(plan)
+    plan.kernel_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_step()
+    clock.fence(plan)
+    dt = time.perf_counter() - t0
+    kms, klaunches = plan.kernel_stats()
+    plan.kernel_timing(False)
+    return dt, kms, klaunches, resident
+
+
+def verify_sample(plan, a, resident, twi_mean, ncells, seed=7):
+    """Outside the timed region: fetches `ncells` cells x every day still resident in the ring (what the LAST timed pass
+    left there) and compares all ten outputs with the CPU oracle run on exactly those cells (same forcing, the raster's
+    twi mean installed).  The oracle is the checker here, never the thing timed."""
+    import ctypes as C
+    from oracle import oracle as O
+    hgt = a["vegp"]["hgt"]
+    rows, cols = hgt.shape
+    N = rows * cols
+    rng = np.random.default_rng(seed)
+    flat_h = hgt.reshape(-1, order="F")
+    pick = set(int(v) for v in rng.choice(N, size=min(ncells, N), replace=False))
+    # make sure the three cell classes are in the sample: NA cells, bare ground, vegetated
+    for mask in (np.isnan(flat_h), flat_h == 0.0):
+        idx = np.flatnonzero(mask)
+        for v in idx[:4]:
+            pick.add(int(v))
+    cells = np.array(sorted(pick), dtype=np.int64)
+    n = cells.size
+
+    def take(m):
+        m = np.asarray(m)
+        if m.ndim == 2:
+            return np.asfortranarray(m.reshape(-1, order="F")[cells].reshape(n, 1))
+        d = m.shape[2]
+        return np.asfortranarray(m.reshape(N, d, order="F")[cells].reshape(n, 1, d))
+
+    sub = dict(a)
+    sub["vegp"] = {k: take(v) for k, v in a["vegp"].items()}
+    sub["soilc"] = {k: take(v) for k, v in a["soilc"].items()}
+    lib = O.load()
+    lib.orc_set_twi_mean_override.argtypes = [C.c_double, C.c_int]
+    lib.orc_set_twi_mean_override(float(twi_mean), 1)
+    t0 = time.perf_counter()
+    try:
+        want = O.run_grid(**sub)
+    finally:
+        lib.orc_set_twi_mean_override(0.0, 0)
+    t_or = time.perf_counter() - t0
+    worst, nan_ok, nvals, worst_var = 0.0, True, 0, None
+    days = sorted(set(resident.values()))
+    for (slot, off), day in sorted(resident.items()):
+        for var, w in want.items():
+            got = plan.fetch_cells(slot, var, off * 24, 24, cells)
+            ref = w[:, 0, day * 24:(day + 1) * 24]
+            if not np.array_equal(np.isnan(got), np.isnan(ref)):
+                nan_ok = False
+            fin = np.isfinite(ref) & np.isfinite(got)
+            if fin.any():
+                e = float((np.abs(got[fin] - ref[fin]) / (1.0 + np.abs(ref[fin]))).max())
+                if e > worst:
+                    worst, worst_var = e, var
+            nvals += int(ref.size)
+    tol = 1e-6
+    return {"cells": int(n), "steps": 24 * len(resident), "days": [int(days[0]), int(days[-1])], "values": nvals,
+            "max_scaled_err": worst, "worst_var": worst_var, "na_pattern_equal": bool(nan_ok), "tolerance": tol,
+            "ok": bool(nan_ok and worst <= tol),
+            "how": "mcf_plan_fetch_cells on the ring as the last timed pass left it vs oracle/mcf_oracle.c on the same "
+                   f"cells over the whole series ({t_or:.1f} s), |HIP - oracle| / (1 + |oracle|)"}
+
+
+def roofline_block(valid, T, steps_per_launch, avg_ms, klaunches, af, rows, cols, ring_days, rate_per_gpu, coarse):
+    """Roofline of the dominant kernel (k_solve).  ALGORITHMIC bytes per launch = valid cells x steps per launch x
+    (8 B x n_out written + 440 B / T read); array forcing reads 15 arrays per cell-step (+8 B for the mxtc pre-pass):
+    208 B [SURVEY 8d].  The HBM fraction is what BASELINE.json's metric asks for; the roof that BINDS is fp64 VALU
+    issue (software exp / log / divide), reported next to it from the committed PMC counters of the same sources."""
+    n_out = 10
+    bpl = valid * steps_per_launch * ((8.0 * n_out + 128.0) if af else (8.0 * n_out + 440.0 / T))
+    achieved = bpl / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic, valu, note = None, None, None
+    if not af and not coarse:
+        e, pj, note = committed_counters(rows, cols, ring_days)
+        if e is not None:
+            traffic = e.get("hbm_bytes_per_launch")
+            if pj is not None and "SQ_INSTS_VALU" in pj.get("per_launch_mean", {}):
+                per_cs = pj["per_launch_mean"]["SQ_INSTS_VALU"] * 64.0 / pj["cell_steps_per_launch"]
+                clock = float(pj.get("clock_ghz") or 2.4)
+                valu = {"insts_per_cell_step": per_cs,
+                        # one wave-instruction per 4 cycles per SIMD, 1024 SIMDs, at the clock MEASURED under this load
+                        "frac_of_issue_peak": per_cs * rate_per_gpu / 64.0 / (1024 * clock * 1e9 / 4),
+                        "clock_ghz_measured": clock, "busy_fraction_measured": pj.get("valu_busy_fraction"),
+                        "source": f"profiles/{e.get('tag')}_pmc_summary.json", "kernel_hash": e.get("kernel_hash")}
+    rb = {"bound": "fp64_valu", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+          "frac_is": "achieved algorithmic HBM bytes / 8 TB/s (the metric BASELINE.json names); the binding roof is "
+                     "fp64 VALU issue, see `valu`",
+          "traffic": traffic, "kernel": "k_solve", "avg_launch_ms": avg_ms, "launches": int(klaunches),
+          "algorithmic_bytes_per_launch": bpl, "valu": valu}
+    if note:
+        rb["counters"] = note
+    return rb
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def stub_main(args, world, rank):
+    """TEST ONLY: the rank fan-out, partition and collectives with a stand-in solver over gloo (no GPU, no HIP)."""
+    import torch.distributed as dist
+    from microclimf_amd import synthetic
+    from microclimf_amd.distributed import allreduce_max, allreduce_sum, allreduce_twi_mean, row_block
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows, cols = args.rows, args.cols
+    row0, rows_total = rank * rows, rows * world
+    if args.scaling == "strong":
+        rows_total = args.rows
+        row0, rows = row_block(rank, max(world, args.share or 0), rows_total)
+    vegp, soilc, _ = synthetic.rasters(rows, cols, row0, rows_total, reqhgt=args.reqhgt)
+    twi = soilc["twi"]
+    s, n = float(np.sum(np.log(twi) / 1.5)), float(twi.size)
+    mean = allreduce_twi_mean(s, n)
+    valid = float((~np.isnan(vegp["hgt"])).sum())
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01)
+    if world > 1:
+        dist.barrier()
+    dt = allreduce_max(time.perf_counter() - t0)
+    valid_all = allreduce_sum(valid)
+    if rank == 0:
+        ndays = args.tsteps // 24
+        print(json.dumps({"metric": "cell-steps/s", "value": valid_all * ndays * 24 * args.steps / dt, "unit": "cell-steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
+                          "data": "synthetic", "stub": True,
+                          "config": {"workload": "STUB (no solver ran): launcher / partition / collectives only",
+                                     "rows_per_gpu": rows, "cols": cols, "valid_cells": int(valid_all), "twi_mean": mean}}),
+              flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def build_workload(args, synthetic, rank, world, local_rank, rows, cols, row0, rows_total, T, af, coarse, exchange_ok):
+    """Inputs of one rank's block (+ the device terrain pre-compute when asked for).  Returns (args dict, coarse
+    positions or None, terrain seconds or None)."""
+    cpos = None
+    if coarse:
+        a, rp, cp = synthetic.coarse_workload(rows, cols, T, coarse[0], coarse[1], reqhgt=args.reqhgt, row0=row0,
+                                              rows_total=rows_total)
+        cpos = {"rowpos": rp, "colpos": cp}
+    else:
+        a = synthetic.workload(rows, cols, T, reqhgt=args.reqhgt, row0=row0, rows_total=rows_total,
+                               array_forcing=af, start_doy=152 if af else 1)
+    terrain_s = None
+    if args.terrain == "device":
+        from microclimf_amd.terrain import HALO, precompute_terrain, precompute_terrain_tiled
+        if exchange_ok:
+            _, _, dtm = synthetic.rasters(rows, cols, row0, rows_total, reqhgt=args.reqhgt)
+            tt0 = time.perf_counter()
+            ter = precompute_terrain_tiled(dtm, 1.0, a["zref"], rank, world, row0, rows_total, device=local_rank)
+        else:
+            # one rank's share of a larger partition without its neighbours: the halo rows are generated, not exchanged
+            hn = min(HALO, row0)
+            hs = min(HALO, rows_total - (row0 + rows))
+            _, _, ext = synthetic.rasters(rows + hn + hs, cols, row0 - hn, rows_total, reqhgt=args.reqhgt)
+            tt0 = time.perf_counter()
+            ter = precompute_terrain(ext, 1.0, a["zref"], halo_north=hn, halo_south=hs, row0=row0, rows_total=rows_total,
+                                     device=local_rank)
+        terrain_s = time.perf_counter() - tt0
+        a["soilc"].update(ter)
+    return a, cpos, terrain_s
+
+
+def measure(args, torch, dist, use_dist, rank, world, local_rank, *, rows, cols, row0, rows_total, T, af, coarse, steps, warmup,
+            ring_slots, ring_days, exchange_ok, verify):
+    """One measurement: build inputs, plan, twi all-reduce, timed passes, optional verification."""
+    from microclimf_amd import synthetic
+    from microclimf_amd.api import Plan
+    from microclimf_amd.distributed import allreduce_max, allreduce_sum, allreduce_twi_mean
+    ndays = T // 24
+    if af:
+        T = min(T, ring_days * ring_slots * 24)
+        ndays = T // 24
+    tg0 = time.perf_counter()
+    a, cpos, terrain_s = build_workload(args, synthetic, rank, world, local_rank, rows, cols, row0, rows_total, T, af, coarse,
+                                        exchange_ok)
+    setup_s = time.perf_counter() - tg0
+    plan = Plan(**a, ring_days=ring_days, ring_slots=ring_slots, device=local_rank,
+                cells_per_block=args.cells_per_block, array_forcing=af, coarse=cpos)
+    try:
+        if af:
+            for sl, d0 in enumerate(range(0, ndays, ring_days)):
+                plan.upload_forcing_days(d0, min(ring_days, ndays - d0), sl)
+        # the solver's one global reduction: mean of log(twi)/tfact over the WHOLE raster
+        s, n = plan.twi_partial()
+        twi_mean = allreduce_twi_mean(s, float(n))      # one 2-double all-reduce (RCCL over xGMI)
+        plan.set_twi_mean(twi_mean)
+        valid = plan.valid_cells
+        clock = Clock(use_dist, dist, torch)
+        dt, kms, klaunches, resident = timed_year(plan, ndays, ring_days, ring_slots, steps, warmup, clock)
+        dt = allreduce_max(dt)                   # slowest rank
+        valid_all = allreduce_sum(float(valid))  # whole-job units
+        res = {"dt": dt, "kms": kms, "klaunches": klaunches, "valid": valid, "valid_all": valid_all, "ndays": ndays, "T": T,
+               "terrain_s": terrain_s, "setup_s": setup_s, "value": valid_all * ndays * 24 * steps / dt, "verified": None,
+               "plan_bytes": plan.device_bytes}
+        if verify and rank == 0 and not af and not coarse:
+            res["verified"] = verify_sample(plan, a, resident, twi_mean, args.verify_cells)
+    finally:
+        plan.close()
+    return res
+
+
+def secondary_block(args, torch, dist, local_rank):
+    """Short measurements of the other geometries on this GPU (single rank): configs[1], array forcing, coarse array
+    forcing.  Same kernels, same accounting; each entry names its workload."""
+    out = {}
+    sub = argparse.Namespace(**vars(args))
+    sub.terrain = "random"
+    jobs = [("configs[1]", dict(rows=1024, cols=1024, af=False, coarse=None, steps=3, ring=(2, 10))),
+            ("array_forcing", dict(rows=1024, cols=1024, af=True, coarse=None, steps=5, ring=(2, 5))),
+            ("coarse_forcing_8x8", dict(rows=1024, cols=1024, af=False, coarse=(8, 8), steps=3, ring=(2, 5)))]
+    for name, j in jobs:
+        if name == "configs[1]" and args.config == 1 and (args.rows, args.cols) == (1024, 1024):
+            continue      # that is the primary line
+        try:
+            slots, days = j["ring"]
+            r = measure(sub, torch, dist, False, 0, 1, local_rank, rows=j["rows"], cols=j["cols"], row0=0, rows_total=j["rows"],
+                        T=8760, af=j["af"], coarse=j["coarse"], steps=j["steps"], warmup=1, ring_slots=slots, ring_days=days,
+                        exchange_ok=True, verify=(name == "configs[1]" and not args.no_verify))
+            steps_per_launch = (r["ndays"] * 24 * j["steps"]) / max(r["klaunches"], 1)
+            avg_ms = r["kms"] / max(r["klaunches"], 1)
+            rb = roofline_block(r["valid"], r["T"], steps_per_launch, avg_ms, r["klaunches"], j["af"], j["rows"], j["cols"], days,
+                                r["value"], j["coarse"])
+            what = ("vector forcing (runmicro1Cpp geometry), random terrain inputs [BASELINE.json configs[1]]" if name == "configs[1]"
+                    else f"array forcing (runmicro2Cpp geometry), {r['T']} steps of forcing resident in HBM" if j["af"]
+                    else "coarse array forcing (8x8 climate grid interpolated in the solver, `.runmodel2Cpp` geometry), whole year")
+            out[name] = {"workload": f"{j['rows']}x{j['cols']} cells x {r['T']} hourly steps, {what}", "value": r["value"],
+                         "unit": "cell-steps/s", "steps": j["steps"], "ms_per_step": r["dt"] / j["steps"] * 1e3,
+                         "hbm_frac": rb["frac"], "achieved_GBps": rb["achieved"], "avg_launch_ms": avg_ms,
+                         "bytes_per_cell_step": 208.0 if j["af"] else 80.0 + 440.0 / r["T"]}
+            if rb.get("valu"):
+                out[name]["valu"] = rb["valu"]
+            if r["verified"]:
+                out[name]["verified"] = r["verified"]
+        except Exception as e:    # a secondary figure never takes the primary line down
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.stub:
+        return stub_main(args, world, rank)
+    if args.config == 4:
+        try:
+            from tools.bench_snow import run_snow_config      # kept out of the default path
+        except ImportError:
+            raise SystemExit("bench.py --config 4 (solver + snow branch) has no bench mode yet: tools/snow_rate.py measures "
+                             "the snow kernels on one GPU")
+        return run_snow_config(args, world, rank, local_rank)
     cpu_first = None
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline:
         # both CPU legs run before torch / HIP are touched: the all-cores leg forks worker processes
         sys.stdout.flush()
         _saved = os.dup(1)
@@ -121,9 +546,6 @@ def main():
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -134,173 +556,83 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as ge
     if rank == 0:
         ge.build_library()
     if use_dist:
         dist.barrier()
-    from microclimf_amd import synthetic
-    from microclimf_amd.api import Plan
-    from microclimf_amd.distributed import allreduce_max, allreduce_sum, allreduce_twi_mean
+    from microclimf_amd.distributed import row_block
 
     rows, cols, T = args.rows, args.cols, args.tsteps
     row0, rows_total = rank * rows, rows * world
+    nblocks = world
     if args.scaling == "strong":
-        from microclimf_amd.distributed import row_block
         rows_total = args.rows
-        row0, rows = row_block(rank, world, rows_total)
-    ndays = T // 24
+        nblocks = max(world, args.share or 0)
+        row0, rows = row_block(rank, nblocks, rows_total)
     af = args.array_forcing
     coarse = tuple(int(v) for v in args.coarse.split("x")) if args.coarse else None
-    # the output ring (and, with array forcing, the forcing slabs) must fit the GPU: shrink the days per slot
-    # until slots x days x 24 h x cells x 8 B x (10 outputs [+ 15 forcing arrays]) stays under 160 GB
-    per_day = rows * cols * 24 * 8 * (10 + (15 if af else 0))
-    # (longer launches first: at 4096^2 one 4-day slot runs 11 % faster than two 2-day slots — the cell tables are
-    # re-read once per launch)
-    while args.ring_slots * args.ring_days * per_day > 160e9 and (args.ring_slots > 1 or args.ring_days > 1):
-        if args.ring_slots > 1 and not af:
-            args.ring_slots -= 1
-        elif args.ring_days > 1:
-            args.ring_days -= 1
-        else:
-            break
-    if af:
-        T = min(T, args.ring_days * args.ring_slots * 24)
-        ndays = T // 24
-    cpos = None
-    if coarse:
-        a, rp, cp = synthetic.coarse_workload(rows, cols, T, coarse[0], coarse[1], reqhgt=args.reqhgt, row0=row0,
-                                              rows_total=rows_total)
-        cpos = {"rowpos": rp, "colpos": cp}
-    else:
-        a = synthetic.workload(rows, cols, T, reqhgt=args.reqhgt, row0=row0, rows_total=rows_total,
-                               array_forcing=af, start_doy=152 if af else 1)
-    terrain_s = None
-    if args.terrain == "device":
-        from microclimf_amd.terrain import precompute_terrain_tiled
-        _, _, dtm = synthetic.rasters(rows, cols, row0, rows_total, reqhgt=args.reqhgt)
-        tt0 = time.perf_counter()
-        ter = precompute_terrain_tiled(dtm, 1.0, a["zref"], rank, world, row0, rows_total,
-                                       device=local_rank)
-        terrain_s = time.perf_counter() - tt0
-        a["soilc"].update(ter)
-    n_out = 10
-    plan = Plan(**a, ring_days=args.ring_days, ring_slots=args.ring_slots, device=local_rank,
-                cells_per_block=args.cells_per_block, array_forcing=af, coarse=cpos)
-    if af:
-        for sl, d0 in enumerate(range(0, ndays, args.ring_days)):
-            plan.upload_forcing_days(d0, min(args.ring_days, ndays - d0), sl)
-    # the solver's one global reduction: mean of log(twi)/tfact over the WHOLE raster
-    s, n = plan.twi_partial()
-    plan.set_twi_mean(allreduce_twi_mean(s, float(n)))      # one 2-double all-reduce (RCCL over xGMI)
-    valid = plan.valid_cells
-
-    def one_step():
-        slot = 0
-        for d0 in range(0, ndays, args.ring_days):
-            plan.run_days(d0, min(args.ring_days, ndays - d0), slot)
-            slot = (slot + 1) % args.ring_slots
-
-    def fence():
-        plan.sync()
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        one_step()
-    fence()
-    plan.kernel_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    fence()
-    dt = time.perf_counter() - t0
-    kms, klaunches = plan.kernel_stats()
-    dt = allreduce_max(dt)                   # slowest rank
-    valid_all = allreduce_sum(float(valid))  # whole-job units
-    cellsteps_per_step = valid_all * ndays * 24
-    value = cellsteps_per_step * args.steps / dt
-
+    ring_slots, ring_days = fit_ring(args, rows * cols, af)
+    r = measure(args, torch, dist, use_dist, rank, world, local_rank, rows=rows, cols=cols, row0=row0, rows_total=rows_total, T=T,
+                af=af, coarse=coarse, steps=args.steps, warmup=args.warmup, ring_slots=ring_slots, ring_days=ring_days,
+                exchange_ok=(nblocks == world), verify=not args.no_verify)
+    rc = 0
     if rank == 0:
-        # roofline of the dominant kernel (k_solve): ALGORITHMIC bytes per launch =
-        # valid cells x steps per launch x (8 B x n_out written + 440 B / T read)   [SURVEY §8d]
-        steps_per_launch = (ndays * 24 * args.steps) / max(klaunches, 1)
-        # array forcing reads 15 arrays per cell-step (+8 B for the mxtc pre-pass): 208 B   [SURVEY §8d]
-        bytes_per_launch = valid * steps_per_launch * ((8.0 * n_out + 128.0) if af else (8.0 * n_out + 440.0 / T))
-        avg_ms = kms / max(klaunches, 1)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tf = ROOT / "profiles" / "traffic.json"
-        if tf.exists() and not coarse and not af:
-            try:
-                tj = json.loads(tf.read_text())
-                if tj.get("rows") == rows and tj.get("cols") == cols and tj.get("ring_days") == args.ring_days:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # second roof ("both fractions must be reported"): fp64 VALU issue slots.  Instructions per cell-step
-        # come from the committed PMC summary of this kernel (SQ_INSTS_VALU); the peak is one wave-instruction per
-        # 4 cycles per SIMD at the 2.4 GHz nominal clock (256 CUs x 4 SIMDs)
-        valu = None
-        try:
-            ptag = json.loads(tf.read_text()).get("tag") if tf.exists() else None
-        except Exception:
-            ptag = None
-        pf = ROOT / "profiles" / f"{ptag}_pmc_summary.json"
-        if ptag and pf.exists() and not coarse and not af:
-            try:
-                pj = json.loads(pf.read_text())
-                per_cs = pj["per_launch_mean"]["SQ_INSTS_VALU"] * 64.0 / pj.get("cell_steps_per_launch", 1038103 * 120)
-                valu = {"insts_per_cell_step": per_cs, "frac_of_issue_peak": per_cs * (value / world) / 64.0 / (1024 * 2.4e9 / 4),
-                        "busy_fraction_measured": pj.get("valu_busy_fraction"), "source": f"profiles/{ptag}_pmc_summary.json"}
-            except Exception:
-                valu = None
+        T = r["T"]
+        steps_per_launch = (r["ndays"] * 24 * args.steps) / max(r["klaunches"], 1)
+        avg_ms = r["kms"] / max(r["klaunches"], 1)
+        geometry = (f"coarse array forcing ({coarse[0]}x{coarse[1]} climate grid interpolated in the solver, `.runmodel2Cpp` "
+                    "geometry), whole series resident, " if coarse else
+                    "array forcing (runmicro2Cpp geometry), forcing resident in HBM, " if af else
+                    "vector forcing (runmicro1Cpp geometry), ")
+        raster = (f"{rows}x{cols} synthetic DTM per GPU" if args.scaling == "weak" else
+                  f"{rows_total}x{cols} synthetic DTM in {nblocks} row blocks, {world} of them solved by {world} GPU(s)"
+                  if nblocks != world else f"{rows_total}x{cols} synthetic DTM over {world} GPU(s)")
+        tag = "" if (af or coarse or T != 8760) else f" [BASELINE.json configs[{args.config}]]"
         line = {
-            "metric": "cell-steps/s", "value": value, "unit": "cell-steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "metric": "cell-steps/s", "value": r["value"], "unit": "cell-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["dt"] / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": ((f"{rows}x{cols} synthetic DTM per GPU" if args.scaling == "weak" else
-                              f"{rows_total}x{cols} synthetic DTM over {world} GPU(s)") + f", {T} hourly steps, "
-                             + (f"coarse array forcing ({coarse[0]}x{coarse[1]} climate grid interpolated in the solver, "
-                                "`.runmodel2Cpp` geometry), whole series resident, " if coarse else
-                                "array forcing (runmicro2Cpp geometry), forcing resident in HBM, "
-                                if af else "vector forcing (runmicro1Cpp geometry), ")
-                             + f"reqhgt={args.reqhgt}, no snow"
-                             + ("" if (af or coarse) else (" [BASELINE.json configs[1]]" if (rows, cols) == (1024, 1024) else
-                                               " [BASELINE.json configs[2]]" if (rows, cols) == (4096, 4096)
-                                               else ""))),
-                "rows_per_gpu": rows, "cols": cols, "tsteps": T, "outputs": n_out,
-                "valid_cells": int(valid_all),
-                "sink": f"HBM ring ({args.ring_slots} slots x {args.ring_days} days), no D2H",
-                "partition": "row blocks, one per GPU; all-reduce of twi (sum,count) only",
-                "terrain": ("on-device pre-compute from the synthetic DTM, %.2f s incl. H2D/D2H (untimed)" % terrain_s
-                            if terrain_s is not None else "random (SURVEY 8d config 2)"),
+                "workload": f"{raster}, {T} hourly steps, {geometry}reqhgt={args.reqhgt}, no snow, "
+                            + ("terrain inputs pre-computed on the device from the DTM" if args.terrain == "device"
+                               else "random terrain inputs (SURVEY 8d)") + tag,
+                "baseline_config": args.config, "rows_per_gpu": rows, "cols": cols, "tsteps": T, "outputs": 10,
+                "valid_cells": int(r["valid_all"]),
+                "sink": f"HBM ring ({ring_slots} slots x {ring_days} days), no D2H",
+                "partition": "row blocks, one per GPU; all-reduce of twi (sum,count); terrain halo rows point-to-point",
+                "terrain": ("on-device pre-compute from the synthetic DTM (untimed, see terrain_precompute_s)"
+                            if r["terrain_s"] is not None else "random (SURVEY 8d config 2)"),
+                "device_bytes": int(r["plan_bytes"]),
             },
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": "k_solve", "avg_launch_ms": avg_ms, "launches": int(klaunches),
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "valu": valu,
-                         "note": "fp64 VALU (software transcendentals) is the binding roof, see DESIGN.md"},
+            "terrain_precompute_s": r["terrain_s"],
+            "input_setup_s": r["setup_s"],
+            "roofline": roofline_block(r["valid"], T, steps_per_launch, avg_ms, r["klaunches"], af, rows, cols, ring_days,
+                                       r["value"] / world, coarse),
+            "verified": r["verified"],
         }
+        if nblocks != world:
+            line["config"]["share"] = f"block(s) 0..{world - 1} of a {nblocks}-block partition; halo rows generated, not exchanged"
+        if r["verified"] is not None and not r["verified"]["ok"]:
+            rc = 3
         if cpu_first is not None:
             line["cpu_baseline"], line["cpu_baseline_all_cores"] = cpu_first
+        if world == 1 and not args.no_secondary and not af and not coarse:
+            line["secondary"] = secondary_block(args, torch, dist, local_rank)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)
         os.dup2(2, 1)
-    plan.close()
+        if rc:
+            print("bench.py: the timed run's output does NOT match the oracle: " + json.dumps(r["verified"]), file=sys.stderr)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -223,6 +223,12 @@ int mcf_plan_sync(mcf_plan *plan);
  * step `step0` within the slot) to host memory. */
 int mcf_plan_fetch(mcf_plan *plan, int32_t slot, int32_t var, int64_t step0,
                    int64_t nsteps, double *host_dst);
+/* Sparse read-back for verification and point queries: `nsteps` steps of variable `var` for the `ncells`
+ * cells listed in `cells` (0-based column-major cell indices i + rows*j, any order), gathered on the device
+ * and returned as host_dst[ci + ncells*k].  Moves ncells*nsteps values instead of a whole [rows,cols,nsteps]
+ * slab (bench.py checks a sample of the timed run's last ring slot against the oracle with it). */
+int mcf_plan_fetch_cells(mcf_plan *plan, int32_t slot, int32_t var, int64_t step0, int64_t nsteps,
+                         const int64_t *cells, int64_t ncells, double *host_dst);
 /* The same, packed as `writetonc` stores it (R/dataprep.R:1064-1069 `atonc`, :1158-1167): int32
  * round-half-even(value * scale), transposed per step to [cols, rows] (east fastest), NA ->
  * NA_integer_ (INT32_MIN; ncvar_put writes the variable's missval -9999 for it).  writetonc's scales:

@@ -164,7 +164,7 @@ EXPORTS = (
     "mcf_runmicro1", "mcf_runmicro2", "mcf_runmicro3", "mcf_runmicro4",
     "mcf_plan_create", "mcf_plan_destroy", "mcf_plan_twi_partial",
     "mcf_plan_set_twi_mean", "mcf_plan_upload_forcing_days", "mcf_plan_run_days",
-    "mcf_plan_belowground", "mcf_plan_sync", "mcf_plan_fetch", "mcf_plan_fetch_packed", "mcf_plan_slot_ptr",
+    "mcf_plan_belowground", "mcf_plan_sync", "mcf_plan_fetch", "mcf_plan_fetch_cells", "mcf_plan_fetch_packed", "mcf_plan_slot_ptr",
     "mcf_plan_timer_start", "mcf_plan_timer_stop", "mcf_plan_kernel_timing",
     "mcf_plan_kernel_stats", "mcf_plan_valid_cells", "mcf_plan_bytes", "mcf_selftest_math",
     "mcf_precompute_terrain", "mcf_runbioclim1", "mcf_runbioclim2", "mcf_runbioclim3", "mcf_runbioclim4",
@@ -223,6 +223,9 @@ def load() -> C.CDLL:
     lib.mcf_plan_sync.argtypes = [P]
     lib.mcf_plan_fetch.restype = C.c_int
     lib.mcf_plan_fetch.argtypes = [P, C.c_int32, C.c_int32, C.c_int64, C.c_int64, c_double_p]
+    lib.mcf_plan_fetch_cells.restype = C.c_int
+    lib.mcf_plan_fetch_cells.argtypes = [P, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.c_int64,
+                                         c_double_p]
     lib.mcf_plan_fetch_packed.restype = C.c_int
     lib.mcf_plan_fetch_packed.argtypes = [P, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_double, c_int32_p,
                                           C.POINTER(C.c_float)]

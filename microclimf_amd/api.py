@@ -221,6 +221,16 @@ class Plan:
                                             a.ctypes.data_as(_abi.c_double_p)))
         return a
 
+    def fetch_cells(self, slot: int, var, step0: int, nsteps: int, cells) -> np.ndarray:
+        """[len(cells), nsteps] values of `var` for the listed cells (0-based column-major indices i + rows*j)."""
+        v = _abi.OUT_NAMES.index(var) if isinstance(var, str) else int(var)
+        cells = np.ascontiguousarray(np.asarray(cells, dtype=np.int64))
+        a = np.empty((cells.size, nsteps), dtype=np.float64, order="F")
+        _abi.check(self._lib.mcf_plan_fetch_cells(self._p, slot, v, step0, nsteps,
+                                                  cells.ctypes.data_as(C.POINTER(C.c_int64)), cells.size,
+                                                  a.ctypes.data_as(_abi.c_double_p)))
+        return a
+
     # writetonc's scale per variable (R/dataprep.R:1158-1167): x100 for temperatures, soil moisture, wind
     NC_SCALE = {"Tz": 100.0, "tleaf": 100.0, "relhum": 1.0, "soilm": 100.0, "windspeed": 100.0, "Rdirdown": 1.0,
                 "Rdifdown": 1.0, "Rlwdown": 1.0, "Rswup": 1.0, "Rlwup": 1.0}

@@ -775,6 +775,37 @@ int mcf_plan_fetch(mcf_plan* p, int32_t slot, int32_t var, int64_t step0, int64_
     return MCF_OK;
 }
 
+int mcf_plan_fetch_cells(mcf_plan* p, int32_t slot, int32_t var, int64_t step0, int64_t nsteps, const int64_t* cells,
+                         int64_t ncells, double* host_dst) {
+    if (!p || !host_dst || !cells) return fail(MCF_ERR_ARG, "null argument");
+    if (slot < 0 || slot >= p->ring_slots || var < 0 || var >= MCF_NOUT) return fail(MCF_ERR_ARG, "bad slot/var");
+    if (p->var_slot[var] < 0) return fail(MCF_ERR_ARG, "variable was not requested in out[]");
+    const int64_t cap_steps = (int64_t)p->ring_days * 24;
+    if (step0 < 0 || nsteps < 0 || step0 + nsteps > cap_steps) return fail(MCF_ERR_ARG, "step range out of slot");
+    if (ncells < 0) return fail(MCF_ERR_ARG, "negative cell count");
+    for (int64_t i = 0; i < ncells; ++i)
+        if (cells[i] < 0 || cells[i] >= p->N) return fail(MCF_ERR_ARG, "cell index outside the raster");
+    if (ncells == 0 || nsteps == 0) return MCF_OK;
+    HIP_TRY(hipSetDevice(p->device));
+    int64_t* d_cells = nullptr;
+    double* d_dst = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_cells, (size_t)ncells * 8));
+    hipError_t e = hipMalloc((void**)&d_dst, (size_t)(ncells * nsteps) * 8);
+    if (e != hipSuccess) { (void)hipFree(d_cells); return fail(MCF_ERR_NOMEM, "hipMalloc failed for the gather buffer"); }
+    const double* src = p->d_ring + ((int64_t)slot * p->nvars + p->var_slot[var]) * (p->N * cap_steps) + p->N * step0;
+    e = hipMemcpyAsync(d_cells, cells, (size_t)ncells * 8, hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess) {
+        mcf::launch_gather_cells(src, p->N, nsteps, d_cells, ncells, d_dst, p->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(host_dst, d_dst, (size_t)(ncells * nsteps) * 8, hipMemcpyDeviceToHost, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+    (void)hipFree(d_cells);
+    (void)hipFree(d_dst);
+    if (e != hipSuccess) return fail(MCF_ERR_HIP, std::string("mcf_plan_fetch_cells: ") + hipGetErrorString(e));
+    return MCF_OK;
+}
+
 int mcf_plan_fetch_packed(mcf_plan* p, int32_t slot, int32_t var, int64_t step0, int64_t nsteps, double scale,
                           int32_t* host_dst, float* kernel_ms) {
     if (!p || !host_dst) return fail(MCF_ERR_ARG, "null argument");

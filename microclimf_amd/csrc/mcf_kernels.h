@@ -106,6 +106,9 @@ struct BioclimArgs {
 };
 void launch_bioclim(const BioclimArgs& a, hipStream_t s);
 void launch_fill(double* p, int64_t n, double v, hipStream_t s);
+// dst[ci + ncells*k] = src[cells[ci] + N*k], k < nsteps
+void launch_gather_cells(const double* src, int64_t N, int64_t nsteps, const int64_t* cells, int64_t ncells, double* dst,
+                         hipStream_t s);
 // per-cell maximum over time of the bilinearly interpolated coarse temperature [crows*ccols][tsteps]
 // `force`: the 15 coarse slabs (stride elements apart); elevd / pkfac null without altitude correction
 void launch_mxtc_coarse(const double* force, int64_t stride, int crows, int ccols, int tsteps, const double* rowpos,

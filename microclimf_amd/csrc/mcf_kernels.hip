@@ -61,6 +61,15 @@ __global__ void k_fill(double* __restrict__ p, int64_t n, double v) {
     for (; i < n; i += stride) p[i] = v;
 }
 
+// sparse read-back of a ring slot: one lane per (sampled cell, step)
+__global__ void k_gather_cells(const double* __restrict__ src, int64_t N, int64_t nsteps, const int64_t* __restrict__ cells,
+                               int64_t ncells, double* __restrict__ dst) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncells * nsteps) return;
+    const int64_t ci = i % ncells, k = i / ncells;
+    dst[i] = src[cells[ci] + N * k];
+}
+
 // ------------------------------------------------------------------------------------
 // Deterministic two-stage reduction: kTwiParts workgroups reduce fixed strided subsets with a fixed-shape LDS
 // tree into out[2 + 2p], a single lane then adds the partials in order into out[0..1].
@@ -1073,6 +1082,12 @@ void launch_mxtc_coarse(const double* force, int64_t stride, int crows, int ccol
                         const double* pkfac, double* mx, hipStream_t s) {
     hipLaunchKernelGGL(k_mxtc_coarse, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, force, stride, crows, ccols, tsteps,
                        rowpos, colpos, rows, N, altcorrect, elevd, pkfac, mx);
+}
+void launch_gather_cells(const double* src, int64_t N, int64_t nsteps, const int64_t* cells, int64_t ncells, double* dst,
+                         hipStream_t s) {
+    const int64_t n = ncells * nsteps;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_gather_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, N, nsteps, cells, ncells, dst);
 }
 void launch_fill(double* p, int64_t n, double v, hipStream_t s) {
     if (n <= 0) return;

@@ -10,7 +10,8 @@
  *   _microclimf_gridmicrosnow1/2  src/RcppExports.cpp:542-578  ->  mcfhip_gridmicrosnow1/2
  * Same 15 arguments in the same order as R/RcppExports.R:72-78, same named-list
  * result (src/microclimfCpp.cpp:2326-2335).  Uses only R's C API (Rinternals.h);
- * no Rcpp.  NOT compiled in the build image (R is not installed there): build with
+ * no Rcpp.  NOT compiled in the build image (R is not installed there; tests/test_r_glue_syntax_cpu.py runs
+ * `gcc -fsyntax-only` on it against declarations-only headers — a syntax check, nothing more): build with
  *   R CMD SHLIB mcfhip_glue.c -I../include -L../microclimf_amd/csrc -lmcfhip
  *
  * Error discipline: libmcfhip never longjmps; it returns a status and
@@ -23,7 +24,26 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stddef.h>
+
 #include "mcf.h"
+
+/* The fill loops below walk these structs as arrays of `const double *` in the order of their name tables: a reorder or
+ * an added field in include/mcf.h must fail the build, not shift the pointers silently. */
+#define MCF_PTR_STRUCT(type, first, last, n)                                                           \
+    _Static_assert(sizeof(type) == (n) * sizeof(const double *), #type " is not " #n " pointers");     \
+    _Static_assert(offsetof(type, first) == 0, #type "." #first " is not the first field");            \
+    _Static_assert(offsetof(type, last) == ((n) - 1) * sizeof(const double *), #type "." #last " is not the last field")
+MCF_PTR_STRUCT(mcf_vegp, hgt, leafden, 10);
+MCF_PTR_STRUCT(mcf_soilc, Smin, hor, 15);
+MCF_PTR_STRUCT(mcf_snow_climate, temp, umu, 10);
+MCF_PTR_STRUCT(mcf_snow_pointm, Gp, umu, 5);
+MCF_PTR_STRUCT(mcf_snow_vegp, pai, leafden, 7);
+_Static_assert(offsetof(mcf_vegp, paia) == 8 * sizeof(const double *), "mcf_vegp.paia");
+_Static_assert(offsetof(mcf_soilc, slope) == 9 * sizeof(const double *), "mcf_soilc.slope");
+_Static_assert(offsetof(mcf_soilc, wsa) == 13 * sizeof(const double *), "mcf_soilc.wsa");
+_Static_assert(offsetof(mcf_snow_climate, precip) == 8 * sizeof(const double *), "mcf_snow_climate.precip");
+_Static_assert(offsetof(mcf_snow_vegp, clump) == 3 * sizeof(const double *), "mcf_snow_vegp.clump");
 
 static SEXP elt(SEXP list, const char *name, const char *alt) {
     SEXP names = getAttrib(list, R_NamesSymbol);

@@ -40,29 +40,44 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc"):
     ds = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(kt))
           if "k_solve" in r["Kernel_Name"]]
     dur[d] = sum(ds) / len(ds)
-# days per launch: from the bench line written during the profiled run ("HBM ring (2 slots x N days)")
+# days per launch and raster: from the bench line written during the PMC run itself ("HBM ring (S slots x N days)")
 import re
-ring_days, valid_cells = 5, 1038103
-bj = dst / f"{tag}_bench_under_rocprof.json"
-if bj.exists():
-    try:
-        cfg = json.loads(bj.read_text())["config"]
-        ring_days = int(re.search(r"x (\d+) days", cfg["sink"]).group(1))
-        valid_cells = int(cfg["valid_cells"])
-    except Exception:
-        pass
+sys.path.insert(0, str(root))
+import bench  # noqa: E402  (kernel_hash(): the stamp bench.py checks before it reports these counters)
+ring_days, valid_cells, rows, cols = 5, 1038103, 1024, 1024
+for bj in (src / "pmc_fetch.json", dst / f"{tag}_bench_under_rocprof.json"):
+    if bj.exists():
+        try:
+            cfg = json.loads(bj.read_text().strip().splitlines()[-1])["config"]
+            ring_days = int(re.search(r"x (\d+) days", cfg["sink"]).group(1))
+            valid_cells = int(cfg["valid_cells"])
+            rows, cols = int(cfg["rows_per_gpu"]), int(cfg["cols"])
+            break
+        except Exception:
+            pass
+bargs = (src / "bench_args.txt").read_text().strip() if (src / "bench_args.txt").exists() else ""
 summary = {"kernel": "k_solve<21,0,false>", "per_launch_mean": pmc, "avg_launch_ms_under_pmc": dur,
-           "ring_days": ring_days, "cell_steps_per_launch": valid_cells * ring_days * 24,
-           "command": f"python3 bench.py --tsteps 1200 --steps 1 --warmup 0 --no-cpu-baseline ({ring_days}-day launches)"}
+           "ring_days": ring_days, "rows": rows, "cols": cols, "cell_steps_per_launch": valid_cells * ring_days * 24,
+           "kernel_hash": bench.kernel_hash(),
+           "command": f"python3 bench.py {bargs} --tsteps 1920 --steps 1 --warmup 0 --no-cpu-baseline --no-secondary "
+                      f"--no-verify ({ring_days}-day launches; 80 days: a whole number of launches for 1, 2, 4, 5, 8 and 10-day slots)"}
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     fetch_b = pmc["FETCH_SIZE"] * 1024 * 2       # gfx950: FETCH_SIZE reports half of a coalesced stream
     write_b = pmc["WRITE_SIZE"] * 1024
     summary["hbm_bytes_per_launch"] = {"read": fetch_b, "write": write_b, "total": fetch_b + write_b}
-    (dst / "traffic.json").write_text(json.dumps({
-        "rows": 1024, "cols": 1024, "ring_days": ring_days, "tag": tag,
-        "hbm_bytes_per_launch": fetch_b + write_b, "read_bytes": fetch_b, "write_bytes": write_b,
-        "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KB -> B; FETCH_SIZE x2 (gfx950)"},
-        indent=1))
+    tf = dst / "traffic.json"
+    try:
+        old = json.loads(tf.read_text())
+        entries = old.get("entries", [old])
+    except Exception:
+        entries = []
+    entries = [e for e in entries if (e.get("rows"), e.get("cols"), e.get("ring_days")) != (rows, cols, ring_days)]
+    entries.append({"rows": rows, "cols": cols, "ring_days": ring_days, "tag": tag, "kernel_hash": bench.kernel_hash(),
+                    "hbm_bytes_per_launch": fetch_b + write_b, "read_bytes": fetch_b, "write_bytes": write_b})
+    tf.write_text(json.dumps({
+        "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KB -> B; FETCH_SIZE x2 (gfx950); "
+                  "kernel_hash = bench.kernel_hash() of the sources the counters were taken from",
+        "entries": entries}, indent=1))
 if "SQ_ACTIVE_INST_VALU" in pmc and "GRBM_GUI_ACTIVE" in pmc:
     cyc = pmc["GRBM_GUI_ACTIVE"] / 8          # summed over 8 XCDs
     summary["valu_busy_fraction"] = pmc["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cyc)   # quad-cycles, 1024 SIMDs
