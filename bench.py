@@ -470,7 +470,7 @@ def measure(args, torch, dist, use_dist, rank, world, local_rank, *, rows, cols,
         valid_all = allreduce_sum(float(valid))  # whole-job units
         res = {"dt": dt, "kms": kms, "klaunches": klaunches, "valid": valid, "valid_all": valid_all, "ndays": ndays, "T": T,
                "terrain_s": terrain_s, "setup_s": setup_s, "value": valid_all * ndays * 24 * steps / dt, "verified": None,
-               "plan_bytes": plan.device_bytes}
+               "plan_bytes": plan.device_bytes, "dispatch": plan.dispatch_stats()}
         if verify and rank == 0 and not af and not coarse:
             res["verified"] = verify_sample(plan, a, resident, twi_mean, args.verify_cells)
     finally:
@@ -607,6 +607,7 @@ def main(argv=None):
                 "terrain": ("on-device pre-compute from the synthetic DTM (untimed, see terrain_precompute_s)"
                             if r["terrain_s"] is not None else "random (SURVEY 8d config 2)"),
                 "device_bytes": int(r["plan_bytes"]),
+                "dispatch": r["dispatch"],
             },
             "terrain_precompute_s": r["terrain_s"],
             "input_setup_s": r["setup_s"],

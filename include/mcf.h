@@ -289,6 +289,19 @@ int mcf_plan_timer_stop(mcf_plan *plan, float *ms);
 int mcf_plan_kernel_timing(mcf_plan *plan, int32_t enable);
 int mcf_plan_kernel_stats(mcf_plan *plan, double *total_ms, int64_t *launches);
 
+/* How the plan's launches were dispatched (vector forcing, reqhgt >= 0): the solver has two instantiations of its
+ * clamps — one v_min_f64 / v_max_f64 each ("fast") for tiles whose cells' constants are all finite and in range, and the
+ * reference's compare-and-select form for the others, for launches that contain a step with non-finite forcing, and for
+ * tiles in which a fast wave met a NaN at a watched clamp (redone by a fix-up kernel).  Results are identical either way;
+ * the counts are diagnostics (tests assert which path ran).  Synchronises the plan's stream. */
+typedef struct mcf_dispatch_stats {
+    int64_t fast_tiles, slow_tiles;   /* tiles per class (cells_per_block cells each)                    */
+    int64_t irregular_days;           /* days with a non-finite / out-of-range forcing step             */
+    int64_t fast_launches, slow_launches;
+    int64_t canary_trips;             /* tiles redone by the fix-up kernel, summed over launches         */
+} mcf_dispatch_stats;
+int mcf_plan_dispatch_stats(mcf_plan *plan, mcf_dispatch_stats *stats);
+
 /* ---- fused bioclim sink --------------------------------------------------------------
  * Replace _microclimf_runbioclim1Cpp / _microclimf_runbioclim2Cpp (bodies
  * src/microclimfCpp.cpp:3563-3588 / 3590-3616): the grid solver run with

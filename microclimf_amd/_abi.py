@@ -166,7 +166,7 @@ EXPORTS = (
     "mcf_plan_set_twi_mean", "mcf_plan_upload_forcing_days", "mcf_plan_run_days",
     "mcf_plan_belowground", "mcf_plan_sync", "mcf_plan_fetch", "mcf_plan_fetch_cells", "mcf_plan_fetch_packed", "mcf_plan_slot_ptr",
     "mcf_plan_timer_start", "mcf_plan_timer_stop", "mcf_plan_kernel_timing",
-    "mcf_plan_kernel_stats", "mcf_plan_valid_cells", "mcf_plan_bytes", "mcf_selftest_math",
+    "mcf_plan_kernel_stats", "mcf_plan_dispatch_stats", "mcf_plan_valid_cells", "mcf_plan_bytes", "mcf_selftest_math",
     "mcf_precompute_terrain", "mcf_runbioclim1", "mcf_runbioclim2", "mcf_runbioclim3", "mcf_runbioclim4",
     "mcf_snowenv_from_name", "mcf_gridmodelsnow1", "mcf_gridmodelsnow2", "mcf_gridmicrosnow1",
     "mcf_gridmicrosnow2", "mcf_snowmodel1", "mcf_applycpp3",
@@ -183,6 +183,11 @@ _lib = None
 
 class McfError(RuntimeError):
     """Raised when libmcfhip reports a non-zero status."""
+
+
+class DispatchStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("fast_tiles", "slow_tiles", "irregular_days", "fast_launches", "slow_launches",
+                                         "canary_trips")]
 
 
 def load() -> C.CDLL:
@@ -239,6 +244,8 @@ def load() -> C.CDLL:
     lib.mcf_plan_kernel_timing.argtypes = [P, C.c_int32]
     lib.mcf_plan_kernel_stats.restype = C.c_int
     lib.mcf_plan_kernel_stats.argtypes = [P, c_double_p, C.POINTER(C.c_int64)]
+    lib.mcf_plan_dispatch_stats.restype = C.c_int
+    lib.mcf_plan_dispatch_stats.argtypes = [P, C.POINTER(DispatchStats)]
     lib.mcf_plan_valid_cells.restype = C.c_int64
     lib.mcf_plan_valid_cells.argtypes = [P]
     lib.mcf_plan_bytes.restype = C.c_int64

@@ -260,6 +260,12 @@ class Plan:
     def kernel_timing(self, enable: bool = True):
         _abi.check(self._lib.mcf_plan_kernel_timing(self._p, 1 if enable else 0))
 
+    def dispatch_stats(self) -> dict:
+        """Which clamp variant the launches ran (include/mcf.h mcf_dispatch_stats): diagnostics, results are identical."""
+        st = _abi.DispatchStats()
+        _abi.check(self._lib.mcf_plan_dispatch_stats(self._p, C.byref(st)))
+        return {n: int(getattr(st, n)) for n, _ in st._fields_}
+
     def kernel_stats(self):
         ms, n = C.c_double(), C.c_int64()
         _abi.check(self._lib.mcf_plan_kernel_stats(self._p, C.byref(ms), C.byref(n)))

@@ -87,6 +87,16 @@ struct mcf_plan {
     int64_t twi_count = 0;
     double twi_mean = 0;
     bool cells_ready = false;
+    // fast-clamp dispatch (vector forcing, reqhgt >= 0): tiles whose valid cells are all FL_REGULAR run the min / max
+    // variant of the solver, the others the reference's compare-and-select form; days with an irregular forcing step
+    // send the whole launch through the latter (mcf_device.hpp `cap`, mcf_kernels.hip k_solve / k_solve_fix)
+    bool fast_enabled = false;
+    std::vector<char> day_irregular, day_soil_daily;
+    int32_t *d_tiles_fast = nullptr, *d_tiles_slow = nullptr;
+    int64_t n_fast = 0, n_slow = 0, tiles_cap = 0;
+    int32_t *d_fix_count = nullptr, *d_fix_list = nullptr;
+    int fix_cap = 8192;
+    int64_t fast_launches = 0, slow_launches = 0;
     // array forcing
     double* d_dt = nullptr;
     int32_t* d_windex = nullptr;
@@ -214,6 +224,7 @@ int ensure_cells(mcf_plan* p) {
     a.Psie = p->d_soil[4]; a.Vq = p->d_soil[5]; a.Vm = p->d_soil[6]; a.Mc = p->d_soil[7];
     a.rho = p->d_soil[8]; a.slope = p->d_soil[9]; a.aspect = p->d_soil[10]; a.twi = p->d_soil[11];
     a.svfa = p->d_soil[12];
+    a.hor = p->d_hor; a.wsa = p->d_wsa;
     a.lats = p->d_lats; a.lons = p->d_lons; a.lat = p->lat; a.lon = p->lon;
     a.crowpos = p->d_crowpos; a.ccolpos = p->d_ccolpos; a.rows = p->rows;
     a.elevd = p->d_elevd; a.pkfac = p->d_pkfac;
@@ -225,6 +236,58 @@ int ensure_cells(mcf_plan* p) {
     HIP_TRY(hipGetLastError());
   }
     p->cells_ready = true;
+    if (!p->af && p->day_irregular.empty() && p->ndays > 0) {
+        // the per-day flags of the time table, once: kStepIrregular and kSoilDaily in TF_IDX (its last field)
+        const int tfc = mcf::time_field_count();
+        std::vector<double> idx((size_t)p->ndays * 24);
+        HIP_TRY(hipMemcpy2DAsync(idx.data(), 24 * 8, p->d_tt + (int64_t)(tfc - 1) * 24, (size_t)tfc * 24 * 8, 24 * 8,
+                                 (size_t)p->ndays, hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        static const bool no_share = getenv("MCF_NO_SOIL_SHARE") != nullptr;     // A/B runs
+        p->day_irregular.assign((size_t)p->ndays, 0);
+        p->day_soil_daily.assign((size_t)p->ndays, 0);
+        for (int d = 0; d < p->ndays; ++d) {
+            for (int h = 0; h < 24; ++h)
+                if ((int)idx[(size_t)d * 24 + h] & mcf::step_irregular_bit()) p->day_irregular[(size_t)d] = 1;
+            p->day_soil_daily[(size_t)d] = (!no_share && ((int)idx[(size_t)d * 24] & mcf::soil_daily_bit())) ? 1 : 0;
+        }
+    }
+    if (p->fast_enabled) {
+        int rc;
+        const int64_t ntiles = (p->N + p->cpb - 1) / p->cpb;
+        if (p->tiles_cap < ntiles) {
+            void* q;
+            if ((rc = dalloc(p, &q, ntiles * 4))) return rc;
+            p->d_tiles_fast = (int32_t*)q;
+            if ((rc = dalloc(p, &q, ntiles * 4))) return rc;
+            p->d_tiles_slow = (int32_t*)q;
+            p->tiles_cap = ntiles;
+        }
+        if (!p->d_fix_count) {
+            void* q;
+            if ((rc = dalloc(p, &q, 64))) return rc;
+            p->d_fix_count = (int32_t*)q;
+            HIP_TRY(hipMemsetAsync(p->d_fix_count, 0, 64, p->stream));
+            if ((rc = dalloc(p, &q, (int64_t)p->fix_cap * 8))) return rc;
+            p->d_fix_list = (int32_t*)q;
+        }
+        // tile classes: the fast list borrows d_tiles_fast as the device-side byte scratch first
+        uint8_t* d_flag = (uint8_t*)p->d_tiles_fast;
+        mcf::launch_tile_regular(p->d_cellc, p->N, p->layers, p->cpb, d_flag, p->stream);
+        HIP_TRY(hipGetLastError());
+        std::vector<uint8_t> flag((size_t)ntiles);
+        HIP_TRY(hipMemcpyAsync(flag.data(), d_flag, (size_t)ntiles, hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        std::vector<int32_t> fastl, slowl;
+        fastl.reserve((size_t)ntiles);
+        for (int64_t t = 0; t < ntiles; ++t) (flag[(size_t)t] ? fastl : slowl).push_back((int32_t)t);
+        p->n_fast = (int64_t)fastl.size();
+        p->n_slow = (int64_t)slowl.size();
+        if (p->n_slow > 0) {     // with no irregular tile the fast launch needs no list (identity)
+            HIP_TRY(hipMemcpy(p->d_tiles_fast, fastl.data(), fastl.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(p->d_tiles_slow, slowl.data(), slowl.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
     return MCF_OK;
 }
 
@@ -362,6 +425,10 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
     }
     // vector forcing: two 8-wave workgroups per CU (21 cells); array forcing: one 12-wave workgroup
     p->cpb = opt->cells_per_block ? opt->cells_per_block : (in->array_forcing ? 32 : 21);
+    {
+        static const bool no_fast = getenv("MCF_NO_FAST_CLAMPS") != nullptr;     // A/B runs and tools/canary_audit.py
+        p->fast_enabled = !no_fast && in->array_forcing == 0 && !(opt->reqhgt < 0.0);
+    }
     p->layers = in->veg_layers > 1 ? in->veg_layers : 1;
     p->opt = *opt;
     p->lat = in->lat; p->lon = in->lon;
@@ -700,7 +767,7 @@ int mcf_plan_run_days(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot) {
         a.out_sel |= (uint64_t)(p->var_slot[v] < 0 ? 15 : p->var_slot[v]) << (4 * v);
     a.slot_step0 = p->bg ? (int64_t)day0 * 24 : 0;
     a.tgser = p->d_tgser; a.ddsum = p->d_ddsum;
-    a.day0 = day0; a.ndays = ndays;
+    a.day0 = day0; a.ndays = ndays; a.total_days = p->ndays;
     {
         // pass 2 yields Tz (+ tleaf, relhum for reqhgt > 0) and the long-wave fluxes; requests for
         // soilm / windspeed / short-wave fluxes alone are served by pass 1
@@ -712,18 +779,63 @@ int mcf_plan_run_days(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot) {
         a.need_pass2 = p->bg ? (o0 ? 1 : 0) : (a.need_tv || (rq == 0.0 && o0));
     }
     a.g = p->g;
+    a.fix_count = p->d_fix_count; a.fix_list = p->d_fix_list; a.fix_cap = p->fix_cap;
+    bool fast = p->fast_enabled && p->n_fast > 0;
+    for (int d = day0; fast && d < day0 + ndays; ++d)
+        if (p->day_irregular[(size_t)d]) fast = false;
+    bool soil_daily = !p->af && !p->day_soil_daily.empty();
+    for (int d = day0; soil_daily && d < day0 + ndays; ++d)
+        if (!p->day_soil_daily[(size_t)d]) soil_daily = false;
+    auto launch = [&]() {
+        if (fast) {
+            (void)hipMemsetAsync(p->d_fix_count, 0, 4, p->stream);
+            a.tile_list = p->n_slow > 0 ? p->d_tiles_fast : nullptr;
+            a.ntiles_launch = p->n_fast;
+            mcf::launch_solve(a, p->cpb, false, false, true, soil_daily, p->stream);
+            ++p->fast_launches;
+            if (p->n_slow > 0) {
+                ++p->slow_launches;
+                a.tile_list = p->d_tiles_slow;
+                a.ntiles_launch = p->n_slow;
+                mcf::launch_solve(a, p->cpb, false, false, false, soil_daily, p->stream);
+            }
+        } else {
+            a.tile_list = nullptr;
+            a.ntiles_launch = 0;
+            ++p->slow_launches;
+            mcf::launch_solve(a, p->cpb, p->af, p->bg, false, soil_daily, p->stream);
+        }
+    };
     if (p->ktiming) {
         hipEvent_t e0, e1;
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, p->stream));
-        mcf::launch_solve(a, p->cpb, p->af, p->bg, p->stream);
+        launch();
         HIP_TRY(hipEventRecord(e1, p->stream));
         p->kev.emplace_back(e0, e1);
     } else {
-        mcf::launch_solve(a, p->cpb, p->af, p->bg, p->stream);
+        launch();
     }
     HIP_TRY(hipGetLastError());
+    return MCF_OK;
+}
+
+int mcf_plan_dispatch_stats(mcf_plan* p, mcf_dispatch_stats* st) {
+    if (!p || !st) return fail(MCF_ERR_ARG, "null argument");
+    memset(st, 0, sizeof *st);
+    HIP_TRY(hipSetDevice(p->device));
+    HIP_TRY(hipStreamSynchronize(p->stream));
+    st->fast_tiles = p->fast_enabled ? p->n_fast : 0;
+    st->slow_tiles = p->fast_enabled ? p->n_slow : (p->N + p->cpb - 1) / p->cpb;
+    for (char c : p->day_irregular) st->irregular_days += c ? 1 : 0;
+    st->fast_launches = p->fast_launches;
+    st->slow_launches = p->slow_launches;
+    if (p->d_fix_count) {
+        int32_t v[2] = {0, 0};
+        HIP_TRY(hipMemcpy(v, p->d_fix_count, 8, hipMemcpyDeviceToHost));
+        st->canary_trips = v[1];
+    }
     return MCF_OK;
 }
 

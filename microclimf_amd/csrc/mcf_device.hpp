@@ -31,8 +31,8 @@
                          // per cell-step, +2.6 % same-box, max scaled difference to the oracle 2e-13 -> 2.9e-12.  Not
                          // shipped: a 15x wider margin at the path's comparisons for 2.6 % is a bad trade
 #endif
-#ifndef MCF_FDIV_NR2
-#define MCF_FDIV_NR2 0   // 1: second Newton step on the reciprocal inside fdiv (not needed, see fdiv)
+#ifndef MCF_DIV_EXACT_LAST_BIT
+#define MCF_DIV_EXACT_LAST_BIT 0   // 1: the 0.5-ulp quotient (one more FMA per division); 0: a * (1/b), 1.5 ulp
 #endif
 
 namespace mcf {
@@ -56,8 +56,19 @@ enum : int {
     FL_ABOVE1 = 64,    // reqhgt2 > d + zh                    cpp:1303 (TVabove at reqhgt)
     FL_ABOVE2 = 128,   // hgt > d + zh                        cpp:1303 (TVabove at hgt)
     FL_OMPNAN = 256,   // isnan(omp)                          cpp:464
-    FL_STOM = 512      // gsmax < 999.99                      cpp:1351
+    FL_STOM = 512,     // gsmax < 999.99                      cpp:1351
+    FL_REGULAR = 1024  // every constant this cell's path reads is finite and in its physical range: no clamp of the
+                       // hot loop can then meet a NaN operand (see `cap` / `flr` below); set by k_cell_setup
 };
+// Step flag packed into TF_IDX beside sindex / windex / ksat: the step's forcing is not finite or outside the range the
+// fast clamps assume (pk, De, ghr > 0).
+constexpr int kStepIrregular = 512;
+// Day flag, set on all 24 rows of a day: the point model's soil moisture (pointm$soilm) has ONE value on this day — what
+// soilmCpp's daily bucket model produces (src/microclimfCpp.cpp:931-972).  Everything that depends on the cell and on soil
+// moisture only (spread soil moisture, matric potential, conductivity and damping depth, the stomatal water-stress
+// factor) is then one value per cell-DAY, and k_solve computes it once per tile and day (SoilDay below) instead of in
+// each of the 24 hour lanes.
+constexpr int kSoilDaily = 1024;
 
 // ---- per-cell constant table ------------------------------------------------
 enum CellField : int {
@@ -129,36 +140,40 @@ __device__ __forceinline__ double na_real() { return __longlong_as_double((long 
 // below are valid on the domains this path produces (finite, normal operands; exp
 // also for very negative arguments, where it returns 0) and are accurate to ~1 ulp
 // (checked against numpy by tests/test_math_gpu.py through mcf_selftest_math).
+// v_rcp_f64 / v_rsq_f64 deliver ~23 bits.  With e = 1 - b*r0 (|e| < 2^-23) the CUBIC step r1 = r0*(1 + e + e^2) leaves a
+// relative error of e^3 < 2^-69, i.e. a correctly rounded-to-nearest-ish reciprocal in three FMAs — one fewer than two
+// Newton steps.  (MCF_DIV_FAST = 1, experiment: a single Newton step, 46 bits.)
 __device__ __forceinline__ double frcp(double b) {           // 1/b, b finite normal non-zero
     double r = __builtin_amdgcn_rcp(b);
-    r = fma(fma(-b, r, 1.0), r, r);
-#if !MCF_DIV_FAST
-    r = fma(fma(-b, r, 1.0), r, r);
+    const double e = fma(-b, r, 1.0);
+#if MCF_DIV_FAST
+    return fma(e, r, r);
+#else
+    return fma(fma(e, e, e), r, r);
 #endif
-    return r;
 }
 __device__ __forceinline__ double fdiv(double a, double b) {  // a/b, b finite normal non-zero
-    // v_rcp_f64 delivers ~23 bits; ONE Newton step (46 bits, relative error e) is enough here because the
-    // quotient correction below is itself a Newton step on q: q' = (a/b)(1 - e^2)
+#if MCF_DIV_EXACT_LAST_BIT
+    // one Newton step on the reciprocal (46 bits), then a Newton step on the quotient: q' = (a/b)(1 - e^2); 0.5 ulp
     double r = __builtin_amdgcn_rcp(b);
-#if !MCF_DIV_FAST
     r = fma(fma(-b, r, 1.0), r, r);
-#endif
-#if MCF_FDIV_NR2
-    r = fma(fma(-b, r, 1.0), r, r);
-#endif
     double q = a * r;
     return fma(fma(-b, q, a), r, q);
+#else
+    // a * (1/b) with the 69-bit reciprocal above: one FMA fewer; the two roundings (of 1/b and of the product) bound the
+    // error by 1.5 ulp (3.3e-16), checked by tests/test_math_gpu.py
+    return a * frcp(b);
+#endif
 }
 __device__ __forceinline__ double fsqrt(double x) {           // sqrt(x), x finite normal positive
+    // coupled Goldschmidt step from the 23-bit v_rsq_f64 (g ~ sqrt x and h ~ 1/(2 sqrt x) to 46 bits), then ONE residual
+    // correction g += (x - g^2) * h: the residual is exact in the FMA and h's 46 bits leave an error far below an ulp
     double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = 0.5 * y;
     double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
     h = fma(h, r, h);
     double e = fma(-g, g, x);
-    g = fma(e, h, g);
-    e = fma(-g, g, x);
     return fma(e, h, g);
 }
 // A 64-bit literal used as a VALU operand has to live in a register pair.  Left alone,
@@ -176,10 +191,17 @@ __device__ __forceinline__ double fsqrt(double x) {           // sqrt(x), x fini
 // (MathK::pin), so that the ~25 exp and ~7 log evaluations of a cell-step share them.  Rematerialised at every
 // call (22 + 14 s_mov_b32 each) they made up ~70 % of the kernel's scalar instructions, and the scalar issue slots
 // they take from their own wave cost 9 % of the run time (measured by doubling them).
+#ifndef MCF_PIN_VCONST
+#define MCF_PIN_VCONST 2   // exp's c11 (and log's Lg6, Lg7) live in VGPR pairs for the whole day loop: the first Horner step
+                           // p = r*c11 + c10 reads TWO constants and a VOP3 can take only one from the scalar file, so the
+                           // other was re-created by two v_mov_b32 in front of (nearly) every evaluation
+#endif
 struct MathK {
     double e[12];   // exp: 1/ln2, -ln2_hi, -ln2_lo, c10 .. c2
     double l[7];    // log: Lg4, Lg5, Lg2, Lg3, Lg1, ln2_lo, ln2_hi
+    double c11, lg6, lg7;   // VGPR residents (MCF_PIN_VCONST)
     __device__ __forceinline__ void set() {
+        c11 = 0x1.ade156a5dcb37p-26; lg6 = 1.531383769920937332e-01; lg7 = 1.479819860511658591e-01;
         e[0] = 0x1.71547652b82fep+0; e[1] = -0x1.62e42fefa39efp-1; e[2] = -0x1.abc9e3b39803fp-56;
         e[3] = 0x1.28af3fca7ab0cp-22; e[4] = 0x1.71dee623fde64p-19; e[5] = 0x1.a01997c89e6b0p-16;
         e[6] = 0x1.a01a014761f6ep-13; e[7] = 0x1.6c16c1852b7b0p-10; e[8] = 0x1.1111111122322p-7;
@@ -196,12 +218,18 @@ struct MathK {
 #pragma unroll
             for (int i = 0; i < 7; ++i) asm volatile("" : "+s"(l[i]));
         }
+#if MCF_PIN_VCONST
+        asm volatile("" : "+v"(c11));
+#if MCF_PIN_VCONST > 1
+        if (with_log) { asm volatile("" : "+v"(lg6)); asm volatile("" : "+v"(lg7)); }
+#endif
+#endif
     }
 };
 __device__ __forceinline__ double fexp(double x, const MathK& K) {
     double n, r, p, out;
     int t;
-    const double c11 = 0x1.ade156a5dcb37p-26;
+    const double c11 = K.c11;
 #if MCF_EXPERIMENT_SALU
     {   // timing experiment only: 22 extra scalar moves per exp (as many as its coefficients cost)
         int dummy;
@@ -246,7 +274,7 @@ __device__ __forceinline__ double flog(double x, const MathK& K) {
     const double s = fdiv(f, 2.0 + f);
     const double hfsq = 0.5 * f * f;
     const double dk = (double)e;
-    const double lg6 = 1.531383769920937332e-01, lg7 = 1.479819860511658591e-01;
+    const double lg6 = K.lg6, lg7 = K.lg7;
     double z, w, t1, t2, out;
     asm("v_mul_f64 %0, %5, %5\n\t"              // z = s*s
         "v_mul_f64 %1, %0, %0\n\t"              // w = z*z
@@ -388,7 +416,11 @@ __device__ inline void derive_time(TimeVals& t, const SolPos& sp, int windex) {
     t.v[TF_RB] = rbeam * t.v[TF_CZ];                                        // cpp:1124
     int sindex = dir_index(sp.azid, 15.0, 24);
     int ksat = (sp.zend > (kPi / 2.0)) ? 1 : 0;
-    t.v[TF_IDX] = (double)(sindex | (windex << 5) | (ksat << 8));
+    // kStepIrregular: a value of this row is not finite, or one of the signs the fast clamps rely on does not hold
+    // (Penman-Monteith's denominator 29.3*(g + ghr) + la/pk*g*De stays positive for ghr, De, la/pk > 0)
+    bool ok = t.v[TF_DE] > 0.0 && t.v[TF_GHRRAD] > 0.0 && t.v[TF_LAPK] > 0.0 && t.v[TF_PK] > 0.0;
+    for (int f = 0; f < TF_IDX; ++f) ok = ok && isfinite(t.v[f]);
+    t.v[TF_IDX] = (double)(sindex | (windex << 5) | (ksat << 8) | (ok ? 0 : kStepIrregular));
 }
 
 // Array forcing (runmicro2Cpp geometry): the same TF_ values per CELL-step, from the date part of
@@ -548,6 +580,9 @@ struct TimeReg {
 struct Carry {
     double soilm, num0, den, radCsw, Rddown, Rbdown, X, uf;
 };
+#ifndef MCF_SOIL_SHARE
+#define MCF_SOIL_SHARE 1
+#endif
 struct Pass1Out {
     double Tg0, absRnet;   // to the day reduction
     double uz, Rdup;       // outputs only
@@ -563,34 +598,189 @@ __device__ __forceinline__ void pin(A&... a) {
     (pin1(a), ...);
 }
 
-// Penman-Monteith surface temperature, cpp:1220-1247, from pre-assembled parts.
-__device__ __forceinline__ double pm_temperature(double num, double den, double dTmx, double tc, double tdew) {
+// ---- clamps ---------------------------------------------------------------------------------------------------------
+// The reference clamps with `if (x > hi) x = hi;`, which leaves a NaN x alone; v_min_f64 / v_max_f64 return the OTHER
+// operand for a NaN.  On a 64-bit value the compare-and-select form costs v_cmp + 2 v_cndmask (+ moves for a literal
+// bound), the min / max form one instruction — ~60 clamps per cell-step.  They are therefore written through cap / flr:
+//   F = false  the reference's form, always right;
+//   F = true   one v_min_f64 / v_max_f64 — equal to the reference's form whenever x is not NaN.
+// k_solve runs the F = true instantiation of pass 1 / pass 2 only for waves whose lanes are all REGULAR (FL_REGULAR
+// cells on steps without kStepIrregular): every cell constant and forcing value read is finite and in range, so the
+// operands of most clamps are finite by construction (DESIGN.md lists the argument per site).  The few clamp operands
+// that can still become NaN from finite inputs (a vanishing two-stream denominator, a non-positive soil diffusivity,
+// coinciding Lagrangian resistances) are WATCHED: Canary::watch folds them into a value that is NaN iff any of them
+// was NaN or infinite, and a wave with a tripped canary recomputes the pass with F = false.  Building with
+// -DMCF_CANARY_ALL=1 watches every clamp operand instead (tools/canary_audit.py counts how often that trips).
+#ifndef MCF_SKIP_MINCOND
+#define MCF_SKIP_MINCOND 1   // see pass2's leaf block: mincondCpp's floors skipped when they provably cannot bind
+#endif
+#ifndef MCF_CANARY_ALL
+#define MCF_CANARY_ALL 0
+#endif
+struct Canary {
+    double c = 0.0;
+    __device__ __forceinline__ void watch(double x) { c = fma(0.0, x, c); }     // 0*x: 0 for finite x, NaN otherwise
+    __device__ __forceinline__ bool tripped() const { return c != c; }
+};
+// one v_min_f64 / v_max_f64; a bound known at compile time is taken from the scalar file (two s_mov_b32 on the scalar
+// unit) or as an inline constant instead of being copied into a VGPR pair
+#ifndef MCF_CLAMP_LITERALS
+#define MCF_CLAMP_LITERALS 1   // 1: literal bounds from SGPR pairs / inline constants; 0: whatever register the compiler picks ("v")
+#endif
+__device__ __forceinline__ void vmin64(double& x, double hi) {
+#if MCF_CLAMP_LITERALS == 2
+    x = __builtin_fmin(x, hi);
+#else
+    if (MCF_CLAMP_LITERALS && __builtin_constant_p(hi)) {
+        if (hi == 1.0) asm("v_min_f64 %0, %0, 1.0" : "+v"(x));
+        else asm("v_min_f64 %0, %0, %1" : "+v"(x) : "s"(hi));
+    } else asm("v_min_f64 %0, %0, %1" : "+v"(x) : "v"(hi));
+#endif
+}
+__device__ __forceinline__ void vmax64(double& x, double lo) {
+#if MCF_CLAMP_LITERALS == 2
+    x = __builtin_fmax(x, lo);
+#else
+    if (MCF_CLAMP_LITERALS && __builtin_constant_p(lo)) {
+        if (lo == 0.0) asm("v_max_f64 %0, %0, 0" : "+v"(x));
+        else asm("v_max_f64 %0, %0, %1" : "+v"(x) : "s"(lo));
+    } else asm("v_max_f64 %0, %0, %1" : "+v"(x) : "v"(lo));
+#endif
+}
+template <bool F>
+__device__ __forceinline__ void cap(double& x, double hi, Canary& cn) {          // if (x > hi) x = hi;
+    if (F) {
+#if MCF_CANARY_ALL
+        cn.watch(x);
+#endif
+        vmin64(x, hi);
+    } else if (x > hi) x = hi;
+}
+template <bool F>
+__device__ __forceinline__ void flr(double& x, double lo, Canary& cn) {          // if (x < lo) x = lo;
+    if (F) {
+#if MCF_CANARY_ALL
+        cn.watch(x);
+#endif
+        vmax64(x, lo);
+    } else if (x < lo) x = lo;
+}
+
+// Penman-Monteith surface temperature, cpp:1220-1247, from pre-assembled parts.  den > 0 on regular lanes (gHa >= 1e-4,
+// ghr, De, lapk > 0), so dT is finite there.
+template <bool F>
+__device__ __forceinline__ double pm_temperature(double num, double den, double dTmx, double tc, double tdew, Canary& cn) {
     double dT = fdiv(num, den);
-    if (dT > dTmx) dT = dTmx;
-    if (dT > 80.0) dT = 80.0;
+    cap<F>(dT, dTmx, cn);
+    cap<F>(dT, 80.0, cn);
     double Ts = dT + tc;
-    if (Ts < tdew) Ts = tdew;
+    flr<F>(Ts, tdew, cn);
     return Ts;
 }
+
+// ---- per cell-day soil state --------------------------------------------------------------------------------------------
+// cpp:1021-1032 (soildCpp), cpp:1264-1266 (matric potential of soiltempG0), cpp:1249-1260 (soilcondCpp),
+// cpp:451-455 + 382-389 (the theta-only part of stomcondCpp).  The same inline functions serve the hour lanes (days
+// whose soil moisture varies within the day, array forcing) and the tile's producer wave, so both give the same bits.
+enum SoilField : int { SD_SOILM = 0, SD_MATRIC, SD_KSOIL, SD_RDD, SD_DD, SD_GS2, SD_COUNT };
+template <bool F>
+__device__ __forceinline__ double soil_spread(double soilmp, double smin, double invrge, double eta, double rge, Canary& cn) {
+    double theta = (soilmp - smin) * invrge;
+    cap<F>(theta, 0.9999, cn);
+    flr<F>(theta, 0.0001, cn);
+    double sm = theta / (theta + (1.0 - theta) * eta);
+    return sm * rge + smin;
+}
+__device__ __forceinline__ double soil_ksoil_arg(double soilm, double c3) { return -pow4(c3 * soilm); }
+__device__ __forceinline__ double soil_ksoil(double soilm, double rho, double c1, double c1mc4, double e) {
+    double c2 = 1.06 * rho * soilm;
+    return c1 + c2 * soilm - c1mc4 * e;
+}
+__device__ __forceinline__ void soil_damping(double soilm, double ksoil, double rho, double csa, double& DD, double& rdd) {
+    double cs = csa + 4180.0 * soilm;
+    double ph = (rho * (1.0 - soilm) + soilm) * 1000.0;
+    double kap = fdiv(ksoil, cs * ph);
+    DD = fsqrt(kap * (2.0 / kOmdy));
+    rdd = frcp(DD);
+}
+template <bool F>
+__device__ __forceinline__ double stom_se(double soilm, double rat, double ratc, double invsmax, Canary& cn) {
+    double thetan = rat * soilm + ratc;
+    double Se = thetan * invsmax;
+    cap<F>(Se, 1.0, cn);
+    return Se;
+}
+template <bool F>
+__device__ __forceinline__ double stom_psiw(double pw, double abspsie, double psiw0, Canary& cn) {   // pw = Se^-b
+    double psiw = -abspsie * pw * 0.01;
+    flr<F>(psiw, psiw0, cn);
+    return psiw;
+}
+__device__ __forceinline__ double stom_gs2(double e, double mudeninv, double gsmax) {               // e = exp(-kk*psiw)
+    double mu = 1.0 - (e - 1.0) * mudeninv;
+    return mu * gsmax;
+}
+// One tile's soil state for one day, by ONE wave: lanes 0 .. CPB-1 take the soil side of their cell (spread, matric
+// potential, conductivity, damping depth), lanes CPB .. 2*CPB-1 the stomatal side, so that the two pow() (same exponent
+// -b) and the two exp() each run as ONE wave instruction stream.  cellc: the tile's constants in LDS [field][CPB];
+// dst: [SD_COUNT][CPB].
+template <int CPB, bool F>
+__device__ __forceinline__ void soil_day_produce(const double* cellc, double soilmp, double* dst, int lane, const MathK& K) {
+    static_assert(2 * CPB <= 64, "two roles per cell must fit a wave");
+    const int role = lane / CPB, cell = lane - role * CPB;
+    if (role > 1) return;
+    auto C = [&](int f) { return cellc[f * CPB + cell]; };
+    Canary cn;
+    const double soilm = soil_spread<F>(soilmp, C(CF_SMIN), C(CF_INVRGE), C(CF_ETA), C(CF_RGE), cn);
+    const double abspsie = C(CF_ABSPSIE), invsmax = C(CF_INVSMAX);
+    const double se = stom_se<F>(soilm, C(CF_RAT), C(CF_RATC), invsmax, cn);
+    const double pw = powxy(role ? se : soilm * invsmax, -C(CF_SOILB), K);
+    const double psiw = stom_psiw<F>(pw, abspsie, C(CF_PSIW0), cn);
+    const double e = fexp(role ? -C(CF_KK) * psiw : soil_ksoil_arg(soilm, C(CF_C3)), K);
+    if (role == 0) {
+        const double rho = C(CF_RHO);
+        const double ksoil = soil_ksoil(soilm, rho, C(CF_C1), C(CF_C1MC4), e);
+        double DD, rdd;
+        soil_damping(soilm, ksoil, rho, C(CF_CSA), DD, rdd);
+        dst[SD_SOILM * CPB + cell] = soilm;
+        dst[SD_MATRIC * CPB + cell] = -abspsie * pw;
+        dst[SD_KSOIL * CPB + cell] = ksoil;
+        dst[SD_RDD * CPB + cell] = rdd;
+        dst[SD_DD * CPB + cell] = DD;
+    } else {
+        dst[SD_GS2 * CPB + cell] = stom_gs2(e, C(CF_MUDENINV), C(CF_GSMAX));
+    }
+}
+// a lane's view of its cell's entry; SS = false: never read (array forcing)
+template <int CPB>
+struct SoilLds {
+    const double* p;   // + cell
+    __device__ __forceinline__ double operator()(int f) const { return p[f * CPB]; }
+};
 
 // ---------------------------------------------------------------------------------
 // PASS 1 (cpp:2214-2262): terrain-adjusted solar index, soil moisture spread,
 // two-stream radiation, wind, G = 0 soil surface temperature.
 // ---------------------------------------------------------------------------------
-template <class CL, class TM>
-__device__ __forceinline__ void pass1(const CL& C, const TM& T, const Globals& g, int flags, double dTmx,
-                                      Carry& cy, Pass1Out& o, const MathK& K) {
+template <bool F, bool SS, class CL, class TM, class SL>
+__device__ __forceinline__ void pass1(const CL& C, const TM& T, const SL& S, const Globals& g, int flags, double dTmx,
+                                      Carry& cy, Pass1Out& o, const MathK& K, Canary& cn) {
     // ---- section A operands: soil moisture spread + branch selectors
-    double t_idx = T(TF_IDX), rsw = T(TF_RSW), rdif = T(TF_RDIF), t_soilmp = T(TF_SOILMP);
-    double c_smin = C(CF_SMIN), c_invrge = C(CF_INVRGE), c_eta = C(CF_ETA), c_rge = C(CF_RGE);
-    pin(t_idx, rsw, rdif, t_soilmp, c_smin, c_invrge, c_eta, c_rge);
+    double t_idx = T(TF_IDX), rsw = T(TF_RSW), rdif = T(TF_RDIF);
+    pin(t_idx, rsw, rdif);
     const int idx = (int)t_idx;
-    // --- distributed soil moisture, cpp:1021-1032 --------------------------------
-    double theta = (t_soilmp - c_smin) * c_invrge;
-    if (theta > 0.9999) theta = 0.9999;
-    if (theta < 0.0001) theta = 0.0001;
-    double sm = theta / (theta + (1.0 - theta) * c_eta);
-    const double soilm = sm * c_rge + c_smin;
+    constexpr bool soil_shared = SS;     // the host launches the SS instantiation only for days flagged kSoilDaily
+    // --- distributed soil moisture, cpp:1021-1032, and the matric potential of soiltempG0, cpp:1264-1266 ---------
+    double soilm, matric;
+    if (soil_shared) {
+        soilm = S(SD_SOILM);
+        matric = S(SD_MATRIC);
+    } else {
+        double t_soilmp = T(TF_SOILMP), c_smin = C(CF_SMIN), c_invrge = C(CF_INVRGE), c_eta = C(CF_ETA), c_rge = C(CF_RGE);
+        pin(t_soilmp, c_smin, c_invrge, c_eta, c_rge);
+        soilm = soil_spread<F>(t_soilmp, c_smin, c_invrge, c_eta, c_rge, cn);
+        matric = -C(CF_ABSPSIE) * powxy(soilm * C(CF_INVSMAX), -C(CF_SOILB), K);
+    }
     cy.soilm = soilm;
     // --- short wave, cpp:1086-1163 --------------------------------------------------
     double radGsw = 0.0, radCsw = 0.0, Rbdown = 0.0, Rddown = 0.0, Rdup = 0.0, X = 0.0;
@@ -604,7 +794,7 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const Globals& g
         // solar index, cpp:85-102 + horizon shading cpp:2219-2223
         double si = cz * c_cs + t_sz * (c_ssca * t_caz + c_sssa * t_saz);
         if (!g.shadowmask && t_zend > 90.0) si = 0.0;
-        if (si < 0.0) si = 0.0;
+        flr<F>(si, 0.0, cn);
         if (c_hor > t_tansa) si = 0.0;
         if (flags & FL_PAI) {
             // ---- section C operands: extinction + direct-beam two-stream coefficients
@@ -619,7 +809,7 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const Globals& g
             double k = fsqrt(c_xx + t_tan2c) * c_kdeninv;
             if (flags & (FL_XONE | FL_XINF | FL_XZERO))
                 k = (flags & FL_XONE) ? T(TF_INV2COSC) : (flags & FL_XINF) ? 1.0 : T(TF_TANC);
-            if (k > 6000.0) k = 6000.0;
+            cap<F>(k, 6000.0, cn);
             double rsi = frcp(si);
             double kd = k * t_cosc * rsi;
             double Kc = rsi;
@@ -652,33 +842,37 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const Globals& g
                 c_rdupz, Rbeam, Rb);
             // gap transmissions, cpp:1095-1100
             double trbn = fexp(Kc * c_logclump, K);
-            if (trbn > 0.999) trbn = 0.999;
-            if (trbn < 0.0) trbn = 0.0;
+            cap<F>(trbn, 0.999, cn);
+            flr<F>(trbn, 0.0, cn);
             double trb = fexp(Kc * c_loggi, K);
-            if (trb > 0.999) trb = 0.999;
-            if (trb < 0.0) trb = 0.0;
+            cap<F>(trb, 0.999, cn);
+            flr<F>(trb, 0.0, cn);
             double albb = (1.0 - trdn * trbn) * (p5s + p6 + p7) + trdn * trbn * gref;      // cpp:1102
-            if (albb > amx) albb = amx;
-            if (albb < 0.01) albb = 0.01;
+            if (F) cn.watch(albb);        // 1/sig, 1/D1, 1/D2 products: NaN if a two-stream denominator vanishes
+            cap<F>(albb, amx, cn);
+            flr<F>(albb, 0.01, cn);
             double Rdbdn_g = (1.0 - trbn) * (p8s * S2 + p9 * S1 + p10 * c_ehp);            // cpp:1106
-            if (Rdbdn_g > amx) Rdbdn_g = amx;
-            if (Rdbdn_g < 0.0) Rdbdn_g = 0.0;
+            if (F) cn.watch(Rdbdn_g);
+            cap<F>(Rdbdn_g, amx, cn);
+            flr<F>(Rdbdn_g, 0.0, cn);
             double S2a = fexp(-kd * c_paiaa, K);
             double Rdbup_z = (1.0 - trdu * trbn) * (p5s * S2a + p6 * emhpa + p7 * ehpa) + trdu * trbn * gref;
-            if (Rdbup_z > amx) Rdbup_z = amx;
-            if (Rdbup_z < 0.0) Rdbup_z = 0.0;
+            if (F) cn.watch(Rdbup_z);
+            cap<F>(Rdbup_z, amx, cn);
+            flr<F>(Rdbup_z, 0.0, cn);
             double Rdbdn_z = (1.0 - trb) * (p8s * S2a + p9 * emhpa + p10 * ehpa);           // cpp:1117
-            if (Rdbdn_z > amx) Rdbdn_z = amx;
-            if (Rdbdn_z < 0.0) Rdbdn_z = 0.0;
+            if (F) cn.watch(Rdbdn_z);
+            cap<F>(Rdbdn_z, amx, cn);
+            flr<F>(Rdbdn_z, 0.0, cn);
             double trg = trb + (1 - trb) * S2;                                              // cpp:1125
             double Rbc = (trg * si + (1 - trg) * cz) * Rbeam;
             double Rbdn_g = trbn + (1.0 - trbn) * S2;
-            if (Rbdn_g > 1.0) Rbdn_g = 1.0;
-            if (Rbdn_g < 0.0) Rbdn_g = 0.0;
+            cap<F>(Rbdn_g, 1.0, cn);
+            flr<F>(Rbdn_g, 0.0, cn);
             const double rds = rdif * svfa;
             radGsw = (1.0 - gref) * (c_rddng * rds + Rdbdn_g * Rb + Rbdn_g * Rbeam * si);  // cpp:1131
             double maxg = (1.0 - gref) * (rds + Rbeam * si);
-            if (radGsw > maxg) radGsw = maxg;
+            cap<F>(radGsw, maxg, cn);
             radCsw = (1.0 - c_albd) * rds + (1.0 - albb) * Rbc;                              // cpp:1136
             Rbdown = (trb + (1.0 - trb) * S2a) * Rbeam;
             Rddown = c_rddnz * rds + Rdbdn_z * Rb;
@@ -700,37 +894,35 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const Globals& g
     o.Rdup = Rdup;
     // ---- section E operands: long wave, wind, G = 0 soil surface temperature
     double c_tsv = C(CF_TSV), c_omtrdif = C(CF_OMTRDIF), ws = C.wsa((idx >> 5) & 7), c_ufc = C(CF_UFC),
-           c_uzfac = C(CF_UZFAC), c_ghafac = C(CF_GHAFAC), c_abspsie = C(CF_ABSPSIE), c_invsmax = C(CF_INVSMAX),
-           c_soilb = C(CF_SOILB);
+           c_uzfac = C(CF_UZFAC), c_ghafac = C(CF_GHAFAC);
     double t_rlw = T(TF_RLW), t_rem = T(TF_REM), u2m = T(TF_U2), t_umu = T(TF_UMU), t_wfac = T(TF_WFAC),
            t_lapk = T(TF_LAPK), t_es = T(TF_ES), t_ea = T(TF_EA), t_ghr = T(TF_GHRRAD), t_de = T(TF_DE),
            tc = T(TF_TC), tdew = T(TF_TDEW);
-    pin(c_tsv, c_omtrdif, ws, c_ufc, c_uzfac, c_ghafac, c_abspsie, c_invsmax, c_soilb, t_rlw, t_rem, u2m, t_umu,
+    pin(c_tsv, c_omtrdif, ws, c_ufc, c_uzfac, c_ghafac, t_rlw, t_rem, u2m, t_umu,
         t_wfac, t_lapk, t_es, t_ea, t_ghr, t_de, tc, tdew);
     // --- long wave absorbed by the ground, cpp:1165-1175 -----------------------------
     const double radGlw = 0.97 * (c_tsv * t_rlw + c_omtrdif * t_rem);
     // --- wind, cpp:1189-1218 ------------------------------------------------------------
     if (isnan(ws)) ws = 1.0;
-    if (ws < 0.05) ws = 0.05;
+    flr<F>(ws, 0.05, cn);
     double uf = u2m * c_ufc * t_umu * ws;
-    if (uf < 0.001) uf = 0.001;
+    flr<F>(uf, 0.001, cn);
     double uz = uf * c_uzfac;
-    if (uz > u2m) uz = u2m;
+    cap<F>(uz, u2m, cn);
     double gHa = uf * c_ghafac;
-    if (gHa < 0.0001) gHa = 0.0001;
+    flr<F>(gHa, 0.0001, cn);
     cy.uf = uf;
     o.uz = uz;
     // --- soil surface temperature with G = 0, cpp:1262-1275 ------------------------------
     const double radabs = radGsw + radGlw;
-    double matric = -c_abspsie * powxy(soilm * c_invsmax, -c_soilb, K);
     double surfwet = fexp(matric * t_wfac, K);
-    if (surfwet > 1.0) surfwet = 1.0;
+    cap<F>(surfwet, 1.0, cn);
     const double m = t_lapk * gHa;
     const double num0 = radabs - t_rem - m * (t_es - t_ea) * surfwet;
     const double den = 29.3 * (gHa + t_ghr) + m * t_de;
     cy.num0 = num0;
     cy.den = den;
-    double Tg0 = pm_temperature(num0, den, dTmx, tc, tdew);
+    double Tg0 = pm_temperature<F>(num0, den, dTmx, tc, tdew, cn);
     o.Tg0 = Tg0;
     o.absRnet = fabs(radabs - lw_emit(Tg0));
 }
@@ -740,25 +932,29 @@ struct Stom {
     double gsmax, rsmx, inv02rsmx, gs2;
 };
 // cpp:442-458 stomcondCpp with the soil-water factor `gs2 = mu*gsmax` passed in.
-__device__ __forceinline__ double stomcond(double Rswabs, const Stom& s, const MathK& K) {
+// Rswabs IS NaN for bare ground (its shade factor is 0/0): the two tests on it stay compare-and-branch; gs and gs2 are finite
+template <bool F>
+__device__ __forceinline__ double stomcond(double Rswabs, const Stom& s, const MathK& K, Canary& cn) {
     if (Rswabs <= 0.0) return 0.0;
     double gs = s.gsmax;          // light-saturated (Rswabs >= Rsmx): 2^0 = 1
     if (Rswabs < s.rsmx) gs = s.gsmax * fexp(-(s.rsmx - Rswabs) * s.inv02rsmx * 0.693147180559945309417, K);
-    if (gs > s.gs2) gs = s.gs2;
+    cap<F>(gs, s.gs2, cn);
     return gs;
 }
 
 // cpp:1316-1331 mincondCpp: gmin = max(0.0463*(|Hf*Rnet|/leafd)^0.2, 0.05).  The two calls of a
 // cell-step share Rnet and leafd, so (|Rnet|/leafd)^0.2 is evaluated once (`a02`) and each call
 // supplies |Hf|^0.2 (`hf02`).
-__device__ __forceinline__ double mincond_a02(double Rnet, double invleafd, const MathK& K) {
+template <bool F>
+__device__ __forceinline__ double mincond_a02(double Rnet, double invleafd, const MathK& K, Canary& cn) {
     double arg = fabs(Rnet) * invleafd;
-    if (arg < 1e-300) arg = 1e-300;      // pow(0, 0.2) = 0 and tiny values end in the 0.05 floor alike
+    flr<F>(arg, 1e-300, cn);             // pow(0, 0.2) = 0 and tiny values end in the 0.05 floor alike
     return powxy(arg, 0.2, K);
 }
-__device__ __forceinline__ double mincond_gmin(double hf02, double a02) {
+template <bool F>
+__device__ __forceinline__ double mincond_gmin(double hf02, double a02, Canary& cn) {
     double gmin = 0.0463 * (hf02 * a02);
-    if (gmin < 0.05) gmin = 0.05;
+    flr<F>(gmin, 0.05, cn);
     return gmin;
 }
 
@@ -770,27 +966,33 @@ struct Pass2Out {
 // PASS 2 (cpp:2264-2305): ground temperature with the scaled ground heat flux,
 // canopy / leaf / air temperature and humidity at reqhgt.
 // ---------------------------------------------------------------------------------
-template <class CL, class TM>
-__device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g, int flags, double dTmx,
+template <bool F, bool SS, class CL, class TM, class SL>
+__device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, const Globals& g, int flags, double dTmx,
                                       const Carry& cy, double dtr, double Rmx, bool above_ground,
-                                      Pass2Out& o, const MathK& K) {
+                                      Pass2Out& o, const MathK& K, Canary& cn) {
     const double soilm = cy.soilm;
     // ---- section A operands: soil conductivity, ground heat flux, ground temperature
-    double rho = C(CF_RHO), c_csa = C(CF_CSA), c_c1 = C(CF_C1), c_c1mc4 = C(CF_C1MC4), c_c3 = C(CF_C3);
     double t_gfac = T(TF_GFAC), tc = T(TF_TC), tdew = T(TF_TDEW), ea = T(TF_EA);
-    pin(rho, c_csa, c_c1, c_c1mc4, c_c3, t_gfac, tc, tdew, ea);
+    pin(t_gfac, tc, tdew, ea);
+    constexpr bool soil_shared = SS;
     // --- soil conductivity / damping depth, cpp:1249-1260 ---------------------------------
-    double cs = c_csa + 4180.0 * soilm;
-    double ph = (rho * (1.0 - soilm) + soilm) * 1000.0;
-    double c2 = 1.06 * rho * soilm;
-    double ksoil = c_c1 + c2 * soilm - c_c1mc4 * fexp(-pow4(c_c3 * soilm), K);
-    double kap = fdiv(ksoil, cs * ph);
-    double DD = fsqrt(kap * (2.0 / kOmdy));
+    double ksoil, DD, rdd;
+    if (soil_shared) {
+        ksoil = S(SD_KSOIL);
+        rdd = S(SD_RDD);
+        DD = S(SD_DD);
+    } else {
+        double rho = C(CF_RHO), c_csa = C(CF_CSA), c_c1 = C(CF_C1), c_c1mc4 = C(CF_C1MC4), c_c3 = C(CF_C3);
+        pin(rho, c_csa, c_c1, c_c1mc4, c_c3);
+        ksoil = soil_ksoil(soilm, rho, c_c1, c_c1mc4, fexp(soil_ksoil_arg(soilm, c_c3), K));
+        soil_damping(soilm, ksoil, rho, c_csa, DD, rdd);
+    }
     // --- ground heat flux and ground temperature, cpp:1277-1296 ------------------------------
-    double G = fdiv(t_gfac * dtr * ksoil, DD);
-    if (G > 0.6 * Rmx) G = 0.6 * Rmx;
-    if (G < -0.6 * Rmx) G = -0.6 * Rmx;
-    const double Tg = pm_temperature(cy.num0 - G, cy.den, dTmx, tc, tdew);
+    double G = (t_gfac * dtr * ksoil) * rdd;
+    if (F) cn.watch(G);                  // sqrt of the soil diffusivity: NaN for a non-positive conductivity
+    cap<F>(G, 0.6 * Rmx, cn);
+    flr<F>(G, -0.6 * Rmx, cn);
+    const double Tg = pm_temperature<F>(cy.num0 - G, cy.den, dTmx, tc, tdew, cn);
     o.Tg = Tg;
     o.DD = DD;
     if (!above_ground) return;
@@ -805,14 +1007,14 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
     // --- TVaboveground, cpp:1411-1472 ----------------------------------------------------------
     const double uf = cy.uf;
     double gHa = uf * c_ghafac;
-    if (gHa < 0.0001) gHa = 0.0001;
+    flr<F>(gHa, 0.0001, cn);
     const double esTg = satvap(Tg, K);
     double eT = esTg - ea;
-    if (eT < 0.001) eT = 0.001;
+    flr<F>(eT, 0.001, cn);
     double plf = 0.8753 - 1.7126 * flog(eT, K);
     double gwet = frcp(1.0 + fexp(-plf, K));
     const double surfwet = (soilm - c_smin) * c_invrge;
-    if (surfwet > gwet) gwet = surfwet;
+    flr<F>(gwet, surfwet, cn);
     // canopy conductance, cpp:1425-1428 + 460-477
     const int idx = (int)t_idx;
     double gS = 9999.99;
@@ -821,20 +1023,21 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
     bool have_gs2 = false;
     auto load_stom = [&]() {
         // theta-only part of stomcondCpp, cpp:451-455 with psiwfromthetaCpp cpp:382-389
-        double c_rat = C(CF_RAT), c_ratc = C(CF_RATC), c_invsmax = C(CF_INVSMAX), c_abspsie = C(CF_ABSPSIE),
-               c_soilb = C(CF_SOILB), c_psiw0 = C(CF_PSIW0), c_kk = C(CF_KK), c_mudeninv = C(CF_MUDENINV);
         st.gsmax = C(CF_GSMAX);
         st.rsmx = C(CF_RSMX);
         st.inv02rsmx = C(CF_INV02RSMX);
-        pin(c_rat, c_ratc, c_invsmax, c_abspsie, c_soilb, c_psiw0, c_kk, c_mudeninv, st.gsmax, st.rsmx,
-            st.inv02rsmx);
-        double thetan = c_rat * soilm + c_ratc;
-        double Se = thetan * c_invsmax;
-        if (Se > 1.0) Se = 1.0;
-        double psiw = -c_abspsie * powxy(Se, -c_soilb, K) * 0.01;
-        if (psiw < c_psiw0) psiw = c_psiw0;
-        double mu = 1.0 - (fexp(-c_kk * psiw, K) - 1.0) * c_mudeninv;
-        st.gs2 = mu * st.gsmax;
+        if (soil_shared) {
+            st.gs2 = S(SD_GS2);
+            pin(st.gsmax, st.rsmx, st.inv02rsmx, st.gs2);
+        } else {
+            double c_rat = C(CF_RAT), c_ratc = C(CF_RATC), c_invsmax = C(CF_INVSMAX), c_abspsie = C(CF_ABSPSIE),
+                   c_soilb = C(CF_SOILB), c_psiw0 = C(CF_PSIW0), c_kk = C(CF_KK), c_mudeninv = C(CF_MUDENINV);
+            pin(c_rat, c_ratc, c_invsmax, c_abspsie, c_soilb, c_psiw0, c_kk, c_mudeninv, st.gsmax, st.rsmx,
+                st.inv02rsmx);
+            const double Se = stom_se<F>(soilm, c_rat, c_ratc, c_invsmax, cn);
+            const double psiw = stom_psiw<F>(powxy(Se, -c_soilb, K), c_abspsie, c_psiw0, cn);
+            st.gs2 = stom_gs2(fexp(-c_kk * psiw, K), c_mudeninv, st.gsmax);
+        }
         have_gs2 = true;
     };
     if (!(flags & FL_OMPNAN)) {
@@ -846,7 +1049,7 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
             kb = fsqrt(C(CF_XX) + T(TF_TAN2B)) * C(CF_KDENINV);
             if (flags & (FL_XONE | FL_XINF | FL_XZERO))
                 kb = (flags & FL_XONE) ? T(TF_INV2COSB) : (flags & FL_XINF) ? 1.0 : T(TF_TANB);
-            if (kb > 6000.0) kb = 6000.0;
+            cap<F>(kb, 6000.0, cn);
             P_sun = fdiv(1.0 - fexp(-kb * c_pai, K), kb);
         }
         double P_shade = c_pai - P_sun;
@@ -855,8 +1058,8 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
         double gs_sun = 0.0, gs_shade = 0.0;
         if (!(Rsun_abs <= 0.0) || !(Rshade_abs <= 0.0)) {
             load_stom();
-            gs_sun = stomcond(Rsun_abs, st, K);
-            gs_shade = stomcond(Rshade_abs, st, K);
+            gs_sun = stomcond<F>(Rsun_abs, st, K, cn);
+            gs_shade = stomcond<F>(Rshade_abs, st, K, cn);
         }
         gS = gs_sun * P_sun + gs_shade * P_shade;
     }
@@ -865,8 +1068,8 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
     // canopy temperature, cpp:1430-1432 (Penman-Monteith with the linear surface wetness)
     const double Rabs = cy.radCsw + 0.97 * c_svfa * rlw;
     const double mC = lapk * gV;
-    const double Tcan = pm_temperature(Rabs - rem - mC * (es - ea) * surfwet - G,
-                                       29.3 * (gHa + ghr) + mC * De, dTmx, tc, tdew);
+    const double Tcan = pm_temperature<F>(Rabs - rem - mC * (es - ea) * surfwet - G,
+                                          29.3 * (gHa + ghr) + mC * De, dTmx, tc, tdew, cn);
     const double esTcan = satvap(Tcan, K);
     double ez;
     if (!(flags & FL_BELOW)) {
@@ -885,7 +1088,7 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
         pin(c_uzfac, emg, ema, invleafd, c_hom, c_homp, t_u2);
         // ---- leaf temperature, cpp:1333-1364 -------------------------------------------------
         double uz = uf * c_uzfac;
-        if (uz > t_u2) uz = t_u2;
+        cap<F>(uz, t_u2, cn);
         const double lwcan = lw_emit(Tcan), lwgro = lw_emit(Tg);
         const double lwup = emg * lwgro + (1 - emg) * lwcan;
         const double lwdn = ema * rlw + (1 - ema) * lwcan;
@@ -896,9 +1099,25 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
         const double leafabs = (lit ? c_hom * cy.X : 0.0) + lwabs;   // radLsw + lwabs
         double gh = 0.135 * fsqrt(uz * invleafd) * 1.4;
         const double RnetL = leafabs - lwcan;                // cpp:1319 with tc = Tcan
-        const double a02 = mincond_a02(RnetL, invleafd, K);
-        double gmin = mincond_gmin(g.hf0p, a02);             // mincondCpp(leafabs, 999.99, Tcan, leafd)
-        if (gh < gmin) gh = gmin;
+        // mincondCpp's floor is gmin = max(0.0463 * (|Hf| * |Rnet| / leafd)^0.2, 0.05) with |Hf| = 1/(1 + exp(2 - Hlf)) < 1,
+        // so gmin <= max(0.0463 * (|Rnet|/leafd)^0.2, 0.05) whatever the stomatal resistance.  When gh clears THAT bound —
+        // tested without a pow as (gh/0.0463)^5 >= |Rnet|/leafd, with a margin six orders above any rounding — neither of
+        // the two floors can bind, and the pow() of the bound and the three exp() / two log() of |Hf|^0.2 are not
+        // evaluated.  Wave-uniform (every lane in this branch must clear it); a NaN operand fails the test.
+        bool floors_idle = false;
+#if MCF_SKIP_MINCOND
+        {
+            const double tq = gh * (1.0 / 0.0463), tq2 = tq * tq;
+            const bool clear = gh >= 0.0500001 && tq2 * tq2 * tq >= (fabs(RnetL) * invleafd) * 1.000001;
+            floors_idle = __builtin_amdgcn_ballot_w64(!clear) == 0;
+        }
+#endif
+        double a02 = 0.0;
+        if (!floors_idle) {
+            a02 = mincond_a02<F>(RnetL, invleafd, K, cn);
+            double gmin = mincond_gmin<F>(g.hf0p, a02, cn);  // mincondCpp(leafabs, 999.99, Tcan, leafd)
+            flr<F>(gh, gmin, cn);
+        }
         double gVl = gh;
         if (flags & FL_STOM) {
             gVl = 0.0;
@@ -906,22 +1125,24 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
             double gs = 0.0;
             if (PARabs > 0.0) {
                 if (!have_gs2) load_stom();
-                gs = stomcond(PARabs, st, K);
+                gs = stomcond<F>(PARabs, st, K, cn);
             }
-            // rs = min(1/gs, 500) (500 when gs <= 0), Hlf = 1.09767*rs^0.2672778,
-            // Hf = -1/(1 + exp(2 - Hlf)), cpp:1321-1325; |Hf|^0.2 = exp(-0.2*log(1 + exp(2 - Hlf)))
-            double hf02 = g.hf500p;                           // rs = 500: a constant (night, closed stomata)
-            if (gs > 0.002) {
-                double Hlf = 1.09767 * fexp(-0.2672778 * flog(gs, K), K);
-                hf02 = fexp(-0.2 * flog(1.0 + fexp(2.0 - Hlf, K), K), K);
+            if (!floors_idle) {
+                // rs = min(1/gs, 500) (500 when gs <= 0), Hlf = 1.09767*rs^0.2672778,
+                // Hf = -1/(1 + exp(2 - Hlf)), cpp:1321-1325; |Hf|^0.2 = exp(-0.2*log(1 + exp(2 - Hlf)))
+                double hf02 = g.hf500p;                       // rs = 500: a constant (night, closed stomata)
+                if (gs > 0.002) {
+                    double Hlf = 1.09767 * fexp(-0.2672778 * flog(gs, K), K);
+                    hf02 = fexp(-0.2 * flog(1.0 + fexp(2.0 - Hlf, K), K), K);
+                }
+                double gmin = mincond_gmin<F>(hf02, a02, cn); // mincondCpp(leafabs, gs, Tcan, leafd)
+                flr<F>(gh, gmin, cn);
             }
-            gmin = mincond_gmin(hf02, a02);                   // mincondCpp(leafabs, gs, Tcan, leafd)
-            if (gh < gmin) gh = gmin;
             if (gs > 0.0) gVl = fdiv(gh * gs, gh + gs);
         }
         const double mL = lapk * gVl;
-        const double tleaf = pm_temperature(leafabs - rem - mL * (es - ea) * surfwet - 0.0,
-                                            29.3 * (gh + ghr) + mL * De, dTmx, tc, tdew);
+        const double tleaf = pm_temperature<F>(leafabs - rem - mL * (es - ea) * surfwet - 0.0,
+                                               29.3 * (gh + ghr) + mL * De, dTmx, tc, tdew, cn);
         const double esTl = satvap(tleaf, K);
         const double HL = 29.3 * gh * (tleaf - tc);                       // cpp:1242
         const double LL = mL * (esTl - ea) * surfwet;                     // cpp:1243
@@ -944,9 +1165,9 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
         const double z = g.reqhgt2;
         const double muR = frcp(c_a2h * uf);                 // uf/(a2*h) / uf^2
         double Rc = c_inthh * muR;
-        if (Rc < 0.001) Rc = 0.001;
+        flr<F>(Rc, 0.001, cn);
         double Rz = c_inthz * muR;
-        if (Rz < 0.001) Rz = 0.001;
+        flr<F>(Rz, 0.001, cn);
         const double Kc = fdiv(hgt, Rc);
         const double rKc = Rc * c_invhgt;                    // 1/Kc
         const double Kg = frcp(Rz * z);
@@ -977,19 +1198,20 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const Globals& g
         }
     }
     double rh = fdiv(ez, satvap(o.Tz, K)) * 100.0;
-    if (rh > 100.0) rh = 100.0;
+    if (F) cn.watch(rh);                 // NaN with Tz or ez: the Lagrangian far field divides by Rc - Rz, which both floors can make 0
+    cap<F>(rh, 100.0, cn);
     o.rh = rh;
-    // clamp Tz to the source temperatures +-2, cpp:1467-1470
+    // clamp Tz to the source temperatures +-2, cpp:1467-1470 (all four are Penman-Monteith results: finite)
     double tmx = o.tleaf;
-    if (tmx < tc) tmx = tc;
-    if (tmx < Tg) tmx = Tg;
-    if (tmx < Tcan) tmx = Tcan;
+    flr<F>(tmx, tc, cn);
+    flr<F>(tmx, Tg, cn);
+    flr<F>(tmx, Tcan, cn);
     double tmn = o.tleaf;
-    if (tc < tmn) tmn = tc;
-    if (Tg < tmn) tmn = Tg;
-    if (Tcan < tmn) tmn = Tcan;
-    if (o.Tz > tmx + 2.0) o.Tz = tmx + 2.0;
-    if (o.Tz < tmn - 2.0) o.Tz = tmn - 2.0;
+    cap<F>(tmn, tc, cn);
+    cap<F>(tmn, Tg, cn);
+    cap<F>(tmn, Tcan, cn);
+    cap<F>(o.Tz, tmx + 2.0, cn);
+    flr<F>(o.Tz, tmn - 2.0, cn);
 }
 
 }  // namespace mcf

@@ -22,6 +22,7 @@ struct CellSetupArgs {
     const double* hgt0;  // layer-0 height: the NA test of the cell (cpp:2182 / 2759)
     // soilc
     const double *Smin, *Smax, *gref, *soilb, *Psie, *Vq, *Vm, *Mc, *rho, *slope, *aspect, *twi, *svfa;
+    const double *hor, *wsa;    // [24][N], [8][N]: only their finiteness is looked at here (FL_REGULAR)
     const double *lats, *lons;  // array forcing, else null
     const double *crowpos, *ccolpos;  // coarse array forcing: [rows], [cols]; else null
     const double *elevd, *pkfac;      // coarse array forcing with altitude correction: [N]; else null
@@ -78,8 +79,16 @@ struct SolveArgs {
     double* tgser;          // [N][tsteps]
     double* ddsum;          // [N]
     int32_t day0, ndays;
+    int32_t total_days;  // days of the whole series (the time table's extent)
     int32_t need_pass2;  // 0: no requested output comes from pass 2 (Tz, tleaf, relhum, Rlwdown, Rlwup)
     int32_t need_tv;     // 0: no requested output comes from TVaboveground (cpp:2287-2303)
+    // tiles of this launch: tile_list[ntiles_launch] (null: tiles 0 .. ntiles_launch-1; ntiles_launch <= 0: all)
+    const int32_t* tile_list;
+    int64_t ntiles_launch;
+    // fast-clamp launches: tiles in which a canary tripped, redone by k_solve_fix for the launch's days
+    int32_t* fix_count;
+    int32_t* fix_list;      // [fix_cap]
+    int32_t fix_cap;
     Globals g;
 };
 
@@ -135,11 +144,19 @@ void launch_cell_setup(const CellSetupArgs& a, hipStream_t s);
 void launch_time_setup(const TimeSetupArgs& a, hipStream_t s);
 void launch_date_setup(const DateSetupArgs& a, hipStream_t s);
 void launch_mxtc(const double* tc, int64_t N, int nsteps, double* mx, hipStream_t s);
-void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, hipStream_t s);
+// fast: vector forcing, reqhgt >= 0 only — the min / max clamp variant followed by the fix-up kernel (needs fix_count /
+// fix_list; the caller zeroes *fix_count on the stream first); the tiles and days handed over must be REGULAR
+// soil_daily: every day of the launch carries kSoilDaily (vector forcing): the per cell-day soil state is computed once per
+// tile and day and shared through LDS
+void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, bool fast, bool soil_daily, hipStream_t s);
+// out[t] = 1 if every valid cell of tile t (cpb consecutive cells) is FL_REGULAR in all layers
+void launch_tile_regular(const double* cellc, int64_t N, int layers, int cpb, uint8_t* out, hipStream_t s);
 void launch_belowground(const BelowArgs& a, hipStream_t s);
 void launch_selftest_math(int kind, const double* x, const double* y, double* out, int64_t n, hipStream_t s);
 
 int cell_field_count();
+int soil_daily_bit();        // kSoilDaily, likewise
+int step_irregular_bit();   // kStepIrregular of the packed TF_IDX value (last time field)
 int time_field_count();
 double hf_pow02(double rs);
 

@@ -51,6 +51,12 @@
 #ifndef MCF_DAYPRIO
 #define MCF_DAYPRIO 0
 #endif
+#ifndef MCF_EXPERIMENT_NOPUSH
+#define MCF_EXPERIMENT_NOPUSH 0
+#endif
+#ifndef MCF_FAST_CLAMPS
+#define MCF_FAST_CLAMPS 1   // vector forcing: waves of REGULAR lanes run the min / max form of the clamps (mcf_device.hpp `cap`)
+#endif
 
 namespace mcf {
 
@@ -143,12 +149,39 @@ __device__ inline double rh_integral(double h, double z) {
              (32.0 * s) / (c1 * ((25.0 * (s * s)) / (c1 * c1) + 5.0)))) / kPi;
 }
 
+// Which lanes read a cell constant (pass1 / pass2 in mcf_device.hpp): 0 every valid cell, 1 only cells with a canopy
+// (FL_PAI), 2 only cells whose sensor is below the canopy top (FL_BELOW), 3 only cells at or above it.  Constants a
+// cell's path never reads may be 0/0 by construction (the canopy block of bare ground, the above-canopy profile weight
+// of a sensor below the displacement height) and do not count against FL_REGULAR.
+__device__ constexpr int field_reader_class(int f) {
+    switch (f) {
+    case CF_XX: case CF_KDENINV: return 0;          // also read by pass 2's canopy conductance for every cell
+    case CF_OM: case CF_JDEL: case CF_GMA: case CF_GMA2: case CF_AGM: case CF_AGM2: case CF_U1: case CF_U2: case CF_H:
+    case CF_S1: case CF_INVS1: case CF_INVD1: case CF_INVD2: case CF_GMAGREF: case CF_LOGCLUMP: case CF_LOGGI: case CF_TRDN:
+    case CF_TRDU: case CF_AMX: case CF_EHP: case CF_PAIAA: case CF_EHPA: case CF_EMHPA: case CF_ALBD: case CF_RDDNG:
+    case CF_RDDNZ: case CF_RDUPZ: case CF_PAIT: case CF_SHADEFAC:
+        return 1;
+    case CF_EMG: case CF_EMA: case CF_INVLEAFD: case CF_HOM: case CF_HOMP: case CF_OML2: case CF_HGT: case CF_A2H:
+    case CF_INTHH: case CF_INTHZ: case CF_INVHGT: case CF_INVHMZ: case CF_OMEMPAI: case CF_NEARFAC: case CF_LEAFDEN:
+        return 2;
+    case CF_OML1:
+        return 3;
+    default:
+        return 0;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_cell_setup(CellSetupArgs a) {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.N) return;
     const int64_t N = a.N;
     double* out = a.cellc;
-    auto put = [&](int f, double v) { out[(int64_t)f * N + c] = v; };
+    // FL_REGULAR (mcf_device.hpp): every constant the cell's path reads is finite (field_reader_class above)
+    bool fin[4] = {true, true, true, true};     // by field_reader_class
+    auto put = [&](int f, double v) {
+        out[(int64_t)f * N + c] = v;
+        if (!isfinite(v)) fin[field_reader_class(f)] = false;
+    };
     const double hgt = a.hgt[c], pai = a.pai[c], x = a.x[c], lref = a.leafr[c], ltra = a.leaft[c],
                  clump = a.clump[c], gref = a.gref[c], paia = a.paia[c];
     int flags = 0;
@@ -337,6 +370,18 @@ __global__ __launch_bounds__(256) void k_cell_setup(CellSetupArgs a) {
         put(CF_LEAFDEN, a.leafden[c]);
         put(CF_OMEMPAI, 1.0 - exp(-pai));
     }
+    {
+        bool dirs_ok = true;                        // horizons finite; a NaN wind-shelter value is the reference's "1" (cpp:1193)
+        for (int d = 0; d < 24; ++d) dirs_ok = dirs_ok && isfinite(a.hor[(int64_t)d * N + c]);
+        for (int d = 0; d < 8; ++d) dirs_ok = dirs_ok && !isinf(a.wsa[(int64_t)d * N + c]);
+        const bool bare = pai == 0.0 && hgt == 0.0;
+        const bool veg = pai > 0.0 && hgt > 0.0 && clump >= 0.0 && clump < 1.0 && a.leafd[c] > 0.0 && isfinite(x) && x > 0.0;
+        // soil moisture stays positive (Smin >= 0, Smax > Smin), which keeps the matric potential's log and pow real
+        const bool soil = Smin >= 0.0 && Smax > Smin && a.gsmax[c] >= 0.0 && a.g.zref > 0.0;
+        const bool below = (flags & FL_BELOW) != 0;
+        const bool fields = fin[0] && (veg ? fin[1] : true) && (below ? fin[2] : fin[3]);
+        if (dirs_ok && soil && (bare || veg) && fields) flags |= FL_REGULAR;
+    }
     put(CF_FLAGS, (double)flags);
 }
 
@@ -351,6 +396,12 @@ __global__ __launch_bounds__(256) void k_time_setup(TimeSetupArgs a) {
     SolPos sp = sol_site(sd, a.hour[k], sin(a.lat * kPi / 180.0), cos(a.lat * kPi / 180.0), a.lon);
     derive_time(t, sp, dir_index(a.winddir[k], 45.0, 8));
     int dy = k / 24, hr = k % 24;
+    {   // kSoilDaily: the day's 24 point soil moistures are one value (bitwise; a NaN never equals itself)
+        const double* sm = a.raw[TF_SOILMP] + dy * 24;
+        bool daily = true;
+        for (int h = 1; h < 24; ++h) daily = daily && sm[h] == sm[0];
+        if (daily) t.v[TF_IDX] = (double)((int)t.v[TF_IDX] | kSoilDaily);
+    }
     double* dst = a.tt + ((int64_t)dy * TF_COUNT) * 24 + hr;
     for (int f = 0; f < TF_COUNT; ++f) dst[f * 24] = t.v[f];
 }
@@ -419,10 +470,12 @@ __global__ __launch_bounds__(256) void k_mxtc_coarse(const double* __restrict__ 
 // threads per workgroup: CPB*24 lanes rounded up to whole waves on all four SIMDs
 constexpr int solve_threads(int cpb) { return ((cpb * 24 + 255) / 256) * 256; }
 
-template <int CPB, int AF, bool BG>   // AF: 0 vector forcing, 1 array forcing, 2 coarse array forcing
-// array forcing keeps ~17 more doubles live per lane (forcing values instead of an LDS table):
-// it is built for 3 waves/SIMD (168 VGPRs, no scratch) and run with 32-cell workgroups
-__global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_PER_EU) void k_solve(SolveArgs a) {
+// One tile (CPB consecutive cells) over days [day0, day0 + ndays) of the launch described by `a`.
+//   F   fast clamps (mcf_device.hpp `cap`): only for tiles / days the host has classified REGULAR; a wave whose canary
+//       trips appends (tile, day) to a.fix_list and k_solve_fix redoes that tile-day with F = false afterwards
+//   SSREQ  per cell-day soil state shared through LDS (mcf_device.hpp SoilDay): only for launches whose days are all kSoilDaily
+template <int CPB, int AF, bool BG, bool F, bool SSREQ>   // AF: 0 vector forcing, 1 array forcing, 2 coarse array forcing
+__device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t tile, const int day0, const int ndays, const int rot) {
     constexpr int NT = solve_threads(CPB);
     __shared__ double s_cell[CF_COUNT * CPB];
     __shared__ double s_dirs[kCellDirs * CPB];
@@ -431,6 +484,9 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
     constexpr bool PRE = (CPB == 21) && MCF_LANES21 && MCF_WAVE_PREREDUCE;
     __shared__ double s_red[2][PRE ? 3 : 2][(PRE ? 8 : 24) * CPB];
     __shared__ double s_dd[BG ? 24 * CPB : 1];
+    // per cell-day soil state (mcf_device.hpp SoilDay): a ring of three days, filled two days ahead by one wave
+    constexpr bool SS = SSREQ && (AF == 0) && (2 * CPB <= 64);
+    __shared__ double s_soil[SS ? 3 * SD_COUNT * CPB : 1];
 
     const int tid = threadIdx.x;
     int cl = tid % CPB;
@@ -477,26 +533,13 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
         // equinox, but two day waves (hours 6-8 and 18-20) on one SIMD in summer and two night waves in winter.
         // Two workgroups are resident per CU; shifting every other one by six hours puts the complementary
         // pattern on the same SIMDs.  Workgroups q and q+32 of an XCD's dispatch sequence tend to share a CU.
-        const int rot = (int)((blockIdx.x >> 8) & 1);
         hr = hr + 6 * rot;
         hr -= hr >= 24 ? 24 : 0;
 #endif
     }
 #endif
     const int64_t N = a.N;
-#if MCF_XCD_REMAP
-    // Workgroups are dealt round-robin to the 8 XCDs (b and b+8 share one, each XCD has its own
-    // L2).  A tile's 168-B row segments share their boundary cache lines with the neighbouring
-    // tiles, so consecutive tiles are given to the SAME XCD: its L2 then merges the two partial
-    // line writes instead of two L2s each writing a partial line back.  Speed only.
-    const int64_t ntiles = (N + CPB - 1) / CPB;
-    const int64_t per_xcd = (ntiles + 7) / 8;
-    const int64_t tile = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (tile >= ntiles || (int64_t)(blockIdx.x >> 3) >= per_xcd) return;
     const int64_t c0 = tile * CPB;
-#else
-    const int64_t c0 = (int64_t)blockIdx.x * CPB;
-#endif
     const int64_t c = c0 + cl;
     const bool in_grid = lane_on && c < N;   // the other lanes only help staging and keep the barriers
 
@@ -509,7 +552,7 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
         s_dirs[q] = v;
     }
     if (!AF) {
-        const double* src = a.tt + (int64_t)a.day0 * TF_COUNT * 24;
+        const double* src = a.tt + (int64_t)day0 * TF_COUNT * 24;
         for (int q = tid; q < TF_COUNT * 24; q += NT) s_time[q] = src[q];
     }
 
@@ -529,8 +572,15 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
 #endif
     const double NA = na_real();
 
-    for (int dl = 0; dl < a.ndays; ++dl) {
-        const int dabs = a.day0 + dl;
+    Canary cn;      // F: NaN as soon as one watched clamp of this lane has met a NaN, on any day of the launch
+    // soil state of day `d` into its ring slot, by the calling wave (all 64 lanes call)
+    auto produce_soil = [&](int d) {
+        if (SS)
+            soil_day_produce<SS ? CPB : 1, F>(s_cell, a.tt[((int64_t)d * TF_COUNT + TF_SOILMP) * 24], s_soil + (d % 3) * (SD_COUNT * CPB),
+                                              tid & 63, MK);
+    };
+    for (int dl = 0; dl < ndays; ++dl) {
+        const int dabs = day0 + dl;
         // vegetation layer of this day (runmicro3Cpp/4Cpp `dfsel`, cpp:2760-2768); the tile's cell
         // constants are (re)staged whenever it changes — a workgroup-uniform, rare event
         const int layer = a.daylayer ? a.daylayer[dabs] : 0;
@@ -548,8 +598,16 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
             cur_layer = layer;
             flags = (in_grid && layer >= 0) ? (int)s_cell[CF_FLAGS * CPB + cl] : 0;
             valid = (flags & FL_VALID) != 0;
+            if (SS && layer >= 0) {
+                // (re)start the soil ring with this layer's constants: this day and the next, one wave each; from here
+                // on the wave that is first behind a day's barrier fills the slot of the day after next
+                const int wv = tid >> 6;
+                if (wv == 0) produce_soil(dabs);
+                if (wv == 1 && dabs + 1 < day0 + ndays) produce_soil(dabs + 1);
+                __syncthreads();
+            }
         }
-        const int64_t kl = (int64_t)dl * 24 + hr;            // step within the slot
+        const int64_t kl = (int64_t)(dabs - a.day0) * 24 + hr;   // step within the launch's part of the slot
         const int64_t oidx = c + N * (a.slot_step0 + kl);
 #if MCF_OPAQUE_OUTSEL
         // Left alone, hipcc hoists a 64-bit "variable v is requested" mask and a 64-bit slab pointer per
@@ -579,7 +637,7 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
 #if MCF_EXPERIMENT_NOPREFETCH
         const bool stage = false;
 #else
-        const bool stage = !AF && (dl + 1 < a.ndays);
+        const bool stage = !AF && (dl + 1 < ndays);
 #endif
         if (stage) {
             const double* src = a.tt + (int64_t)(dabs + 1) * TF_COUNT * 24;
@@ -621,6 +679,7 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
         }
         TimeLds TL{s_time + (AF ? 0 : (dl % 3) * (TF_COUNT * 24)) + hr};
         TimeReg TR{&tv};
+        SoilLds<CPB> SL{s_soil + (SS ? (dabs % 3) * (SD_COUNT * CPB) + cl : 0)};
 
 #if MCF_DAYPRIO
         // daytime waves carry the short-wave block and are the critical path to the barrier
@@ -631,8 +690,8 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
         double* red_t = &s_red[dl & 1][0][PRE ? 0 : hr * CPB + cl];
         double* red_r = &s_red[dl & 1][1][PRE ? 0 : hr * CPB + cl];
         if (valid) {
-            if (AF) pass1(C, TR, g, flags, dTmx, cy, p1, MK);
-            else pass1(C, TL, g, flags, dTmx, cy, p1, MK);
+            if (AF) pass1<F, false>(C, TR, SL, g, flags, dTmx, cy, p1, MK, cn);
+            else pass1<F, SS>(C, TL, SL, g, flags, dTmx, cy, p1, MK, cn);
             if (!PRE) {
                 *red_t = p1.Tg0;
                 *red_r = p1.absRnet;
@@ -689,6 +748,13 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
 #if !MCF_EXPERIMENT_NOBARRIER
         __syncthreads();
 #endif
+        if (SS) {
+            // Every wave is past day dabs-1 now, so the ring slot of day dabs+2 (= that of dabs-1) is free; whoever fills
+            // it reaches the NEXT barrier before any wave starts day dabs+2.  The waves take turns.  A change of layer
+            // on the way restarts the ring above, so a slot filled with the wrong layer's constants is never read.
+            const int d2 = dabs + 2;
+            if (d2 < day0 + ndays && (tid >> 6) == (dabs & 7) % (NT / 64)) produce_soil(d2);
+        }
         if (valid && a.need_pass2) {
             // day reductions in hour order with the reference's comparisons, cpp:2196-2198, 2256-2263
             double Rmx = -999.9, tmx = -999.0, tmn = 999.0;
@@ -735,8 +801,8 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
                                          a.af_base[(int64_t)TF_KP * a.af_stride + fidx]);
                 }
             }
-            if (AF) pass2(C, TR, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2, MK);
-            else pass2(C, TL, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2, MK);
+            if (AF) pass2<F, false>(C, TR, SL, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2, MK, cn);
+            else pass2<F, SS>(C, TL, SL, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2, MK, cn);
             if (BG) {
                 a.tgser[c + N * ((int64_t)dabs * 24 + hr)] = p2.Tg;
                 s_dd[hr * CPB + cl] = p2.DD;
@@ -772,6 +838,78 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
             __syncthreads();
         }
     }
+    if (F && !MCF_EXPERIMENT_NOPUSH) {
+        // a watched clamp met a NaN somewhere in this wave's share of the tile: k_solve_fix redoes the tile's days of this launch
+        const uint64_t bad = __builtin_amdgcn_ballot_w64(cn.tripped());
+        if (bad != 0 && (tid & 63) == 0) {
+            const int i = atomicAdd(a.fix_count, 1);
+            if (i < a.fix_cap) a.fix_list[i] = (int32_t)tile;
+        }
+    }
+}
+
+// blockIdx -> position in the launch's tile sequence.  Workgroups are dealt round-robin to the 8 XCDs (b and b+8
+// share one, each XCD has its own L2).  A tile's 168-B row segments share their boundary cache lines with the
+// neighbouring tiles, so consecutive tiles are given to the SAME XCD: its L2 then merges the two partial line
+// writes instead of two L2s each writing a partial line back.  Speed only.
+__device__ __forceinline__ int64_t tile_position(int64_t ntiles) {
+#if MCF_XCD_REMAP
+    const int64_t per_xcd = (ntiles + 7) / 8;
+    const int64_t pos = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (pos >= ntiles || (int64_t)(blockIdx.x >> 3) >= per_xcd) return -1;
+    return pos;
+#else
+    return blockIdx.x < ntiles ? (int64_t)blockIdx.x : -1;
+#endif
+}
+
+// array forcing keeps ~17 more doubles live per lane (forcing values instead of an LDS table):
+// it is built for 3 waves/SIMD (168 VGPRs, no scratch) and run with 32-cell workgroups
+template <int CPB, int AF, bool BG, bool F, bool SSREQ>
+__global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_PER_EU) void k_solve(SolveArgs a) {
+    const int64_t pos = tile_position(a.ntiles_launch);
+    if (pos < 0) return;
+    const int64_t tile = a.tile_list ? (int64_t)a.tile_list[pos] : pos;
+    // every other resident workgroup shifts its wave-to-hour assignment by six hours (MCF_HOUR_ROTATE)
+    solve_tile<CPB, AF, BG, F, SSREQ>(a, tile, a.day0, a.ndays, (int)((blockIdx.x >> 8) & 1));
+}
+
+// Redoes, with the reference's compare-and-select clamps, the tiles in which a fast wave's canary tripped.  Launched
+// behind every fast launch with a fixed small grid; with an empty list (the normal case) every workgroup leaves at once.
+// An overflowing list means "everything": all tiles, all days of the launch.
+template <int CPB>
+__global__ __launch_bounds__(solve_threads(CPB), MCF_WAVES_PER_EU) void k_solve_fix(SolveArgs a) {
+    const int n = *a.fix_count;
+    if (n <= 0) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.fix_count + 1, n);     // running total, for mcf_plan_dispatch_stats
+    if (n > a.fix_cap) {
+        const int64_t ntiles = (a.N + CPB - 1) / CPB;
+        for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+            __syncthreads();
+            solve_tile<CPB, 0, false, false, false>(a, t, a.day0, a.ndays, 0);
+        }
+        return;
+    }
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+        __syncthreads();
+        solve_tile<CPB, 0, false, false, false>(a, (int64_t)a.fix_list[i], a.day0, a.ndays, 0);
+    }
+}
+
+// per tile of `cpb` cells: 1 if every valid cell is FL_REGULAR in every vegetation layer
+__global__ void k_tile_regular(const double* __restrict__ cellc, int64_t N, int layers, int cpb, int64_t ntiles,
+                               uint8_t* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    bool ok = true;
+    for (int l = 0; l < layers; ++l) {
+        const double* fl = cellc + ((int64_t)l * CF_COUNT + CF_FLAGS) * N;
+        for (int64_t c = t * cpb; c < (t + 1) * cpb && c < N; ++c) {
+            const int f = (int)fl[c];
+            if ((f & FL_VALID) && !(f & FL_REGULAR)) ok = false;
+        }
+    }
+    out[t] = ok ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------
@@ -1117,36 +1255,52 @@ void launch_belowground(const BelowArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_belowground, dim3((unsigned)((a.N + 63) / 64)), dim3(64), 0, s, a);
 }
 
-template <int CPB>
-static void launch_solve_cpb(const SolveArgs& a, bool af, bool bg, hipStream_t s) {
+static dim3 solve_grid(int64_t ntiles) {
 #if MCF_XCD_REMAP
-    const int64_t ntiles = (a.N + CPB - 1) / CPB;
-    dim3 grid((unsigned)(8 * ((ntiles + 7) / 8))), block(solve_threads(CPB));
+    return dim3((unsigned)(8 * ((ntiles + 7) / 8)));
 #else
-    dim3 grid((unsigned)((a.N + CPB - 1) / CPB)), block(solve_threads(CPB));
+    return dim3((unsigned)ntiles);
 #endif
+}
+template <int CPB>
+static void launch_solve_cpb(SolveArgs a, bool af, bool bg, bool fast, bool ss, hipStream_t s) {
+    if (a.ntiles_launch <= 0) {                      // no list: every tile of the raster
+        a.ntiles_launch = (a.N + CPB - 1) / CPB;
+        a.tile_list = nullptr;
+    }
+    const dim3 grid = solve_grid(a.ntiles_launch), block(solve_threads(CPB));
+    ss = ss && MCF_SOIL_SHARE && 2 * CPB <= 64;
     if (af) {
-        if (bg) hipLaunchKernelGGL((k_solve<CPB, 1, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_solve<CPB, 1, false>), grid, block, 0, s, a);
+        if (bg) hipLaunchKernelGGL((k_solve<CPB, 1, true, false, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_solve<CPB, 1, false, false, false>), grid, block, 0, s, a);
+    } else if (bg) {
+        hipLaunchKernelGGL((k_solve<CPB, 0, true, false, false>), grid, block, 0, s, a);
+    } else if (fast && MCF_FAST_CLAMPS) {
+        if (ss) hipLaunchKernelGGL((k_solve<CPB, 0, false, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_solve<CPB, 0, false, true, false>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((k_solve_fix<CPB>), dim3(512), block, 0, s, a);
     } else {
-        if (bg) hipLaunchKernelGGL((k_solve<CPB, 0, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_solve<CPB, 0, false>), grid, block, 0, s, a);
+        if (ss) hipLaunchKernelGGL((k_solve<CPB, 0, false, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_solve<CPB, 0, false, false, false>), grid, block, 0, s, a);
     }
 }
+void launch_tile_regular(const double* cellc, int64_t N, int layers, int cpb, uint8_t* out, hipStream_t s) {
+    const int64_t ntiles = (N + cpb - 1) / cpb;
+    if (ntiles <= 0) return;
+    hipLaunchKernelGGL(k_tile_regular, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, s, cellc, N, layers, cpb, ntiles, out);
+}
 // coarse array forcing is built for the array-forcing geometry (32 cells per workgroup) only
-static void launch_solve_coarse(const SolveArgs& a, bool bg, hipStream_t s) {
+static void launch_solve_coarse(SolveArgs a, bool bg, hipStream_t s) {
     constexpr int CPB = 32;
-#if MCF_XCD_REMAP
-    const int64_t ntiles = (a.N + CPB - 1) / CPB;
-    dim3 grid((unsigned)(8 * ((ntiles + 7) / 8))), block(solve_threads(CPB));
-#else
-    dim3 grid((unsigned)((a.N + CPB - 1) / CPB)), block(solve_threads(CPB));
-#endif
-    if (bg) hipLaunchKernelGGL((k_solve<CPB, 2, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_solve<CPB, 2, false>), grid, block, 0, s, a);
+    a.ntiles_launch = (a.N + CPB - 1) / CPB;
+    a.tile_list = nullptr;
+    const dim3 grid = solve_grid(a.ntiles_launch), block(solve_threads(CPB));
+    if (bg) hipLaunchKernelGGL((k_solve<CPB, 2, true, false, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_solve<CPB, 2, false, false, false>), grid, block, 0, s, a);
 }
 int twi_scratch_doubles() { return 2 + 2 * kTwiParts; }
 int cell_field_count() { return CF_COUNT; }
+int step_irregular_bit() { return kStepIrregular; }
 int time_field_count() { return TF_COUNT; }
 // mincondCpp (cpp:1321-1328): for a fixed stomatal resistance rs, Hlf and Hf are constants and
 // gmin = 0.0463*|Hf|^0.2 * (|Rnet|/leafd)^0.2; returns |Hf|^0.2
@@ -1156,13 +1310,14 @@ double hf_pow02(double rs) {
     return pow(fabs(Hf), 0.2);
 }
 
-void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, hipStream_t s) {
+void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, bool fast, bool soil_daily, hipStream_t s) {
     if (a.N <= 0 || a.ndays <= 0) return;
     if (a.crows > 0) { launch_solve_coarse(a, bg, s); return; }
-    if (cells_per_block == 32) launch_solve_cpb<32>(a, af, bg, s);
-    else if (cells_per_block == 21) launch_solve_cpb<21>(a, af, bg, s);
-    else if (cells_per_block == 42) launch_solve_cpb<42>(a, af, bg, s);
-    else launch_solve_cpb<16>(a, af, bg, s);
+    if (cells_per_block == 32) launch_solve_cpb<32>(a, af, bg, fast, soil_daily, s);
+    else if (cells_per_block == 21) launch_solve_cpb<21>(a, af, bg, fast, soil_daily, s);
+    else if (cells_per_block == 42) launch_solve_cpb<42>(a, af, bg, fast, soil_daily, s);
+    else launch_solve_cpb<16>(a, af, bg, fast, soil_daily, s);
 }
+int soil_daily_bit() { return kSoilDaily; }
 
 }  // namespace mcf

@@ -1,0 +1,119 @@
+"""The solver's two clamp variants (include/mcf.h mcf_dispatch_stats; mcf_device.hpp `cap` / `flr`): tiles of REGULAR cells
+run one v_min_f64 / v_max_f64 per clamp, everything else the reference's compare-and-select form, and a fast wave that meets
+a NaN at a watched clamp has its tile redone by the fix-up kernel.  Whatever path runs, the result is the oracle's — value
+for value and NaN for NaN; these tests pin WHICH path ran on inputs built to need each of them."""
+import numpy as np
+import pytest
+
+from microclimf_amd import synthetic
+from microclimf_amd.api import Plan
+
+pytestmark = pytest.mark.gpu
+NAMES = ("Tz", "tleaf", "relhum", "soilm", "windspeed", "Rdirdown", "Rdifdown", "Rlwdown", "Rswup", "Rlwup")
+
+
+def _solve(a, days, cpb=21):
+    with Plan(**a, ring_days=days, cells_per_block=cpb) as p:
+        p.run_days(0, days)
+        p.sync()
+        got = {k: p.fetch(0, k, 0, days * 24) for k in NAMES}
+        st = p.dispatch_stats()
+    return got, st
+
+
+def _same(got, want):
+    worst = 0.0
+    for k, w in want.items():
+        g = got[k]
+        assert np.array_equal(np.isnan(g), np.isnan(w)), f"NaN pattern of {k}"
+        fin = np.isfinite(w)
+        if fin.any():
+            worst = max(worst, float((np.abs(g[fin] - w[fin]) / (1 + np.abs(w[fin]))).max()))
+        inf = np.isinf(w)
+        assert np.array_equal(g[inf], w[inf]), k
+    assert worst < 1e-6, worst
+    return worst
+
+
+def test_a_regular_raster_runs_the_fast_clamps(oracle):
+    a = synthetic.workload(30, 21, 72, reqhgt=0.05, start_doy=170, variety=True)     # bare and NA cells are regular too
+    got, st = _solve(a, 3)
+    ntiles = -(-30 * 21 // 21)
+    assert st["fast_tiles"] == ntiles and st["slow_tiles"] == 0, st
+    assert st["fast_launches"] == 1 and st["slow_launches"] == 0 and st["canary_trips"] == 0, st
+    _same(got, oracle.run_grid(**a))
+
+
+def test_cells_with_non_finite_constants_go_to_the_reference_form(oracle):
+    a = synthetic.workload(42, 10, 48, reqhgt=0.05, start_doy=170)
+    a["soilc"]["twi"][3, 0] = np.nan          # tile 0: NA twi in a valid cell
+    a["vegp"]["leafr"][5, 2] = np.nan         # tile (5 + 42*2) // 21 = 4
+    a["vegp"]["x"][7, 4] = np.inf             # tile (7 + 42*4) // 21 = 8
+    a["soilc"]["hor"][9, 6, 3] = np.nan       # tile (9 + 42*6) // 21 = 12
+    got, st = _solve(a, 2)
+    assert st["slow_tiles"] == 4 and st["fast_tiles"] == 20 - 4, st
+    assert st["fast_launches"] == 1 and st["slow_launches"] == 1, st
+    _same(got, oracle.run_grid(**a))
+
+
+def test_a_step_with_non_finite_forcing_sends_its_launch_to_the_reference_form(oracle):
+    a = synthetic.workload(21, 6, 96, reqhgt=0.05, start_doy=170)
+    a["climdata"]["lwdown"] = a["climdata"]["lwdown"].copy()
+    a["climdata"]["lwdown"][30] = np.nan      # day 1
+    with Plan(**a, ring_days=1, ring_slots=1) as p:
+        got = {k: [] for k in NAMES}
+        for d in range(4):
+            p.run_days(d, 1, 0)
+            p.sync()
+            for k in NAMES:
+                got[k].append(p.fetch(0, k, 0, 24))
+        st = p.dispatch_stats()
+    got = {k: np.concatenate(v, axis=2) for k, v in got.items()}
+    assert st["irregular_days"] == 1 and st["slow_launches"] == 1 and st["fast_launches"] == 3, st
+    _same(got, oracle.run_grid(**a))
+
+
+def test_a_nan_born_inside_a_regular_cell_trips_the_canary_and_is_redone(oracle):
+    """Soil volume fractions that make the conductivity negative: every cell constant is finite (the cell is REGULAR), but
+    the damping depth is the square root of a negative number, so the ground heat flux meets its clamp as a NaN.  The
+    reference's `if (G > 0.6*Rmx)` leaves it NaN; v_min_f64 would not — the watched clamp trips and the tile is redone."""
+    a = synthetic.workload(21, 4, 48, reqhgt=0.05, start_doy=170)
+    a["soilc"]["Vq"][4, 1] = 1.6              # 1 - 0.74*Vq - 0.49*Vm < 0: c1 < 0 (src/microclimfCpp.cpp:628-636)
+    got, st = _solve(a, 2)
+    want = oracle.run_grid(**a)
+    assert np.isnan(want["Tz"][4, 1]).all() and np.isfinite(want["Tz"][5, 1]).all()
+    assert st["slow_tiles"] == 0 and st["canary_trips"] >= 1, st
+    _same(got, want)
+
+
+@pytest.mark.parametrize("cpb", [16, 21, 32, 42])
+def test_every_tile_geometry_has_both_variants(oracle, cpb):
+    a = synthetic.workload(23, 9, 48, reqhgt=1.0, start_doy=200, variety=True, hgt_range=(0.1, 1.9))   # above and below canopy
+    a["soilc"]["twi"][0, 0] = np.nan
+    got, st = _solve(a, 2, cpb)
+    assert st["slow_tiles"] == 1 and st["fast_tiles"] == -(-23 * 9 // cpb) - 1, st
+    _same(got, oracle.run_grid(**a))
+
+
+def test_soil_state_shared_per_day_or_per_lane_gives_the_same_bits(oracle):
+    """Days on which pointm$soilm has one value (what soilmCpp's daily bucket model gives) compute the soil-only state once
+    per tile and day; a day on which it varies within the day must go through the hour lanes.  One series with such a day
+    in the middle, solved as ONE launch (no day shared) and day by day (days 0 and 2 shared): bit for bit the same, and
+    the oracle's values."""
+    a = synthetic.workload(25, 7, 72, reqhgt=0.05, start_doy=170, variety=True)
+    sm = a["pointm"]["soilm"].copy()
+    assert (sm[:24] == sm[0]).all()                       # the synthetic series is daily
+    sm[24:48] = sm[24] + 0.01 * np.sin(np.arange(24))     # day 1 varies hour by hour
+    a["pointm"]["soilm"] = sm
+    whole, _ = _solve(a, 3)
+    with Plan(**a, ring_days=1) as p:
+        parts = {k: [] for k in NAMES}
+        for d in range(3):
+            p.run_days(d, 1, 0)
+            p.sync()
+            for k in NAMES:
+                parts[k].append(p.fetch(0, k, 0, 24))
+    for k in NAMES:
+        by_day = np.concatenate(parts[k], axis=2)
+        assert np.array_equal(by_day.view(np.uint64), whole[k].view(np.uint64)), k
+    _same(whole, oracle.run_grid(**a))
