@@ -495,6 +495,12 @@ int mcf_snowplan_create(const mcf_snowdriver_in *in, int64_t row0, int64_t rows_
 void mcf_snowplan_destroy(mcf_snowplan *plan);
 int32_t mcf_snowplan_chunks(const mcf_snowplan *plan);
 int mcf_snowplan_surface(mcf_snowplan *plan, double *host_own);
+/* The pack depth the loop hands from the chunk just run to the next one (`other$isnowdc <- (asc + cdsnow + dsnow2)[,,last]`,
+ * R/internal.R:2607), own rows, [rows, cols].  Once a pack has melted this is a rounding residue (0 or +-1e-17 m) and
+ * `sdepcp > 0` (src/microclimfCpp.cpp:4337) decides on it whether the next chunk runs the model: the reference's loop is
+ * discontinuous in its own rounding there.  Exposed so that a checker can tell such ill-conditioned hand-overs from
+ * wrong ones (tests/test_snow_gpu.py::test_full_year_chunk_loop_*). */
+int mcf_snowplan_handover(mcf_snowplan *plan, double *host_isnowdc);
 int mcf_snowplan_surface_partial(mcf_snowplan *plan, double *sum, double *count);
 int mcf_snowplan_prepare_chunk(mcf_snowplan *plan, int32_t chunk, const double *ext, int32_t halo_north,
                                int32_t halo_south, double surface_mean, double *tpic_sum, double *tpic_count);

@@ -1029,6 +1029,12 @@ extern "C" int mcf_snowplan_surface(mcf_snowplan* sp, double* host_own) {
     S_TRY(hipMemcpy(host_own, sp->d_dtms, (size_t)sp->N * 8, hipMemcpyDeviceToHost));
     return MCF_OK;
 }
+extern "C" int mcf_snowplan_handover(mcf_snowplan* sp, double* host_isnowdc) {
+    if (!sp || !host_isnowdc) return mcf::api_fail(MCF_ERR_ARG, "null argument");
+    S_TRY(hipSetDevice(sp->device));
+    S_TRY(hipMemcpy(host_isnowdc, sp->d_isnowdc, (size_t)sp->N * 8, hipMemcpyDeviceToHost));
+    return MCF_OK;
+}
 extern "C" int mcf_snowplan_surface_partial(mcf_snowplan* sp, double* sum, double* count) {
     if (!sp || !sum || !count) return mcf::api_fail(MCF_ERR_ARG, "null argument");
     S_TRY(hipSetDevice(sp->device));

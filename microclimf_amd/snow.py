@@ -634,6 +634,12 @@ class SnowPlan:
         _abi.check(self._lib.mcf_snowplan_surface(self._p, a.ctypes.data_as(_abi.c_double_p)))
         return a
 
+    def handover(self) -> np.ndarray:
+        """The pack depth handed to the next chunk (`other$isnowdc`), own rows."""
+        a = np.empty((self.rows, self.cols), dtype=np.float64, order="F")
+        _abi.check(self._lib.mcf_snowplan_handover(self._p, a.ctypes.data_as(_abi.c_double_p)))
+        return a
+
     def surface_partial(self):
         s, n = C.c_double(), C.c_double()
         _abi.check(self._lib.mcf_snowplan_surface_partial(self._p, C.byref(s), C.byref(n)))

@@ -43,7 +43,9 @@ def tpicalc(af: int, me: int, dtm, tfact: float):
     return tpic / np.nanmean(tpic)
 
 
-def snowmodel1_chunks(obstime, climdata, pointm, vegp, other, snowenv, dtm, res, tfact=0.02, chunk_steps=120):
+def snowmodel1_chunks(obstime, climdata, pointm, vegp, other, snowenv, dtm, res, tfact=0.02, chunk_steps=120, handover=None):
+    """`handover(chunk, isnowdc)` (optional) may return a replacement for the pack depth handed to the next chunk — the hook
+    by which a test aligns the loop's ill-conditioned gate (`sdepcp > 0` on a rounding residue) with another run's."""
     dtm = np.asarray(dtm, dtype=np.float64)
     R, Cc = dtm.shape
     h = len(np.asarray(obstime["year"]))
@@ -84,6 +86,8 @@ def snowmodel1_chunks(obstime, climdata, pointm, vegp, other, snowenv, dtm, res,
             outs["groundsnowdepth"][:, :, sl] = asd + dsnow2
             outs["snowden"][:, :, sl] = smod["sden"]
             oth["isnowdc"] = tot[:, :, -1]
+            if handover is not None:
+                oth["isnowdc"] = handover(ch, oth["isnowdc"])
             oth["isnowac"] = np.nan_to_num(smod["agec"])
             oth["isnowag"] = np.nan_to_num(smod["ageg"])
             dtms = dtm + outs["groundsnowdepth"][:, :, ed - 1]

@@ -1,0 +1,70 @@
+"""Comparison of model series with the machine-digitised curves of the reference's published figures
+(tests/golden/vignette_points.json, written by tools/digitize_vignette.py — see there for how).
+
+Everything is done in PIXEL space of the original figure: the model's series is mapped through the figure's axis
+calibration and drawn as a polyline; the figure's curve is the set of pixels of its colour.  Two directed distances:
+  fig -> model   how far the published curve strays from the model's polyline (every published pixel accounted for)
+  model -> fig   how far the model's polyline strays from the published curve (only meaningful where the curve is not hidden
+                 behind another one drawn later)
+One pixel is the digitisation error; a line of width 1-2 px, the rasterisation and the axis fit (<= 0.5 px) add ~1.5 px."""
+import json
+from pathlib import Path
+
+import numpy as np
+from scipy.spatial import cKDTree
+
+FIXTURE = Path(__file__).resolve().parent / "golden" / "vignette_points.json"
+
+
+def panel(fig: str, k: int = 0) -> dict:
+    return json.loads(FIXTURE.read_text())["figures"][fig]["panels"][k]
+
+
+def curve_pixels(p: dict, curve: str) -> np.ndarray:
+    pts = []
+    for x, flat in p["curves"][curve]["columns"]:
+        for a, b in zip(flat[0::2], flat[1::2]):
+            pts += [(x, r) for r in range(a, b + 1)]
+    return np.array(pts, dtype=np.float64)
+
+
+def to_px(p: dict, x, y):
+    ax, bx, ay, by = p["x"]["per_px"], p["x"]["at_px0"], p["y"]["per_px"], p["y"]["at_px0"]
+    return (np.asarray(x, float) - bx) / ax, (np.asarray(y, float) - by) / ay
+
+
+def polyline_px(p: dict, x, y, step: float = 0.25) -> np.ndarray:
+    """the model's series as R draws it: straight segments between consecutive points, clipped to the frame"""
+    px, py = to_px(p, x, y)
+    ok = np.isfinite(px) & np.isfinite(py)
+    out = []
+    for i in range(len(px) - 1):
+        if not (ok[i] and ok[i + 1]):
+            continue
+        n = max(2, int(np.hypot(px[i + 1] - px[i], py[i + 1] - py[i]) / step) + 1)
+        t = np.linspace(0.0, 1.0, n)
+        out.append(np.column_stack([px[i] + t * (px[i + 1] - px[i]), py[i] + t * (py[i + 1] - py[i])]))
+    q = np.concatenate(out)
+    f = p["frame_px"]
+    keep = (q[:, 0] >= f["left"]) & (q[:, 0] <= f["right"]) & (q[:, 1] >= f["top"]) & (q[:, 1] <= f["bottom"])
+    return q[keep]
+
+
+def distances(p: dict, curve: str, x, y) -> dict:
+    """directed distances in pixels (max and 99th percentile) between the published curve and the model's polyline"""
+    fig = curve_pixels(p, curve)
+    mod = polyline_px(p, x, y)
+    d_fm = cKDTree(mod).query(fig)[0]
+    d_mf = cKDTree(fig).query(mod)[0]
+    return {"fig_to_model_max": float(d_fm.max()), "fig_to_model_p99": float(np.percentile(d_fm, 99)),
+            "model_to_fig_max": float(d_mf.max()), "model_to_fig_p99": float(np.percentile(d_mf, 99)),
+            "fig_pixels": int(len(fig)), "px": p["px"], "d_fm": d_fm, "d_mf": d_mf, "fig": fig, "mod": mod}
+
+
+def envelope_columns(p: dict, curve: str):
+    """per pixel column: (x pixel, lowest value, highest value) of the curve's colour"""
+    ay, by = p["y"]["per_px"], p["y"]["at_px0"]
+    out = []
+    for x, flat in p["curves"][curve]["columns"]:
+        out.append((x, ay * max(flat) + by, ay * min(flat) + by))
+    return np.array(out)

@@ -26,19 +26,21 @@ for name in ("bench_under_rocprof.json", "bench.json"):
 
 pmc = {}
 dur = {}
+kname = "k_solve"
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc"):
     cc = glob.glob(str(src / d / "*" / "*_counter_collection.csv"))
     if not cc:
         continue
     agg = defaultdict(list)
     for r in csv.DictReader(open(cc[0])):
-        if "k_solve" in r["Kernel_Name"]:
+        if "k_solve<" in r["Kernel_Name"]:            # not k_solve_fix (the empty fix-up launches)
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            kname = r["Kernel_Name"]
     for k, v in agg.items():
         pmc[k] = sum(v) / len(v)
     kt = glob.glob(str(src / d / "*" / "*_kernel_trace.csv"))[0]
     ds = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(kt))
-          if "k_solve" in r["Kernel_Name"]]
+          if "k_solve<" in r["Kernel_Name"]]
     dur[d] = sum(ds) / len(ds)
 # days per launch and raster: from the bench line written during the PMC run itself ("HBM ring (S slots x N days)")
 import re
@@ -56,7 +58,7 @@ for bj in (src / "pmc_fetch.json", dst / f"{tag}_bench_under_rocprof.json"):
         except Exception:
             pass
 bargs = (src / "bench_args.txt").read_text().strip() if (src / "bench_args.txt").exists() else ""
-summary = {"kernel": "k_solve<21,0,false>", "per_launch_mean": pmc, "avg_launch_ms_under_pmc": dur,
+summary = {"kernel": kname.replace("void mcf::", "").replace("(mcf::SolveArgs)", ""), "per_launch_mean": pmc, "avg_launch_ms_under_pmc": dur,
            "ring_days": ring_days, "rows": rows, "cols": cols, "cell_steps_per_launch": valid_cells * ring_days * 24,
            "kernel_hash": bench.kernel_hash(),
            "command": f"python3 bench.py {bargs} --tsteps 1920 --steps 1 --warmup 0 --no-cpu-baseline --no-secondary "
