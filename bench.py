@@ -63,6 +63,7 @@ def parse(argv=None):
     ap.add_argument("--reqhgt", type=float, default=0.05)
     ap.add_argument("--ring-days", type=int, default=10)
     ap.add_argument("--ring-slots", type=int, default=2)
+    ap.add_argument("--ring-gb", type=float, default=250.0, help="HBM the plan may use for tables + output ring")
     ap.add_argument("--cells-per-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (configs[1], array forcing, "
@@ -212,12 +213,14 @@ def committed_counters(rows, cols, ring_days):
 
 
 def fit_ring(args, cells, af):
-    """The output ring (and, with array forcing, the forcing slabs) must fit the GPU: shrink until
-    slots x days x 24 h x cells x 8 B x (10 outputs [+ 15 forcing arrays]) stays under 160 GB.  Longer launches first:
-    at 4096^2 one 4-day slot runs 11 % faster than two 2-day slots (the cell tables are re-read once per launch)."""
+    """The output ring (and, with array forcing, the forcing slabs) must fit the GPU beside the plan's tables (1.2 KB per
+    cell): shrink until slots x days x 24 h x cells x 8 B x (10 outputs [+ 15 forcing arrays]) stays under the budget
+    (--ring-gb, default 230 of the 288 GB).  Longer launches first: every launch pays a fixed ~6.6 us per tile (staging the
+    tile's constants, the soil-state prologue, the tail), 15 % of a 4-day launch and 9 % of a 7-day one."""
     per_day = cells * 24 * 8 * (10 + (15 if af else 0))
     slots, days = args.ring_slots, args.ring_days
-    while slots * days * per_day > 160e9 and (slots > 1 or days > 1):
+    budget = args.ring_gb * 1e9 - cells * 1300.0
+    while slots * days * per_day > budget and (slots > 1 or days > 1):
         if slots > 1 and not af:
             slots -= 1
         elif days > 1:

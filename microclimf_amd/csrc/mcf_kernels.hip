@@ -51,6 +51,9 @@
 #ifndef MCF_DAYPRIO
 #define MCF_DAYPRIO 0
 #endif
+#ifndef MCF_EXPERIMENT_SKIPDAYS
+#define MCF_EXPERIMENT_SKIPDAYS 0   // timing experiment: prologue only
+#endif
 #ifndef MCF_EXPERIMENT_NOPUSH
 #define MCF_EXPERIMENT_NOPUSH 0
 #endif
@@ -543,7 +546,9 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
     const int64_t c = c0 + cl;
     const bool in_grid = lane_on && c < N;   // the other lanes only help staging and keep the barriers
 
-    // ---- stage the tile's direction tables and the first day's time table in LDS
+    // ---- stage the tile's direction tables, the first day's time table and the first day's cell constants in LDS: all
+    // global loads of the prologue are in flight together (one HBM latency per workgroup instead of three; the fixed cost
+    // of a workgroup is ~7 us, 9 % of a 7-day launch)
     for (int q = tid; q < kCellDirs * CPB; q += NT) {
         int dI = q / CPB, l = q % CPB;
         int64_t cc = c0 + l;
@@ -556,10 +561,20 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
         for (int q = tid; q < TF_COUNT * 24; q += NT) s_time[q] = src[q];
     }
 
+    auto stage_cells = [&](int layer) {
+        const double* src = a.cellc + (int64_t)layer * CF_COUNT * N;
+        for (int q = tid; q < CF_COUNT * CPB; q += NT) {
+            int f = q / CPB, l = q % CPB;
+            int64_t cc = c0 + l;
+            s_cell[q] = cc < N ? src[(int64_t)f * N + cc] : 0.0;
+        }
+    };
     CellLds<CPB> C{s_cell, s_dirs, cl};
     int flags = 0;
     bool valid = false;
-    int cur_layer = -2;
+    // vegetation layer of a day (runmicro3Cpp/4Cpp `dfsel`, cpp:2760-2768)
+    int cur_layer = a.daylayer ? a.daylayer[day0] : 0;
+    if (cur_layer >= 0) stage_cells(cur_layer);
     Globals g = a.g;
     double dTmx = g.dTmx;
     if (AF && in_grid) dTmx = -0.6273 * a.mxtc[c] + 49.79;   // cpp:1236 with the per-cell mxtc
@@ -579,33 +594,31 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
             soil_day_produce<SS ? CPB : 1, F>(s_cell, a.tt[((int64_t)d * TF_COUNT + TF_SOILMP) * 24], s_soil + (d % 3) * (SD_COUNT * CPB),
                                               tid & 63, MK);
     };
-    for (int dl = 0; dl < ndays; ++dl) {
+    // after the tile's constants of `cur_layer` have landed in LDS (barrier before): the lane's flags, and the soil ring
+    // (re)started with this layer's constants — day `d` and the next, one wave each; from there on the wave whose turn it
+    // is fills, behind each day's barrier, the slot of the day after next
+    auto enter_layer = [&](int d) {
+        flags = (in_grid && cur_layer >= 0) ? (int)s_cell[CF_FLAGS * CPB + cl] : 0;
+        valid = (flags & FL_VALID) != 0;
+        if (SS && cur_layer >= 0) {
+            const int wv = tid >> 6;
+            if (wv == 0) produce_soil(d);
+            if (wv == 1 && d + 1 < day0 + ndays) produce_soil(d + 1);
+            __syncthreads();
+        }
+    };
+    __syncthreads();
+    enter_layer(day0);
+    for (int dl = 0; dl < (MCF_EXPERIMENT_SKIPDAYS ? 0 : ndays); ++dl) {
         const int dabs = day0 + dl;
-        // vegetation layer of this day (runmicro3Cpp/4Cpp `dfsel`, cpp:2760-2768); the tile's cell
-        // constants are (re)staged whenever it changes — a workgroup-uniform, rare event
+        // the tile's cell constants are restaged whenever the day's vegetation layer changes — workgroup-uniform and rare
         const int layer = a.daylayer ? a.daylayer[dabs] : 0;
         if (layer != cur_layer) {
             __syncthreads();
-            if (layer >= 0) {
-                const double* src = a.cellc + (int64_t)layer * CF_COUNT * N;
-                for (int q = tid; q < CF_COUNT * CPB; q += NT) {
-                    int f = q / CPB, l = q % CPB;
-                    int64_t cc = c0 + l;
-                    s_cell[q] = cc < N ? src[(int64_t)f * N + cc] : 0.0;
-                }
-            }
+            if (layer >= 0) stage_cells(layer);
             __syncthreads();
             cur_layer = layer;
-            flags = (in_grid && layer >= 0) ? (int)s_cell[CF_FLAGS * CPB + cl] : 0;
-            valid = (flags & FL_VALID) != 0;
-            if (SS && layer >= 0) {
-                // (re)start the soil ring with this layer's constants: this day and the next, one wave each; from here
-                // on the wave that is first behind a day's barrier fills the slot of the day after next
-                const int wv = tid >> 6;
-                if (wv == 0) produce_soil(dabs);
-                if (wv == 1 && dabs + 1 < day0 + ndays) produce_soil(dabs + 1);
-                __syncthreads();
-            }
+            enter_layer(dabs);
         }
         const int64_t kl = (int64_t)(dabs - a.day0) * 24 + hr;   // step within the launch's part of the slot
         const int64_t oidx = c + N * (a.slot_step0 + kl);

@@ -9,18 +9,61 @@
 // it is tabulated once per step on the device (k_snow_steps / k_snow_days), with array climate
 // the same derive functions run per cell-step.
 //
-// Plain device libm here (exp/log/pow/tan): unlike the no-snow solver this path has zero and
-// non-finite operands by construction (log(0) in the albedo, pow(0, Kc) for clump = 0, NaN
-// propagation past the last whole day), and the reference's comparison directions are kept so
-// that NaNs fall through the same branches.
+// Unlike the no-snow solver this path has zero and non-finite operands by construction (log(0) in the albedo,
+// pow(0, Kc) for clump = 0, NaN propagation past the last whole day), and the reference's comparison directions are
+// kept so that NaNs fall through the same branches.  The lean fp64 routines of mcf_device.hpp are therefore used under
+// EXPLICIT OPERAND GUARDS (gexp / glog / gsqrt / gpow0 below): each returns what libm returns for the operands outside
+// the lean routine's domain (NaN stays NaN, exp saturates to 0 / inf, log(0) = -inf, log(< 0) = NaN) and the lean value
+// inside it.  Divisions by quantities that are finite and non-zero by construction go through fdiv (a * 1/b, 1.5 ulp);
+// the few whose divisor can be 0 or infinite stay IEEE divisions.  Trigonometry stays device libm (per step or per cell,
+// not in the recurrence), except cos(atan(x)) = 1/sqrt(1 + x^2) in the interception model.
 #pragma once
 #include "mcf_device.hpp"
 
 namespace mcf {
 namespace snow {
 
+#ifndef MCF_SNOW_LEAN
+#define MCF_SNOW_LEAN 1   // 0: plain device libm and IEEE division everywhere (the round-1 build)
+#endif
+#if MCF_SNOW_LEAN
+__device__ __forceinline__ double gexp(double x) {      // exp(x) for ANY operand
+    MathK K;
+    K.set();
+    if (x < -750.0) x = -750.0;                         // compare-select: a NaN passes through; fexp(-750) = 0,
+    if (x > 710.0) x = 710.0;                           // fexp(710) = inf by ldexp's saturation
+    return fexp(x, K);
+}
+__device__ __forceinline__ double glog(double x) {      // log(x) for ANY operand
+    MathK K;
+    K.set();
+    double r = flog(x > 0.0 ? x : 1.0, K);
+    if (!(x > 0.0)) r = (x == 0.0) ? -__longlong_as_double(0x7FF0000000000000LL) : __longlong_as_double(0x7FF8000000000000LL);
+    if (x > 1.7e308) r = x;                             // log(inf) = inf
+    return r;
+}
+__device__ __forceinline__ double gsqrt(double x) {     // sqrt(x) for ANY operand
+    if (x > 1e-300 && x < 1e300) return fsqrt(x);
+    return ::sqrt(x);
+}
+__device__ __forceinline__ double gdiv(double a, double b) { return fdiv(a, b); }   // b finite, non-zero by construction (or NaN)
+#else
+__device__ __forceinline__ double gexp(double x) { return ::exp(x); }
+__device__ __forceinline__ double glog(double x) { return ::log(x); }
+__device__ __forceinline__ double gsqrt(double x) { return ::sqrt(x); }
+__device__ __forceinline__ double gdiv(double a, double b) { return a / b; }
+#endif
+// pow(b, e) for b >= 0 and e > 0 (clump^Kc): pow(0, e) = 0
+__device__ __forceinline__ double gpow0(double b, double e) {
+#if MCF_SNOW_LEAN
+    return b > 0.0 ? gexp(e * glog(b)) : ::pow(b, e);
+#else
+    return ::pow(b, e);
+#endif
+}
+
 __device__ __forceinline__ double svp(double tc) {  // cpp:480-490 satvapCpp
-    return tc > 0 ? 0.61078 * exp(17.27 * tc / (tc + 237.3)) : 0.61078 * exp(21.875 * tc / (tc + 265.5));
+    return 0.61078 * gexp(tc > 0 ? gdiv(17.27 * tc, tc + 237.3) : gdiv(21.875 * tc, tc + 265.5));
 }
 __device__ __forceinline__ double rad4(double tc) {  // cpp:24-26 radem
     double t = tc + 273.15;
@@ -28,7 +71,7 @@ __device__ __forceinline__ double rad4(double tc) {  // cpp:24-26 radem
     return t * t;
 }
 __device__ __forceinline__ double dewpoint(double ea) {  // cpp:493-496
-    const double l = log(ea / 0.6112);
+    const double l = glog(ea / 0.6112);
     return 243.5 * l / (17.67 - l);
 }
 // latent heat of vaporisation / sublimation, the `T < 0` flavour of cpp:3879-3884, 4837-4842
@@ -37,12 +80,12 @@ __device__ __forceinline__ double latent_lt0(double t) {
 }
 __device__ __forceinline__ double zeroplane(double h, double pai) {  // cpp:294-299
     if (pai < 0.001) pai = 0.001;
-    const double s = sqrt(7.5 * pai);
-    return (1.0 - (1.0 - exp(-s)) / s) * h;
+    const double s = gsqrt(7.5 * pai);
+    return (1.0 - gdiv(1.0 - gexp(-s), s)) * h;
 }
 __device__ __forceinline__ double roughlen0(double h, double pai, double d) {  // cpp:302-310, psi_h = 0
-    const double Be = sqrt(0.003 + (0.2 * pai) / 2);
-    double zm = (h - d) * exp(-kKa / Be);
+    const double Be = gsqrt(0.003 + (0.2 * pai) / 2);
+    double zm = (h - d) * gexp(gdiv(-kKa, Be));
     if (zm > (0.9 * (h - d))) zm = 0.9 * (h - d);
     if (zm < 0.0005) zm = 0.0005;
     return zm;
@@ -56,16 +99,17 @@ __device__ __forceinline__ TsDif ts_dif(double pait, double lref, double ltra, d
     p.a = 1.0 - p.om;
     p.del = lref - ltra;
     p.gma = 0.5 * (p.om + (1.0 / 3.0) * p.del);
-    p.h = sqrt(p.a * p.a + 2.0 * p.a * p.gma);
-    p.S1 = exp(-p.h * pait);
-    p.u1 = p.a + p.gma * (1.0 - 1.0 / gref);
+    p.h = gsqrt(p.a * p.a + 2.0 * p.a * p.gma);
+    p.S1 = gexp(-p.h * pait);
+    p.u1 = p.a + p.gma * (1.0 - gdiv(1.0, gref));
     p.u2 = p.a + p.gma * (1.0 - gref);
-    p.D1 = (p.a + p.gma + p.h) * (p.u1 - p.h) * 1.0 / p.S1 - (p.a + p.gma - p.h) * (p.u1 + p.h) * p.S1;
-    p.D2 = (p.u2 + p.h) * 1.0 / p.S1 - (p.u2 - p.h) * p.S1;
-    p.p1 = (p.gma / (p.D1 * p.S1)) * (p.u1 - p.h);
-    p.p2 = (-p.gma * p.S1 / p.D1) * (p.u1 + p.h);
-    p.p3 = (1.0 / (p.D2 * p.S1)) * (p.u2 + p.h);
-    p.p4 = (-p.S1 / p.D2) * (p.u2 - p.h);
+    const double iS1 = gdiv(1.0, p.S1);
+    p.D1 = (p.a + p.gma + p.h) * (p.u1 - p.h) * iS1 - (p.a + p.gma - p.h) * (p.u1 + p.h) * p.S1;
+    p.D2 = (p.u2 + p.h) * iS1 - (p.u2 - p.h) * p.S1;
+    p.p1 = gdiv(p.gma, p.D1 * p.S1) * (p.u1 - p.h);
+    p.p2 = gdiv(-p.gma * p.S1, p.D1) * (p.u1 + p.h);
+    p.p3 = gdiv(1.0, p.D2 * p.S1) * (p.u2 + p.h);
+    p.p4 = gdiv(-p.S1, p.D2) * (p.u2 - p.h);
     return p;
 }
 struct TsDir { double sig, p5, p6, p7, p8, p9, p10; };
@@ -73,19 +117,21 @@ __device__ __forceinline__ TsDir ts_dir(double pait, const TsDif& f, double gref
     TsDir p;
     const double ag = f.a + f.gma;
     const double sig = kd * kd + f.gma * f.gma - ag * ag;
-    const double ss = 0.5 * (f.om + (1.0 / 3.0) * f.del / kd) * kd;
+    const double ss = 0.5 * (f.om + gdiv((1.0 / 3.0) * f.del, kd)) * kd;
     const double sstr = f.om * kd - ss;
-    const double S2 = exp(-kd * pait);
+    const double S2 = gexp(-kd * pait);
     p.p5 = -ss * (ag - kd) - f.gma * sstr;
-    const double v1 = ss - (p.p5 * (ag + kd)) / sig;
-    const double v2 = ss - f.gma - (p.p5 / sig) * (f.u1 + kd);
-    p.p6 = (1.0 / f.D1) * ((v1 / f.S1) * (f.u1 - f.h) - (ag - f.h) * S2 * v2);
-    p.p7 = (-1.0 / f.D1) * ((v1 * f.S1) * (f.u1 + f.h) - (ag + f.h) * S2 * v2);
+    const double v1 = ss - gdiv(p.p5 * (ag + kd), sig);
+    const double v2 = ss - f.gma - gdiv(p.p5, sig) * (f.u1 + kd);
+    const double iD1 = gdiv(1.0, f.D1), iD2 = gdiv(1.0, f.D2);
+    p.p6 = iD1 * (gdiv(v1, f.S1) * (f.u1 - f.h) - (ag - f.h) * S2 * v2);
+    p.p7 = -iD1 * ((v1 * f.S1) * (f.u1 + f.h) - (ag + f.h) * S2 * v2);
     p.sig = -sig;
     p.p8 = sstr * (ag + kd) - f.gma * ss;
-    const double v3 = (sstr + f.gma * gref - (p.p8 / p.sig) * (f.u2 - kd)) * S2;
-    p.p9 = (-1 / f.D2) * ((p.p8 / (p.sig * f.S1)) * (f.u2 + f.h) + v3);
-    p.p10 = (1 / f.D2) * (((p.p8 * f.S1) / p.sig) * (f.u2 - f.h) + v3);
+    const double p8s = gdiv(p.p8, p.sig);
+    const double v3 = (sstr + f.gma * gref - p8s * (f.u2 - kd)) * S2;
+    p.p9 = -iD2 * (gdiv(p.p8, p.sig * f.S1) * (f.u2 + f.h) + v3);
+    p.p10 = iD2 * (gdiv(p.p8 * f.S1, p.sig) * (f.u2 - f.h) + v3);
     return p;
 }
 // cankCpp for x = 1 (cpp:104-132): k, kd = k cos(z)/si, Kc = 1/si
@@ -94,9 +140,9 @@ __device__ __forceinline__ CanK cank1(double kx, double kcos, double si) {
     if (si < 0.0) si = 0.0;
     CanK o;
     o.k = kx;
-    o.kd = kcos / si;
+    o.Kc = gdiv(1.0, si);           // si == 0: overwritten below, whatever the quotient
+    o.kd = kcos * o.Kc;
     if (si == 0) o.kd = 1.0;
-    o.Kc = 1.0 / si;
     if (si == 0.0) o.Kc = 600.0;
     return o;
 }
@@ -179,7 +225,7 @@ __device__ __forceinline__ void met_derive(MetT& m, double tc, double rh, double
     m.De = svp(te + 0.5) - svp(te - 0.5);
     m.tdew = dewpoint(m.ea);
     m.ph = 44.6 * (pk / 101.3) * (273.15 / (tc + 273.15));     // cpp:280-285
-    const double rhos = 67.92 + 51.25 * exp(tc / 2.59);
+    const double rhos = 67.92 + 51.25 * gexp(tc / 2.59);
     m.sint = 6.2 * (0.26 + 46 / rhos);
 }
 struct DayT { double rmx, rmn, rswmx, rlwmx, rswmn, rlwmn, gmx; };   // cpp:4231-4282
@@ -195,7 +241,7 @@ __device__ __forceinline__ void day_accum(DayT& d, double rnet, double rsw, doub
 }
 // snowalbCpp (cpp:3752-3771): the logarithm's argument is the INTEGER quotient hs / 24
 __device__ __forceinline__ double snow_albedo(int hs) {
-    double alb = (-9.8740 * log((double)(hs / 24)) + 78.3434) / 100.0;
+    double alb = (-9.8740 * glog((double)(hs / 24)) + 78.3434) / 100.0;
     if (alb > 0.95) alb = 0.95;
     if (alb < 0.1) alb = 0.1;
     return alb;
@@ -207,7 +253,7 @@ struct PackOut { double Tc, Tg, melc, melg; };
 struct CellV { double pai, hgt, clump, ltra, skyview; SiteK site; };
 
 __device__ __forceinline__ double snow_density(const double* sdp, double depth, double age_h) {  // cpp:3952-3955
-    return ((sdp[0] - sdp[1]) * (1.0 - exp(-sdp[2] * depth / 100.0 - sdp[3] * age_h / 24.0)) + sdp[1]) * 1000.0;
+    return ((sdp[0] - sdp[1]) * (1.0 - gexp(-sdp[2] * depth * (1.0 / 100.0) - sdp[3] * age_h * (1.0 / 24.0))) + sdp[1]) * 1000.0;
 }
 
 // The body of the k loop of gridmodelsnow1/2 for a step that passed `snowtest` (cpp:4340-4396).
@@ -215,12 +261,13 @@ __device__ __forceinline__ void pack_step(const MetT& m, const DayT& dy, const S
                                           double ws, const double* sdp, double zref, Pack& s, PackOut& o) {
     // ground heat flux of the cell from the point model's (cpp:4341-4354)
     double paip = c.pai;
-    if (c.hgt > s.sdepg) paip = paip * (c.hgt - s.sdepg) / c.hgt;
+    const double ihgt = gdiv(1.0, c.hgt > 0.0 ? c.hgt : 1.0);      // only used under hgt > sdepg >= 0
+    if (c.hgt > s.sdepg) paip = paip * (c.hgt - s.sdepg) * ihgt;
     const double dtR = dy.rmx - dy.rmn;
-    const double trS = c.skyview * exp(-paip);
+    const double trS = c.skyview * gexp(-paip);
     const double dmxS = trS * dy.rswmx + trS * dy.rlwmx + (1 - trS) * m.rem - m.rem;
     const double dmnS = trS * dy.rswmn + trS * dy.rlwmn + (1 - trS) * m.rem - m.rem;
-    double G = m.gp * ((dmxS - dmnS) / dtR);
+    double G = m.gp * ((dmxS - dmnS) / dtR);       // IEEE: dtR is 0 past the last whole day (0/0 = NaN there)
     if (G > dy.gmx) G = dy.gmx;
     if (G < -dy.gmx) G = -dy.gmx;
     // terrain-adjusted forcing (cpp:4355-4367)
@@ -232,24 +279,24 @@ __device__ __forceinline__ void pack_step(const MetT& m, const DayT& dy, const S
     const double Rlw = m.rlw * c.skyview;
     // vegetation above the ground snow (cpp:3840-3852)
     double pai = 0.0;
-    if (c.hgt > s.sdepg) pai = c.pai * (c.hgt - s.sdepg) / c.hgt;
+    if (c.hgt > s.sdepg) pai = c.pai * (c.hgt - s.sdepg) * ihgt;
     double hgt = c.hgt - s.sdepg;
     if (hgt < 0.0) hgt = 0.0;
     double zi = 0.0;
-    if (s.sdepg > 0.0 && hgt > 0.0) zi = ((s.sdepc - s.sdepg) * s.sdenc) / (hgt * 1000.0);
-    double ltra = c.ltra * exp(-10.1 * zi);
+    if (s.sdepg > 0.0 && hgt > 0.0) zi = gdiv((s.sdepc - s.sdepg) * s.sdenc, hgt * 1000.0);
+    double ltra = c.ltra * gexp(-10.1 * zi);
     // radoneB (cpp:3773-3833)
     const double RlwabsC = 0.97 * Rlw;
     double RlwabsG = RlwabsC;
     const double cld = c.clump * c.clump;
-    const double pait = pai / (1.0 - c.clump);
-    const double ept = exp(-pait);
+    const double pait = gdiv(pai, 1.0 - c.clump);
+    const double ept = gexp(-pait);
     const double tr = (1.0 - cld) * ept + cld;
     if (hgt > 0.0) RlwabsG = 0.97 * (tr * Rlw + (1.0 - tr) * m.rcan);
     double RabsC = RlwabsC, RswabsG = 0.0;
     if (Rsw > 0.0) {
         const double si = solar_index(sun, c.site, false);
-        double Rbeam = (Rsw - Rdif) / sun.cosz;
+        double Rbeam = gdiv(Rsw - Rdif, sun.cosz);
         if (Rbeam > 1352.2) Rbeam = 1352.2;
         const double RswabsC = (1.0 - m.alb) * (Rdif + Rbeam * sun.cosz);
         RabsC = RswabsC + RlwabsC;
@@ -259,11 +306,11 @@ __device__ __forceinline__ void pack_step(const MetT& m, const DayT& dy, const S
             const TsDif f = ts_dif(pait, m.alb, ltra, m.alb);
             const CanK kp = cank1(sun.kx, sun.kcos, si);
             const TsDir d = ts_dir(pait, f, m.alb, kp.kd);
-            const double clb = pow(c.clump, kp.Kc);
-            const double ehp = exp(f.h * pait);
-            const double ekp = exp(-kp.kd * pait);
+            const double clb = gpow0(c.clump, kp.Kc);
+            const double ehp = gexp(f.h * pait);
+            const double ekp = gexp(-kp.kd * pait);
             const double Rddm = clamp01((1.0 - cld) * (f.p3 * f.S1 + f.p4 * ehp) + cld);
-            const double Rdbm = clamp01((1.0 - clb) * ((d.p8 / d.sig) * ekp + d.p9 * f.S1 + d.p10 * ehp));
+            const double Rdbm = clamp01((1.0 - clb) * (gdiv(d.p8, d.sig) * ekp + d.p9 * f.S1 + d.p10 * ehp));
             const double Rbgm = clamp01((1.0 - clb) * ekp + clb);
             const double RdifG = (1.0 - m.alb) * (Rdbm * Rbeam * sun.cosz) + Rddm * Rdif;
             const double RdirG = (1.0 - m.alb) * (Rbgm * Rbeam * 0.5);
@@ -278,46 +325,49 @@ __device__ __forceinline__ void pack_step(const MetT& m, const DayT& dy, const S
         zm = roughlen0(hgt, pai, d0);
     }
     if (zm < 0.0009) zm = 0.0009;
-    const double uf = (kKa * u2p) / log((zref - d0) / zm);
-    double gHa = (kKa * m.ph * uf) / log((zref - d0) / (0.2 * zm + d0 - d0));   // gturbCpp, cpp:373-380
+    const double izm = gdiv(1.0, zm);
+    const double uf = gdiv(kKa * u2p, glog((zref - d0) * izm));
+    double gHa = gdiv(kKa * m.ph * uf, glog(gdiv(zref - d0, 0.2 * zm + d0 - d0)));   // gturbCpp, cpp:373-380
     if (gHa < 0.03) gHa = 0.03;
     // surface temperatures (cpp:3871-3875, PenmanMonteithCpp cpp:498-514 with gV = gHa, erh = 1)
-    const double lg = m.la * (gHa / m.pk);
+    const double gpk = gdiv(gHa, m.pk);
+    const double lg = m.la * gpk;
     const double den = m.cp * (gHa + m.gR) + lg * m.De;
-    double Tc = m.tc + ((RabsC - m.rem - lg * m.Da - G) / den);
-    double Tg = m.tc + ((RabsG - m.rem - lg * m.Da - G) / den);
+    const double iden = gdiv(1.0, den);
+    double Tc = m.tc + ((RabsC - m.rem - lg * m.Da - G) * iden);
+    double Tg = m.tc + ((RabsG - m.rem - lg * m.Da - G) * iden);
     if (Tc < m.tdew) Tc = m.tdew;
     if (Tg < m.tdew) Tg = m.tdew;
     // canopy + ground pack: sublimation, melt, rain melt (cpp:3878-3901)
     double la = latent_lt0(Tc);
-    double L = la * (gHa / m.pk) * (svp(Tc) - m.ea);
-    la = la / 0.018015;
-    const double mSc = (L / la) * 3.6;
+    double L = la * gpk * (svp(Tc) - m.ea);
+    la = la * (1.0 / 0.018015);
+    const double mSc = gdiv(L, la) * 3.6;
     double mMc = 0.0;
     if (Tc > 0.0) {
-        const double S = s.sdepc * (s.sdenc / 1000);
-        mMc = ((583.3 * Tc * S) / 334000.0) * 3.6;
+        const double S = s.sdepc * (s.sdenc * 0.001);
+        mMc = ((583.3 * Tc * S) * (1.0 / 334000.0)) * 3.6;
         if (s.sdepc > 0.0) Tc = 0.0;
     }
     double mRc = 0.0;
-    if (m.tc > 0.0) mRc = 0.0125 * m.tc * m.prec / 1000;
+    if (m.tc > 0.0) mRc = 0.0125 * m.tc * m.prec * 0.001;
     // ground pack (cpp:3904-3922)
     la = latent_lt0(Tg);
-    double mu = exp(-pai);
+    double mu = gexp(-pai);
     if (mu > 1.0) mu = 1.0;
-    L = la * (gHa / m.pk) * (svp(Tg) - m.ea) * mu;
-    la = la / 0.018015;
-    const double mSg = (L / la) * 3.6;
+    L = la * gpk * (svp(Tg) - m.ea) * mu;
+    la = la * (1.0 / 0.018015);
+    const double mSg = gdiv(L, la) * 3.6;
     double mMg = 0.0;
     if (Tg > 0.0) {
-        const double S = s.sdepg * (s.sdeng / 1000.0);
-        mMg = ((583.3 * Tg * S) / 334000.0) * 3.6;
+        const double S = s.sdepg * (s.sdeng * 0.001);
+        mMg = ((583.3 * Tg * S) * (1.0 / 334000.0)) * 3.6;
         if (s.sdepg > 0.0) Tg = 0.0;
     }
     // canopy interception (cpp:3924-3934, canopysnowintCpp cpp:3713-3739)
     double Li = 0.0;
     if (s.sdepc > 0.0) {
-        double wgtg = s.sdepg / s.sdepc;
+        double wgtg = gdiv(s.sdepg, s.sdepc);
         if (wgtg < 0.0) wgtg = 0.0;
         if (wgtg > 1.0) wgtg = 1.0;
         Li = (s.sdepc - s.sdepg) * (wgtg * s.sdeng + (1.0 - wgtg) * s.sdenc);
@@ -328,33 +378,38 @@ __device__ __forceinline__ void pack_step(const MetT& m, const DayT& dy, const S
         double h = hgt, p = pai;
         if (h < 0.001) h = 0.001;
         if (p < 0.001) p = 0.001;
-        const double Be = sqrt(0.003 + (0.2 * p) / 2.0);
-        const double uh = uf / Be;
-        const double Lc = 1.0 / (0.25 * (p / h));
+        const double Be = gsqrt(0.003 + (0.2 * p) * 0.5);
+        const double uh = gdiv(uf, Be);
+        const double Lc = gdiv(h, 0.25 * p);                       // 1 / (0.25 * (p / h))
         const double Lm = 2.0 * (Be * Be * Be) * Lc;
-        const double k1 = Be / Lm;
-        double uzm = (uh / (h * k1)) * (1 - exp(-k1 * h));
+        const double k1 = gdiv(Be, Lm);
+        double uzm = gdiv(uh, h * k1) * (1 - gexp(-k1 * h));
         if (uzm < uf) uzm = uf;
         const double Lstr = m.sint * p;
+#if MCF_SNOW_LEAN
+        const double tz = uzm * (1.0 / 0.8);
+        const double kc = 0.5 * gsqrt(1.0 + tz * tz);              // 1 / (2 cos(atan(t))) = sqrt(1 + t^2) / 2
+#else
         const double Z = atan(uzm / 0.8);
         const double kc = 1.0 / (2.0 * cos(Z));
-        const double Cp = 1.0 - exp(-kc * p);
-        const double I1 = (Lstr - Li) * (1.0 - exp(-(Cp / Lstr) * m.prec));
+#endif
+        const double Cp = 1.0 - gexp(-kc * p);
+        const double I1 = (Lstr - Li) * (1.0 - gexp(-gdiv(Cp, Lstr) * m.prec));
         cis = I1 * 0.678;
         if (cis > m.prec) cis = m.prec;
     }
     double mRg = 0.0;
-    if (m.tc > 0.0) mRg = 0.0125 * m.tc * (m.prec - cis) / 1000.0;
+    if (m.tc > 0.0) mRg = 0.0125 * m.tc * (m.prec - cis) * 0.001;
     // mass balance, density, age (cpp:3941-3965)
     double snowc = m.prec, snowg = m.prec - cis;
     if (m.tc > 2.0) { snowc = 0.0; snowg = 0.0; }
-    const double swec = snowc / 1000.0 - mSc - mMc - mRc;
-    const double sweg = snowg / 1000.0 - mSg - mMg - mRg;
+    const double swec = snowc * 0.001 - mSc - mMc - mRc;
+    const double sweg = snowg * 0.001 - mSg - mMg - mRg;
     double agec = (double)s.agec + 1.0, ageg = (double)s.ageg + 1.0;
     const double sdenc = snow_density(sdp, s.sdepc, agec);
     const double sdeng = snow_density(sdp, s.sdepg, ageg);
-    double sdepc = s.sdepc + (swec * 1000.0) / sdenc;
-    double sdepg = s.sdepg + (sweg * 1000.0) / sdeng;
+    double sdepc = s.sdepc + gdiv(swec * 1000.0, sdenc);
+    double sdepg = s.sdepg + gdiv(sweg * 1000.0, sdeng);
     if (sdepc < 0.0) { sdepc = 0.0; agec = 0.0; }
     if (sdepg < 0.0) { sdepg = 0.0; ageg = 0.0; }
     s.sdenc = sdenc; s.sdeng = sdeng; s.sdepc = sdepc; s.sdepg = sdepg;
@@ -379,7 +434,7 @@ __device__ __forceinline__ double rh_canopy(double uf, double h, double d, doubl
     double inth = 4.293251 * h;
     if (z != h) {
         const double sn = sin((kPi * z) / h), c1 = cos((kPi * z) / h) + 1;
-        inth = (2.0 * h * ((48 * atan((sqrt(5.0) * sn) / c1)) / pow(5.0, 1.5) +
+        inth = (2.0 * h * ((48 * atan((gsqrt(5.0) * sn) / c1)) / pow(5.0, 1.5) +
                            (32.0 * sn) / (c1 * ((25.0 * (sn * sn)) / (c1 * c1) + 5.0)))) / kPi;
     }
     const double mu = uf / (a2 * h) * 1.0 / (uf * uf);
@@ -413,7 +468,7 @@ __device__ __forceinline__ AboveTV tv_above(double reqhgt, double zref, double d
     const double estl = svp(T0);
     AboveTV o;
     if (reqhgt > (d + zh)) {
-        const double lnr = log((reqhgt - d) / zh) / log((zref - d) / zh);
+        const double lnr = glog((reqhgt - d) / zh) / glog((zref - d) / zh);
         o.Tz = tc + (T0 - tc) * (1 - lnr);
         o.ez = ea + (estl - ea) * (1 - lnr);
     } else {
@@ -458,24 +513,24 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const SunT& su
     double ws = q.ws;
     if (isnan(ws)) ws = 1.0;
     if (ws < 0.05) ws = 0.05;
-    double uf = ((kKa * q.u2) / log((q.zref - d) / zm)) * q.umu * ws;
+    double uf = ((kKa * q.u2) / glog((q.zref - d) / zm)) * q.umu * ws;
     if (uf < 0.001) uf = 0.001;
     double uz = uf;
     if (reqhgt > 0) {
         if (reqhgt >= hgts) {
-            uz = (uf / kKa) * log((reqhgt - d) / zm);
+            uz = (uf / kKa) * glog((reqhgt - d) / zm);
         } else {
-            double uh = (uf / kKa) * log((hgts - d) / zm);
+            double uh = (uf / kKa) * glog((hgts - d) / zm);
             if (uh < uf) uh = uf;
             double Be = uf / uh;
             if (Be < 0.001) Be = 0.001;
             const double Lc = 1.0 / (0.25 * wa);
             const double Lm = 2 * (Be * Be * Be) * Lc;
-            uz = uh * exp(Be * (reqhgt - hgts) / Lm);
+            uz = uh * gexp(Be * (reqhgt - hgts) / Lm);
         }
         if (uz > q.u2) uz = q.u2;
     }
-    double gHa = (kKa * 43 * uf) / log((q.zref - d) / (0.2 * zm + d - d));   // gturbCpp(.., 43, 0, 0.0001)
+    double gHa = (kKa * 43 * uf) / glog((q.zref - d) / (0.2 * zm + d - d));   // gturbCpp(.., 43, 0, 0.0001)
     if (gHa < 0.0001) gHa = 0.0001;
     out.uz = uz;
     double ez;
@@ -504,7 +559,7 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const SunT& su
         if (hgts > 0.0) paias = q.paia * hgts / q.hgt;
         double zi = 0.0;
         if (q.sdepg > 0.0) zi = ((q.sdepc - q.sdepg) * q.sden) / (hgts * 1000.0);
-        double ltras = q.ltra * exp(-10.1 * zi);
+        double ltras = q.ltra * gexp(-10.1 * zi);
         if ((ltras + q.alb) > 0.999) ltras = 0.999 - q.alb;
         double clumps = q.clump;
         if (q.clump > 0.0) clumps = pow(q.clump, pais / q.pai);
@@ -523,7 +578,7 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const SunT& su
         const double trd = gi * gi, trdn = clumps * clumps, trdu = giu * giu;
         const double paiaa = paias / (1.0 - gi);
         const double amx = q.alb;                                // max(gref, lref), both the albedo
-        const double eh_a = exp(-f.h * paiaa), eH_a = exp(f.h * paiaa);
+        const double eh_a = gexp(-f.h * paiaa), eH_a = gexp(f.h * paiaa);
         double Rdup_z = (1.0 - trdu * trdn) * (f.p1 * eh_a + f.p2 * eH_a) + trdu * trdn * q.alb;
         Rdup_z = clamp01(Rdup_z);
         const double Rddn_z = clamp01((1.0 - trd) * (f.p3 * eh_a + f.p4 * eH_a) + trd);
@@ -543,7 +598,7 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const SunT& su
                 double trb = pow(gi, kp.Kc);
                 if (trb > 0.999) trb = 0.999;
                 if (trb < 0.0) trb = 0.0;
-                const double ek_a = exp(-kp.kd * paiaa);
+                const double ek_a = gexp(-kp.kd * paiaa);
                 double Rdbup_z = (1.0 - trdu * trbn) * ((dr.p5 / -dr.sig) * ek_a + dr.p6 * eh_a + dr.p7 * eH_a) +
                                  trdu * trbn * q.alb;
                 if (Rdbup_z > amx) Rdbup_z = amx;
@@ -568,15 +623,15 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const SunT& su
         // leaftemp (cpp:1333-1364) with gsmax = 999.999: gV = gh
         const double lwcan = 0.97 * kSb * rad4(q.Tc);
         const double lwgro = 0.97 * kSb * rad4(q.Tg);
-        const double eg = exp(-(pais - paias)), eaa = exp(-paias);
+        const double eg = gexp(-(pais - paias)), eaa = gexp(-paias);
         const double lwup = eg * lwgro + (1 - eg) * lwcan;
         const double lwdn = eaa * q.Rlw + (1 - eaa) * lwcan;
         const double leafabs = radLsw + 0.97 * 0.5 * (lwup + lwdn);
-        double gh = 0.135 * sqrt(uz / q.leafd) * 1.4;
+        double gh = 0.135 * gsqrt(uz / q.leafd) * 1.4;
         {   // mincondCpp(leafabs, 999.99, Tcan, leafd) cpp:1316-1331
             const double Rnet = leafabs - 0.97 * kSb * rad4(q.Tc);
             const double rs = 1 / 999.99;
-            const double Hf = -1.0 / (1.0 + exp(2.0 - 1.09767 * pow(rs, 0.2672778)));
+            const double Hf = -1.0 / (1.0 + gexp(2.0 - 1.09767 * pow(rs, 0.2672778)));
             double gmin = 0.0463 * pow(fabs(Hf * Rnet) / q.leafd, 0.2);
             if (gmin < 0.05) gmin = 0.05;
             if (gh < gmin) gh = gmin;
@@ -599,9 +654,9 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const SunT& su
         out.tleaf = tleaf;
         // Lagrangian below-canopy profile (cpp:4827-4851)
         const BelowK bk = below_k(reqhgt, d, hgts, uf);
-        const double lnpai = log(pais);
+        const double lnpai = glog(pais);
         const double H = 29.3 * gHa * (q.Tc - q.tc);
-        const double fr = 1.0 - exp(-pais);
+        const double fr = 1.0 - gexp(-pais);
         const AboveTV tv = tv_above(hgts, q.zref, d, zm, q.Tc, q.tc, ea);
         out.Tz = tv_below(bk, lnpai, q.leafden, H * fr, Hl, tv.Tz * 29.3 * 43.0, q.Tg * 29.3 * 43.0,
                           fabs(tleaf - tv.Tz) * 29.3 * 43.0) / (29.3 * 43);
