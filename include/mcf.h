@@ -505,6 +505,10 @@ int mcf_snowplan_surface_partial(mcf_snowplan *plan, double *sum, double *count)
 int mcf_snowplan_prepare_chunk(mcf_snowplan *plan, int32_t chunk, const double *ext, int32_t halo_north,
                                int32_t halo_south, double surface_mean, double *tpic_sum, double *tpic_count);
 int mcf_snowplan_run_chunk(mcf_snowplan *plan, int32_t chunk, double tpic_mean, mcf_snowdriver_out *out);
+/* applycpp3 (src/microclimfCpp.cpp:5553-5588) of the totalSWE series of the chunk just run, straight from the device:
+ * result / count [steps of that chunk] as mcf_applycpp3 gives them.  `.runmicrosnow1` decides snow / no-snow days on the
+ * per-step minimum and maximum of totalSWE (R/internal.R:3592-3594); row-block ranks combine them with one all-reduce. */
+int mcf_snowplan_apply3(mcf_snowplan *plan, int32_t chunk, int32_t fun, double *result, double *count);
 
 /* applycpp3 (src/microclimfCpp.cpp:5553-5588; `.runmicrosnow1/2` use it on totalSWE, R/internal.R:3592-3593):
  * reduction of a [rows,cols,tsteps] array over space, per time step, skipping NA.  fun: 0 mean, 1 sum,

@@ -170,7 +170,7 @@ EXPORTS = (
     "mcf_precompute_terrain", "mcf_runbioclim1", "mcf_runbioclim2", "mcf_runbioclim3", "mcf_runbioclim4",
     "mcf_snowenv_from_name", "mcf_gridmodelsnow1", "mcf_gridmodelsnow2", "mcf_gridmicrosnow1",
     "mcf_gridmicrosnow2", "mcf_snowmodel1", "mcf_applycpp3",
-    "mcf_snowplan_create", "mcf_snowplan_destroy", "mcf_snowplan_chunks", "mcf_snowplan_surface", "mcf_snowplan_handover",
+    "mcf_snowplan_create", "mcf_snowplan_destroy", "mcf_snowplan_chunks", "mcf_snowplan_surface", "mcf_snowplan_handover", "mcf_snowplan_apply3",
     "mcf_snowplan_surface_partial", "mcf_snowplan_prepare_chunk", "mcf_snowplan_run_chunk",
     "mcf_bigleaf", "mcf_soilm", "mcf_pointmprocess", "mcf_weatherhgt", "mcf_man", "mcf_pointmodelsnow", "mcf_canintfrac", "mcf_meltmu", "mcf_meltmu2", "mcf_tpicalc",
     "mcf_nc_create", "mcf_nc_write_host", "mcf_nc_write_plan", "mcf_nc_close",
@@ -303,6 +303,8 @@ def load() -> C.CDLL:
     lib.mcf_snowplan_chunks.argtypes = [P]
     lib.mcf_snowplan_surface.restype = C.c_int
     lib.mcf_snowplan_surface.argtypes = [P, c_double_p]
+    lib.mcf_snowplan_apply3.restype = C.c_int
+    lib.mcf_snowplan_apply3.argtypes = [P, C.c_int32, C.c_int32, c_double_p, c_double_p]
     lib.mcf_snowplan_handover.restype = C.c_int
     lib.mcf_snowplan_handover.argtypes = [P, c_double_p]
     lib.mcf_snowplan_surface_partial.restype = C.c_int

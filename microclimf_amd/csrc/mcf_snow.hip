@@ -924,6 +924,8 @@ struct mcf_snowplan {
     Downloader dl;
     int prepared = -1;
     double t_terrain = 0, t_model = 0;   // ms, MCF_TIMING
+    mcf::TerrainWork twork;              // terrain_device's scratch, kept across the chunks
+    ~mcf_snowplan() { twork.release(); }
 };
 
 namespace {
@@ -1094,7 +1096,7 @@ extern "C" int mcf_snowplan_prepare_chunk(mcf_snowplan* sp, int32_t ch, const do
     td.rows = rows; td.cols = cols; td.halo_north = hn; td.halo_south = hs; td.row0 = sp->row0; td.rows_total = sp->rows_total;
     td.d_dtm = d_z; td.res = sp->res; td.zref = sp->zref; td.agg = sp->ss; td.aspect_na = 180.0;
     td.d_slope = sp->d_slope; td.d_aspect = sp->d_aspect; td.d_hor = sp->d_hor; td.d_svfa = sp->d_svf; td.d_wsa = sp->d_wsa;
-    if ((rc = mcf::terrain_device(td))) return rc;
+    if ((rc = mcf::terrain_device(td, &sp->twork))) return rc;
     const unsigned gridN = (unsigned)((N + 255) / 256);
     hipLaunchKernelGGL(k_mask2, dim3(gridN), dim3(256), 0, nullptr, sp->d_dtm, N, sp->d_slope, sp->d_aspect);
     // topographic positioning index (int:2589-2592, 2471-2485)
@@ -1190,6 +1192,33 @@ extern "C" int mcf_snowmodel1(const mcf_snowdriver_in* in, mcf_snowdriver_out* o
     return MCF_OK;
 }
 
+// applycpp3 over device-resident data: [N][tsteps] -> result / count [tsteps] on the host
+static int apply3_device(const double* d_a, int64_t N, int64_t tsteps, int fun, double* result, double* count) {
+    int rc;
+    Bufs b;
+    double *d_r, *d_c = nullptr;
+    if ((rc = b.alloc((void**)&d_r, tsteps * 8))) return rc;
+    if (count && (rc = b.alloc((void**)&d_c, tsteps * 8))) return rc;
+    // enough workgroups to keep the memory system busy whatever the ratio of cells to steps
+    int parts = (int)std::min<int64_t>(64, std::max<int64_t>(1, N / 16384));
+    if (tsteps * parts < 2048) parts = (int)std::min<int64_t>(64, std::max<int64_t>(parts, (2048 + tsteps - 1) / tsteps));
+    double* d_ws;
+    if ((rc = b.alloc((void**)&d_ws, tsteps * parts * 16))) return rc;
+    hipLaunchKernelGGL(k_apply3_part, dim3((unsigned)parts, (unsigned)tsteps), dim3(256), 0, nullptr, d_a, N, fun, parts, d_ws);
+    hipLaunchKernelGGL(k_apply3_fin, dim3((unsigned)((tsteps + 255) / 256)), dim3(256), 0, nullptr, d_ws, tsteps, fun, parts, d_r,
+                       d_c);
+    S_TRY(hipGetLastError());
+    S_TRY(hipMemcpy(result, d_r, (size_t)tsteps * 8, hipMemcpyDeviceToHost));
+    if (count) S_TRY(hipMemcpy(count, d_c, (size_t)tsteps * 8, hipMemcpyDeviceToHost));
+    return MCF_OK;
+}
+extern "C" int mcf_snowplan_apply3(mcf_snowplan* sp, int32_t chunk, int32_t fun, double* result, double* count) {
+    if (!sp || !result || fun < 0 || fun > 3) return mcf::api_fail(MCF_ERR_ARG, "bad mcf_snowplan_apply3 argument");
+    if (chunk < 0 || chunk >= sp->nchunks) return mcf::api_fail(MCF_ERR_ARG, "chunk out of range");
+    S_TRY(hipSetDevice(sp->device));
+    const int ns = std::min(sp->chunk, sp->T - chunk * sp->chunk);
+    return apply3_device(sp->a.sdepc, sp->N, ns, fun, result, count);     // sdepc holds totalSWE after the redistribution
+}
 extern "C" int mcf_applycpp3(const double* a, int64_t rows, int64_t cols, int64_t tsteps, int32_t fun, double* result,
                              double* count, int32_t device) {
     if (!a || !result || rows <= 0 || cols <= 0 || tsteps <= 0 || tsteps > 65535 || fun < 0 || fun > 3)
@@ -1200,23 +1229,8 @@ extern "C" int mcf_applycpp3(const double* a, int64_t rows, int64_t cols, int64_
     if ((rc = check_room(N * tsteps * 8))) return rc;
     Bufs b;
     const double* d_a;
-    double *d_r, *d_c = nullptr;
     UP(d_a, a, N * tsteps);
-    if ((rc = b.alloc((void**)&d_r, tsteps * 8))) return rc;
-    if (count && (rc = b.alloc((void**)&d_c, tsteps * 8))) return rc;
-    // enough workgroups to keep the memory system busy whatever the ratio of cells to steps
-    int parts = (int)std::min<int64_t>(64, std::max<int64_t>(1, N / 16384));
-    if (tsteps * parts < 2048) parts = (int)std::min<int64_t>(64, std::max<int64_t>(parts, (2048 + tsteps - 1) / tsteps));
-    double* d_ws;
-    if ((rc = b.alloc((void**)&d_ws, tsteps * parts * 16))) return rc;
-    hipLaunchKernelGGL(k_apply3_part, dim3((unsigned)parts, (unsigned)tsteps), dim3(256), 0, nullptr, d_a, N, (int)fun, parts,
-                       d_ws);
-    hipLaunchKernelGGL(k_apply3_fin, dim3((unsigned)((tsteps + 255) / 256)), dim3(256), 0, nullptr, d_ws, tsteps, (int)fun,
-                       parts, d_r, d_c);
-    S_TRY(hipGetLastError());
-    S_TRY(hipMemcpy(result, d_r, (size_t)tsteps * 8, hipMemcpyDeviceToHost));
-    if (count) S_TRY(hipMemcpy(count, d_c, (size_t)tsteps * 8, hipMemcpyDeviceToHost));
-    return MCF_OK;
+    return apply3_device(d_a, N, tsteps, (int)fun, result, count);
 }
 
 // k_tpi_fine's result divided by its raster mean

@@ -14,6 +14,14 @@ struct TerrainDev {
                                        // marshaller (R/internal.R:1136), 180 for the snow driver (R/internal.R:2570)
     double *d_slope, *d_aspect, *d_hor, *d_svfa, *d_wsa;   // device outputs or null
 };
+// Scratch of terrain_device kept by a caller that runs it repeatedly (the snow plan's 5-day refresh): three buffers grown
+// on demand, never shrunk, released by release().  Without one, terrain_device allocates and frees its scratch per call
+// (hundreds of MB at 4096 columns: tens of milliseconds of hipMalloc / hipFree).
+struct TerrainWork {
+    void* p[3] = {nullptr, nullptr, nullptr};
+    int64_t cap[3] = {0, 0, 0};
+    void release();
+};
 // All launches on the null stream; returns after the device has finished.
-int terrain_device(const TerrainDev& t);
+int terrain_device(const TerrainDev& t, TerrainWork* work = nullptr);
 }  // namespace mcf

@@ -221,7 +221,14 @@ struct DevBufs {
 // Device-level entry: `t.d_dtm` and every output pointer are device memory.  Used by
 // mcf_precompute_terrain (host arrays) and by the snow driver's 5-day terrain refresh (mcf_snow.hip).
 namespace mcf {
-int terrain_device(const TerrainDev& t) {
+void TerrainWork::release() {
+    for (int i = 0; i < 3; ++i) {
+        if (p[i]) (void)hipFree(p[i]);
+        p[i] = nullptr;
+        cap[i] = 0;
+    }
+}
+int terrain_device(const TerrainDev& t, TerrainWork* work) {
     const int64_t rows_total = t.rows_total > 0 ? t.rows_total : t.rows;
     const int64_t row0 = t.rows_total > 0 ? t.row0 : 0;
     const int s = t.agg > 0 ? t.agg : 10;
@@ -233,8 +240,22 @@ int terrain_device(const TerrainDev& t) {
     const int64_t N = g.rows * g.cols, NB = g.RB * g.cols;
     DevBufs db;
     int rc;
+    // scratch buffer `slot` of at least `bytes`: the caller's workspace if there is one, else released on return
+    auto scratch = [&](int slot, void** out, int64_t bytes) -> int {
+        if (!work) return db.alloc(out, bytes);
+        if (work->cap[slot] < bytes) {
+            if (work->p[slot]) (void)hipFree(work->p[slot]);
+            work->p[slot] = nullptr;
+            work->cap[slot] = 0;
+            hipError_t e = hipMalloc(&work->p[slot], (size_t)bytes);
+            if (e != hipSuccess) return mcf::api_fail(MCF_ERR_NOMEM, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+            work->cap[slot] = bytes;
+        }
+        *out = work->p[slot];
+        return MCF_OK;
+    };
     double* d_Z;
-    if ((rc = db.alloc((void**)&d_Z, NB * 8))) return rc;
+    if ((rc = scratch(0, (void**)&d_Z, NB * 8))) return rc;
     hipLaunchKernelGGL(k_prep, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, nullptr, t.d_dtm, d_Z, NB, 1.0 / t.res);
     const unsigned gridN = (unsigned)((N + 255) / 256);
     if (t.d_hor || t.d_svfa) {
@@ -254,8 +275,8 @@ int terrain_device(const TerrainDev& t) {
         const int64_t nI = I1 - I0 + 1;
         const int64_t e0 = I0 * s, e1 = std::min<int64_t>((I1 + 1) * s, rows_total), ne = e1 - e0;
         double *d_W, *d_C;
-        if ((rc = db.alloc((void**)&d_W, 16 * ne * g.cols * 8))) return rc;
-        if ((rc = db.alloc((void**)&d_C, 16 * nI * nJ * 8))) return rc;
+        if ((rc = scratch(1, (void**)&d_W, 16 * ne * g.cols * 8))) return rc;
+        if ((rc = scratch(2, (void**)&d_C, 16 * nI * nJ * 8))) return rc;
         int64_t M = ne * g.cols;
         hipLaunchKernelGGL(k_windcoef, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, nullptr, d_Z, g, t16,
                            t.zref / t.res, e0, ne, d_W);

@@ -589,7 +589,7 @@ class SnowPlan:
     place the block in the raster."""
 
     def __init__(self, obstime, climdata, pointm, vegp, other, snowenv, dtm, res, tfact=0.02, *, chunk_steps=120,
-                 row0=0, rows_total=0, device=0):
+                 row0=0, rows_total=0, device=0, keep_results=True):
         self._lib = _abi.load()
         R, Cc = np.shape(vegp["pai"])
         oth = dict(other)
@@ -605,12 +605,16 @@ class SnowPlan:
         _abi.check(self._lib.mcf_snowplan_create(C.byref(din), int(row0), int(rows_total), device, C.byref(self._p)))
         self.rows, self.cols, self.tsteps = R, Cc, self._m.tsteps
         self.chunks = int(self._lib.mcf_snowplan_chunks(self._p))
+        self._chunk_steps = int(chunk_steps) if chunk_steps else 120
         self._out = _abi.SnowDriverOut()
         self.result = {}
-        for f in _abi.SNOWDRIVER_OUT:
-            a = np.empty((R, Cc, self.tsteps), dtype=np.float64, order="F")
-            self.result[f] = a
-            setattr(self._out, f, a.ctypes.data_as(_abi.c_double_p))
+        for f in _abi.SNOWDRIVER_OUT:          # keep_results=False: the series stay on the device (no [rows, cols, tsteps] host arrays)
+            if keep_results:
+                a = np.empty((R, Cc, self.tsteps), dtype=np.float64, order="F")
+                self.result[f] = a
+                setattr(self._out, f, a.ctypes.data_as(_abi.c_double_p))
+            else:
+                setattr(self._out, f, None)
 
     def close(self):
         if getattr(self, "_p", None) is not None and self._p.value:
@@ -629,8 +633,11 @@ class SnowPlan:
     def __exit__(self, *exc):
         self.close()
 
-    def surface(self) -> np.ndarray:
-        a = np.empty((self.rows, self.cols), dtype=np.float64, order="F")
+    def surface(self, out=None) -> np.ndarray:
+        """dtm + ground snow depth of the own rows; `out`: a column-major [rows, cols] array to fill (reused across chunks)"""
+        a = np.empty((self.rows, self.cols), dtype=np.float64, order="F") if out is None else out
+        if a.shape != (self.rows, self.cols) or not a.flags.f_contiguous:
+            raise ValueError("out must be a column-major [rows, cols] array")
         _abi.check(self._lib.mcf_snowplan_surface(self._p, a.ctypes.data_as(_abi.c_double_p)))
         return a
 
@@ -639,6 +646,15 @@ class SnowPlan:
         a = np.empty((self.rows, self.cols), dtype=np.float64, order="F")
         _abi.check(self._lib.mcf_snowplan_handover(self._p, a.ctypes.data_as(_abi.c_double_p)))
         return a
+
+    def apply3(self, chunk: int, fun_name: str):
+        """applycpp3 of the chunk's totalSWE on the device: (result, non-NA counts), each [steps of the chunk]"""
+        fun = {"mean": 0, "sum": 1, "max": 2, "min": 3}[fun_name]
+        n = min(self._chunk_steps, self.tsteps - chunk * self._chunk_steps)
+        r, c = np.empty(n), np.empty(n)
+        _abi.check(self._lib.mcf_snowplan_apply3(self._p, int(chunk), fun, r.ctypes.data_as(_abi.c_double_p),
+                                                 c.ctypes.data_as(_abi.c_double_p)))
+        return r, c
 
     def surface_partial(self):
         s, n = C.c_double(), C.c_double()

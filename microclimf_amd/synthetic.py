@@ -255,13 +255,13 @@ def layered(args: dict, layers: int, cover_days: int | None = None, seed=SEED):
 def snow_workload(rows: int, cols: int, tsteps: int, seed=SEED, array_forcing: bool = False, start_doy: int = 15,
                   cold: float = 11.0, lat: float = 57.0, lon: float = -4.0, zref: float = 2.0,
                   hgt_range=(0.05, 3.0), na_frac: float = 0.02, bare_frac: float = 0.1, snowenv: str = "Alpine",
-                  year: int = 2023):
+                  year: int = 2023, row0: int = 0, rows_total: int | None = None):
     """Seeded inputs of the snow branch: the argument lists of gridmodelsnow1/2
     (src/microclimfCpp.cpp:4172, 4426).  Winter calendar, temperatures straddling 0 and 2 degC so
     that snowfall, rain-on-snow, melt and snow-free steps all occur; cells start with 0 - 0.6 m of
     snow (a fifth of them bare) and vegetation from below to well above the pack."""
     obstime, clim, pm = forcing_vectors(tsteps, lat, lon, year, start_doy, seed, cold)
-    vegp0, soilc, _ = rasters(rows, cols, 0, None, seed, 0.05, hgt_range, bare_frac=bare_frac, na_frac=na_frac,
+    vegp0, soilc, _ = rasters(rows, cols, row0, rows_total, seed, 0.05, hgt_range, bare_frac=bare_frac, na_frac=na_frac,
                               variety=True)
     k = np.arange(tsteps, dtype=np.uint64) + np.uint64((start_doy - 1) * 24)
     h = obstime["hour"]
@@ -275,9 +275,9 @@ def snow_workload(rows: int, cols: int, tsteps: int, seed=SEED, array_forcing: b
               "Tc": np.minimum(clim["temp"] - 0.8 + 0.004 * clim["swdown"], 0.5),
               "RswabsG": 0.2 * clim["swdown"], "RlwabsG": 0.9 * 0.97 * clim["lwdown"], "umu": pm["umu"],
               "tr": np.full(tsteps, 0.5)}
-    i = np.arange(rows, dtype=np.uint64)[:, None]
+    i = (np.arange(rows, dtype=np.uint64) + np.uint64(row0))[:, None]
     j = np.arange(cols, dtype=np.uint64)[None, :]
-    idx = i + np.uint64(rows) * j
+    idx = i + np.uint64(rows if rows_total is None else rows_total) * j          # global cell index: blocks of one raster agree
 
     def U(f, lo=0.0, hi=1.0):
         return lo + (hi - lo) * uniform(f, idx, seed)

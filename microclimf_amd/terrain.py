@@ -79,27 +79,40 @@ def exchange_halo(block: np.ndarray, rank: int, world: int, halo: int = HALO, de
     counts[rank] = rows
     dist.all_reduce(counts)
     counts = [int(v) for v in counts.tolist()]
-    t = torch.from_numpy(np.ascontiguousarray(block)).to(device)      # [rows, cols] row-major
+    block = np.asarray(block)
+    # only the boundary rows travel: row slices as row-major tensors (a raster block arrives column-major, so this is the one
+    # transposing copy, of `halo` rows, not of the block)
     ops, recv_n, recv_s = [], None, None
     if rank > 0:
         hn = min(halo, counts[rank - 1])
         recv_n = torch.empty((hn, cols), dtype=torch.float64, device=device)
         ops.append(dist.P2POp(dist.irecv, recv_n, rank - 1))
-        ops.append(dist.P2POp(dist.isend, t[:min(halo, rows)].contiguous(), rank - 1))
+        ops.append(dist.P2POp(dist.isend, torch.from_numpy(np.ascontiguousarray(block[:min(halo, rows)])).to(device), rank - 1))
     if rank < world - 1:
         hs = min(halo, counts[rank + 1])
         recv_s = torch.empty((hs, cols), dtype=torch.float64, device=device)
-        ops.append(dist.P2POp(dist.isend, t[max(rows - halo, 0):].contiguous(), rank + 1))
+        ops.append(dist.P2POp(dist.isend, torch.from_numpy(np.ascontiguousarray(block[max(rows - halo, 0):])).to(device), rank + 1))
         ops.append(dist.P2POp(dist.irecv, recv_s, rank + 1))
     for w in dist.batch_isend_irecv(ops):
         w.wait()
-    parts, hn, hs = [], 0, 0
-    if recv_n is not None:
-        parts.append(recv_n.cpu().numpy()); hn = recv_n.shape[0]
-    parts.append(np.asarray(block))
-    if recv_s is not None:
-        parts.append(recv_s.cpu().numpy()); hs = recv_s.shape[0]
-    return np.concatenate(parts, axis=0), hn, hs
+    hn = 0 if recv_n is None else recv_n.shape[0]
+    hs = 0 if recv_s is None else recv_s.shape[0]
+    return assemble_halo(block, None if recv_n is None else recv_n.cpu().numpy(), None if recv_s is None else recv_s.cpu().numpy()), hn, hs
+
+
+def assemble_halo(block, north=None, south=None, out=None) -> np.ndarray:
+    """[north; block; south] as ONE column-major array (what mcf_precompute_terrain / mcf_snowplan_prepare_chunk take): the
+    block is copied column by column, never transposed.  `out`: an array of that shape to reuse."""
+    hn = 0 if north is None else north.shape[0]
+    hs = 0 if south is None else south.shape[0]
+    rows, cols = block.shape
+    ext = np.empty((hn + rows + hs, cols), dtype=np.float64, order="F") if out is None else out
+    if hn:
+        ext[:hn] = north
+    ext[hn:hn + rows] = block
+    if hs:
+        ext[hn + rows:] = south
+    return ext
 
 
 def precompute_terrain_tiled(block, res, zref, rank, world, row0, rows_total, *, agg=10, what=WHAT,

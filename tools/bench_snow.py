@@ -1,0 +1,190 @@
+"""bench.py --config 4: BASELINE.json configs[4] — 4096 x 4096 cells x 8760 hourly steps with the snow branch, the raster
+dealt to 8 ranks in row blocks (strong scaling; with fewer GPUs every rank runs its block of the 8-block partition).
+
+One "step" = one simulated year of a rank's block through the reference's snow pipeline, device-resident:
+  per 5-day chunk (R/internal.R:2553-2617 `.snowmodel1`, 73 chunks):
+    snow surface of the own rows -> halo rows point-to-point to the neighbouring ranks (RCCL send/recv; the terrain stencil
+    and `.tpicalc`'s block means reach +-128 rows), (sum, count) all-reduce of the surface
+    -> terrain refresh from dtm + snow depth (slope, aspect, 24 horizons, sky view, 8 wind-shelter maps), tpic
+    -> (sum, count) all-reduce of tpic -> gridmodelsnow1 on the chunk (k_snowmodel) -> redistribution, hand-over
+    -> applycpp3 min / max of totalSWE per step on the device, all-reduced over the ranks (R/internal.R:3592-3593)
+    -> snowdaysfun: the chunk's no-snow days -> the grid solver (k_solve) on exactly those days, into the output ring
+  (gridmicrosnow1, the correction of the solver's output on snow days, has a host-pointer ABI only and is not part of
+  the timed pipeline; tools/snow_rate.py times it.)
+value = valid cells x 8760 / seconds: every cell-step went through the snowpack model, and through the solver unless its
+day had snow everywhere."""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def run_snow_config(args, world, rank, local_rank):
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    use_dist = world > 1 or os.environ.get("MCF_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build_library()
+    if use_dist:
+        dist.barrier()
+    from microclimf_amd import synthetic
+    from microclimf_amd.api import Plan
+    from microclimf_amd.distributed import allreduce_apply3, allreduce_max, allreduce_sum, allreduce_twi_mean, row_block
+    from microclimf_amd.snow import SnowPlan, snowdaysfun
+    from microclimf_amd.terrain import assemble_halo, exchange_halo
+
+    rows_total, cols, T = args.rows, args.cols, args.tsteps
+    nblocks = max(world, args.share or 0)
+    row0, rows = row_block(rank, nblocks, rows_total)
+    exchange_ok = nblocks == world
+    ndays, chunk_days = T // 24, 5
+    t0 = time.perf_counter()
+    sw = synthetic.snow_workload(rows, cols, T, cold=3.0, zref=3.5, row0=row0, rows_total=rows_total, start_doy=1)
+    _, _, dtm = synthetic.rasters(rows, cols, row0, rows_total)
+    dtm = np.where(np.isnan(sw["vegp"]["hgt"]), np.nan, dtm)
+    from microclimf_amd.terrain import HALO
+    halo_n = halo_s = None
+    hn_ = hs_ = 0
+    surf_buf = np.empty((rows, cols), order="F")
+    ext_buf = None
+    if not exchange_ok:
+        # a rank's share without its neighbours: the halo rows are the neighbouring blocks' snow-FREE surface (generated from
+        # the seeded DTM), not their snow surface — the exchange itself only runs when every block has its rank
+        hn_, hs_ = min(HALO, row0), min(HALO, rows_total - (row0 + rows))
+        if hn_:
+            halo_n = synthetic.rasters(hn_, cols, row0 - hn_, rows_total)[2]
+        if hs_:
+            halo_s = synthetic.rasters(hs_, cols, row0 + rows, rows_total)[2]
+        ext_buf = np.empty((hn_ + rows + hs_, cols), order="F")
+    a = synthetic.workload(rows, cols, T, reqhgt=args.reqhgt, row0=row0, rows_total=rows_total, zref=3.5, hgt_range=(0.05, 3.0))
+    setup_s = time.perf_counter() - t0
+    sp = SnowPlan(sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"], sw["other"], sw["snowenv"], dtm, 1.0, 0.02,
+                  row0=row0, rows_total=rows_total, device=local_rank, keep_results=False)
+    plan = Plan(**a, ring_days=chunk_days, ring_slots=2, device=local_rank)
+    s, n = plan.twi_partial()
+    plan.set_twi_mean(allreduce_twi_mean(s, float(n)))
+    valid = plan.valid_cells
+    stats = {"solver_days": 0, "snow_days": 0}
+
+    def fence():
+        plan.sync()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    stage_s = {}
+    timing = os.environ.get("MCF_BENCH_STAGES") == "1"
+
+    def lap(name, t_last):
+        if not timing:
+            return t_last
+        plan.sync()
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        stage_s[name] = stage_s.get(name, 0.0) + now - t_last
+        return now
+
+    def one_year():
+        slot = 0
+        for ch in range(sp.chunks):
+            tl = time.perf_counter()
+            surf = sp.surface(out=surf_buf)
+            if exchange_ok:
+                ext, hn, hs = exchange_halo(surf, rank, world)
+            else:
+                ext, hn, hs = assemble_halo(surf, halo_n, halo_s, out=ext_buf), hn_, hs_
+            tl = lap("surface+halo", tl)
+            ss, sn = sp.surface_partial()
+            smean = allreduce_twi_mean(ss, sn)                      # (sum, count) -> mean over the whole raster
+            ts, tn = sp.prepare_chunk(ch, ext if (hn or hs) else None, hn, hs, smean)
+            tl = lap("terrain+tpic", tl)
+            sp.run_chunk(ch, allreduce_twi_mean(ts, tn))
+            tl = lap("snowmodel+redistribute", tl)
+            mx, cmx = sp.apply3(ch, "max")
+            mn, cmn = sp.apply3(ch, "min")
+            mx, mn = allreduce_apply3(mx, cmx, "max"), allreduce_apply3(mn, cmn, "min")
+            days = snowdaysfun(mx, mn)
+            tl = lap("apply3", tl)
+            d0 = ch * chunk_days
+            nos = days["nosnowdays"]
+            stats["snow_days"] += int(days["snowdays"].sum())
+            k = 0
+            while k < len(nos):                                       # runs of consecutive no-snow days -> one launch each
+                if not nos[k]:
+                    k += 1
+                    continue
+                e = k
+                while e < len(nos) and nos[e]:
+                    e += 1
+                if d0 + k < ndays:
+                    nd = min(e, ndays - d0) - k
+                    plan.run_days(d0 + k, nd, slot)
+                    stats["solver_days"] += nd
+                k = e
+            tl = lap("solver", tl)
+            slot = (slot + 1) % 2
+
+    for _ in range(args.warmup):
+        one_year()
+    fence()
+    stats["solver_days"] = stats["snow_days"] = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_year()
+    fence()
+    dt = allreduce_max(time.perf_counter() - t0)
+    valid_all = allreduce_sum(float(valid))
+    value = valid_all * ndays * 24 * args.steps / dt
+    if rank == 0:
+        sd = stats["solver_days"] / max(args.steps, 1)
+        alg = valid_all * 24 * (ndays * 40.0 + sd * 80.05) * args.steps          # 5 snow series + 10 solver outputs per cell-step
+        line = {
+            "metric": "cell-steps/s", "value": value, "unit": "cell-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"{rows_total}x{cols} synthetic DTM in {nblocks} row blocks, {world} of them solved by {world} GPU(s), {T} hourly "
+                            "steps, snow branch: `.snowmodel1` chunk loop (terrain refresh from dtm + snow every 5 days, gridmodelsnow1, "
+                            "`.tpicalc` redistribution) + applycpp3 min/max of totalSWE + the grid solver on the no-snow days "
+                            "[BASELINE.json configs[4]]",
+                "baseline_config": 4, "rows_per_gpu": rows, "cols": cols, "tsteps": T, "valid_cells": int(valid_all),
+                "solver_days_per_year": sd, "snow_days_per_year": stats["snow_days"] / max(args.steps, 1),
+                "halo": "RCCL send/recv of 128 surface rows per neighbour and chunk" if exchange_ok and world > 1 else
+                        "generated, not exchanged: the neighbouring blocks' snow-free surface (a rank's share of the partition "
+                        "without its neighbours)" if not exchange_ok else "single block",
+                "collectives": "per chunk: 2 (sum, count) all-reduces + min / max all-reduce of [120] doubles; once: twi (sum, count)",
+                "not_timed": "gridmicrosnow1 (host-pointer ABI only)",
+                "sink": "solver: HBM ring (2 slots x 5 days); snow series: chunk buffers on the device, no D2H",
+            },
+            "input_setup_s": setup_s,
+            "stage_seconds": stage_s or None,
+            "roofline": {"bound": "fp64_valu", "achieved": alg / dt / 1e9, "peak": 8000.0 * world, "unit": "GB/s",
+                         "frac": alg / dt / 1e9 / (8000.0 * world), "traffic": None, "kernel": "pipeline: k_snowmodel + terrain + k_solve",
+                         "frac_is": "algorithmic bytes (40 B per snow cell-step + 80 B per solver cell-step) / time / 8 TB/s per GPU"},
+        }
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
+    plan.close()
+    sp.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
