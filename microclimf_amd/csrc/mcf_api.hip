@@ -786,24 +786,26 @@ int mcf_plan_run_days(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot) {
     bool soil_daily = !p->af && !p->day_soil_daily.empty();
     for (int d = day0; soil_daily && d < day0 + ndays; ++d)
         if (!p->day_soil_daily[(size_t)d]) soil_daily = false;
+    static const bool no_persist = getenv("MCF_NO_PERSISTENT_TILES") != nullptr;     // A/B runs
+    const bool persistent = !no_persist && p->layers <= 1;
     auto launch = [&]() {
         if (fast) {
             (void)hipMemsetAsync(p->d_fix_count, 0, 4, p->stream);
             a.tile_list = p->n_slow > 0 ? p->d_tiles_fast : nullptr;
             a.ntiles_launch = p->n_fast;
-            mcf::launch_solve(a, p->cpb, false, false, true, soil_daily, p->stream);
+            mcf::launch_solve(a, p->cpb, false, false, true, soil_daily, persistent, p->stream);
             ++p->fast_launches;
             if (p->n_slow > 0) {
                 ++p->slow_launches;
                 a.tile_list = p->d_tiles_slow;
                 a.ntiles_launch = p->n_slow;
-                mcf::launch_solve(a, p->cpb, false, false, false, soil_daily, p->stream);
+                mcf::launch_solve(a, p->cpb, false, false, false, soil_daily, false, p->stream);
             }
         } else {
             a.tile_list = nullptr;
             a.ntiles_launch = 0;
             ++p->slow_launches;
-            mcf::launch_solve(a, p->cpb, p->af, p->bg, false, soil_daily, p->stream);
+            mcf::launch_solve(a, p->cpb, p->af, p->bg, false, soil_daily, false, p->stream);
         }
     };
     if (p->ktiming) {

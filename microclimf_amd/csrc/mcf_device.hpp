@@ -557,14 +557,13 @@ __device__ __forceinline__ void derive_time_af_pass2(TimeVals& t, double gp, dou
 // ---- accessors ----------------------------------------------------------------
 // Cell constants in LDS, laid out [field][cells_per_block]; `dirs` holds the 24
 // horizon + 8 wind-shelter values [dir][cells_per_block].
+// One pointer per lane: the tile's image is [CF_COUNT cell fields, then 24 horizon + 8 wind-shelter rows][cells_per_block].
 template <int CPB>
 struct CellLds {
-    const double* f;
-    const double* dirs;
-    int c;
-    __device__ __forceinline__ double operator()(int field) const { return f[field * CPB + c]; }
-    __device__ __forceinline__ double hor(int s) const { return dirs[s * CPB + c]; }
-    __device__ __forceinline__ double wsa(int w) const { return dirs[(24 + w) * CPB + c]; }
+    const double* p;   // image + the lane's cell
+    __device__ __forceinline__ double operator()(int field) const { return p[field * CPB]; }
+    __device__ __forceinline__ double hor(int s) const { return p[(CF_COUNT + s) * CPB]; }
+    __device__ __forceinline__ double wsa(int w) const { return p[(CF_COUNT + 24 + w) * CPB]; }
 };
 // A day's time table in LDS, laid out [field][24].
 struct TimeLds {

@@ -85,6 +85,7 @@ struct SolveArgs {
     // tiles of this launch: tile_list[ntiles_launch] (null: tiles 0 .. ntiles_launch-1; ntiles_launch <= 0: all)
     const int32_t* tile_list;
     int64_t ntiles_launch;
+    int32_t tiles_per_wg;   // persistent tiles: consecutive positions of the sequence solved by one workgroup (set by the launcher)
     // fast-clamp launches: tiles in which a canary tripped, redone by k_solve_fix for the launch's days
     int32_t* fix_count;
     int32_t* fix_list;      // [fix_cap]
@@ -148,7 +149,9 @@ void launch_mxtc(const double* tc, int64_t N, int nsteps, double* mx, hipStream_
 // fix_list; the caller zeroes *fix_count on the stream first); the tiles and days handed over must be REGULAR
 // soil_daily: every day of the launch carries kSoilDaily (vector forcing): the per cell-day soil state is computed once per
 // tile and day and shared through LDS
-void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, bool fast, bool soil_daily, hipStream_t s);
+// persistent: a workgroup may solve several consecutive tiles, prefetching the next one's constants (see solve_tile PT)
+void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, bool fast, bool soil_daily, bool persistent,
+                  hipStream_t s);
 // out[t] = 1 if every valid cell of tile t (cpb consecutive cells) is FL_REGULAR in all layers
 void launch_tile_regular(const double* cellc, int64_t N, int layers, int cpb, uint8_t* out, hipStream_t s);
 void launch_belowground(const BelowArgs& a, hipStream_t s);

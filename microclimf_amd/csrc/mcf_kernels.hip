@@ -57,6 +57,23 @@
 #ifndef MCF_EXPERIMENT_NOPUSH
 #define MCF_EXPERIMENT_NOPUSH 0
 #endif
+#ifndef MCF_PT_UNPIN_LOG
+#define MCF_PT_UNPIN_LOG 1   // the persistent-tile variant carries more uniform state: log's 7 coefficient pairs are not pinned there
+#endif
+#ifndef MCF_EXPERIMENT_LDSPAD
+#define MCF_EXPERIMENT_LDSPAD 0
+#endif
+#ifndef MCF_PERSISTENT_TILES
+// 1 (experiment, NOT shipped): a workgroup walks several tiles and streams the next tile's constants into a second LDS
+// image by LDS-DMA while it computes (solve_tile PT).  It does what it is built for — the fixed cost of a launch drops from
+// 0.63 to 0.45 ms at 1024^2 with 4 tiles per workgroup — and passes every parity test, but the extra uniform state costs
+// the day loop 59 instead of 23 SGPR-spill lane moves and 36 B of scratch: +6 % per day, a net 3-4 % LOSS same-box
+// (10-day launches at 1024^2: 9.97 vs 9.59 ms; 7-day launches at 4096^2: 119.4 vs 115.8 ms).  Two lessons kept in the
+// code: tiles of one workgroup must be strided so that the workgroups in flight sit on ADJACENT tiles (walking consecutive
+// tiles lost another 20 %: the L2 no longer merges the neighbours' partial lines), and a workgroup of K tiles needs >= 24
+// rounds over the chip or the last round eats the gain.
+#define MCF_PERSISTENT_TILES 0
+#endif
 #ifndef MCF_FAST_CLAMPS
 #define MCF_FAST_CLAMPS 1   // vector forcing: waves of REGULAR lanes run the min / max form of the clamps (mcf_device.hpp `cap`)
 #endif
@@ -477,12 +494,24 @@ constexpr int solve_threads(int cpb) { return ((cpb * 24 + 255) / 256) * 256; }
 //   F   fast clamps (mcf_device.hpp `cap`): only for tiles / days the host has classified REGULAR; a wave whose canary
 //       trips appends (tile, day) to a.fix_list and k_solve_fix redoes that tile-day with F = false afterwards
 //   SSREQ  per cell-day soil state shared through LDS (mcf_device.hpp SoilDay): only for launches whose days are all kSoilDaily
-template <int CPB, int AF, bool BG, bool F, bool SSREQ>   // AF: 0 vector forcing, 1 array forcing, 2 coarse array forcing
-__device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t tile, const int day0, const int ndays, const int rot) {
+//   PT   persistent tiles: the workgroup solves `nseq` tiles one after the other (positions first .. first + nseq - 1 of the
+//        launch's tile sequence) and the NEXT tile's constants stream into a second LDS image by LDS-DMA while the current
+//        tile computes, so that only the first tile pays the ~7 us of a cold start (9 % of a 7-day launch).  Static
+//        vegetation, vector forcing, reqhgt >= 0 and ndays >= 3 only.  PT = false: `first` IS the tile, nseq = 1.
+template <int CPB, int AF, bool BG, bool F, bool SSREQ, bool PT>   // AF: 0 vector forcing, 1 array forcing, 2 coarse array forcing
+__device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t first, const int64_t seq_stride, const int nseq,
+                                           const int day0, const int ndays, const int rot) {
     constexpr int NT = solve_threads(CPB);
-    __shared__ double s_cell[CF_COUNT * CPB];
-    __shared__ double s_dirs[kCellDirs * CPB];
+    constexpr int TILE_DOUBLES = (CF_COUNT + kCellDirs) * CPB;      // a tile's LDS image: [CF_COUNT + 32 fields][CPB]
+    constexpr int TILE_STRIDE = (TILE_DOUBLES + 31) / 32 * 32;      // images start on 256-byte boundaries
+    __shared__ __attribute__((aligned(256))) double s_tile[(PT ? 2 : 1) * TILE_STRIDE];
+    double* s_cell = s_tile;
+    double* s_dirs = s_tile + CF_COUNT * CPB;
     __shared__ double s_time[AF ? 1 : 3 * TF_COUNT * 24];
+#if MCF_EXPERIMENT_LDSPAD
+    __shared__ double s_pad[MCF_EXPERIMENT_LDSPAD];     // occupancy experiment: extra LDS per workgroup
+    if (threadIdx.x == 0 && a.N < 0) s_pad[a.day0] = 1.0;
+#endif
     // day-reduction staging: per (hour, cell) values, or — 21-cell tiles — per (wave, cell) partial extremes
     constexpr bool PRE = (CPB == 21) && MCF_LANES21 && MCF_WAVE_PREREDUCE;
     __shared__ double s_red[2][PRE ? 3 : 2][(PRE ? 8 : 24) * CPB];
@@ -542,9 +571,14 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
     }
 #endif
     const int64_t N = a.N;
-    const int64_t c0 = tile * CPB;
-    const int64_t c = c0 + cl;
-    const bool in_grid = lane_on && c < N;   // the other lanes only help staging and keep the barriers
+    auto tile_at = [&](int it) -> int64_t {
+        const int64_t pos = first + it * seq_stride;
+        return PT ? (a.tile_list ? (int64_t)a.tile_list[pos] : pos) : first;
+    };
+    int64_t tile = tile_at(0);
+    int64_t c0 = tile * CPB;
+    int64_t c = c0 + cl;
+    bool in_grid = lane_on && c < N;   // the other lanes only help staging and keep the barriers
 
     // ---- stage the tile's direction tables, the first day's time table and the first day's cell constants in LDS: all
     // global loads of the prologue are in flight together (one HBM latency per workgroup instead of three; the fixed cost
@@ -569,7 +603,7 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
             s_cell[q] = cc < N ? src[(int64_t)f * N + cc] : 0.0;
         }
     };
-    CellLds<CPB> C{s_cell, s_dirs, cl};
+    CellLds<CPB> C{s_cell + cl};     // reassigned when a persistent workgroup moves on to its next tile
     int flags = 0;
     bool valid = false;
     // vegetation layer of a day (runmicro3Cpp/4Cpp `dfsel`, cpp:2760-2768)
@@ -583,15 +617,16 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
     MathK MK;
     MK.set();
 #if MCF_PIN_MATHK
-    MK.pin(MCF_PIN_MATHK > 1);   // exp (and log) coefficients resident in SGPRs for the whole day loop
+    MK.pin(MCF_PIN_MATHK > 1 && !(PT && MCF_PT_UNPIN_LOG));   // exp (and log) coefficients resident in SGPRs for the whole day loop
 #endif
     const double NA = na_real();
 
     Canary cn;      // F: NaN as soon as one watched clamp of this lane has met a NaN, on any day of the launch
-    // soil state of day `d` into its ring slot, by the calling wave (all 64 lanes call)
-    auto produce_soil = [&](int d) {
+    int run = 0;    // days this workgroup has started, over all its tiles: indexes the time, reduction and soil rings
+    // soil state of day `d`, from the tile image `cells`, into ring slot `slot`, by the calling wave (all 64 lanes call)
+    auto produce_soil = [&](int d, int slot, const double* cells) {
         if (SS)
-            soil_day_produce<SS ? CPB : 1, F>(s_cell, a.tt[((int64_t)d * TF_COUNT + TF_SOILMP) * 24], s_soil + (d % 3) * (SD_COUNT * CPB),
+            soil_day_produce<SS ? CPB : 1, F>(cells, a.tt[((int64_t)d * TF_COUNT + TF_SOILMP) * 24], s_soil + (slot % 3) * (SD_COUNT * CPB),
                                               tid & 63, MK);
     };
     // after the tile's constants of `cur_layer` have landed in LDS (barrier before): the lane's flags, and the soil ring
@@ -602,15 +637,37 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
         valid = (flags & FL_VALID) != 0;
         if (SS && cur_layer >= 0) {
             const int wv = tid >> 6;
-            if (wv == 0) produce_soil(d);
-            if (wv == 1 && d + 1 < day0 + ndays) produce_soil(d + 1);
+            if (wv == 0) produce_soil(d, run, s_cell);
+            if (wv == 1 && d + 1 < day0 + ndays) produce_soil(d + 1, run + 1, s_cell);
             __syncthreads();
         }
     };
     __syncthreads();
     enter_layer(day0);
-    for (int dl = 0; dl < (MCF_EXPERIMENT_SKIPDAYS ? 0 : ndays); ++dl) {
+    for (int it = 0; it < (PT ? nseq : 1); ++it) {
+    const bool has_next = PT && it + 1 < nseq;
+    double* const s_alt = s_tile + (PT ? ((it & 1) ? 0 : TILE_STRIDE) : 0);     // the other tile image (tile `it` lives in image it & 1)
+    for (int dl = 0; dl < (MCF_EXPERIMENT_SKIPDAYS ? 0 : ndays); ++dl, ++run) {
         const int dabs = day0 + dl;
+        if (PT && has_next && dl == 1) {
+            // Every wave has left the previous tile (this one is past the barrier of day 0), so the other image is free: stream
+            // the next tile's constants into it, 4 bytes per lane per instruction straight from global memory to LDS (no
+            // VGPRs) — here, at the top of a day, where a lane carries nothing.
+            const int64_t c0n = tile_at(it + 1) * CPB;
+            const double* cells = a.cellc + (int64_t)cur_layer * CF_COUNT * N;
+            constexpr int TILE_DW = TILE_DOUBLES * 2, NCHUNK = (TILE_DW + 63) / 64;     // 64-dword pieces, one per wave instruction
+#pragma unroll 1
+            for (int k = tid >> 6; k < NCHUNK; k += NT / 64) {
+                const int D = 64 * k + (tid & 63), q = D >> 1, f = q / CPB;
+                const int64_t cc = c0n + (q - f * CPB);
+                const double* src = f < CF_COUNT ? cells + (int64_t)f * N + cc
+                                  : f < CF_COUNT + 24 ? a.hor + (int64_t)(f - CF_COUNT) * N + cc
+                                                      : a.wsa + (int64_t)(f - CF_COUNT - 24) * N + cc;
+                if (D < TILE_DW && cc < N)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)src + 4 * (D & 1)),
+                                                     (__attribute__((address_space(3))) void*)((char*)s_alt + 256 * k), 4, 0, 0);
+            }
+        }
         // the tile's cell constants are restaged whenever the day's vegetation layer changes — workgroup-uniform and rare
         const int layer = a.daylayer ? a.daylayer[dabs] : 0;
         if (layer != cur_layer) {
@@ -650,10 +707,10 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
 #if MCF_EXPERIMENT_NOPREFETCH
         const bool stage = false;
 #else
-        const bool stage = !AF && (dl + 1 < ndays);
+        const bool stage = !AF && (dl + 1 < ndays || has_next);      // the next tile starts over at day0
 #endif
         if (stage) {
-            const double* src = a.tt + (int64_t)(dabs + 1) * TF_COUNT * 24;
+            const double* src = a.tt + (int64_t)(dl + 1 < ndays ? dabs + 1 : day0) * TF_COUNT * 24;
 #pragma unroll
             for (int i = 0; i < TPER; ++i) {
                 int q = tid + i * NT;
@@ -690,9 +747,9 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
             DateRow dr{a.dt[4 * kabs + 0], a.dt[4 * kabs + 1], a.dt[4 * kabs + 2], a.dt[4 * kabs + 3]};
             derive_time_af(tv, dr, C(CF_SINLAT), C(CF_COSLAT), C(CF_COSB), C(CF_SINB), a.windex[kabs], MK);
         }
-        TimeLds TL{s_time + (AF ? 0 : (dl % 3) * (TF_COUNT * 24)) + hr};
+        TimeLds TL{s_time + (AF ? 0 : (run % 3) * (TF_COUNT * 24)) + hr};
         TimeReg TR{&tv};
-        SoilLds<CPB> SL{s_soil + (SS ? (dabs % 3) * (SD_COUNT * CPB) + cl : 0)};
+        SoilLds<CPB> SL{s_soil + (SS ? (run % 3) * (SD_COUNT * CPB) + cl : 0)};
 
 #if MCF_DAYPRIO
         // daytime waves carry the short-wave block and are the critical path to the barrier
@@ -700,8 +757,8 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
 #endif
         Carry cy;
         Pass1Out p1;
-        double* red_t = &s_red[dl & 1][0][PRE ? 0 : hr * CPB + cl];
-        double* red_r = &s_red[dl & 1][1][PRE ? 0 : hr * CPB + cl];
+        double* red_t = &s_red[run & 1][0][PRE ? 0 : hr * CPB + cl];
+        double* red_r = &s_red[run & 1][1][PRE ? 0 : hr * CPB + cl];
         if (valid) {
             if (AF) pass1<F, false>(C, TR, SL, g, flags, dTmx, cy, p1, MK, cn);
             else pass1<F, SS>(C, TL, SL, g, flags, dTmx, cy, p1, MK, cn);
@@ -742,13 +799,13 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
             asm("v_max_f64 %0, %0, %1" : "+v"(rmx3) : "v"(r2));
             if (valid && (l < 16 || (l >= 48 && l < 53))) {
                 const int wv = tid >> 6;
-                s_red[dl & 1][0][wv * CPB + cl] = tmx3;
-                s_red[dl & 1][1][wv * CPB + cl] = tmn3;
-                s_red[dl & 1][PRE ? 2 : 0][wv * CPB + cl] = rmx3;
+                s_red[run & 1][0][wv * CPB + cl] = tmx3;
+                s_red[run & 1][1][wv * CPB + cl] = tmn3;
+                s_red[run & 1][PRE ? 2 : 0][wv * CPB + cl] = rmx3;
             }
         }
         if (stage) {
-            double* dst = s_time + ((dl + 1) % 3) * (TF_COUNT * 24);
+            double* dst = s_time + ((run + 1) % 3) * (TF_COUNT * 24);
 #pragma unroll
             for (int i = 0; i < TPER; ++i) {
                 int q = tid + i * NT;
@@ -758,15 +815,20 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
 #if MCF_DAYPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
+        // the next tile's image must have landed (and be visible) behind the barrier of the last day but one, where its soil
+        // state is first computed from it: every wave drains its own LDS-DMA loads before that barrier
+        if (PT && has_next && dl == ndays - 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if !MCF_EXPERIMENT_NOBARRIER
         __syncthreads();
 #endif
         if (SS) {
-            // Every wave is past day dabs-1 now, so the ring slot of day dabs+2 (= that of dabs-1) is free; whoever fills
-            // it reaches the NEXT barrier before any wave starts day dabs+2.  The waves take turns.  A change of layer
-            // on the way restarts the ring above, so a slot filled with the wrong layer's constants is never read.
-            const int d2 = dabs + 2;
-            if (d2 < day0 + ndays && (tid >> 6) == (dabs & 7) % (NT / 64)) produce_soil(d2);
+            // Every wave is past the day before now, so the soil ring slot of the day after next (= that of the day before)
+            // is free; whoever fills it reaches the NEXT barrier before any wave starts that day.  The waves take turns.  A
+            // change of layer on the way restarts the ring above, so a slot filled with the wrong layer's constants is never
+            // read.  Past the tile's last day the ring runs on into the next tile's first two days, from its image.
+            const int d2 = dl + 2;
+            if ((tid >> 6) == (run & 7) % (NT / 64) && (d2 < ndays || has_next))
+                produce_soil(d2 < ndays ? day0 + d2 : day0 + d2 - ndays, run + 2, d2 < ndays ? s_cell : s_alt);
         }
         if (valid && a.need_pass2) {
             // day reductions in hour order with the reference's comparisons, cpp:2196-2198, 2256-2263
@@ -858,6 +920,21 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
             const int i = atomicAdd(a.fix_count, 1);
             if (i < a.fix_cap) a.fix_list[i] = (int32_t)tile;
         }
+        cn = Canary();
+    }
+    if (has_next) {
+        // on to the next tile: its image is complete since the barrier of the last day but one, its first day's time table
+        // and its first two days' soil state were staged during the last day — no barrier, no cold start
+        s_cell = s_alt;
+        s_dirs = s_alt + CF_COUNT * CPB;
+        C = CellLds<CPB>{s_cell + cl};
+        tile = tile_at(it + 1);
+        c0 = tile * CPB;
+        c = c0 + cl;
+        in_grid = lane_on && c < N;
+        flags = (in_grid && cur_layer >= 0) ? (int)s_cell[CF_FLAGS * CPB + cl] : 0;
+        valid = (flags & FL_VALID) != 0;
+    }
     }
 }
 
@@ -878,13 +955,28 @@ __device__ __forceinline__ int64_t tile_position(int64_t ntiles) {
 
 // array forcing keeps ~17 more doubles live per lane (forcing values instead of an LDS table):
 // it is built for 3 waves/SIMD (168 VGPRs, no scratch) and run with 32-cell workgroups
-template <int CPB, int AF, bool BG, bool F, bool SSREQ>
+template <int CPB, int AF, bool BG, bool F, bool SSREQ, bool PT>
 __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_PER_EU) void k_solve(SolveArgs a) {
-    const int64_t pos = tile_position(a.ntiles_launch);
-    if (pos < 0) return;
-    const int64_t tile = a.tile_list ? (int64_t)a.tile_list[pos] : pos;
     // every other resident workgroup shifts its wave-to-hour assignment by six hours (MCF_HOUR_ROTATE)
-    solve_tile<CPB, AF, BG, F, SSREQ>(a, tile, a.day0, a.ndays, (int)((blockIdx.x >> 8) & 1));
+    const int rot = (int)((blockIdx.x >> 8) & 1);
+    if (PT) {
+        // Each XCD keeps its contiguous eighth of the tile sequence (the L2 merges the partial lines of neighbouring tiles).
+        // Inside it, the R workgroups of the XCD take tiles r, r + R, r + 2R, ...: at any moment the workgroups in flight are
+        // on ADJACENT tiles, as in the one-tile-per-workgroup launch — a workgroup walking K consecutive tiles instead would
+        // write neighbouring tiles' shared cache lines a whole tile apart in time, after the L2 has given them up.
+        const int64_t per_xcd = (a.ntiles_launch + 7) / 8;
+        const int x = (int)(blockIdx.x & 7);
+        const int64_t lo = x * per_xcd, hi = lo + per_xcd < a.ntiles_launch ? lo + per_xcd : a.ntiles_launch;
+        const int64_t R = (per_xcd + a.tiles_per_wg - 1) / a.tiles_per_wg, r = blockIdx.x >> 3;
+        if (r >= R || lo + r >= hi) return;
+        const int nseq = (int)((hi - (lo + r) + R - 1) / R);
+        solve_tile<CPB, AF, BG, F, SSREQ, PT>(a, lo + r, R, nseq, a.day0, a.ndays, rot);
+    } else {
+        const int64_t pos = tile_position(a.ntiles_launch);
+        if (pos < 0) return;
+        const int64_t tile = a.tile_list ? (int64_t)a.tile_list[pos] : pos;
+        solve_tile<CPB, AF, BG, F, SSREQ, false>(a, tile, 0, 1, a.day0, a.ndays, rot);
+    }
 }
 
 // Redoes, with the reference's compare-and-select clamps, the tiles in which a fast wave's canary tripped.  Launched
@@ -899,13 +991,13 @@ __global__ __launch_bounds__(solve_threads(CPB), MCF_WAVES_PER_EU) void k_solve_
         const int64_t ntiles = (a.N + CPB - 1) / CPB;
         for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
             __syncthreads();
-            solve_tile<CPB, 0, false, false, false>(a, t, a.day0, a.ndays, 0);
+            solve_tile<CPB, 0, false, false, false, false>(a, t, 0, 1, a.day0, a.ndays, 0);
         }
         return;
     }
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         __syncthreads();
-        solve_tile<CPB, 0, false, false, false>(a, (int64_t)a.fix_list[i], a.day0, a.ndays, 0);
+        solve_tile<CPB, 0, false, false, false, false>(a, (int64_t)a.fix_list[i], 0, 1, a.day0, a.ndays, 0);
     }
 }
 
@@ -1276,25 +1368,37 @@ static dim3 solve_grid(int64_t ntiles) {
 #endif
 }
 template <int CPB>
-static void launch_solve_cpb(SolveArgs a, bool af, bool bg, bool fast, bool ss, hipStream_t s) {
+static void launch_solve_cpb(SolveArgs a, bool af, bool bg, bool fast, bool ss, bool persistent, hipStream_t s) {
     if (a.ntiles_launch <= 0) {                      // no list: every tile of the raster
         a.ntiles_launch = (a.N + CPB - 1) / CPB;
         a.tile_list = nullptr;
     }
     const dim3 grid = solve_grid(a.ntiles_launch), block(solve_threads(CPB));
     ss = ss && MCF_SOIL_SHARE && 2 * CPB <= 64;
-    if (af) {
-        if (bg) hipLaunchKernelGGL((k_solve<CPB, 1, true, false, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_solve<CPB, 1, false, false, false>), grid, block, 0, s, a);
+    // persistent tiles (the main configuration only: 21-cell tiles, fast clamps, shared soil state, static vegetation):
+    // enough tiles per workgroup to amortise the cold start, enough workgroups to keep every CU busy to the end
+    constexpr bool kPtBuilt = CPB == 21 && MCF_PERSISTENT_TILES;
+    const bool pt = kPtBuilt && persistent && !af && !bg && fast && MCF_FAST_CLAMPS && ss && a.daylayer == nullptr && a.ndays >= 3;
+    if (pt) {
+        // at least ~24 rounds of workgroups over the chip's 512 resident slots: a workgroup that runs K tiles is K times
+        // as long, and the last, partly filled round costs a whole one (measured: K = 12 on 8 rounds lost 12 %)
+        a.tiles_per_wg = (int32_t)std::min<int64_t>(16, std::max<int64_t>(1, a.ntiles_launch / (512 * 24)));
+        const int64_t per_xcd = (a.ntiles_launch + 7) / 8;
+        const dim3 gridp((unsigned)(8 * ((per_xcd + a.tiles_per_wg - 1) / a.tiles_per_wg)));
+        hipLaunchKernelGGL((k_solve<CPB, 0, false, true, true, kPtBuilt>), gridp, block, 0, s, a);
+        hipLaunchKernelGGL((k_solve_fix<CPB>), dim3(512), block, 0, s, a);
+    } else if (af) {
+        if (bg) hipLaunchKernelGGL((k_solve<CPB, 1, true, false, false, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_solve<CPB, 1, false, false, false, false>), grid, block, 0, s, a);
     } else if (bg) {
-        hipLaunchKernelGGL((k_solve<CPB, 0, true, false, false>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((k_solve<CPB, 0, true, false, false, false>), grid, block, 0, s, a);
     } else if (fast && MCF_FAST_CLAMPS) {
-        if (ss) hipLaunchKernelGGL((k_solve<CPB, 0, false, true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_solve<CPB, 0, false, true, false>), grid, block, 0, s, a);
+        if (ss) hipLaunchKernelGGL((k_solve<CPB, 0, false, true, true, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_solve<CPB, 0, false, true, false, false>), grid, block, 0, s, a);
         hipLaunchKernelGGL((k_solve_fix<CPB>), dim3(512), block, 0, s, a);
     } else {
-        if (ss) hipLaunchKernelGGL((k_solve<CPB, 0, false, false, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_solve<CPB, 0, false, false, false>), grid, block, 0, s, a);
+        if (ss) hipLaunchKernelGGL((k_solve<CPB, 0, false, false, true, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_solve<CPB, 0, false, false, false, false>), grid, block, 0, s, a);
     }
 }
 void launch_tile_regular(const double* cellc, int64_t N, int layers, int cpb, uint8_t* out, hipStream_t s) {
@@ -1308,8 +1412,8 @@ static void launch_solve_coarse(SolveArgs a, bool bg, hipStream_t s) {
     a.ntiles_launch = (a.N + CPB - 1) / CPB;
     a.tile_list = nullptr;
     const dim3 grid = solve_grid(a.ntiles_launch), block(solve_threads(CPB));
-    if (bg) hipLaunchKernelGGL((k_solve<CPB, 2, true, false, false>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_solve<CPB, 2, false, false, false>), grid, block, 0, s, a);
+    if (bg) hipLaunchKernelGGL((k_solve<CPB, 2, true, false, false, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_solve<CPB, 2, false, false, false, false>), grid, block, 0, s, a);
 }
 int twi_scratch_doubles() { return 2 + 2 * kTwiParts; }
 int cell_field_count() { return CF_COUNT; }
@@ -1323,13 +1427,14 @@ double hf_pow02(double rs) {
     return pow(fabs(Hf), 0.2);
 }
 
-void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, bool fast, bool soil_daily, hipStream_t s) {
+void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, bool fast, bool soil_daily, bool persistent,
+                  hipStream_t s) {
     if (a.N <= 0 || a.ndays <= 0) return;
     if (a.crows > 0) { launch_solve_coarse(a, bg, s); return; }
-    if (cells_per_block == 32) launch_solve_cpb<32>(a, af, bg, fast, soil_daily, s);
-    else if (cells_per_block == 21) launch_solve_cpb<21>(a, af, bg, fast, soil_daily, s);
-    else if (cells_per_block == 42) launch_solve_cpb<42>(a, af, bg, fast, soil_daily, s);
-    else launch_solve_cpb<16>(a, af, bg, fast, soil_daily, s);
+    if (cells_per_block == 32) launch_solve_cpb<32>(a, af, bg, fast, soil_daily, persistent, s);
+    else if (cells_per_block == 21) launch_solve_cpb<21>(a, af, bg, fast, soil_daily, persistent, s);
+    else if (cells_per_block == 42) launch_solve_cpb<42>(a, af, bg, fast, soil_daily, persistent, s);
+    else launch_solve_cpb<16>(a, af, bg, fast, soil_daily, persistent, s);
 }
 int soil_daily_bit() { return kSoilDaily; }
 
