@@ -373,6 +373,7 @@ int mcf_device_count(void) {
 }
 
 void mcf_plan_destroy(mcf_plan* p) {
+    if (p) mcf::print_skipstats();
     if (!p) return;
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);

@@ -196,12 +196,42 @@ __device__ __forceinline__ double fsqrt(double x) {           // sqrt(x), x fini
                            // p = r*c11 + c10 reads TWO constants and a VOP3 can take only one from the scalar file, so the
                            // other was re-created by two v_mov_b32 in front of (nearly) every evaluation
 #endif
+#ifndef MCF_EXP_TABLE
+#define MCF_EXP_TABLE 1   // k_solve: exp through a 64-entry table of 2^(j/64) in LDS + a degree-5 polynomial (12 fp64
+                          // instructions + 3 integer ones instead of 17 fp64); kernels that do not set MathK::tab keep the
+                          // degree-11 polynomial
+#endif
+// 2^(j/64), j = 0 .. 63, correctly rounded (computed with 60 decimal digits)
+__device__ const double kExp2Tab[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
 struct MathK {
     double e[12];   // exp: 1/ln2, -ln2_hi, -ln2_lo, c10 .. c2
     double l[7];    // log: Lg4, Lg5, Lg2, Lg3, Lg1, ln2_lo, ln2_hi
     double c11, lg6, lg7;   // VGPR residents (MCF_PIN_VCONST)
+    double t[5];    // table exp: 64/ln2, -(ln2/64)_hi (30 bits: n * hi is exact), -(ln2/64)_lo, 1/24, 1/6
+    double c5;      // 1/120 (VGPR resident)
+    const double* tab = nullptr;   // LDS copy of kExp2Tab
+    bool table = false;            // fexp goes through it (a compile-time fact after inlining: LDS address 0 is valid, so
+                                   // the pointer cannot say)
     __device__ __forceinline__ void set() {
         c11 = 0x1.ade156a5dcb37p-26; lg6 = 1.531383769920937332e-01; lg7 = 1.479819860511658591e-01;
+        t[0] = 0x1.71547652b82fep+6; t[1] = -0x1.62e42fec00000p-7; t[2] = -0x1.d1cf79abc9e3bp-38;
+        t[3] = 1.0 / 24.0; t[4] = 1.0 / 6.0; c5 = 1.0 / 120.0;
         e[0] = 0x1.71547652b82fep+0; e[1] = -0x1.62e42fefa39efp-1; e[2] = -0x1.abc9e3b39803fp-56;
         e[3] = 0x1.28af3fca7ab0cp-22; e[4] = 0x1.71dee623fde64p-19; e[5] = 0x1.a01997c89e6b0p-16;
         e[6] = 0x1.a01a014761f6ep-13; e[7] = 0x1.6c16c1852b7b0p-10; e[8] = 0x1.1111111122322p-7;
@@ -211,22 +241,63 @@ struct MathK {
         l[6] = 6.93147180369123816490e-01;
     }
     // makes the values opaque SGPR residents: the compiler can no longer re-create them from literals
+    // copies the table into `lds` (64 doubles; the caller's barrier makes it visible) and switches fexp to it
+    __device__ __forceinline__ void use_table(double* lds, int tid) {
+        if (tid < 64) lds[tid] = kExp2Tab[tid];
+        tab = lds;
+        table = true;
+    }
     __device__ __forceinline__ void pin(bool with_log) {
+        if (table) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) asm volatile("" : "+s"(e[i]));
+            for (int i = 0; i < 5; ++i) asm volatile("" : "+s"(t[i]));
+            asm volatile("" : "+v"(c5));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) asm volatile("" : "+s"(e[i]));
+        }
         if (with_log) {
 #pragma unroll
             for (int i = 0; i < 7; ++i) asm volatile("" : "+s"(l[i]));
         }
 #if MCF_PIN_VCONST
-        asm volatile("" : "+v"(c11));
+        if (!table) asm volatile("" : "+v"(c11));
 #if MCF_PIN_VCONST > 1
         if (with_log) { asm volatile("" : "+v"(lg6)); asm volatile("" : "+v"(lg7)); }
 #endif
 #endif
     }
 };
+// exp(x) = 2^e * 2^(j/64) * exp(r), n = round(x * 64/ln2) = 64 e + j, r = x - n ln2/64, |r| <= ln2/128: the table value T
+// comes from LDS while the degree-5 polynomial p = exp(r) - 1 is evaluated (r^6/720 < 3.4e-17), then T + T p and ldexp.
+// Same saturation behaviour as the polynomial route (v_cvt_i32_f64 and v_ldexp_f64 saturate; NaN stays NaN).
+__device__ __forceinline__ double fexp_tab(double x, const MathK& K) {
+    double n, r, p, r2, out;
+    int t;
+    asm("v_mul_f64 %0, %3, %4\n\t"
+        "v_rndne_f64 %0, %0\n\t"
+        "v_fma_f64 %1, %0, %5, %3\n\t"
+        "v_fma_f64 %1, %0, %6, %1\n\t"
+        "v_cvt_i32_f64 %2, %0"
+        : "=&v"(n), "=&v"(r), "=v"(t)
+        : "v"(x), "s"(K.t[0]), "s"(K.t[1]), "s"(K.t[2]));
+    const double T = K.tab[t & 63];
+    const int e = t >> 6;
+    asm("v_fma_f64 %0, %2, %3, %4\n\t"        // p = r/120 + 1/24
+        "v_fma_f64 %0, %2, %0, %5\n\t"        // p = r p + 1/6
+        "v_fma_f64 %0, %2, %0, 0.5\n\t"       // p = r p + 1/2
+        "v_mul_f64 %1, %2, %2\n\t"            // r^2
+        "v_fma_f64 %0, %1, %0, %2"             // p = r^2 p + r
+        : "=&v"(p), "=&v"(r2)
+        : "v"(r), "v"(K.c5), "s"(K.t[3]), "s"(K.t[4]));
+    asm("v_fma_f64 %0, %1, %2, %1\n\t"        // T p + T
+        "v_ldexp_f64 %0, %0, %3"
+        : "=&v"(out)
+        : "v"(T), "v"(p), "v"(e));
+    return out;
+}
 __device__ __forceinline__ double fexp(double x, const MathK& K) {
+    if (MCF_EXP_TABLE && K.table) return fexp_tab(x, K);
     double n, r, p, out;
     int t;
     const double c11 = K.c11;
@@ -612,6 +683,12 @@ __device__ __forceinline__ void pin(A&... a) {
 // -DMCF_CANARY_ALL=1 watches every clamp operand instead (tools/canary_audit.py counts how often that trips).
 #ifndef MCF_SKIP_MINCOND
 #define MCF_SKIP_MINCOND 1   // see pass2's leaf block: mincondCpp's floors skipped when they provably cannot bind
+#endif
+#ifndef MCF_EXPERIMENT_SKIPSTATS
+#define MCF_EXPERIMENT_SKIPSTATS 0
+#endif
+#if MCF_EXPERIMENT_SKIPSTATS
+__device__ unsigned long long g_skipstats[4];
 #endif
 #ifndef MCF_CANARY_ALL
 #define MCF_CANARY_ALL 0
@@ -1109,6 +1186,17 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
             const double tq = gh * (1.0 / 0.0463), tq2 = tq * tq;
             const bool clear = gh >= 0.0500001 && tq2 * tq2 * tq >= (fabs(RnetL) * invleafd) * 1.000001;
             floors_idle = __builtin_amdgcn_ballot_w64(!clear) == 0;
+#if MCF_EXPERIMENT_SKIPSTATS
+            {   // how often the bound clears: waves, waves with every lane clear, lanes, lanes clear (debug build only)
+                const uint64_t act = __builtin_amdgcn_ballot_w64(true), bad = __builtin_amdgcn_ballot_w64(!clear);
+                if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(act)) {
+                    atomicAdd(&g_skipstats[0], 1ull);
+                    atomicAdd(&g_skipstats[1], bad == 0 ? 1ull : 0ull);
+                    atomicAdd(&g_skipstats[2], (unsigned long long)__builtin_popcountll(act));
+                    atomicAdd(&g_skipstats[3], (unsigned long long)__builtin_popcountll(act & ~bad));
+                }
+            }
+#endif
         }
 #endif
         double a02 = 0.0;

@@ -158,6 +158,7 @@ void launch_belowground(const BelowArgs& a, hipStream_t s);
 void launch_selftest_math(int kind, const double* x, const double* y, double* out, int64_t n, hipStream_t s);
 
 int cell_field_count();
+void print_skipstats();     // MCF_EXPERIMENT_SKIPSTATS builds: how often pass 2's mincond bound clears
 int soil_daily_bit();        // kSoilDaily, likewise
 int step_irregular_bit();   // kStepIrregular of the packed TF_IDX value (last time field)
 int time_field_count();

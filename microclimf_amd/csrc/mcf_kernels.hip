@@ -9,6 +9,7 @@
 //   k_fill          constant fill (NA_real_ for steps past the last whole day)
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdint.h>
 
 #include "mcf_device.hpp"
@@ -616,6 +617,10 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
     const bool need_tv = g.reqhgt >= 0.0 && a.need_tv != 0;
     MathK MK;
     MK.set();
+#if MCF_EXP_TABLE
+    __shared__ double s_exptab[64];
+    MK.use_table(s_exptab, tid);       // visible after the prologue's barrier
+#endif
 #if MCF_PIN_MATHK
     MK.pin(MCF_PIN_MATHK > 1 && !(PT && MCF_PT_UNPIN_LOG));   // exp (and log) coefficients resident in SGPRs for the whole day loop
 #endif
@@ -1219,10 +1224,16 @@ void launch_bioclim(const BioclimArgs& a, hipStream_t s) {
 __global__ void k_selftest_math(int kind, const double* __restrict__ x, const double* __restrict__ y,
                                 double* __restrict__ out, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const bool live = i < n;
+    if (!live) i = 0;
     double a = x[i], b = y ? y[i] : 0.0, r;
     MathK K;
     K.set();
+#if MCF_EXP_TABLE
+    __shared__ double s_exptab[64];      // the route k_solve takes
+    K.use_table(s_exptab, (int)threadIdx.x);
+    __syncthreads();
+#endif
     switch (kind) {
         case 0: r = fexp(a, K); break;
         case 1: r = flog(a, K); break;
@@ -1232,7 +1243,7 @@ __global__ void k_selftest_math(int kind, const double* __restrict__ x, const do
         case 5: r = satvap(a, K); break;
         default: r = powxy(a, b, K); break;
     }
-    out[i] = r;
+    if (live) out[i] = r;
 }
 void launch_selftest_math(int kind, const double* x, const double* y, double* out, int64_t n, hipStream_t s) {
     if (n <= 0) return;
@@ -1437,5 +1448,15 @@ void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, boo
     else launch_solve_cpb<16>(a, af, bg, fast, soil_daily, persistent, s);
 }
 int soil_daily_bit() { return kSoilDaily; }
+#if MCF_EXPERIMENT_SKIPSTATS
+void print_skipstats() {
+    unsigned long long h[4] = {0, 0, 0, 0};
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_skipstats), sizeof h);
+    fprintf(stderr, "[mcf] mincond bound: %llu waves, %llu all-clear (%.1f %%); %llu lanes, %llu clear (%.2f %%)\n", h[0], h[1],
+            100.0 * h[1] / (h[0] ? h[0] : 1), h[2], h[3], 100.0 * h[3] / (h[2] ? h[2] : 1));
+}
+#else
+void print_skipstats() {}
+#endif
 
 }  // namespace mcf

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/prof_<tag>_aux/ (tools/profile_aux.sh) into profiles/<tag>_aux_kernel_stats.csv and
+profiles/<tag>_aux_pmc_summary.json: per kernel the mean duration, VALU instructions per lane and the VALU-busy fraction."""
+import csv
+import glob
+import json
+import shutil
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+root = Path(__file__).resolve().parents[1]
+src = root / "gpurun_out" / f"prof_{tag}_aux"
+dst = root / "profiles"
+st = glob.glob(str(src / "trace" / "*" / "*_kernel_stats.csv"))
+if st:
+    shutil.copy(st[0], dst / f"{tag}_aux_kernel_stats.csv")
+agg = defaultdict(lambda: defaultdict(list))
+dur = defaultdict(list)
+for d in ("pmc_sq", "pmc_misc"):
+    for f in glob.glob(str(src / d / "*" / "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for f in glob.glob(str(src / d / "*" / "*_kernel_trace.csv")):
+        if d == "pmc_misc":
+            for r in csv.DictReader(open(f)):
+                dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+out = {}
+for k, c in agg.items():
+    if not any(s in k for s in ("k_snowmodel", "k_microsnow", "k_snow_redistribute", "k_horizon", "k_windcoef", "k_apply3_part",
+                                "k_pack", "k_tpi")):
+        continue
+    m = {n: sum(v) / len(v) for n, v in c.items()}
+    e = {"launches": len(next(iter(c.values()))), "mean_ms": sum(dur[k]) / max(len(dur[k]), 1), "per_launch_mean": m}
+    if "SQ_ACTIVE_INST_VALU" in m and "GRBM_GUI_ACTIVE" in m:
+        cyc = m["GRBM_GUI_ACTIVE"] / 8
+        e["valu_busy_fraction"] = m["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * cyc)
+    if "SQ_INSTS_VALU" in m and "SQ_WAVES" in m:
+        e["valu_insts_per_wave"] = m["SQ_INSTS_VALU"] / m["SQ_WAVES"]
+    out[k.replace("(anonymous namespace)::", "")[:90]] = e
+(dst / f"{tag}_aux_pmc_summary.json").write_text(json.dumps(out, indent=1))
+for k, e in out.items():
+    print(f"{k[:60]:60s} {e['launches']:4d} x {e['mean_ms']:8.3f} ms  VALU/wave {e.get('valu_insts_per_wave', 0):9.0f}  busy {e.get('valu_busy_fraction', 0):.2f}")

@@ -27,6 +27,7 @@ for name in ("bench_under_rocprof.json", "bench.json"):
 pmc = {}
 dur = {}
 kname = "k_solve"
+nlaunch = 0
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc"):
     cc = glob.glob(str(src / d / "*" / "*_counter_collection.csv"))
     if not cc:
@@ -38,6 +39,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc"):
             kname = r["Kernel_Name"]
     for k, v in agg.items():
         pmc[k] = sum(v) / len(v)
+        nlaunch = len(v)
     kt = glob.glob(str(src / d / "*" / "*_kernel_trace.csv"))[0]
     ds = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(kt))
           if "k_solve<" in r["Kernel_Name"]]
@@ -46,7 +48,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc"):
 import re
 sys.path.insert(0, str(root))
 import bench  # noqa: E402  (kernel_hash(): the stamp bench.py checks before it reports these counters)
-ring_days, valid_cells, rows, cols = 5, 1038103, 1024, 1024
+ring_days, valid_cells, rows, cols, tsteps = 5, 1038103, 1024, 1024, 1920
 for bj in (src / "pmc_fetch.json", dst / f"{tag}_bench_under_rocprof.json"):
     if bj.exists():
         try:
@@ -54,12 +56,15 @@ for bj in (src / "pmc_fetch.json", dst / f"{tag}_bench_under_rocprof.json"):
             ring_days = int(re.search(r"x (\d+) days", cfg["sink"]).group(1))
             valid_cells = int(cfg["valid_cells"])
             rows, cols = int(cfg["rows_per_gpu"]), int(cfg["cols"])
+            tsteps = int(cfg["tsteps"])
             break
         except Exception:
             pass
 bargs = (src / "bench_args.txt").read_text().strip() if (src / "bench_args.txt").exists() else ""
 summary = {"kernel": kname.replace("void mcf::", "").replace("(mcf::SolveArgs)", ""), "per_launch_mean": pmc, "avg_launch_ms_under_pmc": dur,
-           "ring_days": ring_days, "rows": rows, "cols": cols, "cell_steps_per_launch": valid_cells * ring_days * 24,
+           "ring_days": ring_days, "rows": rows, "cols": cols,
+           # the series need not be a whole number of launches: the MEAN launch covers total / launches cell-steps
+           "launches": nlaunch, "cell_steps_per_launch": valid_cells * (tsteps // 24) * 24 / max(nlaunch, 1),
            "kernel_hash": bench.kernel_hash(),
            "command": f"python3 bench.py {bargs} --tsteps 1920 --steps 1 --warmup 0 --no-cpu-baseline --no-secondary "
                       f"--no-verify ({ring_days}-day launches; 80 days: a whole number of launches for 1, 2, 4, 5, 8 and 10-day slots)"}
