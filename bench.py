@@ -553,13 +553,21 @@ def main(argv=None):
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # MCF_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (the ranks share a device,
+    # the collectives run over gloo on host tensors); the driver's runs use nccl = RCCL, one rank per GPU
+    backend = os.environ.get("MCF_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     # MCF_BENCH_FORCE_DIST=1 exercises the RCCL path (init, all-reduce, barrier) on a single rank
     use_dist = world > 1 or os.environ.get("MCF_BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -606,7 +614,9 @@ def main(argv=None):
                 "baseline_config": args.config, "rows_per_gpu": rows, "cols": cols, "tsteps": T, "outputs": 10,
                 "valid_cells": int(r["valid_all"]),
                 "sink": f"HBM ring ({ring_slots} slots x {ring_days} days), no D2H",
-                "partition": "row blocks, one per GPU; all-reduce of twi (sum,count); terrain halo rows point-to-point",
+                "partition": "row blocks, one per GPU; all-reduce of twi (sum,count); terrain halo rows point-to-point"
+                             + ("" if os.environ.get("MCF_BENCH_BACKEND", "nccl") == "nccl" else
+                                " [REHEARSAL: backend " + os.environ["MCF_BENCH_BACKEND"] + ", ranks share a GPU — not a scaling measurement]"),
                 "terrain": ("on-device pre-compute from the synthetic DTM (untimed, see terrain_precompute_s)"
                             if r["terrain_s"] is not None else "random (SURVEY 8d config 2)"),
                 "device_bytes": int(r["plan_bytes"]),

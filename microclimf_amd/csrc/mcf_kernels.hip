@@ -838,10 +838,10 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
         if (valid && a.need_pass2) {
             // day reductions in hour order with the reference's comparisons, cpp:2196-2198, 2256-2263
             double Rmx = -999.9, tmx = -999.0, tmn = 999.0;
-            const double* rt = &s_red[dl & 1][0][cl];
-            const double* rr = &s_red[dl & 1][1][cl];
+            const double* rt = &s_red[run & 1][0][cl];
+            const double* rr = &s_red[run & 1][1][cl];
             if (PRE) {
-                const double* rq = &s_red[dl & 1][PRE ? 2 : 0][cl];
+                const double* rq = &s_red[run & 1][PRE ? 2 : 0][cl];
 #pragma unroll
                 for (int wv = 0; wv < 8; ++wv) {
                     const double a1 = rt[wv * CPB], a2 = rr[wv * CPB], a3 = rq[wv * CPB];

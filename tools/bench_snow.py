@@ -31,12 +31,20 @@ def run_snow_config(args, world, rank, local_rank):
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # MCF_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (the ranks share a device,
+    # the collectives run over gloo on host tensors); the driver's runs use nccl = RCCL, one rank per GPU
+    backend = os.environ.get("MCF_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("MCF_BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     import __graft_entry__ as ge
     if rank == 0:
         ge.build_library()
@@ -165,7 +173,8 @@ def run_snow_config(args, world, rank, local_rank):
                             "[BASELINE.json configs[4]]",
                 "baseline_config": 4, "rows_per_gpu": rows, "cols": cols, "tsteps": T, "valid_cells": int(valid_all),
                 "solver_days_per_year": sd, "snow_days_per_year": stats["snow_days"] / max(args.steps, 1),
-                "halo": "RCCL send/recv of 128 surface rows per neighbour and chunk" if exchange_ok and world > 1 else
+                "halo": (("RCCL" if backend == "nccl" else backend + " (REHEARSAL: ranks share a GPU)")
+                         + " send/recv of 128 surface rows per neighbour and chunk") if exchange_ok and world > 1 else
                         "generated, not exchanged: the neighbouring blocks' snow-free surface (a rank's share of the partition "
                         "without its neighbours)" if not exchange_ok else "single block",
                 "collectives": "per chunk: 2 (sum, count) all-reduces + min / max all-reduce of [120] doubles; once: twi (sum, count)",
