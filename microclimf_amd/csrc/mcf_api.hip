@@ -428,7 +428,7 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
     p->cpb = opt->cells_per_block ? opt->cells_per_block : (in->array_forcing ? 32 : 21);
     {
         static const bool no_fast = getenv("MCF_NO_FAST_CLAMPS") != nullptr;     // A/B runs and tools/canary_audit.py
-        p->fast_enabled = !no_fast && in->array_forcing == 0 && !(opt->reqhgt < 0.0);
+        p->fast_enabled = !no_fast && !(opt->reqhgt < 0.0);
     }
     p->layers = in->veg_layers > 1 ? in->veg_layers : 1;
     p->opt = *opt;
@@ -782,7 +782,7 @@ int mcf_plan_run_days(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot) {
     a.g = p->g;
     a.fix_count = p->d_fix_count; a.fix_list = p->d_fix_list; a.fix_cap = p->fix_cap;
     bool fast = p->fast_enabled && p->n_fast > 0;
-    for (int d = day0; fast && d < day0 + ndays; ++d)
+    for (int d = day0; fast && !p->af && d < day0 + ndays; ++d)     // array forcing: every lane checks its own forcing values
         if (p->day_irregular[(size_t)d]) fast = false;
     bool soil_daily = !p->af && !p->day_soil_daily.empty();
     for (int d = day0; soil_daily && d < day0 + ndays; ++d)
@@ -794,13 +794,13 @@ int mcf_plan_run_days(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot) {
             (void)hipMemsetAsync(p->d_fix_count, 0, 4, p->stream);
             a.tile_list = p->n_slow > 0 ? p->d_tiles_fast : nullptr;
             a.ntiles_launch = p->n_fast;
-            mcf::launch_solve(a, p->cpb, false, false, true, soil_daily, persistent, p->stream);
+            mcf::launch_solve(a, p->cpb, p->af, false, true, soil_daily, persistent, p->stream);
             ++p->fast_launches;
             if (p->n_slow > 0) {
                 ++p->slow_launches;
                 a.tile_list = p->d_tiles_slow;
                 a.ntiles_launch = p->n_slow;
-                mcf::launch_solve(a, p->cpb, false, false, false, soil_daily, false, p->stream);
+                mcf::launch_solve(a, p->cpb, p->af, false, false, soil_daily, false, p->stream);
             }
         } else {
             a.tile_list = nullptr;

@@ -247,11 +247,13 @@ struct MathK {
         tab = lds;
         table = true;
     }
-    __device__ __forceinline__ void pin(bool with_log) {
+    // vconst: c5 / c11, lg6, lg7 held in VGPRs as well (an instruction reads one scalar operand, so a second constant costs
+    // two moves wherever it is used) — not in the array-forcing kernels, which have no register to spare
+    __device__ __forceinline__ void pin(bool with_log, bool vconst = true) {
         if (table) {
 #pragma unroll
             for (int i = 0; i < 5; ++i) asm volatile("" : "+s"(t[i]));
-            asm volatile("" : "+v"(c5));
+            if (vconst) asm volatile("" : "+v"(c5));
         } else {
 #pragma unroll
             for (int i = 0; i < 12; ++i) asm volatile("" : "+s"(e[i]));
@@ -261,6 +263,7 @@ struct MathK {
             for (int i = 0; i < 7; ++i) asm volatile("" : "+s"(l[i]));
         }
 #if MCF_PIN_VCONST
+        if (!vconst) return;
         if (!table) asm volatile("" : "+v"(c11));
 #if MCF_PIN_VCONST > 1
         if (with_log) { asm volatile("" : "+v"(lg6)); asm volatile("" : "+v"(lg7)); }
@@ -528,13 +531,7 @@ __device__ __forceinline__ void derive_time_af(TimeVals& t, const DateRow& dr, d
     t.v[TF_TANC] = tn;
     t.v[TF_TAN2C] = tn * tn;
     t.v[TF_INV2COSC] = 0.5 * frcp(cc);
-    const int ksat = zend > (kPi / 2.0) ? 1 : 0;
-    if (!ksat) {
-        double cb = cos(zend), tb = tan(zend);     // rare: sun within 1.57 degrees of the zenith
-        t.v[TF_TANB] = tb;
-        t.v[TF_TAN2B] = tb * tb;
-        t.v[TF_INV2COSB] = 1.0 / (2.0 * cb);
-    }
+    const int ksat = zend > (kPi / 2.0) ? 1 : 0;       // TANB, TAN2B, INV2COSB (pass 2, !ksat only): derive_time_af_pass2
     // azimuth, cpp:59-75
     double sazi = fdiv(dr.cosdec * stt, sz);
     const double num = sinlat * dr.cosdec * ctt - coslat * dr.sindec;         // sign of cazi
@@ -617,12 +614,21 @@ __device__ __forceinline__ double dewpoint_r(double ea, double tc, const MathK& 
     return tdew < 0.0 ? tfrost : tdew;
 }
 
-// second half, evaluated in front of pass 2 (keeps these out of the registers during pass 1)
-__device__ __forceinline__ void derive_time_af_pass2(TimeVals& t, double gp, double mugp, double dtrp, double kp) {
-    const double mu = latent(t.v[TF_TC]) * (43.0 * frcp(t.v[TF_PK]));          // cpp:1245
+// Second half, evaluated in front of pass 2.  A lane carries every time value pass 2 reads in registers across the day's
+// barrier (no table in LDS to re-read them from), so what is cheap to make again from a carried value is made again here
+// instead of carried: the long-wave operands from tc (opaque to the compiler from here on, or it would carry pass 1's
+// copies) and mu from la/pk.  (The degrees-call extinction operands of the rare lane whose zenith angle in DEGREES is
+// below pi/2 are made inside pass 2, from the carried zenith.)
+__device__ __forceinline__ void derive_time_af_pass2(TimeVals& t) {
+    double tc = t.v[TF_TC];
+    asm volatile("" : "+v"(tc));
+    t.v[TF_TC] = tc;
+    const double tk = tc + 273.15;
+    t.v[TF_GHRRAD] = (4 * 0.97 * kSb * (tk * tk * tk)) * (1.0 / 29.3);       // cpp:1224
+    t.v[TF_REM] = lw_emit(tc);                                                // cpp:1225
+    const double mu = 43.0 * t.v[TF_LAPK];                                    // la*(43/pk), cpp:1245
     t.v[TF_MUPM] = mu;
     t.v[TF_INVMUPM] = frcp(mu);
-    t.v[TF_GFAC] = fdiv(gp * mugp, dtrp * kp);                                 // cpp:1282-1289
 }
 
 // ---- accessors ----------------------------------------------------------------
@@ -638,10 +644,12 @@ struct CellLds {
 };
 // A day's time table in LDS, laid out [field][24].
 struct TimeLds {
+    static constexpr bool in_registers = false;
     const double* row;  // + hour
     __device__ __forceinline__ double operator()(int field) const { return row[field * 24]; }
 };
 struct TimeReg {
+    static constexpr bool in_registers = true;      // array forcing: the passes are short of registers (see pass2, section B)
     const TimeVals* t;
     __device__ __forceinline__ double operator()(int field) const { return t->v[field]; }
 };
@@ -696,6 +704,7 @@ __device__ unsigned long long g_skipstats[4];
 struct Canary {
     double c = 0.0;
     __device__ __forceinline__ void watch(double x) { c = fma(0.0, x, c); }     // 0*x: 0 for finite x, NaN otherwise
+    __device__ __forceinline__ void trip() { c = __builtin_nan(""); }
     __device__ __forceinline__ bool tripped() const { return c != c; }
 };
 // one v_min_f64 / v_max_f64; a bound known at compile time is taken from the scalar file (two s_mov_b32 on the scalar
@@ -1042,10 +1051,14 @@ struct Pass2Out {
 // PASS 2 (cpp:2264-2305): ground temperature with the scaled ground heat flux,
 // canopy / leaf / air temperature and humidity at reqhgt.
 // ---------------------------------------------------------------------------------
-template <bool F, bool SS, class CL, class TM, class SL>
+// `midway` is called once, by every lane of pass 2, behind the canopy temperature: roughly the last third of the pass (leaf
+// temperature and the Lagrangian profile of a below-canopy cell) is still to come and the register file is past its
+// fullest — where the array-forcing kernel starts loading the next day's forcing (solve_tile).
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <bool F, bool SS, class CL, class TM, class SL, class HK = NoHook>
 __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, const Globals& g, int flags, double dTmx,
                                       const Carry& cy, double dtr, double Rmx, bool above_ground,
-                                      Pass2Out& o, const MathK& K, Canary& cn) {
+                                      Pass2Out& o, const MathK& K, Canary& cn, HK&& midway = NoHook()) {
     const double soilm = cy.soilm;
     // ---- section A operands: soil conductivity, ground heat flux, ground temperature
     double t_gfac = T(TF_GFAC), tc = T(TF_TC), tdew = T(TF_TDEW), ea = T(TF_EA);
@@ -1073,13 +1086,17 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
     o.DD = DD;
     if (!above_ground) return;
     // ---- section B operands: TVaboveground up to the canopy temperature
+    // (with the time values in registers, the three constants used last are read where they are used: one LDS latency
+    // each there, six registers fewer from here to there)
+    constexpr bool lean = TM::in_registers;
     double c_ghafac = C(CF_GHAFAC), c_smin = C(CF_SMIN), c_invrge = C(CF_INVRGE), c_pai = C(CF_PAI),
-           c_ksat = C(CF_KSAT), c_psunsat = C(CF_PSUNSAT), c_shadefac = C(CF_SHADEFAC), c_ompc = C(CF_OMPC),
-           c_svfa = C(CF_SVFA);
+           c_ksat = C(CF_KSAT), c_psunsat = C(CF_PSUNSAT), c_shadefac = lean ? 0.0 : C(CF_SHADEFAC),
+           c_ompc = lean ? 0.0 : C(CF_OMPC), c_svfa = lean ? 0.0 : C(CF_SVFA);
     double rlw = T(TF_RLW), rsw = T(TF_RSW), rdif = T(TF_RDIF), t_idx = T(TF_IDX), lapk = T(TF_LAPK),
            es = T(TF_ES), De = T(TF_DE), rem = T(TF_REM), ghr = T(TF_GHRRAD);
-    pin(c_ghafac, c_smin, c_invrge, c_pai, c_ksat, c_psunsat, c_shadefac, c_ompc, c_svfa, rlw, rsw, rdif, t_idx,
-        lapk, es, De, rem, ghr);
+    if (lean) pin(c_ghafac, c_smin, c_invrge, c_pai, c_ksat, c_psunsat);
+    else pin(c_ghafac, c_smin, c_invrge, c_pai, c_ksat, c_psunsat, c_shadefac, c_ompc, c_svfa, rlw, rsw, rdif, t_idx,
+             lapk, es, De, rem, ghr);
     // --- TVaboveground, cpp:1411-1472 ----------------------------------------------------------
     const double uf = cy.uf;
     double gHa = uf * c_ghafac;
@@ -1099,19 +1116,25 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
     bool have_gs2 = false;
     auto load_stom = [&]() {
         // theta-only part of stomcondCpp, cpp:451-455 with psiwfromthetaCpp cpp:382-389
-        st.gsmax = C(CF_GSMAX);
-        st.rsmx = C(CF_RSMX);
-        st.inv02rsmx = C(CF_INV02RSMX);
         if (soil_shared) {
+            st.gsmax = C(CF_GSMAX);
+            st.rsmx = C(CF_RSMX);
+            st.inv02rsmx = C(CF_INV02RSMX);
             st.gs2 = S(SD_GS2);
             pin(st.gsmax, st.rsmx, st.inv02rsmx, st.gs2);
         } else {
+            // two batches of LDS reads rather than one: 11 operands at once are 22 VGPRs at the kernel's tightest spot
             double c_rat = C(CF_RAT), c_ratc = C(CF_RATC), c_invsmax = C(CF_INVSMAX), c_abspsie = C(CF_ABSPSIE),
-                   c_soilb = C(CF_SOILB), c_psiw0 = C(CF_PSIW0), c_kk = C(CF_KK), c_mudeninv = C(CF_MUDENINV);
-            pin(c_rat, c_ratc, c_invsmax, c_abspsie, c_soilb, c_psiw0, c_kk, c_mudeninv, st.gsmax, st.rsmx,
-                st.inv02rsmx);
+                   c_soilb = C(CF_SOILB), c_psiw0 = C(CF_PSIW0);
+            pin(c_rat, c_ratc, c_invsmax, c_abspsie, c_soilb, c_psiw0);
             const double Se = stom_se<F>(soilm, c_rat, c_ratc, c_invsmax, cn);
-            const double psiw = stom_psiw<F>(powxy(Se, -c_soilb, K), c_abspsie, c_psiw0, cn);
+            double psiw = stom_psiw<F>(powxy(Se, -c_soilb, K), c_abspsie, c_psiw0, cn);
+            pin1(psiw);
+            st.gsmax = C(CF_GSMAX);
+            st.rsmx = C(CF_RSMX);
+            st.inv02rsmx = C(CF_INV02RSMX);
+            double c_kk = C(CF_KK), c_mudeninv = C(CF_MUDENINV);
+            pin(c_kk, c_mudeninv, st.gsmax, st.rsmx, st.inv02rsmx);
             st.gs2 = stom_gs2(fexp(-c_kk * psiw, K), c_mudeninv, st.gsmax);
         }
         have_gs2 = true;
@@ -1122,13 +1145,25 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
             kb = c_ksat;
             P_sun = c_psunsat;
         } else {
-            kb = fsqrt(C(CF_XX) + T(TF_TAN2B)) * C(CF_KDENINV);
+            // the degrees-call operands (cpp:1425): from the time table, or — array forcing, where this branch is the rare
+            // lane whose zenith angle in DEGREES is below pi/2 — made here from the carried zenith rather than carried
+            double tanb, tan2b, inv2cosb;
+            if (lean) {
+                const double zend = T(TF_ZEND);
+                tanb = tan(zend);
+                tan2b = tanb * tanb;
+                inv2cosb = 1.0 / (2.0 * cos(zend));
+            } else {
+                tanb = T(TF_TANB); tan2b = T(TF_TAN2B); inv2cosb = T(TF_INV2COSB);
+            }
+            kb = fsqrt(C(CF_XX) + tan2b) * C(CF_KDENINV);
             if (flags & (FL_XONE | FL_XINF | FL_XZERO))
-                kb = (flags & FL_XONE) ? T(TF_INV2COSB) : (flags & FL_XINF) ? 1.0 : T(TF_TANB);
+                kb = (flags & FL_XONE) ? inv2cosb : (flags & FL_XINF) ? 1.0 : tanb;
             cap<F>(kb, 6000.0, cn);
             P_sun = fdiv(1.0 - fexp(-kb * c_pai, K), kb);
         }
         double P_shade = c_pai - P_sun;
+        if (lean) { c_shadefac = C(CF_SHADEFAC); c_ompc = C(CF_OMPC); }
         double Rshade_abs = rdif * c_shadefac;
         double Rsun_abs = (rsw - rdif) * kb * (1 - c_ompc) + Rshade_abs;
         double gs_sun = 0.0, gs_shade = 0.0;
@@ -1142,11 +1177,13 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
     double gV = 0.0;
     if (gS > 0.0) gV = fdiv(gHa * gS, gHa + gS);           // 1/(1/gHa + 1/gS)
     // canopy temperature, cpp:1430-1432 (Penman-Monteith with the linear surface wetness)
+    if (lean) c_svfa = C(CF_SVFA);
     const double Rabs = cy.radCsw + 0.97 * c_svfa * rlw;
     const double mC = lapk * gV;
     const double Tcan = pm_temperature<F>(Rabs - rem - mC * (es - ea) * surfwet - G,
                                           29.3 * (gHa + ghr) + mC * De, dTmx, tc, tdew, cn);
     const double esTcan = satvap(Tcan, K);
+    midway();
     double ez;
     if (!(flags & FL_BELOW)) {
         // above canopy: log profile, cpp:1298-1313 / 1434-1441

@@ -28,6 +28,9 @@
 #define MCF_NT_STORES 0   // 1 (experiment): non-temporal output stores — 13 % SLOWER same-box (6.87 vs 5.99 ms per launch):
                           // the L2 no longer merges the partial lines neighbouring tiles write
 #endif
+#ifndef MCF_AF_UNPIN_VCONST
+#define MCF_AF_UNPIN_VCONST 1
+#endif
 #ifndef MCF_AF_WAVES
 #define MCF_AF_WAVES 3   // waves per SIMD the array-forcing kernels are built for (168 VGPRs)
 #endif
@@ -622,10 +625,11 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
     MK.use_table(s_exptab, tid);       // visible after the prologue's barrier
 #endif
 #if MCF_PIN_MATHK
-    MK.pin(MCF_PIN_MATHK > 1 && !(PT && MCF_PT_UNPIN_LOG));   // exp (and log) coefficients resident in SGPRs for the whole day loop
+    MK.pin(MCF_PIN_MATHK > 1 && !(PT && MCF_PT_UNPIN_LOG), AF == 0 || !MCF_AF_UNPIN_VCONST);   // exp (and log) coefficients resident in SGPRs for the whole day loop
 #endif
     const double NA = na_real();
 
+    static_assert(TF_TC == 0 && TF_SOILMP == 9 && TF_UMU < 15 && TF_GP < 15 && TF_KP < 15 && TF_MUGP < 15 && TF_DTRP < 15, "the 15 forcing series");
     Canary cn;      // F: NaN as soon as one watched clamp of this lane has met a NaN, on any day of the launch
     int run = 0;    // days this workgroup has started, over all its tiles: indexes the time, reduction and soil rings
     // soil state of day `d`, from the tile image `cells`, into ring slot `slot`, by the calling wave (all 64 lanes call)
@@ -726,6 +730,9 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
         const int64_t fidx = c + N * (a.force_step0 + kl);
         if (AF && valid) {
             const int64_t kabs = (int64_t)dabs * 24 + hr;
+            // pass 2's ground heat flux takes four more series, through ONE value (cpp:1282-1289): loaded here with the rest,
+            // so that one memory latency is exposed per day instead of two, and carried as that value
+            double p2gp = 1.0, p2mugp = 1.0, p2dtrp = 1.0, p2kp = 1.0;
             if (AF == 2) {
                 // coarse arrays: interpolate, then derive what `.runmodel2Cpp` derives after resampling
                 // (slot TF_ES carries relhum, TF_U2 / TF_EA the wind components u, v)
@@ -744,13 +751,34 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
                 const double s2 = wu * wu + wv * wv;
                 tv.v[TF_U2] = s2 > 0.0 ? fsqrt(s2) : 0.0;
                 tv.v[TF_SOILMP] = at(TF_SOILMP); tv.v[TF_UMU] = at(TF_UMU);
+                if (a.need_pass2) { p2gp = at(TF_GP); p2mugp = at(TF_MUGP); p2dtrp = at(TF_DTRP); p2kp = at(TF_KP); }
             } else {
-            // TF_TC .. TF_SOILMP and TF_UMU feed pass 1; Gp, kp, muGp, dtrp are reloaded for pass 2
-            for (int f = 0; f < 10; ++f) tv.v[f] = a.af_base[(int64_t)f * a.af_stride + fidx];
-            tv.v[TF_UMU] = a.af_base[(int64_t)TF_UMU * a.af_stride + fidx];
+                // the 15 series, slots TF_TC .. TF_DTRP: ten raw inputs and umu feed pass 1; Gp, kp, muGp, dtrp feed GFAC below
+                for (int f = 0; f < 10; ++f) tv.v[f] = a.af_base[(int64_t)f * a.af_stride + fidx];
+                tv.v[TF_UMU] = a.af_base[(int64_t)TF_UMU * a.af_stride + fidx];
+                if (a.need_pass2) {
+                    p2gp = a.af_base[(int64_t)TF_GP * a.af_stride + fidx]; p2mugp = a.af_base[(int64_t)TF_MUGP * a.af_stride + fidx];
+                    p2dtrp = a.af_base[(int64_t)TF_DTRP * a.af_stride + fidx]; p2kp = a.af_base[(int64_t)TF_KP * a.af_stride + fidx];
+                }
             }
             DateRow dr{a.dt[4 * kabs + 0], a.dt[4 * kabs + 1], a.dt[4 * kabs + 2], a.dt[4 * kabs + 3]};
             derive_time_af(tv, dr, C(CF_SINLAT), C(CF_COSLAT), C(CF_COSB), C(CF_SINB), a.windex[kabs], MK);
+            // (a zero or infinite divisor is a forcing value like any other here: IEEE division where the clamps are the
+            // reference's — the fast reciprocal makes 0 * inf of it; the fast variant's check below sends such a lane there)
+            tv.v[TF_GFAC] = F ? fdiv(p2gp * p2mugp, p2dtrp * p2kp) : (p2gp * p2mugp) / (p2dtrp * p2kp);
+            if (F) {
+                // a NaN or a zero denominator among the four shows in GFAC, an infinite one in their sum
+                cn.watch(tv.v[TF_GFAC]);
+                cn.watch((p2gp + p2mugp) + (p2dtrp + p2kp));
+                // Array forcing has no per-step table the host could classify (kStepIrregular): every lane checks its own
+                // forcing here, with derive_time's conditions — the values read are finite, the signs the fast clamps rely on
+                // hold — and a failing lane trips the canary, so that k_solve_fix redoes its tile with the reference's clamps.
+                for (int f = 0; f < 10; ++f) cn.watch(tv.v[f]);
+                cn.watch(tv.v[TF_UMU]);
+                cn.watch(tv.v[TF_RBEAM]);
+                cn.watch(dTmx);                 // from the cell's mxtc, the maximum of its temperature series
+                if (!(tv.v[TF_DE] > 0.0 && tv.v[TF_GHRRAD] > 0.0 && tv.v[TF_LAPK] > 0.0 && tv.v[TF_PK] > 0.0)) cn.trip();
+            }
         }
         TimeLds TL{s_time + (AF ? 0 : (run % 3) * (TF_COUNT * 24)) + hr};
         TimeReg TR{&tv};
@@ -868,19 +896,7 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
             }
             const double dtr = tmx - tmn;
             Pass2Out p2{};
-            if (AF) {
-                if (AF == 2) {
-                    const CoarseTap tap(C(CF_CROWPOS), C(CF_CCOLPOS), a.crows, a.ccols);
-                    const double* q = a.af_base + (int64_t)a.crows * a.ccols * ((int64_t)dabs * 24 + hr);
-                    derive_time_af_pass2(tv, tap(q + (int64_t)TF_GP * a.af_stride), tap(q + (int64_t)TF_MUGP * a.af_stride),
-                                         tap(q + (int64_t)TF_DTRP * a.af_stride), tap(q + (int64_t)TF_KP * a.af_stride));
-                } else {
-                    derive_time_af_pass2(tv, a.af_base[(int64_t)TF_GP * a.af_stride + fidx],
-                                         a.af_base[(int64_t)TF_MUGP * a.af_stride + fidx],
-                                         a.af_base[(int64_t)TF_DTRP * a.af_stride + fidx],
-                                         a.af_base[(int64_t)TF_KP * a.af_stride + fidx]);
-                }
-            }
+            if (AF) derive_time_af_pass2(tv);
             if (AF) pass2<F, false>(C, TR, SL, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2, MK, cn);
             else pass2<F, SS>(C, TL, SL, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2, MK, cn);
             if (BG) {
@@ -987,8 +1003,8 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
 // Redoes, with the reference's compare-and-select clamps, the tiles in which a fast wave's canary tripped.  Launched
 // behind every fast launch with a fixed small grid; with an empty list (the normal case) every workgroup leaves at once.
 // An overflowing list means "everything": all tiles, all days of the launch.
-template <int CPB>
-__global__ __launch_bounds__(solve_threads(CPB), MCF_WAVES_PER_EU) void k_solve_fix(SolveArgs a) {
+template <int CPB, int AF>
+__global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_PER_EU) void k_solve_fix(SolveArgs a) {
     const int n = *a.fix_count;
     if (n <= 0) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.fix_count + 1, n);     // running total, for mcf_plan_dispatch_stats
@@ -996,13 +1012,13 @@ __global__ __launch_bounds__(solve_threads(CPB), MCF_WAVES_PER_EU) void k_solve_
         const int64_t ntiles = (a.N + CPB - 1) / CPB;
         for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
             __syncthreads();
-            solve_tile<CPB, 0, false, false, false, false>(a, t, 0, 1, a.day0, a.ndays, 0);
+            solve_tile<CPB, AF, false, false, false, false>(a, t, 0, 1, a.day0, a.ndays, 0);
         }
         return;
     }
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         __syncthreads();
-        solve_tile<CPB, 0, false, false, false, false>(a, (int64_t)a.fix_list[i], 0, 1, a.day0, a.ndays, 0);
+        solve_tile<CPB, AF, false, false, false, false>(a, (int64_t)a.fix_list[i], 0, 1, a.day0, a.ndays, 0);
     }
 }
 
@@ -1397,16 +1413,19 @@ static void launch_solve_cpb(SolveArgs a, bool af, bool bg, bool fast, bool ss, 
         const int64_t per_xcd = (a.ntiles_launch + 7) / 8;
         const dim3 gridp((unsigned)(8 * ((per_xcd + a.tiles_per_wg - 1) / a.tiles_per_wg)));
         hipLaunchKernelGGL((k_solve<CPB, 0, false, true, true, kPtBuilt>), gridp, block, 0, s, a);
-        hipLaunchKernelGGL((k_solve_fix<CPB>), dim3(512), block, 0, s, a);
+        hipLaunchKernelGGL((k_solve_fix<CPB, 0>), dim3(512), block, 0, s, a);
     } else if (af) {
         if (bg) hipLaunchKernelGGL((k_solve<CPB, 1, true, false, false, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_solve<CPB, 1, false, false, false, false>), grid, block, 0, s, a);
+        else if (fast && MCF_FAST_CLAMPS) {
+            hipLaunchKernelGGL((k_solve<CPB, 1, false, true, false, false>), grid, block, 0, s, a);
+            hipLaunchKernelGGL((k_solve_fix<CPB, 1>), dim3(512), block, 0, s, a);
+        } else hipLaunchKernelGGL((k_solve<CPB, 1, false, false, false, false>), grid, block, 0, s, a);
     } else if (bg) {
         hipLaunchKernelGGL((k_solve<CPB, 0, true, false, false, false>), grid, block, 0, s, a);
     } else if (fast && MCF_FAST_CLAMPS) {
         if (ss) hipLaunchKernelGGL((k_solve<CPB, 0, false, true, true, false>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((k_solve<CPB, 0, false, true, false, false>), grid, block, 0, s, a);
-        hipLaunchKernelGGL((k_solve_fix<CPB>), dim3(512), block, 0, s, a);
+        hipLaunchKernelGGL((k_solve_fix<CPB, 0>), dim3(512), block, 0, s, a);
     } else {
         if (ss) hipLaunchKernelGGL((k_solve<CPB, 0, false, false, true, false>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((k_solve<CPB, 0, false, false, false, false>), grid, block, 0, s, a);
@@ -1418,13 +1437,18 @@ void launch_tile_regular(const double* cellc, int64_t N, int layers, int cpb, ui
     hipLaunchKernelGGL(k_tile_regular, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, s, cellc, N, layers, cpb, ntiles, out);
 }
 // coarse array forcing is built for the array-forcing geometry (32 cells per workgroup) only
-static void launch_solve_coarse(SolveArgs a, bool bg, hipStream_t s) {
+static void launch_solve_coarse(SolveArgs a, bool bg, bool fast, hipStream_t s) {
     constexpr int CPB = 32;
-    a.ntiles_launch = (a.N + CPB - 1) / CPB;
-    a.tile_list = nullptr;
+    if (a.ntiles_launch <= 0) {
+        a.ntiles_launch = (a.N + CPB - 1) / CPB;
+        a.tile_list = nullptr;
+    }
     const dim3 grid = solve_grid(a.ntiles_launch), block(solve_threads(CPB));
     if (bg) hipLaunchKernelGGL((k_solve<CPB, 2, true, false, false, false>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_solve<CPB, 2, false, false, false, false>), grid, block, 0, s, a);
+    else if (fast && MCF_FAST_CLAMPS) {
+        hipLaunchKernelGGL((k_solve<CPB, 2, false, true, false, false>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((k_solve_fix<CPB, 2>), dim3(512), block, 0, s, a);
+    } else hipLaunchKernelGGL((k_solve<CPB, 2, false, false, false, false>), grid, block, 0, s, a);
 }
 int twi_scratch_doubles() { return 2 + 2 * kTwiParts; }
 int cell_field_count() { return CF_COUNT; }
@@ -1441,7 +1465,7 @@ double hf_pow02(double rs) {
 void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, bool fast, bool soil_daily, bool persistent,
                   hipStream_t s) {
     if (a.N <= 0 || a.ndays <= 0) return;
-    if (a.crows > 0) { launch_solve_coarse(a, bg, s); return; }
+    if (a.crows > 0) { launch_solve_coarse(a, bg, fast, s); return; }
     if (cells_per_block == 32) launch_solve_cpb<32>(a, af, bg, fast, soil_daily, persistent, s);
     else if (cells_per_block == 21) launch_solve_cpb<21>(a, af, bg, fast, soil_daily, persistent, s);
     else if (cells_per_block == 42) launch_solve_cpb<42>(a, af, bg, fast, soil_daily, persistent, s);

@@ -117,3 +117,38 @@ def test_soil_state_shared_per_day_or_per_lane_gives_the_same_bits(oracle):
         by_day = np.concatenate(parts[k], axis=2)
         assert np.array_equal(by_day.view(np.uint64), whole[k].view(np.uint64)), k
     _same(whole, oracle.run_grid(**a))
+
+
+# ---- array forcing: no per-step table the host could classify; every lane checks its own forcing values ---------------
+def _solve_af(a, days, **kw):
+    with Plan(**a, array_forcing=kw.pop("mode", True), ring_days=days, ring_slots=1, **kw) as p:
+        if not kw.get("coarse_rows"):
+            p.upload_forcing_days(0, days, 0)
+        p.run_days(0, days, 0)
+        p.sync()
+        got = {k: p.fetch(0, k, 0, days * 24) for k in NAMES}
+        st = p.dispatch_stats()
+    return got, st
+
+
+def test_array_forcing_runs_the_fast_clamps_too(oracle):
+    a = synthetic.workload(33, 8, 72, reqhgt=0.05, start_doy=170, variety=True, array_forcing=True)
+    got, st = _solve_af(a, 3)
+    assert st["fast_tiles"] == -(-33 * 8 // 32) and st["slow_tiles"] == 0, st
+    assert st["fast_launches"] == 1 and st["slow_launches"] == 0 and st["canary_trips"] == 0, st
+    _same(got, oracle.run_grid(**a, array_forcing=True))
+
+
+@pytest.mark.parametrize("series,value", [("lwdown", np.nan), ("tc", np.inf), ("pk", -101.3), ("Gp", np.nan), ("dtrp", 0.0),
+                                          ("kp", np.inf)])
+def test_a_lane_with_bad_array_forcing_has_its_tile_redone(oracle, series, value):
+    """One value of one cell's series is not finite, or has the sign that breaks what the min / max clamps rely on (a negative
+    pressure; a zero or infinite divisor of the ground-heat-flux factor): the lane's check trips the canary, the fix-up
+    kernel redoes the tile with the reference's clamps, and the result is the oracle's — NaN for NaN."""
+    a = synthetic.workload(32, 5, 48, reqhgt=0.05, start_doy=170, array_forcing=True)
+    grp = "pointm" if series in a["pointm"] else "climdata"
+    a[grp][series] = a[grp][series].copy(order="F")
+    a[grp][series][7, 2, 30] = value            # tile 2, day 1, hour 6
+    got, st = _solve_af(a, 2)
+    assert st["slow_tiles"] == 0 and st["fast_launches"] == 1 and st["canary_trips"] >= 1, st
+    _same(got, oracle.run_grid(**a, array_forcing=True))
