@@ -621,7 +621,7 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
     MathK MK;
     MK.set();
 #if MCF_EXP_TABLE
-    __shared__ double s_exptab[64];
+    __shared__ double s_exptab[256];
     MK.use_table(s_exptab, tid);       // visible after the prologue's barrier
 #endif
 #if MCF_PIN_MATHK
@@ -1246,7 +1246,7 @@ __global__ void k_selftest_math(int kind, const double* __restrict__ x, const do
     MathK K;
     K.set();
 #if MCF_EXP_TABLE
-    __shared__ double s_exptab[64];      // the route k_solve takes
+    __shared__ double s_exptab[256];      // the route k_solve takes
     K.use_table(s_exptab, (int)threadIdx.x);
     __syncthreads();
 #endif
