@@ -8,8 +8,11 @@ for spec in "$@"; do
   name=${spec%%=*}; args=${spec#*=}
   rocprofv3 --kernel-trace --output-format csv -d $out/$name --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT -- \
     python3 bench.py $args --steps 1 --warmup 0 --no-cpu-baseline --no-secondary --no-verify > $out/$name.json 2> $out/$name.err
-  rocprofv3 --kernel-trace --output-format csv -d $out/${name}_mem --pmc FETCH_SIZE WRITE_SIZE -- \
-    python3 bench.py $args --steps 1 --warmup 0 --no-cpu-baseline --no-secondary --no-verify > /dev/null 2> $out/${name}_mem.err
+  for c in FETCH_SIZE WRITE_SIZE; do      # one counter per pass: the two together stalled the run on this pool
+    rocprofv3 --kernel-trace --output-format csv -d $out/${name}_mem --pmc $c -- \
+      python3 bench.py $args --steps 1 --warmup 0 --no-cpu-baseline --no-secondary --no-verify > /dev/null 2> $out/${name}_mem_$c.err
+    echo "$name $c done"
+  done
   python3 - <<P
 import csv, glob, collections
 for sub in ("$name", "${name}_mem"):
