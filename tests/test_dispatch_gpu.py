@@ -152,3 +152,18 @@ def test_a_lane_with_bad_array_forcing_has_its_tile_redone(oracle, series, value
     got, st = _solve_af(a, 2)
     assert st["slow_tiles"] == 0 and st["fast_launches"] == 1 and st["canary_trips"] >= 1, st
     _same(got, oracle.run_grid(**a, array_forcing=True))
+
+
+def test_coinciding_lagrangian_resistances_are_redone_with_the_reference_form(oracle):
+    """A wind speed so large (finite, so the step is REGULAR) that both canopy resistances fall under their 0.001 floor
+    (rhcanopy, src/microclimfCpp.cpp:1378-1379): Rc - Rz = 0 and the reference's far field is inf * 0 = NaN (cpp:1388-1395).
+    The fast variant's single-reciprocal form has the finite limit there, so it must hand such tiles to the reference form —
+    the result is the oracle's, NaN for NaN."""
+    a = synthetic.workload(21, 4, 48, reqhgt=0.05, start_doy=170)
+    a["climdata"]["windspeed"] = a["climdata"]["windspeed"].copy()
+    a["climdata"]["windspeed"][30] = 1e8
+    got, st = _solve(a, 2)
+    want = oracle.run_grid(**a)
+    assert np.isnan(want["Tz"][:, :, 30]).sum() > 60 and np.isfinite(want["Tz"][:, :, 31]).all()
+    assert st["irregular_days"] == 0 and st["fast_launches"] == 1 and st["canary_trips"] >= 1, st
+    _same(got, want)
