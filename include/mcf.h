@@ -504,6 +504,15 @@ int mcf_snowplan_handover(mcf_snowplan *plan, double *host_isnowdc);
 int mcf_snowplan_surface_partial(mcf_snowplan *plan, double *sum, double *count);
 int mcf_snowplan_prepare_chunk(mcf_snowplan *plan, int32_t chunk, const double *ext, int32_t halo_north,
                                int32_t halo_south, double surface_mean, double *tpic_sum, double *tpic_count);
+/* The same exchange without host staging (one process per GPU, RCCL send / recv on device buffers): pack_halo copies the own
+ * block's first `rows_north` / last `rows_south` surface rows into the caller's DEVICE buffers as column-major
+ * [rows_north, cols] / [rows_south, cols] pieces — what the neighbouring ranks receive as their halos — and returns when they
+ * are complete; prepare_chunk_dev takes the received pieces as device pointers and puts [north; own; south] together on the
+ * device.  Same results as the host-pointer pair above, bit for bit. */
+int mcf_snowplan_pack_halo(mcf_snowplan *plan, int32_t rows_north, double *d_north, int32_t rows_south, double *d_south);
+int mcf_snowplan_prepare_chunk_dev(mcf_snowplan *plan, int32_t chunk, const double *d_halo_north, int32_t halo_north,
+                                   const double *d_halo_south, int32_t halo_south, double surface_mean, double *tpic_sum,
+                                   double *tpic_count);
 int mcf_snowplan_run_chunk(mcf_snowplan *plan, int32_t chunk, double tpic_mean, mcf_snowdriver_out *out);
 /* applycpp3 (src/microclimfCpp.cpp:5553-5588) of the totalSWE series of the chunk just run, straight from the device:
  * result / count [steps of that chunk] as mcf_applycpp3 gives them.  `.runmicrosnow1` decides snow / no-snow days on the

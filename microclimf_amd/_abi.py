@@ -171,7 +171,8 @@ EXPORTS = (
     "mcf_snowenv_from_name", "mcf_gridmodelsnow1", "mcf_gridmodelsnow2", "mcf_gridmicrosnow1",
     "mcf_gridmicrosnow2", "mcf_snowmodel1", "mcf_applycpp3",
     "mcf_snowplan_create", "mcf_snowplan_destroy", "mcf_snowplan_chunks", "mcf_snowplan_surface", "mcf_snowplan_handover", "mcf_snowplan_apply3",
-    "mcf_snowplan_surface_partial", "mcf_snowplan_prepare_chunk", "mcf_snowplan_run_chunk",
+    "mcf_snowplan_surface_partial", "mcf_snowplan_prepare_chunk", "mcf_snowplan_run_chunk", "mcf_snowplan_pack_halo",
+    "mcf_snowplan_prepare_chunk_dev",
     "mcf_bigleaf", "mcf_soilm", "mcf_pointmprocess", "mcf_weatherhgt", "mcf_man", "mcf_pointmodelsnow", "mcf_canintfrac", "mcf_meltmu", "mcf_meltmu2", "mcf_tpicalc",
     "mcf_nc_create", "mcf_nc_write_host", "mcf_nc_write_plan", "mcf_nc_close",
     "mcf_flowacc", "mcf_topidx",
@@ -190,6 +191,30 @@ class DispatchStats(C.Structure):
                                          "canary_trips")]
 
 
+def _share_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's); the copy
+    that is loaded first serves every later user.  If libmcfhip pulled in /opt/rocm's first, a later `import torch` would
+    bring a SECOND runtime into the process and find no device ("No HIP GPUs are available").  Where torch is installed but
+    not imported yet, its copy is therefore loaded first — the same state as importing torch before this package.  Hosts
+    without torch (an R session) use /opt/rocm's."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    cand = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+    if cand.exists():
+        try:
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load() -> C.CDLL:
     """Load libmcfhip.so (built by `make -C microclimf_amd/csrc` / build())."""
     global _lib
@@ -201,6 +226,7 @@ def load() -> C.CDLL:
             f"{path} not found: the HIP extension is not built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'` or "
             "`make -C microclimf_amd/csrc`). There is no CPU fallback.")
+    _share_hip_runtime()
     lib = C.CDLL(str(path))
     lib.mcf_abi_version.restype = C.c_int
     lib.mcf_last_error.restype = C.c_char_p
@@ -312,6 +338,11 @@ def load() -> C.CDLL:
     lib.mcf_snowplan_prepare_chunk.restype = C.c_int
     lib.mcf_snowplan_prepare_chunk.argtypes = [P, C.c_int32, c_double_p, C.c_int32, C.c_int32, C.c_double, c_double_p,
                                                c_double_p]
+    lib.mcf_snowplan_pack_halo.restype = C.c_int
+    lib.mcf_snowplan_pack_halo.argtypes = [P, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.mcf_snowplan_prepare_chunk_dev.restype = C.c_int
+    lib.mcf_snowplan_prepare_chunk_dev.argtypes = [P, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_double, c_double_p,
+                                                   c_double_p]
     lib.mcf_snowplan_run_chunk.restype = C.c_int
     lib.mcf_snowplan_run_chunk.argtypes = [P, C.c_int32, C.c_double, C.POINTER(SnowDriverOut)]
     lib.mcf_snowmodel1.restype = C.c_int

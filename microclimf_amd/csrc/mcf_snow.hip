@@ -1046,24 +1046,83 @@ extern "C" int mcf_snowplan_surface_partial(mcf_snowplan* sp, double* sum, doubl
     *sum = h[0]; *count = h[1];
     return MCF_OK;
 }
+// own block + halo rows, column-major [hn + rows + hs, cols], put together on the device from three column-major pieces
+__global__ void k_ext_assemble(double* __restrict__ ext, const double* __restrict__ own, const double* __restrict__ north,
+                               const double* __restrict__ south, int64_t rows, int64_t cols, int hn, int hs) {
+    const int64_t RB = hn + rows + hs, t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= RB * cols) return;
+    const int64_t r = t % RB, c = t / RB;
+    ext[t] = r < hn ? north[r + (int64_t)hn * c] : r < hn + rows ? own[(r - hn) + rows * c] : south[(r - hn - rows) + (int64_t)hs * c];
+}
+// the own block's first hn / last hs rows as column-major [h, cols] pieces (what a neighbouring rank receives as its halo)
+__global__ void k_halo_pack(const double* __restrict__ own, int64_t rows, int64_t cols, int hn, int hs, double* __restrict__ north,
+                            double* __restrict__ south) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, h = hn + hs;
+    if (t >= h * cols) return;
+    const int64_t i = t % h, c = t / h;
+    if (i < hn) north[i + (int64_t)hn * c] = own[i + rows * c];
+    else south[(i - hn) + (int64_t)hs * c] = own[(rows - hs + (i - hn)) + rows * c];
+}
+static int ext_room(mcf_snowplan* sp, int64_t n) {
+    if (sp->ext_cap < n) {
+        int rc;
+        if ((rc = sp->b.alloc((void**)&sp->d_ext, n * 8))) return rc;
+        sp->ext_cap = n;
+    }
+    return MCF_OK;
+}
+static int prepare_chunk_on(mcf_snowplan* sp, int32_t ch, const double* d_z, int32_t hn, int32_t hs, double surface_mean,
+                            double* tpic_sum, double* tpic_count);
+
 extern "C" int mcf_snowplan_prepare_chunk(mcf_snowplan* sp, int32_t ch, const double* ext, int32_t hn, int32_t hs,
                                           double surface_mean, double* tpic_sum, double* tpic_count) {
     if (!sp || !tpic_sum || !tpic_count) return mcf::api_fail(MCF_ERR_ARG, "null argument");
     if (ch < 0 || ch >= sp->nchunks) return mcf::api_fail(MCF_ERR_ARG, "chunk out of range");
     if (hn < 0 || hs < 0 || (!ext && (hn || hs))) return mcf::api_fail(MCF_ERR_ARG, "bad halo");
     S_TRY(hipSetDevice(sp->device));
+    const double* d_z = sp->d_dtms;
+    if (ext) {
+        const int64_t n = (hn + sp->rows + hs) * sp->cols;
+        int rc;
+        if ((rc = ext_room(sp, n))) return rc;
+        S_TRY(hipMemcpy(sp->d_ext, ext, (size_t)n * 8, hipMemcpyHostToDevice));
+        d_z = sp->d_ext;
+    }
+    return prepare_chunk_on(sp, ch, d_z, hn, hs, surface_mean, tpic_sum, tpic_count);
+}
+extern "C" int mcf_snowplan_pack_halo(mcf_snowplan* sp, int32_t hn, double* d_north, int32_t hs, double* d_south) {
+    if (!sp || hn < 0 || hs < 0 || hn > sp->rows || hs > sp->rows || (hn && !d_north) || (hs && !d_south))
+        return mcf::api_fail(MCF_ERR_ARG, "bad mcf_snowplan_pack_halo argument");
+    S_TRY(hipSetDevice(sp->device));
+    const int64_t n = (int64_t)(hn + hs) * sp->cols;
+    if (n > 0) hipLaunchKernelGGL(k_halo_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, sp->d_dtms, sp->rows, sp->cols, hn, hs, d_north, d_south);
+    S_TRY(hipGetLastError());
+    S_TRY(hipStreamSynchronize(nullptr));      // the pieces are the caller's to send from here on
+    return MCF_OK;
+}
+extern "C" int mcf_snowplan_prepare_chunk_dev(mcf_snowplan* sp, int32_t ch, const double* d_north, int32_t hn, const double* d_south,
+                                              int32_t hs, double surface_mean, double* tpic_sum, double* tpic_count) {
+    if (!sp || !tpic_sum || !tpic_count) return mcf::api_fail(MCF_ERR_ARG, "null argument");
+    if (ch < 0 || ch >= sp->nchunks) return mcf::api_fail(MCF_ERR_ARG, "chunk out of range");
+    if (hn < 0 || hs < 0 || (hn && !d_north) || (hs && !d_south)) return mcf::api_fail(MCF_ERR_ARG, "bad halo");
+    S_TRY(hipSetDevice(sp->device));
+    const double* d_z = sp->d_dtms;
+    if (hn || hs) {
+        const int64_t n = (hn + sp->rows + hs) * sp->cols;
+        int rc;
+        if ((rc = ext_room(sp, n))) return rc;
+        hipLaunchKernelGGL(k_ext_assemble, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, sp->d_ext, sp->d_dtms, d_north, d_south,
+                           sp->rows, sp->cols, hn, hs);
+        S_TRY(hipGetLastError());
+        d_z = sp->d_ext;
+    }
+    return prepare_chunk_on(sp, ch, d_z, hn, hs, surface_mean, tpic_sum, tpic_count);
+}
+static int prepare_chunk_on(mcf_snowplan* sp, int32_t ch, const double* d_z, int32_t hn, int32_t hs, double surface_mean,
+                            double* tpic_sum, double* tpic_count) {
     int rc, af;
     if ((rc = chunk_af(sp, ch, &af))) return rc;
     const int64_t rows = sp->rows, cols = sp->cols, N = sp->N, RB = hn + rows + hs;
-    const double* d_z = sp->d_dtms;
-    if (ext) {
-        if (sp->ext_cap < RB * cols) {
-            if ((rc = sp->b.alloc((void**)&sp->d_ext, RB * cols * 8))) return rc;
-            sp->ext_cap = RB * cols;
-        }
-        S_TRY(hipMemcpy(sp->d_ext, ext, (size_t)(RB * cols) * 8, hipMemcpyHostToDevice));
-        d_z = sp->d_ext;
-    }
     const int64_t me = std::min(sp->rows_total, cols);
     const bool coarse = (double)af < me / 2.0;
     TpiGeo g;

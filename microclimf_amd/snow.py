@@ -604,6 +604,7 @@ class SnowPlan:
         self._p = C.c_void_p()
         _abi.check(self._lib.mcf_snowplan_create(C.byref(din), int(row0), int(rows_total), device, C.byref(self._p)))
         self.rows, self.cols, self.tsteps = R, Cc, self._m.tsteps
+        self.device = int(device)
         self.chunks = int(self._lib.mcf_snowplan_chunks(self._p))
         self._chunk_steps = int(chunk_steps) if chunk_steps else 120
         self._out = _abi.SnowDriverOut()
@@ -673,8 +674,87 @@ class SnowPlan:
                                                         float(surface_mean), C.byref(s), C.byref(n)))
         return s.value, n.value
 
+    def pack_halo(self, north=None, south=None):
+        """The own block's first / last surface rows into DEVICE tensors `north` [cols, h] / `south` (torch, float64, contiguous:
+        the memory is a column-major [h, cols] piece) — what the neighbouring ranks receive as their halos.  No host staging."""
+        hn, pn = _dev_piece(north, self.cols)
+        hs, ps = _dev_piece(south, self.cols)
+        _abi.check(self._lib.mcf_snowplan_pack_halo(self._p, hn, pn, hs, ps))
+
+    def prepare_chunk_dev(self, chunk: int, north=None, south=None, surface_mean: float = 0.0):
+        """prepare_chunk with the halo pieces as device tensors ([cols, h], as pack_halo writes them)."""
+        hn, pn = _dev_piece(north, self.cols)
+        hs, ps = _dev_piece(south, self.cols)
+        s, n = C.c_double(), C.c_double()
+        _abi.check(self._lib.mcf_snowplan_prepare_chunk_dev(self._p, int(chunk), pn, hn, ps, hs, float(surface_mean), C.byref(s),
+                                                            C.byref(n)))
+        return s.value, n.value
+
     def run_chunk(self, chunk: int, tpic_mean: float):
         _abi.check(self._lib.mcf_snowplan_run_chunk(self._p, int(chunk), float(tpic_mean), C.byref(self._out)))
+
+
+def _dev_piece(t, cols):
+    """(rows, device pointer) of a halo piece held as a torch tensor [cols, h] on the GPU"""
+    if t is None or t.numel() == 0:
+        return 0, None
+    if not t.is_cuda or str(t.dtype) != "torch.float64" or not t.is_contiguous() or t.dim() != 2 or t.shape[0] != cols:
+        raise ValueError("a halo piece is a contiguous float64 CUDA tensor of shape [cols, rows]")
+    return int(t.shape[1]), C.c_void_p(t.data_ptr())
+
+
+class DeviceHalo:
+    """Halo exchange of a SnowPlan's surface between neighbouring ranks without host staging: the 128 boundary rows are packed
+    on the device, sent / received point-to-point as device tensors (RCCL when the backend is nccl; any other backend moves
+    those rows — not the block — through the host) and handed to prepare_chunk_dev.  Buffers are allocated once."""
+
+    def __init__(self, plan, rank: int, world: int, halo: int | None = None):
+        import torch
+        import torch.distributed as dist
+        from .terrain import HALO
+        self.plan, self.rank, self.world = plan, rank, world
+        halo = HALO if halo is None else halo
+        dev = torch.device("cuda", plan.device)
+        counts = torch.zeros(world, dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        counts[rank] = plan.rows
+        dist.all_reduce(counts)
+        counts = [int(v) for v in counts.tolist()]
+        mk = lambda h: torch.empty((plan.cols, h), dtype=torch.float64, device=dev)      # noqa: E731
+        own = min(halo, plan.rows)
+        self.send_n = mk(own) if rank > 0 else None
+        self.send_s = mk(own) if rank < world - 1 else None
+        self.recv_n = mk(min(halo, counts[rank - 1])) if rank > 0 else None
+        self.recv_s = mk(min(halo, counts[rank + 1])) if rank < world - 1 else None
+        self.on_device = dist.get_backend() == "nccl"
+
+    def exchange(self):
+        """-> (north piece, south piece) as device tensors (None at the raster's edge)"""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return None, None
+        self.plan.pack_halo(self.send_n, self.send_s)
+        st = (lambda t: t) if self.on_device else (lambda t: t.cpu())
+        ops, rn, rs = [], None, None
+        if self.rank > 0:
+            rn = self.recv_n if self.on_device else torch.empty(self.recv_n.shape, dtype=torch.float64)
+            ops.append(dist.P2POp(dist.irecv, rn, self.rank - 1))
+            ops.append(dist.P2POp(dist.isend, st(self.send_n), self.rank - 1))
+        if self.rank < self.world - 1:
+            rs = self.recv_s if self.on_device else torch.empty(self.recv_s.shape, dtype=torch.float64)
+            ops.append(dist.P2POp(dist.isend, st(self.send_s), self.rank + 1))
+            ops.append(dist.P2POp(dist.irecv, rs, self.rank + 1))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if self.on_device:
+            torch.cuda.current_stream().synchronize()      # the library's kernels run on the null stream
+        else:
+            if rn is not None:
+                self.recv_n.copy_(rn)
+            if rs is not None:
+                self.recv_s.copy_(rs)
+            torch.cuda.synchronize()
+        return self.recv_n, self.recv_s
 
 
 def snowmodel1_chunks_tiled(plan, rank: int, world: int, *, exchange=None, allreduce=None) -> dict:

@@ -213,6 +213,54 @@ def test_snowplan_two_row_blocks_equal_the_whole_raster(rows, cols, split):
             assert_close(got, w, 1e-9, k)
 
 
+@pytest.mark.parametrize("rows,cols,split", [(300, 40, 150), (290, 30, 160)])
+def test_halo_pieces_packed_and_joined_on_the_device_give_the_same_bits(rows, cols, split):
+    """mcf_snowplan_pack_halo / prepare_chunk_dev: the 128 boundary rows go from one plan to the other as device tensors
+    (what RCCL send / recv carries between ranks), nothing passes through the host — and every series equals, bit for bit,
+    what the host-staged exchange of the test above produces."""
+    import torch
+    from microclimf_amd.snow import SnowPlan
+    sw, dtm = _driver_case(rows, cols, 240)
+
+    def block(sl):
+        veg = {k: v[sl] for k, v in sw["vegp"].items()}
+        oth = {k: (v[sl] if isinstance(v, np.ndarray) and v.ndim >= 2 else v) for k, v in sw["other"].items()}
+        return SnowPlan(sw["obstime"], sw["climdata"], sw["pointm"], veg, oth, sw["snowenv"], dtm[sl], 1.0, 0.02,
+                        row0=sl.start, rows_total=rows)
+
+    H = 128
+    ha, hb = min(H, split), min(H, rows - split)
+    results = []
+    for on_device in (False, True):
+        with block(slice(0, split)) as pa, block(slice(split, rows)) as pb:
+            a_south = torch.empty((cols, ha), dtype=torch.float64, device="cuda")     # pa's last rows -> pb's northern halo
+            b_north = torch.empty((cols, hb), dtype=torch.float64, device="cuda")     # pb's first rows -> pa's southern halo
+            for ch in range(pa.chunks):
+                (s1, n1), (s2, n2) = pa.surface_partial(), pb.surface_partial()
+                smean = (s1 + s2) / (n1 + n2)
+                if on_device:
+                    pa.pack_halo(None, a_south)
+                    pb.pack_halo(b_north, None)
+                    ta = pa.prepare_chunk_dev(ch, None, b_north, smean)
+                    tb = pb.prepare_chunk_dev(ch, a_south, None, smean)
+                else:
+                    sa, sb = pa.surface(), pb.surface()
+                    ta = pa.prepare_chunk(ch, np.concatenate([sa, sb[:H]], axis=0), 0, hb, smean)
+                    tb = pb.prepare_chunk(ch, np.concatenate([sa[-H:], sb], axis=0), ha, 0, smean)
+                assert ta[1] > 0 and tb[1] > 0
+                tmean = (ta[0] + tb[0]) / (ta[1] + tb[1])
+                pa.run_chunk(ch, tmean)
+                pb.run_chunk(ch, tmean)
+            results.append({k: np.concatenate([pa.result[k], pb.result[k]], axis=0).copy() for k in pa.result})
+    for k in results[0]:
+        assert np.array_equal(results[0][k], results[1][k], equal_nan=True), k
+    with block(slice(0, split)) as pa:
+        with pytest.raises(ValueError, match="halo piece"):
+            pa.pack_halo(None, torch.empty((cols, 4), dtype=torch.float32, device="cuda"))
+        with pytest.raises(_abi.McfError, match="halo rows"):
+            pa.prepare_chunk_dev(0, None, None, 0.0)
+
+
 def test_snowplan_checks_halo_and_order():
     from microclimf_amd.snow import SnowPlan
     sw, dtm = _driver_case(200, 24, 48)

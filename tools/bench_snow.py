@@ -3,8 +3,8 @@ dealt to 8 ranks in row blocks (strong scaling; with fewer GPUs every rank runs 
 
 One "step" = one simulated year of a rank's block through the reference's snow pipeline, device-resident:
   per 5-day chunk (R/internal.R:2553-2617 `.snowmodel1`, 73 chunks):
-    snow surface of the own rows -> halo rows point-to-point to the neighbouring ranks (RCCL send/recv; the terrain stencil
-    and `.tpicalc`'s block means reach +-128 rows), (sum, count) all-reduce of the surface
+    128 boundary rows of the snow surface point-to-point to the neighbouring ranks, device to device (RCCL send/recv; the
+    terrain stencil and `.tpicalc`'s block means reach +-128 rows), (sum, count) all-reduce of the surface
     -> terrain refresh from dtm + snow depth (slope, aspect, 24 horizons, sky view, 8 wind-shelter maps), tpic
     -> (sum, count) all-reduce of tpic -> gridmodelsnow1 on the chunk (k_snowmodel) -> redistribution, hand-over
     -> applycpp3 min / max of totalSWE per step on the device, all-reduced over the ranks (R/internal.R:3592-3593)
@@ -53,8 +53,7 @@ def run_snow_config(args, world, rank, local_rank):
     from microclimf_amd import synthetic
     from microclimf_amd.api import Plan
     from microclimf_amd.distributed import allreduce_apply3, allreduce_max, allreduce_sum, allreduce_twi_mean, row_block
-    from microclimf_amd.snow import SnowPlan, snowdaysfun
-    from microclimf_amd.terrain import assemble_halo, exchange_halo
+    from microclimf_amd.snow import DeviceHalo, SnowPlan, snowdaysfun
 
     rows_total, cols, T = args.rows, args.cols, args.tsteps
     nblocks = max(world, args.share or 0)
@@ -67,23 +66,21 @@ def run_snow_config(args, world, rank, local_rank):
     dtm = np.where(np.isnan(sw["vegp"]["hgt"]), np.nan, dtm)
     from microclimf_amd.terrain import HALO
     halo_n = halo_s = None
-    hn_ = hs_ = 0
-    surf_buf = np.empty((rows, cols), order="F")
-    ext_buf = None
     if not exchange_ok:
         # a rank's share without its neighbours: the halo rows are the neighbouring blocks' snow-FREE surface (generated from
-        # the seeded DTM), not their snow surface — the exchange itself only runs when every block has its rank
+        # the seeded DTM, uploaded once), not their snow surface — the exchange itself only runs when every block has its rank
         hn_, hs_ = min(HALO, row0), min(HALO, rows_total - (row0 + rows))
-        if hn_:
-            halo_n = synthetic.rasters(hn_, cols, row0 - hn_, rows_total)[2]
+        dev = torch.device("cuda", local_rank)
+        if hn_:     # a piece is column-major [h, cols] = a contiguous [cols, h] tensor
+            halo_n = torch.from_numpy(np.ascontiguousarray(synthetic.rasters(hn_, cols, row0 - hn_, rows_total)[2].T)).to(dev)
         if hs_:
-            halo_s = synthetic.rasters(hs_, cols, row0 + rows, rows_total)[2]
-        ext_buf = np.empty((hn_ + rows + hs_, cols), order="F")
+            halo_s = torch.from_numpy(np.ascontiguousarray(synthetic.rasters(hs_, cols, row0 + rows, rows_total)[2].T)).to(dev)
     a = synthetic.workload(rows, cols, T, reqhgt=args.reqhgt, row0=row0, rows_total=rows_total, zref=3.5, hgt_range=(0.05, 3.0))
     setup_s = time.perf_counter() - t0
     sp = SnowPlan(sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"], sw["other"], sw["snowenv"], dtm, 1.0, 0.02,
                   row0=row0, rows_total=rows_total, device=local_rank, keep_results=False)
     plan = Plan(**a, ring_days=chunk_days, ring_slots=2, device=local_rank)
+    halo = DeviceHalo(sp, rank, world) if exchange_ok and world > 1 else None
     s, n = plan.twi_partial()
     plan.set_twi_mean(allreduce_twi_mean(s, float(n)))
     valid = plan.valid_cells
@@ -112,15 +109,12 @@ def run_snow_config(args, world, rank, local_rank):
         slot = 0
         for ch in range(sp.chunks):
             tl = time.perf_counter()
-            surf = sp.surface(out=surf_buf)
-            if exchange_ok:
-                ext, hn, hs = exchange_halo(surf, rank, world)
-            else:
-                ext, hn, hs = assemble_halo(surf, halo_n, halo_s, out=ext_buf), hn_, hs_
-            tl = lap("surface+halo", tl)
+            # the surface never leaves the device: its 128 boundary rows go point-to-point to the neighbouring ranks
+            pn, ps = halo.exchange() if halo is not None else (halo_n, halo_s)
+            tl = lap("halo", tl)
             ss, sn = sp.surface_partial()
             smean = allreduce_twi_mean(ss, sn)                      # (sum, count) -> mean over the whole raster
-            ts, tn = sp.prepare_chunk(ch, ext if (hn or hs) else None, hn, hs, smean)
+            ts, tn = sp.prepare_chunk_dev(ch, pn, ps, smean)
             tl = lap("terrain+tpic", tl)
             sp.run_chunk(ch, allreduce_twi_mean(ts, tn))
             tl = lap("snowmodel+redistribute", tl)
@@ -174,9 +168,9 @@ def run_snow_config(args, world, rank, local_rank):
                 "baseline_config": 4, "rows_per_gpu": rows, "cols": cols, "tsteps": T, "valid_cells": int(valid_all),
                 "solver_days_per_year": sd, "snow_days_per_year": stats["snow_days"] / max(args.steps, 1),
                 "halo": (("RCCL" if backend == "nccl" else backend + " (REHEARSAL: ranks share a GPU)")
-                         + " send/recv of 128 surface rows per neighbour and chunk") if exchange_ok and world > 1 else
-                        "generated, not exchanged: the neighbouring blocks' snow-free surface (a rank's share of the partition "
-                        "without its neighbours)" if not exchange_ok else "single block",
+                         + " send/recv of 128 surface rows per neighbour and chunk, packed and unpacked on the device") if exchange_ok and world > 1 else
+                        "generated, not exchanged: the neighbouring blocks' snow-free surface, resident on the device (a rank's share of "
+                        "the partition without its neighbours)" if not exchange_ok else "single block",
                 "collectives": "per chunk: 2 (sum, count) all-reduces + min / max all-reduce of [120] doubles; once: twi (sum, count)",
                 "not_timed": "gridmicrosnow1 (host-pointer ABI only)",
                 "sink": "solver: HBM ring (2 slots x 5 days); snow series: chunk buffers on the device, no D2H",
