@@ -22,8 +22,9 @@ def main():
     ap.add_argument("--top", type=int, default=40)
     ap.add_argument("--bucket", type=int, default=1, help="group source lines into buckets of this many lines")
     ap.add_argument("-D", action="append", default=[])
+    ap.add_argument("--src", default=str(isa_mix.CSRC / "mcf_kernels.hip"))
     a = ap.parse_args()
-    src = isa_mix.CSRC / "mcf_kernels.hip"
+    src = Path(a.src)
     out = Path("/tmp/isa_lines.s")
     cmd = ["/opt/rocm/bin/hipcc", *isa_mix.hipflags(), *[f"-D{d}" for d in a.D], "-gline-tables-only", "-S", "--cuda-device-only",
            "-o", str(out), str(src)]
