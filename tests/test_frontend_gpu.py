@@ -235,22 +235,35 @@ def test_runmicro_big_writes_one_file_per_tile(oracle, tmp_path):
         f.close()
 
 
+def _map_matches(fig, k, raster, max_classes, allow_far=0):
+    """every cell of the model's raster against the cell the reference PUBLISHED there (tests/golden/vignette_points.json
+    `maps`, digitised by tools/digitize_vignette.py: a cell's value is known to the width of its legend colour class)"""
+    d = V.map_compare(V.map_panel(fig, k), raster)
+    assert d["na_equal"], (fig, k, "NA pattern")
+    assert d["cells"] == 2372
+    if allow_far:
+        assert d["p99"] < max_classes and d["within_3"] >= 1.0 - allow_far / d["cells"], (fig, k, d)
+    else:
+        assert d["max"] < max_classes, (fig, k, d)
+    return d
+
+
 def test_vignette_quick_start_maps_match_the_published_figure():
-    """vignettes/images/image1a.png of the reference: air temperature 5 cm above ground on the hottest hour (colour scale
-    about 26 .. 53 degC) and the mean of the monthly maximum and minimum days (about 10.2 .. 14.1 degC), with the no-data
-    block in the south-west corner — the quick start of vignettes/running-microclimf.Rmd:113-126 run through the front end"""
+    """vignettes/images/image1a.png of the reference: air temperature 5 cm above ground on the hottest hour and the mean of
+    the monthly maximum and minimum days, with the no-data block in the south-west corner — the quick start of
+    vignettes/running-microclimf.Rmd:113-126 run through the front end, CELL BY CELL against the published maps: every one
+    of the 2 372 cells within 2.5 colour classes (0.13 degC / 0.018 degC wide; the figure's cells are 4 px and its legend
+    skips every seventh palette colour; observed: max 1.7 / 1.6, 98 % inside their class or the next)"""
     weather, vegp, soilc, dtm = load()
     mp = F.runpointmodel(weather, 0.05, dtm, vegp, soilc)
     mx, mn = F.subsetpointmodel(mp, what="tmax"), F.subsetpointmodel(mp, what="tmin")
     tmx, tmn = F.runmicro(mx, 0.05, vegp, soilc, dtm)["Tz"], F.runmicro(mn, 0.05, vegp, soilc, dtm)["Tz"]
     hot = tmx[:, :, 133]
     mairt = ((tmn + tmx) / 2).mean(axis=2)
-    assert 24.0 < np.nanmin(hot) < 28.0 and 51.0 < np.nanmax(hot) < 55.0
-    assert 9.8 < np.nanmin(mairt) < 10.6 and 13.8 < np.nanmax(mairt) < 14.3
+    _map_matches("image1a", 0, hot, 2.5)
+    _map_matches("image1a", 1, mairt, 2.5)
     na = np.isnan(hot)
     assert na.sum() == 128 and na[38:, :12].mean() > 0.8                  # the white block of the figure
-    # the shaded gully of the figure (x about 18..22, y about 3..17) is the coolest part of the hot map
-    assert np.nanmean(hot[33:47, 18:22]) < np.nanmean(hot) - 4.0
 
 
 def test_vignette_bioclim_map_matches_the_published_figure():
@@ -259,13 +272,9 @@ def test_vignette_bioclim_map_matches_the_published_figure():
     `.topidx` replaces the undefined edge slopes by their median"""
     weather, vegp, soilc, dtm = load()
     b12 = F.runbioclim(weather, 0.05, vegp, soilc, dtm, temp="air")["bio12"]
-    assert 0.386 < np.nanmin(b12) < 0.392 and 0.4180 < np.nanmax(b12) <= 0.4190
+    # cell by cell against the published map: colour classes of 0.00011 (observed: every cell within 0.7 of a class)
+    _map_matches("image11", 0, b12, 1.5)
     assert np.isnan(b12).sum() == 128
-    # the driest spots of the figure are three hill tops: near (x, y) = (169507, 12522), (169496, 12489), (169494, 12479)
-    r, c = np.unravel_index(np.nanargmin(np.where(np.isnan(b12), 9, b12)), b12.shape)
-    assert any(abs(r - rr) <= 4 and abs(c - cc) <= 4 for rr, cc in ((2, 32), (35, 21), (45, 19))), (r, c)
-    for rr, cc in ((2, 32), (35, 21), (45, 19)):
-        assert np.nanmin(b12[max(rr - 3, 0):rr + 4, cc - 3:cc + 4]) < 0.398                 # each of them is dry
     edge = np.concatenate([b12[0, 15:], b12[15:38, -1]])
     assert np.nanstd(edge) < 0.004 and abs(np.nanmean(edge) - 0.4065) < 0.004     # the green band
 
@@ -291,32 +300,23 @@ def test_vignette_snow_curves_match_the_published_figure():
 
 
 def test_vignette_component_maps_match_the_published_colour_scales():
-    """vignettes/images/image2, 3b, 4, 5 (running-microclimf.Rmd:322-395; drawn there with the R-language model path on
-    the monthly-maximum subset): soil moisture 0.13 .. 0.41 on the hottest hour, downward short wave ~50 .. 950 and upward
-    ~10 .. 285 W/m2 at 10:00 on 20 June, wind speed ~0.15 .. 3.15 m/s at step 100, soil surface temperature ~25 .. 59 degC"""
+    """vignettes/images/image2, 3b, 4, 5 (running-microclimf.Rmd:322-395, the monthly-maximum subset): soil moisture on the
+    hottest hour, downward and upward short wave at 10:00 on 20 June, wind speed at step 100, soil surface temperature —
+    each of the five published maps cell by cell"""
     weather, vegp, soilc, dtm = load()
     mx = F.subsetpointmodel(F.runpointmodel(weather, 0.05, dtm, vegp, soilc), what="tmax")
     m = F.runmicro(mx, 0.05, vegp, soilc, dtm)
     tg = F.runmicro(mx, 0.0, vegp, soilc, dtm)["Tz"][:, :, 133]
     with np.errstate(invalid="ignore"):
         down = (m["Rdirdown"] + m["Rdifdown"])[:, :, 130]
-    rng = lambda a: (float(np.nanmin(a)), float(np.nanmax(a)))          # noqa: E731
-    lo, hi = rng(m["soilm"][:, :, 133])
-    assert 0.125 < lo < 0.145 and 0.40 < hi < 0.42
-    lo, hi = rng(down)
-    assert 30 < lo < 70 and 940 < hi < 955
-    lo, hi = rng(m["Rswup"][:, :, 130])
-    assert 5 < lo < 20 and 278 < hi < 292
-    lo, hi = rng(m["windspeed"][:, :, 99])
-    assert 0.12 < lo < 0.20 and 3.10 < hi < 3.20
-    lo, hi = rng(tg)
-    assert 24.0 < lo < 26.5 and 58.0 < hi < 60.5
-    # the sheltered valley of image4 runs from the lower left to the upper right; the north-west and south-east corners are exposed
-    ws = m["windspeed"][:, :, 99]
-    assert np.nanmean(ws[:8, :15]) > 2.5 and np.nanmean(ws[40:, 35:]) > 2.5 and np.nanmean(ws[22:30, 18:28]) < 0.8
-    # the drainage lines of image2 are the wettest cells: far above the median soil moisture
-    sm = m["soilm"][:, :, 133]
-    assert np.nanpercentile(sm, 97) > 0.35 > np.nanmedian(sm) + 0.1
+    # cell by cell against the published maps (colour classes: 0.00094 of soil moisture, 4.1 / 1.2 W/m2, 0.01 m/s, 0.12 degC;
+    # observed: every cell within 1.4 classes — except nine cells of image2 on the rim of the no-data block, where the
+    # figure's older model run distributed soil water differently; image11, drawn from today's code, matches there too)
+    _map_matches("image2", 0, m["soilm"][:, :, 133], 1.0, allow_far=12)
+    _map_matches("image3b", 0, down, 2.0)
+    _map_matches("image3b", 1, m["Rswup"][:, :, 130], 2.0)
+    _map_matches("image4", 0, m["windspeed"][:, :, 99], 1.5)
+    _map_matches("image5", 0, tg, 1.5)
 
 
 def _flat_uniform_site(pai, hgt):
@@ -392,7 +392,7 @@ def test_vignette_air_temperature_map_and_its_netcdf_copy_match_the_published_fi
     mp = F.subsetpointmodel(F.runpointmodel(weather, 0.05, dtm, vegp, soilc), tstep="month", what="tmax")
     mout = dict(F.runmicro(mp, 0.05, vegp, soilc, dtm))
     t6 = mout["Tz"][:, :, 133]
-    assert 24.5 < np.nanmin(t6) < 26.0 and 53.0 < np.nanmax(t6) < 54.5
+    _map_matches("image6", 0, t6, 1.5)          # 0.097 degC classes; observed: every cell within 0.6 of a class
     mout["tme"] = mp["obstime"]
     xmin, xmax, ymin, ymax = dtm["extent"]
     f = str(tmp_path / "modelout.nc")
@@ -403,8 +403,7 @@ def test_vignette_air_temperature_map_and_its_netcdf_copy_match_the_published_fi
         lay[lay == v._FillValue] = np.nan
     lay /= 100
     assert np.isnan(lay).sum() == np.isnan(dtm["z"]).sum() > 0
-    assert 7.0 < np.nanmin(lay) < 7.6 and 19.2 < np.nanmax(lay) < 19.6
-    assert np.nanmean(lay[10:25, 0:20]) > 13.0 and np.nanmean(lay[20:45, 20:30]) < 10.0
+    _map_matches("image10", 0, lay, 1.5)        # the file's layer against the published read-back: 0.045 degC classes
 
 
 def test_vignette_subset_snow_depth_steps_match_the_published_figure():

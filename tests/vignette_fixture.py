@@ -68,3 +68,28 @@ def envelope_columns(p: dict, curve: str):
     for x, flat in p["curves"][curve]["columns"]:
         out.append((x, ay * max(flat) + by, ay * min(flat) + by))
     return np.array(out)
+
+
+# ---- raster maps -----------------------------------------------------------------------------------------------------------
+def map_panel(fig: str, k: int = 0) -> dict:
+    """A digitised map: `lo` / `hi` [rows, cols] = the value range of the colour class each cell was drawn in (NaN = NA)."""
+    p = json.loads(FIXTURE.read_text())["maps"][fig]["panels"][k]
+    cls = np.array(p["classes"], dtype=np.float64)
+    idx = np.array(p["cells"], dtype=np.int64)
+    lo = np.where(idx >= 0, cls[np.maximum(idx, 0), 0], np.nan)
+    hi = np.where(idx >= 0, cls[np.maximum(idx, 0), 1], np.nan)
+    return {"lo": lo, "hi": hi, "class_width": float(np.median(cls[:, 1] - cls[:, 0])), "legend": p["legend"], "what": p["what"]}
+
+
+def map_compare(m: dict, raster) -> dict:
+    """How far the model's raster lies outside the published cells' colour classes, in class widths: 0 inside the class."""
+    r = np.asarray(raster, dtype=np.float64)
+    na_equal = bool(np.array_equal(np.isnan(r), np.isnan(m["lo"])))
+    with np.errstate(invalid="ignore"):
+        d = np.maximum(np.maximum(m["lo"] - r, r - m["hi"]), 0.0) / m["class_width"]
+    ok = np.isfinite(d)
+    d = d[ok]
+    return {"na_equal": na_equal, "cells": int(ok.sum()), "max": float(d.max()), "p99": float(np.percentile(d, 99)), "p90": float(np.percentile(d, 90)),
+            "median": float(np.median(d)), "within_1": float((d <= 1.0).mean()), "within_3": float((d <= 3.0).mean()),
+            "class_width": m["class_width"], "legend_min": m["legend"]["min"], "legend_max": m["legend"]["max"],
+            "model_min": float(np.nanmin(r)), "model_max": float(np.nanmax(r))}

@@ -16,6 +16,9 @@ screen:
     converted to data units.  One pixel is the digitisation error (`px` per axis in the fixture), e.g. 0.046 degC in
     image9, 0.39 mm of snow water equivalent in image14a.
 
+Raster maps (terra::plot with a colour legend) are digitised too, cell by cell: the legend's ramp gives colour -> value, every
+raster cell's colour then gives its value to the width of one colour class (~0.1 degC on the temperature maps) — see MAPS.
+
 The fixture carries the calibration, the per-column envelopes of every curve and where they were taken from;
 tests/test_frontend_gpu.py::test_vignette_* draw the model's own series into the same pixel columns and compare
 envelopes.  The PNGs themselves are not copied (they stay under /root/reference); the fixture is data derived from them.
@@ -118,16 +121,18 @@ def find_boxes(img):
     return boxes
 
 
-def tick_pixels(img, box, side):
-    """Centres of the tick strokes outside the frame: side 'left' -> rows, 'bottom' -> columns."""
+def tick_pixels(img, box, side, depth=(3, 6)):
+    """Centres of the tick strokes outside the frame: side 'left' -> rows, 'bottom' -> columns.  `depth`: the pixels beyond
+    the frame line that a stroke must cover in full (base R's strokes are 7 px long, terra's 4)."""
     dk = colour_mask(img, "black")
     top, bot, left, right = box
+    d0, d1 = depth
     if side == "left":
-        strip = dk[:, left - 5:left - 2].all(axis=1)        # a tick covers these columns in full; label glyphs are further out
+        strip = dk[:, left - d1 + 1:left - d0 + 1].all(axis=1)        # a tick covers these columns in full; label glyphs are further out
         strip[:max(top - 2, 0)] = False
         strip[bot + 3:] = False
     else:
-        strip = dk[bot + 3:bot + 6, :].all(axis=0)
+        strip = dk[bot + d0:bot + d1, :].all(axis=0)
         strip[:max(left - 2, 0)] = False
         strip[right + 3:] = False
     return [0.5 * (a + b - 1) for a, b in runs(strip, 1)]
@@ -179,6 +184,145 @@ def digitize(name, spec):
     return {"source": f"vignettes/images/{name}.png", "rmd_lines": spec["rmd"], "what": spec["what"], "panels": panels}
 
 
+# ---- raster maps (terra::plot of a 50 x 50 SpatRaster with a continuous colour legend) ---------------------------------------
+# Per panel: the printed tick labels of the two axes and of the legend, top to bottom / left to right as for the line plots.
+# Everything else is detected: the frames (black rectangles: wide = map, narrow = legend), the tick strokes, the legend's
+# colour ramp (one colour per pixel row -> value by the legend's calibration) and the colour of every raster cell.  A cell's
+# value is then known to the width of its colour class (terra cuts the data range into equal classes): the fixture stores
+# the classes ([lo, hi] in data units) and the class index of each cell, -1 = NA (white).
+XT50 = [0, 10, 20, 30, 40, 50]
+MAPS = {
+    "image1a": dict(rmd="113-126", nrow=50, ncol=50, panels=[
+        dict(what="Tz at 5 cm on the hottest hour of the monthly-tmax subset", xticks=XT50, yticks=[0, 20, 40], legend=[30, 35, 40, 45, 50]),
+        dict(what="mean of the monthly tmax / tmin subsets' Tz", xticks=XT50, yticks=[0, 20, 40],
+             legend=[10.5, 11.0, 11.5, 12.0, 12.5, 13.0, 13.5, 14.0])]),
+    "image2": dict(rmd="322-330", nrow=50, ncol=50, panels=[
+        dict(what="soil moisture on the hottest hour", xticks=XT50, yticks=XT50, legend=[0.15, 0.20, 0.25, 0.30, 0.35, 0.40])]),
+    "image4": dict(rmd="370-378", nrow=50, ncol=50, panels=[
+        dict(what="wind speed at step 100 of the monthly-tmax subset", xticks=XT50, yticks=XT50, legend=[0.5, 1.0, 1.5, 2.0, 2.5, 3.0])]),
+    "image3b": dict(rmd="340-360", nrow=50, ncol=50, panels=[
+        dict(what="downward short wave at 10:00 on 20 June", xticks=XT50, yticks=[0, 20, 40], legend=[200, 400, 600, 800]),
+        dict(what="upward short wave at 10:00 on 20 June", xticks=XT50, yticks=[0, 20, 40], legend=[50, 100, 150, 200, 250])]),
+    "image5": dict(rmd="380-390", nrow=50, ncol=50, panels=[
+        dict(what="soil surface temperature on the hottest hour", xticks=XT50, yticks=XT50, legend=[25, 30, 35, 40, 45, 50, 55])]),
+    "image6": dict(rmd="392-397", nrow=50, ncol=50, panels=[
+        dict(what="Tz[,,134] of the monthly-tmax subset", xticks=XT50, yticks=XT50, legend=[30, 35, 40, 45, 50])]),
+    "image10": dict(rmd="540-549", nrow=50, ncol=50, panels=[
+        dict(what="layer 12 of Tz read back from the writetonc file, / 100", xticks=[169480, 169490, 169500, 169510, 169520],
+             yticks=[12480, 12490, 12500, 12510, 12520], legend=[8, 10, 12, 14, 16, 18])]),
+    "image11": dict(rmd="590-600", nrow=50, ncol=50, panels=[
+        dict(what="runbioclim(..., temp = 'air')[[12]]", xticks=[169480, 169490, 169500, 169510, 169520],
+             yticks=[12480, 12490, 12500, 12510, 12520], legend=[0.390, 0.395, 0.400, 0.405, 0.410, 0.415])]),
+}
+
+
+def _runs2d(mask, axis, min_len):
+    """black strokes: [(fixed index, start, stop)] of runs of at least min_len along `axis`"""
+    out = []
+    m = mask if axis == 1 else mask.T
+    for i in range(m.shape[0]):
+        for a, b in runs(m[i], min_len):
+            out.append((i, a, b - 1))
+    return out
+
+
+def find_rectangles(img, min_side=60):
+    """Black axis-aligned frames as (top, bottom, left, right): pairs of vertical strokes joined by horizontal ones."""
+    dk = colour_mask(img, "black")
+    vert = _runs2d(dk, 0, min_side)           # (column, row0, row1)
+    # merge neighbouring columns of one stroke
+    vert.sort()
+    strokes = []
+    for c, a, b in vert:
+        if strokes and c - strokes[-1][0] <= 1 and abs(a - strokes[-1][1]) <= 2 and abs(b - strokes[-1][2]) <= 2:
+            continue
+        strokes.append((c, a, b))
+    rects = []
+    for i, (c0, a0, b0) in enumerate(strokes):
+        for c1, a1, b1 in strokes[i + 1:]:
+            if abs(a0 - a1) <= 2 and abs(b0 - b1) <= 2 and c1 - c0 >= 6:
+                # the horizontal strokes that close the frame (corner ticks may carry the vertical strokes past them)
+                full = [y for y in range(min(a0, a1), max(b0, b1) + 1) if dk[y, c0:c1 + 1].mean() > 0.97]
+                if len(full) >= 2 and full[-1] - full[0] >= min_side:
+                    rects.append((full[0], full[-1], c0, c1))
+                    break
+    return rects
+
+
+def digitize_map(name, spec):
+    img = np.array(Image.open(IMAGES / f"{name}.png").convert("RGB"))
+    rects = find_rectangles(img)
+    maps = sorted([r for r in rects if r[3] - r[2] > 100], key=lambda r: r[2])
+    bars = sorted([r for r in rects if r[3] - r[2] <= 40], key=lambda r: r[2])
+    assert len(maps) == len(bars) == len(spec["panels"]), f"{name}: {len(maps)} map frames, {len(bars)} legends, {len(spec['panels'])} expected"
+    nrow, ncol = spec["nrow"], spec["ncol"]
+    panels = []
+    for box, bar, ps in zip(maps, bars, spec["panels"]):
+        top, bot, left, right = box
+        ax, bx, rx = calibrate(tick_pixels(img, box, "bottom", (1, 4)), ps["xticks"], f"{name} x")
+        ay, by, ry = calibrate(tick_pixels(img, box, "left", (1, 4))[::-1], ps["yticks"], f"{name} y")
+        # legend: ticks to the right of the bar
+        bt, bb, bl, br = bar
+        dk = colour_mask(img, "black")
+        strip = dk[:, br + 2:br + 5].all(axis=1)
+        strip[:max(bt - 2, 0)] = False
+        strip[bb + 3:] = False
+        lpix = [0.5 * (a + b - 1) for a, b in runs(strip, 1)]
+        al, bl0, rl = calibrate(lpix[::-1], ps["legend"], f"{name} legend")
+        ramp = np.median(img[bt + 1:bb, bl + 2:br - 1].astype(np.int32), axis=1).astype(np.int32)      # one colour per pixel row
+        rows = np.arange(bt + 1, bb)
+        # colour classes: maximal runs of rows with one colour
+        classes, start = [], 0
+        for i in range(1, len(ramp) + 1):
+            if i == len(ramp) or (ramp[i] != ramp[start]).any():
+                # a class spans pixel rows [start, i): its values run from the lower edge of the last row to the upper edge of the first
+                v_hi = al * (rows[start] - 0.5) + bl0
+                v_lo = al * (rows[i - 1] + 0.5) + bl0
+                classes.append({"rgb": [int(v) for v in ramp[start]], "lo": float(min(v_lo, v_hi)), "hi": float(max(v_lo, v_hi))})
+                start = i
+        cols_rgb = np.array([c["rgb"] for c in classes], dtype=np.int32)
+        # raster cells: the commonest colour of the cell's inner pixels
+        cw, ch = (right - left) / ncol, (bot - top) / nrow
+        extent = [ax * left + bx, ax * right + bx, ay * bot + by, ay * top + by]          # xmin, xmax, ymin, ymax by the axes
+        assert abs((extent[1] - extent[0]) - ncol * round((extent[1] - extent[0]) / ncol)) < 0.25 and \
+            abs((extent[3] - extent[2]) - nrow * round((extent[3] - extent[2]) / nrow)) < 0.25, f"{name}: frame is not the raster's extent {extent}"
+        idx = np.full((nrow, ncol), -1, dtype=np.int32)
+        worst = 0
+        for r in range(nrow):
+            for c in range(ncol):
+                # the frame lines are the raster's edges (checked against the axis calibration below): row 0 is the top row
+                x0, x1 = left + (c + 0.25) * cw, left + (c + 0.75) * cw
+                y0, y1 = top + (r + 0.25) * ch, top + (r + 0.75) * ch
+                xa, xb = int(np.ceil(x0)), int(np.floor(x1))
+                ya, yb = int(np.ceil(y0)), int(np.floor(y1))
+                if xb < xa or yb < ya:                                  # cells of a few pixels: the centre pixel
+                    xa = xb = int(round(left + (c + 0.5) * cw))
+                    ya = yb = int(round(top + (r + 0.5) * ch))
+                px = img[ya:yb + 1, xa:xb + 1].reshape(-1, 3).astype(np.int32)
+                vals, counts = np.unique(px, axis=0, return_counts=True)
+                col = vals[counts.argmax()]                             # cells are flat-coloured: the commonest colour
+                if (col > 245).all():
+                    continue                                           # white: NA
+                d = np.abs(cols_rgb - col).sum(axis=1)
+                k = int(d.argmin())
+                worst = max(worst, int(d[k]))
+                idx[r, c] = k
+        # (a legend shorter than the palette skips colours: a cell may then sit one palette step from the nearest legend row)
+        assert worst <= (6 if len(ramp) >= 300 else 16), f"{name}: a cell colour is {worst} away from every legend colour"
+        panels.append({
+            "what": ps["what"], "frame_px": {"top": top, "bottom": bot, "left": left, "right": right},
+            "legend_px": {"top": bt, "bottom": bb, "left": bl, "right": br}, "extent_by_axes": [round(v, 3) for v in extent],
+            "x": {"tick_labels": ps["xticks"], "per_px": ax, "at_px0": bx, "fit_resid_px": rx},
+            "y": {"tick_labels": ps["yticks"], "per_px": ay, "at_px0": by, "fit_resid_px": ry},
+            "legend": {"tick_px": lpix[::-1], "tick_labels": ps["legend"], "per_px": al, "at_px0": bl0, "fit_resid_px": rl,
+                       "min": float(al * (bb - 0.5) + bl0) if al < 0 else float(al * (bt + 0.5) + bl0),
+                       "max": float(al * (bt + 0.5) + bl0) if al < 0 else float(al * (bb - 0.5) + bl0)},
+            "classes": [[round(c["lo"], 6), round(c["hi"], 6)] for c in classes],
+            "cells": idx.tolist(), "worst_colour_distance": worst,
+        })
+    return {"source": f"vignettes/images/{name}.png", "rmd_lines": spec["rmd"], "panels": panels}
+
+
 def main():
     if not IMAGES.exists():
         raise SystemExit("the reference's vignette images are not here: this script runs in the build container only")
@@ -196,6 +340,18 @@ def main():
             print(f"{name} panel {k}: frame {p['frame_px']}, 1 px = {p['px']['x']:.4g} ({p['x']['is']}) x {p['px']['y']:.4g} "
                   f"({p['y']['is']}); fit residual {p['x']['fit_resid_px']:.2f} / {p['y']['fit_resid_px']:.2f} px; "
                   + ", ".join(f"{c}: {len(v['columns'])} columns" for c, v in p["curves"].items()))
+    out["_about_maps"] = ("maps: terra::plot rasters; `classes` = [lo, hi] of every legend colour in data units (value = per_px * "
+                          "pixel row + at_px0 on the legend), `cells` = [row][col] class index of the raster cell drawn there (row 0 "
+                          "= northernmost), -1 = NA; a cell's value is known to the width of its class")
+    out["maps"] = {}
+    for name, spec in MAPS.items():
+        if only and name not in only:
+            continue
+        out["maps"][name] = digitize_map(name, spec)
+        for k, p in enumerate(out["maps"][name]["panels"]):
+            w = np.median([b - a for a, b in p["classes"]])
+            print(f"{name} map {k}: legend {p['legend']['min']:.5g} .. {p['legend']['max']:.5g}, {len(p['classes'])} colour classes of "
+                  f"{w:.3g}, fit residual {p['legend']['fit_resid_px']:.2f} px, {sum(v < 0 for r in p['cells'] for v in r)} NA cells")
     if not only:
         OUT.write_text(json.dumps(out, separators=(",", ":")))
         print("wrote", OUT, OUT.stat().st_size, "bytes")
