@@ -196,6 +196,9 @@ __device__ __forceinline__ double fsqrt(double x) {           // sqrt(x), x fini
                            // p = r*c11 + c10 reads TWO constants and a VOP3 can take only one from the scalar file, so the
                            // other was re-created by two v_mov_b32 in front of (nearly) every evaluation
 #endif
+#ifndef MCF_LOG_TABLE
+#define MCF_LOG_TABLE 1   // k_solve: log through a 256-entry table of (reciprocal, -log reciprocal) in LDS: no division
+#endif
 #ifndef MCF_EXP_TABLE
 #define MCF_EXP_TABLE 1   // k_solve: exp through a 64-entry table of 2^(j/64) in LDS + a degree-5 polynomial (12 fp64
                           // instructions + 3 integer ones instead of 17 fp64); kernels that do not set MathK::tab keep the
@@ -267,19 +270,157 @@ __device__ const double kExp2Tab[256] = {
     0x1.efa1bee615a27p+0, 0x1.f0f9c1cb6412ap+0, 0x1.f252b376bba97p+0, 0x1.f3ac948dd7274p+0,
     0x1.f50765b6e4540p+0, 0x1.f6632798844f8p+0, 0x1.f7bfdad9cbe14p+0, 0x1.f91d802243c89p+0,
     0x1.fa7c1819e90d8p+0, 0x1.fbdba3692d514p+0, 0x1.fd3c22b8f71f1p+0, 0x1.fe9d96b2a23d9p+0};
+// log table (tools/gen_math_tables.py log): interval j of the mantissa m in [0.5, 1) is [0.5 + j/512, 0.5 + (j+1)/512); pairs
+// (c_j, l_j) with m c_j - 1 = r, |r| <= 2^-8 and l_j = -log of the reciprocal used — see flog_tab.
+constexpr int kLogSplit = 106;     // intervals below reduce 2m towards 1 (exponent - 1), the others m towards 1
+__device__ const double kLogTab[512] = {
+    0x1.0000000000000p+1, 0x0.0p+0, 0x1.fd04794a10e6ap+0, 0x1.7ee11ebd82ec4p-8,
+    0x1.fb0c610d5e939p+0, 0x1.3e7295d25a7d5p-7, 0x1.f9182b6813bafp+0, 0x1.bcf712c743853p-7,
+    0x1.f727cce5f530ap+0, 0x1.1d7f7eb9eebf1p-6, 0x1.f53b3a3fa204ep+0, 0x1.5c45a51b8d393p-6,
+    0x1.f3526859b8cecp+0, 0x1.9ace7551cc515p-6, 0x1.f16d4c4401f17p+0, 0x1.d91a66c543cbep-6,
+    0x1.ef8bdb389ebadp+0, 0x1.0b94f7c196173p-5, 0x1.edae0a9b3d3a5p+0, 0x1.2a7ec2214e879p-5,
+    0x1.ebd3cff850b0cp+0, 0x1.494acc34d911dp-5, 0x1.e9fd21044e799p+0, 0x1.67f94f094bd92p-5,
+    0x1.e829f39aef509p+0, 0x1.868a83083f6d0p-5, 0x1.e65a3dbe74d6bp+0, 0x1.a4fe9ffa3d233p-5,
+    0x1.e48df596f3394p+0, 0x1.c355dd0921f2fp-5, 0x1.e2c511719ee16p+0, 0x1.e19070c276010p-5,
+    0x1.e0ff87c01e100p+0, 0x1.ffae9119b92fbp-5, 0x1.df3d4f17de4dbp+0, 0x1.0ed839b5526fep-4,
+    0x1.dd7e5e316d94cp+0, 0x1.1dcb263db1944p-4, 0x1.dbc2abe7d71d4p+0, 0x1.2cb0283f5de22p-4,
+    0x1.da0a2f3803b41p+0, 0x1.3b87598b1b6f0p-4, 0x1.d854df401d855p+0, 0x1.4a50d3aa1b03fp-4,
+    0x1.d6a2b33ef7448p+0, 0x1.590cafdf01c26p-4, 0x1.d4f3a293769cap+0, 0x1.67bb0726ec0fbp-4,
+    0x1.d347a4bc01d34p+0, 0x1.765bf23a6be17p-4, 0x1.d19eb155f08a4p+0, 0x1.84ef898e82828p-4,
+    0x1.cff8c01cff8c0p+0, 0x1.9375e55595edfp-4, 0x1.ce55c8eac7900p+0, 0x1.a1ef1d8061cd8p-4,
+    0x1.ccb5c3b636e3ap+0, 0x1.b05b49bee4403p-4, 0x1.cb18a8930de60p+0, 0x1.beba818146764p-4,
+    0x1.c97e6fb15e44dp+0, 0x1.cd0cdbf8c13e0p-4, 0x1.c7e7115d0ce95p+0, 0x1.db5270187d925p-4,
+    0x1.c65285fd56843p+0, 0x1.e98b54967146bp-4, 0x1.c4c0c61456a8ep+0, 0x1.f7b79fec37de2p-4,
+    0x1.c331ca3e91679p+0, 0x1.02ebb42bf3d4ap-3, 0x1.c1a58b327f576p+0, 0x1.09f561ee719c4p-3,
+    0x1.c01c01c01c01cp+0, 0x1.10f8e422539b1p-3, 0x1.be9526d0769fap+0, 0x1.17f6458fca611p-3,
+    0x1.bd10f365451b6p+0, 0x1.1eed90e2dc2c3p-3, 0x1.bb8f609879493p+0, 0x1.25ded0abc6ad3p-3,
+    0x1.ba10679bd8488p+0, 0x1.2cca0f5f5f252p-3, 0x1.b89401b89401cp+0, 0x1.33af575770e4dp-3,
+    0x1.b71a284ee6b34p+0, 0x1.3a8eb2d31a375p-3, 0x1.b5a2d4d5b081fp+0, 0x1.41682bf727bbfp-3,
+    0x1.b42e00da17007p+0, 0x1.483bccce6e3dcp-3, 0x1.b2bba5ff26a23p+0, 0x1.4f099f4a230b1p-3,
+    0x1.b14bbdfd760e6p+0, 0x1.55d1ad4232d70p-3, 0x1.afde42a2cb482p+0, 0x1.5c940075972b9p-3,
+    0x1.ae732dd1c2a09p+0, 0x1.6350a28aaa759p-3, 0x1.ad0a798177693p+0, 0x1.6a079d0f7aad0p-3,
+    0x1.aba41fbd2e5b1p+0, 0x1.70b8f97a1aa74p-3, 0x1.aa401aa401aa4p+0, 0x1.7764c128f2127p-3,
+    0x1.a8de64688ebabp+0, 0x1.7e0afd630c276p-3, 0x1.a77ef750a56dap+0, 0x1.84abb75865137p-3,
+    0x1.a621cdb4f8fdfp+0, 0x1.8b46f8223625bp-3, 0x1.a4c6e200d2637p+0, 0x1.91dcc8c340bdfp-3,
+    0x1.a36e2eb1c432dp+0, 0x1.986d3228180c8p-3, 0x1.a217ae575ff2fp+0, 0x1.9ef83d2769a34p-3,
+    0x1.a0c35b92ecdf1p+0, 0x1.a57df28244dcbp-3, 0x1.9f713117200d0p+0, 0x1.abfe5ae46124ap-3,
+    0x1.9e2129a7d5f0ap+0, 0x1.b2797ee46320cp-3, 0x1.9cd34019cd340p+0, 0x1.b8ef670420c3bp-3,
+    0x1.9b876f5262dd1p+0, 0x1.bf601bb0e44e0p-3, 0x1.9a3db2474fb98p+0, 0x1.c5cba543ae424p-3,
+    0x1.98f603fe670a0p+0, 0x1.cc320c0176501p-3, 0x1.97b05f8d56652p+0, 0x1.d293581b6b3e7p-3,
+    0x1.966cc01966cc0p+0, 0x1.d8ef91af31d5ep-3, 0x1.952b20d73ee97p+0, 0x1.df46c0c722d30p-3,
+    0x1.93eb7d0aa6759p+0, 0x1.e598ed5a87e2ep-3, 0x1.92add0064ab74p+0, 0x1.ebe61f4dd7b0bp-3,
+    0x1.9172152b841ddp+0, 0x1.f22e5e72f105cp-3, 0x1.903847ea1cec1p+0, 0x1.f871b28955045p-3,
+    0x1.8f0063c018f00p+0, 0x1.feb0233e607cep-3, 0x1.8dca64397e408p+0, 0x1.0274dc16c232fp-2,
+    0x1.8c9644f01efbcp+0, 0x1.058f3c703ebc5p-2, 0x1.8b64018b64019p+0, 0x1.08a73667c57aep-2,
+    0x1.8a3395c018a34p+0, 0x1.0bbccdb0d24bcp-2, 0x1.8904fd503744bp+0, 0x1.0ed005f657da5p-2,
+    0x1.87d8340ab6e97p+0, 0x1.11e0e2dad9cb6p-2, 0x1.86ad35cb59a84p+0, 0x1.14ef67f88685ap-2,
+    0x1.8583fe7a7c018p+0, 0x1.17fb98e15095ep-2, 0x1.845c8a0ce5129p+0, 0x1.1b05791f07b4ap-2,
+    0x1.8336d48397a24p+0, 0x1.1e0d0c33716bdp-2, 0x1.8212d9eba4018p+0, 0x1.211255986160cp-2,
+    0x1.80f0965dfabcbp+0, 0x1.241558bfd1405p-2, 0x1.7fd005ff40180p+0, 0x1.27161913f853dp-2,
+    0x1.7eb124ffa053bp+0, 0x1.2a1499f762bcap-2, 0x1.7d93ef9aa4b46p+0, 0x1.2d10dec508582p-2,
+    0x1.7c7862170949fp+0, 0x1.300aead06350cp-2, 0x1.7b5e78c693733p+0, 0x1.3302c1658658ap-2,
+    0x1.7a463005e918cp+0, 0x1.35f865c93293ep-2, 0x1.792f843c689c3p+0, 0x1.38ebdb38ed320p-2,
+    0x1.781a71dc01782p+0, 0x1.3bdd24eb14b69p-2, 0x1.7706f5610d8d0p+0, 0x1.3ecc460ef5f50p-2,
+    0x1.75f50b522b17cp+0, 0x1.41b941cce0beep-2, 0x1.74e4b040174e5p+0, 0x1.44a41b463c47bp-2,
+    0x1.73d5e0c5899f7p+0, 0x1.478cd5959b3d8p-2, 0x1.72c899870f91fp+0, 0x1.4a7373cecf997p-2,
+    0x1.71bcd732e940ap+0, 0x1.4d57f8fefe27fp-2, 0x1.70b29680e66fap+0, 0x1.503a682cb1cb3p-2,
+    0x1.6fa9d43244380p+0, 0x1.531ac457ee77fp-2, 0x1.6ea28d118b474p+0, 0x1.55f9107a43ee2p-2,
+    0x1.6d9cbdf26eaefp+0, 0x1.58d54f86e02f3p-2, 0x1.6c9863b1ab429p+0, 0x1.5baf846aa1b1ap-2,
+    0x1.6b957b34e7803p+0, 0x1.5e87b20c2954ap-2, 0x1.6a94016a94017p+0, 0x1.615ddb4bec13cp-2,
+    0x1.6993f349cc726p+0, -0x1.61965cdb02c1ep-2, 0x1.68954dd2390bap+0, -0x1.5ec433d5c35aep-2,
+    0x1.67980e0bf08c7p+0, -0x1.5bf406b543db1p-2, 0x1.669c31075ab40p+0, -0x1.5925d2b112a59p-2,
+    0x1.65a1b3dd13357p+0, -0x1.565995069514cp-2, 0x1.64a893adcd25fp+0, -0x1.538f4af8f72fcp-2,
+    0x1.63b0cda236e1cp+0, -0x1.50c6f1d11b97bp-2, 0x1.62ba5eeade65ep+0, -0x1.4e0086dd8baccp-2,
+    0x1.61c544c0161c5p+0, -0x1.4b3c077267e9ap-2, 0x1.60d17c61da198p+0, -0x1.487970e958771p-2,
+    0x1.5fdf0317b5c6fp+0, -0x1.45b8c0a17df12p-2, 0x1.5eedd630a9fb3p+0, -0x1.42f9f3ff62641p-2,
+    0x1.5dfdf303137b6p+0, -0x1.403d086cea79bp-2, 0x1.5d0f56ec91e57p+0, -0x1.3d81fb5946dbcp-2,
+    0x1.5c21ff51ef005p+0, -0x1.3ac8ca38e5c5dp-2, 0x1.5b35e99f06714p+0, -0x1.3811728564cb2p-2,
+    0x1.5a4b1346add2bp+0, -0x1.355bf1bd82c8bp-2, 0x1.596179c29d2cep+0, -0x1.32a84565120a9p-2,
+    0x1.58791a9357ccep+0, -0x1.2ff66b04ea9d5p-2, 0x1.5791f34015792p+0, -0x1.2d46602adccefp-2,
+    0x1.56ac0156ac015p+0, -0x1.2a982269a3dbep-2, 0x1.55c7426b79286p+0, -0x1.27ebaf58d8c9cp-2,
+    0x1.54e3b4194ce66p+0, -0x1.25410494e56c8p-2, 0x1.5401540154015p+0, -0x1.22981fbef797ap-2,
+    0x1.53201fcb02fb1p+0, -0x1.1ff0fe7cf47a9p-2, 0x1.5240152401524p+0, -0x1.1d4b9e796c245p-2,
+    0x1.516131c015161p+0, -0x1.1aa7fd638d33ep-2, 0x1.508373590ec9cp+0, -0x1.180618ef18adep-2,
+    0x1.4fa6d7aeb597cp+0, -0x1.1565eed455fc2p-2, 0x1.4ecb5c86b3d24p+0, -0x1.12c77cd00713cp-2,
+    0x1.4df0ffac83c01p+0, -0x1.102ac0a35cc1bp-2, 0x1.4d17bef15cb4ep+0, -0x1.0d8fb813eb1efp-2,
+    0x1.4c3f982c20723p+0, -0x1.0af660eb9e278p-2, 0x1.4b68893948d1cp+0, -0x1.085eb8f8ae799p-2,
+    0x1.4a928ffad5b5cp+0, -0x1.05c8be0d9635ap-2, 0x1.49bdaa583b401p+0, -0x1.03346e0106062p-2,
+    0x1.48e9d63e504d1p+0, -0x1.00a1c6adda472p-2, 0x1.4817119f3d325p+0, -0x1.fc218be620a5fp-3,
+    0x1.47455a726abf2p+0, -0x1.f702d36777df0p-3, 0x1.4674aeb4717e9p+0, -0x1.f1e75fadf9bdep-3,
+    0x1.45a50c670938fp+0, -0x1.eccf2c8fe920bp-3, 0x1.44d67190f8b43p+0, -0x1.e7ba35eb77e2ap-3,
+    0x1.4408dc3e05b22p+0, -0x1.e2a877a6b2c0fp-3, 0x1.433c4a7ee52b4p+0, -0x1.dd99edaf6d7e9p-3,
+    0x1.4270ba692bc4dp+0, -0x1.d88e93fb2f451p-3, 0x1.41a62a173e821p+0, -0x1.d38666871f467p-3,
+    0x1.40dc97a843ae8p+0, -0x1.ce816157f1985p-3, 0x1.4014014014014p+0, -0x1.c97f8079d44ecp-3,
+    0x1.3f4c65072bf74p+0, -0x1.c480c0005cccfp-3, 0x1.3e85c12a9d651p+0, -0x1.bf851c067555cp-3,
+    0x1.3dc013dc013dcp+0, -0x1.ba8c90ae4ad19p-3, 0x1.3cfb5b51698ebp+0, -0x1.b5971a213acd9p-3,
+    0x1.3c3795c553afbp+0, -0x1.b0a4b48fc1b44p-3, 0x1.3b74c1769aa5cp+0, -0x1.abb55c31693aep-3,
+    0x1.3ab2dca869b81p+0, -0x1.a6c90d44b704cp-3, 0x1.39f1e5a22f36ep+0, -0x1.a1dfc40f1b7f1p-3,
+    0x1.3931daaf8f721p+0, -0x1.9cf97cdce0ec1p-3, 0x1.3872ba2057e04p+0, -0x1.981634011aa74p-3,
+    0x1.37b4824872744p+0, -0x1.9335e5d594985p-3, 0x1.36f7317fd9212p+0, -0x1.8e588ebac2dc1p-3,
+    0x1.363ac622898b1p+0, -0x1.897e2b17b19a6p-3, 0x1.357f3e9078e5bp+0, -0x1.84a6b759f512dp-3,
+    0x1.34c4992d87fd9p+0, -0x1.7fd22ff599d4cp-3, 0x1.340ad461776d3p+0, -0x1.7b0091651528bp-3,
+    0x1.3351ee97dbfc6p+0, -0x1.7631d82935a84p-3, 0x1.3299e6401329ap+0, -0x1.716600c914055p-3,
+    0x1.31e2b9cd37dc2p+0, -0x1.6c9d07d203fc4p-3, 0x1.312c67b6173eep+0, -0x1.67d6e9d785770p-3,
+    0x1.3076ee7525c2cp+0, -0x1.6313a37335d76p-3, 0x1.2fc24c8874486p+0, -0x1.5e533144c1718p-3,
+    0x1.2f0e8071a5703p+0, -0x1.59958ff1d52f4p-3, 0x1.2e5b88b5e3104p+0, -0x1.54dabc26105d3p-3,
+    0x1.2da963ddd3cfbp+0, -0x1.5022b292f6a45p-3, 0x1.2cf8107590e67p+0, -0x1.4b6d6fefe22a5p-3,
+    0x1.2c478d0c9c013p+0, -0x1.46baf0f9f5db8p-3, 0x1.2b97d835d548ep+0, -0x1.420b32740fdd6p-3,
+    0x1.2ae8f087718d0p+0, -0x1.3d5e3126bc281p-3, 0x1.2a3ad49af0907p+0, -0x1.38b3e9e027477p-3,
+    0x1.298d830d13780p+0, -0x1.340c59741142dp-3, 0x1.28e0fa7dd35a3p+0, -0x1.2f677cbbc0a98p-3,
+    0x1.2835399057efdp+0, -0x1.2ac55095f5c5bp-3, 0x1.278a3eeaee650p+0, -0x1.2625d1e6ddf55p-3,
+    0x1.26e009370049cp+0, -0x1.2188fd9807266p-3, 0x1.263697210aa18p+0, -0x1.1ceed09853755p-3,
+    0x1.258de75895121p+0, -0x1.185747dbecf34p-3, 0x1.24e5f89029305p+0, -0x1.13c2605c398bfp-3,
+    0x1.243ec97d49eaep+0, -0x1.0f301717cf0fbp-3, 0x1.239858d86b11fp+0, -0x1.0aa06912675d5p-3,
+    0x1.22f2a55ce8fc5p+0, -0x1.06135354d4b19p-3, 0x1.224dadc900489p+0, -0x1.0188d2ecf613ep-3,
+    0x1.21a970ddc5ba7p+0, -0x1.fa01c9db57ce7p-4, 0x1.2105ed5f1e336p+0, -0x1.f0f70cdd992e4p-4,
+    0x1.20632213b6c6dp+0, -0x1.e7f1691a32d3ap-4, 0x1.1fc10dc4fce8bp+0, -0x1.def0d8d466dbbp-4,
+    0x1.1f1faf3f16b64p+0, -0x1.d5f55659210e1p-4, 0x1.1e7f0550db594p+0, -0x1.ccfedbfee13a8p-4,
+    0x1.1ddf0ecbcb841p+0, -0x1.c40d6425a5cb4p-4, 0x1.1d3fca840a074p+0, -0x1.bb20e936d6976p-4,
+    0x1.1ca13750547fep+0, -0x1.b23965a52ff04p-4, 0x1.1c035409fc1dfp+0, -0x1.a956d3ecade60p-4,
+    0x1.1b661f8cde833p+0, -0x1.a0792e9277cadp-4, 0x1.1ac998b75eb90p+0, -0x1.97a07024cbe6ep-4,
+    0x1.1a2dbe6a5e3e4p+0, -0x1.8ecc933aeb6e2p-4, 0x1.19928f89362b7p+0, -0x1.85fd927506a46p-4,
+    0x1.18f80af9b06dcp+0, -0x1.7d33687c293c8p-4, 0x1.185e2fa401186p+0, -0x1.746e100226edbp-4,
+    0x1.17c4fc72bfcb9p+0, -0x1.6bad83c1883bap-4, 0x1.172c7052e1316p+0, -0x1.62f1be7d7774ap-4,
+    0x1.16948a33b08fap+0, -0x1.5a3abb01ade21p-4, 0x1.15fd4906c96f1p+0, -0x1.5188742261311p-4,
+    0x1.1566abc011567p+0, -0x1.48dae4bc3101dp-4, 0x1.14d0b155b19aep+0, -0x1.403207b414b79p-4,
+    0x1.143b58c01143bp+0, -0x1.378dd7f74970fp-4, 0x1.13a6a0f9cf01ep+0, -0x1.2eee507b402ffp-4,
+    0x1.131288ffbb3b6p+0, -0x1.26536c3d8c36cp-4, 0x1.127f0fd0d2295p+0, -0x1.1dbd2643d1913p-4,
+    0x1.11ec346e36092p+0, -0x1.152b799bb3cd0p-4, 0x1.1159f5db29606p+0, -0x1.0c9e615ac4e19p-4,
+    0x1.10c8531d0952ep+0, -0x1.0415d89e7444bp-4, 0x1.10374b3b480aap+0, -0x1.f723b517fc51fp-5,
+    0x1.0fa6dd3f67322p+0, -0x1.e624c4a0b5e15p-5, 0x1.0f170834f27fap+0, -0x1.d52ed6405d87ap-5,
+    0x1.0e87cb297a51ep+0, -0x1.c441e06f72a93p-5, 0x1.0df9252c8e5e6p+0, -0x1.b35dd9b58baa8p-5,
+    0x1.0d6b154fb86f9p+0, -0x1.a282b8a936174p-5, 0x1.0cdd9aa677344p+0, -0x1.91b073efd7314p-5,
+    0x1.0c50b446391f3p+0, -0x1.80e7023d8ccc8p-5, 0x1.0bc4614657569p+0, -0x1.70265a550e77bp-5,
+    0x1.0b38a0c010b39p+0, -0x1.5f6e73078efc3p-5, 0x1.0aad71ce84d16p+0, -0x1.4ebf43349e26ap-5,
+    0x1.0a22d38eaf2bfp+0, -0x1.3e18c1ca0ae99p-5, 0x1.0998c51f624d5p+0, -0x1.2d7ae5c3c5bb7p-5,
+    0x1.090f45a1430aap+0, -0x1.1ce5a62bc3540p-5, 0x1.08865436c3cf7p+0, -0x1.0c58fa19dfaabp-5,
+    0x1.07fdf0041ff7cp+0, -0x1.f7a9b16782855p-6, 0x1.0776182f57386p+0, -0x1.d6b272597981fp-6,
+    0x1.06eecbe029155p+0, -0x1.b5cc258b718e7p-6, 0x1.06680a4010668p+0, -0x1.94f6b99a24473p-6,
+    0x1.05e1d27a3ee9cp+0, -0x1.74321d3d006d2p-6, 0x1.055c23bb98e2ap+0, -0x1.537e3f45f354ep-6,
+    0x1.04d6fd32b0c7bp+0, -0x1.32db0ea132e10p-6, 0x1.04525e0fc2fcbp+0, -0x1.12487a5507f68p-6,
+    0x1.03ce4584b19a0p+0, -0x1.e38ce30333100p-7, 0x1.034ab2c50040dp+0, -0x1.a2a9c6c17044dp-7,
+    0x1.02c7a505cffbfp+0, -0x1.61e77e8b53f9fp-7, 0x1.02451b7ddb2d2p+0, -0x1.2145e939ef1bcp-7,
+    0x1.01c315657186bp+0, -0x1.c189cbb0e283fp-8, 0x1.014191f674111p+0, -0x1.40c8a7478788dp-8,
+    0x1.00c0906c513cfp+0, -0x1.809048289860ap-9, 0x1.0000000000000p+0, 0x0.0p+0};
 struct MathK {
     double e[12];   // exp: 1/ln2, -ln2_hi, -ln2_lo, c10 .. c2
     double l[7];    // log: Lg4, Lg5, Lg2, Lg3, Lg1, ln2_lo, ln2_hi
     double c11, lg6, lg7;   // VGPR residents (MCF_PIN_VCONST)
     double t[5];    // table exp: 256/ln2, -(ln2/256)_hi (30 bits: n * hi is exact), -(ln2/256)_lo, 1/24, 1/6
     double c5;      // 1/6 (VGPR resident: an instruction reads one scalar operand)
+    double g[7];    // table log: (unused), -1/6, 1/5, -1/4, 1/3, ln2_lo, ln2_hi
+    double g7v;     // 1/7 (VGPR resident: the first Horner step has two constants)
+    const double* ltab = nullptr;  // LDS copy of kLogTab
     const double* tab = nullptr;   // LDS copy of kExp2Tab
+    bool logtab = false;           // flog goes through ltab (set with use_log_table; same reason)
     bool table = false;            // fexp goes through it (a compile-time fact after inlining: LDS address 0 is valid, so
                                    // the pointer cannot say)
     __device__ __forceinline__ void set() {
         c11 = 0x1.ade156a5dcb37p-26; lg6 = 1.531383769920937332e-01; lg7 = 1.479819860511658591e-01;
         t[0] = 0x1.71547652b82fep+8; t[1] = -0x1.62e42fec00000p-9; t[2] = -0x1.d1cf79abc9e3bp-40;
         t[3] = 1.0 / 24.0; t[4] = 0.0; c5 = 1.0 / 6.0;
+        g[0] = 0.0; g7v = 1.0 / 7.0; g[1] = -1.0 / 6.0; g[2] = 1.0 / 5.0; g[3] = -0.25; g[4] = 1.0 / 3.0;
+        g[5] = 1.90821492927058770002e-10; g[6] = 6.93147180369123816490e-01;
         e[0] = 0x1.71547652b82fep+0; e[1] = -0x1.62e42fefa39efp-1; e[2] = -0x1.abc9e3b39803fp-56;
         e[3] = 0x1.28af3fca7ab0cp-22; e[4] = 0x1.71dee623fde64p-19; e[5] = 0x1.a01997c89e6b0p-16;
         e[6] = 0x1.a01a014761f6ep-13; e[7] = 0x1.6c16c1852b7b0p-10; e[8] = 0x1.1111111122322p-7;
@@ -295,6 +436,12 @@ struct MathK {
         tab = lds;
         table = true;
     }
+    // `lds`: 512 doubles for kLogTab; switches flog to the table route (with use_table)
+    __device__ __forceinline__ void use_log_table(double* lds, int tid, int nthreads) {
+        for (int i = tid; i < 512; i += nthreads) lds[i] = kLogTab[i];
+        ltab = lds;
+        logtab = true;
+    }
     // vconst: c5 / c11, lg6, lg7 held in VGPRs as well (an instruction reads one scalar operand, so a second constant costs
     // two moves wherever it is used) — not in the array-forcing kernels, which have no register to spare
     __device__ __forceinline__ void pin(bool with_log, bool vconst = true) {
@@ -308,13 +455,16 @@ struct MathK {
         }
         if (with_log) {
 #pragma unroll
-            for (int i = 0; i < 7; ++i) asm volatile("" : "+s"(l[i]));
+            for (int i = 0; i < 7; ++i)
+                if (!logtab) asm volatile("" : "+s"(l[i]));
+                else if (i > 0) asm volatile("" : "+s"(g[i]));
+            if (logtab && vconst) asm volatile("" : "+v"(g7v));
         }
 #if MCF_PIN_VCONST
         if (!vconst) return;
         if (!table) asm volatile("" : "+v"(c11));
 #if MCF_PIN_VCONST > 1
-        if (with_log) { asm volatile("" : "+v"(lg6)); asm volatile("" : "+v"(lg7)); }
+        if (with_log && !logtab) { asm volatile("" : "+v"(lg6)); asm volatile("" : "+v"(lg7)); }
 #endif
 #endif
     }
@@ -385,7 +535,36 @@ __device__ __forceinline__ double fexp(double x, const MathK& K) {
 }
 // log(x) for finite normal x > 0: m in [sqrt(1/2), sqrt(2)), s = f/(2+f), the
 // classic 7-term series in s^2 with the hi/lo split of ln2.
+// Table route: m in [0.5, 1) and e from frexp; the top 8 mantissa bits pick (c, l) with r = m c - 1, |r| <= 2^-8, and
+//   log x = (e - [j < kLogSplit]) ln2 + l + log1p(r),   log1p(r) = r - r^2/2 + ... + r^7/7   (r^8/8 < 2^-67).
+// Around x = 1 both neighbouring intervals have c = 1 (or 2) and l = 0 exactly, so the result is log1p(x - 1) there: no
+// cancellation against e ln2.  No division: 14 fp64 + 5 integer instructions + one 16-byte LDS read, against 27 + rcp.
+__device__ __forceinline__ double flog_tab(double x, const MathK& K) {
+    const double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const int j = (__double2hiint(m) >> 12) & 255;
+    const double2 cl = *reinterpret_cast<const double2*>(K.ltab + 2 * j);
+    e -= j < kLogSplit ? 1 : 0;
+    const double dk = (double)e;
+    double r, q, r2, out;
+    asm("v_fma_f64 %0, %4, %5, -1.0\n\t"       // r = m c - 1
+        "v_fma_f64 %1, %0, %7, %8\n\t"         // q = r/7 - 1/6
+        "v_fma_f64 %1, %0, %1, %9\n\t"         // q = r q + 1/5
+        "v_fma_f64 %1, %0, %1, %10\n\t"        // q = r q - 1/4
+        "v_fma_f64 %1, %0, %1, %11\n\t"        // q = r q + 1/3
+        "v_fma_f64 %1, %0, %1, -0.5\n\t"       // q = r q - 1/2
+        "v_mul_f64 %2, %0, %0\n\t"             // r^2
+        "v_fma_f64 %1, %2, %1, %0\n\t"         // p = r^2 q + r
+        "v_fma_f64 %1, %6, %12, %1\n\t"        // + dk ln2_lo
+        "v_fma_f64 %3, %6, %13, %14\n\t"       // dk ln2_hi + l   (dk ln2_hi is exact)
+        "v_add_f64 %3, %3, %1"
+        : "=&v"(r), "=&v"(q), "=&v"(r2), "=&v"(out)
+        : "v"(m), "v"(cl.x), "v"(dk), "v"(K.g7v), "s"(K.g[1]), "s"(K.g[2]), "s"(K.g[3]), "s"(K.g[4]), "s"(K.g[5]), "s"(K.g[6]),
+          "v"(cl.y));
+    return out;
+}
 __device__ __forceinline__ double flog(double x, const MathK& K) {
+    if (MCF_LOG_TABLE && K.logtab) return flog_tab(x, K);
     double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
     int e = __builtin_amdgcn_frexp_exp(x);
     const int lo = m < 0.70710678118654752440 ? 1 : 0;

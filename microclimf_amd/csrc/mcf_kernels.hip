@@ -623,6 +623,10 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
 #if MCF_EXP_TABLE
     __shared__ double s_exptab[256];
     MK.use_table(s_exptab, tid);       // visible after the prologue's barrier
+#if MCF_LOG_TABLE
+    __shared__ __attribute__((aligned(16))) double s_logtab[512];
+    MK.use_log_table(s_logtab, tid, NT);
+#endif
 #endif
 #if MCF_PIN_MATHK
     MK.pin(MCF_PIN_MATHK > 1 && !(PT && MCF_PT_UNPIN_LOG), AF == 0 || !MCF_AF_UNPIN_VCONST);   // exp (and log) coefficients resident in SGPRs for the whole day loop
@@ -1248,6 +1252,10 @@ __global__ void k_selftest_math(int kind, const double* __restrict__ x, const do
 #if MCF_EXP_TABLE
     __shared__ double s_exptab[256];      // the route k_solve takes
     K.use_table(s_exptab, (int)threadIdx.x);
+#if MCF_LOG_TABLE
+    __shared__ __attribute__((aligned(16))) double s_logtab[512];
+    K.use_log_table(s_logtab, (int)threadIdx.x, (int)blockDim.x);
+#endif
     __syncthreads();
 #endif
     switch (kind) {

@@ -36,12 +36,18 @@ def test_exp():
 
 def test_log():
     rng = np.random.default_rng(2)
-    x = np.concatenate([np.exp(rng.uniform(-700, 700, 300000)), rng.uniform(0.5, 2.0, 300000),
+    # (the table route's interval boundaries: mantissa 0.5 + j/512, the switch of reduction target at j = 106, and both
+    # sides of 1, where the result must come from log1p(x - 1) alone)
+    edges = (0.5 + np.arange(257) / 512.0)
+    x = np.concatenate([np.exp(rng.uniform(-700, 700, 300000)), rng.uniform(0.5, 2.0, 300000), rng.uniform(0.99, 1.01, 100000),
+                        1.0 + rng.uniform(-1, 1, 100000) * 10.0 ** rng.uniform(-15, -3, 100000),
+                        edges, np.nextafter(edges, 0), np.nextafter(edges, 2), 2 * edges, 8 * np.nextafter(edges, 0),
                         np.array([1.0, 1e-300, 1e300, 0.001, 0.70710678118654746, 0.70710678118654757])])
     got, want = run(1, x), np.log(x)
     err = np.abs(got - want)
     assert np.max(err / np.maximum(np.abs(want), 1e-3)) < 1e-15
-    assert np.max(err[np.abs(want) < 1e-3]) < 1e-18 if (np.abs(want) < 1e-3).any() else True
+    small = np.abs(want) < 1e-3
+    assert np.max(err[small]) < 1e-18 and np.max(err[small & (want != 0)] / np.abs(want[small & (want != 0)])) < 4e-16
     assert np.isnan(run(1, np.array([np.nan]))).all()
 
 
