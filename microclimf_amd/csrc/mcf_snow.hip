@@ -66,6 +66,7 @@ struct StepArgs {
 
 // ---- data.frame climate: per-step table -------------------------------------------------------
 __global__ __launch_bounds__(256) void k_snow_steps(StepArgs a) {
+    snow::snow_tables_init();
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.tsteps) return;
     StepRow r;
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void k_snow_steps(StepArgs a) {
 }
 // daily extremes of the point model's net radiation (cpp:4231-4282): one lane per day
 __global__ __launch_bounds__(64) void k_snow_days(StepRow* rows, int tsteps) {
+    snow::snow_tables_init();
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= tsteps / 24) return;
     DayT dy;
@@ -100,6 +102,7 @@ __global__ __launch_bounds__(64) void k_snow_days(StepRow* rows, int tsteps) {
 // snowalbCpp is a scan over time (hours since snowfall): a single lane walks the series once;
 // the same walk yields the series maximum of temperature that gridmicrosnow1 needs (cpp:4973-4974)
 __global__ void k_snow_alb(StepRow* rows, const double* precip, const double* temp, int tsteps, double* mxtc) {
+    snow::snow_tables_init();
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     int hs = 0;
     double mx = -273.15;
@@ -112,6 +115,7 @@ __global__ void k_snow_alb(StepRow* rows, const double* precip, const double* te
 }
 // array climate: date-only part of the sun position
 __global__ __launch_bounds__(256) void k_snow_dates(StepArgs a) {
+    snow::snow_tables_init();
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.tsteps) return;
     const SolDate sd = sol_date(a.year[k], a.month[k], a.day[k]);
@@ -141,6 +145,7 @@ struct ModelArgs {
 
 template <bool AF>
 __global__ __launch_bounds__(256, MCF_SNOW_WAVES) void k_snowmodel(ModelArgs a) {
+    snow::snow_tables_init();
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.N) return;
     const int64_t N = a.N;
@@ -269,6 +274,7 @@ struct MicroArgs {
 // cell's maximum temperature (cpp:5139-5145) and the albedo clock at every day start
 template <bool AF>
 __global__ __launch_bounds__(256) void k_microsnow_cell(MicroArgs a) {
+    snow::snow_tables_init();
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.N) return;
     if (isnan(a.hgt[c])) return;
@@ -302,6 +308,7 @@ __global__ __launch_bounds__(256) void k_microsnow_cell(MicroArgs a) {
 
 template <bool AF>
 __global__ __launch_bounds__(256) void k_microsnow(MicroArgs a) {
+    snow::snow_tables_init();
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t N = a.N;
     const int nch = (a.tsteps + 23) / 24;
@@ -390,6 +397,7 @@ __global__ __launch_bounds__(256) void k_microsnow(MicroArgs a) {
 // ---- .snowmodel1's chunk loop (R/internal.R "int:" 2553-2617) ---------------------------------------
 // albedo clock restarted at every chunk start: each gridmodelsnow1 call runs snowalbCpp on its own slice
 __global__ void k_snow_alb_chunks(StepRow* rows, const double* precip, int tsteps, int chunk, int nchunks) {
+    snow::snow_tables_init();
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nchunks) return;
     const int k0 = c * chunk, k1 = min(tsteps, k0 + chunk);

@@ -26,17 +26,44 @@ namespace snow {
 #ifndef MCF_SNOW_LEAN
 #define MCF_SNOW_LEAN 1   // 0: plain device libm and IEEE division everywhere (the round-1 build)
 #endif
+#ifndef MCF_SNOW_TABLES
+#define MCF_SNOW_TABLES 1   // exp / log through the LDS tables of mcf_device.hpp (fexp_tab, flog_tab)
+#endif
+// The workgroup's copies of kExp2Tab / kLogTab: ONE static LDS array per kernel, reached from any depth of the call tree
+// through this accessor.  EVERY kernel that can reach gexp / glog / gpow0 calls snow_tables_init() first (before any early
+// return) — a kernel that did not would read uninitialised LDS; tests/test_snow_gpu.py runs each of them against the oracle.
+__device__ __forceinline__ double* snow_tables() {
+    __shared__ __attribute__((aligned(16))) double t[512 + 256];
+    return t;
+}
+__device__ __forceinline__ void snow_tables_init() {
+#if MCF_SNOW_TABLES
+    double* t = snow_tables();
+    const int n = (int)(blockDim.x * blockDim.y * blockDim.z), tid = (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z));
+    for (int i = tid; i < 512; i += n) t[i] = kLogTab[i];
+    for (int i = tid; i < 256; i += n) t[512 + i] = kExp2Tab[i];
+    __syncthreads();
+#endif
+}
+__device__ __forceinline__ void snow_mathk(MathK& K) {
+    K.set();
+#if MCF_SNOW_TABLES
+    double* t = snow_tables();
+    K.ltab = t; K.logtab = true;
+    K.tab = t + 512; K.table = true;
+#endif
+}
 #if MCF_SNOW_LEAN
 __device__ __forceinline__ double gexp(double x) {      // exp(x) for ANY operand
     MathK K;
-    K.set();
+    snow_mathk(K);
     if (x < -750.0) x = -750.0;                         // compare-select: a NaN passes through; fexp(-750) = 0,
     if (x > 710.0) x = 710.0;                           // fexp(710) = inf by ldexp's saturation
     return fexp(x, K);
 }
 __device__ __forceinline__ double glog(double x) {      // log(x) for ANY operand
     MathK K;
-    K.set();
+    snow_mathk(K);
     double r = flog(x > 0.0 ? x : 1.0, K);
     if (!(x > 0.0)) r = (x == 0.0) ? -__longlong_as_double(0x7FF0000000000000LL) : __longlong_as_double(0x7FF8000000000000LL);
     if (x > 1.7e308) r = x;                             // log(inf) = inf
