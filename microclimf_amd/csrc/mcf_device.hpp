@@ -472,7 +472,23 @@ struct MathK {
 // exp(x) = 2^e * 2^(j/256) * exp(r), n = round(x * 256/ln2) = 256 e + j, r = x - n ln2/256, |r| <= ln2/512: the table value
 // T comes from LDS (2 KB) while the degree-4 polynomial p = exp(r) - 1 is evaluated (r^5/120 < 3.8e-17), then T + T p and
 // ldexp.  Same saturation behaviour as the polynomial route (v_cvt_i32_f64 and v_ldexp_f64 saturate; NaN stays NaN).
+#ifndef MCF_MATH_ASM
+#define MCF_MATH_ASM 1   // 1: the table routes' arithmetic as fixed instruction sequences; 0: as C++ (experiment: scheduler freedom)
+#endif
 __device__ __forceinline__ double fexp_tab(double x, const MathK& K) {
+#if !MCF_MATH_ASM
+    {
+        const double n = __builtin_rint(x * K.t[0]);
+        double r = fma(n, K.t[1], x);
+        r = fma(n, K.t[2], r);
+        const int t = (int)n;
+        const double T = K.tab[t & 255];
+        double p = fma(r, K.t[3], K.c5);
+        p = fma(r, p, 0.5);
+        p = fma(r * r, p, r);
+        return __builtin_amdgcn_ldexp(fma(T, p, T), t >> 8);
+    }
+#endif
     double n, r, p, r2, out;
     int t;
     asm("v_mul_f64 %0, %3, %4\n\t"
@@ -546,6 +562,18 @@ __device__ __forceinline__ double flog_tab(double x, const MathK& K) {
     const double2 cl = *reinterpret_cast<const double2*>(K.ltab + 2 * j);
     e -= j < kLogSplit ? 1 : 0;
     const double dk = (double)e;
+#if !MCF_MATH_ASM
+    {
+        const double r = fma(m, cl.x, -1.0);
+        double q = fma(r, K.g7v, K.g[1]);
+        q = fma(r, q, K.g[2]);
+        q = fma(r, q, K.g[3]);
+        q = fma(r, q, K.g[4]);
+        q = fma(r, q, -0.5);
+        const double p = fma(r * r, q, r);
+        return fma(dk, K.g[6], cl.y) + fma(dk, K.g[5], p);
+    }
+#endif
     double r, q, r2, out;
     asm("v_fma_f64 %0, %4, %5, -1.0\n\t"       // r = m c - 1
         "v_fma_f64 %1, %0, %7, %8\n\t"         // q = r/7 - 1/6
