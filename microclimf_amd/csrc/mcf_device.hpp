@@ -472,6 +472,9 @@ struct MathK {
 // exp(x) = 2^e * 2^(j/256) * exp(r), n = round(x * 256/ln2) = 256 e + j, r = x - n ln2/256, |r| <= ln2/512: the table value
 // T comes from LDS (2 KB) while the degree-4 polynomial p = exp(r) - 1 is evaluated (r^5/120 < 3.8e-17), then T + T p and
 // ldexp.  Same saturation behaviour as the polynomial route (v_cvt_i32_f64 and v_ldexp_f64 saturate; NaN stays NaN).
+#ifndef MCF_EXPERIMENT_NOTABLE
+#define MCF_EXPERIMENT_NOTABLE 0
+#endif
 #ifndef MCF_MATH_ASM
 #define MCF_MATH_ASM 1   // 1: the table routes' arithmetic as fixed instruction sequences; 0: as C++ (experiment: scheduler freedom)
 #endif
@@ -498,7 +501,11 @@ __device__ __forceinline__ double fexp_tab(double x, const MathK& K) {
         "v_cvt_i32_f64 %2, %0"
         : "=&v"(n), "=&v"(r), "=v"(t)
         : "v"(x), "s"(K.t[0]), "s"(K.t[1]), "s"(K.t[2]));
+#if MCF_EXPERIMENT_NOTABLE      // timing experiment (wrong results): the table look-ups replaced by constants
+    const double T = 1.0;
+#else
     const double T = K.tab[t & 255];
+#endif
     const int e = t >> 8;
     asm("v_fma_f64 %0, %2, %3, %4\n\t"        // p = r/24 + 1/6
         "v_fma_f64 %0, %2, %0, 0.5\n\t"       // p = r p + 1/2
@@ -559,7 +566,11 @@ __device__ __forceinline__ double flog_tab(double x, const MathK& K) {
     const double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
     int e = __builtin_amdgcn_frexp_exp(x);
     const int j = (__double2hiint(m) >> 12) & 255;
+#if MCF_EXPERIMENT_NOTABLE
+    const double2 cl = make_double2(1.0 + 1e-3 * (double)j, 0.25);
+#else
     const double2 cl = *reinterpret_cast<const double2*>(K.ltab + 2 * j);
+#endif
     e -= j < kLogSplit ? 1 : 0;
     const double dk = (double)e;
 #if !MCF_MATH_ASM

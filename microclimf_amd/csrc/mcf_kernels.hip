@@ -31,6 +31,22 @@
 #ifndef MCF_AF_UNPIN_VCONST
 #define MCF_AF_UNPIN_VCONST 1
 #endif
+#ifndef MCF_EXPERIMENT_STOREONLY
+#define MCF_EXPERIMENT_STOREONLY 0
+#endif
+#ifndef MCF_EXPERIMENT_STORE_HOT
+#define MCF_EXPERIMENT_STORE_HOT 0
+#endif
+#ifndef MCF_PREFETCH_UNCOND
+#define MCF_PREFETCH_UNCOND 1   // every lane loads a row element (no default value to write into the load's registers first:
+                                // that write made the compiler drain the memory counter at the top of every day)
+#endif
+#ifndef MCF_STORES_AFTER_STAGE
+#define MCF_STORES_AFTER_STAGE 0   // measured: no gain (the wait is not where the stores cost), 4 VGPRs
+#endif
+#ifndef MCF_SOILMP_SCALAR
+#define MCF_SOILMP_SCALAR 1
+#endif
 #ifndef MCF_AF_WAVES
 #define MCF_AF_WAVES 3   // waves per SIMD the array-forcing kernels are built for (168 VGPRs)
 #endif
@@ -639,8 +655,13 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
     // soil state of day `d`, from the tile image `cells`, into ring slot `slot`, by the calling wave (all 64 lanes call)
     auto produce_soil = [&](int d, int slot, const double* cells) {
         if (SS)
-            soil_day_produce<SS ? CPB : 1, F>(cells, a.tt[((int64_t)d * TF_COUNT + TF_SOILMP) * 24], s_soil + (slot % 3) * (SD_COUNT * CPB),
-                                              tid & 63, MK);
+        {
+            // the day's point-model soil moisture: a wave-uniform address, read through the scalar cache (its own counter: a
+            // vector load here would make the producing wave wait for the ten stores it has just issued)
+            const double* pt = a.tt + ((int64_t)__builtin_amdgcn_readfirstlane(d) * TF_COUNT + TF_SOILMP) * 24;
+            const double smp = MCF_SOILMP_SCALAR ? *(const __attribute__((address_space(4))) double*)(uintptr_t)pt : *pt;
+            soil_day_produce<SS ? CPB : 1, F>(cells, smp, s_soil + (slot % 3) * (SD_COUNT * CPB), tid & 63, MK);
+        }
     };
     // after the tile's constants of `cur_layer` have landed in LDS (barrier before): the lane's flags, and the soil ring
     // (re)started with this layer's constants — day `d` and the next, one wave each; from there on the wave whose turn it
@@ -706,6 +727,8 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
             unsigned sel = (unsigned)(osel >> (4 * v)) & 15u;
 #if MCF_EXPERIMENT_NOSTORE
             if (sel != 15u && val == 1.2345e300) a.out_base[(int64_t)sel * a.out_stride + oidx] = val;
+#elif MCF_EXPERIMENT_STORE_HOT   // timing experiment: every store issued, all into one L2-resident 2 MB window per variable
+            if (sel != 15u) a.out_base[(int64_t)sel * a.out_stride + (oidx & 0x3ffff)] = val;
 #else
 #if MCF_NT_STORES
             if (sel != 15u) __builtin_nontemporal_store(val, &a.out_base[(int64_t)sel * a.out_stride + oidx]);
@@ -727,7 +750,11 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
 #pragma unroll
             for (int i = 0; i < TPER; ++i) {
                 int q = tid + i * NT;
+#if MCF_PREFETCH_UNCOND
+                pre[i] = src[q < TF_COUNT * 24 ? q : TF_COUNT * 24 - 1];     // every lane loads: no default to write first
+#else
                 pre[i] = q < TF_COUNT * 24 ? src[q] : 0.0;
+#endif
             }
         }
         TimeVals tv;
@@ -797,12 +824,17 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
         double* red_t = &s_red[run & 1][0][PRE ? 0 : hr * CPB + cl];
         double* red_r = &s_red[run & 1][1][PRE ? 0 : hr * CPB + cl];
         if (valid) {
+#if MCF_EXPERIMENT_STOREONLY    // timing experiment: the launch's stores with no physics in front of them
+            cy.soilm = cy.Rbdown = cy.Rddown = p1.uz = p1.Rdup = p1.Tg0 = p1.absRnet = (double)dl;
+#else
             if (AF) pass1<F, false>(C, TR, SL, g, flags, dTmx, cy, p1, MK, cn);
             else pass1<F, SS>(C, TL, SL, g, flags, dTmx, cy, p1, MK, cn);
+#endif
             if (!PRE) {
                 *red_t = p1.Tg0;
                 *red_r = p1.absRnet;
             }
+#if !MCF_STORES_AFTER_STAGE
             put(3, cy.soilm);     // soilm      cpp:2227
             put(4, p1.uz);        // windspeed  cpp:2253
             put(5, cy.Rbdown);    // Rdirdown   cpp:2242
@@ -814,6 +846,7 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
             put(5, NA);
             put(6, NA);
             put(8, NA);
+#endif
         }
         if (PRE) {
             // The three hour lanes of a cell inside this wave (lanes l, l+16, l+32, or 48+j, 48+j+5, 48+j+10) first
@@ -849,6 +882,24 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
                 if (q < TF_COUNT * 24) dst[q] = pre[i];
             }
         }
+#if MCF_STORES_AFTER_STAGE
+        // Pass 1's five outputs are stored HERE, behind the wait for the prefetched table rows: the counter that says the loads
+        // have landed counts stores too, in order, so a store issued between the loads and that wait would be waited for as
+        // well — a round trip to the L2 per day, on every wave (31 % of the kernel's time when it was so).
+        if (valid) {
+            put(3, cy.soilm);     // soilm      cpp:2227
+            put(4, p1.uz);        // windspeed  cpp:2253
+            put(5, cy.Rbdown);    // Rdirdown   cpp:2242
+            put(6, cy.Rddown);    // Rdifdown   cpp:2243
+            put(8, p1.Rdup);      // Rswup      cpp:2244
+        } else if (in_grid) {
+            put(3, NA);
+            put(4, NA);
+            put(5, NA);
+            put(6, NA);
+            put(8, NA);
+        }
+#endif
 #if MCF_DAYPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -901,8 +952,12 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
             const double dtr = tmx - tmn;
             Pass2Out p2{};
             if (AF) derive_time_af_pass2(tv);
+#if MCF_EXPERIMENT_STOREONLY
+            p2.Tz = p2.Tg = p2.tleaf = p2.rh = p2.lwdn = p2.lwup = dtr + Rmx;
+#else
             if (AF) pass2<F, false>(C, TR, SL, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2, MK, cn);
             else pass2<F, SS>(C, TL, SL, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2, MK, cn);
+#endif
             if (BG) {
                 a.tgser[c + N * ((int64_t)dabs * 24 + hr)] = p2.Tg;
                 s_dd[hr * CPB + cl] = p2.DD;
