@@ -359,8 +359,8 @@ def roofline_block(valid, T, steps_per_launch, avg_ms, klaunches, af, rows, cols
                         "source": f"profiles/{e.get('tag')}_pmc_summary.json", "kernel_hash": e.get("kernel_hash")}
     rb = {"bound": "fp64_valu", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
           "frac_is": "achieved algorithmic HBM bytes / 8 TB/s (the metric BASELINE.json names); the binding roof is "
-                     "fp64 VALU issue, see `valu` — co-limited by the output write stream since round 2: a launch of the "
-                     "stores alone takes 0.86 of the full launch (168-byte row segments; profiles/r02_timing_experiments.txt)",
+                     "fp64 VALU issue, see `valu`; eliding the output stores would free 24-30 % more (timing experiments: "
+                     "profiles/r02_timing_experiments.txt, DESIGN 5)",
           "traffic": traffic, "kernel": "k_solve", "avg_launch_ms": avg_ms, "launches": int(klaunches),
           "algorithmic_bytes_per_launch": bpl, "valu": valu}
     if note:
