@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define MCF_ABI_VERSION 2   /* 2: mcf_grid_inputs grew the coarse-forcing fields */
+#define MCF_ABI_VERSION 3   /* 2: mcf_grid_inputs grew the coarse-forcing fields; 3: tiled output ring (mcf_plan_ring_layout) */
 
 /* Output variables, in the order of the reference's returned list
  * (src/microclimfCpp.cpp:2326-2335) and of its `out` logical(10). */
@@ -212,7 +212,10 @@ int mcf_plan_upload_forcing_days(mcf_plan *plan, const mcf_grid_inputs *in,
                                  int32_t day0, int32_t ndays, int32_t slot);
 
 /* Solve days [day0, day0+ndays) into ring slot `slot` (async on the plan's
- * stream).  Slot layout per variable: [rows,cols,24*ndays]. */
+ * stream).  The slot holds the reference's [rows,cols,24*ndays] arrays
+ * (src/microclimfCpp.cpp:2292-2303) in a device-internal order — see
+ * mcf_plan_ring_layout; mcf_plan_fetch* / mcf_nc_write_plan return them in the
+ * reference's layout. */
 int mcf_plan_run_days(mcf_plan *plan, int32_t day0, int32_t ndays, int32_t slot);
 /* reqhgt<0: after every day has been solved into slot 0, smooth the stored
  * ground-temperature series into Tz (Tbelowgroundv, cpp:1474-1539). */
@@ -277,8 +280,28 @@ int mcf_nc_write_plan(mcf_ncfile *nc, mcf_plan *plan, int32_t slot, int64_t slot
                       int64_t nsteps, float *kernel_ms);
 int mcf_nc_close(mcf_ncfile *nc);
 
-/* Device address of a ring slot variable (for device-side consumers). */
+/* Device address of a ring slot variable, for device-side consumers, and the layout it is to be read with.
+ * reqhgt >= 0: the ring is TILED — the values k_solve's workgroup produces for one variable on one day (cells_per_tile
+ * consecutive cells x 24 hours) are one block of block_doubles doubles in the workgroup's lane order, so that the solver
+ * stores whole 128-byte lines of one contiguous run per tile and day instead of 240 row segments 8 B x cells apart.
+ * Value (cell c, step k of the slot) of the variable is at dev_ptr[mcf_ring_index(layout, c, k)]:
+ *   (c / cells_per_tile) * tile_stride + (k / 24) * day_stride + pos(c % cells_per_tile, k % 24),
+ *   pos(cell, h) = h * cells_per_tile + cell, except for 21-cell tiles:
+ *   64 * (h / 3) + (cell < 16 ? 16 * (h % 3) + cell : 48 + 5 * (h % 3) + cell - 16).
+ * reqhgt < 0 (tiled == 0): linear, dev_ptr[c + cells * k], the reference's layout. */
 int mcf_plan_slot_ptr(mcf_plan *plan, int32_t slot, int32_t var, void **dev_ptr);
+typedef struct mcf_ring_layout {
+    int32_t tiled;            /* 0: linear [step][cell]                                  */
+    int32_t cells_per_tile;
+    int32_t block_doubles;    /* doubles per (tile, day, variable) block                 */
+    int32_t slot_days;
+    int64_t cells;            /* rows * cols                                             */
+    int64_t tile_stride;      /* doubles between consecutive tiles                       */
+    int64_t day_stride;       /* doubles between consecutive days of a tile              */
+} mcf_ring_layout;
+int mcf_plan_ring_layout(mcf_plan *plan, mcf_ring_layout *layout);
+/* Host-side index helper (no device needed); -1 when (cell, step) is outside the slot. */
+int64_t mcf_ring_index(const mcf_ring_layout *layout, int64_t cell, int64_t step);
 
 /* HIP-event timing on the plan's stream: start records an event, stop records
  * another, synchronises and returns the elapsed milliseconds between them. */
@@ -298,7 +321,8 @@ typedef struct mcf_dispatch_stats {
     int64_t fast_tiles, slow_tiles;   /* tiles per class (cells_per_block cells each)                    */
     int64_t irregular_days;           /* days with a non-finite / out-of-range forcing step             */
     int64_t fast_launches, slow_launches;
-    int64_t canary_trips;             /* tiles redone by the fix-up kernel, summed over launches         */
+    int64_t canary_trips;             /* tiles redone by the fix-up kernel, summed over launches (one entry per
+                                       * tile and launch, however many of its waves tripped)            */
 } mcf_dispatch_stats;
 int mcf_plan_dispatch_stats(mcf_plan *plan, mcf_dispatch_stats *stats);
 

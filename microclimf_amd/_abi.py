@@ -165,6 +165,7 @@ EXPORTS = (
     "mcf_plan_create", "mcf_plan_destroy", "mcf_plan_twi_partial",
     "mcf_plan_set_twi_mean", "mcf_plan_upload_forcing_days", "mcf_plan_run_days",
     "mcf_plan_belowground", "mcf_plan_sync", "mcf_plan_fetch", "mcf_plan_fetch_cells", "mcf_plan_fetch_packed", "mcf_plan_slot_ptr",
+    "mcf_plan_ring_layout", "mcf_ring_index",
     "mcf_plan_timer_start", "mcf_plan_timer_stop", "mcf_plan_kernel_timing",
     "mcf_plan_kernel_stats", "mcf_plan_dispatch_stats", "mcf_plan_valid_cells", "mcf_plan_bytes", "mcf_selftest_math",
     "mcf_precompute_terrain", "mcf_runbioclim1", "mcf_runbioclim2", "mcf_runbioclim3", "mcf_runbioclim4",
@@ -178,7 +179,7 @@ EXPORTS = (
     "mcf_flowacc", "mcf_topidx",
 )
 
-ABI_VERSION = 2     # include/mcf.h MCF_ABI_VERSION this mirror was written against
+ABI_VERSION = 3     # include/mcf.h MCF_ABI_VERSION this mirror was written against
 _lib = None
 
 
@@ -189,6 +190,12 @@ class McfError(RuntimeError):
 class DispatchStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in ("fast_tiles", "slow_tiles", "irregular_days", "fast_launches", "slow_launches",
                                          "canary_trips")]
+
+
+class RingLayout(C.Structure):
+    """include/mcf.h mcf_ring_layout: how a ring slot variable is addressed on the device."""
+    _fields_ = [("tiled", C.c_int32), ("cells_per_tile", C.c_int32), ("block_doubles", C.c_int32), ("slot_days", C.c_int32),
+                ("cells", C.c_int64), ("tile_stride", C.c_int64), ("day_stride", C.c_int64)]
 
 
 def _share_hip_runtime():
@@ -262,6 +269,10 @@ def load() -> C.CDLL:
                                           C.POINTER(C.c_float)]
     lib.mcf_plan_slot_ptr.restype = C.c_int
     lib.mcf_plan_slot_ptr.argtypes = [P, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.mcf_plan_ring_layout.restype = C.c_int
+    lib.mcf_plan_ring_layout.argtypes = [P, C.POINTER(RingLayout)]
+    lib.mcf_ring_index.restype = C.c_int64
+    lib.mcf_ring_index.argtypes = [C.POINTER(RingLayout), C.c_int64, C.c_int64]
     lib.mcf_plan_timer_start.restype = C.c_int
     lib.mcf_plan_timer_start.argtypes = [P]
     lib.mcf_plan_timer_stop.restype = C.c_int

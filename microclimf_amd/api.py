@@ -249,6 +249,12 @@ class Plan:
                                                    C.byref(ms) if timing else None))
         return (a, ms.value) if timing else a
 
+    def ring_layout(self) -> dict:
+        """How a ring slot variable is addressed on the device (include/mcf.h mcf_ring_layout)."""
+        lay = _abi.RingLayout()
+        _abi.check(self._lib.mcf_plan_ring_layout(self._p, C.byref(lay)))
+        return {n: int(getattr(lay, n)) for n, _ in lay._fields_}
+
     def timer_start(self):
         _abi.check(self._lib.mcf_plan_timer_start(self._p))
 

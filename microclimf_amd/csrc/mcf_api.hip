@@ -105,7 +105,14 @@ struct mcf_plan {
     std::vector<int> force_day0, force_ndays;
     // outputs
     int ring_days = 0, ring_slots = 0;
-    double* d_ring = nullptr;   // [slots][nvars][N*ring_days*24]
+    // reqhgt >= 0: TILED, [slots][tile][day][var][ring_block_doubles(cpb)] in the solver's lane order (mcf_kernels.h
+    // RingView); reqhgt < 0: linear, [slots][nvars][N*ring_days*24]
+    double* d_ring = nullptr;
+    bool tiled = false;
+    int64_t ntiles = 0, slot_elems = 0;                        // elements per slot (all variables)
+    int64_t ring_tile_stride = 0, ring_day_stride = 0, ring_var_stride = 0;
+    double* d_stage = nullptr;   // untiled [N][steps] pieces on their way to the host (mcf_plan_fetch)
+    int64_t stage_elems = 0;
     int var_slot[MCF_NOUT];     // index among enabled vars or -1
     int nvars = 0;
     // reqhgt < 0
@@ -153,6 +160,21 @@ int dalloc(mcf_plan* p, void** ptr, int64_t nbytes) {
     p->allocs.push_back(*ptr);
     p->bytes += nbytes;
     return MCF_OK;
+}
+
+// variable `var` (requested) of ring slot `slot` as its consumers address it
+mcf::RingView ring_view(const mcf_plan* p, int slot, int var) {
+    mcf::RingView v{};
+    v.N = p->N;
+    const double* sb = p->d_ring + (int64_t)slot * p->slot_elems;
+    if (p->tiled) {
+        v.base = sb + (int64_t)p->var_slot[var] * p->ring_var_stride;
+        v.tile_stride = p->ring_tile_stride; v.day_stride = p->ring_day_stride; v.cpb = p->cpb;
+    } else {
+        v.base = sb + (int64_t)p->var_slot[var] * (p->N * (int64_t)p->ring_days * 24);
+        v.cpb = 0;
+    }
+    return v;
 }
 
 int upload(mcf_plan* p, const double* host, int64_t n, const double** dev, const char* name) {
@@ -426,6 +448,9 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
     }
     // vector forcing: two 8-wave workgroups per CU (21 cells); array forcing: one 12-wave workgroup
     p->cpb = opt->cells_per_block ? opt->cells_per_block : (in->array_forcing ? 32 : 21);
+    // coarse array forcing is built for 32-cell tiles only: tile classes, tile lists and the ring's blocks must agree
+    if (p->coarse) p->cpb = 32;
+    if (p->N >= ((int64_t)1 << 31)) return fail(MCF_ERR_ARG, "at most 2^31 - 1 cells per plan (row-tile larger rasters)");
     {
         static const bool no_fast = getenv("MCF_NO_FAST_CLAMPS") != nullptr;     // A/B runs and tools/canary_audit.py
         p->fast_enabled = !no_fast && !(opt->reqhgt < 0.0);
@@ -670,8 +695,18 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
     // ---- output ring
     p->nvars = 0;
     for (int v = 0; v < MCF_NOUT; ++v) p->var_slot[v] = opt->out[v] ? p->nvars++ : -1;
-    int64_t slot_elems = N * (int64_t)ring_days * 24;
-    if ((rc = dalloc(p, &tmp, (int64_t)ring_slots * std::max(p->nvars, 1) * slot_elems * 8))) return rc;
+    p->tiled = !p->bg;
+    p->ntiles = (N + p->cpb - 1) / p->cpb;
+    if (p->tiled) {
+        const int64_t blk = mcf::ring_block_doubles(p->cpb);
+        p->ring_var_stride = blk;
+        p->ring_day_stride = (int64_t)std::max(p->nvars, 1) * blk;
+        p->ring_tile_stride = (int64_t)ring_days * p->ring_day_stride;
+        p->slot_elems = p->ntiles * p->ring_tile_stride;
+    } else {
+        p->slot_elems = (int64_t)std::max(p->nvars, 1) * N * (int64_t)ring_days * 24;
+    }
+    if ((rc = dalloc(p, &tmp, (int64_t)ring_slots * p->slot_elems * 8))) return rc;
     p->d_ring = (double*)tmp;
 
     // ---- below-ground series
@@ -761,8 +796,10 @@ int mcf_plan_run_days(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot) {
         a.dt = p->d_dt; a.windex = p->d_windex; a.mxtc = p->d_mxtc;
         a.force_step0 = 0;
     }
-    a.out_base = p->d_ring + (int64_t)slot * p->nvars * cap;
+    a.out_base = p->d_ring + (int64_t)slot * p->slot_elems;
     a.out_stride = cap;
+    a.out_tile_stride = p->ring_tile_stride; a.out_day_stride = p->ring_day_stride; a.out_var_stride = p->ring_var_stride;
+    a.slot_day0 = 0;
     a.out_sel = 0;
     for (int v = 0; v < MCF_NOUT; ++v)
         a.out_sel |= (uint64_t)(p->var_slot[v] < 0 ? 15 : p->var_slot[v]) << (4 * v);
@@ -787,26 +824,24 @@ int mcf_plan_run_days(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot) {
     bool soil_daily = !p->af && !p->day_soil_daily.empty();
     for (int d = day0; soil_daily && d < day0 + ndays; ++d)
         if (!p->day_soil_daily[(size_t)d]) soil_daily = false;
-    static const bool no_persist = getenv("MCF_NO_PERSISTENT_TILES") != nullptr;     // A/B runs
-    const bool persistent = !no_persist && p->layers <= 1;
     auto launch = [&]() {
         if (fast) {
             (void)hipMemsetAsync(p->d_fix_count, 0, 4, p->stream);
             a.tile_list = p->n_slow > 0 ? p->d_tiles_fast : nullptr;
             a.ntiles_launch = p->n_fast;
-            mcf::launch_solve(a, p->cpb, p->af, false, true, soil_daily, persistent, p->stream);
+            mcf::launch_solve(a, p->cpb, p->af, false, true, soil_daily, p->stream);
             ++p->fast_launches;
             if (p->n_slow > 0) {
                 ++p->slow_launches;
                 a.tile_list = p->d_tiles_slow;
                 a.ntiles_launch = p->n_slow;
-                mcf::launch_solve(a, p->cpb, p->af, false, false, soil_daily, false, p->stream);
+                mcf::launch_solve(a, p->cpb, p->af, false, false, soil_daily, p->stream);
             }
         } else {
             a.tile_list = nullptr;
             a.ntiles_launch = 0;
             ++p->slow_launches;
-            mcf::launch_solve(a, p->cpb, p->af, p->bg, false, soil_daily, false, p->stream);
+            mcf::launch_solve(a, p->cpb, p->af, p->bg, false, soil_daily, p->stream);
         }
     };
     if (p->ktiming) {
@@ -854,7 +889,7 @@ int mcf_plan_belowground(mcf_plan* p) {
     b.cellflag_hgt = p->d_veg[0];
     b.tg = p->d_tgser; b.ddsum = p->d_ddsum; b.Tgp = p->d_Tgp; b.Tbp = p->d_Tbp;
     b.scratch = p->d_scratch;
-    b.tz = p->d_ring + (int64_t)p->var_slot[MCF_OUT_TZ] * (p->N * (int64_t)p->ring_days * 24);
+    b.tz = const_cast<double*>(ring_view(p, 0, MCF_OUT_TZ).base);      // reqhgt < 0: the linear ring
     if (p->tsteps > (int64_t)p->ring_days * 24)
         return fail(MCF_ERR_STATE, "ring slot smaller than the series");
     mcf::launch_belowground(b, p->stream);
@@ -876,17 +911,37 @@ int mcf_plan_fetch(mcf_plan* p, int32_t slot, int32_t var, int64_t step0, int64_
     const int64_t cap_steps = (int64_t)p->ring_days * 24;
     if (step0 < 0 || nsteps < 0 || step0 + nsteps > cap_steps) return fail(MCF_ERR_ARG, "step range out of slot");
     HIP_TRY(hipSetDevice(p->device));
-    const double* src = p->d_ring + ((int64_t)slot * p->nvars + p->var_slot[var]) * (p->N * cap_steps) + p->N * step0;
-    const size_t bytes = (size_t)(p->N * nsteps) * 8;
+    if (nsteps == 0) return MCF_OK;
+    const mcf::RingView view = ring_view(p, slot, var);
     // large results: pinned ring + host copy threads instead of hipMemcpy's single-threaded staging
     static const bool no_pipe = getenv("MCF_NO_HOSTPIPE") != nullptr;
-    if (bytes >= ((size_t)64 << 20) && !no_pipe && ensure_pipe(p)) {
-        HIP_TRY(hipEventRecord(p->ev_pipe, p->stream));
-        HIP_TRY(p->pipe->copy(host_dst, src, bytes, p->ev_pipe));
+    auto to_host = [&](double* dst, const double* src, size_t bytes) -> int {
+        if (bytes >= ((size_t)64 << 20) && !no_pipe && ensure_pipe(p)) {
+            HIP_TRY(hipEventRecord(p->ev_pipe, p->stream));
+            HIP_TRY(p->pipe->copy(dst, src, bytes, p->ev_pipe));
+            return MCF_OK;
+        }
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, p->stream));
+        HIP_TRY(hipStreamSynchronize(p->stream));
         return MCF_OK;
+    };
+    if (!p->tiled) return to_host(host_dst, view.base + p->N * step0, (size_t)(p->N * nsteps) * 8);
+    // tiled ring: the reference's [rows, cols, steps] layout is made on the device (k_untile), in pieces of <= 1 GB
+    const int64_t piece = std::max<int64_t>(1, std::min<int64_t>(nsteps, ((int64_t)1 << 27) / std::max<int64_t>(p->N, 1)));
+    if (p->stage_elems < piece * p->N) {
+        int rc;
+        void* q;
+        if ((rc = dalloc(p, &q, piece * p->N * 8))) return rc;      // an earlier (smaller) buffer is released with the plan
+        p->d_stage = (double*)q;
+        p->stage_elems = piece * p->N;
     }
-    HIP_TRY(hipMemcpyAsync(host_dst, src, bytes, hipMemcpyDeviceToHost, p->stream));
-    HIP_TRY(hipStreamSynchronize(p->stream));
+    for (int64_t k0 = 0; k0 < nsteps; k0 += piece) {
+        const int64_t n = std::min(piece, nsteps - k0);
+        mcf::launch_untile(view, step0 + k0, n, p->d_stage, p->stream);
+        HIP_TRY(hipGetLastError());
+        int rc = to_host(host_dst + p->N * k0, p->d_stage, (size_t)(p->N * n) * 8);
+        if (rc) return rc;
+    }
     return MCF_OK;
 }
 
@@ -907,10 +962,9 @@ int mcf_plan_fetch_cells(mcf_plan* p, int32_t slot, int32_t var, int64_t step0, 
     HIP_TRY(hipMalloc((void**)&d_cells, (size_t)ncells * 8));
     hipError_t e = hipMalloc((void**)&d_dst, (size_t)(ncells * nsteps) * 8);
     if (e != hipSuccess) { (void)hipFree(d_cells); return fail(MCF_ERR_NOMEM, "hipMalloc failed for the gather buffer"); }
-    const double* src = p->d_ring + ((int64_t)slot * p->nvars + p->var_slot[var]) * (p->N * cap_steps) + p->N * step0;
     e = hipMemcpyAsync(d_cells, cells, (size_t)ncells * 8, hipMemcpyHostToDevice, p->stream);
     if (e == hipSuccess) {
-        mcf::launch_gather_cells(src, p->N, nsteps, d_cells, ncells, d_dst, p->stream);
+        mcf::launch_gather_cells(ring_view(p, slot, var), step0, nsteps, d_cells, ncells, d_dst, p->stream);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(host_dst, d_dst, (size_t)(ncells * nsteps) * 8, hipMemcpyDeviceToHost, p->stream);
@@ -937,9 +991,8 @@ int mcf_plan_fetch_packed(mcf_plan* p, int32_t slot, int32_t var, int64_t step0,
         p->d_pack = (int32_t*)q;
         p->pack_elems = p->N * nsteps;
     }
-    const double* src = p->d_ring + ((int64_t)slot * p->nvars + p->var_slot[var]) * (p->N * cap_steps) + p->N * step0;
     if (kernel_ms) HIP_TRY(hipEventRecord(p->ev0, p->stream));
-    mcf::launch_pack_transpose(src, p->rows, p->cols, nsteps, scale, p->d_pack, p->stream);
+    mcf::launch_pack_transpose(ring_view(p, slot, var), step0, p->rows, p->cols, nsteps, scale, p->d_pack, p->stream);
     HIP_TRY(hipGetLastError());
     if (kernel_ms) HIP_TRY(hipEventRecord(p->ev1, p->stream));
     HIP_TRY(hipMemcpyAsync(host_dst, p->d_pack, (size_t)(p->N * nsteps) * 4, hipMemcpyDeviceToHost, p->stream));
@@ -1023,9 +1076,9 @@ int mcf_nc_write_plan(mcf_ncfile* nc, mcf_plan* p, int32_t slot, int64_t slot_st
         const int v = nc->out_of[k];
         a.scale[k] = nc->scale[k];
         a.fill_only[k] = nc->fill_only[k];
-        if (a.fill_only[k]) { a.src[k] = p->d_ring; continue; }   // never read
+        if (a.fill_only[k]) { a.src[k] = mcf::RingView{p->d_ring, p->N, 0, 0, 0}; continue; }   // never read
         if (p->var_slot[v] < 0) return fail(MCF_ERR_ARG, "mcf_nc_write_plan: a variable of the file was not requested in out[]");
-        a.src[k] = p->d_ring + ((int64_t)slot * p->nvars + p->var_slot[v]) * (p->N * cap_steps) + p->N * slot_step0;
+        a.src[k] = ring_view(p, slot, v);
     }
     HIP_TRY(hipSetDevice(p->device));
     const int64_t rb = nc->f.rec_bytes;
@@ -1047,7 +1100,7 @@ int mcf_nc_write_plan(mcf_ncfile* nc, mcf_plan* p, int32_t slot, int64_t slot_st
     for (int64_t s0 = 0, i = 0; s0 < nsteps && rc == MCF_OK; s0 += piece, ++i) {
         const int64_t n = std::min(piece, nsteps - s0);
         mcf::PackNcArgs b = a;
-        for (int k = 0; k < a.nv; ++k) b.src[k] = a.src[k] + (a.fill_only[k] ? 0 : s0 * p->N);
+        b.step0 = slot_step0 + s0;
         hipError_t e = hipSuccess;
         if (kernel_ms) e = hipEventRecord(p->ev0, p->stream);
         mcf::launch_pack_nc(b, n, p->stream);
@@ -1092,8 +1145,29 @@ int mcf_plan_slot_ptr(mcf_plan* p, int32_t slot, int32_t var, void** dev_ptr) {
     if (!p || !dev_ptr) return fail(MCF_ERR_ARG, "null argument");
     if (slot < 0 || slot >= p->ring_slots || var < 0 || var >= MCF_NOUT || p->var_slot[var] < 0)
         return fail(MCF_ERR_ARG, "bad slot/var");
-    *dev_ptr = p->d_ring + ((int64_t)slot * p->nvars + p->var_slot[var]) * (p->N * (int64_t)p->ring_days * 24);
+    *dev_ptr = const_cast<double*>(ring_view(p, slot, var).base);
     return MCF_OK;
+}
+
+int mcf_plan_ring_layout(mcf_plan* p, mcf_ring_layout* out) {
+    if (!p || !out) return fail(MCF_ERR_ARG, "null argument");
+    memset(out, 0, sizeof *out);
+    out->tiled = p->tiled ? 1 : 0;
+    out->cells = p->N;
+    out->slot_days = p->ring_days;
+    if (p->tiled) {
+        out->cells_per_tile = p->cpb;
+        out->block_doubles = mcf::ring_block_doubles(p->cpb);
+        out->tile_stride = p->ring_tile_stride;
+        out->day_stride = p->ring_day_stride;
+    }
+    return MCF_OK;
+}
+
+int64_t mcf_ring_index(const mcf_ring_layout* l, int64_t cell, int64_t step) {
+    if (!l || cell < 0 || cell >= l->cells || step < 0 || step >= (int64_t)l->slot_days * 24) return -1;
+    mcf::RingView v{nullptr, l->cells, l->tile_stride, l->day_stride, l->tiled ? l->cells_per_tile : 0};
+    return v.index(cell, step);
 }
 
 int mcf_plan_timer_start(mcf_plan* p) {
@@ -1203,12 +1277,10 @@ static int run_bioclim(const mcf_grid_inputs* in_caller, const mcf_options* opt_
     if (in->array_forcing && (rc = mcf_plan_upload_forcing_days(p, in, 0, ndays, 0))) return rc;
     if ((rc = mcf_plan_run_days(p, 0, ndays, 0))) return rc;
     if (p->bg && (rc = mcf_plan_belowground(p))) return rc;
-    void *d_t = nullptr, *d_s = nullptr, *tmp = nullptr;
-    if ((rc = mcf_plan_slot_ptr(p, 0, tvar, &d_t))) return rc;
-    if ((rc = mcf_plan_slot_ptr(p, 0, MCF_OUT_SOILM, &d_s))) return rc;
+    void* tmp = nullptr;
     mcf::BioclimArgs b{};
     b.N = N; b.tsteps = (int)T;
-    b.tz = (const double*)d_t; b.soilm = (const double*)d_s;
+    b.tz = ring_view(p, 0, tvar); b.soilm = ring_view(p, 0, MCF_OUT_SOILM);
     const int32_t** dq[4] = {&b.wetq, &b.dryq, &b.hotq, &b.colq};
     b.nwet = nq[0]; b.ndry = nq[1]; b.nhot = nq[2]; b.ncol = nq[3];
     for (int i = 0; i < 4; ++i) {

@@ -15,6 +15,36 @@ struct Globals {
     int shadowmask;  // 1: runmicro1Cpp, 0: runmicro2Cpp         cpp:2218 vs 2499
 };
 
+// ---- the output ring as its consumers see it -------------------------------------------------------------------------
+// Doubles per tile-day block of the tiled ring = lanes of the solver's workgroup for `cpb` cells per tile.
+#define RING_BLOCK(cpb) ((((cpb) * 24 + 255) / 256) * 256)
+__host__ __device__ inline int ring_block_doubles(int cpb) { return RING_BLOCK(cpb); }
+// Place of (cell of the tile, hour of the day) inside a block: the lane that computes it in k_solve.  21-cell tiles:
+// wave w = hour / 3 holds [3 hours x cells 0..15 | 3 hours x cells 16..20 | one padding double]; others hour-major.
+__host__ __device__ inline int ring_pos(int cpb, int cell, int hour) {
+    if (cpb == 21) {
+        const int w = hour / 3, hh = hour - 3 * w;
+        return 64 * w + (cell < 16 ? 16 * hh + cell : 48 + 5 * hh + (cell - 16));
+    }
+    return hour * cpb + cell;
+}
+// One variable of one ring slot: value of cell c (0-based, column-major) at step k of the slot.
+//   cpb == 0  linear [step][N] (reqhgt < 0, staging buffers)
+//   cpb  > 0  tiled (k_solve's layout): tile = c / cpb, block of day k / 24 at tile * tile_stride + day * day_stride
+struct RingView {
+    const double* base;
+    int64_t N;
+    int64_t tile_stride, day_stride;
+    int32_t cpb;
+    __host__ __device__ inline int64_t index(int64_t c, int64_t k) const {
+        if (cpb == 0) return c + N * k;
+        const uint32_t cc = (uint32_t)c, t = cc / (uint32_t)cpb, cell = cc - t * (uint32_t)cpb;   // N < 2^31 (checked by the host)
+        const uint32_t kk = (uint32_t)k, d = kk / 24u, h = kk - 24u * d;
+        return (int64_t)t * tile_stride + (int64_t)d * day_stride + ring_pos(cpb, (int)cell, (int)h);
+    }
+    __device__ inline double at(int64_t c, int64_t k) const { return base[index(c, k)]; }
+};
+
 struct CellSetupArgs {
     int64_t N;
     // vegp
@@ -69,12 +99,17 @@ struct SolveArgs {
     // coarse array forcing (af_base = [15][crows*ccols][tsteps], whole series resident): crows > 0
     int32_t crows, ccols;
     int32_t altcorrect;     // 0, 1 (fixed lapse rate), 2 (humidity-dependent)
-    // outputs: enabled variables are consecutive slabs [N][slot steps] from out_base;
-    // out_sel packs, 4 bits per variable, the slab index of variable v (15 = not requested)
+    // outputs.  out_sel packs, 4 bits per variable, the slab index of variable v (15 = not requested).
+    // reqhgt >= 0, the TILED ring (RingView below): the block of (tile, day d of the slot, slab s) starts at
+    //   out_base + tile * out_tile_stride + d * out_day_stride + s * out_var_stride
+    // and holds ring_block_doubles(cells per tile) values in the solver's lane order (ring_pos).
+    // reqhgt < 0, the linear ring: slab s is [slot steps][N] at out_base + s * out_stride.
     double* out_base;
     int64_t out_stride;
     uint64_t out_sel;
-    int64_t slot_step0;     // first step of this launch inside the slot
+    int64_t slot_step0;     // linear ring: first step of this launch inside the slot
+    int64_t out_tile_stride, out_day_stride, out_var_stride;
+    int32_t slot_day0;      // tiled ring: first day of this launch inside the slot
     // reqhgt < 0
     double* tgser;          // [N][tsteps]
     double* ddsum;          // [N]
@@ -85,7 +120,6 @@ struct SolveArgs {
     // tiles of this launch: tile_list[ntiles_launch] (null: tiles 0 .. ntiles_launch-1; ntiles_launch <= 0: all)
     const int32_t* tile_list;
     int64_t ntiles_launch;
-    int32_t tiles_per_wg;   // persistent tiles: consecutive positions of the sequence solved by one workgroup (set by the launcher)
     // fast-clamp launches: tiles in which a canary tripped, redone by k_solve_fix for the launch's days
     int32_t* fix_count;
     int32_t* fix_list;      // [fix_cap]
@@ -108,24 +142,27 @@ struct BelowArgs {
 struct BioclimArgs {
     int64_t N;
     int32_t tsteps;
-    const double* tz;      // [N][tsteps] Tz or tleaf
-    const double* soilm;   // [N][tsteps]
+    RingView tz;           // Tz or tleaf, tsteps steps from step 0 of the slot
+    RingView soilm;
     const int32_t *wetq, *dryq, *hotq, *colq;
     int32_t nwet, ndry, nhot, ncol;
     double* bio;           // [19][N]
 };
 void launch_bioclim(const BioclimArgs& a, hipStream_t s);
 void launch_fill(double* p, int64_t n, double v, hipStream_t s);
-// dst[ci + ncells*k] = src[cells[ci] + N*k], k < nsteps
-void launch_gather_cells(const double* src, int64_t N, int64_t nsteps, const int64_t* cells, int64_t ncells, double* dst,
+// dst[ci + ncells*k] = src(cells[ci], step0 + k), k < nsteps
+void launch_gather_cells(const RingView& src, int64_t step0, int64_t nsteps, const int64_t* cells, int64_t ncells, double* dst,
                          hipStream_t s);
+// dst[c + N*k] = src(c, step0 + k), k < nsteps: the reference's [rows, cols, steps] layout out of the tiled ring
+void launch_untile(const RingView& src, int64_t step0, int64_t nsteps, double* dst, hipStream_t s);
 // per-cell maximum over time of the bilinearly interpolated coarse temperature [crows*ccols][tsteps]
 // `force`: the 15 coarse slabs (stride elements apart); elevd / pkfac null without altitude correction
 void launch_mxtc_coarse(const double* force, int64_t stride, int crows, int ccols, int tsteps, const double* rowpos,
                         const double* colpos, int64_t rows, int64_t N, int altcorrect, const double* elevd,
                         const double* pkfac, double* mx, hipStream_t s);
 struct PackNcArgs {
-    const double* src[10];   // first step of each variable, [rows, cols, steps] column-major
+    RingView src[10];        // each variable's slot view
+    int64_t step0;           // first step (of the slot) of this launch
     double scale[10];
     int32_t fill_only[10];
     int32_t nv;
@@ -136,8 +173,8 @@ struct PackNcArgs {
 };
 // at most 65535 / nv steps per launch
 void launch_pack_nc(const PackNcArgs& a, int64_t nsteps, hipStream_t s);
-void launch_pack_transpose(const double* src, int64_t rows, int64_t cols, int64_t nsteps, double scale, int32_t* dst,
-                           hipStream_t s);
+void launch_pack_transpose(const RingView& src, int64_t step0, int64_t rows, int64_t cols, int64_t nsteps, double scale,
+                           int32_t* dst, hipStream_t s);
 // out2: twi_scratch_doubles() doubles; [0] = sum, [1] = count on completion
 void launch_twi_partial(const double* twi, int64_t n, double tfact, double* out2, hipStream_t s);
 int twi_scratch_doubles();
@@ -149,9 +186,7 @@ void launch_mxtc(const double* tc, int64_t N, int nsteps, double* mx, hipStream_
 // fix_list; the caller zeroes *fix_count on the stream first); the tiles and days handed over must be REGULAR
 // soil_daily: every day of the launch carries kSoilDaily (vector forcing): the per cell-day soil state is computed once per
 // tile and day and shared through LDS
-// persistent: a workgroup may solve several consecutive tiles, prefetching the next one's constants (see solve_tile PT)
-void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, bool fast, bool soil_daily, bool persistent,
-                  hipStream_t s);
+void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, bool fast, bool soil_daily, hipStream_t s);
 // out[t] = 1 if every valid cell of tile t (cpb consecutive cells) is FL_REGULAR in all layers
 void launch_tile_regular(const double* cellc, int64_t N, int layers, int cpb, uint8_t* out, hipStream_t s);
 void launch_belowground(const BelowArgs& a, hipStream_t s);

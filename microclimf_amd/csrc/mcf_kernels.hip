@@ -11,92 +11,19 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdint.h>
+#include <algorithm>
 
 #include "mcf_device.hpp"
 #include "mcf_kernels.h"
 
 #ifndef MCF_WAVES_PER_EU
-#define MCF_WAVES_PER_EU 4
-#endif
-#ifndef MCF_HOUR_PERMUTE
-#define MCF_HOUR_PERMUTE 1
-#endif
-#ifndef MCF_PIN_MATHK
-#define MCF_PIN_MATHK 2   // 0: literals re-created at every exp/log, 1: exp coefficients pinned, 2: exp and log
-#endif
-#ifndef MCF_NT_STORES
-#define MCF_NT_STORES 0   // 1 (experiment): non-temporal output stores — 13 % SLOWER same-box (6.87 vs 5.99 ms per launch):
-                          // the L2 no longer merges the partial lines neighbouring tiles write
-#endif
-#ifndef MCF_AF_UNPIN_VCONST
-#define MCF_AF_UNPIN_VCONST 1
-#endif
-#ifndef MCF_EXPERIMENT_STOREONLY
-#define MCF_EXPERIMENT_STOREONLY 0
-#endif
-#ifndef MCF_EXPERIMENT_STORE_HOT
-#define MCF_EXPERIMENT_STORE_HOT 0
-#endif
-#ifndef MCF_PREFETCH_UNCOND
-#define MCF_PREFETCH_UNCOND 1   // every lane loads a row element (no default value to write into the load's registers first:
-                                // that write made the compiler drain the memory counter at the top of every day)
-#endif
-#ifndef MCF_STORES_AFTER_STAGE
-#define MCF_STORES_AFTER_STAGE 0   // measured: no gain (the wait is not where the stores cost), 4 VGPRs
-#endif
-#ifndef MCF_SOILMP_SCALAR
-#define MCF_SOILMP_SCALAR 1
+#define MCF_WAVES_PER_EU 4   // waves per SIMD the vector-forcing kernels are built for (<= 128 VGPRs)
 #endif
 #ifndef MCF_AF_WAVES
-#define MCF_AF_WAVES 3   // waves per SIMD the array-forcing kernels are built for (168 VGPRs)
+#define MCF_AF_WAVES 3       // ... and the array-forcing kernels (168 VGPRs)
 #endif
-#ifndef MCF_HOUR_ROTATE
-#define MCF_HOUR_ROTATE 1
-#endif
-#ifndef MCF_WAVE_PREREDUCE
-#define MCF_WAVE_PREREDUCE 1
-#endif
-#ifndef MCF_LANES21
-#define MCF_LANES21 1
-#endif
-#ifndef MCF_REDUCE_MINMAX
-#define MCF_REDUCE_MINMAX 1
-#endif
-#ifndef MCF_OPAQUE_OUTSEL
-#define MCF_OPAQUE_OUTSEL 1
-#endif
-#ifndef MCF_XCD_REMAP
-#define MCF_XCD_REMAP 1
-#endif
-#ifndef MCF_DAYPRIO
-#define MCF_DAYPRIO 0
-#endif
-#ifndef MCF_EXPERIMENT_SKIPDAYS
-#define MCF_EXPERIMENT_SKIPDAYS 0   // timing experiment: prologue only
-#endif
-#ifndef MCF_EXPERIMENT_NOPUSH
-#define MCF_EXPERIMENT_NOPUSH 0
-#endif
-#ifndef MCF_PT_UNPIN_LOG
-#define MCF_PT_UNPIN_LOG 1   // the persistent-tile variant carries more uniform state: log's 7 coefficient pairs are not pinned there
-#endif
-#ifndef MCF_EXPERIMENT_LDSPAD
-#define MCF_EXPERIMENT_LDSPAD 0
-#endif
-#ifndef MCF_PERSISTENT_TILES
-// 1 (experiment, NOT shipped): a workgroup walks several tiles and streams the next tile's constants into a second LDS
-// image by LDS-DMA while it computes (solve_tile PT).  It does what it is built for — the fixed cost of a launch drops from
-// 0.63 to 0.45 ms at 1024^2 with 4 tiles per workgroup — and passes every parity test, but the extra uniform state costs
-// the day loop 59 instead of 23 SGPR-spill lane moves and 36 B of scratch: +6 % per day, a net 3-4 % LOSS same-box
-// (10-day launches at 1024^2: 9.97 vs 9.59 ms; 7-day launches at 4096^2: 119.4 vs 115.8 ms).  Two lessons kept in the
-// code: tiles of one workgroup must be strided so that the workgroups in flight sit on ADJACENT tiles (walking consecutive
-// tiles lost another 20 %: the L2 no longer merges the neighbours' partial lines), and a workgroup of K tiles needs >= 24
-// rounds over the chip or the last round eats the gain.
-#define MCF_PERSISTENT_TILES 0
-#endif
-#ifndef MCF_FAST_CLAMPS
-#define MCF_FAST_CLAMPS 1   // vector forcing: waves of REGULAR lanes run the min / max form of the clamps (mcf_device.hpp `cap`)
-#endif
+// Timing experiments (results wrong on purpose, only the launch time is read) are not in this file: they are patches
+// under tools/variants/, applied to a scratch copy by tools/build_variant.sh.
 
 namespace mcf {
 
@@ -108,12 +35,23 @@ __global__ void k_fill(double* __restrict__ p, int64_t n, double v) {
 }
 
 // sparse read-back of a ring slot: one lane per (sampled cell, step)
-__global__ void k_gather_cells(const double* __restrict__ src, int64_t N, int64_t nsteps, const int64_t* __restrict__ cells,
+__global__ void k_gather_cells(RingView src, int64_t step0, int64_t nsteps, const int64_t* __restrict__ cells,
                                int64_t ncells, double* __restrict__ dst) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ncells * nsteps) return;
     const int64_t ci = i % ncells, k = i / ncells;
-    dst[i] = src[cells[ci] + N * k];
+    dst[i] = src.at(cells[ci], step0 + k);
+}
+
+// The reference's [rows, cols, steps] layout out of the tiled ring (host fetches: PCIe-bound, 30 x slower than this).
+// One lane per cell, blockIdx.y = step: the stores are contiguous runs along the raster; the loads take a whole
+// 128-byte line (cells 0..15 of an hour) + 40 bytes (cells 16..20) per 21-cell tile, the three hours that share the
+// second line meet in the L2.
+__global__ __launch_bounds__(256) void k_untile(RingView src, int64_t step0, double* __restrict__ dst) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= src.N) return;
+    const int64_t k = blockIdx.y;
+    dst[c + src.N * k] = src.at(c, step0 + k);
 }
 
 // ------------------------------------------------------------------------------------
@@ -501,104 +439,87 @@ __global__ __launch_bounds__(256) void k_mxtc_coarse(const double* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------
-// The solver.  Workgroup = CPB cells x 24 hours; thread t -> cell t % CPB, hour t / CPB,
-// so the lanes of a wave are CPB consecutive raster rows (coalesced stores of
-// CPB*8 B per hour) and 64/CPB consecutive hours.
-//   AF   array forcing (runmicro2Cpp geometry)
+// The solver.  Workgroup = one tile of CPB consecutive cells x 24 hours, one lane per (cell, hour).
+//   AF   0 vector forcing, 1 array forcing (runmicro2Cpp geometry), 2 coarse array forcing
 //   BG   reqhgt < 0: store the ground temperature series and the damping-depth sum
+//
+// Output ring.  reqhgt >= 0 writes the TILED ring: the values one workgroup produces for one variable on one day —
+// CPB cells x 24 hours — form one block of ring_block_doubles(CPB) doubles in the workgroup's own lane order
+// (mcf_kernels.h `ring_pos`), blocks ordered [tile][day of slot][variable].  Every wave stores 64 consecutive doubles
+// = four whole 128-byte lines per variable, a tile-day is one contiguous 40 KB run, and the address of a store is
+// (uniform block base) + (the lane's constant position): the base lives in SGPRs, no per-store vector arithmetic.
+// The reference's [rows, cols, steps] view (src/microclimfCpp.cpp:2292-2303) is re-created by the consumers
+// (RingView: k_untile, k_gather_cells, k_pack_transpose, k_pack_nc, k_bioclim).  Until round 3 the ring itself was
+// [variable][step][cell]: 240 row segments of 168 B per workgroup-day, consecutive hours 133 MB apart at 4096^2,
+// partial lines completed by the neighbouring tiles — a pure store stream at 32 % of the HBM peak.
+// reqhgt < 0 keeps the linear layout (k_belowground smooths whole series in place).
 // ------------------------------------------------------------------------------------
 // threads per workgroup: CPB*24 lanes rounded up to whole waves on all four SIMDs
 constexpr int solve_threads(int cpb) { return ((cpb * 24 + 255) / 256) * 256; }
+static_assert(solve_threads(21) == 512 && solve_threads(32) == 768, "ring_block_doubles() must agree");
 
 // One tile (CPB consecutive cells) over days [day0, day0 + ndays) of the launch described by `a`.
-//   F   fast clamps (mcf_device.hpp `cap`): only for tiles / days the host has classified REGULAR; a wave whose canary
-//       trips appends (tile, day) to a.fix_list and k_solve_fix redoes that tile-day with F = false afterwards
+//   F   fast clamps (mcf_device.hpp `cap`): only for tiles / days the host has classified REGULAR; a workgroup in which a
+//       canary trips appends its tile to a.fix_list and k_solve_fix redoes the tile's days of this launch with F = false
 //   SSREQ  per cell-day soil state shared through LDS (mcf_device.hpp SoilDay): only for launches whose days are all kSoilDaily
-//   PT   persistent tiles: the workgroup solves `nseq` tiles one after the other (positions first .. first + nseq - 1 of the
-//        launch's tile sequence) and the NEXT tile's constants stream into a second LDS image by LDS-DMA while the current
-//        tile computes, so that only the first tile pays the ~7 us of a cold start (9 % of a 7-day launch).  Static
-//        vegetation, vector forcing, reqhgt >= 0 and ndays >= 3 only.  PT = false: `first` IS the tile, nseq = 1.
-template <int CPB, int AF, bool BG, bool F, bool SSREQ, bool PT>   // AF: 0 vector forcing, 1 array forcing, 2 coarse array forcing
-__device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t first, const int64_t seq_stride, const int nseq,
-                                           const int day0, const int ndays, const int rot) {
+template <int CPB, int AF, bool BG, bool F, bool SSREQ>
+__device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t tile, const int day0, const int ndays, const int rot) {
     constexpr int NT = solve_threads(CPB);
-    constexpr int TILE_DOUBLES = (CF_COUNT + kCellDirs) * CPB;      // a tile's LDS image: [CF_COUNT + 32 fields][CPB]
-    constexpr int TILE_STRIDE = (TILE_DOUBLES + 31) / 32 * 32;      // images start on 256-byte boundaries
-    __shared__ __attribute__((aligned(256))) double s_tile[(PT ? 2 : 1) * TILE_STRIDE];
-    double* s_cell = s_tile;
-    double* s_dirs = s_tile + CF_COUNT * CPB;
+    static_assert(NT == RING_BLOCK(CPB), "tile-day block = one value per lane");
+    // the tile's LDS image: [CF_COUNT cell fields + 24 horizon + 8 wind-shelter rows][CPB]
+    __shared__ __attribute__((aligned(256))) double s_tile[(CF_COUNT + kCellDirs) * CPB];
+    double* const s_cell = s_tile;
+    double* const s_dirs = s_tile + CF_COUNT * CPB;
     __shared__ double s_time[AF ? 1 : 3 * TF_COUNT * 24];
-#if MCF_EXPERIMENT_LDSPAD
-    __shared__ double s_pad[MCF_EXPERIMENT_LDSPAD];     // occupancy experiment: extra LDS per workgroup
-    if (threadIdx.x == 0 && a.N < 0) s_pad[a.day0] = 1.0;
-#endif
     // day-reduction staging: per (hour, cell) values, or — 21-cell tiles — per (wave, cell) partial extremes
-    constexpr bool PRE = (CPB == 21) && MCF_LANES21 && MCF_WAVE_PREREDUCE;
+    constexpr bool PRE = CPB == 21;
     __shared__ double s_red[2][PRE ? 3 : 2][(PRE ? 8 : 24) * CPB];
     __shared__ double s_dd[BG ? 24 * CPB : 1];
     // per cell-day soil state (mcf_device.hpp SoilDay): a ring of three days, filled two days ahead by one wave
     constexpr bool SS = SSREQ && (AF == 0) && (2 * CPB <= 64);
     __shared__ double s_soil[SS ? 3 * SD_COUNT * CPB : 1];
+    __shared__ int s_trip;      // F: a wave of this workgroup tripped its canary
 
     const int tid = threadIdx.x;
     int cl = tid % CPB;
     bool lane_on = tid < CPB * 24;
-#if MCF_LANES21
-    // CPB = 21: with cell = t % 21 a 16-lane group (the unit in which ds_read_b64 resolves banks) straddles two
-    // hours in 15 of 21 cases and then holds cells {16..20, 0..10}: cells k and 16+k fall in the same bank pair
-    // (2-way conflicts on every per-cell table read; SQ_LDS_BANK_CONFLICT = 13 % of the kernel's cycles).  Each
-    // wave therefore takes 3 hours as three full groups (cells 0..15 of one hour each) plus one group holding
-    // cells 16..20 of the same three hours (15 lanes, one idle): 16 distinct consecutive addresses, or 5 distinct
-    // ones read by 3 lanes each — conflict-free — and the same 168-B row segment per hour in the stores.
-    int hr21 = 0;
-    if (CPB == 21) {
-        const int w = tid >> 6, l = tid & 63;
-        if (l < 48) { cl = l & 15; hr21 = 3 * w + (l >> 4); }
-        else { const int j = l - 48; cl = 16 + (j % 5); hr21 = 3 * w + (j / 5); lane_on = j < 15; if (!lane_on) { cl = 20; hr21 = 3 * w + 2; } }
-    }
-#endif
-#if MCF_HOUR_PERMUTE
-    // Waves w, w+4, w+8 of a workgroup share a SIMD.  Daytime waves carry the short-wave block
-    // (about twice the work of a night wave), so hour groups are dealt to waves so that every
-    // SIMD gets one midday, one morning/evening and one night group.
     int hr;
-    if (CPB == 32) {
+    uint32_t pos;       // the lane's place in a tile-day block of the ring = ring_pos(CPB, cl, hr) for the lanes that are on
+    if (CPB == 21) {
+        // With cell = t % 21 a 16-lane group (the unit in which ds_read_b64 resolves banks) straddles two hours in 15 of
+        // 21 cases and then holds cells {16..20, 0..10}: cells k and 16+k fall in the same bank pair (2-way conflicts on
+        // every per-cell table read; SQ_LDS_BANK_CONFLICT = 13 % of the kernel's cycles).  Each wave therefore takes 3
+        // hours as three full groups (cells 0..15 of one hour each) plus one group holding cells 16..20 of the same three
+        // hours (15 lanes, one idle): 16 distinct consecutive addresses, or 5 distinct ones read by 3 lanes each.
+        const int w = tid >> 6, l = tid & 63;
+        if (l < 48) { cl = l & 15; hr = 3 * w + (l >> 4); }
+        else { const int j = l - 48; cl = 16 + (j % 5); hr = 3 * w + (j / 5); lane_on = j < 15; if (!lane_on) { cl = 20; hr = 3 * w + 2; } }
+        // Waves w and w+4 of a workgroup share a SIMD and sit 12 hours apart: a day and a night wave at the equinox, but two
+        // day waves (hours 6-8 and 18-20) on one SIMD in summer and two night waves in winter.  Two workgroups are resident
+        // per CU; shifting every other one by six hours puts the complementary pattern on the same SIMDs.
+        hr = hr + 6 * rot;
+        hr -= hr >= 24 ? 24 : 0;
+        pos = (uint32_t)(64 * (hr / 3) + l);        // lanes 0..47: 16 (hr % 3) + cell; 48..62: 48 + 5 (hr % 3) + cell - 16; 63: padding
+    } else if (CPB == 32) {
+        // Waves w, w+4, w+8 of a workgroup share a SIMD.  Daytime waves carry the short-wave block (about twice the work of
+        // a night wave), so hour pairs are dealt to waves so that every SIMD gets a midday, a morning/evening and a night pair.
         const int wave = tid >> 6;
         const int tab = ((wave & 3) == 0) ? (wave == 0 ? 12 : wave == 4 ? 16 : 20)
                       : ((wave & 3) == 1) ? (wave == 1 ? 10 : wave == 5 ? 6 : 2)
                       : ((wave & 3) == 2) ? (wave == 2 ? 14 : wave == 6 ? 18 : 22)
                                           : (wave == 3 ? 8 : wave == 7 ? 4 : 0);
         hr = tab + ((tid >> 5) & 1);
+        pos = (uint32_t)(hr * 32 + cl);
     } else {
         hr = tid / CPB;
         if (hr > 23) hr = 23;
+        pos = (uint32_t)tid;                         // hour * CPB + cell; lanes past 24 * CPB: padding
     }
-#else
-    int hr = tid / CPB;
-    if (hr > 23) hr = 23;
-#endif
-#if MCF_LANES21
-    if (CPB == 21) {
-        hr = hr21;
-#if MCF_HOUR_ROTATE
-        // Waves w and w+4 of a workgroup share a SIMD and sit 12 hours apart: a day and a night wave at the
-        // equinox, but two day waves (hours 6-8 and 18-20) on one SIMD in summer and two night waves in winter.
-        // Two workgroups are resident per CU; shifting every other one by six hours puts the complementary
-        // pattern on the same SIMDs.  Workgroups q and q+32 of an XCD's dispatch sequence tend to share a CU.
-        hr = hr + 6 * rot;
-        hr -= hr >= 24 ? 24 : 0;
-#endif
-    }
-#endif
+    uint32_t posb = pos * 8u;       // byte offset of the lane's value in a block
     const int64_t N = a.N;
-    auto tile_at = [&](int it) -> int64_t {
-        const int64_t pos = first + it * seq_stride;
-        return PT ? (a.tile_list ? (int64_t)a.tile_list[pos] : pos) : first;
-    };
-    int64_t tile = tile_at(0);
-    int64_t c0 = tile * CPB;
-    int64_t c = c0 + cl;
-    bool in_grid = lane_on && c < N;   // the other lanes only help staging and keep the barriers
+    const int64_t c0 = tile * CPB;
+    const int64_t c = c0 + cl;
+    const bool in_grid = lane_on && c < N;   // the other lanes only help staging, keep the barriers and write the padding
 
     // ---- stage the tile's direction tables, the first day's time table and the first day's cell constants in LDS: all
     // global loads of the prologue are in flight together (one HBM latency per workgroup instead of three; the fixed cost
@@ -614,7 +535,6 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
         const double* src = a.tt + (int64_t)day0 * TF_COUNT * 24;
         for (int q = tid; q < TF_COUNT * 24; q += NT) s_time[q] = src[q];
     }
-
     auto stage_cells = [&](int layer) {
         const double* src = a.cellc + (int64_t)layer * CF_COUNT * N;
         for (int q = tid; q < CF_COUNT * CPB; q += NT) {
@@ -623,12 +543,13 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
             s_cell[q] = cc < N ? src[(int64_t)f * N + cc] : 0.0;
         }
     };
-    CellLds<CPB> C{s_cell + cl};     // reassigned when a persistent workgroup moves on to its next tile
+    const CellLds<CPB> C{s_cell + cl};
     int flags = 0;
     bool valid = false;
     // vegetation layer of a day (runmicro3Cpp/4Cpp `dfsel`, cpp:2760-2768)
     int cur_layer = a.daylayer ? a.daylayer[day0] : 0;
     if (cur_layer >= 0) stage_cells(cur_layer);
+    if (F && tid == 0) s_trip = 0;
     Globals g = a.g;
     double dTmx = g.dTmx;
     if (AF && in_grid) dTmx = -0.6273 * a.mxtc[c] + 49.79;   // cpp:1236 with the per-cell mxtc
@@ -636,31 +557,25 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
     const bool need_tv = g.reqhgt >= 0.0 && a.need_tv != 0;
     MathK MK;
     MK.set();
-#if MCF_EXP_TABLE
     __shared__ double s_exptab[256];
     MK.use_table(s_exptab, tid);       // visible after the prologue's barrier
-#if MCF_LOG_TABLE
     __shared__ __attribute__((aligned(16))) double s_logtab[512];
     MK.use_log_table(s_logtab, tid, NT);
-#endif
-#endif
-#if MCF_PIN_MATHK
-    MK.pin(MCF_PIN_MATHK > 1 && !(PT && MCF_PT_UNPIN_LOG), AF == 0 || !MCF_AF_UNPIN_VCONST);   // exp (and log) coefficients resident in SGPRs for the whole day loop
-#endif
+    MK.pin(true, AF == 0);   // exp and log coefficients resident in SGPRs for the whole day loop (the array-forcing kernels
+                             // have no VGPR to spare for the second constants)
     const double NA = na_real();
 
     static_assert(TF_TC == 0 && TF_SOILMP == 9 && TF_UMU < 15 && TF_GP < 15 && TF_KP < 15 && TF_MUGP < 15 && TF_DTRP < 15, "the 15 forcing series");
     Canary cn;      // F: NaN as soon as one watched clamp of this lane has met a NaN, on any day of the launch
-    int run = 0;    // days this workgroup has started, over all its tiles: indexes the time, reduction and soil rings
-    // soil state of day `d`, from the tile image `cells`, into ring slot `slot`, by the calling wave (all 64 lanes call)
-    auto produce_soil = [&](int d, int slot, const double* cells) {
-        if (SS)
-        {
+    int run = 0;    // days this workgroup has started: indexes the time, reduction and soil rings
+    // soil state of day `d` into ring slot `slot`, by the calling wave (all 64 lanes call)
+    auto produce_soil = [&](int d, int slot) {
+        if (SS) {
             // the day's point-model soil moisture: a wave-uniform address, read through the scalar cache (its own counter: a
             // vector load here would make the producing wave wait for the ten stores it has just issued)
             const double* pt = a.tt + ((int64_t)__builtin_amdgcn_readfirstlane(d) * TF_COUNT + TF_SOILMP) * 24;
-            const double smp = MCF_SOILMP_SCALAR ? *(const __attribute__((address_space(4))) double*)(uintptr_t)pt : *pt;
-            soil_day_produce<SS ? CPB : 1, F>(cells, smp, s_soil + (slot % 3) * (SD_COUNT * CPB), tid & 63, MK);
+            const double smp = *(const __attribute__((address_space(4))) double*)(uintptr_t)pt;
+            soil_day_produce<SS ? CPB : 1, F>(s_cell, smp, s_soil + (slot % 3) * (SD_COUNT * CPB), tid & 63, MK);
         }
     };
     // after the tile's constants of `cur_layer` have landed in LDS (barrier before): the lane's flags, and the soil ring
@@ -671,37 +586,18 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
         valid = (flags & FL_VALID) != 0;
         if (SS && cur_layer >= 0) {
             const int wv = tid >> 6;
-            if (wv == 0) produce_soil(d, run, s_cell);
-            if (wv == 1 && d + 1 < day0 + ndays) produce_soil(d + 1, run + 1, s_cell);
+            if (wv == 0) produce_soil(d, run);
+            if (wv == 1 && d + 1 < day0 + ndays) produce_soil(d + 1, run + 1);
             __syncthreads();
         }
     };
     __syncthreads();
     enter_layer(day0);
-    for (int it = 0; it < (PT ? nseq : 1); ++it) {
-    const bool has_next = PT && it + 1 < nseq;
-    double* const s_alt = s_tile + (PT ? ((it & 1) ? 0 : TILE_STRIDE) : 0);     // the other tile image (tile `it` lives in image it & 1)
-    for (int dl = 0; dl < (MCF_EXPERIMENT_SKIPDAYS ? 0 : ndays); ++dl, ++run) {
+    // the tile's first block of this launch in the tiled ring (uniform: SGPRs); a day's ten stores are
+    // [block base + variable slab * block] + pos
+    double* ring_day = BG ? nullptr : a.out_base + tile * a.out_tile_stride + (int64_t)a.slot_day0 * a.out_day_stride;
+    for (int dl = 0; dl < ndays; ++dl, ++run) {
         const int dabs = day0 + dl;
-        if (PT && has_next && dl == 1) {
-            // Every wave has left the previous tile (this one is past the barrier of day 0), so the other image is free: stream
-            // the next tile's constants into it, 4 bytes per lane per instruction straight from global memory to LDS (no
-            // VGPRs) — here, at the top of a day, where a lane carries nothing.
-            const int64_t c0n = tile_at(it + 1) * CPB;
-            const double* cells = a.cellc + (int64_t)cur_layer * CF_COUNT * N;
-            constexpr int TILE_DW = TILE_DOUBLES * 2, NCHUNK = (TILE_DW + 63) / 64;     // 64-dword pieces, one per wave instruction
-#pragma unroll 1
-            for (int k = tid >> 6; k < NCHUNK; k += NT / 64) {
-                const int D = 64 * k + (tid & 63), q = D >> 1, f = q / CPB;
-                const int64_t cc = c0n + (q - f * CPB);
-                const double* src = f < CF_COUNT ? cells + (int64_t)f * N + cc
-                                  : f < CF_COUNT + 24 ? a.hor + (int64_t)(f - CF_COUNT) * N + cc
-                                                      : a.wsa + (int64_t)(f - CF_COUNT - 24) * N + cc;
-                if (D < TILE_DW && cc < N)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)src + 4 * (D & 1)),
-                                                     (__attribute__((address_space(3))) void*)((char*)s_alt + 256 * k), 4, 0, 0);
-            }
-        }
         // the tile's cell constants are restaged whenever the day's vegetation layer changes — workgroup-uniform and rare
         const int layer = a.daylayer ? a.daylayer[dabs] : 0;
         if (layer != cur_layer) {
@@ -711,50 +607,39 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
             cur_layer = layer;
             enter_layer(dabs);
         }
-        const int64_t kl = (int64_t)(dabs - a.day0) * 24 + hr;   // step within the launch's part of the slot
-        const int64_t oidx = c + N * (a.slot_step0 + kl);
-#if MCF_OPAQUE_OUTSEL
-        // Left alone, hipcc hoists a 64-bit "variable v is requested" mask and a 64-bit slab pointer per
-        // output variable out of the day loop: 40 SGPRs that do not fit and are spilled to VGPR lanes
-        // (v_readlane + hazard nops around every store).  Making the selector opaque once per day keeps two
-        // SGPRs live instead; slab index and address are re-derived by a handful of SALU ops per store.
+        const int64_t kl = (int64_t)(dabs - a.day0) * 24 + hr;   // step within the launch
+        // Left alone, hipcc hoists a 64-bit "variable v is requested" mask and a 64-bit slab pointer per output variable out
+        // of the day loop: 40 SGPRs that do not fit and are spilled to VGPR lanes (v_readlane + hazard nops around every
+        // store).  Making the selector opaque once per day keeps two SGPRs live instead; the slab base is re-derived by a
+        // handful of SALU ops per store.
         uint64_t osel = a.out_sel;
         asm volatile("" : "+s"(osel));
-#else
-        const uint64_t osel = a.out_sel;
-#endif
+        double* lin = nullptr;                 // linear ring (reqhgt < 0): the lane's element of slab 0
+        if (BG) lin = a.out_base + (c + N * (a.slot_step0 + kl));
         auto put = [&](int v, double val) {
-            unsigned sel = (unsigned)(osel >> (4 * v)) & 15u;
-#if MCF_EXPERIMENT_NOSTORE
-            if (sel != 15u && val == 1.2345e300) a.out_base[(int64_t)sel * a.out_stride + oidx] = val;
-#elif MCF_EXPERIMENT_STORE_HOT   // timing experiment: every store issued, all into one L2-resident 2 MB window per variable
-            if (sel != 15u) a.out_base[(int64_t)sel * a.out_stride + (oidx & 0x3ffff)] = val;
-#else
-#if MCF_NT_STORES
-            if (sel != 15u) __builtin_nontemporal_store(val, &a.out_base[(int64_t)sel * a.out_stride + oidx]);
-#else
-            if (sel != 15u) a.out_base[(int64_t)sel * a.out_stride + oidx] = val;
-#endif
-#endif
+            const unsigned sel = (unsigned)(osel >> (4 * v)) & 15u;
+            if (sel == 15u) return;
+            if (BG) { if (in_grid) lin[(int64_t)sel * a.out_stride] = val; }
+            else {
+                // SGPR base + the lane's 32-bit byte offset (global_store ... v_off, v_data, s[base]): no vector arithmetic per
+                // store.  The empty asm keeps the zero-extension of the offset in the store's own basic block, where
+                // instruction selection can fold it into the addressing mode.
+                asm("" : "+v"(posb));
+                *(double*)((char*)ring_day + ((size_t)sel * (NT * 8)) + posb) = val;
+            }
         };
         // issue the loads of the next day's table rows now; they land in LDS after pass 1
         constexpr int TPER = (TF_COUNT * 24 + NT - 1) / NT;
         double pre[TPER];
-#if MCF_EXPERIMENT_NOPREFETCH
-        const bool stage = false;
-#else
-        const bool stage = !AF && (dl + 1 < ndays || has_next);      // the next tile starts over at day0
-#endif
+        const bool stage = !AF && dl + 1 < ndays;
         if (stage) {
-            const double* src = a.tt + (int64_t)(dl + 1 < ndays ? dabs + 1 : day0) * TF_COUNT * 24;
+            const double* src = a.tt + (int64_t)(dabs + 1) * TF_COUNT * 24;
 #pragma unroll
             for (int i = 0; i < TPER; ++i) {
                 int q = tid + i * NT;
-#if MCF_PREFETCH_UNCOND
-                pre[i] = src[q < TF_COUNT * 24 ? q : TF_COUNT * 24 - 1];     // every lane loads: no default to write first
-#else
-                pre[i] = q < TF_COUNT * 24 ? src[q] : 0.0;
-#endif
+                // every lane loads (no default value to write into the load's registers first: that write made the compiler
+                // drain the memory counter at the top of every day)
+                pre[i] = src[q < TF_COUNT * 24 ? q : TF_COUNT * 24 - 1];
             }
         }
         TimeVals tv;
@@ -815,38 +700,29 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
         TimeReg TR{&tv};
         SoilLds<CPB> SL{s_soil + (SS ? (run % 3) * (SD_COUNT * CPB) + cl : 0)};
 
-#if MCF_DAYPRIO
-        // daytime waves carry the short-wave block and are the critical path to the barrier
-        if (!AF && __builtin_amdgcn_readfirstlane((int)(TL(TF_RSW) > 0.0))) __builtin_amdgcn_s_setprio(1);
-#endif
         Carry cy;
         Pass1Out p1;
         double* red_t = &s_red[run & 1][0][PRE ? 0 : hr * CPB + cl];
         double* red_r = &s_red[run & 1][1][PRE ? 0 : hr * CPB + cl];
         if (valid) {
-#if MCF_EXPERIMENT_STOREONLY    // timing experiment: the launch's stores with no physics in front of them
-            cy.soilm = cy.Rbdown = cy.Rddown = p1.uz = p1.Rdup = p1.Tg0 = p1.absRnet = (double)dl;
-#else
             if (AF) pass1<F, false>(C, TR, SL, g, flags, dTmx, cy, p1, MK, cn);
             else pass1<F, SS>(C, TL, SL, g, flags, dTmx, cy, p1, MK, cn);
-#endif
             if (!PRE) {
                 *red_t = p1.Tg0;
                 *red_r = p1.absRnet;
             }
-#if !MCF_STORES_AFTER_STAGE
             put(3, cy.soilm);     // soilm      cpp:2227
             put(4, p1.uz);        // windspeed  cpp:2253
             put(5, cy.Rbdown);    // Rdirdown   cpp:2242
             put(6, cy.Rddown);    // Rdifdown   cpp:2243
             put(8, p1.Rdup);      // Rswup      cpp:2244
-        } else if (in_grid) {
+        } else {
+            // NA cells, cells past the raster's end and a block's padding lanes: the ring's blocks are written whole
             put(3, NA);
             put(4, NA);
             put(5, NA);
             put(6, NA);
             put(8, NA);
-#endif
         }
         if (PRE) {
             // The three hour lanes of a cell inside this wave (lanes l, l+16, l+32, or 48+j, 48+j+5, 48+j+10) first
@@ -882,44 +758,18 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
                 if (q < TF_COUNT * 24) dst[q] = pre[i];
             }
         }
-#if MCF_STORES_AFTER_STAGE
-        // Pass 1's five outputs are stored HERE, behind the wait for the prefetched table rows: the counter that says the loads
-        // have landed counts stores too, in order, so a store issued between the loads and that wait would be waited for as
-        // well — a round trip to the L2 per day, on every wave (31 % of the kernel's time when it was so).
-        if (valid) {
-            put(3, cy.soilm);     // soilm      cpp:2227
-            put(4, p1.uz);        // windspeed  cpp:2253
-            put(5, cy.Rbdown);    // Rdirdown   cpp:2242
-            put(6, cy.Rddown);    // Rdifdown   cpp:2243
-            put(8, p1.Rdup);      // Rswup      cpp:2244
-        } else if (in_grid) {
-            put(3, NA);
-            put(4, NA);
-            put(5, NA);
-            put(6, NA);
-            put(8, NA);
-        }
-#endif
-#if MCF_DAYPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        // the next tile's image must have landed (and be visible) behind the barrier of the last day but one, where its soil
-        // state is first computed from it: every wave drains its own LDS-DMA loads before that barrier
-        if (PT && has_next && dl == ndays - 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#if !MCF_EXPERIMENT_NOBARRIER
         __syncthreads();
-#endif
         if (SS) {
             // Every wave is past the day before now, so the soil ring slot of the day after next (= that of the day before)
             // is free; whoever fills it reaches the NEXT barrier before any wave starts that day.  The waves take turns.  A
             // change of layer on the way restarts the ring above, so a slot filled with the wrong layer's constants is never
-            // read.  Past the tile's last day the ring runs on into the next tile's first two days, from its image.
-            const int d2 = dl + 2;
-            if ((tid >> 6) == (run & 7) % (NT / 64) && (d2 < ndays || has_next))
-                produce_soil(d2 < ndays ? day0 + d2 : day0 + d2 - ndays, run + 2, d2 < ndays ? s_cell : s_alt);
+            // read.
+            if ((tid >> 6) == (run & 7) % (NT / 64) && dl + 2 < ndays) produce_soil(day0 + dl + 2, run + 2);
         }
         if (valid && a.need_pass2) {
-            // day reductions in hour order with the reference's comparisons, cpp:2196-2198, 2256-2263
+            // day reductions with the reference's comparisons, cpp:2196-2198, 2256-2263.  `if (Rmx < rv) Rmx = rv` with a
+            // finite start value ignores a NaN rv, exactly what v_max_f64 does (the accumulator is never NaN, rv is never a
+            // signalling NaN: it was just computed): one VALU instruction instead of a compare and two 32-bit selects
             double Rmx = -999.9, tmx = -999.0, tmn = 999.0;
             const double* rt = &s_red[run & 1][0][cl];
             const double* rr = &s_red[run & 1][1][cl];
@@ -936,40 +786,27 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
 #pragma unroll
             for (int hh = 0; hh < (PRE ? 0 : 24); ++hh) {
                 double tg = rt[hh * CPB], rv = rr[hh * CPB];
-#if MCF_REDUCE_MINMAX
-                // `if (Rmx < rv) Rmx = rv` with a finite start value ignores a NaN rv, exactly what v_max_f64
-                // does (the accumulator is never NaN, rv is never a signalling NaN: it was just computed):
-                // one VALU instruction instead of a compare and two 32-bit selects, 72 x per cell-step
                 asm("v_max_f64 %0, %0, %1" : "+v"(Rmx) : "v"(rv));
                 asm("v_max_f64 %0, %0, %1" : "+v"(tmx) : "v"(tg));
                 asm("v_min_f64 %0, %0, %1" : "+v"(tmn) : "v"(tg));
-#else
-                if (Rmx < rv) Rmx = rv;
-                if (tmx < tg) tmx = tg;
-                if (tmn > tg) tmn = tg;
-#endif
             }
             const double dtr = tmx - tmn;
             Pass2Out p2{};
             if (AF) derive_time_af_pass2(tv);
-#if MCF_EXPERIMENT_STOREONLY
-            p2.Tz = p2.Tg = p2.tleaf = p2.rh = p2.lwdn = p2.lwup = dtr + Rmx;
-#else
             if (AF) pass2<F, false>(C, TR, SL, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2, MK, cn);
             else pass2<F, SS>(C, TL, SL, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2, MK, cn);
-#endif
             if (BG) {
                 a.tgser[c + N * ((int64_t)dabs * 24 + hr)] = p2.Tg;
                 s_dd[hr * CPB + cl] = p2.DD;
             } else {
-                const bool pos = g.reqhgt > 0.0;
-                put(0, pos ? p2.Tz : p2.Tg);          // cpp:2292-2297
-                put(1, pos ? p2.tleaf : NA);          // cpp:2300-2303
-                put(2, pos ? p2.rh : NA);
+                const bool pos_h = g.reqhgt > 0.0;
+                put(0, pos_h ? p2.Tz : p2.Tg);        // cpp:2292-2297
+                put(1, pos_h ? p2.tleaf : NA);        // cpp:2300-2303
+                put(2, pos_h ? p2.rh : NA);
                 put(7, p2.lwdn);                      // cpp:2298
                 put(9, p2.lwup);                      // cpp:2299
             }
-        } else if (in_grid) {
+        } else if (!BG || in_grid) {
             if (!BG) put(0, NA);
             put(1, NA);
             put(2, NA);
@@ -992,74 +829,44 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t fir
             }
             __syncthreads();
         }
+        if (!BG) ring_day += a.out_day_stride;
     }
-    if (F && !MCF_EXPERIMENT_NOPUSH) {
-        // a watched clamp met a NaN somewhere in this wave's share of the tile: k_solve_fix redoes the tile's days of this launch
-        const uint64_t bad = __builtin_amdgcn_ballot_w64(cn.tripped());
-        if (bad != 0 && (tid & 63) == 0) {
+    if (F) {
+        // a watched clamp met a NaN somewhere in this workgroup's tile: k_solve_fix redoes the tile's days of this launch.
+        // ONE entry per tile: the waves' ballots meet in an LDS flag (every wave is past the last day's barrier; the flag's
+        // own barrier below is reached by all), lane 0 pushes.
+        if (__builtin_amdgcn_ballot_w64(cn.tripped()) != 0 && (tid & 63) == 0) s_trip = 1;
+        __syncthreads();
+        if (tid == 0 && s_trip) {
             const int i = atomicAdd(a.fix_count, 1);
             if (i < a.fix_cap) a.fix_list[i] = (int32_t)tile;
         }
-        cn = Canary();
-    }
-    if (has_next) {
-        // on to the next tile: its image is complete since the barrier of the last day but one, its first day's time table
-        // and its first two days' soil state were staged during the last day — no barrier, no cold start
-        s_cell = s_alt;
-        s_dirs = s_alt + CF_COUNT * CPB;
-        C = CellLds<CPB>{s_cell + cl};
-        tile = tile_at(it + 1);
-        c0 = tile * CPB;
-        c = c0 + cl;
-        in_grid = lane_on && c < N;
-        flags = (in_grid && cur_layer >= 0) ? (int)s_cell[CF_FLAGS * CPB + cl] : 0;
-        valid = (flags & FL_VALID) != 0;
-    }
     }
 }
 
 // blockIdx -> position in the launch's tile sequence.  Workgroups are dealt round-robin to the 8 XCDs (b and b+8
-// share one, each XCD has its own L2).  A tile's 168-B row segments share their boundary cache lines with the
-// neighbouring tiles, so consecutive tiles are given to the SAME XCD: its L2 then merges the two partial line
-// writes instead of two L2s each writing a partial line back.  Speed only.
+// share one, each XCD has its own L2).  The 168-B row segments a tile reads from the [field][cell] constant tables share
+// their boundary cache lines with the neighbouring tiles, so consecutive tiles are given to the SAME XCD.  Speed only.
 __device__ __forceinline__ int64_t tile_position(int64_t ntiles) {
-#if MCF_XCD_REMAP
     const int64_t per_xcd = (ntiles + 7) / 8;
     const int64_t pos = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (pos >= ntiles || (int64_t)(blockIdx.x >> 3) >= per_xcd) return -1;
     return pos;
-#else
-    return blockIdx.x < ntiles ? (int64_t)blockIdx.x : -1;
-#endif
 }
 
 // array forcing keeps ~17 more doubles live per lane (forcing values instead of an LDS table):
 // it is built for 3 waves/SIMD (168 VGPRs, no scratch) and run with 32-cell workgroups
-template <int CPB, int AF, bool BG, bool F, bool SSREQ, bool PT>
+template <int CPB, int AF, bool BG, bool F, bool SSREQ>
 __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_PER_EU) void k_solve(SolveArgs a) {
-    // every other resident workgroup shifts its wave-to-hour assignment by six hours (MCF_HOUR_ROTATE)
+    // every other resident workgroup shifts its wave-to-hour assignment by six hours
     const int rot = (int)((blockIdx.x >> 8) & 1);
-    if (PT) {
-        // Each XCD keeps its contiguous eighth of the tile sequence (the L2 merges the partial lines of neighbouring tiles).
-        // Inside it, the R workgroups of the XCD take tiles r, r + R, r + 2R, ...: at any moment the workgroups in flight are
-        // on ADJACENT tiles, as in the one-tile-per-workgroup launch — a workgroup walking K consecutive tiles instead would
-        // write neighbouring tiles' shared cache lines a whole tile apart in time, after the L2 has given them up.
-        const int64_t per_xcd = (a.ntiles_launch + 7) / 8;
-        const int x = (int)(blockIdx.x & 7);
-        const int64_t lo = x * per_xcd, hi = lo + per_xcd < a.ntiles_launch ? lo + per_xcd : a.ntiles_launch;
-        const int64_t R = (per_xcd + a.tiles_per_wg - 1) / a.tiles_per_wg, r = blockIdx.x >> 3;
-        if (r >= R || lo + r >= hi) return;
-        const int nseq = (int)((hi - (lo + r) + R - 1) / R);
-        solve_tile<CPB, AF, BG, F, SSREQ, PT>(a, lo + r, R, nseq, a.day0, a.ndays, rot);
-    } else {
-        const int64_t pos = tile_position(a.ntiles_launch);
-        if (pos < 0) return;
-        const int64_t tile = a.tile_list ? (int64_t)a.tile_list[pos] : pos;
-        solve_tile<CPB, AF, BG, F, SSREQ, false>(a, tile, 0, 1, a.day0, a.ndays, rot);
-    }
+    const int64_t pos = tile_position(a.ntiles_launch);
+    if (pos < 0) return;
+    const int64_t tile = a.tile_list ? (int64_t)a.tile_list[pos] : pos;
+    solve_tile<CPB, AF, BG, F, SSREQ>(a, tile, a.day0, a.ndays, rot);
 }
 
-// Redoes, with the reference's compare-and-select clamps, the tiles in which a fast wave's canary tripped.  Launched
+// Redoes, with the reference's compare-and-select clamps, the tiles in which a fast workgroup's canary tripped.  Launched
 // behind every fast launch with a fixed small grid; with an empty list (the normal case) every workgroup leaves at once.
 // An overflowing list means "everything": all tiles, all days of the launch.
 template <int CPB, int AF>
@@ -1071,13 +878,13 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
         const int64_t ntiles = (a.N + CPB - 1) / CPB;
         for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
             __syncthreads();
-            solve_tile<CPB, AF, false, false, false, false>(a, t, 0, 1, a.day0, a.ndays, 0);
+            solve_tile<CPB, AF, false, false, false>(a, t, a.day0, a.ndays, 0);
         }
         return;
     }
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
         __syncthreads();
-        solve_tile<CPB, AF, false, false, false, false>(a, (int64_t)a.fix_list[i], 0, 1, a.day0, a.ndays, 0);
+        solve_tile<CPB, AF, false, false, false>(a, (int64_t)a.fix_list[i], a.day0, a.ndays, 0);
     }
 }
 
@@ -1209,17 +1016,31 @@ __global__ __launch_bounds__(64) void k_belowground(BelowArgs a) {
 // runbioclimCpp, cpp:3245-3560: per-cell reductions of Tz (or tleaf) and soilm over time; one
 // lane per cell, lanes along raster rows (coalesced).  All 19 values are produced; bio7 / bio3
 // come from the values, not from possibly unrequested matrices.
-__device__ inline double quarter_mean(const double* __restrict__ x, int64_t N, const int32_t* q, int nq) {
+// a cell's series in a ring slot: tile and cell resolved once per lane
+struct RingCell {
+    const double* p;      // linear: the cell's first step; tiled: the tile's first block
+    int64_t N, day_stride;
+    int cpb, cell;
+    __device__ RingCell(const RingView& v, int64_t c) : N(v.N), day_stride(v.day_stride), cpb(v.cpb) {
+        if (cpb == 0) { p = v.base + c; cell = 0; }
+        else { const uint32_t t = (uint32_t)c / (uint32_t)cpb; cell = (int)((uint32_t)c - t * (uint32_t)cpb); p = v.base + (int64_t)t * v.tile_stride; }
+    }
+    __device__ __forceinline__ double operator[](int k) const {
+        if (cpb == 0) return p[N * k];
+        const int d = k / 24;
+        return p[(int64_t)d * day_stride + ring_pos(cpb, cell, k - 24 * d)];
+    }
+};
+__device__ inline double quarter_mean(const RingCell& x, const int32_t* q, int nq) {
     double s = 0.0;
-    for (int i = 0; i < nq; ++i) s = s + x[N * q[i]];
+    for (int i = 0; i < nq; ++i) s = s + x[q[i]];
     return s / 72.0;                                                    // cpp:3325 (fixed divisor)
 }
 __global__ __launch_bounds__(64) void k_bioclim(BioclimArgs a) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t N = a.N;
     if (c >= N) return;
-    const double* tz = a.tz + c;
-    const double* sm = a.soilm + c;
+    const RingCell tz(a.tz, c), sm(a.soilm, c);
     double* out = a.bio + c;
     const double NA = na_real();
     if (isnan(tz[0])) {                                                 // cpp:3505-3506
@@ -1233,7 +1054,7 @@ __global__ __launch_bounds__(64) void k_bioclim(BioclimArgs a) {
         for (int d = 0; d < 12; ++d) {
             double tmx = -273.15, tmn = 273.15, ms = 0.0;
             for (int h = 0; h < 24; ++h) {
-                double v = tz[N * (d * 24 + h)];
+                double v = tz[d * 24 + h];
                 s = s + v;
                 if (v > tmx) tmx = v;
                 if (v < tmn) tmn = v;
@@ -1253,38 +1074,38 @@ __global__ __launch_bounds__(64) void k_bioclim(BioclimArgs a) {
     }
     {   // bio5 cpp:3297, bio6 cpp:3307
         double tmx = -273.15, tmn = 273.15;
-        for (int i = 288; i < 312; ++i) { double v = tz[N * i]; if (v > tmx) tmx = v; }
-        for (int i = 312; i < 336; ++i) { double v = tz[N * i]; if (v < tmn) tmn = v; }
+        for (int i = 288; i < 312; ++i) { double v = tz[i]; if (v > tmx) tmx = v; }
+        for (int i = 312; i < 336; ++i) { double v = tz[i]; if (v < tmn) tmn = v; }
         bio[4] = tmx;
         bio[5] = tmn;
     }
-    bio[7] = quarter_mean(tz, N, a.wetq, a.nwet);
-    bio[8] = quarter_mean(tz, N, a.dryq, a.ndry);
-    bio[9] = quarter_mean(tz, N, a.hotq, a.nhot);
-    bio[10] = quarter_mean(tz, N, a.colq, a.ncol);
+    bio[7] = quarter_mean(tz, a.wetq, a.nwet);
+    bio[8] = quarter_mean(tz, a.dryq, a.ndry);
+    bio[9] = quarter_mean(tz, a.hotq, a.nhot);
+    bio[10] = quarter_mean(tz, a.colq, a.ncol);
     {   // bio12..bio15 cpp:3361-3404
         double me = 0.0;
-        for (int i = 0; i < 288; ++i) me = me + sm[N * i];
+        for (int i = 0; i < 288; ++i) me = me + sm[i];
         me = me / 288.0;
         double mx = 0.0, mn = 1.0, all = 0.0;
         for (int i = 0; i < T; ++i) {
-            double v = sm[N * i];
+            double v = sm[i];
             if (v > mx) mx = v;
             if (v < mn) mn = v;
             all += v;
         }
         double mean = all / T, ss = 0.0;
-        for (int i = 0; i < T; ++i) { double dlt = sm[N * i] - mean; ss += dlt * dlt; }
+        for (int i = 0; i < T; ++i) { double dlt = sm[i] - mean; ss += dlt * dlt; }
         double sd = T <= 1 ? NA : sqrt(ss / (T - 1));
         bio[11] = me;
         bio[12] = mx;
         bio[13] = mn;
         bio[14] = me / sd;                                              // cpp:3402 (sic: mean / sd)
     }
-    bio[15] = quarter_mean(sm, N, a.wetq, a.nwet);
-    bio[16] = quarter_mean(sm, N, a.dryq, a.ndry);
-    bio[17] = quarter_mean(sm, N, a.hotq, a.nhot);
-    bio[18] = quarter_mean(sm, N, a.colq, a.ncol);
+    bio[15] = quarter_mean(sm, a.wetq, a.nwet);
+    bio[16] = quarter_mean(sm, a.dryq, a.ndry);
+    bio[17] = quarter_mean(sm, a.hotq, a.nhot);
+    bio[18] = quarter_mean(sm, a.colq, a.ncol);
     bio[6] = bio[4] - bio[5];                                           // cpp:3533
     bio[2] = bio[1] / bio[6];                                           // cpp:3534
     for (int b = 0; b < 19; ++b) out[N * b] = bio[b];
@@ -1336,11 +1157,11 @@ void launch_selftest_math(int kind, const double* x, const double* y, double* ou
 // file's missval).  32 x 32 tiles through LDS so that both the fp64 loads (along rows) and the int32
 // stores (along cols) are coalesced; 12 B of HBM traffic per element.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pack_transpose(const double* __restrict__ src, int64_t rows, int64_t cols,
+__global__ __launch_bounds__(256) void k_pack_transpose(RingView src, int64_t step0, int64_t rows, int64_t cols,
                                                         double scale, int32_t* __restrict__ dst) {
     __shared__ int32_t tile[32][33];
     const int64_t N = rows * cols;
-    const double* in = src + (int64_t)blockIdx.z * N;
+    const int64_t step = step0 + blockIdx.z;
     int32_t* out = dst + (int64_t)blockIdx.z * N;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
     const int64_t r0 = (int64_t)blockIdx.x * 32, c0 = (int64_t)blockIdx.y * 32;
@@ -1349,7 +1170,7 @@ __global__ __launch_bounds__(256) void k_pack_transpose(const double* __restrict
         const int64_t r = r0 + tx, c = c0 + j;
         int32_t v = INT32_MIN;
         if (r < rows && c < cols) {
-            const double x = rint(in[r + rows * c] * scale);
+            const double x = rint(src.at(r + rows * c, step) * scale);
             if (x > -2147483648.0 && x < 2147483648.0) v = (int32_t)x;   // NaN and out-of-range -> NA_integer_
         }
         tile[j][tx] = v;
@@ -1372,7 +1193,6 @@ __global__ __launch_bounds__(256) void k_pack_nc(PackNcArgs a) {
     __shared__ int32_t tile[32][33];
     const int step = blockIdx.z / a.nv, v = blockIdx.z - step * a.nv;
     const int64_t N = a.rows * a.cols;
-    const double* in = a.src[v] + (int64_t)step * N;
     int32_t* out = a.dst + (int64_t)step * a.rec_words + 2 + (int64_t)v * N;
     const double scale = a.scale[v];
     const bool fill = a.fill_only[v] != 0;
@@ -1383,7 +1203,7 @@ __global__ __launch_bounds__(256) void k_pack_nc(PackNcArgs a) {
         const int64_t r = r0 + tx, c = c0 + j;
         int32_t q = a.missval;
         if (!fill && r < a.rows && c < a.cols) {
-            const double x = rint(in[r + a.rows * c] * scale);
+            const double x = rint(a.src[v].at(r + a.rows * c, a.step0 + step) * scale);
             if (x > -2147483648.0 && x < 2147483648.0) q = (int32_t)x;
         }
         tile[j][tx] = (int32_t)__builtin_bswap32((uint32_t)q);
@@ -1404,11 +1224,19 @@ void launch_pack_nc(const PackNcArgs& a, int64_t nsteps, hipStream_t s) {
     dim3 grid((unsigned)((a.rows + 31) / 32), (unsigned)((a.cols + 31) / 32), (unsigned)(nsteps * a.nv));
     hipLaunchKernelGGL(k_pack_nc, grid, dim3(256), 0, s, a);
 }
-void launch_pack_transpose(const double* src, int64_t rows, int64_t cols, int64_t nsteps, double scale, int32_t* dst,
-                           hipStream_t s) {
+void launch_pack_transpose(const RingView& src, int64_t step0, int64_t rows, int64_t cols, int64_t nsteps, double scale,
+                           int32_t* dst, hipStream_t s) {
     if (nsteps <= 0) return;
     dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32), (unsigned)nsteps);
-    hipLaunchKernelGGL(k_pack_transpose, grid, dim3(256), 0, s, src, rows, cols, scale, dst);
+    hipLaunchKernelGGL(k_pack_transpose, grid, dim3(256), 0, s, src, step0, rows, cols, scale, dst);
+}
+void launch_untile(const RingView& src, int64_t step0, int64_t nsteps, double* dst, hipStream_t s) {
+    if (nsteps <= 0 || src.N <= 0) return;
+    for (int64_t k0 = 0; k0 < nsteps; k0 += 65535) {      // gridDim.y limit
+        const int64_t n = std::min<int64_t>(65535, nsteps - k0);
+        dim3 grid((unsigned)((src.N + 255) / 256), (unsigned)n);
+        hipLaunchKernelGGL(k_untile, grid, dim3(256), 0, s, src, step0 + k0, dst + src.N * k0);
+    }
 }
 void launch_mxtc_coarse(const double* force, int64_t stride, int crows, int ccols, int tsteps, const double* rowpos,
                         const double* colpos, int64_t rows, int64_t N, int altcorrect, const double* elevd,
@@ -1416,11 +1244,11 @@ void launch_mxtc_coarse(const double* force, int64_t stride, int crows, int ccol
     hipLaunchKernelGGL(k_mxtc_coarse, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, force, stride, crows, ccols, tsteps,
                        rowpos, colpos, rows, N, altcorrect, elevd, pkfac, mx);
 }
-void launch_gather_cells(const double* src, int64_t N, int64_t nsteps, const int64_t* cells, int64_t ncells, double* dst,
+void launch_gather_cells(const RingView& src, int64_t step0, int64_t nsteps, const int64_t* cells, int64_t ncells, double* dst,
                          hipStream_t s) {
     const int64_t n = ncells * nsteps;
     if (n <= 0) return;
-    hipLaunchKernelGGL(k_gather_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, N, nsteps, cells, ncells, dst);
+    hipLaunchKernelGGL(k_gather_cells, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, step0, nsteps, cells, ncells, dst);
 }
 void launch_fill(double* p, int64_t n, double v, hipStream_t s) {
     if (n <= 0) return;
@@ -1450,48 +1278,30 @@ void launch_belowground(const BelowArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_belowground, dim3((unsigned)((a.N + 63) / 64)), dim3(64), 0, s, a);
 }
 
-static dim3 solve_grid(int64_t ntiles) {
-#if MCF_XCD_REMAP
-    return dim3((unsigned)(8 * ((ntiles + 7) / 8)));
-#else
-    return dim3((unsigned)ntiles);
-#endif
-}
+static dim3 solve_grid(int64_t ntiles) { return dim3((unsigned)(8 * ((ntiles + 7) / 8))); }     // tile_position()
 template <int CPB>
-static void launch_solve_cpb(SolveArgs a, bool af, bool bg, bool fast, bool ss, bool persistent, hipStream_t s) {
+static void launch_solve_cpb(SolveArgs a, bool af, bool bg, bool fast, bool ss, hipStream_t s) {
     if (a.ntiles_launch <= 0) {                      // no list: every tile of the raster
         a.ntiles_launch = (a.N + CPB - 1) / CPB;
         a.tile_list = nullptr;
     }
     const dim3 grid = solve_grid(a.ntiles_launch), block(solve_threads(CPB));
-    ss = ss && MCF_SOIL_SHARE && 2 * CPB <= 64;
-    // persistent tiles (the main configuration only: 21-cell tiles, fast clamps, shared soil state, static vegetation):
-    // enough tiles per workgroup to amortise the cold start, enough workgroups to keep every CU busy to the end
-    constexpr bool kPtBuilt = CPB == 21 && MCF_PERSISTENT_TILES;
-    const bool pt = kPtBuilt && persistent && !af && !bg && fast && MCF_FAST_CLAMPS && ss && a.daylayer == nullptr && a.ndays >= 3;
-    if (pt) {
-        // at least ~24 rounds of workgroups over the chip's 512 resident slots: a workgroup that runs K tiles is K times
-        // as long, and the last, partly filled round costs a whole one (measured: K = 12 on 8 rounds lost 12 %)
-        a.tiles_per_wg = (int32_t)std::min<int64_t>(16, std::max<int64_t>(1, a.ntiles_launch / (512 * 24)));
-        const int64_t per_xcd = (a.ntiles_launch + 7) / 8;
-        const dim3 gridp((unsigned)(8 * ((per_xcd + a.tiles_per_wg - 1) / a.tiles_per_wg)));
-        hipLaunchKernelGGL((k_solve<CPB, 0, false, true, true, kPtBuilt>), gridp, block, 0, s, a);
-        hipLaunchKernelGGL((k_solve_fix<CPB, 0>), dim3(512), block, 0, s, a);
-    } else if (af) {
-        if (bg) hipLaunchKernelGGL((k_solve<CPB, 1, true, false, false, false>), grid, block, 0, s, a);
-        else if (fast && MCF_FAST_CLAMPS) {
-            hipLaunchKernelGGL((k_solve<CPB, 1, false, true, false, false>), grid, block, 0, s, a);
+    ss = ss && 2 * CPB <= 64;
+    if (af) {
+        if (bg) hipLaunchKernelGGL((k_solve<CPB, 1, true, false, false>), grid, block, 0, s, a);
+        else if (fast) {
+            hipLaunchKernelGGL((k_solve<CPB, 1, false, true, false>), grid, block, 0, s, a);
             hipLaunchKernelGGL((k_solve_fix<CPB, 1>), dim3(512), block, 0, s, a);
-        } else hipLaunchKernelGGL((k_solve<CPB, 1, false, false, false, false>), grid, block, 0, s, a);
+        } else hipLaunchKernelGGL((k_solve<CPB, 1, false, false, false>), grid, block, 0, s, a);
     } else if (bg) {
-        hipLaunchKernelGGL((k_solve<CPB, 0, true, false, false, false>), grid, block, 0, s, a);
-    } else if (fast && MCF_FAST_CLAMPS) {
-        if (ss) hipLaunchKernelGGL((k_solve<CPB, 0, false, true, true, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_solve<CPB, 0, false, true, false, false>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((k_solve<CPB, 0, true, false, false>), grid, block, 0, s, a);
+    } else if (fast) {
+        if (ss) hipLaunchKernelGGL((k_solve<CPB, 0, false, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_solve<CPB, 0, false, true, false>), grid, block, 0, s, a);
         hipLaunchKernelGGL((k_solve_fix<CPB, 0>), dim3(512), block, 0, s, a);
     } else {
-        if (ss) hipLaunchKernelGGL((k_solve<CPB, 0, false, false, true, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((k_solve<CPB, 0, false, false, false, false>), grid, block, 0, s, a);
+        if (ss) hipLaunchKernelGGL((k_solve<CPB, 0, false, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_solve<CPB, 0, false, false, false>), grid, block, 0, s, a);
     }
 }
 void launch_tile_regular(const double* cellc, int64_t N, int layers, int cpb, uint8_t* out, hipStream_t s) {
@@ -1507,11 +1317,11 @@ static void launch_solve_coarse(SolveArgs a, bool bg, bool fast, hipStream_t s) 
         a.tile_list = nullptr;
     }
     const dim3 grid = solve_grid(a.ntiles_launch), block(solve_threads(CPB));
-    if (bg) hipLaunchKernelGGL((k_solve<CPB, 2, true, false, false, false>), grid, block, 0, s, a);
-    else if (fast && MCF_FAST_CLAMPS) {
-        hipLaunchKernelGGL((k_solve<CPB, 2, false, true, false, false>), grid, block, 0, s, a);
+    if (bg) hipLaunchKernelGGL((k_solve<CPB, 2, true, false, false>), grid, block, 0, s, a);
+    else if (fast) {
+        hipLaunchKernelGGL((k_solve<CPB, 2, false, true, false>), grid, block, 0, s, a);
         hipLaunchKernelGGL((k_solve_fix<CPB, 2>), dim3(512), block, 0, s, a);
-    } else hipLaunchKernelGGL((k_solve<CPB, 2, false, false, false, false>), grid, block, 0, s, a);
+    } else hipLaunchKernelGGL((k_solve<CPB, 2, false, false, false>), grid, block, 0, s, a);
 }
 int twi_scratch_doubles() { return 2 + 2 * kTwiParts; }
 int cell_field_count() { return CF_COUNT; }
@@ -1525,14 +1335,13 @@ double hf_pow02(double rs) {
     return pow(fabs(Hf), 0.2);
 }
 
-void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, bool fast, bool soil_daily, bool persistent,
-                  hipStream_t s) {
+void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, bool fast, bool soil_daily, hipStream_t s) {
     if (a.N <= 0 || a.ndays <= 0) return;
     if (a.crows > 0) { launch_solve_coarse(a, bg, fast, s); return; }
-    if (cells_per_block == 32) launch_solve_cpb<32>(a, af, bg, fast, soil_daily, persistent, s);
-    else if (cells_per_block == 21) launch_solve_cpb<21>(a, af, bg, fast, soil_daily, persistent, s);
-    else if (cells_per_block == 42) launch_solve_cpb<42>(a, af, bg, fast, soil_daily, persistent, s);
-    else launch_solve_cpb<16>(a, af, bg, fast, soil_daily, persistent, s);
+    if (cells_per_block == 32) launch_solve_cpb<32>(a, af, bg, fast, soil_daily, s);
+    else if (cells_per_block == 21) launch_solve_cpb<21>(a, af, bg, fast, soil_daily, s);
+    else if (cells_per_block == 42) launch_solve_cpb<42>(a, af, bg, fast, soil_daily, s);
+    else launch_solve_cpb<16>(a, af, bg, fast, soil_daily, s);
 }
 int soil_daily_bit() { return kSoilDaily; }
 #if MCF_EXPERIMENT_SKIPSTATS

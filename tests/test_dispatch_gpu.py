@@ -167,3 +167,66 @@ def test_coinciding_lagrangian_resistances_are_redone_with_the_reference_form(or
     assert np.isnan(want["Tz"][:, :, 30]).sum() > 60 and np.isfinite(want["Tz"][:, :, 31]).all()
     assert st["irregular_days"] == 0 and st["fast_launches"] == 1 and st["canary_trips"] >= 1, st
     _same(got, want)
+
+
+# ---- round 3 ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cpb", [16, 21, 42])
+def test_coarse_forcing_solves_every_cell_whatever_cells_per_block_was_asked_for(oracle, cpb):
+    """Coarse array forcing is built for 32-cell tiles only; a plan asked for another tile size used to launch
+    ceil(N / cpb) 32-cell tiles — a quarter of the raster never solved.  The plan now forces 32: tile classes, tile lists,
+    the ring's blocks and the kernel agree, with an irregular cell (slow list) in the raster."""
+    a, rp, cp = synthetic.coarse_workload(45, 11, 48, 3, 4, reqhgt=0.05)
+    a["soilc"]["twi"][3, 0] = np.nan           # one irregular tile
+    with Plan(**a, ring_days=2, ring_slots=1, cells_per_block=cpb, coarse={"rowpos": rp, "colpos": cp}) as p:
+        p.run_days(0, 2, 0)
+        p.sync()
+        got = {k: p.fetch(0, k, 0, 48) for k in NAMES}
+        st = p.dispatch_stats()
+        lay = p.ring_layout()
+    assert lay["cells_per_tile"] == 32 and lay["block_doubles"] == 768, lay
+    assert st["fast_tiles"] + st["slow_tiles"] == -(-45 * 11 // 32) and st["slow_tiles"] == 1, st
+    from oracle import coarse_oracle as CO
+    clim, pm = CO.expand(a["climdata"], a["pointm"], rp, cp)
+    b = dict(a)
+    b.update(climdata=clim, pointm=pm)
+    _same(got, oracle.run_grid(**b, array_forcing=True))
+
+
+def test_a_tile_whose_waves_all_trip_is_pushed_once(oracle):
+    """Every cell of one tile makes a NaN inside a regular cell (negative soil conductivity): all eight waves of the tile's
+    workgroup trip, the tile is listed ONCE (canary_trips counts tiles per launch, not waves)."""
+    a = synthetic.workload(21, 4, 48, reqhgt=0.05, start_doy=170)
+    a["soilc"]["Vq"][:, 1] = 1.6               # tile 1, all 21 cells
+    got, st = _solve(a, 2)
+    assert st["slow_tiles"] == 0 and st["canary_trips"] == 1, st
+    _same(got, oracle.run_grid(**a))
+
+
+def test_more_tripped_tiles_than_the_fix_list_holds_redoes_the_raster(oracle):
+    """fix_cap = 8192 entries; 8400 tripped tiles overflow it and k_solve_fix redoes every tile of the launch."""
+    rows, cols = 21 * 8400 // 16, 16
+    a = synthetic.workload(rows, cols, 24, reqhgt=0.05, start_doy=170)
+    a["soilc"]["Vq"][:, :] = 1.6
+    a["soilc"]["Vq"][:21, 0] = a["soilc"]["Vq"][0, 0] * 0 + 0.3        # tile 0 stays clean
+    got, st = _solve(a, 1)
+    assert st["canary_trips"] == 8400 - 1, st
+    # a sample of cells against the oracle (the whole raster is 176 400 cells)
+    sub = dict(a)
+    pick = np.r_[0:42, 5000:5042, rows * cols - 42:rows * cols]
+    def take(m):
+        m = np.asarray(m)
+        flat = m.reshape((rows * cols,) + m.shape[2:], order="F")[pick]
+        return np.asfortranarray(flat.reshape((pick.size, 1) + m.shape[2:]))
+    sub["vegp"] = {k: take(v) for k, v in a["vegp"].items()}
+    sub["soilc"] = {k: take(v) for k, v in a["soilc"].items()}
+    import ctypes as C
+    lib = oracle.load()
+    lib.orc_set_twi_mean_override.argtypes = [C.c_double, C.c_int]
+    tw = a["soilc"]["twi"]
+    lib.orc_set_twi_mean_override(float(np.mean(np.log(tw) / a["tfact"])), 1)
+    try:
+        want = oracle.run_grid(**sub)
+    finally:
+        lib.orc_set_twi_mean_override(0.0, 0)
+    sample = {k: np.asfortranarray(v.reshape(rows * cols, 24, order="F")[pick].reshape(pick.size, 1, 24)) for k, v in got.items()}
+    _same(sample, want)
