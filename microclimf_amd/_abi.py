@@ -269,10 +269,14 @@ def load() -> C.CDLL:
                                           C.POINTER(C.c_float)]
     lib.mcf_plan_slot_ptr.restype = C.c_int
     lib.mcf_plan_slot_ptr.argtypes = [P, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
-    lib.mcf_plan_ring_layout.restype = C.c_int
-    lib.mcf_plan_ring_layout.argtypes = [P, C.POINTER(RingLayout)]
-    lib.mcf_ring_index.restype = C.c_int64
-    lib.mcf_ring_index.argtypes = [C.POINTER(RingLayout), C.c_int64, C.c_int64]
+    try:
+        lib.mcf_plan_ring_layout.restype = C.c_int
+        lib.mcf_plan_ring_layout.argtypes = [P, C.POINTER(RingLayout)]
+        lib.mcf_ring_index.restype = C.c_int64
+        lib.mcf_ring_index.argtypes = [C.POINTER(RingLayout), C.c_int64, C.c_int64]
+    except AttributeError:
+        if "MCF_LIB" not in os.environ:     # an older library named for a same-box A/B run (tools/ab_bench2.sh) may lack them
+            raise
     lib.mcf_plan_timer_start.restype = C.c_int
     lib.mcf_plan_timer_start.argtypes = [P]
     lib.mcf_plan_timer_stop.restype = C.c_int

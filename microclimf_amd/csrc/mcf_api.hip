@@ -253,7 +253,8 @@ int ensure_cells(mcf_plan* p) {
     a.tfact = p->opt.tfact;
     a.twi_mean = p->twi_mean;
     a.g = p->g;
-    a.cellc = p->d_cellc + (int64_t)l * mcf::cell_field_count() * p->N;
+    a.cpb = p->cpb;
+    a.cellc = p->d_cellc + (int64_t)l * p->ntiles * mcf::tile_image_doubles(p->cpb);
     mcf::launch_cell_setup(a, p->stream);
     HIP_TRY(hipGetLastError());
   }
@@ -395,7 +396,7 @@ int mcf_device_count(void) {
 }
 
 void mcf_plan_destroy(mcf_plan* p) {
-    if (p) mcf::print_skipstats();
+    if (p) mcf::print_variant_stats();
     if (!p) return;
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
@@ -547,8 +548,13 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
     p->twi_count = (int64_t)h2[1];
     p->twi_mean = h2[0] / h2[1];
 
-    if ((rc = dalloc(p, &tmp, (int64_t)p->layers * mcf::cell_field_count() * N * 8))) return rc;
+    // per-cell constants, tile-major (mcf_kernels.h CellSetupArgs); zeroed once: the cells past the raster's end in the last
+    // tile's image are read (not used) by the solver
+    p->ntiles = (N + p->cpb - 1) / p->cpb;
+    const int64_t cellc_bytes = (int64_t)p->layers * p->ntiles * mcf::tile_image_doubles(p->cpb) * 8;
+    if ((rc = dalloc(p, &tmp, cellc_bytes))) return rc;
     p->d_cellc = (double*)tmp;
+    HIP_TRY(hipMemsetAsync(p->d_cellc, 0, (size_t)cellc_bytes, p->stream));
     if (p->layers > 1) {
         // day -> layer map from dfsel (cpp:2629-2640, k = dy*24 + hr + st[lyr]); -1 = not covered
         std::vector<int32_t> dl((size_t)std::max(p->ndays, 1), -1);
@@ -778,7 +784,7 @@ int mcf_plan_run_days(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot) {
     if (rc) return rc;
     mcf::SolveArgs a{};
     a.N = p->N;
-    a.cellc = p->d_cellc; a.hor = p->d_hor; a.wsa = p->d_wsa; a.tt = p->d_tt;
+    a.cellc = p->d_cellc; a.ntiles_total = p->ntiles; a.tt = p->d_tt;
     a.daylayer = p->d_daylayer;
     const int64_t cap = p->N * (int64_t)p->ring_days * 24;
     if (p->af && p->coarse) {

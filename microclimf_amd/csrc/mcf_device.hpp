@@ -957,12 +957,6 @@ __device__ __forceinline__ void pin(A&... a) {
 #ifndef MCF_SKIP_MINCOND
 #define MCF_SKIP_MINCOND 1   // see pass2's leaf block: mincondCpp's floors skipped when they provably cannot bind
 #endif
-#ifndef MCF_EXPERIMENT_SKIPSTATS
-#define MCF_EXPERIMENT_SKIPSTATS 0
-#endif
-#if MCF_EXPERIMENT_SKIPSTATS
-__device__ unsigned long long g_skipstats[4];
-#endif
 #ifndef MCF_CANARY_ALL
 #define MCF_CANARY_ALL 0
 #endif
@@ -1488,17 +1482,6 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
             const double tq = gh * (1.0 / 0.0463), tq2 = tq * tq;
             const bool clear = gh >= 0.0500001 && tq2 * tq2 * tq >= (fabs(RnetL) * invleafd) * 1.000001;
             floors_idle = __builtin_amdgcn_ballot_w64(!clear) == 0;
-#if MCF_EXPERIMENT_SKIPSTATS
-            {   // how often the bound clears: waves, waves with every lane clear, lanes, lanes clear (debug build only)
-                const uint64_t act = __builtin_amdgcn_ballot_w64(true), bad = __builtin_amdgcn_ballot_w64(!clear);
-                if ((threadIdx.x & 63) == (unsigned)__builtin_ctzll(act)) {
-                    atomicAdd(&g_skipstats[0], 1ull);
-                    atomicAdd(&g_skipstats[1], bad == 0 ? 1ull : 0ull);
-                    atomicAdd(&g_skipstats[2], (unsigned long long)__builtin_popcountll(act));
-                    atomicAdd(&g_skipstats[3], (unsigned long long)__builtin_popcountll(act & ~bad));
-                }
-            }
-#endif
         }
 #endif
         double a02 = 0.0;

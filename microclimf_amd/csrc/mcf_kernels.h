@@ -60,8 +60,14 @@ struct CellSetupArgs {
     double lat, lon;
     double tfact, twi_mean;
     Globals g;
-    double* cellc;  // [CF_COUNT][N]
+    // The per-cell constant table is TILE-MAJOR: one image per (layer, tile of cpb cells), [CF_COUNT + 32 rows][cpb] doubles
+    // (the 24 horizon and 8 wind-shelter values follow the CF_ rows), images tile_image_doubles(cpb) apart — what the solver
+    // copies into LDS is one contiguous, line-aligned run (one page) instead of 122 row segments 8 B x N apart.
+    double* cellc;      // this layer's images
+    int32_t cpb;
 };
+// doubles between consecutive tile images: (cell fields + 32 direction rows) x cpb, rounded up to whole 128-byte lines
+int64_t tile_image_doubles(int cpb);
 
 struct TimeSetupArgs {
     int nsteps;
@@ -84,10 +90,9 @@ struct DateSetupArgs {
 
 struct SolveArgs {
     int64_t N;
-    const double* cellc;  // [layers][CF_COUNT][N]
+    const double* cellc;  // [layers][ntiles][tile image], see CellSetupArgs
+    int64_t ntiles_total; // tiles of the raster = images per layer
     const int32_t* daylayer;  // [ndays] vegetation layer of each day, -1: no layer covers it; null: layer 0
-    const double* hor;    // [24][N]
-    const double* wsa;    // [8][N]
     const double* tt;     // vector forcing: [ndays][TF_COUNT][24]
     // array forcing
     const double* af_base;  // forcing slabs [15][N][steps in buffer], TF_TC .. TF_DTRP order
@@ -193,7 +198,7 @@ void launch_belowground(const BelowArgs& a, hipStream_t s);
 void launch_selftest_math(int kind, const double* x, const double* y, double* out, int64_t n, hipStream_t s);
 
 int cell_field_count();
-void print_skipstats();     // MCF_EXPERIMENT_SKIPSTATS builds: how often pass 2's mincond bound clears
+void print_variant_stats();  // hook for the timing variants under tools/variants/ (empty in the shipped library)
 int soil_daily_bit();        // kSoilDaily, likewise
 int step_irregular_bit();   // kStepIrregular of the packed TF_IDX value (last time field)
 int time_field_count();

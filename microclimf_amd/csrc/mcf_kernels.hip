@@ -149,15 +149,21 @@ __device__ constexpr int field_reader_class(int f) {
     }
 }
 
+__host__ __device__ constexpr int64_t tile_image_doubles_dev(int cpb) { return (((int64_t)(CF_COUNT + kCellDirs) * cpb + 15) / 16) * 16; }
+int64_t tile_image_doubles(int cpb) { return tile_image_doubles_dev(cpb); }
+
 __global__ __launch_bounds__(256) void k_cell_setup(CellSetupArgs a) {
     int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.N) return;
     const int64_t N = a.N;
-    double* out = a.cellc;
+    // the cell's column of its tile's image (CellSetupArgs)
+    const int cpb = a.cpb;
+    const int64_t tile = c / cpb;
+    double* out = a.cellc + tile * tile_image_doubles_dev(cpb) + (c - tile * cpb);
     // FL_REGULAR (mcf_device.hpp): every constant the cell's path reads is finite (field_reader_class above)
     bool fin[4] = {true, true, true, true};     // by field_reader_class
     auto put = [&](int f, double v) {
-        out[(int64_t)f * N + c] = v;
+        out[f * cpb] = v;
         if (!isfinite(v)) fin[field_reader_class(f)] = false;
     };
     const double hgt = a.hgt[c], pai = a.pai[c], x = a.x[c], lref = a.leafr[c], ltra = a.leaft[c],
@@ -350,8 +356,8 @@ __global__ __launch_bounds__(256) void k_cell_setup(CellSetupArgs a) {
     }
     {
         bool dirs_ok = true;                        // horizons finite; a NaN wind-shelter value is the reference's "1" (cpp:1193)
-        for (int d = 0; d < 24; ++d) dirs_ok = dirs_ok && isfinite(a.hor[(int64_t)d * N + c]);
-        for (int d = 0; d < 8; ++d) dirs_ok = dirs_ok && !isinf(a.wsa[(int64_t)d * N + c]);
+        for (int d = 0; d < 24; ++d) { const double v = a.hor[(int64_t)d * N + c]; out[(CF_COUNT + d) * cpb] = v; dirs_ok = dirs_ok && isfinite(v); }
+        for (int d = 0; d < 8; ++d) { const double v = a.wsa[(int64_t)d * N + c]; out[(CF_COUNT + 24 + d) * cpb] = v; dirs_ok = dirs_ok && !isinf(v); }
         const bool bare = pai == 0.0 && hgt == 0.0;
         const bool veg = pai > 0.0 && hgt > 0.0 && clump >= 0.0 && clump < 1.0 && a.leafd[c] > 0.0 && isfinite(x) && x > 0.0;
         // soil moisture stays positive (Smin >= 0, Smax > Smin), which keeps the matric potential's log and pow real
@@ -466,10 +472,10 @@ template <int CPB, int AF, bool BG, bool F, bool SSREQ>
 __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t tile, const int day0, const int ndays, const int rot) {
     constexpr int NT = solve_threads(CPB);
     static_assert(NT == RING_BLOCK(CPB), "tile-day block = one value per lane");
-    // the tile's LDS image: [CF_COUNT cell fields + 24 horizon + 8 wind-shelter rows][CPB]
-    __shared__ __attribute__((aligned(256))) double s_tile[(CF_COUNT + kCellDirs) * CPB];
+    // the tile's LDS image: [CF_COUNT cell fields + 24 horizon + 8 wind-shelter rows][CPB], as it lies in the table
+    constexpr int IMG = (int)tile_image_doubles_dev(CPB);
+    __shared__ __attribute__((aligned(256))) double s_tile[IMG];
     double* const s_cell = s_tile;
-    double* const s_dirs = s_tile + CF_COUNT * CPB;
     __shared__ double s_time[AF ? 1 : 3 * TF_COUNT * 24];
     // day-reduction staging: per (hour, cell) values, or — 21-cell tiles — per (wave, cell) partial extremes
     constexpr bool PRE = CPB == 21;
@@ -524,24 +530,15 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
     // ---- stage the tile's direction tables, the first day's time table and the first day's cell constants in LDS: all
     // global loads of the prologue are in flight together (one HBM latency per workgroup instead of three; the fixed cost
     // of a workgroup is ~7 us, 9 % of a 7-day launch)
-    for (int q = tid; q < kCellDirs * CPB; q += NT) {
-        int dI = q / CPB, l = q % CPB;
-        int64_t cc = c0 + l;
-        double v = 0.0;
-        if (cc < N) v = dI < 24 ? a.hor[(int64_t)dI * N + cc] : a.wsa[(int64_t)(dI - 24) * N + cc];
-        s_dirs[q] = v;
-    }
     if (!AF) {
         const double* src = a.tt + (int64_t)day0 * TF_COUNT * 24;
         for (int q = tid; q < TF_COUNT * 24; q += NT) s_time[q] = src[q];
     }
+    // one contiguous, line-aligned image per (layer, tile): 16 bytes per lane and load, no index arithmetic
     auto stage_cells = [&](int layer) {
-        const double* src = a.cellc + (int64_t)layer * CF_COUNT * N;
-        for (int q = tid; q < CF_COUNT * CPB; q += NT) {
-            int f = q / CPB, l = q % CPB;
-            int64_t cc = c0 + l;
-            s_cell[q] = cc < N ? src[(int64_t)f * N + cc] : 0.0;
-        }
+        const double2* src = reinterpret_cast<const double2*>(a.cellc + ((int64_t)layer * a.ntiles_total + tile) * IMG);
+        double2* dst = reinterpret_cast<double2*>(s_tile);
+        for (int q = tid; q < IMG / 2; q += NT) dst[q] = src[q];
     };
     const CellLds<CPB> C{s_cell + cl};
     int flags = 0;
@@ -895,9 +892,9 @@ __global__ void k_tile_regular(const double* __restrict__ cellc, int64_t N, int 
     if (t >= ntiles) return;
     bool ok = true;
     for (int l = 0; l < layers; ++l) {
-        const double* fl = cellc + ((int64_t)l * CF_COUNT + CF_FLAGS) * N;
+        const double* fl = cellc + ((int64_t)l * ntiles + t) * tile_image_doubles_dev(cpb) + CF_FLAGS * cpb;
         for (int64_t c = t * cpb; c < (t + 1) * cpb && c < N; ++c) {
-            const int f = (int)fl[c];
+            const int f = (int)fl[c - t * cpb];
             if ((f & FL_VALID) && !(f & FL_REGULAR)) ok = false;
         }
     }
@@ -1344,15 +1341,7 @@ void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, boo
     else launch_solve_cpb<16>(a, af, bg, fast, soil_daily, s);
 }
 int soil_daily_bit() { return kSoilDaily; }
-#if MCF_EXPERIMENT_SKIPSTATS
-void print_skipstats() {
-    unsigned long long h[4] = {0, 0, 0, 0};
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_skipstats), sizeof h);
-    fprintf(stderr, "[mcf] mincond bound: %llu waves, %llu all-clear (%.1f %%); %llu lanes, %llu clear (%.2f %%)\n", h[0], h[1],
-            100.0 * h[1] / (h[0] ? h[0] : 1), h[2], h[3], 100.0 * h[3] / (h[2] ? h[2] : 1));
-}
-#else
-void print_skipstats() {}
-#endif
+// timing variants (tools/variants/*.patch) report through this hook at plan destruction; the shipped library has nothing to say
+void print_variant_stats() {}
 
 }  // namespace mcf
