@@ -442,6 +442,11 @@ struct MathK {
         ltab = lds;
         logtab = true;
     }
+    // tables already in LDS (k_solve fills them with its other prologue loads)
+    __device__ __forceinline__ void tables(const double* exp_lds, const double* log_lds) {
+        tab = exp_lds; table = true;
+        ltab = log_lds; logtab = true;
+    }
     // vconst: c5 / c11, lg6, lg7 held in VGPRs as well (an instruction reads one scalar operand, so a second constant costs
     // two moves wherever it is used) — not in the array-forcing kernels, which have no register to spare
     __device__ __forceinline__ void pin(bool with_log, bool vconst = true) {

@@ -527,16 +527,15 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
     const int64_t c = c0 + cl;
     const bool in_grid = lane_on && c < N;   // the other lanes only help staging, keep the barriers and write the padding
 
-    // ---- stage the tile's direction tables, the first day's time table and the first day's cell constants in LDS: all
-    // global loads of the prologue are in flight together (one HBM latency per workgroup instead of three; the fixed cost
-    // of a workgroup is ~7 us, 9 % of a 7-day launch)
-    if (!AF) {
-        const double* src = a.tt + (int64_t)day0 * TF_COUNT * 24;
-        for (int q = tid; q < TF_COUNT * 24; q += NT) s_time[q] = src[q];
-    }
-    // one contiguous, line-aligned image per (layer, tile): 16 bytes per lane and load, no index arithmetic
+    // ---- stage the tile's image (one contiguous, line-aligned run per (layer, tile): 16 bytes per lane and load, no index
+    // arithmetic), the first day's time table and the exp / log tables in LDS.  ALL global loads of the prologue are issued
+    // before the first one is waited for: written as plain copy loops, hipcc made load -> s_waitcnt vmcnt(0) -> ds_write of
+    // every iteration — eight dependent trips through a memory system busy with this kernel's own stores, 13 700 cycles
+    // (5.7 us, nearly a whole day of the workgroup's eight wave slots) from entry to the first barrier.
+    auto image_of = [&](int layer) { return reinterpret_cast<const double2*>(a.cellc + ((int64_t)layer * a.ntiles_total + tile) * IMG); };
+    // (a change of vegetation layer inside the launch restages the image with this plain loop: rare)
     auto stage_cells = [&](int layer) {
-        const double2* src = reinterpret_cast<const double2*>(a.cellc + ((int64_t)layer * a.ntiles_total + tile) * IMG);
+        const double2* src = image_of(layer);
         double2* dst = reinterpret_cast<double2*>(s_tile);
         for (int q = tid; q < IMG / 2; q += NT) dst[q] = src[q];
     };
@@ -545,7 +544,37 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
     bool valid = false;
     // vegetation layer of a day (runmicro3Cpp/4Cpp `dfsel`, cpp:2760-2768)
     int cur_layer = a.daylayer ? a.daylayer[day0] : 0;
-    if (cur_layer >= 0) stage_cells(cur_layer);
+    __shared__ double s_exptab[256];
+    __shared__ __attribute__((aligned(16))) double s_logtab[512];
+    {
+        constexpr int NIMG = (IMG / 2 + NT - 1) / NT, NTT = AF ? 0 : (TF_COUNT * 24 + NT - 1) / NT, NLOG = (512 + NT - 1) / NT;
+        double2 im[NIMG];
+        double tt0[NTT ? NTT : 1], lg[NLOG];
+        const double2* isrc = image_of(cur_layer >= 0 ? cur_layer : 0);
+        const double* tsrc = a.tt + (int64_t)day0 * TF_COUNT * 24;
+        // clamped indices instead of predicates: every lane loads, nothing is written into the loads' registers first
+#pragma unroll
+        for (int i = 0; i < NIMG; ++i) { const int q = tid + i * NT; im[i] = isrc[q < IMG / 2 ? q : IMG / 2 - 1]; }
+#pragma unroll
+        for (int i = 0; i < NTT; ++i) { const int q = tid + i * NT; tt0[i] = tsrc[q < TF_COUNT * 24 ? q : TF_COUNT * 24 - 1]; }
+        const double ex = kExp2Tab[tid & 255];
+#pragma unroll
+        for (int i = 0; i < NLOG; ++i) lg[i] = kLogTab[(tid + i * NT) & 511];
+        // (pinned: left alone, the compiler sinks each load into the guarded store that uses it and waits for it there)
+#pragma unroll
+        for (int i = 0; i < NIMG; ++i) pin(im[i].x, im[i].y);
+#pragma unroll
+        for (int i = 0; i < NTT; ++i) pin1(tt0[i]);
+        if (cur_layer >= 0) {
+#pragma unroll
+            for (int i = 0; i < NIMG; ++i) { const int q = tid + i * NT; if (q < IMG / 2) reinterpret_cast<double2*>(s_tile)[q] = im[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < NTT; ++i) { const int q = tid + i * NT; if (q < TF_COUNT * 24) s_time[q] = tt0[i]; }
+        if (tid < 256) s_exptab[tid] = ex;
+#pragma unroll
+        for (int i = 0; i < NLOG; ++i) { const int q = tid + i * NT; if (q < 512) s_logtab[q] = lg[i]; }
+    }
     if (F && tid == 0) s_trip = 0;
     Globals g = a.g;
     double dTmx = g.dTmx;
@@ -554,10 +583,7 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
     const bool need_tv = g.reqhgt >= 0.0 && a.need_tv != 0;
     MathK MK;
     MK.set();
-    __shared__ double s_exptab[256];
-    MK.use_table(s_exptab, tid);       // visible after the prologue's barrier
-    __shared__ __attribute__((aligned(16))) double s_logtab[512];
-    MK.use_log_table(s_logtab, tid, NT);
+    MK.tables(s_exptab, s_logtab);     // filled above, visible after the prologue's barrier
     MK.pin(true, AF == 0);   // exp and log coefficients resident in SGPRs for the whole day loop (the array-forcing kernels
                              // have no VGPR to spare for the second constants)
     const double NA = na_real();
