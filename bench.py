@@ -63,7 +63,7 @@ def parse(argv=None):
     ap.add_argument("--reqhgt", type=float, default=0.05)
     ap.add_argument("--ring-days", type=int, default=10)
     ap.add_argument("--ring-slots", type=int, default=2)
-    ap.add_argument("--ring-gb", type=float, default=250.0, help="HBM the plan may use for tables + output ring")
+    ap.add_argument("--ring-gb", type=float, default=262.0, help="HBM the plan may use for tables + output ring")
     ap.add_argument("--cells-per-block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (configs[1], array forcing, "
@@ -221,7 +221,7 @@ def fit_ring(args, cells, af):
     pad = (((cpb * 24 + 255) // 256) * 256) / (cpb * 24.0)       # the tiled ring's blocks are whole wave-rows (21 cells: 512 / 504)
     per_day = cells * 24 * 8 * (10 * pad + (15 if af else 0))
     slots, days = args.ring_slots, args.ring_days
-    budget = args.ring_gb * 1e9 - cells * 1300.0
+    budget = args.ring_gb * 1e9 - cells * 1500.0      # inputs 23 x 8 B, hor / wsa 256 B, tile-major constant table 976 B per cell
     while slots * days * per_day > budget and (slots > 1 or days > 1):
         if slots > 1 and not af:
             slots -= 1

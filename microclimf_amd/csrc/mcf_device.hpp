@@ -23,17 +23,6 @@
 
 #include "mcf_kernels.h"
 
-#ifndef MCF_EXPERIMENT_SALU
-#define MCF_EXPERIMENT_SALU 0
-#endif
-#ifndef MCF_DIV_FAST
-#define MCF_DIV_FAST 0   // 1 (experiment): 46-bit reciprocals and quotients, two instructions fewer each: 57 VALU fewer
-                         // per cell-step, +2.6 % same-box, max scaled difference to the oracle 2e-13 -> 2.9e-12.  Not
-                         // shipped: a 15x wider margin at the path's comparisons for 2.6 % is a bad trade
-#endif
-#ifndef MCF_DIV_EXACT_LAST_BIT
-#define MCF_DIV_EXACT_LAST_BIT 0   // 1: the 0.5-ulp quotient (one more FMA per division); 0: a * (1/b), 1.5 ulp
-#endif
 
 namespace mcf {
 
@@ -142,28 +131,17 @@ __device__ __forceinline__ double na_real() { return __longlong_as_double((long 
 // (checked against numpy by tests/test_math_gpu.py through mcf_selftest_math).
 // v_rcp_f64 / v_rsq_f64 deliver ~23 bits.  With e = 1 - b*r0 (|e| < 2^-23) the CUBIC step r1 = r0*(1 + e + e^2) leaves a
 // relative error of e^3 < 2^-69, i.e. a correctly rounded-to-nearest-ish reciprocal in three FMAs — one fewer than two
-// Newton steps.  (MCF_DIV_FAST = 1, experiment: a single Newton step, 46 bits.)
+// Newton steps.  (Measured and not shipped: a single Newton step, 46 bits — 57 VALU fewer per cell-step, +2.6 %, at a 15 x
+// wider margin to the oracle, 2.9e-12.)
 __device__ __forceinline__ double frcp(double b) {           // 1/b, b finite normal non-zero
     double r = __builtin_amdgcn_rcp(b);
     const double e = fma(-b, r, 1.0);
-#if MCF_DIV_FAST
-    return fma(e, r, r);
-#else
     return fma(fma(e, e, e), r, r);
-#endif
 }
 __device__ __forceinline__ double fdiv(double a, double b) {  // a/b, b finite normal non-zero
-#if MCF_DIV_EXACT_LAST_BIT
-    // one Newton step on the reciprocal (46 bits), then a Newton step on the quotient: q' = (a/b)(1 - e^2); 0.5 ulp
-    double r = __builtin_amdgcn_rcp(b);
-    r = fma(fma(-b, r, 1.0), r, r);
-    double q = a * r;
-    return fma(fma(-b, q, a), r, q);
-#else
     // a * (1/b) with the 69-bit reciprocal above: one FMA fewer; the two roundings (of 1/b and of the product) bound the
     // error by 1.5 ulp (3.3e-16), checked by tests/test_math_gpu.py
     return a * frcp(b);
-#endif
 }
 __device__ __forceinline__ double fsqrt(double x) {           // sqrt(x), x finite normal positive
     // coupled Goldschmidt step from the 23-bit v_rsq_f64 (g ~ sqrt x and h ~ 1/(2 sqrt x) to 46 bits), then ONE residual
@@ -191,19 +169,10 @@ __device__ __forceinline__ double fsqrt(double x) {           // sqrt(x), x fini
 // (MathK::pin), so that the ~25 exp and ~7 log evaluations of a cell-step share them.  Rematerialised at every
 // call (22 + 14 s_mov_b32 each) they made up ~70 % of the kernel's scalar instructions, and the scalar issue slots
 // they take from their own wave cost 9 % of the run time (measured by doubling them).
-#ifndef MCF_PIN_VCONST
-#define MCF_PIN_VCONST 2   // exp's c11 (and log's Lg6, Lg7) live in VGPR pairs for the whole day loop: the first Horner step
-                           // p = r*c11 + c10 reads TWO constants and a VOP3 can take only one from the scalar file, so the
-                           // other was re-created by two v_mov_b32 in front of (nearly) every evaluation
-#endif
-#ifndef MCF_LOG_TABLE
-#define MCF_LOG_TABLE 1   // k_solve: log through a 256-entry table of (reciprocal, -log reciprocal) in LDS: no division
-#endif
-#ifndef MCF_EXP_TABLE
-#define MCF_EXP_TABLE 1   // k_solve: exp through a 64-entry table of 2^(j/64) in LDS + a degree-5 polynomial (12 fp64
-                          // instructions + 3 integer ones instead of 17 fp64); kernels that do not set MathK::tab keep the
-                          // degree-11 polynomial
-#endif
+// k_solve routes exp and log through tables in LDS (fexp_tab, flog_tab); exp's c11 / c5 and log's Lg6, Lg7 / 1/7 live in VGPR
+// pairs for the whole day loop there: the first Horner step reads TWO constants and a VOP3 can take only one from the scalar
+// file, so the other was re-created by two v_mov_b32 in front of (nearly) every evaluation.  Kernels that do not set
+// MathK::tab keep the degree-11 polynomial.
 // 2^(j/64), j = 0 .. 63, correctly rounded (computed with 60 decimal digits)
 __device__ const double kExp2Tab[256] = {
     0x1.0000000000000p+0, 0x1.00b1afa5abcbfp+0, 0x1.0163da9fb3335p+0, 0x1.02168143b0281p+0,
@@ -410,6 +379,9 @@ struct MathK {
     double c5;      // 1/6 (VGPR resident: an instruction reads one scalar operand)
     double g[7];    // table log: (unused), -1/6, 1/5, -1/4, 1/3, ln2_lo, ln2_hi
     double g7v;     // 1/7 (VGPR resident: the first Horner step has two constants)
+    double magic;   // 1.5 * 2^52 (VGPR resident): x * 256/ln2 + magic holds round(x * 256/ln2) in its low mantissa bits
+    int sh3;        // 3 (VGPR resident): shift operand of the SDWA instruction that makes the table's byte offset
+    bool vfast = false;   // magic / sh3 are pinned (k_solve's vector-forcing kernels; the array-forcing ones have no VGPR to spare)
     const double* ltab = nullptr;  // LDS copy of kLogTab
     const double* tab = nullptr;   // LDS copy of kExp2Tab
     bool logtab = false;           // flog goes through ltab (set with use_log_table; same reason)
@@ -417,6 +389,7 @@ struct MathK {
                                    // the pointer cannot say)
     __device__ __forceinline__ void set() {
         c11 = 0x1.ade156a5dcb37p-26; lg6 = 1.531383769920937332e-01; lg7 = 1.479819860511658591e-01;
+        magic = 0x1.8p52; sh3 = 3;
         t[0] = 0x1.71547652b82fep+8; t[1] = -0x1.62e42fec00000p-9; t[2] = -0x1.d1cf79abc9e3bp-40;
         t[3] = 1.0 / 24.0; t[4] = 0.0; c5 = 1.0 / 6.0;
         g[0] = 0.0; g7v = 1.0 / 7.0; g[1] = -1.0 / 6.0; g[2] = 1.0 / 5.0; g[3] = -0.25; g[4] = 1.0 / 3.0;
@@ -453,7 +426,12 @@ struct MathK {
         if (table) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) asm volatile("" : "+s"(t[i]));
-            if (vconst) asm volatile("" : "+v"(c5));
+            if (vconst) {
+                asm volatile("" : "+v"(c5));
+                asm volatile("" : "+v"(magic));
+                asm volatile("" : "+v"(sh3));
+                vfast = true;
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < 12; ++i) asm volatile("" : "+s"(e[i]));
@@ -465,52 +443,51 @@ struct MathK {
                 else if (i > 0) asm volatile("" : "+s"(g[i]));
             if (logtab && vconst) asm volatile("" : "+v"(g7v));
         }
-#if MCF_PIN_VCONST
         if (!vconst) return;
         if (!table) asm volatile("" : "+v"(c11));
-#if MCF_PIN_VCONST > 1
         if (with_log && !logtab) { asm volatile("" : "+v"(lg6)); asm volatile("" : "+v"(lg7)); }
-#endif
-#endif
     }
 };
 // exp(x) = 2^e * 2^(j/256) * exp(r), n = round(x * 256/ln2) = 256 e + j, r = x - n ln2/256, |r| <= ln2/512: the table value
 // T comes from LDS (2 KB) while the degree-4 polynomial p = exp(r) - 1 is evaluated (r^5/120 < 3.8e-17), then T + T p and
 // ldexp.  Same saturation behaviour as the polynomial route (v_cvt_i32_f64 and v_ldexp_f64 saturate; NaN stays NaN).
-#ifndef MCF_EXPERIMENT_NOTABLE
-#define MCF_EXPERIMENT_NOTABLE 0
-#endif
-#ifndef MCF_MATH_ASM
-#define MCF_MATH_ASM 1   // 1: the table routes' arithmetic as fixed instruction sequences; 0: as C++ (experiment: scheduler freedom)
-#endif
+// BOUNDED = true: the caller guarantees |x| < 5e6 (then n = round(x * 256/ln2) fits 32 bits): n comes out of ONE fma as
+// the low mantissa bits of x * 256/ln2 + 1.5 * 2^52 — no v_rndne, no v_cvt — and as a double by one subtraction.  Two VALU
+// instructions fewer; no saturation for huge arguments, which is why the two-stream transmissions (arguments down to -inf)
+// keep the general form.  NaN stays NaN in both.
+template <bool BOUNDED>
 __device__ __forceinline__ double fexp_tab(double x, const MathK& K) {
-#if !MCF_MATH_ASM
-    {
-        const double n = __builtin_rint(x * K.t[0]);
-        double r = fma(n, K.t[1], x);
-        r = fma(n, K.t[2], r);
-        const int t = (int)n;
-        const double T = K.tab[t & 255];
-        double p = fma(r, K.t[3], K.c5);
-        p = fma(r, p, 0.5);
-        p = fma(r * r, p, r);
-        return __builtin_amdgcn_ldexp(fma(T, p, T), t >> 8);
-    }
-#endif
     double n, r, p, r2, out;
     int t;
-    asm("v_mul_f64 %0, %3, %4\n\t"
-        "v_rndne_f64 %0, %0\n\t"
-        "v_fma_f64 %1, %0, %5, %3\n\t"
-        "v_fma_f64 %1, %0, %6, %1\n\t"
-        "v_cvt_i32_f64 %2, %0"
-        : "=&v"(n), "=&v"(r), "=v"(t)
-        : "v"(x), "s"(K.t[0]), "s"(K.t[1]), "s"(K.t[2]));
-#if MCF_EXPERIMENT_NOTABLE      // timing experiment (wrong results): the table look-ups replaced by constants
-    const double T = 1.0;
-#else
-    const double T = K.tab[t & 255];
-#endif
+    if (BOUNDED && K.vfast) {
+        double y;
+        asm("v_fma_f64 %0, %3, %4, %5\n\t"       // y = x * 256/ln2 + 1.5 * 2^52: an integer in the low mantissa bits
+            "v_add_f64 %1, %0, -%5\n\t"          // n (exact)
+            "v_fma_f64 %2, %1, %6, %3\n\t"
+            "v_fma_f64 %2, %1, %7, %2"
+            : "=&v"(y), "=&v"(n), "=&v"(r)
+            : "v"(x), "s"(K.t[0]), "v"(K.magic), "s"(K.t[1]), "s"(K.t[2]));
+        t = __double2loint(y);
+    } else {
+        asm("v_mul_f64 %0, %3, %4\n\t"
+            "v_rndne_f64 %0, %0\n\t"
+            "v_fma_f64 %1, %0, %5, %3\n\t"
+            "v_fma_f64 %1, %0, %6, %1\n\t"
+            "v_cvt_i32_f64 %2, %0"
+            : "=&v"(n), "=&v"(r), "=v"(t)
+            : "v"(x), "s"(K.t[0]), "s"(K.t[1]), "s"(K.t[2]));
+    }
+    double T;
+    if (K.vfast) {
+        // byte offset of table entry t & 255 in ONE instruction (SDWA byte select + shift); its shift operand has to be a VGPR,
+        // which the compiler re-created with a v_mov in front of every exp
+        unsigned off;
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0"
+            : "=v"(off) : "v"(K.sh3), "v"(t));
+        T = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(K.tab) + off);
+    } else {
+        T = K.tab[t & 255];
+    }
     const int e = t >> 8;
     asm("v_fma_f64 %0, %2, %3, %4\n\t"        // p = r/24 + 1/6
         "v_fma_f64 %0, %2, %0, 0.5\n\t"       // p = r p + 1/2
@@ -524,21 +501,19 @@ __device__ __forceinline__ double fexp_tab(double x, const MathK& K) {
         : "v"(T), "v"(p), "v"(e));
     return out;
 }
+// exp(x) for |x| < 5e6 (see fexp_tab) where the caller can vouch for the bound — the fast-clamp instantiations (F), whose
+// operands are finite and in range by construction; the general form otherwise and where the table route is not in use
+__device__ __forceinline__ double fexp(double x, const MathK& K);
+template <bool F = true>
+__device__ __forceinline__ double fexp_b(double x, const MathK& K) {
+    if (F && K.table) return fexp_tab<true>(x, K);
+    return fexp(x, K);
+}
 __device__ __forceinline__ double fexp(double x, const MathK& K) {
-    if (MCF_EXP_TABLE && K.table) return fexp_tab(x, K);
+    if (K.table) return fexp_tab<false>(x, K);
     double n, r, p, out;
     int t;
     const double c11 = K.c11;
-#if MCF_EXPERIMENT_SALU
-    {   // timing experiment only: 22 extra scalar moves per exp (as many as its coefficients cost)
-        int dummy;
-        asm volatile("s_mov_b32 %0, 1\n\ts_mov_b32 %0, 2\n\ts_mov_b32 %0, 3\n\ts_mov_b32 %0, 4\n\ts_mov_b32 %0, 5\n\t"
-                     "s_mov_b32 %0, 6\n\ts_mov_b32 %0, 7\n\ts_mov_b32 %0, 8\n\ts_mov_b32 %0, 9\n\ts_mov_b32 %0, 10\n\t"
-                     "s_mov_b32 %0, 11\n\ts_mov_b32 %0, 12\n\ts_mov_b32 %0, 13\n\ts_mov_b32 %0, 14\n\ts_mov_b32 %0, 15\n\t"
-                     "s_mov_b32 %0, 16\n\ts_mov_b32 %0, 17\n\ts_mov_b32 %0, 18\n\ts_mov_b32 %0, 19\n\ts_mov_b32 %0, 20\n\t"
-                     "s_mov_b32 %0, 21\n\ts_mov_b32 %0, 22" : "=s"(dummy));
-    }
-#endif
     asm("v_mul_f64 %0, %5, %6\n\t"
         "v_rndne_f64 %0, %0\n\t"
         "v_fma_f64 %1, %0, %7, %5\n\t"
@@ -571,25 +546,9 @@ __device__ __forceinline__ double flog_tab(double x, const MathK& K) {
     const double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
     int e = __builtin_amdgcn_frexp_exp(x);
     const int j = (__double2hiint(m) >> 12) & 255;
-#if MCF_EXPERIMENT_NOTABLE
-    const double2 cl = make_double2(1.0 + 1e-3 * (double)j, 0.25);
-#else
     const double2 cl = *reinterpret_cast<const double2*>(K.ltab + 2 * j);
-#endif
     e -= j < kLogSplit ? 1 : 0;
     const double dk = (double)e;
-#if !MCF_MATH_ASM
-    {
-        const double r = fma(m, cl.x, -1.0);
-        double q = fma(r, K.g7v, K.g[1]);
-        q = fma(r, q, K.g[2]);
-        q = fma(r, q, K.g[3]);
-        q = fma(r, q, K.g[4]);
-        q = fma(r, q, -0.5);
-        const double p = fma(r * r, q, r);
-        return fma(dk, K.g[6], cl.y) + fma(dk, K.g[5], p);
-    }
-#endif
     double r, q, r2, out;
     asm("v_fma_f64 %0, %4, %5, -1.0\n\t"       // r = m c - 1
         "v_fma_f64 %1, %0, %7, %8\n\t"         // q = r/7 - 1/6
@@ -608,7 +567,7 @@ __device__ __forceinline__ double flog_tab(double x, const MathK& K) {
     return out;
 }
 __device__ __forceinline__ double flog(double x, const MathK& K) {
-    if (MCF_LOG_TABLE && K.logtab) return flog_tab(x, K);
+    if (K.logtab) return flog_tab(x, K);
     double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
     int e = __builtin_amdgcn_frexp_exp(x);
     const int lo = m < 0.70710678118654752440 ? 1 : 0;
@@ -646,11 +605,27 @@ __device__ __forceinline__ double powxy(double x, double y, const MathK& K) { re
 __device__ __forceinline__ double sq(double x) { return x * x; }
 __device__ __forceinline__ double pow4(double x) { double x2 = x * x; return x2 * x2; }
 
-// cpp:480-490 satvapCpp
-__device__ __forceinline__ double satvap(double tc, const MathK& K) {
-    double a = tc > 0 ? 17.27 : 21.875;
-    double b = tc > 0 ? 237.3 : 265.5;
-    return 0.61078 * fexp(fdiv(a * tc, tc + b), K);
+// cpp:480-490 satvapCpp: 0.61078 exp(a tc / (tc + b)), (a, b) = (17.27, 237.3) over water (tc > 0), (21.875, 265.5) over ice.
+// Chosen per lane the pair costs a compare, four 32-bit selects and the moves that put one constant of each pair into a
+// VGPR — 9 of the function's ~26 VALU instructions.  The lanes of a wave (three consecutive hours of 21 neighbouring
+// cells) are nearly always on the same side of 0 degrees C: then the constants are scalar operands of the multiply and the
+// add, and only a wave that straddles the freezing point selects per lane.  Same operands, same operations: same bits.
+__device__ __forceinline__ double satvap_arg(double tc) {
+    const bool water = tc > 0;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(water);
+    double num, den;
+    // (opaque results: or the compiler hoists the add out of the branches and selects its constant in VGPRs after all)
+    if (m == __builtin_amdgcn_ballot_w64(true)) { num = 17.27 * tc; den = tc + 237.3; asm("" : "+v"(num), "+v"(den)); }
+    else if (m == 0) { num = 21.875 * tc; den = tc + 265.5; asm("" : "+v"(num), "+v"(den)); }
+    else { num = (water ? 17.27 : 21.875) * tc; den = tc + (water ? 237.3 : 265.5); }
+    return fdiv(num, den);
+}
+__device__ __forceinline__ double satvap(double tc, const MathK& K) { return 0.61078 * fexp(satvap_arg(tc), K); }
+// On REGULAR steps (kStepIrregular clear) air and dew-point temperature lie in (-150, 150) and every temperature of the path is a
+// Penman-Monteith result in [tdew, tc + 80] (pm_temperature), so |a t / (t + b)| < 60: the bounded exp applies.
+template <bool F>
+__device__ __forceinline__ double satvap_f(double t, const MathK& K) {
+    return 0.61078 * fexp_b<F>(satvap_arg(t), K);
 }
 // cpp:24-26 with the 0.97*sb factor every caller applies
 __device__ __forceinline__ double lw_emit(double tc) { return 0.97 * kSb * pow4(tc + 273.15); }
@@ -763,6 +738,7 @@ __device__ inline void derive_time(TimeVals& t, const SolPos& sp, int windex) {
     // kStepIrregular: a value of this row is not finite, or one of the signs the fast clamps rely on does not hold
     // (Penman-Monteith's denominator 29.3*(g + ghr) + la/pk*g*De stays positive for ghr, De, la/pk > 0)
     bool ok = t.v[TF_DE] > 0.0 && t.v[TF_GHRRAD] > 0.0 && t.v[TF_LAPK] > 0.0 && t.v[TF_PK] > 0.0;
+    ok = ok && tc > -150.0 && tc < 150.0 && t.v[TF_TDEW] > -150.0 && t.v[TF_TDEW] < 150.0;     // satvap_f's bounded exp
     for (int f = 0; f < TF_IDX; ++f) ok = ok && isfinite(t.v[f]);
     t.v[TF_IDX] = (double)(sindex | (windex << 5) | (ksat << 8) | (ok ? 0 : kStepIrregular));
 }
@@ -926,11 +902,8 @@ struct TimeReg {
 
 // Values a lane carries from pass 1 to pass 2 of the same cell-hour.
 struct Carry {
-    double soilm, num0, den, radCsw, Rddown, Rbdown, X, uf;
+    double soilm, num0, rden, radCsw, Rddown, Rbdown, X, uf;
 };
-#ifndef MCF_SOIL_SHARE
-#define MCF_SOIL_SHARE 1
-#endif
 struct Pass1Out {
     double Tg0, absRnet;   // to the day reduction
     double uz, Rdup;       // outputs only
@@ -959,9 +932,6 @@ __device__ __forceinline__ void pin(A&... a) {
 // coinciding Lagrangian resistances) are WATCHED: Canary::watch folds them into a value that is NaN iff any of them
 // was NaN or infinite, and a wave with a tripped canary recomputes the pass with F = false.  Building with
 // -DMCF_CANARY_ALL=1 watches every clamp operand instead (tools/canary_audit.py counts how often that trips).
-#ifndef MCF_SKIP_MINCOND
-#define MCF_SKIP_MINCOND 1   // see pass2's leaf block: mincondCpp's floors skipped when they provably cannot bind
-#endif
 #ifndef MCF_CANARY_ALL
 #define MCF_CANARY_ALL 0
 #endif
@@ -973,28 +943,17 @@ struct Canary {
 };
 // one v_min_f64 / v_max_f64; a bound known at compile time is taken from the scalar file (two s_mov_b32 on the scalar
 // unit) or as an inline constant instead of being copied into a VGPR pair
-#ifndef MCF_CLAMP_LITERALS
-#define MCF_CLAMP_LITERALS 1   // 1: literal bounds from SGPR pairs / inline constants; 0: whatever register the compiler picks ("v")
-#endif
 __device__ __forceinline__ void vmin64(double& x, double hi) {
-#if MCF_CLAMP_LITERALS == 2
-    x = __builtin_fmin(x, hi);
-#else
-    if (MCF_CLAMP_LITERALS && __builtin_constant_p(hi)) {
+    if (__builtin_constant_p(hi)) {
         if (hi == 1.0) asm("v_min_f64 %0, %0, 1.0" : "+v"(x));
         else asm("v_min_f64 %0, %0, %1" : "+v"(x) : "s"(hi));
     } else asm("v_min_f64 %0, %0, %1" : "+v"(x) : "v"(hi));
-#endif
 }
 __device__ __forceinline__ void vmax64(double& x, double lo) {
-#if MCF_CLAMP_LITERALS == 2
-    x = __builtin_fmax(x, lo);
-#else
-    if (MCF_CLAMP_LITERALS && __builtin_constant_p(lo)) {
+    if (__builtin_constant_p(lo)) {
         if (lo == 0.0) asm("v_max_f64 %0, %0, 0" : "+v"(x));
         else asm("v_max_f64 %0, %0, %1" : "+v"(x) : "s"(lo));
     } else asm("v_max_f64 %0, %0, %1" : "+v"(x) : "v"(lo));
-#endif
 }
 template <bool F>
 __device__ __forceinline__ void cap(double& x, double hi, Canary& cn) {          // if (x > hi) x = hi;
@@ -1017,6 +976,17 @@ __device__ __forceinline__ void flr(double& x, double lo, Canary& cn) {         
 
 // Penman-Monteith surface temperature, cpp:1220-1247, from pre-assembled parts.  den > 0 on regular lanes (gHa >= 1e-4,
 // ghr, De, lapk > 0), so dT is finite there.
+// (`rden`: the reciprocal of the denominator — pass 1 and pass 2 solve for the ground with the SAME denominator, cpp:1272 /
+// 1293, so the lane carries 1 / den across the day's barrier instead of den and pass 2 divides by a multiplication)
+template <bool F>
+__device__ __forceinline__ double pm_temperature_r(double num, double rden, double dTmx, double tc, double tdew, Canary& cn) {
+    double dT = num * rden;
+    cap<F>(dT, dTmx, cn);
+    cap<F>(dT, 80.0, cn);
+    double Ts = dT + tc;
+    flr<F>(Ts, tdew, cn);
+    return Ts;
+}
 template <bool F>
 __device__ __forceinline__ double pm_temperature(double num, double den, double dTmx, double tc, double tdew, Canary& cn) {
     double dT = fdiv(num, den);
@@ -1270,8 +1240,9 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const SL& S, con
     const double num0 = radabs - t_rem - m * (t_es - t_ea) * surfwet;
     const double den = 29.3 * (gHa + t_ghr) + m * t_de;
     cy.num0 = num0;
-    cy.den = den;
-    double Tg0 = pm_temperature<F>(num0, den, dTmx, tc, tdew, cn);
+    const double rden = frcp(den);
+    cy.rden = rden;
+    double Tg0 = pm_temperature_r<F>(num0, rden, dTmx, tc, tdew, cn);
     o.Tg0 = Tg0;
     o.absRnet = fabs(radabs - lw_emit(Tg0));
 }
@@ -1286,7 +1257,7 @@ template <bool F>
 __device__ __forceinline__ double stomcond(double Rswabs, const Stom& s, const MathK& K, Canary& cn) {
     if (Rswabs <= 0.0) return 0.0;
     double gs = s.gsmax;          // light-saturated (Rswabs >= Rsmx): 2^0 = 1
-    if (Rswabs < s.rsmx) gs = s.gsmax * fexp(-(s.rsmx - Rswabs) * s.inv02rsmx * 0.693147180559945309417, K);
+    if (Rswabs < s.rsmx) gs = s.gsmax * fexp_b<F>(-(s.rsmx - Rswabs) * s.inv02rsmx * 0.693147180559945309417, K);     // (-3.5, 0)
     cap<F>(gs, s.gs2, cn);
     return gs;
 }
@@ -1298,13 +1269,26 @@ template <bool F>
 __device__ __forceinline__ double mincond_a02(double Rnet, double invleafd, const MathK& K, Canary& cn) {
     double arg = fabs(Rnet) * invleafd;
     flr<F>(arg, 1e-300, cn);             // pow(0, 0.2) = 0 and tiny values end in the 0.05 floor alike
-    return powxy(arg, 0.2, K);
+    return fexp_b<F>(0.2 * flog(arg, K), K);      // F: arg finite in [1e-300, DBL_MAX]: (-139, 142)
 }
 template <bool F>
 __device__ __forceinline__ double mincond_gmin(double hf02, double a02, Canary& cn) {
     double gmin = 0.0463 * (hf02 * a02);
     flr<F>(gmin, 0.05, cn);
     return gmin;
+}
+
+// rhcanopy's limit on the near-field term (cpp:1400-1407): |near| <= mxnear, NaN -> 0.  On regular lanes `near` is a product of
+// finite factors and mxnear a finite magnitude, so the limit is one v_max_f64 and one v_min_f64 instead of two compares and
+// five selects (and the NaN case cannot arise).
+template <bool F>
+__device__ __forceinline__ void near_field_limit(double& near, double mxnear) {
+    if (F) {
+        asm("v_max_f64 %0, %0, -%1\n\tv_min_f64 %0, %0, %1" : "+v"(near) : "v"(mxnear));
+    } else {
+        if (fabs(near) > mxnear) near = near > 0.0 ? mxnear : -mxnear;
+        if (isnan(near)) near = 0;
+    }
 }
 
 struct Pass2Out {
@@ -1345,7 +1329,7 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
     if (F) cn.watch(G);                  // sqrt of the soil diffusivity: NaN for a non-positive conductivity
     cap<F>(G, 0.6 * Rmx, cn);
     flr<F>(G, -0.6 * Rmx, cn);
-    const double Tg = pm_temperature<F>(cy.num0 - G, cy.den, dTmx, tc, tdew, cn);
+    const double Tg = pm_temperature_r<F>(cy.num0 - G, cy.rden, dTmx, tc, tdew, cn);
     o.Tg = Tg;
     o.DD = DD;
     if (!above_ground) return;
@@ -1365,11 +1349,11 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
     const double uf = cy.uf;
     double gHa = uf * c_ghafac;
     flr<F>(gHa, 0.0001, cn);
-    const double esTg = satvap(Tg, K);
+    const double esTg = satvap_f<F>(Tg, K);
     double eT = esTg - ea;
     flr<F>(eT, 0.001, cn);
     double plf = 0.8753 - 1.7126 * flog(eT, K);
-    double gwet = frcp(1.0 + fexp(-plf, K));
+    double gwet = frcp(1.0 + fexp_b<F>(-plf, K));       // eT in [1e-3, DBL_MAX]: -plf in (-13, 1215)
     const double surfwet = (soilm - c_smin) * c_invrge;
     flr<F>(gwet, surfwet, cn);
     // canopy conductance, cpp:1425-1428 + 460-477
@@ -1446,7 +1430,7 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
     const double mC = lapk * gV;
     const double Tcan = pm_temperature<F>(Rabs - rem - mC * (es - ea) * surfwet - G,
                                           29.3 * (gHa + ghr) + mC * De, dTmx, tc, tdew, cn);
-    const double esTcan = satvap(Tcan, K);
+    const double esTcan = satvap_f<F>(Tcan, K);
     midway();
     double ez;
     if (!(flags & FL_BELOW)) {
@@ -1482,13 +1466,11 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
         // the two floors can bind, and the pow() of the bound and the three exp() / two log() of |Hf|^0.2 are not
         // evaluated.  Wave-uniform (every lane in this branch must clear it); a NaN operand fails the test.
         bool floors_idle = false;
-#if MCF_SKIP_MINCOND
         {
             const double tq = gh * (1.0 / 0.0463), tq2 = tq * tq;
             const bool clear = gh >= 0.0500001 && tq2 * tq2 * tq >= (fabs(RnetL) * invleafd) * 1.000001;
             floors_idle = __builtin_amdgcn_ballot_w64(!clear) == 0;
         }
-#endif
         double a02 = 0.0;
         if (!floors_idle) {
             a02 = mincond_a02<F>(RnetL, invleafd, K, cn);
@@ -1509,8 +1491,9 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
                 // Hf = -1/(1 + exp(2 - Hlf)), cpp:1321-1325; |Hf|^0.2 = exp(-0.2*log(1 + exp(2 - Hlf)))
                 double hf02 = g.hf500p;                       // rs = 500: a constant (night, closed stomata)
                 if (gs > 0.002) {
-                    double Hlf = 1.09767 * fexp(-0.2672778 * flog(gs, K), K);
-                    hf02 = fexp(-0.2 * flog(1.0 + fexp(2.0 - Hlf, K), K), K);
+                    // gs in (0.002, DBL_MAX): arguments in (-190, 1.7), (-inf .. 2] with Hlf >= 0 finite, (-0.5, 0)
+                    double Hlf = 1.09767 * fexp_b<F>(-0.2672778 * flog(gs, K), K);
+                    hf02 = fexp_b<F>(-0.2 * flog(1.0 + fexp_b<F>(2.0 - Hlf, K), K), K);
                 }
                 double gmin = mincond_gmin<F>(hf02, a02, cn); // mincondCpp(leafabs, gs, Tcan, leafd)
                 flr<F>(gh, gmin, cn);
@@ -1520,7 +1503,7 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
         const double mL = lapk * gVl;
         const double tleaf = pm_temperature<F>(leafabs - rem - mL * (es - ea) * surfwet - 0.0,
                                                29.3 * (gh + ghr) + mL * De, dTmx, tc, tdew, cn);
-        const double esTl = satvap(tleaf, K);
+        const double esTl = satvap_f<F>(tleaf, K);
         const double HL = 29.3 * gh * (tleaf - tc);                       // cpp:1242
         const double LL = mL * (esTl - ea) * surfwet;                     // cpp:1243
         o.tleaf = tleaf;
@@ -1572,8 +1555,7 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
             double SC = SH + Flux * rKc;
             double farg = (Kg * SG + Kh * SH + Kc * SC) * invK;
             double near = nf * (HL * lden);
-            if (fabs(near) > mxnear) near = near > 0.0 ? mxnear : -mxnear;
-            if (isnan(near)) near = 0;
+            near_field_limit<F>(near, mxnear);
             o.Tz = (near + farg) * (1.0 / cp43);
         }
         // vapour pressure
@@ -1583,16 +1565,14 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
             double SC = SH + Flux * rKc;
             double farg = (Kg * SG + Kh * SH + Kc * SC) * invK;
             double near = nf * (LL * lden);
-            if (fabs(near) > mxnear) near = near > 0.0 ? mxnear : -mxnear;
-            if (isnan(near)) near = 0;
+            near_field_limit<F>(near, mxnear);
             ez = (near + farg) * invmu;
         }
     }
     // ez / satvap(Tz) * 100, cpp:1463-1465; 1 / (0.61078 exp(u)) = exp(-u) / 0.61078 spares the fast variant the division
     double rh;
     if (F) {
-        const double tz = o.Tz, sa = tz > 0 ? -17.27 : -21.875, sb = tz > 0 ? 237.3 : 265.5;
-        rh = (ez * (100.0 / 0.61078)) * fexp(fdiv(sa * tz, tz + sb), K);
+        rh = (ez * (100.0 / 0.61078)) * fexp_b<true>(-satvap_arg(o.Tz), K);     // Tz lies within 2 K of the temperatures above
     } else {
         rh = fdiv(ez, satvap(o.Tz, K)) * 100.0;
     }

@@ -1148,15 +1148,12 @@ __global__ void k_selftest_math(int kind, const double* __restrict__ x, const do
     double a = x[i], b = y ? y[i] : 0.0, r;
     MathK K;
     K.set();
-#if MCF_EXP_TABLE
     __shared__ double s_exptab[256];      // the route k_solve takes
     K.use_table(s_exptab, (int)threadIdx.x);
-#if MCF_LOG_TABLE
     __shared__ __attribute__((aligned(16))) double s_logtab[512];
     K.use_log_table(s_logtab, (int)threadIdx.x, (int)blockDim.x);
-#endif
+    K.pin(true, true);     // as k_solve's vector-forcing kernels: the VGPR-resident constants the bounded exp needs
     __syncthreads();
-#endif
     switch (kind) {
         case 0: r = fexp(a, K); break;
         case 1: r = flog(a, K); break;
@@ -1164,6 +1161,8 @@ __global__ void k_selftest_math(int kind, const double* __restrict__ x, const do
         case 3: r = fsqrt(a); break;
         case 4: r = frcp(a); break;
         case 5: r = satvap(a, K); break;
+        case 7: r = fexp_b<true>(a, K); break;        // |x| < 5e6
+        case 8: r = satvap_f<true>(a, K); break;      // the fast-clamp kernels' satvap (wave-uniform constants, bounded exp)
         default: r = powxy(a, b, K); break;
     }
     if (live) out[i] = r;

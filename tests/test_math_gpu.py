@@ -69,3 +69,19 @@ def test_satvap_and_pow():
     x = rng.uniform(1e-4, 1.0, 200000)
     y = rng.uniform(-12, 1, 200000)
     assert relerr(run(6, x, y), x ** y) < 3e-14
+
+
+def test_bounded_exp_and_fast_satvap():
+    """fexp_b (mcf_device.hpp): n = round(x * 256/ln2) out of the low mantissa bits of x * 256/ln2 + 1.5 * 2^52, for
+    |x| < 5e6; the same accuracy as the general form, and exactly 0 / inf once 2^e leaves the double range."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-700, 700, 200000), rng.uniform(-60, 60, 200000), rng.uniform(-2, 2, 200000),
+                        np.array([0.0, -0.0, 1e-300, -1e-300, 709.0, -745.0, 0.5 * np.log(2) / 256, -0.5 * np.log(2) / 256])])
+    assert relerr(run(7, x), np.exp(x)) < 4e-16
+    assert (run(7, np.array([-800.0, -1e5, -4.9e6])) == 0.0).all() and np.isinf(run(7, np.array([800.0, 4.9e6]))).all()
+    assert np.isnan(run(7, np.array([np.nan]))).all()
+    # satvap with wave-uniform constants: all-water waves, all-ice waves, waves that straddle 0 degrees C
+    for t in (np.linspace(0.01, 150, 64 * 500), np.linspace(-150, 0.0, 64 * 500), rng.uniform(-5, 5, 64 * 500)):
+        want = np.where(t > 0, 0.61078 * np.exp(17.27 * t / (t + 237.3)), 0.61078 * np.exp(21.875 * t / (t + 265.5)))
+        assert relerr(run(8, t), want) < 1e-14               # |a t / (t + b)| up to 28: the quotient's rounding, amplified
+        assert np.array_equal(run(8, t), run(5, t))          # same operands, same operations as the general form
