@@ -610,15 +610,26 @@ __device__ __forceinline__ double pow4(double x) { double x2 = x * x; return x2 
 // VGPR — 9 of the function's ~26 VALU instructions.  The lanes of a wave (three consecutive hours of 21 neighbouring
 // cells) are nearly always on the same side of 0 degrees C: then the constants are scalar operands of the multiply and the
 // add, and only a wave that straddles the freezing point selects per lane.  Same operands, same operations: same bits.
-__device__ __forceinline__ double satvap_arg(double tc) {
+__device__ __forceinline__ void satvap_nd(double tc, double& num, double& den) {
     const bool water = tc > 0;
     const uint64_t m = __builtin_amdgcn_ballot_w64(water);
-    double num, den;
     // (opaque results: or the compiler hoists the add out of the branches and selects its constant in VGPRs after all)
     if (m == __builtin_amdgcn_ballot_w64(true)) { num = 17.27 * tc; den = tc + 237.3; asm("" : "+v"(num), "+v"(den)); }
     else if (m == 0) { num = 21.875 * tc; den = tc + 265.5; asm("" : "+v"(num), "+v"(den)); }
     else { num = (water ? 17.27 : 21.875) * tc; den = tc + (water ? 237.3 : 265.5); }
+}
+__device__ __forceinline__ double satvap_arg(double tc) {
+    double num, den;
+    satvap_nd(tc, num, den);
     return fdiv(num, den);
+}
+// 1/a and 1/b out of ONE reciprocal: r = 1/(a b), 1/a = r b, 1/b = r a.  v_rcp_f64 runs at quarter rate (four issue slots) and
+// its cubic refinement takes three more; a pair costs one reciprocal and three multiplications (10 slots) instead of two
+// reciprocals (14).  For finite, normal a, b whose product stays in range — the fast-clamp instantiations; ~2 ulp.
+__device__ __forceinline__ void frcp2(double a, double b, double& ra, double& rb) {
+    const double r = frcp(a * b);
+    ra = r * b;
+    rb = r * a;
 }
 __device__ __forceinline__ double satvap(double tc, const MathK& K) { return 0.61078 * fexp(satvap_arg(tc), K); }
 // On REGULAR steps (kStepIrregular clear) air and dew-point temperature lie in (-150, 150) and every temperature of the path is a
@@ -626,6 +637,11 @@ __device__ __forceinline__ double satvap(double tc, const MathK& K) { return 0.6
 template <bool F>
 __device__ __forceinline__ double satvap_f(double t, const MathK& K) {
     return 0.61078 * fexp_b<F>(satvap_arg(t), K);
+}
+// ... from the quotient's parts, where its reciprocal was shared with another division (frcp2)
+template <bool F>
+__device__ __forceinline__ double satvap_rd(double num, double rden, const MathK& K) {
+    return 0.61078 * fexp_b<F>(num * rden, K);
 }
 // cpp:24-26 with the 0.97*sb factor every caller applies
 __device__ __forceinline__ double lw_emit(double tc) { return 0.97 * kSb * pow4(tc + 273.15); }
@@ -1353,9 +1369,17 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
     double eT = esTg - ea;
     flr<F>(eT, 0.001, cn);
     double plf = 0.8753 - 1.7126 * flog(eT, K);
-    double gwet = frcp(1.0 + fexp_b<F>(-plf, K));       // eT in [1e-3, DBL_MAX]: -plf in (-13, 1215)
+    // Two pairs of reciprocals that do not depend on each other are taken from one v_rcp_f64 each (frcp2) in the fast-clamp
+    // vector-forcing kernels.  Which divisions are paired is fixed per code path, never by what the other lanes of the wave
+    // do: results stay bit-identical whatever the tile geometry, chunking or raster partition.
+    constexpr bool PAIR = F && !lean;
+    const double dgw = 1.0 + fexp_b<F>(-plf, K);            // eT in [1e-3, DBL_MAX]: -plf in (-13, 1215)
     const double surfwet = (soilm - c_smin) * c_invrge;
-    flr<F>(gwet, surfwet, cn);
+    double gwet = 0.0;                                      // PAIR: with the canopy temperature's division below
+    if (!PAIR) {
+        gwet = frcp(dgw);
+        flr<F>(gwet, surfwet, cn);
+    }
     // canopy conductance, cpp:1425-1428 + 460-477
     const int idx = (int)t_idx;
     double gS = 9999.99;
@@ -1428,8 +1452,16 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
     if (lean) c_svfa = C(CF_SVFA);
     const double Rabs = cy.radCsw + 0.97 * c_svfa * rlw;
     const double mC = lapk * gV;
-    const double Tcan = pm_temperature<F>(Rabs - rem - mC * (es - ea) * surfwet - G,
-                                          29.3 * (gHa + ghr) + mC * De, dTmx, tc, tdew, cn);
+    const double numC = Rabs - rem - mC * (es - ea) * surfwet - G, denC = 29.3 * (gHa + ghr) + mC * De;
+    double Tcan;
+    if (PAIR) {
+        double rC;
+        frcp2(dgw, denC, gwet, rC);
+        flr<F>(gwet, surfwet, cn);
+        Tcan = pm_temperature_r<F>(numC, rC, dTmx, tc, tdew, cn);
+    } else {
+        Tcan = pm_temperature<F>(numC, denC, dTmx, tc, tdew, cn);
+    }
     const double esTcan = satvap_f<F>(Tcan, K);
     midway();
     double ez;
@@ -1503,9 +1535,6 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
         const double mL = lapk * gVl;
         const double tleaf = pm_temperature<F>(leafabs - rem - mL * (es - ea) * surfwet - 0.0,
                                                29.3 * (gh + ghr) + mL * De, dTmx, tc, tdew, cn);
-        const double esTl = satvap_f<F>(tleaf, K);
-        const double HL = 29.3 * gh * (tleaf - tc);                       // cpp:1242
-        const double LL = mL * (esTl - ea) * surfwet;                     // cpp:1243
         o.tleaf = tleaf;
         o.lwdn = lwdn;
         o.lwup = lwup;
@@ -1546,7 +1575,19 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
             Kg = frcp(Rz * z);
             Kh = fdiv(c_invhmz, Rc - Rz);
         }
-        invK = frcp(Kg + Kh + Kc);
+        // the leaf's saturated vapour pressure and the far field's normalisation share a reciprocal
+        double esTl;
+        if (PAIR) {
+            double nTl, dTl, rTl;
+            satvap_nd(tleaf, nTl, dTl);
+            frcp2(dTl, Kg + Kh + Kc, rTl, invK);
+            esTl = satvap_rd<F>(nTl, rTl, K);
+        } else {
+            esTl = satvap_f<F>(tleaf, K);
+            invK = frcp(Kg + Kh + Kc);
+        }
+        const double HL = 29.3 * gh * (tleaf - tc);                       // cpp:1242
+        const double LL = mL * (esTl - ea) * surfwet;                     // cpp:1243
         const double cp43 = 29.3 * 43.0;
         // temperature
         {
