@@ -477,9 +477,15 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
     __shared__ __attribute__((aligned(256))) double s_tile[IMG];
     double* const s_cell = s_tile;
     __shared__ double s_time[AF ? 1 : 3 * TF_COUNT * 24];
-    // day-reduction staging: per (hour, cell) values, or — 21-cell tiles — per (wave, cell) partial extremes
+    // day-reduction staging: per (hour, cell) values for every lane to walk after the barrier, or — 21-cell tiles — ONE slot
+    // per cell and statistic that the waves fold their partial extremes into with LDS atomics (ds_max_f64 / ds_min_f64):
+    // after the barrier a lane reads its cell's three results instead of reducing 8 x 3 partials (24 LDS reads and 24
+    // v_max / v_min per cell-step, by each of the cell's 24 hour lanes).  Three buffers: the one of day d + 2 is reset behind
+    // the barrier of day d, when every wave is past reading it (it held day d - 1) and none can write it before the barrier of
+    // day d + 1.
     constexpr bool PRE = CPB == 21;
-    __shared__ double s_red[2][PRE ? 3 : 2][(PRE ? 8 : 24) * CPB];
+    __shared__ double s_red[PRE ? 1 : 2][2][PRE ? 1 : 24 * CPB];
+    __shared__ double s_ext[PRE ? 3 : 1][3][PRE ? CPB : 1];        // [buffer][max Tg0, min Tg0, max |Rnet|][cell]
     __shared__ double s_dd[BG ? 24 * CPB : 1];
     // per cell-day soil state (mcf_device.hpp SoilDay): a ring of three days, filled two days ahead by one wave
     constexpr bool SS = SSREQ && (AF == 0) && (2 * CPB <= 64);
@@ -576,6 +582,7 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
         for (int i = 0; i < NLOG; ++i) { const int q = tid + i * NT; if (q < 512) s_logtab[q] = lg[i]; }
     }
     if (F && tid == 0) s_trip = 0;
+    if (PRE && tid < 9 * CPB) (&s_ext[0][0][0])[tid] = ((tid / CPB) % 3 == 0) ? -999.0 : ((tid / CPB) % 3 == 1) ? 999.0 : -999.9;   // cpp:2196-2198
     Globals g = a.g;
     double dTmx = g.dTmx;
     if (AF && in_grid) dTmx = -0.6273 * a.mxtc[c] + 49.79;   // cpp:1236 with the per-cell mxtc
@@ -725,8 +732,8 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
 
         Carry cy;
         Pass1Out p1;
-        double* red_t = &s_red[run & 1][0][PRE ? 0 : hr * CPB + cl];
-        double* red_r = &s_red[run & 1][1][PRE ? 0 : hr * CPB + cl];
+        double* red_t = &s_red[PRE ? 0 : run & 1][0][PRE ? 0 : hr * CPB + cl];
+        double* red_r = &s_red[PRE ? 0 : run & 1][1][PRE ? 0 : hr * CPB + cl];
         if (valid) {
             if (AF) pass1<F, false>(C, TR, SL, g, flags, dTmx, cy, p1, MK, cn);
             else pass1<F, SS>(C, TL, SL, g, flags, dTmx, cy, p1, MK, cn);
@@ -766,11 +773,12 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
             asm("v_min_f64 %0, %0, %1" : "+v"(tmn3) : "v"(t2));
             asm("v_max_f64 %0, %0, %1" : "+v"(rmx3) : "v"(r1));
             asm("v_max_f64 %0, %0, %1" : "+v"(rmx3) : "v"(r2));
+            // `if (m < x) m = x` ignores a NaN x; so does the LDS unit's float max / min (the slot is never NaN: it starts finite)
             if (valid && (l < 16 || (l >= 48 && l < 53))) {
-                const int wv = tid >> 6;
-                s_red[run & 1][0][wv * CPB + cl] = tmx3;
-                s_red[run & 1][1][wv * CPB + cl] = tmn3;
-                s_red[run & 1][PRE ? 2 : 0][wv * CPB + cl] = rmx3;
+                double (*ext)[PRE ? CPB : 1] = s_ext[PRE ? run % 3 : 0];
+                __hip_atomic_fetch_max(&ext[0][PRE ? cl : 0], tmx3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_min(&ext[1][PRE ? cl : 0], tmn3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(&ext[2][PRE ? cl : 0], rmx3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         if (stage) {
@@ -782,6 +790,8 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
             }
         }
         __syncthreads();
+        if (PRE && tid < 3 * CPB)      // reset the buffer of the day after next (see s_ext)
+            s_ext[PRE ? (run + 2) % 3 : 0][PRE ? tid / CPB : 0][PRE ? tid % CPB : 0] = tid < CPB ? -999.0 : tid < 2 * CPB ? 999.0 : -999.9;
         if (SS) {
             // Every wave is past the day before now, so the soil ring slot of the day after next (= that of the day before)
             // is free; whoever fills it reaches the NEXT barrier before any wave starts that day.  The waves take turns.  A
@@ -794,17 +804,12 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
             // finite start value ignores a NaN rv, exactly what v_max_f64 does (the accumulator is never NaN, rv is never a
             // signalling NaN: it was just computed): one VALU instruction instead of a compare and two 32-bit selects
             double Rmx = -999.9, tmx = -999.0, tmn = 999.0;
-            const double* rt = &s_red[run & 1][0][cl];
-            const double* rr = &s_red[run & 1][1][cl];
+            const double* rt = &s_red[PRE ? 0 : run & 1][0][PRE ? 0 : cl];
+            const double* rr = &s_red[PRE ? 0 : run & 1][1][PRE ? 0 : cl];
             if (PRE) {
-                const double* rq = &s_red[run & 1][PRE ? 2 : 0][cl];
-#pragma unroll
-                for (int wv = 0; wv < 8; ++wv) {
-                    const double a1 = rt[wv * CPB], a2 = rr[wv * CPB], a3 = rq[wv * CPB];
-                    asm("v_max_f64 %0, %0, %1" : "+v"(tmx) : "v"(a1));
-                    asm("v_min_f64 %0, %0, %1" : "+v"(tmn) : "v"(a2));
-                    asm("v_max_f64 %0, %0, %1" : "+v"(Rmx) : "v"(a3));
-                }
+                tmx = s_ext[PRE ? run % 3 : 0][0][PRE ? cl : 0];
+                tmn = s_ext[PRE ? run % 3 : 0][1][PRE ? cl : 0];
+                Rmx = s_ext[PRE ? run % 3 : 0][2][PRE ? cl : 0];
             }
 #pragma unroll
             for (int hh = 0; hh < (PRE ? 0 : 24); ++hh) {

@@ -1,0 +1,11 @@
+set -e
+cd $GRAFT_REPO_ROOT
+out=gpurun_out/r03m; mkdir -p $out
+python3 bench.py --gpus 1 --steps 5 --warmup 1 > $out/bench_default.json 2> $out/bench_default.err || { tail -20 $out/bench_default.err; exit 1; }
+python3 - <<P
+import json
+d=json.load(open("$out/bench_default.json"))
+print("value %.4e  ms/step %.1f  frac %.3f  verified %s" % (d["value"], d["ms_per_step"], d["roofline"]["frac"], d["verified"] and (d["verified"]["ok"], d["verified"]["max_scaled_err"])))
+print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline_all_cores"]["value"])
+for k,v in d["secondary"].items(): print(k, v.get("value"), v.get("hbm_frac"), v.get("avg_launch_ms"), v.get("error"))
+P
