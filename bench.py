@@ -218,7 +218,7 @@ def fit_ring(args, cells, af):
     (--ring-gb, default 230 of the 288 GB).  Longer launches first: every launch pays a fixed ~6.6 us per tile (staging the
     tile's constants, the soil-state prologue, the tail), 15 % of a 4-day launch and 9 % of a 7-day one."""
     cpb = args.cells_per_block or (32 if af else 21)
-    pad = (((cpb * 24 + 255) // 256) * 256) / (cpb * 24.0)       # the tiled ring's blocks are whole wave-rows (21 cells: 512 / 504)
+    pad = (((cpb * 24 + 63) // 64) * 64) / (cpb * 24.0)       # the tiled ring's blocks are whole wave-rows (21 cells: 512 / 504)
     per_day = cells * 24 * 8 * (10 * pad + (15 if af else 0))
     slots, days = args.ring_slots, args.ring_days
     budget = args.ring_gb * 1e9 - cells * 1500.0      # inputs 23 x 8 B, hor / wsa 256 B, tile-major constant table 976 B per cell

@@ -101,7 +101,9 @@ struct mcf_plan {
     double* d_dt = nullptr;
     int32_t* d_windex = nullptr;
     double* d_mxtc = nullptr;
-    double* d_force = nullptr;  // [slots][15][N*ring_days*24]
+    double* d_force = nullptr;  // array forcing: tiled ring (see mcf_plan_create); coarse: [15][crows*ccols][T]
+    double* d_force_stage = nullptr;
+    int64_t force_tile_stride = 0, force_day_stride = 0, force_slot_elems = 0;
     std::vector<int> force_day0, force_ndays;
     // outputs
     int ring_days = 0, ring_slots = 0;
@@ -689,10 +691,18 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
             }
             HIP_TRY(hipGetLastError());
         }
-        // forcing ring
-        int64_t fbytes = (int64_t)ring_slots * 15 * N * ring_days * 24 * 8;
-        if ((rc = dalloc(p, &tmp, fbytes))) return rc;
+        // forcing ring, TILED like the output ring: [slots][tile][day][15 series][ring_block_doubles(cpb)] in the solver's lane
+        // order, so that a workgroup's 360 loads per day (15 series x 24 hours, each 8 B x N x hour apart in the caller's
+        // arrays) become whole lines of one contiguous 90 KB run; mcf_plan_upload_forcing_days re-lays each series on the
+        // device behind its host-to-device copy
+        p->ntiles = (N + p->cpb - 1) / p->cpb;
+        p->force_day_stride = 15 * (int64_t)mcf::ring_block_doubles(p->cpb);
+        p->force_tile_stride = (int64_t)ring_days * p->force_day_stride;
+        p->force_slot_elems = p->ntiles * p->force_tile_stride;
+        if ((rc = dalloc(p, &tmp, (int64_t)ring_slots * p->force_slot_elems * 8))) return rc;
         p->d_force = (double*)tmp;
+        if ((rc = dalloc(p, &tmp, N * (int64_t)ring_days * 24 * 8))) return rc;     // one series of one slot, as uploaded
+        p->d_force_stage = (double*)tmp;
         p->force_day0.assign(ring_slots, -1);
         p->force_ndays.assign(ring_slots, 0);
         }
@@ -762,12 +772,19 @@ int mcf_plan_upload_forcing_days(mcf_plan* p, const mcf_grid_inputs* in, int32_t
     HIP_TRY(hipSetDevice(p->device));
     const double* raw[15];
     clim_ptrs(in, raw);
-    const int64_t N = p->N, cap = N * (int64_t)p->ring_days * 24, n = N * (int64_t)ndays * 24;
-    for (int f = 0; f < 15; ++f) {
+    const int64_t N = p->N, n = N * (int64_t)ndays * 24;
+    for (int f = 0; f < 15; ++f)
         if (!raw[f]) return fail(MCF_ERR_ARG, std::string("missing forcing array: ") + kRawNames[f]);
-        double* dst = p->d_force + ((int64_t)slot * 15 + f) * cap;
+    for (int f = 0; f < 15; ++f) {
+        // the series as the caller holds it ([rows, cols, steps]) into the staging slab, then into its tiled place on the device
+        // (stream order: the next copy into the slab waits for this series' kernel)
         const double* src = raw[f] + N * (int64_t)day0 * 24;
-        HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n * 8, hipMemcpyHostToDevice, p->stream));
+        HIP_TRY(hipMemcpyAsync(p->d_force_stage, src, (size_t)n * 8, hipMemcpyHostToDevice, p->stream));
+        mcf::RingView v{};
+        v.base = p->d_force + (int64_t)slot * p->force_slot_elems + (int64_t)f * mcf::ring_block_doubles(p->cpb);
+        v.N = N; v.tile_stride = p->force_tile_stride; v.day_stride = p->force_day_stride; v.cpb = p->cpb;
+        mcf::launch_tile_series(p->d_force_stage, (int64_t)ndays * 24, v, p->stream);
+        HIP_TRY(hipGetLastError());
     }
     p->force_day0[slot] = day0;
     p->force_ndays[slot] = ndays;
@@ -793,14 +810,12 @@ int mcf_plan_run_days(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot) {
         a.crows = p->crows; a.ccols = p->ccols;
         a.altcorrect = p->altcorrect;
         a.dt = p->d_dt; a.windex = p->d_windex; a.mxtc = p->d_mxtc;
-        a.force_step0 = 0;
     } else if (p->af) {
         if (p->force_day0[slot] != day0 || p->force_ndays[slot] < ndays)
             return fail(MCF_ERR_STATE, "forcing for these days has not been uploaded to this slot");
-        a.af_base = p->d_force + (int64_t)slot * 15 * cap;
-        a.af_stride = cap;
+        a.af_base = p->d_force + (int64_t)slot * p->force_slot_elems;
+        a.af_tile_stride = p->force_tile_stride; a.af_day_stride = p->force_day_stride;
         a.dt = p->d_dt; a.windex = p->d_windex; a.mxtc = p->d_mxtc;
-        a.force_step0 = 0;
     }
     a.out_base = p->d_ring + (int64_t)slot * p->slot_elems;
     a.out_stride = cap;

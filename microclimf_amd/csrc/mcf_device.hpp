@@ -422,12 +422,13 @@ struct MathK {
     }
     // vconst: c5 / c11, lg6, lg7 held in VGPRs as well (an instruction reads one scalar operand, so a second constant costs
     // two moves wherever it is used) — not in the array-forcing kernels, which have no register to spare
-    __device__ __forceinline__ void pin(bool with_log, bool vconst = true) {
+    // lean_fast: only the bounded exp's two VGPR residents (three registers) — the array-forcing kernels
+    __device__ __forceinline__ void pin(bool with_log, bool vconst = true, bool lean_fast = false) {
         if (table) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) asm volatile("" : "+s"(t[i]));
-            if (vconst) {
-                asm volatile("" : "+v"(c5));
+            if (vconst) asm volatile("" : "+v"(c5));
+            if (vconst || lean_fast) {
                 asm volatile("" : "+v"(magic));
                 asm volatile("" : "+v"(sh3));
                 vfast = true;

@@ -17,7 +17,7 @@ struct Globals {
 
 // ---- the output ring as its consumers see it -------------------------------------------------------------------------
 // Doubles per tile-day block of the tiled ring = lanes of the solver's workgroup for `cpb` cells per tile.
-#define RING_BLOCK(cpb) ((((cpb) * 24 + 255) / 256) * 256)
+#define RING_BLOCK(cpb) ((((cpb) * 24 + 63) / 64) * 64)
 __host__ __device__ inline int ring_block_doubles(int cpb) { return RING_BLOCK(cpb); }
 // Place of (cell of the tile, hour of the day) inside a block: the lane that computes it in k_solve.  21-cell tiles:
 // wave w = hour / 3 holds [3 hours x cells 0..15 | 3 hours x cells 16..20 | one padding double]; others hour-major.
@@ -94,13 +94,16 @@ struct SolveArgs {
     int64_t ntiles_total; // tiles of the raster = images per layer
     const int32_t* daylayer;  // [ndays] vegetation layer of each day, -1: no layer covers it; null: layer 0
     const double* tt;     // vector forcing: [ndays][TF_COUNT][24]
-    // array forcing
-    const double* af_base;  // forcing slabs [15][N][steps in buffer], TF_TC .. TF_DTRP order
-    int64_t af_stride;      // elements between consecutive forcing slabs
+    // array forcing: the slot of the TILED forcing ring — block of (tile, day d of the launch, series f) at
+    //   af_base + tile * af_tile_stride + d * af_day_stride + f * ring_block_doubles(cells per tile), lane order (ring_pos),
+    // series in TF_TC .. TF_DTRP order.  Coarse array forcing (crows > 0): af_base = [15][crows*ccols][tsteps], af_stride
+    // elements between the series.
+    const double* af_base;
+    int64_t af_stride;
+    int64_t af_tile_stride, af_day_stride;
     const double* dt;       // [tsteps][4]
     const int32_t* windex;  // [tsteps]
     const double* mxtc;     // [N]
-    int64_t force_step0;    // first step of this launch inside the forcing slabs
     // coarse array forcing (af_base = [15][crows*ccols][tsteps], whole series resident): crows > 0
     int32_t crows, ccols;
     int32_t altcorrect;     // 0, 1 (fixed lapse rate), 2 (humidity-dependent)
@@ -160,6 +163,8 @@ void launch_gather_cells(const RingView& src, int64_t step0, int64_t nsteps, con
                          hipStream_t s);
 // dst[c + N*k] = src(c, step0 + k), k < nsteps: the reference's [rows, cols, steps] layout out of the tiled ring
 void launch_untile(const RingView& src, int64_t step0, int64_t nsteps, double* dst, hipStream_t s);
+// the other way (array forcing's upload path): dst(c, k) = src[c + N*k], k < nsteps, `dst` a tiled view (its base is written)
+void launch_tile_series(const double* src, int64_t nsteps, const RingView& dst, hipStream_t s);
 // per-cell maximum over time of the bilinearly interpolated coarse temperature [crows*ccols][tsteps]
 // `force`: the 15 coarse slabs (stride elements apart); elevd / pkfac null without altitude correction
 void launch_mxtc_coarse(const double* force, int64_t stride, int crows, int ccols, int tsteps, const double* rowpos,

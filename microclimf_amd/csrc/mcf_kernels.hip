@@ -47,6 +47,12 @@ __global__ void k_gather_cells(RingView src, int64_t step0, int64_t nsteps, cons
 // One lane per cell, blockIdx.y = step: the stores are contiguous runs along the raster; the loads take a whole
 // 128-byte line (cells 0..15 of an hour) + 40 bytes (cells 16..20) per 21-cell tile, the three hours that share the
 // second line meet in the L2.
+__global__ __launch_bounds__(256) void k_tile_series(const double* __restrict__ src, RingView dst) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= dst.N) return;
+    const int64_t k = blockIdx.y;
+    const_cast<double*>(dst.base)[dst.index(c, k)] = src[c + dst.N * k];
+}
 __global__ __launch_bounds__(256) void k_untile(RingView src, int64_t step0, double* __restrict__ dst) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= src.N) return;
@@ -460,8 +466,9 @@ __global__ __launch_bounds__(256) void k_mxtc_coarse(const double* __restrict__ 
 // partial lines completed by the neighbouring tiles — a pure store stream at 32 % of the HBM peak.
 // reqhgt < 0 keeps the linear layout (k_belowground smooths whole series in place).
 // ------------------------------------------------------------------------------------
-// threads per workgroup: CPB*24 lanes rounded up to whole waves on all four SIMDs
-constexpr int solve_threads(int cpb) { return ((cpb * 24 + 255) / 256) * 256; }
+// threads per workgroup: CPB*24 lanes rounded up to whole waves (21 cells: 8 waves, 32: 12, 16: 6 — two 16-cell workgroups of the
+// 168-VGPR array-forcing kernel fill a CU's twelve wave slots)
+constexpr int solve_threads(int cpb) { return ((cpb * 24 + 63) / 64) * 64; }
 static_assert(solve_threads(21) == 512 && solve_threads(32) == 768, "ring_block_doubles() must agree");
 
 // One tile (CPB consecutive cells) over days [day0, day0 + ndays) of the launch described by `a`.
@@ -591,7 +598,7 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
     MathK MK;
     MK.set();
     MK.tables(s_exptab, s_logtab);     // filled above, visible after the prologue's barrier
-    MK.pin(true, AF == 0);   // exp and log coefficients resident in SGPRs for the whole day loop (the array-forcing kernels
+    MK.pin(true, AF == 0, AF == 1);     // (the coarse kernel is short of SGPRs: the two extra residents cost it 4 %)   // exp and log coefficients resident in SGPRs for the whole day loop (the array-forcing kernels
                              // have no VGPR to spare for the second constants)
     const double NA = na_real();
 
@@ -673,7 +680,12 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
             }
         }
         TimeVals tv;
-        const int64_t fidx = c + N * (a.force_step0 + kl);
+        // the tile-day block of the tiled forcing ring (uniform) — the lane's value of series f is at [f][pos]
+        const double* fday = (AF == 1) ? a.af_base + tile * a.af_tile_stride + (int64_t)(dabs - a.day0) * a.af_day_stride : nullptr;
+        auto force = [&](int f) {
+            asm("" : "+v"(posb));      // (see `put`: keeps the addressing mode SGPR base + lane offset)
+            return *(const double*)((const char*)fday + (size_t)f * (NT * 8) + posb);
+        };
         if (AF && valid) {
             const int64_t kabs = (int64_t)dabs * 24 + hr;
             // pass 2's ground heat flux takes four more series, through ONE value (cpp:1282-1289): loaded here with the rest,
@@ -700,11 +712,11 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
                 if (a.need_pass2) { p2gp = at(TF_GP); p2mugp = at(TF_MUGP); p2dtrp = at(TF_DTRP); p2kp = at(TF_KP); }
             } else {
                 // the 15 series, slots TF_TC .. TF_DTRP: ten raw inputs and umu feed pass 1; Gp, kp, muGp, dtrp feed GFAC below
-                for (int f = 0; f < 10; ++f) tv.v[f] = a.af_base[(int64_t)f * a.af_stride + fidx];
-                tv.v[TF_UMU] = a.af_base[(int64_t)TF_UMU * a.af_stride + fidx];
+                for (int f = 0; f < 10; ++f) tv.v[f] = force(f);
+                tv.v[TF_UMU] = force(TF_UMU);
                 if (a.need_pass2) {
-                    p2gp = a.af_base[(int64_t)TF_GP * a.af_stride + fidx]; p2mugp = a.af_base[(int64_t)TF_MUGP * a.af_stride + fidx];
-                    p2dtrp = a.af_base[(int64_t)TF_DTRP * a.af_stride + fidx]; p2kp = a.af_base[(int64_t)TF_KP * a.af_stride + fidx];
+                    p2gp = force(TF_GP); p2mugp = force(TF_MUGP);
+                    p2dtrp = force(TF_DTRP); p2kp = force(TF_KP);
                 }
             }
             DateRow dr{a.dt[4 * kabs + 0], a.dt[4 * kabs + 1], a.dt[4 * kabs + 2], a.dt[4 * kabs + 3]};
@@ -724,6 +736,7 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
                 cn.watch(tv.v[TF_RBEAM]);
                 cn.watch(dTmx);                 // from the cell's mxtc, the maximum of its temperature series
                 if (!(tv.v[TF_DE] > 0.0 && tv.v[TF_GHRRAD] > 0.0 && tv.v[TF_LAPK] > 0.0 && tv.v[TF_PK] > 0.0)) cn.trip();
+                if (!(fabs(tv.v[TF_TC]) < 150.0 && fabs(tv.v[TF_TDEW]) < 150.0)) cn.trip();     // satvap_f's bounded exp
             }
         }
         TimeLds TL{s_time + (AF ? 0 : (run % 3) * (TF_COUNT * 24)) + hr};
@@ -1256,6 +1269,16 @@ void launch_pack_transpose(const RingView& src, int64_t step0, int64_t rows, int
     if (nsteps <= 0) return;
     dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32), (unsigned)nsteps);
     hipLaunchKernelGGL(k_pack_transpose, grid, dim3(256), 0, s, src, step0, rows, cols, scale, dst);
+}
+void launch_tile_series(const double* src, int64_t nsteps, const RingView& dst, hipStream_t s) {
+    if (nsteps <= 0 || dst.N <= 0) return;
+    for (int64_t k0 = 0; k0 < nsteps; k0 += 65535) {      // gridDim.y limit; whole days only reach here in one piece
+        const int64_t n = std::min<int64_t>(65535, nsteps - k0);
+        RingView v = dst;
+        v.base = dst.base + (k0 / 24) * dst.day_stride;
+        dim3 grid((unsigned)((dst.N + 255) / 256), (unsigned)n);
+        hipLaunchKernelGGL(k_tile_series, grid, dim3(256), 0, s, src + dst.N * k0, v);
+    }
 }
 void launch_untile(const RingView& src, int64_t step0, int64_t nsteps, double* dst, hipStream_t s) {
     if (nsteps <= 0 || src.N <= 0) return;

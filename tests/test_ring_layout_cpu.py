@@ -10,7 +10,7 @@ from microclimf_amd import _abi
 
 
 def _layout(cells, cpb, days, nvars=10):
-    blk = ((cpb * 24 + 255) // 256) * 256
+    blk = ((cpb * 24 + 63) // 64) * 64
     lay = _abi.RingLayout()
     lay.tiled, lay.cells_per_tile, lay.block_doubles, lay.slot_days = 1, cpb, blk, days
     lay.cells = cells

@@ -1,6 +1,8 @@
 set -e
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/r03m; mkdir -p $out
+timeout -k 10 1000 python -m pytest tests -x -q -m gpu > $out/tests.log 2>&1 || { tail -40 $out/tests.log; exit 1; }
+tail -2 $out/tests.log
 python3 bench.py --gpus 1 --steps 5 --warmup 1 > $out/bench_default.json 2> $out/bench_default.err || { tail -20 $out/bench_default.err; exit 1; }
 python3 - <<P
 import json
