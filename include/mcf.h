@@ -217,6 +217,13 @@ int mcf_plan_upload_forcing_days(mcf_plan *plan, const mcf_grid_inputs *in,
  * mcf_plan_ring_layout; mcf_plan_fetch* / mcf_nc_write_plan return them in the
  * reference's layout. */
 int mcf_plan_run_days(mcf_plan *plan, int32_t day0, int32_t ndays, int32_t slot);
+/* The same with the days written at day `slot_day0` of the slot instead of its start (vector forcing, reqhgt >= 0): several
+ * runs of days of one chunk, each at its own place (the snow branch's no-snow days). */
+int mcf_plan_run_days_at(mcf_plan *plan, int32_t day0, int32_t ndays, int32_t slot, int32_t slot_day0);
+/* Vector forcing: replace the series' maximum air temperature (src/microclimfCpp.cpp:2159-2168; it caps the
+ * Penman-Monteith temperature excess, cpp:1236).  The snow branch solves a SUBSET of the days and the reference takes
+ * the maximum over that subset. */
+int mcf_plan_set_mxtc(mcf_plan *plan, double mxtc);
 /* reqhgt<0: after every day has been solved into slot 0, smooth the stored
  * ground-temperature series into Tz (Tbelowgroundv, cpp:1474-1539). */
 int mcf_plan_belowground(mcf_plan *plan);
@@ -542,6 +549,30 @@ int mcf_snowplan_run_chunk(mcf_snowplan *plan, int32_t chunk, double tpic_mean, 
  * result / count [steps of that chunk] as mcf_applycpp3 gives them.  `.runmicrosnow1` decides snow / no-snow days on the
  * per-step minimum and maximum of totalSWE (R/internal.R:3592-3594); row-block ranks combine them with one all-reduce. */
 int mcf_snowplan_apply3(mcf_snowplan *plan, int32_t chunk, int32_t fun, double *result, double *count);
+
+/* ---- the snow-day microclimate inside the chunk loop: `.runmicrosnow1` (R/internal.R:3581-3659) device-resident ----------
+ * The reference runs the no-snow solver on the days with a snow-free cell somewhere, gridmicrosnow1
+ * (src/microclimfCpp.cpp:4894-5056) on the days with snow somewhere, and merges by day, with the whole year's snow series in
+ * memory.  Here the series exist one 5-day chunk at a time, and gridmicrosnow1 needs two things of the WHOLE snow-day series
+ * before its first step — the per-cell mean snow damping depth (cpp:4713-4737) and the day list itself (its albedo clock and
+ * maximum temperature run over the subset) — so the year is walked twice:
+ *   pass 1  chunk loop as before (prepare_chunk, run_chunk, apply3 -> snowdaysfun); per chunk
+ *           mcf_snowplan_meand_accumulate(chunk, snowday[]) adds the chunk's snow days to the running sum
+ *   between mcf_snowplan_micro_setup(subset inputs, day map, reqhgt, mat, out mask): the snow-day subset's weather (incl. umu),
+ *           `.sortl2` vegetation, bare-ground terrain, Smax; builds its step table; finishes the mean damping depth;
+ *           mcf_plan_set_mxtc(solver plan, max temperature of the NO-snow subset) (cpp:2159-2168 over the subset the
+ *           reference hands to runmicro1Cpp); mcf_snowplan_reset() puts the hand-over state back to the series' start
+ *   pass 2  chunk loop again; per chunk the solver on the chunk's no-snow days at their own place in the ring slot
+ *           (mcf_plan_run_days_at), then mcf_snowplan_microsnow(solver plan, chunk, slot, nosnowday[]) writes the snow
+ *           microclimate over it: snow-covered cell-steps of snow days get gridmicrosnow1's values, snow-free cell-steps keep
+ *           the solver's value when the day is a no-snow day as well and are NA otherwise (the reference's blank template).
+ * The slot then holds `.runmicrosnow1`'s merged output for the chunk's days. */
+int mcf_snowplan_reset(mcf_snowplan *plan);
+int mcf_snowplan_meand_accumulate(mcf_snowplan *plan, int32_t chunk, const int32_t *snowday /* [days of the chunk] */);
+int mcf_snowplan_micro_setup(mcf_snowplan *plan, const mcf_snow_inputs *subset, const int32_t *subset_day_of_day,
+                             int32_t ndays, double reqhgt, double mat, const int32_t out[MCF_NOUT]);
+int mcf_snowplan_microsnow(mcf_snowplan *plan, mcf_plan *solver, int32_t chunk, int32_t slot,
+                           const int32_t *nosnowday /* [days of the chunk] */);
 
 /* applycpp3 (src/microclimfCpp.cpp:5553-5588; `.runmicrosnow1/2` use it on totalSWE, R/internal.R:3592-3593):
  * reduction of a [rows,cols,tsteps] array over space, per time step, skipping NA.  fun: 0 mean, 1 sum,

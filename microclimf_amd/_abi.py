@@ -165,7 +165,8 @@ EXPORTS = (
     "mcf_plan_create", "mcf_plan_destroy", "mcf_plan_twi_partial",
     "mcf_plan_set_twi_mean", "mcf_plan_upload_forcing_days", "mcf_plan_run_days",
     "mcf_plan_belowground", "mcf_plan_sync", "mcf_plan_fetch", "mcf_plan_fetch_cells", "mcf_plan_fetch_packed", "mcf_plan_slot_ptr",
-    "mcf_plan_ring_layout", "mcf_ring_index",
+    "mcf_plan_ring_layout", "mcf_ring_index", "mcf_plan_run_days_at", "mcf_plan_set_mxtc",
+    "mcf_snowplan_reset", "mcf_snowplan_meand_accumulate", "mcf_snowplan_micro_setup", "mcf_snowplan_microsnow",
     "mcf_plan_timer_start", "mcf_plan_timer_stop", "mcf_plan_kernel_timing",
     "mcf_plan_kernel_stats", "mcf_plan_dispatch_stats", "mcf_plan_valid_cells", "mcf_plan_bytes", "mcf_selftest_math",
     "mcf_precompute_terrain", "mcf_runbioclim1", "mcf_runbioclim2", "mcf_runbioclim3", "mcf_runbioclim4",
@@ -255,6 +256,20 @@ def load() -> C.CDLL:
     lib.mcf_plan_upload_forcing_days.argtypes = [P, GI, C.c_int32, C.c_int32, C.c_int32]
     lib.mcf_plan_run_days.restype = C.c_int
     lib.mcf_plan_run_days.argtypes = [P, C.c_int32, C.c_int32, C.c_int32]
+    if hasattr(lib, "mcf_plan_run_days_at"):     # (absent from an older library named by MCF_LIB for an A/B run)
+        lib.mcf_plan_run_days_at.restype = C.c_int
+        lib.mcf_plan_run_days_at.argtypes = [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        lib.mcf_plan_set_mxtc.restype = C.c_int
+        lib.mcf_plan_set_mxtc.argtypes = [P, C.c_double]
+        lib.mcf_snowplan_reset.restype = C.c_int
+        lib.mcf_snowplan_reset.argtypes = [P]
+        lib.mcf_snowplan_meand_accumulate.restype = C.c_int
+        lib.mcf_snowplan_meand_accumulate.argtypes = [P, C.c_int32, c_int32_p]
+        lib.mcf_snowplan_micro_setup.restype = C.c_int
+        lib.mcf_snowplan_micro_setup.argtypes = [P, C.POINTER(SnowInputs), c_int32_p, C.c_int32, C.c_double, C.c_double,
+                                                 C.POINTER(C.c_int32 * NOUT)]
+        lib.mcf_snowplan_microsnow.restype = C.c_int
+        lib.mcf_snowplan_microsnow.argtypes = [P, P, C.c_int32, C.c_int32, c_int32_p]
     lib.mcf_plan_belowground.restype = C.c_int
     lib.mcf_plan_belowground.argtypes = [P]
     lib.mcf_plan_sync.restype = C.c_int

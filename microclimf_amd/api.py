@@ -208,6 +208,14 @@ class Plan:
     def run_days(self, day0: int, ndays: int, slot: int = 0):
         _abi.check(self._lib.mcf_plan_run_days(self._p, day0, ndays, slot))
 
+    def run_days_at(self, day0: int, ndays: int, slot: int, slot_day0: int):
+        """run_days with the days written at day `slot_day0` of the slot (include/mcf.h mcf_plan_run_days_at)."""
+        _abi.check(self._lib.mcf_plan_run_days_at(self._p, day0, ndays, slot, slot_day0))
+
+    def set_mxtc(self, mxtc: float):
+        """Replace the series' maximum air temperature (the snow branch solves a subset of the days)."""
+        _abi.check(self._lib.mcf_plan_set_mxtc(self._p, float(mxtc)))
+
     def belowground(self):
         _abi.check(self._lib.mcf_plan_belowground(self._p))
 

@@ -748,6 +748,29 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
     return MCF_OK;
 }
 
+}  // extern "C"
+namespace mcf {
+int plan_ring_views(mcf_plan* p, int slot, RingView views[10], int32_t has[10], hipStream_t* stream, int64_t* N, int* device,
+                    int* slot_days) {
+    if (!p) return fail(MCF_ERR_ARG, "null plan");
+    if (slot < 0 || slot >= p->ring_slots) return fail(MCF_ERR_ARG, "slot out of range");
+    for (int v = 0; v < MCF_NOUT; ++v) {
+        has[v] = p->var_slot[v] >= 0;
+        if (has[v]) views[v] = ring_view(p, slot, v);
+    }
+    *stream = p->stream; *N = p->N; *device = p->device; *slot_days = p->ring_days;
+    return MCF_OK;
+}
+}  // namespace mcf
+extern "C" {
+
+int mcf_plan_set_mxtc(mcf_plan* p, double mxtc) {
+    if (!p) return fail(MCF_ERR_ARG, "null plan");
+    if (p->af) return fail(MCF_ERR_STATE, "array forcing takes the maximum per cell from its series");
+    p->g.dTmx = -0.6273 * mxtc + 49.79;                              // cpp:1236 (every launch takes the plan's globals)
+    return MCF_OK;
+}
+
 int mcf_plan_twi_partial(mcf_plan* p, double* sum, int64_t* count) {
     if (!p || !sum || !count) return fail(MCF_ERR_ARG, "null argument");
     *sum = p->twi_sum;
@@ -792,10 +815,15 @@ int mcf_plan_upload_forcing_days(mcf_plan* p, const mcf_grid_inputs* in, int32_t
 }
 
 int mcf_plan_run_days(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot) {
+    return mcf_plan_run_days_at(p, day0, ndays, slot, 0);
+}
+
+int mcf_plan_run_days_at(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot, int32_t slot_day0) {
     if (!p) return fail(MCF_ERR_ARG, "null plan");
     if (slot < 0 || slot >= p->ring_slots) return fail(MCF_ERR_ARG, "slot out of range");
     if (day0 < 0 || ndays < 1 || day0 + ndays > p->ndays) return fail(MCF_ERR_ARG, "day range out of bounds");
-    if (!p->bg && ndays > p->ring_days) return fail(MCF_ERR_ARG, "more days than the ring slot holds");
+    if (!p->bg && (slot_day0 < 0 || slot_day0 + ndays > p->ring_days)) return fail(MCF_ERR_ARG, "more days than the ring slot holds");
+    if (slot_day0 != 0 && (p->bg || p->af)) return fail(MCF_ERR_ARG, "a day offset inside the slot needs vector forcing and reqhgt >= 0");
     HIP_TRY(hipSetDevice(p->device));
     int rc = ensure_cells(p);
     if (rc) return rc;
@@ -820,7 +848,7 @@ int mcf_plan_run_days(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot) {
     a.out_base = p->d_ring + (int64_t)slot * p->slot_elems;
     a.out_stride = cap;
     a.out_tile_stride = p->ring_tile_stride; a.out_day_stride = p->ring_day_stride; a.out_var_stride = p->ring_var_stride;
-    a.slot_day0 = 0;
+    a.slot_day0 = slot_day0;
     a.out_sel = 0;
     for (int v = 0; v < MCF_NOUT; ++v)
         a.out_sel |= (uint64_t)(p->var_slot[v] < 0 ? 15 : p->var_slot[v]) << (4 * v);

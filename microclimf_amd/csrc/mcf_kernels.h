@@ -202,6 +202,14 @@ void launch_tile_regular(const double* cellc, int64_t N, int layers, int cpb, ui
 void launch_belowground(const BelowArgs& a, hipStream_t s);
 void launch_selftest_math(int kind, const double* x, const double* y, double* out, int64_t n, hipStream_t s);
 
+// a plan's ring slot as another translation unit's kernels address it (mcf_snow.hip writes the snow-day microclimate into it):
+// views of the requested variables (has[v] = 0: not requested), the plan's stream, its cell count and its device
+}  // namespace mcf
+struct mcf_plan;
+namespace mcf {
+int plan_ring_views(mcf_plan* p, int slot, RingView views[10], int32_t has[10], hipStream_t* stream, int64_t* N, int* device,
+                    int* slot_days);
+
 int cell_field_count();
 void print_variant_stats();  // hook for the timing variants under tools/variants/ (empty in the shipped library)
 int soil_daily_bit();        // kSoilDaily, likewise

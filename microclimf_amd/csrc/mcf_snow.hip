@@ -394,6 +394,134 @@ __global__ __launch_bounds__(256) void k_microsnow(MicroArgs a) {
     }
 }
 
+// ---- gridmicrosnow1 inside the chunk loop, device-resident (mcf_snowplan_micro_*) ---------------------------------
+// meanDsnow (cpp:4713-4737) is the mean over the WHOLE snow-day series of sqrt(2 kappa / omega); the series lives on the
+// device one chunk at a time, so a first pass over the year adds the chunk's snow days to a per-cell running sum — the
+// same terms in the same order as k_microsnow_cell's loop.
+__global__ __launch_bounds__(256) void k_meand_accumulate(const double* __restrict__ sden, const double* __restrict__ hgt,
+                                                          int64_t N, int ndays, const int32_t* __restrict__ snowday, int first,
+                                                          double* __restrict__ sumD, int32_t* __restrict__ sden_na) {
+    snow::snow_tables_init();
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N || isnan(hgt[c])) return;
+    double s = sumD[c];
+    bool seen = !first;
+    for (int d = 0; d < ndays; ++d) {
+        if (!snowday[d]) continue;
+        if (!seen) { sden_na[c] = isnan(sden[c + N * (d * 24)]) ? 1 : 0; seen = true; }
+        for (int h = 0; h < 24; ++h) {
+            const double den = sden[c + N * (d * 24 + h)];
+            const double co = 0.0442 * exp(5.181 * den / 1000.0);
+            const double kap = co / (den * 2090.0);
+            s += sqrt(2.0 * kap / kOmdy);
+        }
+    }
+    sumD[c] = s;
+}
+__global__ __launch_bounds__(256) void k_meand_finish(const double* __restrict__ sumD, const int32_t* __restrict__ sden_na,
+                                                      const double* __restrict__ hgt, int64_t N, double nsteps,
+                                                      double* __restrict__ meanD) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    meanD[c] = (isnan(hgt[c]) || sden_na[c]) ? na_real() : sumD[c] / nsteps;
+}
+
+// k_microsnow on one chunk's snow days, reading the chunk's snow series where mcf_snowplan_run_chunk left them and
+// writing into a ring slot of the grid solver's plan (tiled layout, RingView) — the merge of `.runmicrosnow1`
+// (R/internal.R:3565-3578, 3633-3656) per cell-step:
+//   snow day, SWE > 0              the snow microclimate (variables of `outsel`; the others as in the last line)
+//   snow day, no snow on the cell  the no-snow solver's value if the day is a no-snow day as well, else NA
+//   other days                     untouched (the solver's value)
+// One lane per (cell, day of the chunk).  m.rows / m.temp ... are the SUBSET series of the snow days (daymap[d]: the
+// chunk day's place in it, -1: not a snow day); m.sTc ... m.sden the chunk's series, chunk-local steps.
+struct MicroRingArgs {
+    MicroArgs m;
+    mcf::RingView out[MCF_NOUT];
+    int32_t has[MCF_NOUT];       // the plan holds the variable
+    int32_t sel[MCF_NOUT];       // gridmicrosnow1's `out` mask
+    const int32_t *daymap, *nosnow;
+    int32_t ndays;
+};
+__global__ __launch_bounds__(256) void k_microsnow_ring(MicroRingArgs q) {
+    snow::snow_tables_init();
+    const MicroArgs& a = q.m;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t N = a.N;
+    if (t >= N * q.ndays) return;
+    const int64_t c = t % N;
+    const int day = (int)(t / N);
+    const int sub = q.daymap[day];
+    if (sub < 0) return;
+    const bool keep = q.nosnow[day] != 0;        // the solver ran this day: snow-free cell-steps keep its values
+    const double NA = na_real();
+    auto put = [&](int i, int h, double v) {
+        const_cast<double*>(q.out[i].base)[q.out[i].index(c, day * 24 + h)] = v;
+    };
+    const double hgt = a.hgt[c];
+    const int k0 = day * 24;
+    if (isnan(hgt)) {            // cpp:4988-4989: the cell is skipped — the blank template's NA unless the solver wrote it
+        if (!keep)
+            for (int h = 0; h < 24; ++h)
+                for (int i = 0; i < MCF_NOUT; ++i) if (q.has[i]) put(i, h, NA);
+        return;
+    }
+    double Tzd = NA;
+    if (!isnan(a.sTg[c + N * k0])) {
+        double sumd = 0.0;
+        for (int h = 0; h < 24; ++h) sumd += a.sTg[c + N * (k0 + h)];
+        Tzd = sumd / 24.0;
+    }
+    // (snowdayan's NA test looks at the FIRST step of the whole series, cpp:4700; a chunk sees its own days only: the
+    // first step of the day — equal unless a cell's ground-snow temperature turns NA part way, which gridmodelsnow never does)
+    const double meanD = a.meanD[c];
+    const SiteK site = site_derive(a.slope[c], a.aspect[c]);
+    const double pai = a.pai[c], paia = a.paia[c], leafd = a.leafd[c], clump = a.clump[c], ltra = a.leaft[c],
+                 leafden = a.leafden[c], svfa = a.skyview[c];
+    const double mxtc = *a.mxtc1;
+    for (int h = 0; h < 24; ++h) {
+        const int64_t o = c + N * (k0 + h);          // chunk-local
+        const int f = sub * 24 + h;                   // step of the snow-day subset series
+        if (!(a.swe[o] > 0.0)) {                      // cpp:4993
+            if (!keep)
+                for (int i = 0; i < MCF_NOUT; ++i) if (q.has[i]) put(i, h, NA);
+            continue;
+        }
+        const double reqhgts = a.reqhgt - a.sdepg[o];
+        double v[MCF_NOUT];
+        if (reqhgts >= 0.0) {
+            const StepRow& r = a.rows[f];
+            const SunT sun = r.s;
+            MicroIn mi;
+            mi.si = solar_index(sun, site, true);
+            if (isnan(mi.si)) mi.si = sun.cz;                          // cpp:5002
+            mi.shadowmask = a.hor[(int64_t)r.sindex * N + c] > sun.tansa ? 0 : 1;
+            mi.ws = a.wsa[(int64_t)r.windex * N + c];
+            mi.reqhgt = reqhgts; mi.zref = a.zref;
+            mi.tc = a.temp[f]; mi.relhum = a.relhum[f]; mi.pk = a.pres[f]; mi.u2 = a.windspeed[f];
+            mi.Rsw = a.swdown[f]; mi.Rdif = a.difrad[f]; mi.Rlw = a.lwdown[f]; mi.umu = a.umu[f];
+            mi.hgt = hgt; mi.pai = pai; mi.paia = paia; mi.leafd = leafd; mi.clump = clump; mi.ltra = ltra;
+            mi.leafden = leafden; mi.svfa = svfa; mi.mxtc = mxtc;
+            mi.Tg = a.sTg[o]; mi.Tc = a.sTc[o]; mi.sden = a.sden[o]; mi.sdepg = a.sdepg[o];
+            mi.sdepc = a.swe[o] / mi.sden;
+            mi.alb = r.m.alb;
+            const MicroOut mo = micro_above(mi, sun);
+            v[0] = mo.Tz; v[1] = mo.tleaf; v[2] = mo.rh; v[4] = mo.uz; v[5] = mo.Rbdown; v[6] = mo.Rddown;
+            v[7] = mo.Rlwdn; v[8] = mo.Rdup; v[9] = mo.Rlwup;
+        } else {
+            const double b = micro_below(reqhgts, meanD, a.sTg[o], Tzd, a.mat, a.hiy);
+            v[0] = b; v[1] = b; v[2] = 100.0;
+            v[4] = v[5] = v[6] = v[7] = v[8] = v[9] = 0.0;
+        }
+        v[3] = a.Smax ? a.Smax[c] : 0.0;
+#pragma unroll
+        for (int i = 0; i < MCF_NOUT; ++i) {
+            if (!q.has[i]) continue;
+            if (q.sel[i]) put(i, h, v[i]);
+            else if (!keep) put(i, h, NA);
+        }
+    }
+}
+
 // ---- .snowmodel1's chunk loop (R/internal.R "int:" 2553-2617) ---------------------------------------
 // albedo clock restarted at every chunk start: each gridmodelsnow1 call runs snowalbCpp on its own slice
 __global__ void k_snow_alb_chunks(StepRow* rows, const double* precip, int tsteps, int chunk, int nchunks) {
@@ -610,7 +738,8 @@ struct Events {   // timing events released on every exit path
 struct Bufs {
     std::vector<void*> p;
     int64_t bytes = 0;
-    ~Bufs() { for (void* q : p) (void)hipFree(q); }
+    ~Bufs() { release_all(); }
+    void release_all() { for (void* q : p) (void)hipFree(q); p.clear(); bytes = 0; }
     int alloc(void** out, int64_t n) {
         if (n <= 0) n = 8;
         hipError_t e = hipMalloc(out, (size_t)n);
@@ -933,6 +1062,19 @@ struct mcf_snowplan {
     int prepared = -1;
     double t_terrain = 0, t_model = 0;   // ms, MCF_TIMING
     mcf::TerrainWork twork;              // terrain_device's scratch, kept across the chunks
+    // initial hand-over state, for mcf_snowplan_reset (the snow-day microclimate needs a second pass over the series)
+    double* d_isnowdc0 = nullptr;
+    int32_t *d_ac0 = nullptr, *d_ag0 = nullptr;
+    // gridmicrosnow1 inside the chunk loop (mcf_snowplan_micro_*)
+    double *d_sumD = nullptr, *d_meanD = nullptr;
+    int32_t* d_sden_na = nullptr;        // the subset series' first snow density is NA (cpp:4716)
+    int64_t sumD_steps = 0;
+    bool micro_ready = false;
+    Bufs mb;                             // the micro set-up's own buffers
+    MicroArgs ma;
+    int32_t outsel[MCF_NOUT] = {};
+    std::vector<int32_t> sub_of_day;     // absolute day -> day of the snow-day subset series, or -1
+    int32_t *d_daymap = nullptr, *d_nosnow = nullptr;     // [chunk days]
     ~mcf_snowplan() { twork.release(); }
 };
 
@@ -991,6 +1133,14 @@ extern "C" int mcf_snowplan_create(const mcf_snowdriver_in* din, int64_t row0, i
     { const double* t; UP(t, in->other.isnowdc, N); sp->d_isnowdc = const_cast<double*>(t); }
     { const int32_t* t; UP(t, in->other.isnowac, N); sp->d_ac = const_cast<int32_t*>(t); }
     { const int32_t* t; UP(t, in->other.isnowag, N); sp->d_ag = const_cast<int32_t*>(t); }
+    { const double* t; UP(t, in->other.isnowdc, N); sp->d_isnowdc0 = const_cast<double*>(t); }
+    { const int32_t* t; UP(t, in->other.isnowac, N); sp->d_ac0 = const_cast<int32_t*>(t); }
+    { const int32_t* t; UP(t, in->other.isnowag, N); sp->d_ag0 = const_cast<int32_t*>(t); }
+    if ((rc = b.alloc((void**)&sp->d_sumD, N * 8))) return rc;
+    if ((rc = b.alloc((void**)&sp->d_meanD, N * 8))) return rc;
+    if ((rc = b.alloc((void**)&sp->d_sden_na, N * 4))) return rc;
+    if ((rc = b.alloc((void**)&sp->d_daymap, (sp->chunk / 24 + 1) * 4))) return rc;
+    if ((rc = b.alloc((void**)&sp->d_nosnow, (sp->chunk / 24 + 1) * 4))) return rc;
     if ((rc = b.alloc((void**)&sp->d_dtms, N * 8))) return rc;
     if ((rc = b.alloc((void**)&sp->d_slope, N * 8))) return rc;
     if ((rc = b.alloc((void**)&sp->d_aspect, N * 8))) return rc;
@@ -1337,6 +1487,128 @@ extern "C" int mcf_tpicalc(int64_t rows, int64_t cols, const double* dtm, int32_
     hipLaunchKernelGGL(k_scale_by_mean, dim3(gridN), dim3(256), 0, nullptr, d_t, N, (const double*)d_m2);
     S_TRY(hipGetLastError());
     S_TRY(hipMemcpy(tpic, d_t, (size_t)N * 8, hipMemcpyDeviceToHost));
+    return MCF_OK;
+}
+
+// ---- the snow-day microclimate inside the chunk loop --------------------------------------------------------------------
+extern "C" int mcf_snowplan_reset(mcf_snowplan* sp) {
+    if (!sp) return mcf::api_fail(MCF_ERR_ARG, "null snow plan");
+    S_TRY(hipSetDevice(sp->device));
+    const int64_t N = sp->N;
+    S_TRY(hipMemcpy(sp->d_isnowdc, sp->d_isnowdc0, (size_t)N * 8, hipMemcpyDeviceToDevice));
+    S_TRY(hipMemcpy(sp->d_ac, sp->d_ac0, (size_t)N * 4, hipMemcpyDeviceToDevice));
+    S_TRY(hipMemcpy(sp->d_ag, sp->d_ag0, (size_t)N * 4, hipMemcpyDeviceToDevice));
+    hipLaunchKernelGGL(k_add_snow, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, nullptr, sp->d_dtm, sp->d_isnowdg, 1.0, N,
+                       sp->d_dtms);
+    S_TRY(hipGetLastError());
+    sp->prepared = -1;
+    return MCF_OK;
+}
+extern "C" int mcf_snowplan_meand_accumulate(mcf_snowplan* sp, int32_t ch, const int32_t* snowday) {
+    if (!sp || !snowday) return mcf::api_fail(MCF_ERR_ARG, "null argument");
+    if (ch < 0 || ch >= sp->nchunks) return mcf::api_fail(MCF_ERR_ARG, "chunk out of range");
+    S_TRY(hipSetDevice(sp->device));
+    const int ns = std::min(sp->chunk, sp->T - ch * sp->chunk), nd = ns / 24;
+    int nsnow = 0;
+    for (int d = 0; d < nd; ++d) nsnow += snowday[d] != 0;
+    if (ch == 0 || sp->sumD_steps < 0) sp->sumD_steps = 0;
+    if (ch == 0) S_TRY(hipMemset(sp->d_sumD, 0, (size_t)sp->N * 8));
+    if (ch == 0) S_TRY(hipMemset(sp->d_sden_na, 0, (size_t)sp->N * 4));
+    if (nsnow == 0) return MCF_OK;
+    S_TRY(hipMemcpy(sp->d_daymap, snowday, (size_t)nd * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_meand_accumulate, dim3((unsigned)((sp->N + 255) / 256)), dim3(256), 0, nullptr, sp->a.sden, sp->a.hgt,
+                       sp->N, nd, (const int32_t*)sp->d_daymap, sp->sumD_steps == 0 ? 1 : 0, sp->d_sumD, sp->d_sden_na);
+    S_TRY(hipGetLastError());
+    sp->sumD_steps += (int64_t)nsnow * 24;
+    return MCF_OK;
+}
+extern "C" int mcf_snowplan_micro_setup(mcf_snowplan* sp, const mcf_snow_inputs* sub, const int32_t* sub_of_day, int32_t ndays,
+                                        double reqhgt, double mat, const int32_t outsel[MCF_NOUT]) {
+    if (!sp || !sub || !sub_of_day || !outsel) return mcf::api_fail(MCF_ERR_ARG, "null argument");
+    int rc;
+    if ((rc = common_checks(sub))) return rc;
+    if (sub->array_forcing) return mcf::api_fail(MCF_ERR_ARG, "the snow plan takes data.frame (vector) climate");
+    if (sub->rows != sp->rows || sub->cols != sp->cols) return mcf::api_fail(MCF_ERR_ARG, "micro set-up: the raster is not the plan's");
+    if (ndays * 24 > sp->T) return mcf::api_fail(MCF_ERR_ARG, "micro set-up: more days than the series");
+    if (outsel[MCF_OUT_SOILM] && !sub->other.Smax) return mcf::api_fail(MCF_ERR_ARG, "soilm requested but other$Smax is null");
+    S_TRY(hipSetDevice(sp->device));
+    sp->mb.release_all();
+    sp->micro_ready = false;
+    const int64_t N = sp->N;
+    const int T = (int)sub->tsteps;
+    for (int d = 0; d < ndays; ++d)
+        if (sub_of_day[d] >= 0 && (int64_t)sub_of_day[d] * 24 + 24 > T) return mcf::api_fail(MCF_ERR_ARG, "micro set-up: day map points past the subset series");
+    sp->sub_of_day.assign(sub_of_day, sub_of_day + ndays);
+    Bufs& b = sp->mb;
+    MicroArgs& a = sp->ma;
+    memset(&a, 0, sizeof a);
+    a.N = N; a.tsteps = T; a.reqhgt = reqhgt; a.mat = mat; a.zref = sub->other.zref;
+    const int y0 = sub->obstime.year[0];
+    a.hiy = (y0 % 4 == 0 && (y0 % 100 != 0 || y0 % 400 == 0)) ? 366 * 24 : 365 * 24;   // cpp:4984
+    UP(a.pai, sub->vegp.pai, N);
+    UP(a.hgt, sub->vegp.hgt, N);
+    UP(a.leaft, sub->vegp.leaft, N);
+    UP(a.clump, sub->vegp.clump, N);
+    UP(a.paia, sub->vegp.paia, N);
+    UP(a.leafd, sub->vegp.leafd, N);
+    UP(a.leafden, sub->vegp.leafden, N);
+    UP(a.slope, sub->other.slope, N);
+    UP(a.aspect, sub->other.aspect, N);
+    UP(a.skyview, sub->other.skyview, N);
+    UP(a.wsa, sub->other.wsa, 8 * N);
+    UP(a.hor, sub->other.hor, 24 * N);
+    if (outsel[MCF_OUT_SOILM]) UP(a.Smax, sub->other.Smax, N);
+    if ((rc = build_step_tables(b, sub, false, false, false, &a.rows, &a.dates, &a.mxtc1))) return rc;
+    UP(a.temp, sub->clim.temp, T);
+    UP(a.relhum, sub->clim.relhum, T);
+    UP(a.pres, sub->clim.pres, T);
+    UP(a.swdown, sub->clim.swdown, T);
+    UP(a.difrad, sub->clim.difrad, T);
+    UP(a.lwdown, sub->clim.lwdown, T);
+    UP(a.windspeed, sub->clim.windspeed, T);
+    UP(a.precip, sub->clim.precip, T);
+    UP(a.umu, sub->clim.umu, T);
+    // the chunk's snow series, where mcf_snowplan_run_chunk leaves them (sdepc holds totalSWE after the redistribution)
+    a.sTc = sp->a.Tc; a.sTg = sp->a.Tg; a.swe = sp->a.sdepc; a.sdepg = sp->a.sdepg; a.sden = sp->a.sden;
+    // meanDsnow of the first pass (mcf_snowplan_meand_accumulate over every chunk)
+    hipLaunchKernelGGL(k_meand_finish, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, nullptr, (const double*)sp->d_sumD,
+                       (const int32_t*)sp->d_sden_na, a.hgt, N, (double)std::max<int64_t>(sp->sumD_steps, 1), sp->d_meanD);
+    S_TRY(hipGetLastError());
+    a.meanD = sp->d_meanD;
+    memcpy(sp->outsel, outsel, sizeof sp->outsel);
+    S_TRY(hipDeviceSynchronize());
+    sp->micro_ready = true;
+    return MCF_OK;
+}
+extern "C" int mcf_snowplan_microsnow(mcf_snowplan* sp, mcf_plan* plan, int32_t ch, int32_t slot, const int32_t* nosnowday) {
+    if (!sp || !plan || !nosnowday) return mcf::api_fail(MCF_ERR_ARG, "null argument");
+    if (!sp->micro_ready) return mcf::api_fail(MCF_ERR_STATE, "snow plan: mcf_snowplan_micro_setup first");
+    if (ch < 0 || ch >= sp->nchunks) return mcf::api_fail(MCF_ERR_ARG, "chunk out of range");
+    MicroRingArgs q;
+    memset(&q, 0, sizeof q);
+    hipStream_t stream;
+    int64_t N;
+    int device, slot_days, rc;
+    if ((rc = mcf::plan_ring_views(plan, slot, q.out, q.has, &stream, &N, &device, &slot_days))) return rc;
+    if (N != sp->N || device != sp->device) return mcf::api_fail(MCF_ERR_ARG, "snow plan and solver plan differ in raster or device");
+    const int ns = std::min(sp->chunk, sp->T - ch * sp->chunk), nd = ns / 24, day0 = ch * (sp->chunk / 24);
+    if (nd > slot_days) return mcf::api_fail(MCF_ERR_ARG, "the ring slot holds fewer days than a snow chunk");
+    if (day0 + nd > (int)sp->sub_of_day.size()) return mcf::api_fail(MCF_ERR_ARG, "chunk past the day map of the micro set-up");
+    S_TRY(hipSetDevice(sp->device));
+    int any = 0;
+    for (int d = 0; d < nd; ++d) any |= sp->sub_of_day[day0 + d] >= 0;
+    if (!any) return MCF_OK;
+    // (the snow kernels run on the null stream, which orders itself against the plan's non-blocking stream only through the
+    // explicit waits here: the solver's launches of this chunk first, this kernel before the plan's next use of the slot)
+    S_TRY(hipStreamSynchronize(stream));
+    S_TRY(hipMemcpy(sp->d_daymap, sp->sub_of_day.data() + day0, (size_t)nd * 4, hipMemcpyHostToDevice));
+    S_TRY(hipMemcpy(sp->d_nosnow, nosnowday, (size_t)nd * 4, hipMemcpyHostToDevice));
+    q.m = sp->ma;
+    for (int v = 0; v < MCF_NOUT; ++v) q.sel[v] = sp->outsel[v];
+    q.daymap = sp->d_daymap; q.nosnow = sp->d_nosnow; q.ndays = nd;
+    hipLaunchKernelGGL(k_microsnow_ring, dim3((unsigned)((N * nd + 255) / 256)), dim3(256), 0, nullptr, q);
+    S_TRY(hipGetLastError());
+    S_TRY(hipDeviceSynchronize());
     return MCF_OK;
 }
 

@@ -693,6 +693,30 @@ class SnowPlan:
     def run_chunk(self, chunk: int, tpic_mean: float):
         _abi.check(self._lib.mcf_snowplan_run_chunk(self._p, int(chunk), float(tpic_mean), C.byref(self._out)))
 
+    # ---- the snow-day microclimate inside the chunk loop (include/mcf.h: two passes over the year) ------------------
+    def reset(self):
+        """Back to the series' start (hand-over depths, ages, snow surface): the second pass."""
+        _abi.check(self._lib.mcf_snowplan_reset(self._p))
+
+    def meand_accumulate(self, chunk: int, snowday):
+        sd = np.ascontiguousarray(snowday, dtype=np.int32)
+        _abi.check(self._lib.mcf_snowplan_meand_accumulate(self._p, int(chunk), sd.ctypes.data_as(_abi.c_int32_p)))
+
+    def micro_setup(self, reqhgt, obstime, climdata, vegp, other, mat, out, sub_of_day):
+        """gridmicrosnow1's inputs for the snow-day SUBSET series (what `.prepsnowinputs1` hands it: subset weather incl.
+        umu, `.sortl2` vegetation, bare-ground terrain + Smax) and, per day of the whole series, its day in the subset
+        (-1: not a snow day)."""
+        m = marshal_snow(obstime, climdata, vegp, other, False, micro=True)
+        sod = np.ascontiguousarray(sub_of_day, dtype=np.int32)
+        sel = (C.c_int32 * _abi.NOUT)(*[1 if v else 0 for v in out])
+        _abi.check(self._lib.mcf_snowplan_micro_setup(self._p, C.byref(m.inputs), sod.ctypes.data_as(_abi.c_int32_p),
+                                                      int(sod.size), float(reqhgt), float(mat), C.byref(sel)))
+
+    def microsnow(self, plan, chunk: int, slot: int, nosnowday):
+        """gridmicrosnow1 on the chunk's snow days, written over the solver's outputs in ring slot `slot` of `plan`."""
+        nd = np.ascontiguousarray(nosnowday, dtype=np.int32)
+        _abi.check(self._lib.mcf_snowplan_microsnow(self._p, plan._p, int(chunk), int(slot), nd.ctypes.data_as(_abi.c_int32_p)))
+
 
 def _dev_piece(t, cols):
     """(rows, device pointer) of a halo piece held as a torch tensor [cols, h] on the GPU"""

@@ -1,0 +1,116 @@
+"""`.runmicrosnow1` (R/internal.R:3581-3659) device-resident: the snow chunk loop, the grid solver on the no-snow days and
+gridmicrosnow1 on the snow days, merged in the solver's ring slot chunk by chunk (include/mcf.h mcf_snowplan_micro_*), against
+the same thing orchestrated on the host through the one-shot entry points — whole-series snow arrays in host memory, the
+solver and gridmicrosnow1 on day SUBSETS, `merge_snow_outputs` — which is how the reference does it and what
+tests/test_frontend_gpu.py holds against the vignette's figures."""
+import numpy as np
+import pytest
+
+from microclimf_amd import snow as S
+from microclimf_amd import synthetic
+from microclimf_amd.api import Plan, runmicro1Cpp
+
+pytestmark = pytest.mark.gpu
+NAMES = ("Tz", "tleaf", "relhum", "soilm", "windspeed", "Rdirdown", "Rdifdown", "Rlwdown", "Rswup", "Rlwup")
+ARGS = ("obstime", "climdata", "pointm", "vegp", "soilc", "reqhgt", "zref", "lat", "lon", "Sminp", "Smaxp", "tfact",
+        "complete", "mat", "out")
+
+
+def _steps(days0):
+    return (np.repeat(np.asarray(days0) * 24, 24) + np.tile(np.arange(24), len(days0))).astype(np.int64)
+
+
+def _sub(d, idx):
+    return {k: (np.asarray(v)[idx] if np.ndim(v) == 1 else v) for k, v in d.items()}
+
+
+@pytest.mark.parametrize("reqhgt,cold,doy", [(0.05, 0.0, 90), (0.3, -3.0, 20), (0.0, 3.0, 120)])
+def test_device_resident_snow_run_equals_the_host_orchestrated_merge(reqhgt, cold, doy):
+    """(the settings give, over 20 days: snow-only, mixed and snow-free days around a melt-out; snow somewhere on every day
+    with snow-free cells on most; tools/scan_snow_days.py lists the day classes.  Settings in which a day is in NEITHER
+    class — a melted pack leaves a negative rounding residue, so that max <= 0 and min != 0 — are avoided: the reference's
+    merge indexes past its array there, R/internal.R:3650-3655.)"""
+    rows, cols, ndays = 22, 13, 20
+    T = ndays * 24
+    sw = synthetic.snow_workload(rows, cols, T, cold=cold, zref=3.5, start_doy=doy)
+    a = synthetic.workload(rows, cols, T, reqhgt=reqhgt, zref=3.5, hgt_range=(0.05, 3.0), start_doy=doy, variety=True)
+    _, _, dtm = synthetic.rasters(rows, cols)
+    dtm = np.where(np.isnan(sw["vegp"]["hgt"]), np.nan, dtm)
+    mat = 7.5
+    outm = [1] * 10 if reqhgt > 0 else [1 if i in (0, 3, 5, 6, 7, 8, 9) else 0 for i in range(10)]
+
+    with S.SnowPlan(sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"], sw["other"], sw["snowenv"], dtm, 1.0, 0.02,
+                    keep_results=True) as sp, Plan(**a, ring_days=5, ring_slots=2) as plan:
+        # ---- pass 1: the snow series, the day classes, the running sum behind the mean snow damping depth
+        snowday, nosnowday = np.zeros(ndays, np.int32), np.zeros(ndays, np.int32)
+
+        def chunk(ch):
+            ss, sn = sp.surface_partial()
+            ts, tn = sp.prepare_chunk(ch, None, 0, 0, ss / sn)
+            sp.run_chunk(ch, ts / tn)
+            mx, _ = sp.apply3(ch, "max")
+            mn, _ = sp.apply3(ch, "min")
+            return S.snowdaysfun(mx, mn)
+
+        for ch in range(sp.chunks):
+            d = chunk(ch)
+            snowday[ch * 5:ch * 5 + 5], nosnowday[ch * 5:ch * 5 + 5] = d["snowdays"], d["nosnowdays"]
+            sp.meand_accumulate(ch, d["snowdays"])
+        smod = {k: v.copy() for k, v in sp.result.items()}
+        assert snowday.sum() >= 3 and nosnowday.sum() >= 3 and (snowday & nosnowday).sum() >= 1, (snowday, nosnowday)
+        sdays, ndays_ = np.flatnonzero(snowday), np.flatnonzero(nosnowday)
+
+        # ---- the reference's orchestration on the host
+        ni = _steps(ndays_)
+        an = dict(a, obstime=_sub(a["obstime"], ni), climdata=_sub(a["climdata"], ni), pointm=_sub(a["pointm"], ni))
+        moutn = runmicro1Cpp(*[an[k] for k in ARGS])
+        si = _steps(sdays)
+        micro = {}
+        s1 = np.arange(si.size)[np.repeat(np.isin(sdays, ndays_), 24)]
+        s2 = np.arange(ni.size)[np.repeat(np.isin(ndays_, sdays), 24)]
+        for k, v in moutn.items():
+            m = np.full((rows, cols, si.size), np.nan, order="F")
+            m[:, :, s1] = v[:, :, s2]
+            micro[k] = m
+        swe = smod["totalSWE"].copy()
+        swe[np.isnan(swe)] = 0.0
+        swe[np.isnan(dtm)] = np.nan
+        smods = {k: np.asfortranarray((swe if k == "totalSWE" else v)[:, :, si]) for k, v in smod.items()}
+        subw = _sub(sw["climdata"], si)
+        mouts = S.gridmicrosnow1(reqhgt, _sub(sw["obstime"], si), subw, smods, micro, sw["vegp"], sw["other"], mat, outm)
+        for k in moutn:
+            if k not in mouts:
+                mouts[k] = micro[k]
+        want = S.merge_snow_outputs(moutn, mouts, sdays + 1, ndays_ + 1, rows, cols)
+
+        # ---- pass 2 on the device
+        sub_of_day = np.full(ndays, -1, np.int32)
+        sub_of_day[sdays] = np.arange(sdays.size)
+        sp.micro_setup(reqhgt, _sub(sw["obstime"], si), subw, sw["vegp"], sw["other"], mat, outm, sub_of_day)
+        plan.set_mxtc(float(np.max(a["climdata"]["temp"][ni])))
+        sp.reset()
+        got = {k: np.full((rows, cols, T), np.nan, order="F") for k in moutn}
+        for ch in range(sp.chunks):
+            d = chunk(ch)
+            assert np.array_equal(d["snowdays"], snowday[ch * 5:ch * 5 + 5])          # the second pass repeats the first
+            slot = ch % 2
+            nos = d["nosnowdays"]
+            k = 0
+            while k < 5:
+                if not nos[k]:
+                    k += 1
+                    continue
+                e = k
+                while e < 5 and nos[e]:
+                    e += 1
+                plan.run_days_at(ch * 5 + k, e - k, slot, k)
+                k = e
+            sp.microsnow(plan, ch, slot, nos)
+            for kname in got:
+                got[kname][:, :, ch * 120:(ch + 1) * 120] = plan.fetch(slot, kname, 0, 120)
+    for k in want:
+        g, w = got[k], want[k]
+        assert np.array_equal(np.isnan(g), np.isnan(w)), k
+        fin = np.isfinite(w)
+        if fin.any():        # (reqhgt == 0: tleaf and relhum are NA throughout)
+            assert np.max(np.abs(g[fin] - w[fin]) / (1 + np.abs(w[fin]))) < 1e-12, k
