@@ -569,8 +569,10 @@ int mcf_snowplan_apply3(mcf_snowplan *plan, int32_t chunk, int32_t fun, double *
  * The slot then holds `.runmicrosnow1`'s merged output for the chunk's days. */
 int mcf_snowplan_reset(mcf_snowplan *plan);
 int mcf_snowplan_meand_accumulate(mcf_snowplan *plan, int32_t chunk, const int32_t *snowday /* [days of the chunk] */);
+/* reuse_static != 0: the vegetation, terrain and Smax matrices of the previous set-up stay (only the series and the day map
+ * are new). */
 int mcf_snowplan_micro_setup(mcf_snowplan *plan, const mcf_snow_inputs *subset, const int32_t *subset_day_of_day,
-                             int32_t ndays, double reqhgt, double mat, const int32_t out[MCF_NOUT]);
+                             int32_t ndays, double reqhgt, double mat, const int32_t out[MCF_NOUT], int32_t reuse_static);
 int mcf_snowplan_microsnow(mcf_snowplan *plan, mcf_plan *solver, int32_t chunk, int32_t slot,
                            const int32_t *nosnowday /* [days of the chunk] */);
 

@@ -267,7 +267,7 @@ def load() -> C.CDLL:
         lib.mcf_snowplan_meand_accumulate.argtypes = [P, C.c_int32, c_int32_p]
         lib.mcf_snowplan_micro_setup.restype = C.c_int
         lib.mcf_snowplan_micro_setup.argtypes = [P, C.POINTER(SnowInputs), c_int32_p, C.c_int32, C.c_double, C.c_double,
-                                                 C.POINTER(C.c_int32 * NOUT)]
+                                                 C.POINTER(C.c_int32 * NOUT), C.c_int32]
         lib.mcf_snowplan_microsnow.restype = C.c_int
         lib.mcf_snowplan_microsnow.argtypes = [P, P, C.c_int32, C.c_int32, c_int32_p]
     lib.mcf_plan_belowground.restype = C.c_int

@@ -436,8 +436,8 @@ __global__ __launch_bounds__(256) void k_meand_finish(const double* __restrict__
 // chunk day's place in it, -1: not a snow day); m.sTc ... m.sden the chunk's series, chunk-local steps.
 struct MicroRingArgs {
     MicroArgs m;
-    mcf::RingView out[MCF_NOUT];
-    int32_t has[MCF_NOUT];       // the plan holds the variable
+    mcf::RingView ring;          // the slot's geometry (base unused)
+    double* obase[MCF_NOUT];     // each held variable's base in the slot, null: the plan does not hold it
     int32_t sel[MCF_NOUT];       // gridmicrosnow1's `out` mask
     const int32_t *daymap, *nosnow;
     int32_t ndays;
@@ -454,15 +454,18 @@ __global__ __launch_bounds__(256) void k_microsnow_ring(MicroRingArgs q) {
     if (sub < 0) return;
     const bool keep = q.nosnow[day] != 0;        // the solver ran this day: snow-free cell-steps keep its values
     const double NA = na_real();
-    auto put = [&](int i, int h, double v) {
-        const_cast<double*>(q.out[i].base)[q.out[i].index(c, day * 24 + h)] = v;
-    };
+    // the cell's place in the ring: its tile's block of this day, then the solver's lane position of (cell, hour)
+    const int cpb = q.ring.cpb;
+    const uint32_t tile = (uint32_t)c / (uint32_t)cpb;
+    const int cell = (int)((uint32_t)c - tile * (uint32_t)cpb);
+    const int64_t blk = (int64_t)tile * q.ring.tile_stride + (int64_t)day * q.ring.day_stride;
+    auto put = [&](int i, int h, double v) { q.obase[i][blk + mcf::ring_pos(cpb, cell, h)] = v; };
     const double hgt = a.hgt[c];
     const int k0 = day * 24;
     if (isnan(hgt)) {            // cpp:4988-4989: the cell is skipped — the blank template's NA unless the solver wrote it
         if (!keep)
             for (int h = 0; h < 24; ++h)
-                for (int i = 0; i < MCF_NOUT; ++i) if (q.has[i]) put(i, h, NA);
+                for (int i = 0; i < MCF_NOUT; ++i) if (q.obase[i]) put(i, h, NA);
         return;
     }
     double Tzd = NA;
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(256) void k_microsnow_ring(MicroRingArgs q) {
         const int f = sub * 24 + h;                   // step of the snow-day subset series
         if (!(a.swe[o] > 0.0)) {                      // cpp:4993
             if (!keep)
-                for (int i = 0; i < MCF_NOUT; ++i) if (q.has[i]) put(i, h, NA);
+                for (int i = 0; i < MCF_NOUT; ++i) if (q.obase[i]) put(i, h, NA);
             continue;
         }
         const double reqhgts = a.reqhgt - a.sdepg[o];
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(256) void k_microsnow_ring(MicroRingArgs q) {
         v[3] = a.Smax ? a.Smax[c] : 0.0;
 #pragma unroll
         for (int i = 0; i < MCF_NOUT; ++i) {
-            if (!q.has[i]) continue;
+            if (!q.obase[i]) continue;
             if (q.sel[i]) put(i, h, v[i]);
             else if (!keep) put(i, h, NA);
         }
@@ -1070,7 +1073,8 @@ struct mcf_snowplan {
     int32_t* d_sden_na = nullptr;        // the subset series' first snow density is NA (cpp:4716)
     int64_t sumD_steps = 0;
     bool micro_ready = false;
-    Bufs mb;                             // the micro set-up's own buffers
+    Bufs mb, mbs;                        // the micro set-up's buffers: per-call (series) and static (vegetation, terrain)
+    bool micro_static = false;
     MicroArgs ma;
     int32_t outsel[MCF_NOUT] = {};
     std::vector<int32_t> sub_of_day;     // absolute day -> day of the snow-day subset series, or -1
@@ -1523,7 +1527,7 @@ extern "C" int mcf_snowplan_meand_accumulate(mcf_snowplan* sp, int32_t ch, const
     return MCF_OK;
 }
 extern "C" int mcf_snowplan_micro_setup(mcf_snowplan* sp, const mcf_snow_inputs* sub, const int32_t* sub_of_day, int32_t ndays,
-                                        double reqhgt, double mat, const int32_t outsel[MCF_NOUT]) {
+                                        double reqhgt, double mat, const int32_t outsel[MCF_NOUT], int32_t reuse_static) {
     if (!sp || !sub || !sub_of_day || !outsel) return mcf::api_fail(MCF_ERR_ARG, "null argument");
     int rc;
     if ((rc = common_checks(sub))) return rc;
@@ -1534,6 +1538,11 @@ extern "C" int mcf_snowplan_micro_setup(mcf_snowplan* sp, const mcf_snow_inputs*
     S_TRY(hipSetDevice(sp->device));
     sp->mb.release_all();
     sp->micro_ready = false;
+    // reuse_static: vegetation, terrain and Smax are those of the previous set-up (a year's day list changes, the raster does
+    // not) — 45 matrices that are not uploaded again
+    const bool keep_static = reuse_static && sp->micro_static;
+    const MicroArgs prev = sp->ma;
+    if (!keep_static) { sp->mbs.release_all(); sp->micro_static = false; }
     const int64_t N = sp->N;
     const int T = (int)sub->tsteps;
     for (int d = 0; d < ndays; ++d)
@@ -1545,19 +1554,28 @@ extern "C" int mcf_snowplan_micro_setup(mcf_snowplan* sp, const mcf_snow_inputs*
     a.N = N; a.tsteps = T; a.reqhgt = reqhgt; a.mat = mat; a.zref = sub->other.zref;
     const int y0 = sub->obstime.year[0];
     a.hiy = (y0 % 4 == 0 && (y0 % 100 != 0 || y0 % 400 == 0)) ? 366 * 24 : 365 * 24;   // cpp:4984
-    UP(a.pai, sub->vegp.pai, N);
-    UP(a.hgt, sub->vegp.hgt, N);
-    UP(a.leaft, sub->vegp.leaft, N);
-    UP(a.clump, sub->vegp.clump, N);
-    UP(a.paia, sub->vegp.paia, N);
-    UP(a.leafd, sub->vegp.leafd, N);
-    UP(a.leafden, sub->vegp.leafden, N);
-    UP(a.slope, sub->other.slope, N);
-    UP(a.aspect, sub->other.aspect, N);
-    UP(a.skyview, sub->other.skyview, N);
-    UP(a.wsa, sub->other.wsa, 8 * N);
-    UP(a.hor, sub->other.hor, 24 * N);
-    if (outsel[MCF_OUT_SOILM]) UP(a.Smax, sub->other.Smax, N);
+    if (keep_static) {
+        a.pai = prev.pai; a.hgt = prev.hgt; a.leaft = prev.leaft; a.clump = prev.clump; a.paia = prev.paia; a.leafd = prev.leafd;
+        a.leafden = prev.leafden; a.slope = prev.slope; a.aspect = prev.aspect; a.skyview = prev.skyview; a.wsa = prev.wsa;
+        a.hor = prev.hor; a.Smax = prev.Smax;
+        if (outsel[MCF_OUT_SOILM] && !a.Smax) return mcf::api_fail(MCF_ERR_ARG, "micro set-up: soilm was not part of the static set-up being reused");
+    } else {
+        Bufs& b = sp->mbs;       // (shadows the series' buffer set: these uploads outlive the next set-up)
+        UP(a.pai, sub->vegp.pai, N);
+        UP(a.hgt, sub->vegp.hgt, N);
+        UP(a.leaft, sub->vegp.leaft, N);
+        UP(a.clump, sub->vegp.clump, N);
+        UP(a.paia, sub->vegp.paia, N);
+        UP(a.leafd, sub->vegp.leafd, N);
+        UP(a.leafden, sub->vegp.leafden, N);
+        UP(a.slope, sub->other.slope, N);
+        UP(a.aspect, sub->other.aspect, N);
+        UP(a.skyview, sub->other.skyview, N);
+        UP(a.wsa, sub->other.wsa, 8 * N);
+        UP(a.hor, sub->other.hor, 24 * N);
+        if (sub->other.Smax) UP(a.Smax, sub->other.Smax, N);
+        sp->micro_static = true;
+    }
     if ((rc = build_step_tables(b, sub, false, false, false, &a.rows, &a.dates, &a.mxtc1))) return rc;
     UP(a.temp, sub->clim.temp, T);
     UP(a.relhum, sub->clim.relhum, T);
@@ -1589,7 +1607,14 @@ extern "C" int mcf_snowplan_microsnow(mcf_snowplan* sp, mcf_plan* plan, int32_t 
     hipStream_t stream;
     int64_t N;
     int device, slot_days, rc;
-    if ((rc = mcf::plan_ring_views(plan, slot, q.out, q.has, &stream, &N, &device, &slot_days))) return rc;
+    mcf::RingView views[MCF_NOUT];
+    int32_t has[MCF_NOUT];
+    if ((rc = mcf::plan_ring_views(plan, slot, views, has, &stream, &N, &device, &slot_days))) return rc;
+    for (int v = 0; v < MCF_NOUT; ++v) {
+        q.obase[v] = has[v] ? const_cast<double*>(views[v].base) : nullptr;
+        if (has[v]) q.ring = views[v];
+    }
+    if (q.ring.cpb <= 0) return mcf::api_fail(MCF_ERR_STATE, "the snow-day microclimate needs a plan with the tiled ring (reqhgt >= 0)");
     if (N != sp->N || device != sp->device) return mcf::api_fail(MCF_ERR_ARG, "snow plan and solver plan differ in raster or device");
     const int ns = std::min(sp->chunk, sp->T - ch * sp->chunk), nd = ns / 24, day0 = ch * (sp->chunk / 24);
     if (nd > slot_days) return mcf::api_fail(MCF_ERR_ARG, "the ring slot holds fewer days than a snow chunk");

@@ -702,15 +702,30 @@ class SnowPlan:
         sd = np.ascontiguousarray(snowday, dtype=np.int32)
         _abi.check(self._lib.mcf_snowplan_meand_accumulate(self._p, int(chunk), sd.ctypes.data_as(_abi.c_int32_p)))
 
-    def micro_setup(self, reqhgt, obstime, climdata, vegp, other, mat, out, sub_of_day):
+    def micro_setup(self, reqhgt, obstime, climdata, vegp, other, mat, out, sub_of_day, reuse_static: bool = False):
         """gridmicrosnow1's inputs for the snow-day SUBSET series (what `.prepsnowinputs1` hands it: subset weather incl.
         umu, `.sortl2` vegetation, bare-ground terrain + Smax) and, per day of the whole series, its day in the subset
-        (-1: not a snow day)."""
-        m = marshal_snow(obstime, climdata, vegp, other, False, micro=True)
+        (-1: not a snow day).  `reuse_static`: the matrices (vegp, other) of the previous set-up stay on the device — only the
+        series and the day map are new."""
+        if reuse_static and getattr(self, "_micro_static", None) is not None:
+            m = self._micro_static                     # the marshalled matrices (kept alive; not uploaded again)
+            T = len(np.asarray(obstime["year"]))
+            si = m.inputs
+            si.tsteps = m.tsteps = T
+            si.obstime.year = m.i32(obstime["year"], (T,), "obstime$year")
+            si.obstime.month = m.i32(obstime["month"], (T,), "obstime$month")
+            si.obstime.day = m.i32(obstime["day"], (T,), "obstime$day")
+            si.obstime.hour = m.f64(obstime["hour"], (T,), "obstime$hour")
+            for f in _abi.SNOW_CLIM_FIELDS:
+                src = _get(climdata, *(("precip", "prec") if f == "precip" else (f,)))
+                setattr(si.clim, f, m.f64(src, (T,), f"climdata${f}"))
+        else:
+            m = marshal_snow(obstime, climdata, vegp, other, False, micro=True)
+            self._micro_static = m
         sod = np.ascontiguousarray(sub_of_day, dtype=np.int32)
         sel = (C.c_int32 * _abi.NOUT)(*[1 if v else 0 for v in out])
         _abi.check(self._lib.mcf_snowplan_micro_setup(self._p, C.byref(m.inputs), sod.ctypes.data_as(_abi.c_int32_p),
-                                                      int(sod.size), float(reqhgt), float(mat), C.byref(sel)))
+                                                      int(sod.size), float(reqhgt), float(mat), C.byref(sel), 1 if reuse_static else 0))
 
     def microsnow(self, plan, chunk: int, slot: int, nosnowday):
         """gridmicrosnow1 on the chunk's snow days, written over the solver's outputs in ring slot `slot` of `plan`."""

@@ -8,11 +8,17 @@ One "step" = one simulated year of a rank's block through the reference's snow p
     -> terrain refresh from dtm + snow depth (slope, aspect, 24 horizons, sky view, 8 wind-shelter maps), tpic
     -> (sum, count) all-reduce of tpic -> gridmodelsnow1 on the chunk (k_snowmodel) -> redistribution, hand-over
     -> applycpp3 min / max of totalSWE per step on the device, all-reduced over the ranks (R/internal.R:3592-3593)
-    -> snowdaysfun: the chunk's no-snow days -> the grid solver (k_solve) on exactly those days, into the output ring
-  (gridmicrosnow1, the correction of the solver's output on snow days, has a host-pointer ABI only and is not part of
-  the timed pipeline; tools/snow_rate.py times it.)
-value = valid cells x 8760 / seconds: every cell-step went through the snowpack model, and through the solver unless its
-day had snow everywhere."""
+    -> snowdaysfun: the chunk's snow / no-snow days
+The reference (`.runmicrosnow1`, R/internal.R:3581-3659) then solves the no-snow days with the grid solver, the snow days with
+gridmicrosnow1 (src/microclimfCpp.cpp:4894-5056) and merges by day — with the year's snow series in memory.  Here they exist
+one chunk at a time, and gridmicrosnow1 needs the per-cell mean snow damping depth of the WHOLE snow-day series (cpp:4713-4737)
+and the day list itself before its first step, so the year is walked TWICE (include/mcf.h mcf_snowplan_micro_*):
+  pass 1  the chunk loop above + the running sum behind the mean damping depth
+  between gridmicrosnow1's set-up for the snow-day subset, the solver's maximum temperature over the no-snow subset, reset
+  pass 2  the chunk loop again (without apply3) + k_solve on the chunk's no-snow days at their place in the ring slot +
+          k_microsnow_ring: the snow-day microclimate written over it — the slot holds `.runmicrosnow1`'s merged output
+value = valid cells x 8760 / seconds of BOTH passes: every cell-step went through the snowpack model twice, and through the
+solver or gridmicrosnow1 (or both, on days that have snow somewhere and bare cells elsewhere)."""
 from __future__ import annotations
 
 import json
@@ -84,7 +90,7 @@ def run_snow_config(args, world, rank, local_rank):
     s, n = plan.twi_partial()
     plan.set_twi_mean(allreduce_twi_mean(s, float(n)))
     valid = plan.valid_cells
-    stats = {"solver_days": 0, "snow_days": 0}
+    stats = {"solver_days": 0, "snow_days": 0, "years": 0}
 
     def fence():
         plan.sync()
@@ -105,27 +111,62 @@ def run_snow_config(args, world, rank, local_rank):
         stage_s[name] = stage_s.get(name, 0.0) + now - t_last
         return now
 
+    def snow_chunk(ch):
+        tl = time.perf_counter()
+        # the surface never leaves the device: its 128 boundary rows go point-to-point to the neighbouring ranks
+        pn, ps = halo.exchange() if halo is not None else (halo_n, halo_s)
+        tl = lap("halo", tl)
+        ss, sn = sp.surface_partial()
+        smean = allreduce_twi_mean(ss, sn)                      # (sum, count) -> mean over the whole raster
+        ts, tn = sp.prepare_chunk_dev(ch, pn, ps, smean)
+        tl = lap("terrain+tpic", tl)
+        sp.run_chunk(ch, allreduce_twi_mean(ts, tn))
+        return lap("snowmodel+redistribute", tl)
+
+    def steps_of(days0):
+        return (np.repeat(np.asarray(days0, dtype=np.int64) * 24, 24) + np.tile(np.arange(24), len(days0))).astype(np.int64)
+
+    def sub(d, idx):
+        return {k: (np.asarray(v)[idx] if np.ndim(v) == 1 else v) for k, v in d.items()}
+
+    outm = [1] * 10 if args.reqhgt > 0 else [1 if i in (0, 3, 5, 6, 7, 8, 9) else 0 for i in range(10)]
+    ncd = sp.chunks * chunk_days
+
     def one_year():
-        slot = 0
+        # ---- pass 1: snow series chunk by chunk -> day classes, running sum of the snow damping depth
+        snowday, nosnowday = np.zeros(ncd, np.int32), np.zeros(ncd, np.int32)
         for ch in range(sp.chunks):
-            tl = time.perf_counter()
-            # the surface never leaves the device: its 128 boundary rows go point-to-point to the neighbouring ranks
-            pn, ps = halo.exchange() if halo is not None else (halo_n, halo_s)
-            tl = lap("halo", tl)
-            ss, sn = sp.surface_partial()
-            smean = allreduce_twi_mean(ss, sn)                      # (sum, count) -> mean over the whole raster
-            ts, tn = sp.prepare_chunk_dev(ch, pn, ps, smean)
-            tl = lap("terrain+tpic", tl)
-            sp.run_chunk(ch, allreduce_twi_mean(ts, tn))
-            tl = lap("snowmodel+redistribute", tl)
+            tl = snow_chunk(ch)
             mx, cmx = sp.apply3(ch, "max")
             mn, cmn = sp.apply3(ch, "min")
             mx, mn = allreduce_apply3(mx, cmx, "max"), allreduce_apply3(mn, cmn, "min")
             days = snowdaysfun(mx, mn)
-            tl = lap("apply3", tl)
             d0 = ch * chunk_days
-            nos = days["nosnowdays"]
-            stats["snow_days"] += int(days["snowdays"].sum())
+            snowday[d0:d0 + chunk_days], nosnowday[d0:d0 + chunk_days] = days["snowdays"], days["nosnowdays"]
+            tl = lap("apply3", tl)
+            sp.meand_accumulate(ch, days["snowdays"])
+            tl = lap("meanD", tl)
+        # ---- between: gridmicrosnow1's set-up on the snow-day subset, the solver's maximum temperature on the no-snow subset
+        tl = time.perf_counter()
+        sdays, ndays_ = np.flatnonzero(snowday), np.flatnonzero(nosnowday)
+        stats["snow_days"] += int(sdays.size)
+        if sdays.size:
+            si = steps_of(sdays)
+            sod = np.full(ncd, -1, np.int32)
+            sod[sdays] = np.arange(sdays.size)
+            sp.micro_setup(args.reqhgt, sub(sw["obstime"], si), sub(sw["climdata"], si), sw["vegp"], sw["other"], 7.5, outm, sod,
+                           reuse_static=stats["years"] > 0)       # vegetation / terrain matrices go up once per plan
+        stats["years"] += 1
+        if ndays_.size:
+            plan.set_mxtc(float(np.max(a["climdata"]["temp"][steps_of(ndays_[ndays_ < ndays])])))
+        sp.reset()
+        tl = lap("micro set-up", tl)
+        # ---- pass 2: the series again + the solver on the no-snow days + the snow-day microclimate over it
+        slot = 0
+        for ch in range(sp.chunks):
+            tl = snow_chunk(ch)
+            d0 = ch * chunk_days
+            nos = nosnowday[d0:d0 + chunk_days]
             k = 0
             while k < len(nos):                                       # runs of consecutive no-snow days -> one launch each
                 if not nos[k]:
@@ -136,10 +177,13 @@ def run_snow_config(args, world, rank, local_rank):
                     e += 1
                 if d0 + k < ndays:
                     nd = min(e, ndays - d0) - k
-                    plan.run_days(d0 + k, nd, slot)
+                    plan.run_days_at(d0 + k, nd, slot, k)
                     stats["solver_days"] += nd
                 k = e
             tl = lap("solver", tl)
+            if sdays.size:
+                sp.microsnow(plan, ch, slot, nos)
+            tl = lap("microsnow", tl)
             slot = (slot + 1) % 2
 
     for _ in range(args.warmup):
@@ -155,7 +199,9 @@ def run_snow_config(args, world, rank, local_rank):
     value = valid_all * ndays * 24 * args.steps / dt
     if rank == 0:
         sd = stats["solver_days"] / max(args.steps, 1)
-        alg = valid_all * 24 * (ndays * 40.0 + sd * 80.05) * args.steps          # 5 snow series + 10 solver outputs per cell-step
+        snd = stats["snow_days"] / max(args.steps, 1)
+        # 5 snow series per cell-step in each of the two passes + 10 outputs per cell-step of a solver day or a snow day
+        alg = valid_all * 24 * (2 * ndays * 40.0 + (sd + snd) * 80.05) * args.steps
         line = {
             "metric": "cell-steps/s", "value": value, "unit": "cell-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
@@ -163,7 +209,8 @@ def run_snow_config(args, world, rank, local_rank):
             "config": {
                 "workload": f"{rows_total}x{cols} synthetic DTM in {nblocks} row blocks, {world} of them solved by {world} GPU(s), {T} hourly "
                             "steps, snow branch: `.snowmodel1` chunk loop (terrain refresh from dtm + snow every 5 days, gridmodelsnow1, "
-                            "`.tpicalc` redistribution) + applycpp3 min/max of totalSWE + the grid solver on the no-snow days "
+                            "`.tpicalc` redistribution) + applycpp3 min/max of totalSWE, walked twice; the grid solver on the no-snow days, "
+                            "gridmicrosnow1 on the snow days, merged in the device ring as `.runmicrosnow1` does "
                             "[BASELINE.json configs[4]]",
                 "baseline_config": 4, "rows_per_gpu": rows, "cols": cols, "tsteps": T, "valid_cells": int(valid_all),
                 "solver_days_per_year": sd, "snow_days_per_year": stats["snow_days"] / max(args.steps, 1),
@@ -172,14 +219,17 @@ def run_snow_config(args, world, rank, local_rank):
                         "generated, not exchanged: the neighbouring blocks' snow-free surface, resident on the device (a rank's share of "
                         "the partition without its neighbours)" if not exchange_ok else "single block",
                 "collectives": "per chunk: 2 (sum, count) all-reduces + min / max all-reduce of [120] doubles; once: twi (sum, count)",
-                "not_timed": "gridmicrosnow1 (host-pointer ABI only)",
+                "passes": "2 over the snow series (gridmicrosnow1 needs the whole series' mean snow damping depth and day list first)",
+                "verified": "not in this run: the snow surface feeds neighbourhood operators (terrain, tpi), so a sample of cells cannot be "
+                            "re-run by the oracle; tests/test_snow_micro_pipeline_gpu.py and tests/test_snow_gpu.py hold the same calls "
+                            "against the host-orchestrated route and the oracle on small rasters",
                 "sink": "solver: HBM ring (2 slots x 5 days); snow series: chunk buffers on the device, no D2H",
             },
             "input_setup_s": setup_s,
             "stage_seconds": stage_s or None,
             "roofline": {"bound": "fp64_valu", "achieved": alg / dt / 1e9, "peak": 8000.0 * world, "unit": "GB/s",
-                         "frac": alg / dt / 1e9 / (8000.0 * world), "traffic": None, "kernel": "pipeline: k_snowmodel + terrain + k_solve",
-                         "frac_is": "algorithmic bytes (40 B per snow cell-step + 80 B per solver cell-step) / time / 8 TB/s per GPU"},
+                         "frac": alg / dt / 1e9 / (8000.0 * world), "traffic": None, "kernel": "pipeline: 2 x (k_snowmodel + terrain) + k_solve + k_microsnow_ring",
+                         "frac_is": "algorithmic bytes (2 x 40 B per snow cell-step + 80 B per solver or snow-microclimate cell-step) / time / 8 TB/s per GPU"},
         }
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
