@@ -154,6 +154,11 @@ typedef struct mcf_grid_inputs {
      * es, ea, tdew come from the UNcorrected temperature, as in the reference. */
     int32_t coarse_altcorrect;
     const double *coarse_dtm, *fine_dtm;
+    /* 0 or rows: dense arrays.  > rows: every raster array above ([rows, cols(, layers | steps)]: vegp, soilc, wsa, hor, lats,
+     * lons, fine_dtm, the array-forcing series) AND the output arrays of the one-shot entry points are row blocks of a
+     * taller column-major raster with `row_pitch` rows — read and written in place (how mcf_runmicro1_multi hands a block
+     * to a device without copying the host arrays). */
+    int64_t row_pitch;
 } mcf_grid_inputs;
 
 typedef struct mcf_options {
@@ -181,6 +186,21 @@ int mcf_device_count(void);
 /* One-shot host-to-host solves. */
 int mcf_runmicro1(const mcf_grid_inputs *in, const mcf_options *opt, mcf_outputs *out);
 int mcf_runmicro2(const mcf_grid_inputs *in, const mcf_options *opt, mcf_outputs *out);
+/* The same solves on several devices of one node from ONE process — the R drop-in's way to a multi-GPU node (R has no
+ * torch.distributed): the raster is cut into `n_blocks` contiguous row blocks of about equal valid-cell count (boundaries
+ * on multiples of 10 rows; R/internal.R:909-925 is the reference's own tiling), block b goes to devices[b % n_devices],
+ * one host thread per device.  The solver's one global reduction (mean of log(twi)/tfact, src/microclimfCpp.cpp:993-1004)
+ * is taken over the whole raster first and installed in every block, so the result is bit for bit the single-device one.
+ * n_devices = 0: every visible device; n_blocks = 0: one block per device (more blocks than devices are time-sliced).
+ * Static vegetation only. */
+typedef struct mcf_multi {
+    int32_t n_devices;
+    const int32_t *devices;
+    int32_t n_blocks;
+} mcf_multi;
+int mcf_runmicro1_multi(const mcf_grid_inputs *in, const mcf_options *opt, const mcf_multi *multi, mcf_outputs *out);
+int mcf_runmicro2_multi(const mcf_grid_inputs *in, const mcf_options *opt, const mcf_multi *multi, mcf_outputs *out);
+
 /* Time-varying vegetation: replace _microclimf_runmicro3Cpp / _microclimf_runmicro4Cpp
  * (src/RcppExports.cpp:300-322 / 326-348; bodies src/microclimfCpp.cpp:2624-2924 / 2926-3226).
  * Same physics with the vegetation layer chosen per day from `dfsel`; steps outside every
@@ -233,6 +253,9 @@ int mcf_plan_sync(mcf_plan *plan);
  * step `step0` within the slot) to host memory. */
 int mcf_plan_fetch(mcf_plan *plan, int32_t slot, int32_t var, int64_t step0,
                    int64_t nsteps, double *host_dst);
+/* ... into a row block of a taller column-major array (row_pitch rows per column; 0 = dense). */
+int mcf_plan_fetch_pitched(mcf_plan *plan, int32_t slot, int32_t var, int64_t step0,
+                           int64_t nsteps, double *host_dst, int64_t row_pitch);
 /* Sparse read-back for verification and point queries: `nsteps` steps of variable `var` for the `ncells`
  * cells listed in `cells` (0-based column-major cell indices i + rows*j, any order), gathered on the device
  * and returned as host_dst[ci + ncells*k].  Moves ncells*nsteps values instead of a whole [rows,cols,nsteps]

@@ -54,7 +54,13 @@ class GridInputs(C.Structure):
                 ("coarse_rows", C.c_int32), ("coarse_cols", C.c_int32),
                 ("coarse_rowpos", c_double_p), ("coarse_colpos", c_double_p),
                 ("coarse_relhum", c_double_p), ("coarse_winddir", c_double_p),
-                ("coarse_altcorrect", C.c_int32), ("coarse_dtm", c_double_p), ("fine_dtm", c_double_p)]
+                ("coarse_altcorrect", C.c_int32), ("coarse_dtm", c_double_p), ("fine_dtm", c_double_p),
+                ("row_pitch", C.c_int64)]
+
+
+class Multi(C.Structure):
+    """include/mcf.h mcf_multi: devices and row blocks of the one-process multi-device entry points."""
+    _fields_ = [("n_devices", C.c_int32), ("devices", c_int32_p), ("n_blocks", C.c_int32)]
 
 
 class Options(C.Structure):
@@ -166,6 +172,7 @@ EXPORTS = (
     "mcf_plan_set_twi_mean", "mcf_plan_upload_forcing_days", "mcf_plan_run_days",
     "mcf_plan_belowground", "mcf_plan_sync", "mcf_plan_fetch", "mcf_plan_fetch_cells", "mcf_plan_fetch_packed", "mcf_plan_slot_ptr",
     "mcf_plan_ring_layout", "mcf_ring_index", "mcf_plan_run_days_at", "mcf_plan_set_mxtc",
+    "mcf_runmicro1_multi", "mcf_runmicro2_multi", "mcf_plan_fetch_pitched",
     "mcf_snowplan_reset", "mcf_snowplan_meand_accumulate", "mcf_snowplan_micro_setup", "mcf_snowplan_microsnow",
     "mcf_plan_timer_start", "mcf_plan_timer_stop", "mcf_plan_kernel_timing",
     "mcf_plan_kernel_stats", "mcf_plan_dispatch_stats", "mcf_plan_valid_cells", "mcf_plan_bytes", "mcf_selftest_math",
@@ -257,6 +264,11 @@ def load() -> C.CDLL:
     lib.mcf_plan_run_days.restype = C.c_int
     lib.mcf_plan_run_days.argtypes = [P, C.c_int32, C.c_int32, C.c_int32]
     if hasattr(lib, "mcf_plan_run_days_at"):     # (absent from an older library named by MCF_LIB for an A/B run)
+        for fn in (lib.mcf_runmicro1_multi, lib.mcf_runmicro2_multi):
+            fn.restype = C.c_int
+            fn.argtypes = [GI, OP, C.POINTER(Multi), OU]
+        lib.mcf_plan_fetch_pitched.restype = C.c_int
+        lib.mcf_plan_fetch_pitched.argtypes = [P, C.c_int32, C.c_int32, C.c_int64, C.c_int64, c_double_p, C.c_int64]
         lib.mcf_plan_run_days_at.restype = C.c_int
         lib.mcf_plan_run_days_at.argtypes = [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
         lib.mcf_plan_set_mxtc.restype = C.c_int

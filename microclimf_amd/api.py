@@ -24,11 +24,19 @@ from .marshal import Marshalled, alloc_outputs, marshal
 
 
 def _run(fn_name, array_forcing, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon,
-         Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block, dfsel=None, coarse=None):
+         Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block, dfsel=None, coarse=None,
+         devices=None, n_blocks=0):
     lib = _abi.load()
     m = marshal(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp,
                 tfact, complete, mat, out, array_forcing, device, days_per_chunk, cells_per_block, dfsel, coarse)
     outs, arrays = alloc_outputs(m)
+    if devices is not None or n_blocks:
+        # one process, several devices (include/mcf.h mcf_runmicro1_multi): row blocks dealt to the listed devices
+        mu = _abi.Multi()
+        devs = np.ascontiguousarray([] if devices is None else list(devices), dtype=np.int32)
+        mu.n_devices, mu.devices, mu.n_blocks = int(devs.size), devs.ctypes.data_as(_abi.c_int32_p), int(n_blocks)
+        _abi.check(getattr(lib, fn_name + "_multi")(C.byref(m.inputs), C.byref(m.options), C.byref(mu), C.byref(outs)))
+        return arrays
     _abi.check(getattr(lib, fn_name)(C.byref(m.inputs), C.byref(m.options), C.byref(outs)))
     return arrays
 
@@ -36,23 +44,24 @@ def _run(fn_name, array_forcing, obstime, climdata, pointm, vegp, soilc, reqhgt,
 def runmicro1Cpp(obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Mapping, soilc: Mapping,
                  reqhgt: float, zref: float, lat: float, lon: float, Sminp: float, Smaxp: float,
                  tfact: float, complete: bool, mat: float, out: Sequence, *, device: int = 0,
-                 days_per_chunk: int = 0, cells_per_block: int = 0) -> dict:
+                 days_per_chunk: int = 0, cells_per_block: int = 0, devices=None, n_blocks: int = 0) -> dict:
     """Grid microclimate model, hourly, static vegetation, data.frame (vector) climate.
 
-    Drop-in for the reference's runmicro1Cpp (src/microclimfCpp.cpp:2052-2337)."""
+    Drop-in for the reference's runmicro1Cpp (src/microclimfCpp.cpp:2052-2337).  `devices` (a list of HIP ordinals, [] =
+    all visible) / `n_blocks`: the raster in row blocks over several devices from this one process, same bits."""
     return _run("mcf_runmicro1", False, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon,
-                Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block)
+                Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block, devices=devices, n_blocks=n_blocks)
 
 
 def runmicro2Cpp(obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Mapping, soilc: Mapping,
                  reqhgt: float, zref: float, lats, lons, Sminp: float, Smaxp: float, tfact: float,
                  complete: bool, mat: float, out: Sequence, *, device: int = 0,
-                 days_per_chunk: int = 0, cells_per_block: int = 0) -> dict:
+                 days_per_chunk: int = 0, cells_per_block: int = 0, devices=None, n_blocks: int = 0) -> dict:
     """Grid microclimate model, hourly, static vegetation, array climate inputs.
 
-    Drop-in for the reference's runmicro2Cpp (src/microclimfCpp.cpp:2340-2621)."""
+    Drop-in for the reference's runmicro2Cpp (src/microclimfCpp.cpp:2340-2621); `devices` / `n_blocks` as runmicro1Cpp."""
     return _run("mcf_runmicro2", True, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons,
-                Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block)
+                Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block, devices=devices, n_blocks=n_blocks)
 
 
 def coarse_positions(n_fine: int, n_coarse: int):

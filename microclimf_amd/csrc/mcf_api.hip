@@ -15,6 +15,7 @@
 #include <future>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mcf.h"
@@ -60,6 +61,7 @@ struct mcf_plan {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int64_t rows = 0, cols = 0, N = 0, tsteps = 0;
+    int64_t pitch = 0;      // rows of the (taller) column-major raster the host arrays are blocks of; = rows: dense
     int ndays = 0;
     bool af = false, bg = false;
     bool coarse = false;                 // array_forcing == 2: coarse arrays interpolated in the solver
@@ -179,12 +181,20 @@ mcf::RingView ring_view(const mcf_plan* p, int slot, int var) {
     return v;
 }
 
-int upload(mcf_plan* p, const double* host, int64_t n, const double** dev, const char* name) {
+// host [rows x ncols] with leading dimension p->pitch -> dense device memory (and the other way): plain copies for dense hosts
+hipError_t copy_in(mcf_plan* p, void* dev, const double* host, int64_t ncols) {
+    if (p->pitch == p->rows) return hipMemcpyAsync(dev, host, (size_t)(p->rows * ncols) * 8, hipMemcpyHostToDevice, p->stream);
+    return hipMemcpy2DAsync(dev, (size_t)p->rows * 8, host, (size_t)p->pitch * 8, (size_t)p->rows * 8, (size_t)ncols,
+                            hipMemcpyHostToDevice, p->stream);
+}
+// `spatial`: n = rows x (cols x layers) values of a raster array (read with the plan's row pitch); else a plain vector
+int upload(mcf_plan* p, const double* host, int64_t n, const double** dev, const char* name, bool spatial = true) {
     if (!host) return fail(MCF_ERR_ARG, std::string("missing input array: ") + name);
     void* d = nullptr;
     int rc = dalloc(p, &d, n * 8);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(d, host, (size_t)n * 8, hipMemcpyHostToDevice, p->stream));
+    if (spatial && p->pitch != p->rows) HIP_TRY(copy_in(p, d, host, n / p->rows));
+    else HIP_TRY(hipMemcpyAsync(d, host, (size_t)n * 8, hipMemcpyHostToDevice, p->stream));
     *dev = (const double*)d;
     return MCF_OK;
 }
@@ -427,6 +437,8 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
     HIP_TRY(hipEventCreate(&p->ev0));
     HIP_TRY(hipEventCreate(&p->ev1));
     p->rows = in->rows; p->cols = in->cols; p->N = in->rows * in->cols; p->tsteps = in->tsteps;
+    p->pitch = in->row_pitch > 0 ? in->row_pitch : in->rows;
+    if (p->pitch < p->rows) return fail(MCF_ERR_ARG, "row_pitch smaller than rows");
     p->ndays = (int)(in->tsteps / 24);                       // cpp:2116 truncation
     p->af = in->array_forcing != 0;
     p->coarse = in->array_forcing == 2;
@@ -490,8 +502,8 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
     }
     std::vector<double> cpk_sea;     // coarse pressure reduced to sea level (altitude correction)
     if (p->coarse) {
-        if ((rc = upload(p, in->coarse_rowpos, in->rows, &p->d_crowpos, "coarse_rowpos"))) return rc;
-        if ((rc = upload(p, in->coarse_colpos, in->cols, &p->d_ccolpos, "coarse_colpos"))) return rc;
+        if ((rc = upload(p, in->coarse_rowpos, in->rows, &p->d_crowpos, "coarse_rowpos", false))) return rc;
+        if ((rc = upload(p, in->coarse_colpos, in->cols, &p->d_ccolpos, "coarse_colpos", false))) return rc;
         if (p->altcorrect) {
             // R/internal.R:1236-1241: psl = pk / ((293 - 0.0065 zc) / 293)^5.26 on the coarse grid, back up with the
             // fine elevation after resampling; elevd = resample(dtmc) - dtm
@@ -506,13 +518,13 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
                     const int r0 = (int)fr, r1 = r0 + 1 < cr ? r0 + 1 : r0;
                     const double top = (1.0 - wx) * zc[(size_t)(r0 + cr * c0)] + wx * zc[(size_t)(r0 + cr * c1)];
                     const double bot = (1.0 - wx) * zc[(size_t)(r1 + cr * c0)] + wx * zc[(size_t)(r1 + cr * c1)];
-                    const double z = in->fine_dtm[i + in->rows * j];
+                    const double z = in->fine_dtm[i + p->pitch * j];
                     elevd[(size_t)(i + in->rows * j)] = ((1.0 - wy) * top + wy * bot) - z;
                     pkfac[(size_t)(i + in->rows * j)] = pow((293.0 - 0.0065 * z) / 293.0, 5.26);
                 }
             }
-            if ((rc = upload(p, elevd.data(), N, &p->d_elevd, "elevd"))) return rc;
-            if ((rc = upload(p, pkfac.data(), N, &p->d_pkfac, "pkfac"))) return rc;
+            if ((rc = upload(p, elevd.data(), N, &p->d_elevd, "elevd", false))) return rc;
+            if ((rc = upload(p, pkfac.data(), N, &p->d_pkfac, "pkfac", false))) return rc;
             HIP_TRY(hipStreamSynchronize(p->stream));
             if (in->tsteps > 0 && in->clim.pk) {
                 const int64_t cN = (int64_t)cr * cc;
@@ -524,7 +536,8 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
         }
     }
     int64_t nvalid = 0;
-    for (int64_t c = 0; c < N; ++c) nvalid += !std::isnan(in->vegp.hgt[c]);
+    for (int64_t j = 0; j < in->cols; ++j)
+        for (int64_t i = 0; i < in->rows; ++i) nvalid += !std::isnan(in->vegp.hgt[i + p->pitch * j]);
     p->valid_cells = nvalid;
 
     // ---- solver constants
@@ -685,8 +698,7 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
             if ((rc = up_tmp(nullptr, slab_steps * N * 8, &dslab))) return rc;
             for (int64_t k0 = 0; k0 < T; k0 += slab_steps) {
                 int64_t ns = std::min(slab_steps, T - k0);
-                HIP_TRY(hipMemcpyAsync(dslab, in->clim.tc + N * k0, (size_t)(ns * N * 8), hipMemcpyHostToDevice,
-                                       p->stream));
+                HIP_TRY(copy_in(p, dslab, in->clim.tc + p->pitch * p->cols * k0, p->cols * ns));
                 mcf::launch_mxtc((const double*)dslab, N, (int)ns, p->d_mxtc, p->stream);
             }
             HIP_TRY(hipGetLastError());
@@ -738,8 +750,8 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
         p->d_scratch = (double*)tmp;
         if (!opt->complete) {
             int64_t n = p->af ? N * T : T;
-            if ((rc = upload(p, in->pointm.Tg, n, &p->d_Tgp, "pointm$Tg"))) return rc;
-            if ((rc = upload(p, in->pointm.Tbp, n, &p->d_Tbp, "pointm$Tbp"))) return rc;
+            if ((rc = upload(p, in->pointm.Tg, n, &p->d_Tgp, "pointm$Tg", p->af))) return rc;
+            if ((rc = upload(p, in->pointm.Tbp, n, &p->d_Tbp, "pointm$Tbp", p->af))) return rc;
         }
     }
     HIP_TRY(hipStreamSynchronize(p->stream));
@@ -801,8 +813,8 @@ int mcf_plan_upload_forcing_days(mcf_plan* p, const mcf_grid_inputs* in, int32_t
     for (int f = 0; f < 15; ++f) {
         // the series as the caller holds it ([rows, cols, steps]) into the staging slab, then into its tiled place on the device
         // (stream order: the next copy into the slab waits for this series' kernel)
-        const double* src = raw[f] + N * (int64_t)day0 * 24;
-        HIP_TRY(hipMemcpyAsync(p->d_force_stage, src, (size_t)n * 8, hipMemcpyHostToDevice, p->stream));
+        const double* src = raw[f] + p->pitch * p->cols * (int64_t)day0 * 24;
+        HIP_TRY(copy_in(p, p->d_force_stage, src, p->cols * (int64_t)ndays * 24));
         mcf::RingView v{};
         v.base = p->d_force + (int64_t)slot * p->force_slot_elems + (int64_t)f * mcf::ring_block_doubles(p->cpb);
         v.N = N; v.tile_stride = p->force_tile_stride; v.day_stride = p->force_day_stride; v.cpb = p->cpb;
@@ -954,7 +966,13 @@ int mcf_plan_sync(mcf_plan* p) {
 }
 
 int mcf_plan_fetch(mcf_plan* p, int32_t slot, int32_t var, int64_t step0, int64_t nsteps, double* host_dst) {
+    return mcf_plan_fetch_pitched(p, slot, var, step0, nsteps, host_dst, 0);
+}
+
+int mcf_plan_fetch_pitched(mcf_plan* p, int32_t slot, int32_t var, int64_t step0, int64_t nsteps, double* host_dst, int64_t row_pitch) {
     if (!p || !host_dst) return fail(MCF_ERR_ARG, "null argument");
+    if (row_pitch == 0) row_pitch = p->rows;
+    if (row_pitch < p->rows) return fail(MCF_ERR_ARG, "row_pitch smaller than rows");
     if (slot < 0 || slot >= p->ring_slots || var < 0 || var >= MCF_NOUT) return fail(MCF_ERR_ARG, "bad slot/var");
     if (p->var_slot[var] < 0) return fail(MCF_ERR_ARG, "variable was not requested in out[]");
     const int64_t cap_steps = (int64_t)p->ring_days * 24;
@@ -965,6 +983,12 @@ int mcf_plan_fetch(mcf_plan* p, int32_t slot, int32_t var, int64_t step0, int64_
     // large results: pinned ring + host copy threads instead of hipMemcpy's single-threaded staging
     static const bool no_pipe = getenv("MCF_NO_HOSTPIPE") != nullptr;
     auto to_host = [&](double* dst, const double* src, size_t bytes) -> int {
+        if (row_pitch != p->rows) {      // a block of a taller raster: one strided DMA, column by column into its place
+            HIP_TRY(hipMemcpy2DAsync(dst, (size_t)row_pitch * 8, src, (size_t)p->rows * 8, (size_t)p->rows * 8,
+                                     bytes / ((size_t)p->rows * 8), hipMemcpyDeviceToHost, p->stream));
+            HIP_TRY(hipStreamSynchronize(p->stream));
+            return MCF_OK;
+        }
         if (bytes >= ((size_t)64 << 20) && !no_pipe && ensure_pipe(p)) {
             HIP_TRY(hipEventRecord(p->ev_pipe, p->stream));
             HIP_TRY(p->pipe->copy(dst, src, bytes, p->ev_pipe));
@@ -988,7 +1012,7 @@ int mcf_plan_fetch(mcf_plan* p, int32_t slot, int32_t var, int64_t step0, int64_
         const int64_t n = std::min(piece, nsteps - k0);
         mcf::launch_untile(view, step0 + k0, n, p->d_stage, p->stream);
         HIP_TRY(hipGetLastError());
-        int rc = to_host(host_dst + p->N * k0, p->d_stage, (size_t)(p->N * n) * 8);
+        int rc = to_host(host_dst + row_pitch * p->cols * k0, p->d_stage, (size_t)(p->N * n) * 8);
         if (rc) return rc;
     }
     return MCF_OK;
@@ -1365,7 +1389,9 @@ int64_t mcf_plan_valid_cells(const mcf_plan* p) { return p ? p->valid_cells : 0;
 int64_t mcf_plan_bytes(const mcf_plan* p) { return p ? p->bytes : 0; }
 
 // ---- one-shot host-to-host solve ---------------------------------------------------------
-static int run_oneshot(const mcf_grid_inputs* in, const mcf_options* opt, mcf_outputs* out, int want_af) {
+// twi_mean: null, or the raster-wide mean of log(twi)/tfact to install (a row block of a larger raster, run_multi)
+static int run_oneshot(const mcf_grid_inputs* in, const mcf_options* opt, mcf_outputs* out, int want_af,
+                       const double* twi_mean = nullptr) {
     int rc = check_inputs(in, opt);
     if (rc) return rc;
     if (!out) return fail(MCF_ERR_ARG, "null outputs");
@@ -1376,6 +1402,8 @@ static int run_oneshot(const mcf_grid_inputs* in, const mcf_options* opt, mcf_ou
     rc = ensure_device(opt->device);
     if (rc) return rc;
     const int64_t N = in->rows * in->cols, T = in->tsteps;
+    // host arrays may be row blocks of a taller raster (row_pitch): a time step of an output is then pitch x cols values on
+    const int64_t pitch = in->row_pitch > 0 ? in->row_pitch : in->rows, HS = pitch * in->cols;
     const int ndays = (int)(T / 24);
     int nvars = 0;
     for (int v = 0; v < MCF_NOUT; ++v) nvars += opt->out[v] ? 1 : 0;
@@ -1400,6 +1428,7 @@ static int run_oneshot(const mcf_grid_inputs* in, const mcf_options* opt, mcf_ou
     rc = mcf_plan_create(in, opt, chunk, 1, &p);
     if (rc) return rc;
     struct Guard { mcf_plan* p; ~Guard() { mcf_plan_destroy(p); } } guard{p};
+    if (twi_mean && (rc = mcf_plan_set_twi_mean(p, *twi_mean))) return rc;
     double t_create = now() - t0;
     for (int d0 = 0; d0 < ndays; d0 += chunk) {
         int nd = std::min(chunk, ndays - d0);
@@ -1410,7 +1439,7 @@ static int run_oneshot(const mcf_grid_inputs* in, const mcf_options* opt, mcf_ou
         if (!bg) {
             for (int v = 0; v < MCF_NOUT; ++v)
                 if (opt->out[v])
-                    if ((rc = mcf_plan_fetch(p, 0, v, 0, (int64_t)nd * 24, out->var[v] + N * (int64_t)d0 * 24)))
+                    if ((rc = mcf_plan_fetch_pitched(p, 0, v, 0, (int64_t)nd * 24, out->var[v] + HS * (int64_t)d0 * 24, pitch)))
                         return rc;
         }
         if (timing) t_fetch += now() - ta;
@@ -1421,23 +1450,144 @@ static int run_oneshot(const mcf_grid_inputs* in, const mcf_options* opt, mcf_ou
     if (bg && ndays > 0) {
         for (int v = 0; v < MCF_NOUT; ++v)
             if (opt->out[v] && v != MCF_OUT_TZ)
-                if ((rc = mcf_plan_fetch(p, 0, v, 0, (int64_t)ndays * 24, out->var[v]))) return rc;
+                if ((rc = mcf_plan_fetch_pitched(p, 0, v, 0, (int64_t)ndays * 24, out->var[v], pitch))) return rc;
     }
     // steps past the last whole day are never computed by the reference and stay NA (cpp:2116)
     const double na = na_real_host();
     for (int v = 0; v < MCF_NOUT; ++v)
         if (opt->out[v])
-            for (int64_t q = N * (int64_t)ndays * 24; q < N * T; ++q) out->var[v][q] = na;
+            for (int64_t k = (int64_t)ndays * 24; k < T; ++k)
+                for (int64_t j = 0; j < in->cols; ++j)
+                    for (int64_t i = 0; i < in->rows; ++i) out->var[v][i + pitch * j + HS * k] = na;
     if (bg && opt->out[MCF_OUT_TZ] && T > 0) {
         // Tbelowgroundv runs over all tsteps (cpp:2314-2319)
         if ((rc = mcf_plan_belowground(p))) return rc;
-        if ((rc = mcf_plan_fetch(p, 0, MCF_OUT_TZ, 0, T, out->var[MCF_OUT_TZ]))) return rc;
+        if ((rc = mcf_plan_fetch_pitched(p, 0, MCF_OUT_TZ, 0, T, out->var[MCF_OUT_TZ], pitch))) return rc;
     }
     return mcf_plan_sync(p);
 }
 
+// ---- one process, several devices --------------------------------------------------------------------------------------
+// The raster is cut into contiguous row blocks holding about the same number of valid cells (boundaries on multiples of 10
+// rows, as microclimf_amd/distributed.py balanced_row_blocks); block b is solved on devices[b % n_devices] by that device's
+// host thread with its own plan and stream.  Cells are independent inside the solver; its one global reduction — the mean
+// of log(twi)/tfact over the raster (src/microclimfCpp.cpp:993-1004) — is taken over the WHOLE raster first, with the
+// kernels a single-device plan uses, and installed in every block's plan: the result is bit for bit the single-device one.
+// Host arrays are not copied: a block reads and writes its rows in place through the row pitch.
+static std::vector<std::pair<int64_t, int64_t>> row_blocks(const mcf_grid_inputs* in, int nb) {
+    const int64_t R = in->rows, pitch = in->row_pitch > 0 ? in->row_pitch : in->rows;
+    const int64_t mult = R / 10 >= nb ? 10 : 1, ng = (R + mult - 1) / mult;
+    std::vector<double> cum((size_t)ng + 1, 0.0);
+    for (int64_t j = 0; j < in->cols; ++j)
+        for (int64_t i = 0; i < R; ++i)
+            if (!std::isnan(in->vegp.hgt[i + pitch * j])) cum[(size_t)(i / mult) + 1] += 1.0;
+    for (int64_t g = 0; g < ng; ++g) cum[(size_t)g + 1] += cum[(size_t)g];
+    const double total = cum[(size_t)ng];
+    std::vector<int64_t> cuts{0};
+    for (int r = 1; r < nb; ++r) {
+        int64_t g = ng * r / nb;
+        if (total > 0) {
+            const double want = total * r / nb;
+            g = std::lower_bound(cum.begin(), cum.end(), want) - cum.begin();
+            if (g > 0 && std::fabs(cum[(size_t)g - 1] - want) <= std::fabs(cum[(size_t)std::min(g, ng)] - want)) --g;
+        }
+        g = std::min(std::max(g, cuts.back() + 1), ng - (nb - r));
+        cuts.push_back(g);
+    }
+    cuts.push_back(ng);
+    std::vector<std::pair<int64_t, int64_t>> out;
+    for (int r = 0; r < nb; ++r) {
+        const int64_t r0 = cuts[(size_t)r] * mult, r1 = std::min(cuts[(size_t)r + 1] * mult, R);
+        out.emplace_back(r0, r1 - r0);
+    }
+    return out;
+}
+
+static int run_multi(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_multi* mu, mcf_outputs* out, int want_af) {
+    int rc = check_inputs(in, opt);
+    if (rc) return rc;
+    if (!mu || !out) return fail(MCF_ERR_ARG, "null argument");
+    if (in->veg_layers > 1) return fail(MCF_ERR_ARG, "the multi-device entry points take static vegetation");
+    int ndev_avail = 0;
+    if (hipGetDeviceCount(&ndev_avail) != hipSuccess || ndev_avail <= 0)
+        return fail(MCF_ERR_NO_DEVICE, "no HIP device available (libmcfhip has no CPU fallback)");
+    std::vector<int> devs;
+    if (mu->n_devices <= 0) for (int d = 0; d < ndev_avail; ++d) devs.push_back(d);      // every visible device
+    else {
+        if (!mu->devices) return fail(MCF_ERR_ARG, "n_devices > 0 with a null device list");
+        for (int i = 0; i < mu->n_devices; ++i) {
+            if (mu->devices[i] < 0 || mu->devices[i] >= ndev_avail) return fail(MCF_ERR_ARG, "device ordinal out of range");
+            devs.push_back(mu->devices[i]);
+        }
+    }
+    int nb = mu->n_blocks > 0 ? mu->n_blocks : (int)devs.size();
+    nb = (int)std::min<int64_t>(nb, in->rows);
+    const int64_t pitch = in->row_pitch > 0 ? in->row_pitch : in->rows;
+    // ---- the one global reduction, over the whole raster, on the first device (the kernels of mcf_plan_create)
+    double twi_mean;
+    {
+        HIP_TRY(hipSetDevice(devs[0]));
+        const int64_t N = in->rows * in->cols;
+        if (!in->soilc.twi) return fail(MCF_ERR_ARG, "missing input array: twi");
+        double *d_twi = nullptr, *d_ws = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_twi, (size_t)N * 8));
+        struct G { double *&a, *&b; ~G() { (void)hipFree(a); (void)hipFree(b); } } g{d_twi, d_ws};
+        HIP_TRY(hipMalloc((void**)&d_ws, (size_t)mcf::twi_scratch_doubles() * 8));
+        HIP_TRY(hipMemcpy2D(d_twi, (size_t)in->rows * 8, in->soilc.twi, (size_t)pitch * 8, (size_t)in->rows * 8, (size_t)in->cols,
+                            hipMemcpyHostToDevice));
+        mcf::launch_twi_partial(d_twi, N, opt->tfact, d_ws, nullptr);
+        double h2[2];
+        HIP_TRY(hipMemcpy(h2, d_ws, 16, hipMemcpyDeviceToHost));
+        twi_mean = h2[0] / h2[1];
+    }
+    const auto blocks = row_blocks(in, nb);
+    std::vector<int> rcs(devs.size(), MCF_OK);
+    std::vector<std::string> errs(devs.size());
+    std::vector<std::thread> threads;
+    for (size_t t = 0; t < devs.size(); ++t) {
+        threads.emplace_back([&, t] {
+            for (int b = (int)t; b < nb; b += (int)devs.size()) {
+                const int64_t r0 = blocks[(size_t)b].first, nr = blocks[(size_t)b].second;
+                if (nr <= 0) continue;
+                mcf_grid_inputs sub = *in;
+                sub.rows = nr;
+                sub.row_pitch = pitch;
+                auto off = [&](const double*& q) { if (q) q += r0; };
+                off(sub.vegp.hgt); off(sub.vegp.pai); off(sub.vegp.x); off(sub.vegp.gsmax); off(sub.vegp.leafr); off(sub.vegp.leaft);
+                off(sub.vegp.clump); off(sub.vegp.leafd); off(sub.vegp.paia); off(sub.vegp.leafden);
+                off(sub.soilc.Smin); off(sub.soilc.Smax); off(sub.soilc.gref); off(sub.soilc.soilb); off(sub.soilc.Psie);
+                off(sub.soilc.Vq); off(sub.soilc.Vm); off(sub.soilc.Mc); off(sub.soilc.rho); off(sub.soilc.slope);
+                off(sub.soilc.aspect); off(sub.soilc.twi); off(sub.soilc.svfa); off(sub.soilc.wsa); off(sub.soilc.hor);
+                off(sub.lats); off(sub.lons); off(sub.coarse_rowpos); off(sub.fine_dtm);
+                if (in->array_forcing == 1) {
+                    off(sub.clim.tc); off(sub.clim.es); off(sub.clim.ea); off(sub.clim.tdew); off(sub.clim.pk); off(sub.clim.swdown);
+                    off(sub.clim.difrad); off(sub.clim.lwdown); off(sub.clim.windspeed);
+                    off(sub.pointm.soilm); off(sub.pointm.G); off(sub.pointm.umu); off(sub.pointm.kp); off(sub.pointm.muGp);
+                    off(sub.pointm.dtrp); off(sub.pointm.Tg); off(sub.pointm.Tbp);
+                }
+                mcf_options o = *opt;
+                o.device = devs[t];
+                mcf_outputs so = *out;
+                for (int v = 0; v < MCF_NOUT; ++v) if (so.var[v]) so.var[v] += r0;
+                const int rcb = run_oneshot(&sub, &o, &so, want_af, &twi_mean);
+                if (rcb != MCF_OK) { rcs[t] = rcb; errs[t] = g_err; return; }
+            }
+        });
+    }
+    for (auto& th : threads) th.join();
+    for (size_t t = 0; t < devs.size(); ++t)
+        if (rcs[t] != MCF_OK) return fail(rcs[t], errs[t]);
+    return MCF_OK;
+}
+
 int mcf_runmicro1(const mcf_grid_inputs* in, const mcf_options* opt, mcf_outputs* out) {
     return run_oneshot(in, opt, out, 0);
+}
+int mcf_runmicro1_multi(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_multi* multi, mcf_outputs* out) {
+    return run_multi(in, opt, multi, out, 0);
+}
+int mcf_runmicro2_multi(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_multi* multi, mcf_outputs* out) {
+    return run_multi(in, opt, multi, out, 1);
 }
 int mcf_runmicro2(const mcf_grid_inputs* in, const mcf_options* opt, mcf_outputs* out) {
     return run_oneshot(in, opt, out, 1);

@@ -8,10 +8,16 @@
 # bindings is all it takes: modelin()/runmicro()/runmicro_big()/runbioclim() above stay untouched.
 #
 # Usage (after building r/mcfhip_glue.so, see INTEGRATION.md):
-#   library(microclimf); source("r/mcfhip_overrides.R"); mcfhip_enable()
+#   library(microclimf); source("r/mcfhip_overrides.R"); mcfhip_enable()             # one GPU
+#   mcfhip_enable(devices = 0:7)                                                     # every GPU of an 8-GPU node
 
-mcfhip_enable <- function(glue = "r/mcfhip_glue.so") {
+# `devices`: HIP device ordinals (0-based) the grid solver may use from this one R session, e.g. 0:7 on an 8-GPU node — the
+# raster is dealt to them in row blocks inside libmcfhip (mcf_runmicro1_multi), results bit for bit those of one device;
+# `blocks`: more row blocks than devices (each device solves its blocks one after the other: smaller HBM footprint per block).
+mcfhip_enable <- function(glue = "r/mcfhip_glue.so", devices = NULL, blocks = NULL) {
   dyn.load(glue)
+  options(mcfhip.devices = if (is.null(devices)) NULL else as.integer(devices),
+          mcfhip.blocks = if (is.null(blocks)) NULL else as.integer(blocks))
   rm1 <- function(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, long,
                   Sminp, Smaxp, tfact, complete, mat, out)
     .Call("mcfhip_runmicro1", obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, long,

@@ -39,6 +39,7 @@ SEXP Rf_getAttrib(SEXP, SEXP);
 SEXP Rf_setAttrib(SEXP, SEXP, SEXP);
 SEXP Rf_mkChar(const char *);
 SEXP Rf_install(const char *);
+SEXP Rf_GetOption1(SEXP);
 double Rf_asReal(SEXP);
 int Rf_asInteger(SEXP);
 int Rf_asLogical(SEXP);
@@ -57,6 +58,7 @@ SEXP Rf_asChar(SEXP);
 #define setAttrib Rf_setAttrib
 #define mkChar Rf_mkChar
 #define install Rf_install
+#define GetOption1 Rf_GetOption1
 #define asReal Rf_asReal
 #define asInteger Rf_asInteger
 #define asLogical Rf_asLogical

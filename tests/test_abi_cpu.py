@@ -35,7 +35,7 @@ def test_struct_layout_matches_header():
     assert C.sizeof(_abi.Pointm) == 8 * 8
     assert C.sizeof(_abi.Vegp) == 10 * 8
     assert C.sizeof(_abi.Soilc) == 15 * 8
-    assert C.sizeof(_abi.GridInputs) == 3 * 8 + 8 + (4 + 10 + 8 + 10 + 15) * 8 + 2 * 8 + 2 * 8 + 2 * 8 + 8 + 4 * 8 + 8 + 2 * 8
+    assert C.sizeof(_abi.GridInputs) == 3 * 8 + 8 + (4 + 10 + 8 + 10 + 15) * 8 + 2 * 8 + 2 * 8 + 2 * 8 + 8 + 4 * 8 + 8 + 2 * 8 + 8     # + row_pitch
 
 
 def test_ctypes_structs_agree_with_the_compiled_header(tmp_path):

@@ -1,0 +1,50 @@
+"""One process, several devices (include/mcf.h mcf_runmicro1_multi / mcf_runmicro2_multi): the raster in row blocks, each
+block solved by its device's host thread in place through the row pitch.  On a one-GPU box the blocks are time-sliced on
+device 0 — the partition, the whole-raster twi mean installed in every block, the pitched uploads and fetches are the same
+code; the result must be the single-device one BIT FOR BIT (no scaling is measured here: unmeasured on N > 1 hardware)."""
+import numpy as np
+import pytest
+
+from microclimf_amd import synthetic
+from microclimf_amd.api import runmicro1Cpp, runmicro2Cpp
+
+pytestmark = pytest.mark.gpu
+ARGS = ("obstime", "climdata", "pointm", "vegp", "soilc", "reqhgt", "zref", "lat", "lon", "Sminp", "Smaxp", "tfact",
+        "complete", "mat", "out")
+
+
+def _bits_equal(a, b):
+    assert list(a) == list(b)
+    for k in a:
+        assert np.array_equal(a[k].view(np.uint64), b[k].view(np.uint64)), k
+
+
+@pytest.mark.parametrize("rows,cols,T,reqhgt,nb", [(67, 23, 72, 0.05, 3), (40, 31, 55, 1.0, 4), (9, 12, 48, 0.05, 9),
+                                                    (53, 17, 72, -0.08, 2), (120, 8, 24, 0.0, 5)])
+def test_row_blocks_on_one_device_equal_the_whole_raster_bitwise(rows, cols, T, reqhgt, nb):
+    a = synthetic.workload(rows, cols, T, reqhgt=reqhgt, start_doy=160, variety=True, na_frac=0.08)
+    whole = runmicro1Cpp(*[a[k] for k in ARGS])
+    parts = runmicro1Cpp(*[a[k] for k in ARGS], devices=[0], n_blocks=nb)
+    _bits_equal(whole, parts)
+
+
+def test_array_forcing_row_blocks_bitwise():
+    a = synthetic.workload(45, 19, 72, reqhgt=0.05, start_doy=170, variety=True, array_forcing=True, na_frac=0.05)
+    whole = runmicro2Cpp(*[a[k] for k in ARGS])
+    parts = runmicro2Cpp(*[a[k] for k in ARGS], devices=[0, 0], n_blocks=3)          # two host threads on the one device
+    _bits_equal(whole, parts)
+
+
+def test_a_sea_of_na_cells_moves_the_block_boundaries_not_the_result():
+    a = synthetic.workload(80, 14, 48, reqhgt=0.05, start_doy=200)
+    a["vegp"]["hgt"][:55, :] = np.nan                 # the valid cells sit in the last 25 rows
+    whole = runmicro1Cpp(*[a[k] for k in ARGS])
+    parts = runmicro1Cpp(*[a[k] for k in ARGS], devices=[0], n_blocks=4)
+    _bits_equal(whole, parts)
+
+
+def test_multi_argument_checks():
+    from microclimf_amd import McfError
+    a = synthetic.workload(12, 12, 24, reqhgt=0.05)
+    with pytest.raises(McfError, match="device ordinal"):
+        runmicro1Cpp(*[a[k] for k in ARGS], devices=[7])
