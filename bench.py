@@ -539,8 +539,10 @@ def main(argv=None):
                              "the snow kernels on one GPU")
         return run_snow_config(args, world, rank, local_rank)
     cpu_first = None
-    if world == 1 and not args.no_cpu_baseline:
-        # both CPU legs run before torch / HIP are touched: the all-cores leg forks worker processes
+    if rank == 0 and not args.no_cpu_baseline:
+        # Rank 0 (a fresh process under torch.distributed.run too) times the CPU legs before torch / HIP are touched — the
+        # all-cores leg forks worker processes; the other ranks wait for it at the process group's first barrier.  With
+        # N > 1 ranks on the box the legs share the host with the other ranks' start-up: a reported baseline, not a target.
         sys.stdout.flush()
         _saved = os.dup(1)
         os.dup2(2, 1)

@@ -29,7 +29,42 @@ import time
 import numpy as np
 
 
+def cpu_legs(args):
+    """The three kernels of the pipeline as the oracle runs them on one host core, on a bounded sample (before torch / HIP are
+    touched): gridmodelsnow1 (oracle/snow_oracle.c), the grid solver (oracle/mcf_oracle.c) and gridmicrosnow1, each over every
+    step of the sample.  run_snow_config weights them by the share of days each one covers in the measured year — the
+    reference's single pass over the snow model, its solver on the no-snow days, gridmicrosnow1 on the snow days."""
+    from microclimf_amd import synthetic
+    from oracle import oracle as O
+    r, c, t = 128, 128, 240
+    sw = synthetic.snow_workload(r, c, t, cold=3.0, zref=3.5, start_doy=1)
+    a = synthetic.workload(r, c, t, reqhgt=args.reqhgt, zref=3.5, hgt_range=(0.05, 3.0))
+    O.load()
+    t0 = time.perf_counter()
+    smod = O.run_snowmodel(sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"], sw["other"], sw["snowenv"])
+    t_snow = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.run_grid(**a)
+    t_solver = time.perf_counter() - t0
+    snowm, micro = synthetic.microsnow_inputs(sw, smod)
+    t0 = time.perf_counter()
+    O.run_microsnow(args.reqhgt, sw["obstime"], sw["climdata"], snowm, micro, sw["vegp"], sw["other"], 7.5, [1] * 10)
+    t_micro = time.perf_counter() - t0
+    n = float(np.count_nonzero(~np.isnan(sw["vegp"]["hgt"]))) * t
+    return {"cell_steps": n, "snowmodel_s": t_snow, "solver_s": t_solver, "microsnow_s": t_micro,
+            "sample": f"{r}x{c} cells x {t} hourly steps, oracle (gcc -O2, 1 thread): gridmodelsnow1 {t_snow:.1f} s, grid solver "
+                      f"{t_solver:.1f} s, gridmicrosnow1 {t_micro:.1f} s (every step of the sample each)"}
+
+
 def run_snow_config(args, world, rank, local_rank):
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        sys.stdout.flush()
+        _saved = os.dup(1)
+        os.dup2(2, 1)
+        cpu = cpu_legs(args)
+        os.dup2(_saved, 1)
+        os.close(_saved)
     sys.stdout.flush()
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
@@ -231,6 +266,12 @@ def run_snow_config(args, world, rank, local_rank):
                          "frac": alg / dt / 1e9 / (8000.0 * world), "traffic": None, "kernel": "pipeline: 2 x (k_snowmodel + terrain) + k_solve + k_microsnow_ring",
                          "frac_is": "algorithmic bytes (2 x 40 B per snow cell-step + 80 B per solver or snow-microclimate cell-step) / time / 8 TB/s per GPU"},
         }
+        if cpu is not None:
+            # one pass over the snow model for every step + the solver / gridmicrosnow1 on their shares of the year's days
+            per_cs = (cpu["snowmodel_s"] + cpu["solver_s"] * sd / ndays + cpu["microsnow_s"] * snd / ndays) / cpu["cell_steps"]
+            line["cpu_baseline"] = {"value": 1.0 / per_cs, "unit": "cell-steps/s", "cores": 1, "kind": "port",
+                                    "sample": cpu["sample"] + f"; weighted as the measured year: solver on {sd:.0f}, "
+                                              f"gridmicrosnow1 on {snd:.0f} of {ndays} days, the snow model once per step"}
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)
