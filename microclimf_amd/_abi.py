@@ -206,15 +206,32 @@ class RingLayout(C.Structure):
                 ("cells", C.c_int64), ("tile_stride", C.c_int64), ("day_stride", C.c_int64)]
 
 
-def _share_hip_runtime():
+def _needed_hip_soname(lib_path: Path):
+    """DT_NEEDED entry of libmcfhip.so that names the HIP runtime (e.g. 'libamdhip64.so.7'), read from the ELF's dynamic
+    section's strings; None if it cannot be found."""
+    import re
+    try:
+        data = lib_path.read_bytes()
+    except OSError:
+        return None
+    m = re.search(rb"libamdhip64\.so\.\d+", data)
+    return m.group(0).decode() if m else None
+
+
+def _share_hip_runtime(lib_path: Path):
     """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's); the copy
     that is loaded first serves every later user.  If libmcfhip pulled in /opt/rocm's first, a later `import torch` would
     bring a SECOND runtime into the process and find no device ("No HIP GPUs are available").  Where torch is installed but
     not imported yet, its copy is therefore loaded first — the same state as importing torch before this package.  Hosts
-    without torch (an R session) use /opt/rocm's."""
+    without torch (an R session) use /opt/rocm's.
+
+    Only when the wheel's runtime carries the SONAME libmcfhip was linked against (a different major would leave two runtimes
+    in the process after all, silently): otherwise a warning says so and nothing is preloaded.  MCF_NO_HIP_PRELOAD=1 opts out
+    (processes that will never import torch)."""
     import importlib.util
     import sys
-    if "torch" in sys.modules:
+    import warnings
+    if "torch" in sys.modules or os.environ.get("MCF_NO_HIP_PRELOAD"):
         return
     try:
         spec = importlib.util.find_spec("torch")
@@ -223,11 +240,17 @@ def _share_hip_runtime():
     if spec is None or not spec.origin:
         return
     cand = Path(spec.origin).parent / "lib" / "libamdhip64.so"
-    if cand.exists():
-        try:
-            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass
+    if not cand.exists():
+        return
+    need, have = _needed_hip_soname(lib_path), _needed_hip_soname(cand)      # (a library's own SONAME string matches too)
+    if need and have and need != have:
+        warnings.warn(f"libmcfhip is linked against {need}, the installed torch bundles {have}: not preloading torch's HIP "
+                      "runtime — import torch BEFORE microclimf_amd if both are used in this process", RuntimeWarning)
+        return
+    try:
+        C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass
 
 
 def load() -> C.CDLL:
@@ -241,7 +264,7 @@ def load() -> C.CDLL:
             f"{path} not found: the HIP extension is not built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'` or "
             "`make -C microclimf_amd/csrc`). There is no CPU fallback.")
-    _share_hip_runtime()
+    _share_hip_runtime(path)
     lib = C.CDLL(str(path))
     lib.mcf_abi_version.restype = C.c_int
     lib.mcf_last_error.restype = C.c_char_p

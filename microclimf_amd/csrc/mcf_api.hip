@@ -270,7 +270,6 @@ int ensure_cells(mcf_plan* p) {
     mcf::launch_cell_setup(a, p->stream);
     HIP_TRY(hipGetLastError());
   }
-    p->cells_ready = true;
     if (!p->af && p->day_irregular.empty() && p->ndays > 0) {
         // the per-day flags of the time table, once: kStepIrregular and kSoilDaily in TF_IDX (its last field)
         const int tfc = mcf::time_field_count();
@@ -323,6 +322,7 @@ int ensure_cells(mcf_plan* p) {
             HIP_TRY(hipMemcpy(p->d_tiles_slow, slowl.data(), slowl.size() * 4, hipMemcpyHostToDevice));
         }
     }
+    p->cells_ready = true;     // only now: a failed allocation or copy above leaves the plan to try again, not half set up
     return MCF_OK;
 }
 
