@@ -447,7 +447,8 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
         if (in->coarse_rows < 1 || in->coarse_cols < 1 || !in->coarse_rowpos || !in->coarse_colpos || !in->coarse_relhum ||
             !in->coarse_winddir)
             return fail(MCF_ERR_ARG, "coarse array forcing needs coarse_rows/cols, coarse_rowpos/colpos, coarse_relhum and coarse_winddir");
-        if ((int64_t)in->coarse_rows * in->coarse_cols > INT32_MAX / 2) return fail(MCF_ERR_ARG, "coarse grid too large");
+        // (the solver addresses a day of a coarse field with 32-bit byte offsets: 24 x cells x 8 B < 2^32)
+        if ((int64_t)in->coarse_rows * in->coarse_cols > 11000000) return fail(MCF_ERR_ARG, "coarse grid too large (more than 1.1e7 cells)");
         if (p->bg && !opt->complete) return fail(MCF_ERR_ARG, "coarse array forcing: reqhgt < 0 needs complete = 1");
         for (int64_t i = 0; i < in->rows; ++i)
             if (!(in->coarse_rowpos[i] >= 0.0 && in->coarse_rowpos[i] <= in->coarse_rows - 1))

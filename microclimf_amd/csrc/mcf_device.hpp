@@ -839,20 +839,29 @@ __device__ __forceinline__ void derive_time_af(TimeVals& t, const DateRow& dr, d
 // Bilinear tap into a coarse [crows, ccols] field: the four neighbours and weights of one raster cell, from its
 // position in coarse-grid units (clamped by the host, so that r1 / c1 fall back onto r0 / c0 at the far edges).
 struct CoarseTap {
-    int i00, i01, i10, i11;
+    uint32_t o00, o01, o10, o11;     // BYTE offsets of the four neighbours in a field: the field's base is wave-uniform, so a
+                                     // tap is global_load v, v_off, s[base:base+1] — no 64-bit vector address arithmetic
     double wx, wy;
-    __device__ __forceinline__ CoarseTap(double rowpos, double colpos, int crows, int ccols) {
+    // hour: the lane's hour of the day — `p` below is then the field at the DAY's first step (uniform over the workgroup)
+    __device__ __forceinline__ CoarseTap(double rowpos, double colpos, int crows, int ccols, int hour = 0) {
         const double fr = floor(rowpos), fc = floor(colpos);
         const int r0 = (int)fr, c0 = (int)fc;
         const int r1 = r0 + 1 < crows ? r0 + 1 : r0, c1 = c0 + 1 < ccols ? c0 + 1 : c0;
         wy = rowpos - fr;
         wx = colpos - fc;
-        i00 = r0 + crows * c0; i01 = r0 + crows * c1; i10 = r1 + crows * c0; i11 = r1 + crows * c1;
+        const uint32_t h = (uint32_t)hour * (uint32_t)(crows * ccols);       // (24 x cells x 8 B < 2^32: checked by the host)
+        o00 = 8u * (h + (uint32_t)(r0 + crows * c0)); o01 = 8u * (h + (uint32_t)(r0 + crows * c1));
+        o10 = 8u * (h + (uint32_t)(r1 + crows * c0)); o11 = 8u * (h + (uint32_t)(r1 + crows * c1));
     }
     // p: the field at one time step
     __device__ __forceinline__ double operator()(const double* __restrict__ p) const {
-        const double top = (1.0 - wx) * p[i00] + wx * p[i01];
-        const double bot = (1.0 - wx) * p[i10] + wx * p[i11];
+        uint32_t a = o00, b = o01, c = o10, d = o11;
+        asm("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));      // keeps the zero-extensions in the loads' own block (see k_solve `put`)
+        const char* q = reinterpret_cast<const char*>(p);
+        const double v00 = *reinterpret_cast<const double*>(q + a), v01 = *reinterpret_cast<const double*>(q + b),
+                     v10 = *reinterpret_cast<const double*>(q + c), v11 = *reinterpret_cast<const double*>(q + d);
+        const double top = (1.0 - wx) * v00 + wx * v01;
+        const double bot = (1.0 - wx) * v10 + wx * v11;
         return (1.0 - wy) * top + wy * bot;
     }
 };

@@ -694,8 +694,8 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
             if (AF == 2) {
                 // coarse arrays: interpolate, then derive what `.runmodel2Cpp` derives after resampling
                 // (slot TF_ES carries relhum, TF_U2 / TF_EA the wind components u, v)
-                const CoarseTap tap(C(CF_CROWPOS), C(CF_CCOLPOS), a.crows, a.ccols);
-                const double* q = a.af_base + (int64_t)a.crows * a.ccols * kabs;
+                const CoarseTap tap(C(CF_CROWPOS), C(CF_CCOLPOS), a.crows, a.ccols, hr);
+                const double* q = a.af_base + (int64_t)a.crows * a.ccols * ((int64_t)dabs * 24);     // the day's first step: uniform
                 auto at = [&](int f) { return tap(q + (int64_t)f * a.af_stride); };
                 double tc = at(TF_TC);
                 const double rh = at(TF_ES), wu = at(TF_U2), wv = at(TF_EA);
