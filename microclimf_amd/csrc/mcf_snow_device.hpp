@@ -589,7 +589,8 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const SunT& su
         double ltras = q.ltra * gexp(-10.1 * zi);
         if ((ltras + q.alb) > 0.999) ltras = 0.999 - q.alb;
         double clumps = q.clump;
-        if (q.clump > 0.0) clumps = pow(q.clump, pais / q.pai);
+        if (q.clump > 0.0) clumps = gpow0(q.clump, pais / q.pai);     // (device pow() is ~200 VALU instructions; five of them per
+                                                                      // in-canopy cell-step were a third of this function)
         double pait = pais;
         if (q.clump > 0.0) pait = pais / (1.0 - clumps);
         // twostreamdif (cpp:1034-1084) with lref = gref = snow albedo
@@ -597,8 +598,8 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const SunT& su
         const TsDif f = ts_dif(pait2, q.alb, ltras, q.alb);
         double gi = 0.0, giu = 0.0;
         if (clumps > 0.0) {
-            gi = pow(clumps, paias / pais);
-            giu = pow(clumps, (pais - paias) / pais);
+            gi = gpow0(clumps, paias / pais);
+            giu = gpow0(clumps, (pais - paias) / pais);
         }
         if (gi > 0.99) gi = 0.99;
         if (giu > 0.99) giu = 0.99;
@@ -619,10 +620,10 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const SunT& su
         if (q.Rsw > 0.0) {
             const double cosz = sun.cosz;
             if (pais > 0.0) {
-                double trbn = pow(clumps, kp.Kc);
+                double trbn = gpow0(clumps, kp.Kc);
                 if (trbn > 0.999) trbn = 0.999;
                 if (trbn < 0.0) trbn = 0.0;
-                double trb = pow(gi, kp.Kc);
+                double trb = gpow0(gi, kp.Kc);
                 if (trb > 0.999) trb = 0.999;
                 if (trb < 0.0) trb = 0.0;
                 const double ek_a = gexp(-kp.kd * paiaa);
@@ -657,9 +658,9 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const SunT& su
         double gh = 0.135 * gsqrt(uz / q.leafd) * 1.4;
         {   // mincondCpp(leafabs, 999.99, Tcan, leafd) cpp:1316-1331
             const double Rnet = leafabs - 0.97 * kSb * rad4(q.Tc);
-            const double rs = 1 / 999.99;
-            const double Hf = -1.0 / (1.0 + gexp(2.0 - 1.09767 * pow(rs, 0.2672778)));
-            double gmin = 0.0463 * pow(fabs(Hf * Rnet) / q.leafd, 0.2);
+            // Hf = -1 / (1 + exp(2 - 1.09767 * rs^0.2672778)) with rs = 1 / 999.99: a constant of the model
+            const double Hf = -0x1.1be70d7011323p-3;
+            double gmin = 0.0463 * gpow0(fabs(Hf * Rnet) / q.leafd, 0.2);
             if (gmin < 0.05) gmin = 0.05;
             if (gh < gmin) gh = gmin;
         }
