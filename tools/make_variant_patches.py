@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Regenerates tools/variants/*.patch against the current microclimf_amd/csrc/mcf_kernels.hip.
+
+The timing / ablation variants of k_solve (results wrong on purpose — only the launch time is read) are kept OUT of the
+shipped source: each is a list of (old, new) text replacements, written here as a unified diff that
+tools/build_variant.sh applies to a scratch copy of csrc/.  Run this after editing the kernel (the diffs carry context)."""
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+SRC = ROOT / "microclimf_amd" / "csrc" / "mcf_kernels.hip"
+OUT = ROOT / "tools" / "variants"
+
+P1 = '''            if (AF) pass1<F, false>(C, TR, SL, g, flags, dTmx, cy, p1, MK, cn);
+            else pass1<F, SS>(C, TL, SL, g, flags, dTmx, cy, p1, MK, cn);
+'''
+P2 = '''            if (AF) pass2<F, false>(C, TR, SL, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2, MK, cn);
+            else pass2<F, SS>(C, TL, SL, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2, MK, cn);
+'''
+ST = '''                asm("" : "+v"(posb));
+                *(double*)((char*)ring_day + ((size_t)sel * (NT * 8)) + posb) = val;'''
+BAR = '''        __syncthreads();
+        if (PRE && tid < 3 * CPB)      // reset the buffer of the day after next (see s_ext)'''
+LOOP = '''    for (int dl = 0; dl < ndays; ++dl, ++run) {
+        const int dabs = day0 + dl;'''
+SECT_GLOBAL = ('''namespace mcf {
+
+// ------------------------------------------------------------------------------------
+__global__ void k_fill(''', '''namespace mcf {
+// TIMING VARIANT: shader-clock cycles per wave, by hour group (hour / 3): per day {pass 1 + its stores, wait at the day
+// barrier, soil producer + pass 2 + its stores, whole day}, and per tile the prologue (entry -> top of the first day), split
+// at the barrier behind the staging loads.  Summed in registers over the launch's days; one tile in 16 reports (a few
+// atomics per wave: the atomics must not become the load).
+__device__ unsigned long long g_sect[8 * 8];
+
+// ------------------------------------------------------------------------------------
+__global__ void k_fill(''')
+
+VARIANTS = {
+    # the launch's stores with no physics in front of them
+    "storeonly": [(P1, "            cy.soilm = cy.Rbdown = cy.Rddown = p1.uz = p1.Rdup = p1.Tg0 = p1.absRnet = (double)dl;   // TIMING VARIANT: no physics\n"),
+                  (P2, "            p2.Tz = p2.Tg = p2.tleaf = p2.rh = p2.lwdn = p2.lwup = dtr + Rmx;   // TIMING VARIANT: no physics\n")],
+    # every store elided (the compiler cannot prove the predicate false)
+    "nostore": [(ST, '''                asm("" : "+v"(posb));
+                if (val == 1.2345e300) *(double*)((char*)ring_day + ((size_t)sel * (NT * 8)) + posb) = val;   // TIMING VARIANT: stores elided''')],
+    # every store issued, all into an L2-resident window
+    "storehot": [(ST, '''                asm("" : "+v"(posb));
+                *(double*)((char*)a.out_base + (((size_t)tile & 63) * 40960 + (size_t)sel * (NT * 8)) + posb) = val;   // TIMING VARIANT: every store issued, into an L2-resident window''')],
+    "nobarrier": [(BAR, '''        // TIMING VARIANT: no day barrier
+        if (PRE && tid < 3 * CPB)      // reset the buffer of the day after next (see s_ext)''')],
+    "prologue_only": [(LOOP, '''    for (int dl = 0; dl < (a.N < 0 ? ndays : 0); ++dl, ++run) {     // TIMING VARIANT: prologue only
+        const int dabs = day0 + dl;''')],
+    "sections": [SECT_GLOBAL,
+                 ('''    constexpr int NT = solve_threads(CPB);
+    static_assert(NT == RING_BLOCK(CPB), "tile-day block = one value per lane");''', '''    constexpr int NT = solve_threads(CPB);
+    static_assert(NT == RING_BLOCK(CPB), "tile-day block = one value per lane");
+    const long long t_entry = clock64();'''),
+                 ('''    __syncthreads();
+    enter_layer(day0);''', '''    __syncthreads();
+    const long long t_staged = clock64();
+    enter_layer(day0);'''),
+                 (LOOP, '''    long long acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0;
+    const long long t_loop = clock64();
+    for (int dl = 0; dl < ndays; ++dl, ++run) {
+        const long long t_top = clock64();
+        const int dabs = day0 + dl;'''),
+                 (BAR, '''        const long long t_p1 = clock64();
+        __syncthreads();
+        const long long t_bar = clock64();
+        if (PRE && tid < 3 * CPB)      // reset the buffer of the day after next (see s_ext)'''),
+                 ('''        if (!BG) ring_day += a.out_day_stride;
+    }''', '''        if (!BG) ring_day += a.out_day_stride;
+        const long long t_end = clock64();
+        acc1 += t_p1 - t_top; acc2 += t_bar - t_p1; acc3 += t_end - t_bar; acc4 += t_end - t_top;
+    }
+    if (F && SS && (tid & 63) == 0 && (tile & 15) == 0) {
+        const int grp = hr / 3;
+        atomicAdd(&g_sect[grp * 8 + 0], (unsigned long long)acc1);
+        atomicAdd(&g_sect[grp * 8 + 1], (unsigned long long)acc2);
+        atomicAdd(&g_sect[grp * 8 + 2], (unsigned long long)acc3);
+        atomicAdd(&g_sect[grp * 8 + 3], (unsigned long long)acc4);
+        atomicAdd(&g_sect[grp * 8 + 4], (unsigned long long)ndays);
+        atomicAdd(&g_sect[grp * 8 + 5], (unsigned long long)(t_staged - t_entry));
+        atomicAdd(&g_sect[grp * 8 + 6], (unsigned long long)(t_loop - t_staged));
+        atomicAdd(&g_sect[grp * 8 + 7], 1ull);
+    }'''),
+                 ('''void print_variant_stats() {}''', '''void print_variant_stats() {
+    unsigned long long h[64];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sect), sizeof h) != hipSuccess) return;
+    fprintf(stderr, "[mcf sections] hours  wave-days   pass1  barrier    pass2      day | tiles  staging  soil+flags  (shader-clock cycles per wave: per day | per tile)\\n");
+    for (int g = 0; g < 8; ++g) {
+        const double n = (double)(h[g * 8 + 4] ? h[g * 8 + 4] : 1), m = (double)(h[g * 8 + 7] ? h[g * 8 + 7] : 1);
+        fprintf(stderr, "[mcf sections] %2d-%2d %10llu %8.0f %8.0f %8.0f %8.0f | %8llu %8.0f %8.0f\\n", 3 * g, 3 * g + 2, h[g * 8 + 4], h[g * 8] / n,
+                h[g * 8 + 1] / n, h[g * 8 + 2] / n, h[g * 8 + 3] / n, h[g * 8 + 7], h[g * 8 + 5] / m, h[g * 8 + 6] / m);
+    }
+}''')],
+    # persistent workgroups (a fixed grid walking the tile sequence): measured a loss in rounds 2 and 3 (128 VGPRs, scratch)
+    "persistent_loop": [('''    const int rot = (int)((blockIdx.x >> 8) & 1);
+    const int64_t pos = tile_position(a.ntiles_launch);
+    if (pos < 0) return;
+    const int64_t tile = a.tile_list ? (int64_t)a.tile_list[pos] : pos;
+    solve_tile<CPB, AF, BG, F, SSREQ>(a, tile, a.day0, a.ndays, rot);''', '''    // VARIANT: persistent workgroups — a fixed grid (gridDim.x = 8 R), workgroup (x, r) walks positions r, r + R, ... of XCD
+    // x's eighth of the tile sequence; no dispatch gap between a workgroup's tiles
+    const int rot = (int)((blockIdx.x >> 8) & 1);
+    const int64_t per_xcd = (a.ntiles_launch + 7) / 8;
+    const int64_t lo = (int64_t)(blockIdx.x & 7) * per_xcd, hi = lo + per_xcd < a.ntiles_launch ? lo + per_xcd : a.ntiles_launch;
+    const int64_t R = gridDim.x >> 3;
+    for (int64_t pos = lo + (blockIdx.x >> 3); pos < hi; pos += R) {
+        const int64_t tile = a.tile_list ? (int64_t)a.tile_list[pos] : pos;
+        __syncthreads();
+        solve_tile<CPB, AF, BG, F, SSREQ>(a, tile, a.day0, a.ndays, rot);
+    }'''),
+                        ('''static dim3 solve_grid(int64_t ntiles) { return dim3((unsigned)(8 * ((ntiles + 7) / 8))); }     // tile_position()''',
+                         '''static dim3 solve_grid(int64_t ntiles) {
+    static const int wg = getenv("MCF_PERSIST_WGS") ? atoi(getenv("MCF_PERSIST_WGS")) : 512;
+    return dim3((unsigned)std::min<int64_t>(wg, 8 * ((ntiles + 7) / 8)));
+}''')],
+}
+
+
+def main():
+    src = SRC.read_text()
+    OUT.mkdir(exist_ok=True)
+    bad = 0
+    with tempfile.TemporaryDirectory() as td:
+        a = Path(td) / "a.hip"
+        a.write_text(src)
+        for name, edits in VARIANTS.items():
+            s = src
+            for old, new in edits:
+                if s.count(old) != 1:
+                    print(f"{name}: anchor not found exactly once: {old[:60]!r}", file=sys.stderr)
+                    bad += 1
+                    break
+                s = s.replace(old, new)
+            else:
+                b = Path(td) / "b.hip"
+                b.write_text(s)
+                d = subprocess.run(["diff", "-u", "--label", "a/microclimf_amd/csrc/mcf_kernels.hip", "--label",
+                                    "b/microclimf_amd/csrc/mcf_kernels.hip", str(a), str(b)], capture_output=True, text=True).stdout
+                (OUT / f"{name}.patch").write_text(d)
+                print(f"{name}: {len(d.splitlines())} lines")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

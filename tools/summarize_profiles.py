@@ -68,7 +68,11 @@ summary = {"kernel": kname.replace("void mcf::", "").replace("(mcf::SolveArgs)",
            "kernel_hash": bench.kernel_hash(),
            "command": f"python3 bench.py {bargs} --tsteps 1920 --steps 1 --warmup 0 --no-cpu-baseline --no-secondary "
                       f"--no-verify ({ring_days}-day launches; 80 days: a whole number of launches for 1, 2, 4, 5, 8 and 10-day slots)"}
-if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+special = any(f in bargs for f in ("--array-forcing", "--coarse"))     # other geometries: summary only, traffic.json is bench.py's
+if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc and special:
+    summary["hbm_bytes_per_launch"] = {"read": pmc["FETCH_SIZE"] * 1024 * 2, "write": pmc["WRITE_SIZE"] * 1024,
+                                       "total": pmc["FETCH_SIZE"] * 1024 * 2 + pmc["WRITE_SIZE"] * 1024}
+if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc and not special:
     fetch_b = pmc["FETCH_SIZE"] * 1024 * 2       # gfx950: FETCH_SIZE reports half of a coalesced stream
     write_b = pmc["WRITE_SIZE"] * 1024
     summary["hbm_bytes_per_launch"] = {"read": fetch_b, "write": write_b, "total": fetch_b + write_b}
