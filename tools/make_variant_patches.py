@@ -50,6 +50,10 @@ VARIANTS = {
                 *(double*)((char*)a.out_base + (((size_t)tile & 63) * 40960 + (size_t)sel * (NT * 8)) + posb) = val;   // TIMING VARIANT: every store issued, into an L2-resident window''')],
     "nobarrier": [(BAR, '''        // TIMING VARIANT: no day barrier
         if (PRE && tid < 3 * CPB)      // reset the buffer of the day after next (see s_ext)''')],
+    # (No "no time-table prefetch" variant: without the rows the physics runs on whatever the LDS slots hold — zeros send every
+    # step down the night path — so its launch time says nothing about the prefetch's cost.  Two real reorderings were measured
+    # in round 3 instead, same box: the rows written in front of pass 1's stores, and staged two days ahead and written in front
+    # of pass 2's stores: -0.5 % and -1 %.  The prefetch is not where time goes.)
     "prologue_only": [(LOOP, '''    for (int dl = 0; dl < (a.N < 0 ? ndays : 0); ++dl, ++run) {     // TIMING VARIANT: prologue only
         const int dabs = day0 + dl;''')],
     "sections": [SECT_GLOBAL,
