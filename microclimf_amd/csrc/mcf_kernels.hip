@@ -588,6 +588,13 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
 #pragma unroll
         for (int i = 0; i < NLOG; ++i) { const int q = tid + i * NT; if (q < 512) s_logtab[q] = lg[i]; }
     }
+    // Every load of the prologue has landed — said explicitly, as an instruction the compiler's wait-count pass sees.  Some of
+    // the LDS writes above sit behind lane predicates (`q < 512`); on the path that skips one, the pass keeps the load into
+    // that register "possibly in flight" for ever, carries that into the day loop through the loop header, and drains the
+    // memory counter (vmcnt(0): every store in flight as well) in front of the first write to that register in each region
+    // of every day.  Hygiene: with the drains gone the launch time is the same to 0.1 % — a store's acknowledgement from the
+    // L2 is quick; what the output stream costs is clock (profiles/r03_timing_experiments.txt).
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
     if (F && tid == 0) s_trip = 0;
     if (PRE && tid < 9 * CPB) (&s_ext[0][0][0])[tid] = ((tid / CPB) % 3 == 0) ? -999.0 : ((tid / CPB) % 3 == 1) ? 999.0 : -999.9;   // cpp:2196-2198
     Globals g = a.g;

@@ -54,6 +54,9 @@ VARIANTS = {
     # step down the night path — so its launch time says nothing about the prefetch's cost.  Two real reorderings were measured
     # in round 3 instead, same box: the rows written in front of pass 1's stores, and staged two days ahead and written in front
     # of pass 2's stores: -0.5 % and -1 %.  The prefetch is not where time goes.)
+    # an explicit drain of the memory counter behind each batch of five stores: if the launch time does not move, the waits
+    # are already there (the compiler's vmcnt(0) in front of the first LDS / memory load into a pending store's data register)
+    "drain_after_stores": [("        if (!BG) ring_day += a.out_day_stride;\n    }", "        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");     // TIMING VARIANT\n        if (!BG) ring_day += a.out_day_stride;\n    }")],
     "prologue_only": [(LOOP, '''    for (int dl = 0; dl < (a.N < 0 ? ndays : 0); ++dl, ++run) {     // TIMING VARIANT: prologue only
         const int dabs = day0 + dl;''')],
     "sections": [SECT_GLOBAL,
