@@ -808,7 +808,7 @@ int mcf_plan_upload_forcing_days(mcf_plan* p, const mcf_grid_inputs* in, int32_t
     HIP_TRY(hipSetDevice(p->device));
     const double* raw[15];
     clim_ptrs(in, raw);
-    const int64_t N = p->N, n = N * (int64_t)ndays * 24;
+    const int64_t N = p->N;
     for (int f = 0; f < 15; ++f)
         if (!raw[f]) return fail(MCF_ERR_ARG, std::string("missing forcing array: ") + kRawNames[f]);
     for (int f = 0; f < 15; ++f) {

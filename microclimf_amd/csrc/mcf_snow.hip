@@ -237,8 +237,8 @@ __global__ __launch_bounds__(256, MCF_SNOW_WAVES) void k_snowmodel(ModelArgs a) 
             }
             vTc = po.Tc; vTg = po.Tg; vdc = s.sdepc; vdg = s.sdepg; vden = s.sdenc;
             meltc = meltc + po.melc;                          // cpp:4394-4396 (meltc is added twice)
-            meltc = meltc + (po.melc * 1000.0) / s.sdenc;
-            meltg = meltg + (po.melg * 1000.0) / s.sdeng;
+            meltc = meltc + gdiv(po.melc * 1000.0, s.sdenc);   // densities are >= 1000 sdp[1] > 0 (or NaN)
+            meltg = meltg + gdiv(po.melg * 1000.0, s.sdeng);
         }
         if (a.Tc) a.Tc[o] = vTc;
         if (a.Tg) a.Tg[o] = vTg;
@@ -262,6 +262,8 @@ struct MicroArgs {
     const StepRow* rows;
     const DateRow2* dates;
     const double* mxtc1;   // [1] data.frame climate
+    const MicroMet* mmet;  // [T] data.frame climate: weather-only terms of every step (k_micro_steps)
+    int32_t day0;          // first day of this launch (blockIdx.y counts from it)
     const double *temp, *relhum, *pres, *swdown, *difrad, *lwdown, *windspeed, *precip, *umu;   // [T] or [N][T]
     const double *sTc, *sTg, *swe, *sdepg, *sden;   // snowm, [N][T]
     double* meanD;      // [N]
@@ -269,6 +271,15 @@ struct MicroArgs {
     int32_t* hs0;       // [N][nchunks] hours since snowfall at the start of each day (array climate)
     double* out[MCF_NOUT];   // [N][T] or null
 };
+
+// data.frame climate: the weather-only terms of snowabovepoint, once per step instead of once per cell-step
+__global__ __launch_bounds__(256) void k_micro_steps(const double* __restrict__ temp, const double* __restrict__ relhum,
+                                                     const double* __restrict__ mxtc1, int tsteps, MicroMet* __restrict__ out) {
+    snow::snow_tables_init();
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= tsteps) return;
+    out[k] = micro_met(temp[k], relhum[k], *mxtc1);
+}
 
 // per-cell reductions over the whole series: meanDsnow (cpp:4713-4737) and, with array climate, the
 // cell's maximum temperature (cpp:5139-5145) and the albedo clock at every day start
@@ -309,12 +320,11 @@ __global__ __launch_bounds__(256) void k_microsnow_cell(MicroArgs a) {
 template <bool AF>
 __global__ __launch_bounds__(256) void k_microsnow(MicroArgs a) {
     snow::snow_tables_init();
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // one lane per (cell, day); the day is the block's (blockIdx.y), so the step rows are wave-uniform scalar loads
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t N = a.N;
-    const int nch = (a.tsteps + 23) / 24;
-    if (t >= N * nch) return;
-    const int64_t c = t % N;
-    const int day = (int)(t / N);
+    if (c >= N) return;
+    const int day = a.day0 + (int)blockIdx.y;
     const double hgt = a.hgt[c];
     if (isnan(hgt)) return;   // cpp:4988-4989
     const int k0 = day * 24;
@@ -331,6 +341,7 @@ __global__ __launch_bounds__(256) void k_microsnow(MicroArgs a) {
     const SiteK site = site_derive(a.slope[c], a.aspect[c]);
     const double pai = a.pai[c], paia = a.paia[c], leafd = a.leafd[c], clump = a.clump[c], ltra = a.leaft[c],
                  leafden = a.leafden[c], svfa = a.skyview[c];
+    const double lnclump = clump > 0.0 ? glog(clump) : 0.0;
     double sinlat = 0.0, coslat = 0.0, lon = 0.0, mxtc;
     int hs = 0;
     if (AF) {
@@ -372,14 +383,15 @@ __global__ __launch_bounds__(256) void k_microsnow(MicroArgs a) {
             q.shadowmask = a.hor[(int64_t)sindex * N + c] > sun.tansa ? 0 : 1;
             q.ws = a.wsa[(int64_t)windex * N + c];
             q.reqhgt = reqhgts; q.zref = a.zref;
-            q.tc = a.temp[f]; q.relhum = a.relhum[f]; q.pk = a.pres[f]; q.u2 = a.windspeed[f];
+            q.tc = a.temp[f]; q.pk = a.pres[f]; q.u2 = a.windspeed[f];
             q.Rsw = a.swdown[f]; q.Rdif = a.difrad[f]; q.Rlw = a.lwdown[f]; q.umu = a.umu[f];
             q.hgt = hgt; q.pai = pai; q.paia = paia; q.leafd = leafd; q.clump = clump; q.ltra = ltra;
-            q.leafden = leafden; q.svfa = svfa; q.mxtc = mxtc;
+            q.leafden = leafden; q.svfa = svfa; q.lnclump = lnclump;
             q.Tg = a.sTg[o]; q.Tc = a.sTc[o]; q.sden = a.sden[o]; q.sdepg = a.sdepg[o];
             q.sdepc = a.swe[o] / q.sden;
             q.alb = alb;
-            const MicroOut m = micro_above(q, sun);
+            const MicroMet mm = AF ? micro_met(q.tc, a.relhum[f], mxtc) : a.mmet[k];
+            const MicroOut m = micro_above(q, mm, sun);
             v[0] = m.Tz; v[1] = m.tleaf; v[2] = m.rh; v[4] = m.uz; v[5] = m.Rbdown; v[6] = m.Rddown;
             v[7] = m.Rlwdn; v[8] = m.Rdup; v[9] = m.Rlwup;
         } else {
@@ -445,11 +457,10 @@ struct MicroRingArgs {
 __global__ __launch_bounds__(256) void k_microsnow_ring(MicroRingArgs q) {
     snow::snow_tables_init();
     const MicroArgs& a = q.m;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t N = a.N;
-    if (t >= N * q.ndays) return;
-    const int64_t c = t % N;
-    const int day = (int)(t / N);
+    if (c >= N) return;
+    const int day = (int)blockIdx.y;             // uniform: the day's rows of the step tables are scalar loads
     const int sub = q.daymap[day];
     if (sub < 0) return;
     const bool keep = q.nosnow[day] != 0;        // the solver ran this day: snow-free cell-steps keep its values
@@ -480,7 +491,7 @@ __global__ __launch_bounds__(256) void k_microsnow_ring(MicroRingArgs q) {
     const SiteK site = site_derive(a.slope[c], a.aspect[c]);
     const double pai = a.pai[c], paia = a.paia[c], leafd = a.leafd[c], clump = a.clump[c], ltra = a.leaft[c],
                  leafden = a.leafden[c], svfa = a.skyview[c];
-    const double mxtc = *a.mxtc1;
+    const double lnclump = clump > 0.0 ? glog(clump) : 0.0;
     for (int h = 0; h < 24; ++h) {
         const int64_t o = c + N * (k0 + h);          // chunk-local
         const int f = sub * 24 + h;                   // step of the snow-day subset series
@@ -500,14 +511,14 @@ __global__ __launch_bounds__(256) void k_microsnow_ring(MicroRingArgs q) {
             mi.shadowmask = a.hor[(int64_t)r.sindex * N + c] > sun.tansa ? 0 : 1;
             mi.ws = a.wsa[(int64_t)r.windex * N + c];
             mi.reqhgt = reqhgts; mi.zref = a.zref;
-            mi.tc = a.temp[f]; mi.relhum = a.relhum[f]; mi.pk = a.pres[f]; mi.u2 = a.windspeed[f];
+            mi.tc = a.temp[f]; mi.pk = a.pres[f]; mi.u2 = a.windspeed[f];
             mi.Rsw = a.swdown[f]; mi.Rdif = a.difrad[f]; mi.Rlw = a.lwdown[f]; mi.umu = a.umu[f];
             mi.hgt = hgt; mi.pai = pai; mi.paia = paia; mi.leafd = leafd; mi.clump = clump; mi.ltra = ltra;
-            mi.leafden = leafden; mi.svfa = svfa; mi.mxtc = mxtc;
+            mi.leafden = leafden; mi.svfa = svfa; mi.lnclump = lnclump;
             mi.Tg = a.sTg[o]; mi.Tc = a.sTc[o]; mi.sden = a.sden[o]; mi.sdepg = a.sdepg[o];
             mi.sdepc = a.swe[o] / mi.sden;
             mi.alb = r.m.alb;
-            const MicroOut mo = micro_above(mi, sun);
+            const MicroOut mo = micro_above(mi, a.mmet[f], sun);
             v[0] = mo.Tz; v[1] = mo.tleaf; v[2] = mo.rh; v[4] = mo.uz; v[5] = mo.Rbdown; v[6] = mo.Rddown;
             v[7] = mo.Rlwdn; v[8] = mo.Rdup; v[9] = mo.Rlwup;
         } else {
@@ -1025,13 +1036,19 @@ int run_microsnow(const mcf_snow_inputs* in, const mcf_snowm* sm, double reqhgt,
         a.out[v] = const_cast<double*>(d);
     }
     const unsigned gridN = (unsigned)((N + 255) / 256);
-    const unsigned gridD = (unsigned)((N * nch + 255) / 256);
-    if (af) {
-        hipLaunchKernelGGL(k_microsnow_cell<true>, dim3(gridN), dim3(256), 0, nullptr, a);
-        hipLaunchKernelGGL(k_microsnow<true>, dim3(gridD), dim3(256), 0, nullptr, a);
-    } else {
-        hipLaunchKernelGGL(k_microsnow_cell<false>, dim3(gridN), dim3(256), 0, nullptr, a);
-        hipLaunchKernelGGL(k_microsnow<false>, dim3(gridD), dim3(256), 0, nullptr, a);
+    if (!af) {
+        MicroMet* mm;
+        if ((rc = b.alloc((void**)&mm, (int64_t)T * sizeof(MicroMet)))) return rc;
+        hipLaunchKernelGGL(k_micro_steps, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, nullptr, a.temp, a.relhum, a.mxtc1, T, mm);
+        a.mmet = mm;
+    }
+    if (af) hipLaunchKernelGGL(k_microsnow_cell<true>, dim3(gridN), dim3(256), 0, nullptr, a);
+    else hipLaunchKernelGGL(k_microsnow_cell<false>, dim3(gridN), dim3(256), 0, nullptr, a);
+    for (int d0 = 0; d0 < nch; d0 += 32768) {        // (cells, days): the grid's y extent is 16 bits
+        a.day0 = d0;
+        const dim3 grid(gridN, (unsigned)std::min(32768, nch - d0));
+        if (af) hipLaunchKernelGGL(k_microsnow<true>, grid, dim3(256), 0, nullptr, a);
+        else hipLaunchKernelGGL(k_microsnow<false>, grid, dim3(256), 0, nullptr, a);
     }
     S_TRY(hipGetLastError());
     Downloader dl;
@@ -1586,6 +1603,12 @@ extern "C" int mcf_snowplan_micro_setup(mcf_snowplan* sp, const mcf_snow_inputs*
     UP(a.windspeed, sub->clim.windspeed, T);
     UP(a.precip, sub->clim.precip, T);
     UP(a.umu, sub->clim.umu, T);
+    {
+        MicroMet* mm;
+        if ((rc = b.alloc((void**)&mm, (int64_t)T * sizeof(MicroMet)))) return rc;
+        hipLaunchKernelGGL(k_micro_steps, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, nullptr, a.temp, a.relhum, a.mxtc1, T, mm);
+        a.mmet = mm;
+    }
     // the chunk's snow series, where mcf_snowplan_run_chunk leaves them (sdepc holds totalSWE after the redistribution)
     a.sTc = sp->a.Tc; a.sTg = sp->a.Tg; a.swe = sp->a.sdepc; a.sdepg = sp->a.sdepg; a.sden = sp->a.sden;
     // meanDsnow of the first pass (mcf_snowplan_meand_accumulate over every chunk)
@@ -1631,7 +1654,7 @@ extern "C" int mcf_snowplan_microsnow(mcf_snowplan* sp, mcf_plan* plan, int32_t 
     q.m = sp->ma;
     for (int v = 0; v < MCF_NOUT; ++v) q.sel[v] = sp->outsel[v];
     q.daymap = sp->d_daymap; q.nosnow = sp->d_nosnow; q.ndays = nd;
-    hipLaunchKernelGGL(k_microsnow_ring, dim3((unsigned)((N * nd + 255) / 256)), dim3(256), 0, nullptr, q);
+    hipLaunchKernelGGL(k_microsnow_ring, dim3((unsigned)((N + 255) / 256), (unsigned)nd), dim3(256), 0, nullptr, q);
     S_TRY(hipGetLastError());
     S_TRY(hipDeviceSynchronize());
     return MCF_OK;

@@ -54,20 +54,21 @@ __device__ __forceinline__ void snow_mathk(MathK& K) {
 #endif
 }
 #if MCF_SNOW_LEAN
-__device__ __forceinline__ double gexp(double x) {      // exp(x) for ANY operand
+// exp(x) for NaN or |x| < 1e90: the table route saturates by itself (v_cvt_i32_f64 and v_ldexp_f64 saturate: exactly 0 for
+// very negative, inf for very positive arguments; NaN stays NaN).  Only an INFINITE argument would come out as NaN — none is
+// reachable: the one source of an infinity on this path, pai / (1 - clump) at clump = 1, is a NaN in the lean division
+// already.  (Round 2 clamped the argument to [-750, 710] in front of every call: 8 VALU instructions x 16-20 calls a step.)
+__device__ __forceinline__ double gexp(double x) {
     MathK K;
     snow_mathk(K);
-    if (x < -750.0) x = -750.0;                         // compare-select: a NaN passes through; fexp(-750) = 0,
-    if (x > 710.0) x = 710.0;                           // fexp(710) = inf by ldexp's saturation
     return fexp(x, K);
 }
-__device__ __forceinline__ double glog(double x) {      // log(x) for ANY operand
+__device__ __forceinline__ double glog(double x) {      // log(x) for any operand but +inf: log(0) = -inf, log(< 0) = log(NaN) = NaN
     MathK K;
     snow_mathk(K);
-    double r = flog(x > 0.0 ? x : 1.0, K);
-    if (!(x > 0.0)) r = (x == 0.0) ? -__longlong_as_double(0x7FF0000000000000LL) : __longlong_as_double(0x7FF8000000000000LL);
-    if (x > 1.7e308) r = x;                             // log(inf) = inf
-    return r;
+    const double r = flog(x, K);                        // (garbage for x <= 0, replaced below)
+    const double bad = (x == 0.0) ? -__longlong_as_double(0x7FF0000000000000LL) : __longlong_as_double(0x7FF8000000000000LL);
+    return x > 0.0 ? r : bad;
 }
 __device__ __forceinline__ double gsqrt(double x) {     // sqrt(x) for ANY operand
     if (x > 1e-300 && x < 1e300) return fsqrt(x);
@@ -90,7 +91,9 @@ __device__ __forceinline__ double gpow0(double b, double e) {
 }
 
 __device__ __forceinline__ double svp(double tc) {  // cpp:480-490 satvapCpp
-    return 0.61078 * gexp(tc > 0 ? gdiv(17.27 * tc, tc + 237.3) : gdiv(21.875 * tc, tc + 265.5));
+    const bool w = tc > 0;                              // one division: the constant pair is selected, not the quotient
+    const double a = w ? 17.27 : 21.875, b = w ? 237.3 : 265.5;
+    return 0.61078 * gexp(gdiv(a * tc, tc + b));
 }
 __device__ __forceinline__ double rad4(double tc) {  // cpp:24-26 radem
     double t = tc + 273.15;
@@ -119,7 +122,7 @@ __device__ __forceinline__ double roughlen0(double h, double pai, double d) {  /
 }
 
 // ---- two-stream coefficients for spherical leaves (x = 1 -> J = 1/3), cpp:134-185 -------------
-struct TsDif { double om, a, gma, del, h, S1, u1, u2, D1, D2, p1, p2, p3, p4; };
+struct TsDif { double om, a, gma, del, h, S1, iS1, u1, u2, D1, D2, p1, p2, p3, p4; };
 __device__ __forceinline__ TsDif ts_dif(double pait, double lref, double ltra, double gref) {
     TsDif p;
     p.om = lref + ltra;
@@ -131,6 +134,7 @@ __device__ __forceinline__ TsDif ts_dif(double pait, double lref, double ltra, d
     p.u1 = p.a + p.gma * (1.0 - gdiv(1.0, gref));
     p.u2 = p.a + p.gma * (1.0 - gref);
     const double iS1 = gdiv(1.0, p.S1);
+    p.iS1 = iS1;                                        // = exp(+h pait) to 1.5 ulp: the callers' second exponential
     p.D1 = (p.a + p.gma + p.h) * (p.u1 - p.h) * iS1 - (p.a + p.gma - p.h) * (p.u1 + p.h) * p.S1;
     p.D2 = (p.u2 + p.h) * iS1 - (p.u2 - p.h) * p.S1;
     p.p1 = gdiv(p.gma, p.D1 * p.S1) * (p.u1 - p.h);
@@ -139,7 +143,7 @@ __device__ __forceinline__ TsDif ts_dif(double pait, double lref, double ltra, d
     p.p4 = gdiv(-p.S1, p.D2) * (p.u2 - p.h);
     return p;
 }
-struct TsDir { double sig, p5, p6, p7, p8, p9, p10; };
+struct TsDir { double sig, S2, p5, p6, p7, p8, p9, p10; };
 __device__ __forceinline__ TsDir ts_dir(double pait, const TsDif& f, double gref, double kd) {
     TsDir p;
     const double ag = f.a + f.gma;
@@ -147,6 +151,7 @@ __device__ __forceinline__ TsDir ts_dir(double pait, const TsDif& f, double gref
     const double ss = 0.5 * (f.om + gdiv((1.0 / 3.0) * f.del, kd)) * kd;
     const double sstr = f.om * kd - ss;
     const double S2 = gexp(-kd * pait);
+    p.S2 = S2;
     p.p5 = -ss * (ag - kd) - f.gma * sstr;
     const double v1 = ss - gdiv(p.p5 * (ag + kd), sig);
     const double v2 = ss - f.gma - gdiv(p.p5, sig) * (f.u1 + kd);
@@ -289,9 +294,11 @@ __device__ __forceinline__ void pack_step(const MetT& m, const DayT& dy, const S
     // ground heat flux of the cell from the point model's (cpp:4341-4354)
     double paip = c.pai;
     const double ihgt = gdiv(1.0, c.hgt > 0.0 ? c.hgt : 1.0);      // only used under hgt > sdepg >= 0
-    if (c.hgt > s.sdepg) paip = paip * (c.hgt - s.sdepg) * ihgt;
+    const bool emerged = c.hgt > s.sdepg;
+    if (emerged) paip = paip * (c.hgt - s.sdepg) * ihgt;
     const double dtR = dy.rmx - dy.rmn;
-    const double trS = c.skyview * gexp(-paip);
+    const double epaip = gexp(-paip);                  // = exp(-pai) of the ground pack's sublimation below when `emerged`
+    const double trS = c.skyview * epaip;
     const double dmxS = trS * dy.rswmx + trS * dy.rlwmx + (1 - trS) * m.rem - m.rem;
     const double dmnS = trS * dy.rswmn + trS * dy.rlwmn + (1 - trS) * m.rem - m.rem;
     double G = m.gp * ((dmxS - dmnS) / dtR);       // IEEE: dtR is 0 past the last whole day (0/0 = NaN there)
@@ -306,7 +313,7 @@ __device__ __forceinline__ void pack_step(const MetT& m, const DayT& dy, const S
     const double Rlw = m.rlw * c.skyview;
     // vegetation above the ground snow (cpp:3840-3852)
     double pai = 0.0;
-    if (c.hgt > s.sdepg) pai = c.pai * (c.hgt - s.sdepg) * ihgt;
+    if (emerged) pai = paip;                           // the same expression, cpp:3841 / 4343
     double hgt = c.hgt - s.sdepg;
     if (hgt < 0.0) hgt = 0.0;
     double zi = 0.0;
@@ -334,8 +341,8 @@ __device__ __forceinline__ void pack_step(const MetT& m, const DayT& dy, const S
             const CanK kp = cank1(sun.kx, sun.kcos, si);
             const TsDir d = ts_dir(pait, f, m.alb, kp.kd);
             const double clb = gpow0(c.clump, kp.Kc);
-            const double ehp = gexp(f.h * pait);
-            const double ekp = gexp(-kp.kd * pait);
+            const double ehp = f.iS1;                       // exp(h pait) = 1 / S1
+            const double ekp = d.S2;                        // exp(-kd pait), ts_dir's own
             const double Rddm = clamp01((1.0 - cld) * (f.p3 * f.S1 + f.p4 * ehp) + cld);
             const double Rdbm = clamp01((1.0 - clb) * (gdiv(d.p8, d.sig) * ekp + d.p9 * f.S1 + d.p10 * ehp));
             const double Rbgm = clamp01((1.0 - clb) * ekp + clb);
@@ -380,7 +387,7 @@ __device__ __forceinline__ void pack_step(const MetT& m, const DayT& dy, const S
     if (m.tc > 0.0) mRc = 0.0125 * m.tc * m.prec * 0.001;
     // ground pack (cpp:3904-3922)
     la = latent_lt0(Tg);
-    double mu = gexp(-pai);
+    double mu = emerged ? epaip : 1.0;                 // exp(-pai), pai = 0 under the pack
     if (mu > 1.0) mu = 1.0;
     L = la * gpk * (svp(Tg) - m.ea) * mu;
     la = la * (1.0 / 0.018015);
@@ -400,8 +407,11 @@ __device__ __forceinline__ void pack_step(const MetT& m, const DayT& dy, const S
         Li = (s.sdepc - s.sdepg) * (wgtg * s.sdeng + (1.0 - wgtg) * s.sdenc);
     }
     if (Li < 0.0) Li = 0.0;
-    double cis;
-    {
+    // With prec = 0 the intercepted amount is (Lstr - Li) (1 - exp(-0)) 0.678 = +-0 and only `prec - cis` reads it: the
+    // whole model (three exponentials, two square roots, five divisions) is skipped on dry steps — unless a NaN is on its
+    // way through Li or uf, which the reference would pass on to the ground pack.
+    double cis = 0.0;
+    if (!(m.prec == 0.0 && Li == Li && uf == uf)) {
         double h = hgt, p = pai;
         if (h < 0.001) h = 0.001;
         if (p < 0.001) p = 0.001;
@@ -447,42 +457,100 @@ __device__ __forceinline__ void pack_step(const MetT& m, const DayT& dy, const S
 }
 
 // ---- snow microclimate: snowabovepoint (cpp:4739-4866) ------------------------------------------
+// Round 3: the weather-only terms of a step (MicroMet: three saturation pressures, the dew point's logarithm, the
+// Penman-Monteith constants) come from the step table with data.frame climate (k_micro_steps; the kernels' day is
+// blockIdx.y, so a row is read through the scalar cache) and from the same function per cell-step with array climate; every
+// division whose divisor is finite and non-zero by construction is the lean one; pow(5, 1.5) and sqrt(5) are constants (the
+// device evaluated both at every in-canopy cell-step: ~230 VALU instructions); the five powers of the clumping factor
+// share their logarithms; exp(+h pai) is the reciprocal of exp(-h pai); sin / cos of pi z / h, z < h, by a [0, pi] routine.
+struct MicroMet {
+    double es, ea, tdew;      // satvap(tc), vapour pressure, dew point                   cpp:4745-4747
+    double De, gHrad, Rem;    // PenmanMonteith2Cpp's step-only operands                  cpp:1220-1247
+    double la_pm, lat0;       // latent heat, the `>= 0` and the `< 0` flavours           cpp:1226-1229, 4837-4842
+    double dTmx;              // leaf temperature cap from the series' maximum            cpp:1355
+};
+__device__ __forceinline__ MicroMet micro_met(double tc, double relhum, double mxtc) {
+    MicroMet m;
+    m.es = svp(tc);
+    m.ea = m.es * relhum / 100.0;
+    m.tdew = dewpoint(m.ea);
+    m.De = svp(tc + 0.5) - svp(tc - 0.5);
+    const double tk = tc + 273.15;
+    m.gHrad = (4 * 0.97 * kSb * (tk * tk * tk)) / 29.3;
+    m.Rem = 0.97 * kSb * rad4(tc);
+    m.la_pm = tc >= 0 ? 45068.7 - 42.8428 * tc : 51078.69 - 4.338 * tc - 0.06367 * tc * tc;
+    m.lat0 = latent_lt0(tc);
+    m.dTmx = -0.6273 * mxtc + 49.79;
+    return m;
+}
 struct MicroIn {
-    double reqhgt, zref, tc, relhum, pk, u2, Rsw, Rdif, Rlw;       // step
+    double reqhgt, zref, tc, pk, u2, Rsw, Rdif, Rlw;               // step
     double hgt, pai, paia, leafd, clump, ltra, leafden, svfa;      // cell
-    double si, ws, umu, mxtc;
+    double lnclump;                                                // glog(clump) where clump > 0 (cell)
+    double si, ws, umu;
     int shadowmask;
     double Tg, Tc, sdepc, sdepg, sden, alb;                        // snowpoint2
 };
 struct MicroOut { double Tz, tleaf, rh, uz, Rbdown, Rddown, Rlwdn, Rdup, Rlwup; };
 
-__device__ __forceinline__ double rh_canopy(double uf, double h, double d, double z) {  // cpp:1365-1380
-    const double a2 = 0.4 * (1.0 - (d / h)) / (1.25 * 1.25);
+// sin(x) and cos(x) for x in [0, pi] (quadrant reduction with a two-part pi/2, the classic degree-13 / degree-14 kernels on
+// [-pi/4, pi/4]: < 1 ulp); anything else goes to the device libm
+__device__ __forceinline__ void sincos_0pi(double x, double& sn, double& cs) {
+    if (x >= 0.0 && x <= 3.1416) {
+        const double k = __builtin_rint(x * 0x1.45f306dc9c883p-1);          // 2/pi: k = 0, 1, 2
+        double r = fma(-k, 0x1.921fb54400000p+0, x);                        // exact: pi/2's leading 33 bits
+        r = fma(-k, 0x1.0b4611a626331p-34, r);
+        const double z = r * r;
+        const double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+                          z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+        const double sr = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
+        const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                          z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+        const double hz = 0.5 * z, w = 1.0 - hz;
+        const double cr = w + (((1.0 - w) - hz) + z * pc);
+        const bool odd = (k == 1.0);
+        const double a = odd ? cr : sr, b = odd ? sr : cr;
+        sn = (k == 2.0) ? -a : a;
+        cs = (k == 0.0) ? b : -b;
+    } else {
+        sn = sin(x); cs = cos(x);
+    }
+}
+__device__ __forceinline__ double rh_canopy(double uf, double h, double ih, double d, double z) {  // cpp:1365-1380; ih = 1/h
+    const double a2 = 0.4 * (1.0 - (d * ih)) * (1.0 / (1.25 * 1.25));
     double inth = 4.293251 * h;
     if (z != h) {
-        const double sn = sin((kPi * z) / h), c1 = cos((kPi * z) / h) + 1;
-        inth = (2.0 * h * ((48 * atan((gsqrt(5.0) * sn) / c1)) / pow(5.0, 1.5) +
-                           (32.0 * sn) / (c1 * ((25.0 * (sn * sn)) / (c1 * c1) + 5.0)))) / kPi;
+        double sn, c1;
+        sincos_0pi((kPi * z) * ih, sn, c1);
+        c1 = c1 + 1;
+        const double ic1 = gdiv(1.0, c1);                          // c1 = 0 only at z = h
+        const double t = sn * ic1;                                 // tan(pi z / 2h)
+        // sqrt(5) and pow(5, 1.5), correctly rounded
+        inth = (2.0 * h * (48 * atan(0x1.1e3779b97f4a8p+1 * t) * (1.0 / 0x1.65c55827df1d2p+3) +
+                           gdiv(32.0 * sn, c1 * (25.0 * (t * t) + 5.0)))) * (1.0 / kPi);
     }
-    const double mu = uf / (a2 * h) * 1.0 / (uf * uf);
+    const double mu = gdiv(uf, a2 * h) * gdiv(1.0, uf * uf);
     double r = inth * mu;
     if (r < 0.001) r = 0.001;
     return r;
 }
-struct BelowK { double Kg, Kh, Kc; };   // TVbelow's diffusivities (cpp:1385-1390): shared by T and e
+struct BelowK { double Kg, Kh, Kc, iKc, iKs; };   // TVbelow's diffusivities (cpp:1385-1390): shared by T and e
 __device__ __forceinline__ BelowK below_k(double z, double d, double h, double uf) {
-    const double Rc = rh_canopy(uf, h, d, h);
-    const double rz = rh_canopy(uf, h, d, z);
+    const double ih = gdiv(1.0, h);
+    const double Rc = rh_canopy(uf, h, ih, d, h);
+    const double rz = rh_canopy(uf, h, ih, d, z);
     BelowK k;
-    k.Kc = h / Rc;
-    k.Kg = (1.0 / rz) / z;
-    k.Kh = (1.0 / (Rc - rz)) / (h - z);
+    k.iKc = Rc * ih;
+    k.Kc = h * gdiv(1.0, Rc);
+    k.Kg = gdiv(gdiv(1.0, rz), z);
+    k.Kh = gdiv(gdiv(1.0, Rc - rz), h - z);                        // Rc = rz: 0 x inf, a NaN as in the reference's inf / inf
+    k.iKs = gdiv(1.0, k.Kg + k.Kh + k.Kc);
     return k;
 }
 __device__ __forceinline__ double tv_below(const BelowK& k, double lnpai, double leafden, double Flux, double Fluxz,
                                            double SH, double SG, double mxnear) {   // cpp:1391-1409
-    const double SC = SH + Flux / k.Kc;
-    const double farg = (k.Kg * SG + k.Kh * SH + k.Kc * SC) / (k.Kg + k.Kh + k.Kc);
+    const double SC = SH + Flux * k.iKc;
+    const double farg = (k.Kg * SG + k.Kh * SH + k.Kc * SC) * k.iKs;
     double near = (3.047519 + 0.128642 * lnpai) * (Fluxz * leafden);
     if (fabs(near) > mxnear) near = near > 0.0 ? mxnear : -mxnear;
     if (isnan(near)) near = 0;
@@ -495,7 +563,8 @@ __device__ __forceinline__ AboveTV tv_above(double reqhgt, double zref, double d
     const double estl = svp(T0);
     AboveTV o;
     if (reqhgt > (d + zh)) {
-        const double lnr = glog((reqhgt - d) / zh) / glog((zref - d) / zh);
+        const double izh = gdiv(1.0, zh);
+        const double lnr = gdiv(glog((reqhgt - d) * izh), glog((zref - d) * izh));
         o.Tz = tc + (T0 - tc) * (1 - lnr);
         o.ez = ea + (estl - ea) * (1 - lnr);
     } else {
@@ -519,45 +588,46 @@ __device__ __forceinline__ double min4(double a, double b, double c, double d) {
     return m;
 }
 
-__device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const SunT& sun) {
+__device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet& mm, const SunT& sun) {
     MicroOut out;
     double reqhgt = q.reqhgt;
     if (reqhgt == 0.0) reqhgt = 0.001;
-    const double es = svp(q.tc);
-    const double ea = es * q.relhum / 100.0;
-    const double tdew = dewpoint(ea);
+    const double es = mm.es, ea = mm.ea, tdew = mm.tdew;
     double hgts = q.hgt - q.sdepg;
     if (hgts < 0.0) hgts = 0.0;
-    double pais = 0.0, d = 0.0, zm = 1e-5, wa = 0.0;
+    const double ipk = gdiv(1.0, q.pk);
+    double pais = 0.0, d = 0.0, zm = 1e-5, wa = 0.0, ihgts = 0.0, frac = 0.0;
     if (hgts > 0.0) {                                            // windtiCpp cpp:1179-1187
-        pais = q.pai * hgts / q.hgt;
+        frac = hgts * gdiv(1.0, q.hgt);                          // hgt > sdepg >= 0 here
+        ihgts = gdiv(1.0, hgts);
+        pais = q.pai * frac;
         d = zeroplane(hgts, pais);
         zm = roughlen0(hgts, pais, d);
         if (zm < 1e-6) zm = 1e-6;
-        wa = pais / hgts;
+        wa = pais * ihgts;
     }
     // windCpp cpp:1189-1218
     double ws = q.ws;
     if (isnan(ws)) ws = 1.0;
     if (ws < 0.05) ws = 0.05;
-    double uf = ((kKa * q.u2) / glog((q.zref - d) / zm)) * q.umu * ws;
+    const double izm = gdiv(1.0, zm);
+    double uf = gdiv(kKa * q.u2, glog((q.zref - d) * izm)) * q.umu * ws;
     if (uf < 0.001) uf = 0.001;
     double uz = uf;
     if (reqhgt > 0) {
         if (reqhgt >= hgts) {
-            uz = (uf / kKa) * glog((reqhgt - d) / zm);
+            uz = (uf * (1.0 / kKa)) * glog((reqhgt - d) * izm);
         } else {
-            double uh = (uf / kKa) * glog((hgts - d) / zm);
+            double uh = (uf * (1.0 / kKa)) * glog((hgts - d) * izm);
             if (uh < uf) uh = uf;
-            double Be = uf / uh;
+            double Be = gdiv(uf, uh);
             if (Be < 0.001) Be = 0.001;
-            const double Lc = 1.0 / (0.25 * wa);
-            const double Lm = 2 * (Be * Be * Be) * Lc;
-            uz = uh * gexp(Be * (reqhgt - hgts) / Lm);
+            const double Lm = 2 * (Be * Be * Be) * gdiv(1.0, 0.25 * wa);
+            uz = uh * gexp(gdiv(Be * (reqhgt - hgts), Lm));
         }
         if (uz > q.u2) uz = q.u2;
     }
-    double gHa = (kKa * 43 * uf) / glog((q.zref - d) / (0.2 * zm + d - d));   // gturbCpp(.., 43, 0, 0.0001)
+    double gHa = gdiv(kKa * 43 * uf, glog(gdiv(q.zref - d, 0.2 * zm + d - d)));   // gturbCpp(.., 43, 0, 0.0001)
     if (gHa < 0.0001) gHa = 0.0001;
     out.uz = uz;
     double ez;
@@ -565,7 +635,7 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const SunT& su
         if (q.Rsw > 0.0) {
             out.Rddown = q.Rdif * q.svfa;
             if (q.si > 0.0 && q.shadowmask > 0) {
-                out.Rbdown = (q.Rsw - q.Rdif) / q.si;
+                out.Rbdown = gdiv(q.Rsw - q.Rdif, q.si);
                 if (out.Rbdown > 1352.0) out.Rbdown = 1352.0;
                 out.Rdup = q.alb * q.Rsw * q.svfa;
             } else {
@@ -582,31 +652,36 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const SunT& su
         out.tleaf = q.Tc;
         ez = tv.ez;
     } else {                                                     // inside the canopy, cpp:4799-4857
-        double paias = 0.0;
-        if (hgts > 0.0) paias = q.paia * hgts / q.hgt;
+        const double paias = q.paia * frac;                      // (hgts > reqhgt > 0 here)
         double zi = 0.0;
-        if (q.sdepg > 0.0) zi = ((q.sdepc - q.sdepg) * q.sden) / (hgts * 1000.0);
+        if (q.sdepg > 0.0) zi = ((q.sdepc - q.sdepg) * q.sden) * (ihgts * (1.0 / 1000.0));
         double ltras = q.ltra * gexp(-10.1 * zi);
         if ((ltras + q.alb) > 0.999) ltras = 0.999 - q.alb;
-        double clumps = q.clump;
-        if (q.clump > 0.0) clumps = gpow0(q.clump, pais / q.pai);     // (device pow() is ~200 VALU instructions; five of them per
-                                                                      // in-canopy cell-step were a third of this function)
-        double pait = pais;
-        if (q.clump > 0.0) pait = pais / (1.0 - clumps);
-        // twostreamdif (cpp:1034-1084) with lref = gref = snow albedo
-        const double pait2 = pais / (1.0 - clumps);
-        const TsDif f = ts_dif(pait2, q.alb, ltras, q.alb);
-        double gi = 0.0, giu = 0.0;
-        if (clumps > 0.0) {
-            gi = gpow0(clumps, paias / pais);
-            giu = gpow0(clumps, (pais - paias) / pais);
+        // clumps = clump^(pais / pai) and its own powers through ONE logarithm: log(clumps) = (pais / pai) log(clump)
+        const double ipais = gdiv(1.0, pais);
+        double clumps = q.clump, lncl = 0.0;
+        if (q.clump > 0.0) {
+            lncl = gdiv(pais, q.pai) * q.lnclump;
+            clumps = gexp(lncl);
         }
-        if (gi > 0.99) gi = 0.99;
+        const double i1c = gdiv(1.0, 1.0 - clumps);
+        double pait = pais;
+        if (q.clump > 0.0) pait = pais * i1c;
+        // twostreamdif (cpp:1034-1084) with lref = gref = snow albedo
+        const double pait2 = pais * i1c;
+        const TsDif f = ts_dif(pait2, q.alb, ltras, q.alb);
+        double gi = 0.0, giu = 0.0, lngi = 0.0;
+        if (clumps > 0.0) {
+            lngi = (paias * ipais) * lncl;
+            gi = gexp(lngi);
+            giu = gexp(((pais - paias) * ipais) * lncl);
+        }
+        if (gi > 0.99) { gi = 0.99; lngi = -0x1.495453e6fd4bcp-7; }   // log(0.99)
         if (giu > 0.99) giu = 0.99;
         const double trd = gi * gi, trdn = clumps * clumps, trdu = giu * giu;
-        const double paiaa = paias / (1.0 - gi);
+        const double paiaa = gdiv(paias, 1.0 - gi);
         const double amx = q.alb;                                // max(gref, lref), both the albedo
-        const double eh_a = gexp(-f.h * paiaa), eH_a = gexp(f.h * paiaa);
+        const double eh_a = gexp(-f.h * paiaa), eH_a = gdiv(1.0, eh_a);
         double Rdup_z = (1.0 - trdu * trdn) * (f.p1 * eh_a + f.p2 * eH_a) + trdu * trdn * q.alb;
         Rdup_z = clamp01(Rdup_z);
         const double Rddn_z = clamp01((1.0 - trd) * (f.p3 * eh_a + f.p4 * eH_a) + trd);
@@ -619,22 +694,24 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const SunT& su
         double Rbdown = 0.0, Rddown = 0.0, Rdup = 0.0, radLsw = 0.0;
         if (q.Rsw > 0.0) {
             const double cosz = sun.cosz;
+            const double icosz = gdiv(1.0, cosz);
             if (pais > 0.0) {
-                double trbn = gpow0(clumps, kp.Kc);
+                double trbn = clumps > 0.0 ? gexp(kp.Kc * lncl) : gpow0(clumps, kp.Kc);
                 if (trbn > 0.999) trbn = 0.999;
                 if (trbn < 0.0) trbn = 0.0;
-                double trb = gpow0(gi, kp.Kc);
+                double trb = gi > 0.0 ? gexp(kp.Kc * lngi) : gpow0(gi, kp.Kc);
                 if (trb > 0.999) trb = 0.999;
                 if (trb < 0.0) trb = 0.0;
                 const double ek_a = gexp(-kp.kd * paiaa);
-                double Rdbup_z = (1.0 - trdu * trbn) * ((dr.p5 / -dr.sig) * ek_a + dr.p6 * eh_a + dr.p7 * eH_a) +
+                const double isig = gdiv(1.0, dr.sig);
+                double Rdbup_z = (1.0 - trdu * trbn) * ((dr.p5 * -isig) * ek_a + dr.p6 * eh_a + dr.p7 * eH_a) +
                                  trdu * trbn * q.alb;
                 if (Rdbup_z > amx) Rdbup_z = amx;
                 if (Rdbup_z < 0.0) Rdbup_z = 0.0;
-                double Rdbdn_z = (1.0 - trb) * ((dr.p8 / dr.sig) * ek_a + dr.p9 * eh_a + dr.p10 * eH_a);
+                double Rdbdn_z = (1.0 - trb) * ((dr.p8 * isig) * ek_a + dr.p9 * eh_a + dr.p10 * eH_a);
                 if (Rdbdn_z > amx) Rdbdn_z = amx;
                 if (Rdbdn_z < 0.0) Rdbdn_z = 0.0;
-                double Rbeam = (q.Rsw - q.Rdif) / cosz;
+                double Rbeam = (q.Rsw - q.Rdif) * icosz;
                 if (Rbeam > 1352.0) Rbeam = 1352.0;
                 const double Rb = Rbeam * cosz;
                 Rbdown = (trb + (1.0 - trb) * ek_a) * Rbeam;
@@ -642,7 +719,7 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const SunT& su
                 Rdup = Rdup_z * q.Rdif * q.svfa + Rdbup_z * Rb;
                 radLsw = 0.5 * (1.0 - f.om) * (Rddown + Rdup + kp.k * cosz * Rbdown);
             } else {
-                Rbdown = (q.Rsw - q.Rdif) / cosz;
+                Rbdown = (q.Rsw - q.Rdif) * icosz;
                 Rddown = q.Rdif * q.svfa;
                 Rdup = q.alb * (q.Rdif * q.svfa + (q.Rsw - q.Rdif));
             }
@@ -655,30 +732,27 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const SunT& su
         const double lwup = eg * lwgro + (1 - eg) * lwcan;
         const double lwdn = eaa * q.Rlw + (1 - eaa) * lwcan;
         const double leafabs = radLsw + 0.97 * 0.5 * (lwup + lwdn);
-        double gh = 0.135 * gsqrt(uz / q.leafd) * 1.4;
+        const double ileafd = gdiv(1.0, q.leafd);
+        double gh = 0.135 * gsqrt(uz * ileafd) * 1.4;
         {   // mincondCpp(leafabs, 999.99, Tcan, leafd) cpp:1316-1331
-            const double Rnet = leafabs - 0.97 * kSb * rad4(q.Tc);
+            const double Rnet = leafabs - lwcan;
             // Hf = -1 / (1 + exp(2 - 1.09767 * rs^0.2672778)) with rs = 1 / 999.99: a constant of the model
             const double Hf = -0x1.1be70d7011323p-3;
-            double gmin = 0.0463 * gpow0(fabs(Hf * Rnet) / q.leafd, 0.2);
+            double gmin = 0.0463 * gpow0(fabs(Hf * Rnet) * ileafd, 0.2);
             if (gmin < 0.05) gmin = 0.05;
             if (gh < gmin) gh = gmin;
         }
         // PenmanMonteith2Cpp (cpp:1220-1247), G = 0, surfwet = 1
-        const double De = svp(q.tc + 0.5) - svp(q.tc - 0.5);
-        const double tk = q.tc + 273.15;
-        const double gHr = gh + (4 * 0.97 * kSb * (tk * tk * tk)) / 29.3;
-        const double Rem = 0.97 * kSb * rad4(q.tc);
-        const double la_pm = q.tc >= 0 ? 45068.7 - 42.8428 * q.tc : 51078.69 - 4.338 * q.tc - 0.06367 * q.tc * q.tc;
-        const double mpm = la_pm * (gh / q.pk);
-        double dT = (leafabs - Rem - mpm * (es - ea)) / (29.3 * gHr + mpm * De);
-        const double dTmx = -0.6273 * q.mxtc + 49.79;
-        if (dT > dTmx) dT = dTmx;
+        const double gHr = gh + mm.gHrad;
+        const double mpm = mm.la_pm * (gh * ipk);
+        double dT = gdiv(leafabs - mm.Rem - mpm * (es - ea), 29.3 * gHr + mpm * mm.De);
+        if (dT > mm.dTmx) dT = mm.dTmx;
         if (dT > 80.0) dT = 80.0;
         double tleaf = dT + q.tc;
         if (tleaf < tdew) tleaf = tdew;
         const double Hl = 29.3 * gh * (tleaf - q.tc);
-        const double Ll = mpm * (svp(tleaf) - ea);
+        const double estl = svp(tleaf);
+        const double Ll = mpm * (estl - ea);
         out.tleaf = tleaf;
         // Lagrangian below-canopy profile (cpp:4827-4851)
         const BelowK bk = below_k(reqhgt, d, hgts, uf);
@@ -687,16 +761,16 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const SunT& su
         const double fr = 1.0 - gexp(-pais);
         const AboveTV tv = tv_above(hgts, q.zref, d, zm, q.Tc, q.tc, ea);
         out.Tz = tv_below(bk, lnpai, q.leafden, H * fr, Hl, tv.Tz * 29.3 * 43.0, q.Tg * 29.3 * 43.0,
-                          fabs(tleaf - tv.Tz) * 29.3 * 43.0) / (29.3 * 43);
-        const double la = latent_lt0(q.tc);
-        const double mm = la * (gHa / q.pk);
-        const double mu = la * (43 / q.pk);
-        ez = tv_below(bk, lnpai, q.leafden, (mm * (es - ea)) * fr, Ll, tv.ez * mu, svp(q.Tg) * mu,
-                      fabs(svp(tleaf) - tv.ez) * mu) / mu;
+                          fabs(tleaf - tv.Tz) * 29.3 * 43.0) * (1.0 / (29.3 * 43));
+        const double la = mm.lat0;
+        const double mmg = la * (gHa * ipk);
+        const double mu = la * (43 * ipk);
+        ez = tv_below(bk, lnpai, q.leafden, (mmg * (es - ea)) * fr, Ll, tv.ez * mu, svp(q.Tg) * mu,
+                      fabs(estl - tv.ez) * mu) * gdiv(1.0, mu);
         out.Rbdown = Rbdown; out.Rddown = Rddown; out.Rdup = Rdup;
         out.Rlwdn = lwdn; out.Rlwup = lwup;
     }
-    out.rh = (ez / svp(out.Tz)) * 100.0;
+    out.rh = gdiv(ez, svp(out.Tz)) * 100.0;
     if (out.rh > 100.0) out.rh = 100.0;
     const double tmx = max4(out.tleaf, q.tc, q.Tg, q.Tc) + 2.0;
     const double tmn = min4(out.tleaf, q.tc, q.Tg, q.Tc) - 2.0;
