@@ -361,8 +361,9 @@ def roofline_block(valid, T, steps_per_launch, avg_ms, klaunches, af, rows, cols
                         "source": f"profiles/{e.get('tag')}_pmc_summary.json", "kernel_hash": e.get("kernel_hash")}
     rb = {"bound": "fp64_valu", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
           "frac_is": "achieved algorithmic HBM bytes / 8 TB/s (the metric BASELINE.json names); the binding roof is "
-                     "fp64 VALU issue, see `valu`; eliding the output stores would free 24-30 % more (timing experiments: "
-                     "profiles/r02_timing_experiments.txt, DESIGN 5)",
+                     "fp64 VALU issue at a power-limited clock, see `valu`: with the output stream beside it the shader clock "
+                     "drops 2.38 -> 2.15 GHz (10.8 %) and the launch costs 7.9 % more cycles (timing experiments: "
+                     "profiles/r03_timing_experiments.txt, DESIGN 5)",
           "traffic": traffic, "kernel": "k_solve", "avg_launch_ms": avg_ms, "launches": int(klaunches),
           "algorithmic_bytes_per_launch": bpl, "valu": valu}
     if note:

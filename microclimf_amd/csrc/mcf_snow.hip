@@ -109,6 +109,7 @@ __global__ void k_snow_alb(StepRow* rows, const double* precip, const double* te
     for (int k = 0; k < tsteps; ++k) {
         if (k > 0) hs = precip[k] > 0 ? 0 : hs + 1;
         rows[k].m.alb = snow_albedo(hs);
+        rows[k].m.ialb = gdiv(1.0, rows[k].m.alb);
         if (temp[k] > mx) mx = temp[k];
     }
     if (mxtc) *mxtc = mx;
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(256, MCF_SNOW_WAVES) void k_snowmodel(ModelArgs a) 
                 m.rsw = a.swdown[o]; m.rdif = a.difrad[o]; m.rlw = a.lwdown[o];
                 m.umu = a.umu[o]; m.u2 = a.windspeed[o]; m.gp = a.Gp[o];
                 m.alb = snow_albedo(hs);
+                m.ialb = gdiv(1.0, m.alb);
                 const DateRow2 dr = a.dates[k];
                 SolDate sd;
                 sd.sindec = dr.sindec; sd.cosdec = dr.cosdec; sd.eot = dr.eot;
@@ -274,11 +276,12 @@ struct MicroArgs {
 
 // data.frame climate: the weather-only terms of snowabovepoint, once per step instead of once per cell-step
 __global__ __launch_bounds__(256) void k_micro_steps(const double* __restrict__ temp, const double* __restrict__ relhum,
+                                                     const double* __restrict__ pres,
                                                      const double* __restrict__ mxtc1, int tsteps, MicroMet* __restrict__ out) {
     snow::snow_tables_init();
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= tsteps) return;
-    out[k] = micro_met(temp[k], relhum[k], *mxtc1);
+    out[k] = micro_met(temp[k], relhum[k], pres[k], *mxtc1);
 }
 
 // per-cell reductions over the whole series: meanDsnow (cpp:4713-4737) and, with array climate, the
@@ -342,6 +345,7 @@ __global__ __launch_bounds__(256) void k_microsnow(MicroArgs a) {
     const double pai = a.pai[c], paia = a.paia[c], leafd = a.leafd[c], clump = a.clump[c], ltra = a.leaft[c],
                  leafden = a.leafden[c], svfa = a.skyview[c];
     const double lnclump = clump > 0.0 ? glog(clump) : 0.0;
+    const double ihgt = gdiv(1.0, hgt), ileafd = gdiv(1.0, leafd), ipai = gdiv(1.0, pai);
     double sinlat = 0.0, coslat = 0.0, lon = 0.0, mxtc;
     int hs = 0;
     if (AF) {
@@ -386,11 +390,12 @@ __global__ __launch_bounds__(256) void k_microsnow(MicroArgs a) {
             q.tc = a.temp[f]; q.pk = a.pres[f]; q.u2 = a.windspeed[f];
             q.Rsw = a.swdown[f]; q.Rdif = a.difrad[f]; q.Rlw = a.lwdown[f]; q.umu = a.umu[f];
             q.hgt = hgt; q.pai = pai; q.paia = paia; q.leafd = leafd; q.clump = clump; q.ltra = ltra;
-            q.leafden = leafden; q.svfa = svfa; q.lnclump = lnclump;
+            q.leafden = leafden; q.svfa = svfa; q.lnclump = lnclump; q.ihgt = ihgt; q.ileafd = ileafd; q.ipai = ipai;
             q.Tg = a.sTg[o]; q.Tc = a.sTc[o]; q.sden = a.sden[o]; q.sdepg = a.sdepg[o];
             q.sdepc = a.swe[o] / q.sden;
             q.alb = alb;
-            const MicroMet mm = AF ? micro_met(q.tc, a.relhum[f], mxtc) : a.mmet[k];
+            q.ialb = AF ? gdiv(1.0, alb) : a.rows[k].m.ialb;
+            const MicroMet mm = AF ? micro_met(q.tc, a.relhum[f], q.pk, mxtc) : a.mmet[k];
             const MicroOut m = micro_above(q, mm, sun);
             v[0] = m.Tz; v[1] = m.tleaf; v[2] = m.rh; v[4] = m.uz; v[5] = m.Rbdown; v[6] = m.Rddown;
             v[7] = m.Rlwdn; v[8] = m.Rdup; v[9] = m.Rlwup;
@@ -492,6 +497,7 @@ __global__ __launch_bounds__(256) void k_microsnow_ring(MicroRingArgs q) {
     const double pai = a.pai[c], paia = a.paia[c], leafd = a.leafd[c], clump = a.clump[c], ltra = a.leaft[c],
                  leafden = a.leafden[c], svfa = a.skyview[c];
     const double lnclump = clump > 0.0 ? glog(clump) : 0.0;
+    const double ihgt = gdiv(1.0, hgt), ileafd = gdiv(1.0, leafd), ipai = gdiv(1.0, pai);
     for (int h = 0; h < 24; ++h) {
         const int64_t o = c + N * (k0 + h);          // chunk-local
         const int f = sub * 24 + h;                   // step of the snow-day subset series
@@ -514,10 +520,10 @@ __global__ __launch_bounds__(256) void k_microsnow_ring(MicroRingArgs q) {
             mi.tc = a.temp[f]; mi.pk = a.pres[f]; mi.u2 = a.windspeed[f];
             mi.Rsw = a.swdown[f]; mi.Rdif = a.difrad[f]; mi.Rlw = a.lwdown[f]; mi.umu = a.umu[f];
             mi.hgt = hgt; mi.pai = pai; mi.paia = paia; mi.leafd = leafd; mi.clump = clump; mi.ltra = ltra;
-            mi.leafden = leafden; mi.svfa = svfa; mi.lnclump = lnclump;
+            mi.leafden = leafden; mi.svfa = svfa; mi.lnclump = lnclump; mi.ihgt = ihgt; mi.ileafd = ileafd; mi.ipai = ipai;
             mi.Tg = a.sTg[o]; mi.Tc = a.sTc[o]; mi.sden = a.sden[o]; mi.sdepg = a.sdepg[o];
             mi.sdepc = a.swe[o] / mi.sden;
-            mi.alb = r.m.alb;
+            mi.alb = r.m.alb; mi.ialb = r.m.ialb;
             const MicroOut mo = micro_above(mi, a.mmet[f], sun);
             v[0] = mo.Tz; v[1] = mo.tleaf; v[2] = mo.rh; v[4] = mo.uz; v[5] = mo.Rbdown; v[6] = mo.Rddown;
             v[7] = mo.Rlwdn; v[8] = mo.Rdup; v[9] = mo.Rlwup;
@@ -547,6 +553,7 @@ __global__ void k_snow_alb_chunks(StepRow* rows, const double* precip, int tstep
     for (int k = k0; k < k1; ++k) {
         if (k > k0) hs = precip[k] > 0 ? 0 : hs + 1;
         rows[k].m.alb = snow_albedo(hs);
+        rows[k].m.ialb = gdiv(1.0, rows[k].m.alb);
     }
 }
 // dtms = dtm + ground snow depth (int:2562, 2614); NaN where the dtm is NA
@@ -1039,7 +1046,7 @@ int run_microsnow(const mcf_snow_inputs* in, const mcf_snowm* sm, double reqhgt,
     if (!af) {
         MicroMet* mm;
         if ((rc = b.alloc((void**)&mm, (int64_t)T * sizeof(MicroMet)))) return rc;
-        hipLaunchKernelGGL(k_micro_steps, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, nullptr, a.temp, a.relhum, a.mxtc1, T, mm);
+        hipLaunchKernelGGL(k_micro_steps, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, nullptr, a.temp, a.relhum, a.pres, a.mxtc1, T, mm);
         a.mmet = mm;
     }
     if (af) hipLaunchKernelGGL(k_microsnow_cell<true>, dim3(gridN), dim3(256), 0, nullptr, a);
@@ -1606,7 +1613,7 @@ extern "C" int mcf_snowplan_micro_setup(mcf_snowplan* sp, const mcf_snow_inputs*
     {
         MicroMet* mm;
         if ((rc = b.alloc((void**)&mm, (int64_t)T * sizeof(MicroMet)))) return rc;
-        hipLaunchKernelGGL(k_micro_steps, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, nullptr, a.temp, a.relhum, a.mxtc1, T, mm);
+        hipLaunchKernelGGL(k_micro_steps, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, nullptr, a.temp, a.relhum, a.pres, a.mxtc1, T, mm);
         a.mmet = mm;
     }
     // the chunk's snow series, where mcf_snowplan_run_chunk leaves them (sdepc holds totalSWE after the redistribution)

@@ -84,7 +84,11 @@ __device__ __forceinline__ double gdiv(double a, double b) { return a / b; }
 // pow(b, e) for b >= 0 and e > 0 (clump^Kc): pow(0, e) = 0
 __device__ __forceinline__ double gpow0(double b, double e) {
 #if MCF_SNOW_LEAN
-    return b > 0.0 ? gexp(e * glog(b)) : ::pow(b, e);
+    // b = 0 is the common special case (clump = 0: every bare cell, and a wave that holds one ran the device's 220-instruction
+    // pow for all its lanes): pow(0, e > 0) = 0.  Anything else outside b > 0 (NaNs, e <= 0) still goes to libm.
+    if (b > 0.0) return gexp(e * glog(b));
+    if (b == 0.0 && e > 0.0) return 0.0;
+    return ::pow(b, e);
 #else
     return ::pow(b, e);
 #endif
@@ -122,8 +126,10 @@ __device__ __forceinline__ double roughlen0(double h, double pai, double d) {  /
 }
 
 // ---- two-stream coefficients for spherical leaves (x = 1 -> J = 1/3), cpp:134-185 -------------
-struct TsDif { double om, a, gma, del, h, S1, iS1, u1, u2, D1, D2, p1, p2, p3, p4; };
-__device__ __forceinline__ TsDif ts_dif(double pait, double lref, double ltra, double gref) {
+struct TsDif { double om, a, gma, del, h, S1, iS1, iD1, iD2, u1, u2, D1, D2, p1, p2, p3, p4; };
+// igref = 1 / gref (the snow albedo: a step value with data.frame climate).  Three reciprocals (1/S1, 1/D1, 1/D2) serve the
+// four p's here and ts_dir's six quotients; round 2 took eleven.
+__device__ __forceinline__ TsDif ts_dif(double pait, double lref, double ltra, double gref, double igref) {
     TsDif p;
     p.om = lref + ltra;
     p.a = 1.0 - p.om;
@@ -131,19 +137,21 @@ __device__ __forceinline__ TsDif ts_dif(double pait, double lref, double ltra, d
     p.gma = 0.5 * (p.om + (1.0 / 3.0) * p.del);
     p.h = gsqrt(p.a * p.a + 2.0 * p.a * p.gma);
     p.S1 = gexp(-p.h * pait);
-    p.u1 = p.a + p.gma * (1.0 - gdiv(1.0, gref));
+    p.u1 = p.a + p.gma * (1.0 - igref);
     p.u2 = p.a + p.gma * (1.0 - gref);
     const double iS1 = gdiv(1.0, p.S1);
     p.iS1 = iS1;                                        // = exp(+h pait) to 1.5 ulp: the callers' second exponential
     p.D1 = (p.a + p.gma + p.h) * (p.u1 - p.h) * iS1 - (p.a + p.gma - p.h) * (p.u1 + p.h) * p.S1;
     p.D2 = (p.u2 + p.h) * iS1 - (p.u2 - p.h) * p.S1;
-    p.p1 = gdiv(p.gma, p.D1 * p.S1) * (p.u1 - p.h);
-    p.p2 = gdiv(-p.gma * p.S1, p.D1) * (p.u1 + p.h);
-    p.p3 = gdiv(1.0, p.D2 * p.S1) * (p.u2 + p.h);
-    p.p4 = gdiv(-p.S1, p.D2) * (p.u2 - p.h);
+    p.iD1 = gdiv(1.0, p.D1);
+    p.iD2 = gdiv(1.0, p.D2);
+    p.p1 = (p.gma * (p.iD1 * iS1)) * (p.u1 - p.h);
+    p.p2 = (-p.gma * p.S1 * p.iD1) * (p.u1 + p.h);
+    p.p3 = (p.iD2 * iS1) * (p.u2 + p.h);
+    p.p4 = (-p.S1 * p.iD2) * (p.u2 - p.h);
     return p;
 }
-struct TsDir { double sig, S2, p5, p6, p7, p8, p9, p10; };
+struct TsDir { double sig, isig, S2, p5, p6, p7, p8, p9, p10; };   // sig, isig: of the NEGATED determinant, as p8 .. p10 use it
 __device__ __forceinline__ TsDir ts_dir(double pait, const TsDif& f, double gref, double kd) {
     TsDir p;
     const double ag = f.a + f.gma;
@@ -153,17 +161,18 @@ __device__ __forceinline__ TsDir ts_dir(double pait, const TsDif& f, double gref
     const double S2 = gexp(-kd * pait);
     p.S2 = S2;
     p.p5 = -ss * (ag - kd) - f.gma * sstr;
-    const double v1 = ss - gdiv(p.p5 * (ag + kd), sig);
-    const double v2 = ss - f.gma - gdiv(p.p5, sig) * (f.u1 + kd);
-    const double iD1 = gdiv(1.0, f.D1), iD2 = gdiv(1.0, f.D2);
-    p.p6 = iD1 * (gdiv(v1, f.S1) * (f.u1 - f.h) - (ag - f.h) * S2 * v2);
-    p.p7 = -iD1 * ((v1 * f.S1) * (f.u1 + f.h) - (ag + f.h) * S2 * v2);
+    const double isg = gdiv(1.0, sig);
+    const double v1 = ss - (p.p5 * (ag + kd)) * isg;
+    const double v2 = ss - f.gma - (p.p5 * isg) * (f.u1 + kd);
+    p.p6 = f.iD1 * ((v1 * f.iS1) * (f.u1 - f.h) - (ag - f.h) * S2 * v2);
+    p.p7 = -f.iD1 * ((v1 * f.S1) * (f.u1 + f.h) - (ag + f.h) * S2 * v2);
     p.sig = -sig;
+    p.isig = -isg;
     p.p8 = sstr * (ag + kd) - f.gma * ss;
-    const double p8s = gdiv(p.p8, p.sig);
+    const double p8s = p.p8 * p.isig;
     const double v3 = (sstr + f.gma * gref - p8s * (f.u2 - kd)) * S2;
-    p.p9 = -iD2 * (gdiv(p.p8, p.sig * f.S1) * (f.u2 + f.h) + v3);
-    p.p10 = iD2 * (gdiv(p.p8 * f.S1, p.sig) * (f.u2 - f.h) + v3);
+    p.p9 = -f.iD2 * ((p8s * f.iS1) * (f.u2 + f.h) + v3);
+    p.p10 = f.iD2 * ((p8s * f.S1) * (f.u2 - f.h) + v3);
     return p;
 }
 // cankCpp for x = 1 (cpp:104-132): k, kd = k cos(z)/si, Kc = 1/si
@@ -239,7 +248,7 @@ struct MetT {          // weather-only values of one step (snowpack model)
     double tc, prec, pk, ea, te, rcan, rem;
     double la, cp, Da, gR, De;   // PenmanMonteithCpp's step-only terms, cpp:498-514
     double tdew, ph, sint;       // dewpoint, molar density, max snow load per branch area (cpp:3728-3729)
-    double rsw, rdif, rlw, umu, u2, gp, alb;
+    double rsw, rdif, rlw, umu, u2, gp, alb, ialb;   // ialb = 1 / alb
 };
 __device__ __forceinline__ void met_derive(MetT& m, double tc, double rh, double pk, double tci) {
     m.tc = tc; m.pk = pk;
@@ -337,14 +346,14 @@ __device__ __forceinline__ void pack_step(const MetT& m, const DayT& dy, const S
         RswabsG = RswabsC;
         if (hgt > 0.0) {
             if ((m.alb + ltra) > 0.999) ltra = 0.999 - m.alb;
-            const TsDif f = ts_dif(pait, m.alb, ltra, m.alb);
+            const TsDif f = ts_dif(pait, m.alb, ltra, m.alb, m.ialb);
             const CanK kp = cank1(sun.kx, sun.kcos, si);
             const TsDir d = ts_dir(pait, f, m.alb, kp.kd);
             const double clb = gpow0(c.clump, kp.Kc);
             const double ehp = f.iS1;                       // exp(h pait) = 1 / S1
             const double ekp = d.S2;                        // exp(-kd pait), ts_dir's own
             const double Rddm = clamp01((1.0 - cld) * (f.p3 * f.S1 + f.p4 * ehp) + cld);
-            const double Rdbm = clamp01((1.0 - clb) * (gdiv(d.p8, d.sig) * ekp + d.p9 * f.S1 + d.p10 * ehp));
+            const double Rdbm = clamp01((1.0 - clb) * ((d.p8 * d.isig) * ekp + d.p9 * f.S1 + d.p10 * ehp));
             const double Rbgm = clamp01((1.0 - clb) * ekp + clb);
             const double RdifG = (1.0 - m.alb) * (Rdbm * Rbeam * sun.cosz) + Rddm * Rdif;
             const double RdirG = (1.0 - m.alb) * (Rbgm * Rbeam * 0.5);
@@ -468,8 +477,9 @@ struct MicroMet {
     double De, gHrad, Rem;    // PenmanMonteith2Cpp's step-only operands                  cpp:1220-1247
     double la_pm, lat0;       // latent heat, the `>= 0` and the `< 0` flavours           cpp:1226-1229, 4837-4842
     double dTmx;              // leaf temperature cap from the series' maximum            cpp:1355
+    double ipk;               // 1 / pressure
 };
-__device__ __forceinline__ MicroMet micro_met(double tc, double relhum, double mxtc) {
+__device__ __forceinline__ MicroMet micro_met(double tc, double relhum, double pk, double mxtc) {
     MicroMet m;
     m.es = svp(tc);
     m.ea = m.es * relhum / 100.0;
@@ -481,15 +491,16 @@ __device__ __forceinline__ MicroMet micro_met(double tc, double relhum, double m
     m.la_pm = tc >= 0 ? 45068.7 - 42.8428 * tc : 51078.69 - 4.338 * tc - 0.06367 * tc * tc;
     m.lat0 = latent_lt0(tc);
     m.dTmx = -0.6273 * mxtc + 49.79;
+    m.ipk = gdiv(1.0, pk);
     return m;
 }
 struct MicroIn {
     double reqhgt, zref, tc, pk, u2, Rsw, Rdif, Rlw;               // step
     double hgt, pai, paia, leafd, clump, ltra, leafden, svfa;      // cell
-    double lnclump;                                                // glog(clump) where clump > 0 (cell)
+    double lnclump, ihgt, ileafd, ipai;                            // glog(clump) where clump > 0; reciprocals (cell)
     double si, ws, umu;
     int shadowmask;
-    double Tg, Tc, sdepc, sdepg, sden, alb;                        // snowpoint2
+    double Tg, Tc, sdepc, sdepg, sden, alb, ialb;                  // snowpoint2; ialb = 1 / alb
 };
 struct MicroOut { double Tz, tleaf, rh, uz, Rbdown, Rddown, Rlwdn, Rdup, Rlwup; };
 
@@ -529,7 +540,7 @@ __device__ __forceinline__ double rh_canopy(double uf, double h, double ih, doub
         inth = (2.0 * h * (48 * atan(0x1.1e3779b97f4a8p+1 * t) * (1.0 / 0x1.65c55827df1d2p+3) +
                            gdiv(32.0 * sn, c1 * (25.0 * (t * t) + 5.0)))) * (1.0 / kPi);
     }
-    const double mu = gdiv(uf, a2 * h) * gdiv(1.0, uf * uf);
+    const double mu = gdiv(1.0, (a2 * h) * uf);                    // uf / (a2 h) / uf^2
     double r = inth * mu;
     if (r < 0.001) r = 0.001;
     return r;
@@ -542,8 +553,8 @@ __device__ __forceinline__ BelowK below_k(double z, double d, double h, double u
     BelowK k;
     k.iKc = Rc * ih;
     k.Kc = h * gdiv(1.0, Rc);
-    k.Kg = gdiv(gdiv(1.0, rz), z);
-    k.Kh = gdiv(gdiv(1.0, Rc - rz), h - z);                        // Rc = rz: 0 x inf, a NaN as in the reference's inf / inf
+    k.Kg = gdiv(1.0, rz * z);
+    k.Kh = gdiv(1.0, (Rc - rz) * (h - z));                         // Rc = rz: NaN here, inf / inf = NaN in the reference
     k.iKs = gdiv(1.0, k.Kg + k.Kh + k.Kc);
     return k;
 }
@@ -595,10 +606,10 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
     const double es = mm.es, ea = mm.ea, tdew = mm.tdew;
     double hgts = q.hgt - q.sdepg;
     if (hgts < 0.0) hgts = 0.0;
-    const double ipk = gdiv(1.0, q.pk);
+    const double ipk = mm.ipk;
     double pais = 0.0, d = 0.0, zm = 1e-5, wa = 0.0, ihgts = 0.0, frac = 0.0;
     if (hgts > 0.0) {                                            // windtiCpp cpp:1179-1187
-        frac = hgts * gdiv(1.0, q.hgt);                          // hgt > sdepg >= 0 here
+        frac = hgts * q.ihgt;                                    // hgt > sdepg >= 0 here
         ihgts = gdiv(1.0, hgts);
         pais = q.pai * frac;
         d = zeroplane(hgts, pais);
@@ -661,7 +672,7 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
         const double ipais = gdiv(1.0, pais);
         double clumps = q.clump, lncl = 0.0;
         if (q.clump > 0.0) {
-            lncl = gdiv(pais, q.pai) * q.lnclump;
+            lncl = (pais * q.ipai) * q.lnclump;
             clumps = gexp(lncl);
         }
         const double i1c = gdiv(1.0, 1.0 - clumps);
@@ -669,7 +680,7 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
         if (q.clump > 0.0) pait = pais * i1c;
         // twostreamdif (cpp:1034-1084) with lref = gref = snow albedo
         const double pait2 = pais * i1c;
-        const TsDif f = ts_dif(pait2, q.alb, ltras, q.alb);
+        const TsDif f = ts_dif(pait2, q.alb, ltras, q.alb, q.ialb);
         double gi = 0.0, giu = 0.0, lngi = 0.0;
         if (clumps > 0.0) {
             lngi = (paias * ipais) * lncl;
@@ -687,7 +698,7 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
         const double Rddn_z = clamp01((1.0 - trd) * (f.p3 * eh_a + f.p4 * eH_a) + trd);
         // the direct-beam coefficients use twostreamdifCpp(pait, ..) (cpp:4814) but tir's D1, D2 come from pait2;
         // the reference passes tspdif's own (cpp:4817), so they are recomputed when the two differ
-        const TsDif fd = (pait == pait2) ? f : ts_dif(pait, q.alb, ltras, q.alb);
+        const TsDif fd = (pait == pait2) ? f : ts_dif(pait, q.alb, ltras, q.alb, q.ialb);
         const CanK kp = cank1(sun.kx, sun.kcos, q.si);
         const TsDir dr = ts_dir(pait, fd, q.alb, kp.kd);
         // twostreamCpp (cpp:1086-1178)
@@ -703,7 +714,7 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
                 if (trb > 0.999) trb = 0.999;
                 if (trb < 0.0) trb = 0.0;
                 const double ek_a = gexp(-kp.kd * paiaa);
-                const double isig = gdiv(1.0, dr.sig);
+                const double isig = dr.isig;
                 double Rdbup_z = (1.0 - trdu * trbn) * ((dr.p5 * -isig) * ek_a + dr.p6 * eh_a + dr.p7 * eH_a) +
                                  trdu * trbn * q.alb;
                 if (Rdbup_z > amx) Rdbup_z = amx;
@@ -732,7 +743,7 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
         const double lwup = eg * lwgro + (1 - eg) * lwcan;
         const double lwdn = eaa * q.Rlw + (1 - eaa) * lwcan;
         const double leafabs = radLsw + 0.97 * 0.5 * (lwup + lwdn);
-        const double ileafd = gdiv(1.0, q.leafd);
+        const double ileafd = q.ileafd;
         double gh = 0.135 * gsqrt(uz * ileafd) * 1.4;
         {   // mincondCpp(leafabs, 999.99, Tcan, leafd) cpp:1316-1331
             const double Rnet = leafabs - lwcan;

@@ -45,6 +45,8 @@ def main():
     rows = []            # (index, opcode, loc, label?)
     cur = None
     labels = {}
+    headers = set()
+    last_label = None
     for line in s[i:j].split("\n"):
         t = line.strip()
         if t.startswith(".loc"):
@@ -52,14 +54,19 @@ def main():
             cur = (files.get(int(p[1]), p[1]), int(p[2]))
         elif re.match(r"^\.LBB\w+:", t):
             labels[t.split(":")[0]] = len(rows)
+            last_label = t.split(":")[0]
+            if "Loop Header" in t or "in Loop:" in t:           # LLVM's own annotation: a real loop, not an exec-mask waterfall
+                headers.add(last_label)
+        elif t.startswith(";") and ("Loop Header" in t or "in Loop:" in t) and last_label:   # (the annotation can sit on its own line)
+            headers.add(last_label)
         elif line.startswith("\t") and not t.startswith((".", ";")):
             rows.append((t.split()[0], t, cur))
-    # the day loop: the backward branch spanning the most instructions
+    # the day loop: the backward branch (to a loop header) spanning the most instructions
     best = (0, 0, 0)
     for n, (op, t, _) in enumerate(rows):
         if op.startswith(("s_cbranch", "s_branch")):
             tgt = t.split()[-1]
-            if tgt in labels and labels[tgt] < n and n - labels[tgt] > best[0]:
+            if tgt in labels and labels[tgt] < n and n - labels[tgt] > best[0] and (not headers or tgt in headers):
                 best = (n - labels[tgt], labels[tgt], n)
     _, lo, hi = best
     cost = collections.Counter()

@@ -102,14 +102,20 @@ def main():
     if start is None:
         sys.exit(f"kernel {a.kernel} not found")
     body = lines[start:end]
-    ins, labels = [], {}
+    ins, labels, headers = [], {}, set()
+    last_label = None
     for ln in body:
         s = ln.split(";")[0].strip()
         if not s:
+            if ("Loop Header" in ln or "in Loop:" in ln) and last_label:      # (the annotation can sit on its own line)
+                headers.add(last_label)
             continue
         m = re.match(r"^(\.L\w+):$", s)
         if m:
             labels[m.group(1)] = len(ins)
+            last_label = m.group(1)
+            if "Loop Header" in ln or "in Loop:" in ln:          # LLVM's own annotation: a real loop, not an exec-mask waterfall
+                headers.add(m.group(1))
             continue
         if s.startswith("."):
             continue
@@ -118,7 +124,7 @@ def main():
     best = (0, 0, 0)
     for i, s in enumerate(ins):
         m = re.match(r"s_c?branch\w*\s+(\.L\w+)", s)
-        if m and m.group(1) in labels and labels[m.group(1)] <= i:
+        if m and m.group(1) in labels and labels[m.group(1)] <= i and (not headers or m.group(1) in headers):
             span = i - labels[m.group(1)]
             if span > best[0]:
                 best = (span, labels[m.group(1)], i)
