@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <condition_variable>
@@ -53,6 +54,15 @@ public:
     // Copies `bytes` from device memory to pageable host memory; `after` (may be null) is an event on
     // the producing stream that the first DMA must wait for.  Returns when `dst` is complete.
     hipError_t copy(void* dst, const void* dev_src, size_t bytes, hipEvent_t after) {
+        // A fresh destination is first touched by the copy threads below, and with 4 KB pages those faults, not PCIe, bound the
+        // call.  numpy asks for transparent huge pages on its big arrays itself; R's vectors (plain malloc) do not — so the
+        // 2 MB-aligned inside of the destination is advised here (a no-op where THP is `never` or already `always`).
+        static const bool thp = getenv("MCF_NO_THP") == nullptr;
+        if (thp && bytes >= ((size_t)8 << 20)) {
+            const uintptr_t two = (uintptr_t)2 << 20;
+            const uintptr_t a = ((uintptr_t)dst + two - 1) & ~(two - 1), b = ((uintptr_t)dst + bytes) & ~(two - 1);
+            if (b > a) (void)madvise((void*)a, b - a, MADV_HUGEPAGE);
+        }
         if (after) {
             hipError_t e = hipStreamWaitEvent(stream_, after, 0);
             if (e != hipSuccess) return e;

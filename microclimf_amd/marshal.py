@@ -9,6 +9,7 @@ row as the fastest index.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Mapping, Sequence
 
 import numpy as np
@@ -164,7 +165,14 @@ def alloc_outputs(m: Marshalled):
     arrays = {}
     for v, name in enumerate(_abi.OUT_NAMES):
         if m.options.out[v]:
-            a = np.empty((m.rows, m.cols, m.tsteps), dtype=np.float64, order="F")
+            if os.environ.get("MCF_TEST_PLAIN_OUTPUTS"):
+                # (measurement aid, tools/oneshot_rate.py: an anonymous mapping without numpy's own huge-page advice —
+                # what an R vector's malloc gives the library to write into)
+                import mmap
+                buf = mmap.mmap(-1, m.rows * m.cols * m.tsteps * 8, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
+                a = np.frombuffer(buf, dtype=np.float64).reshape((m.rows, m.cols, m.tsteps), order="F")
+            else:
+                a = np.empty((m.rows, m.cols, m.tsteps), dtype=np.float64, order="F")
             arrays[name] = a
             outs.var[v] = a.ctypes.data_as(_abi.c_double_p)
         else:
