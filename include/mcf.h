@@ -591,6 +591,13 @@ int mcf_snowplan_apply3(mcf_snowplan *plan, int32_t chunk, int32_t fun, double *
  *           the solver's value when the day is a no-snow day as well and are NA otherwise (the reference's blank template).
  * The slot then holds `.runmicrosnow1`'s merged output for the chunk's days. */
 int mcf_snowplan_reset(mcf_snowplan *plan);
+/* Pass 2 need not walk the whole series again: mcf_snowplan_checkpoint(chunk), called in pass 1 BEFORE the chunk's
+ * prepare_chunk, keeps the state the chunk starts from (pack depth handed over, snow surface, the two ages: 24 bytes per cell)
+ * on the device; mcf_snowplan_restore(chunk) puts it back.  A chunk without a snow day contributes only the no-snow solver's
+ * days to the merged output, so pass 2 restores and re-runs the chunks that hold one and skips the others.  (On a row-tiled
+ * raster every rank takes the same decision: the day classes come from all-reduced extremes.) */
+int mcf_snowplan_checkpoint(mcf_snowplan *plan, int32_t chunk);
+int mcf_snowplan_restore(mcf_snowplan *plan, int32_t chunk);
 int mcf_snowplan_meand_accumulate(mcf_snowplan *plan, int32_t chunk, const int32_t *snowday /* [days of the chunk] */);
 /* reuse_static != 0: the vegetation, terrain and Smax matrices of the previous set-up stay (only the series and the day map
  * are new). */

@@ -1103,6 +1103,8 @@ struct mcf_snowplan {
     int32_t outsel[MCF_NOUT] = {};
     std::vector<int32_t> sub_of_day;     // absolute day -> day of the snow-day subset series, or -1
     int32_t *d_daymap = nullptr, *d_nosnow = nullptr;     // [chunk days]
+    // hand-over state at the start of a chunk (mcf_snowplan_checkpoint): isnowdc, the snow surface, the two age matrices
+    std::vector<char*> ckpt;
     ~mcf_snowplan() { twork.release(); }
 };
 
@@ -1529,6 +1531,40 @@ extern "C" int mcf_snowplan_reset(mcf_snowplan* sp) {
     hipLaunchKernelGGL(k_add_snow, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, nullptr, sp->d_dtm, sp->d_isnowdg, 1.0, N,
                        sp->d_dtms);
     S_TRY(hipGetLastError());
+    sp->prepared = -1;
+    return MCF_OK;
+}
+// The state a chunk starts from — the pack depth handed over, the snow surface the terrain refresh reads, the two ages:
+// 24 bytes per cell.  Pass 1 of the snow-day microclimate checkpoints every chunk; pass 2 then restores and re-runs only the
+// chunks that hold a snow day (the others contribute nothing but the no-snow solver's days).
+extern "C" int mcf_snowplan_checkpoint(mcf_snowplan* sp, int32_t ch) {
+    if (!sp) return mcf::api_fail(MCF_ERR_ARG, "null snow plan");
+    if (ch < 0 || ch >= sp->nchunks) return mcf::api_fail(MCF_ERR_ARG, "chunk out of range");
+    S_TRY(hipSetDevice(sp->device));
+    const size_t N = (size_t)sp->N;
+    if (sp->ckpt.size() < (size_t)sp->nchunks) sp->ckpt.resize((size_t)sp->nchunks, nullptr);
+    if (!sp->ckpt[ch]) {
+        int rc;
+        if ((rc = sp->b.alloc((void**)&sp->ckpt[ch], (int64_t)N * 24))) return rc;
+    }
+    char* c = sp->ckpt[ch];
+    S_TRY(hipMemcpyAsync(c, sp->d_isnowdc, N * 8, hipMemcpyDeviceToDevice, nullptr));
+    S_TRY(hipMemcpyAsync(c + N * 8, sp->d_dtms, N * 8, hipMemcpyDeviceToDevice, nullptr));
+    S_TRY(hipMemcpyAsync(c + N * 16, sp->d_ac, N * 4, hipMemcpyDeviceToDevice, nullptr));
+    S_TRY(hipMemcpyAsync(c + N * 20, sp->d_ag, N * 4, hipMemcpyDeviceToDevice, nullptr));
+    return MCF_OK;
+}
+extern "C" int mcf_snowplan_restore(mcf_snowplan* sp, int32_t ch) {
+    if (!sp) return mcf::api_fail(MCF_ERR_ARG, "null snow plan");
+    if (ch < 0 || (size_t)ch >= sp->ckpt.size() || !sp->ckpt[ch])
+        return mcf::api_fail(MCF_ERR_STATE, "snow plan: no checkpoint of this chunk (mcf_snowplan_checkpoint in the first pass)");
+    S_TRY(hipSetDevice(sp->device));
+    const size_t N = (size_t)sp->N;
+    const char* c = sp->ckpt[ch];
+    S_TRY(hipMemcpyAsync(sp->d_isnowdc, c, N * 8, hipMemcpyDeviceToDevice, nullptr));
+    S_TRY(hipMemcpyAsync(sp->d_dtms, c + N * 8, N * 8, hipMemcpyDeviceToDevice, nullptr));
+    S_TRY(hipMemcpyAsync(sp->d_ac, c + N * 16, N * 4, hipMemcpyDeviceToDevice, nullptr));
+    S_TRY(hipMemcpyAsync(sp->d_ag, c + N * 20, N * 4, hipMemcpyDeviceToDevice, nullptr));
     sp->prepared = -1;
     return MCF_OK;
 }

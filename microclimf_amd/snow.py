@@ -698,6 +698,14 @@ class SnowPlan:
         """Back to the series' start (hand-over depths, ages, snow surface): the second pass."""
         _abi.check(self._lib.mcf_snowplan_reset(self._p))
 
+    def checkpoint(self, chunk: int):
+        """Keeps the state `chunk` starts from on the device (call before its prepare_chunk, in the first pass)."""
+        _abi.check(self._lib.mcf_snowplan_checkpoint(self._p, int(chunk)))
+
+    def restore(self, chunk: int):
+        """Puts the checkpointed start state of `chunk` back: the second pass re-runs only the chunks with a snow day."""
+        _abi.check(self._lib.mcf_snowplan_restore(self._p, int(chunk)))
+
     def meand_accumulate(self, chunk: int, snowday):
         sd = np.ascontiguousarray(snowday, dtype=np.int32)
         _abi.check(self._lib.mcf_snowplan_meand_accumulate(self._p, int(chunk), sd.ctypes.data_as(_abi.c_int32_p)))

@@ -53,6 +53,7 @@ def test_device_resident_snow_run_equals_the_host_orchestrated_merge(reqhgt, col
             return S.snowdaysfun(mx, mn)
 
         for ch in range(sp.chunks):
+            sp.checkpoint(ch)
             d = chunk(ch)
             snowday[ch * 5:ch * 5 + 5], nosnowday[ch * 5:ch * 5 + 5] = d["snowdays"], d["nosnowdays"]
             sp.meand_accumulate(ch, d["snowdays"])
@@ -108,6 +109,36 @@ def test_device_resident_snow_run_equals_the_host_orchestrated_merge(reqhgt, col
             sp.microsnow(plan, ch, slot, nos)
             for kname in got:
                 got[kname][:, :, ch * 120:(ch + 1) * 120] = plan.fetch(slot, kname, 0, 120)
+        # ---- pass 2 again from the checkpoints: only the chunks that hold a snow day are re-run, in any order (here: backwards)
+        got2 = {k: np.full((rows, cols, T), np.nan, order="F") for k in moutn}
+        rerun = 0
+        for ch in reversed(range(sp.chunks)):
+            slot = ch % 2
+            nos = nosnowday[ch * 5:ch * 5 + 5]
+            has_snow = bool(snowday[ch * 5:ch * 5 + 5].any())
+            if has_snow:
+                sp.restore(ch)
+                d = chunk(ch)
+                assert np.array_equal(d["snowdays"], snowday[ch * 5:ch * 5 + 5])
+                rerun += 1
+            k = 0
+            while k < 5:
+                if not nos[k]:
+                    k += 1
+                    continue
+                e = k
+                while e < 5 and nos[e]:
+                    e += 1
+                plan.run_days_at(ch * 5 + k, e - k, slot, k)
+                k = e
+            if has_snow:
+                sp.microsnow(plan, ch, slot, nos)
+            for kname in got2:
+                got2[kname][:, :, ch * 120:(ch + 1) * 120] = plan.fetch(slot, kname, 0, 120)
+        for k in got:
+            assert np.array_equal(got[k], got2[k], equal_nan=True), k
+        with pytest.raises(RuntimeError):
+            sp.restore(sp.chunks)           # no such checkpoint
     for k in want:
         g, w = got[k], want[k]
         assert np.array_equal(np.isnan(g), np.isnan(w)), k

@@ -171,6 +171,7 @@ def run_snow_config(args, world, rank, local_rank):
         # ---- pass 1: snow series chunk by chunk -> day classes, running sum of the snow damping depth
         snowday, nosnowday = np.zeros(ncd, np.int32), np.zeros(ncd, np.int32)
         for ch in range(sp.chunks):
+            sp.checkpoint(ch)                                   # 24 B per cell: pass 2 starts any chunk from here
             tl = snow_chunk(ch)
             mx, cmx = sp.apply3(ch, "max")
             mn, cmn = sp.apply3(ch, "min")
@@ -194,14 +195,19 @@ def run_snow_config(args, world, rank, local_rank):
         stats["years"] += 1
         if ndays_.size:
             plan.set_mxtc(float(np.max(a["climdata"]["temp"][steps_of(ndays_[ndays_ < ndays])])))
-        sp.reset()
         tl = lap("micro set-up", tl)
         # ---- pass 2: the series again + the solver on the no-snow days + the snow-day microclimate over it
         slot = 0
         for ch in range(sp.chunks):
-            tl = snow_chunk(ch)
             d0 = ch * chunk_days
             nos = nosnowday[d0:d0 + chunk_days]
+            has_snow = bool(snowday[d0:d0 + chunk_days].any())
+            tl = time.perf_counter()
+            if has_snow:                                          # a chunk without a snow day is the solver's alone
+                sp.restore(ch)
+                tl = snow_chunk(ch)
+            else:
+                stats["chunks_skipped"] = stats.get("chunks_skipped", 0) + 1
             k = 0
             while k < len(nos):                                       # runs of consecutive no-snow days -> one launch each
                 if not nos[k]:
@@ -216,7 +222,7 @@ def run_snow_config(args, world, rank, local_rank):
                     stats["solver_days"] += nd
                 k = e
             tl = lap("solver", tl)
-            if sdays.size:
+            if sdays.size and has_snow:
                 sp.microsnow(plan, ch, slot, nos)
             tl = lap("microsnow", tl)
             slot = (slot + 1) % 2
@@ -254,7 +260,9 @@ def run_snow_config(args, world, rank, local_rank):
                         "generated, not exchanged: the neighbouring blocks' snow-free surface, resident on the device (a rank's share of "
                         "the partition without its neighbours)" if not exchange_ok else "single block",
                 "collectives": "per chunk: 2 (sum, count) all-reduces + min / max all-reduce of [120] doubles; once: twi (sum, count)",
-                "passes": "2 over the snow series (gridmicrosnow1 needs the whole series' mean snow damping depth and day list first)",
+                "passes": "2 over the snow series (gridmicrosnow1 needs the whole series' mean snow damping depth and day list "
+                          "first); pass 1 checkpoints every chunk's start state (24 B per cell), pass 2 restores and re-runs only the "
+                          f"chunks that hold a snow day ({stats.get('chunks_skipped', 0) // max(stats['years'], 1)} of {sp.chunks} skipped per year)",
                 "verified": "not in this run: the snow surface feeds neighbourhood operators (terrain, tpi), so a sample of cells cannot be "
                             "re-run by the oracle; tests/test_snow_micro_pipeline_gpu.py and tests/test_snow_gpu.py hold the same calls "
                             "against the host-orchestrated route and the oracle on small rasters",
