@@ -596,6 +596,16 @@ int mcf_snowplan_reset(mcf_snowplan *plan);
  * on the device; mcf_snowplan_restore(chunk) puts it back.  A chunk without a snow day contributes only the no-snow solver's
  * days to the merged output, so pass 2 restores and re-runs the chunks that hold one and skips the others.  (On a row-tiled
  * raster every rank takes the same decision: the day classes come from all-reduced extremes.) */
+/* Sparse read-back of the plan's device arrays for n cells (0-based, column-major index within the block): out is
+ * [n, depth] column-major, depth = 1 (hand-over state, slope, aspect, sky view), 8 (wind shelter), 24 (horizons) or the
+ * chunk's steps (the series of the chunk run last; MCF_SNOWPLAN_TOTALSWE after the redistribution).  For in-run checks of a
+ * sample of cells against a CPU model (bench.py --config 4); no counterpart in the reference. */
+enum {
+    MCF_SNOWPLAN_ISNOWDC = 0, MCF_SNOWPLAN_ISNOWAC = 1, MCF_SNOWPLAN_ISNOWAG = 2, MCF_SNOWPLAN_SLOPE = 3, MCF_SNOWPLAN_ASPECT = 4,
+    MCF_SNOWPLAN_SKYVIEW = 5, MCF_SNOWPLAN_WSA = 6, MCF_SNOWPLAN_HOR = 7, MCF_SNOWPLAN_TC = 8, MCF_SNOWPLAN_TG = 9,
+    MCF_SNOWPLAN_SDEPG = 10, MCF_SNOWPLAN_SDEN = 11, MCF_SNOWPLAN_TOTALSWE = 12
+};
+int mcf_snowplan_fetch_cells(mcf_snowplan *plan, int32_t what, const int64_t *cells, int32_t n, double *out, int32_t *depth);
 int mcf_snowplan_checkpoint(mcf_snowplan *plan, int32_t chunk);
 int mcf_snowplan_restore(mcf_snowplan *plan, int32_t chunk);
 int mcf_snowplan_meand_accumulate(mcf_snowplan *plan, int32_t chunk, const int32_t *snowday /* [days of the chunk] */);

@@ -1534,6 +1534,58 @@ extern "C" int mcf_snowplan_reset(mcf_snowplan* sp) {
     sp->prepared = -1;
     return MCF_OK;
 }
+// Sparse read-back of the plan's device state: `n` cells x the array's depth (planes N apart), for in-run checks of a sample
+// of cells against the oracle (tools/bench_snow.py) — the analogue of mcf_plan_fetch_cells for the snow plan.
+__global__ __launch_bounds__(256) void k_gather_planes(const double* __restrict__ src, const int32_t* __restrict__ isrc, int64_t N,
+                                                       const int64_t* __restrict__ cells, int n, int depth,
+                                                       double* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * depth) return;
+    const int j = t % n, k = t / n;
+    const int64_t q = cells[j] + N * (int64_t)k;
+    out[t] = src ? src[q] : (double)isrc[q];
+}
+extern "C" int mcf_snowplan_fetch_cells(mcf_snowplan* sp, int32_t what, const int64_t* cells, int32_t n, double* out,
+                                        int32_t* depth_out) {
+    if (!sp || !cells || !out || n <= 0) return mcf::api_fail(MCF_ERR_ARG, "null argument");
+    const int ns = sp->chunk;
+    const double* src = nullptr;
+    const int32_t* isrc = nullptr;
+    int depth = 1;
+    switch (what) {
+        case MCF_SNOWPLAN_ISNOWDC: src = sp->d_isnowdc; break;
+        case MCF_SNOWPLAN_ISNOWAC: isrc = sp->d_ac; break;
+        case MCF_SNOWPLAN_ISNOWAG: isrc = sp->d_ag; break;
+        case MCF_SNOWPLAN_SLOPE: src = sp->d_slope; break;
+        case MCF_SNOWPLAN_ASPECT: src = sp->d_aspect; break;
+        case MCF_SNOWPLAN_SKYVIEW: src = sp->d_svf; break;
+        case MCF_SNOWPLAN_WSA: src = sp->d_wsa; depth = 8; break;
+        case MCF_SNOWPLAN_HOR: src = sp->d_hor; depth = 24; break;
+        case MCF_SNOWPLAN_TC: src = sp->a.Tc; depth = ns; break;
+        case MCF_SNOWPLAN_TG: src = sp->a.Tg; depth = ns; break;
+        case MCF_SNOWPLAN_SDEPG: src = sp->a.sdepg; depth = ns; break;
+        case MCF_SNOWPLAN_SDEN: src = sp->a.sden; depth = ns; break;
+        case MCF_SNOWPLAN_TOTALSWE: src = sp->a.sdepc; depth = ns; break;
+        default: return mcf::api_fail(MCF_ERR_ARG, "snow plan: unknown array");
+    }
+    for (int j = 0; j < n; ++j)
+        if (cells[j] < 0 || cells[j] >= sp->N) return mcf::api_fail(MCF_ERR_ARG, "snow plan: cell index outside the block");
+    S_TRY(hipSetDevice(sp->device));
+    Bufs tmp;
+    int rc;
+    int64_t* d_cells;
+    double* d_out;
+    if ((rc = tmp.alloc((void**)&d_cells, (int64_t)n * 8))) return rc;
+    if ((rc = tmp.alloc((void**)&d_out, (int64_t)n * depth * 8))) return rc;
+    S_TRY(hipMemcpy(d_cells, cells, (size_t)n * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_gather_planes, dim3((unsigned)((n * depth + 255) / 256)), dim3(256), 0, nullptr, src, isrc, sp->N,
+                       (const int64_t*)d_cells, n, depth, d_out);
+    S_TRY(hipGetLastError());
+    S_TRY(hipMemcpy(out, d_out, (size_t)n * depth * 8, hipMemcpyDeviceToHost));
+    if (depth_out) *depth_out = depth;
+    return MCF_OK;
+}
+
 // The state a chunk starts from — the pack depth handed over, the snow surface the terrain refresh reads, the two ages:
 // 24 bytes per cell.  Pass 1 of the snow-day microclimate checkpoints every chunk; pass 2 then restores and re-runs only the
 // chunks that hold a snow day (the others contribute nothing but the no-snow solver's days).

@@ -698,6 +698,21 @@ class SnowPlan:
         """Back to the series' start (hand-over depths, ages, snow surface): the second pass."""
         _abi.check(self._lib.mcf_snowplan_reset(self._p))
 
+    FETCH = {"isnowdc": 0, "isnowac": 1, "isnowag": 2, "slope": 3, "aspect": 4, "skyview": 5, "wsa": 6, "hor": 7,
+             "Tc": 8, "Tg": 9, "groundsnowdepth": 10, "snowden": 11, "totalSWE": 12}
+
+    def fetch_cells(self, what: str, cells) -> np.ndarray:
+        """[len(cells), depth] values of one of the plan's device arrays (FETCH) for a sample of cells (0-based column-major
+        indices within the block): the hand-over state, the chunk's terrain, the series of the chunk run last."""
+        c = np.ascontiguousarray(cells, dtype=np.int64)
+        depth = {"wsa": 8, "hor": 24}.get(what, self._chunk_steps if self.FETCH[what] >= 8 else 1)
+        out = np.empty((c.size, depth), dtype=np.float64, order="F")
+        d = C.c_int32()
+        _abi.check(self._lib.mcf_snowplan_fetch_cells(self._p, self.FETCH[what], c.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                      int(c.size), out.ctypes.data_as(_abi.c_double_p), C.byref(d)))
+        assert d.value == depth
+        return out
+
     def checkpoint(self, chunk: int):
         """Keeps the state `chunk` starts from on the device (call before its prepare_chunk, in the first pass)."""
         _abi.check(self._lib.mcf_snowplan_checkpoint(self._p, int(chunk)))

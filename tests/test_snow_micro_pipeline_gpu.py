@@ -58,6 +58,16 @@ def test_device_resident_snow_run_equals_the_host_orchestrated_merge(reqhgt, col
             snowday[ch * 5:ch * 5 + 5], nosnowday[ch * 5:ch * 5 + 5] = d["snowdays"], d["nosnowdays"]
             sp.meand_accumulate(ch, d["snowdays"])
         smod = {k: v.copy() for k, v in sp.result.items()}
+        # sparse read-back of the plan's device arrays (bench.py --config 4 checks a sample of cells with it)
+        cells = np.array([0, 7, rows + 3, rows * cols - 1], dtype=np.int64)
+        last = slice((sp.chunks - 1) * 120, sp.chunks * 120)
+        for name in ("Tc", "Tg", "groundsnowdepth", "snowden", "totalSWE"):
+            whole = smod[name].reshape(rows * cols, T, order="F")
+            assert np.array_equal(sp.fetch_cells(name, cells), whole[cells][:, last], equal_nan=True), name
+        assert np.array_equal(sp.fetch_cells("isnowdc", cells)[:, 0], sp.handover().ravel(order="F")[cells], equal_nan=True)
+        assert sp.fetch_cells("hor", cells).shape == (4, 24) and sp.fetch_cells("wsa", cells).shape == (4, 8)
+        with pytest.raises(RuntimeError):
+            sp.fetch_cells("Tc", [rows * cols])
         assert snowday.sum() >= 3 and nosnowday.sum() >= 3 and (snowday & nosnowday).sum() >= 1, (snowday, nosnowday)
         sdays, ndays_ = np.flatnonzero(snowday), np.flatnonzero(nosnowday)
 

@@ -226,23 +226,85 @@ def run_snow_config(args, world, rank, local_rank):
                 sp.microsnow(plan, ch, slot, nos)
             tl = lap("microsnow", tl)
             slot = (slot + 1) % 2
+        return snowday
+
+    def verify_sample(snowday, ncells=256):
+        """The snow model of the year's LAST chunk with a snow day, re-run from the timed run's own checkpoint and held against
+        the oracle for a sample of cells: the oracle gets the cells' hand-over state and the chunk's terrain (slope, aspect,
+        sky view, wind shelter, horizons — products of neighbourhood operators the oracle cannot redo for a sample) from the
+        device and runs gridmodelsnow1 on the chunk's 120 steps.  Every rank re-runs the chunk (its halo exchange and
+        reductions are collective); rank 0 compares its own block."""
+        chs = [ch for ch in range(sp.chunks) if snowday[ch * chunk_days:(ch + 1) * chunk_days].any()]
+        if not chs:
+            return {"ok": None, "note": "no snow day in the year"}
+        ch = chs[-1]
+        sp.restore(ch)
+        hg = np.asarray(sw["vegp"]["hgt"]).ravel(order="F")
+        ok_cells = np.flatnonzero(~np.isnan(hg))
+        cells = ok_cells[np.linspace(0, ok_cells.size - 1, min(ncells, ok_cells.size)).astype(np.int64)]
+        state = {k: sp.fetch_cells(k, cells)[:, 0] for k in ("isnowdc", "isnowac", "isnowag")}
+        snow_chunk(ch)
+        if rank != 0:
+            return None
+        from oracle import oracle as O
+        O.load()
+        K = cells.size
+        k0, ns = ch * chunk_days * 24, chunk_days * 24
+        sl = slice(k0, k0 + ns)
+        col = lambda a: np.asfortranarray(np.asarray(a, dtype=np.float64).ravel(order="F")[cells].reshape(K, 1))
+        oth = dict(sw["other"])
+        for k in ("slope", "aspect", "skyview"):
+            oth[k] = np.asfortranarray(sp.fetch_cells(k, cells).reshape(K, 1))
+        oth["wsa"] = np.asfortranarray(sp.fetch_cells("wsa", cells).reshape(K, 1, 8))
+        oth["hor"] = np.asfortranarray(sp.fetch_cells("hor", cells).reshape(K, 1, 24))
+        oth["isnowdc"] = np.asfortranarray(state["isnowdc"].reshape(K, 1))
+        oth["isnowdg"] = col(sw["other"]["isnowdg"])
+        oth["isnowac"] = np.asfortranarray(state["isnowac"].reshape(K, 1))
+        oth["isnowag"] = np.asfortranarray(state["isnowag"].reshape(K, 1))
+        vg = {k: col(v) for k, v in sw["vegp"].items()}
+        cut = lambda d: {k: (np.asarray(v)[sl] if np.ndim(v) == 1 else v) for k, v in d.items()}
+        want = O.run_snowmodel(cut(sw["obstime"]), cut(sw["climdata"]), cut(sw["pointm"]), vg, oth, sw["snowenv"])
+        worst, bad = 0.0, []
+        # (ground snow depth and totalSWE leave the chunk redistributed by the topographic position index: not comparable)
+        for name, key in (("Tc", "Tc"), ("Tg", "Tg"), ("snowden", "sden")):
+            g = sp.fetch_cells(name, cells)
+            w = want[key].reshape(K, ns, order="F")
+            if not np.array_equal(np.isnan(g), np.isnan(w)):
+                bad.append(name + ": NA pattern")
+                continue
+            f = np.isfinite(w)
+            e = float(np.max(np.abs(g[f] - w[f]) / (1 + np.abs(w[f])))) if f.any() else 0.0
+            worst = max(worst, e)
+            if e > 1e-6:
+                bad.append(f"{name}: {e:.2e}")
+        return {"ok": not bad, "max_scaled_err": worst, "tolerance": 1e-6, "cells": int(K), "steps": int(ns), "chunk": int(ch),
+                "what": "gridmodelsnow1 of the year's last chunk with a snow day (Tc, Tg and snow density of every step), re-run "
+                        "from the timed run's checkpoint, against oracle/snow_oracle.c given the cells' hand-over state and the "
+                        "chunk's terrain from the device; the terrain refresh, the tpi redistribution (which rewrites the chunk's snow depths) and the snow-day microclimate are "
+                        "held against the oracle by tests/test_snow_gpu.py, test_terrain_gpu.py and test_snow_micro_pipeline_gpu.py "
+                        "on small rasters", "mismatches": bad or None}
 
     for _ in range(args.warmup):
         one_year()
     fence()
     stats["solver_days"] = stats["snow_days"] = 0
     t0 = time.perf_counter()
+    last_days = None
     for _ in range(args.steps):
-        one_year()
+        last_days = one_year()
     fence()
     dt = allreduce_max(time.perf_counter() - t0)
+    verified = None
+    if not getattr(args, "no_verify", False) and last_days is not None:
+        verified = verify_sample(last_days)
     valid_all = allreduce_sum(float(valid))
     value = valid_all * ndays * 24 * args.steps / dt
     if rank == 0:
         sd = stats["solver_days"] / max(args.steps, 1)
         snd = stats["snow_days"] / max(args.steps, 1)
         # 5 snow series per cell-step in each of the two passes + 10 outputs per cell-step of a solver day or a snow day
-        alg = valid_all * 24 * (2 * ndays * 40.0 + (sd + snd) * 80.05) * args.steps
+        passes = 1.0 + (sp.chunks - stats.get("chunks_skipped", 0) / max(stats["years"], 1)) / sp.chunks
+        alg = valid_all * 24 * (passes * ndays * 40.0 + (sd + snd) * 80.05) * args.steps
         line = {
             "metric": "cell-steps/s", "value": value, "unit": "cell-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
@@ -263,16 +325,14 @@ def run_snow_config(args, world, rank, local_rank):
                 "passes": "2 over the snow series (gridmicrosnow1 needs the whole series' mean snow damping depth and day list "
                           "first); pass 1 checkpoints every chunk's start state (24 B per cell), pass 2 restores and re-runs only the "
                           f"chunks that hold a snow day ({stats.get('chunks_skipped', 0) // max(stats['years'], 1)} of {sp.chunks} skipped per year)",
-                "verified": "not in this run: the snow surface feeds neighbourhood operators (terrain, tpi), so a sample of cells cannot be "
-                            "re-run by the oracle; tests/test_snow_micro_pipeline_gpu.py and tests/test_snow_gpu.py hold the same calls "
-                            "against the host-orchestrated route and the oracle on small rasters",
                 "sink": "solver: HBM ring (2 slots x 5 days); snow series: chunk buffers on the device, no D2H",
             },
             "input_setup_s": setup_s,
             "stage_seconds": stage_s or None,
+            "verified": verified,
             "roofline": {"bound": "fp64_valu", "achieved": alg / dt / 1e9, "peak": 8000.0 * world, "unit": "GB/s",
                          "frac": alg / dt / 1e9 / (8000.0 * world), "traffic": None, "kernel": "pipeline: 2 x (k_snowmodel + terrain) + k_solve + k_microsnow_ring",
-                         "frac_is": "algorithmic bytes (2 x 40 B per snow cell-step + 80 B per solver or snow-microclimate cell-step) / time / 8 TB/s per GPU"},
+                         "frac_is": "algorithmic bytes (40 B per snow-model cell-step of pass 1 and of the chunks pass 2 re-runs + 80 B per solver or snow-microclimate cell-step) / time / 8 TB/s per GPU"},
         }
         if cpu is not None:
             # one pass over the snow model for every step + the solver / gridmicrosnow1 on their shares of the year's days
@@ -284,9 +344,13 @@ def run_snow_config(args, world, rank, local_rank):
         os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)
         os.dup2(2, 1)
+    rc = 0
+    if rank == 0 and verified is not None and verified.get("ok") is False:
+        print("bench.py --config 4: the timed run's snow series do NOT match the oracle: " + json.dumps(verified), file=sys.stderr)
+        rc = 3
     plan.close()
     sp.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    return 0
+    return rc
