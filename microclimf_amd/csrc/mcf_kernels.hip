@@ -491,8 +491,7 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
     // the barrier of day d, when every wave is past reading it (it held day d - 1) and none can write it before the barrier of
     // day d + 1.
     constexpr bool PRE = CPB == 21;
-    __shared__ double s_red[PRE ? 1 : 2][2][PRE ? 1 : 24 * CPB];
-    __shared__ double s_ext[PRE ? 3 : 1][3][PRE ? CPB : 1];        // [buffer][max Tg0, min Tg0, max |Rnet|][cell]
+    __shared__ double s_ext[3][3][CPB];        // [buffer][max Tg0, min Tg0, max |Rnet|][cell]
     __shared__ double s_dd[BG ? 24 * CPB : 1];
     // per cell-day soil state (mcf_device.hpp SoilDay): a ring of three days, filled two days ahead by one wave
     constexpr bool SS = SSREQ && (AF == 0) && (2 * CPB <= 64);
@@ -596,7 +595,7 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
     // L2 is quick; what the output stream costs is clock (profiles/r03_timing_experiments.txt).
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
     if (F && tid == 0) s_trip = 0;
-    if (PRE && tid < 9 * CPB) (&s_ext[0][0][0])[tid] = ((tid / CPB) % 3 == 0) ? -999.0 : ((tid / CPB) % 3 == 1) ? 999.0 : -999.9;   // cpp:2196-2198
+    if (tid < 9 * CPB) (&s_ext[0][0][0])[tid] = ((tid / CPB) % 3 == 0) ? -999.0 : ((tid / CPB) % 3 == 1) ? 999.0 : -999.9;   // cpp:2196-2198
     Globals g = a.g;
     double dTmx = g.dTmx;
     if (AF && in_grid) dTmx = -0.6273 * a.mxtc[c] + 49.79;   // cpp:1236 with the per-cell mxtc
@@ -752,14 +751,16 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
 
         Carry cy;
         Pass1Out p1;
-        double* red_t = &s_red[PRE ? 0 : run & 1][0][PRE ? 0 : hr * CPB + cl];
-        double* red_r = &s_red[PRE ? 0 : run & 1][1][PRE ? 0 : hr * CPB + cl];
         if (valid) {
             if (AF) pass1<F, false>(C, TR, SL, g, flags, dTmx, cy, p1, MK, cn);
             else pass1<F, SS>(C, TL, SL, g, flags, dTmx, cy, p1, MK, cn);
             if (!PRE) {
-                *red_t = p1.Tg0;
-                *red_r = p1.absRnet;
+                // every hour lane folds its values into the cell's slots (the 21-cell lane map combines a wave's three hours
+                // of a cell through the crossbar first, below); `if (m < x) m = x` ignores a NaN x, so does the LDS unit
+                double (*ext)[CPB] = s_ext[run % 3];
+                __hip_atomic_fetch_max(&ext[0][cl], p1.Tg0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_min(&ext[1][cl], p1.Tg0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(&ext[2][cl], p1.absRnet, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             put(3, cy.soilm);     // soilm      cpp:2227
             put(4, p1.uz);        // windspeed  cpp:2253
@@ -795,10 +796,10 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
             asm("v_max_f64 %0, %0, %1" : "+v"(rmx3) : "v"(r2));
             // `if (m < x) m = x` ignores a NaN x; so does the LDS unit's float max / min (the slot is never NaN: it starts finite)
             if (valid && (l < 16 || (l >= 48 && l < 53))) {
-                double (*ext)[PRE ? CPB : 1] = s_ext[PRE ? run % 3 : 0];
-                __hip_atomic_fetch_max(&ext[0][PRE ? cl : 0], tmx3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_min(&ext[1][PRE ? cl : 0], tmn3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_max(&ext[2][PRE ? cl : 0], rmx3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                double (*ext)[CPB] = s_ext[run % 3];
+                __hip_atomic_fetch_max(&ext[0][cl], tmx3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_min(&ext[1][cl], tmn3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_max(&ext[2][cl], rmx3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         if (stage) {
@@ -810,8 +811,8 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
             }
         }
         __syncthreads();
-        if (PRE && tid < 3 * CPB)      // reset the buffer of the day after next (see s_ext)
-            s_ext[PRE ? (run + 2) % 3 : 0][PRE ? tid / CPB : 0][PRE ? tid % CPB : 0] = tid < CPB ? -999.0 : tid < 2 * CPB ? 999.0 : -999.9;
+        if (tid < 3 * CPB)      // reset the buffer of the day after next (see s_ext)
+            s_ext[(run + 2) % 3][tid / CPB][tid % CPB] = tid < CPB ? -999.0 : tid < 2 * CPB ? 999.0 : -999.9;
         if (SS) {
             // Every wave is past the day before now, so the soil ring slot of the day after next (= that of the day before)
             // is free; whoever fills it reaches the NEXT barrier before any wave starts that day.  The waves take turns.  A
@@ -823,21 +824,7 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
             // day reductions with the reference's comparisons, cpp:2196-2198, 2256-2263.  `if (Rmx < rv) Rmx = rv` with a
             // finite start value ignores a NaN rv, exactly what v_max_f64 does (the accumulator is never NaN, rv is never a
             // signalling NaN: it was just computed): one VALU instruction instead of a compare and two 32-bit selects
-            double Rmx = -999.9, tmx = -999.0, tmn = 999.0;
-            const double* rt = &s_red[PRE ? 0 : run & 1][0][PRE ? 0 : cl];
-            const double* rr = &s_red[PRE ? 0 : run & 1][1][PRE ? 0 : cl];
-            if (PRE) {
-                tmx = s_ext[PRE ? run % 3 : 0][0][PRE ? cl : 0];
-                tmn = s_ext[PRE ? run % 3 : 0][1][PRE ? cl : 0];
-                Rmx = s_ext[PRE ? run % 3 : 0][2][PRE ? cl : 0];
-            }
-#pragma unroll
-            for (int hh = 0; hh < (PRE ? 0 : 24); ++hh) {
-                double tg = rt[hh * CPB], rv = rr[hh * CPB];
-                asm("v_max_f64 %0, %0, %1" : "+v"(Rmx) : "v"(rv));
-                asm("v_max_f64 %0, %0, %1" : "+v"(tmx) : "v"(tg));
-                asm("v_min_f64 %0, %0, %1" : "+v"(tmn) : "v"(tg));
-            }
+            const double tmx = s_ext[run % 3][0][cl], tmn = s_ext[run % 3][1][cl], Rmx = s_ext[run % 3][2][cl];
             const double dtr = tmx - tmn;
             Pass2Out p2{};
             if (AF) derive_time_af_pass2(tv);
