@@ -688,10 +688,8 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
         TimeVals tv;
         // the tile-day block of the tiled forcing ring (uniform) — the lane's value of series f is at [f][pos]
         const double* fday = (AF == 1) ? a.af_base + tile * a.af_tile_stride + (int64_t)(dabs - a.day0) * a.af_day_stride : nullptr;
-        auto force = [&](int f) {
-            asm("" : "+v"(posb));      // (see `put`: keeps the addressing mode SGPR base + lane offset)
-            return *(const double*)((const char*)fday + (size_t)f * (NT * 8) + posb);
-        };
+        // (pb: an opaque copy of the lane offset made ONCE in the loads' own block — one move instead of one per load; see `put`)
+        auto force = [&](int f, unsigned pb) { return *(const double*)((const char*)fday + (size_t)f * (NT * 8) + pb); };
         if (AF && valid) {
             const int64_t kabs = (int64_t)dabs * 24 + hr;
             // pass 2's ground heat flux takes four more series, through ONE value (cpp:1282-1289): loaded here with the rest,
@@ -718,11 +716,15 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
                 if (a.need_pass2) { p2gp = at(TF_GP); p2mugp = at(TF_MUGP); p2dtrp = at(TF_DTRP); p2kp = at(TF_KP); }
             } else {
                 // the 15 series, slots TF_TC .. TF_DTRP: ten raw inputs and umu feed pass 1; Gp, kp, muGp, dtrp feed GFAC below
-                for (int f = 0; f < 10; ++f) tv.v[f] = force(f);
-                tv.v[TF_UMU] = force(TF_UMU);
+                unsigned pb = posb;
+                asm("" : "+v"(pb));
+                for (int f = 0; f < 10; ++f) tv.v[f] = force(f, pb);
+                tv.v[TF_UMU] = force(TF_UMU, pb);
                 if (a.need_pass2) {
-                    p2gp = force(TF_GP); p2mugp = force(TF_MUGP);
-                    p2dtrp = force(TF_DTRP); p2kp = force(TF_KP);
+                    unsigned pc = posb;
+                    asm("" : "+v"(pc));
+                    p2gp = force(TF_GP, pc); p2mugp = force(TF_MUGP, pc);
+                    p2dtrp = force(TF_DTRP, pc); p2kp = force(TF_KP, pc);
                 }
             }
             DateRow dr{a.dt[4 * kabs + 0], a.dt[4 * kabs + 1], a.dt[4 * kabs + 2], a.dt[4 * kabs + 3]};
