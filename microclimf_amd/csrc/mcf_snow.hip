@@ -23,6 +23,9 @@
 #include "mcf_hostpipe.hpp"
 #include "mcf_snow_device.hpp"
 
+#ifndef MCF_MICRO_WAVES
+#define MCF_MICRO_WAVES 2   // waves per SIMD the snow-microclimate kernels are built for (232 VGPRs); 3: 168 VGPRs + 260 B scratch per lane
+#endif
 #ifndef MCF_SNOW_WAVES
 #define MCF_SNOW_WAVES 3   // waves per SIMD k_snowmodel is built for (151 VGPRs); 4 (128 VGPRs + 100 B scratch per lane)
                            // measured the same: 8.2 - 8.4 ms per 1024 x 1024 x 120-step chunk either way
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(256) void k_microsnow_cell(MicroArgs a) {
 }
 
 template <bool AF>
-__global__ __launch_bounds__(256) void k_microsnow(MicroArgs a) {
+__global__ __launch_bounds__(256, MCF_MICRO_WAVES) void k_microsnow(MicroArgs a) {
     snow::snow_tables_init();
     // one lane per (cell, day); the day is the block's (blockIdx.y), so the step rows are wave-uniform scalar loads
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -459,7 +462,7 @@ struct MicroRingArgs {
     const int32_t *daymap, *nosnow;
     int32_t ndays;
 };
-__global__ __launch_bounds__(256) void k_microsnow_ring(MicroRingArgs q) {
+__global__ __launch_bounds__(256, MCF_MICRO_WAVES) void k_microsnow_ring(MicroRingArgs q) {
     snow::snow_tables_init();
     const MicroArgs& a = q.m;
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
