@@ -56,3 +56,11 @@ def test_two_ranks_over_gloo_share_this_gpu():
     d = _bench("--gpus", "2", "--config", "4", "--rows", "320", "--cols", "96", "--share", "2", "--tsteps", "720", "--steps", "1",
                "--warmup", "0", env={"MCF_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["baseline_config"] == 4
+    assert d["verified"]["ok"], d["verified"]          # the last snow chunk's model against the oracle (rank 0's block)
+
+
+def test_snow_config_line_is_checked_against_the_oracle_in_the_run():
+    d = _bench("--config", "4", "--rows", "160", "--cols", "96", "--tsteps", "1440", "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
+    v = d["verified"]
+    assert v["ok"] and v["max_scaled_err"] < 1e-6 and v["cells"] > 100 and v["steps"] == 120, v
+    assert "checkpoint" in d["config"]["passes"]
