@@ -606,6 +606,15 @@ enum {
     MCF_SNOWPLAN_SDEPG = 10, MCF_SNOWPLAN_SDEN = 11, MCF_SNOWPLAN_TOTALSWE = 12
 };
 int mcf_snowplan_fetch_cells(mcf_snowplan *plan, int32_t what, const int64_t *cells, int32_t n, double *out, int32_t *depth);
+/* ... and need not re-run a chunk whose series still fit the device: mcf_snowplan_keep_chunk(chunk, reserve_bytes, &kept),
+ * called in pass 1 after run_chunk and everything that reads the chunk's series (apply3, meand_accumulate), hands the chunk's
+ * five series buffers over to a cache and gives the plan fresh ones — as long as `reserve_bytes` of device memory stay free
+ * (kept = 0 otherwise; a year of one rank's block of configs[4] is 38 snow chunks x 10 GB against 288 GB of HBM).
+ * mcf_snowplan_microsnow reads a kept chunk where it lies: pass 2 skips restore / prepare_chunk / run_chunk for it.
+ * mcf_snowplan_release_kept (before the next year's pass 1) returns the sets to a pool the next year draws from: allocating
+ * 10 GB takes about 0.25 s, more than re-running the chunk — the cache pays from a plan's second year on. */
+int mcf_snowplan_keep_chunk(mcf_snowplan *plan, int32_t chunk, int64_t reserve_bytes, int32_t *kept);
+int mcf_snowplan_release_kept(mcf_snowplan *plan);
 int mcf_snowplan_checkpoint(mcf_snowplan *plan, int32_t chunk);
 int mcf_snowplan_restore(mcf_snowplan *plan, int32_t chunk);
 int mcf_snowplan_meand_accumulate(mcf_snowplan *plan, int32_t chunk, const int32_t *snowday /* [days of the chunk] */);

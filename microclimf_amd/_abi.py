@@ -173,7 +173,8 @@ EXPORTS = (
     "mcf_plan_belowground", "mcf_plan_sync", "mcf_plan_fetch", "mcf_plan_fetch_cells", "mcf_plan_fetch_packed", "mcf_plan_slot_ptr",
     "mcf_plan_ring_layout", "mcf_ring_index", "mcf_plan_run_days_at", "mcf_plan_set_mxtc",
     "mcf_runmicro1_multi", "mcf_runmicro2_multi", "mcf_plan_fetch_pitched",
-    "mcf_snowplan_reset", "mcf_snowplan_checkpoint", "mcf_snowplan_restore", "mcf_snowplan_fetch_cells", "mcf_snowplan_meand_accumulate", "mcf_snowplan_micro_setup", "mcf_snowplan_microsnow",
+    "mcf_snowplan_reset", "mcf_snowplan_checkpoint", "mcf_snowplan_restore", "mcf_snowplan_fetch_cells", "mcf_snowplan_keep_chunk",
+    "mcf_snowplan_release_kept", "mcf_snowplan_meand_accumulate", "mcf_snowplan_micro_setup", "mcf_snowplan_microsnow",
     "mcf_plan_timer_start", "mcf_plan_timer_stop", "mcf_plan_kernel_timing",
     "mcf_plan_kernel_stats", "mcf_plan_dispatch_stats", "mcf_plan_valid_cells", "mcf_plan_bytes", "mcf_selftest_math",
     "mcf_precompute_terrain", "mcf_runbioclim1", "mcf_runbioclim2", "mcf_runbioclim3", "mcf_runbioclim4",
@@ -300,6 +301,10 @@ def load() -> C.CDLL:
         lib.mcf_snowplan_reset.argtypes = [P]
         lib.mcf_snowplan_fetch_cells.restype = C.c_int
         lib.mcf_snowplan_fetch_cells.argtypes = [P, C.c_int32, C.POINTER(C.c_int64), C.c_int32, c_double_p, C.POINTER(C.c_int32)]
+        lib.mcf_snowplan_keep_chunk.restype = C.c_int
+        lib.mcf_snowplan_keep_chunk.argtypes = [P, C.c_int32, C.c_int64, C.POINTER(C.c_int32)]
+        lib.mcf_snowplan_release_kept.restype = C.c_int
+        lib.mcf_snowplan_release_kept.argtypes = [P]
         for fn in (lib.mcf_snowplan_checkpoint, lib.mcf_snowplan_restore):
             fn.restype = C.c_int
             fn.argtypes = [P, C.c_int32]

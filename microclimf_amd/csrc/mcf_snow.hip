@@ -1108,6 +1108,12 @@ struct mcf_snowplan {
     int32_t *d_daymap = nullptr, *d_nosnow = nullptr;     // [chunk days]
     // hand-over state at the start of a chunk (mcf_snowplan_checkpoint): isnowdc, the snow surface, the two age matrices
     std::vector<char*> ckpt;
+    // series of chunks kept on the device between the two passes (mcf_snowplan_keep_chunk): a kept chunk's buffers are the ones
+    // the model wrote — the plan goes on with fresh ones — so pass 2 neither re-runs the chunk nor copies anything
+    struct Kept { double *Tc = nullptr, *Tg = nullptr, *sdepc = nullptr, *sdepg = nullptr, *sden = nullptr; };
+    std::vector<Kept> kept;
+    std::vector<Kept> pool;              // released sets, reused by the next year's pass 1 (hipMalloc of 10 GB costs 0.25 s)
+    Bufs kb;
     ~mcf_snowplan() { twork.release(); }
 };
 
@@ -1589,6 +1595,58 @@ extern "C" int mcf_snowplan_fetch_cells(mcf_snowplan* sp, int32_t what, const in
     return MCF_OK;
 }
 
+// HBM is 288 GB and a chunk's five series of one rank's block are 10 GB: what pass 1 wrote for a chunk with a snow day can
+// simply stay.  keep_chunk (after run_chunk and whatever reads the series) hands the chunk's buffers over to the cache and
+// gives the plan fresh ones, as long as `reserve_bytes` of device memory stay free; mcf_snowplan_microsnow then reads a kept
+// chunk where it lies, and the caller neither restores nor re-runs it.  release_kept hands the sets to a pool for the next
+// year (allocation is the expensive part: the cache pays from the second year of a plan on).
+extern "C" int mcf_snowplan_keep_chunk(mcf_snowplan* sp, int32_t ch, int64_t reserve_bytes, int32_t* kept) {
+    if (!sp || !kept) return mcf::api_fail(MCF_ERR_ARG, "null argument");
+    if (ch < 0 || ch >= sp->nchunks) return mcf::api_fail(MCF_ERR_ARG, "chunk out of range");
+    *kept = 0;
+    S_TRY(hipSetDevice(sp->device));
+    if (sp->kept.size() < (size_t)sp->nchunks) sp->kept.resize((size_t)sp->nchunks);
+    if (sp->kept[ch].Tc) { *kept = 1; return MCF_OK; }
+    const int64_t one = (int64_t)sp->chunk * sp->N * 8;
+    double* fresh[5] = {};
+    if (!sp->pool.empty()) {               // a set an earlier year released
+        const mcf_snowplan::Kept f = sp->pool.back();
+        sp->pool.pop_back();
+        fresh[0] = f.Tc; fresh[1] = f.Tg; fresh[2] = f.sdepc; fresh[3] = f.sdepg; fresh[4] = f.sden;
+    } else {
+        size_t free_b = 0, total_b = 0;
+        S_TRY(hipMemGetInfo(&free_b, &total_b));
+        if ((int64_t)free_b < 5 * one + std::max<int64_t>(reserve_bytes, 0)) return MCF_OK;
+        for (int v = 0; v < 5; ++v) {
+            if (hipMalloc((void**)&fresh[v], (size_t)one) != hipSuccess) {      // (another process took the room: not an error)
+                (void)hipGetLastError();
+                for (int u = 0; u < v; ++u) { (void)hipFree(fresh[u]); sp->kb.p.pop_back(); }
+                return MCF_OK;
+            }
+            sp->kb.p.push_back(fresh[v]);
+        }
+    }
+    S_TRY(hipDeviceSynchronize());         // (the chunk's kernels are done before its buffers change hands)
+    ModelArgs& a = sp->a;
+    mcf_snowplan::Kept k;
+    k.Tc = a.Tc; k.Tg = a.Tg; k.sdepc = a.sdepc; k.sdepg = a.sdepg; k.sden = a.sden;
+    a.Tc = fresh[0]; a.Tg = fresh[1]; a.sdepc = fresh[2]; a.sdepg = fresh[3]; a.sden = fresh[4];
+    sp->kept[ch] = k;
+    *kept = 1;
+    return MCF_OK;
+}
+extern "C" int mcf_snowplan_release_kept(mcf_snowplan* sp) {
+    if (!sp) return mcf::api_fail(MCF_ERR_ARG, "null snow plan");
+    S_TRY(hipSetDevice(sp->device));
+    S_TRY(hipDeviceSynchronize());
+    // the sets go to a pool for the next year's pass 1 (allocating 10 GB takes a quarter of a second: a year's cache costs more
+    // to allocate than it saves, so it is allocated once per plan); the plan's allocation lists still own every buffer
+    for (auto& k : sp->kept)
+        if (k.Tc) sp->pool.push_back(k);
+    sp->kept.clear();
+    return MCF_OK;
+}
+
 // The state a chunk starts from — the pack depth handed over, the snow surface the terrain refresh reads, the two ages:
 // 24 bytes per cell.  Pass 1 of the snow-day microclimate checkpoints every chunk; pass 2 then restores and re-runs only the
 // chunks that hold a snow day (the others contribute nothing but the no-snow solver's days).
@@ -1750,6 +1808,14 @@ extern "C" int mcf_snowplan_microsnow(mcf_snowplan* sp, mcf_plan* plan, int32_t 
     S_TRY(hipMemcpy(sp->d_daymap, sp->sub_of_day.data() + day0, (size_t)nd * 4, hipMemcpyHostToDevice));
     S_TRY(hipMemcpy(sp->d_nosnow, nosnowday, (size_t)nd * 4, hipMemcpyHostToDevice));
     q.m = sp->ma;
+    {   // the chunk's snow series: where pass 1 left them if the chunk was kept, the plan's working buffers otherwise
+        const bool k = (size_t)ch < sp->kept.size() && sp->kept[ch].Tc;
+        q.m.sTc = k ? sp->kept[ch].Tc : sp->a.Tc;
+        q.m.sTg = k ? sp->kept[ch].Tg : sp->a.Tg;
+        q.m.swe = k ? sp->kept[ch].sdepc : sp->a.sdepc;
+        q.m.sdepg = k ? sp->kept[ch].sdepg : sp->a.sdepg;
+        q.m.sden = k ? sp->kept[ch].sden : sp->a.sden;
+    }
     for (int v = 0; v < MCF_NOUT; ++v) q.sel[v] = sp->outsel[v];
     q.daymap = sp->d_daymap; q.nosnow = sp->d_nosnow; q.ndays = nd;
     hipLaunchKernelGGL(k_microsnow_ring, dim3((unsigned)((N + 255) / 256), (unsigned)nd), dim3(256), 0, nullptr, q);

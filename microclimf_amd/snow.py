@@ -713,6 +713,16 @@ class SnowPlan:
         assert d.value == depth
         return out
 
+    def keep_chunk(self, chunk: int, reserve_bytes: int = 32 << 30) -> bool:
+        """After run_chunk (and apply3 / meand_accumulate): the chunk's series stay on the device for the second pass if
+        `reserve_bytes` of device memory remain free; True if kept (then pass 2 only calls microsnow for it)."""
+        k = C.c_int32()
+        _abi.check(self._lib.mcf_snowplan_keep_chunk(self._p, int(chunk), int(reserve_bytes), C.byref(k)))
+        return bool(k.value)
+
+    def release_kept(self):
+        _abi.check(self._lib.mcf_snowplan_release_kept(self._p))
+
     def checkpoint(self, chunk: int):
         """Keeps the state `chunk` starts from on the device (call before its prepare_chunk, in the first pass)."""
         _abi.check(self._lib.mcf_snowplan_checkpoint(self._p, int(chunk)))

@@ -147,6 +147,38 @@ def test_device_resident_snow_run_equals_the_host_orchestrated_merge(reqhgt, col
                 got2[kname][:, :, ch * 120:(ch + 1) * 120] = plan.fetch(slot, kname, 0, 120)
         for k in got:
             assert np.array_equal(got[k], got2[k], equal_nan=True), k
+        # ---- and with the snow chunks' series kept on the device by a repeated pass 1: pass 2 runs no snow model at all
+        sp.reset()
+        sp.release_kept()
+        assert not sp.keep_chunk(0, reserve_bytes=1 << 50)          # no room by decree: not kept, no error
+        kept = []
+        for ch in range(sp.chunks):
+            d = chunk(ch)
+            kept.append(bool(d["snowdays"].any()) and sp.keep_chunk(ch, reserve_bytes=1 << 30))
+        assert any(kept)
+        got3 = {k: np.full((rows, cols, T), np.nan, order="F") for k in moutn}
+        for ch in range(sp.chunks):
+            slot = ch % 2
+            nos = nosnowday[ch * 5:ch * 5 + 5]
+            has_snow = bool(snowday[ch * 5:ch * 5 + 5].any())
+            assert kept[ch] == has_snow
+            k = 0
+            while k < 5:
+                if not nos[k]:
+                    k += 1
+                    continue
+                e = k
+                while e < 5 and nos[e]:
+                    e += 1
+                plan.run_days_at(ch * 5 + k, e - k, slot, k)
+                k = e
+            if has_snow:
+                sp.microsnow(plan, ch, slot, nos)
+            for kname in got3:
+                got3[kname][:, :, ch * 120:(ch + 1) * 120] = plan.fetch(slot, kname, 0, 120)
+        for k in got:
+            assert np.array_equal(got[k], got3[k], equal_nan=True), k
+        sp.release_kept()                                           # (the sets go to a pool the next year's pass 1 draws from)
         with pytest.raises(RuntimeError):
             sp.restore(sp.chunks)           # no such checkpoint
     for k in want:
