@@ -22,7 +22,7 @@ P2 = '''            if (AF) pass2<F, false>(C, TR, SL, g, flags, dTmx, cy, dtr, 
 ST = '''                asm("" : "+v"(posb));
                 *(double*)((char*)ring_day + ((size_t)sel * (NT * 8)) + posb) = val;'''
 BAR = '''        __syncthreads();
-        if (PRE && tid < 3 * CPB)      // reset the buffer of the day after next (see s_ext)'''
+        if (tid < 3 * CPB)      // reset the buffer of the day after next (see s_ext)'''
 LOOP = '''    for (int dl = 0; dl < ndays; ++dl, ++run) {
         const int dabs = day0 + dl;'''
 SECT_GLOBAL = ('''namespace mcf {
@@ -49,7 +49,7 @@ VARIANTS = {
     "storehot": [(ST, '''                asm("" : "+v"(posb));
                 *(double*)((char*)a.out_base + (((size_t)tile & 63) * 40960 + (size_t)sel * (NT * 8)) + posb) = val;   // TIMING VARIANT: every store issued, into an L2-resident window''')],
     "nobarrier": [(BAR, '''        // TIMING VARIANT: no day barrier
-        if (PRE && tid < 3 * CPB)      // reset the buffer of the day after next (see s_ext)''')],
+        if (tid < 3 * CPB)      // reset the buffer of the day after next (see s_ext)''')],
     # (No "no time-table prefetch" variant: without the rows the physics runs on whatever the LDS slots hold — zeros send every
     # step down the night path — so its launch time says nothing about the prefetch's cost.  Two real reorderings were measured
     # in round 3 instead, same box: the rows written in front of pass 1's stores, and staged two days ahead and written in front
@@ -76,7 +76,7 @@ VARIANTS = {
                  (BAR, '''        const long long t_p1 = clock64();
         __syncthreads();
         const long long t_bar = clock64();
-        if (PRE && tid < 3 * CPB)      // reset the buffer of the day after next (see s_ext)'''),
+        if (tid < 3 * CPB)      // reset the buffer of the day after next (see s_ext)'''),
                  ('''        if (!BG) ring_day += a.out_day_stride;
     }''', '''        if (!BG) ring_day += a.out_day_stride;
         const long long t_end = clock64();
