@@ -50,7 +50,8 @@
 extern "C" {
 #endif
 
-#define MCF_ABI_VERSION 3   /* 2: mcf_grid_inputs grew the coarse-forcing fields; 3: tiled output ring (mcf_plan_ring_layout) */
+#define MCF_ABI_VERSION 4   /* 2: mcf_grid_inputs grew the coarse-forcing fields; 3: tiled output ring (mcf_plan_ring_layout);
+                             * 4: mcf_nc_spec grew format / deflate_level (zero = the behaviour of version 3) */
 
 /* Output variables, in the order of the reference's returned list
  * (src/microclimfCpp.cpp:2326-2335) and of its `out` logical(10). */
@@ -275,9 +276,14 @@ int mcf_plan_fetch_packed(mcf_plan *plan, int32_t slot, int32_t var, int64_t ste
  * runmicro_big, R/Cppwrappers.R:531): the solver's outputs as int32 (x100 for Tz, tleaf, soilm,
  * windspeed; x1 for relhum and the radiation terms; round half even; NA -> missval -9999) on the
  * dimensions east, north, time, with writetonc's variable names, long names, units, `crs` variable and
- * time attributes.  File format: netCDF classic, 64-bit offsets, `time` as the record dimension,
- * uncompressed (the reference writes netCDF-4/deflate through ncdf4; every netCDF reader opens both;
- * see mcf_ncfile.hpp).  The dataset keeps writetonc's orientation: north[i] belongs to raster row i,
+ * time attributes.  Two containers (`format`):
+ *   MCF_NC_CLASSIC  netCDF classic, 64-bit offsets, `time` as the record dimension, uncompressed — needs nothing on the
+ *                   host and streams at disk speed (mcf_ncfile.hpp); every netCDF reader opens it like the reference's file;
+ *   MCF_NC_NETCDF4  the reference's own container (ncvar_def(..., compression = 9), dataprep.R:1110-1111): HDF5 laid out by
+ *                   the netCDF-4 conventions, chunked [1 step][row strip][cols], deflate `deflate_level`; written through
+ *                   the host's HDF5 library, bound at run time (MCF_ERR_ARG with the reason if there is none), the chunks
+ *                   deflated by a team of host threads (mcf_nc4file.hpp).
+ * Both take the same records (the device packs them once, k_pack_nc).  The dataset keeps writetonc's orientation: north[i] belongs to raster row i,
  * with `north` the ASCENDING northings of dataprep.R:1073 (the reference does not flip the rows).
  *
  * `vars[v]` selects solver output v (MCF_OUT order); writetonc defines Tz, tleaf, relhum, soilm,
@@ -286,6 +292,7 @@ int mcf_plan_fetch_packed(mcf_plan *plan, int32_t slot, int32_t var, int64_t ste
  * reference really produces: its `ncvar_put` guards test names ("raddir", …) that never occur in `vars`
  * (dataprep.R:1163-1167) and the soilm put refers to an undefined object (:1161), so those variables
  * are defined but hold missval throughout; 0 writes what was evidently meant. */
+enum { MCF_NC_CLASSIC = 0, MCF_NC_NETCDF4 = 1 };
 typedef struct mcf_nc_spec {
     int32_t rows, cols;          /* raster rows (= length of north), columns (= length of east) */
     int64_t nsteps;
@@ -296,6 +303,8 @@ typedef struct mcf_nc_spec {
     double reqhgt;
     int32_t vars[MCF_NOUT];
     int32_t reference_puts_only;
+    int32_t format;              /* MCF_NC_CLASSIC (0) or MCF_NC_NETCDF4                                    */
+    int32_t deflate_level;       /* MCF_NC_NETCDF4: 0 = writetonc's compression = 9, 1..9, -1 = none      */
 } mcf_nc_spec;
 typedef struct mcf_ncfile mcf_ncfile;
 /* Host only (no device needed): create the file with header, coordinates and room for every record. */

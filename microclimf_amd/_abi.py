@@ -142,7 +142,8 @@ class BigLeafOut(C.Structure):
 class NcSpec(C.Structure):
     _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("nsteps", C.c_int64), ("east", c_double_p),
                 ("north", c_double_p), ("time_hours", c_double_p), ("crs_wkt", C.c_char_p), ("reqhgt", C.c_double),
-                ("vars", C.c_int32 * 10), ("reference_puts_only", C.c_int32)]
+                ("vars", C.c_int32 * 10), ("reference_puts_only", C.c_int32), ("format", C.c_int32),
+                ("deflate_level", C.c_int32)]
 
 
 POINTSNOW_FIELDS = ("Tc", "Tg", "sdepc", "sdepg", "sdenc", "sdeng", "G", "RswabsG", "RlwabsG", "tr", "umu", "sublmelt",
@@ -188,7 +189,7 @@ EXPORTS = (
     "mcf_flowacc", "mcf_topidx",
 )
 
-ABI_VERSION = 3     # include/mcf.h MCF_ABI_VERSION this mirror was written against
+ABI_VERSION = 4     # include/mcf.h MCF_ABI_VERSION this mirror was written against
 _lib = None
 
 

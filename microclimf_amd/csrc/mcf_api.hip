@@ -22,6 +22,7 @@
 #include "mcf_kernels.h"
 #include "mcf_hostpipe.hpp"
 #include "mcf_ncfile.hpp"
+#include "mcf_nc4file.hpp"
 
 namespace {
 
@@ -330,7 +331,7 @@ int ensure_cells(mcf_plan* p) {
 
 // ---- writetonc sink (R/dataprep.R:1063-1260) -------------------------------------------------------------------
 struct mcf_ncfile {
-    mcf::NcFile f;
+    std::unique_ptr<mcf::NcFile> f;
     int var_of[MCF_NOUT];        // file variable index of solver output v, or -1
     int out_of[MCF_NOUT];        // solver output of file variable k
     double scale[MCF_NOUT];      // per file variable
@@ -1097,8 +1098,21 @@ int mcf_nc_create(const char* path, const mcf_nc_spec* sp, mcf_ncfile** out) {
         defs.push_back(d);
     }
     if (defs.empty()) { delete nc; return fail(MCF_ERR_ARG, "mcf_nc_create: no variable selected"); }
-    const std::string e = nc->f.create(path, sp->rows, sp->cols, sp->nsteps, sp->east, sp->north, sp->time_hours,
-                                       sp->crs_wkt, defs);
+    std::string e;
+    if (sp->format == MCF_NC_NETCDF4) {
+        // the reference's container (dataprep.R:1110: compression = 9); deflate_level 0 = the reference's 9, -1 = none
+        const int level = sp->deflate_level == 0 ? 9 : sp->deflate_level < 0 ? 0 : sp->deflate_level;
+        mcf::Nc4File* f4 = new mcf::Nc4File();
+        nc->f.reset(f4);
+        if (sp->nsteps == 0) e = "a netCDF-4 file needs at least one time step";
+        else if (level > 9) e = "deflate_level above 9";
+        else e = f4->create4(path, sp->rows, sp->cols, sp->nsteps, sp->east, sp->north, sp->time_hours, sp->crs_wkt, defs, level);
+    } else if (sp->format == MCF_NC_CLASSIC) {
+        nc->f.reset(new mcf::NcFile());
+        e = nc->f->create(path, sp->rows, sp->cols, sp->nsteps, sp->east, sp->north, sp->time_hours, sp->crs_wkt, defs);
+    } else {
+        e = "unknown format";
+    }
     if (!e.empty()) { delete nc; return fail(MCF_ERR_ARG, "mcf_nc_create: " + e); }
     *out = nc;
     return MCF_OK;
@@ -1106,30 +1120,30 @@ int mcf_nc_create(const char* path, const mcf_nc_spec* sp, mcf_ncfile** out) {
 
 int mcf_nc_close(mcf_ncfile* nc) {
     if (!nc) return MCF_OK;
-    const std::string e = nc->f.close();
+    const std::string e = nc->f->close();
     delete nc;
     return e.empty() ? MCF_OK : fail(MCF_ERR_ARG, "mcf_nc_close: " + e);
 }
 
 int mcf_nc_write_host(mcf_ncfile* nc, int64_t step0, int64_t nsteps, const double* const vars[MCF_NOUT]) {
     if (!nc || !vars) return fail(MCF_ERR_ARG, "null argument");
-    if (step0 < 0 || nsteps < 0 || step0 + nsteps > nc->f.nsteps) return fail(MCF_ERR_ARG, "mcf_nc_write_host: step range outside the file");
-    const int64_t R = nc->f.rows, C = nc->f.cols, N = R * C, rb = nc->f.rec_bytes;
-    for (int k = 0; k < nc->f.nvars; ++k)
+    if (step0 < 0 || nsteps < 0 || step0 + nsteps > nc->f->nsteps) return fail(MCF_ERR_ARG, "mcf_nc_write_host: step range outside the file");
+    const int64_t R = nc->f->rows, C = nc->f->cols, N = R * C, rb = nc->f->rec_bytes;
+    for (int k = 0; k < nc->f->nvars; ++k)
         if (!nc->fill_only[k] && !vars[nc->out_of[k]]) return fail(MCF_ERR_ARG, "mcf_nc_write_host: a variable of the file is missing");
     const int64_t piece = std::max<int64_t>(1, ((int64_t)64 << 20) / rb);
     for (int64_t s0 = 0; s0 < nsteps; s0 += piece) {
         const int64_t n = std::min(piece, nsteps - s0);
         uint8_t* st = nc->staging(0, (size_t)(n * rb));
         for (int64_t s = 0; s < n; ++s)
-            for (int k = 0; k < nc->f.nvars; ++k) {
+            for (int k = 0; k < nc->f->nvars; ++k) {
                 uint8_t* dst = st + s * rb + 8 + (int64_t)k * N * 4;
                 const double* src = nc->fill_only[k] ? nullptr : vars[nc->out_of[k]] + (s0 + s) * N;
                 for (int64_t r = 0; r < R; ++r)
                     for (int64_t c = 0; c < C; ++c)
                         mcf::NcFile::store_i32(dst + 4 * (c + C * r), src ? nc_pack(src[r + R * c], nc->scale[k]) : mcf::NcFile::kMissval);
             }
-        const std::string e = nc->f.write_records(step0 + s0, n, st);
+        const std::string e = nc->f->write_records(step0 + s0, n, st);
         if (!e.empty()) return fail(MCF_ERR_ARG, "mcf_nc_write_host: " + e);
     }
     return MCF_OK;
@@ -1138,14 +1152,14 @@ int mcf_nc_write_host(mcf_ncfile* nc, int64_t step0, int64_t nsteps, const doubl
 int mcf_nc_write_plan(mcf_ncfile* nc, mcf_plan* p, int32_t slot, int64_t slot_step0, int64_t file_step0, int64_t nsteps,
                       float* kernel_ms) {
     if (!nc || !p) return fail(MCF_ERR_ARG, "null argument");
-    if (nc->f.rows != p->rows || nc->f.cols != p->cols) return fail(MCF_ERR_ARG, "mcf_nc_write_plan: the file's grid is not the plan's");
+    if (nc->f->rows != p->rows || nc->f->cols != p->cols) return fail(MCF_ERR_ARG, "mcf_nc_write_plan: the file's grid is not the plan's");
     if (slot < 0 || slot >= p->ring_slots) return fail(MCF_ERR_ARG, "bad slot");
     const int64_t cap_steps = (int64_t)p->ring_days * 24;
     if (slot_step0 < 0 || nsteps < 0 || slot_step0 + nsteps > cap_steps) return fail(MCF_ERR_ARG, "step range out of slot");
-    if (file_step0 < 0 || file_step0 + nsteps > nc->f.nsteps) return fail(MCF_ERR_ARG, "mcf_nc_write_plan: step range outside the file");
+    if (file_step0 < 0 || file_step0 + nsteps > nc->f->nsteps) return fail(MCF_ERR_ARG, "mcf_nc_write_plan: step range outside the file");
     mcf::PackNcArgs a{};
-    a.nv = nc->f.nvars; a.missval = mcf::NcFile::kMissval; a.rows = p->rows; a.cols = p->cols;
-    a.rec_words = nc->f.rec_bytes / 4;
+    a.nv = nc->f->nvars; a.missval = mcf::NcFile::kMissval; a.rows = p->rows; a.cols = p->cols;
+    a.rec_words = nc->f->rec_bytes / 4;
     for (int k = 0; k < a.nv; ++k) {
         const int v = nc->out_of[k];
         a.scale[k] = nc->scale[k];
@@ -1155,7 +1169,7 @@ int mcf_nc_write_plan(mcf_ncfile* nc, mcf_plan* p, int32_t slot, int64_t slot_st
         a.src[k] = ring_view(p, slot, v);
     }
     HIP_TRY(hipSetDevice(p->device));
-    const int64_t rb = nc->f.rec_bytes;
+    const int64_t rb = nc->f->rec_bytes;
     int64_t piece = std::min<int64_t>(65535 / a.nv, std::max<int64_t>(1, ((int64_t)256 << 20) / rb));
     piece = std::min(piece, std::max<int64_t>(nsteps, 1));
     if (p->pack_elems < piece * (rb / 4)) {
@@ -1200,7 +1214,7 @@ int mcf_nc_write_plan(mcf_ncfile* nc, mcf_plan* p, int32_t slot, int64_t slot_st
         if (pending.valid()) werr = pending.get();
         if (e != hipSuccess) { rc = fail(MCF_ERR_HIP, std::string("mcf_nc_write_plan: ") + hipGetErrorString(e)); break; }
         if (!werr.empty()) break;
-        mcf::NcFile* f = &nc->f;
+        mcf::NcFile* f = nc->f.get();
         uint8_t* data = st;
         const int64_t fs = file_step0 + s0;
         pending = std::async(std::launch::async, [f, fs, n, data] { return f->write_records(fs, n, data); });

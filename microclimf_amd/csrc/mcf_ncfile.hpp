@@ -1,7 +1,8 @@
 // mcf_ncfile.hpp — the file side of the `writetonc` sink (reference R/dataprep.R:1063-1260).
 //
-// writetonc goes through ncdf4 -> libnetcdf -> HDF5 (netCDF-4, deflate 9); none of those exist in this image, and
-// a hand-rolled HDF5 writer is out of proportion.  This writes the same dataset — dimensions east, north, time;
+// writetonc goes through ncdf4 -> libnetcdf -> HDF5 (netCDF-4, deflate 9).  That container is mcf_nc4file.hpp (format =
+// MCF_NC_NETCDF4; it needs an HDF5 library on the host at run time).  This is the container that needs nothing and streams
+// fastest (format = MCF_NC_CLASSIC, the default): it writes the same dataset — dimensions east, north, time;
 // int variables named as the solver's outputs with writetonc's long names, units and missval -9999; the `crs`
 // variable and the time attributes of add_crs_info — in netCDF CLASSIC 64-bit-offset format ("CDF\x02"), which
 // ncdf4::nc_open, terra and every other netCDF reader open like a netCDF-4 file.  Differences a reader can see:
@@ -40,7 +41,7 @@ public:
     NcFile() = default;
     NcFile(const NcFile&) = delete;
     NcFile& operator=(const NcFile&) = delete;
-    ~NcFile() { close(); }
+    virtual ~NcFile() { NcFile::close(); }
 
     int64_t rows = 0, cols = 0, nsteps = 0;
     int nvars = 0;
@@ -122,7 +123,7 @@ public:
     }
 
     // records [step0, step0 + n) as they lie in the file, except for the 8 leading time bytes of each, which are set here
-    std::string write_records(int64_t step0, int64_t n, uint8_t* recs) {
+    virtual std::string write_records(int64_t step0, int64_t n, uint8_t* recs) {
         if (fd_ < 0) return "file is closed";
         if (step0 < 0 || n < 0 || step0 + n > nsteps) return "record range outside the file";
         for (int64_t s = 0; s < n; ++s) store_f64(recs + s * rec_bytes, time_hours[step0 + s]);
@@ -145,7 +146,7 @@ public:
         return "";
     }
 
-    std::string close() {
+    virtual std::string close() {
         std::string e;
         if (fd_ >= 0 && ::close(fd_) != 0) e = std::string("close: ") + strerror(errno);
         fd_ = -1;

@@ -2,7 +2,9 @@
 int32 variables on (east, north, time).  `NcWriter` is the streaming form (day chunks straight from a `Plan`'s device
 ring, packed and byte-ordered on the GPU); `writetonc` has the reference's call shape for a finished `mout`.
 
-File format: netCDF classic / 64-bit offsets, `time` as record dimension, uncompressed (include/mcf.h, mcf_ncfile.hpp).
+Two containers (`format=`): "classic" — netCDF classic / 64-bit offsets, `time` as record dimension, uncompressed, needs
+nothing on the host (mcf_ncfile.hpp) — and "netcdf4", the reference's own (HDF5 by the netCDF-4 conventions, chunked,
+deflate 9 unless `deflate_level` says otherwise; needs an HDF5 library on the host at run time, mcf_nc4file.hpp).
 """
 from __future__ import annotations
 
@@ -18,6 +20,9 @@ from . import _abi
 DEFAULT_VARS_ABOVE = ("Tz", "tleaf", "relhum", "windspeed", "Rdirdown", "Rdifdown", "Rlwdown", "Rswup", "Rlwup")
 DEFAULT_VARS_SURFACE = ("Tz", "soilm", "Rdirdown", "Rdifdown", "Rlwdown", "Rswup", "Rlwup")
 DEFAULT_VARS_BELOW = ("Tz", "soilm")
+
+
+FORMATS = {"classic": 0, "netcdf4": 1}      # MCF_NC_CLASSIC, MCF_NC_NETCDF4
 
 
 def default_vars(reqhgt: float) -> tuple:
@@ -41,7 +46,8 @@ def hours_since_epoch(obstime: Mapping) -> np.ndarray:
 
 class NcWriter:
     def __init__(self, fileout: str, rows: int, cols: int, time_hours, east, north, reqhgt: float,
-                 vars: Sequence[str] | None = None, crs_wkt: str = "", reference_puts_only: bool = False):
+                 vars: Sequence[str] | None = None, crs_wkt: str = "", reference_puts_only: bool = False,
+                 format: str = "classic", deflate_level: int = 0):
         self._lib = _abi.load()
         self.vars = tuple(default_vars(reqhgt) if vars is None else vars)
         unknown = [v for v in self.vars if v not in _abi.OUT_NAMES]
@@ -63,6 +69,10 @@ class NcWriter:
         for v in self.vars:
             sp.vars[_abi.OUT_NAMES.index(v)] = 1
         sp.reference_puts_only = 1 if reference_puts_only else 0
+        if format not in FORMATS:
+            raise ValueError(f"format must be one of {sorted(FORMATS)}")
+        sp.format = FORMATS[format]
+        sp.deflate_level = int(deflate_level)       # netcdf4: 0 = writetonc's compression = 9, -1 = none
         self.rows, self.cols, self.nsteps = rows, cols, len(self._t)
         self._h = C.c_void_p()
         _abi.check(self._lib.mcf_nc_create(str(fileout).encode(), C.byref(sp), C.byref(self._h)))
@@ -109,7 +119,7 @@ class NcWriter:
 
 
 def writetonc(mout: Mapping, fileout: str, dtm: Mapping, reqhgt: float, vars: Sequence[str] | None = None,
-              reference_puts_only: bool = False):
+              reference_puts_only: bool = False, format: str = "classic", deflate_level: int = 0):
     """`writetonc(mout, fileout, dtm, reqhgt, vars)`: `mout` holds the output arrays and `tme` (an obstime table or
     hours since 1970); `dtm` = {"xmin","xmax","ymin","ymax","res", optional "crs"} stands for the SpatRaster."""
     names = tuple(default_vars(reqhgt) if vars is None else vars)
@@ -120,5 +130,6 @@ def writetonc(mout: Mapping, fileout: str, dtm: Mapping, reqhgt: float, vars: Se
     res = dtm["res"]
     xres, yres = (res, res) if np.isscalar(res) else res
     east, north = coords_from_extent(dtm["xmin"], dtm["xmax"], dtm["ymin"], dtm["ymax"], xres, yres)
-    with NcWriter(fileout, rows, cols, hours, east, north, reqhgt, names, dtm.get("crs", ""), reference_puts_only) as w:
+    with NcWriter(fileout, rows, cols, hours, east, north, reqhgt, names, dtm.get("crs", ""), reference_puts_only,
+                  format=format, deflate_level=deflate_level) as w:
         w.write_host(0, {k: mout[k] for k in names if k in mout})

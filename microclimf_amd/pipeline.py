@@ -18,12 +18,14 @@ from .api import Plan
 
 def run_to_nc(inputs: Mapping, fileout: str, dtm: Mapping, *, vars: Sequence[str] | None = None,
               days_per_chunk: int = 5, device: int = 0, array_forcing: bool = False,
-              reference_puts_only: bool = False, twi_mean: float | None = None) -> dict:
+              reference_puts_only: bool = False, twi_mean: float | None = None, format: str = "classic",
+              deflate_level: int = 0) -> dict:
     """`inputs`: the 15 arguments of runmicro1Cpp / runmicro2Cpp by name (as `synthetic.workload` returns them);
     with "dfsel" added for time-varying vegetation (runmicro3Cpp); `dtm`: {"xmin","xmax","ymin","ymax","res"[, "crs"]} of
     the tile.  Variables default to writetonc's for the height.
     `twi_mean`: the raster-wide mean of log(twi)/tfact when this tile is part of a larger raster
-    (`distributed.allreduce_twi_mean`).  Returns timings and sizes."""
+    (`distributed.allreduce_twi_mean`).  `format` / `deflate_level`: the file's container (ncsink: "classic", or "netcdf4" —
+    the reference's, deflate 9 by default).  Returns timings and sizes."""
     reqhgt = float(inputs["reqhgt"])
     if reqhgt < 0:
         raise ValueError("reqhgt < 0 needs the whole series in the ring (Plan.belowground); fetch and use writetonc")
@@ -46,7 +48,7 @@ def run_to_nc(inputs: Mapping, fileout: str, dtm: Mapping, *, vars: Sequence[str
             plan.set_twi_mean(twi_mean)
         rows, cols = plan.rows, plan.cols
         with ncsink.NcWriter(fileout, rows, cols, hours[:ndays * 24], east, north, reqhgt, names, dtm.get("crs", ""),
-                             reference_puts_only) as nc:
+                             reference_puts_only, format=format, deflate_level=deflate_level) as nc:
             t_setup = time.perf_counter() - t_begin
             for d0 in range(0, ndays, days_per_chunk):
                 nd = min(days_per_chunk, ndays - d0)

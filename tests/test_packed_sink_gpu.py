@@ -117,6 +117,41 @@ def test_nc_file_from_the_device_ring_is_bytewise_the_host_written_file(rows, co
     f.close()
 
 
+def test_netcdf4_file_from_the_device_ring_holds_the_host_written_values(tmp_path):
+    """the reference's container (netCDF-4, deflate 9) fed by the same device records: read back through the HDF5 library
+    (tests/h5mini.py) it equals the host-written netCDF-4 file, the classic file and numpy's atonc of the fetched doubles"""
+    import h5mini
+    if h5mini.load() is None:
+        pytest.skip("no HDF5 library on this host")
+    rows, cols, T = 37, 29, 72
+    ncsink, east, north, hours = _nc_inputs(rows, cols, T)
+    a = synthetic.workload(rows, cols, T, reqhgt=0.05, variety=True, start_doy=120, na_frac=0.05)
+    names = ncsink.default_vars(0.05) + ("soilm",)
+    with Plan(a["obstime"], a["climdata"], a["pointm"], a["vegp"], a["soilc"], a["reqhgt"], a["zref"], a["lat"],
+              a["lon"], a["Sminp"], a["Smaxp"], a["tfact"], True, a["mat"], a["out"], ring_days=3) as p:
+        p.run_days(0, 3)
+        p.sync()
+        with ncsink.NcWriter(tmp_path / "dev4.nc", rows, cols, hours, east, north, 0.05, names, "wkt", format="netcdf4") as w:
+            w.write_plan(p, 0, 24, 24, 48)
+            w.write_plan(p, 0, 0, 0, 24)
+        full = {k: p.fetch(0, k, 0, T) for k in names}
+        with ncsink.NcWriter(tmp_path / "host4.nc", rows, cols, hours, east, north, 0.05, names, "wkt", format="netcdf4") as w:
+            w.write_host(0, full)
+        with ncsink.NcWriter(tmp_path / "host3.nc", rows, cols, hours, east, north, 0.05, names, "wkt") as w:
+            w.write_host(0, full)
+    from scipy.io import netcdf_file
+    dev, host, classic = h5mini.File(tmp_path / "dev4.nc"), h5mini.File(tmp_path / "host4.nc"), netcdf_file(str(tmp_path / "host3.nc"), "r", mmap=False)
+    for k in names:
+        got = dev.read(k)
+        assert np.array_equal(got, host.read(k)) and np.array_equal(got, classic.variables[k][:]), k
+        want = atonc(full[k], Plan.NC_SCALE[k])
+        want[want == NA_INT] = -9999
+        assert np.array_equal(np.transpose(got, (2, 1, 0)), want), k
+        assert dev.chunk_and_filters(k) == ((1, rows, cols), [(1, (9,))])
+    assert np.array_equal(dev.read("time"), hours)
+    dev.close(); host.close(); classic.close()
+
+
 def test_nc_sink_needs_the_files_variables_in_the_plan(tmp_path):
     from microclimf_amd import _abi
     ncsink, east, north, hours = _nc_inputs(8, 8, 24)
