@@ -426,6 +426,12 @@ typedef struct mcf_terrain_out {
 } mcf_terrain_out;
 
 int mcf_precompute_terrain(const mcf_terrain_in *in, const mcf_terrain_out *out, int32_t device);
+/* The same for a WHOLE raster (no halos, no placement in `in`) over several devices from one process — the companion of
+ * mcf_runmicro1_multi for BASELINE configs[3]'s geometry: contiguous row blocks, block b on devices[b % n_devices], each
+ * with the halo rows its stencils need gathered out of the caller's array (the rows the one-process-per-GPU route exchanges
+ * between ranks), results written into the caller's arrays in place.  n_devices = 0: every visible device; n_blocks = 0: one
+ * block per device (more blocks than devices are time-sliced).  The values are those of the single-device call. */
+int mcf_precompute_terrain_multi(const mcf_terrain_in *in, const mcf_terrain_out *out, const mcf_multi *multi);
 
 /* ---- snow branch ----------------------------------------------------------------------
  *   mcf_gridmodelsnow1/2()  replace  _microclimf_gridmodelsnow1 / _microclimf_gridmodelsnow2

@@ -178,7 +178,7 @@ EXPORTS = (
     "mcf_snowplan_release_kept", "mcf_snowplan_meand_accumulate", "mcf_snowplan_micro_setup", "mcf_snowplan_microsnow",
     "mcf_plan_timer_start", "mcf_plan_timer_stop", "mcf_plan_kernel_timing",
     "mcf_plan_kernel_stats", "mcf_plan_dispatch_stats", "mcf_plan_valid_cells", "mcf_plan_bytes", "mcf_selftest_math",
-    "mcf_precompute_terrain", "mcf_runbioclim1", "mcf_runbioclim2", "mcf_runbioclim3", "mcf_runbioclim4",
+    "mcf_precompute_terrain", "mcf_precompute_terrain_multi", "mcf_runbioclim1", "mcf_runbioclim2", "mcf_runbioclim3", "mcf_runbioclim4",
     "mcf_snowenv_from_name", "mcf_gridmodelsnow1", "mcf_gridmodelsnow2", "mcf_gridmicrosnow1",
     "mcf_gridmicrosnow2", "mcf_snowmodel1", "mcf_applycpp3",
     "mcf_snowplan_create", "mcf_snowplan_destroy", "mcf_snowplan_chunks", "mcf_snowplan_surface", "mcf_snowplan_handover", "mcf_snowplan_apply3",
@@ -425,6 +425,8 @@ def load() -> C.CDLL:
     lib.mcf_snowmodel1.argtypes = [C.POINTER(SnowDriverIn), C.POINTER(SnowDriverOut), C.c_int32]
     lib.mcf_precompute_terrain.restype = C.c_int
     lib.mcf_precompute_terrain.argtypes = [C.POINTER(TerrainIn), C.POINTER(TerrainOut), C.c_int32]
+    lib.mcf_precompute_terrain_multi.restype = C.c_int
+    lib.mcf_precompute_terrain_multi.argtypes = [C.POINTER(TerrainIn), C.POINTER(TerrainOut), C.POINTER(Multi)]
     if lib.mcf_abi_version() != ABI_VERSION:
         raise McfError("libmcfhip ABI version mismatch")
     _lib = lib

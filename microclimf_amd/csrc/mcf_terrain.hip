@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mcf.h"
@@ -341,5 +342,70 @@ extern "C" int mcf_precompute_terrain(const mcf_terrain_in* in, const mcf_terrai
     if (out->hor) T_TRY(hipMemcpy(out->hor, t.d_hor, (size_t)N * 24 * 8, hipMemcpyDeviceToHost));
     if (out->svfa) T_TRY(hipMemcpy(out->svfa, t.d_svfa, (size_t)N * 8, hipMemcpyDeviceToHost));
     if (out->wsa) T_TRY(hipMemcpy(out->wsa, t.d_wsa, (size_t)N * 8 * 8, hipMemcpyDeviceToHost));
+    return MCF_OK;
+}
+
+// ---- one process, several devices (include/mcf.h mcf_precompute_terrain_multi) ------------------------------------------------
+// The raster in contiguous row blocks, block b on devices[b % n_devices] by that device's host thread.  What couples the
+// blocks are the stencils' halo rows, and the whole elevation raster is in THIS process's memory: each block gathers its rows
+// plus the halo it needs (the very rows route 1 exchanges between ranks, terrain.py exchange_halo) out of the caller's array,
+// runs mcf_precompute_terrain with its placement (row0 / rows_total), and scatters its rows of the results into the caller's
+// arrays — no peer copies, no collective.
+extern "C" int mcf_precompute_terrain_multi(const mcf_terrain_in* in, const mcf_terrain_out* out, const mcf_multi* mu) {
+    if (!in || !out || !mu || !in->dtm) return mcf::api_fail(MCF_ERR_ARG, "null terrain argument");
+    if (in->rows <= 0 || in->cols <= 0 || !(in->res > 0)) return mcf::api_fail(MCF_ERR_ARG, "bad terrain geometry");
+    if (in->halo_north != 0 || in->halo_south != 0 || (in->rows_total > 0 && (in->row0 != 0 || in->rows_total != in->rows)))
+        return mcf::api_fail(MCF_ERR_ARG, "mcf_precompute_terrain_multi takes the whole raster (no halos, no placement)");
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0)
+        return mcf::api_fail(MCF_ERR_NO_DEVICE, "no HIP device available (libmcfhip has no CPU fallback)");
+    std::vector<int> devs;
+    if (mu->n_devices <= 0) for (int d = 0; d < nd; ++d) devs.push_back(d);
+    else {
+        if (!mu->devices) return mcf::api_fail(MCF_ERR_ARG, "n_devices > 0 with a null device list");
+        for (int i = 0; i < mu->n_devices; ++i) {
+            if (mu->devices[i] < 0 || mu->devices[i] >= nd) return mcf::api_fail(MCF_ERR_ARG, "device ordinal out of range");
+            devs.push_back(mu->devices[i]);
+        }
+    }
+    const int64_t R = in->rows, C = in->cols;
+    const int nb = (int)std::min<int64_t>(mu->n_blocks > 0 ? mu->n_blocks : (int)devs.size(), R);
+    const int s = in->agg > 0 ? in->agg : 10;
+    const int64_t need = out->wsa ? 100 + 2 * s + s / 2 : ((out->hor || out->svfa) ? 100 : 1);     // as mcf_precompute_terrain asks
+    std::vector<int> rcs(devs.size(), MCF_OK);
+    std::vector<std::string> errs(devs.size());
+    std::vector<std::thread> threads;
+    for (size_t t = 0; t < devs.size(); ++t) {
+        threads.emplace_back([&, t] {
+            std::vector<double> ext, part[5];
+            for (int b = (int)t; b < nb; b += (int)devs.size()) {
+                const int64_t r0 = R * b / nb, r1 = R * (b + 1) / nb, nr = r1 - r0;
+                if (nr <= 0) continue;
+                const int64_t hn = std::min(need, r0), hs = std::min(need, R - r1), RB = hn + nr + hs;
+                ext.resize((size_t)(RB * C));
+                for (int64_t c = 0; c < C; ++c) memcpy(&ext[(size_t)(RB * c)], in->dtm + (r0 - hn) + R * c, (size_t)RB * 8);
+                mcf_terrain_in bi = *in;
+                bi.rows = nr; bi.halo_north = (int32_t)hn; bi.halo_south = (int32_t)hs; bi.dtm = ext.data();
+                bi.row0 = r0; bi.rows_total = R;
+                double* const dst[5] = {out->slope, out->aspect, out->hor, out->svfa, out->wsa};
+                const int layers[5] = {1, 1, 24, 1, 8};
+                mcf_terrain_out bo;
+                double** const bop[5] = {&bo.slope, &bo.aspect, &bo.hor, &bo.svfa, &bo.wsa};
+                for (int k = 0; k < 5; ++k) {
+                    if (dst[k]) part[k].resize((size_t)(nr * C * layers[k]));
+                    *bop[k] = dst[k] ? part[k].data() : nullptr;
+                }
+                const int rc = mcf_precompute_terrain(&bi, &bo, devs[t]);
+                if (rc != MCF_OK) { rcs[t] = rc; errs[t] = mcf_last_error(); return; }
+                for (int k = 0; k < 5; ++k)
+                    if (dst[k])
+                        for (int64_t lc = 0; lc < C * layers[k]; ++lc)      // layer-column lc of the block -> the same one of the raster
+                            memcpy(dst[k] + r0 + R * lc, &part[k][(size_t)(nr * lc)], (size_t)nr * 8);
+            }
+        });
+    }
+    for (auto& th : threads) th.join();
+    for (size_t t = 0; t < devs.size(); ++t)
+        if (rcs[t] != MCF_OK) return mcf::api_fail(rcs[t], errs[t]);
     return MCF_OK;
 }

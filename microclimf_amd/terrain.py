@@ -20,8 +20,11 @@ WHAT = ("slope", "aspect", "hor", "svfa", "wsa")
 
 
 def precompute_terrain(dtm, res: float, zref: float, *, agg: int = 10, halo_north: int = 0,
-                       halo_south: int = 0, row0: int = 0, rows_total: int = 0, what=WHAT, device: int = 0):
-    """dtm: [(halo_north + rows + halo_south), cols] elevations (NaN = NA)."""
+                       halo_south: int = 0, row0: int = 0, rows_total: int = 0, what=WHAT, device: int = 0,
+                       devices=None, n_blocks: int = 0):
+    """dtm: [(halo_north + rows + halo_south), cols] elevations (NaN = NA).
+    `devices` (a list of HIP ordinals, [] = all visible) / `n_blocks`: the WHOLE raster in row blocks over several devices
+    from this one process (include/mcf.h mcf_precompute_terrain_multi), same values."""
     lib = _abi.load()
     z = np.asfortranarray(np.asarray(dtm, dtype=np.float64))
     rb, cols = z.shape
@@ -43,7 +46,13 @@ def precompute_terrain(dtm, res: float, zref: float, *, agg: int = 10, halo_nort
             setattr(tout, k, a.ctypes.data_as(_abi.c_double_p))
         else:
             setattr(tout, k, None)
-    _abi.check(lib.mcf_precompute_terrain(C.byref(tin), C.byref(tout), device))
+    if devices is not None or n_blocks:
+        mu = _abi.Multi()
+        devs = np.ascontiguousarray([] if devices is None else list(devices), dtype=np.int32)
+        mu.n_devices, mu.devices, mu.n_blocks = int(devs.size), devs.ctypes.data_as(_abi.c_int32_p), int(n_blocks)
+        _abi.check(lib.mcf_precompute_terrain_multi(C.byref(tin), C.byref(tout), C.byref(mu)))
+    else:
+        _abi.check(lib.mcf_precompute_terrain(C.byref(tin), C.byref(tout), device))
     return res_arrays
 
 

@@ -48,3 +48,30 @@ def test_multi_argument_checks():
     a = synthetic.workload(12, 12, 24, reqhgt=0.05)
     with pytest.raises(McfError, match="device ordinal"):
         runmicro1Cpp(*[a[k] for k in ARGS], devices=[7])
+
+
+@pytest.mark.parametrize("rows,cols,res,nb", [(420, 37, 1.0, 3), (300, 24, 2.5, 5), (131, 64, 1.0, 2)])
+def test_terrain_row_blocks_on_one_device_equal_the_whole_raster_bitwise(rows, cols, res, nb):
+    """mcf_precompute_terrain_multi: the whole raster cut into row blocks, each with the halo its stencils need gathered in the
+    library — slope, aspect, 24 horizons, sky view and 8 wind-shelter coefficients are bit for bit the single-device call's"""
+    from microclimf_amd.terrain import precompute_terrain
+    from test_terrain_cpu import synth_dtm
+    z = synth_dtm(rows, cols)
+    z[3, 4] = z[rows // 2, cols // 3] = np.nan
+    want = precompute_terrain(z, res, 2.0)
+    got = precompute_terrain(z, res, 2.0, devices=[0], n_blocks=nb)
+    for k, w in want.items():
+        assert np.array_equal(got[k], w, equal_nan=True), k
+    two = precompute_terrain(z, res, 2.0, devices=[0, 0], n_blocks=nb + 1, what=("hor", "svfa"))      # two host threads on one device
+    assert set(two) == {"hor", "svfa"} and np.array_equal(two["hor"], want["hor"], equal_nan=True)
+
+
+def test_terrain_multi_argument_checks():
+    from microclimf_amd import McfError
+    from microclimf_amd.terrain import precompute_terrain
+    from test_terrain_cpu import synth_dtm
+    z = synth_dtm(60, 12)
+    with pytest.raises(McfError, match="whole raster"):
+        precompute_terrain(z, 1.0, 2.0, halo_north=5, halo_south=5, devices=[0])
+    with pytest.raises(McfError, match="ordinal"):
+        precompute_terrain(z, 1.0, 2.0, devices=[99])
