@@ -180,7 +180,7 @@ EXPORTS = (
     "mcf_plan_kernel_stats", "mcf_plan_dispatch_stats", "mcf_plan_valid_cells", "mcf_plan_bytes", "mcf_selftest_math",
     "mcf_precompute_terrain", "mcf_precompute_terrain_multi", "mcf_runbioclim1", "mcf_runbioclim2", "mcf_runbioclim3", "mcf_runbioclim4",
     "mcf_snowenv_from_name", "mcf_gridmodelsnow1", "mcf_gridmodelsnow2", "mcf_gridmicrosnow1",
-    "mcf_gridmicrosnow2", "mcf_snowmodel1", "mcf_applycpp3",
+    "mcf_gridmicrosnow2", "mcf_snowmodel1", "mcf_snowmodel1_multi", "mcf_applycpp3",
     "mcf_snowplan_create", "mcf_snowplan_destroy", "mcf_snowplan_chunks", "mcf_snowplan_surface", "mcf_snowplan_handover", "mcf_snowplan_apply3",
     "mcf_snowplan_surface_partial", "mcf_snowplan_prepare_chunk", "mcf_snowplan_run_chunk", "mcf_snowplan_pack_halo",
     "mcf_snowplan_prepare_chunk_dev",
@@ -423,6 +423,8 @@ def load() -> C.CDLL:
     lib.mcf_snowplan_run_chunk.argtypes = [P, C.c_int32, C.c_double, C.POINTER(SnowDriverOut)]
     lib.mcf_snowmodel1.restype = C.c_int
     lib.mcf_snowmodel1.argtypes = [C.POINTER(SnowDriverIn), C.POINTER(SnowDriverOut), C.c_int32]
+    lib.mcf_snowmodel1_multi.restype = C.c_int
+    lib.mcf_snowmodel1_multi.argtypes = [C.POINTER(SnowDriverIn), C.POINTER(SnowDriverOut), C.POINTER(Multi)]
     lib.mcf_precompute_terrain.restype = C.c_int
     lib.mcf_precompute_terrain.argtypes = [C.POINTER(TerrainIn), C.POINTER(TerrainOut), C.c_int32]
     lib.mcf_precompute_terrain_multi.restype = C.c_int

@@ -16,7 +16,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mcf.h"
@@ -1445,6 +1449,164 @@ extern "C" int mcf_snowmodel1(const mcf_snowdriver_in* in, mcf_snowdriver_out* o
     if (getenv("MCF_TIMING"))
         fprintf(stderr, "[mcf] snowmodel1: %d chunks of %d steps, %lld cells: terrain + tpi %.2f ms, gridmodelsnow + "
                 "redistribute %.2f ms\n", sp->nchunks, sp->chunk, (long long)sp->N, sp->t_terrain, sp->t_model);
+    return MCF_OK;
+}
+
+// ---- one process, several devices (include/mcf.h mcf_snowmodel1_multi) ---------------------------------------------------------
+// The chunk loop over row blocks of ONE raster held by this process: block b is a snow plan on devices[b % n_devices], driven
+// by that device's host thread.  What couples the blocks per chunk — the snow surface's halo rows for the terrain stencil and
+// .tpicalc's block means, and the two raster-wide means as (sum, count) — goes through host memory between three phases
+// (the phases of snow.py snowmodel1_chunks_tiled, where ranks exchange the same things over RCCL):
+//   1  every block writes its rows of the surface into one whole-raster array and reports its (sum, count)
+//   2  every block takes its rows plus halo out of that array, refreshes terrain + tpi, reports tpic's (sum, count)
+//   3  every block runs the chunk with the raster-wide tpic mean and copies its series out
+// Partial sums are added in block order, so a run is reproducible for a given n_blocks; against the single-plan run the two
+// means differ in their last bits (another summation tree), like route 1's.
+namespace {
+struct PhaseBarrier {
+    std::mutex m;
+    std::condition_variable cv;
+    int n, waiting = 0, generation = 0;
+    explicit PhaseBarrier(int n_) : n(n_) {}
+    void wait() {
+        std::unique_lock<std::mutex> lk(m);
+        const int g = generation;
+        if (++waiting == n) { waiting = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lk, [&] { return g != generation; });
+    }
+};
+template <class T>
+void gather_rows(std::vector<T>& dst, const T* src, int64_t R, int64_t C, int64_t r0, int64_t nr, int64_t layers = 1) {
+    dst.resize((size_t)(nr * C * layers));
+    for (int64_t lc = 0; lc < C * layers; ++lc) memcpy(&dst[(size_t)(nr * lc)], src + r0 + R * lc, (size_t)nr * sizeof(T));
+}
+}  // namespace
+
+extern "C" int mcf_snowmodel1_multi(const mcf_snowdriver_in* in, mcf_snowdriver_out* out, const mcf_multi* mu) {
+    if (!in || !out || !mu) return mcf::api_fail(MCF_ERR_ARG, "null snow driver argument");
+    const mcf_snow_inputs& base = in->base;
+    if (base.rows <= 0 || base.cols <= 0 || !in->dtm) return mcf::api_fail(MCF_ERR_ARG, "snow driver needs the raster and its dtm");
+    const mcf_snow_vegp& vg = base.vegp;
+    const mcf_snow_other& ot = base.other;
+    if (!vg.pai || !vg.hgt || !vg.leaft || !vg.clump || !ot.isnowdc || !ot.isnowdg || !ot.isnowac || !ot.isnowag)
+        return mcf::api_fail(MCF_ERR_ARG, "null input: a vegetation or initial-snow raster");
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0)
+        return mcf::api_fail(MCF_ERR_NO_DEVICE, "no HIP device available (libmcfhip has no CPU fallback)");
+    std::vector<int> devs;
+    if (mu->n_devices <= 0) for (int d = 0; d < nd; ++d) devs.push_back(d);
+    else {
+        if (!mu->devices) return mcf::api_fail(MCF_ERR_ARG, "n_devices > 0 with a null device list");
+        for (int i = 0; i < mu->n_devices; ++i) {
+            if (mu->devices[i] < 0 || mu->devices[i] >= nd) return mcf::api_fail(MCF_ERR_ARG, "device ordinal out of range");
+            devs.push_back(mu->devices[i]);
+        }
+    }
+    const int64_t R = base.rows, C = base.cols, T = base.tsteps;
+    const int nb = (int)std::min<int64_t>(mu->n_blocks > 0 ? mu->n_blocks : (int)devs.size(), R);
+    const int nt = (int)std::min<size_t>(devs.size(), (size_t)nb);
+    struct Block {
+        int64_t r0 = 0, nr = 0;
+        std::vector<double> pai, hgt, leaft, clump, dc, dg, dtm, ext, series[5];
+        std::vector<int32_t> ac, ag;
+        mcf_snowplan* sp = nullptr;
+        double s = 0, n = 0, ts = 0, tn = 0;
+        ~Block() { if (sp) mcf_snowplan_destroy(sp); }
+    };
+    std::vector<Block> blocks((size_t)nb);
+    std::vector<double> surface((size_t)(R * C));        // the whole raster's snow surface of the current chunk
+    std::vector<int> rcs((size_t)nt, MCF_OK);
+    std::vector<std::string> errs((size_t)nt);
+    std::atomic<bool> failed{false};
+    PhaseBarrier bar(nt);
+    int nchunks = 0;
+    double smean = 0.0, tmean = 0.0;
+    double* const dst[5] = {out->Tc, out->Tg, out->groundsnowdepth, out->totalSWE, out->snowden};
+    // every thread runs every phase of every chunk (also after a failure: the barrier counts heads), doing nothing once failed
+    auto worker = [&](int t) {
+        auto fail_here = [&](int rc) { rcs[(size_t)t] = rc; errs[(size_t)t] = mcf_last_error(); failed = true; };
+        for (int b = t; b < nb && !failed; b += nt) {        // ---- plans
+            Block& k = blocks[(size_t)b];
+            k.r0 = R * b / nb; k.nr = R * (b + 1) / nb - k.r0;
+            gather_rows(k.pai, vg.pai, R, C, k.r0, k.nr); gather_rows(k.hgt, vg.hgt, R, C, k.r0, k.nr);
+            gather_rows(k.leaft, vg.leaft, R, C, k.r0, k.nr); gather_rows(k.clump, vg.clump, R, C, k.r0, k.nr);
+            gather_rows(k.dc, ot.isnowdc, R, C, k.r0, k.nr); gather_rows(k.dg, ot.isnowdg, R, C, k.r0, k.nr);
+            gather_rows(k.ac, ot.isnowac, R, C, k.r0, k.nr); gather_rows(k.ag, ot.isnowag, R, C, k.r0, k.nr);
+            gather_rows(k.dtm, in->dtm, R, C, k.r0, k.nr);
+            mcf_snowdriver_in bi = *in;
+            bi.base.rows = k.nr;
+            bi.base.vegp.pai = k.pai.data(); bi.base.vegp.hgt = k.hgt.data(); bi.base.vegp.leaft = k.leaft.data();
+            bi.base.vegp.clump = k.clump.data();
+            bi.base.other.isnowdc = k.dc.data(); bi.base.other.isnowdg = k.dg.data();
+            bi.base.other.isnowac = k.ac.data(); bi.base.other.isnowag = k.ag.data();
+            bi.base.other.slope = bi.base.other.aspect = bi.base.other.skyview = bi.base.other.wsa = bi.base.other.hor = nullptr;
+            bi.dtm = k.dtm.data();
+            const int rc = mcf_snowplan_create(&bi, k.r0, R, devs[(size_t)t], &k.sp);
+            if (rc) { fail_here(rc); break; }
+            for (int v = 0; v < 5; ++v) if (dst[v]) k.series[v].resize((size_t)(k.nr * C * T));
+        }
+        bar.wait();
+        if (t == 0 && !failed) nchunks = blocks[0].sp->nchunks;
+        bar.wait();
+        for (int ch = 0; ch < nchunks; ++ch) {
+            for (int b = t; b < nb && !failed; b += nt) {    // ---- phase 1: the surface
+                Block& k = blocks[(size_t)b];
+                k.ext.resize((size_t)(k.nr * C));
+                int rc = mcf_snowplan_surface(k.sp, k.ext.data());
+                if (!rc) rc = mcf_snowplan_surface_partial(k.sp, &k.s, &k.n);
+                if (rc) { fail_here(rc); break; }
+                for (int64_t c = 0; c < C; ++c) memcpy(&surface[(size_t)(k.r0 + R * c)], &k.ext[(size_t)(k.nr * c)], (size_t)k.nr * 8);
+            }
+            bar.wait();
+            if (t == 0 && !failed) {
+                double s = 0, n = 0;
+                for (const Block& k : blocks) { s += k.s; n += k.n; }
+                smean = s / n;
+            }
+            bar.wait();
+            for (int b = t; b < nb && !failed; b += nt) {    // ---- phase 2: halos, terrain, tpi
+                Block& k = blocks[(size_t)b];
+                int af = 1;
+                int rc = chunk_af(k.sp, ch, &af);
+                if (rc) { fail_here(rc); break; }
+                // what prepare_chunk asks for at most (the stencil's reach, whole af x af blocks), or every row up to the edge
+                const int64_t want = 100 + 3 * (int64_t)k.sp->ss + 2 * (int64_t)af;
+                const int64_t hn = std::min(want, k.r0), hs = std::min(want, R - k.r0 - k.nr), RB = hn + k.nr + hs;
+                gather_rows(k.ext, surface.data(), R, C, k.r0 - hn, RB);
+                rc = mcf_snowplan_prepare_chunk(k.sp, ch, (hn || hs) ? k.ext.data() : nullptr, (int32_t)hn, (int32_t)hs, smean, &k.ts, &k.tn);
+                if (rc) { fail_here(rc); break; }
+            }
+            bar.wait();
+            if (t == 0 && !failed) {
+                double s = 0, n = 0;
+                for (const Block& k : blocks) { s += k.ts; n += k.tn; }
+                tmean = s / n;
+            }
+            bar.wait();
+            for (int b = t; b < nb && !failed; b += nt) {    // ---- phase 3: the chunk
+                Block& k = blocks[(size_t)b];
+                mcf_snowdriver_out bo;
+                double** const bop[5] = {&bo.Tc, &bo.Tg, &bo.groundsnowdepth, &bo.totalSWE, &bo.snowden};
+                for (int v = 0; v < 5; ++v) *bop[v] = dst[v] ? k.series[v].data() : nullptr;
+                const int rc = mcf_snowplan_run_chunk(k.sp, ch, tmean, &bo);
+                if (rc) { fail_here(rc); break; }
+            }
+            bar.wait();
+        }
+        for (int b = t; b < nb && !failed; b += nt) {        // ---- the blocks' series into the caller's arrays
+            Block& k = blocks[(size_t)b];
+            // (the steps the loop ran: as in R, `1:n5days` truncates and later steps keep what the caller put there — NA)
+            const int64_t done = std::min<int64_t>(T, (int64_t)nchunks * k.sp->chunk);
+            for (int v = 0; v < 5; ++v)
+                if (dst[v])
+                    for (int64_t lc = 0; lc < C * done; ++lc) memcpy(dst[v] + k.r0 + R * lc, &k.series[v][(size_t)(k.nr * lc)], (size_t)k.nr * 8);
+        }
+    };
+    std::vector<std::thread> threads;
+    for (int t = 0; t < nt; ++t) threads.emplace_back(worker, t);
+    for (auto& th : threads) th.join();
+    for (int t = 0; t < nt; ++t)
+        if (rcs[(size_t)t] != MCF_OK) return mcf::api_fail(rcs[(size_t)t], errs[(size_t)t]);
     return MCF_OK;
 }
 

@@ -196,13 +196,15 @@ def gridmicrosnow2(reqhgt, obstime, climdata, snowm, micro, vegp, other, mat, ou
 
 
 def snowmodel1_chunks(obstime, climdata, pointm, vegp, other, snowenv, dtm, res, tfact=0.02, *,
-                      chunk_steps: int = 120, device: int = 0) -> dict:
+                      chunk_steps: int = 120, device: int = 0, devices=None, n_blocks: int = 0) -> dict:
     """The chunk loop of the reference's `.snowmodel1` (R/internal.R:2553-2617) resident on the
     device: per 5-day chunk terrain refresh from dtm + snow, gridmodelsnow1, `.tpicalc`
     redistribution, hand-over of depths and ages.  Arguments are what the loop works with:
     `pointm` is pointmodelsnow's output, `vegp` the snow-season means of `.sortl`, `other`
     holds lat, lon, zref and the initial isnowdc / isnowdg / isnowac / isnowag.  Returns the
-    list `.snowmodel1` returns (R/internal.R:2619) minus `umu`."""
+    list `.snowmodel1` returns (R/internal.R:2619) minus `umu`.
+    `devices` (a list of HIP ordinals, [] = all visible) / `n_blocks`: the raster in row blocks over several devices from
+    this one process (include/mcf.h mcf_snowmodel1_multi); equal up to the summation order of the two raster-wide means."""
     lib = _abi.load()
     R, Cc = np.shape(vegp["pai"])
     oth = dict(other)
@@ -220,7 +222,13 @@ def snowmodel1_chunks(obstime, climdata, pointm, vegp, other, snowenv, dtm, res,
         a = np.empty((R, Cc, m.tsteps), dtype=np.float64, order="F")
         arrays[f] = a
         setattr(out, f, a.ctypes.data_as(_abi.c_double_p))
-    _abi.check(lib.mcf_snowmodel1(C.byref(din), C.byref(out), device))
+    if devices is not None or n_blocks:
+        mu = _abi.Multi()
+        devs = np.ascontiguousarray([] if devices is None else list(devices), dtype=np.int32)
+        mu.n_devices, mu.devices, mu.n_blocks = int(devs.size), devs.ctypes.data_as(_abi.c_int32_p), int(n_blocks)
+        _abi.check(lib.mcf_snowmodel1_multi(C.byref(din), C.byref(out), C.byref(mu)))
+    else:
+        _abi.check(lib.mcf_snowmodel1(C.byref(din), C.byref(out), device))
     return arrays
 
 

@@ -506,7 +506,21 @@ SEXP mcfhip_snowmodel1(SEXP obstime, SEXP weather, SEXP pointm, SEXP vegp, SEXP 
         rp[v] = REAL(a);
     }
     setAttrib(ans, R_NamesSymbol, nms);
-    int rc = mcf_snowmodel1(&din, &res5, 0);
+    /* options(mcfhip.devices) — mcfhip_enable(devices = ) — sends the chunk loop over the listed devices too (row blocks, one
+     * snow plan per block: include/mcf.h mcf_snowmodel1_multi) */
+    SEXP dv = GetOption1(install("mcfhip.devices"));
+    int rc;
+    if (dv != R_NilValue && LENGTH(dv) > 0) {
+        SEXP dvi = PROTECT(coerceVector(dv, INTSXP)); ++np;
+        SEXP nbo = GetOption1(install("mcfhip.blocks"));
+        mcf_multi mu;
+        mu.n_devices = LENGTH(dvi);
+        mu.devices = INTEGER(dvi);
+        mu.n_blocks = nbo == R_NilValue ? 0 : asInteger(nbo);
+        rc = mcf_snowmodel1_multi(&din, &res5, &mu);
+    } else {
+        rc = mcf_snowmodel1(&din, &res5, 0);
+    }
     if (rc != MCF_OK) raise_last(rc, np);
     UNPROTECT(np);
     return ans;

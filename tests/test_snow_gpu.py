@@ -213,6 +213,25 @@ def test_snowplan_two_row_blocks_equal_the_whole_raster(rows, cols, split):
             assert_close(got, w, 1e-9, k)
 
 
+@pytest.mark.parametrize("rows,cols,nb,devices", [(300, 40, 2, [0]), (290, 30, 3, [0, 0]), (420, 24, 4, [0])])
+def test_snowmodel1_multi_row_blocks_in_the_library_equal_the_whole_raster(rows, cols, nb, devices):
+    """mcf_snowmodel1_multi: the chunk loop of a whole raster over row blocks from one process — surface halos and the two
+    (sum, count) means pass through host memory inside the library; against the single-plan run (cols = 30 and 24 take
+    .tpicalc's raster-mean branch; two host threads on one device in the second case; blocks narrower than the halo in the third)"""
+    from microclimf_amd.snow import snowmodel1_chunks
+    sw, dtm = _driver_case(rows, cols, 240)
+    args = (sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"], sw["other"], sw["snowenv"])
+    whole = snowmodel1_chunks(*args, dtm, 1.0, 0.02)
+    got = snowmodel1_chunks(*args, dtm, 1.0, 0.02, devices=devices, n_blocks=nb)
+    for k, w in whole.items():
+        assert_close(got[k], w, 1e-9, k)
+    one = snowmodel1_chunks(*args, dtm, 1.0, 0.02, devices=[0], n_blocks=1)          # one block: the single-plan run bit for bit
+    for k, w in whole.items():
+        assert np.array_equal(one[k], w, equal_nan=True), k
+    with pytest.raises(_abi.McfError, match="ordinal"):
+        snowmodel1_chunks(*args, dtm, 1.0, 0.02, devices=[7, 99])
+
+
 @pytest.mark.parametrize("rows,cols,split", [(300, 40, 150), (290, 30, 160)])
 def test_halo_pieces_packed_and_joined_on_the_device_give_the_same_bits(rows, cols, split):
     """mcf_snowplan_pack_halo / prepare_chunk_dev: the 128 boundary rows go from one plan to the other as device tensors
