@@ -39,6 +39,25 @@ def test_year_slice_to_file_equals_packed_oracle(reqhgt, af, oracle, tmp_path):
     f.close()
 
 
+def test_the_reference_container_end_to_end_holds_the_classic_files_values(tmp_path):
+    """run_to_nc(format="netcdf4"): solver -> device-packed records -> deflated chunks -> HDF5; read back through the HDF5
+    library it holds exactly the values of the classic file of the same run"""
+    import h5mini
+    if h5mini.load() is None:
+        pytest.skip("no HDF5 library on this host")
+    rows, cols, T = 23, 31, 4 * 24
+    a = synthetic.workload(rows, cols, T, reqhgt=0.05, variety=True, start_doy=200, na_frac=0.04)
+    dtm = {"xmin": 0.0, "xmax": cols * 2.0, "ymin": 10.0, "ymax": 10.0 + rows * 2.0, "res": 2.0, "crs": "local"}
+    pipeline.run_to_nc(a, tmp_path / "c.nc", dtm, days_per_chunk=3)
+    info = pipeline.run_to_nc(a, tmp_path / "h.nc", dtm, days_per_chunk=3, format="netcdf4", deflate_level=4)
+    c, h = netcdf_file(str(tmp_path / "c.nc"), "r", mmap=False), h5mini.File(tmp_path / "h.nc")
+    for k in info["vars"]:
+        assert np.array_equal(h.read(k), c.variables[k][:]), k
+        assert h.chunk_and_filters(k) == ((1, rows, cols), [(1, (4,))])
+    assert np.array_equal(h.read("time"), c.variables["time"][:]) and h.attr("crs", "crs_wkt") == b"local"
+    c.close(); h.close()
+
+
 def test_below_ground_is_refused(tmp_path):
     a = synthetic.workload(8, 8, 48, reqhgt=-0.1)
     with pytest.raises(ValueError, match="reqhgt < 0"):
