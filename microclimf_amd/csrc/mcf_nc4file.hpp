@@ -175,9 +175,8 @@ public:
         h5->Pclose(fcpl);
         if (file_ < 0) return std::string("cannot create ") + path + " (H5Fcreate)";
         bool ok = true;
-        char prov[96];
-        snprintf(prov, sizeof prov, "version=2,mcfhip=1,hdf5=%u.%u.%u", h5->ver[0], h5->ver[1], h5->ver[2]);
-        ok = ok && att_text(file_, "_NCProperties", prov);
+        // (no `_NCProperties`: the attribute is libnetcdf's own provenance stamp and optional — files of netCDF < 4.4.1 have
+        // none — and a reader must not be told that libnetcdf wrote this file)
         // dimensions = coordinate variables, in ncdf4's order of definition (dimids 0, 1, 2)
         hid_t d_east = -1, d_north = -1, d_time = -1;
         ok = ok && coord(d_east, "east", cols, east, 0) && att_text(d_east, "units", "metres") && att_text(d_east, "long_name", "Eastings");
