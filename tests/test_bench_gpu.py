@@ -39,6 +39,16 @@ def test_one_line_with_roofline_baseline_and_in_run_verification():
     assert d["config"]["dispatch"]["fast_launches"] > 0
 
 
+def test_headline_raster_at_full_size_one_launch_is_verified():
+    """BASELINE.json configs[2]'s raster at FULL size — 4096 x 4096 cells, terrain inputs built on the device — for one 7-day
+    launch (the year is 53 of them): the timed output of 264 sampled cells against the oracle, every tile through the fast path"""
+    d = _bench("--config", "2", "--tsteps", "168", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary")
+    assert d["config"]["rows_per_gpu"] == 4096 and d["config"]["cols"] == 4096 and d["config"]["baseline_config"] == 2 and d["config"]["terrain"].startswith("on-device")
+    v = d["verified"]
+    assert v["ok"] and v["na_pattern_equal"] and v["max_scaled_err"] < 1e-6 and v["cells"] >= 200
+    assert d["config"]["dispatch"]["fast_launches"] > 0 and d["value"] > 1e10
+
+
 def test_secondary_block_covers_the_other_geometries():
     d = _bench("--config", "2", "--rows", "64", "--cols", "64", "--tsteps", "240", "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
     s = d["secondary"]
