@@ -526,6 +526,54 @@ SEXP mcfhip_snowmodel1(SEXP obstime, SEXP weather, SEXP pointm, SEXP vegp, SEXP 
     return ans;
 }
 
+/* writetonc(mout, fileout, dtm, reqhgt, vars) (R/dataprep.R:1063-1260): the R side hands over what it takes terra for (the
+ * cell-centre coordinates, the hours since 1970, the projection's text); the dataset — names, long names, units, packing,
+ * missval, crs variable — is made by libmcfhip (mcf_nc_*).  format: "classic" or "netcdf4" (the reference's container). */
+SEXP mcfhip_writetonc(SEXP mout, SEXP fileout, SEXP east, SEXP north, SEXP hours, SEXP crs_wkt, SEXP reqhgt, SEXP vars,
+                      SEXP format) {
+    static const char *on[MCF_NOUT] = {"Tz", "tleaf", "relhum", "soilm", "windspeed", "Rdirdown", "Rdifdown", "Rlwdown",
+                                       "Rswup", "Rlwup"};
+    int np = 0;
+    mcf_nc_spec sp;
+    memset(&sp, 0, sizeof sp);
+    const double *ptr[MCF_NOUT] = {0};
+    if (TYPEOF(vars) != STRSXP || LENGTH(vars) < 1) Rf_error("mcfhip: vars must name at least one variable");
+    SEXP dim = R_NilValue;
+    for (int i = 0; i < LENGTH(vars); ++i) {
+        const char *nm = CHAR(STRING_ELT(vars, i));
+        int v = -1;
+        for (int k = 0; k < MCF_NOUT; ++k) if (strcmp(nm, on[k]) == 0) v = k;
+        if (v < 0) Rf_error("mcfhip: writetonc knows no variable '%s'", nm);
+        SEXP a = elt(mout, nm, NULL);
+        SEXP d = getAttrib(a, R_DimSymbol);
+        if (TYPEOF(d) != INTSXP || LENGTH(d) != 3) Rf_error("mcfhip: mout$%s must be a [rows, cols, steps] array", nm);
+        if (dim != R_NilValue && (INTEGER(d)[0] != INTEGER(dim)[0] || INTEGER(d)[1] != INTEGER(dim)[1] || INTEGER(d)[2] != INTEGER(dim)[2]))
+            Rf_error("mcfhip: the arrays of mout differ in shape");
+        dim = d;
+        sp.vars[v] = 1;
+        ptr[v] = dbl(a, &np);
+    }
+    sp.rows = INTEGER(dim)[0]; sp.cols = INTEGER(dim)[1]; sp.nsteps = INTEGER(dim)[2];
+    if (XLENGTH(east) != sp.cols || XLENGTH(north) != sp.rows || XLENGTH(hours) != sp.nsteps)
+        Rf_error("mcfhip: dtm / mout$tme do not match the arrays (east %ld, north %ld, time %ld)", (long)XLENGTH(east),
+                 (long)XLENGTH(north), (long)XLENGTH(hours));
+    sp.east = dbl(east, &np); sp.north = dbl(north, &np); sp.time_hours = dbl(hours, &np);
+    sp.crs_wkt = CHAR(asChar(crs_wkt));
+    sp.reqhgt = asReal(reqhgt);
+    sp.reference_puts_only = 0;      /* what writetonc evidently means, not the file its never-true `%in%` guards produce */
+    sp.format = strcmp(CHAR(asChar(format)), "netcdf4") == 0 ? MCF_NC_NETCDF4 : MCF_NC_CLASSIC;
+    mcf_ncfile *nc = NULL;
+    int rc = mcf_nc_create(CHAR(asChar(fileout)), &sp, &nc);
+    if (rc == MCF_OK) {
+        rc = mcf_nc_write_host(nc, 0, sp.nsteps, ptr);
+        const int rc2 = mcf_nc_close(nc);
+        if (rc == MCF_OK) rc = rc2;
+    }
+    if (rc != MCF_OK) raise_last(rc, np);
+    UNPROTECT(np);
+    return R_NilValue;
+}
+
 static const R_CallMethodDef CallEntries[] = {
     {"mcfhip_runmicro1", (DL_FUNC)&mcfhip_runmicro1, 15},
     {"mcfhip_runmicro2", (DL_FUNC)&mcfhip_runmicro2, 15},
@@ -541,6 +589,7 @@ static const R_CallMethodDef CallEntries[] = {
     {"mcfhip_gridmicrosnow2", (DL_FUNC)&mcfhip_gridmicrosnow2, 9},
     {"mcfhip_applycpp3", (DL_FUNC)&mcfhip_applycpp3, 2},
     {"mcfhip_snowmodel1", (DL_FUNC)&mcfhip_snowmodel1, 9},
+    {"mcfhip_writetonc", (DL_FUNC)&mcfhip_writetonc, 9},
     {NULL, NULL, 0}};
 
 void R_init_mcfhip_glue(DllInfo *dll) {

@@ -56,6 +56,23 @@ mcfhip_enable <- function(glue = "r/mcfhip_glue.so", devices = NULL, blocks = NU
     utils::assignInNamespace(nm, function(reqhgt, obstime, climdata, snowm, micro, vegp, other, mat, out)
       .Call(sym, reqhgt, obstime, climdata, snowm, micro, vegp, other, mat, out), ns = "microclimf")
   })
+  # output file (R/dataprep.R:1063-1260): same arguments.  terra stays on this side (cell-centre coordinates, projection text);
+  # the dataset is written by libmcfhip: format "netcdf4" = the reference's container (deflate 9; through the host's HDF5
+  # library, which any host with ncdf4 has), "classic" = uncompressed netCDF classic, needs nothing; options(mcfhip.ncformat).
+  wnc <- function(mout, fileout, dtm, reqhgt, vars = NULL) {
+    if (class(dtm)[1] == "PackedSpatRaster") dtm <- terra::rast(dtm)
+    e <- terra::ext(dtm); r <- terra::res(dtm)
+    est <- seq(e$xmin + r[1] / 2, e$xmax - r[1] / 2, r[1])
+    nth <- seq(e$ymin + r[2] / 2, e$ymax - r[2] / 2, r[2])
+    hours <- as.numeric(as.POSIXct(mout$tme)) / 3600
+    if (is.null(vars)) vars <- if (reqhgt > 0) c("Tz", "tleaf", "relhum", "windspeed", "Rdirdown", "Rdifdown", "Rlwdown", "Rswup", "Rlwup")
+                               else if (reqhgt == 0) c("Tz", "soilm", "Rdirdown", "Rdifdown", "Rlwdown", "Rswup", "Rlwup")
+                               else c("Tz", "soilm")
+    fileout <- as.character(fileout); wkt <- as.character(terra::crs(dtm)); vars <- as.character(vars)
+    fmt <- getOption("mcfhip.ncformat", "netcdf4")
+    invisible(.Call("mcfhip_writetonc", mout, fileout, est, nth, hours, wkt, reqhgt, vars, fmt))
+  }
+  utils::assignInNamespace("writetonc", wnc, ns = "microclimf")
   utils::assignInNamespace("runmicro1Cpp", rm1, ns = "microclimf")
   utils::assignInNamespace("runmicro2Cpp", rm2, ns = "microclimf")
   utils::assignInNamespace("runmicro3Cpp", rm3, ns = "microclimf")
