@@ -102,3 +102,10 @@ MCF_NC_WRITE_THREADS=4 /tmp/mcf_nc_asan
 g++ -O1 -g -std=c++17 -fsanitize=thread -Imicroclimf_amd/csrc -pthread -o /tmp/mcf_nc_tsan /tmp/mcf_nc_harness.cpp
 MCF_NC_WRITE_THREADS=4 /tmp/mcf_nc_tsan
 echo "netCDF file layer through ASan + UBSan and TSan: clean"
+# the netCDF-4 container (mcf_nc4file.hpp: HDF5 bound at run time, chunks deflated by a team of threads): ragged row strips, edge
+# chunks, pieces out of order, empty pieces, every deflate level class — ASan + UBSan, then ThreadSanitizer on the deflate team
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -Imicroclimf_amd/csrc -pthread -o /tmp/mcf_nc4_asan tools/harness/nc4_harness.cpp -lz -ldl
+ASAN_OPTIONS=detect_leaks=0 MCF_NC_DEFLATE_THREADS=4 /tmp/mcf_nc4_asan > /tmp/mcf_nc4_asan.log || { cat /tmp/mcf_nc4_asan.log; exit 1; }
+g++ -O1 -g -std=c++17 -fsanitize=thread -Imicroclimf_amd/csrc -pthread -o /tmp/mcf_nc4_tsan tools/harness/nc4_harness.cpp -lz -ldl
+MCF_NC_DEFLATE_THREADS=4 /tmp/mcf_nc4_tsan > /tmp/mcf_nc4_tsan.log || { tail -40 /tmp/mcf_nc4_tsan.log; exit 1; }
+echo "netCDF-4 container through ASan + UBSan and TSan: clean"
