@@ -66,6 +66,23 @@ def test_terrain_row_blocks_on_one_device_equal_the_whole_raster_bitwise(rows, c
     assert set(two) == {"hor", "svfa"} and np.array_equal(two["hor"], want["hor"], equal_nan=True)
 
 
+def test_terrain_row_blocks_random_geometries_bitwise():
+    """seeded sweep over raster shapes, cell sizes, aggregation factors and block counts (blocks narrower than the halo, a
+    single row per block, more blocks than rows asked for)"""
+    from microclimf_amd.terrain import precompute_terrain
+    from test_terrain_cpu import synth_dtm
+    rng = np.random.default_rng(11)
+    for _ in range(8):
+        rows, cols = int(rng.integers(3, 260)), int(rng.integers(2, 40))
+        res, agg, nb = float(rng.choice([0.5, 1.0, 2.5, 30.0])), int(rng.choice([1, 4, 10])), int(rng.integers(2, 12))
+        z = synth_dtm(rows, cols)
+        z[rng.random((rows, cols)) < 0.03] = np.nan
+        want = precompute_terrain(z, res, 2.0, agg=agg)
+        got = precompute_terrain(z, res, 2.0, agg=agg, devices=[0], n_blocks=nb)
+        for k, w in want.items():
+            assert np.array_equal(got[k], w, equal_nan=True), (k, rows, cols, res, agg, nb)
+
+
 def test_terrain_multi_argument_checks():
     from microclimf_amd import McfError
     from microclimf_amd.terrain import precompute_terrain
