@@ -1387,7 +1387,15 @@ static int prepare_chunk_on(mcf_snowplan* sp, int32_t ch, const double* d_z, int
     sp->prepared = ch;
     return MCF_OK;
 }
+// host_step0: the step of the host arrays the chunk's first step goes to (the chunk's own place in whole-series arrays, or 0
+// for a caller that takes the chunk into a chunk-sized buffer); fill_tail: whole-series arrays — the steps no chunk covers
+// become NA behind the last chunk
+static int run_chunk_to(mcf_snowplan* sp, int32_t ch, double tpic_mean, mcf_snowdriver_out* out, int64_t host_step0, bool fill_tail);
 extern "C" int mcf_snowplan_run_chunk(mcf_snowplan* sp, int32_t ch, double tpic_mean, mcf_snowdriver_out* out) {
+    if (!sp) return mcf::api_fail(MCF_ERR_ARG, "null argument");
+    return run_chunk_to(sp, ch, tpic_mean, out, (int64_t)ch * sp->chunk, true);
+}
+static int run_chunk_to(mcf_snowplan* sp, int32_t ch, double tpic_mean, mcf_snowdriver_out* out, int64_t host_step0, bool fill_tail) {
     if (!sp || !out) return mcf::api_fail(MCF_ERR_ARG, "null argument");
     if (ch != sp->prepared) return mcf::api_fail(MCF_ERR_STATE, "snow plan: run_chunk needs prepare_chunk of the same chunk first");
     S_TRY(hipSetDevice(sp->device));
@@ -1417,8 +1425,8 @@ extern "C" int mcf_snowplan_run_chunk(mcf_snowplan* sp, int32_t ch, double tpic_
     double* hostv[5] = {out->Tc, out->Tg, out->groundsnowdepth, out->totalSWE, out->snowden};
     double* devv[5] = {a.Tc, a.Tg, a.sdepg, a.sdepc, a.sden};
     for (int v = 0; v < 5; ++v)
-        if (hostv[v]) S_TRY(sp->dl.get(hostv[v] + (int64_t)k0 * N, devv[v], (size_t)ns * N * 8));
-    if (ch == sp->nchunks - 1) {   // steps that no chunk covers stay NA (R pre-fills its arrays, int:2554-2558)
+        if (hostv[v]) S_TRY(sp->dl.get(hostv[v] + host_step0 * N, devv[v], (size_t)ns * N * 8));
+    if (fill_tail && ch == sp->nchunks - 1) {   // steps that no chunk covers stay NA (R pre-fills its arrays, int:2554-2558)
         union { uint64_t u; double d; } na; na.u = kNaRealBits;
         const int covered = std::min(sp->T, sp->nchunks * sp->chunk);
         for (double* h : hostv)
@@ -1543,7 +1551,6 @@ extern "C" int mcf_snowmodel1_multi(const mcf_snowdriver_in* in, mcf_snowdriver_
             bi.dtm = k.dtm.data();
             const int rc = mcf_snowplan_create(&bi, k.r0, R, devs[(size_t)t], &k.sp);
             if (rc) { fail_here(rc); break; }
-            for (int v = 0; v < 5; ++v) if (dst[v]) k.series[v].resize((size_t)(k.nr * C * T));
         }
         bar.wait();
         if (t == 0 && !failed) nchunks = blocks[0].sp->nchunks;
@@ -1585,21 +1592,29 @@ extern "C" int mcf_snowmodel1_multi(const mcf_snowdriver_in* in, mcf_snowdriver_
             bar.wait();
             for (int b = t; b < nb && !failed; b += nt) {    // ---- phase 3: the chunk
                 Block& k = blocks[(size_t)b];
+                // the chunk into a chunk-sized buffer of the block, and from there into the block's rows of the caller's arrays
+                const int64_t k0 = (int64_t)ch * k.sp->chunk, ns = std::min<int64_t>(k.sp->chunk, T - k0);
+                for (int v = 0; v < 5; ++v) if (dst[v]) k.series[v].resize((size_t)(k.nr * C * k.sp->chunk));
                 mcf_snowdriver_out bo;
                 double** const bop[5] = {&bo.Tc, &bo.Tg, &bo.groundsnowdepth, &bo.totalSWE, &bo.snowden};
                 for (int v = 0; v < 5; ++v) *bop[v] = dst[v] ? k.series[v].data() : nullptr;
-                const int rc = mcf_snowplan_run_chunk(k.sp, ch, tmean, &bo);
+                const int rc = run_chunk_to(k.sp, ch, tmean, &bo, 0, false);
                 if (rc) { fail_here(rc); break; }
+                for (int v = 0; v < 5; ++v)
+                    if (dst[v])
+                        for (int64_t lc = 0; lc < C * ns; ++lc)
+                            memcpy(dst[v] + k.r0 + R * (lc + C * k0), &k.series[v][(size_t)(k.nr * lc)], (size_t)k.nr * 8);
             }
             bar.wait();
         }
-        for (int b = t; b < nb && !failed; b += nt) {        // ---- the blocks' series into the caller's arrays
+        for (int b = t; b < nb && !failed; b += nt) {        // ---- steps no chunk covers: NA, as the single-plan run leaves them
             Block& k = blocks[(size_t)b];
-            // (the steps the loop ran: as in R, `1:n5days` truncates and later steps keep what the caller put there — NA)
-            const int64_t done = std::min<int64_t>(T, (int64_t)nchunks * k.sp->chunk);
+            union { uint64_t u; double d; } na; na.u = kNaRealBits;
+            const int64_t covered = std::min<int64_t>(T, (int64_t)nchunks * k.sp->chunk);
             for (int v = 0; v < 5; ++v)
                 if (dst[v])
-                    for (int64_t lc = 0; lc < C * done; ++lc) memcpy(dst[v] + k.r0 + R * lc, &k.series[v][(size_t)(k.nr * lc)], (size_t)k.nr * 8);
+                    for (int64_t lc = C * covered; lc < C * T; ++lc)
+                        for (int64_t r = 0; r < k.nr; ++r) dst[v][k.r0 + r + R * lc] = na.d;
         }
     };
     std::vector<std::thread> threads;

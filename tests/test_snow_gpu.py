@@ -213,18 +213,22 @@ def test_snowplan_two_row_blocks_equal_the_whole_raster(rows, cols, split):
             assert_close(got, w, 1e-9, k)
 
 
-@pytest.mark.parametrize("rows,cols,nb,devices", [(300, 40, 2, [0]), (290, 30, 3, [0, 0]), (420, 24, 4, [0])])
-def test_snowmodel1_multi_row_blocks_in_the_library_equal_the_whole_raster(rows, cols, nb, devices):
+@pytest.mark.parametrize("rows,cols,nb,devices,T", [(300, 40, 2, [0], 240), (290, 30, 3, [0, 0], 240), (420, 24, 4, [0], 240),
+                                                     (150, 36, 3, [0], 250)])
+def test_snowmodel1_multi_row_blocks_in_the_library_equal_the_whole_raster(rows, cols, nb, devices, T):
     """mcf_snowmodel1_multi: the chunk loop of a whole raster over row blocks from one process — surface halos and the two
     (sum, count) means pass through host memory inside the library; against the single-plan run (cols = 30 and 24 take
-    .tpicalc's raster-mean branch; two host threads on one device in the second case; blocks narrower than the halo in the third)"""
+    .tpicalc's raster-mean branch; two host threads on one device in the second case; blocks narrower than the halo in the third;
+    250 steps in the fourth: two chunks and ten steps no chunk covers, NA in both)"""
     from microclimf_amd.snow import snowmodel1_chunks
-    sw, dtm = _driver_case(rows, cols, 240)
+    sw, dtm = _driver_case(rows, cols, T)
     args = (sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"], sw["other"], sw["snowenv"])
     whole = snowmodel1_chunks(*args, dtm, 1.0, 0.02)
     got = snowmodel1_chunks(*args, dtm, 1.0, 0.02, devices=devices, n_blocks=nb)
     for k, w in whole.items():
         assert_close(got[k], w, 1e-9, k)
+        if T % 120:
+            assert np.isnan(got[k][:, :, T - T % 120:]).all() and np.isnan(w[:, :, T - T % 120:]).all(), k
     one = snowmodel1_chunks(*args, dtm, 1.0, 0.02, devices=[0], n_blocks=1)          # one block: the single-plan run bit for bit
     for k, w in whole.items():
         assert np.array_equal(one[k], w, equal_nan=True), k
