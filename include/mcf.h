@@ -193,7 +193,7 @@ int mcf_runmicro2(const mcf_grid_inputs *in, const mcf_options *opt, mcf_outputs
  * one host thread per device.  The solver's one global reduction (mean of log(twi)/tfact, src/microclimfCpp.cpp:993-1004)
  * is taken over the whole raster first and installed in every block, so the result is bit for bit the single-device one.
  * n_devices = 0: every visible device; n_blocks = 0: one block per device (more blocks than devices are time-sliced).
- * Static vegetation only. */
+ * mcf_runmicro3_multi / 4_multi: the same with time-varying vegetation (declared behind mcf_runmicro3 / 4 below). */
 typedef struct mcf_multi {
     int32_t n_devices;
     const int32_t *devices;
@@ -208,6 +208,8 @@ int mcf_runmicro2_multi(const mcf_grid_inputs *in, const mcf_options *opt, const
  * layer's range stay NA. */
 int mcf_runmicro3(const mcf_grid_inputs *in, const mcf_options *opt, mcf_outputs *out);
 int mcf_runmicro4(const mcf_grid_inputs *in, const mcf_options *opt, mcf_outputs *out);
+int mcf_runmicro3_multi(const mcf_grid_inputs *in, const mcf_options *opt, const mcf_multi *multi, mcf_outputs *out);
+int mcf_runmicro4_multi(const mcf_grid_inputs *in, const mcf_options *opt, const mcf_multi *multi, mcf_outputs *out);
 
 /* ---- plan API: HBM-resident inputs, device output ring ---------------------- */
 typedef struct mcf_plan mcf_plan;

@@ -173,7 +173,7 @@ EXPORTS = (
     "mcf_plan_set_twi_mean", "mcf_plan_upload_forcing_days", "mcf_plan_run_days",
     "mcf_plan_belowground", "mcf_plan_sync", "mcf_plan_fetch", "mcf_plan_fetch_cells", "mcf_plan_fetch_packed", "mcf_plan_slot_ptr",
     "mcf_plan_ring_layout", "mcf_ring_index", "mcf_plan_run_days_at", "mcf_plan_set_mxtc",
-    "mcf_runmicro1_multi", "mcf_runmicro2_multi", "mcf_plan_fetch_pitched",
+    "mcf_runmicro1_multi", "mcf_runmicro2_multi", "mcf_runmicro3_multi", "mcf_runmicro4_multi", "mcf_plan_fetch_pitched",
     "mcf_snowplan_reset", "mcf_snowplan_checkpoint", "mcf_snowplan_restore", "mcf_snowplan_fetch_cells", "mcf_snowplan_keep_chunk",
     "mcf_snowplan_release_kept", "mcf_snowplan_meand_accumulate", "mcf_snowplan_micro_setup", "mcf_snowplan_microsnow",
     "mcf_plan_timer_start", "mcf_plan_timer_stop", "mcf_plan_kernel_timing",
@@ -289,7 +289,7 @@ def load() -> C.CDLL:
     lib.mcf_plan_run_days.restype = C.c_int
     lib.mcf_plan_run_days.argtypes = [P, C.c_int32, C.c_int32, C.c_int32]
     if hasattr(lib, "mcf_plan_run_days_at"):     # (absent from an older library named by MCF_LIB for an A/B run)
-        for fn in (lib.mcf_runmicro1_multi, lib.mcf_runmicro2_multi):
+        for fn in (lib.mcf_runmicro1_multi, lib.mcf_runmicro2_multi, lib.mcf_runmicro3_multi, lib.mcf_runmicro4_multi):
             fn.restype = C.c_int
             fn.argtypes = [GI, OP, C.POINTER(Multi), OU]
         lib.mcf_plan_fetch_pitched.restype = C.c_int

@@ -93,22 +93,24 @@ def runmicro2Cpp_coarse(obstime: Mapping, climdata: Mapping, pointm: Mapping, ve
 def runmicro3Cpp(dfsel: Mapping, obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Mapping,
                  soilc: Mapping, reqhgt: float, zref: float, lat: float, lon: float, Sminp: float,
                  Smaxp: float, tfact: float, complete: bool, mat: float, out: Sequence, *, device: int = 0,
-                 days_per_chunk: int = 0, cells_per_block: int = 0) -> dict:
+                 days_per_chunk: int = 0, cells_per_block: int = 0, devices=None, n_blocks: int = 0) -> dict:
     """Hourly, changing vegetation, data.frame climate: drop-in for the reference's runmicro3Cpp
     (src/microclimfCpp.cpp:2624-2924).  `dfsel` has columns lyr, st, ed (0-based step ranges of
-    each vegetation layer, R/internal.R:1391-1399); vegp entries are [rows, cols, layers]."""
+    each vegetation layer, R/internal.R:1391-1399); vegp entries are [rows, cols, layers].  `devices` / `n_blocks`: as runmicro1Cpp."""
     return _run("mcf_runmicro3", False, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon,
-                Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block, dfsel)
+                Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block, dfsel,
+                devices=devices, n_blocks=n_blocks)
 
 
 def runmicro4Cpp(dfsel: Mapping, obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Mapping,
                  soilc: Mapping, reqhgt: float, zref: float, lats, lons, Sminp: float, Smaxp: float,
                  tfact: float, complete: bool, mat: float, out: Sequence, *, device: int = 0,
-                 days_per_chunk: int = 0, cells_per_block: int = 0) -> dict:
+                 days_per_chunk: int = 0, cells_per_block: int = 0, devices=None, n_blocks: int = 0) -> dict:
     """Hourly, changing vegetation, array climate: drop-in for the reference's runmicro4Cpp
-    (src/microclimfCpp.cpp:2926-3226)."""
+    (src/microclimfCpp.cpp:2926-3226).  `devices` / `n_blocks`: as runmicro1Cpp."""
     return _run("mcf_runmicro4", True, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons,
-                Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block, dfsel)
+                Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, cells_per_block, dfsel,
+                devices=devices, n_blocks=n_blocks)
 
 
 BIOCLIM_DFSEL = {"lyr": np.arange(1, 15), "st": np.arange(14) * 24, "ed": np.arange(14) * 24 + 23}   # cpp:3634-3646

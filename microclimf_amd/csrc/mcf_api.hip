@@ -1522,7 +1522,6 @@ static int run_multi(const mcf_grid_inputs* in, const mcf_options* opt, const mc
     int rc = check_inputs(in, opt);
     if (rc) return rc;
     if (!mu || !out) return fail(MCF_ERR_ARG, "null argument");
-    if (in->veg_layers > 1) return fail(MCF_ERR_ARG, "the multi-device entry points take static vegetation");
     int ndev_avail = 0;
     if (hipGetDeviceCount(&ndev_avail) != hipSuccess || ndev_avail <= 0)
         return fail(MCF_ERR_NO_DEVICE, "no HIP device available (libmcfhip has no CPU fallback)");
@@ -1614,6 +1613,15 @@ int mcf_runmicro3(const mcf_grid_inputs* in, const mcf_options* opt, mcf_outputs
 int mcf_runmicro4(const mcf_grid_inputs* in, const mcf_options* opt, mcf_outputs* out) {
     if (in && in->veg_layers < 1) return fail(MCF_ERR_ARG, "mcf_runmicro4 needs veg_layers >= 1 and dfsel");
     return run_oneshot(in, opt, out, 1);
+}
+// time-varying vegetation over row blocks: the layered arrays [rows, cols, layers] are read through the same row pitch
+int mcf_runmicro3_multi(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_multi* multi, mcf_outputs* out) {
+    if (in && in->veg_layers < 1) return fail(MCF_ERR_ARG, "mcf_runmicro3_multi needs veg_layers >= 1 and dfsel");
+    return run_multi(in, opt, multi, out, 0);
+}
+int mcf_runmicro4_multi(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_multi* multi, mcf_outputs* out) {
+    if (in && in->veg_layers < 1) return fail(MCF_ERR_ARG, "mcf_runmicro4_multi needs veg_layers >= 1 and dfsel");
+    return run_multi(in, opt, multi, out, 1);
 }
 
 }  // extern "C"

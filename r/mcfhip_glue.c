@@ -163,19 +163,21 @@ static SEXP run(int array_forcing, SEXP dfsel, SEXP obstime, SEXP climdata, SEXP
     }
     setAttrib(ans, R_NamesSymbol, nms);
 
-    /* options(mcfhip.devices = c(0L, 1L, ...)) — set by mcfhip_enable(devices = ) — sends the static-vegetation solves through
+    /* options(mcfhip.devices = c(0L, 1L, ...)) — set by mcfhip_enable(devices = ) — sends the solves through
      * the one-process multi-device entry points: row blocks dealt to the listed HIP devices, the same bits as one device
      * (include/mcf.h mcf_runmicro1_multi).  options(mcfhip.blocks = n): more row blocks than devices (time-sliced). */
     SEXP dv = GetOption1(install("mcfhip.devices"));
     int rc;
-    if (dfsel == R_NilValue && dv != R_NilValue && LENGTH(dv) > 0) {
+    if (dv != R_NilValue && LENGTH(dv) > 0) {
         SEXP dvi = PROTECT(coerceVector(dv, INTSXP)); ++np;
         SEXP nbo = GetOption1(install("mcfhip.blocks"));
         mcf_multi mu;
         mu.n_devices = LENGTH(dvi);
         mu.devices = INTEGER(dvi);
         mu.n_blocks = nbo == R_NilValue ? 0 : asInteger(nbo);
-        rc = array_forcing ? mcf_runmicro2_multi(&in, &opt, &mu, &res) : mcf_runmicro1_multi(&in, &opt, &mu, &res);
+        rc = dfsel == R_NilValue
+                 ? (array_forcing ? mcf_runmicro2_multi(&in, &opt, &mu, &res) : mcf_runmicro1_multi(&in, &opt, &mu, &res))
+                 : (array_forcing ? mcf_runmicro4_multi(&in, &opt, &mu, &res) : mcf_runmicro3_multi(&in, &opt, &mu, &res));
     } else {
         rc = dfsel == R_NilValue
                  ? (array_forcing ? mcf_runmicro2(&in, &opt, &res) : mcf_runmicro1(&in, &opt, &res))

@@ -35,6 +35,22 @@ def test_array_forcing_row_blocks_bitwise():
     _bits_equal(whole, parts)
 
 
+def test_time_varying_vegetation_row_blocks_bitwise():
+    """mcf_runmicro3_multi / 4_multi: the layered vegetation arrays [rows, cols, layers] go through the same row pitch; a day
+    no layer covers stays NA in every block"""
+    from microclimf_amd.api import runmicro3Cpp, runmicro4Cpp
+    a = synthetic.layered(synthetic.workload(47, 13, 24 * 7, reqhgt=0.05, variety=True, start_doy=150, na_frac=0.05), 3, cover_days=6)
+    dfsel = a.pop("dfsel")
+    whole = runmicro3Cpp(dfsel, **a)
+    parts = runmicro3Cpp(dfsel, **a, devices=[0], n_blocks=4)
+    _bits_equal(whole, parts)
+    assert np.isnan(parts["Tz"][:, :, 144:]).all() and np.isfinite(parts["Tz"][:, :, :144]).any()
+    b = synthetic.layered(synthetic.workload(33, 11, 96, reqhgt=0.05, variety=True, start_doy=170, array_forcing=True), 2)
+    dfsel = b.pop("dfsel")
+    b["lats"], b["lons"] = b.pop("lat"), b.pop("lon")
+    _bits_equal(runmicro4Cpp(dfsel, **b), runmicro4Cpp(dfsel, **b, devices=[0, 0], n_blocks=3))
+
+
 def test_a_sea_of_na_cells_moves_the_block_boundaries_not_the_result():
     a = synthetic.workload(80, 14, 48, reqhgt=0.05, start_doy=200)
     a["vegp"]["hgt"][:55, :] = np.nan                 # the valid cells sit in the last 25 rows
