@@ -397,6 +397,17 @@ int mcf_runbioclim3(const mcf_grid_inputs *in, const mcf_options *opt, const mcf
                     mcf_bioclim_out *out);
 int mcf_runbioclim4(const mcf_grid_inputs *in, const mcf_options *opt, const mcf_bioclim_sel *sel,
                     mcf_bioclim_out *out);
+/* The four over row blocks on several devices from one process (mcf_multi as for mcf_runmicro1_multi: the whole-raster twi
+ * mean installed in every block, inputs read and the [rows, cols] results written in place through the row pitch): bit for
+ * bit the single-device matrices. */
+int mcf_runbioclim1_multi(const mcf_grid_inputs *in, const mcf_options *opt, const mcf_bioclim_sel *sel, const mcf_multi *multi,
+                          mcf_bioclim_out *out);
+int mcf_runbioclim2_multi(const mcf_grid_inputs *in, const mcf_options *opt, const mcf_bioclim_sel *sel, const mcf_multi *multi,
+                          mcf_bioclim_out *out);
+int mcf_runbioclim3_multi(const mcf_grid_inputs *in, const mcf_options *opt, const mcf_bioclim_sel *sel, const mcf_multi *multi,
+                          mcf_bioclim_out *out);
+int mcf_runbioclim4_multi(const mcf_grid_inputs *in, const mcf_options *opt, const mcf_bioclim_sel *sel, const mcf_multi *multi,
+                          mcf_bioclim_out *out);
 
 /* ---- terrain pre-compute (the solver's terrain inputs, built on the device) ------
  * Restates the R-side arithmetic of the reference's marshaller (R/internal.R):

@@ -178,7 +178,8 @@ EXPORTS = (
     "mcf_snowplan_release_kept", "mcf_snowplan_meand_accumulate", "mcf_snowplan_micro_setup", "mcf_snowplan_microsnow",
     "mcf_plan_timer_start", "mcf_plan_timer_stop", "mcf_plan_kernel_timing",
     "mcf_plan_kernel_stats", "mcf_plan_dispatch_stats", "mcf_plan_valid_cells", "mcf_plan_bytes", "mcf_selftest_math",
-    "mcf_precompute_terrain", "mcf_precompute_terrain_multi", "mcf_runbioclim1", "mcf_runbioclim2", "mcf_runbioclim3", "mcf_runbioclim4",
+    "mcf_precompute_terrain", "mcf_precompute_terrain_multi", "mcf_runbioclim1_multi", "mcf_runbioclim2_multi",
+    "mcf_runbioclim3_multi", "mcf_runbioclim4_multi", "mcf_runbioclim1", "mcf_runbioclim2", "mcf_runbioclim3", "mcf_runbioclim4",
     "mcf_snowenv_from_name", "mcf_gridmodelsnow1", "mcf_gridmodelsnow2", "mcf_gridmicrosnow1",
     "mcf_gridmicrosnow2", "mcf_snowmodel1", "mcf_snowmodel1_multi", "mcf_applycpp3",
     "mcf_snowplan_create", "mcf_snowplan_destroy", "mcf_snowplan_chunks", "mcf_snowplan_surface", "mcf_snowplan_handover", "mcf_snowplan_apply3",
@@ -357,6 +358,9 @@ def load() -> C.CDLL:
     for fn in (lib.mcf_runbioclim1, lib.mcf_runbioclim2, lib.mcf_runbioclim3, lib.mcf_runbioclim4):
         fn.restype = C.c_int
         fn.argtypes = [GI, OP, C.POINTER(BioclimSel), C.POINTER(BioclimOut)]
+    for fn in (lib.mcf_runbioclim1_multi, lib.mcf_runbioclim2_multi, lib.mcf_runbioclim3_multi, lib.mcf_runbioclim4_multi):
+        fn.restype = C.c_int
+        fn.argtypes = [GI, OP, C.POINTER(BioclimSel), C.POINTER(Multi), C.POINTER(BioclimOut)]
     lib.mcf_snowenv_from_name.restype = C.c_int32
     lib.mcf_snowenv_from_name.argtypes = [C.c_char_p]
     SI = C.POINTER(SnowInputs)

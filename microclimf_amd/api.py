@@ -117,7 +117,7 @@ BIOCLIM_DFSEL = {"lyr": np.arange(1, 15), "st": np.arange(14) * 24, "ed": np.ara
 
 
 def _bioclim(fn_name, array_forcing, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp,
-             Smaxp, tfact, mat, out, wetq, dryq, hotq, colq, air, device, layered=False):
+             Smaxp, tfact, mat, out, wetq, dryq, hotq, colq, air, device, layered=False, devices=None, n_blocks=0):
     lib = _abi.load()
     m = marshal(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact, True, mat,
                 [1] * 10, array_forcing, device, dfsel=BIOCLIM_DFSEL if layered else None)
@@ -142,24 +142,31 @@ def _bioclim(fn_name, array_forcing, obstime, climdata, pointm, vegp, soilc, req
             bo.bio[v] = a.ctypes.data_as(_abi.c_double_p)
         else:
             bo.bio[v] = None
-    _abi.check(getattr(lib, fn_name)(C.byref(m.inputs), C.byref(m.options), C.byref(sel), C.byref(bo)))
+    if devices is not None or n_blocks:
+        # one process, several devices (include/mcf.h mcf_runbioclim1_multi): row blocks dealt to the listed devices, same bits
+        mu = _abi.Multi()
+        devs = np.ascontiguousarray([] if devices is None else list(devices), dtype=np.int32)
+        mu.n_devices, mu.devices, mu.n_blocks = int(devs.size), devs.ctypes.data_as(_abi.c_int32_p), int(n_blocks)
+        _abi.check(getattr(lib, fn_name + "_multi")(C.byref(m.inputs), C.byref(m.options), C.byref(sel), C.byref(mu), C.byref(bo)))
+    else:
+        _abi.check(getattr(lib, fn_name)(C.byref(m.inputs), C.byref(m.options), C.byref(sel), C.byref(bo)))
     return res
 
 
 def runbioclim1Cpp(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact, mat, out,
-                   wetq, dryq, hotq, colq, air, *, device: int = 0) -> dict:
+                   wetq, dryq, hotq, colq, air, *, device: int = 0, devices=None, n_blocks: int = 0) -> dict:
     """Drop-in for the reference's runbioclim1Cpp (src/microclimfCpp.cpp:3563-3588): the grid solver on
     the selected days followed by the 19 per-cell bioclim reductions, both on the device; only the
-    requested [rows, cols] matrices are copied back."""
+    requested [rows, cols] matrices are copied back.  `devices` / `n_blocks`: row blocks over several devices, same bits."""
     return _bioclim("mcf_runbioclim1", False, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon,
-                    Sminp, Smaxp, tfact, mat, out, wetq, dryq, hotq, colq, air, device)
+                    Sminp, Smaxp, tfact, mat, out, wetq, dryq, hotq, colq, air, device, devices=devices, n_blocks=n_blocks)
 
 
 def runbioclim2Cpp(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons, Sminp, Smaxp, tfact, mat, out,
-                   wetq, dryq, hotq, colq, air, *, device: int = 0) -> dict:
+                   wetq, dryq, hotq, colq, air, *, device: int = 0, devices=None, n_blocks: int = 0) -> dict:
     """Drop-in for the reference's runbioclim2Cpp (src/microclimfCpp.cpp:3590-3616), array climate."""
     return _bioclim("mcf_runbioclim2", True, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons,
-                    Sminp, Smaxp, tfact, mat, out, wetq, dryq, hotq, colq, air, device)
+                    Sminp, Smaxp, tfact, mat, out, wetq, dryq, hotq, colq, air, device, devices=devices, n_blocks=n_blocks)
 
 
 class Plan:
@@ -298,15 +305,15 @@ class Plan:
 
 
 def runbioclim3Cpp(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon, Sminp, Smaxp, tfact, mat, out,
-                   wetq, dryq, hotq, colq, air, *, device: int = 0) -> dict:
+                   wetq, dryq, hotq, colq, air, *, device: int = 0, devices=None, n_blocks: int = 0) -> dict:
     """Drop-in for runbioclim3Cpp (src/microclimfCpp.cpp:3620-3658): vegetation arrays [rows, cols, 14], one layer per
     selected day (twelve monthly days, the hottest, the coldest); steps past the 336th stay NA as in the reference."""
     return _bioclim("mcf_runbioclim3", False, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, lon,
-                    Sminp, Smaxp, tfact, mat, out, wetq, dryq, hotq, colq, air, device, True)
+                    Sminp, Smaxp, tfact, mat, out, wetq, dryq, hotq, colq, air, device, True, devices=devices, n_blocks=n_blocks)
 
 
 def runbioclim4Cpp(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons, Sminp, Smaxp, tfact, mat, out,
-                   wetq, dryq, hotq, colq, air, *, device: int = 0) -> dict:
+                   wetq, dryq, hotq, colq, air, *, device: int = 0, devices=None, n_blocks: int = 0) -> dict:
     """Drop-in for runbioclim4Cpp (src/microclimfCpp.cpp:3660-3700), array climate."""
     return _bioclim("mcf_runbioclim4", True, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons,
-                    Sminp, Smaxp, tfact, mat, out, wetq, dryq, hotq, colq, air, device, True)
+                    Sminp, Smaxp, tfact, mat, out, wetq, dryq, hotq, colq, air, device, True, devices=devices, n_blocks=n_blocks)

@@ -1323,20 +1323,22 @@ int mcf_selftest_math(int32_t kind, const double* x, const double* y, double* ou
     return MCF_OK;
 }
 
+static const int32_t kBioSt[14] = {0, 24, 48, 72, 96, 120, 144, 168, 192, 216, 240, 264, 288, 312};
+static const int32_t kBioEd[14] = {23, 47, 71, 95, 119, 143, 167, 191, 215, 239, 263, 287, 311, 335};
+// twi_mean / out_pitch: a row block of a taller raster (the bioclim `_multi` entries): the raster-wide twi mean to install, and
+// the rows of the caller's [rows_total, cols] matrices the block's rows are written into in place
 static int run_bioclim(const mcf_grid_inputs* in_caller, const mcf_options* opt_in, const mcf_bioclim_sel* sel,
-                       mcf_bioclim_out* out, int want_af, int layered = 0) {
+                       mcf_bioclim_out* out, int want_af, int layered = 0, const double* twi_mean = nullptr, int64_t out_pitch = 0) {
     if (!sel || !out || !in_caller) return fail(MCF_ERR_ARG, "null bioclim argument");
     // runbioclim3Cpp / 4Cpp (cpp:3620-3658 / 3660-3700): vegetation arrays [rows, cols, >= 14] and a fixed dfsel of
     // fourteen one-day layers — the twelve monthly days, the hottest and the coldest day; later steps (the quarter
     // days) belong to no layer and stay NA, as in the reference
-    static const int32_t kSt[14] = {0, 24, 48, 72, 96, 120, 144, 168, 192, 216, 240, 264, 288, 312};
-    static const int32_t kEd[14] = {23, 47, 71, 95, 119, 143, 167, 191, 215, 239, 263, 287, 311, 335};
     mcf_grid_inputs in_l;
     if (layered) {
         in_l = *in_caller;
         in_l.veg_layers = 14;
-        in_l.lyr_st = kSt;
-        in_l.lyr_ed = kEd;
+        in_l.lyr_st = kBioSt;
+        in_l.lyr_ed = kBioEd;
     }
     const mcf_grid_inputs* in = layered ? &in_l : in_caller;
     int rc = check_inputs(in, opt_in);
@@ -1362,6 +1364,7 @@ static int run_bioclim(const mcf_grid_inputs* in_caller, const mcf_options* opt_
     mcf_plan* p = nullptr;
     if ((rc = mcf_plan_create(in, &opt, ndays, 1, &p))) return rc;
     struct Guard { mcf_plan* p; ~Guard() { mcf_plan_destroy(p); } } guard{p};
+    if (twi_mean && (rc = mcf_plan_set_twi_mean(p, *twi_mean))) return rc;
     if (in->array_forcing && (rc = mcf_plan_upload_forcing_days(p, in, 0, ndays, 0))) return rc;
     if ((rc = mcf_plan_run_days(p, 0, ndays, 0))) return rc;
     if (p->bg && (rc = mcf_plan_belowground(p))) return rc;
@@ -1383,7 +1386,11 @@ static int run_bioclim(const mcf_grid_inputs* in_caller, const mcf_options* opt_
     for (int v = 0; v < MCF_NBIO; ++v)
         if (sel->out[v]) {
             if (!out->bio[v]) return fail(MCF_ERR_ARG, "requested bioclim variable has a null buffer");
-            HIP_TRY(hipMemcpyAsync(out->bio[v], b.bio + (int64_t)v * N, (size_t)N * 8, hipMemcpyDeviceToHost, p->stream));
+            if (out_pitch > in->rows)
+                HIP_TRY(hipMemcpy2DAsync(out->bio[v], (size_t)out_pitch * 8, b.bio + (int64_t)v * N, (size_t)in->rows * 8,
+                                         (size_t)in->rows * 8, (size_t)in->cols, hipMemcpyDeviceToHost, p->stream));
+            else
+                HIP_TRY(hipMemcpyAsync(out->bio[v], b.bio + (int64_t)v * N, (size_t)N * 8, hipMemcpyDeviceToHost, p->stream));
         }
     return mcf_plan_sync(p);
 }
@@ -1518,10 +1525,14 @@ static std::vector<std::pair<int64_t, int64_t>> row_blocks(const mcf_grid_inputs
     return out;
 }
 
-static int run_multi(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_multi* mu, mcf_outputs* out, int want_af) {
+extern "C++" {
+// block_fn(sub, o, r0, twi_mean): one row block — `sub` is the caller's inputs narrowed to the block's rows (same arrays, offset,
+// read through the row pitch), `o` the options with the block's device, r0 the block's first row
+template <class F>
+static int for_row_blocks(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_multi* mu, F&& block_fn) {
     int rc = check_inputs(in, opt);
     if (rc) return rc;
-    if (!mu || !out) return fail(MCF_ERR_ARG, "null argument");
+    if (!mu) return fail(MCF_ERR_ARG, "null argument");
     int ndev_avail = 0;
     if (hipGetDeviceCount(&ndev_avail) != hipSuccess || ndev_avail <= 0)
         return fail(MCF_ERR_NO_DEVICE, "no HIP device available (libmcfhip has no CPU fallback)");
@@ -1581,9 +1592,7 @@ static int run_multi(const mcf_grid_inputs* in, const mcf_options* opt, const mc
                 }
                 mcf_options o = *opt;
                 o.device = devs[t];
-                mcf_outputs so = *out;
-                for (int v = 0; v < MCF_NOUT; ++v) if (so.var[v]) so.var[v] += r0;
-                const int rcb = run_oneshot(&sub, &o, &so, want_af, &twi_mean);
+                const int rcb = block_fn(sub, o, r0, &twi_mean);
                 if (rcb != MCF_OK) { rcs[t] = rcb; errs[t] = g_err; return; }
             }
         });
@@ -1592,6 +1601,41 @@ static int run_multi(const mcf_grid_inputs* in, const mcf_options* opt, const mc
     for (size_t t = 0; t < devs.size(); ++t)
         if (rcs[t] != MCF_OK) return fail(rcs[t], errs[t]);
     return MCF_OK;
+}
+
+}  // extern "C++"
+static int run_multi(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_multi* mu, mcf_outputs* out, int want_af) {
+    if (!out) return fail(MCF_ERR_ARG, "null argument");
+    return for_row_blocks(in, opt, mu, [&](const mcf_grid_inputs& sub, const mcf_options& o, int64_t r0, const double* twi_mean) {
+        mcf_outputs so = *out;
+        for (int v = 0; v < MCF_NOUT; ++v) if (so.var[v]) so.var[v] += r0;
+        return run_oneshot(&sub, &o, &so, want_af, twi_mean);
+    });
+}
+// the fused bioclim sink over row blocks: a block's nineteen [rows, cols] matrices go into its rows of the caller's
+static int run_bioclim_multi(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_bioclim_sel* sel, const mcf_multi* mu,
+                             mcf_bioclim_out* out, int want_af, int layered) {
+    if (!out || !sel || !in) return fail(MCF_ERR_ARG, "null bioclim argument");
+    const int64_t pitch = in->row_pitch > 0 ? in->row_pitch : in->rows;
+    mcf_grid_inputs in_l = *in;
+    if (layered) { in_l.veg_layers = 14; in_l.lyr_st = kBioSt; in_l.lyr_ed = kBioEd; }     // as run_bioclim: the fixed dfsel
+    return for_row_blocks(&in_l, opt, mu, [&](const mcf_grid_inputs& sub, const mcf_options& o, int64_t r0, const double* twi_mean) {
+        mcf_bioclim_out bo = *out;
+        for (int v = 0; v < MCF_NBIO; ++v) if (bo.bio[v]) bo.bio[v] += r0;
+        return run_bioclim(&sub, &o, sel, &bo, want_af, layered, twi_mean, pitch);
+    });
+}
+int mcf_runbioclim1_multi(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_bioclim_sel* sel, const mcf_multi* mu, mcf_bioclim_out* out) {
+    return run_bioclim_multi(in, opt, sel, mu, out, 0, 0);
+}
+int mcf_runbioclim2_multi(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_bioclim_sel* sel, const mcf_multi* mu, mcf_bioclim_out* out) {
+    return run_bioclim_multi(in, opt, sel, mu, out, 1, 0);
+}
+int mcf_runbioclim3_multi(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_bioclim_sel* sel, const mcf_multi* mu, mcf_bioclim_out* out) {
+    return run_bioclim_multi(in, opt, sel, mu, out, 0, 1);
+}
+int mcf_runbioclim4_multi(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_bioclim_sel* sel, const mcf_multi* mu, mcf_bioclim_out* out) {
+    return run_bioclim_multi(in, opt, sel, mu, out, 1, 1);
 }
 
 int mcf_runmicro1(const mcf_grid_inputs* in, const mcf_options* opt, mcf_outputs* out) {

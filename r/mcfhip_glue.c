@@ -252,8 +252,22 @@ static SEXP run_bioclim(int array_forcing, int layered, SEXP obstime, SEXP climd
     }
     setAttrib(ans, R_NamesSymbol, nms);
     /* layered (runbioclim3Cpp / 4Cpp): vegp holds [rows, cols, 14] arrays; the library installs the fixed dfsel */
-    int rc = layered ? (array_forcing ? mcf_runbioclim4(&in, &opt, &sel, &bo) : mcf_runbioclim3(&in, &opt, &sel, &bo))
+    /* options(mcfhip.devices) — mcfhip_enable(devices = ) —: row blocks over the listed devices, same bits (mcf_runbioclim1_multi) */
+    SEXP dv = GetOption1(install("mcfhip.devices"));
+    int rc;
+    if (dv != R_NilValue && LENGTH(dv) > 0) {
+        SEXP dvi = PROTECT(coerceVector(dv, INTSXP)); ++np;
+        SEXP nbo = GetOption1(install("mcfhip.blocks"));
+        mcf_multi mu;
+        mu.n_devices = LENGTH(dvi);
+        mu.devices = INTEGER(dvi);
+        mu.n_blocks = nbo == R_NilValue ? 0 : asInteger(nbo);
+        rc = layered ? (array_forcing ? mcf_runbioclim4_multi(&in, &opt, &sel, &mu, &bo) : mcf_runbioclim3_multi(&in, &opt, &sel, &mu, &bo))
+                     : (array_forcing ? mcf_runbioclim2_multi(&in, &opt, &sel, &mu, &bo) : mcf_runbioclim1_multi(&in, &opt, &sel, &mu, &bo));
+    } else {
+        rc = layered ? (array_forcing ? mcf_runbioclim4(&in, &opt, &sel, &bo) : mcf_runbioclim3(&in, &opt, &sel, &bo))
                      : (array_forcing ? mcf_runbioclim2(&in, &opt, &sel, &bo) : mcf_runbioclim1(&in, &opt, &sel, &bo));
+    }
     if (rc != MCF_OK) {
         char msg[600];
         strncpy(msg, mcf_last_error(), sizeof msg - 1); msg[sizeof msg - 1] = 0;

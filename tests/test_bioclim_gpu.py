@@ -82,3 +82,35 @@ def test_runbioclim3_and_4_layered_vegetation(oracle, af):
         assert np.array_equal(np.isnan(got[k]), np.isnan(w)), k
         np.testing.assert_allclose(got[k], w, rtol=1e-9, atol=1e-9, err_msg=k)
     assert np.isfinite(got["bio1"][0, 0]) and np.isnan(got["bio1"][2, 1])
+
+
+def test_bioclim_row_blocks_on_one_device_give_the_same_bits():
+    """mcf_runbioclim1_multi ... 4_multi: the fused sink over row blocks from one process (whole-raster twi mean installed in
+    every block, the nineteen matrices written in place through the row pitch) — bit for bit the single-device matrices"""
+    from microclimf_amd.api import runbioclim3Cpp
+    wq, dq, hq, cq = quarters()
+    out = [1] * 19
+    a = synthetic.workload(37, 9, T, reqhgt=0.05, variety=True, start_doy=120, na_frac=0.05)
+    for k in ("complete", "out"):
+        a.pop(k)
+    whole = runbioclim1Cpp(**a, out=out, wetq=wq, dryq=dq, hotq=hq, colq=cq, air=True)
+    parts = runbioclim1Cpp(**a, out=out, wetq=wq, dryq=dq, hotq=hq, colq=cq, air=True, devices=[0, 0], n_blocks=3)
+    assert list(whole) == list(parts)
+    for k in whole:
+        assert np.array_equal(whole[k].view(np.uint64), parts[k].view(np.uint64)), k
+    b = synthetic.workload(23, 8, T, reqhgt=0.05, variety=True, start_doy=100, array_forcing=True)
+    for k in ("complete", "out"):
+        b.pop(k)
+    b["lats"], b["lons"] = b.pop("lat"), b.pop("lon")
+    sel = [1, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 1]
+    w2 = runbioclim2Cpp(**b, out=sel, wetq=wq, dryq=dq, hotq=hq, colq=cq, air=False)
+    p2 = runbioclim2Cpp(**b, out=sel, wetq=wq, dryq=dq, hotq=hq, colq=cq, air=False, devices=[0], n_blocks=4)
+    for k in w2:
+        assert np.array_equal(w2[k].view(np.uint64), p2[k].view(np.uint64)), k
+    c = synthetic.layered(synthetic.workload(21, 6, T, reqhgt=0.05, variety=True, start_doy=100), 14)
+    for k in ("complete", "out", "dfsel"):
+        c.pop(k)
+    w3 = runbioclim3Cpp(**c, out=out, wetq=wq, dryq=dq, hotq=hq, colq=cq, air=True)
+    p3 = runbioclim3Cpp(**c, out=out, wetq=wq, dryq=dq, hotq=hq, colq=cq, air=True, devices=[0], n_blocks=2)
+    for k in w3:
+        assert np.array_equal(w3[k].view(np.uint64), p3[k].view(np.uint64)), k
