@@ -46,7 +46,8 @@ def test_ctypes_structs_agree_with_the_compiled_header(tmp_path):
                                                     "lyr_ed", "coarse_rows", "coarse_cols", "coarse_rowpos", "coarse_winddir",
                                                     "coarse_altcorrect", "coarse_dtm", "fine_dtm"]),
               "mcf_options": (_abi.Options, ["tfact", "complete", "out", "device", "cells_per_block"]),
-              "mcf_nc_spec": (_abi.NcSpec, ["nsteps", "east", "crs_wkt", "reqhgt", "vars", "reference_puts_only"])}
+              "mcf_nc_spec": (_abi.NcSpec, ["nsteps", "east", "crs_wkt", "reqhgt", "vars", "reference_puts_only", "format", "deflate_level"]),
+              "mcf_multi": (_abi.Multi, ["n_devices", "devices", "n_blocks"])}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "mcf.h"', 'int main(void) {']
     for name, (_, fields) in probes.items():
         src.append(f'printf("{name} %zu\\n", sizeof({name}));')
@@ -74,6 +75,23 @@ def test_no_cpu_fallback_without_device():
     a = synthetic.workload(4, 4, 24)
     with pytest.raises(_abi.McfError, match="no HIP device"):
         runmicro1Cpp(**a)
+    # ... nor through the one-process multi-device entries (solver, terrain pre-compute, snow chunk loop, bioclim sink)
+    with pytest.raises(_abi.McfError, match="no HIP device"):
+        runmicro1Cpp(**a, devices=[0], n_blocks=2)
+    from microclimf_amd.terrain import precompute_terrain
+    with pytest.raises(_abi.McfError, match="no HIP device"):
+        precompute_terrain(np.zeros((8, 8)), 1.0, 2.0, devices=[0], n_blocks=2)
+    from microclimf_amd.snow import snowmodel1_chunks
+    sw = synthetic.snow_workload(6, 5, 120, cold=3.0, zref=3.5)
+    with pytest.raises(_abi.McfError, match="no HIP device"):
+        snowmodel1_chunks(sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"], sw["other"], sw["snowenv"],
+                          np.zeros((6, 5)), 1.0, 0.02, devices=[0], n_blocks=2)
+    from microclimf_amd.api import runbioclim1Cpp
+    b = synthetic.workload(4, 4, 336)
+    for k in ("complete", "out"):
+        b.pop(k)
+    with pytest.raises(_abi.McfError, match="no HIP device"):
+        runbioclim1Cpp(**b, out=[1] * 19, wetq=[0], dryq=[0], hotq=[0], colq=[0], air=True, devices=[0], n_blocks=2)
 
 
 def test_marshal_rejects_bad_shapes():
