@@ -460,24 +460,22 @@ template <bool BOUNDED>
 __device__ __forceinline__ double fexp_tab(double x, const MathK& K) {
     double n, r, p, r2, out;
     int t;
+    // (the table index is ready after the first (bounded) or second instruction: the LDS read is issued there and the
+    // reduction's two FMAs run under its latency as well as the polynomial's four)
     if (BOUNDED && K.vfast) {
         double y;
-        asm("v_fma_f64 %0, %3, %4, %5\n\t"       // y = x * 256/ln2 + 1.5 * 2^52: an integer in the low mantissa bits
-            "v_add_f64 %1, %0, -%5\n\t"          // n (exact)
-            "v_fma_f64 %2, %1, %6, %3\n\t"
-            "v_fma_f64 %2, %1, %7, %2"
-            : "=&v"(y), "=&v"(n), "=&v"(r)
-            : "v"(x), "s"(K.t[0]), "v"(K.magic), "s"(K.t[1]), "s"(K.t[2]));
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(y) : "v"(x), "s"(K.t[0]), "v"(K.magic));    // x * 256/ln2 + 1.5 * 2^52: an integer in the low mantissa bits
         t = __double2loint(y);
+        asm("v_add_f64 %0, %1, -%2" : "=v"(n) : "v"(y), "v"(K.magic));                      // n (exact)
     } else {
-        asm("v_mul_f64 %0, %3, %4\n\t"
-            "v_rndne_f64 %0, %0\n\t"
-            "v_fma_f64 %1, %0, %5, %3\n\t"
-            "v_fma_f64 %1, %0, %6, %1\n\t"
-            "v_cvt_i32_f64 %2, %0"
-            : "=&v"(n), "=&v"(r), "=v"(t)
-            : "v"(x), "s"(K.t[0]), "s"(K.t[1]), "s"(K.t[2]));
+        asm("v_mul_f64 %0, %1, %2\n\t"
+            "v_rndne_f64 %0, %0"
+            : "=v"(n) : "v"(x), "s"(K.t[0]));
+        asm("v_cvt_i32_f64 %0, %1" : "=v"(t) : "v"(n));
     }
+    asm("v_fma_f64 %0, %1, %2, %3\n\t"
+        "v_fma_f64 %0, %1, %4, %0"
+        : "=&v"(r) : "v"(n), "s"(K.t[1]), "v"(x), "s"(K.t[2]));
     double T;
     if (K.vfast) {
         // byte offset of table entry t & 255 in ONE instruction (SDWA byte select + shift); its shift operand has to be a VGPR,

@@ -103,6 +103,14 @@ VARIANTS = {
                 h[g * 8 + 1] / n, h[g * 8 + 2] / n, h[g * 8 + 3] / n, h[g * 8 + 7], h[g * 8 + 5] / m, h[g * 8 + 6] / m);
     }
 }''')],
+    # static priority for one half of the workgroup's waves (MI355X_MICROARCH.md, "Two waves per SIMD" item 4): waves w and
+    # w + 4 share a SIMD; results bitwise the shipped ones
+    "setprio_hi": [(LOOP, '''    if ((tid >> 6) >= 4) __builtin_amdgcn_s_setprio(1);     // VARIANT
+    for (int dl = 0; dl < ndays; ++dl, ++run) {
+        const int dabs = day0 + dl;''')],
+    "setprio_lo": [(LOOP, '''    if ((tid >> 6) < 4) __builtin_amdgcn_s_setprio(1);     // VARIANT
+    for (int dl = 0; dl < ndays; ++dl, ++run) {
+        const int dabs = day0 + dl;''')],
     # persistent workgroups (a fixed grid walking the tile sequence): measured a loss in rounds 2 and 3 (128 VGPRs, scratch)
     "persistent_loop": [('''    const int rot = (int)((blockIdx.x >> 8) & 1);
     const int64_t pos = tile_position(a.ntiles_launch);
