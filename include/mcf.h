@@ -50,8 +50,8 @@
 extern "C" {
 #endif
 
-#define MCF_ABI_VERSION 4   /* 2: mcf_grid_inputs grew the coarse-forcing fields; 3: tiled output ring (mcf_plan_ring_layout);
-                             * 4: mcf_nc_spec grew format / deflate_level (zero = the behaviour of version 3) */
+#define MCF_ABI_VERSION 5   /* 2: mcf_grid_inputs grew the coarse-forcing fields; 3: tiled output ring (mcf_plan_ring_layout);
+                             * 4: mcf_nc_spec grew format / deflate_level (zero = the behaviour of version 3); 5: mcf_runmicrosnow1 / mcf_snowrun_* */
 
 /* Output variables, in the order of the reference's returned list
  * (src/microclimfCpp.cpp:2326-2335) and of its `out` logical(10). */
@@ -604,6 +604,12 @@ int mcf_snowplan_prepare_chunk_dev(mcf_snowplan *plan, int32_t chunk, const doub
                                    const double *d_halo_south, int32_t halo_south, double surface_mean, double *tpic_sum,
                                    double *tpic_count);
 int mcf_snowplan_run_chunk(mcf_snowplan *plan, int32_t chunk, double tpic_mean, mcf_snowdriver_out *out);
+/* ... with the chunk's series written into row blocks of taller column-major host arrays (`row_pitch` rows per column; 0 =
+ * dense): one strided DMA per series straight into the caller's rows, no block-sized host buffer (mcf_snowmodel1_multi). */
+int mcf_snowplan_run_chunk_pitched(mcf_snowplan *plan, int32_t chunk, double tpic_mean, const mcf_snowdriver_out *out, int64_t row_pitch);
+/* `.tpicalc`'s aggregation factor of a chunk, round(10 * sqrt(mean wind speed of the chunk) / res) (R/internal.R:2589-2590):
+ * what sizes the halo a row block needs around its rows (100 + 3 s + 2 af rows, or all rows up to the raster edge). */
+int mcf_snowplan_chunk_af(const mcf_snowplan *plan, int32_t chunk, int32_t *af);
 /* applycpp3 (src/microclimfCpp.cpp:5553-5588) of the totalSWE series of the chunk just run, straight from the device:
  * result / count [steps of that chunk] as mcf_applycpp3 gives them.  `.runmicrosnow1` decides snow / no-snow days on the
  * per-step minimum and maximum of totalSWE (R/internal.R:3592-3594); row-block ranks combine them with one all-reduce. */
@@ -660,6 +666,55 @@ int mcf_snowplan_micro_setup(mcf_snowplan *plan, const mcf_snow_inputs *subset, 
                              int32_t ndays, double reqhgt, double mat, const int32_t out[MCF_NOUT], int32_t reuse_static);
 int mcf_snowplan_microsnow(mcf_snowplan *plan, mcf_plan *solver, int32_t chunk, int32_t slot,
                            const int32_t *nosnowday /* [days of the chunk] */);
+
+/* ---- `runmicro(..., snow = TRUE)` for data.frame weather as ONE call: `.snowmodel1` + `.runmicrosnow1` -----------------------
+ * The reference's `.runmicrosnow1(micropoint, reqhgt, vegp, soilc, dtm, smod, ...)` (R/internal.R:3581-3659, called from
+ * runmicro at R/Cppwrappers.R:382) takes `smod` — five [rows, cols, tsteps] arrays that `runsnowmodel` -> `.snowmodel1`
+ * (R/internal.R:2498-2619) produced — from host memory, runs the grid solver on the days with a snow-free cell somewhere
+ * (`.runmicronosnow` on subsetpointmodel(days = nosnowdays), :3603-3606), gridmicrosnow1 on the days with snow somewhere
+ * (:3612-3625) and merges by day (:3633-3656).  This entry is that whole sequence with the snow series kept on the device:
+ * the chunk loop of `.snowmodel1` is driven here (mcf_snowplan_*), the two models meet in the solver's output ring, and only
+ * the merged [rows, cols, tsteps] outputs — and the snow series too, if `smod` asks for them — cross PCIe.  An R session
+ * reaches it through r/mcfhip_overrides.R (runsnowmodel returns a light handle instead of the arrays, `.runmicrosnow1` passes
+ * it on).
+ *   grid    what `.runmicronosnow` -> runmicro1Cpp would get for EVERY day of the series (vector forcing; static vegetation)
+ *   snow    `.snowmodel1`'s inputs as for mcf_snowmodel1 (obstime / climate / pointmodelsnow output for the whole series, the
+ *           `.sortl` vegetation, initial depths and ages, dtm, res, tfact)
+ *   micro   gridmicrosnow1's inputs as `.prepsnowinputs1` (R/internal.R:3375-3443) makes them, but for the WHOLE series
+ *           (tsteps = the series' length; the entry takes the snow-day subset itself): obstime, climate incl. umu =
+ *           smod$umu, `.sortl2` vegetation, bare-ground terrain (slope, aspect, skyview, wsa, hor), lat, lon, zref, Smax.
+ *           May be NULL only if the year has no snow day.
+ *   mat     micropoint$matemp
+ * `opt`: reqhgt >= 0 (below ground the reference smooths whole series: use mcf_runmicro1 + mcf_gridmicrosnow1 on host
+ * arrays), out[] as for mcf_runmicro1; with reqhgt == 0 gridmicrosnow1 is given the reference's fixed mask (:3616-3619).
+ * `out`: [rows, cols, tsteps] per requested variable; `smod` (optional, members may be NULL): `.snowmodel1`'s returned arrays.
+ * Days that are in neither class (max totalSWE <= 0 and min != 0: a melted pack's negative rounding residue) are NA in
+ * `out` — the reference's merge indexes past its arrays there (:3650-3655).  Steps past the last whole 5-day chunk are
+ * no-snow days, as `.runmicrosnow1`'s NA -> 0 makes them (:3586).
+ * The staged form, for callers whose gridmicrosnow1 inputs depend on the day classes (`.sortl2` weights time-varying
+ * vegetation layers by the snow-covered steps): create -> pass1 (returns snowday[] / nosnowday[], one flag per day) -> pass2. */
+typedef struct mcf_microsnow_in {
+    const mcf_grid_inputs *grid;
+    const mcf_snowdriver_in *snow;
+    const mcf_snow_inputs *micro;
+    double mat;
+} mcf_microsnow_in;
+int mcf_runmicrosnow1(const mcf_microsnow_in *in, const mcf_options *opt, mcf_outputs *out, const mcf_snowdriver_out *smod);
+/* The same over row blocks on several devices from one process (mcf_multi as for mcf_runmicro1_multi; equal-row blocks as
+ * mcf_snowmodel1_multi): per chunk the blocks' snow surfaces meet in one host array, the raster-wide means (snow surface, tpi,
+ * the solver's twi mean) and the per-step extremes of totalSWE are combined in block order.  One block: bit for bit
+ * mcf_runmicrosnow1; more blocks: equal up to the summation order of those means. */
+int mcf_runmicrosnow1_multi(const mcf_microsnow_in *in, const mcf_options *opt, const mcf_multi *multi, mcf_outputs *out,
+                            const mcf_snowdriver_out *smod);
+typedef struct mcf_snowrun mcf_snowrun;
+/* `in->micro` and `in->mat` are not read here; multi = NULL: one block on opt->device.  The caller's arrays must stay valid
+ * until mcf_snowrun_destroy. */
+int mcf_snowrun_create(const mcf_microsnow_in *in, const mcf_options *opt, const mcf_multi *multi, mcf_snowrun **run);
+void mcf_snowrun_destroy(mcf_snowrun *run);
+int32_t mcf_snowrun_days(const mcf_snowrun *run);     /* tsteps / 24 */
+/* snowday / nosnowday: [mcf_snowrun_days] or NULL */
+int mcf_snowrun_pass1(mcf_snowrun *run, const mcf_snowdriver_out *smod, int32_t *snowday, int32_t *nosnowday);
+int mcf_snowrun_pass2(mcf_snowrun *run, const mcf_snow_inputs *micro, double mat, mcf_outputs *out);
 
 /* applycpp3 (src/microclimfCpp.cpp:5553-5588; `.runmicrosnow1/2` use it on totalSWE, R/internal.R:3592-3593):
  * reduction of a [rows,cols,tsteps] array over space, per time step, skipping NA.  fun: 0 mean, 1 sum,

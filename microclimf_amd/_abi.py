@@ -162,6 +162,12 @@ class SnowDriverIn(C.Structure):
 SNOWDRIVER_OUT = ("Tc", "Tg", "groundsnowdepth", "totalSWE", "snowden")
 SnowDriverOut = _ptr_struct("SnowDriverOut", SNOWDRIVER_OUT)
 
+
+class MicrosnowIn(C.Structure):
+    """include/mcf.h mcf_microsnow_in"""
+    _fields_ = [("grid", C.POINTER(GridInputs)), ("snow", C.POINTER(SnowDriverIn)), ("micro", C.POINTER(SnowInputs)),
+                ("mat", C.c_double)]
+
 _PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = _PKG_DIR / "csrc" / "libmcfhip.so"
 
@@ -188,9 +194,11 @@ EXPORTS = (
     "mcf_bigleaf", "mcf_soilm", "mcf_pointmprocess", "mcf_weatherhgt", "mcf_man", "mcf_pointmodelsnow", "mcf_canintfrac", "mcf_meltmu", "mcf_meltmu2", "mcf_tpicalc",
     "mcf_nc_create", "mcf_nc_write_host", "mcf_nc_write_plan", "mcf_nc_close",
     "mcf_flowacc", "mcf_topidx",
+    "mcf_runmicrosnow1", "mcf_runmicrosnow1_multi", "mcf_snowrun_create", "mcf_snowrun_destroy", "mcf_snowrun_days",
+    "mcf_snowrun_pass1", "mcf_snowrun_pass2", "mcf_snowplan_run_chunk_pitched", "mcf_snowplan_chunk_af",
 )
 
-ABI_VERSION = 4     # include/mcf.h MCF_ABI_VERSION this mirror was written against
+ABI_VERSION = 5     # include/mcf.h MCF_ABI_VERSION this mirror was written against
 _lib = None
 
 
@@ -429,6 +437,26 @@ def load() -> C.CDLL:
     lib.mcf_snowmodel1.argtypes = [C.POINTER(SnowDriverIn), C.POINTER(SnowDriverOut), C.c_int32]
     lib.mcf_snowmodel1_multi.restype = C.c_int
     lib.mcf_snowmodel1_multi.argtypes = [C.POINTER(SnowDriverIn), C.POINTER(SnowDriverOut), C.POINTER(Multi)]
+    if hasattr(lib, "mcf_runmicrosnow1"):     # (absent from an older library named by MCF_LIB for an A/B run)
+        MI, SO = C.POINTER(MicrosnowIn), C.POINTER(SnowDriverOut)
+        lib.mcf_runmicrosnow1.restype = C.c_int
+        lib.mcf_runmicrosnow1.argtypes = [MI, OP, OU, SO]
+        lib.mcf_runmicrosnow1_multi.restype = C.c_int
+        lib.mcf_runmicrosnow1_multi.argtypes = [MI, OP, C.POINTER(Multi), OU, SO]
+        lib.mcf_snowrun_create.restype = C.c_int
+        lib.mcf_snowrun_create.argtypes = [MI, OP, C.POINTER(Multi), C.POINTER(P)]
+        lib.mcf_snowrun_destroy.restype = None
+        lib.mcf_snowrun_destroy.argtypes = [P]
+        lib.mcf_snowrun_days.restype = C.c_int32
+        lib.mcf_snowrun_days.argtypes = [P]
+        lib.mcf_snowrun_pass1.restype = C.c_int
+        lib.mcf_snowrun_pass1.argtypes = [P, SO, c_int32_p, c_int32_p]
+        lib.mcf_snowrun_pass2.restype = C.c_int
+        lib.mcf_snowrun_pass2.argtypes = [P, C.POINTER(SnowInputs), C.c_double, OU]
+        lib.mcf_snowplan_run_chunk_pitched.restype = C.c_int
+        lib.mcf_snowplan_run_chunk_pitched.argtypes = [P, C.c_int32, C.c_double, SO, C.c_int64]
+        lib.mcf_snowplan_chunk_af.restype = C.c_int
+        lib.mcf_snowplan_chunk_af.argtypes = [P, C.c_int32, C.POINTER(C.c_int32)]
     lib.mcf_precompute_terrain.restype = C.c_int
     lib.mcf_precompute_terrain.argtypes = [C.POINTER(TerrainIn), C.POINTER(TerrainOut), C.c_int32]
     lib.mcf_precompute_terrain_multi.restype = C.c_int

@@ -1137,6 +1137,14 @@ int chunk_af(const mcf_snowplan* sp, int ch, int* af) {   // int:2589-2590
 
 }  // namespace
 
+extern "C" int mcf_snowplan_chunk_af(const mcf_snowplan* sp, int32_t chunk, int32_t* af) {
+    if (!sp || !af) return mcf::api_fail(MCF_ERR_ARG, "null argument");
+    if (chunk < 0 || chunk >= sp->nchunks) return mcf::api_fail(MCF_ERR_ARG, "chunk out of range");
+    int a = 1;
+    const int rc = chunk_af(sp, chunk, &a);
+    *af = a;
+    return rc;
+}
 extern "C" int mcf_snowplan_create(const mcf_snowdriver_in* din, int64_t row0, int64_t rows_total, int32_t device,
                                    mcf_snowplan** out) {
     int rc;
@@ -1390,13 +1398,24 @@ static int prepare_chunk_on(mcf_snowplan* sp, int32_t ch, const double* d_z, int
 // host_step0: the step of the host arrays the chunk's first step goes to (the chunk's own place in whole-series arrays, or 0
 // for a caller that takes the chunk into a chunk-sized buffer); fill_tail: whole-series arrays — the steps no chunk covers
 // become NA behind the last chunk
-static int run_chunk_to(mcf_snowplan* sp, int32_t ch, double tpic_mean, mcf_snowdriver_out* out, int64_t host_step0, bool fill_tail);
+// row_pitch: 0 / rows = dense [rows, cols, steps] host arrays; > rows: the host arrays are row blocks of a taller column-major
+// raster with that many rows per column, written in place (one strided DMA per series: no block-sized host buffer, no scatter)
+static int run_chunk_to(mcf_snowplan* sp, int32_t ch, double tpic_mean, const mcf_snowdriver_out* out, int64_t host_step0, bool fill_tail,
+                        int64_t row_pitch);
 extern "C" int mcf_snowplan_run_chunk(mcf_snowplan* sp, int32_t ch, double tpic_mean, mcf_snowdriver_out* out) {
     if (!sp) return mcf::api_fail(MCF_ERR_ARG, "null argument");
-    return run_chunk_to(sp, ch, tpic_mean, out, (int64_t)ch * sp->chunk, true);
+    return run_chunk_to(sp, ch, tpic_mean, out, (int64_t)ch * sp->chunk, true, 0);
 }
-static int run_chunk_to(mcf_snowplan* sp, int32_t ch, double tpic_mean, mcf_snowdriver_out* out, int64_t host_step0, bool fill_tail) {
+extern "C" int mcf_snowplan_run_chunk_pitched(mcf_snowplan* sp, int32_t ch, double tpic_mean, const mcf_snowdriver_out* out,
+                                              int64_t row_pitch) {
+    if (!sp) return mcf::api_fail(MCF_ERR_ARG, "null argument");
+    if (row_pitch != 0 && row_pitch < sp->rows) return mcf::api_fail(MCF_ERR_ARG, "row_pitch smaller than rows");
+    return run_chunk_to(sp, ch, tpic_mean, out, (int64_t)ch * sp->chunk, true, row_pitch);
+}
+static int run_chunk_to(mcf_snowplan* sp, int32_t ch, double tpic_mean, const mcf_snowdriver_out* out, int64_t host_step0, bool fill_tail,
+                        int64_t row_pitch) {
     if (!sp || !out) return mcf::api_fail(MCF_ERR_ARG, "null argument");
+    if (row_pitch <= 0) row_pitch = sp->rows;
     if (ch != sp->prepared) return mcf::api_fail(MCF_ERR_STATE, "snow plan: run_chunk needs prepare_chunk of the same chunk first");
     S_TRY(hipSetDevice(sp->device));
     const int64_t N = sp->N;
@@ -1424,13 +1443,20 @@ static int run_chunk_to(mcf_snowplan* sp, int32_t ch, double tpic_mean, mcf_snow
     }
     double* hostv[5] = {out->Tc, out->Tg, out->groundsnowdepth, out->totalSWE, out->snowden};
     double* devv[5] = {a.Tc, a.Tg, a.sdepg, a.sdepc, a.sden};
-    for (int v = 0; v < 5; ++v)
-        if (hostv[v]) S_TRY(sp->dl.get(hostv[v] + host_step0 * N, devv[v], (size_t)ns * N * 8));
+    const int64_t HS = row_pitch * sp->cols;        // host doubles per step
+    for (int v = 0; v < 5; ++v) {
+        if (!hostv[v]) continue;
+        if (row_pitch == sp->rows) S_TRY(sp->dl.get(hostv[v] + host_step0 * N, devv[v], (size_t)ns * N * 8));
+        else S_TRY(hipMemcpy2D(hostv[v] + host_step0 * HS, (size_t)row_pitch * 8, devv[v], (size_t)sp->rows * 8, (size_t)sp->rows * 8,
+                               (size_t)(sp->cols * ns), hipMemcpyDeviceToHost));
+    }
     if (fill_tail && ch == sp->nchunks - 1) {   // steps that no chunk covers stay NA (R pre-fills its arrays, int:2554-2558)
         union { uint64_t u; double d; } na; na.u = kNaRealBits;
         const int covered = std::min(sp->T, sp->nchunks * sp->chunk);
         for (double* h : hostv)
-            if (h) for (int64_t q = (int64_t)covered * N; q < (int64_t)sp->T * N; ++q) h[q] = na.d;
+            if (h)
+                for (int64_t lc = (int64_t)covered * sp->cols; lc < (int64_t)sp->T * sp->cols; ++lc)
+                    for (int64_t r = 0; r < sp->rows; ++r) h[r + row_pitch * lc] = na.d;
     }
     sp->prepared = -1;
     return MCF_OK;
@@ -1490,7 +1516,12 @@ void gather_rows(std::vector<T>& dst, const T* src, int64_t R, int64_t C, int64_
 }
 }  // namespace
 
+static int snowmodel1_multi_impl(const mcf_snowdriver_in* in, mcf_snowdriver_out* out, const mcf_multi* mu);
 extern "C" int mcf_snowmodel1_multi(const mcf_snowdriver_in* in, mcf_snowdriver_out* out, const mcf_multi* mu) {
+    try { return snowmodel1_multi_impl(in, out, mu); }
+    catch (const std::exception& e) { return mcf::api_fail(MCF_ERR_NOMEM, std::string("mcf_snowmodel1_multi: ") + e.what()); }
+}
+static int snowmodel1_multi_impl(const mcf_snowdriver_in* in, mcf_snowdriver_out* out, const mcf_multi* mu) {
     if (!in || !out || !mu) return mcf::api_fail(MCF_ERR_ARG, "null snow driver argument");
     const mcf_snow_inputs& base = in->base;
     if (base.rows <= 0 || base.cols <= 0 || !in->dtm) return mcf::api_fail(MCF_ERR_ARG, "snow driver needs the raster and its dtm");
@@ -1510,12 +1541,12 @@ extern "C" int mcf_snowmodel1_multi(const mcf_snowdriver_in* in, mcf_snowdriver_
             devs.push_back(mu->devices[i]);
         }
     }
-    const int64_t R = base.rows, C = base.cols, T = base.tsteps;
+    const int64_t R = base.rows, C = base.cols;
     const int nb = (int)std::min<int64_t>(mu->n_blocks > 0 ? mu->n_blocks : (int)devs.size(), R);
     const int nt = (int)std::min<size_t>(devs.size(), (size_t)nb);
     struct Block {
         int64_t r0 = 0, nr = 0;
-        std::vector<double> pai, hgt, leaft, clump, dc, dg, dtm, ext, series[5];
+        std::vector<double> pai, hgt, leaft, clump, dc, dg, dtm, ext;
         std::vector<int32_t> ac, ag;
         mcf_snowplan* sp = nullptr;
         double s = 0, n = 0, ts = 0, tn = 0;
@@ -1533,6 +1564,13 @@ extern "C" int mcf_snowmodel1_multi(const mcf_snowdriver_in* in, mcf_snowdriver_
     // every thread runs every phase of every chunk (also after a failure: the barrier counts heads), doing nothing once failed
     auto worker = [&](int t) {
         auto fail_here = [&](int rc) { rcs[(size_t)t] = rc; errs[(size_t)t] = mcf_last_error(); failed = true; };
+        // (a std::bad_alloc from a block's host vectors must neither leave the thread — std::terminate would take the host R /
+        // Python process down — nor skip a barrier the other threads wait at: each phase body runs under this guard)
+        auto guarded = [&](auto&& body) {
+            try { body(); }
+            catch (const std::exception& e) { rcs[(size_t)t] = MCF_ERR_NOMEM; errs[(size_t)t] = std::string("snow driver: ") + e.what(); failed = true; }
+        };
+        guarded([&] {
         for (int b = t; b < nb && !failed; b += nt) {        // ---- plans
             Block& k = blocks[(size_t)b];
             k.r0 = R * b / nb; k.nr = R * (b + 1) / nb - k.r0;
@@ -1552,10 +1590,12 @@ extern "C" int mcf_snowmodel1_multi(const mcf_snowdriver_in* in, mcf_snowdriver_
             const int rc = mcf_snowplan_create(&bi, k.r0, R, devs[(size_t)t], &k.sp);
             if (rc) { fail_here(rc); break; }
         }
+        });
         bar.wait();
         if (t == 0 && !failed) nchunks = blocks[0].sp->nchunks;
         bar.wait();
         for (int ch = 0; ch < nchunks; ++ch) {
+            guarded([&] {
             for (int b = t; b < nb && !failed; b += nt) {    // ---- phase 1: the surface
                 Block& k = blocks[(size_t)b];
                 k.ext.resize((size_t)(k.nr * C));
@@ -1564,6 +1604,7 @@ extern "C" int mcf_snowmodel1_multi(const mcf_snowdriver_in* in, mcf_snowdriver_
                 if (rc) { fail_here(rc); break; }
                 for (int64_t c = 0; c < C; ++c) memcpy(&surface[(size_t)(k.r0 + R * c)], &k.ext[(size_t)(k.nr * c)], (size_t)k.nr * 8);
             }
+            });
             bar.wait();
             if (t == 0 && !failed) {
                 double s = 0, n = 0;
@@ -1571,6 +1612,7 @@ extern "C" int mcf_snowmodel1_multi(const mcf_snowdriver_in* in, mcf_snowdriver_
                 smean = s / n;
             }
             bar.wait();
+            guarded([&] {
             for (int b = t; b < nb && !failed; b += nt) {    // ---- phase 2: halos, terrain, tpi
                 Block& k = blocks[(size_t)b];
                 int af = 1;
@@ -1583,6 +1625,7 @@ extern "C" int mcf_snowmodel1_multi(const mcf_snowdriver_in* in, mcf_snowdriver_
                 rc = mcf_snowplan_prepare_chunk(k.sp, ch, (hn || hs) ? k.ext.data() : nullptr, (int32_t)hn, (int32_t)hs, smean, &k.ts, &k.tn);
                 if (rc) { fail_here(rc); break; }
             }
+            });
             bar.wait();
             if (t == 0 && !failed) {
                 double s = 0, n = 0;
@@ -1592,29 +1635,15 @@ extern "C" int mcf_snowmodel1_multi(const mcf_snowdriver_in* in, mcf_snowdriver_
             bar.wait();
             for (int b = t; b < nb && !failed; b += nt) {    // ---- phase 3: the chunk
                 Block& k = blocks[(size_t)b];
-                // the chunk into a chunk-sized buffer of the block, and from there into the block's rows of the caller's arrays
-                const int64_t k0 = (int64_t)ch * k.sp->chunk, ns = std::min<int64_t>(k.sp->chunk, T - k0);
-                for (int v = 0; v < 5; ++v) if (dst[v]) k.series[v].resize((size_t)(k.nr * C * k.sp->chunk));
+                // the chunk's series go straight into the block's rows of the caller's arrays (strided DMA through the row
+                // pitch); the steps no chunk covers become NA behind the last chunk, as in the single-plan run
                 mcf_snowdriver_out bo;
                 double** const bop[5] = {&bo.Tc, &bo.Tg, &bo.groundsnowdepth, &bo.totalSWE, &bo.snowden};
-                for (int v = 0; v < 5; ++v) *bop[v] = dst[v] ? k.series[v].data() : nullptr;
-                const int rc = run_chunk_to(k.sp, ch, tmean, &bo, 0, false);
+                for (int v = 0; v < 5; ++v) *bop[v] = dst[v] ? dst[v] + k.r0 : nullptr;
+                const int rc = run_chunk_to(k.sp, ch, tmean, &bo, (int64_t)ch * k.sp->chunk, true, R);
                 if (rc) { fail_here(rc); break; }
-                for (int v = 0; v < 5; ++v)
-                    if (dst[v])
-                        for (int64_t lc = 0; lc < C * ns; ++lc)
-                            memcpy(dst[v] + k.r0 + R * (lc + C * k0), &k.series[v][(size_t)(k.nr * lc)], (size_t)k.nr * 8);
             }
             bar.wait();
-        }
-        for (int b = t; b < nb && !failed; b += nt) {        // ---- steps no chunk covers: NA, as the single-plan run leaves them
-            Block& k = blocks[(size_t)b];
-            union { uint64_t u; double d; } na; na.u = kNaRealBits;
-            const int64_t covered = std::min<int64_t>(T, (int64_t)nchunks * k.sp->chunk);
-            for (int v = 0; v < 5; ++v)
-                if (dst[v])
-                    for (int64_t lc = C * covered; lc < C * T; ++lc)
-                        for (int64_t r = 0; r < k.nr; ++r) dst[v][k.r0 + r + R * lc] = na.d;
         }
     };
     std::vector<std::thread> threads;

@@ -856,3 +856,128 @@ def snowmodel1_chunks_tiled(plan, rank: int, world: int, *, exchange=None, allre
         ts, tn = plan.prepare_chunk(ch, ext if (hn or hs) else None, hn, hs, smean)
         plan.run_chunk(ch, allreduce(ts, tn))
     return plan.result
+
+
+# ---- `runmicro(..., snow = TRUE)` as one library call (include/mcf.h mcf_runmicrosnow1 / mcf_snowrun_*) -------------------
+class SnowRun:
+    """`.snowmodel1` + `.runmicrosnow1` (R/internal.R:2498-2619, 3581-3659) device-resident, staged:
+    `pass1()` walks the snow model's chunk loop and returns the day classes, `pass2(micro inputs)` the merged microclimate.
+
+    grid   the fifteen arguments of runmicro1Cpp for the WHOLE series (mapping with the names of api.runmicro1Cpp's parameters)
+    snow   {"obstime", "climdata", "pointm", "vegp", "other", "snowenv", "dtm", "res", "tfact"[, "chunk_steps"]} as for
+           `SnowPlan` / snowmodel1_chunks
+    devices / n_blocks: row blocks over several devices from this one process (None: one block on `device`)."""
+
+    def __init__(self, grid: Mapping, snow: Mapping, *, device: int = 0, devices=None, n_blocks: int = 0, cells_per_block: int = 0):
+        self._marshal_only(grid, snow, device, cells_per_block)
+        mu = None
+        if devices is not None or n_blocks:
+            mu = _abi.Multi()
+            self._devs = np.ascontiguousarray([] if devices is None else list(devices), dtype=np.int32)
+            mu.n_devices, mu.devices, mu.n_blocks = int(self._devs.size), self._devs.ctypes.data_as(_abi.c_int32_p), int(n_blocks)
+        self._p = C.c_void_p()
+        _abi.check(self._lib.mcf_snowrun_create(C.byref(self._in), C.byref(self._gm.options), C.byref(mu) if mu is not None else None,
+                                                C.byref(self._p)))
+        self.days = int(self._lib.mcf_snowrun_days(self._p))
+
+    def _marshal_only(self, grid: Mapping, snow: Mapping, device: int, cells_per_block: int):
+        from .marshal import alloc_outputs, marshal
+        self._lib = _abi.load()
+        g = grid
+        self._gm = marshal(g["obstime"], g["climdata"], g["pointm"], g["vegp"], g["soilc"], g["reqhgt"], g["zref"], g["lat"], g["lon"],
+                           g.get("Sminp", 0.0), g.get("Smaxp", 0.0), g["tfact"], g.get("complete", True), g.get("mat", 0.0),
+                           g.get("out", (1,) * 10), False, device, 0, cells_per_block)
+        self._alloc_outputs = lambda: alloc_outputs(self._gm)
+        R, Cc = np.shape(snow["vegp"]["pai"])
+        oth = dict(snow["other"])
+        for k, shp in (("slope", (R, Cc)), ("aspect", (R, Cc)), ("skyview", (R, Cc)), ("wsa", (R, Cc, 8)), ("hor", (R, Cc, 24))):
+            oth.setdefault(k, np.zeros(shp))
+        self._sm = marshal_snow(snow["obstime"], snow["climdata"], snow["vegp"], oth, False, pointm=snow["pointm"],
+                                snowenv=snow.get("snowenv", "Alpine"))
+        self._din = _abi.SnowDriverIn()
+        self._din.base = self._sm.inputs
+        self._din.dtm = self._sm.f64(snow["dtm"], (R, Cc), "dtm")
+        self._din.res, self._din.tfact = float(snow["res"]), float(snow.get("tfact", 0.02))
+        self._din.chunk_steps = int(snow.get("chunk_steps", 120))
+        self._in = _abi.MicrosnowIn()
+        self._in.grid = C.pointer(self._gm.inputs)
+        self._in.snow = C.pointer(self._din)
+        self._in.micro = None
+        self._in.mat = 0.0
+        self.rows, self.cols, self.tsteps = R, Cc, self._sm.tsteps
+        self._mm = None
+
+    def close(self):
+        if getattr(self, "_p", None) is not None and self._p.value:
+            self._lib.mcf_snowrun_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def pass1(self, want_smod: bool = False):
+        """-> (snowdays, nosnowdays[, smod]): one 0/1 flag per day; smod = `.snowmodel1`'s five [rows, cols, tsteps] arrays"""
+        sd, nd = np.zeros(self.days, np.int32), np.zeros(self.days, np.int32)
+        so, smod = None, None
+        if want_smod:
+            so, smod = _abi.SnowDriverOut(), {}
+            for f in _abi.SNOWDRIVER_OUT:
+                a = np.empty((self.rows, self.cols, self.tsteps), dtype=np.float64, order="F")
+                smod[f] = a
+                setattr(so, f, a.ctypes.data_as(_abi.c_double_p))
+        _abi.check(self._lib.mcf_snowrun_pass1(self._p, C.byref(so) if so is not None else None, sd.ctypes.data_as(_abi.c_int32_p),
+                                               nd.ctypes.data_as(_abi.c_int32_p)))
+        return (sd, nd, smod) if want_smod else (sd, nd)
+
+    def pass2(self, micro: Mapping | None, mat: float) -> dict:
+        """micro = {"obstime", "climdata" (with umu), "vegp" (`.sortl2`), "other" (bare-ground terrain, lat, lon, zref, Smax)} for
+        the WHOLE series, or None when the year has no snow day -> the ten merged outputs"""
+        mi = None
+        if micro is not None:
+            self._mm = marshal_snow(micro["obstime"], micro["climdata"], micro["vegp"], micro["other"], False, micro=True)
+            mi = C.byref(self._mm.inputs)
+        outs, arrays = self._alloc_outputs()
+        _abi.check(self._lib.mcf_snowrun_pass2(self._p, mi, float(mat), C.byref(outs)))
+        return arrays
+
+
+def runmicrosnow1(grid: Mapping, snow: Mapping, micro: Mapping | None, mat: float, *, device: int = 0, devices=None, n_blocks: int = 0,
+                  want_smod: bool = False, cells_per_block: int = 0):
+    """mcf_runmicrosnow1 / mcf_runmicrosnow1_multi: the whole snow run as ONE library call (arguments as `SnowRun`, `micro` as
+    `SnowRun.pass2`) -> the merged outputs[, smod]"""
+    from .marshal import alloc_outputs
+    with SnowRun.__new__(SnowRun) as run:
+        run._p = None
+        SnowRun._marshal_only(run, grid, snow, device, cells_per_block)
+        mi = None
+        if micro is not None:
+            run._mm = marshal_snow(micro["obstime"], micro["climdata"], micro["vegp"], micro["other"], False, micro=True)
+            run._in.micro = C.pointer(run._mm.inputs)
+        run._in.mat = float(mat)
+        outs, arrays = alloc_outputs(run._gm)
+        so, smod = None, None
+        if want_smod:
+            so, smod = _abi.SnowDriverOut(), {}
+            for f in _abi.SNOWDRIVER_OUT:
+                a = np.empty((run.rows, run.cols, run.tsteps), dtype=np.float64, order="F")
+                smod[f] = a
+                setattr(so, f, a.ctypes.data_as(_abi.c_double_p))
+        sop = C.byref(so) if so is not None else None
+        lib = _abi.load()
+        if devices is not None or n_blocks:
+            mu = _abi.Multi()
+            devs = np.ascontiguousarray([] if devices is None else list(devices), dtype=np.int32)
+            mu.n_devices, mu.devices, mu.n_blocks = int(devs.size), devs.ctypes.data_as(_abi.c_int32_p), int(n_blocks)
+            _abi.check(lib.mcf_runmicrosnow1_multi(C.byref(run._in), C.byref(run._gm.options), C.byref(mu), C.byref(outs), sop))
+        else:
+            _abi.check(lib.mcf_runmicrosnow1(C.byref(run._in), C.byref(run._gm.options), C.byref(outs), sop))
+    return (arrays, smod) if want_smod else arrays

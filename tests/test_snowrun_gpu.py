@@ -1,0 +1,145 @@
+"""mcf_runmicrosnow1 / mcf_runmicrosnow1_multi / mcf_snowrun_* (include/mcf.h): `runmicro(..., snow = TRUE)` with data.frame
+weather as ONE library call — `.snowmodel1`'s chunk loop (R/internal.R:2498-2619) and `.runmicrosnow1`'s two models and merge
+(R/internal.R:3581-3659) device-resident.  Held against
+  (1) the reference's orchestration on the host through the one-shot entry points (whole-series snow arrays in host memory,
+      the solver and gridmicrosnow1 on day SUBSETS, merge_snow_outputs): HIP vs HIP, 1e-12;
+  (2) the same orchestration with the ORACLE's solver and snow microclimate behind it (oracle/mcf_oracle.c, snow_oracle.c)
+      on the device's snow series: 1e-6 — every one of the merged ten outputs, every cell-step;
+  (3) row blocks (more blocks than devices, two host threads on one device): 1e-9 / bitwise for one block."""
+import numpy as np
+import pytest
+
+from microclimf_amd import snow as S
+from microclimf_amd import synthetic
+from microclimf_amd.api import runmicro1Cpp
+
+pytestmark = pytest.mark.gpu
+ARGS = ("obstime", "climdata", "pointm", "vegp", "soilc", "reqhgt", "zref", "lat", "lon", "Sminp", "Smaxp", "tfact",
+        "complete", "mat", "out")
+MAT = 7.5
+
+
+def _steps(days0):
+    return (np.repeat(np.asarray(days0) * 24, 24) + np.tile(np.arange(24), len(days0))).astype(np.int64)
+
+
+def _sub(d, idx):
+    return {k: (np.asarray(v)[idx] if np.ndim(v) == 1 else v) for k, v in d.items()}
+
+
+def _case(reqhgt, cold, doy, rows=22, cols=13, ndays=20):
+    T = ndays * 24
+    sw = synthetic.snow_workload(rows, cols, T, cold=cold, zref=3.5, start_doy=doy)
+    a = synthetic.workload(rows, cols, T, reqhgt=reqhgt, zref=3.5, hgt_range=(0.05, 3.0), start_doy=doy, variety=True)
+    _, _, dtm = synthetic.rasters(rows, cols)
+    dtm = np.where(np.isnan(sw["vegp"]["hgt"]), np.nan, dtm)
+    snow = dict(sw, dtm=dtm, res=1.0, tfact=0.02)
+    micro = {"obstime": sw["obstime"], "climdata": sw["climdata"], "vegp": sw["vegp"], "other": sw["other"]}
+    return sw, a, dtm, snow, micro
+
+
+def _orchestrate(a, sw, dtm, smod, sdays, ndays_, reqhgt, solve, microsnow):
+    """`.runmicrosnow1` steps (3)-(5) on host arrays: `solve(args of the day subset)`, `microsnow(...)` on the snow-day subset"""
+    rows, cols = dtm.shape
+    ni, si = _steps(ndays_), _steps(sdays)
+    outm = [1] * 10 if reqhgt > 0 else [1 if i in (0, 3, 5, 6, 7, 8, 9) else 0 for i in range(10)]
+    an = dict(a, obstime=_sub(a["obstime"], ni), climdata=_sub(a["climdata"], ni), pointm=_sub(a["pointm"], ni))
+    moutn = solve(an)
+    micro = {}
+    s1 = np.arange(si.size)[np.repeat(np.isin(sdays, ndays_), 24)]
+    s2 = np.arange(ni.size)[np.repeat(np.isin(ndays_, sdays), 24)]
+    for k, v in moutn.items():
+        m = np.full((rows, cols, si.size), np.nan, order="F")
+        m[:, :, s1] = v[:, :, s2]
+        micro[k] = m
+    swe = smod["totalSWE"].copy()
+    swe[np.isnan(swe)] = 0.0
+    swe[np.isnan(dtm)] = np.nan
+    smods = {k: np.asfortranarray((swe if k == "totalSWE" else v)[:, :, si]) for k, v in smod.items()}
+    mouts = microsnow(reqhgt, _sub(sw["obstime"], si), _sub(sw["climdata"], si), smods, micro, sw["vegp"], sw["other"], MAT, outm)
+    for k in moutn:
+        if k not in mouts:
+            mouts[k] = micro[k]
+    return S.merge_snow_outputs(moutn, mouts, sdays + 1, ndays_ + 1, rows, cols)
+
+
+def _close(got, want, tol, what):
+    assert list(got) == list(want)
+    for k in want:
+        g, w = got[k], want[k]
+        assert g.shape == w.shape, (what, k)
+        assert np.array_equal(np.isnan(g), np.isnan(w)), (what, k)
+        fin = np.isfinite(w)
+        if fin.any():
+            err = float(np.max(np.abs(g[fin] - w[fin]) / (1 + np.abs(w[fin]))))
+            assert err < tol, (what, k, err)
+
+
+@pytest.mark.parametrize("reqhgt,cold,doy", [(0.05, 0.0, 90), (0.3, -3.0, 20), (0.0, 3.0, 120)])
+def test_one_call_equals_the_host_orchestration_and_the_oracle_backed_one(oracle, reqhgt, cold, doy):
+    sw, a, dtm, snow, micro = _case(reqhgt, cold, doy)
+    got, smod = S.runmicrosnow1(a, snow, micro, MAT, want_smod=True)
+    # the snow series the entry returns are mcf_snowmodel1's
+    want_smod = S.snowmodel1_chunks(sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"], sw["other"], sw["snowenv"], dtm, 1.0, 0.02)
+    for k in smod:
+        assert np.array_equal(smod[k], want_smod[k], equal_nan=True), k
+    # the staged form gives the day classes — and the same output
+    with S.SnowRun(a, snow) as run:
+        sd, nd = run.pass1()
+        got2 = run.pass2(micro, MAT)
+    for k in got:
+        assert np.array_equal(got[k], got2[k], equal_nan=True), k
+    swe = smod["totalSWE"].copy()
+    swe[np.isnan(swe)] = 0.0
+    swe[np.isnan(dtm)] = np.nan
+    days = S.snowdaysfun(S.applycpp3(swe, "max"), S.applycpp3(swe, "min"))
+    assert np.array_equal(sd, days["snowdays"]) and np.array_equal(nd, days["nosnowdays"])
+    sdays, ndays_ = np.flatnonzero(sd), np.flatnonzero(nd)
+    assert sdays.size >= 3 and ndays_.size >= 3 and (sd & nd).sum() >= 1 and (sd | nd).all()
+    # (1) the reference's orchestration on the host, HIP behind it
+    want = _orchestrate(a, sw, dtm, smod, sdays, ndays_, reqhgt, lambda an: runmicro1Cpp(*[an[k] for k in ARGS]), S.gridmicrosnow1)
+    _close(got, want, 1e-12, "host-orchestrated HIP")
+    # (2) ... and with the oracle's solver and snow microclimate behind it
+    want_o = _orchestrate(a, sw, dtm, smod, sdays, ndays_, reqhgt, lambda an: oracle.run_grid(**{k: an[k] for k in ARGS}),
+                          oracle.run_microsnow)
+    _close(got, want_o, 1e-6, "oracle-backed orchestration")
+    # every class of cell-step is in the comparison: snow-covered, snow-free on a snow day, no-snow day
+    si = _steps(sdays)
+    covered = swe[:, :, si] > 0
+    assert covered.any() and (~covered & ~np.isnan(dtm)[:, :, None]).any()
+    if doy == 90:
+        assert np.setdiff1d(ndays_, sdays).size > 0 and np.setdiff1d(sdays, ndays_).size > 0       # days of one class only, both ways
+
+
+def test_row_blocks_and_host_threads(oracle):
+    reqhgt, cold, doy = 0.05, 0.0, 90
+    sw, a, dtm, snow, micro = _case(reqhgt, cold, doy, rows=320, cols=24, ndays=10)
+    one = S.runmicrosnow1(a, snow, micro, MAT)
+    same = S.runmicrosnow1(a, snow, micro, MAT, devices=[0], n_blocks=1)
+    for k in one:
+        assert np.array_equal(one[k], same[k], equal_nan=True), k            # one block: bit for bit
+    for devices, nb in (([0], 2), ([0, 0], 2)):                               # blocks > devices; two host threads on one device
+        multi, smod_m = S.runmicrosnow1(a, snow, micro, MAT, devices=devices, n_blocks=nb, want_smod=True)
+        _close(multi, one, 1e-9, f"{nb} blocks on {devices}")
+    smod_1 = S.snowmodel1_chunks(sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"], sw["other"], sw["snowenv"], dtm, 1.0, 0.02)
+    for k in smod_m:
+        w = smod_1[k]
+        assert np.array_equal(np.isnan(smod_m[k]), np.isnan(w)), k
+        assert np.nanmax(np.abs(smod_m[k] - w) / (1 + np.abs(w))) < 1e-9, k
+
+
+def test_a_year_without_snow_and_bad_arguments():
+    sw, a, dtm, snow, micro = _case(0.05, -25.0, 170, rows=10, cols=9, ndays=7)       # midsummer, 25 K warmer: no pack survives
+    snow["other"] = dict(snow["other"], isnowdc=np.zeros_like(dtm), isnowdg=np.zeros_like(dtm))
+    with S.SnowRun(a, snow) as run:
+        sd, nd = run.pass1()
+        assert not sd.any() and nd.all()
+        got = run.pass2(None, MAT)                     # no snow day: gridmicrosnow1's inputs are not needed
+    want = runmicro1Cpp(*[a[k] for k in ARGS])
+    for k in want:
+        assert np.array_equal(got[k], want[k], equal_nan=True), k     # the solver's own output (mxtc of all days = the series')
+    with pytest.raises(Exception, match="reqhgt < 0"):
+        S.runmicrosnow1(dict(a, reqhgt=-0.1), snow, micro, MAT)
+    with S.SnowRun(a, snow) as run:
+        with pytest.raises(Exception, match="pass1 first"):
+            run.pass2(micro, MAT)

@@ -26,5 +26,5 @@ cd $root/microclimf_amd/csrc
 for u in mcf_kernels mcf_api mcf_terrain mcf_snow; do
   if [ $u = $unit ]; then objs="$objs $out/$u.o"; else objs="$objs $u.o"; fi
 done
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $root/build/variants/libmcfhip_$name.so $objs mcf_pointmodel.o mcf_hydro.o -lz -ldl
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $root/build/variants/libmcfhip_$name.so $objs mcf_snowrun.o mcf_pointmodel.o mcf_hydro.o -lz -ldl
 echo build/variants/libmcfhip_$name.so

@@ -111,6 +111,14 @@ VARIANTS = {
     "setprio_lo": [(LOOP, '''    if ((tid >> 6) < 4) __builtin_amdgcn_s_setprio(1);     // VARIANT
     for (int dl = 0; dl < ndays; ++dl, ++run) {
         const int dabs = day0 + dl;''')],
+    # the ten stores as non-temporal stores
+    "store_nt": [(ST, '''                asm("" : "+v"(posb));
+                {   // VARIANT: nt
+                    double* const sb = (double*)((char*)ring_day + ((size_t)sel * (NT * 8)));
+                    asm volatile("global_store_dwordx2 %0, %1, %2 nt" :: "v"(posb), "v"(val), "s"(sb) : "memory");
+                }''')],
+    # what the output selector costs: every variable held, in order (sel = v known at compile time) — bench.py's mask
+    "allout": [("            const unsigned sel = (unsigned)(osel >> (4 * v)) & 15u;\n", "            const unsigned sel = (unsigned)v;     // VARIANT: all ten outputs, identity order\n")],
     # persistent workgroups (a fixed grid walking the tile sequence): measured a loss in rounds 2 and 3 (128 VGPRs, scratch)
     "persistent_loop": [('''    const int rot = (int)((blockIdx.x >> 8) & 1);
     const int64_t pos = tile_position(a.ntiles_launch);
