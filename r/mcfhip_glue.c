@@ -22,6 +22,7 @@
 #include <Rinternals.h>
 #include <R_ext/Rdynload.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <stddef.h>
@@ -55,13 +56,22 @@ static SEXP elt(SEXP list, const char *name, const char *alt) {
     return R_NilValue;
 }
 
+/* Entry points whose C structs outlive the .Call (mcfhip_snowrun_create: the library reads the caller's arrays until the run
+ * is destroyed) set g_keep to a list that then holds every vector a coercion below had to create. */
+static SEXP g_keep = NULL;
+static int g_nkeep = 0;
+static void keep(SEXP x) {
+    if (!g_keep) return;
+    if (g_nkeep >= LENGTH(g_keep)) Rf_error("mcfhip: too many coerced arguments to keep alive");
+    SET_VECTOR_ELT(g_keep, g_nkeep++, x);
+}
 /* numeric column/array as double*; *np counts PROTECTs added by coercion */
 static const double *dbl(SEXP x, int *np) {
-    if (TYPEOF(x) != REALSXP) { x = PROTECT(coerceVector(x, REALSXP)); ++*np; }
+    if (TYPEOF(x) != REALSXP) { x = PROTECT(coerceVector(x, REALSXP)); ++*np; keep(x); }
     return REAL(x);
 }
 static const int *intcol(SEXP x, int *np) {   /* obstime$year etc. arrive as doubles (int:1085) */
-    if (TYPEOF(x) != INTSXP) { x = PROTECT(coerceVector(x, INTSXP)); ++*np; }
+    if (TYPEOF(x) != INTSXP) { x = PROTECT(coerceVector(x, INTSXP)); ++*np; keep(x); }
     return INTEGER(x);
 }
 
@@ -470,43 +480,48 @@ SEXP mcfhip_applycpp3(SEXP a, SEXP fun_name) {
     UNPROTECT(np);
     return ans;
 }
-/* the `for (day in 1:n5days)` loop of .snowmodel1 (R/internal.R:2563-2617) in one call */
-SEXP mcfhip_snowmodel1(SEXP obstime, SEXP weather, SEXP pointm, SEXP vegp, SEXP other, SEXP snowenv, SEXP dtm,
-                       SEXP res, SEXP tfact) {
-    int np = 0;
-    mcf_snowdriver_in din;
-    memset(&din, 0, sizeof din);
-    mcf_snow_inputs *in = &din.base;
+static void fill_snowdriver(mcf_snowdriver_in *din, int *np, SEXP obstime, SEXP weather, SEXP pointm, SEXP vegp, SEXP other,
+                            SEXP snowenv, SEXP dtm, SEXP res, SEXP tfact) {
+    memset(din, 0, sizeof *din);
+    mcf_snow_inputs *in = &din->base;
     /* fill_snow() wants the terrain members the loop recomputes: take what the driver needs by hand */
     SEXP dim = getAttrib(elt(vegp, "pai", NULL), R_DimSymbol);
     if (TYPEOF(dim) != INTSXP || LENGTH(dim) != 2) Rf_error("mcfhip: vegp$pai must be a matrix");
     in->rows = INTEGER(dim)[0]; in->cols = INTEGER(dim)[1];
     in->tsteps = XLENGTH(elt(obstime, "year", NULL));
-    in->obstime.year = intcol(elt(obstime, "year", NULL), &np);
-    in->obstime.month = intcol(elt(obstime, "month", NULL), &np);
-    in->obstime.day = intcol(elt(obstime, "day", NULL), &np);
-    in->obstime.hour = dbl(elt(obstime, "hour", NULL), &np);
+    in->obstime.year = intcol(elt(obstime, "year", NULL), np);
+    in->obstime.month = intcol(elt(obstime, "month", NULL), np);
+    in->obstime.day = intcol(elt(obstime, "day", NULL), np);
+    in->obstime.hour = dbl(elt(obstime, "hour", NULL), np);
     static const char *cn[9] = {"temp", "relhum", "pres", "swdown", "difrad", "lwdown", "windspeed", "winddir",
                                 "precip"};
     const double **cp = (const double **)&in->clim;
-    for (int i = 0; i < 9; ++i) cp[i] = dbl(elt(weather, cn[i], NULL), &np);
+    for (int i = 0; i < 9; ++i) cp[i] = dbl(elt(weather, cn[i], NULL), np);
     static const char *pn[5] = {"Gp", "Tc", "RswabsG", "RlwabsG", "umu"};
     const double **pp = (const double **)&in->pointm;
-    for (int i = 0; i < 5; ++i) pp[i] = dbl(elt(pointm, pn[i], NULL), &np);
+    for (int i = 0; i < 5; ++i) pp[i] = dbl(elt(pointm, pn[i], NULL), np);
     static const char *vn[4] = {"pai", "hgt", "leaft", "clump"};
     const double **vp = (const double **)&in->vegp;
-    for (int i = 0; i < 4; ++i) vp[i] = dbl(elt(vegp, vn[i], NULL), &np);
+    for (int i = 0; i < 4; ++i) vp[i] = dbl(elt(vegp, vn[i], NULL), np);
     in->other.lat = asReal(elt(other, "lat", NULL));
     in->other.lon = asReal(elt(other, "lon", NULL));
     in->other.zref = asReal(elt(other, "zref", NULL));
-    in->other.isnowdc = dbl(elt(other, "isnowdc", NULL), &np);
-    in->other.isnowdg = dbl(elt(other, "isnowdg", NULL), &np);
-    in->other.isnowac = intcol(elt(other, "isnowac", NULL), &np);
-    in->other.isnowag = intcol(elt(other, "isnowag", NULL), &np);
+    in->other.isnowdc = dbl(elt(other, "isnowdc", NULL), np);
+    in->other.isnowdg = dbl(elt(other, "isnowdg", NULL), np);
+    in->other.isnowac = intcol(elt(other, "isnowac", NULL), np);
+    in->other.isnowag = intcol(elt(other, "isnowag", NULL), np);
     in->snowenv = mcf_snowenv_from_name(CHAR(asChar(snowenv)));
-    din.dtm = dbl(dtm, &np);
-    din.res = asReal(res);
-    din.tfact = asReal(tfact);
+    din->dtm = dbl(dtm, np);
+    din->res = asReal(res);
+    din->tfact = asReal(tfact);
+}
+/* the `for (day in 1:n5days)` loop of .snowmodel1 (R/internal.R:2563-2617) in one call */
+SEXP mcfhip_snowmodel1(SEXP obstime, SEXP weather, SEXP pointm, SEXP vegp, SEXP other, SEXP snowenv, SEXP dtm,
+                       SEXP res, SEXP tfact) {
+    int np = 0;
+    mcf_snowdriver_in din;
+    fill_snowdriver(&din, &np, obstime, weather, pointm, vegp, other, snowenv, dtm, res, tfact);
+    mcf_snow_inputs *in = &din.base;
     static const char *on[5] = {"Tc", "Tg", "groundsnowdepth", "totalSWE", "snowden"};
     mcf_snowdriver_out res5;
     double **rp = (double **)&res5;
@@ -537,6 +552,127 @@ SEXP mcfhip_snowmodel1(SEXP obstime, SEXP weather, SEXP pointm, SEXP vegp, SEXP 
     } else {
         rc = mcf_snowmodel1(&din, &res5, 0);
     }
+    if (rc != MCF_OK) raise_last(rc, np);
+    UNPROTECT(np);
+    return ans;
+}
+
+/* ---- runmicro(snow = TRUE) device-resident (include/mcf.h mcf_snowrun_*): `.snowmodel1`'s chunk loop + `.runmicrosnow1`
+ * (R/internal.R:2563-2617, 3581-3659) without the year's snow arrays in R.  Three calls (r/mcfhip_overrides.R):
+ *   h    <- .Call("mcfhip_snowrun_create", grid, snow)  grid: the fifteen arguments of runmicro1Cpp for the whole series, in order;
+ *                                                     snow: list(obstime, weather, pointm, vegp, other, snowenv, dtm, res, tfact)
+ *   days <- .Call("mcfhip_snowrun_pass1", h)            list(snowdays, nosnowdays): 1-based day numbers, as snowdaysfun's callers make
+ *   mout <- .Call("mcfhip_snowrun_pass2", h, obstime, weather, vegp, other, mat)   gridmicrosnow1's inputs for the WHOLE series
+ * The external pointer keeps every R vector the library reads alive and destroys the run when it is collected. */
+typedef struct snowrun_box {
+    mcf_snowrun *run;
+    mcf_grid_inputs grid;
+    mcf_options opt;
+    mcf_snowdriver_in snow;
+    mcf_microsnow_in in;
+} snowrun_box;
+static void snowrun_finalize(SEXP xp) {
+    snowrun_box *b = (snowrun_box *)R_ExternalPtrAddr(xp);
+    if (!b) return;
+    if (b->run) mcf_snowrun_destroy(b->run);
+    free(b);
+    R_ClearExternalPtr(xp);
+}
+SEXP mcfhip_snowrun_create(SEXP grid, SEXP snow) {
+    if (TYPEOF(grid) != VECSXP || LENGTH(grid) != 15) Rf_error("mcfhip: grid must be the list of runmicro1Cpp's fifteen arguments");
+    if (TYPEOF(snow) != VECSXP || LENGTH(snow) != 9) Rf_error("mcfhip: snow must be list(obstime, weather, pointm, vegp, other, snowenv, dtm, res, tfact)");
+    int np = 0;
+    snowrun_box *b = (snowrun_box *)calloc(1, sizeof *b);
+    if (!b) Rf_error("mcfhip: out of memory");
+    /* prot = list(grid, snow, coerced vectors): alive as long as the external pointer */
+    SEXP prot = PROTECT(allocVector(VECSXP, 3)); ++np;
+    SEXP keepl = PROTECT(allocVector(VECSXP, 128)); ++np;
+    SET_VECTOR_ELT(prot, 0, grid); SET_VECTOR_ELT(prot, 1, snow); SET_VECTOR_ELT(prot, 2, keepl);
+    SEXP xp = PROTECT(R_MakeExternalPtr(b, R_NilValue, prot)); ++np;
+    R_RegisterCFinalizerEx(xp, snowrun_finalize, TRUE);
+    g_keep = keepl; g_nkeep = 0;
+#define G(i) VECTOR_ELT(grid, i)
+    fill_inputs(&b->grid, &b->opt, &np, 0, R_NilValue, G(0), G(1), G(2), G(3), G(4), G(5), G(6), G(7), G(8), G(9), G(10), G(11), G(12),
+                G(13), G(14));
+#undef G
+#define S(i) VECTOR_ELT(snow, i)
+    fill_snowdriver(&b->snow, &np, S(0), S(1), S(2), S(3), S(4), S(5), S(6), S(7), S(8));
+#undef S
+    g_keep = NULL;
+    b->in.grid = &b->grid; b->in.snow = &b->snow; b->in.micro = NULL; b->in.mat = 0.0;
+    SEXP dv = GetOption1(install("mcfhip.devices"));
+    int rc;
+    if (dv != R_NilValue && LENGTH(dv) > 0) {
+        SEXP dvi = PROTECT(coerceVector(dv, INTSXP)); ++np;
+        SEXP nbo = GetOption1(install("mcfhip.blocks"));
+        mcf_multi mu;
+        mu.n_devices = LENGTH(dvi);
+        mu.devices = INTEGER(dvi);
+        mu.n_blocks = nbo == R_NilValue ? 0 : asInteger(nbo);
+        rc = mcf_snowrun_create(&b->in, &b->opt, &mu, &b->run);
+    } else {
+        rc = mcf_snowrun_create(&b->in, &b->opt, NULL, &b->run);
+    }
+    if (rc != MCF_OK) raise_last(rc, np);      /* (the finalizer frees the box) */
+    UNPROTECT(np);
+    return xp;
+}
+static snowrun_box *snowrun_of(SEXP h) {
+    if (TYPEOF(h) != EXTPTRSXP || !R_ExternalPtrAddr(h)) Rf_error("mcfhip: not a live snow run");
+    return (snowrun_box *)R_ExternalPtrAddr(h);
+}
+SEXP mcfhip_snowrun_pass1(SEXP h) {
+    snowrun_box *b = snowrun_of(h);
+    const int nd = mcf_snowrun_days(b->run);
+    int np = 0;
+    SEXP sf = PROTECT(allocVector(INTSXP, nd)); ++np;
+    SEXP nf = PROTECT(allocVector(INTSXP, nd)); ++np;
+    const int rc = mcf_snowrun_pass1(b->run, NULL, INTEGER(sf), INTEGER(nf));
+    if (rc != MCF_OK) raise_last(rc, np);
+    int ns = 0, nn = 0;
+    for (int d = 0; d < nd; ++d) { ns += INTEGER(sf)[d] != 0; nn += INTEGER(nf)[d] != 0; }
+    SEXP sd = PROTECT(allocVector(INTSXP, ns)); ++np;
+    SEXP nsd = PROTECT(allocVector(INTSXP, nn)); ++np;
+    for (int d = 0, i = 0, j = 0; d < nd; ++d) {
+        if (INTEGER(sf)[d]) INTEGER(sd)[i++] = d + 1;
+        if (INTEGER(nf)[d]) INTEGER(nsd)[j++] = d + 1;
+    }
+    SEXP ans = PROTECT(allocVector(VECSXP, 2)); ++np;
+    SEXP nms = PROTECT(allocVector(STRSXP, 2)); ++np;
+    SET_VECTOR_ELT(ans, 0, sd); SET_VECTOR_ELT(ans, 1, nsd);
+    SET_STRING_ELT(nms, 0, mkChar("snowdays")); SET_STRING_ELT(nms, 1, mkChar("nosnowdays"));
+    setAttrib(ans, R_NamesSymbol, nms);
+    UNPROTECT(np);
+    return ans;
+}
+SEXP mcfhip_snowrun_pass2(SEXP h, SEXP obstime, SEXP weather, SEXP vegp, SEXP other, SEXP mat) {
+    snowrun_box *b = snowrun_of(h);
+    int np = 0;
+    mcf_snow_inputs micro;
+    const int have = obstime != R_NilValue;      /* NULL inputs: a year without a snow day */
+    if (have) fill_snow(&micro, &np, 0, 1, obstime, weather, R_NilValue, vegp, other);
+    static const char *on[MCF_NOUT] = {"Tz", "tleaf", "relhum", "soilm", "windspeed", "Rdirdown", "Rdifdown",
+                                       "Rlwdown", "Rswup", "Rlwup"};
+    mcf_outputs res;
+    memset(&res, 0, sizeof res);
+    int nreq = 0;
+    for (int v = 0; v < MCF_NOUT; ++v) nreq += b->opt.out[v];
+    SEXP ans = PROTECT(allocVector(VECSXP, nreq)); ++np;
+    SEXP nms = PROTECT(allocVector(STRSXP, nreq)); ++np;
+    const R_xlen_t n = (R_xlen_t)b->grid.rows * b->grid.cols * b->grid.tsteps;
+    for (int v = 0, k = 0; v < MCF_NOUT; ++v) {
+        if (!b->opt.out[v]) continue;
+        SEXP a = PROTECT(allocVector(REALSXP, n)); ++np;
+        SEXP d = PROTECT(allocVector(INTSXP, 3)); ++np;
+        INTEGER(d)[0] = (int)b->grid.rows; INTEGER(d)[1] = (int)b->grid.cols; INTEGER(d)[2] = (int)b->grid.tsteps;
+        setAttrib(a, R_DimSymbol, d);
+        SET_VECTOR_ELT(ans, k, a);
+        SET_STRING_ELT(nms, k, mkChar(on[v]));
+        res.var[v] = REAL(a);
+        ++k;
+    }
+    setAttrib(ans, R_NamesSymbol, nms);
+    const int rc = mcf_snowrun_pass2(b->run, have ? &micro : NULL, asReal(mat), &res);
     if (rc != MCF_OK) raise_last(rc, np);
     UNPROTECT(np);
     return ans;
@@ -605,6 +741,9 @@ static const R_CallMethodDef CallEntries[] = {
     {"mcfhip_gridmicrosnow2", (DL_FUNC)&mcfhip_gridmicrosnow2, 9},
     {"mcfhip_applycpp3", (DL_FUNC)&mcfhip_applycpp3, 2},
     {"mcfhip_snowmodel1", (DL_FUNC)&mcfhip_snowmodel1, 9},
+    {"mcfhip_snowrun_create", (DL_FUNC)&mcfhip_snowrun_create, 2},
+    {"mcfhip_snowrun_pass1", (DL_FUNC)&mcfhip_snowrun_pass1, 1},
+    {"mcfhip_snowrun_pass2", (DL_FUNC)&mcfhip_snowrun_pass2, 6},
     {"mcfhip_writetonc", (DL_FUNC)&mcfhip_writetonc, 9},
     {NULL, NULL, 0}};
 

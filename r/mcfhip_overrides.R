@@ -14,8 +14,11 @@
 # `devices`: HIP device ordinals (0-based) the grid solver may use from this one R session, e.g. 0:7 on an 8-GPU node — the
 # raster is dealt to them in row blocks inside libmcfhip (mcf_runmicro1_multi), results bit for bit those of one device;
 # `blocks`: more row blocks than devices (each device solves its blocks one after the other: smaller HBM footprint per block).
-mcfhip_enable <- function(glue = "r/mcfhip_glue.so", devices = NULL, blocks = NULL) {
+# `snow_resident = TRUE`: runsnowmodel() + runmicro(snow = TRUE) for data.frame weather keep the year's snow series on the
+# device (see mcfhip_snow_resident below); FALSE (default): the reference's own R drivers over the replaced bindings.
+mcfhip_enable <- function(glue = "r/mcfhip_glue.so", devices = NULL, blocks = NULL, snow_resident = FALSE) {
   dyn.load(glue)
+  if (snow_resident) mcfhip_snow_resident()
   options(mcfhip.devices = if (is.null(devices)) NULL else as.integer(devices),
           mcfhip.blocks = if (is.null(blocks)) NULL else as.integer(blocks))
   rm1 <- function(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, long,
@@ -77,5 +80,77 @@ mcfhip_enable <- function(glue = "r/mcfhip_glue.so", devices = NULL, blocks = NU
   utils::assignInNamespace("runmicro2Cpp", rm2, ns = "microclimf")
   utils::assignInNamespace("runmicro3Cpp", rm3, ns = "microclimf")
   utils::assignInNamespace("runmicro4Cpp", rm4, ns = "microclimf")
+  invisible(TRUE)
+}
+
+
+# ---- runmicro(snow = TRUE) with the snow series kept on the device (include/mcf.h mcf_snowrun_*) --------------------------
+# The reference hands five [rows, cols, hours] arrays from runsnowmodel() to runmicro(snow = TRUE, snowmod = ) through R.
+# With these two bindings the chunk loop of `.snowmodel1` (R/internal.R:2563-2617) and `.runmicrosnow1`'s two models and merge
+# (R/internal.R:3581-3659) run inside libmcfhip instead, chunk by chunk on the device, and only the merged microclimate
+# comes back.  No line of the reference's R preparation is restated here: its own functions run up to the point where they
+# would enter compiled code, and a recording stand-in for that entry point takes what they prepared.
+#   .snowmodel1    runs as written up to its first gridmodelsnow1 call (weather height adjustment, pointmodelsnow, `.sortl`,
+#                  initial depths and ages), then returns a light "mcfhip_smod": the loop's arguments + umu, no arrays
+#   .runmicrosnow1 given a "mcfhip_smod": the solver's fifteen arguments for the WHOLE series through `.runmicronosnow`'s own
+#                  marshalling (recorded at runmicro1Cpp), the run's first pass -> snow days / no-snow days, gridmicrosnow1's
+#                  inputs through `.prepsnowinputs1` (every day handed over, the true snow-day steps for `.sortl2`), second pass.
+#                  Anything else (arrays from the reference's runsnowmodel, reqhgt < 0) goes to the reference's function.
+# NOT run in the build image (no R there): tests/test_r_glue_syntax_cpu.py checks the .Call names and arities only.
+mcfhip_snow_resident <- function() {
+  ns <- asNamespace("microclimf")
+  captured <- function() structure(class = c("mcfhip_captured", "error", "condition"), list(message = "mcfhip: captured", call = NULL))
+  with_binding <- function(name, fun, expr) {
+    old <- get(name, envir = ns)
+    utils::assignInNamespace(name, fun, ns = "microclimf")
+    on.exit(utils::assignInNamespace(name, old, ns = "microclimf"))
+    tryCatch(expr, mcfhip_captured = function(e) NULL)
+  }
+  sm1_ref <- get(".snowmodel1", envir = ns)
+  rms1_ref <- get(".runmicrosnow1", envir = ns)
+  sm1 <- function(weather, dtm, vegp, soilc, snowenv = "Taiga", snowinitd = 0, snowinita = 0, zref = 2, windhgt = zref, tfact = 0.02) {
+    cap <- new.env()
+    pms <- get("pointmodelsnow", envir = ns)
+    with_binding("pointmodelsnow", function(obstime, weather, vegp, other, snowenv) {
+      r <- pms(obstime, weather, vegp, other, snowenv)
+      cap$obstime <- obstime; cap$weather <- weather; cap$pmod <- r
+      r
+    }, with_binding("gridmodelsnow1", function(obstime, climdata, pointm, vegp, other, snowenv) {
+      cap$vegp <- vegp; cap$other <- other; cap$snowenv <- snowenv
+      stop(captured())
+    }, sm1_ref(weather, dtm, vegp, soilc, snowenv, snowinitd, snowinita, zref, windhgt, tfact)))
+    pm <- cap$pmod
+    pointm <- data.frame(Gp = pm$G, Tc = pm$Tc, RswabsG = pm$RswabsG, RlwabsG = pm$RlwabsG, umu = pm$umu)
+    if (class(dtm)[1] == "PackedSpatRaster") dtm <- terra::rast(dtm)
+    structure(list(args = list(cap$obstime, cap$weather, pointm, cap$vegp, cap$other, cap$snowenv,
+                               get(".is", envir = ns)(dtm), terra::res(dtm)[1], tfact), umu = pm$umu),
+              class = "mcfhip_smod")
+  }
+  rms1 <- function(micropoint, reqhgt, vegp, soilc, dtm, smod, runchecks = TRUE, pai_a = NA, tfact = 1.5,
+                   out = rep(TRUE, 10), slr = NA, apr = NA, hor = NA, twi = NA, wsa = NA, svf = NA) {
+    if (!inherits(smod, "mcfhip_smod") || reqhgt < 0)
+      return(rms1_ref(micropoint, reqhgt, vegp, soilc, dtm, smod, runchecks, pai_a, tfact, out, slr, apr, hor, twi, wsa, svf))
+    if (class(dtm)[1] == "PackedSpatRaster") dtm <- terra::rast(dtm)
+    grid <- NULL
+    with_binding("runmicro1Cpp", function(...) { grid <<- list(...); stop(captured()) },
+                 get(".runmicronosnow", envir = ns)(micropoint, reqhgt, vegp, soilc, dtm, dtmc = NA, altcorrect = 0, runchecks,
+                                                    pai_a, tfact, out, slr, apr, hor, twi, wsa, svf))
+    h <- .Call("mcfhip_snowrun_create", grid, smod$args)
+    days <- .Call("mcfhip_snowrun_pass1", h)
+    mi <- list(NULL, NULL, NULL, NULL)
+    if (length(days$snowdays) > 0) {
+      mps <- microclimf::subsetpointmodel(micropoint, days = days$snowdays)
+      mpa <- micropoint
+      mpa$subs <- mps$subs
+      alld <- seq_len(length(smod$umu) %/% 24)
+      blank <- list(Tz = array(NA_real_, dim = c(dim(dtm)[1:2], 0)))
+      pin <- get(".prepsnowinputs1", envir = ns)(reqhgt, dtm, vegp, soilc, mpa, alld, integer(0), list(umu = smod$umu), blank,
+                                                 micropoint$tmeorig, mps$subs, runchecks, slr, apr, hor, svf, wsa, pai_a)
+      mi <- list(pin$obstime, pin$weather, pin$vegp, pin$other)
+    }
+    .Call("mcfhip_snowrun_pass2", h, mi[[1]], mi[[2]], mi[[3]], mi[[4]], micropoint$matemp)
+  }
+  utils::assignInNamespace(".snowmodel1", sm1, ns = "microclimf")
+  utils::assignInNamespace(".runmicrosnow1", rms1, ns = "microclimf")
   invisible(TRUE)
 }

@@ -12,6 +12,7 @@ typedef unsigned int SEXPTYPE;
 #define REALSXP 14
 #define STRSXP 16
 #define VECSXP 19
+#define EXTPTRSXP 22
 extern SEXP R_NilValue, R_NamesSymbol, R_DimSymbol;
 extern double R_NaReal;
 extern int R_NaInt;
@@ -49,6 +50,12 @@ SEXP Rf_ScalarReal(double);
 SEXP Rf_ScalarInteger(int);
 SEXP Rf_allocMatrix(SEXPTYPE, int, int);
 SEXP Rf_asChar(SEXP);
+/* external pointers (Writing R Extensions 5.13) */
+typedef void (*R_CFinalizer_t)(SEXP);
+SEXP R_MakeExternalPtr(void *p, SEXP tag, SEXP prot);
+void *R_ExternalPtrAddr(SEXP s);
+void R_ClearExternalPtr(SEXP s);
+void R_RegisterCFinalizerEx(SEXP s, R_CFinalizer_t fun, Rboolean onexit);
 #define PROTECT(s) Rf_protect(s)
 #define UNPROTECT(n) Rf_unprotect(n)
 #define allocVector Rf_allocVector
