@@ -277,10 +277,13 @@ def timed_year(plan, ndays, ring_days, ring_slots, steps, warmup, clock):
     return dt, kms, klaunches, resident
 
 
-def verify_sample(plan, a, resident, twi_mean, ncells, seed=7):
+def verify_sample(plan, a, resident, twi_mean, ncells, seed=7, af=False, cpos=None):
     """Outside the timed region: fetches `ncells` cells x every day still resident in the ring (what the LAST timed pass
     left there) and compares all ten outputs with the CPU oracle run on exactly those cells (same forcing, the raster's
-    twi mean installed).  The oracle is the checker here, never the thing timed."""
+    twi mean installed).  The oracle is the checker here, never the thing timed.
+    af: array forcing — the cells' own forcing columns go to the runmicro2Cpp oracle.  cpos (coarse array forcing): the
+    sample is a sub-grid of raster rows x columns, for which `.runmodel2Cpp`'s resampling is restated with numpy
+    (oracle/coarse_oracle.py) before the same oracle."""
     import ctypes as C
     from oracle import oracle as O
     hgt = a["vegp"]["hgt"]
@@ -288,31 +291,50 @@ def verify_sample(plan, a, resident, twi_mean, ncells, seed=7):
     N = rows * cols
     rng = np.random.default_rng(seed)
     flat_h = hgt.reshape(-1, order="F")
-    pick = set(int(v) for v in rng.choice(N, size=min(ncells, N), replace=False))
-    # make sure the three cell classes are in the sample: NA cells, bare ground, vegetated
-    for mask in (np.isnan(flat_h), flat_h == 0.0):
-        idx = np.flatnonzero(mask)
-        for v in idx[:4]:
-            pick.add(int(v))
-    cells = np.array(sorted(pick), dtype=np.int64)
+    sub = dict(a)
+    if cpos is not None:
+        from oracle import coarse_oracle as CO
+        k = max(2, int(round(ncells ** 0.5)))
+        ri = np.sort(rng.choice(rows, size=min(k, rows), replace=False))
+        ci = np.sort(rng.choice(cols, size=min(k, cols), replace=False))
+        cells = (ri[:, None] + rows * ci[None, :]).reshape(-1, order="F").astype(np.int64)
+        grid = lambda m: np.asfortranarray(np.asarray(m)[np.ix_(ri, ci)])                   # noqa: E731
+        sub["vegp"] = {kk: grid(v) for kk, v in a["vegp"].items()}
+        sub["soilc"] = {kk: grid(v) for kk, v in a["soilc"].items()}
+        sub["climdata"], sub["pointm"] = CO.expand(a["climdata"], a["pointm"], np.asarray(cpos["rowpos"])[ri], np.asarray(cpos["colpos"])[ci])
+        sub["lat"], sub["lon"] = grid(a["lat"]), grid(a["lon"])
+    else:
+        pick = set(int(v) for v in rng.choice(N, size=min(ncells, N), replace=False))
+        # make sure the three cell classes are in the sample: NA cells, bare ground, vegetated
+        for mask in (np.isnan(flat_h), flat_h == 0.0):
+            idx = np.flatnonzero(mask)
+            for v in idx[:4]:
+                pick.add(int(v))
+        cells = np.array(sorted(pick), dtype=np.int64)
     n = cells.size
 
     def take(m):
         m = np.asarray(m)
+        if m.ndim < 2:
+            return m
         if m.ndim == 2:
             return np.asfortranarray(m.reshape(-1, order="F")[cells].reshape(n, 1))
         d = m.shape[2]
         return np.asfortranarray(m.reshape(N, d, order="F")[cells].reshape(n, 1, d))
 
-    sub = dict(a)
-    sub["vegp"] = {k: take(v) for k, v in a["vegp"].items()}
-    sub["soilc"] = {k: take(v) for k, v in a["soilc"].items()}
+    if cpos is None:
+        sub["vegp"] = {k: take(v) for k, v in a["vegp"].items()}
+        sub["soilc"] = {k: take(v) for k, v in a["soilc"].items()}
+        if af:
+            sub["climdata"] = {k: take(v) for k, v in a["climdata"].items()}
+            sub["pointm"] = {k: take(v) for k, v in a["pointm"].items()}
+            sub["lat"], sub["lon"] = take(a["lat"]), take(a["lon"])
     lib = O.load()
     lib.orc_set_twi_mean_override.argtypes = [C.c_double, C.c_int]
     lib.orc_set_twi_mean_override(float(twi_mean), 1)
     t0 = time.perf_counter()
     try:
-        want = O.run_grid(**sub)
+        want = O.run_grid(**sub, array_forcing=bool(af or cpos is not None))
     finally:
         lib.orc_set_twi_mean_override(0.0, 0)
     t_or = time.perf_counter() - t0
@@ -321,7 +343,7 @@ def verify_sample(plan, a, resident, twi_mean, ncells, seed=7):
     for (slot, off), day in sorted(resident.items()):
         for var, w in want.items():
             got = plan.fetch_cells(slot, var, off * 24, 24, cells)
-            ref = w[:, 0, day * 24:(day + 1) * 24]
+            ref = w.reshape(n, w.shape[2], order="F")[:, day * 24:(day + 1) * 24]
             if not np.array_equal(np.isnan(got), np.isnan(ref)):
                 nan_ok = False
             fin = np.isfinite(ref) & np.isfinite(got)
@@ -335,7 +357,44 @@ def verify_sample(plan, a, resident, twi_mean, ncells, seed=7):
             "max_scaled_err": worst, "worst_var": worst_var, "na_pattern_equal": bool(nan_ok), "tolerance": tol,
             "ok": bool(nan_ok and worst <= tol),
             "how": "mcf_plan_fetch_cells on the ring as the last timed pass left it vs oracle/mcf_oracle.c on the same "
-                   f"cells over the whole series ({t_or:.1f} s), |HIP - oracle| / (1 + |oracle|)"}
+                   f"cells over the whole series ({t_or:.1f} s), |HIP - oracle| / (1 + |oracle|)"
+                   + ("; the coarse fields resampled for the sample by oracle/coarse_oracle.py" if cpos is not None else "")}
+
+
+def committed_summary(mode, rows, cols, ring_days):
+    """PMC summary of the array-forcing ('af') / coarse ('coarse') solver from profiles/*_<mode>_pmc_summary.json: the newest
+    one whose kernel hash is that of the sources being run (tools/profile_round.sh <tag>_<mode> --config 1 ...)."""
+    best, note = None, f"no profiles/*_{mode}_pmc_summary.json for {rows}x{cols} with {ring_days}-day launches"
+    for pf in sorted((ROOT / "profiles").glob(f"*_{mode}_pmc_summary.json")):
+        try:
+            pj = json.loads(pf.read_text())
+        except Exception:
+            continue
+        if (pj.get("rows"), pj.get("cols"), pj.get("ring_days")) != (rows, cols, ring_days):
+            continue
+        if pj.get("kernel_hash") != kernel_hash():
+            note = f"stale: {pf.name} was taken from kernel sources {pj.get('kernel_hash')}, this run is {kernel_hash()}"
+            continue
+        best, note = (pf, pj), None
+    return best, note
+
+
+def valu_block(pj, rate_per_gpu, source, khash):
+    """Issue accounting from a PMC summary.  SQ_ACTIVE_INST_VALU counts one unit per VALU wave-instruction and four per
+    v_rcp_f64 / v_rsq_f64 (profiles/r04_microbench_waves_pmc.txt): `issue_slots`.  A slot costs 4.16 cycles of a SIMD with
+    four resident waves issuing nothing but fp64 (4.38 from the waves' own clocks; 32-bit VOP1 / VOP2 cost 2.2-2.4 alone
+    but only v_mov_b32 keeps that price beside fp64 work): the issue peak is 1024 SIMDs x clock / 4.16 slots per second."""
+    m = pj.get("per_launch_mean", {})
+    if "SQ_INSTS_VALU" not in m:
+        return None
+    cs = pj["cell_steps_per_launch"]
+    per_cs = m["SQ_INSTS_VALU"] * 64.0 / cs
+    slots = m.get("SQ_ACTIVE_INST_VALU", m["SQ_INSTS_VALU"]) * 64.0 / cs
+    clock = float(pj.get("clock_ghz") or 2.4)
+    return {"insts_per_cell_step": per_cs, "issue_slots_per_cell_step": slots,
+            "frac_of_issue_peak": slots * rate_per_gpu / 64.0 / (1024 * clock * 1e9 / 4.16),
+            "cycles_per_slot": 4.16, "clock_ghz_measured": clock, "busy_fraction_measured": pj.get("valu_busy_fraction"),
+            "source": source, "kernel_hash": khash}
 
 
 def roofline_block(valid, T, steps_per_launch, avg_ms, klaunches, af, rows, cols, ring_days, rate_per_gpu, coarse):
@@ -351,14 +410,14 @@ def roofline_block(valid, T, steps_per_launch, avg_ms, klaunches, af, rows, cols
         e, pj, note = committed_counters(rows, cols, ring_days)
         if e is not None:
             traffic = e.get("hbm_bytes_per_launch")
-            if pj is not None and "SQ_INSTS_VALU" in pj.get("per_launch_mean", {}):
-                per_cs = pj["per_launch_mean"]["SQ_INSTS_VALU"] * 64.0 / pj["cell_steps_per_launch"]
-                clock = float(pj.get("clock_ghz") or 2.4)
-                valu = {"insts_per_cell_step": per_cs,
-                        # one wave-instruction per 4 cycles per SIMD, 1024 SIMDs, at the clock MEASURED under this load
-                        "frac_of_issue_peak": per_cs * rate_per_gpu / 64.0 / (1024 * clock * 1e9 / 4),
-                        "clock_ghz_measured": clock, "busy_fraction_measured": pj.get("valu_busy_fraction"),
-                        "source": f"profiles/{e.get('tag')}_pmc_summary.json", "kernel_hash": e.get("kernel_hash")}
+            if pj is not None:
+                valu = valu_block(pj, rate_per_gpu, f"profiles/{e.get('tag')}_pmc_summary.json", e.get("kernel_hash"))
+    else:
+        best, note = committed_summary("af" if af else "coarse", rows, cols, ring_days)
+        if best is not None:
+            pf, pj = best
+            traffic = (pj.get("hbm_bytes_per_launch") or {}).get("total")
+            valu = valu_block(pj, rate_per_gpu, f"profiles/{pf.name}", pj.get("kernel_hash"))
     rb = {"bound": "fp64_valu", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
           "frac_is": "achieved algorithmic HBM bytes / 8 TB/s (the metric BASELINE.json names); the binding roof is "
                      "fp64 VALU issue at a power-limited clock, see `valu`: with the output stream beside it the shader clock "
@@ -478,8 +537,8 @@ def measure(args, torch, dist, use_dist, rank, world, local_rank, *, rows, cols,
         res = {"dt": dt, "kms": kms, "klaunches": klaunches, "valid": valid, "valid_all": valid_all, "ndays": ndays, "T": T,
                "terrain_s": terrain_s, "setup_s": setup_s, "value": valid_all * ndays * 24 * steps / dt, "verified": None,
                "plan_bytes": plan.device_bytes, "dispatch": plan.dispatch_stats()}
-        if verify and rank == 0 and not af and not coarse:
-            res["verified"] = verify_sample(plan, a, resident, twi_mean, args.verify_cells)
+        if verify and rank == 0:
+            res["verified"] = verify_sample(plan, a, resident, twi_mean, args.verify_cells, af=af, cpos=cpos)
     finally:
         plan.close()
     return res
@@ -502,7 +561,7 @@ def secondary_block(args, torch, dist, local_rank):
             slots, days = j["ring"]
             r = measure(sub, torch, dist, False, 0, 1, local_rank, rows=j["rows"], cols=j["cols"], row0=0, rows_total=j["rows"],
                         T=8760, af=j["af"], coarse=j["coarse"], steps=j["steps"], warmup=1, ring_slots=slots, ring_days=days,
-                        exchange_ok=True, verify=(name == "configs[1]" and not args.no_verify))
+                        exchange_ok=True, verify=not args.no_verify)
             steps_per_launch = (r["ndays"] * 24 * j["steps"]) / max(r["klaunches"], 1)
             avg_ms = r["kms"] / max(r["klaunches"], 1)
             rb = roofline_block(r["valid"], r["T"], steps_per_launch, avg_ms, r["klaunches"], j["af"], j["rows"], j["cols"], days,
@@ -516,6 +575,8 @@ def secondary_block(args, torch, dist, local_rank):
                          "bytes_per_cell_step": 208.0 if j["af"] else 80.0 + 440.0 / r["T"]}
             if rb.get("valu"):
                 out[name]["valu"] = rb["valu"]
+            elif rb.get("counters"):
+                out[name]["counters"] = rb["counters"]
             if r["verified"]:
                 out[name]["verified"] = r["verified"]
         except Exception as e:    # a secondary figure never takes the primary line down

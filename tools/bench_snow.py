@@ -123,7 +123,8 @@ def run_snow_config(args, world, rank, local_rank):
     plan = Plan(**a, ring_days=chunk_days, ring_slots=2, device=local_rank)
     halo = DeviceHalo(sp, rank, world) if exchange_ok and world > 1 else None
     s, n = plan.twi_partial()
-    plan.set_twi_mean(allreduce_twi_mean(s, float(n)))
+    twi_mean = allreduce_twi_mean(s, float(n))
+    plan.set_twi_mean(twi_mean)
     valid = plan.valid_cells
     stats = {"solver_days": 0, "snow_days": 0, "years": 0}
 
@@ -170,7 +171,10 @@ def run_snow_config(args, world, rank, local_rank):
     outm = [1] * 10 if args.reqhgt > 0 else [1 if i in (0, 3, 5, 6, 7, 8, 9) else 0 for i in range(10)]
     ncd = sp.chunks * chunk_days
 
-    def one_year():
+    def one_year(probe=None):
+        """probe (the untimed verification year): {"cells": ...} — the sample cells' five snow series are read back behind
+        every chunk of pass 1 and their ten merged outputs behind every chunk of pass 2 (nothing is kept in HBM then: the
+        read-back sees the plan's working buffers)"""
         # ---- pass 1: snow series chunk by chunk -> day classes, running sum of the snow damping depth
         snowday, nosnowday = np.zeros(ncd, np.int32), np.zeros(ncd, np.int32)
         sp.release_kept()
@@ -186,7 +190,10 @@ def run_snow_config(args, world, rank, local_rank):
             snowday[d0:d0 + chunk_days], nosnowday[d0:d0 + chunk_days] = days["snowdays"], days["nosnowdays"]
             tl = lap("apply3", tl)
             sp.meand_accumulate(ch, days["snowdays"])
-            if days["snowdays"].any():                          # its five series stay in HBM for pass 2 while room remains
+            if probe is not None:
+                for name in probe["smod"]:
+                    probe["smod"][name][:, ch * 120:(ch + 1) * 120] = sp.fetch_cells(name, probe["cells"])
+            elif days["snowdays"].any():                        # its five series stay in HBM for pass 2 while room remains
                 kept[ch] = sp.keep_chunk(ch, reserve_bytes=keep_reserve)
             tl = lap("meanD", tl)
         # ---- between: gridmicrosnow1's set-up on the snow-day subset, the solver's maximum temperature on the no-snow subset
@@ -234,7 +241,12 @@ def run_snow_config(args, world, rank, local_rank):
             if sdays.size and has_snow:
                 sp.microsnow(plan, ch, slot, nos)
             tl = lap("microsnow", tl)
+            if probe is not None:
+                for name in probe["out"]:
+                    probe["out"][name][:, ch * 120:(ch + 1) * 120] = plan.fetch_cells(slot, name, 0, 120, probe["cells"])
             slot = (slot + 1) % 2
+        if probe is not None:
+            probe["snowday"], probe["nosnowday"] = snowday.copy(), nosnowday.copy()
         return snowday
 
     def verify_sample(snowday, ncells=256):
@@ -293,6 +305,109 @@ def run_snow_config(args, world, rank, local_rank):
                         "held against the oracle by tests/test_snow_gpu.py, test_terrain_gpu.py and test_snow_micro_pipeline_gpu.py "
                         "on small rasters", "mismatches": bad or None}
 
+    def verify_merged(ncells=256):
+        """What the line's cell-steps count, against the oracle: one more (untimed) year with a probe on a sample of cells —
+        their five snow series out of pass 1 and their ten MERGED outputs out of the ring slot behind every chunk of pass 2
+        — and, on the host, `.runmicrosnow1`'s orchestration (R/internal.R:3581-3659) with the oracle behind it on exactly
+        those cells: oracle/mcf_oracle.c on the no-snow-day subset, oracle/snow_oracle.c (gridmicrosnow1) on the snow-day
+        subset given the device's snow series, merged by day.  Every rank runs the year (its exchanges are collective);
+        rank 0 compares its own block."""
+        import ctypes as C
+        from microclimf_amd.snow import merge_snow_outputs
+        hg = np.asarray(sw["vegp"]["hgt"]).ravel(order="F")
+        ok_cells = np.flatnonzero(~np.isnan(hg))
+        na_cells = np.flatnonzero(np.isnan(hg))[:4]
+        cells = np.unique(np.concatenate([ok_cells[np.linspace(0, ok_cells.size - 1, min(ncells, ok_cells.size)).astype(np.int64)],
+                                          na_cells])).astype(np.int64)
+        K, TT = cells.size, sp.chunks * 120
+        names = [n for i, n in enumerate(("Tz", "tleaf", "relhum", "soilm", "windspeed", "Rdirdown", "Rdifdown", "Rlwdown", "Rswup",
+                                          "Rlwup")) if a["out"][i]]
+        probe = {"cells": cells, "smod": {k: np.full((K, TT), np.nan) for k in ("Tc", "Tg", "groundsnowdepth", "snowden", "totalSWE")},
+                 "out": {k: np.full((K, TT), np.nan) for k in names}}
+        one_year(probe)
+        if rank != 0:
+            return None
+        from oracle import oracle as O
+        lib = O.load()
+        snowday, nosnowday = probe["snowday"][:ndays], probe["nosnowday"][:ndays]
+        nd_cov = min(ndays, sp.chunks * chunk_days)              # days past the last whole chunk are the solver's alone: not probed
+        sdays = np.flatnonzero(snowday[:nd_cov])
+        ndays_ = np.flatnonzero(nosnowday[:nd_cov])
+        neither = np.flatnonzero((snowday[:nd_cov] == 0) & (nosnowday[:nd_cov] == 0))
+        col = lambda m: np.asfortranarray(np.asarray(m, dtype=np.float64).reshape(-1, order="F")[cells].reshape(K, 1))      # noqa: E731
+        col3 = lambda m: np.asfortranarray(np.asarray(m).reshape(rows * cols, -1, order="F")[cells].reshape(K, 1, -1))    # noqa: E731
+        sub = lambda d, idx: {k: (np.asarray(v)[idx] if np.ndim(v) == 1 else v) for k, v in d.items()}                       # noqa: E731
+        # ---- the no-snow solver on the no-snow-day subset (its temperature cap takes the SUBSET's maximum, cpp:2159-2168)
+        ni_all = steps_of(np.flatnonzero(nosnowday[:ndays]))
+        an = dict(a, obstime=sub(a["obstime"], ni_all), climdata=sub(a["climdata"], ni_all), pointm=sub(a["pointm"], ni_all))
+        an["vegp"] = {k: col(v) for k, v in a["vegp"].items()}
+        an["soilc"] = {k: (col3(v) if np.ndim(v) == 3 else col(v)) for k, v in a["soilc"].items()}
+        lib.orc_set_twi_mean_override.argtypes = [C.c_double, C.c_int]
+        lib.orc_set_twi_mean_override(float(twi_mean), 1)
+        t0 = time.perf_counter()
+        try:
+            moutn = O.run_grid(**an)
+        finally:
+            lib.orc_set_twi_mean_override(0.0, 0)
+        keepn = np.repeat(np.flatnonzero(nosnowday[:ndays]) < nd_cov, 24)
+        moutn = {k: np.asfortranarray(v[:, :, keepn]) for k, v in moutn.items()}
+        # ---- gridmicrosnow1 on the snow-day subset, the device's snow series behind it
+        si, ni = steps_of(sdays), steps_of(ndays_)
+        micro = {}
+        s1 = np.arange(si.size)[np.repeat(np.isin(sdays, ndays_), 24)]
+        s2 = np.arange(ni.size)[np.repeat(np.isin(ndays_, sdays), 24)]
+        for k, v in moutn.items():
+            m = np.full((K, 1, si.size), np.nan, order="F")
+            m[:, :, s1] = v[:, :, s2]
+            micro[k] = m
+        swe = probe["smod"]["totalSWE"].copy()
+        swe[np.isnan(swe)] = 0.0
+        swe[np.isnan(hg[cells])] = np.nan
+        smods = {k: np.asfortranarray((swe if k == "totalSWE" else v)[:, si].reshape(K, 1, si.size)) for k, v in probe["smod"].items()}
+        vg = {k: col(v) for k, v in sw["vegp"].items()}
+        oth = {k: (col3(v) if np.ndim(v) == 3 else col(v) if np.ndim(v) == 2 else v) for k, v in sw["other"].items()}
+        mouts = O.run_microsnow(args.reqhgt, sub(sw["obstime"], si), sub(sw["climdata"], si), smods, micro, vg, oth, 7.5, outm)
+        for k in moutn:
+            if k not in mouts:
+                mouts[k] = micro[k]
+        # (days in neither class — a melted pack's negative rounding residue — have no place in the reference's merge, which
+        # indexes by absolute hour, R/internal.R:3650-3655: the days are renumbered without them)
+        rank_of_day = np.cumsum((snowday[:nd_cov] | nosnowday[:nd_cov]).astype(np.int64)) - 1
+        want = merge_snow_outputs(moutn, mouts, rank_of_day[sdays] + 1, rank_of_day[ndays_] + 1, K, 1)
+        t_or = time.perf_counter() - t0
+        # ---- the comparison: every day that is in a class (the reference's merge has no place for the others)
+        inclass = np.repeat((snowday[:nd_cov] | nosnowday[:nd_cov]).astype(bool), 24)
+        worst, bad, nvals = 0.0, [], 0
+        cls = {"snow_covered": 0, "snow_free_on_a_snow_day": 0, "no_snow_day": 0}
+        for k, w in want.items():
+            g = probe["out"][k][:, :nd_cov * 24][:, inclass]
+            w = w.reshape(K, -1)
+            if g.shape != w.shape:
+                bad.append(f"{k}: shape {g.shape} vs {w.shape}")
+                continue
+            if not np.array_equal(np.isnan(g), np.isnan(w)):
+                bad.append(k + ": NA pattern")
+                continue
+            f = np.isfinite(w)
+            e = float(np.max(np.abs(g[f] - w[f]) / (1 + np.abs(w[f])))) if f.any() else 0.0
+            worst = max(worst, e)
+            nvals += int(f.sum())
+            if e > 1e-6:
+                bad.append(f"{k}: {e:.2e}")
+        day_of = np.repeat(np.arange(nd_cov), 24)[inclass]
+        cov = (swe[:, :nd_cov * 24][:, inclass] > 0)
+        valid_row = ~np.isnan(hg[cells])[:, None]
+        cls["snow_covered"] = int((cov & valid_row).sum())
+        cls["snow_free_on_a_snow_day"] = int((~cov & valid_row & snowday[day_of].astype(bool)[None, :]).sum())
+        cls["no_snow_day"] = int((valid_row & (snowday[day_of] == 0)[None, :]).sum())
+        return {"ok": not bad, "max_scaled_err": worst, "tolerance": 1e-6, "cells": int(K), "days": int(nd_cov - neither.size),
+                "days_in_neither_class": int(neither.size), "values": nvals, "cell_steps_by_class": cls, "outputs": names,
+                "what": "the ten MERGED outputs of a whole (untimed, probed) year for a sample of cells — read out of the solver's "
+                        "ring slot behind every chunk of pass 2 — against `.runmicrosnow1`'s orchestration with the oracle behind it: "
+                        "oracle/mcf_oracle.c on the no-snow-day subset, oracle/snow_oracle.c gridmicrosnow1 on the snow-day subset "
+                        f"given the device's snow series of those cells, merged by day ({t_or:.1f} s of oracle)",
+                "mismatches": bad or None}
+
     for _ in range(args.warmup):
         one_year()
     fence()
@@ -305,7 +420,12 @@ def run_snow_config(args, world, rank, local_rank):
     dt = allreduce_max(time.perf_counter() - t0)
     verified = None
     if not getattr(args, "no_verify", False) and last_days is not None:
-        verified = verify_sample(last_days)
+        vm = verify_merged()
+        vs = verify_sample(last_days)
+        if rank == 0:
+            verified = dict(vm)
+            verified["snowmodel"] = vs
+            verified["ok"] = bool(vm["ok"] and (vs.get("ok") is not False))
     valid_all = allreduce_sum(float(valid))
     value = valid_all * ndays * 24 * args.steps / dt
     if rank == 0:
