@@ -171,7 +171,8 @@ typedef struct mcf_options {
     int32_t out[MCF_NOUT];
     int32_t device;          /* HIP device ordinal                                      */
     int32_t days_per_chunk;  /* 0 = choose from free HBM                                */
-    int32_t cells_per_block; /* 0 = default (21: two 8-wave workgroups per CU); 16, 21, 32, 42 */
+    int32_t cells_per_block; /* 0 = default (21: two 8-wave workgroups per CU); 16, 21, 32, 42 (42: vector forcing only —
+                              * array forcing is given its 32-cell tiles instead) */
 } mcf_options;
 
 /* Host output buffers, each [rows,cols,tsteps] or NULL when out[v]==0. */

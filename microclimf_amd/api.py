@@ -74,7 +74,7 @@ def coarse_positions(n_fine: int, n_coarse: int):
 def runmicro2Cpp_coarse(obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Mapping, soilc: Mapping,
                         reqhgt: float, zref: float, lats, lons, Sminp: float, Smaxp: float, tfact: float,
                         complete: bool, mat: float, out: Sequence, *, rowpos=None, colpos=None, altcorrect: int = 0,
-                        dtmc=None, dtm=None, device: int = 0, days_per_chunk: int = 0) -> dict:
+                        dtmc=None, dtm=None, device: int = 0, days_per_chunk: int = 0, devices=None, n_blocks: int = 0) -> dict:
     """`.runmodel2Cpp` with the resampling fused into the solver (include/mcf.h, array_forcing == 2): `climdata` =
     {temp, relhum, pres, swdown, difrad, lwdown, windspeed, winddir} and `pointm` = {soilm, Gp, umu, kp, muGp, dtrp} as
     COARSE arrays [coarse_rows, coarse_cols, tsteps] — what `.cca(..., dtmc, dtmc)` gives before `resample` — instead of
@@ -87,7 +87,7 @@ def runmicro2Cpp_coarse(obstime: Mapping, climdata: Mapping, pointm: Mapping, ve
     if altcorrect:                     # `.runmodel2Cpp`'s altcorrect 1 / 2 with the coarse (dtmc) and fine (dtm) elevations
         coarse.update(altcorrect=int(altcorrect), dtmc=dtmc, dtm=dtm)
     return _run("mcf_runmicro2", True, obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lats, lons,
-                Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, 0, None, coarse)
+                Sminp, Smaxp, tfact, complete, mat, out, device, days_per_chunk, 0, None, coarse, devices=devices, n_blocks=n_blocks)
 
 
 def runmicro3Cpp(dfsel: Mapping, obstime: Mapping, climdata: Mapping, pointm: Mapping, vegp: Mapping,

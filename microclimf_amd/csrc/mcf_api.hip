@@ -66,6 +66,7 @@ struct mcf_plan {
     int ndays = 0;
     bool af = false, bg = false;
     bool coarse = false;                 // array_forcing == 2: coarse arrays interpolated in the solver
+    bool coarse_lds = false;             // ... with the taps staged in LDS: every 32-cell tile touches <= 4 coarse rows per column
     int crows = 0, ccols = 0;
     const double *d_crowpos = nullptr, *d_ccolpos = nullptr;
     int altcorrect = 0;
@@ -459,6 +460,13 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
                 return fail(MCF_ERR_ARG, "coarse_colpos must lie in [0, coarse_cols - 1]");
         p->crows = in->coarse_rows; p->ccols = in->coarse_cols;
         p->altcorrect = in->coarse_altcorrect;
+        // the LDS-staged taps (k_solve, CLDS): a tile's 32 cells lie in at most two raster columns and, in each, reach at most
+        // four coarse rows (the rows of its first and last cell and one more)
+        p->coarse_lds = in->rows >= 32 && getenv("MCF_NO_COARSE_LDS") == nullptr;
+        for (int64_t i = 0; p->coarse_lds && i < in->rows; ++i) {
+            const int64_t l = std::min<int64_t>(i + 31, in->rows - 1);
+            if (floor(in->coarse_rowpos[l]) - floor(in->coarse_rowpos[i]) + 2 > 4) p->coarse_lds = false;
+        }
         if (p->altcorrect < 0 || p->altcorrect > 2) return fail(MCF_ERR_ARG, "coarse_altcorrect must be 0, 1 or 2");
         if (p->altcorrect && (!in->coarse_dtm || !in->fine_dtm))
             return fail(MCF_ERR_ARG, "altitude correction needs coarse_dtm and fine_dtm");
@@ -467,9 +475,10 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
     p->cpb = opt->cells_per_block ? opt->cells_per_block : (in->array_forcing ? 32 : 21);
     // coarse array forcing is built for 32-cell tiles only: tile classes, tile lists and the ring's blocks must agree
     if (p->coarse) p->cpb = 32;
+    if (in->array_forcing && p->cpb == 42) p->cpb = 32;      // 42-cell tiles are built for vector forcing only (they would spill)
     if (p->N >= ((int64_t)1 << 31)) return fail(MCF_ERR_ARG, "at most 2^31 - 1 cells per plan (row-tile larger rasters)");
     {
-        static const bool no_fast = getenv("MCF_NO_FAST_CLAMPS") != nullptr;     // A/B runs and tools/canary_audit.py
+        static const bool no_fast = getenv("MCF_NO_FAST_CLAMPS") != nullptr;     // A/B runs
         p->fast_enabled = !no_fast && !(opt->reqhgt < 0.0);
     }
     p->layers = in->veg_layers > 1 ? in->veg_layers : 1;
@@ -481,6 +490,8 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
     if (ring_days > std::max(p->ndays, 1)) ring_days = std::max(p->ndays, 1);
     // reqhgt < 0 smooths the whole series (incl. steps past the last whole day, which read as 0)
     if (p->bg) { ring_slots = 1; ring_days = (int)std::max<int64_t>((in->tsteps + 23) / 24, 1); }
+    // array forcing re-lays a slot's series with one launch row per step (gridDim.y <= 65535): 2730 whole days at most
+    if (in->array_forcing == 1 && ring_days > 2730) ring_days = 2730;
     p->ring_days = ring_days; p->ring_slots = ring_slots;
 
     // ---- static rasters
@@ -887,6 +898,7 @@ int mcf_plan_run_days_at(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot,
     bool soil_daily = !p->af && !p->day_soil_daily.empty();
     for (int d = day0; soil_daily && d < day0 + ndays; ++d)
         if (!p->day_soil_daily[(size_t)d]) soil_daily = false;
+    if (p->coarse) soil_daily = p->coarse_lds;      // (coarse array forcing: the same launch flag selects the LDS-staged taps)
     auto launch = [&]() {
         if (fast) {
             (void)hipMemsetAsync(p->d_fix_count, 0, 4, p->stream);
@@ -1412,8 +1424,10 @@ int64_t mcf_plan_bytes(const mcf_plan* p) { return p ? p->bytes : 0; }
 
 // ---- one-shot host-to-host solve ---------------------------------------------------------
 // twi_mean: null, or the raster-wide mean of log(twi)/tfact to install (a row block of a larger raster, run_multi)
+// sharers: host threads that solve their blocks on this device at the same time (one-process multi-device route with a device
+// listed more than once): each sizes its ring from its share of the free HBM
 static int run_oneshot(const mcf_grid_inputs* in, const mcf_options* opt, mcf_outputs* out, int want_af,
-                       const double* twi_mean = nullptr) {
+                       const double* twi_mean = nullptr, int sharers = 1) {
     int rc = check_inputs(in, opt);
     if (rc) return rc;
     if (!out) return fail(MCF_ERR_ARG, "null outputs");
@@ -1438,7 +1452,7 @@ static int run_oneshot(const mcf_grid_inputs* in, const mcf_options* opt, mcf_ou
         size_t fr = 0, tot = 0;
         HIP_TRY(hipMemGetInfo(&fr, &tot));
         double per_day = (double)N * 24 * 8 * (nvars + (in->array_forcing ? 15 : 0));
-        double budget = 0.6 * (double)fr - (double)N * 8 * 200;
+        double budget = 0.6 * (double)fr / std::max(sharers, 1) - (double)N * 8 * 200;
         chunk = (int)std::max(1.0, std::min((double)std::max(ndays, 1), budget / std::max(per_day, 1.0)));
         chunk = std::min(chunk, 64);
     }
@@ -1526,16 +1540,23 @@ static std::vector<std::pair<int64_t, int64_t>> row_blocks(const mcf_grid_inputs
 }
 
 extern "C++" {
-// block_fn(sub, o, r0, twi_mean): one row block — `sub` is the caller's inputs narrowed to the block's rows (same arrays, offset,
+// block_fn(sub, o, r0, twi_mean, sharers): one row block — `sub` is the caller's inputs narrowed to the block's rows (same arrays, offset,
 // read through the row pitch), `o` the options with the block's device, r0 the block's first row
 template <class F>
 static int for_row_blocks(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_multi* mu, F&& block_fn) {
     int rc = check_inputs(in, opt);
     if (rc) return rc;
     if (!mu) return fail(MCF_ERR_ARG, "null argument");
+    // what row_blocks and the whole-raster twi mean read, before any plan has validated the inputs
+    if (!in->vegp.hgt) return fail(MCF_ERR_ARG, "missing input array: vegp$hgt");
+    if (!in->soilc.twi) return fail(MCF_ERR_ARG, "missing input array: twi");
     int ndev_avail = 0;
     if (hipGetDeviceCount(&ndev_avail) != hipSuccess || ndev_avail <= 0)
         return fail(MCF_ERR_NO_DEVICE, "no HIP device available (libmcfhip has no CPU fallback)");
+    // the calling thread's current device is put back on every way out
+    int caller_dev = 0;
+    const bool have_caller_dev = hipGetDevice(&caller_dev) == hipSuccess;
+    struct RestoreDev { bool on; int d; ~RestoreDev() { if (on) (void)hipSetDevice(d); } } restore_dev{have_caller_dev, caller_dev};
     std::vector<int> devs;
     if (mu->n_devices <= 0) for (int d = 0; d < ndev_avail; ++d) devs.push_back(d);      // every visible device
     else {
@@ -1571,6 +1592,8 @@ static int for_row_blocks(const mcf_grid_inputs* in, const mcf_options* opt, con
     std::vector<std::thread> threads;
     for (size_t t = 0; t < devs.size(); ++t) {
         threads.emplace_back([&, t] {
+            // (an exception must not leave a worker thread: std::terminate would take the host R / Python process down)
+            try {
             for (int b = (int)t; b < nb; b += (int)devs.size()) {
                 const int64_t r0 = blocks[(size_t)b].first, nr = blocks[(size_t)b].second;
                 if (nr <= 0) continue;
@@ -1592,8 +1615,13 @@ static int for_row_blocks(const mcf_grid_inputs* in, const mcf_options* opt, con
                 }
                 mcf_options o = *opt;
                 o.device = devs[t];
-                const int rcb = block_fn(sub, o, r0, &twi_mean);
+                int sharers = 0;
+                for (int d : devs) sharers += d == devs[t];
+                const int rcb = block_fn(sub, o, r0, &twi_mean, sharers);
                 if (rcb != MCF_OK) { rcs[t] = rcb; errs[t] = g_err; return; }
+            }
+            } catch (const std::exception& e) {
+                rcs[t] = MCF_ERR_NOMEM; errs[t] = std::string("row-block worker: ") + e.what();
             }
         });
     }
@@ -1606,10 +1634,10 @@ static int for_row_blocks(const mcf_grid_inputs* in, const mcf_options* opt, con
 }  // extern "C++"
 static int run_multi(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_multi* mu, mcf_outputs* out, int want_af) {
     if (!out) return fail(MCF_ERR_ARG, "null argument");
-    return for_row_blocks(in, opt, mu, [&](const mcf_grid_inputs& sub, const mcf_options& o, int64_t r0, const double* twi_mean) {
+    return for_row_blocks(in, opt, mu, [&](const mcf_grid_inputs& sub, const mcf_options& o, int64_t r0, const double* twi_mean, int sharers) {
         mcf_outputs so = *out;
         for (int v = 0; v < MCF_NOUT; ++v) if (so.var[v]) so.var[v] += r0;
-        return run_oneshot(&sub, &o, &so, want_af, twi_mean);
+        return run_oneshot(&sub, &o, &so, want_af, twi_mean, sharers);
     });
 }
 // the fused bioclim sink over row blocks: a block's nineteen [rows, cols] matrices go into its rows of the caller's
@@ -1619,7 +1647,7 @@ static int run_bioclim_multi(const mcf_grid_inputs* in, const mcf_options* opt, 
     const int64_t pitch = in->row_pitch > 0 ? in->row_pitch : in->rows;
     mcf_grid_inputs in_l = *in;
     if (layered) { in_l.veg_layers = 14; in_l.lyr_st = kBioSt; in_l.lyr_ed = kBioEd; }     // as run_bioclim: the fixed dfsel
-    return for_row_blocks(&in_l, opt, mu, [&](const mcf_grid_inputs& sub, const mcf_options& o, int64_t r0, const double* twi_mean) {
+    return for_row_blocks(&in_l, opt, mu, [&](const mcf_grid_inputs& sub, const mcf_options& o, int64_t r0, const double* twi_mean, int) {
         mcf_bioclim_out bo = *out;
         for (int v = 0; v < MCF_NBIO; ++v) if (bo.bio[v]) bo.bio[v] += r0;
         return run_bioclim(&sub, &o, sel, &bo, want_af, layered, twi_mean, pitch);

@@ -858,10 +858,11 @@ struct CoarseTap {
         const char* q = reinterpret_cast<const char*>(p);
         const double v00 = *reinterpret_cast<const double*>(q + a), v01 = *reinterpret_cast<const double*>(q + b),
                      v10 = *reinterpret_cast<const double*>(q + c), v11 = *reinterpret_cast<const double*>(q + d);
-        const double top = (1.0 - wx) * v00 + wx * v01;
-        const double bot = (1.0 - wx) * v10 + wx * v11;
-        return (1.0 - wy) * top + wy * bot;
+        return mix(mix(v00, v01, wx), mix(v10, v11, wx), wy);
     }
+    // (1 - w) a + w b, with the contraction written out: the LDS-staged form of the taps (k_solve, CLDS) interpolates along the
+    // columns once per tile-day and along the rows per lane, and must give the bits of this per-lane form
+    static __device__ __forceinline__ double mix(double a, double b, double w) { return fma(w, b, (1.0 - w) * a); }
 };
 // `.satvap` and `.dewpoint` of the R side (R/internal.R:501-521), which `.runmodel2Cpp` applies to the resampled
 // temperature and humidity (R/internal.R:1230-1232); NOT satvapCpp / dewpointCpp (other ice threshold, other constants).
@@ -955,7 +956,8 @@ __device__ __forceinline__ void pin(A&... a) {
 // that can still become NaN from finite inputs (a vanishing two-stream denominator, a non-positive soil diffusivity,
 // coinciding Lagrangian resistances) are WATCHED: Canary::watch folds them into a value that is NaN iff any of them
 // was NaN or infinite, and a wave with a tripped canary recomputes the pass with F = false.  Building with
-// -DMCF_CANARY_ALL=1 watches every clamp operand instead (tools/canary_audit.py counts how often that trips).
+// -DMCF_CANARY_ALL=1 watches every clamp operand instead (an audit build: mcf_plan_dispatch_stats then counts how often
+// any clamp of a fast launch met a NaN).
 #ifndef MCF_CANARY_ALL
 #define MCF_CANARY_ALL 0
 #endif

@@ -497,6 +497,19 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
     constexpr bool SS = SSREQ && (AF == 0) && (2 * CPB <= 64);
     __shared__ double s_soil[SS ? 3 * SD_COUNT * CPB : 1];
     __shared__ int s_trip;      // F: a wave of this workgroup tripped its canary
+    // Coarse array forcing with the taps staged in LDS (CLDS = the SSREQ instantiation of AF == 2; mcf_plan_create chooses it
+    // when every tile touches at most 4 coarse rows per raster column).  The 32 cells of a tile lie in at most two raster
+    // columns (rows >= 32), and within one column every cell has the same two coarse columns and the same weight wx: the
+    // bilinear interpolation's inner step — along the columns — is done ONCE per tile, day, series, hour and coarse row
+    // (2 x 4 x 15 x 24 values, ~4 per lane and day: 8 loads) and a lane is left with the step along the rows, two LDS reads and
+    // two instructions per series, instead of 4 global loads and 6 instructions (52 loads per cell-step before).  Double
+    // buffered by day: the values of day d + 1 are written in front of pass 1 of day d, the day's barrier orders them before
+    // their readers.  Same operations as CoarseTap in the same order (CoarseTap::mix): same bits.
+    constexpr bool CLDS = (AF == 2) && SSREQ;
+    constexpr int CU_ROWS = 4, CU_F = 15, CU_SLOT = CU_ROWS * CU_F * 24;
+    __shared__ double s_cu[CLDS ? 2 * 2 * CU_SLOT : 1];      // [day parity][column slot][coarse row][series][hour]
+    __shared__ double s_cw[CLDS ? 2 : 1];                    // wx of the two column slots
+    __shared__ int s_ci[CLDS ? 9 : 1];                       // per slot: first coarse row, rows staged, coarse columns c0, c1; [8]: slot 1's first cell
 
     const int tid = threadIdx.x;
     int cl = tid % CPB;
@@ -635,6 +648,64 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
         }
     };
     __syncthreads();
+    // CLDS: stages the column-interpolated coarse values of day `d` into buffer `buf` (all lanes; s_ci / s_cw set below)
+    auto stage_coarse = [&](int d, int buf) {
+        if (!CLDS) return;
+        const int64_t cN = (int64_t)a.crows * a.ccols;
+        const double* qd = a.af_base + cN * ((int64_t)d * 24);                      // the day's first step: uniform
+        double* dst = s_cu + buf * (2 * CU_SLOT);
+        constexpr int ITEMS = 2 * CU_SLOT, PER = (ITEMS + NT - 1) / NT;
+        double v0[PER], v1[PER];
+        int tq = tid;
+        asm volatile("" : "+v"(tq));        // (opaque per call: the items' addresses are made again every day, or hipcc keeps
+                                            // eight 64-bit pointers and their parts alive across the whole day loop: 84 B of scratch)
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int q = tq + i * NT;
+            const int h = q % 24, f = (q / 24) % CU_F, r = (q / (24 * CU_F)) % CU_ROWS, sl = q / CU_SLOT;
+            const bool on = q < ITEMS && r < s_ci[4 * sl + 1] && f != TF_TDEW;     // rows / slots the tile does not touch: nothing
+            v0[i] = v1[i] = 0.0;
+            if (on) {
+                const double* fp = qd + (int64_t)f * a.af_stride + (int64_t)h * cN + (s_ci[4 * sl] + r);
+                v0[i] = fp[(int64_t)a.crows * s_ci[4 * sl + 2]];
+                v1[i] = fp[(int64_t)a.crows * s_ci[4 * sl + 3]];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int q = tq + i * NT;
+            if (q < ITEMS) dst[q] = CoarseTap::mix(v0[i], v1[i], s_cw[q / CU_SLOT]);
+        }
+    };
+    if (CLDS) {
+        // the tile's two column slots: slot 0 = the raster column of its first cell, slot 1 = the next one, from the cell at
+        // which the tile wraps into it (rows restart: the row position falls, or — a one-row coarse grid — the column
+        // position changes; if neither does, both columns read the same coarse cells with the same weights)
+        if (tid < 64) {
+            const int k = tid & 31;
+            const bool have = c0 + k < N;
+            const double rp = s_cell[CF_CROWPOS * CPB + k], cp = s_cell[CF_CCOLPOS * CPB + k];
+            const double rpp = s_cell[CF_CROWPOS * CPB + (k ? k - 1 : 0)], cpp = s_cell[CF_CCOLPOS * CPB + (k ? k - 1 : 0)];
+            const bool brk = have && k > 0 && tid < 32 && (rp < rpp || cp != cpp);
+            const uint64_t mb = __builtin_amdgcn_ballot_w64(brk), mh = __builtin_amdgcn_ballot_w64(have && tid < 32);
+            const int nk = 64 - __builtin_clzll(mh | 1ull);                 // cells of the tile inside the raster
+            const int b = mb ? __builtin_ctzll(mb) : nk;                    // first cell of slot 1 (= nk: there is none)
+            if (tid < 2) {
+                const int fk = tid ? (b < nk ? b : 0) : 0, lk = tid ? nk - 1 : b - 1;
+                const double rpf = s_cell[CF_CROWPOS * CPB + fk], rpl = s_cell[CF_CROWPOS * CPB + lk], cpx = s_cell[CF_CCOLPOS * CPB + fk];
+                const int rb = (int)floor(rpf), re = (int)floor(rpl) + 1;
+                const int cc0 = (int)floor(cpx), cc1 = cc0 + 1 < a.ccols ? cc0 + 1 : cc0;
+                int nr = (re < a.crows ? re : a.crows - 1) - rb + 1;
+                if (tid == 1 && b >= nk) nr = 0;
+                s_ci[4 * tid + 0] = rb; s_ci[4 * tid + 1] = nr < CU_ROWS ? nr : CU_ROWS; s_ci[4 * tid + 2] = cc0; s_ci[4 * tid + 3] = cc1;
+                s_cw[tid] = cpx - floor(cpx);
+                if (tid == 0) s_ci[8] = b;
+            }
+        }
+        __syncthreads();
+        stage_coarse(day0, 0);
+        __syncthreads();
+    }
     enter_layer(day0);
     // the tile's first block of this launch in the tiled ring (uniform: SGPRs); a day's ten stores are
     // [block base + variable slab * block] + pos
@@ -685,6 +756,7 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
                 pre[i] = src[q < TF_COUNT * 24 ? q : TF_COUNT * 24 - 1];
             }
         }
+        if (CLDS && dl + 1 < ndays) stage_coarse(dabs + 1, (run + 1) & 1);
         TimeVals tv;
         // the tile-day block of the tiled forcing ring (uniform) — the lane's value of series f is at [f][pos]
         const double* fday = (AF == 1) ? a.af_base + tile * a.af_tile_stride + (int64_t)(dabs - a.day0) * a.af_day_stride : nullptr;
@@ -700,7 +772,24 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
                 // (slot TF_ES carries relhum, TF_U2 / TF_EA the wind components u, v)
                 const CoarseTap tap(C(CF_CROWPOS), C(CF_CCOLPOS), a.crows, a.ccols, hr);
                 const double* q = a.af_base + (int64_t)a.crows * a.ccols * ((int64_t)dabs * 24);     // the day's first step: uniform
-                auto at = [&](int f) { return tap(q + (int64_t)f * a.af_stride); };
+                // CLDS: the lane's place in the day's staged buffer (column slot, the first of its two coarse rows) and its weight
+                // along the rows — made again every day from the tile's image rather than carried (three registers short)
+                const double* cu = s_cu;
+                int cu_r1 = 0;
+                double cu_wy = 0.0;
+                if (CLDS) {
+                    const double rp = C(CF_CROWPOS);
+                    const int sl = cl >= s_ci[8] ? 1 : 0;
+                    const double fr = floor(rp);
+                    const int r0 = (int)fr;
+                    cu_wy = rp - fr;
+                    cu = s_cu + (run & 1) * (2 * CU_SLOT) + (sl * CU_ROWS + (r0 - s_ci[4 * sl])) * (CU_F * 24) + hr;
+                    cu_r1 = r0 + 1 < a.crows ? CU_F * 24 : 0;
+                }
+                auto at = [&](int f) {
+                    if (CLDS) return CoarseTap::mix(cu[f * 24], cu[f * 24 + cu_r1], cu_wy);
+                    return tap(q + (int64_t)f * a.af_stride);
+                };
                 double tc = at(TF_TC);
                 const double rh = at(TF_ES), wu = at(TF_U2), wv = at(TF_EA);
                 const double es = satvap_r(tc, MK), ea = es * rh / 100.0;
@@ -1268,8 +1357,10 @@ void launch_pack_transpose(const RingView& src, int64_t step0, int64_t rows, int
 }
 void launch_tile_series(const double* src, int64_t nsteps, const RingView& dst, hipStream_t s) {
     if (nsteps <= 0 || dst.N <= 0) return;
-    for (int64_t k0 = 0; k0 < nsteps; k0 += 65535) {      // gridDim.y limit; whole days only reach here in one piece
-        const int64_t n = std::min<int64_t>(65535, nsteps - k0);
+    // gridDim.y limit; a piece is a whole number of days (65520 = 2730 x 24), so that a second piece lands on a day boundary
+    // of the tiled ring (mcf_plan_create refuses ring slots of more than 2730 days, so one piece is all there ever is)
+    for (int64_t k0 = 0; k0 < nsteps; k0 += 65520) {
+        const int64_t n = std::min<int64_t>(65520, nsteps - k0);
         RingView v = dst;
         v.base = dst.base + (k0 / 24) * dst.day_stride;
         dim3 grid((unsigned)((dst.N + 255) / 256), (unsigned)n);
@@ -1334,11 +1425,15 @@ static void launch_solve_cpb(SolveArgs a, bool af, bool bg, bool fast, bool ss, 
     const dim3 grid = solve_grid(a.ntiles_launch), block(solve_threads(CPB));
     ss = ss && 2 * CPB <= 64;
     if (af) {
-        if (bg) hipLaunchKernelGGL((k_solve<CPB, 1, true, false, false>), grid, block, 0, s, a);
-        else if (fast) {
-            hipLaunchKernelGGL((k_solve<CPB, 1, false, true, false>), grid, block, 0, s, a);
-            hipLaunchKernelGGL((k_solve_fix<CPB, 1>), dim3(512), block, 0, s, a);
-        } else hipLaunchKernelGGL((k_solve<CPB, 1, false, false, false>), grid, block, 0, s, a);
+        // (42-cell tiles are a vector-forcing geometry: with the forcing values in registers a 16-wave workgroup spills
+        // 52-148 bytes per lane; mcf_plan_create gives array forcing its 32-cell tiles instead and nothing is built here)
+        if constexpr (CPB != 42) {
+            if (bg) hipLaunchKernelGGL((k_solve<CPB, 1, true, false, false>), grid, block, 0, s, a);
+            else if (fast) {
+                hipLaunchKernelGGL((k_solve<CPB, 1, false, true, false>), grid, block, 0, s, a);
+                hipLaunchKernelGGL((k_solve_fix<CPB, 1>), dim3(512), block, 0, s, a);
+            } else hipLaunchKernelGGL((k_solve<CPB, 1, false, false, false>), grid, block, 0, s, a);
+        }
     } else if (bg) {
         hipLaunchKernelGGL((k_solve<CPB, 0, true, false, false>), grid, block, 0, s, a);
     } else if (fast) {
@@ -1356,7 +1451,8 @@ void launch_tile_regular(const double* cellc, int64_t N, int layers, int cpb, ui
     hipLaunchKernelGGL(k_tile_regular, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, s, cellc, N, layers, cpb, ntiles, out);
 }
 // coarse array forcing is built for the array-forcing geometry (32 cells per workgroup) only
-static void launch_solve_coarse(SolveArgs a, bool bg, bool fast, hipStream_t s) {
+// lds: every tile touches at most 4 coarse rows per raster column (mcf_plan_create): the taps are staged in LDS
+static void launch_solve_coarse(SolveArgs a, bool bg, bool fast, bool lds, hipStream_t s) {
     constexpr int CPB = 32;
     if (a.ntiles_launch <= 0) {
         a.ntiles_launch = (a.N + CPB - 1) / CPB;
@@ -1365,7 +1461,8 @@ static void launch_solve_coarse(SolveArgs a, bool bg, bool fast, hipStream_t s) 
     const dim3 grid = solve_grid(a.ntiles_launch), block(solve_threads(CPB));
     if (bg) hipLaunchKernelGGL((k_solve<CPB, 2, true, false, false>), grid, block, 0, s, a);
     else if (fast) {
-        hipLaunchKernelGGL((k_solve<CPB, 2, false, true, false>), grid, block, 0, s, a);
+        if (lds) hipLaunchKernelGGL((k_solve<CPB, 2, false, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_solve<CPB, 2, false, true, false>), grid, block, 0, s, a);
         hipLaunchKernelGGL((k_solve_fix<CPB, 2>), dim3(512), block, 0, s, a);
     } else hipLaunchKernelGGL((k_solve<CPB, 2, false, false, false>), grid, block, 0, s, a);
 }
@@ -1383,7 +1480,7 @@ double hf_pow02(double rs) {
 
 void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, bool fast, bool soil_daily, hipStream_t s) {
     if (a.N <= 0 || a.ndays <= 0) return;
-    if (a.crows > 0) { launch_solve_coarse(a, bg, fast, s); return; }
+    if (a.crows > 0) { launch_solve_coarse(a, bg, fast, soil_daily, s); return; }     // (coarse: the flag says "taps through LDS")
     if (cells_per_block == 32) launch_solve_cpb<32>(a, af, bg, fast, soil_daily, s);
     else if (cells_per_block == 21) launch_solve_cpb<21>(a, af, bg, fast, soil_daily, s);
     else if (cells_per_block == 42) launch_solve_cpb<42>(a, af, bg, fast, soil_daily, s);

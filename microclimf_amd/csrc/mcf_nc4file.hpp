@@ -48,6 +48,7 @@ struct H5Api {
     herr_t (*open)();
     herr_t (*get_libversion)(unsigned*, unsigned*, unsigned*);
     herr_t (*Eset_auto2)(hid_t, void*, void*);
+    herr_t (*Eget_auto2)(hid_t, void**, void**);
     hid_t (*Fcreate)(const char*, unsigned, hid_t, hid_t);
     herr_t (*Fclose)(hid_t);
     hid_t (*Pcreate)(hid_t);
@@ -89,10 +90,17 @@ struct H5Api {
     }
 
 private:
+    // A host process (an R session with ncdf4 / terra, Python with netCDF4 / h5py) usually has ONE HDF5 mapped already, and
+    // libnetcdf resolves its H5* symbols against it.  So: first the library that is already there (RTLD_NOLOAD on the versioned
+    // sonames — nothing new enters the process); only then a fresh one, and then with RTLD_LOCAL, so that a second HDF5 of
+    // another soname can never capture another library's symbol look-ups.
     static void* open_first(const std::vector<std::string>& names, std::string& tried) {
+        for (const std::string& n : names)
+            if (!n.empty())
+                if (void* h = dlopen(n.c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL)) return h;
         for (const std::string& n : names) {
             if (n.empty()) continue;
-            if (void* h = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL)) return h;
+            if (void* h = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL)) return h;
             tried += (tried.empty() ? "" : ", ") + n;
         }
         return nullptr;
@@ -103,11 +111,16 @@ private:
         std::string tried;
         // MCF_HDF5_LIB / MCF_HDF5_HL_LIB name THE library to use; without them the usual names are tried in turn
         typedef std::vector<std::string> Names;
-        void* h = open_first(e1 ? Names{e1} : Names{"libhdf5.so", "libhdf5.so.103", "libhdf5.so.200", "libhdf5_serial.so",
-                                                    "libhdf5_serial.so.103", "/opt/conda/lib/libhdf5.so"}, tried);
+        void* h = open_first(e1 ? Names{e1} : Names{"libhdf5.so.310", "libhdf5.so.200", "libhdf5.so.103", "libhdf5.so.101", "libhdf5.so.100",
+                                                    "libhdf5_serial.so.310", "libhdf5_serial.so.200", "libhdf5_serial.so.103",
+                                                    "libhdf5_serial.so.100", "libhdf5.so", "libhdf5_serial.so",
+                                                    "/opt/conda/lib/libhdf5.so"}, tried);
         if (!h) { why = "the netCDF-4 container needs the HDF5 library and none could be loaded (tried " + tried + "; MCF_HDF5_LIB names one)"; return false; }
-        void* hl = open_first(e2 ? Names{e2} : Names{"libhdf5_hl.so", "libhdf5_hl.so.100", "libhdf5_hl.so.200", "libhdf5_serial_hl.so",
-                                                     "libhdf5_serial_hl.so.100", "/opt/conda/lib/libhdf5_hl.so"}, tried);
+        // (libhdf5_hl names the core library it was linked against in its own DT_NEEDED; with the core mapped above the loader
+        // resolves it to that copy)
+        void* hl = open_first(e2 ? Names{e2} : Names{"libhdf5_hl.so.310", "libhdf5_hl.so.200", "libhdf5_hl.so.100", "libhdf5_serial_hl.so.310",
+                                                     "libhdf5_serial_hl.so.200", "libhdf5_serial_hl.so.100", "libhdf5_hl.so",
+                                                     "libhdf5_serial_hl.so", "/opt/conda/lib/libhdf5_hl.so"}, tried);
         if (!hl) { why = "HDF5's high-level library (dimension scales) could not be loaded (tried " + tried + "; MCF_HDF5_HL_LIB names one)"; return false; }
         bool ok = true;
         std::string missing;
@@ -117,6 +130,7 @@ private:
             fp = reinterpret_cast<std::remove_reference_t<decltype(fp)>>(p);
         };
         sym(h, "H5open", open); sym(h, "H5get_libversion", get_libversion); sym(h, "H5Eset_auto2", Eset_auto2);
+        sym(h, "H5Eget_auto2", Eget_auto2);
         sym(h, "H5Fcreate", Fcreate); sym(h, "H5Fclose", Fclose); sym(h, "H5Pcreate", Pcreate); sym(h, "H5Pclose", Pclose);
         sym(h, "H5Pset_link_creation_order", Pset_link_creation_order); sym(h, "H5Pset_attr_creation_order", Pset_attr_creation_order);
         sym(h, "H5Pset_chunk", Pset_chunk); sym(h, "H5Pset_deflate", Pset_deflate); sym(h, "H5Pset_fill_value", Pset_fill_value);
@@ -138,9 +152,22 @@ private:
         id("H5T_NATIVE_INT_g", T_NATIVE_INT); id("H5T_C_S1_g", T_C_S1);
         id("H5P_CLS_FILE_CREATE_ID_g", P_FILE_CREATE); id("H5P_CLS_DATASET_CREATE_ID_g", P_DATASET_CREATE);
         if (!ok) { why = "this HDF5 library lacks" + missing; return false; }
-        Eset_auto2(0, nullptr, nullptr);      // errors come back as return codes; nothing is printed behind the caller's back
         return true;
     }
+
+public:
+    // HDF5 builds without thread safety are common: every call of this translation unit into the library is made under ONE
+    // process-wide lock (two files written from two host threads must not meet inside it).
+    static std::mutex& lock() { static std::mutex m; return m; }
+    // The library's automatic error printing is the HOST's setting (an R session's ncdf4 relies on it): it is switched off
+    // only while one of our calls runs — errors come back as return codes — and put back as it was.
+    struct Quiet {
+        const H5Api* a;
+        void* fn = nullptr;
+        void* data = nullptr;
+        explicit Quiet(const H5Api* api) : a(api) { if (a->Eget_auto2(0, &fn, &data) >= 0) a->Eset_auto2(0, nullptr, nullptr); else fn = nullptr; }
+        ~Quiet() { if (fn) a->Eset_auto2(0, fn, data); }
+    };
 };
 
 class Nc4File : public NcFile {
@@ -158,6 +185,8 @@ public:
         std::string err;
         h5 = H5Api::get(err);
         if (!h5) return err;
+        std::lock_guard<std::mutex> lk(H5Api::lock());
+        H5Api::Quiet quiet(h5);
         rows = rows_; cols = cols_; nsteps = nsteps_; nvars = (int)vars.size();
         rec_bytes = 8 + (int64_t)nvars * rows * cols * 4;      // a record piece arrives in the classic container's shape
         rec_begin = 0;
@@ -215,7 +244,7 @@ public:
             h5->Pclose(dcpl);
         }
         for (hid_t d : {d_east, d_north, d_time}) if (d >= 0) h5->Dclose(d);
-        if (!ok) { close(); return "HDF5 refused a call while the dataset was being defined"; }
+        if (!ok) { close_locked(); return "HDF5 refused a call while the dataset was being defined"; }
         return "";
     }
 
@@ -252,7 +281,8 @@ public:
                     out = comp.data(); out_n = (size_t)cn;
                 }
                 const hsize_t off[3] = {(hsize_t)(step0 + s), (hsize_t)r0, 0};
-                std::lock_guard<std::mutex> lk(h5mu_);
+                std::lock_guard<std::mutex> lk(H5Api::lock());
+                H5Api::Quiet quiet(h5);
                 if (h5->Dwrite_chunk(dsets_[k], 0, 0, off, out_n, out) < 0) { errs[t] = "H5Dwrite_chunk failed"; return; }
             }
         };
@@ -267,6 +297,14 @@ public:
     }
 
     std::string close() override {
+        if (!h5) return "";
+        std::lock_guard<std::mutex> lk(H5Api::lock());
+        H5Api::Quiet quiet(h5);
+        return close_locked();
+    }
+
+private:
+    std::string close_locked() {
         std::string e;
         if (!h5) return e;
         for (hid_t d : dsets_) if (h5->Dclose(d) < 0) e = "H5Dclose failed";
@@ -276,11 +314,9 @@ public:
         return e;
     }
 
-private:
     const H5Api* h5 = nullptr;
     hid_t file_ = -1;
     std::vector<hid_t> dsets_;
-    std::mutex h5mu_;
     int level_ = 9;
     int64_t strip_rows = 1, nstrips = 1;
 

@@ -1115,6 +1115,9 @@ struct mcf_snowplan {
     // series of chunks kept on the device between the two passes (mcf_snowplan_keep_chunk): a kept chunk's buffers are the ones
     // the model wrote — the plan goes on with fresh ones — so pass 2 neither re-runs the chunk nor copies anything
     struct Kept { double *Tc = nullptr, *Tg = nullptr, *sdepc = nullptr, *sdepg = nullptr, *sden = nullptr; };
+    // (a kept set belongs to the run of its chunk that was current when it was handed over: running the chunk again — a new
+    // pass 1 without mcf_snowplan_release_kept, a re-run after mcf_snowplan_reset — returns the stale set to the pool, so that
+    // mcf_snowplan_microsnow can never read last year's series for it)
     std::vector<Kept> kept;
     std::vector<Kept> pool;              // released sets, reused by the next year's pass 1 (hipMalloc of 10 GB costs 0.25 s)
     Bufs kb;
@@ -1418,6 +1421,10 @@ static int run_chunk_to(mcf_snowplan* sp, int32_t ch, double tpic_mean, const mc
     if (row_pitch <= 0) row_pitch = sp->rows;
     if (ch != sp->prepared) return mcf::api_fail(MCF_ERR_STATE, "snow plan: run_chunk needs prepare_chunk of the same chunk first");
     S_TRY(hipSetDevice(sp->device));
+    if ((size_t)ch < sp->kept.size() && sp->kept[(size_t)ch].Tc) {     // a set kept from an earlier run of this chunk is stale now
+        sp->pool.push_back(sp->kept[(size_t)ch]);
+        sp->kept[(size_t)ch] = mcf_snowplan::Kept();
+    }
     const int64_t N = sp->N;
     const int k0 = ch * sp->chunk, ns = std::min(sp->chunk, sp->T - k0);
     const unsigned gridN = (unsigned)((N + 255) / 256);

@@ -60,8 +60,10 @@ mcfhip_enable <- function(glue = "r/mcfhip_glue.so", devices = NULL, blocks = NU
       .Call(sym, reqhgt, obstime, climdata, snowm, micro, vegp, other, mat, out), ns = "microclimf")
   })
   # output file (R/dataprep.R:1063-1260): same arguments.  terra stays on this side (cell-centre coordinates, projection text);
-  # the dataset is written by libmcfhip: format "netcdf4" = the reference's container (deflate 9; through the host's HDF5
-  # library, which any host with ncdf4 has), "classic" = uncompressed netCDF classic, needs nothing; options(mcfhip.ncformat).
+  # the dataset is written by libmcfhip: "classic" (default) = uncompressed netCDF classic, needs nothing and every netCDF
+  # reader opens it; options(mcfhip.ncformat = "netcdf4") = the reference's container (deflate 9) written through the HDF5
+  # library the session has mapped already (ncdf4's / terra's own copy is used when there is one).  The netCDF-4 files have
+  # been read back with HDF5's own tools only — not yet by libnetcdf / ncdf4 — which is why they are not the default.
   wnc <- function(mout, fileout, dtm, reqhgt, vars = NULL) {
     if (class(dtm)[1] == "PackedSpatRaster") dtm <- terra::rast(dtm)
     e <- terra::ext(dtm); r <- terra::res(dtm)
@@ -72,7 +74,7 @@ mcfhip_enable <- function(glue = "r/mcfhip_glue.so", devices = NULL, blocks = NU
                                else if (reqhgt == 0) c("Tz", "soilm", "Rdirdown", "Rdifdown", "Rlwdown", "Rswup", "Rlwup")
                                else c("Tz", "soilm")
     fileout <- as.character(fileout); wkt <- as.character(terra::crs(dtm)); vars <- as.character(vars)
-    fmt <- getOption("mcfhip.ncformat", "netcdf4")
+    fmt <- getOption("mcfhip.ncformat", "classic")
     invisible(.Call("mcfhip_writetonc", mout, fileout, est, nth, hours, wkt, reqhgt, vars, fmt))
   }
   utils::assignInNamespace("writetonc", wnc, ns = "microclimf")

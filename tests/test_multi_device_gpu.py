@@ -35,6 +35,22 @@ def test_array_forcing_row_blocks_bitwise():
     _bits_equal(whole, parts)
 
 
+@pytest.mark.parametrize("altcorrect", [0, 2])
+def test_coarse_array_forcing_row_blocks_bitwise(altcorrect):
+    """array_forcing == 2: the coarse climate grid is shared by the blocks, the cells' positions in it (coarse_rowpos) and the
+    fine elevations of the altitude correction are offset by the block's first row"""
+    from microclimf_amd.api import runmicro2Cpp_coarse
+    a, rp, cp = synthetic.coarse_workload(57, 21, 72, 4, 3, reqhgt=0.05, start_doy=165)
+    kw = dict(rowpos=rp, colpos=cp)
+    if altcorrect:
+        _, _, dtm = synthetic.rasters(57, 21)
+        kw.update(altcorrect=altcorrect, dtmc=200.0 + 30.0 * np.arange(12, dtype=np.float64).reshape(4, 3), dtm=dtm)
+    args = [a[k] for k in ARGS]
+    whole = runmicro2Cpp_coarse(*args, **kw)
+    for devices, nb in (([0], 4), ([0, 0], 3)):
+        _bits_equal(whole, runmicro2Cpp_coarse(*args, **kw, devices=devices, n_blocks=nb))
+
+
 def test_time_varying_vegetation_row_blocks_bitwise():
     """mcf_runmicro3_multi / 4_multi: the layered vegetation arrays [rows, cols, layers] go through the same row pitch; a day
     no layer covers stays NA in every block"""
