@@ -508,8 +508,8 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
     constexpr bool CLDS = (AF == 2) && SSREQ;
     constexpr int CU_ROWS = 4, CU_F = 15, CU_SLOT = CU_ROWS * CU_F * 24;
     __shared__ double s_cu[CLDS ? 2 * 2 * CU_SLOT : 1];      // [day parity][column slot][coarse row][series][hour]
-    __shared__ double s_cw[CLDS ? 2 : 1];                    // wx of the two column slots
-    __shared__ int s_ci[CLDS ? 9 : 1];                       // per slot: first coarse row, rows staged, coarse columns c0, c1; [8]: slot 1's first cell
+    __shared__ double s_cw[2];                    // wx of the two column slots
+    __shared__ int s_ci[9];                       // per slot: first coarse row, rows staged, coarse columns c0, c1; [8]: slot 1's first cell
 
     const int tid = threadIdx.x;
     int cl = tid % CPB;
@@ -648,34 +648,46 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
         }
     };
     __syncthreads();
-    // CLDS: stages the column-interpolated coarse values of day `d` into buffer `buf` (all lanes; s_ci / s_cw set below)
-    auto stage_coarse = [&](int d, int buf) {
-        if (!CLDS) return;
+    // CLDS: the column-interpolated coarse values of day `d` into buffer `buf` (all lanes; s_ci / s_cw set below).  The items —
+    // (coarse row the tile touches, series, hour) — are dealt compactly: a tile inside one raster column with two coarse rows has
+    // 720 of them, ONE per lane.  A lane's first item is only LOADED by stage_issue (two values held in registers) and written
+    // by stage_commit in front of the day's barrier, so that the loads' latency runs under pass 1 (one 12-wave workgroup per
+    // CU: nothing else hides it); the rare further items are loaded and written at once.
+    auto stage_item = [&](int q, int d, int& dst, const double*& p0, const double*& p1, double& w) {
+        const int nr0 = s_ci[1], nr1 = s_ci[5];
+        const int rr = q / (CU_F * 24), rem = q - rr * (CU_F * 24), f = rem / 24, h = rem - f * 24;
+        const int sl = rr >= nr0 ? 1 : 0, r = rr - (sl ? nr0 : 0);
+        const bool on = rr < nr0 + nr1 && f != TF_TDEW;
         const int64_t cN = (int64_t)a.crows * a.ccols;
-        const double* qd = a.af_base + cN * ((int64_t)d * 24);                      // the day's first step: uniform
-        double* dst = s_cu + buf * (2 * CU_SLOT);
-        constexpr int ITEMS = 2 * CU_SLOT, PER = (ITEMS + NT - 1) / NT;
-        double v0[PER], v1[PER];
+        const double* fp = a.af_base + cN * ((int64_t)d * 24) + (int64_t)f * a.af_stride + (int64_t)h * cN + (s_ci[4 * sl] + r);
+        p0 = fp + (int64_t)a.crows * s_ci[4 * sl + 2];
+        p1 = fp + (int64_t)a.crows * s_ci[4 * sl + 3];
+        w = s_cw[sl];
+        dst = on ? (sl * CU_ROWS + r) * (CU_F * 24) + rem : -1;
+    };
+    auto stage_issue = [&](int d, int buf, double& v0, double& v1) {
         int tq = tid;
-        asm volatile("" : "+v"(tq));        // (opaque per call: the items' addresses are made again every day, or hipcc keeps
-                                            // eight 64-bit pointers and their parts alive across the whole day loop: 84 B of scratch)
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int q = tq + i * NT;
-            const int h = q % 24, f = (q / 24) % CU_F, r = (q / (24 * CU_F)) % CU_ROWS, sl = q / CU_SLOT;
-            const bool on = q < ITEMS && r < s_ci[4 * sl + 1] && f != TF_TDEW;     // rows / slots the tile does not touch: nothing
-            v0[i] = v1[i] = 0.0;
-            if (on) {
-                const double* fp = qd + (int64_t)f * a.af_stride + (int64_t)h * cN + (s_ci[4 * sl] + r);
-                v0[i] = fp[(int64_t)a.crows * s_ci[4 * sl + 2]];
-                v1[i] = fp[(int64_t)a.crows * s_ci[4 * sl + 3]];
-            }
+        asm volatile("" : "+v"(tq));        // (opaque per call: or hipcc keeps the items' 64-bit addresses alive across the day loop)
+        int dst;
+        const double *p0, *p1;
+        double w;
+        stage_item(tq, d, dst, p0, p1, w);
+        v0 = v1 = 0.0;
+        if (dst >= 0) { v0 = *p0; v1 = *p1; }
+        const int items = (s_ci[1] + s_ci[5]) * (CU_F * 24);
+        for (int q = tq + NT; q < items; q += NT) {       // workgroup-uniform trip count; normally zero
+            stage_item(q, d, dst, p0, p1, w);
+            if (dst >= 0) s_cu[buf * (2 * CU_SLOT) + dst] = CoarseTap::mix(*p0, *p1, w);
         }
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int q = tq + i * NT;
-            if (q < ITEMS) dst[q] = CoarseTap::mix(v0[i], v1[i], s_cw[q / CU_SLOT]);
-        }
+    };
+    auto stage_commit = [&](int d, int buf, double v0, double v1) {
+        int tq = tid;
+        asm volatile("" : "+v"(tq));
+        int dst;
+        const double *p0, *p1;
+        double w;
+        stage_item(tq, d, dst, p0, p1, w);
+        if (dst >= 0) s_cu[buf * (2 * CU_SLOT) + dst] = CoarseTap::mix(v0, v1, w);
     };
     if (CLDS) {
         // the tile's two column slots: slot 0 = the raster column of its first cell, slot 1 = the next one, from the cell at
@@ -703,7 +715,9 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
             }
         }
         __syncthreads();
-        stage_coarse(day0, 0);
+        double v0, v1;
+        stage_issue(day0, 0, v0, v1);
+        stage_commit(day0, 0, v0, v1);
         __syncthreads();
     }
     enter_layer(day0);
@@ -756,7 +770,8 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
                 pre[i] = src[q < TF_COUNT * 24 ? q : TF_COUNT * 24 - 1];
             }
         }
-        if (CLDS && dl + 1 < ndays) stage_coarse(dabs + 1, (run + 1) & 1);
+        double cs0 = 0.0, cs1 = 0.0;        // CLDS: the lane's staging item of the next day, in flight across pass 1
+        if (CLDS && dl + 1 < ndays) stage_issue(dabs + 1, (run + 1) & 1, cs0, cs1);
         TimeVals tv;
         // the tile-day block of the tiled forcing ring (uniform) — the lane's value of series f is at [f][pos]
         const double* fday = (AF == 1) ? a.af_base + tile * a.af_tile_stride + (int64_t)(dabs - a.day0) * a.af_day_stride : nullptr;
@@ -893,6 +908,7 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
                 __hip_atomic_fetch_max(&ext[2][cl], rmx3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
+        if (CLDS && dl + 1 < ndays) stage_commit(dabs + 1, (run + 1) & 1, cs0, cs1);
         if (stage) {
             double* dst = s_time + ((run + 1) % 3) * (TF_COUNT * 24);
 #pragma unroll
