@@ -28,11 +28,18 @@
 #include "mcf_snow_device.hpp"
 
 #ifndef MCF_MICRO_WAVES
-#define MCF_MICRO_WAVES 2   // waves per SIMD the snow-microclimate kernels are built for (232 VGPRs); 3: 168 VGPRs + 260 B scratch per lane
+#define MCF_MICRO_WAVES 2   // waves per SIMD the lane-per-(cell, day) snow-microclimate kernels are built for (204 VGPRs); the ring
+                            // kernel (lane per cell-hour, cell table in LDS) is built for 3: 168 VGPRs, no scratch
 #endif
+// waves per SIMD k_snowmodel is built for.  Round 4: with the cell's constants read from the workgroup's LDS table at their uses
+// and the five output streams addressed as uniform base + 32-bit lane offset, the data.frame kernel fits 128 VGPRs without
+// scratch (156 in round 3: three waves); the array-climate kernel derives the step's weather terms per lane and stays at three
+// (168 VGPRs + 96 B of scratch; 232 B in round 3).
 #ifndef MCF_SNOW_WAVES
-#define MCF_SNOW_WAVES 3   // waves per SIMD k_snowmodel is built for (151 VGPRs); 4 (128 VGPRs + 100 B scratch per lane)
-                           // measured the same: 8.2 - 8.4 ms per 1024 x 1024 x 120-step chunk either way
+#define MCF_SNOW_WAVES 4
+#endif
+#ifndef MCF_SNOW_WAVES_AF
+#define MCF_SNOW_WAVES_AF 3
 #endif
 #include "mcf_terrain.h"
 
@@ -152,7 +159,7 @@ struct ModelArgs {
 };
 
 template <bool AF>
-__global__ __launch_bounds__(256, MCF_SNOW_WAVES) void k_snowmodel(ModelArgs a) {
+__global__ __launch_bounds__(256, AF ? MCF_SNOW_WAVES_AF : MCF_SNOW_WAVES) void k_snowmodel(ModelArgs a) {
     snow::snow_tables_init();
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.N) return;
@@ -174,9 +181,16 @@ __global__ __launch_bounds__(256, MCF_SNOW_WAVES) void k_snowmodel(ModelArgs a) 
         if (a.meltg) a.meltg[c] = NA;
         return;
     }
-    CellV cv;
-    cv.pai = a.pai[c]; cv.hgt = hgt0; cv.clump = a.clump[c]; cv.ltra = a.leaft[c]; cv.skyview = a.skyview[c];
-    cv.site = site_derive(a.slope[c], a.aspect[c]);
+    // the cell's constants into the workgroup's LDS table (lane = column): read inside the step where they are used
+    __shared__ double s_cv[CV_COUNT][256];
+    {
+        const int l = threadIdx.x;
+        const double slope = a.slope[c];
+        const SiteK sk = site_derive(slope, a.aspect[c]);
+        s_cv[CV_PAI][l] = a.pai[c]; s_cv[CV_HGT][l] = hgt0; s_cv[CV_CLUMP][l] = a.clump[c]; s_cv[CV_LTRA][l] = a.leaft[c];
+        s_cv[CV_SKYVIEW][l] = a.skyview[c];
+        s_cv[CV_CS][l] = sk.cS; s_cv[CV_SS][l] = sk.sS; s_cv[CV_CA][l] = sk.cA; s_cv[CV_SA][l] = sk.sA; s_cv[CV_SLOPE][l] = slope;
+    }
     double sinlat = 0.0, coslat = 0.0, lon = 0.0;
     if (AF) {
         const double latr = a.lats[c] * kPi / 180.0;
@@ -198,6 +212,11 @@ __global__ __launch_bounds__(256, MCF_SNOW_WAVES) void k_snowmodel(ModelArgs a) 
     DayT dy;
     for (int k = 0; k < a.tsteps; ++k) {
         const int64_t o = c + N * k;
+        // (an opaque lane index per step: the table's values are read at their uses, not hoisted in front of the loop)
+        int li = (int)threadIdx.x;
+        asm volatile("" : "+v"(li));
+        CellV cv;
+        cv.p = &s_cv[0][li]; cv.cs = 256;
         double tc, prec;
         if (AF) {
             tc = a.temp[o]; prec = a.precip[o];
@@ -249,11 +268,19 @@ __global__ __launch_bounds__(256, MCF_SNOW_WAVES) void k_snowmodel(ModelArgs a) 
             meltc = meltc + gdiv(po.melc * 1000.0, s.sdenc);   // densities are >= 1000 sdp[1] > 0 (or NaN)
             meltg = meltg + gdiv(po.melg * 1000.0, s.sdeng);
         }
-        if (a.Tc) a.Tc[o] = vTc;
-        if (a.Tg) a.Tg[o] = vTg;
-        if (a.sdepc) a.sdepc[o] = vdc;
-        if (a.sdepg) a.sdepg[o] = vdg;
-        if (a.sden) a.sden[o] = vden;
+        // the step's slab of an output is a uniform base (scalar registers) + the lane's 32-bit byte offset: no 64-bit vector
+        // address per series kept across the loop (N * 8 < 4 GB: checked by the host)
+        {
+            uint32_t cb = (uint32_t)c * 8u;
+            asm volatile("" : "+v"(cb));
+            const int64_t so = N * k;
+            auto st = [&](double* base, double v) { *(double*)((char*)(base + so) + cb) = v; };
+            if (a.Tc) st(a.Tc, vTc);
+            if (a.Tg) st(a.Tg, vTg);
+            if (a.sdepc) st(a.sdepc, vdc);
+            if (a.sdepg) st(a.sdepg, vdg);
+            if (a.sden) st(a.sden, vden);
+        }
     }
     if (a.agec) a.agec[c] = (double)s.agec;
     if (a.ageg) a.ageg[c] = (double)s.ageg;
@@ -353,6 +380,7 @@ __global__ __launch_bounds__(256, MCF_MICRO_WAVES) void k_microsnow(MicroArgs a)
                  leafden = a.leafden[c], svfa = a.skyview[c];
     const double lnclump = clump > 0.0 ? glog(clump) : 0.0;
     const double ihgt = gdiv(1.0, hgt), ileafd = gdiv(1.0, leafd), ipai = gdiv(1.0, pai);
+    const double cellv[MQ_COUNT] = {hgt, pai, paia, leafd, clump, ltra, leafden, svfa, lnclump, ihgt, ileafd, ipai};
     double sinlat = 0.0, coslat = 0.0, lon = 0.0, mxtc;
     int hs = 0;
     if (AF) {
@@ -396,8 +424,7 @@ __global__ __launch_bounds__(256, MCF_MICRO_WAVES) void k_microsnow(MicroArgs a)
             q.reqhgt = reqhgts; q.zref = a.zref;
             q.tc = a.temp[f]; q.pk = a.pres[f]; q.u2 = a.windspeed[f];
             q.Rsw = a.swdown[f]; q.Rdif = a.difrad[f]; q.Rlw = a.lwdown[f]; q.umu = a.umu[f];
-            q.hgt = hgt; q.pai = pai; q.paia = paia; q.leafd = leafd; q.clump = clump; q.ltra = ltra;
-            q.leafden = leafden; q.svfa = svfa; q.lnclump = lnclump; q.ihgt = ihgt; q.ileafd = ileafd; q.ipai = ipai;
+            q.cell = cellv; q.cs = 1;
             q.Tg = a.sTg[o]; q.Tc = a.sTc[o]; q.sden = a.sden[o]; q.sdepg = a.sdepg[o];
             q.sdepc = a.swe[o] / q.sden;
             q.alb = alb;
@@ -466,58 +493,100 @@ struct MicroRingArgs {
     const int32_t *daymap, *nosnow;
     int32_t ndays;
 };
-__global__ __launch_bounds__(256, MCF_MICRO_WAVES) void k_microsnow_ring(MicroRingArgs q) {
+// Shape (round 4): one lane per (cell, hour).  A workgroup is 64 consecutive cells x one day of the chunk (blockIdx.y: the
+// step rows are wave-uniform scalar loads); wave w takes the hours w, w + 4, ..., w + 20.  What depends on the cell only —
+// the raw rasters and what is derived from them (the slope / aspect sines and cosines, log(clump), three reciprocals), the
+// day's mean ground-snow temperature — is made ONCE per workgroup-day, a quarter by each wave, into LDS, and read from there
+// inside the hour loop: until round 3 a lane walked the 24 hours of its cell with all of it in registers (230 VGPRs, two
+// waves per SIMD).
+enum MicroCell : int { MC_HGT, MC_PAI, MC_PAIA, MC_LEAFD, MC_CLUMP, MC_LTRA, MC_LEAFDEN, MC_SVFA, MC_LNCLUMP, MC_IHGT, MC_ILEAFD,
+                       MC_IPAI, MC_CS, MC_SS, MC_CA, MC_SA, MC_SLOPE, MC_MEAND, MC_SMAX, MC_TZD, MC_COUNT };
+static_assert(MC_HGT == MQ_HGT && MC_PAI == MQ_PAI && MC_PAIA == MQ_PAIA && MC_LEAFD == MQ_LEAFD && MC_CLUMP == MQ_CLUMP &&
+              MC_LTRA == MQ_LTRA && MC_LEAFDEN == MQ_LEAFDEN && MC_SVFA == MQ_SVFA && MC_LNCLUMP == MQ_LNCLUMP &&
+              MC_IHGT == MQ_IHGT && MC_ILEAFD == MQ_ILEAFD && MC_IPAI == MQ_IPAI, "micro_above reads the table's first rows");
+__global__ __launch_bounds__(256, 3) void k_microsnow_ring(MicroRingArgs q) {
     snow::snow_tables_init();
+    __shared__ double s_mc[MC_COUNT][64];
     const MicroArgs& a = q.m;
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t N = a.N;
-    if (c >= N) return;
+    const int64_t c = (int64_t)blockIdx.x * 64 + lane;
     const int day = (int)blockIdx.y;             // uniform: the day's rows of the step tables are scalar loads
     const int sub = q.daymap[day];
     if (sub < 0) return;
     const bool keep = q.nosnow[day] != 0;        // the solver ran this day: snow-free cell-steps keep its values
     const double NA = na_real();
+    const bool inr = c < N;
+    const int64_t cc = inr ? c : N - 1;          // lanes past the raster read the last cell and write nothing
+    const int k0 = day * 24;
+    // ---- the workgroup-day's cell table
+    if (wv == 0) {
+        const double hgt = a.hgt[cc], pai = a.pai[cc], leafd = a.leafd[cc];
+        s_mc[MC_HGT][lane] = hgt; s_mc[MC_PAI][lane] = pai; s_mc[MC_LEAFD][lane] = leafd;
+        s_mc[MC_IHGT][lane] = gdiv(1.0, hgt); s_mc[MC_ILEAFD][lane] = gdiv(1.0, leafd); s_mc[MC_IPAI][lane] = gdiv(1.0, pai);
+        s_mc[MC_PAIA][lane] = a.paia[cc]; s_mc[MC_LTRA][lane] = a.leaft[cc];
+    } else if (wv == 1) {
+        const double slope = a.slope[cc];
+        s_mc[MC_SLOPE][lane] = slope;
+        s_mc[MC_CS][lane] = cos(slope * kToRad); s_mc[MC_SS][lane] = sin(slope * kToRad);
+        s_mc[MC_LEAFDEN][lane] = a.leafden[cc]; s_mc[MC_SVFA][lane] = a.skyview[cc];
+    } else if (wv == 2) {
+        const double aspect = a.aspect[cc], clump = a.clump[cc];
+        s_mc[MC_CA][lane] = cos(aspect * kToRad); s_mc[MC_SA][lane] = sin(aspect * kToRad);
+        s_mc[MC_CLUMP][lane] = clump;
+        s_mc[MC_LNCLUMP][lane] = clump > 0.0 ? glog(clump) : 0.0;
+    } else {
+        // snowdayan's daily mean of the ground-snow temperature (its NA test looks at the FIRST step of the whole series,
+        // cpp:4700; a chunk sees its own days only: the first step of the day — equal unless a cell's ground-snow
+        // temperature turns NA part way, which gridmodelsnow never does)
+        double Tzd = NA;
+        if (!isnan(a.sTg[cc + N * k0])) {
+            double sumd = 0.0;
+            for (int h = 0; h < 24; ++h) sumd += a.sTg[cc + N * (k0 + h)];
+            Tzd = sumd / 24.0;
+        }
+        s_mc[MC_TZD][lane] = Tzd;
+        s_mc[MC_MEAND][lane] = a.meanD[cc];
+        s_mc[MC_SMAX][lane] = a.Smax ? a.Smax[cc] : 0.0;
+    }
+    __syncthreads();
+    if (!inr) return;
     // the cell's place in the ring: its tile's block of this day, then the solver's lane position of (cell, hour)
     const int cpb = q.ring.cpb;
     const uint32_t tile = (uint32_t)c / (uint32_t)cpb;
     const int cell = (int)((uint32_t)c - tile * (uint32_t)cpb);
     const int64_t blk = (int64_t)tile * q.ring.tile_stride + (int64_t)day * q.ring.day_stride;
-    auto put = [&](int i, int h, double v) { q.obase[i][blk + mcf::ring_pos(cpb, cell, h)] = v; };
-    const double hgt = a.hgt[c];
-    const int k0 = day * 24;
-    if (isnan(hgt)) {            // cpp:4988-4989: the cell is skipped — the blank template's NA unless the solver wrote it
-        if (!keep)
-            for (int h = 0; h < 24; ++h)
-                for (int i = 0; i < MCF_NOUT; ++i) if (q.obase[i]) put(i, h, NA);
-        return;
-    }
-    double Tzd = NA;
-    if (!isnan(a.sTg[c + N * k0])) {
-        double sumd = 0.0;
-        for (int h = 0; h < 24; ++h) sumd += a.sTg[c + N * (k0 + h)];
-        Tzd = sumd / 24.0;
-    }
-    // (snowdayan's NA test looks at the FIRST step of the whole series, cpp:4700; a chunk sees its own days only: the
-    // first step of the day — equal unless a cell's ground-snow temperature turns NA part way, which gridmodelsnow never does)
-    const double meanD = a.meanD[c];
-    const SiteK site = site_derive(a.slope[c], a.aspect[c]);
-    const double pai = a.pai[c], paia = a.paia[c], leafd = a.leafd[c], clump = a.clump[c], ltra = a.leaft[c],
-                 leafden = a.leafden[c], svfa = a.skyview[c];
-    const double lnclump = clump > 0.0 ? glog(clump) : 0.0;
-    const double ihgt = gdiv(1.0, hgt), ileafd = gdiv(1.0, leafd), ipai = gdiv(1.0, pai);
-    for (int h = 0; h < 24; ++h) {
-        const int64_t o = c + N * (k0 + h);          // chunk-local
-        const int f = sub * 24 + h;                   // step of the snow-day subset series
-        if (!(a.swe[o] > 0.0)) {                      // cpp:4993
+    for (int h = wv; h < 24; h += 4) {
+        // (an opaque lane index per hour: the table is read where a value is used, not hoisted into registers in front of the loop;
+        // an opaque block offset: or the ten variables' per-lane store addresses are kept across the loop — twenty registers)
+        int li = lane;
+        asm volatile("" : "+v"(li));
+        int64_t bo = blk;
+        asm volatile("" : "+v"(bo));
+        auto put = [&](int i, int hh, double v) { q.obase[i][bo + mcf::ring_pos(cpb, cell, hh)] = v; };
+        auto MC = [&](int f) { return s_mc[f][li]; };
+        const double hgt = MC(MC_HGT);
+        if (isnan(hgt)) {            // cpp:4988-4989: the cell is skipped — the blank template's NA unless the solver wrote it
             if (!keep)
                 for (int i = 0; i < MCF_NOUT; ++i) if (q.obase[i]) put(i, h, NA);
             continue;
         }
-        const double reqhgts = a.reqhgt - a.sdepg[o];
+        const int64_t o = c + N * (k0 + h);          // chunk-local
+        const int f = sub * 24 + h;                   // step of the snow-day subset series
+        const double swe = a.swe[o];
+        if (!(swe > 0.0)) {                           // cpp:4993
+            if (!keep)
+                for (int i = 0; i < MCF_NOUT; ++i) if (q.obase[i]) put(i, h, NA);
+            continue;
+        }
+        const double sdepg = a.sdepg[o], sTg = a.sTg[o];
+        const double reqhgts = a.reqhgt - sdepg;
         double v[MCF_NOUT];
         if (reqhgts >= 0.0) {
             const StepRow& r = a.rows[f];
             const SunT sun = r.s;
+            SiteK site;
+            site.cS = MC(MC_CS); site.sS = MC(MC_SS); site.cA = MC(MC_CA); site.sA = MC(MC_SA); site.flat = MC(MC_SLOPE) == 0.0;
             MicroIn mi;
             mi.si = solar_index(sun, site, true);
             if (isnan(mi.si)) mi.si = sun.cz;                          // cpp:5002
@@ -526,20 +595,19 @@ __global__ __launch_bounds__(256, MCF_MICRO_WAVES) void k_microsnow_ring(MicroRi
             mi.reqhgt = reqhgts; mi.zref = a.zref;
             mi.tc = a.temp[f]; mi.pk = a.pres[f]; mi.u2 = a.windspeed[f];
             mi.Rsw = a.swdown[f]; mi.Rdif = a.difrad[f]; mi.Rlw = a.lwdown[f]; mi.umu = a.umu[f];
-            mi.hgt = hgt; mi.pai = pai; mi.paia = paia; mi.leafd = leafd; mi.clump = clump; mi.ltra = ltra;
-            mi.leafden = leafden; mi.svfa = svfa; mi.lnclump = lnclump; mi.ihgt = ihgt; mi.ileafd = ileafd; mi.ipai = ipai;
-            mi.Tg = a.sTg[o]; mi.Tc = a.sTc[o]; mi.sden = a.sden[o]; mi.sdepg = a.sdepg[o];
-            mi.sdepc = a.swe[o] / mi.sden;
+            mi.cell = &s_mc[0][li]; mi.cs = 64;           // (MC_HGT .. MC_IPAI are MQ_HGT .. MQ_IPAI)
+            mi.Tg = sTg; mi.Tc = a.sTc[o]; mi.sden = a.sden[o]; mi.sdepg = sdepg;
+            mi.sdepc = swe / mi.sden;
             mi.alb = r.m.alb; mi.ialb = r.m.ialb;
             const MicroOut mo = micro_above(mi, a.mmet[f], sun);
             v[0] = mo.Tz; v[1] = mo.tleaf; v[2] = mo.rh; v[4] = mo.uz; v[5] = mo.Rbdown; v[6] = mo.Rddown;
             v[7] = mo.Rlwdn; v[8] = mo.Rdup; v[9] = mo.Rlwup;
         } else {
-            const double b = micro_below(reqhgts, meanD, a.sTg[o], Tzd, a.mat, a.hiy);
+            const double b = micro_below(reqhgts, MC(MC_MEAND), sTg, MC(MC_TZD), a.mat, a.hiy);
             v[0] = b; v[1] = b; v[2] = 100.0;
             v[4] = v[5] = v[6] = v[7] = v[8] = v[9] = 0.0;
         }
-        v[3] = a.Smax ? a.Smax[c] : 0.0;
+        v[3] = MC(MC_SMAX);
 #pragma unroll
         for (int i = 0; i < MCF_NOUT; ++i) {
             if (!q.obase[i]) continue;
@@ -844,6 +912,8 @@ int common_checks(const mcf_snow_inputs* in) {
     if (!in) return mcf::api_fail(MCF_ERR_ARG, "null snow inputs");
     if (in->rows <= 0 || in->cols <= 0 || in->tsteps <= 0) return mcf::api_fail(MCF_ERR_ARG, "bad snow dimensions");
     if (in->tsteps > (1 << 30)) return mcf::api_fail(MCF_ERR_ARG, "tsteps too large");
+    // (the snow kernels address a step's slab as uniform base + 32-bit lane byte offset)
+    if (in->rows * in->cols >= ((int64_t)1 << 29)) return mcf::api_fail(MCF_ERR_ARG, "at most 2^29 - 1 cells per snow call (row-tile larger rasters)");
     if (!in->obstime.year || !in->obstime.month || !in->obstime.day || !in->obstime.hour)
         return mcf::api_fail(MCF_ERR_ARG, "null obstime");
     return MCF_OK;
@@ -2031,7 +2101,7 @@ extern "C" int mcf_snowplan_microsnow(mcf_snowplan* sp, mcf_plan* plan, int32_t 
     }
     for (int v = 0; v < MCF_NOUT; ++v) q.sel[v] = sp->outsel[v];
     q.daymap = sp->d_daymap; q.nosnow = sp->d_nosnow; q.ndays = nd;
-    hipLaunchKernelGGL(k_microsnow_ring, dim3((unsigned)((N + 255) / 256), (unsigned)nd), dim3(256), 0, nullptr, q);
+    hipLaunchKernelGGL(k_microsnow_ring, dim3((unsigned)((N + 63) / 64), (unsigned)nd), dim3(256), 0, nullptr, q);
     S_TRY(hipGetLastError());
     S_TRY(hipDeviceSynchronize());
     return MCF_OK;

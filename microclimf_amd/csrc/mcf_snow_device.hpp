@@ -291,7 +291,19 @@ __device__ __forceinline__ double snow_albedo(int hs) {
 // ---- snowpack state and one step of snowoneB ----------------------------------------------------
 struct Pack { double sdenc, sdeng, sdepc, sdepg; int agec, ageg; };
 struct PackOut { double Tc, Tg, melc, melg; };
-struct CellV { double pai, hgt, clump, ltra, skyview; SiteK site; };
+// the cell's constants (rasters, slope / aspect sines and cosines), read through `p[f * cs]` AT THEIR USES: k_snowmodel keeps
+// them in its workgroup's LDS table (cs = 256) — nine doubles fewer per lane across the whole step
+enum CellVF : int { CV_PAI, CV_HGT, CV_CLUMP, CV_LTRA, CV_SKYVIEW, CV_CS, CV_SS, CV_CA, CV_SA, CV_SLOPE, CV_COUNT };
+struct CellV {
+    const double* p;
+    int cs;
+    __device__ __forceinline__ double C(int f) const { return p[f * cs]; }
+    __device__ __forceinline__ SiteK site() const {
+        SiteK k;
+        k.cS = C(CV_CS); k.sS = C(CV_SS); k.cA = C(CV_CA); k.sA = C(CV_SA); k.flat = C(CV_SLOPE) == 0.0;
+        return k;
+    }
+};
 
 __device__ __forceinline__ double snow_density(const double* sdp, double depth, double age_h) {  // cpp:3952-3955
     return ((sdp[0] - sdp[1]) * (1.0 - gexp(-sdp[2] * depth * (1.0 / 100.0) - sdp[3] * age_h * (1.0 / 24.0))) + sdp[1]) * 1000.0;
@@ -301,13 +313,13 @@ __device__ __forceinline__ double snow_density(const double* sdp, double depth, 
 __device__ __forceinline__ void pack_step(const MetT& m, const DayT& dy, const SunT& sun, const CellV& c, double ha,
                                           double ws, const double* sdp, double zref, Pack& s, PackOut& o) {
     // ground heat flux of the cell from the point model's (cpp:4341-4354)
-    double paip = c.pai;
-    const double ihgt = gdiv(1.0, c.hgt > 0.0 ? c.hgt : 1.0);      // only used under hgt > sdepg >= 0
-    const bool emerged = c.hgt > s.sdepg;
-    if (emerged) paip = paip * (c.hgt - s.sdepg) * ihgt;
+    double paip = c.C(CV_PAI);
+    const double ihgt = gdiv(1.0, c.C(CV_HGT) > 0.0 ? c.C(CV_HGT) : 1.0);      // only used under hgt > sdepg >= 0
+    const bool emerged = c.C(CV_HGT) > s.sdepg;
+    if (emerged) paip = paip * (c.C(CV_HGT) - s.sdepg) * ihgt;
     const double dtR = dy.rmx - dy.rmn;
     const double epaip = gexp(-paip);                  // = exp(-pai) of the ground pack's sublimation below when `emerged`
-    const double trS = c.skyview * epaip;
+    const double trS = c.C(CV_SKYVIEW) * epaip;
     const double dmxS = trS * dy.rswmx + trS * dy.rlwmx + (1 - trS) * m.rem - m.rem;
     const double dmnS = trS * dy.rswmn + trS * dy.rlwmn + (1 - trS) * m.rem - m.rem;
     double G = m.gp * ((dmxS - dmnS) / dtR);       // IEEE: dtR is 0 past the last whole day (0/0 = NaN there)
@@ -317,28 +329,28 @@ __device__ __forceinline__ void pack_step(const MetT& m, const DayT& dy, const S
     double smu = 1.0;
     if (ha > sun.tansa) smu = 0.0;
     const double u2p = m.umu * ws * m.u2;
-    const double Rdif = m.rdif * c.skyview;
+    const double Rdif = m.rdif * c.C(CV_SKYVIEW);
     const double Rsw = (m.rsw - m.rdif) * smu + Rdif;
-    const double Rlw = m.rlw * c.skyview;
+    const double Rlw = m.rlw * c.C(CV_SKYVIEW);
     // vegetation above the ground snow (cpp:3840-3852)
     double pai = 0.0;
     if (emerged) pai = paip;                           // the same expression, cpp:3841 / 4343
-    double hgt = c.hgt - s.sdepg;
+    double hgt = c.C(CV_HGT) - s.sdepg;
     if (hgt < 0.0) hgt = 0.0;
     double zi = 0.0;
     if (s.sdepg > 0.0 && hgt > 0.0) zi = gdiv((s.sdepc - s.sdepg) * s.sdenc, hgt * 1000.0);
-    double ltra = c.ltra * gexp(-10.1 * zi);
+    double ltra = c.C(CV_LTRA) * gexp(-10.1 * zi);
     // radoneB (cpp:3773-3833)
     const double RlwabsC = 0.97 * Rlw;
     double RlwabsG = RlwabsC;
-    const double cld = c.clump * c.clump;
-    const double pait = gdiv(pai, 1.0 - c.clump);
+    const double cld = c.C(CV_CLUMP) * c.C(CV_CLUMP);
+    const double pait = gdiv(pai, 1.0 - c.C(CV_CLUMP));
     const double ept = gexp(-pait);
     const double tr = (1.0 - cld) * ept + cld;
     if (hgt > 0.0) RlwabsG = 0.97 * (tr * Rlw + (1.0 - tr) * m.rcan);
     double RabsC = RlwabsC, RswabsG = 0.0;
     if (Rsw > 0.0) {
-        const double si = solar_index(sun, c.site, false);
+        const double si = solar_index(sun, c.site(), false);
         double Rbeam = gdiv(Rsw - Rdif, sun.cosz);
         if (Rbeam > 1352.2) Rbeam = 1352.2;
         const double RswabsC = (1.0 - m.alb) * (Rdif + Rbeam * sun.cosz);
@@ -349,7 +361,7 @@ __device__ __forceinline__ void pack_step(const MetT& m, const DayT& dy, const S
             const TsDif f = ts_dif(pait, m.alb, ltra, m.alb, m.ialb);
             const CanK kp = cank1(sun.kx, sun.kcos, si);
             const TsDir d = ts_dir(pait, f, m.alb, kp.kd);
-            const double clb = gpow0(c.clump, kp.Kc);
+            const double clb = gpow0(c.C(CV_CLUMP), kp.Kc);
             const double ehp = f.iS1;                       // exp(h pait) = 1 / S1
             const double ekp = d.S2;                        // exp(-kd pait), ts_dir's own
             const double Rddm = clamp01((1.0 - cld) * (f.p3 * f.S1 + f.p4 * ehp) + cld);
@@ -494,10 +506,16 @@ __device__ __forceinline__ MicroMet micro_met(double tc, double relhum, double p
     m.ipk = gdiv(1.0, pk);
     return m;
 }
+// the cell's values: raw rasters, glog(clump) where clump > 0, three reciprocals.  Read through `cell[f * cs]` AT THEIR USES:
+// k_microsnow_ring points this at its workgroup's LDS table (cs = 64), so that a value occupies registers only around its
+// use; the lane-per-(cell, day) kernels point it at a local array (cs = 1: registers, as before).
+enum MicroCellF : int { MQ_HGT, MQ_PAI, MQ_PAIA, MQ_LEAFD, MQ_CLUMP, MQ_LTRA, MQ_LEAFDEN, MQ_SVFA, MQ_LNCLUMP, MQ_IHGT, MQ_ILEAFD, MQ_IPAI,
+                        MQ_COUNT };
 struct MicroIn {
     double reqhgt, zref, tc, pk, u2, Rsw, Rdif, Rlw;               // step
-    double hgt, pai, paia, leafd, clump, ltra, leafden, svfa;      // cell
-    double lnclump, ihgt, ileafd, ipai;                            // glog(clump) where clump > 0; reciprocals (cell)
+    const double* cell;
+    int cs;
+    __device__ __forceinline__ double C(int f) const { return cell[f * cs]; }
     double si, ws, umu;
     int shadowmask;
     double Tg, Tc, sdepc, sdepg, sden, alb, ialb;                  // snowpoint2; ialb = 1 / alb
@@ -604,80 +622,89 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
     double reqhgt = q.reqhgt;
     if (reqhgt == 0.0) reqhgt = 0.001;
     const double es = mm.es, ea = mm.ea, tdew = mm.tdew;
-    double hgts = q.hgt - q.sdepg;
+    double hgts = q.C(MQ_HGT) - q.sdepg;
     if (hgts < 0.0) hgts = 0.0;
     const double ipk = mm.ipk;
-    double pais = 0.0, d = 0.0, zm = 1e-5, wa = 0.0, ihgts = 0.0, frac = 0.0;
+    double pais = 0.0, ihgts = 0.0, frac = 0.0;
     if (hgts > 0.0) {                                            // windtiCpp cpp:1179-1187
-        frac = hgts * q.ihgt;                                    // hgt > sdepg >= 0 here
+        frac = hgts * q.C(MQ_IHGT);                                    // hgt > sdepg >= 0 here
         ihgts = gdiv(1.0, hgts);
-        pais = q.pai * frac;
-        d = zeroplane(hgts, pais);
-        zm = roughlen0(hgts, pais, d);
-        if (zm < 1e-6) zm = 1e-6;
-        wa = pais * ihgts;
+        pais = q.C(MQ_PAI) * frac;
     }
-    // windCpp cpp:1189-1218
-    double ws = q.ws;
-    if (isnan(ws)) ws = 1.0;
-    if (ws < 0.05) ws = 0.05;
-    const double izm = gdiv(1.0, zm);
-    double uf = gdiv(kKa * q.u2, glog((q.zref - d) * izm)) * q.umu * ws;
-    if (uf < 0.001) uf = 0.001;
-    double uz = uf;
-    if (reqhgt > 0) {
-        if (reqhgt >= hgts) {
-            uz = (uf * (1.0 / kKa)) * glog((reqhgt - d) * izm);
-        } else {
-            double uh = (uf * (1.0 / kKa)) * glog((hgts - d) * izm);
-            if (uh < uf) uh = uf;
-            double Be = gdiv(uf, uh);
-            if (Be < 0.001) Be = 0.001;
-            const double Lm = 2 * (Be * Be * Be) * gdiv(1.0, 0.25 * wa);
-            uz = uh * gexp(gdiv(Be * (reqhgt - hgts), Lm));
+    // Roughness and wind (windtiCpp, windCpp cpp:1189-1218, gturbCpp) read nothing the radiation block makes and the radiation
+    // block reads nothing of theirs: inside the canopy they are evaluated BEHIND it (same operations, same values) — five
+    // doubles fewer alive through the two-stream algebra, the fullest stretch of the function.
+    double d = 0.0, zm = 1e-5, uf, uz, gHa;
+    auto wind = [&]() {
+        double wa = 0.0;
+        if (hgts > 0.0) {
+            d = zeroplane(hgts, pais);
+            zm = roughlen0(hgts, pais, d);
+            if (zm < 1e-6) zm = 1e-6;
+            wa = pais * ihgts;
         }
-        if (uz > q.u2) uz = q.u2;
-    }
-    double gHa = gdiv(kKa * 43 * uf, glog(gdiv(q.zref - d, 0.2 * zm + d - d)));   // gturbCpp(.., 43, 0, 0.0001)
-    if (gHa < 0.0001) gHa = 0.0001;
-    out.uz = uz;
+        double ws = q.ws;
+        if (isnan(ws)) ws = 1.0;
+        if (ws < 0.05) ws = 0.05;
+        const double izm = gdiv(1.0, zm);
+        uf = gdiv(kKa * q.u2, glog((q.zref - d) * izm)) * q.umu * ws;
+        if (uf < 0.001) uf = 0.001;
+        uz = uf;
+        if (reqhgt > 0) {
+            if (reqhgt >= hgts) {
+                uz = (uf * (1.0 / kKa)) * glog((reqhgt - d) * izm);
+            } else {
+                double uh = (uf * (1.0 / kKa)) * glog((hgts - d) * izm);
+                if (uh < uf) uh = uf;
+                double Be = gdiv(uf, uh);
+                if (Be < 0.001) Be = 0.001;
+                const double Lm = 2 * (Be * Be * Be) * gdiv(1.0, 0.25 * wa);
+                uz = uh * gexp(gdiv(Be * (reqhgt - hgts), Lm));
+            }
+            if (uz > q.u2) uz = q.u2;
+        }
+        gHa = gdiv(kKa * 43 * uf, glog(gdiv(q.zref - d, 0.2 * zm + d - d)));   // gturbCpp(.., 43, 0, 0.0001)
+        if (gHa < 0.0001) gHa = 0.0001;
+        out.uz = uz;
+    };
     double ez;
     if (reqhgt >= hgts) {                                        // above the canopy, cpp:4768-4798
+        wind();
         if (q.Rsw > 0.0) {
-            out.Rddown = q.Rdif * q.svfa;
+            out.Rddown = q.Rdif * q.C(MQ_SVFA);
             if (q.si > 0.0 && q.shadowmask > 0) {
                 out.Rbdown = gdiv(q.Rsw - q.Rdif, q.si);
                 if (out.Rbdown > 1352.0) out.Rbdown = 1352.0;
-                out.Rdup = q.alb * q.Rsw * q.svfa;
+                out.Rdup = q.alb * q.Rsw * q.C(MQ_SVFA);
             } else {
                 out.Rbdown = 0.0;
-                out.Rdup = q.alb * q.Rdif * q.svfa;
+                out.Rdup = q.alb * q.Rdif * q.C(MQ_SVFA);
             }
         } else {
             out.Rbdown = 0.0; out.Rddown = 0.0; out.Rdup = 0.0;
         }
-        out.Rlwdn = q.svfa * q.Rlw;
-        out.Rlwup = q.svfa * 0.97 * kSb * rad4(q.Tc);
+        out.Rlwdn = q.C(MQ_SVFA) * q.Rlw;
+        out.Rlwup = q.C(MQ_SVFA) * 0.97 * kSb * rad4(q.Tc);
         const AboveTV tv = tv_above(reqhgt, q.zref, d, zm, q.Tc, q.tc, ea);
         out.Tz = tv.Tz;
         out.tleaf = q.Tc;
         ez = tv.ez;
     } else {                                                     // inside the canopy, cpp:4799-4857
-        const double paias = q.paia * frac;                      // (hgts > reqhgt > 0 here)
+        const double paias = q.C(MQ_PAIA) * frac;                      // (hgts > reqhgt > 0 here)
         double zi = 0.0;
         if (q.sdepg > 0.0) zi = ((q.sdepc - q.sdepg) * q.sden) * (ihgts * (1.0 / 1000.0));
-        double ltras = q.ltra * gexp(-10.1 * zi);
+        double ltras = q.C(MQ_LTRA) * gexp(-10.1 * zi);
         if ((ltras + q.alb) > 0.999) ltras = 0.999 - q.alb;
         // clumps = clump^(pais / pai) and its own powers through ONE logarithm: log(clumps) = (pais / pai) log(clump)
         const double ipais = gdiv(1.0, pais);
-        double clumps = q.clump, lncl = 0.0;
-        if (q.clump > 0.0) {
-            lncl = (pais * q.ipai) * q.lnclump;
+        double clumps = q.C(MQ_CLUMP), lncl = 0.0;
+        if (q.C(MQ_CLUMP) > 0.0) {
+            lncl = (pais * q.C(MQ_IPAI)) * q.C(MQ_LNCLUMP);
             clumps = gexp(lncl);
         }
         const double i1c = gdiv(1.0, 1.0 - clumps);
         double pait = pais;
-        if (q.clump > 0.0) pait = pais * i1c;
+        if (q.C(MQ_CLUMP) > 0.0) pait = pais * i1c;
         // twostreamdif (cpp:1034-1084) with lref = gref = snow albedo
         const double pait2 = pais * i1c;
         const TsDif f = ts_dif(pait2, q.alb, ltras, q.alb, q.ialb);
@@ -726,16 +753,17 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
                 if (Rbeam > 1352.0) Rbeam = 1352.0;
                 const double Rb = Rbeam * cosz;
                 Rbdown = (trb + (1.0 - trb) * ek_a) * Rbeam;
-                Rddown = Rddn_z * q.Rdif * q.svfa + Rdbdn_z * Rb;
-                Rdup = Rdup_z * q.Rdif * q.svfa + Rdbup_z * Rb;
+                Rddown = Rddn_z * q.Rdif * q.C(MQ_SVFA) + Rdbdn_z * Rb;
+                Rdup = Rdup_z * q.Rdif * q.C(MQ_SVFA) + Rdbup_z * Rb;
                 radLsw = 0.5 * (1.0 - f.om) * (Rddown + Rdup + kp.k * cosz * Rbdown);
             } else {
                 Rbdown = (q.Rsw - q.Rdif) * icosz;
-                Rddown = q.Rdif * q.svfa;
-                Rdup = q.alb * (q.Rdif * q.svfa + (q.Rsw - q.Rdif));
+                Rddown = q.Rdif * q.C(MQ_SVFA);
+                Rdup = q.alb * (q.Rdif * q.C(MQ_SVFA) + (q.Rsw - q.Rdif));
             }
         }
         if (q.shadowmask == 0) Rbdown = 0.0;
+        wind();
         // leaftemp (cpp:1333-1364) with gsmax = 999.999: gV = gh
         const double lwcan = 0.97 * kSb * rad4(q.Tc);
         const double lwgro = 0.97 * kSb * rad4(q.Tg);
@@ -743,7 +771,7 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
         const double lwup = eg * lwgro + (1 - eg) * lwcan;
         const double lwdn = eaa * q.Rlw + (1 - eaa) * lwcan;
         const double leafabs = radLsw + 0.97 * 0.5 * (lwup + lwdn);
-        const double ileafd = q.ileafd;
+        const double ileafd = q.C(MQ_ILEAFD);
         double gh = 0.135 * gsqrt(uz * ileafd) * 1.4;
         {   // mincondCpp(leafabs, 999.99, Tcan, leafd) cpp:1316-1331
             const double Rnet = leafabs - lwcan;
@@ -771,12 +799,12 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
         const double H = 29.3 * gHa * (q.Tc - q.tc);
         const double fr = 1.0 - gexp(-pais);
         const AboveTV tv = tv_above(hgts, q.zref, d, zm, q.Tc, q.tc, ea);
-        out.Tz = tv_below(bk, lnpai, q.leafden, H * fr, Hl, tv.Tz * 29.3 * 43.0, q.Tg * 29.3 * 43.0,
+        out.Tz = tv_below(bk, lnpai, q.C(MQ_LEAFDEN), H * fr, Hl, tv.Tz * 29.3 * 43.0, q.Tg * 29.3 * 43.0,
                           fabs(tleaf - tv.Tz) * 29.3 * 43.0) * (1.0 / (29.3 * 43));
         const double la = mm.lat0;
         const double mmg = la * (gHa * ipk);
         const double mu = la * (43 * ipk);
-        ez = tv_below(bk, lnpai, q.leafden, (mmg * (es - ea)) * fr, Ll, tv.ez * mu, svp(q.Tg) * mu,
+        ez = tv_below(bk, lnpai, q.C(MQ_LEAFDEN), (mmg * (es - ea)) * fr, Ll, tv.ez * mu, svp(q.Tg) * mu,
                       fabs(estl - tv.ez) * mu) * gdiv(1.0, mu);
         out.Rbdown = Rbdown; out.Rddown = Rddown; out.Rdup = Rdup;
         out.Rlwdn = lwdn; out.Rlwup = lwup;
