@@ -156,6 +156,15 @@ struct ModelArgs {
     const double *Gp, *Tcp, *RswabsG, *RlwabsG, *umu;                                     // [N][T]
     double *Tc, *Tg, *sdepc, *sdepg, *sden;   // [N][T] or null
     double *agec, *ageg, *meltc, *meltg;      // [N] or null
+    // `.snowmodel1`'s topographic redistribution and hand-over (R/internal.R:2589-2612) fused into the chunk's model run
+    // (tpic != null; the snow plan's chunk loop): the depths leave the kernel redistributed — sdepc holds totalSWE, sdepg the
+    // ground snow depth — and the state of the next chunk (pack depth, snow surface, the two ages) is written by the same lane.
+    // Until round 4 a second kernel re-read and re-wrote the chunk's three depth / density series: 10 GB per chunk of a
+    // 512 x 4096 block, 0.21 s of a simulated year.
+    const double *tpic, *dtm;
+    double tpimean;
+    double *isnowdc_out, *dtms;
+    int32_t *isnowac_out, *isnowag_out;
 };
 
 template <bool AF>
@@ -166,23 +175,53 @@ __global__ __launch_bounds__(256, AF ? MCF_SNOW_WAVES_AF : MCF_SNOW_WAVES) void 
     const int64_t N = a.N;
     const double NA = na_real();
     const double hgt0 = a.hgt[c];
+    // fused redistribution (see ModelArgs): the cell's tpi weight and the depths the chunk starts from
+    const bool redist = a.tpic != nullptr;
+    // (the cell's constants and the redistribution's state live in the workgroup's LDS table, lane = column: read — and the
+    // two running values written — inside the step where they are used, not carried in registers)
+    __shared__ double s_cv[CV_COUNT + 5][256];
+    enum { RV_TPI = CV_COUNT, RV_ASD, RV_ASC, RV_TOT, RV_GD };
+    {
+        const int l = threadIdx.x;
+        s_cv[RV_TPI][l] = redist ? a.tpic[c] / a.tpimean : 0.0;      // tpic / mean(tpic, na.rm = TRUE)
+        s_cv[RV_ASD][l] = redist ? a.isnowdg[c] : 0.0;
+        s_cv[RV_ASC][l] = redist ? a.isnowdc[c] : 0.0;
+        s_cv[RV_TOT][l] = 0.0; s_cv[RV_GD][l] = 0.0;
+    }
+    // (dc, dg, den) of a step -> what is stored: as they are, or redistributed (int:2593-2606; the operations of the former
+    // k_snow_redistribute in its order, also on an NA cell's NAs)
+    auto finish = [&](double& dc, double& dg, double den) {
+        if (!redist) return;
+        int l = threadIdx.x;
+        asm volatile("" : "+v"(l));
+        const double r_asd = s_cv[RV_ASD][l], r_asc = s_cv[RV_ASC][l];
+        const double dsnow = dg - r_asd;
+        double dsnow2 = dsnow * s_cv[RV_TPI][l];
+        if (dsnow < 0) dsnow2 = dsnow;
+        const double cdsnow = dc - r_asc - dsnow;
+        const double r_tot = r_asc + cdsnow + dsnow2, r_gd = r_asd + dsnow2;
+        s_cv[RV_TOT][l] = r_tot; s_cv[RV_GD][l] = r_gd;
+        dc = r_tot * den;
+        dg = r_gd;
+    };
     if (isnan(hgt0)) {   // cpp:4320-4321
         for (int k = 0; k < a.tsteps; ++k) {
             const int64_t o = c + N * k;
+            double dc = NA, dg = NA;
+            finish(dc, dg, NA);
             if (a.Tc) a.Tc[o] = NA;
             if (a.Tg) a.Tg[o] = NA;
-            if (a.sdepc) a.sdepc[o] = NA;
-            if (a.sdepg) a.sdepg[o] = NA;
+            if (a.sdepc) a.sdepc[o] = dc;
+            if (a.sdepg) a.sdepg[o] = dg;
             if (a.sden) a.sden[o] = NA;
         }
+        if (redist && a.tsteps > 0) { a.isnowdc_out[c] = s_cv[RV_TOT][threadIdx.x]; a.dtms[c] = a.dtm[c] + s_cv[RV_GD][threadIdx.x]; }
         if (a.agec) a.agec[c] = NA;
         if (a.ageg) a.ageg[c] = NA;
         if (a.meltc) a.meltc[c] = NA;
         if (a.meltg) a.meltg[c] = NA;
         return;
     }
-    // the cell's constants into the workgroup's LDS table (lane = column): read inside the step where they are used
-    __shared__ double s_cv[CV_COUNT][256];
     {
         const int l = threadIdx.x;
         const double slope = a.slope[c];
@@ -268,6 +307,7 @@ __global__ __launch_bounds__(256, AF ? MCF_SNOW_WAVES_AF : MCF_SNOW_WAVES) void 
             meltc = meltc + gdiv(po.melc * 1000.0, s.sdenc);   // densities are >= 1000 sdp[1] > 0 (or NaN)
             meltg = meltg + gdiv(po.melg * 1000.0, s.sdeng);
         }
+        finish(vdc, vdg, vden);
         // the step's slab of an output is a uniform base (scalar registers) + the lane's 32-bit byte offset: no 64-bit vector
         // address per series kept across the loop (N * 8 < 4 GB: checked by the host)
         {
@@ -286,6 +326,12 @@ __global__ __launch_bounds__(256, AF ? MCF_SNOW_WAVES_AF : MCF_SNOW_WAVES) void 
     if (a.ageg) a.ageg[c] = (double)s.ageg;
     if (a.meltc) a.meltc[c] = meltc;
     if (a.meltg) a.meltg[c] = meltg;
+    if (redist && a.tsteps > 0) {      // hand-over to the next chunk, int:2607-2612
+        a.isnowdc_out[c] = s_cv[RV_TOT][threadIdx.x];
+        a.dtms[c] = a.dtm[c] + s_cv[RV_GD][threadIdx.x];
+        a.isnowac_out[c] = s.agec;
+        a.isnowag_out[c] = s.ageg;
+    }
 }
 
 // ---- gridmicrosnow ---------------------------------------------------------------------------------
@@ -501,9 +547,9 @@ struct MicroRingArgs {
 // waves per SIMD).
 enum MicroCell : int { MC_HGT, MC_PAI, MC_PAIA, MC_LEAFD, MC_CLUMP, MC_LTRA, MC_LEAFDEN, MC_SVFA, MC_LNCLUMP, MC_IHGT, MC_ILEAFD,
                        MC_IPAI, MC_CS, MC_SS, MC_CA, MC_SA, MC_SLOPE, MC_MEAND, MC_SMAX, MC_TZD, MC_COUNT };
-static_assert(MC_HGT == MQ_HGT && MC_PAI == MQ_PAI && MC_PAIA == MQ_PAIA && MC_LEAFD == MQ_LEAFD && MC_CLUMP == MQ_CLUMP &&
-              MC_LTRA == MQ_LTRA && MC_LEAFDEN == MQ_LEAFDEN && MC_SVFA == MQ_SVFA && MC_LNCLUMP == MQ_LNCLUMP &&
-              MC_IHGT == MQ_IHGT && MC_ILEAFD == MQ_ILEAFD && MC_IPAI == MQ_IPAI, "micro_above reads the table's first rows");
+static_assert((int)MC_HGT == (int)MQ_HGT && (int)MC_PAI == (int)MQ_PAI && (int)MC_PAIA == (int)MQ_PAIA && (int)MC_LEAFD == (int)MQ_LEAFD && (int)MC_CLUMP == (int)MQ_CLUMP &&
+              (int)MC_LTRA == (int)MQ_LTRA && (int)MC_LEAFDEN == (int)MQ_LEAFDEN && (int)MC_SVFA == (int)MQ_SVFA && (int)MC_LNCLUMP == (int)MQ_LNCLUMP &&
+              (int)MC_IHGT == (int)MQ_IHGT && (int)MC_ILEAFD == (int)MQ_ILEAFD && (int)MC_IPAI == (int)MQ_IPAI, "micro_above reads the table's first rows");
 __global__ __launch_bounds__(256, 3) void k_microsnow_ring(MicroRingArgs q) {
     snow::snow_tables_init();
     __shared__ double s_mc[MC_COUNT][64];
@@ -724,39 +770,6 @@ __global__ __launch_bounds__(256) void k_tpi_fine(const double* __restrict__ z, 
 }
 // redistribution of the chunk's snow-depth changes and hand-over to the next chunk (int:2589-2614);
 // sdepc / sdepg are overwritten by totalSWE / groundsnowdepth
-struct RedistArgs {
-    int64_t N;
-    int nsteps;
-    const double* hgt;
-    const double *dtm, *tpic, *isnowdg, *sden, *agec, *ageg;
-    double tpimean;                 // mean(tpic, na.rm = TRUE) over the whole raster
-    double *sdepc, *sdepg;          // in: smod$sdepc / sdepg, out: swe / snowdepg   [N][nsteps]
-    double *isnowdc, *dtms;         // state for the next chunk
-    int32_t *isnowac, *isnowag;
-};
-__global__ __launch_bounds__(256) void k_snow_redistribute(RedistArgs a) {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.N) return;
-    const double tpi = a.tpic[c] / a.tpimean;   // tpic / mean(tpic, na.rm = TRUE)
-    const double asd = a.isnowdg[c], asc = a.isnowdc[c];
-    double tot = 0.0, gd = 0.0;
-    for (int k = 0; k < a.nsteps; ++k) {
-        const int64_t o = c + a.N * k;
-        const double dsnow = a.sdepg[o] - asd;
-        double dsnow2 = dsnow * tpi;
-        if (dsnow < 0) dsnow2 = dsnow;
-        const double cdsnow = a.sdepc[o] - asc - dsnow;
-        tot = asc + cdsnow + dsnow2;
-        gd = asd + dsnow2;
-        a.sdepc[o] = tot * a.sden[o];
-        a.sdepg[o] = gd;
-    }
-    a.isnowdc[c] = tot;
-    a.dtms[c] = a.dtm[c] + gd;
-    if (!isnan(a.agec[c])) a.isnowac[c] = (int32_t)a.agec[c];
-    if (!isnan(a.ageg[c])) a.isnowag[c] = (int32_t)a.ageg[c];
-}
-
 // applycpp3 (cpp:5553-5588): `parts` workgroups per time step stream fixed strided subsets of the cells (coalesced),
 // fixed-shape tree in LDS, partials combined in order by a second kernel -> deterministic; NaN cells are skipped
 __device__ __forceinline__ double apply3_combine(int fun, double a, double b) {
@@ -1504,12 +1517,10 @@ static int run_chunk_to(mcf_snowplan* sp, int32_t ch, double tpic_mean, const mc
     ModelArgs a = sp->a;
     a.rows = sp->rows_tab + k0;            // gridmodelsnow1 on the chunk (int:2587)
     a.tsteps = ns;
+    // ... with the redistribution by the topographic position index and the hand-over fused in (ModelArgs)
+    a.tpic = sp->d_tpic; a.tpimean = tpic_mean; a.dtm = sp->d_dtm;
+    a.isnowdc_out = sp->d_isnowdc; a.dtms = sp->d_dtms; a.isnowac_out = sp->d_ac; a.isnowag_out = sp->d_ag;
     hipLaunchKernelGGL(k_snowmodel<false>, dim3(gridN), dim3(256), 0, nullptr, a);
-    RedistArgs ra;
-    ra.N = N; ra.nsteps = ns; ra.hgt = a.hgt; ra.dtm = sp->d_dtm; ra.tpic = sp->d_tpic; ra.tpimean = tpic_mean;
-    ra.isnowdg = sp->d_isnowdg; ra.sden = a.sden; ra.agec = a.agec; ra.ageg = a.ageg; ra.sdepc = a.sdepc;
-    ra.sdepg = a.sdepg; ra.isnowdc = sp->d_isnowdc; ra.dtms = sp->d_dtms; ra.isnowac = sp->d_ac; ra.isnowag = sp->d_ag;
-    hipLaunchKernelGGL(k_snow_redistribute, dim3(gridN), dim3(256), 0, nullptr, ra);
     S_TRY(hipGetLastError());
     if (timing) {
         S_TRY(hipEventRecord(evs.e[1], nullptr));

@@ -23,12 +23,6 @@
 namespace mcf {
 namespace snow {
 
-#ifndef MCF_SNOW_LEAN
-#define MCF_SNOW_LEAN 1   // 0: plain device libm and IEEE division everywhere (the round-1 build)
-#endif
-#ifndef MCF_SNOW_TABLES
-#define MCF_SNOW_TABLES 1   // exp / log through the LDS tables of mcf_device.hpp (fexp_tab, flog_tab)
-#endif
 // The workgroup's copies of kExp2Tab / kLogTab: ONE static LDS array per kernel, reached from any depth of the call tree
 // through this accessor.  EVERY kernel that can reach gexp / glog / gpow0 calls snow_tables_init() first (before any early
 // return) — a kernel that did not would read uninitialised LDS; tests/test_snow_gpu.py runs each of them against the oracle.
@@ -37,23 +31,18 @@ __device__ __forceinline__ double* snow_tables() {
     return t;
 }
 __device__ __forceinline__ void snow_tables_init() {
-#if MCF_SNOW_TABLES
     double* t = snow_tables();
     const int n = (int)(blockDim.x * blockDim.y * blockDim.z), tid = (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z));
     for (int i = tid; i < 512; i += n) t[i] = kLogTab[i];
     for (int i = tid; i < 256; i += n) t[512 + i] = kExp2Tab[i];
     __syncthreads();
-#endif
 }
 __device__ __forceinline__ void snow_mathk(MathK& K) {
     K.set();
-#if MCF_SNOW_TABLES
-    double* t = snow_tables();
+    double* t = snow_tables();        // exp / log through the LDS tables of mcf_device.hpp (fexp_tab, flog_tab)
     K.ltab = t; K.logtab = true;
     K.tab = t + 512; K.table = true;
-#endif
 }
-#if MCF_SNOW_LEAN
 // exp(x) for NaN or |x| < 1e90: the table route saturates by itself (v_cvt_i32_f64 and v_ldexp_f64 saturate: exactly 0 for
 // very negative, inf for very positive arguments; NaN stays NaN).  Only an INFINITE argument would come out as NaN — none is
 // reachable: the one source of an infinity on this path, pai / (1 - clump) at clump = 1, is a NaN in the lean division
@@ -75,23 +64,13 @@ __device__ __forceinline__ double gsqrt(double x) {     // sqrt(x) for ANY opera
     return ::sqrt(x);
 }
 __device__ __forceinline__ double gdiv(double a, double b) { return fdiv(a, b); }   // b finite, non-zero by construction (or NaN)
-#else
-__device__ __forceinline__ double gexp(double x) { return ::exp(x); }
-__device__ __forceinline__ double glog(double x) { return ::log(x); }
-__device__ __forceinline__ double gsqrt(double x) { return ::sqrt(x); }
-__device__ __forceinline__ double gdiv(double a, double b) { return a / b; }
-#endif
 // pow(b, e) for b >= 0 and e > 0 (clump^Kc): pow(0, e) = 0
 __device__ __forceinline__ double gpow0(double b, double e) {
-#if MCF_SNOW_LEAN
     // b = 0 is the common special case (clump = 0: every bare cell, and a wave that holds one ran the device's 220-instruction
     // pow for all its lanes): pow(0, e > 0) = 0.  Anything else outside b > 0 (NaNs, e <= 0) still goes to libm.
     if (b > 0.0) return gexp(e * glog(b));
     if (b == 0.0 && e > 0.0) return 0.0;
     return ::pow(b, e);
-#else
-    return ::pow(b, e);
-#endif
 }
 
 __device__ __forceinline__ double svp(double tc) {  // cpp:480-490 satvapCpp
@@ -444,13 +423,8 @@ __device__ __forceinline__ void pack_step(const MetT& m, const DayT& dy, const S
         double uzm = gdiv(uh, h * k1) * (1 - gexp(-k1 * h));
         if (uzm < uf) uzm = uf;
         const double Lstr = m.sint * p;
-#if MCF_SNOW_LEAN
         const double tz = uzm * (1.0 / 0.8);
         const double kc = 0.5 * gsqrt(1.0 + tz * tz);              // 1 / (2 cos(atan(t))) = sqrt(1 + t^2) / 2
-#else
-        const double Z = atan(uzm / 0.8);
-        const double kc = 1.0 / (2.0 * cos(Z));
-#endif
         const double Cp = 1.0 - gexp(-kc * p);
         const double I1 = (Lstr - Li) * (1.0 - gexp(-gdiv(Cp, Lstr) * m.prec));
         cis = I1 * 0.678;
