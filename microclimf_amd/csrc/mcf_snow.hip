@@ -1173,6 +1173,13 @@ struct mcf_snowplan {
            *d_wsa = nullptr, *d_hor = nullptr, *d_tpic = nullptr, *d_mean2 = nullptr, *d_cm = nullptr, *d_ext = nullptr,
            *d_sumws = nullptr;
     int64_t ext_cap = 0, cm_cap = 0;
+    // the surface (own rows + halos) the terrain arrays were last derived from, and its geometry: a chunk that starts from the
+    // very same surface — every snow-free stretch of the year — keeps them (bit patterns compared on the device)
+    double* d_zlast = nullptr;
+    int64_t zlast_n = 0, zlast_cap = 0;
+    int32_t zlast_hn = -1, zlast_hs = -1;
+    int32_t* d_zdiff = nullptr;
+    int terrain_reused = 0, terrain_refreshed = 0;
     int32_t *d_ac = nullptr, *d_ag = nullptr;
     std::vector<double> wind;
     Downloader dl;
@@ -1341,6 +1348,13 @@ extern "C" int mcf_snowplan_surface_partial(mcf_snowplan* sp, double* sum, doubl
     *sum = h[0]; *count = h[1];
     return MCF_OK;
 }
+// 1 into *diff if the two surfaces differ in any bit (NaN cells compare by pattern)
+__global__ __launch_bounds__(256) void k_surface_differs(const double* __restrict__ a, const double* __restrict__ b, int64_t n,
+                                                         int32_t* __restrict__ diff) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool d = t < n && __double_as_longlong(a[t]) != __double_as_longlong(b[t]);
+    if (__builtin_amdgcn_ballot_w64(d) != 0 && (threadIdx.x & 63) == 0) atomicOr(diff, 1);
+}
 // own block + halo rows, column-major [hn + rows + hs, cols], put together on the device from three column-major pieces
 __global__ void k_ext_assemble(double* __restrict__ ext, const double* __restrict__ own, const double* __restrict__ north,
                                const double* __restrict__ south, int64_t rows, int64_t cols, int hn, int hs) {
@@ -1450,9 +1464,38 @@ static int prepare_chunk_on(mcf_snowplan* sp, int32_t ch, const double* d_z, int
     td.rows = rows; td.cols = cols; td.halo_north = hn; td.halo_south = hs; td.row0 = sp->row0; td.rows_total = sp->rows_total;
     td.d_dtm = d_z; td.res = sp->res; td.zref = sp->zref; td.agg = sp->ss; td.aspect_na = 180.0;
     td.d_slope = sp->d_slope; td.d_aspect = sp->d_aspect; td.d_hor = sp->d_hor; td.d_svfa = sp->d_svf; td.d_wsa = sp->d_wsa;
-    if ((rc = mcf::terrain_device(td, &sp->twork))) return rc;
     const unsigned gridN = (unsigned)((N + 255) / 256);
-    hipLaunchKernelGGL(k_mask2, dim3(gridN), dim3(256), 0, nullptr, sp->d_dtm, N, sp->d_slope, sp->d_aspect);
+    // The terrain arrays are functions of the surface alone.  If this chunk starts from the surface they were last derived
+    // from, bit for bit — no snow has lain anywhere since — they are kept (MCF_SNOW_TERRAIN_ALWAYS=1: never).
+    const int64_t zn = RB * cols;
+    bool same = false;
+    static const bool always = getenv("MCF_SNOW_TERRAIN_ALWAYS") != nullptr;
+    if (!always) {
+        if (!sp->d_zdiff && (rc = sp->b.alloc((void**)&sp->d_zdiff, 4))) return rc;
+        if (sp->d_zlast && sp->zlast_n == zn && sp->zlast_hn == hn && sp->zlast_hs == hs) {
+            S_TRY(hipMemsetAsync(sp->d_zdiff, 0, 4, nullptr));
+            hipLaunchKernelGGL(k_surface_differs, dim3((unsigned)((zn + 255) / 256)), dim3(256), 0, nullptr, d_z, (const double*)sp->d_zlast, zn,
+                               sp->d_zdiff);
+            int32_t diff = 1;
+            S_TRY(hipMemcpy(&diff, sp->d_zdiff, 4, hipMemcpyDeviceToHost));
+            same = diff == 0;
+        }
+    }
+    if (same) {
+        ++sp->terrain_reused;
+    } else {
+        if ((rc = mcf::terrain_device(td, &sp->twork))) return rc;
+        hipLaunchKernelGGL(k_mask2, dim3(gridN), dim3(256), 0, nullptr, sp->d_dtm, N, sp->d_slope, sp->d_aspect);
+        ++sp->terrain_refreshed;
+        if (!always) {
+            if (sp->zlast_cap < zn) {
+                if ((rc = sp->b.alloc((void**)&sp->d_zlast, zn * 8))) return rc;
+                sp->zlast_cap = zn;
+            }
+            S_TRY(hipMemcpyAsync(sp->d_zlast, d_z, (size_t)zn * 8, hipMemcpyDeviceToDevice, nullptr));
+            sp->zlast_n = zn; sp->zlast_hn = hn; sp->zlast_hs = hs;
+        }
+    }
     // topographic positioning index (int:2589-2592, 2471-2485)
     if (coarse) {
         if (sp->cm_cap < g.nI * g.nJ) {
