@@ -64,10 +64,10 @@ VARIANTS = {
     static_assert(NT == RING_BLOCK(CPB), "tile-day block = one value per lane");''', '''    constexpr int NT = solve_threads(CPB);
     static_assert(NT == RING_BLOCK(CPB), "tile-day block = one value per lane");
     const long long t_entry = clock64();'''),
-                 ('''    __syncthreads();
-    enter_layer(day0);''', '''    __syncthreads();
-    const long long t_staged = clock64();
-    enter_layer(day0);'''),
+                 ('''    enter_layer(day0);
+    // the tile's first block of this launch''', '''    const long long t_staged = clock64();
+    enter_layer(day0);
+    // the tile's first block of this launch'''),
                  (LOOP, '''    long long acc1 = 0, acc2 = 0, acc3 = 0, acc4 = 0;
     const long long t_loop = clock64();
     for (int dl = 0; dl < ndays; ++dl, ++run) {
