@@ -997,9 +997,15 @@ int mcf_plan_fetch_pitched(mcf_plan* p, int32_t slot, int32_t var, int64_t step0
     // large results: pinned ring + host copy threads instead of hipMemcpy's single-threaded staging
     static const bool no_pipe = getenv("MCF_NO_HOSTPIPE") != nullptr;
     auto to_host = [&](double* dst, const double* src, size_t bytes) -> int {
-        if (row_pitch != p->rows) {      // a block of a taller raster: one strided DMA, column by column into its place
-            HIP_TRY(hipMemcpy2DAsync(dst, (size_t)row_pitch * 8, src, (size_t)p->rows * 8, (size_t)p->rows * 8,
-                                     bytes / ((size_t)p->rows * 8), hipMemcpyDeviceToHost, p->stream));
+        if (row_pitch != p->rows) {      // a block of a taller raster: column by column into its place
+            const size_t width = (size_t)p->rows * 8, height = bytes / width;
+            if (bytes >= ((size_t)64 << 20) && width <= mcf::HostPipe::kPiece && !no_pipe && ensure_pipe(p)) {
+                // contiguous DMA into the pinned ring, the scatter by the host copy threads (mcf_hostpipe.hpp)
+                HIP_TRY(hipEventRecord(p->ev_pipe, p->stream));
+                HIP_TRY(p->pipe->copy_pitched(dst, (size_t)row_pitch * 8, src, width, height, p->ev_pipe));
+                return MCF_OK;
+            }
+            HIP_TRY(hipMemcpy2DAsync(dst, (size_t)row_pitch * 8, src, width, width, height, hipMemcpyDeviceToHost, p->stream));
             HIP_TRY(hipStreamSynchronize(p->stream));
             return MCF_OK;
         }

@@ -53,6 +53,42 @@ public:
 
     // Copies `bytes` from device memory to pageable host memory; `after` (may be null) is an event on
     // the producing stream that the first DMA must wait for.  Returns when `dst` is complete.
+    // The same into a PITCHED destination: `height` rows of `width` bytes, contiguous on the device, land `dpitch` bytes apart
+    // in host memory (a row block of a taller column-major raster: width = the block's rows x 8 B, one row per raster
+    // column and step).  hipMemcpy2D into pageable memory copies such rows one by one from a single thread (measured: half
+    // the contiguous rate at 8 KB rows); here the DMA stays contiguous and the copy threads do the scatter.
+    hipError_t copy_pitched(void* dst, size_t dpitch, const void* dev_src, size_t width, size_t height, hipEvent_t after) {
+        if (width == 0 || height == 0) return hipSuccess;
+        if (dpitch == width) return copy(dst, dev_src, width * height, after);
+        if (after) {
+            hipError_t e = hipStreamWaitEvent(stream_, after, 0);
+            if (e != hipSuccess) return e;
+        }
+        const size_t rows_per_piece = std::max<size_t>(1, kPiece / width);
+        if (width > kPiece) return hipErrorInvalidValue;              // (a single row larger than a piece: the caller falls back)
+        const size_t npieces = (height + rows_per_piece - 1) / rows_per_piece;
+        auto issue = [&](size_t i) -> hipError_t {
+            const int b = (int)(i % kBufs);
+            const size_t r0 = i * rows_per_piece, nr = std::min(rows_per_piece, height - r0);
+            hipError_t e = hipMemcpyAsync(pin_[b], (const char*)dev_src + r0 * width, nr * width, hipMemcpyDeviceToHost, stream_);
+            if (e != hipSuccess) return e;
+            return hipEventRecord(ev_[b], stream_);
+        };
+        for (size_t i = 0; i < std::min<size_t>(kBufs, npieces); ++i) {
+            hipError_t e = issue(i);
+            if (e != hipSuccess) return e;
+        }
+        for (size_t i = 0; i < npieces; ++i) {
+            const int b = (int)(i % kBufs);
+            hipError_t e = hipEventSynchronize(ev_[b]);
+            if (e != hipSuccess) return e;
+            const size_t r0 = i * rows_per_piece, nr = std::min(rows_per_piece, height - r0);
+            parallel_scatter((char*)dst + r0 * dpitch, dpitch, (const char*)pin_[b], width, nr);
+            if (i + kBufs < npieces && (e = issue(i + kBufs)) != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+
     hipError_t copy(void* dst, const void* dev_src, size_t bytes, hipEvent_t after) {
         // A fresh destination is first touched by the copy threads below, and with 4 KB pages those faults, not PCIe, bound the
         // call.  numpy asks for transparent huge pages on its big arrays itself; R's vectors (plain malloc) do not — so the
@@ -91,6 +127,24 @@ public:
     }
 
 private:
+    // rows of `width` bytes from a contiguous source to rows `dpitch` apart: the rows are dealt to the copy threads in slices
+    void parallel_scatter(char* dst, size_t dpitch, const char* src, size_t width, size_t nrows) {
+        if (nthreads_ <= 1 || nrows * width < ((size_t)1 << 20)) {
+            for (size_t r = 0; r < nrows; ++r) memcpy(dst + r * dpitch, src + r * width, width);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_dst_ = dst; job_src_ = src; job_n_ = nrows; job_width_ = width; job_dpitch_ = dpitch;
+            pending_ = nthreads_ - 1;
+            ++generation_;
+        }
+        cv_.notify_all();
+        slice(0);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [this] { return pending_ == 0; });
+        job_width_ = 0;
+    }
     void parallel_copy(char* dst, const char* src, size_t n) {
         if (nthreads_ <= 1 || n < ((size_t)1 << 20)) { memcpy(dst, src, n); return; }
         {
@@ -105,6 +159,12 @@ private:
         done_cv_.wait(lk, [this] { return pending_ == 0; });
     }
     void slice(int t) {
+        if (job_width_) {               // scatter job: job_n_ rows
+            const size_t per = (job_n_ + nthreads_ - 1) / nthreads_;
+            const size_t a = std::min(job_n_, per * t), b = std::min(job_n_, a + per);
+            for (size_t r = a; r < b; ++r) memcpy(job_dst_ + r * job_dpitch_, job_src_ + r * job_width_, job_width_);
+            return;
+        }
         const size_t per = ((job_n_ / nthreads_) + 4095) & ~(size_t)4095;   // page-aligned slices
         const size_t a = std::min(job_n_, per * t), b = std::min(job_n_, a + per);
         const size_t end = (t == nthreads_ - 1) ? job_n_ : b;
@@ -159,7 +219,7 @@ private:
     bool stop_ = false;
     char* job_dst_ = nullptr;
     const char* job_src_ = nullptr;
-    size_t job_n_ = 0;
+    size_t job_n_ = 0, job_width_ = 0, job_dpitch_ = 0;
 };
 
 }  // namespace mcf

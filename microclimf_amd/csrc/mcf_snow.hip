@@ -875,6 +875,19 @@ struct Bufs {
 struct Downloader {
     mcf::HostPipe pipe;
     bool tried = false, ok = false;
+    // rows of `width` bytes, contiguous on the device, `dpitch` bytes apart on the host (a row block's series)
+    hipError_t get_pitched(void* dst, size_t dpitch, const void* dev, size_t width, size_t height) {
+        static const bool no_pipe = getenv("MCF_NO_HOSTPIPE") != nullptr;
+        if (width * height >= ((size_t)64 << 20) && width <= mcf::HostPipe::kPiece && !no_pipe) {
+            if (!tried) { tried = true; ok = pipe.init(); }
+            if (ok) {
+                hipError_t e = hipDeviceSynchronize();      // the producers ran on the null stream
+                if (e != hipSuccess) return e;
+                return pipe.copy_pitched(dst, dpitch, dev, width, height, nullptr);
+            }
+        }
+        return hipMemcpy2D(dst, dpitch, dev, width, width, height, hipMemcpyDeviceToHost);
+    }
     hipError_t get(void* dst, const void* dev, size_t bytes) {
         static const bool no_pipe = getenv("MCF_NO_HOSTPIPE") != nullptr;
         if (bytes >= ((size_t)64 << 20) && !no_pipe) {
@@ -1578,8 +1591,7 @@ static int run_chunk_to(mcf_snowplan* sp, int32_t ch, double tpic_mean, const mc
     for (int v = 0; v < 5; ++v) {
         if (!hostv[v]) continue;
         if (row_pitch == sp->rows) S_TRY(sp->dl.get(hostv[v] + host_step0 * N, devv[v], (size_t)ns * N * 8));
-        else S_TRY(hipMemcpy2D(hostv[v] + host_step0 * HS, (size_t)row_pitch * 8, devv[v], (size_t)sp->rows * 8, (size_t)sp->rows * 8,
-                               (size_t)(sp->cols * ns), hipMemcpyDeviceToHost));
+        else S_TRY(sp->dl.get_pitched(hostv[v] + host_step0 * HS, (size_t)row_pitch * 8, devv[v], (size_t)sp->rows * 8, (size_t)(sp->cols * ns)));
     }
     if (fill_tail && ch == sp->nchunks - 1) {   // steps that no chunk covers stay NA (R pre-fills its arrays, int:2554-2558)
         union { uint64_t u; double d; } na; na.u = kNaRealBits;

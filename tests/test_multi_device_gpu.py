@@ -28,6 +28,17 @@ def test_row_blocks_on_one_device_equal_the_whole_raster_bitwise(rows, cols, T, 
     _bits_equal(whole, parts)
 
 
+def test_large_row_blocks_take_the_pinned_ring_scatter_bitwise():
+    """>= 64 MB per block and variable: the pitched fetch goes through HostPipe::copy_pitched (contiguous DMA into the pinned
+    ring, rows scattered by the copy threads) instead of hipMemcpy2D; odd block heights, so no row run is page-aligned"""
+    a = synthetic.workload(1030, 131, 240, reqhgt=0.05, start_doy=160, variety=True, na_frac=0.03)
+    out = [1, 0, 0, 0, 0, 0, 1, 0, 0, 0]
+    args = [a[k] for k in ARGS[:-1]] + [out]
+    whole = runmicro1Cpp(*args)
+    _bits_equal(whole, runmicro1Cpp(*args, devices=[0], n_blocks=3))
+    _bits_equal(whole, runmicro1Cpp(*args, devices=[0, 0], n_blocks=2))
+
+
 def test_array_forcing_row_blocks_bitwise():
     a = synthetic.workload(45, 19, 72, reqhgt=0.05, start_doy=170, variety=True, array_forcing=True, na_frac=0.05)
     whole = runmicro2Cpp(*[a[k] for k in ARGS])

@@ -214,12 +214,13 @@ def test_snowplan_two_row_blocks_equal_the_whole_raster(rows, cols, split):
 
 
 @pytest.mark.parametrize("rows,cols,nb,devices,T", [(300, 40, 2, [0], 240), (290, 30, 3, [0, 0], 240), (420, 24, 4, [0], 240),
-                                                     (150, 36, 3, [0], 250)])
+                                                     (150, 36, 3, [0], 250), (1100, 128, 2, [0], 240)])
 def test_snowmodel1_multi_row_blocks_in_the_library_equal_the_whole_raster(rows, cols, nb, devices, T):
     """mcf_snowmodel1_multi: the chunk loop of a whole raster over row blocks from one process — surface halos and the two
     (sum, count) means pass through host memory inside the library; against the single-plan run (cols = 30 and 24 take
     .tpicalc's raster-mean branch; two host threads on one device in the second case; blocks narrower than the halo in the third;
-    250 steps in the fourth: two chunks and ten steps no chunk covers, NA in both)"""
+    250 steps in the fourth: two chunks and ten steps no chunk covers, NA in both; the fifth is large enough — 67 MB per block,
+    chunk and series — for the pitched download to take the pinned ring and its scatter threads instead of hipMemcpy2D)"""
     from microclimf_amd.snow import snowmodel1_chunks
     sw, dtm = _driver_case(rows, cols, T)
     args = (sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"], sw["other"], sw["snowenv"])
