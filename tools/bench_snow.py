@@ -410,6 +410,7 @@ def run_snow_config(args, world, rank, local_rank):
 
     for _ in range(args.warmup):
         one_year()
+    stage_s.clear()             # (MCF_BENCH_STAGES=1: the timed years only — the warm-up year holds the allocations)
     fence()
     stats["solver_days"] = stats["snow_days"] = 0
     t0 = time.perf_counter()
