@@ -244,6 +244,13 @@ int mcf_plan_run_days(mcf_plan *plan, int32_t day0, int32_t ndays, int32_t slot)
 /* The same with the days written at day `slot_day0` of the slot instead of its start (vector forcing, reqhgt >= 0): several
  * runs of days of one chunk, each at its own place (the snow branch's no-snow days). */
 int mcf_plan_run_days_at(mcf_plan *plan, int32_t day0, int32_t ndays, int32_t slot, int32_t slot_day0);
+/* ... and for a SUBSET of the tiles: skip_tile[t] != 0 (t < n_tiles = ceil(cells / mcf_ring_layout.cells_per_tile); tile t =
+ * cells t * cells_per_tile ... of the column-major raster) leaves tile t's blocks of these days untouched in the slot.  The
+ * snow run uses it for the days that are no-snow days AND snow days: `.runmicrosnow1` (R/internal.R:3632-3655) overwrites
+ * every snow-covered cell-step of such a day with gridmicrosnow1's value, so the solver's values of a tile whose cells all lie
+ * under snow for the whole run of days are dead — mcf_snowplan_covered_tiles finds those tiles.  skip_tile = NULL: all. */
+int mcf_plan_run_days_masked(mcf_plan *plan, int32_t day0, int32_t ndays, int32_t slot, int32_t slot_day0,
+                             const uint8_t *skip_tile, int64_t n_tiles);
 /* Vector forcing: replace the series' maximum air temperature (src/microclimfCpp.cpp:2159-2168; it caps the
  * Penman-Monteith temperature excess, cpp:1236).  The snow branch solves a SUBSET of the days and the reference takes
  * the maximum over that subset. */
@@ -657,6 +664,14 @@ int mcf_snowplan_fetch_cells(mcf_snowplan *plan, int32_t what, const int64_t *ce
  * mcf_snowplan_release_kept (before the next year's pass 1) returns the sets to a pool the next year draws from: allocating
  * 10 GB takes about 0.25 s, more than re-running the chunk — the cache pays from a plan's second year on. */
 int mcf_snowplan_keep_chunk(mcf_snowplan *plan, int32_t chunk, int64_t reserve_bytes, int32_t *kept);
+/* Would mcf_snowplan_keep_chunk keep a chunk now (a pooled set, or room for a new one beside reserve_bytes)? */
+int mcf_snowplan_can_keep(mcf_snowplan *plan, int64_t reserve_bytes, int32_t *yes);
+/* Which of the five device series the following mcf_snowplan_run_chunk calls write: bit 0 Tc, 1 Tg, 2 totalSWE, 3 ground snow
+ * depth, 4 snow density (default 31).  Pass 1 of the two-pass run needs only totalSWE (the day classes) and the density (the
+ * mean damping depth) of a chunk that will not stay in HBM — pass 2 re-runs it —, and the five stores per cell-step are what a
+ * snow-free chunk costs.  A series that is off cannot be asked for in run_chunk's host outputs; a chunk run with series off
+ * cannot be kept or handed to mcf_snowplan_microsnow (MCF_ERR_STATE). */
+int mcf_snowplan_set_series(mcf_snowplan *plan, uint32_t mask);
 int mcf_snowplan_release_kept(mcf_snowplan *plan);
 int mcf_snowplan_checkpoint(mcf_snowplan *plan, int32_t chunk);
 int mcf_snowplan_restore(mcf_snowplan *plan, int32_t chunk);
@@ -665,6 +680,12 @@ int mcf_snowplan_meand_accumulate(mcf_snowplan *plan, int32_t chunk, const int32
  * are new). */
 int mcf_snowplan_micro_setup(mcf_snowplan *plan, const mcf_snow_inputs *subset, const int32_t *subset_day_of_day,
                              int32_t ndays, double reqhgt, double mat, const int32_t out[MCF_NOUT], int32_t reuse_static);
+/* Pass 2, before the solver's run of the chunk's days [day, day + ndays) (days of the chunk, 0-based): skip_tile[t] = 1
+ * where every cell of the solver plan's tile t has a vegetation height and a snow water equivalent > 0 at every step of
+ * those days — mcf_snowplan_microsnow will overwrite all of the tile's values of these days —, 0 elsewhere; all 0 when the
+ * solver plan holds an output gridmicrosnow1's `out` mask leaves to the solver.  *n_covered = number of ones. */
+int mcf_snowplan_covered_tiles(mcf_snowplan *plan, mcf_plan *solver, int32_t chunk, int32_t day, int32_t ndays,
+                               uint8_t *skip_tile, int64_t n_tiles, int64_t *n_covered);
 int mcf_snowplan_microsnow(mcf_snowplan *plan, mcf_plan *solver, int32_t chunk, int32_t slot,
                            const int32_t *nosnowday /* [days of the chunk] */);
 

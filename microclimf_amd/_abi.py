@@ -178,9 +178,10 @@ EXPORTS = (
     "mcf_plan_create", "mcf_plan_destroy", "mcf_plan_twi_partial",
     "mcf_plan_set_twi_mean", "mcf_plan_upload_forcing_days", "mcf_plan_run_days",
     "mcf_plan_belowground", "mcf_plan_sync", "mcf_plan_fetch", "mcf_plan_fetch_cells", "mcf_plan_fetch_packed", "mcf_plan_slot_ptr",
-    "mcf_plan_ring_layout", "mcf_ring_index", "mcf_plan_run_days_at", "mcf_plan_set_mxtc",
+    "mcf_plan_ring_layout", "mcf_ring_index", "mcf_plan_run_days_at", "mcf_plan_run_days_masked", "mcf_plan_set_mxtc",
+    "mcf_snowplan_covered_tiles",
     "mcf_runmicro1_multi", "mcf_runmicro2_multi", "mcf_runmicro3_multi", "mcf_runmicro4_multi", "mcf_plan_fetch_pitched",
-    "mcf_snowplan_reset", "mcf_snowplan_checkpoint", "mcf_snowplan_restore", "mcf_snowplan_fetch_cells", "mcf_snowplan_keep_chunk",
+    "mcf_snowplan_reset", "mcf_snowplan_checkpoint", "mcf_snowplan_restore", "mcf_snowplan_fetch_cells", "mcf_snowplan_keep_chunk", "mcf_snowplan_can_keep", "mcf_snowplan_set_series",
     "mcf_snowplan_release_kept", "mcf_snowplan_meand_accumulate", "mcf_snowplan_micro_setup", "mcf_snowplan_microsnow",
     "mcf_plan_timer_start", "mcf_plan_timer_stop", "mcf_plan_kernel_timing",
     "mcf_plan_kernel_stats", "mcf_plan_dispatch_stats", "mcf_plan_valid_cells", "mcf_plan_bytes", "mcf_selftest_math",
@@ -311,6 +312,10 @@ def load() -> C.CDLL:
         lib.mcf_snowplan_reset.argtypes = [P]
         lib.mcf_snowplan_fetch_cells.restype = C.c_int
         lib.mcf_snowplan_fetch_cells.argtypes = [P, C.c_int32, C.POINTER(C.c_int64), C.c_int32, c_double_p, C.POINTER(C.c_int32)]
+        lib.mcf_snowplan_can_keep.restype = C.c_int
+        lib.mcf_snowplan_can_keep.argtypes = [P, C.c_int64, C.POINTER(C.c_int32)]
+        lib.mcf_snowplan_set_series.restype = C.c_int
+        lib.mcf_snowplan_set_series.argtypes = [P, C.c_uint32]
         lib.mcf_snowplan_keep_chunk.restype = C.c_int
         lib.mcf_snowplan_keep_chunk.argtypes = [P, C.c_int32, C.c_int64, C.POINTER(C.c_int32)]
         lib.mcf_snowplan_release_kept.restype = C.c_int
@@ -323,6 +328,10 @@ def load() -> C.CDLL:
         lib.mcf_snowplan_micro_setup.restype = C.c_int
         lib.mcf_snowplan_micro_setup.argtypes = [P, C.POINTER(SnowInputs), c_int32_p, C.c_int32, C.c_double, C.c_double,
                                                  C.POINTER(C.c_int32 * NOUT), C.c_int32]
+        lib.mcf_plan_run_days_masked.restype = C.c_int
+        lib.mcf_plan_run_days_masked.argtypes = [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint8), C.c_int64]
+        lib.mcf_snowplan_covered_tiles.restype = C.c_int
+        lib.mcf_snowplan_covered_tiles.argtypes = [P, P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint8), C.c_int64, C.POINTER(C.c_int64)]
         lib.mcf_snowplan_microsnow.restype = C.c_int
         lib.mcf_snowplan_microsnow.argtypes = [P, P, C.c_int32, C.c_int32, c_int32_p]
     lib.mcf_plan_belowground.restype = C.c_int

@@ -230,6 +230,17 @@ class Plan:
         """run_days with the days written at day `slot_day0` of the slot (include/mcf.h mcf_plan_run_days_at)."""
         _abi.check(self._lib.mcf_plan_run_days_at(self._p, day0, ndays, slot, slot_day0))
 
+    def run_days_masked(self, day0: int, ndays: int, slot: int, slot_day0: int, skip_tile):
+        """run_days_at leaving out the tiles with skip_tile[t] != 0 (include/mcf.h mcf_plan_run_days_masked)."""
+        sk = np.ascontiguousarray(skip_tile, dtype=np.uint8)
+        _abi.check(self._lib.mcf_plan_run_days_masked(self._p, day0, ndays, slot, slot_day0, sk.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                      int(sk.size)))
+
+    @property
+    def n_tiles(self) -> int:
+        lay = self.ring_layout()
+        return (lay["cells"] + lay["cells_per_tile"] - 1) // lay["cells_per_tile"]
+
     def set_mxtc(self, mxtc: float):
         """Replace the series' maximum air temperature (the snow branch solves a subset of the days)."""
         _abi.check(self._lib.mcf_plan_set_mxtc(self._p, float(mxtc)))

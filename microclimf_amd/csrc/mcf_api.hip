@@ -97,6 +97,10 @@ struct mcf_plan {
     bool fast_enabled = false;
     std::vector<char> day_irregular, day_soil_daily;
     int32_t *d_tiles_fast = nullptr, *d_tiles_slow = nullptr;
+    // mcf_plan_run_days_masked: the tile classes on the host, and the launch's own lists on the device
+    std::vector<int32_t> h_tiles_fast, h_tiles_slow;
+    int32_t* d_tiles_sub = nullptr;
+    int64_t tiles_sub_cap = 0, masked_tiles_skipped = 0;
     int64_t n_fast = 0, n_slow = 0, tiles_cap = 0;
     int32_t *d_fix_count = nullptr, *d_fix_list = nullptr;
     int fix_cap = 8192;
@@ -319,6 +323,7 @@ int ensure_cells(mcf_plan* p) {
         for (int64_t t = 0; t < ntiles; ++t) (flag[(size_t)t] ? fastl : slowl).push_back((int32_t)t);
         p->n_fast = (int64_t)fastl.size();
         p->n_slow = (int64_t)slowl.size();
+        p->h_tiles_fast = fastl; p->h_tiles_slow = slowl;
         if (p->n_slow > 0) {     // with no irregular tile the fast launch needs no list (identity)
             HIP_TRY(hipMemcpy(p->d_tiles_fast, fastl.data(), fastl.size() * 4, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(p->d_tiles_slow, slowl.data(), slowl.size() * 4, hipMemcpyHostToDevice));
@@ -844,7 +849,14 @@ int mcf_plan_run_days(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot) {
 }
 
 int mcf_plan_run_days_at(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot, int32_t slot_day0) {
+    return mcf_plan_run_days_masked(p, day0, ndays, slot, slot_day0, nullptr, 0);
+}
+
+int mcf_plan_run_days_masked(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot, int32_t slot_day0, const uint8_t* skip_tile,
+                             int64_t n_skip_tile) {
     if (!p) return fail(MCF_ERR_ARG, "null plan");
+    if (skip_tile && (p->bg || p->af)) return fail(MCF_ERR_ARG, "a tile mask needs vector forcing and reqhgt >= 0");
+    if (skip_tile && n_skip_tile != (p->N + p->cpb - 1) / p->cpb) return fail(MCF_ERR_ARG, "the tile mask's length is not the plan's number of tiles");
     if (slot < 0 || slot >= p->ring_slots) return fail(MCF_ERR_ARG, "slot out of range");
     if (day0 < 0 || ndays < 1 || day0 + ndays > p->ndays) return fail(MCF_ERR_ARG, "day range out of bounds");
     if (!p->bg && (slot_day0 < 0 || slot_day0 + ndays > p->ring_days)) return fail(MCF_ERR_ARG, "more days than the ring slot holds");
@@ -899,8 +911,47 @@ int mcf_plan_run_days_at(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot,
     for (int d = day0; soil_daily && d < day0 + ndays; ++d)
         if (!p->day_soil_daily[(size_t)d]) soil_daily = false;
     if (p->coarse) soil_daily = p->coarse_lds;      // (coarse array forcing: the same launch flag selects the LDS-staged taps)
-    auto launch = [&]() {
+    // a tile mask: the launch's tile lists are the plan's minus the masked tiles (the kernel takes any list; a tile it is not
+    // given is simply not touched in the slot)
+    const int32_t *sub_fast = nullptr, *sub_slow = nullptr;
+    int64_t n_sub_fast = 0, n_sub_slow = 0;
+    if (skip_tile) {
+        const int64_t ntiles = p->ntiles;
+        if (p->tiles_sub_cap < ntiles) {
+            void* q;
+            if ((rc = dalloc(p, &q, ntiles * 4))) return rc;
+            p->d_tiles_sub = (int32_t*)q;
+            p->tiles_sub_cap = ntiles;
+        }
+        std::vector<int32_t> lf, ls;
+        lf.reserve((size_t)ntiles);
         if (fast) {
+            for (int32_t t : p->h_tiles_fast) if (!skip_tile[t]) lf.push_back(t);
+            for (int32_t t : p->h_tiles_slow) if (!skip_tile[t]) ls.push_back(t);
+        } else {
+            for (int64_t t = 0; t < ntiles; ++t) if (!skip_tile[t]) lf.push_back((int32_t)t);
+        }
+        n_sub_fast = (int64_t)lf.size(); n_sub_slow = (int64_t)ls.size();
+        p->masked_tiles_skipped += ntiles - n_sub_fast - n_sub_slow;
+        HIP_TRY(hipStreamSynchronize(p->stream));          // (an earlier masked launch may still be reading the lists)
+        if (n_sub_fast) HIP_TRY(hipMemcpy(p->d_tiles_sub, lf.data(), lf.size() * 4, hipMemcpyHostToDevice));
+        if (n_sub_slow) HIP_TRY(hipMemcpy(p->d_tiles_sub + n_sub_fast, ls.data(), ls.size() * 4, hipMemcpyHostToDevice));
+        sub_fast = p->d_tiles_sub; sub_slow = p->d_tiles_sub + n_sub_fast;
+    }
+    auto launch = [&]() {
+        if (skip_tile) {
+            if (fast) (void)hipMemsetAsync(p->d_fix_count, 0, 4, p->stream);
+            if (n_sub_fast) {
+                a.tile_list = sub_fast; a.ntiles_launch = n_sub_fast;
+                if (fast) { mcf::launch_solve(a, p->cpb, p->af, false, true, soil_daily, p->stream); ++p->fast_launches; }
+                else { mcf::launch_solve(a, p->cpb, p->af, p->bg, false, soil_daily, p->stream); ++p->slow_launches; }
+            }
+            if (n_sub_slow) {
+                a.tile_list = sub_slow; a.ntiles_launch = n_sub_slow;
+                mcf::launch_solve(a, p->cpb, p->af, false, false, soil_daily, p->stream);
+                ++p->slow_launches;
+            }
+        } else if (fast) {
             (void)hipMemsetAsync(p->d_fix_count, 0, 4, p->stream);
             a.tile_list = p->n_slow > 0 ? p->d_tiles_fast : nullptr;
             a.ntiles_launch = p->n_fast;

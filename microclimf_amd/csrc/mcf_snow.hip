@@ -28,13 +28,20 @@
 #include "mcf_snow_device.hpp"
 
 #ifndef MCF_MICRO_WAVES
-#define MCF_MICRO_WAVES 2   // waves per SIMD the lane-per-(cell, day) snow-microclimate kernels are built for (204 VGPRs); the ring
-                            // kernel (lane per cell-hour, cell table in LDS) is built for 3: 168 VGPRs, no scratch
+#define MCF_MICRO_WAVES 2   // waves per SIMD the lane-per-(cell, day) snow-microclimate kernels are built for (204 VGPRs)
 #endif
+// the ring kernel (lane per cell-hour, cell table in LDS, step record through scalar loads): 141 VGPRs without scratch at three
+// waves per SIMD, 128 + 44 B (eight spill stores and loads per hour) at four — measured 0.515 against 0.55 s per simulated year
+// of configs[4]'s share (the kernel moves ~144 B per snow cell-step: it is closer to the memory system's limit than to the
+// VALU's, and the fourth wave hides more of the loads)
 // waves per SIMD k_snowmodel is built for.  Round 4: with the cell's constants read from the workgroup's LDS table at their uses
 // and the five output streams addressed as uniform base + 32-bit lane offset, the data.frame kernel fits 128 VGPRs without
-// scratch (156 in round 3: three waves); the array-climate kernel derives the step's weather terms per lane and stays at three
-// (168 VGPRs + 96 B of scratch; 232 B in round 3).
+// scratch (156 in round 3: three waves) — 105 once the step table comes through scalar loads (see the kernel's head); a fifth
+// wave is out of reach through LDS, not registers (36 KB per 4-wave workgroup: the cell table + the exp / log tables).  The
+// array-climate kernel derives the step's weather terms per lane and stays at three (168 VGPRs + 116 B of scratch; 232 B in round 3).
+#ifndef MCF_MICRORING_WAVES
+#define MCF_MICRORING_WAVES 4
+#endif
 #ifndef MCF_SNOW_WAVES
 #define MCF_SNOW_WAVES 4
 #endif
@@ -168,7 +175,11 @@ struct ModelArgs {
 };
 
 template <bool AF>
-__global__ __launch_bounds__(256, AF ? MCF_SNOW_WAVES_AF : MCF_SNOW_WAVES) void k_snowmodel(ModelArgs a) {
+__global__ __launch_bounds__(256, AF ? MCF_SNOW_WAVES_AF : MCF_SNOW_WAVES) void k_snowmodel(ModelArgs a, const StepRow* __restrict__ rows,
+                                                                                             const DateRow2* __restrict__ dates) {
+    // (rows / dates = a.rows / a.dates as `__restrict__` kernel arguments of their own: a pointer read out of the by-value struct
+    // carries no noalias, the series' stores might clobber the table for all the compiler knows, and every field of a step's
+    // row came through a VECTOR load of a uniform address — 40 loads and as many VGPR pairs per step instead of scalar loads)
     snow::snow_tables_init();
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.N) return;
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(256, AF ? MCF_SNOW_WAVES_AF : MCF_SNOW_WAVES) void 
                 }
             }
         } else {
-            tc = a.rows[k].m.tc; prec = a.rows[k].m.prec;
+            tc = rows[k].m.tc; prec = rows[k].m.prec;
         }
         bool snowtest = s.sdepc > 0.0;                       // cpp:4336-4338
         if (tc < 2.0 && prec > 0.0) snowtest = true;
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(256, AF ? MCF_SNOW_WAVES_AF : MCF_SNOW_WAVES) void 
                 m.umu = a.umu[o]; m.u2 = a.windspeed[o]; m.gp = a.Gp[o];
                 m.alb = snow_albedo(hs);
                 m.ialb = gdiv(1.0, m.alb);
-                const DateRow2 dr = a.dates[k];
+                const DateRow2 dr = dates[k];
                 SolDate sd;
                 sd.sindec = dr.sindec; sd.cosdec = dr.cosdec; sd.eot = dr.eot;
                 const SolPos sp = sol_site(sd, dr.hour, sinlat, coslat, lon);
@@ -297,7 +308,7 @@ __global__ __launch_bounds__(256, AF ? MCF_SNOW_WAVES_AF : MCF_SNOW_WAVES) void 
                 const double ws = a.wsa[(int64_t)dr.windex * N + c];
                 pack_step(m, dy, sun, cv, ha, ws, a.sdp, a.zref, s, po);
             } else {
-                const StepRow& r = a.rows[k];
+                const StepRow& r = rows[k];
                 const double ha = a.hor[(int64_t)r.sindex * N + c];
                 const double ws = a.wsa[(int64_t)r.windex * N + c];
                 pack_step(r.m, r.d, r.s, cv, ha, ws, a.sdp, a.zref, s, po);
@@ -345,6 +356,7 @@ struct MicroArgs {
     const DateRow2* dates;
     const double* mxtc1;   // [1] data.frame climate
     const MicroMet* mmet;  // [T] data.frame climate: weather-only terms of every step (k_micro_steps)
+    const void* mstep;     // [T] MicroStep (the snow plan's ring kernel): rows' sun / albedo, mmet and the step's weather in one record
     int32_t day0;          // first day of this launch (blockIdx.y counts from it)
     const double *temp, *relhum, *pres, *swdown, *difrad, *lwdown, *windspeed, *precip, *umu;   // [T] or [N][T]
     const double *sTc, *sTg, *swe, *sdepg, *sden;   // snowm, [N][T]
@@ -366,6 +378,28 @@ __global__ __launch_bounds__(256) void k_micro_steps(const double* __restrict__ 
 
 // per-cell reductions over the whole series: meanDsnow (cpp:4713-4737) and, with array climate, the
 // cell's maximum temperature (cpp:5139-5145) and the albedo clock at every day start
+// Everything k_microsnow_ring reads of a step, in one record: ONE table pointer in scalar registers instead of eleven (the
+// kernel keeps ~100 uniform values alive; what does not fit the SGPR file is spilled to VGPR lanes, a VALU instruction per access)
+struct MicroStep {
+    SunT s;
+    MicroMet mm;
+    double tc, pk, u2, rsw, rdif, rlw, umu, alb, ialb;
+    int32_t sindex, windex;
+};
+__global__ __launch_bounds__(256) void k_micro_pack(const StepRow* __restrict__ rows, const MicroMet* __restrict__ mmet,
+                                                    const double* __restrict__ temp, const double* __restrict__ pres,
+                                                    const double* __restrict__ wind, const double* __restrict__ sw,
+                                                    const double* __restrict__ dif, const double* __restrict__ lw,
+                                                    const double* __restrict__ umu, int T, MicroStep* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= T) return;
+    MicroStep m;
+    m.s = rows[k].s; m.mm = mmet[k];
+    m.tc = temp[k]; m.pk = pres[k]; m.u2 = wind[k]; m.rsw = sw[k]; m.rdif = dif[k]; m.rlw = lw[k]; m.umu = umu[k];
+    m.alb = rows[k].m.alb; m.ialb = rows[k].m.ialb;
+    m.sindex = rows[k].sindex; m.windex = rows[k].windex;
+    out[k] = m;
+}
 template <bool AF>
 __global__ __launch_bounds__(256) void k_microsnow_cell(MicroArgs a) {
     snow::snow_tables_init();
@@ -534,8 +568,11 @@ __global__ __launch_bounds__(256) void k_meand_finish(const double* __restrict__
 struct MicroRingArgs {
     MicroArgs m;
     mcf::RingView ring;          // the slot's geometry (base unused)
-    double* obase[MCF_NOUT];     // each held variable's base in the slot, null: the plan does not hold it
-    int32_t sel[MCF_NOUT];       // gridmicrosnow1's `out` mask
+    // the slot's held variables lie `vstride` doubles apart in the reference's order from `base0` (the tiled ring's
+    // [tile][day][variable][block]): bit i of `held` = the plan holds output i, its base = base0 + popcount(held below i) * vstride
+    double* base0;
+    int64_t vstride;
+    uint32_t held, sel;          // sel: gridmicrosnow1's `out` mask
     const int32_t *daymap, *nosnow;
     int32_t ndays;
 };
@@ -550,17 +587,23 @@ enum MicroCell : int { MC_HGT, MC_PAI, MC_PAIA, MC_LEAFD, MC_CLUMP, MC_LTRA, MC_
 static_assert((int)MC_HGT == (int)MQ_HGT && (int)MC_PAI == (int)MQ_PAI && (int)MC_PAIA == (int)MQ_PAIA && (int)MC_LEAFD == (int)MQ_LEAFD && (int)MC_CLUMP == (int)MQ_CLUMP &&
               (int)MC_LTRA == (int)MQ_LTRA && (int)MC_LEAFDEN == (int)MQ_LEAFDEN && (int)MC_SVFA == (int)MQ_SVFA && (int)MC_LNCLUMP == (int)MQ_LNCLUMP &&
               (int)MC_IHGT == (int)MQ_IHGT && (int)MC_ILEAFD == (int)MQ_ILEAFD && (int)MC_IPAI == (int)MQ_IPAI, "micro_above reads the table's first rows");
-__global__ __launch_bounds__(256, 3) void k_microsnow_ring(MicroRingArgs q) {
+// The per-step table and the two day lists come in as `__restrict__` kernel arguments of their own (tb = q.m.mstep): read out of
+// the by-value struct a pointer carries no noalias, the ring's stores might clobber the table for all the compiler knows, and
+// every field of an hour's record — ~30 doubles — came through VECTOR loads of a uniform address into VGPR pairs.  With that
+// and the wave index declared uniform (readfirstlane) they are scalar loads into SGPRs.
+__global__ __launch_bounds__(256, MCF_MICRORING_WAVES) void k_microsnow_ring(MicroRingArgs q, const MicroStep* __restrict__ tb,
+                                                                             const int32_t* __restrict__ tb_daymap,
+                                                                             const int32_t* __restrict__ tb_nosnow) {
     snow::snow_tables_init();
     __shared__ double s_mc[MC_COUNT][64];
     const MicroArgs& a = q.m;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t N = a.N;
     const int64_t c = (int64_t)blockIdx.x * 64 + lane;
     const int day = (int)blockIdx.y;             // uniform: the day's rows of the step tables are scalar loads
-    const int sub = q.daymap[day];
+    const int sub = tb_daymap[day];
     if (sub < 0) return;
-    const bool keep = q.nosnow[day] != 0;        // the solver ran this day: snow-free cell-steps keep its values
+    const bool keep = tb_nosnow[day] != 0;        // the solver ran this day: snow-free cell-steps keep its values
     const double NA = na_real();
     const bool inr = c < N;
     const int64_t cc = inr ? c : N - 1;          // lanes past the raster read the last cell and write nothing
@@ -609,27 +652,47 @@ __global__ __launch_bounds__(256, 3) void k_microsnow_ring(MicroRingArgs q) {
         asm volatile("" : "+v"(li));
         int64_t bo = blk;
         asm volatile("" : "+v"(bo));
-        auto put = [&](int i, int hh, double v) { q.obase[i][bo + mcf::ring_pos(cpb, cell, hh)] = v; };
+        // (opaque scalars too: or each variable's presence / selection masks, rank and base — 80 SGPRs — are hoisted in front of
+        // the loop as invariants and spilled to VGPR lanes, a v_readlane per use; made at each store they are a few scalar
+        // instructions beside the vector work)
+        uint32_t held = q.held, selm = q.sel;
+        int64_t vs = q.vstride;
+        asm volatile("" : "+s"(held), "+s"(selm), "+s"(vs));
+        auto has = [&](int i) { return (held >> i) & 1u; };
+        auto put = [&](int i, int hh, double v) {
+            const int rank = __builtin_popcount(held & ((1u << i) - 1u));
+            q.base0[bo + rank * vs + mcf::ring_pos(cpb, cell, hh)] = v;
+        };
         auto MC = [&](int f) { return s_mc[f][li]; };
         const double hgt = MC(MC_HGT);
         if (isnan(hgt)) {            // cpp:4988-4989: the cell is skipped — the blank template's NA unless the solver wrote it
-            if (!keep)
-                for (int i = 0; i < MCF_NOUT; ++i) if (q.obase[i]) put(i, h, NA);
+            if (!keep) {
+#pragma unroll
+                for (int i = 0; i < MCF_NOUT; ++i) if (has(i)) put(i, h, NA);
+            }
             continue;
         }
         const int64_t o = c + N * (k0 + h);          // chunk-local
         const int f = sub * 24 + h;                   // step of the snow-day subset series
         const double swe = a.swe[o];
         if (!(swe > 0.0)) {                           // cpp:4993
-            if (!keep)
-                for (int i = 0; i < MCF_NOUT; ++i) if (q.obase[i]) put(i, h, NA);
+            if (!keep) {
+#pragma unroll
+                for (int i = 0; i < MCF_NOUT; ++i) if (has(i)) put(i, h, NA);
+            }
             continue;
         }
         const double sdepg = a.sdepg[o], sTg = a.sTg[o];
         const double reqhgts = a.reqhgt - sdepg;
-        double v[MCF_NOUT];
+        // an output of this cell-step into the ring: gridmicrosnow1's `out` mask, the blank template's NA otherwise
+        auto emit = [&](int i, double val) {
+            if (!has(i)) return;
+            if ((selm >> i) & 1u) put(i, h, val);
+            else if (!keep) put(i, h, NA);
+        };
+        double Tz, tleaf, rh;
         if (reqhgts >= 0.0) {
-            const StepRow& r = a.rows[f];
+            const MicroStep& r = tb[f];
             const SunT sun = r.s;
             SiteK site;
             site.cS = MC(MC_CS); site.sS = MC(MC_SS); site.cA = MC(MC_CA); site.sA = MC(MC_SA); site.flat = MC(MC_SLOPE) == 0.0;
@@ -639,27 +702,22 @@ __global__ __launch_bounds__(256, 3) void k_microsnow_ring(MicroRingArgs q) {
             mi.shadowmask = a.hor[(int64_t)r.sindex * N + c] > sun.tansa ? 0 : 1;
             mi.ws = a.wsa[(int64_t)r.windex * N + c];
             mi.reqhgt = reqhgts; mi.zref = a.zref;
-            mi.tc = a.temp[f]; mi.pk = a.pres[f]; mi.u2 = a.windspeed[f];
-            mi.Rsw = a.swdown[f]; mi.Rdif = a.difrad[f]; mi.Rlw = a.lwdown[f]; mi.umu = a.umu[f];
+            mi.tc = r.tc; mi.pk = r.pk; mi.u2 = r.u2;
+            mi.Rsw = r.rsw; mi.Rdif = r.rdif; mi.Rlw = r.rlw; mi.umu = r.umu;
             mi.cell = &s_mc[0][li]; mi.cs = 64;           // (MC_HGT .. MC_IPAI are MQ_HGT .. MQ_IPAI)
             mi.Tg = sTg; mi.Tc = a.sTc[o]; mi.sden = a.sden[o]; mi.sdepg = sdepg;
             mi.sdepc = swe / mi.sden;
-            mi.alb = r.m.alb; mi.ialb = r.m.ialb;
-            const MicroOut mo = micro_above(mi, a.mmet[f], sun);
-            v[0] = mo.Tz; v[1] = mo.tleaf; v[2] = mo.rh; v[4] = mo.uz; v[5] = mo.Rbdown; v[6] = mo.Rddown;
-            v[7] = mo.Rlwdn; v[8] = mo.Rdup; v[9] = mo.Rlwup;
+            mi.alb = r.alb; mi.ialb = r.ialb;
+            // (wind speed and the five radiation streams go into the ring where micro_above has them final)
+            const MicroOut mo = micro_above(mi, r.mm, sun, [&](int i, double val) { emit(i, val); return true; });
+            Tz = mo.Tz; tleaf = mo.tleaf; rh = mo.rh;
         } else {
             const double b = micro_below(reqhgts, MC(MC_MEAND), sTg, MC(MC_TZD), a.mat, a.hiy);
-            v[0] = b; v[1] = b; v[2] = 100.0;
-            v[4] = v[5] = v[6] = v[7] = v[8] = v[9] = 0.0;
+            Tz = b; tleaf = b; rh = 100.0;
+            for (int i = 4; i < MCF_NOUT; ++i) emit(i, 0.0);
         }
-        v[3] = MC(MC_SMAX);
-#pragma unroll
-        for (int i = 0; i < MCF_NOUT; ++i) {
-            if (!q.obase[i]) continue;
-            if (q.sel[i]) put(i, h, v[i]);
-            else if (!keep) put(i, h, NA);
-        }
+        emit(0, Tz); emit(1, tleaf); emit(2, rh);
+        emit(3, MC(MC_SMAX));
     }
 }
 
@@ -802,6 +860,39 @@ __global__ __launch_bounds__(256) void k_apply3_part(const double* __restrict__ 
     if (threadIdx.x == 0) {
         ws[2 * (k * parts + blockIdx.x)] = sv[0];
         ws[2 * (k * parts + blockIdx.x) + 1] = sn[0];
+    }
+}
+// max AND min of every step in ONE pass over the series (the snow plan asks for both of every chunk: snowdaysfun's operands).
+// Each of the two is folded over the same cells in the same order as k_apply3_part folds it alone — same bits.
+__global__ __launch_bounds__(256) void k_apply3_minmax_part(const double* __restrict__ a, int64_t N, int parts,
+                                                            double* __restrict__ ws_max, double* __restrict__ ws_min) {
+    __shared__ double smx[256];
+    __shared__ double smn[256];
+    __shared__ double sn[256];
+    const int64_t k = blockIdx.y;
+    const double* x = a + k * N;
+    double mx = -INFINITY, mn = INFINITY, n = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)parts * 256) {
+        const double q = x[i];
+        if (isnan(q)) continue;
+        n += 1.0;
+        mx = apply3_combine(2, mx, q);
+        mn = apply3_combine(3, mn, q);
+    }
+    smx[threadIdx.x] = mx; smn[threadIdx.x] = mn; sn[threadIdx.x] = n;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            smx[threadIdx.x] = apply3_combine(2, smx[threadIdx.x], smx[threadIdx.x + w]);
+            smn[threadIdx.x] = apply3_combine(3, smn[threadIdx.x], smn[threadIdx.x + w]);
+            sn[threadIdx.x] += sn[threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int64_t o = 2 * (k * parts + blockIdx.x);
+        ws_max[o] = smx[0]; ws_max[o + 1] = sn[0];
+        ws_min[o] = smn[0]; ws_min[o + 1] = sn[0];
     }
 }
 __global__ __launch_bounds__(256) void k_apply3_fin(const double* __restrict__ ws, int64_t tsteps, int fun, int parts,
@@ -1058,8 +1149,8 @@ int run_snowmodel(const mcf_snow_inputs* in, mcf_snowmodel_out* out, int32_t dev
     Events evs;
     const bool timing = getenv("MCF_TIMING") != nullptr;
     if (timing) { S_TRY(evs.make(2)); S_TRY(hipEventRecord(evs.e[0], nullptr)); }
-    if (af) hipLaunchKernelGGL(k_snowmodel<true>, dim3(grid), dim3(256), 0, nullptr, a);
-    else hipLaunchKernelGGL(k_snowmodel<false>, dim3(grid), dim3(256), 0, nullptr, a);
+    if (af) hipLaunchKernelGGL(k_snowmodel<true>, dim3(grid), dim3(256), 0, nullptr, a, a.rows, a.dates);
+    else hipLaunchKernelGGL(k_snowmodel<false>, dim3(grid), dim3(256), 0, nullptr, a, a.rows, a.dates);
     S_TRY(hipGetLastError());
     if (timing) {
         S_TRY(hipEventRecord(evs.e[1], nullptr));
@@ -1193,6 +1284,11 @@ struct mcf_snowplan {
     int32_t zlast_hn = -1, zlast_hs = -1;
     int32_t* d_zdiff = nullptr;
     int terrain_reused = 0, terrain_refreshed = 0;
+    // mcf_snowplan_apply3: the chunk's per-step max and min of totalSWE come out of one pass (k_apply3_minmax_part) into a
+    // workspace the plan owns; whichever of the two is asked for first computes both, the other is answered from here
+    double* d_mm = nullptr;              // [2 x chunk x parts x 2] partials, [4 x chunk] results
+    int mm_parts = 0, mm_chunk = -1;     // mm_chunk: the chunk whose run the cached values belong to (-1: none)
+    std::vector<double> mm_host;         // max[chunk], count[chunk], min[chunk], count[chunk]
     int32_t *d_ac = nullptr, *d_ag = nullptr;
     std::vector<double> wind;
     Downloader dl;
@@ -1213,6 +1309,11 @@ struct mcf_snowplan {
     int32_t outsel[MCF_NOUT] = {};
     std::vector<int32_t> sub_of_day;     // absolute day -> day of the snow-day subset series, or -1
     int32_t *d_daymap = nullptr, *d_nosnow = nullptr;     // [chunk days]
+    // mcf_snowplan_set_series: which of the five device series (bit 0 Tc, 1 Tg, 2 totalSWE, 3 ground snow depth, 4 density) the
+    // next run_chunk writes; series_valid: what the plan's working buffers hold of the chunk run last
+    uint32_t series_mask = 31, series_valid = 0;
+    uint8_t* d_tflag = nullptr;          // mcf_snowplan_covered_tiles: one flag per tile of the solver plan
+    int64_t tflag_cap = 0;
     // hand-over state at the start of a chunk (mcf_snowplan_checkpoint): isnowdc, the snow surface, the two age matrices
     std::vector<char*> ckpt;
     // series of chunks kept on the device between the two passes (mcf_snowplan_keep_chunk): a kept chunk's buffers are the ones
@@ -1560,6 +1661,7 @@ static int run_chunk_to(mcf_snowplan* sp, int32_t ch, double tpic_mean, const mc
     if (row_pitch <= 0) row_pitch = sp->rows;
     if (ch != sp->prepared) return mcf::api_fail(MCF_ERR_STATE, "snow plan: run_chunk needs prepare_chunk of the same chunk first");
     S_TRY(hipSetDevice(sp->device));
+    sp->mm_chunk = -1;
     if ((size_t)ch < sp->kept.size() && sp->kept[(size_t)ch].Tc) {     // a set kept from an earlier run of this chunk is stale now
         sp->pool.push_back(sp->kept[(size_t)ch]);
         sp->kept[(size_t)ch] = mcf_snowplan::Kept();
@@ -1576,7 +1678,19 @@ static int run_chunk_to(mcf_snowplan* sp, int32_t ch, double tpic_mean, const mc
     // ... with the redistribution by the topographic position index and the hand-over fused in (ModelArgs)
     a.tpic = sp->d_tpic; a.tpimean = tpic_mean; a.dtm = sp->d_dtm;
     a.isnowdc_out = sp->d_isnowdc; a.dtms = sp->d_dtms; a.isnowac_out = sp->d_ac; a.isnowag_out = sp->d_ag;
-    hipLaunchKernelGGL(k_snowmodel<false>, dim3(gridN), dim3(256), 0, nullptr, a);
+    {   // series nobody will read are not written (mcf_snowplan_set_series): the kernel's stores are what a snow-free chunk costs
+        const uint32_t m = sp->series_mask;
+        double* const hostp[5] = {out->Tc, out->Tg, out->totalSWE, out->groundsnowdepth, out->snowden};
+        for (int v = 0; v < 5; ++v)
+            if (!((m >> v) & 1u) && hostp[v]) return mcf::api_fail(MCF_ERR_STATE, "snow plan: a series the caller asks for is switched off (mcf_snowplan_set_series)");
+        if (!(m & 1u)) a.Tc = nullptr;
+        if (!(m & 2u)) a.Tg = nullptr;
+        if (!(m & 4u)) a.sdepc = nullptr;
+        if (!(m & 8u)) a.sdepg = nullptr;
+        if (!(m & 16u)) a.sden = nullptr;
+        sp->series_valid = m;
+    }
+    hipLaunchKernelGGL(k_snowmodel<false>, dim3(gridN), dim3(256), 0, nullptr, a, a.rows, a.dates);
     S_TRY(hipGetLastError());
     if (timing) {
         S_TRY(hipEventRecord(evs.e[1], nullptr));
@@ -1822,7 +1936,33 @@ extern "C" int mcf_snowplan_apply3(mcf_snowplan* sp, int32_t chunk, int32_t fun,
     if (chunk < 0 || chunk >= sp->nchunks) return mcf::api_fail(MCF_ERR_ARG, "chunk out of range");
     S_TRY(hipSetDevice(sp->device));
     const int ns = std::min(sp->chunk, sp->T - chunk * sp->chunk);
-    return apply3_device(sp->a.sdepc, sp->N, ns, fun, result, count);     // sdepc holds totalSWE after the redistribution
+    // (sdepc holds totalSWE after the redistribution; the series are the ones of the chunk run last)
+    if (!(sp->series_valid & 4u)) return mcf::api_fail(MCF_ERR_STATE, "snow plan: the chunk's totalSWE series was switched off (mcf_snowplan_set_series)");
+    if (fun < 2) return apply3_device(sp->a.sdepc, sp->N, ns, fun, result, count);
+    if (sp->mm_chunk != chunk) {
+        const int64_t N = sp->N, C = sp->chunk;
+        int parts = (int)std::min<int64_t>(64, std::max<int64_t>(1, N / 16384));      // (apply3_device's choice: same partials, same bits)
+        if ((int64_t)ns * parts < 2048) parts = (int)std::min<int64_t>(64, std::max<int64_t>(parts, (2048 + ns - 1) / ns));
+        const int pmax = 64;
+        if (!sp->d_mm) {
+            int rc;
+            if ((rc = sp->b.alloc((void**)&sp->d_mm, (2 * C * pmax * 2 + 4 * C) * 8))) return rc;
+            sp->mm_host.assign((size_t)(4 * C), 0.0);
+        }
+        double *ws_max = sp->d_mm, *ws_min = sp->d_mm + C * pmax * 2, *d_r = sp->d_mm + 2 * C * pmax * 2;
+        hipLaunchKernelGGL(k_apply3_minmax_part, dim3((unsigned)parts, (unsigned)ns), dim3(256), 0, nullptr, (const double*)sp->a.sdepc, N, parts,
+                           ws_max, ws_min);
+        hipLaunchKernelGGL(k_apply3_fin, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, nullptr, (const double*)ws_max, (int64_t)ns, 2, parts, d_r, d_r + C);
+        hipLaunchKernelGGL(k_apply3_fin, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, nullptr, (const double*)ws_min, (int64_t)ns, 3, parts, d_r + 2 * C,
+                           d_r + 3 * C);
+        S_TRY(hipGetLastError());
+        S_TRY(hipMemcpy(sp->mm_host.data(), d_r, (size_t)(4 * C) * 8, hipMemcpyDeviceToHost));
+        sp->mm_chunk = chunk;
+    }
+    const double* h = sp->mm_host.data() + (fun == 2 ? 0 : 2 * sp->chunk);
+    memcpy(result, h, (size_t)ns * 8);
+    if (count) memcpy(count, h + sp->chunk, (size_t)ns * 8);
+    return MCF_OK;
 }
 extern "C" int mcf_applycpp3(const double* a, int64_t rows, int64_t cols, int64_t tsteps, int32_t fun, double* result,
                              double* count, int32_t device) {
@@ -1956,6 +2096,7 @@ extern "C" int mcf_snowplan_keep_chunk(mcf_snowplan* sp, int32_t ch, int64_t res
     S_TRY(hipSetDevice(sp->device));
     if (sp->kept.size() < (size_t)sp->nchunks) sp->kept.resize((size_t)sp->nchunks);
     if (sp->kept[ch].Tc) { *kept = 1; return MCF_OK; }
+    if (sp->series_valid != 31) return MCF_OK;      // (a chunk run with some series switched off cannot be kept)
     const int64_t one = (int64_t)sp->chunk * sp->N * 8;
     double* fresh[5] = {};
     if (!sp->pool.empty()) {               // a set an earlier year released
@@ -1981,7 +2122,26 @@ extern "C" int mcf_snowplan_keep_chunk(mcf_snowplan* sp, int32_t ch, int64_t res
     k.Tc = a.Tc; k.Tg = a.Tg; k.sdepc = a.sdepc; k.sdepg = a.sdepg; k.sden = a.sden;
     a.Tc = fresh[0]; a.Tg = fresh[1]; a.sdepc = fresh[2]; a.sdepg = fresh[3]; a.sden = fresh[4];
     sp->kept[ch] = k;
+    sp->mm_chunk = -1;                     // (the plan's buffers are fresh ones now)
     *kept = 1;
+    return MCF_OK;
+}
+extern "C" int mcf_snowplan_set_series(mcf_snowplan* sp, uint32_t mask) {
+    if (!sp) return mcf::api_fail(MCF_ERR_ARG, "null snow plan");
+    if (mask > 31u) return mcf::api_fail(MCF_ERR_ARG, "mcf_snowplan_set_series: five series, mask <= 31");
+    sp->series_mask = mask;
+    return MCF_OK;
+}
+// would mcf_snowplan_keep_chunk keep a chunk now? (a pooled set, or room for a new one beside `reserve_bytes`)
+extern "C" int mcf_snowplan_can_keep(mcf_snowplan* sp, int64_t reserve_bytes, int32_t* yes) {
+    if (!sp || !yes) return mcf::api_fail(MCF_ERR_ARG, "null argument");
+    *yes = 0;
+    if (!sp->pool.empty()) { *yes = 1; return MCF_OK; }
+    S_TRY(hipSetDevice(sp->device));
+    size_t free_b = 0, total_b = 0;
+    S_TRY(hipMemGetInfo(&free_b, &total_b));
+    const int64_t one = (int64_t)sp->chunk * sp->N * 8;
+    *yes = (int64_t)free_b >= 5 * one + std::max<int64_t>(reserve_bytes, 0) ? 1 : 0;
     return MCF_OK;
 }
 extern "C" int mcf_snowplan_release_kept(mcf_snowplan* sp) {
@@ -2041,6 +2201,7 @@ extern "C" int mcf_snowplan_meand_accumulate(mcf_snowplan* sp, int32_t ch, const
     if (ch == 0) S_TRY(hipMemset(sp->d_sumD, 0, (size_t)sp->N * 8));
     if (ch == 0) S_TRY(hipMemset(sp->d_sden_na, 0, (size_t)sp->N * 4));
     if (nsnow == 0) return MCF_OK;
+    if (!(sp->series_valid & 16u)) return mcf::api_fail(MCF_ERR_STATE, "snow plan: the chunk's snow density series was switched off (mcf_snowplan_set_series)");
     S_TRY(hipMemcpy(sp->d_daymap, snowday, (size_t)nd * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_meand_accumulate, dim3((unsigned)((sp->N + 255) / 256)), dim3(256), 0, nullptr, sp->a.sden, sp->a.hgt,
                        sp->N, nd, (const int32_t*)sp->d_daymap, sp->sumD_steps == 0 ? 1 : 0, sp->d_sumD, sp->d_sden_na);
@@ -2113,6 +2274,11 @@ extern "C" int mcf_snowplan_micro_setup(mcf_snowplan* sp, const mcf_snow_inputs*
         if ((rc = b.alloc((void**)&mm, (int64_t)T * sizeof(MicroMet)))) return rc;
         hipLaunchKernelGGL(k_micro_steps, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, nullptr, a.temp, a.relhum, a.pres, a.mxtc1, T, mm);
         a.mmet = mm;
+        MicroStep* ms;
+        if ((rc = b.alloc((void**)&ms, (int64_t)T * sizeof(MicroStep)))) return rc;
+        hipLaunchKernelGGL(k_micro_pack, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, nullptr, a.rows, a.mmet, a.temp, a.pres, a.windspeed,
+                           a.swdown, a.difrad, a.lwdown, a.umu, T, ms);
+        a.mstep = ms;
     }
     // the chunk's snow series, where mcf_snowplan_run_chunk leaves them (sdepc holds totalSWE after the redistribution)
     a.sTc = sp->a.Tc; a.sTg = sp->a.Tg; a.swe = sp->a.sdepc; a.sdepg = sp->a.sdepg; a.sden = sp->a.sden;
@@ -2124,6 +2290,57 @@ extern "C" int mcf_snowplan_micro_setup(mcf_snowplan* sp, const mcf_snow_inputs*
     memcpy(sp->outsel, outsel, sizeof sp->outsel);
     S_TRY(hipDeviceSynchronize());
     sp->micro_ready = true;
+    return MCF_OK;
+}
+// one lane per cell: a cell that is not under snow at every step of the days (or has no vegetation height: gridmicrosnow1 skips
+// it) clears its tile's flag
+__global__ __launch_bounds__(256) void k_tiles_covered(const double* __restrict__ swe, const double* __restrict__ hgt, int64_t N, int k0,
+                                                       int nsteps, int cpb, uint8_t* __restrict__ flag) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    bool cov = !isnan(hgt[c]);
+    for (int k = 0; cov && k < nsteps; ++k) cov = swe[c + N * (int64_t)(k0 + k)] > 0.0;
+    if (!cov) flag[c / cpb] = 0;
+}
+extern "C" int mcf_snowplan_covered_tiles(mcf_snowplan* sp, mcf_plan* plan, int32_t ch, int32_t day, int32_t ndays, uint8_t* skip_tile,
+                                          int64_t n_tiles, int64_t* n_covered) {
+    if (!sp || !plan || !skip_tile || !n_covered) return mcf::api_fail(MCF_ERR_ARG, "null argument");
+    if (!sp->micro_ready) return mcf::api_fail(MCF_ERR_STATE, "snow plan: mcf_snowplan_micro_setup first");
+    if (ch < 0 || ch >= sp->nchunks) return mcf::api_fail(MCF_ERR_ARG, "chunk out of range");
+    const int ns = std::min(sp->chunk, sp->T - ch * sp->chunk);
+    if (day < 0 || ndays < 1 || (day + ndays) * 24 > ns) return mcf::api_fail(MCF_ERR_ARG, "days outside the chunk");
+    hipStream_t stream;
+    int64_t N;
+    int device, slot_days, rc;
+    mcf::RingView views[MCF_NOUT];
+    int32_t has[MCF_NOUT];
+    if ((rc = mcf::plan_ring_views(plan, 0, views, has, &stream, &N, &device, &slot_days))) return rc;
+    int cpb = 0;
+    bool all_sel = true;
+    for (int v = 0; v < MCF_NOUT; ++v)
+        if (has[v]) { cpb = views[v].cpb; all_sel = all_sel && sp->outsel[v] != 0; }
+    if (cpb <= 0) return mcf::api_fail(MCF_ERR_STATE, "the snow-day microclimate needs a plan with the tiled ring (reqhgt >= 0)");
+    if (N != sp->N || device != sp->device) return mcf::api_fail(MCF_ERR_ARG, "snow plan and solver plan differ in raster or device");
+    if (n_tiles != (N + cpb - 1) / cpb) return mcf::api_fail(MCF_ERR_ARG, "n_tiles is not the solver plan's number of tiles");
+    *n_covered = 0;
+    memset(skip_tile, 0, (size_t)n_tiles);
+    if (!all_sel) return MCF_OK;           // an output the snow microclimate does not produce stays the solver's everywhere
+    S_TRY(hipSetDevice(sp->device));
+    if (!sp->d_tflag || sp->tflag_cap < n_tiles) {
+        if ((rc = sp->b.alloc((void**)&sp->d_tflag, n_tiles))) return rc;
+        sp->tflag_cap = n_tiles;
+    }
+    const bool k = (size_t)ch < sp->kept.size() && sp->kept[ch].Tc;
+    if (!k && !(sp->series_valid & 4u)) return mcf::api_fail(MCF_ERR_STATE, "snow plan: the chunk's totalSWE series was switched off (mcf_snowplan_set_series)");
+    const double* swe = k ? sp->kept[ch].sdepc : sp->a.sdepc;
+    S_TRY(hipMemset(sp->d_tflag, 1, (size_t)n_tiles));
+    hipLaunchKernelGGL(k_tiles_covered, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, nullptr, swe, sp->ma.hgt, N, day * 24, ndays * 24, cpb,
+                       sp->d_tflag);
+    S_TRY(hipGetLastError());
+    S_TRY(hipMemcpy(skip_tile, sp->d_tflag, (size_t)n_tiles, hipMemcpyDeviceToHost));
+    int64_t n = 0;
+    for (int64_t t = 0; t < n_tiles; ++t) n += skip_tile[t] != 0;
+    *n_covered = n;
     return MCF_OK;
 }
 extern "C" int mcf_snowplan_microsnow(mcf_snowplan* sp, mcf_plan* plan, int32_t ch, int32_t slot, const int32_t* nosnowday) {
@@ -2139,10 +2356,22 @@ extern "C" int mcf_snowplan_microsnow(mcf_snowplan* sp, mcf_plan* plan, int32_t 
     int32_t has[MCF_NOUT];
     if ((rc = mcf::plan_ring_views(plan, slot, views, has, &stream, &N, &device, &slot_days))) return rc;
     for (int v = 0; v < MCF_NOUT; ++v) {
-        q.obase[v] = has[v] ? const_cast<double*>(views[v].base) : nullptr;
-        if (has[v]) q.ring = views[v];
+        if (!has[v]) continue;
+        if (!q.held) { q.base0 = const_cast<double*>(views[v].base); q.ring = views[v]; }
+        q.held |= 1u << v;
     }
-    if (q.ring.cpb <= 0) return mcf::api_fail(MCF_ERR_STATE, "the snow-day microclimate needs a plan with the tiled ring (reqhgt >= 0)");
+    if (!q.held || q.ring.cpb <= 0) return mcf::api_fail(MCF_ERR_STATE, "the snow-day microclimate needs a plan with the tiled ring (reqhgt >= 0)");
+    {   // the held variables' blocks follow each other at one stride (mcf_kernels.h RingView: [tile][day][variable][block])
+        int rank = 0;
+        const double* prev = nullptr;
+        for (int v = 0; v < MCF_NOUT; ++v) {
+            if (!has[v]) continue;
+            if (rank == 1) q.vstride = views[v].base - prev;
+            if (rank >= 1 && views[v].base - prev != q.vstride) return mcf::api_fail(MCF_ERR_STATE, "snow-day microclimate: the ring's variables are not equally spaced");
+            prev = views[v].base;
+            ++rank;
+        }
+    }
     if (N != sp->N || device != sp->device) return mcf::api_fail(MCF_ERR_ARG, "snow plan and solver plan differ in raster or device");
     const int ns = std::min(sp->chunk, sp->T - ch * sp->chunk), nd = ns / 24, day0 = ch * (sp->chunk / 24);
     if (nd > slot_days) return mcf::api_fail(MCF_ERR_ARG, "the ring slot holds fewer days than a snow chunk");
@@ -2159,15 +2388,17 @@ extern "C" int mcf_snowplan_microsnow(mcf_snowplan* sp, mcf_plan* plan, int32_t 
     q.m = sp->ma;
     {   // the chunk's snow series: where pass 1 left them if the chunk was kept, the plan's working buffers otherwise
         const bool k = (size_t)ch < sp->kept.size() && sp->kept[ch].Tc;
+        if (!k && sp->series_valid != 31) return mcf::api_fail(MCF_ERR_STATE, "snow plan: the chunk was run with series switched off (mcf_snowplan_set_series)");
         q.m.sTc = k ? sp->kept[ch].Tc : sp->a.Tc;
         q.m.sTg = k ? sp->kept[ch].Tg : sp->a.Tg;
         q.m.swe = k ? sp->kept[ch].sdepc : sp->a.sdepc;
         q.m.sdepg = k ? sp->kept[ch].sdepg : sp->a.sdepg;
         q.m.sden = k ? sp->kept[ch].sden : sp->a.sden;
     }
-    for (int v = 0; v < MCF_NOUT; ++v) q.sel[v] = sp->outsel[v];
+    for (int v = 0; v < MCF_NOUT; ++v) q.sel |= sp->outsel[v] ? 1u << v : 0u;
     q.daymap = sp->d_daymap; q.nosnow = sp->d_nosnow; q.ndays = nd;
-    hipLaunchKernelGGL(k_microsnow_ring, dim3((unsigned)((N + 63) / 64), (unsigned)nd), dim3(256), 0, nullptr, q);
+    hipLaunchKernelGGL(k_microsnow_ring, dim3((unsigned)((N + 63) / 64), (unsigned)nd), dim3(256), 0, nullptr, q, (const MicroStep*)q.m.mstep,
+                       q.daymap, q.nosnow);
     S_TRY(hipGetLastError());
     S_TRY(hipDeviceSynchronize());
     return MCF_OK;

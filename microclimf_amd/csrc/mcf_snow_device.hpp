@@ -591,7 +591,13 @@ __device__ __forceinline__ double min4(double a, double b, double c, double d) {
     return m;
 }
 
-__device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet& mm, const SunT& sun) {
+// `sink(i, v)` (i = the output's index in the reference's list: 4 wind speed, 5 Rdirdown, 6 Rdifdown, 7 Rlwdown, 8 Rswup,
+// 9 Rlwup) is offered each of these six the moment it is final; a sink that returns true has taken it (k_microsnow_ring
+// stores it into the ring there and then: the six values are not carried through the rest of the function — ten registers),
+// the default leaves it in the returned struct.
+struct MicroNoSink { __device__ __forceinline__ bool operator()(int, double) const { return false; } };
+template <class Sink = MicroNoSink>
+__device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet& mm, const SunT& sun, Sink sink = Sink()) {
     MicroOut out;
     double reqhgt = q.reqhgt;
     if (reqhgt == 0.0) reqhgt = 0.001;
@@ -639,26 +645,30 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
         }
         gHa = gdiv(kKa * 43 * uf, glog(gdiv(q.zref - d, 0.2 * zm + d - d)));   // gturbCpp(.., 43, 0, 0.0001)
         if (gHa < 0.0001) gHa = 0.0001;
-        out.uz = uz;
+        if (!sink(4, uz)) out.uz = uz;
     };
     double ez;
     if (reqhgt >= hgts) {                                        // above the canopy, cpp:4768-4798
         wind();
-        if (q.Rsw > 0.0) {
-            out.Rddown = q.Rdif * q.C(MQ_SVFA);
-            if (q.si > 0.0 && q.shadowmask > 0) {
-                out.Rbdown = gdiv(q.Rsw - q.Rdif, q.si);
-                if (out.Rbdown > 1352.0) out.Rbdown = 1352.0;
-                out.Rdup = q.alb * q.Rsw * q.C(MQ_SVFA);
-            } else {
-                out.Rbdown = 0.0;
-                out.Rdup = q.alb * q.Rdif * q.C(MQ_SVFA);
+        {
+            double Rbdown = 0.0, Rddown = 0.0, Rdup = 0.0;
+            if (q.Rsw > 0.0) {
+                Rddown = q.Rdif * q.C(MQ_SVFA);
+                if (q.si > 0.0 && q.shadowmask > 0) {
+                    Rbdown = gdiv(q.Rsw - q.Rdif, q.si);
+                    if (Rbdown > 1352.0) Rbdown = 1352.0;
+                    Rdup = q.alb * q.Rsw * q.C(MQ_SVFA);
+                } else {
+                    Rdup = q.alb * q.Rdif * q.C(MQ_SVFA);
+                }
             }
-        } else {
-            out.Rbdown = 0.0; out.Rddown = 0.0; out.Rdup = 0.0;
+            const double lwdn = q.C(MQ_SVFA) * q.Rlw, lwup = q.C(MQ_SVFA) * 0.97 * kSb * rad4(q.Tc);
+            if (!sink(5, Rbdown)) out.Rbdown = Rbdown;
+            if (!sink(6, Rddown)) out.Rddown = Rddown;
+            if (!sink(7, lwdn)) out.Rlwdn = lwdn;
+            if (!sink(8, Rdup)) out.Rdup = Rdup;
+            if (!sink(9, lwup)) out.Rlwup = lwup;
         }
-        out.Rlwdn = q.C(MQ_SVFA) * q.Rlw;
-        out.Rlwup = q.C(MQ_SVFA) * 0.97 * kSb * rad4(q.Tc);
         const AboveTV tv = tv_above(reqhgt, q.zref, d, zm, q.Tc, q.tc, ea);
         out.Tz = tv.Tz;
         out.tleaf = q.Tc;
@@ -737,6 +747,9 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
             }
         }
         if (q.shadowmask == 0) Rbdown = 0.0;
+        if (!sink(5, Rbdown)) out.Rbdown = Rbdown;
+        if (!sink(6, Rddown)) out.Rddown = Rddown;
+        if (!sink(8, Rdup)) out.Rdup = Rdup;
         wind();
         // leaftemp (cpp:1333-1364) with gsmax = 999.999: gV = gh
         const double lwcan = 0.97 * kSb * rad4(q.Tc);
@@ -745,6 +758,8 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
         const double lwup = eg * lwgro + (1 - eg) * lwcan;
         const double lwdn = eaa * q.Rlw + (1 - eaa) * lwcan;
         const double leafabs = radLsw + 0.97 * 0.5 * (lwup + lwdn);
+        if (!sink(7, lwdn)) out.Rlwdn = lwdn;
+        if (!sink(9, lwup)) out.Rlwup = lwup;
         const double ileafd = q.C(MQ_ILEAFD);
         double gh = 0.135 * gsqrt(uz * ileafd) * 1.4;
         {   // mincondCpp(leafabs, 999.99, Tcan, leafd) cpp:1316-1331
@@ -780,8 +795,6 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
         const double mu = la * (43 * ipk);
         ez = tv_below(bk, lnpai, q.C(MQ_LEAFDEN), (mmg * (es - ea)) * fr, Ll, tv.ez * mu, svp(q.Tg) * mu,
                       fabs(estl - tv.ez) * mu) * gdiv(1.0, mu);
-        out.Rbdown = Rbdown; out.Rddown = Rddown; out.Rdup = Rdup;
-        out.Rlwdn = lwdn; out.Rlwup = lwup;
     }
     out.rh = gdiv(ez, svp(out.Tz)) * 100.0;
     if (out.rh > 100.0) out.rh = 100.0;

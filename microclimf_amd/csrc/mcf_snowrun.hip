@@ -399,7 +399,13 @@ extern "C" int mcf_snowrun_pass1(mcf_snowrun* h, const mcf_snowdriver_out* smod,
             for (int ch = 0; ch < h->nchunks; ++ch) {
                 guarded([&] {
                     for (int b = t; b < h->nb && !failed; b += h->nt) {
-                        const int rc2 = mcf_snowplan_checkpoint(h->blocks[(size_t)b].sp, ch);      // pass 2 starts any chunk from here
+                        Block& k = h->blocks[(size_t)b];
+                        int rc2 = mcf_snowplan_checkpoint(k.sp, ch);      // pass 2 starts any chunk from here
+                        // a chunk that could not stay in HBM is re-run by pass 2 if it holds a snow day: unless the caller wants the snow
+                        // series, pass 1 writes only what it reads itself of such a chunk (totalSWE, density: mcf_snowplan_set_series)
+                        int32_t room = 1;
+                        if (!rc2 && !smod) rc2 = mcf_snowplan_can_keep(k.sp, h->keep_reserve, &room);
+                        if (!rc2) rc2 = mcf_snowplan_set_series(k.sp, room ? 31u : (4u | 16u));
                         if (rc2) { fail_here(rc2); break; }
                     }
                 });
@@ -539,6 +545,7 @@ extern "C" int mcf_snowrun_pass2(mcf_snowrun* h, const mcf_snow_inputs* micro, d
                         rc2 = mcf_snowplan_micro_setup(k.sp, &bs, sub_of_day.data(), (int32_t)sub_of_day.size(), h->opt.reqhgt, mat, outm, 0);
                     }
                     if (!rc2 && !ndays_.empty()) rc2 = mcf_plan_set_mxtc(k.plan, mxtc);
+                    if (!rc2) rc2 = mcf_snowplan_set_series(k.sp, 31u);         // (pass 2's re-runs feed the snow microclimate)
                     if (rc2) { fail_here(rc2); break; }
                 }
             });
@@ -559,13 +566,30 @@ extern "C" int mcf_snowrun_pass2(mcf_snowrun* h, const mcf_snow_inputs* micro, d
                 }
                 return MCF_OK;
             };
-            auto solver_days = [&](Block& k, int slot, int d0, int nd) -> int {     // runs of consecutive no-snow days
+            // runs of consecutive no-snow days.  Where such a run lies in a chunk with snow, the tiles whose cells are all under snow
+            // for the whole run are left out (include/mcf.h mcf_plan_run_days_masked): gridmicrosnow1 overwrites every one of their values
+            static const bool no_skip = getenv("MCF_SNOW_NO_TILE_SKIP") != nullptr;
+            std::vector<uint8_t> skip;
+            auto solver_days = [&](Block& k, int slot, int ch, int d0, int nd, bool has_snow) -> int {
                 int q = 0;
                 while (q < nd) {
                     if (!h->nosnowday[(size_t)(d0 + q)]) { ++q; continue; }
                     int e = q;
                     while (e < nd && h->nosnowday[(size_t)(d0 + e)]) ++e;
-                    const int rc2 = mcf_plan_run_days_at(k.plan, d0 + q, e - q, slot, q);
+                    int rc2;
+                    int64_t ncov = 0;
+                    bool any_snow_day = false;
+                    for (int d = q; d < e; ++d) any_snow_day |= h->snowday[(size_t)(d0 + d)] != 0;
+                    if (has_snow && any_snow_day && !no_skip && ch >= 0) {
+                        mcf_ring_layout lay;
+                        if ((rc2 = mcf_plan_ring_layout(k.plan, &lay))) return rc2;
+                        const int64_t nt = (lay.cells + lay.cells_per_tile - 1) / lay.cells_per_tile;
+                        skip.resize((size_t)nt);
+                        if ((rc2 = mcf_snowplan_covered_tiles(k.sp, k.plan, ch, q, e - q, skip.data(), nt, &ncov))) return rc2;
+                        rc2 = mcf_plan_run_days_masked(k.plan, d0 + q, e - q, slot, q, ncov ? skip.data() : nullptr, ncov ? nt : 0);
+                    } else {
+                        rc2 = mcf_plan_run_days_at(k.plan, d0 + q, e - q, slot, q);
+                    }
                     if (rc2) return rc2;
                     q = e;
                 }
@@ -590,7 +614,7 @@ extern "C" int mcf_snowrun_pass2(mcf_snowrun* h, const mcf_snow_inputs* micro, d
                 guarded([&] {
                     for (int b = t; b < h->nb && !failed; b += h->nt) {
                         Block& k = h->blocks[(size_t)b];
-                        int rc2 = solver_days(k, slot, d0, nd);
+                        int rc2 = solver_days(k, slot, ch, d0, nd, has_snow);
                         if (!rc2 && has_snow) rc2 = mcf_snowplan_microsnow(k.sp, k.plan, ch, slot, &h->nosnowday[(size_t)d0]);
                         if (!rc2 && nd > 0) rc2 = fetch_days(k, slot, d0, nd);
                         if (rc2) { fail_here(rc2); break; }
@@ -604,7 +628,7 @@ extern "C" int mcf_snowrun_pass2(mcf_snowrun* h, const mcf_snow_inputs* micro, d
                     Block& k = h->blocks[(size_t)b];
                     for (int d0 = h->nchunks * cd; d0 < ndays && !failed; d0 += cd) {
                         const int nd = std::min(cd, ndays - d0);
-                        int rc2 = solver_days(k, 0, d0, nd);
+                        int rc2 = solver_days(k, 0, -1, d0, nd, false);
                         if (!rc2) rc2 = fetch_days(k, 0, d0, nd);
                         if (rc2) { fail_here(rc2); break; }
                     }

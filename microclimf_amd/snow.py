@@ -728,6 +728,18 @@ class SnowPlan:
         _abi.check(self._lib.mcf_snowplan_keep_chunk(self._p, int(chunk), int(reserve_bytes), C.byref(k)))
         return bool(k.value)
 
+    def can_keep(self, reserve_bytes: int = 32 << 30) -> bool:
+        """Would keep_chunk keep a chunk now? (include/mcf.h mcf_snowplan_can_keep)"""
+        k = C.c_int32()
+        _abi.check(self._lib.mcf_snowplan_can_keep(self._p, int(reserve_bytes), C.byref(k)))
+        return bool(k.value)
+
+    SERIES_ALL, SERIES_PASS1 = 31, 4 | 16       # all five; totalSWE (day classes) + density (mean damping depth)
+
+    def set_series(self, mask: int):
+        """Which of the five device series run_chunk writes from now on (include/mcf.h mcf_snowplan_set_series)."""
+        _abi.check(self._lib.mcf_snowplan_set_series(self._p, int(mask)))
+
     def release_kept(self):
         _abi.check(self._lib.mcf_snowplan_release_kept(self._p))
 
@@ -767,6 +779,16 @@ class SnowPlan:
         sel = (C.c_int32 * _abi.NOUT)(*[1 if v else 0 for v in out])
         _abi.check(self._lib.mcf_snowplan_micro_setup(self._p, C.byref(m.inputs), sod.ctypes.data_as(_abi.c_int32_p),
                                                       int(sod.size), float(reqhgt), float(mat), C.byref(sel), 1 if reuse_static else 0))
+
+    def covered_tiles(self, plan, chunk: int, day: int, ndays: int):
+        """uint8 [tiles of `plan`]: 1 where every cell of the tile lies under snow at every step of the chunk's days
+        [day, day + ndays) — mcf_snowplan_microsnow overwrites all its values, the solver may leave the tile out
+        (include/mcf.h mcf_snowplan_covered_tiles); and the number of such tiles"""
+        sk = np.zeros(plan.n_tiles, np.uint8)
+        n = C.c_int64(0)
+        _abi.check(self._lib.mcf_snowplan_covered_tiles(self._p, plan._p, int(chunk), int(day), int(ndays),
+                                                        sk.ctypes.data_as(C.POINTER(C.c_uint8)), int(sk.size), C.byref(n)))
+        return sk, int(n.value)
 
     def microsnow(self, plan, chunk: int, slot: int, nosnowday):
         """gridmicrosnow1 on the chunk's snow days, written over the solver's outputs in ring slot `slot` of `plan`."""

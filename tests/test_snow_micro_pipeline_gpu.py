@@ -157,6 +157,7 @@ def test_device_resident_snow_run_equals_the_host_orchestrated_merge(reqhgt, col
             kept.append(bool(d["snowdays"].any()) and sp.keep_chunk(ch, reserve_bytes=1 << 30))
         assert any(kept)
         got3 = {k: np.full((rows, cols, T), np.nan, order="F") for k in moutn}
+        left_out = 0
         for ch in range(sp.chunks):
             slot = ch % 2
             nos = nosnowday[ch * 5:ch * 5 + 5]
@@ -170,7 +171,15 @@ def test_device_resident_snow_run_equals_the_host_orchestrated_merge(reqhgt, col
                 e = k
                 while e < 5 and nos[e]:
                     e += 1
-                plan.run_days_at(ch * 5 + k, e - k, slot, k)
+                # ... and the solver leaves out the tiles whose every value the snow microclimate overwrites (the slot holds chunk
+                # ch - 2's values there until it does)
+                sk, ncov = sp.covered_tiles(plan, ch, k, e - k) if has_snow else (None, 0)
+                if ncov:
+                    assert sk.sum() == ncov and snowday[ch * 5 + k:ch * 5 + e].all()
+                    plan.run_days_masked(ch * 5 + k, e - k, slot, k, sk)
+                    left_out += ncov * (e - k)
+                else:
+                    plan.run_days_at(ch * 5 + k, e - k, slot, k)
                 k = e
             if has_snow:
                 sp.microsnow(plan, ch, slot, nos)
@@ -178,6 +187,10 @@ def test_device_resident_snow_run_equals_the_host_orchestrated_merge(reqhgt, col
                 got3[kname][:, :, ch * 120:(ch + 1) * 120] = plan.fetch(slot, kname, 0, 120)
         for k in got:
             assert np.array_equal(got[k], got3[k], equal_nan=True), k
+        if reqhgt == 0.0:
+            assert left_out == 0            # tleaf / relhum / wind speed stay the solver's: nothing may be left out
+        with pytest.raises(RuntimeError, match="number of tiles"):
+            plan.run_days_masked(0, 1, 0, 0, np.zeros(plan.n_tiles + 1, np.uint8))
         sp.release_kept()                                           # (the sets go to a pool the next year's pass 1 draws from)
         with pytest.raises(RuntimeError):
             sp.restore(sp.chunks)           # no such checkpoint
@@ -187,3 +200,47 @@ def test_device_resident_snow_run_equals_the_host_orchestrated_merge(reqhgt, col
         fin = np.isfinite(w)
         if fin.any():        # (reqhgt == 0: tleaf and relhum are NA throughout)
             assert np.max(np.abs(g[fin] - w[fin]) / (1 + np.abs(w[fin]))) < 1e-12, k
+
+
+def test_pass_one_may_leave_the_series_it_does_not_read_unwritten():
+    """mcf_snowplan_set_series: with Tc, Tg and the ground snow depth switched off the chunk loop's state, the per-step
+    extremes of totalSWE and the hand-over are bit for bit those of the full run; such a chunk cannot be kept, handed to the
+    snow microclimate or downloaded."""
+    rows, cols, T = 22, 13, 240
+    sw = synthetic.snow_workload(rows, cols, T, cold=0.0, zref=3.5, start_doy=90)
+    _, _, dtm = synthetic.rasters(rows, cols)
+    dtm = np.where(np.isnan(sw["vegp"]["hgt"]), np.nan, dtm)
+    args = (sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"], sw["other"], sw["snowenv"], dtm, 1.0, 0.02)
+
+    def run(sp, ch):
+        ss, sn = sp.surface_partial()
+        ts, tn = sp.prepare_chunk(ch, None, 0, 0, ss / sn)
+        sp.run_chunk(ch, ts / tn)
+        return sp.apply3(ch, "max")[0], sp.apply3(ch, "min")[0]
+
+    with S.SnowPlan(*args, keep_results=False) as sp:
+        full = [run(sp, ch) for ch in range(sp.chunks)]
+        h_full = sp.handover().copy()
+        sp.reset()
+        sp.set_series(sp.SERIES_PASS1)
+        for ch in range(sp.chunks):
+            mx, mn = run(sp, ch)
+            assert np.array_equal(mx, full[ch][0]) and np.array_equal(mn, full[ch][1])
+            sp.meand_accumulate(ch, np.ones(5, np.int32))
+            assert not sp.keep_chunk(ch, reserve_bytes=0)
+        assert np.array_equal(sp.handover(), h_full, equal_nan=True)
+        sp.reset()
+        sp.set_series(16)                      # without totalSWE the day classes cannot be had
+        ss, sn = sp.surface_partial()
+        ts, tn = sp.prepare_chunk(0, None, 0, 0, ss / sn)
+        sp.run_chunk(0, ts / tn)
+        with pytest.raises(RuntimeError, match="switched off"):
+            sp.apply3(0, "max")
+        with pytest.raises(RuntimeError, match="mask"):
+            sp.set_series(32)
+    with S.SnowPlan(*args, keep_results=True) as sp:
+        sp.set_series(sp.SERIES_PASS1)
+        ss, sn = sp.surface_partial()
+        ts, tn = sp.prepare_chunk(0, None, 0, 0, ss / sn)
+        with pytest.raises(RuntimeError, match="switched off"):
+            sp.run_chunk(0, ts / tn)

@@ -170,6 +170,7 @@ def run_snow_config(args, world, rank, local_rank):
     keep_reserve = int(float(os.environ.get("MCF_SNOW_KEEP_RESERVE_GB", "24")) * 2**30)
     outm = [1] * 10 if args.reqhgt > 0 else [1 if i in (0, 3, 5, 6, 7, 8, 9) else 0 for i in range(10)]
     ncd = sp.chunks * chunk_days
+    tile_skip = os.environ.get("MCF_SNOW_NO_TILE_SKIP") is None
 
     def one_year(probe=None):
         """probe (the untimed verification year): {"cells": ...} — the sample cells' five snow series are read back behind
@@ -181,6 +182,10 @@ def run_snow_config(args, world, rank, local_rank):
         kept = [False] * sp.chunks
         for ch in range(sp.chunks):
             sp.checkpoint(ch)                                   # 24 B per cell: pass 2 starts any chunk from here
+            # a chunk that could not stay in HBM anyway is re-run by pass 2 if it holds a snow day: pass 1 writes only what it
+            # reads itself of such a chunk — totalSWE (day classes) and the density (mean damping depth), 16 of 40 B per cell-step
+            full = probe is not None or sp.can_keep(keep_reserve)
+            sp.set_series(sp.SERIES_ALL if full else sp.SERIES_PASS1)
             tl = snow_chunk(ch)
             mx, cmx = sp.apply3(ch, "max")
             mn, cmn = sp.apply3(ch, "min")
@@ -193,11 +198,12 @@ def run_snow_config(args, world, rank, local_rank):
             if probe is not None:
                 for name in probe["smod"]:
                     probe["smod"][name][:, ch * 120:(ch + 1) * 120] = sp.fetch_cells(name, probe["cells"])
-            elif days["snowdays"].any():                        # its five series stay in HBM for pass 2 while room remains
+            elif full and days["snowdays"].any():               # its five series stay in HBM for pass 2 while room remains
                 kept[ch] = sp.keep_chunk(ch, reserve_bytes=keep_reserve)
             tl = lap("meanD", tl)
         # ---- between: gridmicrosnow1's set-up on the snow-day subset, the solver's maximum temperature on the no-snow subset
         tl = time.perf_counter()
+        sp.set_series(sp.SERIES_ALL)                            # (pass 2's re-runs feed the snow microclimate)
         sdays, ndays_ = np.flatnonzero(snowday), np.flatnonzero(nosnowday)
         stats["snow_days"] += int(sdays.size)
         if sdays.size:
@@ -234,7 +240,17 @@ def run_snow_config(args, world, rank, local_rank):
                     e += 1
                 if d0 + k < ndays:
                     nd = min(e, ndays - d0) - k
-                    plan.run_days_at(d0 + k, nd, slot, k)
+                    # tiles whose cells all lie under snow for the whole run: every value the solver would write there is
+                    # overwritten by the snow microclimate below (`.runmicrosnow1`'s merge) — left out of the launch
+                    ncov = 0
+                    if tile_skip and sdays.size and snowday[d0 + k:d0 + k + nd].any():
+                        sk, ncov = sp.covered_tiles(plan, ch, k, nd)
+                    if ncov:
+                        plan.run_days_masked(d0 + k, nd, slot, k, sk)
+                        stats["tile_days_skipped"] = stats.get("tile_days_skipped", 0) + ncov * nd
+                    else:
+                        plan.run_days_at(d0 + k, nd, slot, k)
+                    stats["tile_days"] = stats.get("tile_days", 0) + plan.n_tiles * nd
                     stats["solver_days"] += nd
                 k = e
             tl = lap("solver", tl)
@@ -446,7 +462,12 @@ def run_snow_config(args, world, rank, local_rank):
                             "gridmicrosnow1 on the snow days, merged in the device ring as `.runmicrosnow1` does "
                             "[BASELINE.json configs[4]]",
                 "baseline_config": 4, "rows_per_gpu": rows, "cols": cols, "tsteps": T, "valid_cells": int(valid_all),
-                "solver_days_per_year": sd, "snow_days_per_year": stats["snow_days"] / max(args.steps, 1),
+                "solver_days_per_year": sd,
+                "solver_tile_days_left_out": (f"{stats.get('tile_days_skipped', 0) / max(stats.get('tile_days', 0), 1):.3f} of the solver's tile-days: "
+                                              "tiles whose cells all lie under snow for a whole run of days that are snow days as well — "
+                                              "gridmicrosnow1 overwrites every value there (`.runmicrosnow1`'s merge), the merged output is the same "
+                                              "(MCF_SNOW_NO_TILE_SKIP=1 solves them all)") if tile_skip else "none (MCF_SNOW_NO_TILE_SKIP)",
+                "snow_days_per_year": stats["snow_days"] / max(args.steps, 1),
                 "halo": (("RCCL" if backend == "nccl" else backend + " (REHEARSAL: ranks share a GPU)")
                          + " send/recv of 128 surface rows per neighbour and chunk, packed and unpacked on the device") if exchange_ok and world > 1 else
                         "generated, not exchanged: the neighbouring blocks' snow-free surface, resident on the device (a rank's share of "
