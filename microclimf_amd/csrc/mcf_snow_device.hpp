@@ -560,14 +560,13 @@ __device__ __forceinline__ double tv_below(const BelowK& k, double lnpai, double
     return near + farg;
 }
 struct AboveTV { double Tz, ez; };
-__device__ __forceinline__ AboveTV tv_above(double reqhgt, double zref, double d, double zm, double T0, double tc,
-                                            double ea) {   // cpp:1298-1313, surfwet = 1
-    const double zh = 0.2 * zm;
+// TVabove (cpp:1298-1313, surfwet = 1) with the two logarithms handed in: Lz5 = log((z - d) / zh), Lref5 = log((zref - d) / zh), zh = 0.2 zm
+__device__ __forceinline__ AboveTV tv_above_l(double z, double d, double zm, double Lz5, double Lref5, double T0, double tc,
+                                              double ea) {
     const double estl = svp(T0);
     AboveTV o;
-    if (reqhgt > (d + zh)) {
-        const double izh = gdiv(1.0, zh);
-        const double lnr = gdiv(glog((reqhgt - d) * izh), glog((zref - d) * izh));
+    if (z > (d + 0.2 * zm)) {
+        const double lnr = gdiv(Lz5, Lref5);
         o.Tz = tc + (T0 - tc) * (1 - lnr);
         o.ez = ea + (estl - ea) * (1 - lnr);
     } else {
@@ -614,7 +613,12 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
     // Roughness and wind (windtiCpp, windCpp cpp:1189-1218, gturbCpp) read nothing the radiation block makes and the radiation
     // block reads nothing of theirs: inside the canopy they are evaluated BEHIND it (same operations, same values) — five
     // doubles fewer alive through the two-stream algebra, the fullest stretch of the function.
-    double d = 0.0, zm = 1e-5, uf, uz, gHa;
+    // One logarithm per height: Lref = log((zref - d) / zm) serves the friction velocity, and — as Lref + log 5 = log((zref - d) /
+    // (0.2 zm)) — gturbCpp's conductance and the reference height of the temperature / vapour profile; Lz = log((z - d) / zm) of
+    // the wind profile's own height z (reqhgt above the canopy, the canopy top inside it) is that profile's too.  (The reference
+    // takes three more logarithms of the same quotients; its `0.2 zm + d - d` differs from 0.2 zm in the last bits only.)
+    double d = 0.0, zm = 1e-5, uf, uz, gHa, Lref5, Lz5 = 0.0;
+    constexpr double kLn5 = 0x1.9c041f7ed8d33p+0;
     auto wind = [&]() {
         double wa = 0.0;
         if (hgts > 0.0) {
@@ -627,14 +631,20 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
         if (isnan(ws)) ws = 1.0;
         if (ws < 0.05) ws = 0.05;
         const double izm = gdiv(1.0, zm);
-        uf = gdiv(kKa * q.u2, glog((q.zref - d) * izm)) * q.umu * ws;
+        const double Lref = glog((q.zref - d) * izm);
+        Lref5 = Lref + kLn5;
+        uf = gdiv(kKa * q.u2, Lref) * q.umu * ws;
         if (uf < 0.001) uf = 0.001;
         uz = uf;
         if (reqhgt > 0) {
             if (reqhgt >= hgts) {
-                uz = (uf * (1.0 / kKa)) * glog((reqhgt - d) * izm);
+                const double Lz = glog((reqhgt - d) * izm);
+                Lz5 = Lz + kLn5;
+                uz = (uf * (1.0 / kKa)) * Lz;
             } else {
-                double uh = (uf * (1.0 / kKa)) * glog((hgts - d) * izm);
+                const double Lz = glog((hgts - d) * izm);
+                Lz5 = Lz + kLn5;
+                double uh = (uf * (1.0 / kKa)) * Lz;
                 if (uh < uf) uh = uf;
                 double Be = gdiv(uf, uh);
                 if (Be < 0.001) Be = 0.001;
@@ -643,7 +653,7 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
             }
             if (uz > q.u2) uz = q.u2;
         }
-        gHa = gdiv(kKa * 43 * uf, glog(gdiv(q.zref - d, 0.2 * zm + d - d)));   // gturbCpp(.., 43, 0, 0.0001)
+        gHa = gdiv(kKa * 43 * uf, Lref5);                       // gturbCpp(.., 43, 0, 0.0001)
         if (gHa < 0.0001) gHa = 0.0001;
         if (!sink(4, uz)) out.uz = uz;
     };
@@ -669,7 +679,7 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
             if (!sink(8, Rdup)) out.Rdup = Rdup;
             if (!sink(9, lwup)) out.Rlwup = lwup;
         }
-        const AboveTV tv = tv_above(reqhgt, q.zref, d, zm, q.Tc, q.tc, ea);
+        const AboveTV tv = tv_above_l(reqhgt, d, zm, Lz5, Lref5, q.Tc, q.tc, ea);
         out.Tz = tv.Tz;
         out.tleaf = q.Tc;
         ez = tv.ez;
@@ -786,8 +796,8 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
         const BelowK bk = below_k(reqhgt, d, hgts, uf);
         const double lnpai = glog(pais);
         const double H = 29.3 * gHa * (q.Tc - q.tc);
-        const double fr = 1.0 - gexp(-pais);
-        const AboveTV tv = tv_above(hgts, q.zref, d, zm, q.Tc, q.tc, ea);
+        const double fr = 1.0 - eg * eaa;                         // exp(-pais) = exp(-(pais - paias)) exp(-paias)
+        const AboveTV tv = tv_above_l(hgts, d, zm, Lz5, Lref5, q.Tc, q.tc, ea);
         out.Tz = tv_below(bk, lnpai, q.C(MQ_LEAFDEN), H * fr, Hl, tv.Tz * 29.3 * 43.0, q.Tg * 29.3 * 43.0,
                           fabs(tleaf - tv.Tz) * 29.3 * 43.0) * (1.0 / (29.3 * 43));
         const double la = mm.lat0;

@@ -19,4 +19,8 @@ echo "trace done"
 rocprofv3 --kernel-trace --output-format csv -d $out/pmc_sq --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY -- python3 $W > /dev/null 2> $out/pmc_sq.err
 echo "sq done"
 rocprofv3 --kernel-trace --output-format csv -d $out/pmc_misc --pmc GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_LDS -- python3 $W > /dev/null 2> $out/pmc_misc.err
+echo "misc done"
+# HBM bytes of the same kernels (separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes)
+rocprofv3 --kernel-trace --output-format csv -d $out/pmc_fetch --pmc FETCH_SIZE -- python3 $W > /dev/null 2> $out/pmc_fetch.err
+rocprofv3 --kernel-trace --output-format csv -d $out/pmc_write --pmc WRITE_SIZE -- python3 $W > /dev/null 2> $out/pmc_write.err
 echo done
