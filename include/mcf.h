@@ -567,8 +567,10 @@ int mcf_snowmodel1(const mcf_snowdriver_in *in, mcf_snowdriver_out *out, int32_t
  * thread; per chunk the blocks' snow surfaces meet in one host array (each block takes its halo rows from it) and the two
  * raster-wide means are formed from the blocks' (sum, count) in block order — the exchanges of the stepwise API below,
  * done in host memory.  Equal to mcf_snowmodel1 up to the summation order of those two means (1e-9 in the tests); a block's
- * series reach the caller's arrays chunk by chunk (host temporaries of one chunk per block).  n_devices = 0: every visible
- * device; n_blocks = 0: one per device. */
+ * series reach the caller's arrays chunk by chunk, downloaded through the row pitch straight into their rows.  n_devices = 0:
+ * every visible device; n_blocks = 0: one per device.  Unlike the solver's _multi entries, EVERY block's snow plan stays
+ * resident for the whole run (the chunk loop couples the blocks at every chunk): more blocks than devices do not lower a
+ * device's memory footprint here, they only share its time. */
 int mcf_snowmodel1_multi(const mcf_snowdriver_in *in, mcf_snowdriver_out *out, const mcf_multi *multi);
 
 /* The same loop one step at a time, for a row block of a tiled raster (one plan per rank): between the
