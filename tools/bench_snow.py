@@ -474,7 +474,8 @@ def run_snow_config(args, world, rank, local_rank):
                         "the partition without its neighbours)" if not exchange_ok else "single block",
                 "collectives": "per chunk: 2 (sum, count) all-reduces + min / max all-reduce of [120] doubles; once: twi (sum, count)",
                 "passes": "2 over the snow series (gridmicrosnow1 needs the whole series' mean snow damping depth and day list "
-                          "first); pass 1 checkpoints every chunk's start state (24 B per cell), pass 2 restores and re-runs only the "
+                          "first); pass 1 checkpoints every chunk's start state (24 B per cell) and, of a chunk that cannot stay in HBM, "
+                          "stores only the two series it reads itself (totalSWE, density: 16 of 40 B per cell-step); pass 2 restores and re-runs only the "
                           f"chunks that hold a snow day ({stats.get('chunks_skipped', 0) // max(stats['years'], 1)} of {sp.chunks} skipped per year) "
                           f"and whose series did not stay in HBM ({stats.get('chunks_kept', 0) // max(stats['years'], 1)} kept per year, 10 GB each "
                           "for a 512 x 4096 block; the cache is allocated once per plan — in the warm-up year here, ~0.25 s per chunk — and "
