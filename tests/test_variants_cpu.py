@@ -16,7 +16,8 @@ def test_every_variant_patch_applies_to_the_shipped_kernel_source(tmp_path):
     for p in patches:
         d = tmp_path / p.stem / "microclimf_amd" / "csrc"
         d.mkdir(parents=True)
-        shutil.copy(CSRC / "mcf_kernels.hip", d / "mcf_kernels.hip")
+        for f in ("mcf_kernels.hip", "mcf_device.hpp"):
+            shutil.copy(CSRC / f, d / f)
         r = subprocess.run(["patch", "-s", "-p1", "--dry-run", "-i", str(p)], cwd=tmp_path / p.stem, capture_output=True, text=True)
         assert r.returncode == 0, f"{p.name} no longer applies (run tools/make_variant_patches.py): {r.stdout}{r.stderr}"
 

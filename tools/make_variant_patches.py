@@ -120,6 +120,13 @@ VARIANTS = {
     # what the output selector costs: every variable held, in order (sel = v known at compile time) — bench.py's mask
     "allout": [("            const unsigned sel = (unsigned)(osel >> (4 * v)) & 15u;\n", "            const unsigned sel = (unsigned)v;     // VARIANT: all ten outputs, identity order\n")],
     # persistent workgroups (a fixed grid walking the tile sequence): measured a loss in rounds 2 and 3 (128 VGPRs, scratch)
+    # (an edit may name its file: (file, old, new); two-element edits are on mcf_kernels.hip)
+    "tab_noconflict": [("mcf_device.hpp", '''            : "=v"(off) : "v"(K.sh3), "v"(t));
+        T = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(K.tab) + off);''', '''            : "=v"(off) : "v"(K.sh3), "v"(t));
+        off &= 8u;      // TIMING VARIANT: every lane reads one of two neighbouring entries (no bank conflicts)
+        T = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(K.tab) + off);'''),
+                       ("mcf_device.hpp", "    const double2 cl = *reinterpret_cast<const double2*>(K.ltab + 2 * j);",
+                        "    const double2 cl = *reinterpret_cast<const double2*>(K.ltab + 2 * (j & 1));     // TIMING VARIANT")],
     "persistent_loop": [('''    const int rot = (int)((blockIdx.x >> 8) & 1);
     const int64_t pos = tile_position(a.ntiles_launch);
     if (pos < 0) return;
@@ -144,27 +151,34 @@ VARIANTS = {
 
 
 def main():
-    src = SRC.read_text()
+    files = {f: (SRC.parent / f).read_text() for f in ("mcf_kernels.hip", "mcf_device.hpp")}
     OUT.mkdir(exist_ok=True)
     bad = 0
     with tempfile.TemporaryDirectory() as td:
-        a = Path(td) / "a.hip"
-        a.write_text(src)
         for name, edits in VARIANTS.items():
-            s = src
-            for old, new in edits:
-                if s.count(old) != 1:
-                    print(f"{name}: anchor not found exactly once: {old[:60]!r}", file=sys.stderr)
+            cur = dict(files)
+            ok = True
+            for e in edits:
+                f, old, new = e if len(e) == 3 else ("mcf_kernels.hip",) + tuple(e)
+                if cur[f].count(old) != 1:
+                    print(f"{name}: anchor not found exactly once in {f}: {old[:60]!r}", file=sys.stderr)
                     bad += 1
+                    ok = False
                     break
-                s = s.replace(old, new)
-            else:
-                b = Path(td) / "b.hip"
-                b.write_text(s)
-                d = subprocess.run(["diff", "-u", "--label", "a/microclimf_amd/csrc/mcf_kernels.hip", "--label",
-                                    "b/microclimf_amd/csrc/mcf_kernels.hip", str(a), str(b)], capture_output=True, text=True).stdout
-                (OUT / f"{name}.patch").write_text(d)
-                print(f"{name}: {len(d.splitlines())} lines")
+                cur[f] = cur[f].replace(old, new)
+            if not ok:
+                continue
+            d = ""
+            for f in files:
+                if cur[f] == files[f]:
+                    continue
+                a, b = Path(td) / ("a_" + f), Path(td) / ("b_" + f)
+                a.write_text(files[f])
+                b.write_text(cur[f])
+                d += subprocess.run(["diff", "-u", "--label", f"a/microclimf_amd/csrc/{f}", "--label", f"b/microclimf_amd/csrc/{f}",
+                                     str(a), str(b)], capture_output=True, text=True).stdout
+            (OUT / f"{name}.patch").write_text(d)
+            print(f"{name}: {len(d.splitlines())} lines")
     return 1 if bad else 0
 
 
