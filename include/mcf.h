@@ -736,6 +736,10 @@ typedef struct mcf_snowrun mcf_snowrun;
 int mcf_snowrun_create(const mcf_microsnow_in *in, const mcf_options *opt, const mcf_multi *multi, mcf_snowrun **run);
 void mcf_snowrun_destroy(mcf_snowrun *run);
 int32_t mcf_snowrun_days(const mcf_snowrun *run);     /* tsteps / 24 */
+/* What pass 2 was spared (diagnostics; tests assert which path ran): stats[0] tile-days of the solver's runs inside snow chunks,
+ * [1] of them left out (tiles wholly under snow, mcf_plan_run_days_masked), [2] snow chunks whose series had stayed in HBM,
+ * [3] snow chunks re-run from their checkpoints. */
+int mcf_snowrun_stats(const mcf_snowrun *run, int64_t stats[4]);
 /* snowday / nosnowday: [mcf_snowrun_days] or NULL */
 int mcf_snowrun_pass1(mcf_snowrun *run, const mcf_snowdriver_out *smod, int32_t *snowday, int32_t *nosnowday);
 int mcf_snowrun_pass2(mcf_snowrun *run, const mcf_snow_inputs *micro, double mat, mcf_outputs *out);

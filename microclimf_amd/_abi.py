@@ -195,7 +195,7 @@ EXPORTS = (
     "mcf_bigleaf", "mcf_soilm", "mcf_pointmprocess", "mcf_weatherhgt", "mcf_man", "mcf_pointmodelsnow", "mcf_canintfrac", "mcf_meltmu", "mcf_meltmu2", "mcf_tpicalc",
     "mcf_nc_create", "mcf_nc_write_host", "mcf_nc_write_plan", "mcf_nc_close",
     "mcf_flowacc", "mcf_topidx",
-    "mcf_runmicrosnow1", "mcf_runmicrosnow1_multi", "mcf_snowrun_create", "mcf_snowrun_destroy", "mcf_snowrun_days",
+    "mcf_runmicrosnow1", "mcf_runmicrosnow1_multi", "mcf_snowrun_create", "mcf_snowrun_destroy", "mcf_snowrun_days", "mcf_snowrun_stats",
     "mcf_snowrun_pass1", "mcf_snowrun_pass2", "mcf_snowplan_run_chunk_pitched", "mcf_snowplan_chunk_af",
 )
 
@@ -456,6 +456,8 @@ def load() -> C.CDLL:
         lib.mcf_snowrun_create.argtypes = [MI, OP, C.POINTER(Multi), C.POINTER(P)]
         lib.mcf_snowrun_destroy.restype = None
         lib.mcf_snowrun_destroy.argtypes = [P]
+        lib.mcf_snowrun_stats.restype = C.c_int
+        lib.mcf_snowrun_stats.argtypes = [P, C.POINTER(C.c_int64)]
         lib.mcf_snowrun_days.restype = C.c_int32
         lib.mcf_snowrun_days.argtypes = [P]
         lib.mcf_snowrun_pass1.restype = C.c_int

@@ -99,6 +99,8 @@ struct mcf_snowrun {
     std::vector<int32_t> snowday, nosnowday;   // [ndays]
     bool pass1_done = false;
     int64_t keep_reserve = (int64_t)8 << 30;
+    // what pass 2 did not have to do (mcf_snowrun_stats)
+    std::atomic<int64_t> st_tile_days{0}, st_tile_days_left_out{0}, st_chunks_kept{0}, st_chunks_rerun{0};
     ~mcf_snowrun() {
         for (Block& k : blocks) {
             if (k.plan || k.sp) (void)hipSetDevice(k.device);
@@ -376,6 +378,11 @@ extern "C" int mcf_snowrun_create(const mcf_microsnow_in* in, const mcf_options*
 extern "C" void mcf_snowrun_destroy(mcf_snowrun* h) { delete h; }
 
 extern "C" int32_t mcf_snowrun_days(const mcf_snowrun* h) { return h ? h->ndays : 0; }
+extern "C" int mcf_snowrun_stats(const mcf_snowrun* h, int64_t stats[4]) {
+    if (!h || !stats) return mcf::api_fail(MCF_ERR_ARG, "null argument");
+    stats[0] = h->st_tile_days; stats[1] = h->st_tile_days_left_out; stats[2] = h->st_chunks_kept; stats[3] = h->st_chunks_rerun;
+    return MCF_OK;
+}
 
 extern "C" int mcf_snowrun_pass1(mcf_snowrun* h, const mcf_snowdriver_out* smod, int32_t* snowday, int32_t* nosnowday) {
     if (!h) return mcf::api_fail(MCF_ERR_ARG, "null snow run");
@@ -587,6 +594,8 @@ extern "C" int mcf_snowrun_pass2(mcf_snowrun* h, const mcf_snow_inputs* micro, d
                         skip.resize((size_t)nt);
                         if ((rc2 = mcf_snowplan_covered_tiles(k.sp, k.plan, ch, q, e - q, skip.data(), nt, &ncov))) return rc2;
                         rc2 = mcf_plan_run_days_masked(k.plan, d0 + q, e - q, slot, q, ncov ? skip.data() : nullptr, ncov ? nt : 0);
+                        h->st_tile_days += nt * (e - q);
+                        h->st_tile_days_left_out += ncov * (e - q);
                     } else {
                         rc2 = mcf_plan_run_days_at(k.plan, d0 + q, e - q, slot, q);
                     }
@@ -601,6 +610,7 @@ extern "C" int mcf_snowrun_pass2(mcf_snowrun* h, const mcf_snow_inputs* micro, d
                 bool has_snow = false, kept_all = true;
                 for (int d = 0; d < cd; ++d) has_snow |= h->snowday[(size_t)(d0 + d)] != 0;
                 for (const Block& k : h->blocks) kept_all = kept_all && k.kept[(size_t)ch];
+                if (t == 0 && has_snow) ++(kept_all ? h->st_chunks_kept : h->st_chunks_rerun);
                 if (has_snow && !kept_all) {          // collective: the blocks' surfaces couple through their halos
                     guarded([&] {
                         for (int b = t; b < h->nb && !failed; b += h->nt) {

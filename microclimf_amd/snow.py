@@ -929,6 +929,12 @@ class SnowRun:
         self.rows, self.cols, self.tsteps = R, Cc, self._sm.tsteps
         self._mm = None
 
+    def stats(self) -> dict:
+        """What pass 2 was spared (include/mcf.h mcf_snowrun_stats)."""
+        st = (C.c_int64 * 4)()
+        _abi.check(self._lib.mcf_snowrun_stats(self._p, st))
+        return dict(zip(("tile_days", "tile_days_left_out", "chunks_kept", "chunks_rerun"), (int(v) for v in st)))
+
     def close(self):
         if getattr(self, "_p", None) is not None and self._p.value:
             self._lib.mcf_snowrun_destroy(self._p)

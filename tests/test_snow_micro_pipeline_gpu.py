@@ -244,3 +244,80 @@ def test_pass_one_may_leave_the_series_it_does_not_read_unwritten():
         ts, tn = sp.prepare_chunk(0, None, 0, 0, ss / sn)
         with pytest.raises(RuntimeError, match="switched off"):
             sp.run_chunk(0, ts / tn)
+
+
+def _two_passes(sw, a, dtm, reqhgt, ndays, mask_tiles):
+    """The device-resident snow run of the first test in short: pass 1, set-up, pass 2 (every chunk re-run); with mask_tiles the
+    solver leaves out the tiles mcf_snowplan_covered_tiles names.  Returns the merged outputs and the tile-days left out."""
+    rows, cols = dtm.shape
+    T = ndays * 24
+    outm = [1] * 10
+    left_out = 0
+    with S.SnowPlan(sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"], sw["other"], sw["snowenv"], dtm, 1.0, 0.02,
+                    keep_results=False) as sp, Plan(**a, ring_days=5, ring_slots=2) as plan:
+        snowday, nosnowday = np.zeros(ndays, np.int32), np.zeros(ndays, np.int32)
+
+        def chunk(ch):
+            ss, sn = sp.surface_partial()
+            ts, tn = sp.prepare_chunk(ch, None, 0, 0, ss / sn)
+            sp.run_chunk(ch, ts / tn)
+            return S.snowdaysfun(sp.apply3(ch, "max")[0], sp.apply3(ch, "min")[0])
+
+        for ch in range(sp.chunks):
+            d = chunk(ch)
+            snowday[ch * 5:ch * 5 + 5], nosnowday[ch * 5:ch * 5 + 5] = d["snowdays"], d["nosnowdays"]
+            sp.meand_accumulate(ch, d["snowdays"])
+        sdays, ndays_ = np.flatnonzero(snowday), np.flatnonzero(nosnowday)
+        si, ni = _steps(sdays), _steps(ndays_)
+        sub_of_day = np.full(ndays, -1, np.int32)
+        sub_of_day[sdays] = np.arange(sdays.size)
+        sp.micro_setup(reqhgt, _sub(sw["obstime"], si), _sub(sw["climdata"], si), sw["vegp"], sw["other"], 7.5, outm, sub_of_day)
+        plan.set_mxtc(float(np.max(a["climdata"]["temp"][ni])))
+        sp.reset()
+        got = {}
+        for ch in range(sp.chunks):
+            chunk(ch)
+            slot, nos = ch % 2, nosnowday[ch * 5:ch * 5 + 5]
+            k = 0
+            while k < 5:
+                if not nos[k]:
+                    k += 1
+                    continue
+                e = k
+                while e < 5 and nos[e]:
+                    e += 1
+                sk, ncov = sp.covered_tiles(plan, ch, k, e - k) if mask_tiles else (None, 0)
+                if ncov:
+                    plan.run_days_masked(ch * 5 + k, e - k, slot, k, sk)
+                    left_out += ncov * (e - k)
+                else:
+                    plan.run_days_at(ch * 5 + k, e - k, slot, k)
+                k = e
+            sp.microsnow(plan, ch, slot, nos)
+            for name in ("Tz", "tleaf", "relhum", "soilm", "windspeed", "Rdirdown", "Rdifdown", "Rlwdown", "Rswup", "Rlwup"):
+                got.setdefault(name, np.full((rows, cols, T), np.nan, order="F"))[:, :, ch * 120:(ch + 1) * 120] = plan.fetch(slot, name, 0, 120)
+    return got, left_out, snowday, nosnowday
+
+
+def test_tiles_under_snow_are_left_out_of_the_solver_and_the_merged_output_is_the_same():
+    """A deep pack everywhere but on the northern rows (no initial snow, no snowfall in the period): every day is a snow day
+    AND a no-snow day, and the tiles that lie wholly inside the pack are covered for whole runs of days — the solver skips
+    them (mcf_plan_run_days_masked), gridmicrosnow1 writes all of their values, and the merged output equals the unmasked
+    run's bit for bit (the slot holds another chunk's values where the solver did not write)."""
+    rows, cols, ndays = 64, 24, 10
+    T = ndays * 24
+    sw = synthetic.snow_workload(rows, cols, T, cold=-2.0, zref=3.5, start_doy=60)
+    a = synthetic.workload(rows, cols, T, reqhgt=0.05, zref=3.5, hgt_range=(0.05, 3.0), start_doy=60, variety=True)
+    _, _, dtm = synthetic.rasters(rows, cols)
+    dtm = np.where(np.isnan(sw["vegp"]["hgt"]), np.nan, dtm)
+    deep = np.where(np.arange(rows)[:, None] >= 9, 0.9, 0.0) * np.ones((1, cols))
+    sw["other"] = dict(sw["other"], isnowdc=np.asfortranarray(deep), isnowdg=np.asfortranarray(0.7 * deep))     # (whole pack, its ground part)
+    sw["climdata"] = dict(sw["climdata"], precip=np.zeros(T))
+    plain, none_out, sd, nd = _two_passes(sw, a, dtm, 0.05, ndays, mask_tiles=False)
+    masked, left_out, sd2, nd2 = _two_passes(sw, a, dtm, 0.05, ndays, mask_tiles=True)
+    assert none_out == 0 and np.array_equal(sd, sd2) and np.array_equal(nd, nd2)
+    assert (sd & nd).sum() >= 5, (sd, nd)                        # mixed days: bare northern rows beside the pack
+    assert left_out >= 20, left_out                               # (74 tiles, about half of them inside the pack)
+    for k in plain:
+        assert np.array_equal(plain[k], masked[k], equal_nan=True), k
+    assert np.isfinite(plain["Tz"]).any()

@@ -128,6 +128,31 @@ def test_row_blocks_and_host_threads(oracle):
         assert np.nanmax(np.abs(smod_m[k] - w) / (1 + np.abs(w))) < 1e-9, k
 
 
+def test_tiles_wholly_under_snow_are_left_out_and_nothing_changes(oracle):
+    """A deep pack everywhere but on the northern rows, no snowfall: every day is a snow day and a no-snow day, and pass 2's
+    solver leaves out the tiles inside the pack (mcf_snowrun_stats says so) — the one call still equals the reference's
+    orchestration on the host, which solves every cell of every no-snow day (1e-12), and the oracle-backed one (1e-6)."""
+    reqhgt, rows, cols, ndays = 0.05, 64, 24, 10
+    sw, a, dtm, snow, micro = _case(reqhgt, -2.0, 60, rows=rows, cols=cols, ndays=ndays)
+    deep = np.asfortranarray(np.where(np.arange(rows)[:, None] >= 9, 0.9, 0.0) * np.ones((1, cols)))
+    other = dict(sw["other"], isnowdc=deep, isnowdg=np.asfortranarray(0.7 * deep))
+    clim = dict(sw["climdata"], precip=np.zeros(ndays * 24))
+    sw = dict(sw, other=other, climdata=clim)
+    snow = dict(snow, other=other, climdata=clim)
+    micro = dict(micro, other=other, climdata=clim)
+    with S.SnowRun(a, snow) as run:
+        sd, nd, smod = run.pass1(want_smod=True)
+        got = run.pass2(micro, MAT)
+        st = run.stats()
+    assert (sd & nd).sum() >= 5 and st["tile_days_left_out"] >= 20 and st["tile_days_left_out"] < st["tile_days"], (sd, nd, st)
+    sdays, ndays_ = np.flatnonzero(sd), np.flatnonzero(nd)
+    want = _orchestrate(a, sw, dtm, smod, sdays, ndays_, reqhgt, lambda an: runmicro1Cpp(*[an[k] for k in ARGS]), S.gridmicrosnow1)
+    _close(got, want, 1e-12, "host-orchestrated HIP")
+    want_o = _orchestrate(a, sw, dtm, smod, sdays, ndays_, reqhgt, lambda an: oracle.run_grid(**{k: an[k] for k in ARGS}),
+                          oracle.run_microsnow)
+    _close(got, want_o, 1e-6, "oracle-backed orchestration")
+
+
 def test_a_year_without_snow_and_bad_arguments():
     sw, a, dtm, snow, micro = _case(0.05, -25.0, 170, rows=10, cols=9, ndays=7)       # midsummer, 25 K warmer: no pack survives
     snow["other"] = dict(snow["other"], isnowdc=np.zeros_like(dtm), isnowdg=np.zeros_like(dtm))
