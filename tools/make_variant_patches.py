@@ -127,6 +127,15 @@ VARIANTS = {
         T = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(K.tab) + off);'''),
                        ("mcf_device.hpp", "    const double2 cl = *reinterpret_cast<const double2*>(K.ltab + 2 * j);",
                         "    const double2 cl = *reinterpret_cast<const double2*>(K.ltab + 2 * (j & 1));     // TIMING VARIANT")],
+    # one more LDS round trip behind every operand batch (17 per cell-step): what an exposed LDS latency costs
+    "extra_lds_wait": [("mcf_device.hpp", """    (pin1(a), ...);
+}""", """    (pin1(a), ...);
+    {   // TIMING VARIANT: a dependent LDS read and its wait behind the batch
+        double d;
+        unsigned z = 0;
+        asm volatile("ds_read_b64 %0, %1\\n\\ts_waitcnt lgkmcnt(0)" : "=v"(d) : "v"(z));
+    }
+}""")],
     "persistent_loop": [('''    const int rot = (int)((blockIdx.x >> 8) & 1);
     const int64_t pos = tile_position(a.ntiles_launch);
     if (pos < 0) return;
