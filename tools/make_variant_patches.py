@@ -136,6 +136,16 @@ VARIANTS = {
         asm volatile("ds_read_b64 %0, %1\\n\\ts_waitcnt lgkmcnt(0)" : "=v"(d) : "v"(z));
     }
 }""")],
+    # ten more scalar moves behind every operand batch (170 per cell-step, +40 % scalar instructions): what a scalar instruction costs here
+    "extra_salu": [("mcf_device.hpp", """    (pin1(a), ...);
+}""", """    (pin1(a), ...);
+    {   // TIMING VARIANT
+        unsigned t;
+        asm volatile("s_mov_b32 %0, 0x3f1a36e2\\n\\ts_mov_b32 %0, 0x3f1a36e3\\n\\ts_mov_b32 %0, 0x3f1a36e4\\n\\ts_mov_b32 %0, 0x3f1a36e5\\n\\t"
+                     "s_mov_b32 %0, 0x3f1a36e6\\n\\ts_mov_b32 %0, 0x3f1a36e7\\n\\ts_mov_b32 %0, 0x3f1a36e8\\n\\ts_mov_b32 %0, 0x3f1a36e9\\n\\t"
+                     "s_mov_b32 %0, 0x3f1a36ea\\n\\ts_mov_b32 %0, 0x3f1a36eb" : "=s"(t));
+    }
+}""")],
     "persistent_loop": [('''    const int rot = (int)((blockIdx.x >> 8) & 1);
     const int64_t pos = tile_position(a.ntiles_launch);
     if (pos < 0) return;
