@@ -179,6 +179,75 @@ __global__ __launch_bounds__(256) void k_slope_aspect(const double* __restrict__
     if (aspect) aspect[cell] = as;
 }
 
+// ---- the same two stencils with 32-bit indices and a three-instruction exact quotient (round 4) -----------------------
+// k_horizon / k_windcoef above spend ~40 vector instructions per sample: 64-bit bounds tests and index arithmetic, and an
+// IEEE division by s^2.  Here a lane keeps (row in the supplied array, global row, column, element index) as 32-bit values
+// (terrain_device takes this route when every extent fits), a sample's three range tests are unsigned compares, the load
+// address is always a valid one (element 0 when the sample lies outside) and x / s^2 is
+//     q = x * y;  r = fma(-q, s^2, x);  q = fma(r, y, q),   y = RN(1 / s^2)
+// which is the correctly rounded quotient for these divisors (Markstein's final step; s^2 = 1 .. 100 has no all-ones
+// significand) — the bits of the division it replaces.  The s loop is unrolled: s^2 and y are literals.
+struct Geo32 { int rows, cols, RB, hn, row0, rows_total; };
+struct Shift32 { int dr, dc; };
+struct ShiftTable32 { Shift32 s[24][10]; };
+struct WindLim { double v[10]; };      // hgt / res / s^2, the windcoef threshold of each step (int:964)
+
+template <bool WIND>
+__device__ __forceinline__ double stencil_max(const double* __restrict__ Z, const Geo32& g, const Shift32* __restrict__ sh, int b, int gr,
+                                              int c, int idx, double z0, const WindLim& lim) {
+    double h = 0.0;
+#pragma unroll
+    for (int s = 0; s < 10; ++s) {
+        const int dr = sh[s].dr, dc = sh[s].dc;
+        const bool in = (unsigned)(gr + dr) < (unsigned)g.rows_total && (unsigned)(b + dr) < (unsigned)g.RB &&
+                        (unsigned)(c + dc) < (unsigned)g.cols;
+        const int off = in ? idx + dr + g.RB * dc : 0;       // (element 0 is always there)
+        const double z = Z[off];
+        const double x = (in ? z : 0.0) - z0;
+        const double s2 = (double)((s + 1) * (s + 1)), y = 1.0 / s2;
+        double q = x * y;
+        const double r = fma(-q, s2, x);
+        q = fma(r, y, q);
+        h = fmax(h, q);
+        if (WIND && h < lim.v[s]) h = 0.0;
+    }
+    return h;
+}
+__global__ __launch_bounds__(256) void k_horizon32(const double* __restrict__ Z, Geo32 g, ShiftTable32 tab, WindLim lim,
+                                                   double* __restrict__ hor, double* __restrict__ svf) {
+    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = g.rows * g.cols;
+    if (cell >= N) return;
+    const int r = cell % g.rows, c = cell / g.rows;
+    const int gr = g.row0 + r, b = r + g.hn, idx = b + g.RB * c;
+    const double z0 = Z[idx];
+    double satan = 0.0;
+    for (int d = 0; d < 24; ++d) {
+        const double h = stencil_max<false>(Z, g, tab.s[d], b, gr, c, idx, z0, lim);
+        if (hor) hor[(int64_t)d * N + cell] = h;
+        satan += atan(h);
+    }
+    if (svf) {
+        const double msl = tan(satan / 24.0);
+        svf[cell] = 0.5 * cos(2 * msl) + 0.5;
+    }
+}
+__global__ __launch_bounds__(256) void k_windcoef32(const double* __restrict__ Z, Geo32 g, ShiftTable32 tab16, WindLim lim, int e0, int ne,
+                                                    double* __restrict__ W /* [16][ne*cols] */) {
+    const int idx0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = ne * g.cols;
+    if (idx0 >= M) return;
+    const int r = idx0 % ne, c = idx0 / ne;
+    const int gr = e0 + r, b = gr - (g.row0 - g.hn), idx = b + g.RB * c;
+    // (rows of the aggregation blocks outside the supplied array: zpad's 0, as in k_windcoef)
+    const bool own = (unsigned)b < (unsigned)g.RB;
+    const double z0 = own ? Z[own ? idx : 0] : 0.0;
+    for (int d = 0; d < 16; ++d) {
+        const double h = stencil_max<true>(Z, g, tab16.s[d], b, gr, c, idx, z0, lim);
+        W[(int64_t)d * M + idx0] = 1 - atan(0.17 * 100 * h) / 1.65;   // int:966
+    }
+}
+
 void fill_shifts(ShiftTable& t, int ndir) {
     for (int d = 0; d < ndir; ++d) {
         double azi = (d * 360.0 / ndir) * (3.14159265358979323846 / 180);   // .ar(), int:113-115
@@ -259,10 +328,26 @@ int terrain_device(const TerrainDev& t, TerrainWork* work) {
     if ((rc = scratch(0, (void**)&d_Z, NB * 8))) return rc;
     hipLaunchKernelGGL(k_prep, dim3((unsigned)((NB + 255) / 256)), dim3(256), 0, nullptr, t.d_dtm, d_Z, NB, 1.0 / t.res);
     const unsigned gridN = (unsigned)((N + 255) / 256);
+    // every extent in 32 bits (a 16 384 x 16 384 block with its halos still is): the lean stencils
+    static const bool no32 = getenv("MCF_TERRAIN_64") != nullptr;
+    const bool fits32 = !no32 && NB < ((int64_t)1 << 30) && rows_total < ((int64_t)1 << 30);
+    Geo32 g32;
+    g32.rows = (int)g.rows; g32.cols = (int)g.cols; g32.RB = (int)g.RB; g32.hn = (int)g.hn; g32.row0 = (int)g.row0; g32.rows_total = (int)g.rows_total;
+    auto narrow = [](const ShiftTable& a, ShiftTable32& b) {
+        for (int d = 0; d < 24; ++d)
+            for (int q = 0; q < 10; ++q) { b.s[d][q].dr = a.s[d][q].dr; b.s[d][q].dc = a.s[d][q].dc; }
+    };
     if (t.d_hor || t.d_svfa) {
         ShiftTable t24;
         fill_shifts(t24, 24);
-        hipLaunchKernelGGL(k_horizon, dim3(gridN), dim3(256), 0, nullptr, d_Z, g, t24, t.d_hor, t.d_svfa);
+        if (fits32) {
+            ShiftTable32 s24;
+            narrow(t24, s24);
+            WindLim lim{};
+            hipLaunchKernelGGL(k_horizon32, dim3(gridN), dim3(256), 0, nullptr, d_Z, g32, s24, lim, t.d_hor, t.d_svfa);
+        } else {
+            hipLaunchKernelGGL(k_horizon, dim3(gridN), dim3(256), 0, nullptr, d_Z, g, t24, t.d_hor, t.d_svfa);
+        }
         T_TRY(hipGetLastError());
     }
     if (want_wsa) {
@@ -279,8 +364,17 @@ int terrain_device(const TerrainDev& t, TerrainWork* work) {
         if ((rc = scratch(1, (void**)&d_W, 16 * ne * g.cols * 8))) return rc;
         if ((rc = scratch(2, (void**)&d_C, 16 * nI * nJ * 8))) return rc;
         int64_t M = ne * g.cols;
-        hipLaunchKernelGGL(k_windcoef, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, nullptr, d_Z, g, t16,
-                           t.zref / t.res, e0, ne, d_W);
+        if (fits32 && M < ((int64_t)1 << 30)) {
+            ShiftTable32 s16;
+            memset(&s16, 0, sizeof s16);
+            narrow(t16, s16);
+            WindLim lim;
+            for (int q = 0; q < 10; ++q) lim.v[q] = (t.zref / t.res) / (double)((q + 1) * (q + 1));
+            hipLaunchKernelGGL(k_windcoef32, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, nullptr, d_Z, g32, s16, lim, (int)e0, (int)ne, d_W);
+        } else {
+            hipLaunchKernelGGL(k_windcoef, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, nullptr, d_Z, g, t16,
+                               t.zref / t.res, e0, ne, d_W);
+        }
         hipLaunchKernelGGL(k_block_mean, dim3((unsigned)((16 * nI * nJ + 255) / 256)), dim3(256), 0, nullptr, d_W, g,
                            s, e0, ne, I0, nI, nJ, d_C);
         hipLaunchKernelGGL(k_resample_blend, dim3(gridN), dim3(256), 0, nullptr, d_C, g, s, I0, nI, nJ, NItot, t.d_wsa);
