@@ -99,6 +99,10 @@ struct mcf_snowrun {
     std::vector<int32_t> snowday, nosnowday;   // [ndays]
     bool pass1_done = false;
     int64_t keep_reserve = (int64_t)8 << 30;
+    // A run is one simulated period on fresh plans: the device memory a kept chunk needs would have to be ALLOCATED for it (5 GB per
+    // chunk of a 1024 x 1024 raster: 0.1 s, measured 3 s of a 6 s call) where re-running the chunk in pass 2 takes 3.5 ms — chunks are
+    // kept only on request (MCF_SNOWRUN_KEEP=1); the stepwise API's pool across years (tools/bench_snow.py) is where keeping pays
+    bool keep = false;
     // what pass 2 did not have to do (mcf_snowrun_stats)
     std::atomic<int64_t> st_tile_days{0}, st_tile_days_left_out{0}, st_chunks_kept{0}, st_chunks_rerun{0};
     ~mcf_snowrun() {
@@ -312,6 +316,7 @@ extern "C" int mcf_snowrun_create(const mcf_microsnow_in* in, const mcf_options*
         h->snowday.assign((size_t)std::max(h->ndays, h->nchunks * h->chunk_days), 0);
         h->nosnowday.assign(h->snowday.size(), 0);
         if (const char* e = getenv("MCF_SNOW_KEEP_RESERVE_GB")) h->keep_reserve = (int64_t)(atof(e) * 1073741824.0);
+        h->keep = getenv("MCF_SNOWRUN_KEEP") != nullptr;
         const mcf_snow_inputs& base = h->snow.base;
         rc = run_workers(h, [&](int t, PhaseBarrier& bar, std::atomic<bool>& failed, auto& guarded, auto& fail_here) {
             guarded([&] {
@@ -410,9 +415,9 @@ extern "C" int mcf_snowrun_pass1(mcf_snowrun* h, const mcf_snowdriver_out* smod,
                         int rc2 = mcf_snowplan_checkpoint(k.sp, ch);      // pass 2 starts any chunk from here
                         // a chunk that could not stay in HBM is re-run by pass 2 if it holds a snow day: unless the caller wants the snow
                         // series, pass 1 writes only what it reads itself of such a chunk (totalSWE, density: mcf_snowplan_set_series)
-                        int32_t room = 1;
-                        if (!rc2 && !smod) rc2 = mcf_snowplan_can_keep(k.sp, h->keep_reserve, &room);
-                        if (!rc2) rc2 = mcf_snowplan_set_series(k.sp, room ? 31u : (4u | 16u));
+                        int32_t room = 0;
+                        if (!rc2 && h->keep) rc2 = mcf_snowplan_can_keep(k.sp, h->keep_reserve, &room);
+                        if (!rc2) rc2 = mcf_snowplan_set_series(k.sp, (room || smod) ? 31u : (4u | 16u));
                         if (rc2) { fail_here(rc2); break; }
                     }
                 });
@@ -435,7 +440,7 @@ extern "C" int mcf_snowrun_pass1(mcf_snowrun* h, const mcf_snowdriver_out* smod,
                         Block& k = h->blocks[(size_t)b];
                         int rc2 = mcf_snowplan_meand_accumulate(k.sp, ch, &h->snowday[(size_t)(ch * cd)]);
                         int32_t kept = 0;
-                        if (!rc2 && any) rc2 = mcf_snowplan_keep_chunk(k.sp, ch, h->keep_reserve, &kept);
+                        if (!rc2 && any && h->keep) rc2 = mcf_snowplan_keep_chunk(k.sp, ch, h->keep_reserve, &kept);
                         if (rc2) { fail_here(rc2); break; }
                         k.kept[(size_t)ch] = (char)kept;
                     }
