@@ -321,3 +321,43 @@ def test_tiles_under_snow_are_left_out_of_the_solver_and_the_merged_output_is_th
     for k in plain:
         assert np.array_equal(plain[k], masked[k], equal_nan=True), k
     assert np.isfinite(plain["Tz"]).any()
+
+
+def test_masked_run_edge_cases():
+    """mcf_plan_run_days_masked: every tile masked = nothing launched, the slot keeps what it held; no tile masked = the plain
+    run; below-ground and array-forcing plans refuse a mask; mcf_snowplan_covered_tiles needs the micro set-up."""
+    rows, cols, T = 30, 17, 120
+    a = synthetic.workload(rows, cols, T, reqhgt=0.05, start_doy=150, variety=True)
+    with Plan(**a, ring_days=5, ring_slots=1) as plan:
+        nt = plan.n_tiles
+        plan.run_days_at(0, 2, 0, 0)
+        before = {k: plan.fetch(0, k, 0, 48).copy() for k in ("Tz", "Rswup")}
+        plan.run_days_masked(2, 2, 0, 0, np.ones(nt, np.uint8))              # days 2-3 over days 0-1's place: nothing may change
+        for k, v in before.items():
+            assert np.array_equal(plan.fetch(0, k, 0, 48), v, equal_nan=True), k
+        plan.run_days_masked(2, 2, 0, 0, np.zeros(nt, np.uint8))
+        plain = {k: plan.fetch(0, k, 0, 48).copy() for k in before}
+        plan.run_days_at(2, 2, 0, 0)
+        for k, v in plain.items():
+            assert np.array_equal(plan.fetch(0, k, 0, 48), v, equal_nan=True), k
+        assert not np.array_equal(plain["Tz"], before["Tz"], equal_nan=True)
+        half = (np.arange(nt) % 2).astype(np.uint8)                          # every other tile: the others keep days 0-1
+        plan.run_days_at(0, 2, 0, 0)
+        plan.run_days_masked(2, 2, 0, 0, half)
+        got = plan.fetch(0, "Tz", 0, 48).reshape(rows * cols, 48, order="F")
+        cpt = plan.ring_layout()["cells_per_tile"]
+        tile_of = np.arange(rows * cols) // cpt
+        b, p = before["Tz"].reshape(rows * cols, 48, order="F"), plain["Tz"].reshape(rows * cols, 48, order="F")
+        assert np.array_equal(got[half[tile_of] == 1], b[half[tile_of] == 1], equal_nan=True)
+        assert np.array_equal(got[half[tile_of] == 0], p[half[tile_of] == 0], equal_nan=True)
+    bg = synthetic.workload(12, 9, 48, reqhgt=-0.05, start_doy=150)
+    with Plan(**bg, ring_days=2, ring_slots=1) as plan:
+        with pytest.raises(RuntimeError, match="tile mask"):
+            plan.run_days_masked(0, 1, 0, 0, np.zeros(plan.n_tiles if plan.ring_layout()["cells_per_tile"] else 1, np.uint8))
+    sw = synthetic.snow_workload(12, 9, 120, cold=0.0, zref=3.5, start_doy=90)
+    _, _, dtm = synthetic.rasters(12, 9)
+    a2 = synthetic.workload(12, 9, 120, reqhgt=0.05, zref=3.5, start_doy=90)
+    with S.SnowPlan(sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"], sw["other"], sw["snowenv"], dtm, 1.0, 0.02,
+                    keep_results=False) as sp, Plan(**a2, ring_days=5, ring_slots=1) as plan:
+        with pytest.raises(RuntimeError, match="micro_setup"):
+            sp.covered_tiles(plan, 0, 0, 1)
