@@ -146,6 +146,8 @@ VARIANTS = {
                      "s_mov_b32 %0, 0x3f1a36ea\\n\\ts_mov_b32 %0, 0x3f1a36eb" : "=s"(t));
     }
 }""")],
+    # the coarse-forcing kernel with the bounded exp's two VGPR residents (three registers: 12 B of scratch in the LDS-staged kernel)
+    "coarse_bounded_exp": [("    MK.pin(true, AF == 0, AF == 1);", "    MK.pin(true, AF == 0, AF != 0);     // VARIANT")],
     "persistent_loop": [('''    const int rot = (int)((blockIdx.x >> 8) & 1);
     const int64_t pos = tile_position(a.ntiles_launch);
     if (pos < 0) return;
