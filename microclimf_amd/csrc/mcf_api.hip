@@ -98,7 +98,7 @@ struct mcf_plan {
     std::vector<char> day_irregular, day_soil_daily;
     int32_t *d_tiles_fast = nullptr, *d_tiles_slow = nullptr;
     // mcf_plan_run_days_masked: the tile classes on the host, and the launch's own lists on the device
-    std::vector<int32_t> h_tiles_fast, h_tiles_slow;
+    std::vector<int32_t> h_tiles_fast, h_tiles_slow, h_tiles_sub;
     int32_t* d_tiles_sub = nullptr;
     int64_t tiles_sub_cap = 0, masked_tiles_skipped = 0;
     int64_t n_fast = 0, n_slow = 0, tiles_cap = 0;
@@ -923,19 +923,23 @@ int mcf_plan_run_days_masked(mcf_plan* p, int32_t day0, int32_t ndays, int32_t s
             p->d_tiles_sub = (int32_t*)q;
             p->tiles_sub_cap = ntiles;
         }
-        std::vector<int32_t> lf, ls;
-        lf.reserve((size_t)ntiles);
+        // (the lists live in the plan: they go up on the plan's own stream, in order with the launches that read them, and an
+        // earlier masked launch may still be reading the device copy or an earlier copy the host one)
+        HIP_TRY(hipStreamSynchronize(p->stream));
+        std::vector<int32_t>& l = p->h_tiles_sub;
+        l.clear();
+        l.reserve((size_t)ntiles);
         if (fast) {
-            for (int32_t t : p->h_tiles_fast) if (!skip_tile[t]) lf.push_back(t);
-            for (int32_t t : p->h_tiles_slow) if (!skip_tile[t]) ls.push_back(t);
+            for (int32_t t : p->h_tiles_fast) if (!skip_tile[t]) l.push_back(t);
+            n_sub_fast = (int64_t)l.size();
+            for (int32_t t : p->h_tiles_slow) if (!skip_tile[t]) l.push_back(t);
+            n_sub_slow = (int64_t)l.size() - n_sub_fast;
         } else {
-            for (int64_t t = 0; t < ntiles; ++t) if (!skip_tile[t]) lf.push_back((int32_t)t);
+            for (int64_t t = 0; t < ntiles; ++t) if (!skip_tile[t]) l.push_back((int32_t)t);
+            n_sub_fast = (int64_t)l.size();
         }
-        n_sub_fast = (int64_t)lf.size(); n_sub_slow = (int64_t)ls.size();
         p->masked_tiles_skipped += ntiles - n_sub_fast - n_sub_slow;
-        HIP_TRY(hipStreamSynchronize(p->stream));          // (an earlier masked launch may still be reading the lists)
-        if (n_sub_fast) HIP_TRY(hipMemcpy(p->d_tiles_sub, lf.data(), lf.size() * 4, hipMemcpyHostToDevice));
-        if (n_sub_slow) HIP_TRY(hipMemcpy(p->d_tiles_sub + n_sub_fast, ls.data(), ls.size() * 4, hipMemcpyHostToDevice));
+        if (!l.empty()) HIP_TRY(hipMemcpyAsync(p->d_tiles_sub, l.data(), l.size() * 4, hipMemcpyHostToDevice, p->stream));
         sub_fast = p->d_tiles_sub; sub_slow = p->d_tiles_sub + n_sub_fast;
     }
     auto launch = [&]() {
