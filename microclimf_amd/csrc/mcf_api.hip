@@ -468,6 +468,11 @@ int mcf_plan_create(const mcf_grid_inputs* in, const mcf_options* opt, int32_t r
         // the LDS-staged taps (k_solve, CLDS): a tile's 32 cells lie in at most two raster columns and, in each, reach at most
         // four coarse rows (the rows of its first and last cell and one more)
         p->coarse_lds = in->rows >= 32 && getenv("MCF_NO_COARSE_LDS") == nullptr;
+        // ... with row positions that do not decrease down a raster column: the kernel finds a tile's wrap into the next column
+        // where the position falls back, and the window test below looks at a window's two ends only.  A flipped or otherwise
+        // non-monotone coarse grid takes the per-lane taps, which make no such assumption.
+        for (int64_t i = 1; p->coarse_lds && i < in->rows; ++i)
+            if (in->coarse_rowpos[i] < in->coarse_rowpos[i - 1]) p->coarse_lds = false;
         for (int64_t i = 0; p->coarse_lds && i < in->rows; ++i) {
             const int64_t l = std::min<int64_t>(i + 31, in->rows - 1);
             if (floor(in->coarse_rowpos[l]) - floor(in->coarse_rowpos[i]) + 2 > 4) p->coarse_lds = false;
@@ -1398,6 +1403,21 @@ int mcf_selftest_math(int32_t kind, const double* x, const double* y, double* ou
 
 static const int32_t kBioSt[14] = {0, 24, 48, 72, 96, 120, 144, 168, 192, 216, 240, 264, 288, 312};
 static const int32_t kBioEd[14] = {23, 47, 71, 95, 119, 143, 167, 191, 215, 239, 263, 287, 311, 335};
+// the requested matrices of bio [19][N] into the caller's arrays (out_pitch > rows: a row block's rows of taller matrices)
+static int bioclim_download(mcf_plan* p, const mcf_grid_inputs* in, const mcf_bioclim_sel* sel, mcf_bioclim_out* out, const double* bio,
+                            int64_t out_pitch) {
+    const int64_t N = in->rows * in->cols;
+    for (int v = 0; v < MCF_NBIO; ++v)
+        if (sel->out[v]) {
+            if (!out->bio[v]) return fail(MCF_ERR_ARG, "requested bioclim variable has a null buffer");
+            if (out_pitch > in->rows)
+                HIP_TRY(hipMemcpy2DAsync(out->bio[v], (size_t)out_pitch * 8, bio + (int64_t)v * N, (size_t)in->rows * 8,
+                                         (size_t)in->rows * 8, (size_t)in->cols, hipMemcpyDeviceToHost, p->stream));
+            else
+                HIP_TRY(hipMemcpyAsync(out->bio[v], bio + (int64_t)v * N, (size_t)N * 8, hipMemcpyDeviceToHost, p->stream));
+        }
+    return mcf_plan_sync(p);
+}
 // twi_mean / out_pitch: a row block of a taller raster (the bioclim `_multi` entries): the raster-wide twi mean to install, and
 // the rows of the caller's [rows_total, cols] matrices the block's rows are written into in place
 static int run_bioclim(const mcf_grid_inputs* in_caller, const mcf_options* opt_in, const mcf_bioclim_sel* sel,
@@ -1434,10 +1454,60 @@ static int run_bioclim(const mcf_grid_inputs* in_caller, const mcf_options* opt_
     opt.out[MCF_OUT_SOILM] = 1;
     if ((rc = ensure_device(opt.device))) return rc;
     const int ndays = (int)(T / 24);
+    // Streamed (round 5; vector forcing above ground, quarter lists in ascending order — what runbioclim passes): the solver
+    // runs in day chunks into a ring of a few GB and k_bioclim_acc folds each chunk into 29 doubles of running state per cell;
+    // nothing of size cells x steps is allocated (the whole-series form below needs 2 x 8 B x cells x steps: 167 GB for a 4096^2
+    // raster, most of the call's time).  Same accumulation order, same operands: the matrices are bit for bit the whole-series
+    // form's (MCF_BIOCLIM_WHOLE=1 selects that one: the A/B of tests/test_bioclim_gpu.py).
+    bool streamed = !in->array_forcing && !(opt.reqhgt < 0.0) && getenv("MCF_BIOCLIM_WHOLE") == nullptr;
+    for (int i = 0; streamed && i < 4; ++i)
+        for (int j = 1; j < nq[i]; ++j)
+            if (q[i][j] < q[i][j - 1]) streamed = false;
+    int chunk_days = ndays;
+    if (streamed) {
+        const int cpb = opt.cells_per_block ? opt.cells_per_block : 21;
+        const double day_bytes = 2.0 * 8.0 * (double)((N + cpb - 1) / cpb) * (double)mcf::ring_block_doubles(cpb);
+        const char* e = getenv("MCF_BIOCLIM_RING_GB");
+        const double budget = (e && atof(e) > 0.0 ? atof(e) : 14.0) * 1e9;     // (4096^2: 0.80 s with 14 GB = two-day chunks, 0.85 s with 8, 2.3 s with 27 — the allocation; profiles/r05_sink_rates.txt)
+        chunk_days = (int)std::max(1.0, std::min((double)ndays, floor(budget / day_bytes)));
+    }
     mcf_plan* p = nullptr;
-    if ((rc = mcf_plan_create(in, &opt, ndays, 1, &p))) return rc;
+    if ((rc = mcf_plan_create(in, &opt, chunk_days, 1, &p))) return rc;
     struct Guard { mcf_plan* p; ~Guard() { mcf_plan_destroy(p); } } guard{p};
     if (twi_mean && (rc = mcf_plan_set_twi_mean(p, *twi_mean))) return rc;
+    if (streamed && p->tiled) {
+        void* tmp = nullptr;
+        mcf::BioAccArgs acc{};
+        acc.N = N;
+        acc.tz = ring_view(p, 0, tvar); acc.soilm = ring_view(p, 0, MCF_OUT_SOILM);
+        for (int i = 0; i < 4; ++i) {
+            if ((rc = dalloc(p, &tmp, (int64_t)std::max(nq[i], 1) * 4))) return rc;
+            if (nq[i] > 0) HIP_TRY(hipMemcpyAsync(tmp, q[i], (size_t)nq[i] * 4, hipMemcpyHostToDevice, p->stream));
+            acc.q[i] = (const int32_t*)tmp;
+        }
+        if ((rc = dalloc(p, &tmp, (int64_t)mcf::kBioStateRows * N * 8))) return rc;
+        acc.state = (double*)tmp;
+        for (int d0 = 0; d0 < ndays; d0 += p->ring_days) {
+            const int nd = std::min(p->ring_days, ndays - d0);
+            if ((rc = mcf_plan_run_days(p, d0, nd, 0))) return rc;
+            acc.day0 = d0; acc.ndays = nd;
+            for (int i = 0; i < 4; ++i) {
+                acc.qlo[i] = (int32_t)(std::lower_bound(q[i], q[i] + nq[i], d0 * 24) - q[i]);
+                acc.qhi[i] = (int32_t)(std::lower_bound(q[i], q[i] + nq[i], (d0 + nd) * 24) - q[i]);
+            }
+            mcf::launch_bioclim_acc(acc, p->stream);
+            HIP_TRY(hipGetLastError());
+        }
+        mcf::BioFinArgs fin{};
+        fin.N = N; fin.tsteps = (int)T; fin.state = acc.state;
+        fin.cellc = p->d_cellc; fin.ntiles_total = p->ntiles; fin.cpb = p->cpb; fin.daylayer = p->d_daylayer; fin.tt = p->d_tt;
+        if ((rc = dalloc(p, &tmp, (int64_t)MCF_NBIO * N * 8))) return rc;
+        fin.bio = (double*)tmp;
+        mcf::launch_bioclim_fin(fin, p->stream);
+        HIP_TRY(hipGetLastError());
+        return bioclim_download(p, in, sel, out, fin.bio, out_pitch);
+    }
+    if (streamed) return fail(MCF_ERR_STATE, "bioclim: the streamed sink expects the tiled ring");
     if (in->array_forcing && (rc = mcf_plan_upload_forcing_days(p, in, 0, ndays, 0))) return rc;
     if ((rc = mcf_plan_run_days(p, 0, ndays, 0))) return rc;
     if (p->bg && (rc = mcf_plan_belowground(p))) return rc;
@@ -1456,16 +1526,7 @@ static int run_bioclim(const mcf_grid_inputs* in_caller, const mcf_options* opt_
     b.bio = (double*)tmp;
     mcf::launch_bioclim(b, p->stream);
     HIP_TRY(hipGetLastError());
-    for (int v = 0; v < MCF_NBIO; ++v)
-        if (sel->out[v]) {
-            if (!out->bio[v]) return fail(MCF_ERR_ARG, "requested bioclim variable has a null buffer");
-            if (out_pitch > in->rows)
-                HIP_TRY(hipMemcpy2DAsync(out->bio[v], (size_t)out_pitch * 8, b.bio + (int64_t)v * N, (size_t)in->rows * 8,
-                                         (size_t)in->rows * 8, (size_t)in->cols, hipMemcpyDeviceToHost, p->stream));
-            else
-                HIP_TRY(hipMemcpyAsync(out->bio[v], b.bio + (int64_t)v * N, (size_t)N * 8, hipMemcpyDeviceToHost, p->stream));
-        }
-    return mcf_plan_sync(p);
+    return bioclim_download(p, in, sel, out, b.bio, out_pitch);
 }
 int mcf_runbioclim1(const mcf_grid_inputs* in, const mcf_options* opt, const mcf_bioclim_sel* sel, mcf_bioclim_out* out) {
     return run_bioclim(in, opt, sel, out, 0);

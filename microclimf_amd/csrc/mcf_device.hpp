@@ -138,6 +138,16 @@ __device__ __forceinline__ double frcp(double b) {           // 1/b, b finite no
     const double e = fma(-b, r, 1.0);
     return fma(fma(e, e, e), r, r);
 }
+// 1/b to 46 bits (relative error < 2^-46 = 1.4e-14): ONE Newton step, two FMAs instead of three.  For the quotients whose error
+// reaches an output unamplified — the Penman-Monteith temperature rises (|dT| <= 80 K: < 1.2e-12 K), the series conductances,
+// the Lagrangian far field's normalisation.  Whatever feeds an exponential's argument (the saturation pressures) or the
+// two-stream coefficient algebra (which amplifies a rounding error 1e5-fold) keeps frcp's 69 bits.
+__device__ __forceinline__ double frcp_m(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    const double e = fma(-b, r, 1.0);
+    return fma(e, r, r);
+}
+__device__ __forceinline__ double fdiv_m(double a, double b) { return a * frcp_m(b); }
 __device__ __forceinline__ double fdiv(double a, double b) {  // a/b, b finite normal non-zero
     // a * (1/b) with the 69-bit reciprocal above: one FMA fewer; the two roundings (of 1/b and of the product) bound the
     // error by 1.5 ulp (3.3e-16), checked by tests/test_math_gpu.py
@@ -153,6 +163,14 @@ __device__ __forceinline__ double fsqrt(double x) {           // sqrt(x), x fini
     h = fma(h, r, h);
     double e = fma(-g, g, x);
     return fma(e, h, g);
+}
+// sqrt(x) to 46 bits: the coupled step above without the residual correction (four instructions behind v_rsq_f64 instead of
+// seven) — the leaf boundary-layer conductance, which enters the leaf's energy balance linearly
+__device__ __forceinline__ double fsqrt_m(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    return fma(g, r, g);
 }
 // A 64-bit literal used as a VALU operand has to live in a register pair.  Left alone,
 // hipcc copies every polynomial coefficient into a VGPR pair (v_mov_b64) in front of each
@@ -375,7 +393,7 @@ struct MathK {
     double e[12];   // exp: 1/ln2, -ln2_hi, -ln2_lo, c10 .. c2
     double l[7];    // log: Lg4, Lg5, Lg2, Lg3, Lg1, ln2_lo, ln2_hi
     double c11, lg6, lg7;   // VGPR residents (MCF_PIN_VCONST)
-    double t[5];    // table exp: 256/ln2, -(ln2/256)_hi (30 bits: n * hi is exact), -(ln2/256)_lo, 1/24, 1/6
+    double t[5];    // table exp: 256/ln2, -(ln2/256)_hi (30 bits: n * hi is exact), -(ln2/256)_lo, 1/24, -ln2/256 (53 bits: fexp_tab SHORT)
     double c5;      // 1/6 (VGPR resident: an instruction reads one scalar operand)
     double g[7];    // table log: (unused), -1/6, 1/5, -1/4, 1/3, ln2_lo, ln2_hi
     double g7v;     // 1/7 (VGPR resident: the first Horner step has two constants)
@@ -391,7 +409,7 @@ struct MathK {
         c11 = 0x1.ade156a5dcb37p-26; lg6 = 1.531383769920937332e-01; lg7 = 1.479819860511658591e-01;
         magic = 0x1.8p52; sh3 = 3;
         t[0] = 0x1.71547652b82fep+8; t[1] = -0x1.62e42fec00000p-9; t[2] = -0x1.d1cf79abc9e3bp-40;
-        t[3] = 1.0 / 24.0; t[4] = 0.0; c5 = 1.0 / 6.0;
+        t[3] = 1.0 / 24.0; t[4] = -0x1.62e42fefa39efp-9; c5 = 1.0 / 6.0;
         g[0] = 0.0; g7v = 1.0 / 7.0; g[1] = -1.0 / 6.0; g[2] = 1.0 / 5.0; g[3] = -0.25; g[4] = 1.0 / 3.0;
         g[5] = 1.90821492927058770002e-10; g[6] = 6.93147180369123816490e-01;
         e[0] = 0x1.71547652b82fep+0; e[1] = -0x1.62e42fefa39efp-1; e[2] = -0x1.abc9e3b39803fp-56;
@@ -427,6 +445,7 @@ struct MathK {
         if (table) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) asm volatile("" : "+s"(t[i]));
+            if (vconst) asm volatile("" : "+s"(t[4]));
             if (vconst) asm volatile("" : "+v"(c5));
             if (vconst || lean_fast) {
                 asm volatile("" : "+v"(magic));
@@ -456,7 +475,12 @@ struct MathK {
 // the low mantissa bits of x * 256/ln2 + 1.5 * 2^52 — no v_rndne, no v_cvt — and as a double by one subtraction.  Two VALU
 // instructions fewer; no saturation for huge arguments, which is why the two-stream transmissions (arguments down to -inf)
 // keep the general form.  NaN stays NaN in both.
-template <bool BOUNDED>
+// SHORT (with BOUNDED, round 5): r = x - n ln2/256 in ONE fma against the 53-bit constant instead of the hi / lo pair.  The
+// constant's rounding (9e-20 of 2.7e-3) leaves an error of 3.3e-17 |x| in r, i.e. a RELATIVE error of |x| 2^-54 in the result
+// on top of the polynomial's — for arguments that are themselves rounded quotients or products of modest size (the
+// saturation pressures' a t / (t + b), |.| < 30; the stomatal and ground-wetness exponents): their own rounding error,
+// >= |x| 2^-53, is amplified the same way, so the result loses less than half of what the argument already lost.
+template <bool BOUNDED, bool SHORT = false>
 __device__ __forceinline__ double fexp_tab(double x, const MathK& K) {
     double n, r, p, r2, out;
     int t;
@@ -473,9 +497,13 @@ __device__ __forceinline__ double fexp_tab(double x, const MathK& K) {
             : "=v"(n) : "v"(x), "s"(K.t[0]));
         asm("v_cvt_i32_f64 %0, %1" : "=v"(t) : "v"(n));
     }
-    asm("v_fma_f64 %0, %1, %2, %3\n\t"
-        "v_fma_f64 %0, %1, %4, %0"
-        : "=&v"(r) : "v"(n), "s"(K.t[1]), "v"(x), "s"(K.t[2]));
+    if (BOUNDED && SHORT && K.vfast) {
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(n), "s"(K.t[4]), "v"(x));
+    } else {
+        asm("v_fma_f64 %0, %1, %2, %3\n\t"
+            "v_fma_f64 %0, %1, %4, %0"
+            : "=&v"(r) : "v"(n), "s"(K.t[1]), "v"(x), "s"(K.t[2]));
+    }
     double T;
     if (K.vfast) {
         // byte offset of table entry t & 255 in ONE instruction (SDWA byte select + shift); its shift operand has to be a VGPR,
@@ -506,6 +534,12 @@ __device__ __forceinline__ double fexp(double x, const MathK& K);
 template <bool F = true>
 __device__ __forceinline__ double fexp_b(double x, const MathK& K) {
     if (F && K.table) return fexp_tab<true>(x, K);
+    return fexp(x, K);
+}
+// ... and of modest size (fexp_tab SHORT): one instruction fewer
+template <bool F = true>
+__device__ __forceinline__ double fexp_s(double x, const MathK& K) {
+    if (F && K.table) return fexp_tab<true, true>(x, K);
     return fexp(x, K);
 }
 __device__ __forceinline__ double fexp(double x, const MathK& K) {
@@ -630,16 +664,31 @@ __device__ __forceinline__ void frcp2(double a, double b, double& ra, double& rb
     ra = r * b;
     rb = r * a;
 }
+// ... to 46 bits each (frcp_m): the pair of the ground wetness factor and the canopy temperature's denominator
+__device__ __forceinline__ void frcp2_m(double a, double b, double& ra, double& rb) {
+    const double r = frcp_m(a * b);
+    ra = r * b;
+    rb = r * a;
+}
 __device__ __forceinline__ double satvap(double tc, const MathK& K) { return 0.61078 * fexp(satvap_arg(tc), K); }
 // On REGULAR steps (kStepIrregular clear) air and dew-point temperature lie in (-150, 150) and every temperature of the path is a
 // Penman-Monteith result in [tdew, tc + 80] (pm_temperature), so |a t / (t + b)| < 60: the bounded exp applies.
+// F: 0.61078 exp(q) = exp(q + ln 0.61078), the addition folded into the quotient's last multiplication (one instruction
+// fewer; the sum's rounding is of the size of the quotient's own), through the one-fma reduction (fexp_s).
+constexpr double kLnSvp0 = -0x1.f8d9d41e4b1ffp-2;     // ln 0.61078
 template <bool F>
 __device__ __forceinline__ double satvap_f(double t, const MathK& K) {
+    if (F && K.table) {
+        double num, den;
+        satvap_nd(t, num, den);
+        return fexp_s<true>(fma(num, frcp(den), kLnSvp0), K);
+    }
     return 0.61078 * fexp_b<F>(satvap_arg(t), K);
 }
 // ... from the quotient's parts, where its reciprocal was shared with another division (frcp2)
 template <bool F>
 __device__ __forceinline__ double satvap_rd(double num, double rden, const MathK& K) {
+    if (F && K.table) return fexp_s<true>(fma(num, rden, kLnSvp0), K);
     return 0.61078 * fexp_b<F>(num * rden, K);
 }
 // cpp:24-26 with the 0.97*sb factor every caller applies
@@ -1004,20 +1053,22 @@ __device__ __forceinline__ void flr(double& x, double lo, Canary& cn) {         
 // ghr, De, lapk > 0), so dT is finite there.
 // (`rden`: the reciprocal of the denominator — pass 1 and pass 2 solve for the ground with the SAME denominator, cpp:1272 /
 // 1293, so the lane carries 1 / den across the day's barrier instead of den and pass 2 divides by a multiplication)
+// F: `dTmx` is min(dTmx, 80) already (solve_tile): the two caps of cpp:1237-1238 are one v_min_f64.  (A NaN dTmx is ignored by
+// the reference's comparison and by fmin alike.)
 template <bool F>
 __device__ __forceinline__ double pm_temperature_r(double num, double rden, double dTmx, double tc, double tdew, Canary& cn) {
     double dT = num * rden;
     cap<F>(dT, dTmx, cn);
-    cap<F>(dT, 80.0, cn);
+    if (!F) cap<F>(dT, 80.0, cn);
     double Ts = dT + tc;
     flr<F>(Ts, tdew, cn);
     return Ts;
 }
 template <bool F>
 __device__ __forceinline__ double pm_temperature(double num, double den, double dTmx, double tc, double tdew, Canary& cn) {
-    double dT = fdiv(num, den);
+    double dT = fdiv_m(num, den);
     cap<F>(dT, dTmx, cn);
-    cap<F>(dT, 80.0, cn);
+    if (!F) cap<F>(dT, 80.0, cn);
     double Ts = dT + tc;
     flr<F>(Ts, tdew, cn);
     return Ts;
@@ -1186,12 +1237,13 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const SL& S, con
             pin(c_logclump, c_loggi, amx, trdn, trdu, c_ehp, c_paiaa, emhpa, ehpa, c_rddng, c_albd, c_rddnz,
                 c_rdupz, Rbeam, Rb);
             // gap transmissions, cpp:1095-1100
+            // (F: an exponential is never negative — the floors at 0 cannot bind on a regular lane)
             double trbn = fexp(Kc * c_logclump, K);
             cap<F>(trbn, 0.999, cn);
-            flr<F>(trbn, 0.0, cn);
+            if (!F) flr<F>(trbn, 0.0, cn);
             double trb = fexp(Kc * c_loggi, K);
             cap<F>(trb, 0.999, cn);
-            flr<F>(trb, 0.0, cn);
+            if (!F) flr<F>(trb, 0.0, cn);
             double albb = (1.0 - trdn * trbn) * (p5s + p6 + p7) + trdn * trbn * gref;      // cpp:1102
             if (F) cn.watch(albb);        // 1/sig, 1/D1, 1/D2 products: NaN if a two-stream denominator vanishes
             cap<F>(albb, amx, cn);
@@ -1202,18 +1254,20 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const SL& S, con
             flr<F>(Rdbdn_g, 0.0, cn);
             double S2a = fexp(-kd * c_paiaa, K);
             double Rdbup_z = (1.0 - trdu * trbn) * (p5s * S2a + p6 * emhpa + p7 * ehpa) + trdu * trbn * gref;
-            if (F) cn.watch(Rdbup_z);
+            // (the same p5s, p6, p7 with finite weights: watched through albb)
             cap<F>(Rdbup_z, amx, cn);
             flr<F>(Rdbup_z, 0.0, cn);
             double Rdbdn_z = (1.0 - trb) * (p8s * S2a + p9 * emhpa + p10 * ehpa);           // cpp:1117
-            if (F) cn.watch(Rdbdn_z);
+            // (p8s, p9, p10: watched through Rdbdn_g)
             cap<F>(Rdbdn_z, amx, cn);
             flr<F>(Rdbdn_z, 0.0, cn);
             double trg = trb + (1 - trb) * S2;                                              // cpp:1125
             double Rbc = (trg * si + (1 - trg) * cz) * Rbeam;
-            double Rbdn_g = trbn + (1.0 - trbn) * S2;
-            cap<F>(Rbdn_g, 1.0, cn);
-            flr<F>(Rbdn_g, 0.0, cn);
+            double Rbdn_g = trbn + (1.0 - trbn) * S2;      // F: a convex combination of trbn in [0, 0.999] and S2 in [0, 1] stays in [0, 1]
+            if (!F) {
+                cap<F>(Rbdn_g, 1.0, cn);
+                flr<F>(Rbdn_g, 0.0, cn);
+            }
             const double rds = rdif * svfa;
             radGsw = (1.0 - gref) * (c_rddng * rds + Rdbdn_g * Rb + Rbdn_g * Rbeam * si);  // cpp:1131
             double maxg = (1.0 - gref) * (rds + Rbeam * si);
@@ -1261,12 +1315,12 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const SL& S, con
     // --- soil surface temperature with G = 0, cpp:1262-1275 ------------------------------
     const double radabs = radGsw + radGlw;
     double surfwet = fexp(matric * t_wfac, K);
-    cap<F>(surfwet, 1.0, cn);
+    if (!F) cap<F>(surfwet, 1.0, cn);      // F: matric <= 0 (|psi_e| >= 0, a positive power) and wfac > 0: the exponent is <= 0
     const double m = t_lapk * gHa;
     const double num0 = radabs - t_rem - m * (t_es - t_ea) * surfwet;
     const double den = 29.3 * (gHa + t_ghr) + m * t_de;
     cy.num0 = num0;
-    const double rden = frcp(den);
+    const double rden = frcp_m(den);
     cy.rden = rden;
     double Tg0 = pm_temperature_r<F>(num0, rden, dTmx, tc, tdew, cn);
     o.Tg0 = Tg0;
@@ -1283,7 +1337,7 @@ template <bool F>
 __device__ __forceinline__ double stomcond(double Rswabs, const Stom& s, const MathK& K, Canary& cn) {
     if (Rswabs <= 0.0) return 0.0;
     double gs = s.gsmax;          // light-saturated (Rswabs >= Rsmx): 2^0 = 1
-    if (Rswabs < s.rsmx) gs = s.gsmax * fexp_b<F>(-(s.rsmx - Rswabs) * s.inv02rsmx * 0.693147180559945309417, K);     // (-3.5, 0)
+    if (Rswabs < s.rsmx) gs = s.gsmax * fexp_s<F>((Rswabs - s.rsmx) * s.inv02rsmx, K);     // 2^-((Rsmx - R)/(0.2 Rsmx)): (-3.5, 0); inv02rsmx = ln2 / (0.2 Rsmx)
     cap<F>(gs, s.gs2, cn);
     return gs;
 }
@@ -1375,18 +1429,25 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
     const double uf = cy.uf;
     double gHa = uf * c_ghafac;
     flr<F>(gHa, 0.0001, cn);
-    const double esTg = satvap_f<F>(Tg, K);
-    double eT = esTg - ea;
-    flr<F>(eT, 0.001, cn);
-    double plf = 0.8753 - 1.7126 * flog(eT, K);
-    // Two pairs of reciprocals that do not depend on each other are taken from one v_rcp_f64 each (frcp2) in the fast-clamp
-    // vector-forcing kernels.  Which divisions are paired is fixed per code path, never by what the other lanes of the wave
-    // do: results stay bit-identical whatever the tile geometry, chunking or raster partition.
+    // Reciprocals that do not depend on each other are taken in pairs from one v_rcp_f64 each (frcp2) in the fast-clamp
+    // vector-forcing kernels: the ground's saturation pressure with the canopy's series conductance (round 5: the stomatal
+    // block runs first), the ground wetness factor with the canopy temperature, the canopy's saturation pressure with the
+    // Lagrangian time scale, the leaf's with the far field's normalisation.  Which divisions are paired is fixed per code path
+    // and per cell, never by what the other lanes of the wave do: results stay bit-identical whatever the tile geometry,
+    // chunking or raster partition.
     constexpr bool PAIR = F && !lean;
-    const double dgw = 1.0 + fexp_b<F>(-plf, K);            // eT in [1e-3, DBL_MAX]: -plf in (-13, 1215)
     const double surfwet = (soilm - c_smin) * c_invrge;
-    double gwet = 0.0;                                      // PAIR: with the canopy temperature's division below
+    double esTg = 0.0, dgw = 0.0, gwet = 0.0;
+    // the ground's saturation pressure -> wetness factor of the ground's vapour source, cpp:1417-1423
+    auto ground_wetness = [&]() {
+        double eT = esTg - ea;
+        flr<F>(eT, 0.001, cn);
+        double plf = 0.8753 - 1.7126 * flog(eT, K);
+        dgw = 1.0 + fexp_s<F>(-plf, K);                     // eT in [1e-3, DBL_MAX]: -plf in (-13, 1215)
+    };
     if (!PAIR) {
+        esTg = satvap_f<F>(Tg, K);
+        ground_wetness();
         gwet = frcp(dgw);
         flr<F>(gwet, surfwet, cn);
     }
@@ -1442,7 +1503,7 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
             if (flags & (FL_XONE | FL_XINF | FL_XZERO))
                 kb = (flags & FL_XONE) ? inv2cosb : (flags & FL_XINF) ? 1.0 : tanb;
             cap<F>(kb, 6000.0, cn);
-            P_sun = fdiv(1.0 - fexp(-kb * c_pai, K), kb);
+            P_sun = fdiv_m(1.0 - fexp(-kb * c_pai, K), kb);
         }
         double P_shade = c_pai - P_sun;
         if (lean) { c_shadefac = C(CF_SHADEFAC); c_ompc = C(CF_OMPC); }
@@ -1457,22 +1518,40 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
         gS = gs_sun * P_sun + gs_shade * P_shade;
     }
     double gV = 0.0;
-    if (gS > 0.0) gV = fdiv(gHa * gS, gHa + gS);           // 1/(1/gHa + 1/gS)
+    if (PAIR) {
+        // gS >= 0 here (conductances times sunlit / shaded leaf areas, P_sun <= pai), so gHa + gS >= 1e-4
+        double nTg, dTg, rTg, rG;
+        satvap_nd(Tg, nTg, dTg);
+        frcp2(dTg, gHa + gS, rTg, rG);
+        esTg = satvap_rd<F>(nTg, rTg, K);
+        if (gS > 0.0) gV = (gHa * gS) * rG;
+        ground_wetness();
+    } else if (gS > 0.0) gV = fdiv_m(gHa * gS, gHa + gS);  // 1/(1/gHa + 1/gS)
     // canopy temperature, cpp:1430-1432 (Penman-Monteith with the linear surface wetness)
     if (lean) c_svfa = C(CF_SVFA);
     const double Rabs = cy.radCsw + 0.97 * c_svfa * rlw;
     const double mC = lapk * gV;
-    const double numC = Rabs - rem - mC * (es - ea) * surfwet - G, denC = 29.3 * (gHa + ghr) + mC * De;
+    const double esw = (es - ea) * surfwet;                 // shared by the canopy's and the leaf's latent heat terms
+    const double numC = Rabs - rem - mC * esw - G, denC = 29.3 * (gHa + ghr) + mC * De;
     double Tcan;
     if (PAIR) {
         double rC;
-        frcp2(dgw, denC, gwet, rC);
+        frcp2_m(dgw, denC, gwet, rC);
         flr<F>(gwet, surfwet, cn);
         Tcan = pm_temperature_r<F>(numC, rC, dTmx, tc, tdew, cn);
     } else {
         Tcan = pm_temperature<F>(numC, denC, dTmx, tc, tdew, cn);
     }
-    const double esTcan = satvap_f<F>(Tcan, K);
+    double esTcan, muR = 0.0;                               // muR: uf/(a2*h) / uf^2, the below-canopy profile's (cpp:1389)
+    if (PAIR) {
+        double nTc, dTc, rTc;
+        satvap_nd(Tcan, nTc, dTc);
+        if (flags & FL_BELOW) frcp2(dTc, C(CF_A2H) * uf, rTc, muR);
+        else rTc = frcp(dTc);
+        esTcan = satvap_rd<F>(nTc, rTc, K);
+    } else {
+        esTcan = satvap_f<F>(Tcan, K);
+    }
     midway();
     double ez;
     if (!(flags & FL_BELOW)) {
@@ -1500,7 +1579,7 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
         // way a NaN leaf reflectance stays confined to the daytime values, as in the reference
         const bool lit = rsw > 0.0 && (flags & FL_PAI);
         const double leafabs = (lit ? c_hom * cy.X : 0.0) + lwabs;   // radLsw + lwabs
-        double gh = 0.135 * fsqrt(uz * invleafd) * 1.4;
+        double gh = (0.135 * 1.4) * fsqrt_m(uz * invleafd);
         const double RnetL = leafabs - lwcan;                // cpp:1319 with tc = Tcan
         // mincondCpp's floor is gmin = max(0.0463 * (|Hf| * |Rnet| / leafd)^0.2, 0.05) with |Hf| = 1/(1 + exp(2 - Hlf)) < 1,
         // so gmin <= max(0.0463 * (|Rnet|/leafd)^0.2, 0.05) whatever the stomatal resistance.  When gh clears THAT bound —
@@ -1540,29 +1619,30 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
                 double gmin = mincond_gmin<F>(hf02, a02, cn); // mincondCpp(leafabs, gs, Tcan, leafd)
                 flr<F>(gh, gmin, cn);
             }
-            if (gs > 0.0) gVl = fdiv(gh * gs, gh + gs);
+            if (gs > 0.0) gVl = fdiv_m(gh * gs, gh + gs);
         }
         const double mL = lapk * gVl;
-        const double tleaf = pm_temperature<F>(leafabs - rem - mL * (es - ea) * surfwet - 0.0,
+        const double tleaf = pm_temperature<F>(leafabs - rem - mL * esw - 0.0,
                                                29.3 * (gh + ghr) + mL * De, dTmx, tc, tdew, cn);
         o.tleaf = tleaf;
         o.lwdn = lwdn;
         o.lwup = lwup;
         // ---- section D operands: canopy-top source + Lagrangian near/far field
-        double w2 = C(CF_OML2), hgt = C(CF_HGT), c_a2h = C(CF_A2H), c_inthh = C(CF_INTHH), c_inthz = C(CF_INTHZ),
+        double w2 = C(CF_OML2), hgt = C(CF_HGT), c_inthh = C(CF_INTHH), c_inthz = C(CF_INTHZ),
                c_invhgt = C(CF_INVHGT), c_invhmz = C(CF_INVHMZ), omem = C(CF_OMEMPAI), nf = C(CF_NEARFAC),
                lden = C(CF_LEAFDEN);
         double mu = T(TF_MUPM), invmu = T(TF_INVMUPM);
-        pin(w2, hgt, c_a2h, c_inthh, c_inthz, c_invhgt, c_invhmz, omem, nf, lden, mu, invmu);
+        pin(w2, hgt, c_inthh, c_inthz, c_invhgt, c_invhmz, omem, nf, lden, mu, invmu);
         // ---- canopy-top source, cpp:1449 ---------------------------------------------------------
         const double HC = 29.3 * gHa * (Tcan - tc);
-        const double LC = mC * (esTcan - ea) * surfwet;
+        const double ecw = (esTcan - ea) * surfwet;          // shared with the canopy-top vapour pressure below
+        const double LC = mC * ecw;
         bool prof2 = (flags & FL_ABOVE2) != 0;
         const double Th = prof2 ? tc + (Tcan - tc) * w2 : Tcan;
-        const double eh = prof2 ? ea + (esTcan - ea) * surfwet * w2 : ea + (esTcan - ea) * surfwet;
+        const double eh = prof2 ? ea + ecw * w2 : ea + ecw;
         // ---- Lagrangian near/far field, cpp:1365-1409 ---------------------------------------------
         const double z = g.reqhgt2;
-        const double muR = frcp(c_a2h * uf);                 // uf/(a2*h) / uf^2
+        if (!PAIR) muR = frcp(C(CF_A2H) * uf);
         double Rc = c_inthh * muR;
         flr<F>(Rc, 0.001, cn);
         double Rz = c_inthz * muR;
@@ -1588,12 +1668,22 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
         // the leaf's saturated vapour pressure and the far field's normalisation share a reciprocal
         double esTl;
         if (PAIR) {
-            double nTl, dTl, rTl;
-            satvap_nd(tleaf, nTl, dTl);
-            frcp2(dTl, Kg + Kh + Kc, rTl, invK);
-            esTl = satvap_rd<F>(nTl, rTl, K);
+            // A leaf with closed stomata (every night step: gs = 0, so gVl = mL = 0) has no latent heat flux: LL = 0, the near
+            // field of the vapour profile is 0 whatever its limit, and the leaf's saturation pressure — the only other use —
+            // is not needed (round 5).  The branch follows the lane's own conductance, so results do not depend on the
+            // lane's neighbours; a night wave (three consecutive hours) skips it whole.
+            if (gVl > 0.0) {
+                double nTl, dTl, rTl;
+                satvap_nd(tleaf, nTl, dTl);
+                frcp2(dTl, Kg + Kh + Kc, rTl, invK);
+                esTl = satvap_rd<F>(nTl, rTl, K);
+            } else {
+                invK = frcp(Kg + Kh + Kc);
+                esTl = eh;
+            }
         } else {
-            esTl = satvap_f<F>(tleaf, K);
+            if (F && !(gVl > 0.0)) esTl = eh;                              // (as above; the reference's clamps keep the evaluation)
+            else esTl = satvap_f<F>(tleaf, K);
             invK = frcp(Kg + Kh + Kc);
         }
         const double HL = 29.3 * gh * (tleaf - tc);                       // cpp:1242
@@ -1623,7 +1713,7 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
     // ez / satvap(Tz) * 100, cpp:1463-1465; 1 / (0.61078 exp(u)) = exp(-u) / 0.61078 spares the fast variant the division
     double rh;
     if (F) {
-        rh = (ez * (100.0 / 0.61078)) * fexp_b<true>(-satvap_arg(o.Tz), K);     // Tz lies within 2 K of the temperatures above
+        rh = (ez * (100.0 / 0.61078)) * fexp_s<true>(-satvap_arg(o.Tz), K);     // Tz lies within 2 K of the temperatures above
     } else {
         rh = fdiv(ez, satvap(o.Tz, K)) * 100.0;
     }

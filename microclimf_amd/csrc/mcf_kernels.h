@@ -157,6 +157,36 @@ struct BioclimArgs {
     double* bio;           // [19][N]
 };
 void launch_bioclim(const BioclimArgs& a, hipStream_t s);
+// The same nineteen values STREAMED (round 5): the solver runs in day chunks into a small ring and each chunk is folded into
+// per-cell running state — sums, day extremes, quarter sums in the reference's index order (cpp:3245-3560) — so that nothing of
+// size cells x steps is ever allocated.  State rows, [kBioStateRows][N]:
+//   0 tz at step 0 (the NA test, cpp:3505)   1 bio1's running sum   2 bio2's sum of daily ranges   3..14 the twelve daily means
+//   15 bio5's maximum   16 bio6's minimum   17..20 tz quarter sums   21 bio12's sum   22 / 23 soil moisture max / min
+//   24 its sum over all steps   25..28 soil moisture quarter sums
+constexpr int kBioStateRows = 29;
+struct BioAccArgs {
+    int64_t N;
+    RingView tz, soilm;        // step 0 of the views = the chunk's first step
+    int32_t day0, ndays;       // the chunk: absolute first day, whole days
+    const int32_t* q[4];       // wettest / driest / hottest / coldest quarter's step indices, ascending (checked by the host)
+    int32_t qlo[4], qhi[4];    // the entries that fall into this chunk
+    double* state;
+};
+void launch_bioclim_acc(const BioAccArgs& a, hipStream_t s);
+struct BioFinArgs {
+    int64_t N;
+    int32_t tsteps;
+    const double* state;
+    double* bio;               // [19][N]
+    // the soil moisture series again for the variance's second pass (cpp:3391-3398): it is a function of the cell's constants and
+    // the point model's soil moisture alone (soil_spread, cpp:1021-1032), made here with the very function the solver's lanes run
+    const double* cellc;       // tile-major constant table
+    int64_t ntiles_total;
+    int32_t cpb;
+    const int32_t* daylayer;   // or null
+    const double* tt;          // time table [day][TF_COUNT][24]
+};
+void launch_bioclim_fin(const BioFinArgs& a, hipStream_t s);
 void launch_fill(double* p, int64_t n, double v, hipStream_t s);
 // dst[ci + ncells*k] = src(cells[ci], step0 + k), k < nsteps
 void launch_gather_cells(const RingView& src, int64_t step0, int64_t nsteps, const int64_t* cells, int64_t ncells, double* dst,

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void k_cell_setup(CellSetupArgs a) {
         }
         const double gsmax = a.gsmax[c];
         if (gsmax < 999.99) flags |= FL_STOM;
-        put(CF_GSMAX, gsmax); put(CF_RSMX, Rsmx); put(CF_INV02RSMX, 1.0 / (0.2 * Rsmx)); put(CF_RAT, rat);
+        put(CF_GSMAX, gsmax); put(CF_RSMX, Rsmx); put(CF_INV02RSMX, 0.693147180559945309417 / (0.2 * Rsmx)); put(CF_RAT, rat);
         put(CF_RATC, (1 - rat) * kThetam); put(CF_PSIW0, psiw0); put(CF_KK, kk);
         put(CF_MUDENINV, 1.0 / (exp(-kk * psiw0) - 1.0));
         put(CF_SINLAT, sin(lat * kPi / 180.0));
@@ -612,6 +612,8 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
     Globals g = a.g;
     double dTmx = g.dTmx;
     if (AF && in_grid) dTmx = -0.6273 * a.mxtc[c] + 49.79;   // cpp:1236 with the per-cell mxtc
+    // the fast clamps take the two caps of cpp:1237-1238 as one (pm_temperature); a NaN dTmx is ignored by both forms
+    const double dTcap = F ? fmin(dTmx, 80.0) : dTmx;
     // TVaboveground (cpp:2272) is only evaluated when one of its outputs was requested
     const bool need_tv = g.reqhgt >= 0.0 && a.need_tv != 0;
     MathK MK;
@@ -858,8 +860,8 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
         Carry cy;
         Pass1Out p1;
         if (valid) {
-            if (AF) pass1<F, false>(C, TR, SL, g, flags, dTmx, cy, p1, MK, cn);
-            else pass1<F, SS>(C, TL, SL, g, flags, dTmx, cy, p1, MK, cn);
+            if (AF) pass1<F, false>(C, TR, SL, g, flags, dTcap, cy, p1, MK, cn);
+            else pass1<F, SS>(C, TL, SL, g, flags, dTcap, cy, p1, MK, cn);
             if (!PRE) {
                 // every hour lane folds its values into the cell's slots (the 21-cell lane map combines a wave's three hours
                 // of a cell through the crossbar first, below); `if (m < x) m = x` ignores a NaN x, so does the LDS unit
@@ -935,8 +937,8 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
             const double dtr = tmx - tmn;
             Pass2Out p2{};
             if (AF) derive_time_af_pass2(tv);
-            if (AF) pass2<F, false>(C, TR, SL, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2, MK, cn);
-            else pass2<F, SS>(C, TL, SL, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2, MK, cn);
+            if (AF) pass2<F, false>(C, TR, SL, g, flags, dTcap, cy, dtr, Rmx, need_tv, p2, MK, cn);
+            else pass2<F, SS>(C, TL, SL, g, flags, dTcap, cy, dtr, Rmx, need_tv, p2, MK, cn);
             if (BG) {
                 a.tgser[c + N * ((int64_t)dabs * 24 + hr)] = p2.Tg;
                 s_dd[hr * CPB + cl] = p2.DD;
@@ -1257,6 +1259,138 @@ void launch_bioclim(const BioclimArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_bioclim, dim3((unsigned)((a.N + 63) / 64)), dim3(64), 0, s, a);
 }
 
+// ---- the streamed form (mcf_kernels.h BioAccArgs): k_bioclim's loops cut at chunk boundaries, every accumulation in the same
+// order on the same operands — the nineteen matrices are bit for bit k_bioclim's (tests/test_bioclim_gpu.py).
+__global__ __launch_bounds__(64) void k_bioclim_acc(BioAccArgs a) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t N = a.N;
+    if (c >= N) return;
+    const RingCell tz(a.tz, c), sm(a.soilm, c);
+    double* st = a.state + c;
+    auto S = [&](int row) -> double& { return st[N * row]; };
+    if (a.day0 == 0) {
+        S(0) = tz[0];
+        S(1) = 0.0; S(2) = 0.0;
+        S(15) = -273.15; S(16) = 273.15;
+        for (int r = 17; r <= 21; ++r) S(r) = 0.0;
+        S(22) = 0.0; S(23) = 1.0; S(24) = 0.0;
+        for (int r = 25; r <= 28; ++r) S(r) = 0.0;
+    }
+    if (isnan(S(0))) return;                                            // cpp:3505-3506: every value NA (k_bioclim_fin)
+    double s1 = S(1), dsum = S(2), b5 = S(15), b6 = S(16), me = S(21), mx = S(22), mn = S(23), all = S(24);
+    for (int dl = 0; dl < a.ndays; ++dl) {
+        const int d = a.day0 + dl, k0 = dl * 24;
+        if (d < 12) {                                                   // bio1 cpp:3245, bio2 cpp:3256, bio4 cpp:3279
+            double tmx = -273.15, tmn = 273.15, ms = 0.0;
+            for (int h = 0; h < 24; ++h) {
+                const double v = tz[k0 + h];
+                s1 = s1 + v;
+                if (v > tmx) tmx = v;
+                if (v < tmn) tmn = v;
+                ms = ms + v;
+            }
+            dsum = dsum + (tmx - tmn);
+            S(3 + d) = ms / 24;
+            for (int h = 0; h < 24; ++h) me = me + sm[k0 + h];          // bio12 cpp:3361
+        } else if (d == 12) {                                           // bio5 cpp:3297
+            for (int h = 0; h < 24; ++h) { const double v = tz[k0 + h]; if (v > b5) b5 = v; }
+        } else if (d == 13) {                                           // bio6 cpp:3307
+            for (int h = 0; h < 24; ++h) { const double v = tz[k0 + h]; if (v < b6) b6 = v; }
+        }
+        for (int h = 0; h < 24; ++h) {                                  // bio13, bio14, bio15's mean cpp:3371-3398
+            const double v = sm[k0 + h];
+            if (v > mx) mx = v;
+            if (v < mn) mn = v;
+            all += v;
+        }
+    }
+    S(1) = s1; S(2) = dsum; S(15) = b5; S(16) = b6; S(21) = me; S(22) = mx; S(23) = mn; S(24) = all;
+    const int kbase = a.day0 * 24;
+    for (int qi = 0; qi < 4; ++qi) {                                    // cpp:3316-3358, 3406-3448
+        if (a.qlo[qi] >= a.qhi[qi]) continue;
+        double st_ = S(17 + qi), ss_ = S(25 + qi);
+        for (int i = a.qlo[qi]; i < a.qhi[qi]; ++i) {
+            const int k = a.q[qi][i] - kbase;
+            st_ = st_ + tz[k];
+            ss_ = ss_ + sm[k];
+        }
+        S(17 + qi) = st_; S(25 + qi) = ss_;
+    }
+}
+void launch_bioclim_acc(const BioAccArgs& a, hipStream_t s) {
+    if (a.N <= 0) return;
+    hipLaunchKernelGGL(k_bioclim_acc, dim3((unsigned)((a.N + 63) / 64)), dim3(64), 0, s, a);
+}
+__global__ __launch_bounds__(64) void k_bioclim_fin(BioFinArgs a) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t N = a.N;
+    if (c >= N) return;
+    const double* st = a.state + c;
+    auto S = [&](int row) { return st[N * row]; };
+    double* out = a.bio + c;
+    const double NA = na_real();
+    if (isnan(S(0))) {
+        for (int b = 0; b < 19; ++b) out[N * b] = NA;
+        return;
+    }
+    const int T = a.tsteps;
+    double bio[19];
+    bio[0] = S(1) / 288.0;
+    bio[1] = S(2) / 12;
+    {
+        double mean = 0.0;                                              // calc_std_dev cpp:3227
+        for (int d = 0; d < 12; ++d) mean += S(3 + d);
+        mean /= 12;
+        double ss = 0.0;
+        for (int d = 0; d < 12; ++d) ss += (S(3 + d) - mean) * (S(3 + d) - mean);
+        bio[3] = sqrt(ss / 11) * 100.0;
+    }
+    bio[4] = S(15);
+    bio[5] = S(16);
+    for (int qi = 0; qi < 4; ++qi) { bio[7 + qi] = S(17 + qi) / 72.0; bio[15 + qi] = S(25 + qi) / 72.0; }     // cpp:3325
+    {
+        const double me = S(21) / 288.0;
+        const double mean = S(24) / T;
+        // second pass over the soil moisture series: the solver's value of every step, made again (BioFinArgs)
+        const uint32_t cc = (uint32_t)c, tile = cc / (uint32_t)a.cpb, cl = cc - tile * (uint32_t)a.cpb;
+        const int64_t IMG = tile_image_doubles_dev(a.cpb);
+        double ss = 0.0;
+        int layer = -2;
+        double smin = 0.0, invrge = 0.0, eta = 0.0, rge = 0.0;
+        bool valid = false;
+        Canary cn;
+        for (int d = 0; d < T / 24; ++d) {
+            const int l = a.daylayer ? a.daylayer[d] : 0;
+            if (l != layer) {
+                layer = l;
+                if (l >= 0) {
+                    const double* img = a.cellc + ((int64_t)l * a.ntiles_total + tile) * IMG + cl;
+                    smin = img[CF_SMIN * a.cpb]; invrge = img[CF_INVRGE * a.cpb]; eta = img[CF_ETA * a.cpb]; rge = img[CF_RGE * a.cpb];
+                    valid = ((int)img[CF_FLAGS * a.cpb] & FL_VALID) != 0;
+                }
+            }
+            const double* sp = a.tt + ((int64_t)d * TF_COUNT + TF_SOILMP) * 24;
+            for (int h = 0; h < 24; ++h) {
+                const double v = (l >= 0 && valid) ? soil_spread<false>(sp[h], smin, invrge, eta, rge, cn) : NA;
+                const double dlt = v - mean;
+                ss += dlt * dlt;
+            }
+        }
+        const double sd = T <= 1 ? NA : sqrt(ss / (T - 1));
+        bio[11] = me;
+        bio[12] = S(22);
+        bio[13] = S(23);
+        bio[14] = me / sd;                                              // cpp:3402 (sic: mean / sd)
+    }
+    bio[6] = bio[4] - bio[5];                                           // cpp:3533
+    bio[2] = bio[1] / bio[6];                                           // cpp:3534
+    for (int b = 0; b < 19; ++b) out[N * b] = bio[b];
+}
+void launch_bioclim_fin(const BioFinArgs& a, hipStream_t s) {
+    if (a.N <= 0) return;
+    hipLaunchKernelGGL(k_bioclim_fin, dim3((unsigned)((a.N + 63) / 64)), dim3(64), 0, s, a);
+}
+
 // ------------------------------------------------------------------------------------
 // Diagnostics: evaluates the lean elementary functions of mcf_device.hpp elementwise.
 __global__ void k_selftest_math(int kind, const double* __restrict__ x, const double* __restrict__ y,
@@ -1282,6 +1416,11 @@ __global__ void k_selftest_math(int kind, const double* __restrict__ x, const do
         case 5: r = satvap(a, K); break;
         case 7: r = fexp_b<true>(a, K); break;        // |x| < 5e6
         case 8: r = satvap_f<true>(a, K); break;      // the fast-clamp kernels' satvap (wave-uniform constants, bounded exp)
+        case 9: r = fexp_s<true>(a, K); break;        // one-fma reduction: relative error grows with |x| 2^-54
+        case 10: r = frcp_m(a); break;                // 46 bits
+        case 11: r = fsqrt_m(a); break;               // 46 bits
+        case 12: { double ra, rb; frcp2_m(a, b, ra, rb); r = ra + rb; break; }
+        case 13: { double ra, rb; frcp2(a, b, ra, rb); r = ra + rb; break; }
         default: r = powxy(a, b, K); break;
     }
     if (live) out[i] = r;

@@ -721,6 +721,176 @@ __global__ __launch_bounds__(256, MCF_MICRORING_WAVES) void k_microsnow_ring(Mic
     }
 }
 
+// Round 5 shape, for the solver's 21-cell tiles: a workgroup is THREE tiles (63 consecutive cells, lane 63 idle) x EVERY snow
+// day of the chunk; eight waves, wave w takes the hours w, w + 8, w + 16 of each day (the hour stays wave-uniform: the step
+// record comes through scalar loads as before).  What that buys (profiles/r04_c4_aux_pmc_summary.json had 1.40 x the values
+// written and 1.47 x the series read):
+//   * the horizon and wind-shelter planes (24 + 8 values per cell; one of each was fetched per cell-STEP: 16 B beside the
+//     40 B of snow series) and the cell table are staged in LDS ONCE per workgroup = once per chunk;
+//   * every store is a whole 128-byte line.  Of a tile-day block's four lines per hour group (mcf_kernels.h ring_pos: three
+//     hours x cells 0-15, then cells 16-20 of the three hours) the first three are one wave's sixteen consecutive lanes; the
+//     fourth was written 40 B at a time by three different waves.  Its values now meet in LDS (s_tail) and are flushed behind
+//     the day's barrier, a line per sixteen lanes.  A slot nobody produced (a snow-free cell-step of a day the solver ran as
+//     well: its value stays) holds a sentinel and is not stored.
+constexpr int kRtCells = 63, kRtWaves = 8;
+constexpr unsigned long long kTailEmpty = 0x7FF8A5A5DEAD0001ULL;      // (a NaN payload no arithmetic produces)
+__global__ __launch_bounds__(64 * kRtWaves, MCF_MICRORING_WAVES) void k_microsnow_tiles(MicroRingArgs q, const MicroStep* __restrict__ tb,
+                                                                                       const int32_t* __restrict__ tb_daymap,
+                                                                                       const int32_t* __restrict__ tb_nosnow) {
+    snow::snow_tables_init();
+    __shared__ double s_mc[MC_COUNT][64];
+    __shared__ double s_hw[32][64];                   // 24 horizon + 8 wind-shelter planes of the workgroup's cells
+    __shared__ double s_tail[MCF_NOUT * 3 * 8 * 16];   // [held variable][tile][hour group][15 values + padding]
+    const MicroArgs& a = q.m;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t N = a.N;
+    const int64_t c0 = (int64_t)blockIdx.x * kRtCells;     // uniform
+    const bool inr = lane < kRtCells && c0 + lane < N;
+    const double NA = na_real();
+    {
+        const int64_t cc = c0 + lane < N ? c0 + lane : N - 1;             // idle lanes read the last cell and write nothing
+        // ---- once per workgroup: the cell table (a part by each of the first three waves) and the 32 direction planes
+        if (wv == 0) {
+            const double hgt = a.hgt[cc], pai = a.pai[cc], leafd = a.leafd[cc];
+            s_mc[MC_HGT][lane] = hgt; s_mc[MC_PAI][lane] = pai; s_mc[MC_LEAFD][lane] = leafd;
+            s_mc[MC_IHGT][lane] = gdiv(1.0, hgt); s_mc[MC_ILEAFD][lane] = gdiv(1.0, leafd); s_mc[MC_IPAI][lane] = gdiv(1.0, pai);
+            s_mc[MC_PAIA][lane] = a.paia[cc]; s_mc[MC_LTRA][lane] = a.leaft[cc];
+        } else if (wv == 1) {
+            const double slope = a.slope[cc];
+            s_mc[MC_SLOPE][lane] = slope;
+            s_mc[MC_CS][lane] = cos(slope * kToRad); s_mc[MC_SS][lane] = sin(slope * kToRad);
+            s_mc[MC_LEAFDEN][lane] = a.leafden[cc]; s_mc[MC_SVFA][lane] = a.skyview[cc];
+        } else if (wv == 2) {
+            const double aspect = a.aspect[cc], clump = a.clump[cc];
+            s_mc[MC_CA][lane] = cos(aspect * kToRad); s_mc[MC_SA][lane] = sin(aspect * kToRad);
+            s_mc[MC_CLUMP][lane] = clump;
+            s_mc[MC_LNCLUMP][lane] = clump > 0.0 ? glog(clump) : 0.0;
+            s_mc[MC_MEAND][lane] = a.meanD[cc];
+            s_mc[MC_SMAX][lane] = a.Smax ? a.Smax[cc] : 0.0;
+        } else {
+            for (int p = wv - 3; p < 32; p += kRtWaves - 3) s_hw[p][lane] = p < 24 ? a.hor[(int64_t)p * N + cc] : a.wsa[(int64_t)(p - 24) * N + cc];
+        }
+    }
+    // The lane's place: in the raster a uniform base + its lane number; in the tiled ring the block of its tile (uniform base of
+    // the workgroup's first tile + tl tile strides) and, for cells 0-15, its column of the hour's line; cells 16-20 go to s_tail.
+    // All as 32-bit byte offsets against uniform bases: no 64-bit vector address arithmetic per load or store.
+    const int tl = lane / 21, cl = lane - 21 * tl;
+    const bool direct = cl < 16;
+    uint32_t rofs = (uint32_t)(tl * (int)q.ring.tile_stride + cl) * 8u;            // (a tile's days x variables x 512 doubles: < 2^29)
+    const int tofs = tl * 128 + (cl - 16);
+    uint32_t lofs = (uint32_t)lane * 8u;
+    const int nheld = __builtin_popcount(q.held);
+    for (int day = 0; day < q.ndays; ++day) {
+        const int sub = tb_daymap[day];               // uniform: scalar loads
+        if (sub < 0) continue;
+        const bool keep = tb_nosnow[day] != 0;        // the solver ran this day: snow-free cell-steps keep its values
+        const int k0 = day * 24;
+        // the day's mean ground-snow temperature (see k_microsnow_ring) by the last wave; the tails' slots emptied by the threads
+        // that flushed them (same thread, same slots: ordered without a barrier)
+        if (wv == kRtWaves - 1) {
+            const double* tg = a.sTg + (N * k0 + c0);
+            const int64_t cc = c0 + lane < N ? lane : N - 1 - c0;
+            double Tzd = NA;
+            if (!isnan(tg[cc])) {
+                double sumd = 0.0;
+                for (int h = 0; h < 24; ++h) sumd += tg[cc + N * h];
+                Tzd = sumd / 24.0;
+            }
+            s_mc[MC_TZD][lane] = Tzd;
+        }
+        for (int e = tid; e < nheld * 384; e += 64 * kRtWaves) reinterpret_cast<unsigned long long*>(s_tail)[e] = kTailEmpty;
+        __syncthreads();
+        // the workgroup's first tile's block of this day (uniform)
+        double* const dayblk = q.base0 + ((int64_t)blockIdx.x * 3) * q.ring.tile_stride + (int64_t)day * q.ring.day_stride;
+        if (inr) {
+            for (int h = wv; h < 24; h += kRtWaves) {
+                int li = lane;
+                asm volatile("" : "+v"(li));
+                uint32_t held = q.held, selm = q.sel;
+                int64_t vs = q.vstride;
+                asm volatile("" : "+s"(held), "+s"(selm), "+s"(vs));
+                auto has = [&](int i) { return (held >> i) & 1u; };
+                const int hg = h / 3, hm = h - 3 * hg;               // uniform
+                auto put = [&](int i, double v) {
+                    const int rank = __builtin_popcount(held & ((1u << i) - 1u));
+                    if (direct) {
+                        asm("" : "+v"(rofs));       // (keeps the offset's zero-extension in the store's own block: mcf_kernels.hip `put`)
+                        *(double*)((char*)(dayblk + (rank * vs + (64 * hg + 16 * hm))) + rofs) = v;
+                    } else {
+                        s_tail[(rank * 384 + hg * 16 + 5 * hm) + tofs] = v;
+                    }
+                };
+                auto MC = [&](int f) { return s_mc[f][li]; };
+                const double hgt = MC(MC_HGT);
+                if (isnan(hgt)) {            // cpp:4988-4989
+                    if (!keep) {
+#pragma unroll
+                        for (int i = 0; i < MCF_NOUT; ++i) if (has(i)) put(i, NA);
+                    }
+                    continue;
+                }
+                // the step's plane of each snow series (uniform) + the lane
+                const int64_t po = N * (k0 + h) + c0;
+                auto ser = [&](const double* p) {
+                    asm("" : "+v"(lofs));
+                    return *(const double*)((const char*)(p + po) + lofs);
+                };
+                const int f = sub * 24 + h;                   // step of the snow-day subset series
+                const double swe = ser(a.swe);
+                if (!(swe > 0.0)) {                           // cpp:4993
+                    if (!keep) {
+#pragma unroll
+                        for (int i = 0; i < MCF_NOUT; ++i) if (has(i)) put(i, NA);
+                    }
+                    continue;
+                }
+                const double sdepg = ser(a.sdepg), sTg = ser(a.sTg);
+                const double reqhgts = a.reqhgt - sdepg;
+                auto emit = [&](int i, double val) {
+                    if (!has(i)) return;
+                    if ((selm >> i) & 1u) put(i, val);
+                    else if (!keep) put(i, NA);
+                };
+                double Tz, tleaf, rh;
+                if (reqhgts >= 0.0) {
+                    const MicroStep& r = tb[f];
+                    const SunT sun = r.s;
+                    SiteK site;
+                    site.cS = MC(MC_CS); site.sS = MC(MC_SS); site.cA = MC(MC_CA); site.sA = MC(MC_SA); site.flat = MC(MC_SLOPE) == 0.0;
+                    MicroIn mi;
+                    mi.si = solar_index(sun, site, true);
+                    if (isnan(mi.si)) mi.si = sun.cz;                          // cpp:5002
+                    mi.shadowmask = s_hw[r.sindex][li] > sun.tansa ? 0 : 1;
+                    mi.ws = s_hw[24 + r.windex][li];
+                    mi.reqhgt = reqhgts; mi.zref = a.zref;
+                    mi.tc = r.tc; mi.pk = r.pk; mi.u2 = r.u2;
+                    mi.Rsw = r.rsw; mi.Rdif = r.rdif; mi.Rlw = r.rlw; mi.umu = r.umu;
+                    mi.cell = &s_mc[0][li]; mi.cs = 64;
+                    mi.Tg = sTg; mi.Tc = ser(a.sTc); mi.sden = ser(a.sden); mi.sdepg = sdepg;
+                    mi.sdepc = swe / mi.sden;
+                    mi.alb = r.alb; mi.ialb = r.ialb;
+                    const MicroOut mo = micro_above(mi, r.mm, sun, [&](int i, double val) { emit(i, val); return true; });
+                    Tz = mo.Tz; tleaf = mo.tleaf; rh = mo.rh;
+                } else {
+                    const double b = micro_below(reqhgts, MC(MC_MEAND), sTg, MC(MC_TZD), a.mat, a.hiy);
+                    Tz = b; tleaf = b; rh = 100.0;
+                    for (int i = 4; i < MCF_NOUT; ++i) emit(i, 0.0);
+                }
+                emit(0, Tz); emit(1, tleaf); emit(2, rh);
+                emit(3, MC(MC_SMAX));
+            }
+        }
+        __syncthreads();
+        // flush: element e = (rank * 3 + tile) * 128 + hour group * 16 + slot -> the fourth line of that block's hour group
+        for (int e = tid; e < nheld * 384; e += 64 * kRtWaves) {
+            const unsigned long long bits = reinterpret_cast<const unsigned long long*>(s_tail)[e];
+            if (bits == kTailEmpty) continue;
+            const int slot = e & 15, g = (e >> 4) & 7, rt = e >> 7, rank = rt / 3, t3 = rt - 3 * rank;
+            dayblk[(int64_t)t3 * q.ring.tile_stride + rank * q.vstride + 64 * g + 48 + slot] = __longlong_as_double((long long)bits);
+        }
+    }
+}
+
 // ---- .snowmodel1's chunk loop (R/internal.R "int:" 2553-2617) ---------------------------------------
 // albedo clock restarted at every chunk start: each gridmodelsnow1 call runs snowalbCpp on its own slice
 __global__ void k_snow_alb_chunks(StepRow* rows, const double* precip, int tsteps, int chunk, int nchunks) {
@@ -2397,8 +2567,13 @@ extern "C" int mcf_snowplan_microsnow(mcf_snowplan* sp, mcf_plan* plan, int32_t 
     }
     for (int v = 0; v < MCF_NOUT; ++v) q.sel |= sp->outsel[v] ? 1u << v : 0u;
     q.daymap = sp->d_daymap; q.nosnow = sp->d_nosnow; q.ndays = nd;
-    hipLaunchKernelGGL(k_microsnow_ring, dim3((unsigned)((N + 63) / 64), (unsigned)nd), dim3(256), 0, nullptr, q, (const MicroStep*)q.m.mstep,
-                       q.daymap, q.nosnow);
+    static const bool old_shape = getenv("MCF_MICRORING_OLD") != nullptr;      // A/B
+    if (q.ring.cpb == 21 && !old_shape)
+        hipLaunchKernelGGL(k_microsnow_tiles, dim3((unsigned)((N + kRtCells - 1) / kRtCells)), dim3(64 * kRtWaves), 0, nullptr, q,
+                           (const MicroStep*)q.m.mstep, q.daymap, q.nosnow);
+    else
+        hipLaunchKernelGGL(k_microsnow_ring, dim3((unsigned)((N + 63) / 64), (unsigned)nd), dim3(256), 0, nullptr, q, (const MicroStep*)q.m.mstep,
+                           q.daymap, q.nosnow);
     S_TRY(hipGetLastError());
     S_TRY(hipDeviceSynchronize());
     return MCF_OK;

@@ -57,7 +57,9 @@ static SEXP elt(SEXP list, const char *name, const char *alt) {
 }
 
 /* Entry points whose C structs outlive the .Call (mcfhip_snowrun_create: the library reads the caller's arrays until the run
- * is destroyed) set g_keep to a list that then holds every vector a coercion below had to create. */
+ * is destroyed) set g_keep to a list that then holds every vector a coercion below had to create.  EVERY entry that coerces
+ * arguments clears it first: fill_inputs / fill_snowdriver can leave through Rf_error (a longjmp) while it is set, and the
+ * list — reachable only from the unwound frame's external pointer — may be collected before the next .Call. */
 static SEXP g_keep = NULL;
 static int g_nkeep = 0;
 static void keep(SEXP x) {
@@ -147,6 +149,7 @@ static SEXP run(int array_forcing, SEXP dfsel, SEXP obstime, SEXP climdata, SEXP
                 SEXP reqhgt, SEXP zref, SEXP lat, SEXP lon, SEXP Sminp, SEXP Smaxp, SEXP tfact,
                 SEXP complete, SEXP mat, SEXP out) {
     int np = 0;
+    g_keep = NULL; g_nkeep = 0;     /* an earlier entry may have left through Rf_error with the list still set: it is unprotected then */
     mcf_grid_inputs in;
     mcf_options opt;
     mcf_outputs res;
@@ -229,6 +232,7 @@ static SEXP run_bioclim(int array_forcing, int layered, SEXP obstime, SEXP climd
                         SEXP reqhgt, SEXP zref, SEXP lat, SEXP lon, SEXP Sminp, SEXP Smaxp, SEXP tfact, SEXP mat,
                         SEXP out, SEXP wetq, SEXP dryq, SEXP hotq, SEXP colq, SEXP air) {
     int np = 0;
+    g_keep = NULL; g_nkeep = 0;     /* an earlier entry may have left through Rf_error with the list still set: it is unprotected then */
     mcf_grid_inputs in;
     mcf_options opt;
     SEXP mask = PROTECT(allocVector(LGLSXP, MCF_NOUT)); ++np;
@@ -380,6 +384,7 @@ static void raise_last(int rc, int np) {
 static SEXP run_snowmodel(int array_forcing, SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, SEXP other,
                           SEXP snowenv) {
     int np = 0;
+    g_keep = NULL; g_nkeep = 0;     /* an earlier entry may have left through Rf_error with the list still set: it is unprotected then */
     mcf_snow_inputs in;
     fill_snow(&in, &np, array_forcing, 0, obstime, climdata, pointm, vegp, other);
     in.snowenv = mcf_snowenv_from_name(CHAR(asChar(snowenv)));
@@ -420,6 +425,7 @@ SEXP mcfhip_gridmodelsnow2(SEXP obstime, SEXP climdata, SEXP pointm, SEXP vegp, 
 static SEXP run_microsnow(int array_forcing, SEXP reqhgt, SEXP obstime, SEXP climdata, SEXP snowm, SEXP micro,
                           SEXP vegp, SEXP other, SEXP mat, SEXP out) {
     int np = 0;
+    g_keep = NULL; g_nkeep = 0;     /* an earlier entry may have left through Rf_error with the list still set: it is unprotected then */
     mcf_snow_inputs in;
     fill_snow(&in, &np, array_forcing, 1, obstime, climdata, R_NilValue, vegp, other);
     mcf_snowm sm;
@@ -467,6 +473,7 @@ SEXP mcfhip_gridmicrosnow2(SEXP reqhgt, SEXP obstime, SEXP climdata, SEXP snowm,
 /* _microclimf_applycpp3 (src/microclimfCpp.cpp:5553-5588): (a [rows,cols,tsteps], fun_name) -> numeric(tsteps) */
 SEXP mcfhip_applycpp3(SEXP a, SEXP fun_name) {
     int np = 0;
+    g_keep = NULL; g_nkeep = 0;     /* an earlier entry may have left through Rf_error with the list still set: it is unprotected then */
     SEXP dim = getAttrib(a, R_DimSymbol);
     if (TYPEOF(dim) != INTSXP || LENGTH(dim) != 3) Rf_error("mcfhip: applycpp3 needs a 3-D array");
     const char *fn = CHAR(asChar(fun_name));
@@ -519,6 +526,7 @@ static void fill_snowdriver(mcf_snowdriver_in *din, int *np, SEXP obstime, SEXP 
 SEXP mcfhip_snowmodel1(SEXP obstime, SEXP weather, SEXP pointm, SEXP vegp, SEXP other, SEXP snowenv, SEXP dtm,
                        SEXP res, SEXP tfact) {
     int np = 0;
+    g_keep = NULL; g_nkeep = 0;     /* an earlier entry may have left through Rf_error with the list still set: it is unprotected then */
     mcf_snowdriver_in din;
     fill_snowdriver(&din, &np, obstime, weather, pointm, vegp, other, snowenv, dtm, res, tfact);
     mcf_snow_inputs *in = &din.base;
@@ -582,6 +590,7 @@ SEXP mcfhip_snowrun_create(SEXP grid, SEXP snow) {
     if (TYPEOF(grid) != VECSXP || LENGTH(grid) != 15) Rf_error("mcfhip: grid must be the list of runmicro1Cpp's fifteen arguments");
     if (TYPEOF(snow) != VECSXP || LENGTH(snow) != 9) Rf_error("mcfhip: snow must be list(obstime, weather, pointm, vegp, other, snowenv, dtm, res, tfact)");
     int np = 0;
+    g_keep = NULL; g_nkeep = 0;     /* an earlier entry may have left through Rf_error with the list still set: it is unprotected then */
     snowrun_box *b = (snowrun_box *)calloc(1, sizeof *b);
     if (!b) Rf_error("mcfhip: out of memory");
     /* prot = list(grid, snow, coerced vectors): alive as long as the external pointer */
@@ -625,6 +634,7 @@ SEXP mcfhip_snowrun_pass1(SEXP h) {
     snowrun_box *b = snowrun_of(h);
     const int nd = mcf_snowrun_days(b->run);
     int np = 0;
+    g_keep = NULL; g_nkeep = 0;     /* an earlier entry may have left through Rf_error with the list still set: it is unprotected then */
     SEXP sf = PROTECT(allocVector(INTSXP, nd)); ++np;
     SEXP nf = PROTECT(allocVector(INTSXP, nd)); ++np;
     const int rc = mcf_snowrun_pass1(b->run, NULL, INTEGER(sf), INTEGER(nf));
@@ -648,6 +658,7 @@ SEXP mcfhip_snowrun_pass1(SEXP h) {
 SEXP mcfhip_snowrun_pass2(SEXP h, SEXP obstime, SEXP weather, SEXP vegp, SEXP other, SEXP mat) {
     snowrun_box *b = snowrun_of(h);
     int np = 0;
+    g_keep = NULL; g_nkeep = 0;     /* an earlier entry may have left through Rf_error with the list still set: it is unprotected then */
     mcf_snow_inputs micro;
     const int have = obstime != R_NilValue;      /* NULL inputs: a year without a snow day */
     if (have) fill_snow(&micro, &np, 0, 1, obstime, weather, R_NilValue, vegp, other);
@@ -686,6 +697,7 @@ SEXP mcfhip_writetonc(SEXP mout, SEXP fileout, SEXP east, SEXP north, SEXP hours
     static const char *on[MCF_NOUT] = {"Tz", "tleaf", "relhum", "soilm", "windspeed", "Rdirdown", "Rdifdown", "Rlwdown",
                                        "Rswup", "Rlwup"};
     int np = 0;
+    g_keep = NULL; g_nkeep = 0;     /* an earlier entry may have left through Rf_error with the list still set: it is unprotected then */
     mcf_nc_spec sp;
     memset(&sp, 0, sizeof sp);
     const double *ptr[MCF_NOUT] = {0};

@@ -114,3 +114,49 @@ def test_bioclim_row_blocks_on_one_device_give_the_same_bits():
     p3 = runbioclim3Cpp(**c, out=out, wetq=wq, dryq=dq, hotq=hq, colq=cq, air=True, devices=[0], n_blocks=2)
     for k in w3:
         assert np.array_equal(w3[k].view(np.uint64), p3[k].view(np.uint64)), k
+
+
+@pytest.mark.parametrize("layered", [False, True])
+def test_streamed_sink_is_bit_for_bit_the_whole_series_sink(monkeypatch, layered):
+    """Round 5: mcf_runbioclim1 / 3 fold the solver's day chunks into per-cell running state (k_bioclim_acc / k_bioclim_fin)
+    instead of keeping cells x steps of output; same accumulation order on the same operands.  One-day chunks, chunks that
+    cut the quarters, the whole series in one chunk: all equal MCF_BIOCLIM_WHOLE=1 (k_bioclim on the whole series) bit for
+    bit — including the variance's second pass, which makes the soil moisture series again from the cell's constants."""
+    from microclimf_amd.api import runbioclim3Cpp
+    wq, dq, hq, cq = quarters()
+    out = [1] * 19
+    a = synthetic.workload(29, 13, T, reqhgt=0.05, variety=True, start_doy=150, na_frac=0.06)
+    if layered:
+        a = synthetic.layered(a, 14)
+        a.pop("dfsel")
+    for k in ("complete", "out"):
+        a.pop(k)
+    fn = runbioclim3Cpp if layered else runbioclim1Cpp
+    run = lambda air: fn(**a, out=out, wetq=wq, dryq=dq, hotq=hq, colq=cq, air=air)      # noqa: E731
+    monkeypatch.setenv("MCF_BIOCLIM_WHOLE", "1")
+    whole = {air: run(air) for air in (True, False)}
+    monkeypatch.delenv("MCF_BIOCLIM_WHOLE")
+    for gb in ("1e-9", "3.6e-5", "8"):                      # one day per chunk / a few (29 x 13 cells: 9.2 KB a day) / everything
+        monkeypatch.setenv("MCF_BIOCLIM_RING_GB", gb)
+        for air in (True, False):
+            got = run(air)
+            for k in whole[air]:
+                assert np.array_equal(got[k], whole[air][k], equal_nan=True), (gb, air, k)
+                fin = np.isfinite(got[k])
+                assert np.array_equal(got[k][fin].view(np.uint64), whole[air][k][fin].view(np.uint64)), (gb, air, k)
+    # a NaN forcing step: its launch runs the reference's clamp forms (k_solve F = false), so WHICH days do depends on the
+    # chunking and the last bits with it — the sink itself must still agree, NaN pattern and all
+    a["climdata"]["temp"][40] = np.nan
+    monkeypatch.setenv("MCF_BIOCLIM_RING_GB", "1e-9")
+    got = run(True)
+    monkeypatch.setenv("MCF_BIOCLIM_WHOLE", "1")
+    ref = run(True)
+    monkeypatch.delenv("MCF_BIOCLIM_WHOLE")
+    for k in ref:
+        assert np.array_equal(np.isnan(got[k]), np.isnan(ref[k])), k
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-9, atol=1e-9, err_msg=k)
+    a["climdata"]["temp"][40] = 10.0
+    # quarter lists that are not ascending take the whole-series form (accumulation order = list order)
+    monkeypatch.delenv("MCF_BIOCLIM_RING_GB")
+    rev = fn(**a, out=out, wetq=wq[::-1].copy(), dryq=dq, hotq=hq, colq=cq, air=True)
+    assert np.allclose(rev["bio8"], whole[True]["bio8"], rtol=1e-12, atol=1e-12, equal_nan=True)

@@ -110,3 +110,19 @@ def test_altitude_correction_is_fused_too(oracle, altcorrect, rows, cols, cr, cc
     compare(got, oracle.run_grid(**b, array_forcing=True))
     plain = runmicro2Cpp_coarse(*[a[k] for k in ARGS], rowpos=rp, colpos=cp)
     assert np.nanmax(np.abs(got["Tz"] - plain["Tz"])) > 0.3                  # the correction does something
+
+
+@pytest.mark.parametrize("kind", ["flipped", "zigzag"])
+def test_row_positions_that_are_not_monotone_take_the_per_lane_taps(oracle, kind, monkeypatch):
+    """the LDS-staged taps assume row positions that do not decrease down a column (a tile's wrap into the next
+    column is found where the position falls back).  A north/south-flipped coarse grid, or any other order, is valid input —
+    mcf_plan_create must route it to the per-lane taps: results equal expand-then-solve, and equal the run with the staged
+    taps switched off."""
+    a, rp, cp = synthetic.coarse_workload(64, 24, 48, 4, 3, reqhgt=0.05, variety=True, start_doy=170, na_frac=0.02)
+    rp = rp[::-1].copy() if kind == "flipped" else np.where(np.arange(64) % 2 == 0, rp, rp[::-1])
+    got = runmicro2Cpp_coarse(*[a[k] for k in ARGS], rowpos=rp, colpos=cp)
+    compare(got, oracle.run_grid(**expanded(a, rp, cp), array_forcing=True))
+    monkeypatch.setenv("MCF_NO_COARSE_LDS", "1")
+    ref = runmicro2Cpp_coarse(*[a[k] for k in ARGS], rowpos=rp, colpos=cp)
+    for k in got:
+        assert np.array_equal(got[k], ref[k], equal_nan=True), k

@@ -84,4 +84,23 @@ def test_bounded_exp_and_fast_satvap():
     for t in (np.linspace(0.01, 150, 64 * 500), np.linspace(-150, 0.0, 64 * 500), rng.uniform(-5, 5, 64 * 500)):
         want = np.where(t > 0, 0.61078 * np.exp(17.27 * t / (t + 237.3)), 0.61078 * np.exp(21.875 * t / (t + 265.5)))
         assert relerr(run(8, t), want) < 1e-14               # |a t / (t + b)| up to 28: the quotient's rounding, amplified
-        assert np.array_equal(run(8, t), run(5, t))          # same operands, same operations as the general form
+        # round 5: 0.61078 folded into the exponent, one-fma reduction — within the quotient's own rounding of the general form
+        q = np.where(t > 0, 17.27 * t / (t + 237.3), 21.875 * t / (t + 265.5))
+        assert np.max(np.abs(run(8, t) / run(5, t) - 1.0) / (1.0 + np.abs(q))) < 6e-16
+
+
+def test_short_exp_and_medium_precision_quotients():
+    """Round 5 (mcf_device.hpp): fexp_s reduces with ONE fma against the 53-bit ln2/256 — error |x| 2^-54 on top of the
+    polynomial's; frcp_m / fsqrt_m / frcp2_m stop at 46 bits (Penman-Monteith quotients, series conductances)."""
+    rng = np.random.default_rng(6)
+    x = np.concatenate([rng.uniform(-60, 60, 300000), rng.uniform(-4, 4, 300000), np.array([0.0, -0.0, 1e-300, -1e-300])])
+    got, want = run(9, x), np.exp(x)
+    assert np.max(np.abs(got / want - 1.0) / (4e-16 + 6e-17 * np.abs(x))) < 1.0
+    assert np.isnan(run(9, np.array([np.nan]))).all()
+    b = np.exp(rng.uniform(-200, 200, 300000)) * rng.choice([-1.0, 1.0], 300000)
+    assert relerr(run(10, b), 1.0 / b) < 2.0 ** -45
+    v = np.exp(rng.uniform(-600, 600, 300000))
+    assert relerr(run(11, v), np.sqrt(v)) < 2.0 ** -45
+    a1, b1 = np.exp(rng.uniform(-60, 60, 300000)), np.exp(rng.uniform(-60, 60, 300000))
+    assert relerr(run(12, a1, b1), 1.0 / a1 + 1.0 / b1) < 2.0 ** -44
+    assert relerr(run(13, a1, b1), 1.0 / a1 + 1.0 / b1) < 5e-16

@@ -13,11 +13,11 @@ ROOT = Path(__file__).resolve().parents[1]
 SRC = ROOT / "microclimf_amd" / "csrc" / "mcf_kernels.hip"
 OUT = ROOT / "tools" / "variants"
 
-P1 = '''            if (AF) pass1<F, false>(C, TR, SL, g, flags, dTmx, cy, p1, MK, cn);
-            else pass1<F, SS>(C, TL, SL, g, flags, dTmx, cy, p1, MK, cn);
+P1 = '''            if (AF) pass1<F, false>(C, TR, SL, g, flags, dTcap, cy, p1, MK, cn);
+            else pass1<F, SS>(C, TL, SL, g, flags, dTcap, cy, p1, MK, cn);
 '''
-P2 = '''            if (AF) pass2<F, false>(C, TR, SL, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2, MK, cn);
-            else pass2<F, SS>(C, TL, SL, g, flags, dTmx, cy, dtr, Rmx, need_tv, p2, MK, cn);
+P2 = '''            if (AF) pass2<F, false>(C, TR, SL, g, flags, dTcap, cy, dtr, Rmx, need_tv, p2, MK, cn);
+            else pass2<F, SS>(C, TL, SL, g, flags, dTcap, cy, dtr, Rmx, need_tv, p2, MK, cn);
 '''
 ST = '''                asm("" : "+v"(posb));
                 *(double*)((char*)ring_day + ((size_t)sel * (NT * 8)) + posb) = val;'''
