@@ -668,6 +668,8 @@ int mcf_snowplan_fetch_cells(mcf_snowplan *plan, int32_t what, const int64_t *ce
 int mcf_snowplan_keep_chunk(mcf_snowplan *plan, int32_t chunk, int64_t reserve_bytes, int32_t *kept);
 /* Would mcf_snowplan_keep_chunk keep a chunk now (a pooled set, or room for a new one beside reserve_bytes)? */
 int mcf_snowplan_can_keep(mcf_snowplan *plan, int64_t reserve_bytes, int32_t *yes);
+/* A ceiling on what mcf_snowplan_keep_chunk may ALLOCATE over the plan's lifetime (pooled sets count once); < 0: none. */
+int mcf_snowplan_set_keep_budget(mcf_snowplan *plan, int64_t bytes);
 /* Which of the five device series the following mcf_snowplan_run_chunk calls write: bit 0 Tc, 1 Tg, 2 totalSWE, 3 ground snow
  * depth, 4 snow density (default 31).  Pass 1 of the two-pass run needs only totalSWE (the day classes) and the density (the
  * mean damping depth) of a chunk that will not stay in HBM — pass 2 re-runs it —, and the five stores per cell-step are what a
@@ -740,6 +742,11 @@ int32_t mcf_snowrun_days(const mcf_snowrun *run);     /* tsteps / 24 */
  * [1] of them left out (tiles wholly under snow, mcf_plan_run_days_masked), [2] snow chunks whose series had stayed in HBM,
  * [3] snow chunks re-run from their checkpoints. */
 int mcf_snowrun_stats(const mcf_snowrun *run, int64_t stats[4]);
+/* Keep pass 1's snow chunks in device memory for pass 2, up to `bytes` in all (0: off, the default — on a fresh handle the
+ * allocation costs more than re-running the chunks).  The sets are pooled in the handle: a second period on the same handle
+ * (mcf_snowrun_pass1 again) allocates nothing and pass 2 re-runs only what did not fit.  Outputs are bit for bit the unkept
+ * run's.  Reference: none (`.runmicrosnow1`, R/internal.R:3581-3659, holds the whole series in host memory). */
+int mcf_snowrun_keep(mcf_snowrun *run, int64_t bytes);
 /* snowday / nosnowday: [mcf_snowrun_days] or NULL */
 int mcf_snowrun_pass1(mcf_snowrun *run, const mcf_snowdriver_out *smod, int32_t *snowday, int32_t *nosnowday);
 int mcf_snowrun_pass2(mcf_snowrun *run, const mcf_snow_inputs *micro, double mat, mcf_outputs *out);

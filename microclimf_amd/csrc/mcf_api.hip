@@ -861,7 +861,8 @@ int mcf_plan_run_days_masked(mcf_plan* p, int32_t day0, int32_t ndays, int32_t s
                              int64_t n_skip_tile) {
     if (!p) return fail(MCF_ERR_ARG, "null plan");
     if (skip_tile && (p->bg || p->af)) return fail(MCF_ERR_ARG, "a tile mask needs vector forcing and reqhgt >= 0");
-    if (skip_tile && n_skip_tile != (p->N + p->cpb - 1) / p->cpb) return fail(MCF_ERR_ARG, "the tile mask's length is not the plan's number of tiles");
+    if (skip_tile && n_skip_tile != (p->ntiles > 0 ? p->ntiles : (p->N + p->cpb - 1) / p->cpb))
+        return fail(MCF_ERR_ARG, "the tile mask's length is not the plan's number of tiles");
     if (slot < 0 || slot >= p->ring_slots) return fail(MCF_ERR_ARG, "slot out of range");
     if (day0 < 0 || ndays < 1 || day0 + ndays > p->ndays) return fail(MCF_ERR_ARG, "day range out of bounds");
     if (!p->bg && (slot_day0 < 0 || slot_day0 + ndays > p->ring_days)) return fail(MCF_ERR_ARG, "more days than the ring slot holds");

@@ -27,9 +27,6 @@
 #include "mcf_hostpipe.hpp"
 #include "mcf_snow_device.hpp"
 
-#ifndef MCF_MICRO_WAVES
-#define MCF_MICRO_WAVES 2   // waves per SIMD the lane-per-(cell, day) snow-microclimate kernels are built for (204 VGPRs)
-#endif
 // the ring kernel (lane per cell-hour, cell table in LDS, step record through scalar loads): 141 VGPRs without scratch at three
 // waves per SIMD, 128 + 44 B (eight spill stores and loads per hour) at four — measured 0.515 against 0.55 s per simulated year
 // of configs[4]'s share (the kernel moves ~144 B per snow cell-step: it is closer to the memory system's limit than to the
@@ -68,7 +65,7 @@ struct StepRow {
 };
 // Date part of a step for array climate (site part applied per cell).
 struct DateRow2 {
-    double sindec, cosdec, eot, hour;
+    double sindec, cosdec, cosA, sinA;     // A = 0.261799 (hour + eot / 60 - 12): the hour angle without the cell's longitude
     int32_t windex, pad;
 };
 
@@ -142,7 +139,8 @@ __global__ __launch_bounds__(256) void k_snow_dates(StepArgs a) {
     if (k >= a.tsteps) return;
     const SolDate sd = sol_date(a.year[k], a.month[k], a.day[k]);
     DateRow2 r;
-    r.sindec = sd.sindec; r.cosdec = sd.cosdec; r.eot = sd.eot; r.hour = a.hour[k];
+    const double A = 0.261799 * (a.hour[k] + sd.eot / 60.0 - 12.0);             // cpp:44, 54 without the longitude term
+    r.sindec = sd.sindec; r.cosdec = sd.cosdec; r.cosA = cos(A); r.sinA = sin(A);
     r.windex = dir_index(a.winddir[k], 45.0, 8);
     r.pad = 0;
     a.dates[k] = r;
@@ -190,7 +188,7 @@ __global__ __launch_bounds__(256, AF ? MCF_SNOW_WAVES_AF : MCF_SNOW_WAVES) void 
     const bool redist = a.tpic != nullptr;
     // (the cell's constants and the redistribution's state live in the workgroup's LDS table, lane = column: read — and the
     // two running values written — inside the step where they are used, not carried in registers)
-    __shared__ double s_cv[CV_COUNT + 5][256];
+    __shared__ double s_cv[CV_COUNT + 5 + (AF ? 4 : 0)][256];
     enum { RV_TPI = CV_COUNT, RV_ASD, RV_ASC, RV_TOT, RV_GD };
     {
         const int l = threadIdx.x;
@@ -241,10 +239,10 @@ __global__ __launch_bounds__(256, AF ? MCF_SNOW_WAVES_AF : MCF_SNOW_WAVES) void 
         s_cv[CV_SKYVIEW][l] = a.skyview[c];
         s_cv[CV_CS][l] = sk.cS; s_cv[CV_SS][l] = sk.sS; s_cv[CV_CA][l] = sk.cA; s_cv[CV_SA][l] = sk.sA; s_cv[CV_SLOPE][l] = slope;
     }
-    double sinlat = 0.0, coslat = 0.0, lon = 0.0;
-    if (AF) {
-        const double latr = a.lats[c] * kPi / 180.0;
-        sinlat = sin(latr); coslat = cos(latr); lon = a.lons[c];
+    if (AF) {     // the cell's part of the sun position: four more rows of the LDS table, read inside the step
+        const SunCell sc = sun_cell(a.lats[c], a.lons[c]);
+        const int l = threadIdx.x;
+        s_cv[RV_GD + 1][l] = sc.sinlat; s_cv[RV_GD + 2][l] = sc.coslat; s_cv[RV_GD + 3][l] = sc.cosB; s_cv[RV_GD + 4][l] = sc.sinB;
     }
     Pack s;   // cpp:4325-4332
     s.agec = a.isnowac[c];
@@ -300,11 +298,11 @@ __global__ __launch_bounds__(256, AF ? MCF_SNOW_WAVES_AF : MCF_SNOW_WAVES) void 
                 m.alb = snow_albedo(hs);
                 m.ialb = gdiv(1.0, m.alb);
                 const DateRow2 dr = dates[k];
-                SolDate sd;
-                sd.sindec = dr.sindec; sd.cosdec = dr.cosdec; sd.eot = dr.eot;
-                const SolPos sp = sol_site(sd, dr.hour, sinlat, coslat, lon);
-                const SunT sun = sun_derive(sp, false);
-                const double ha = a.hor[(int64_t)dir_index(sp.azid, 15.0, 24) * N + c];
+                SunCell sc;
+                sc.sinlat = s_cv[RV_GD + 1][li]; sc.coslat = s_cv[RV_GD + 2][li]; sc.cosB = s_cv[RV_GD + 3][li]; sc.sinB = s_cv[RV_GD + 4][li];
+                int sindex;
+                const SunT sun = sun_at_cell(dr.sindec, dr.cosdec, dr.cosA, dr.sinA, sc, sindex);
+                const double ha = a.hor[(int64_t)sindex * N + c];
                 const double ws = a.wsa[(int64_t)dr.windex * N + c];
                 pack_step(m, dy, sun, cv, ha, ws, a.sdp, a.zref, s, po);
             } else {
@@ -434,97 +432,6 @@ __global__ __launch_bounds__(256) void k_microsnow_cell(MicroArgs a) {
     }
 }
 
-template <bool AF>
-__global__ __launch_bounds__(256, MCF_MICRO_WAVES) void k_microsnow(MicroArgs a) {
-    snow::snow_tables_init();
-    // one lane per (cell, day); the day is the block's (blockIdx.y), so the step rows are wave-uniform scalar loads
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t N = a.N;
-    if (c >= N) return;
-    const int day = a.day0 + (int)blockIdx.y;
-    const double hgt = a.hgt[c];
-    if (isnan(hgt)) return;   // cpp:4988-4989
-    const int k0 = day * 24;
-    const int nh = min(24, a.tsteps - k0);
-    // snowdayan: daily mean of the ground-snow temperature; NA when the first step is NA and for the
-    // hours past the last whole day
-    double Tzd = na_real();
-    if (nh == 24 && !isnan(a.sTg[c])) {
-        double sumd = 0.0;
-        for (int h = 0; h < 24; ++h) sumd += a.sTg[c + N * (k0 + h)];
-        Tzd = sumd / 24.0;
-    }
-    const double meanD = a.meanD[c];
-    const SiteK site = site_derive(a.slope[c], a.aspect[c]);
-    const double pai = a.pai[c], paia = a.paia[c], leafd = a.leafd[c], clump = a.clump[c], ltra = a.leaft[c],
-                 leafden = a.leafden[c], svfa = a.skyview[c];
-    const double lnclump = clump > 0.0 ? glog(clump) : 0.0;
-    const double ihgt = gdiv(1.0, hgt), ileafd = gdiv(1.0, leafd), ipai = gdiv(1.0, pai);
-    const double cellv[MQ_COUNT] = {hgt, pai, paia, leafd, clump, ltra, leafden, svfa, lnclump, ihgt, ileafd, ipai};
-    double sinlat = 0.0, coslat = 0.0, lon = 0.0, mxtc;
-    int hs = 0;
-    if (AF) {
-        const double latr = a.lats[c] * kPi / 180.0;
-        sinlat = sin(latr); coslat = cos(latr); lon = a.lons[c];
-        mxtc = a.mxtc[c];
-        hs = a.hs0[c + N * day];
-    } else {
-        mxtc = *a.mxtc1;
-    }
-    for (int h = 0; h < nh; ++h) {
-        const int k = k0 + h;
-        const int64_t o = c + N * k;
-        const int64_t f = AF ? o : k;
-        if (AF && h > 0) hs = a.precip[o] > 0 ? 0 : hs + 1;
-        if (!(a.swe[o] > 0.0)) continue;   // cpp:4993
-        const double reqhgts = a.reqhgt - a.sdepg[o];
-        double v[MCF_NOUT];
-        if (reqhgts >= 0.0) {
-            SunT sun;
-            int sindex, windex;
-            double alb;
-            if (AF) {
-                const DateRow2 dr = a.dates[k];
-                SolDate sd;
-                sd.sindec = dr.sindec; sd.cosdec = dr.cosdec; sd.eot = dr.eot;
-                const SolPos sp = sol_site(sd, dr.hour, sinlat, coslat, lon);
-                sun = sun_derive(sp, false);
-                sindex = dir_index(sp.azid, 15.0, 24);
-                windex = dr.windex;
-                alb = snow_albedo(hs);
-            } else {
-                const StepRow& r = a.rows[k];
-                sun = r.s; sindex = r.sindex; windex = r.windex; alb = r.m.alb;
-            }
-            MicroIn q;
-            q.si = solar_index(sun, site, true);
-            if (isnan(q.si)) q.si = AF ? sun.cosz : sun.cz;          // cpp:5002 / 5161
-            q.shadowmask = a.hor[(int64_t)sindex * N + c] > sun.tansa ? 0 : 1;
-            q.ws = a.wsa[(int64_t)windex * N + c];
-            q.reqhgt = reqhgts; q.zref = a.zref;
-            q.tc = a.temp[f]; q.pk = a.pres[f]; q.u2 = a.windspeed[f];
-            q.Rsw = a.swdown[f]; q.Rdif = a.difrad[f]; q.Rlw = a.lwdown[f]; q.umu = a.umu[f];
-            q.cell = cellv; q.cs = 1;
-            q.Tg = a.sTg[o]; q.Tc = a.sTc[o]; q.sden = a.sden[o]; q.sdepg = a.sdepg[o];
-            q.sdepc = a.swe[o] / q.sden;
-            q.alb = alb;
-            q.ialb = AF ? gdiv(1.0, alb) : a.rows[k].m.ialb;
-            const MicroMet mm = AF ? micro_met(q.tc, a.relhum[f], q.pk, mxtc) : a.mmet[k];
-            const MicroOut m = micro_above(q, mm, sun);
-            v[0] = m.Tz; v[1] = m.tleaf; v[2] = m.rh; v[4] = m.uz; v[5] = m.Rbdown; v[6] = m.Rddown;
-            v[7] = m.Rlwdn; v[8] = m.Rdup; v[9] = m.Rlwup;
-        } else {
-            const double b = micro_below(reqhgts, meanD, a.sTg[o], Tzd, a.mat, a.hiy);
-            v[0] = b; v[1] = b; v[2] = 100.0;
-            v[4] = v[5] = v[6] = v[7] = v[8] = v[9] = 0.0;
-        }
-        v[3] = a.Smax ? a.Smax[c] : 0.0;
-#pragma unroll
-        for (int i = 0; i < MCF_NOUT; ++i)
-            if (a.out[i]) a.out[i][o] = v[i];
-    }
-}
-
 // ---- gridmicrosnow1 inside the chunk loop, device-resident (mcf_snowplan_micro_*) ---------------------------------
 // meanDsnow (cpp:4713-4737) is the mean over the WHOLE snow-day series of sqrt(2 kappa / omega); the series lives on the
 // device one chunk at a time, so a first pass over the year adds the chunk's snow days to a per-cell running sum — the
@@ -583,7 +490,9 @@ struct MicroRingArgs {
 // inside the hour loop: until round 3 a lane walked the 24 hours of its cell with all of it in registers (230 VGPRs, two
 // waves per SIMD).
 enum MicroCell : int { MC_HGT, MC_PAI, MC_PAIA, MC_LEAFD, MC_CLUMP, MC_LTRA, MC_LEAFDEN, MC_SVFA, MC_LNCLUMP, MC_IHGT, MC_ILEAFD,
-                       MC_IPAI, MC_CS, MC_SS, MC_CA, MC_SA, MC_SLOPE, MC_MEAND, MC_SMAX, MC_TZD, MC_COUNT };
+                       MC_IPAI, MC_CS, MC_SS, MC_CA, MC_SA, MC_SLOPE, MC_MEAND, MC_SMAX, MC_TZD, MC_COUNT,
+                       // array climate (k_microsnow_ring<true>): the cell's part of the sun position, its maximum temperature
+                       MC_SINLAT = MC_COUNT, MC_COSLAT, MC_COSB, MC_SINB, MC_MXTC, MC_COUNT_AF };
 static_assert((int)MC_HGT == (int)MQ_HGT && (int)MC_PAI == (int)MQ_PAI && (int)MC_PAIA == (int)MQ_PAIA && (int)MC_LEAFD == (int)MQ_LEAFD && (int)MC_CLUMP == (int)MQ_CLUMP &&
               (int)MC_LTRA == (int)MQ_LTRA && (int)MC_LEAFDEN == (int)MQ_LEAFDEN && (int)MC_SVFA == (int)MQ_SVFA && (int)MC_LNCLUMP == (int)MQ_LNCLUMP &&
               (int)MC_IHGT == (int)MQ_IHGT && (int)MC_ILEAFD == (int)MQ_ILEAFD && (int)MC_IPAI == (int)MQ_IPAI, "micro_above reads the table's first rows");
@@ -591,16 +500,27 @@ static_assert((int)MC_HGT == (int)MQ_HGT && (int)MC_PAI == (int)MQ_PAI && (int)M
 // the by-value struct a pointer carries no noalias, the ring's stores might clobber the table for all the compiler knows, and
 // every field of an hour's record — ~30 doubles — came through VECTOR loads of a uniform address into VGPR pairs.  With that
 // and the wave index declared uniform (readfirstlane) they are scalar loads into SGPRs.
-__global__ __launch_bounds__(256, MCF_MICRORING_WAVES) void k_microsnow_ring(MicroRingArgs q, const MicroStep* __restrict__ tb,
-                                                                             const int32_t* __restrict__ tb_daymap,
-                                                                             const int32_t* __restrict__ tb_nosnow) {
+// AF (round 5): array climate — gridmicrosnow2 (cpp:5058-5214).  The step's weather is the lane's own (nine [N][T] series), the
+// sun position the cell's (sun_at_cell), the albedo clock the cell's: `hs0` holds the hours since snowfall at every day start
+// (k_microsnow_cell<true>) and the day's precipitation is staged in LDS, so that a lane finds its hour's clock by walking back
+// through at most 23 LDS values instead of re-reading the series.  The table argument then carries the date rows (DateRow2).
+// The one-shot entries mcf_gridmicrosnow1 / 2 run this kernel too, over a linear [steps][cells] view of their output arrays
+// (RingView with cpb = N: ring_pos(N, cell, hour) = hour N + cell) — the lane-per-(cell, day) kernel k_microsnow<AF> (197-201
+// VGPRs, two waves per SIMD) is gone.
+template <bool AF>
+__global__ __launch_bounds__(256, AF ? 3 : MCF_MICRORING_WAVES) void k_microsnow_ring(MicroRingArgs q, const void* __restrict__ tbv,
+                                                                                      const int32_t* __restrict__ tb_daymap,
+                                                                                      const int32_t* __restrict__ tb_nosnow) {
     snow::snow_tables_init();
-    __shared__ double s_mc[MC_COUNT][64];
+    const MicroStep* __restrict__ tb = (const MicroStep*)tbv;
+    const DateRow2* __restrict__ td = (const DateRow2*)tbv;
+    __shared__ double s_mc[AF ? MC_COUNT_AF : MC_COUNT][64];
+    __shared__ double s_prec[AF ? 24 : 1][64];
     const MicroArgs& a = q.m;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t N = a.N;
     const int64_t c = (int64_t)blockIdx.x * 64 + lane;
-    const int day = (int)blockIdx.y;             // uniform: the day's rows of the step tables are scalar loads
+    const int day = a.day0 + (int)blockIdx.y;    // uniform: the day's rows of the step tables are scalar loads
     const int sub = tb_daymap[day];
     if (sub < 0) return;
     const bool keep = tb_nosnow[day] != 0;        // the solver ran this day: snow-free cell-steps keep its values
@@ -608,7 +528,16 @@ __global__ __launch_bounds__(256, MCF_MICRORING_WAVES) void k_microsnow_ring(Mic
     const bool inr = c < N;
     const int64_t cc = inr ? c : N - 1;          // lanes past the raster read the last cell and write nothing
     const int k0 = day * 24;
+    const int nh = min(24, a.tsteps - k0);       // (the one-shot entries: a last day may be short; its Tzd is NA, cpp:4700-4711)
     // ---- the workgroup-day's cell table
+    if (AF) {
+        if (wv == 0) {
+            const SunCell sc = sun_cell(a.lats[cc], a.lons[cc]);
+            s_mc[MC_SINLAT][lane] = sc.sinlat; s_mc[MC_COSLAT][lane] = sc.coslat; s_mc[MC_COSB][lane] = sc.cosB; s_mc[MC_SINB][lane] = sc.sinB;
+            s_mc[MC_MXTC][lane] = a.mxtc[cc];
+        }
+        for (int h = wv; h < nh; h += 4) s_prec[h][lane] = a.precip[cc + N * (int64_t)(sub * 24 + h)];
+    }
     if (wv == 0) {
         const double hgt = a.hgt[cc], pai = a.pai[cc], leafd = a.leafd[cc];
         s_mc[MC_HGT][lane] = hgt; s_mc[MC_PAI][lane] = pai; s_mc[MC_LEAFD][lane] = leafd;
@@ -629,7 +558,7 @@ __global__ __launch_bounds__(256, MCF_MICRORING_WAVES) void k_microsnow_ring(Mic
         // cpp:4700; a chunk sees its own days only: the first step of the day — equal unless a cell's ground-snow
         // temperature turns NA part way, which gridmodelsnow never does)
         double Tzd = NA;
-        if (!isnan(a.sTg[cc + N * k0])) {
+        if (nh == 24 && !isnan(a.sTg[cc + N * k0])) {
             double sumd = 0.0;
             for (int h = 0; h < 24; ++h) sumd += a.sTg[cc + N * (k0 + h)];
             Tzd = sumd / 24.0;
@@ -641,11 +570,12 @@ __global__ __launch_bounds__(256, MCF_MICRORING_WAVES) void k_microsnow_ring(Mic
     __syncthreads();
     if (!inr) return;
     // the cell's place in the ring: its tile's block of this day, then the solver's lane position of (cell, hour)
+    // (cpb == 0: the linear [step][cell] view of the one-shot entries' output arrays, RingView's convention)
     const int cpb = q.ring.cpb;
-    const uint32_t tile = (uint32_t)c / (uint32_t)cpb;
-    const int cell = (int)((uint32_t)c - tile * (uint32_t)cpb);
-    const int64_t blk = (int64_t)tile * q.ring.tile_stride + (int64_t)day * q.ring.day_stride;
-    for (int h = wv; h < 24; h += 4) {
+    const uint32_t tile = cpb ? (uint32_t)c / (uint32_t)cpb : 0u;
+    const int cell = cpb ? (int)((uint32_t)c - tile * (uint32_t)cpb) : 0;
+    const int64_t blk = cpb ? (int64_t)tile * q.ring.tile_stride + (int64_t)day * q.ring.day_stride : c + N * (int64_t)k0;
+    for (int h = wv; h < nh; h += 4) {
         // (an opaque lane index per hour: the table is read where a value is used, not hoisted into registers in front of the loop;
         // an opaque block offset: or the ten variables' per-lane store addresses are kept across the loop — twenty registers)
         int li = lane;
@@ -661,7 +591,7 @@ __global__ __launch_bounds__(256, MCF_MICRORING_WAVES) void k_microsnow_ring(Mic
         auto has = [&](int i) { return (held >> i) & 1u; };
         auto put = [&](int i, int hh, double v) {
             const int rank = __builtin_popcount(held & ((1u << i) - 1u));
-            q.base0[bo + rank * vs + mcf::ring_pos(cpb, cell, hh)] = v;
+            q.base0[bo + rank * vs + (cpb ? (int64_t)mcf::ring_pos(cpb, cell, hh) : N * (int64_t)hh)] = v;
         };
         auto MC = [&](int f) { return s_mc[f][li]; };
         const double hgt = MC(MC_HGT);
@@ -692,25 +622,50 @@ __global__ __launch_bounds__(256, MCF_MICRORING_WAVES) void k_microsnow_ring(Mic
         };
         double Tz, tleaf, rh;
         if (reqhgts >= 0.0) {
-            const MicroStep& r = tb[f];
-            const SunT sun = r.s;
             SiteK site;
             site.cS = MC(MC_CS); site.sS = MC(MC_SS); site.cA = MC(MC_CA); site.sA = MC(MC_SA); site.flat = MC(MC_SLOPE) == 0.0;
             MicroIn mi;
-            mi.si = solar_index(sun, site, true);
-            if (isnan(mi.si)) mi.si = sun.cz;                          // cpp:5002
-            mi.shadowmask = a.hor[(int64_t)r.sindex * N + c] > sun.tansa ? 0 : 1;
-            mi.ws = a.wsa[(int64_t)r.windex * N + c];
             mi.reqhgt = reqhgts; mi.zref = a.zref;
-            mi.tc = r.tc; mi.pk = r.pk; mi.u2 = r.u2;
-            mi.Rsw = r.rsw; mi.Rdif = r.rdif; mi.Rlw = r.rlw; mi.umu = r.umu;
             mi.cell = &s_mc[0][li]; mi.cs = 64;           // (MC_HGT .. MC_IPAI are MQ_HGT .. MQ_IPAI)
             mi.Tg = sTg; mi.Tc = a.sTc[o]; mi.sden = a.sden[o]; mi.sdepg = sdepg;
             mi.sdepc = swe / mi.sden;
-            mi.alb = r.alb; mi.ialb = r.ialb;
-            // (wind speed and the five radiation streams go into the ring where micro_above has them final)
-            const MicroOut mo = micro_above(mi, r.mm, sun, [&](int i, double val) { emit(i, val); return true; });
-            Tz = mo.Tz; tleaf = mo.tleaf; rh = mo.rh;
+            if (AF) {
+                const DateRow2 dr = td[f];
+                SunCell sc;
+                sc.sinlat = MC(MC_SINLAT); sc.coslat = MC(MC_COSLAT); sc.cosB = MC(MC_COSB); sc.sinB = MC(MC_SINB);
+                int sindex;
+                const SunT sun = sun_at_cell(dr.sindec, dr.cosdec, dr.cosA, dr.sinA, sc, sindex);
+                mi.si = solar_index(sun, site, true);
+                if (isnan(mi.si)) mi.si = sun.cosz;                        // cpp:5161
+                mi.shadowmask = a.hor[(int64_t)sindex * N + c] > sun.tansa ? 0 : 1;
+                mi.ws = a.wsa[(int64_t)dr.windex * N + c];
+                const int64_t fo = c + N * (int64_t)f;                      // the lane's step of the (subset) weather series
+                mi.tc = a.temp[fo]; mi.pk = a.pres[fo]; mi.u2 = a.windspeed[fo];
+                mi.Rsw = a.swdown[fo]; mi.Rdif = a.difrad[fo]; mi.Rlw = a.lwdown[fo]; mi.umu = a.umu[fo];
+                // the albedo clock (snowalbCpp, cpp:3733-3739): hours since the last snowfall — the day's start value, then back
+                // through the day's precipitation to the lane's hour
+                int hs = a.hs0[c + N * (int64_t)sub] + h;
+                for (int j = h; j >= 1; --j)
+                    if (s_prec[j][li] > 0) { hs = h - j; break; }
+                mi.alb = snow_albedo(hs);
+                mi.ialb = gdiv(1.0, mi.alb);
+                const MicroMet mm = micro_met(mi.tc, a.relhum[fo], mi.pk, MC(MC_MXTC));
+                const MicroOut mo = micro_above(mi, mm, sun, [&](int i, double val) { emit(i, val); return true; });
+                Tz = mo.Tz; tleaf = mo.tleaf; rh = mo.rh;
+            } else {
+                const MicroStep& r = tb[f];
+                const SunT sun = r.s;
+                mi.si = solar_index(sun, site, true);
+                if (isnan(mi.si)) mi.si = sun.cz;                          // cpp:5002
+                mi.shadowmask = a.hor[(int64_t)r.sindex * N + c] > sun.tansa ? 0 : 1;
+                mi.ws = a.wsa[(int64_t)r.windex * N + c];
+                mi.tc = r.tc; mi.pk = r.pk; mi.u2 = r.u2;
+                mi.Rsw = r.rsw; mi.Rdif = r.rdif; mi.Rlw = r.rlw; mi.umu = r.umu;
+                mi.alb = r.alb; mi.ialb = r.ialb;
+                // (wind speed and the five radiation streams go into the ring where micro_above has them final)
+                const MicroOut mo = micro_above(mi, r.mm, sun, [&](int i, double val) { emit(i, val); return true; });
+                Tz = mo.Tz; tleaf = mo.tleaf; rh = mo.rh;
+            }
         } else {
             const double b = micro_below(reqhgts, MC(MC_MEAND), sTg, MC(MC_TZD), a.mat, a.hiy);
             Tz = b; tleaf = b; rh = 100.0;
@@ -732,7 +687,7 @@ __global__ __launch_bounds__(256, MCF_MICRORING_WAVES) void k_microsnow_ring(Mic
 //     fourth was written 40 B at a time by three different waves.  Its values now meet in LDS (s_tail) and are flushed behind
 //     the day's barrier, a line per sixteen lanes.  A slot nobody produced (a snow-free cell-step of a day the solver ran as
 //     well: its value stays) holds a sentinel and is not stored.
-constexpr int kRtCells = 63, kRtWaves = 8;
+constexpr int kRtCells = 63, kRtWaves = MCF_MICRORING_WAVES == 3 ? 6 : 8;      // two workgroups per CU (56 KB of LDS each): 4 or 3 waves per SIMD
 constexpr unsigned long long kTailEmpty = 0x7FF8A5A5DEAD0001ULL;      // (a NaN payload no arithmetic produces)
 __global__ __launch_bounds__(64 * kRtWaves, MCF_MICRORING_WAVES) void k_microsnow_tiles(MicroRingArgs q, const MicroStep* __restrict__ tb,
                                                                                        const int32_t* __restrict__ tb_daymap,
@@ -1400,11 +1355,25 @@ int run_microsnow(const mcf_snow_inputs* in, const mcf_snowm* sm, double reqhgt,
         if ((rc = b.alloc((void**)&a.mxtc, N * 8))) return rc;
         if ((rc = b.alloc((void**)&a.hs0, N * (int64_t)nch * 4))) return rc;
     }
-    for (int v = 0; v < MCF_NOUT; ++v) {
-        if (!outsel[v]) continue;
-        const double* d;
-        UP(d, (const double*)micro->var[v], NT);   // in/out: starts as the no-snow solver's field
-        a.out[v] = const_cast<double*>(d);
+    // The requested outputs in ONE buffer, NT apart (in/out: each starts as the no-snow solver's field): the linear view the
+    // (cell, hour) kernel of the chunk loop writes through (k_microsnow_ring: RingView cpb = 0) — every day a snow day, every
+    // snow-free cell-step kept.
+    double* outbuf = nullptr;
+    if ((rc = b.alloc((void**)&outbuf, (int64_t)std::max(nsel, 1) * NT * 8))) return rc;
+    MicroRingArgs q;
+    memset(&q, 0, sizeof q);
+    {
+        int rank = 0;
+        for (int v = 0; v < MCF_NOUT; ++v) {
+            if (!outsel[v]) continue;
+            a.out[v] = outbuf + (int64_t)rank * NT;
+            S_TRY(hipMemcpyAsync(a.out[v], micro->var[v], (size_t)NT * 8, hipMemcpyHostToDevice, nullptr));
+            q.held |= 1u << v;
+            ++rank;
+        }
+        q.sel = q.held;
+        q.base0 = outbuf; q.vstride = NT;
+        q.ring.N = N; q.ring.cpb = 0;
     }
     const unsigned gridN = (unsigned)((N + 255) / 256);
     if (!af) {
@@ -1412,14 +1381,30 @@ int run_microsnow(const mcf_snow_inputs* in, const mcf_snowm* sm, double reqhgt,
         if ((rc = b.alloc((void**)&mm, (int64_t)T * sizeof(MicroMet)))) return rc;
         hipLaunchKernelGGL(k_micro_steps, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, nullptr, a.temp, a.relhum, a.pres, a.mxtc1, T, mm);
         a.mmet = mm;
+        MicroStep* ms;
+        if ((rc = b.alloc((void**)&ms, (int64_t)T * sizeof(MicroStep)))) return rc;
+        hipLaunchKernelGGL(k_micro_pack, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, nullptr, a.rows, a.mmet, a.temp, a.pres, a.windspeed,
+                           a.swdown, a.difrad, a.lwdown, a.umu, T, ms);
+        a.mstep = ms;
     }
     if (af) hipLaunchKernelGGL(k_microsnow_cell<true>, dim3(gridN), dim3(256), 0, nullptr, a);
     else hipLaunchKernelGGL(k_microsnow_cell<false>, dim3(gridN), dim3(256), 0, nullptr, a);
-    for (int d0 = 0; d0 < nch; d0 += 32768) {        // (cells, days): the grid's y extent is 16 bits
-        a.day0 = d0;
-        const dim3 grid(gridN, (unsigned)std::min(32768, nch - d0));
-        if (af) hipLaunchKernelGGL(k_microsnow<true>, grid, dim3(256), 0, nullptr, a);
-        else hipLaunchKernelGGL(k_microsnow<false>, grid, dim3(256), 0, nullptr, a);
+    {
+        std::vector<int32_t> ident((size_t)nch), ones((size_t)nch, 1);
+        for (int d = 0; d < nch; ++d) ident[(size_t)d] = d;
+        int32_t *d_map = nullptr, *d_one = nullptr;
+        if ((rc = b.alloc((void**)&d_map, (int64_t)nch * 4))) return rc;
+        if ((rc = b.alloc((void**)&d_one, (int64_t)nch * 4))) return rc;
+        S_TRY(hipMemcpy(d_map, ident.data(), (size_t)nch * 4, hipMemcpyHostToDevice));
+        S_TRY(hipMemcpy(d_one, ones.data(), (size_t)nch * 4, hipMemcpyHostToDevice));
+        q.daymap = d_map; q.nosnow = d_one; q.ndays = nch;
+        for (int d0 = 0; d0 < nch; d0 += 32768) {        // (cells, days): the grid's y extent is 16 bits
+            a.day0 = d0;
+            q.m = a;
+            const dim3 grid((unsigned)((N + 63) / 64), (unsigned)std::min(32768, nch - d0));
+            if (af) hipLaunchKernelGGL(k_microsnow_ring<true>, grid, dim3(256), 0, nullptr, q, (const void*)a.dates, q.daymap, q.nosnow);
+            else hipLaunchKernelGGL(k_microsnow_ring<false>, grid, dim3(256), 0, nullptr, q, a.mstep, q.daymap, q.nosnow);
+        }
     }
     S_TRY(hipGetLastError());
     Downloader dl;
@@ -1494,6 +1479,8 @@ struct mcf_snowplan {
     // mcf_snowplan_microsnow can never read last year's series for it)
     std::vector<Kept> kept;
     std::vector<Kept> pool;              // released sets, reused by the next year's pass 1 (hipMalloc of 10 GB costs 0.25 s)
+    int64_t keep_budget = -1;            // bytes of kept sets this plan may ALLOCATE in all (mcf_snowplan_set_keep_budget); -1: no limit of its own
+    int64_t keep_allocated = 0;
     Bufs kb;
     ~mcf_snowplan() { twork.release(); }
 };
@@ -2277,6 +2264,7 @@ extern "C" int mcf_snowplan_keep_chunk(mcf_snowplan* sp, int32_t ch, int64_t res
         size_t free_b = 0, total_b = 0;
         S_TRY(hipMemGetInfo(&free_b, &total_b));
         if ((int64_t)free_b < 5 * one + std::max<int64_t>(reserve_bytes, 0)) return MCF_OK;
+        if (sp->keep_budget >= 0 && sp->keep_allocated + 5 * one > sp->keep_budget) return MCF_OK;
         for (int v = 0; v < 5; ++v) {
             if (hipMalloc((void**)&fresh[v], (size_t)one) != hipSuccess) {      // (another process took the room: not an error)
                 (void)hipGetLastError();
@@ -2285,6 +2273,7 @@ extern "C" int mcf_snowplan_keep_chunk(mcf_snowplan* sp, int32_t ch, int64_t res
             }
             sp->kb.p.push_back(fresh[v]);
         }
+        sp->keep_allocated += 5 * one;
     }
     S_TRY(hipDeviceSynchronize());         // (the chunk's kernels are done before its buffers change hands)
     ModelArgs& a = sp->a;
@@ -2312,6 +2301,12 @@ extern "C" int mcf_snowplan_can_keep(mcf_snowplan* sp, int64_t reserve_bytes, in
     S_TRY(hipMemGetInfo(&free_b, &total_b));
     const int64_t one = (int64_t)sp->chunk * sp->N * 8;
     *yes = (int64_t)free_b >= 5 * one + std::max<int64_t>(reserve_bytes, 0) ? 1 : 0;
+    if (sp->keep_budget >= 0 && sp->keep_allocated + 5 * one > sp->keep_budget) *yes = 0;
+    return MCF_OK;
+}
+extern "C" int mcf_snowplan_set_keep_budget(mcf_snowplan* sp, int64_t bytes) {
+    if (!sp) return mcf::api_fail(MCF_ERR_ARG, "null snow plan");
+    sp->keep_budget = bytes;
     return MCF_OK;
 }
 extern "C" int mcf_snowplan_release_kept(mcf_snowplan* sp) {
@@ -2556,6 +2551,7 @@ extern "C" int mcf_snowplan_microsnow(mcf_snowplan* sp, mcf_plan* plan, int32_t 
     S_TRY(hipMemcpy(sp->d_daymap, sp->sub_of_day.data() + day0, (size_t)nd * 4, hipMemcpyHostToDevice));
     S_TRY(hipMemcpy(sp->d_nosnow, nosnowday, (size_t)nd * 4, hipMemcpyHostToDevice));
     q.m = sp->ma;
+    q.m.day0 = 0;
     {   // the chunk's snow series: where pass 1 left them if the chunk was kept, the plan's working buffers otherwise
         const bool k = (size_t)ch < sp->kept.size() && sp->kept[ch].Tc;
         if (!k && sp->series_valid != 31) return mcf::api_fail(MCF_ERR_STATE, "snow plan: the chunk was run with series switched off (mcf_snowplan_set_series)");
@@ -2572,7 +2568,7 @@ extern "C" int mcf_snowplan_microsnow(mcf_snowplan* sp, mcf_plan* plan, int32_t 
         hipLaunchKernelGGL(k_microsnow_tiles, dim3((unsigned)((N + kRtCells - 1) / kRtCells)), dim3(64 * kRtWaves), 0, nullptr, q,
                            (const MicroStep*)q.m.mstep, q.daymap, q.nosnow);
     else
-        hipLaunchKernelGGL(k_microsnow_ring, dim3((unsigned)((N + 63) / 64), (unsigned)nd), dim3(256), 0, nullptr, q, (const MicroStep*)q.m.mstep,
+        hipLaunchKernelGGL(k_microsnow_ring<false>, dim3((unsigned)((N + 63) / 64), (unsigned)nd), dim3(256), 0, nullptr, q, q.m.mstep,
                            q.daymap, q.nosnow);
     S_TRY(hipGetLastError());
     S_TRY(hipDeviceSynchronize());

@@ -70,7 +70,17 @@ __device__ __forceinline__ double gpow0(double b, double e) {
     // pow for all its lanes): pow(0, e > 0) = 0.  Anything else outside b > 0 (NaNs, e <= 0) still goes to libm.
     if (b > 0.0) return gexp(e * glog(b));
     if (b == 0.0 && e > 0.0) return 0.0;
-    return ::pow(b, e);
+    // What is left is outside the model's domain (a negative or NaN clumping factor, a non-positive exponent).  Round 5: C's pow
+    // semantics written out with the lean routines instead of the device libm's pow — 220 instructions and the registers of a
+    // second kernel on a path no valid input takes; inlined into the snow-microclimate kernels it cost them 44-48 B of scratch
+    // per lane, whose spill traffic was the "1.4 x write amplification" of profiles/r04_c4_aux_pmc_summary.json.
+    if (b != b || e != e) return (e == 0.0 || b == 1.0) ? 1.0 : b + e;        // pow(x, 0) = pow(1, y) = 1 even for NaN
+    if (e == 0.0) return 1.0;
+    if (b == 0.0) return __longlong_as_double(0x7FF0000000000000LL);           // pow(+-0, e < 0): +inf up to the sign of an odd integer e
+    // b < 0: defined for integer exponents only
+    if (e != __builtin_rint(e)) return __longlong_as_double(0x7FF8000000000000LL);
+    const double m = gexp(e * glog(-b));
+    return (__builtin_fmod(e, 2.0) != 0.0) ? -m : m;
 }
 
 __device__ __forceinline__ double svp(double tc) {  // cpp:480-490 satvapCpp
@@ -199,6 +209,66 @@ __device__ __forceinline__ SunT sun_derive(const SolPos& sp, bool degrees) {
     s.kx = k;
     s.kcos = k * c;
     s.tansa = degrees ? tan((90 - sp.zend) * kToRad) : tan(kPi / 2.0 - sp.zenr);
+    return s;
+}
+// Array climate: the sun at ONE CELL and step from the date part of the step (declination, the hour angle's time part A =
+// 0.261799 (hour + eot / 60 - 12), tabulated per step as cos A / sin A) and the cell's constants (sin / cos of its latitude
+// and of B = 0.261799 * 4 lon / 60, cpp:44, 54).  cpp:48-83 followed algebraically, as mcf_device.hpp derive_time_af does for
+// the solver: with coh = cos(zenith)
+//   cos(zenr) = cos(zend torad) = coh,  sin = sqrt(1 - coh^2),  tan(pi/2 - zenr) = coh / sin,  cos(hh) = sin(zenith),
+//   sin(azimuth) = -sazi,  cos(azimuth) = -+sqrt(1 - sazi^2) by the sign of cazi (cpp:65-75),
+// the 15-degree sector round(azid / 15) % 24 by comparing tangents — no inverse trigonometry, no libm call.  Round 5: until
+// then k_snowmodel<true> / k_microsnow<true> called sol_site + sun_derive per cell-step — two inverse and twelve direct libm
+// trigonometric functions, each with its large-argument reduction inlined: 168 VGPRs + 116 B of scratch in the snow model.
+// Differences to the literal evaluation are rounding-level (1e-16).  `zend` is only ever compared with 90 (solar_index):
+// 45 / 135 stand for "above / below the horizon"; zenr / azid are not read by any consumer and stay NaN.
+struct SunCell { double sinlat, coslat, cosB, sinB; };
+__device__ __forceinline__ SunCell sun_cell(double lat_deg, double lon_deg) {
+    SunCell c;
+    const double latr = lat_deg * kPi / 180.0, B = 0.261799 * (4.0 * lon_deg) / 60.0;
+    c.sinlat = sin(latr); c.coslat = cos(latr); c.cosB = cos(B); c.sinB = sin(B);
+    return c;
+}
+__device__ __forceinline__ SunT sun_at_cell(double sindec, double cosdec, double cosA, double sinA, const SunCell& c, int& sindex) {
+    SunT s;
+    const double ctt = cosA * c.cosB - sinA * c.sinB;
+    const double stt = sinA * c.cosB + cosA * c.sinB;
+    const double coh = sindec * c.sinlat + cosdec * c.coslat * ctt;            // cpp:56
+    double s2 = 1.0 - coh * coh;
+    if (s2 < 0.0) s2 = 0.0;
+    const double sz = fsqrt(s2 > 1e-300 ? s2 : 1e-300);
+    const bool up = coh >= 0.0;
+    s.zend = up ? 45.0 : 135.0;
+    s.zenr = s.azid = __longlong_as_double(0x7FF8000000000000LL);
+    s.cosz = coh; s.cz = coh; s.sz = sz;
+    s.tansa = fdiv(coh, sz);
+    const double cc = up ? coh : 6.123233995736766e-17;                        // cos(pi/2) in fp64 (cpp:106)
+    double k = 0.5 * frcp(cc);
+    if (k > 6000.0) k = 6000.0;
+    s.kx = k;
+    s.kcos = k * cc;
+    double sazi = fdiv(cosdec * stt, sz);                                       // cpp:59-61
+    const double num = c.sinlat * cosdec * ctt - c.coslat * sindec;            // sign of cazi, cpp:62-64
+    double sqt = 1.0 - sazi * sazi;
+    if (sqt < 0.0) sqt = 0.0;
+    if (sazi > 1.0) sazi = 1.0;
+    if (sazi < -1.0) sazi = -1.0;
+    const double rq = fsqrt(sqt > 1e-300 ? sqt : 1e-300);
+    s.sa = -sazi;
+    s.ca = num < 0.0 ? rq : -rq;
+    // sindex = round(azid / 15) % 24: rotate by +7.5 degrees, quadrant, tangent tests
+    const double xr = s.ca * 0.99144486137381038 - s.sa * 0.13052619222005157;
+    const double yr = s.sa * 0.99144486137381038 + s.ca * 0.13052619222005157;
+    int q;
+    double u, v;
+    if (yr >= 0.0) {
+        if (xr > 0.0) { q = 0; u = xr; v = yr; } else { q = 1; u = yr; v = -xr; }
+    } else {
+        if (xr < 0.0) { q = 2; u = -xr; v = -yr; } else { q = 3; u = -yr; v = xr; }
+    }
+    const int n = (v >= u * 0.26794919243112270) + (v >= u * 0.57735026918962573) + (v >= u) + (v >= u * 1.7320508075688772) +
+                  (v >= u * 3.7320508075688776);
+    sindex = (6 * q + n) % 24;
     return s;
 }
 struct SiteK { double cS, sS, cA, sA; bool flat; };   // slope / aspect of the cell
@@ -516,7 +586,24 @@ __device__ __forceinline__ void sincos_0pi(double x, double& sn, double& cs) {
         sn = (k == 2.0) ? -a : a;
         cs = (k == 0.0) ? b : -b;
     } else {
-        sn = sin(x); cs = cos(x);
+        // outside [0, pi]: not reachable from rh_canopy (0 < z < h) except with NaN operands, which propagate through the same
+        // reduction (round 5: the device libm's sin / cos — Payne-Hanek reduction, the registers of a second kernel — are gone
+        // from the snow-microclimate kernels); moderate arguments reduce by quadrants, anything beyond 1e9 is given up as NaN
+        const double k = __builtin_rint(x * 0x1.45f306dc9c883p-1);
+        double r = fma(-k, 0x1.921fb54400000p+0, x);
+        r = fma(-k, 0x1.0b4611a626331p-34, r);
+        if (!(fabs(x) < 1e9)) r = __longlong_as_double(0x7FF8000000000000LL);
+        const double z = r * r;
+        const double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+                          z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+        const double sr = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
+        const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                          z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+        const double hz = 0.5 * z, w = 1.0 - hz;
+        const double cr = w + (((1.0 - w) - hz) + z * pc);
+        const int q = (int)__builtin_fmod(__builtin_fmod(k, 4.0) + 4.0, 4.0);
+        sn = q == 0 ? sr : q == 1 ? cr : q == 2 ? -sr : -cr;
+        cs = q == 0 ? cr : q == 1 ? -sr : q == 2 ? -cr : sr;
     }
 }
 __device__ __forceinline__ double rh_canopy(double uf, double h, double ih, double d, double z) {  // cpp:1365-1380; ih = 1/h

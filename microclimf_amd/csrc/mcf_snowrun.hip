@@ -259,9 +259,15 @@ int check_create(const mcf_microsnow_in* in, const mcf_options* opt) {
     const mcf_snow_inputs& sb = in->snow->base;
     if (g.array_forcing || sb.array_forcing)
         return mcf::api_fail(MCF_ERR_ARG, "mcf_runmicrosnow1 takes data.frame (vector) weather; array weather goes through gridmicrosnow2");
-    if (g.veg_layers > 1)
-        return mcf::api_fail(MCF_ERR_ARG, "mcf_runmicrosnow1: time-varying vegetation layers are indexed on the day subset in the reference "
-                                          "(`.runmicronosnow` on subsetpointmodel): not supported here");
+    // Time-varying vegetation (round 5).  `.runmicronosnow` sends a layered `vegp` to `.runmodel3Cpp` on the no-snow-day SUBSET
+    // (R/internal.R:3333-3342), which deals the subset's days to layers by `.sortvegp(vegp, "C", n, subs)` — the layer a step has
+    // in the WHOLE series (round(seq(0.50001, dmx + 0.5, length.out = n))[subs], the day's mode, R/internal.R:252-270) — and
+    // renumbers the layers it uses (:1391-1399).  A no-snow day therefore runs with the layer the whole-series table gives it:
+    // the solver plan takes the caller's whole-series layer table (lyr_st / lyr_ed in whole-series steps, as mcf_runmicro3) and
+    // the days run at their own place in it.  The snow model's and gridmicrosnow1's rasters are `.sortl` / `.sortl2` means —
+    // single-layer — either way.
+    if (g.veg_layers > 1 && (!g.lyr_st || !g.lyr_ed))
+        return mcf::api_fail(MCF_ERR_ARG, "mcf_runmicrosnow1: layered vegetation needs lyr_st / lyr_ed (whole-series steps)");
     if (opt->reqhgt < 0)
         return mcf::api_fail(MCF_ERR_ARG, "mcf_runmicrosnow1: reqhgt < 0 needs the whole series at once (Tbelowgroundv); use mcf_runmicro1 + "
                                           "mcf_gridmicrosnow1 on host arrays");
@@ -382,6 +388,21 @@ extern "C" int mcf_snowrun_create(const mcf_microsnow_in* in, const mcf_options*
 
 extern "C" void mcf_snowrun_destroy(mcf_snowrun* h) { delete h; }
 
+// Pass 1's snow chunks stay in device memory for pass 2, up to `bytes` in all (shared out among the row blocks by their rows);
+// 0 switches keeping off.  The sets are allocated as pass 1 first needs them and POOLED in the handle's snow plans: a handle that
+// runs a second period (mcf_snowrun_pass1 again) allocates nothing — where allocating 10 GB costs more than re-running the chunk
+// (the struct's comment), keeping pays from the second period on, or on the first when the caller wants `smod` anyway.
+extern "C" int mcf_snowrun_keep(mcf_snowrun* h, int64_t bytes) {
+    if (!h) return mcf::api_fail(MCF_ERR_ARG, "null snow run");
+    if (bytes < 0) return mcf::api_fail(MCF_ERR_ARG, "mcf_snowrun_keep: bytes >= 0");
+    h->keep = bytes > 0;
+    for (Block& k : h->blocks) {
+        const int rc = mcf_snowplan_set_keep_budget(k.sp, bytes > 0 ? (int64_t)((double)bytes * (double)k.nr / (double)h->R) : 0);
+        if (rc) return rc;
+    }
+    return MCF_OK;
+}
+
 extern "C" int32_t mcf_snowrun_days(const mcf_snowrun* h) { return h ? h->ndays : 0; }
 extern "C" int mcf_snowrun_stats(const mcf_snowrun* h, int64_t stats[4]) {
     if (!h || !stats) return mcf::api_fail(MCF_ERR_ARG, "null argument");
@@ -422,7 +443,9 @@ extern "C" int mcf_snowrun_pass1(mcf_snowrun* h, const mcf_snowdriver_out* smod,
                     }
                 });
                 snow_chunk(h, t, ch, bar, failed, guarded, fail_here, true, smod, &smean, &tmean);
-                if (t == 0 && !failed) {
+                // (under `guarded` like every phase body: an exception here — the vectors allocate — must neither leave the thread
+                // while the others are joinable nor skip the barrier below)
+                if (t == 0) guarded([&] {
                     // extremes over the blocks (max / min skip blocks whose step held no value), then the chunk's day classes
                     std::vector<double> mx((size_t)ns, -INFINITY), mn((size_t)ns, INFINITY);
                     for (const Block& k : h->blocks)
@@ -431,7 +454,7 @@ extern "C" int mcf_snowrun_pass1(mcf_snowrun* h, const mcf_snowdriver_out* smod,
                             if (k.cmn[(size_t)q] > 0 && k.mn[(size_t)q] < mn[(size_t)q]) mn[(size_t)q] = k.mn[(size_t)q];
                         }
                     snowdays_of(mx.data(), mn.data(), cd, &h->snowday[(size_t)(ch * cd)], &h->nosnowday[(size_t)(ch * cd)]);
-                }
+                });
                 bar.wait();
                 guarded([&] {
                     bool any = false;

@@ -908,7 +908,7 @@ class SnowRun:
         g = grid
         self._gm = marshal(g["obstime"], g["climdata"], g["pointm"], g["vegp"], g["soilc"], g["reqhgt"], g["zref"], g["lat"], g["lon"],
                            g.get("Sminp", 0.0), g.get("Smaxp", 0.0), g["tfact"], g.get("complete", True), g.get("mat", 0.0),
-                           g.get("out", (1,) * 10), False, device, 0, cells_per_block)
+                           g.get("out", (1,) * 10), False, device, 0, cells_per_block, g.get("dfsel"))
         self._alloc_outputs = lambda: alloc_outputs(self._gm)
         R, Cc = np.shape(snow["vegp"]["pai"])
         oth = dict(snow["other"])
@@ -928,6 +928,11 @@ class SnowRun:
         self._in.mat = 0.0
         self.rows, self.cols, self.tsteps = R, Cc, self._sm.tsteps
         self._mm = None
+
+    def keep(self, gigabytes: float):
+        """Keep pass 1's snow chunks in device memory for pass 2, up to this much (include/mcf.h mcf_snowrun_keep; 0: off).
+        Pays from the handle's second period on — the sets are pooled — or when the snow series are fetched anyway."""
+        _abi.check(self._lib.mcf_snowrun_keep(self._p, int(gigabytes * 2 ** 30)))
 
     def stats(self) -> dict:
         """What pass 2 was spared (include/mcf.h mcf_snowrun_stats)."""

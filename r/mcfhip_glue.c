@@ -623,6 +623,11 @@ SEXP mcfhip_snowrun_create(SEXP grid, SEXP snow) {
         rc = mcf_snowrun_create(&b->in, &b->opt, NULL, &b->run);
     }
     if (rc != MCF_OK) raise_last(rc, np);      /* (the finalizer frees the box) */
+    SEXP kg = GetOption1(install("mcfhip.keep_gb"));     /* mcfhip_enable(keep_gb = ...): pass 1's chunks stay in HBM for pass 2 */
+    if (kg != R_NilValue && LENGTH(kg) > 0 && asReal(kg) > 0) {
+        rc = mcf_snowrun_keep(b->run, (int64_t)(asReal(kg) * 1073741824.0));
+        if (rc != MCF_OK) raise_last(rc, np);
+    }
     UNPROTECT(np);
     return xp;
 }

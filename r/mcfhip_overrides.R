@@ -16,11 +16,14 @@
 # `blocks`: more row blocks than devices (each device solves its blocks one after the other: smaller HBM footprint per block).
 # `snow_resident = TRUE`: runsnowmodel() + runmicro(snow = TRUE) for data.frame weather keep the year's snow series on the
 # device (see mcfhip_snow_resident below); FALSE (default): the reference's own R drivers over the replaced bindings.
-mcfhip_enable <- function(glue = "r/mcfhip_glue.so", devices = NULL, blocks = NULL, snow_resident = FALSE) {
+# `keep_gb` (with snow_resident): pass 1's snow chunks stay in device memory for pass 2, up to this many GB (mcf_snowrun_keep);
+# pays when the snow series are wanted anyway or a handle runs more than one period — 0 (default): re-run from checkpoints.
+mcfhip_enable <- function(glue = "r/mcfhip_glue.so", devices = NULL, blocks = NULL, snow_resident = FALSE, keep_gb = 0) {
   dyn.load(glue)
   if (snow_resident) mcfhip_snow_resident()
   options(mcfhip.devices = if (is.null(devices)) NULL else as.integer(devices),
-          mcfhip.blocks = if (is.null(blocks)) NULL else as.integer(blocks))
+          mcfhip.blocks = if (is.null(blocks)) NULL else as.integer(blocks),
+          mcfhip.keep_gb = as.numeric(keep_gb))
   rm1 <- function(obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, long,
                   Sminp, Smaxp, tfact, complete, mat, out)
     .Call("mcfhip_runmicro1", obstime, climdata, pointm, vegp, soilc, reqhgt, zref, lat, long,

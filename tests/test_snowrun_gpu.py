@@ -38,20 +38,26 @@ def _case(reqhgt, cold, doy, rows=22, cols=13, ndays=20):
     return sw, a, dtm, snow, micro
 
 
-def _orchestrate(a, sw, dtm, smod, sdays, ndays_, reqhgt, solve, microsnow):
-    """`.runmicrosnow1` steps (3)-(5) on host arrays: `solve(args of the day subset)`, `microsnow(...)` on the snow-day subset"""
+def _orchestrate(a, sw, dtm, smod, sdays, ndays_, reqhgt, solve, microsnow, oracle_merge=False):
+    """`.runmicrosnow1` steps (3)-(5) on host arrays: `solve(args of the day subset)`, `microsnow(...)` on the snow-day subset.
+    oracle_merge: the template and the merge by oracle/snowmerge_oracle.py (its own restatement of R/internal.R:3565-3578,
+    3625-3656) instead of the product's snow.merge_snow_outputs — the oracle-backed leg checks the product's merge with it"""
     rows, cols = dtm.shape
     ni, si = _steps(ndays_), _steps(sdays)
     outm = [1] * 10 if reqhgt > 0 else [1 if i in (0, 3, 5, 6, 7, 8, 9) else 0 for i in range(10)]
     an = dict(a, obstime=_sub(a["obstime"], ni), climdata=_sub(a["climdata"], ni), pointm=_sub(a["pointm"], ni))
     moutn = solve(an)
     micro = {}
-    s1 = np.arange(si.size)[np.repeat(np.isin(sdays, ndays_), 24)]
-    s2 = np.arange(ni.size)[np.repeat(np.isin(ndays_, sdays), 24)]
-    for k, v in moutn.items():
-        m = np.full((rows, cols, si.size), np.nan, order="F")
-        m[:, :, s1] = v[:, :, s2]
-        micro[k] = m
+    if oracle_merge:
+        from oracle import snowmerge_oracle as MO
+        micro = MO.prep_micro(moutn, sdays + 1, ndays_ + 1, rows, cols)
+    else:
+        s1 = np.arange(si.size)[np.repeat(np.isin(sdays, ndays_), 24)]
+        s2 = np.arange(ni.size)[np.repeat(np.isin(ndays_, sdays), 24)]
+        for k, v in moutn.items():
+            m = np.full((rows, cols, si.size), np.nan, order="F")
+            m[:, :, s1] = v[:, :, s2]
+            micro[k] = m
     swe = smod["totalSWE"].copy()
     swe[np.isnan(swe)] = 0.0
     swe[np.isnan(dtm)] = np.nan
@@ -60,6 +66,8 @@ def _orchestrate(a, sw, dtm, smod, sdays, ndays_, reqhgt, solve, microsnow):
     for k in moutn:
         if k not in mouts:
             mouts[k] = micro[k]
+    if oracle_merge:
+        return MO.merge(moutn, mouts, sdays + 1, ndays_ + 1, rows, cols)
     return S.merge_snow_outputs(moutn, mouts, sdays + 1, ndays_ + 1, rows, cols)
 
 
@@ -101,7 +109,7 @@ def test_one_call_equals_the_host_orchestration_and_the_oracle_backed_one(oracle
     _close(got, want, 1e-12, "host-orchestrated HIP")
     # (2) ... and with the oracle's solver and snow microclimate behind it
     want_o = _orchestrate(a, sw, dtm, smod, sdays, ndays_, reqhgt, lambda an: oracle.run_grid(**{k: an[k] for k in ARGS}),
-                          oracle.run_microsnow)
+                          oracle.run_microsnow, oracle_merge=True)
     _close(got, want_o, 1e-6, "oracle-backed orchestration")
     # every class of cell-step is in the comparison: snow-covered, snow-free on a snow day, no-snow day
     si = _steps(sdays)
@@ -149,7 +157,7 @@ def test_tiles_wholly_under_snow_are_left_out_and_nothing_changes(oracle):
     want = _orchestrate(a, sw, dtm, smod, sdays, ndays_, reqhgt, lambda an: runmicro1Cpp(*[an[k] for k in ARGS]), S.gridmicrosnow1)
     _close(got, want, 1e-12, "host-orchestrated HIP")
     want_o = _orchestrate(a, sw, dtm, smod, sdays, ndays_, reqhgt, lambda an: oracle.run_grid(**{k: an[k] for k in ARGS}),
-                          oracle.run_microsnow)
+                          oracle.run_microsnow, oracle_merge=True)
     _close(got, want_o, 1e-6, "oracle-backed orchestration")
 
 
@@ -168,3 +176,77 @@ def test_a_year_without_snow_and_bad_arguments():
     with S.SnowRun(a, snow) as run:
         with pytest.raises(Exception, match="pass1 first"):
             run.pass2(micro, MAT)
+
+
+def _subset_dfsel(layer_of_day, days0):
+    """`.runmodel3Cpp` on a day subset (R/internal.R:1391-1399): the subset's days keep the layer the whole series gives them
+    (`.sortvegp`, :252-270), consecutive days of one layer form one row of dfsel, the layers are renumbered 1.. in order —
+    st / ed are step positions IN THE SUBSET.  -> (dfsel, the whole-series layers used, in order)"""
+    lay = [int(layer_of_day[d]) for d in days0]
+    used, st, ed = [], [], []
+    for k, l in enumerate(lay):
+        if not used or used[-1] != l:
+            used.append(l); st.append(k * 24); ed.append(k * 24 + 23)
+        else:
+            ed[-1] = k * 24 + 23
+    return {"lyr": np.arange(1, len(used) + 1), "st": np.array(st), "ed": np.array(ed)}, used
+
+
+def test_time_varying_vegetation_runs_on_the_no_snow_days_with_the_whole_series_layers(oracle):
+    """Round 5: a layered `vegp` — what the reference's BUNDLED example data is — behind the one-call entry.
+    The reference solves the no-snow-day subset with runmicro3Cpp and a dfsel built on the subset (`.runmicronosnow`,
+    R/internal.R:3333-3342); held against exactly that, HIP behind it (1e-12) and the oracle behind it (1e-6, all ten outputs)."""
+    from microclimf_amd.api import runmicro3Cpp
+    reqhgt, L = 0.05, 4
+    sw, a, dtm, snow, micro = _case(reqhgt, 0.0, 90)
+    al = synthetic.layered(a, L)
+    ndays = len(a["obstime"]["year"]) // 24
+    layer_of_day = np.zeros(ndays, int)
+    for l in range(L):
+        layer_of_day[al["dfsel"]["st"][l] // 24:(al["dfsel"]["ed"][l] + 1) // 24] = l
+    got = S.runmicrosnow1(al, snow, micro, MAT)
+    with S.SnowRun(al, snow) as run:
+        sd, nd = run.pass1()
+    sdays, ndays_ = np.flatnonzero(sd), np.flatnonzero(nd)
+    assert len(set(layer_of_day[ndays_])) >= 3          # the no-snow days span several layers
+    smod = S.snowmodel1_chunks(sw["obstime"], sw["climdata"], sw["pointm"], sw["vegp"], sw["other"], sw["snowenv"], dtm, 1.0, 0.02)
+    dfs, used = _subset_dfsel(layer_of_day, ndays_)
+    veg_sub = {k: np.asfortranarray(v[:, :, used]) for k, v in al["vegp"].items()}
+
+    def solve_with(fn):
+        def solve(an):
+            an = dict(an, vegp=veg_sub)
+            return fn(dfs, an)
+        return solve
+    want = _orchestrate(a, sw, dtm, smod, sdays, ndays_, reqhgt, solve_with(lambda d, an: runmicro3Cpp(d, *[an[k] for k in ARGS])),
+                        S.gridmicrosnow1)
+    _close(got, want, 1e-12, "host-orchestrated HIP, layered")
+    want_o = _orchestrate(a, sw, dtm, smod, sdays, ndays_, reqhgt,
+                          solve_with(lambda d, an: oracle.run_grid(**{k: an[k] for k in ARGS}, dfsel=d)), oracle.run_microsnow,
+                          oracle_merge=True)
+    _close(got, want_o, 1e-6, "oracle-backed orchestration, layered")
+    # and the layers matter: the single-layer run differs
+    flat = S.runmicrosnow1(a, snow, micro, MAT)
+    assert np.nanmax(np.abs(flat["Tz"] - got["Tz"])) > 1e-3
+
+
+def test_kept_chunks_are_pooled_across_the_handles_years_and_change_no_bit(oracle):
+    """mcf_snowrun_keep (round 5): pass 1's snow chunks stay in HBM up to a byte budget, pooled in the handle — the second
+    year allocates nothing, pass 2 re-runs only what did not fit — and every output is bit for bit the unkept run's."""
+    sw, a, dtm, snow, micro = _case(0.05, 0.0, 90)
+    plain = S.runmicrosnow1(a, snow, micro, MAT)
+    one = 120 * 22 * 13 * 8 * 5                      # one chunk's five series
+    with S.SnowRun(a, snow) as run:
+        run.keep(1.2 * one / 2 ** 30)                # room for ONE set: the other snow chunks are re-run
+        for year in range(2):
+            run.pass1()
+            got = run.pass2(micro, MAT)
+            st = run.stats()
+            for k in plain:
+                assert np.array_equal(got[k], plain[k], equal_nan=True), (year, k)
+        assert st["chunks_kept"] >= 2 and st["chunks_rerun"] >= 2, st        # (counters run over both years)
+        run.keep(0)                                  # off again: everything re-run, same bits
+        run.pass1()
+        got = run.pass2(micro, MAT)
+        for k in plain:
+            assert np.array_equal(got[k], plain[k], equal_nan=True), k

@@ -329,7 +329,7 @@ def run_snow_config(args, world, rank, local_rank):
         subset given the device's snow series, merged by day.  Every rank runs the year (its exchanges are collective);
         rank 0 compares its own block."""
         import ctypes as C
-        from microclimf_amd.snow import merge_snow_outputs
+        from oracle import snowmerge_oracle as MO          # the merge's own restatement (R/internal.R:3565-3578, 3625-3656)
         hg = np.asarray(sw["vegp"]["hgt"]).ravel(order="F")
         ok_cells = np.flatnonzero(~np.isnan(hg))
         na_cells = np.flatnonzero(np.isnan(hg))[:4]
@@ -369,13 +369,8 @@ def run_snow_config(args, world, rank, local_rank):
         moutn = {k: np.asfortranarray(v[:, :, keepn]) for k, v in moutn.items()}
         # ---- gridmicrosnow1 on the snow-day subset, the device's snow series behind it
         si, ni = steps_of(sdays), steps_of(ndays_)
-        micro = {}
-        s1 = np.arange(si.size)[np.repeat(np.isin(sdays, ndays_), 24)]
-        s2 = np.arange(ni.size)[np.repeat(np.isin(ndays_, sdays), 24)]
-        for k, v in moutn.items():
-            m = np.full((K, 1, si.size), np.nan, order="F")
-            m[:, :, s1] = v[:, :, s2]
-            micro[k] = m
+        rank_of_day = np.cumsum((snowday[:nd_cov] | nosnowday[:nd_cov]).astype(np.int64)) - 1
+        micro = MO.prep_micro(moutn, rank_of_day[sdays] + 1, rank_of_day[ndays_] + 1, K, 1)
         swe = probe["smod"]["totalSWE"].copy()
         swe[np.isnan(swe)] = 0.0
         swe[np.isnan(hg[cells])] = np.nan
@@ -388,8 +383,7 @@ def run_snow_config(args, world, rank, local_rank):
                 mouts[k] = micro[k]
         # (days in neither class — a melted pack's negative rounding residue — have no place in the reference's merge, which
         # indexes by absolute hour, R/internal.R:3650-3655: the days are renumbered without them)
-        rank_of_day = np.cumsum((snowday[:nd_cov] | nosnowday[:nd_cov]).astype(np.int64)) - 1
-        want = merge_snow_outputs(moutn, mouts, rank_of_day[sdays] + 1, rank_of_day[ndays_] + 1, K, 1)
+        want = MO.merge(moutn, mouts, rank_of_day[sdays] + 1, rank_of_day[ndays_] + 1, K, 1)
         t_or = time.perf_counter() - t0
         # ---- the comparison: every day that is in a class (the reference's merge has no place for the others)
         inclass = np.repeat((snowday[:nd_cov] | nosnowday[:nd_cov]).astype(bool), 24)
@@ -451,6 +445,10 @@ def run_snow_config(args, world, rank, local_rank):
         # 5 snow series per cell-step in each of the two passes + 10 outputs per cell-step of a solver day or a snow day
         passes = 1.0 + (sp.chunks - (stats.get("chunks_skipped", 0) + stats.get("chunks_kept", 0)) / max(stats["years"], 1)) / sp.chunks
         alg = valid_all * 24 * (passes * ndays * 40.0 + (sd + snd) * 80.05) * args.steps
+        # counter bytes of the pipeline's kernels for ONE simulated year (the profiled command runs one), beside the algorithmic ones
+        import bench as B
+        ptraf, pnote = B.committed_pipeline_traffic()
+        alg_year = alg / max(args.steps, 1)
         line = {
             "metric": "cell-steps/s", "value": value, "unit": "cell-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
@@ -486,7 +484,13 @@ def run_snow_config(args, world, rank, local_rank):
             "stage_seconds": stage_s or None,
             "verified": verified,
             "roofline": {"bound": "fp64_valu", "achieved": alg / dt / 1e9, "peak": 8000.0 * world, "unit": "GB/s",
-                         "frac": alg / dt / 1e9 / (8000.0 * world), "traffic": None, "kernel": "pipeline: 2 x (k_snowmodel + terrain) + k_solve + k_microsnow_ring",
+                         "frac": alg / dt / 1e9 / (8000.0 * world), "traffic": (ptraf or {}).get("bytes_per_profiled_run"),
+                         "algorithmic_bytes_per_year": alg_year,
+                         "traffic_basis": ({**ptraf, "per": "one simulated year of one rank's block (the profiled command; k_solve's fix-up and the "
+                                                       "small reduction kernels are not in the sum)",
+                                            "ratio_to_algorithmic": ptraf["bytes_per_profiled_run"] / alg_year} if ptraf else None),
+                         "counters": pnote,
+                         "kernel": "pipeline: 2 x (k_snowmodel + terrain) + k_solve + k_microsnow_tiles",
                          "frac_is": "algorithmic bytes (40 B per snow-model cell-step of pass 1 and of the chunks pass 2 re-runs + 80 B per solver or snow-microclimate cell-step) / time / 8 TB/s per GPU"},
         }
         if cpu is not None:

@@ -18,6 +18,8 @@ ap.add_argument("--cols", type=int, default=512)
 ap.add_argument("--days", type=int, default=365)
 ap.add_argument("--out", type=str, default="Tz")
 ap.add_argument("--cold", type=float, default=0.0)
+ap.add_argument("--keep-gb", type=float, default=0.0, help="mcf_snowrun_keep: pass 1's snow chunks stay in HBM up to this much; the "
+                                                           "handle then runs a SECOND year, which finds the sets pooled")
 a = ap.parse_args()
 T = a.days * 24
 want = a.out.split(",")
@@ -45,3 +47,16 @@ valid = int(np.isfinite(dtm).sum())
 gb = sum(v.nbytes for v in got.values()) / 1e9
 print(f"{a.rows} x {a.cols} x {a.days} days, outputs {want}: {dt:.2f} s ({t1 - t:.2f} s pass 1) = {valid * T / dt:.3e} cell-steps/s, "
       f"{gb:.1f} GB into host arrays; snow days {int(sd.sum())}, no-snow days {int(nd.sum())}, {st}")
+if a.keep_gb > 0:
+    with S.SnowRun(g, snow) as run:
+        run.keep(a.keep_gb)
+        for year in (1, 2):
+            t = time.perf_counter()
+            sd, nd = run.pass1()
+            t1 = time.perf_counter()
+            got2 = run.pass2(micro, 7.5)
+            dt = time.perf_counter() - t
+            st2 = run.stats()
+            print(f"  keep {a.keep_gb:g} GB, year {year} of one handle: {dt:.2f} s ({t1 - t:.2f} s pass 1) = {valid * T / dt:.3e} cell-steps/s, {st2}")
+        same = all(np.array_equal(got[k], got2[k], equal_nan=True) for k in got)
+        print(f"  outputs bitwise the unkept run's: {same}")

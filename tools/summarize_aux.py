@@ -29,7 +29,7 @@ for d in ("pmc_sq", "pmc_misc", "pmc_fetch", "pmc_write"):
 out = {}
 for k, c in agg.items():
     if not any(s in k for s in ("k_snowmodel", "k_microsnow", "k_snow_redistribute", "k_horizon", "k_windcoef", "k_apply3_part",
-                                "k_pack", "k_tpi", "k_tiles_covered", "k_meand")):
+                                "k_pack", "k_tpi", "k_tiles_covered", "k_meand", "k_solve<", "k_apply3_minmax", "k_surface")):
         continue
     m = {n: sum(v) / len(v) for n, v in c.items()}
     e = {"launches": len(next(iter(c.values()))), "mean_ms": sum(dur[k]) / max(len(dur[k]), 1), "per_launch_mean": m}
@@ -43,6 +43,12 @@ for k, c in agg.items():
     if "SQ_INSTS_VALU" in m and "SQ_WAVES" in m:
         e["valu_insts_per_wave"] = m["SQ_INSTS_VALU"] / m["SQ_WAVES"]
     out[k.replace("(anonymous namespace)::", "")[:90]] = e
+sys.path.insert(0, str(root))
+import bench  # noqa: E402  (snow_kernel_hash(): the stamp bench.py --config 4 checks before it reports these bytes)
+wl = (src / "workload.txt").read_text().strip() if (src / "workload.txt").exists() else ""
+out["_meta"] = {"kernel_hash": bench.snow_kernel_hash(), "command": "python3 " + wl}
 (dst / f"{tag}_aux_pmc_summary.json").write_text(json.dumps(out, indent=1))
 for k, e in out.items():
+    if k == "_meta":
+        continue
     print(f"{k[:60]:60s} {e['launches']:4d} x {e['mean_ms']:8.3f} ms  VALU/wave {e.get('valu_insts_per_wave', 0):9.0f}  busy {e.get('valu_busy_fraction', 0):.2f}  HBM {e.get('hbm_TBps', 0):.2f} TB/s")

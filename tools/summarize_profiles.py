@@ -84,7 +84,8 @@ if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc and not special:
         entries = []
     entries = [e for e in entries if (e.get("rows"), e.get("cols"), e.get("ring_days")) != (rows, cols, ring_days)]
     entries.append({"rows": rows, "cols": cols, "ring_days": ring_days, "tag": tag, "kernel_hash": bench.kernel_hash(),
-                    "hbm_bytes_per_launch": fetch_b + write_b, "read_bytes": fetch_b, "write_bytes": write_b})
+                    "hbm_bytes_per_launch": fetch_b + write_b, "read_bytes": fetch_b, "write_bytes": write_b,
+                    "cell_steps_per_launch": summary["cell_steps_per_launch"]})
     tf.write_text(json.dumps({
         "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; KB -> B; FETCH_SIZE x2 (gfx950); "
                   "kernel_hash = bench.kernel_hash() of the sources the counters were taken from",
