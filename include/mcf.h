@@ -50,8 +50,9 @@
 extern "C" {
 #endif
 
-#define MCF_ABI_VERSION 5   /* 2: mcf_grid_inputs grew the coarse-forcing fields; 3: tiled output ring (mcf_plan_ring_layout);
-                             * 4: mcf_nc_spec grew format / deflate_level (zero = the behaviour of version 3); 5: mcf_runmicrosnow1 / mcf_snowrun_* */
+#define MCF_ABI_VERSION 6   /* 2: mcf_grid_inputs grew the coarse-forcing fields; 3: tiled output ring (mcf_plan_ring_layout);
+                             * 4: mcf_nc_spec grew format / deflate_level (zero = the behaviour of version 3); 5: mcf_runmicrosnow1 / mcf_snowrun_*;
+                             * 6: mcf_snowdriver_in grew af_wsa_s (the former `reserved`) / af_wind at its end — read only with array weather */
 
 /* Output variables, in the order of the reference's returned list
  * (src/microclimfCpp.cpp:2326-2335) and of its `out` logical(10). */
@@ -555,13 +556,26 @@ typedef struct mcf_snowdriver_in {
     double res;             /* cell size (m)                                              */
     double tfact;           /* .tpicalc's tfact (runsnowmodel default 0.02)               */
     int32_t chunk_steps;    /* 0 -> 120                                                   */
-    int32_t reserved;
+    /* Array weather only (base.array_forcing != 0: `.snowmodel2`'s loop, R/internal.R:2950-3008; mcf_snowmodel2 and the
+     * array-weather snow run).  af_wsa_s: the wind-shelter smoothing factor — `.snowmodel2` takes 10 only when res <= 100 AND
+     * the coarse weather grid has at least ten cells a side (:2963-2964), which the fine arrays here no longer say; 0: as
+     * `.snowmodel1` (10 if res <= 100 else 1).  af_wind: [tsteps] sqrt(wuv^2 + wvv^2) of the coarse wind components' spatial
+     * means (:2907-2908), whose chunk means set the aggregation factor of the position index (:2981-2984, at least 2). */
+    int32_t af_wsa_s;
+    const double *af_wind;
 } mcf_snowdriver_in;
 /* Returned list of .snowmodel1 (R/internal.R:2619): each [rows,cols,tsteps] or NULL. */
 typedef struct mcf_snowdriver_out {
     double *Tc, *Tg, *groundsnowdepth, *totalSWE, *snowden;
 } mcf_snowdriver_out;
 int mcf_snowmodel1(const mcf_snowdriver_in *in, mcf_snowdriver_out *out, int32_t device);
+/* The chunk loop of `.snowmodel2` (R/internal.R:2950-3008: the part behind the resampling of the coarse arrays), device-resident:
+ * `base` carries array weather at the raster's resolution — clim.{temp, relhum, pres, swdown, difrad, lwdown, windspeed, precip}
+ * and pointm.{Gp, Tc, RswabsG, RlwabsG, umu} as [rows,cols,tsteps], clim.winddir [tsteps], other.{lats, lons} [rows,cols] —
+ * what gridmodelsnow2 takes; a chunk's slices are uploaded as the loop reaches them (13 x 8 B per cell-step over PCIe: this is
+ * the boundary the reference's own binding has).  Differences to the data.frame loop kept as the reference has them: the
+ * aggregation factor from af_wind with a floor of 2, af_wsa_s.  One block (no `_multi` form yet). */
+int mcf_snowmodel2(const mcf_snowdriver_in *in, mcf_snowdriver_out *out, int32_t device);
 /* The same loop over several devices from ONE process (the companion of mcf_runmicro1_multi for BASELINE configs[4]): the
  * raster in `n_blocks` contiguous row blocks, block b a snow plan on devices[b % n_devices] driven by that device's host
  * thread; per chunk the blocks' snow surfaces meet in one host array (each block takes its halo rows from it) and the two

@@ -156,7 +156,7 @@ class PointSnowOut(C.Structure):
 
 class SnowDriverIn(C.Structure):
     _fields_ = [("base", SnowInputs), ("dtm", c_double_p), ("res", C.c_double), ("tfact", C.c_double),
-                ("chunk_steps", C.c_int32), ("reserved", C.c_int32)]
+                ("chunk_steps", C.c_int32), ("af_wsa_s", C.c_int32), ("af_wind", c_double_p)]
 
 
 SNOWDRIVER_OUT = ("Tc", "Tg", "groundsnowdepth", "totalSWE", "snowden")
@@ -188,7 +188,7 @@ EXPORTS = (
     "mcf_precompute_terrain", "mcf_precompute_terrain_multi", "mcf_runbioclim1_multi", "mcf_runbioclim2_multi",
     "mcf_runbioclim3_multi", "mcf_runbioclim4_multi", "mcf_runbioclim1", "mcf_runbioclim2", "mcf_runbioclim3", "mcf_runbioclim4",
     "mcf_snowenv_from_name", "mcf_gridmodelsnow1", "mcf_gridmodelsnow2", "mcf_gridmicrosnow1",
-    "mcf_gridmicrosnow2", "mcf_snowmodel1", "mcf_snowmodel1_multi", "mcf_applycpp3",
+    "mcf_gridmicrosnow2", "mcf_snowmodel1", "mcf_snowmodel2", "mcf_snowmodel1_multi", "mcf_applycpp3",
     "mcf_snowplan_create", "mcf_snowplan_destroy", "mcf_snowplan_chunks", "mcf_snowplan_surface", "mcf_snowplan_handover", "mcf_snowplan_apply3",
     "mcf_snowplan_surface_partial", "mcf_snowplan_prepare_chunk", "mcf_snowplan_run_chunk", "mcf_snowplan_pack_halo",
     "mcf_snowplan_prepare_chunk_dev",
@@ -199,7 +199,7 @@ EXPORTS = (
     "mcf_snowrun_pass1", "mcf_snowrun_pass2", "mcf_snowplan_run_chunk_pitched", "mcf_snowplan_chunk_af",
 )
 
-ABI_VERSION = 5     # include/mcf.h MCF_ABI_VERSION this mirror was written against
+ABI_VERSION = 6     # include/mcf.h MCF_ABI_VERSION this mirror was written against
 _lib = None
 
 
@@ -444,6 +444,8 @@ def load() -> C.CDLL:
     lib.mcf_snowplan_run_chunk.argtypes = [P, C.c_int32, C.c_double, C.POINTER(SnowDriverOut)]
     lib.mcf_snowmodel1.restype = C.c_int
     lib.mcf_snowmodel1.argtypes = [C.POINTER(SnowDriverIn), C.POINTER(SnowDriverOut), C.c_int32]
+    lib.mcf_snowmodel2.restype = C.c_int
+    lib.mcf_snowmodel2.argtypes = [C.POINTER(SnowDriverIn), C.POINTER(SnowDriverOut), C.c_int32]
     lib.mcf_snowmodel1_multi.restype = C.c_int
     lib.mcf_snowmodel1_multi.argtypes = [C.POINTER(SnowDriverIn), C.POINTER(SnowDriverOut), C.POINTER(Multi)]
     if hasattr(lib, "mcf_runmicrosnow1"):     # (absent from an older library named by MCF_LIB for an A/B run)

@@ -1427,6 +1427,12 @@ struct mcf_snowplan {
     Bufs b;
     ModelArgs a;
     const StepRow* rows_tab = nullptr;
+    // array weather (`.snowmodel2`'s loop): the caller's thirteen [N][T] series — a chunk's slices go up as the loop reaches it —
+    // and the date rows of every step
+    bool af = false;
+    const double* h_series[13] = {};      // temp, relhum, pres, swdown, difrad, lwdown, windspeed, precip, Gp, Tc, RswabsG, RlwabsG, umu
+    double* d_series[13] = {};            // [N][chunk]
+    const DateRow2* dates_tab = nullptr;
     const double *d_dtm = nullptr, *d_isnowdg = nullptr;
     double *d_isnowdc = nullptr, *d_dtms = nullptr, *d_slope = nullptr, *d_aspect = nullptr, *d_svf = nullptr,
            *d_wsa = nullptr, *d_hor = nullptr, *d_tpic = nullptr, *d_mean2 = nullptr, *d_cm = nullptr, *d_ext = nullptr,
@@ -1492,7 +1498,8 @@ int chunk_af(const mcf_snowplan* sp, int ch, int* af) {   // int:2589-2590
     double wsum = 0.0;
     for (int k = 0; k < ns; ++k) wsum += sp->wind[k0 + k];
     const double tpr = 10 * sqrt(wsum / ns);
-    const double afd = nearbyint(tpr / sp->res);          // R's round(x, 0): half to even
+    double afd = nearbyint(tpr / sp->res);                // R's round(x, 0): half to even
+    if (sp->af && !(afd >= 2.0)) afd = 2.0;               // `.snowmodel2`: `if (af < 2) af <- 2`, int:2984
     if (!(afd >= 1.0))
         return mcf::api_fail(MCF_ERR_ARG, "snow driver: aggregation factor round(10*sqrt(mean wind)/res) is 0 (terra::aggregate fails)");
     *af = (int)std::min(afd, 1e9);
@@ -1515,11 +1522,21 @@ extern "C" int mcf_snowplan_create(const mcf_snowdriver_in* din, int64_t row0, i
     if (!din || !out) return mcf::api_fail(MCF_ERR_ARG, "null snow driver argument");
     const mcf_snow_inputs* in = &din->base;
     if ((rc = common_checks(in))) return rc;
-    if (in->array_forcing) return mcf::api_fail(MCF_ERR_ARG, "the snow driver takes data.frame (vector) climate");
+    const bool af = in->array_forcing != 0;
     if (!din->dtm || !(din->res > 0)) return mcf::api_fail(MCF_ERR_ARG, "snow driver needs dtm and res > 0");
     if (!in->clim.windspeed) return mcf::api_fail(MCF_ERR_ARG, "null input: windspeed");
     if (rows_total <= 0) { rows_total = in->rows; row0 = 0; }
     if (row0 < 0 || row0 + in->rows > rows_total) return mcf::api_fail(MCF_ERR_ARG, "block outside the raster");
+    if (af) {
+        if (row0 != 0 || rows_total != in->rows) return mcf::api_fail(MCF_ERR_ARG, "snow driver, array weather: one block (the whole raster)");
+        if (!din->af_wind) return mcf::api_fail(MCF_ERR_ARG, "snow driver, array weather: af_wind (the chunk wind series) is null");
+        if (!in->other.lats || !in->other.lons || !in->clim.winddir) return mcf::api_fail(MCF_ERR_ARG, "snow driver, array weather: lats / lons / winddir");
+        const double* need[13] = {in->clim.temp, in->clim.relhum, in->clim.pres, in->clim.swdown, in->clim.difrad, in->clim.lwdown,
+                                  in->clim.windspeed, in->clim.precip, in->pointm.Gp, in->pointm.Tc, in->pointm.RswabsG,
+                                  in->pointm.RlwabsG, in->pointm.umu};
+        for (const double* q : need)
+            if (!q) return mcf::api_fail(MCF_ERR_ARG, "snow driver, array weather: a climate / point-model array is null");
+    }
     if ((rc = pick_device(device))) return rc;
     mcf_snowplan* sp = new mcf_snowplan();
     struct Guard { mcf_snowplan* p; ~Guard() { delete p; } } guard{sp};
@@ -1531,7 +1548,10 @@ extern "C" int mcf_snowplan_create(const mcf_snowdriver_in* din, int64_t row0, i
     sp->nchunks = std::max(1, sp->T / sp->chunk);   // `for (day in 1:n5days)`: 1:x truncates, and 1:0.4 still runs once
     sp->res = din->res; sp->tfact = din->tfact; sp->zref = in->other.zref;
     sp->ss = din->res <= 100 ? 10 : 1;              // int:2577-2578
-    sp->wind.assign(in->clim.windspeed, in->clim.windspeed + sp->T);
+    sp->af = af;
+    if (af && din->af_wsa_s > 0) sp->ss = din->af_wsa_s;                        // int:2963-2964
+    if (af) sp->wind.assign(din->af_wind, din->af_wind + sp->T);                // wss, int:2981
+    else sp->wind.assign(in->clim.windspeed, in->clim.windspeed + sp->T);
     const int64_t N = sp->N;
     const int T = sp->T;
     Bufs& b = sp->b;
@@ -1567,16 +1587,35 @@ extern "C" int mcf_snowplan_create(const mcf_snowdriver_in* din, int64_t row0, i
     if ((rc = b.alloc((void**)&sp->d_sumws, 2 * kSumParts * 8))) return rc;
     a.slope = sp->d_slope; a.aspect = sp->d_aspect; a.skyview = sp->d_svf; a.wsa = sp->d_wsa; a.hor = sp->d_hor;
     a.isnowdc = sp->d_isnowdc; a.isnowdg = sp->d_isnowdg; a.isnowac = sp->d_ac; a.isnowag = sp->d_ag;
-    const DateRow2* dates_unused;
+    const int64_t CN = (int64_t)sp->chunk * N;
     const double* mx_unused;
-    if ((rc = build_step_tables(b, in, false, true, true, &sp->rows_tab, &dates_unused, &mx_unused))) return rc;
-    {   // albedo per chunk (overrides the whole-series scan of build_step_tables)
+    if (af) {
+        // gridmodelsnow2 on each chunk: the date rows of every step; the cell's part of the sun position and its albedo clock
+        // (restarted at the chunk's first step, as every gridmodelsnow2 call does) are the kernel's
+        const StepRow* rows_unused;
+        if ((rc = build_step_tables(b, in, true, true, false, &rows_unused, &sp->dates_tab, &mx_unused))) return rc;
+        UP(a.lats, in->other.lats, N);
+        UP(a.lons, in->other.lons, N);
+        const double* hs[13] = {in->clim.temp, in->clim.relhum, in->clim.pres, in->clim.swdown, in->clim.difrad, in->clim.lwdown,
+                                in->clim.windspeed, in->clim.precip, in->pointm.Gp, in->pointm.Tc, in->pointm.RswabsG,
+                                in->pointm.RlwabsG, in->pointm.umu};
+        for (int f = 0; f < 13; ++f) {
+            sp->h_series[f] = hs[f];
+            if ((rc = b.alloc((void**)&sp->d_series[f], CN * 8))) return rc;
+        }
+        a.temp = sp->d_series[0]; a.relhum = sp->d_series[1]; a.pres = sp->d_series[2]; a.swdown = sp->d_series[3];
+        a.difrad = sp->d_series[4]; a.lwdown = sp->d_series[5]; a.windspeed = sp->d_series[6]; a.precip = sp->d_series[7];
+        a.Gp = sp->d_series[8]; a.Tcp = sp->d_series[9]; a.RswabsG = sp->d_series[10]; a.RlwabsG = sp->d_series[11];
+        a.umu = sp->d_series[12];
+    } else {
+        const DateRow2* dates_unused;
+        if ((rc = build_step_tables(b, in, false, true, true, &sp->rows_tab, &dates_unused, &mx_unused))) return rc;
+        // albedo per chunk (overrides the whole-series scan of build_step_tables)
         const double* d_prec;
         UP(d_prec, in->clim.precip, T);
         hipLaunchKernelGGL(k_snow_alb_chunks, dim3((unsigned)((sp->nchunks + 63) / 64)), dim3(64), 0, nullptr,
                            const_cast<StepRow*>(sp->rows_tab), d_prec, T, sp->chunk, sp->nchunks);
     }
-    const int64_t CN = (int64_t)sp->chunk * N;
     if ((rc = b.alloc((void**)&a.Tc, CN * 8))) return rc;
     if ((rc = b.alloc((void**)&a.Tg, CN * 8))) return rc;
     if ((rc = b.alloc((void**)&a.sdepc, CN * 8))) return rc;
@@ -1830,8 +1869,12 @@ static int run_chunk_to(mcf_snowplan* sp, int32_t ch, double tpic_mean, const mc
     Events evs;
     if (timing) { S_TRY(evs.make(2)); S_TRY(hipEventRecord(evs.e[0], nullptr)); }
     ModelArgs a = sp->a;
-    a.rows = sp->rows_tab + k0;            // gridmodelsnow1 on the chunk (int:2587)
+    a.rows = sp->af ? nullptr : sp->rows_tab + k0;            // gridmodelsnow1 on the chunk (int:2587)
+    a.dates = sp->af ? sp->dates_tab + k0 : nullptr;          // gridmodelsnow2 (int:2979)
     a.tsteps = ns;
+    if (sp->af)                                               // the chunk's slices of the caller's series: [N][T], a step's raster contiguous
+        for (int f = 0; f < 13; ++f)
+            S_TRY(hipMemcpyAsync(sp->d_series[f], sp->h_series[f] + (int64_t)k0 * N, (size_t)ns * N * 8, hipMemcpyHostToDevice, nullptr));
     // ... with the redistribution by the topographic position index and the hand-over fused in (ModelArgs)
     a.tpic = sp->d_tpic; a.tpimean = tpic_mean; a.dtm = sp->d_dtm;
     a.isnowdc_out = sp->d_isnowdc; a.dtms = sp->d_dtms; a.isnowac_out = sp->d_ac; a.isnowag_out = sp->d_ag;
@@ -1847,7 +1890,8 @@ static int run_chunk_to(mcf_snowplan* sp, int32_t ch, double tpic_mean, const mc
         if (!(m & 16u)) a.sden = nullptr;
         sp->series_valid = m;
     }
-    hipLaunchKernelGGL(k_snowmodel<false>, dim3(gridN), dim3(256), 0, nullptr, a, a.rows, a.dates);
+    if (sp->af) hipLaunchKernelGGL(k_snowmodel<true>, dim3(gridN), dim3(256), 0, nullptr, a, a.rows, a.dates);
+    else hipLaunchKernelGGL(k_snowmodel<false>, dim3(gridN), dim3(256), 0, nullptr, a, a.rows, a.dates);
     S_TRY(hipGetLastError());
     if (timing) {
         S_TRY(hipEventRecord(evs.e[1], nullptr));
@@ -1876,7 +1920,16 @@ static int run_chunk_to(mcf_snowplan* sp, int32_t ch, double tpic_mean, const mc
     return MCF_OK;
 }
 
+static int snowmodel_loop(const mcf_snowdriver_in* in, mcf_snowdriver_out* out, int32_t device);
 extern "C" int mcf_snowmodel1(const mcf_snowdriver_in* in, mcf_snowdriver_out* out, int32_t device) {
+    if (in && in->base.array_forcing) return mcf::api_fail(MCF_ERR_ARG, "mcf_snowmodel1 takes data.frame (vector) climate; array weather: mcf_snowmodel2");
+    return snowmodel_loop(in, out, device);
+}
+extern "C" int mcf_snowmodel2(const mcf_snowdriver_in* in, mcf_snowdriver_out* out, int32_t device) {
+    if (in && !in->base.array_forcing) return mcf::api_fail(MCF_ERR_ARG, "mcf_snowmodel2 takes array weather; data.frame climate: mcf_snowmodel1");
+    return snowmodel_loop(in, out, device);
+}
+static int snowmodel_loop(const mcf_snowdriver_in* in, mcf_snowdriver_out* out, int32_t device) {
     if (!out) return mcf::api_fail(MCF_ERR_ARG, "null snow driver argument");
     mcf_snowplan* sp = nullptr;
     int rc = mcf_snowplan_create(in, 0, 0, device, &sp);

@@ -232,6 +232,42 @@ def snowmodel1_chunks(obstime, climdata, pointm, vegp, other, snowenv, dtm, res,
     return arrays
 
 
+def _driver_in_array(obstime, climdata, pointm, vegp, other, snowenv, dtm, res, tfact, af_wind, wsa_s, chunk_steps):
+    """mcf_snowdriver_in for array weather at the raster's resolution (include/mcf.h mcf_snowmodel2)"""
+    R, Cc = np.shape(vegp["pai"])
+    oth = dict(other)
+    for k, shp in (("slope", (R, Cc)), ("aspect", (R, Cc)), ("skyview", (R, Cc)), ("wsa", (R, Cc, 8)), ("hor", (R, Cc, 24))):
+        oth.setdefault(k, np.zeros(shp))          # recomputed on the device every chunk
+    m = marshal_snow(obstime, climdata, vegp, oth, True, pointm=pointm, snowenv=snowenv)
+    din = _abi.SnowDriverIn()
+    din.base = m.inputs
+    din.dtm = m.f64(dtm, (R, Cc), "dtm")
+    din.res, din.tfact, din.chunk_steps = float(res), float(tfact), int(chunk_steps)
+    din.af_wsa_s = int(wsa_s)
+    din.af_wind = m.f64(af_wind, (m.tsteps,), "af_wind")
+    return m, din
+
+
+def snowmodel2_device(obstime, climdata, pointm, vegp, other, snowenv, dtm, res, tfact=0.02, *, af_wind, wsa_s: int = 0,
+                      chunk_steps: int = 120, device: int = 0) -> dict:
+    """The chunk loop of `.snowmodel2` (R/internal.R:2950-3008) resident on the device, given what the loop works with: the
+    climate and snow point-model arrays ALREADY at the raster's resolution ([rows, cols, T]; `climdata$winddir` [T]),
+    `other` = zref, lats, lons and the initial depths / ages, `af_wind` = sqrt(wuv^2 + wvv^2) per step (the coarse wind
+    components' spatial means, :2907-2908), `wsa_s` the wind-shelter factor (:2963-2964; 0: from res).  A chunk's slices are
+    uploaded as the loop reaches them.  Returns `.snowmodel2`'s list minus umu (include/mcf.h mcf_snowmodel2)."""
+    lib = _abi.load()
+    m, din = _driver_in_array(obstime, climdata, pointm, vegp, other, snowenv, dtm, res, tfact, af_wind, wsa_s, chunk_steps)
+    R, Cc = m.rows, m.cols
+    out = _abi.SnowDriverOut()
+    arrays = {}
+    for f in _abi.SNOWDRIVER_OUT:
+        a = np.empty((R, Cc, m.tsteps), dtype=np.float64, order="F")
+        arrays[f] = a
+        setattr(out, f, a.ctypes.data_as(_abi.c_double_p))
+    _abi.check(lib.mcf_snowmodel2(C.byref(din), C.byref(out), device))
+    return arrays
+
+
 def canintfrac(hgt, pai, uf: float, prec: float, tc: float, Li: float = 0.0) -> np.ndarray:
     """`canintfrac` (src/microclimfCpp.cpp:5417-5450): the canopy's share of a snowfall of `prec` mm per cell (host code)"""
     lib = _abi.load()
