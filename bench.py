@@ -183,6 +183,8 @@ def cpu_baseline_all_cores(args):
 # helpers
 # ----------------------------------------------------------------------------------------------------------------
 def kernel_hash() -> str:
+    if os.environ.get("MCF_KERNEL_HASH"):          # (tools/summarize_*.py: the stamp of the tree a profile was TAKEN from, recorded when
+        return os.environ["MCF_KERNEL_HASH"]       # the call was launched, if the tree has moved on by the time it is summarised)
     h = hashlib.sha256()
     for rel in KERNEL_SOURCES:
         h.update((ROOT / rel).read_bytes())
@@ -195,6 +197,8 @@ SNOW_KERNEL_SOURCES = KERNEL_SOURCES + ("microclimf_amd/csrc/mcf_snow.hip", "mic
 
 def snow_kernel_hash():
     """... of everything the configs[4] pipeline launches (solver, snow model, snow-day microclimate, terrain refresh)"""
+    if os.environ.get("MCF_SNOW_KERNEL_HASH"):
+        return os.environ["MCF_SNOW_KERNEL_HASH"]
     h = hashlib.sha256()
     for rel in SNOW_KERNEL_SOURCES:
         h.update((ROOT / rel).read_bytes())

@@ -256,6 +256,10 @@ int mcf_plan_run_days_masked(mcf_plan *plan, int32_t day0, int32_t ndays, int32_
  * Penman-Monteith temperature excess, cpp:1236).  The snow branch solves a SUBSET of the days and the reference takes
  * the maximum over that subset. */
 int mcf_plan_set_mxtc(mcf_plan *plan, double mxtc);
+/* Array forcing (at the raster's resolution): the same per CELL (src/microclimfCpp.cpp:2467-2471) over the days with
+ * dayflag[d] != 0 — the temperature series of `in` streamed once more, a run of flagged days at a time.  Also since this
+ * version: mcf_plan_run_days_at accepts a run of days INSIDE the days a slot's forcing was uploaded for, with array forcing. */
+int mcf_plan_set_mxtc_days(mcf_plan *plan, const mcf_grid_inputs *in, const int32_t *dayflag, int32_t ndays);
 /* reqhgt<0: after every day has been solved into slot 0, smooth the stored
  * ground-temperature series into Tz (Tbelowgroundv, cpp:1474-1539). */
 int mcf_plan_belowground(mcf_plan *plan);
@@ -717,7 +721,9 @@ int mcf_snowplan_microsnow(mcf_snowplan *plan, mcf_plan *solver, int32_t chunk, 
  * the merged [rows, cols, tsteps] outputs — and the snow series too, if `smod` asks for them — cross PCIe.  An R session
  * reaches it through r/mcfhip_overrides.R (runsnowmodel returns a light handle instead of the arrays, `.runmicrosnow1` passes
  * it on).
- *   grid    what `.runmicronosnow` -> runmicro1Cpp would get for EVERY day of the series (vector forcing; static vegetation)
+ *   grid    what `.runmicronosnow` -> runmicro1Cpp would get for EVERY day of the series (vector forcing); with time-varying
+ *           vegetation (veg_layers > 1: runmicro3Cpp) the WHOLE-series layer table — a no-snow day runs with the layer it has
+ *           in the whole series, which is what `.runmodel3Cpp` on the day subset comes to (R/internal.R:252-270, 1391-1399)
  *   snow    `.snowmodel1`'s inputs as for mcf_snowmodel1 (obstime / climate / pointmodelsnow output for the whole series, the
  *           `.sortl` vegetation, initial depths and ages, dtm, res, tfact)
  *   micro   gridmicrosnow1's inputs as `.prepsnowinputs1` (R/internal.R:3375-3443) makes them, but for the WHOLE series
@@ -740,6 +746,17 @@ typedef struct mcf_microsnow_in {
     double mat;
 } mcf_microsnow_in;
 int mcf_runmicrosnow1(const mcf_microsnow_in *in, const mcf_options *opt, mcf_outputs *out, const mcf_snowdriver_out *smod);
+/* The same run with ARRAY weather: `.snowmodel2`'s loop (R/internal.R:2950-3008) + `.runmicrosnow2` (:3661-3745).  Everything is
+ * at the raster's resolution, as the reference's bindings take it after `.cca` / resample:
+ *   grid    runmicro2Cpp's arguments for every day (array_forcing = 1: climate and point-model arrays [rows,cols,tsteps], lats / lons)
+ *   snow    mcf_snowmodel2's input (gridmodelsnow2's arrays, af_wind, af_wsa_s)
+ *   micro   gridmicrosnow2's inputs for the WHOLE series (array_forcing = 1: weather arrays incl. umu, winddir [tsteps], lats / lons)
+ *   mat     the point models' mean annual temperature (`matemp`, :3682-3687)
+ * A chunk's slices of the snow model's arrays, its no-snow days of the solver's fifteen and its snow days of the microclimate's nine
+ * are uploaded as the loops reach them (the boundary is PCIe-bound by construction: 8 B x 13 / 15 / 9 per cell-step); the solver's
+ * per-cell temperature cap is taken over the no-snow days (mcf_plan_set_mxtc_days), the microclimate's over the snow days.  One
+ * block on one device (no _multi form); the staged entries below take either geometry. */
+int mcf_runmicrosnow2(const mcf_microsnow_in *in, const mcf_options *opt, mcf_outputs *out, const mcf_snowdriver_out *smod);
 /* The same over row blocks on several devices from one process (mcf_multi as for mcf_runmicro1_multi; equal-row blocks as
  * mcf_snowmodel1_multi): per chunk the blocks' snow surfaces meet in one host array, the raster-wide means (snow surface, tpi,
  * the solver's twi mean) and the per-step extremes of totalSWE are combined in block order.  One block: bit for bit

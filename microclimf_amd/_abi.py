@@ -181,7 +181,7 @@ EXPORTS = (
     "mcf_plan_ring_layout", "mcf_ring_index", "mcf_plan_run_days_at", "mcf_plan_run_days_masked", "mcf_plan_set_mxtc",
     "mcf_snowplan_covered_tiles",
     "mcf_runmicro1_multi", "mcf_runmicro2_multi", "mcf_runmicro3_multi", "mcf_runmicro4_multi", "mcf_plan_fetch_pitched",
-    "mcf_snowplan_reset", "mcf_snowplan_checkpoint", "mcf_snowplan_restore", "mcf_snowplan_fetch_cells", "mcf_snowplan_keep_chunk", "mcf_snowplan_can_keep", "mcf_snowplan_set_keep_budget", "mcf_snowplan_set_series",
+    "mcf_snowplan_reset", "mcf_snowplan_checkpoint", "mcf_snowplan_restore", "mcf_snowplan_fetch_cells", "mcf_snowplan_keep_chunk", "mcf_snowplan_can_keep", "mcf_snowplan_set_keep_budget", "mcf_plan_set_mxtc_days", "mcf_snowplan_set_series",
     "mcf_snowplan_release_kept", "mcf_snowplan_meand_accumulate", "mcf_snowplan_micro_setup", "mcf_snowplan_microsnow",
     "mcf_plan_timer_start", "mcf_plan_timer_stop", "mcf_plan_kernel_timing",
     "mcf_plan_kernel_stats", "mcf_plan_dispatch_stats", "mcf_plan_valid_cells", "mcf_plan_bytes", "mcf_selftest_math",
@@ -195,7 +195,7 @@ EXPORTS = (
     "mcf_bigleaf", "mcf_soilm", "mcf_pointmprocess", "mcf_weatherhgt", "mcf_man", "mcf_pointmodelsnow", "mcf_canintfrac", "mcf_meltmu", "mcf_meltmu2", "mcf_tpicalc",
     "mcf_nc_create", "mcf_nc_write_host", "mcf_nc_write_plan", "mcf_nc_close",
     "mcf_flowacc", "mcf_topidx",
-    "mcf_runmicrosnow1", "mcf_runmicrosnow1_multi", "mcf_snowrun_create", "mcf_snowrun_destroy", "mcf_snowrun_days", "mcf_snowrun_stats", "mcf_snowrun_keep",
+    "mcf_runmicrosnow1", "mcf_runmicrosnow2", "mcf_runmicrosnow1_multi", "mcf_snowrun_create", "mcf_snowrun_destroy", "mcf_snowrun_days", "mcf_snowrun_stats", "mcf_snowrun_keep",
     "mcf_snowrun_pass1", "mcf_snowrun_pass2", "mcf_snowplan_run_chunk_pitched", "mcf_snowplan_chunk_af",
 )
 
@@ -452,6 +452,10 @@ def load() -> C.CDLL:
         MI, SO = C.POINTER(MicrosnowIn), C.POINTER(SnowDriverOut)
         lib.mcf_runmicrosnow1.restype = C.c_int
         lib.mcf_runmicrosnow1.argtypes = [MI, OP, OU, SO]
+        lib.mcf_runmicrosnow2.restype = C.c_int
+        lib.mcf_runmicrosnow2.argtypes = [MI, OP, OU, SO]
+        lib.mcf_plan_set_mxtc_days.restype = C.c_int
+        lib.mcf_plan_set_mxtc_days.argtypes = [P, C.POINTER(GridInputs), c_int32_p, C.c_int32]
         lib.mcf_runmicrosnow1_multi.restype = C.c_int
         lib.mcf_runmicrosnow1_multi.argtypes = [MI, OP, C.POINTER(Multi), OU, SO]
         lib.mcf_snowrun_create.restype = C.c_int

@@ -806,6 +806,28 @@ int mcf_plan_set_mxtc(mcf_plan* p, double mxtc) {
     return MCF_OK;
 }
 
+// array forcing: the per-cell maximum air temperature (src/microclimfCpp.cpp:2467-2471) over the days with dayflag != 0 only — what
+// runmicro2Cpp computes when `.runmicronosnow` hands it the no-snow-day SUBSET (R/internal.R:3689); streamed through the plan's
+// forcing stage, a run of consecutive flagged days at a time
+int mcf_plan_set_mxtc_days(mcf_plan* p, const mcf_grid_inputs* in, const int32_t* dayflag, int32_t ndays) {
+    if (!p || !in || !dayflag) return fail(MCF_ERR_ARG, "null argument");
+    if (!p->af || p->coarse) return fail(MCF_ERR_STATE, "mcf_plan_set_mxtc_days: a plan with (fine) array forcing");
+    if (ndays < 0 || ndays > p->ndays) return fail(MCF_ERR_ARG, "day range out of bounds");
+    if (!in->clim.tc) return fail(MCF_ERR_ARG, "missing forcing array: tc");
+    HIP_TRY(hipSetDevice(p->device));
+    mcf::launch_fill(p->d_mxtc, p->N, -273.15, p->stream);
+    for (int d = 0; d < ndays;) {
+        if (!dayflag[d]) { ++d; continue; }
+        int e = d;
+        while (e < ndays && dayflag[e] && e - d < p->ring_days) ++e;
+        HIP_TRY(copy_in(p, p->d_force_stage, in->clim.tc + p->pitch * p->cols * (int64_t)d * 24, p->cols * (int64_t)(e - d) * 24));
+        mcf::launch_mxtc((const double*)p->d_force_stage, p->N, (e - d) * 24, p->d_mxtc, p->stream);
+        HIP_TRY(hipGetLastError());
+        d = e;
+    }
+    return MCF_OK;
+}
+
 int mcf_plan_twi_partial(mcf_plan* p, double* sum, int64_t* count) {
     if (!p || !sum || !count) return fail(MCF_ERR_ARG, "null argument");
     *sum = p->twi_sum;
@@ -866,7 +888,7 @@ int mcf_plan_run_days_masked(mcf_plan* p, int32_t day0, int32_t ndays, int32_t s
     if (slot < 0 || slot >= p->ring_slots) return fail(MCF_ERR_ARG, "slot out of range");
     if (day0 < 0 || ndays < 1 || day0 + ndays > p->ndays) return fail(MCF_ERR_ARG, "day range out of bounds");
     if (!p->bg && (slot_day0 < 0 || slot_day0 + ndays > p->ring_days)) return fail(MCF_ERR_ARG, "more days than the ring slot holds");
-    if (slot_day0 != 0 && (p->bg || p->af)) return fail(MCF_ERR_ARG, "a day offset inside the slot needs vector forcing and reqhgt >= 0");
+    if (slot_day0 != 0 && p->bg) return fail(MCF_ERR_ARG, "a day offset inside the slot needs reqhgt >= 0");
     HIP_TRY(hipSetDevice(p->device));
     int rc = ensure_cells(p);
     if (rc) return rc;
@@ -882,9 +904,11 @@ int mcf_plan_run_days_masked(mcf_plan* p, int32_t day0, int32_t ndays, int32_t s
         a.altcorrect = p->altcorrect;
         a.dt = p->d_dt; a.windex = p->d_windex; a.mxtc = p->d_mxtc;
     } else if (p->af) {
-        if (p->force_day0[slot] != day0 || p->force_ndays[slot] < ndays)
+        // (the days may be a run INSIDE what the slot's forcing holds — the snow run solves a chunk's no-snow days at their own
+        // place: the kernel counts forcing days from its first day, so the base is moved to that day's block)
+        if (p->force_day0[slot] > day0 || p->force_day0[slot] + p->force_ndays[slot] < day0 + ndays)
             return fail(MCF_ERR_STATE, "forcing for these days has not been uploaded to this slot");
-        a.af_base = p->d_force + (int64_t)slot * p->force_slot_elems;
+        a.af_base = p->d_force + (int64_t)slot * p->force_slot_elems + (int64_t)(day0 - p->force_day0[slot]) * p->force_day_stride;
         a.af_tile_stride = p->force_tile_stride; a.af_day_stride = p->force_day_stride;
         a.dt = p->d_dt; a.windex = p->d_windex; a.mxtc = p->d_mxtc;
     }

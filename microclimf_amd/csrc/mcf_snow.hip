@@ -432,6 +432,29 @@ __global__ __launch_bounds__(256) void k_microsnow_cell(MicroArgs a) {
     }
 }
 
+// Array climate, streamed (mcf_snowplan_micro_setup with array weather): the two per-cell scans of k_microsnow_cell<true> — the
+// maximum air temperature and the albedo clock at every day start over the snow-day SUBSET series (cpp:5139-5145, 3733-3739) —
+// a run of consecutive subset days at a time, the state (mx, hs) carried in memory between the runs; same walk, same values.
+__global__ __launch_bounds__(256) void k_micro_scan(const double* __restrict__ temp, const double* __restrict__ precip, int64_t N, int sub0,
+                                                    int ndays, const double* __restrict__ hgt, double* __restrict__ mxtc,
+                                                    int32_t* __restrict__ hs_state, int32_t* __restrict__ hs0) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    if (isnan(hgt[c])) return;
+    double mx = sub0 == 0 ? -273.15 : mxtc[c];
+    int hs = sub0 == 0 ? 0 : hs_state[c];
+    for (int d = 0; d < ndays; ++d)
+        for (int h = 0; h < 24; ++h) {
+            const int64_t q = c + N * (int64_t)(d * 24 + h);
+            const double t = temp[q];
+            if (t > mx) mx = t;
+            if (sub0 + d > 0 || h > 0) hs = precip[q] > 0 ? 0 : hs + 1;
+            if (h == 0) hs0[c + N * (int64_t)(sub0 + d)] = hs;
+        }
+    mxtc[c] = mx;
+    hs_state[c] = hs;
+}
+
 // ---- gridmicrosnow1 inside the chunk loop, device-resident (mcf_snowplan_micro_*) ---------------------------------
 // meanDsnow (cpp:4713-4737) is the mean over the WHOLE snow-day series of sqrt(2 kappa / omega); the series lives on the
 // device one chunk at a time, so a first pass over the year adds the chunk's snow days to a per-cell running sum — the
@@ -1467,6 +1490,11 @@ struct mcf_snowplan {
     Bufs mb, mbs;                        // the micro set-up's buffers: per-call (series) and static (vegetation, terrain)
     bool micro_static = false;
     MicroArgs ma;
+    // array weather: the caller's whole-series [N][T] arrays of gridmicrosnow2's weather (temp, relhum, pres, swdown, difrad, lwdown,
+    // windspeed, precip, umu) — a chunk's snow days go up when the chunk's microclimate runs — and their device slabs [N][chunk]
+    bool micro_af = false;
+    const double* h_micro[9] = {};
+    double* d_micro[9] = {};
     int32_t outsel[MCF_NOUT] = {};
     std::vector<int32_t> sub_of_day;     // absolute day -> day of the snow-day subset series, or -1
     int32_t *d_daymap = nullptr, *d_nosnow = nullptr;     // [chunk days]
@@ -2432,9 +2460,14 @@ extern "C" int mcf_snowplan_micro_setup(mcf_snowplan* sp, const mcf_snow_inputs*
     if (!sp || !sub || !sub_of_day || !outsel) return mcf::api_fail(MCF_ERR_ARG, "null argument");
     int rc;
     if ((rc = common_checks(sub))) return rc;
-    if (sub->array_forcing) return mcf::api_fail(MCF_ERR_ARG, "the snow plan takes data.frame (vector) climate");
+    // Array weather (gridmicrosnow2, cpp:5058-5214): `sub` then carries the WHOLE series — obstime [T], clim.* as [rows,cols,T],
+    // clim.winddir [T], other.lats / lons — and sub_of_day says which of its days form the snow-day subset series (subsetting
+    // nine arrays on the host would copy them; here a chunk's snow days are uploaded when the chunk's microclimate runs).
+    const bool maf = sub->array_forcing != 0;
+    if (maf != sp->af) return mcf::api_fail(MCF_ERR_ARG, "micro set-up: the weather's geometry (data.frame / array) is not the snow plan's");
     if (sub->rows != sp->rows || sub->cols != sp->cols) return mcf::api_fail(MCF_ERR_ARG, "micro set-up: the raster is not the plan's");
     if (ndays * 24 > sp->T) return mcf::api_fail(MCF_ERR_ARG, "micro set-up: more days than the series");
+    if (maf && sub->tsteps != sp->T) return mcf::api_fail(MCF_ERR_ARG, "micro set-up, array weather: the whole series is expected");
     if (outsel[MCF_OUT_SOILM] && !sub->other.Smax) return mcf::api_fail(MCF_ERR_ARG, "soilm requested but other$Smax is null");
     S_TRY(hipSetDevice(sp->device));
     sp->mb.release_all();
@@ -2445,15 +2478,26 @@ extern "C" int mcf_snowplan_micro_setup(mcf_snowplan* sp, const mcf_snow_inputs*
     const MicroArgs prev = sp->ma;
     if (!keep_static) { sp->mbs.release_all(); sp->micro_static = false; }
     const int64_t N = sp->N;
-    const int T = (int)sub->tsteps;
+    int nsub = 0;
+    for (int d = 0; d < ndays; ++d) nsub += sub_of_day[d] >= 0;
+    const int T = maf ? nsub * 24 : (int)sub->tsteps;          // steps of the subset series
     for (int d = 0; d < ndays; ++d)
         if (sub_of_day[d] >= 0 && (int64_t)sub_of_day[d] * 24 + 24 > T) return mcf::api_fail(MCF_ERR_ARG, "micro set-up: day map points past the subset series");
+    if (maf) {       // the subset's days in the order of the series (the albedo clock and the kernel's addressing walk them so)
+        int next = 0;
+        for (int d = 0; d < ndays; ++d)
+            if (sub_of_day[d] >= 0 && sub_of_day[d] != next++) return mcf::api_fail(MCF_ERR_ARG, "micro set-up, array weather: the day map must number the snow days 0, 1, 2, ... in order");
+    }
     sp->sub_of_day.assign(sub_of_day, sub_of_day + ndays);
+    sp->micro_af = maf;
     Bufs& b = sp->mb;
     MicroArgs& a = sp->ma;
     memset(&a, 0, sizeof a);
     a.N = N; a.tsteps = T; a.reqhgt = reqhgt; a.mat = mat; a.zref = sub->other.zref;
-    const int y0 = sub->obstime.year[0];
+    int y0 = sub->obstime.year[0];          // the SUBSET series' first year (array weather: `sub` is the whole series)
+    if (maf)
+        for (int d = 0; d < ndays; ++d)
+            if (sub_of_day[d] == 0) { y0 = sub->obstime.year[(size_t)d * 24]; break; }
     a.hiy = (y0 % 4 == 0 && (y0 % 100 != 0 || y0 % 400 == 0)) ? 366 * 24 : 365 * 24;   // cpp:4984
     if (keep_static) {
         a.pai = prev.pai; a.hgt = prev.hgt; a.leaft = prev.leaft; a.clump = prev.clump; a.paia = prev.paia; a.leafd = prev.leafd;
@@ -2477,6 +2521,60 @@ extern "C" int mcf_snowplan_micro_setup(mcf_snowplan* sp, const mcf_snow_inputs*
         if (sub->other.Smax) UP(a.Smax, sub->other.Smax, N);
         sp->micro_static = true;
     }
+    if (maf) {
+        if (T == 0) return mcf::api_fail(MCF_ERR_ARG, "micro set-up, array weather: no snow day");
+        const double* hm[9] = {sub->clim.temp, sub->clim.relhum, sub->clim.pres, sub->clim.swdown, sub->clim.difrad, sub->clim.lwdown,
+                               sub->clim.windspeed, sub->clim.precip, sub->clim.umu};
+        for (const double* q : hm)
+            if (!q) return mcf::api_fail(MCF_ERR_ARG, "micro set-up, array weather: a weather array is null");
+        if (!sub->other.lats || !sub->other.lons || !sub->clim.winddir) return mcf::api_fail(MCF_ERR_ARG, "micro set-up, array weather: lats / lons / winddir");
+        UP(a.lats, sub->other.lats, N);
+        UP(a.lons, sub->other.lons, N);
+        // the subset series' date rows (obstime and wind direction of the snow days)
+        std::vector<int32_t> yr((size_t)T), mo((size_t)T), dy((size_t)T);
+        std::vector<double> hr((size_t)T), wd((size_t)T);
+        for (int d = 0; d < ndays; ++d) {
+            if (sub_of_day[d] < 0) continue;
+            for (int hh = 0; hh < 24; ++hh) {
+                const size_t q = (size_t)sub_of_day[d] * 24 + hh, w = (size_t)d * 24 + hh;
+                yr[q] = sub->obstime.year[w]; mo[q] = sub->obstime.month[w]; dy[q] = sub->obstime.day[w]; hr[q] = sub->obstime.hour[w];
+                wd[q] = sub->clim.winddir[w];
+            }
+        }
+        mcf_snow_inputs ds = *sub;
+        ds.tsteps = T;
+        ds.obstime.year = yr.data(); ds.obstime.month = mo.data(); ds.obstime.day = dy.data(); ds.obstime.hour = hr.data();
+        ds.clim.winddir = wd.data();
+        if ((rc = build_step_tables(b, &ds, true, false, false, &a.rows, &a.dates, &a.mxtc1))) return rc;
+        S_TRY(hipDeviceSynchronize());      // (the table kernels have read the host vectors' uploads)
+        // the slabs a chunk's snow days are uploaded into, addressed with the subset series' step numbers (mcf_snowplan_microsnow
+        // shifts the bases by the chunk's first subset day)
+        const int64_t CN = (int64_t)sp->chunk * N;
+        for (int f = 0; f < 9; ++f) {
+            sp->h_micro[f] = hm[f];
+            if ((rc = b.alloc((void**)&sp->d_micro[f], CN * 8))) return rc;
+        }
+        // mxtc and the albedo clock at every subset day's start: the series' temperature and precipitation streamed once, a run of
+        // consecutive snow days at a time through the first two slabs
+        if ((rc = b.alloc((void**)&a.mxtc, N * 8))) return rc;
+        if ((rc = b.alloc((void**)&a.hs0, N * (int64_t)std::max(nsub, 1) * 4))) return rc;
+        int32_t* d_hs;
+        if ((rc = b.alloc((void**)&d_hs, N * 4))) return rc;
+        S_TRY(hipMemset(a.mxtc, 0, (size_t)N * 8));
+        const int cd = sp->chunk / 24;
+        for (int d = 0; d < ndays;) {
+            if (sub_of_day[d] < 0) { ++d; continue; }
+            int e = d;
+            while (e < ndays && sub_of_day[e] >= 0 && e - d < cd) ++e;
+            const int64_t off = (int64_t)d * 24 * N, n = (int64_t)(e - d) * 24 * N;
+            S_TRY(hipMemcpyAsync(sp->d_micro[0], hm[0] + off, (size_t)n * 8, hipMemcpyHostToDevice, nullptr));
+            S_TRY(hipMemcpyAsync(sp->d_micro[1], hm[7] + off, (size_t)n * 8, hipMemcpyHostToDevice, nullptr));
+            hipLaunchKernelGGL(k_micro_scan, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, nullptr, (const double*)sp->d_micro[0],
+                               (const double*)sp->d_micro[1], N, sub_of_day[d], e - d, a.hgt, a.mxtc, d_hs, a.hs0);
+            S_TRY(hipGetLastError());
+            d = e;
+        }
+    } else {
     if ((rc = build_step_tables(b, sub, false, false, false, &a.rows, &a.dates, &a.mxtc1))) return rc;
     UP(a.temp, sub->clim.temp, T);
     UP(a.relhum, sub->clim.relhum, T);
@@ -2487,7 +2585,8 @@ extern "C" int mcf_snowplan_micro_setup(mcf_snowplan* sp, const mcf_snow_inputs*
     UP(a.windspeed, sub->clim.windspeed, T);
     UP(a.precip, sub->clim.precip, T);
     UP(a.umu, sub->clim.umu, T);
-    {
+    }
+    if (!maf) {
         MicroMet* mm;
         if ((rc = b.alloc((void**)&mm, (int64_t)T * sizeof(MicroMet)))) return rc;
         hipLaunchKernelGGL(k_micro_steps, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, nullptr, a.temp, a.relhum, a.pres, a.mxtc1, T, mm);
@@ -2617,7 +2716,25 @@ extern "C" int mcf_snowplan_microsnow(mcf_snowplan* sp, mcf_plan* plan, int32_t 
     for (int v = 0; v < MCF_NOUT; ++v) q.sel |= sp->outsel[v] ? 1u << v : 0u;
     q.daymap = sp->d_daymap; q.nosnow = sp->d_nosnow; q.ndays = nd;
     static const bool old_shape = getenv("MCF_MICRORING_OLD") != nullptr;      // A/B
-    if (q.ring.cpb == 21 && !old_shape)
+    if (sp->micro_af) {
+        // array weather: the chunk's snow days of the nine series into the slabs; the kernel addresses a series with the subset's
+        // step number, so the bases are shifted back by the chunk's first subset day
+        int sub_first = -1;
+        for (int d = 0; d < nd; ++d) {
+            const int sb = sp->sub_of_day[day0 + d];
+            if (sb < 0) continue;
+            if (sub_first < 0) sub_first = sb;
+            for (int f = 0; f < 9; ++f)
+                S_TRY(hipMemcpyAsync(sp->d_micro[f] + (int64_t)(sb - sub_first) * 24 * N, sp->h_micro[f] + (int64_t)(day0 + d) * 24 * N,
+                                     (size_t)24 * N * 8, hipMemcpyHostToDevice, nullptr));
+        }
+        const int64_t back = (int64_t)sub_first * 24 * N;
+        q.m.temp = sp->d_micro[0] - back; q.m.relhum = sp->d_micro[1] - back; q.m.pres = sp->d_micro[2] - back;
+        q.m.swdown = sp->d_micro[3] - back; q.m.difrad = sp->d_micro[4] - back; q.m.lwdown = sp->d_micro[5] - back;
+        q.m.windspeed = sp->d_micro[6] - back; q.m.precip = sp->d_micro[7] - back; q.m.umu = sp->d_micro[8] - back;
+        hipLaunchKernelGGL(k_microsnow_ring<true>, dim3((unsigned)((N + 63) / 64), (unsigned)nd), dim3(256), 0, nullptr, q, (const void*)q.m.dates,
+                           q.daymap, q.nosnow);
+    } else if (q.ring.cpb == 21 && !old_shape)
         hipLaunchKernelGGL(k_microsnow_tiles, dim3((unsigned)((N + kRtCells - 1) / kRtCells)), dim3(64 * kRtWaves), 0, nullptr, q,
                            (const MicroStep*)q.m.mstep, q.daymap, q.nosnow);
     else

@@ -80,6 +80,7 @@ struct Block {
     int64_t twi_n = 0;
     std::vector<double> mx, cmx, mn, cmn;      // applycpp3 of the chunk just run
     std::vector<char> kept;                    // per chunk: its series stayed on the device
+    mcf_grid_inputs gsub{};                    // the block's view of the solver's inputs (array weather: a chunk's forcing is uploaded from it)
     // pass 2: the block's rows of gridmicrosnow1's static rasters
     std::vector<double> m_pai, m_hgt, m_leaft, m_clump, m_paia, m_leafd, m_leafden, m_slope, m_aspect, m_svf, m_wsa, m_hor, m_smax;
 };
@@ -98,6 +99,7 @@ struct mcf_snowrun {
     mcf_snowdriver_in snow{};
     std::vector<int32_t> snowday, nosnowday;   // [ndays]
     bool pass1_done = false;
+    bool af = false;                           // array weather: `.snowmodel2` + `.runmicrosnow2` (mcf_runmicrosnow2)
     int64_t keep_reserve = (int64_t)8 << 30;
     // A run is one simulated period on fresh plans: the device memory a kept chunk needs would have to be ALLOCATED for it (5 GB per
     // chunk of a 1024 x 1024 raster: 0.1 s, measured 3 s of a 6 s call) where re-running the chunk in pass 2 takes 3.5 ms — chunks are
@@ -253,12 +255,19 @@ void snow_chunk(mcf_snowrun* h, int t, int ch, PhaseBarrier& bar, std::atomic<bo
     bar.wait();
 }
 
-int check_create(const mcf_microsnow_in* in, const mcf_options* opt) {
+int check_create(const mcf_microsnow_in* in, const mcf_options* opt, const mcf_multi* mu) {
     if (!in || !opt || !in->grid || !in->snow) return mcf::api_fail(MCF_ERR_ARG, "null snow-run argument");
     const mcf_grid_inputs& g = *in->grid;
     const mcf_snow_inputs& sb = in->snow->base;
-    if (g.array_forcing || sb.array_forcing)
-        return mcf::api_fail(MCF_ERR_ARG, "mcf_runmicrosnow1 takes data.frame (vector) weather; array weather goes through gridmicrosnow2");
+    // Array weather (round 5): `.snowmodel2`'s loop + `.runmicrosnow2` (R/internal.R:2950-3008, 3661-3745) — the solver's and the snow
+    // model's weather as arrays at the raster's resolution, what runmicro2Cpp / gridmodelsnow2 / gridmicrosnow2 take.  Both sides in
+    // the same geometry; one block (a chunk's slices are uploaded from the caller's whole-raster arrays as the loop reaches them).
+    if ((g.array_forcing != 0) != (sb.array_forcing != 0))
+        return mcf::api_fail(MCF_ERR_ARG, "snow run: the solver's and the snow model's weather differ in geometry (data.frame / array)");
+    if (g.array_forcing == 2)
+        return mcf::api_fail(MCF_ERR_ARG, "snow run: coarse array forcing is not supported here (resample to the raster first, as `.snowmodel2` does)");
+    if (g.array_forcing && mu && (mu->n_blocks > 1 || mu->n_devices > 1))
+        return mcf::api_fail(MCF_ERR_ARG, "snow run, array weather: one block on one device");
     // Time-varying vegetation (round 5).  `.runmicronosnow` sends a layered `vegp` to `.runmodel3Cpp` on the no-snow-day SUBSET
     // (R/internal.R:3333-3342), which deals the subset's days to layers by `.sortvegp(vegp, "C", n, subs)` — the layer a step has
     // in the WHOLE series (round(seq(0.50001, dmx + 0.5, length.out = n))[subs], the day's mode, R/internal.R:252-270) — and
@@ -289,7 +298,7 @@ int check_create(const mcf_microsnow_in* in, const mcf_options* opt) {
 extern "C" int mcf_snowrun_create(const mcf_microsnow_in* in, const mcf_options* opt, const mcf_multi* mu, mcf_snowrun** out) {
     try {
         if (!out) return mcf::api_fail(MCF_ERR_ARG, "null snow-run argument");
-        int rc = check_create(in, opt);
+        int rc = check_create(in, opt, mu);
         if (rc) return rc;
         int nd = 0;
         if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0)
@@ -309,6 +318,7 @@ extern "C" int mcf_snowrun_create(const mcf_microsnow_in* in, const mcf_options*
             }
         }
         h->grid = *in->grid; h->opt = *opt; h->snow = *in->snow;
+        h->af = h->grid.array_forcing != 0;
         const int64_t R = h->R = h->grid.rows, C = h->C = h->grid.cols;
         h->T = h->grid.tsteps;
         h->ndays = (int)(h->T / 24);
@@ -316,6 +326,7 @@ extern "C" int mcf_snowrun_create(const mcf_microsnow_in* in, const mcf_options*
         h->chunk_days = chunk / 24;
         h->nchunks = std::max(1, (int)(h->T / chunk));          // `for (day in 1:n5days)`, R/internal.R:2553-2565
         h->nb = (int)std::min<int64_t>(mu && mu->n_blocks > 0 ? mu->n_blocks : (int)h->devs.size(), R);
+        if (h->af) h->nb = 1;
         h->nt = (int)std::min<size_t>(h->devs.size(), (size_t)h->nb);
         h->blocks.resize((size_t)h->nb);
         if (h->nb > 1) h->surface.assign((size_t)(R * C), 0.0);
@@ -358,6 +369,14 @@ extern "C" int mcf_snowrun_create(const mcf_microsnow_in* in, const mcf_options*
                     off(sub.soilc.Smin); off(sub.soilc.Smax); off(sub.soilc.gref); off(sub.soilc.soilb); off(sub.soilc.Psie);
                     off(sub.soilc.Vq); off(sub.soilc.Vm); off(sub.soilc.Mc); off(sub.soilc.rho); off(sub.soilc.slope);
                     off(sub.soilc.aspect); off(sub.soilc.twi); off(sub.soilc.svfa); off(sub.soilc.wsa); off(sub.soilc.hor);
+                    if (h->af) {                 // (layered / lat-lon arrays of the array-forcing solver, read through the same pitch)
+                        off(sub.clim.tc); off(sub.clim.es); off(sub.clim.ea); off(sub.clim.tdew); off(sub.clim.pk); off(sub.clim.swdown);
+                        off(sub.clim.difrad); off(sub.clim.lwdown); off(sub.clim.windspeed);
+                        off(sub.pointm.soilm); off(sub.pointm.Tg); off(sub.pointm.Tbp); off(sub.pointm.G); off(sub.pointm.umu);
+                        off(sub.pointm.kp); off(sub.pointm.muGp); off(sub.pointm.dtrp);
+                        off(sub.lats); off(sub.lons);
+                    }
+                    k.gsub = sub;
                     mcf_options o = h->opt;
                     o.device = k.device;
                     rc2 = mcf_plan_create(&sub, &o, h->chunk_days, 2, &k.plan);
@@ -514,8 +533,8 @@ extern "C" int mcf_snowrun_pass2(mcf_snowrun* h, const mcf_snow_inputs* micro, d
         mcf_snow_inputs sub{};
         if (!sdays.empty()) {
             if (!micro) return mcf::api_fail(MCF_ERR_ARG, "snow run: the year has snow days, gridmicrosnow1's inputs are needed");
-            if (micro->rows != R || micro->cols != C || micro->tsteps != T || micro->array_forcing)
-                return mcf::api_fail(MCF_ERR_ARG, "snow run: gridmicrosnow1's inputs must be the whole series on the whole raster (vector weather)");
+            if (micro->rows != R || micro->cols != C || micro->tsteps != T || (micro->array_forcing != 0) != h->af)
+                return mcf::api_fail(MCF_ERR_ARG, "snow run: gridmicrosnow's inputs must be the whole series on the whole raster, in the run's weather geometry");
             const mcf_snow_climate& cl = micro->clim;
             const double* src[10] = {cl.temp, cl.relhum, cl.pres, cl.swdown, cl.difrad, cl.lwdown, cl.windspeed, cl.winddir, cl.precip, cl.umu};
             static const char* nm[10] = {"temp", "relhum", "pres", "swdown", "difrad", "lwdown", "windspeed", "winddir", "precip", "umu"};
@@ -529,6 +548,8 @@ extern "C" int mcf_snowrun_pass2(mcf_snowrun* h, const mcf_snow_inputs* micro, d
                 !ot.skyview || !ot.wsa || !ot.hor)
                 return mcf::api_fail(MCF_ERR_ARG, "null input: a gridmicrosnow1 raster");
             if (outm[MCF_OUT_SOILM] && h->opt.out[MCF_OUT_SOILM] && !ot.Smax) return mcf::api_fail(MCF_ERR_ARG, "soilm requested but other$Smax is null");
+            sub = *micro;
+            if (!h->af) {      // (array weather: the snow plan takes the whole series and the day map — nine arrays are not copied)
             yr.resize((size_t)TS); mo.resize((size_t)TS); dy.resize((size_t)TS); hr.resize((size_t)TS);
             for (auto& s : ser) s.resize((size_t)TS);
             for (size_t i = 0; i < sdays.size(); ++i)
@@ -537,18 +558,19 @@ extern "C" int mcf_snowrun_pass2(mcf_snowrun* h, const mcf_snow_inputs* micro, d
                     yr[(size_t)q] = ob.year[a]; mo[(size_t)q] = ob.month[a]; dy[(size_t)q] = ob.day[a]; hr[(size_t)q] = ob.hour[a];
                     for (int f = 0; f < 10; ++f) ser[f][(size_t)q] = src[f][a];
                 }
-            sub = *micro;
             sub.tsteps = TS;
             sub.obstime.year = yr.data(); sub.obstime.month = mo.data(); sub.obstime.day = dy.data(); sub.obstime.hour = hr.data();
             sub.clim.temp = ser[0].data(); sub.clim.relhum = ser[1].data(); sub.clim.pres = ser[2].data(); sub.clim.swdown = ser[3].data();
             sub.clim.difrad = ser[4].data(); sub.clim.lwdown = ser[5].data(); sub.clim.windspeed = ser[6].data();
             sub.clim.winddir = ser[7].data(); sub.clim.precip = ser[8].data(); sub.clim.umu = ser[9].data();
+            }
         }
         // the solver's maximum air temperature over the NO-snow subset (src/microclimfCpp.cpp:2159-2168 on what `.runmicronosnow`
         // hands it, R/internal.R:3605)
         double mxtc = -INFINITY;
-        for (int d : ndays_)
-            for (int hh = 0; hh < 24; ++hh) { const double v = h->grid.clim.tc[(int64_t)d * 24 + hh]; if (v > mxtc) mxtc = v; }
+        if (!h->af)
+            for (int d : ndays_)
+                for (int hh = 0; hh < 24; ++hh) { const double v = h->grid.clim.tc[(int64_t)d * 24 + hh]; if (v > mxtc) mxtc = v; }
         const double NA = na_real_host();
         double smean = 0, tmean = 0;
         const int rc = run_workers(h, [&](int t, PhaseBarrier& bar, std::atomic<bool>& failed, auto& guarded, auto& fail_here) {
@@ -579,7 +601,8 @@ extern "C" int mcf_snowrun_pass2(mcf_snowrun* h, const mcf_snow_inputs* micro, d
                         }
                         rc2 = mcf_snowplan_micro_setup(k.sp, &bs, sub_of_day.data(), (int32_t)sub_of_day.size(), h->opt.reqhgt, mat, outm, 0);
                     }
-                    if (!rc2 && !ndays_.empty()) rc2 = mcf_plan_set_mxtc(k.plan, mxtc);
+                    if (!rc2 && !ndays_.empty())         // (array weather: per cell, cpp:2467-2471, over the no-snow days)
+                        rc2 = h->af ? mcf_plan_set_mxtc_days(k.plan, &k.gsub, h->nosnowday.data(), ndays) : mcf_plan_set_mxtc(k.plan, mxtc);
                     if (!rc2) rc2 = mcf_snowplan_set_series(k.sp, 31u);         // (pass 2's re-runs feed the snow microclimate)
                     if (rc2) { fail_here(rc2); break; }
                 }
@@ -607,6 +630,13 @@ extern "C" int mcf_snowrun_pass2(mcf_snowrun* h, const mcf_snow_inputs* micro, d
             std::vector<uint8_t> skip;
             auto solver_days = [&](Block& k, int slot, int ch, int d0, int nd, bool has_snow) -> int {
                 int q = 0;
+                if (h->af) {      // array weather: the chunk's forcing into the slot once (all its days: the runs address them by day)
+                    bool any = false;
+                    for (int d = 0; d < nd; ++d) any |= h->nosnowday[(size_t)(d0 + d)] != 0;
+                    if (!any) return MCF_OK;
+                    const int rc3 = mcf_plan_upload_forcing_days(k.plan, &k.gsub, d0, nd, slot);
+                    if (rc3) return rc3;
+                }
                 while (q < nd) {
                     if (!h->nosnowday[(size_t)(d0 + q)]) { ++q; continue; }
                     int e = q;
@@ -615,7 +645,7 @@ extern "C" int mcf_snowrun_pass2(mcf_snowrun* h, const mcf_snow_inputs* micro, d
                     int64_t ncov = 0;
                     bool any_snow_day = false;
                     for (int d = q; d < e; ++d) any_snow_day |= h->snowday[(size_t)(d0 + d)] != 0;
-                    if (has_snow && any_snow_day && !no_skip && ch >= 0) {
+                    if (has_snow && any_snow_day && !no_skip && ch >= 0 && !h->af) {
                         mcf_ring_layout lay;
                         if ((rc2 = mcf_plan_ring_layout(k.plan, &lay))) return rc2;
                         const int64_t nt = (lay.cells + lay.cells_per_tile - 1) / lay.cells_per_tile;
@@ -694,6 +724,12 @@ static int runmicrosnow1_impl(const mcf_microsnow_in* in, const mcf_options* opt
     return mcf_snowrun_pass2(h, in->micro, in->mat, out);
 }
 extern "C" int mcf_runmicrosnow1(const mcf_microsnow_in* in, const mcf_options* opt, mcf_outputs* out, const mcf_snowdriver_out* smod) {
+    if (in && in->grid && in->grid->array_forcing) return mcf::api_fail(MCF_ERR_ARG, "mcf_runmicrosnow1 takes data.frame (vector) weather; array weather: mcf_runmicrosnow2");
+    return runmicrosnow1_impl(in, opt, nullptr, out, smod);
+}
+// `.snowmodel2`'s loop + `.runmicrosnow2` (R/internal.R:2950-3008, 3661-3745): the same run with array weather
+extern "C" int mcf_runmicrosnow2(const mcf_microsnow_in* in, const mcf_options* opt, mcf_outputs* out, const mcf_snowdriver_out* smod) {
+    if (in && in->grid && !in->grid->array_forcing) return mcf::api_fail(MCF_ERR_ARG, "mcf_runmicrosnow2 takes array weather; data.frame weather: mcf_runmicrosnow1");
     return runmicrosnow1_impl(in, opt, nullptr, out, smod);
 }
 extern "C" int mcf_runmicrosnow1_multi(const mcf_microsnow_in* in, const mcf_options* opt, const mcf_multi* multi, mcf_outputs* out,

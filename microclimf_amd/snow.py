@@ -942,21 +942,29 @@ class SnowRun:
         from .marshal import alloc_outputs, marshal
         self._lib = _abi.load()
         g = grid
-        self._gm = marshal(g["obstime"], g["climdata"], g["pointm"], g["vegp"], g["soilc"], g["reqhgt"], g["zref"], g["lat"], g["lon"],
+        # array weather (mcf_runmicrosnow2): `snow` carries "af_wind" (and optionally "wsa_s"), every weather array is [rows, cols, T]
+        self.array_weather = "af_wind" in snow
+        self._gm = marshal(g["obstime"], g["climdata"], g["pointm"], g["vegp"], g["soilc"], g["reqhgt"], g["zref"],
+                           g["lats"] if "lats" in g else g["lat"], g["lons"] if "lons" in g else g["lon"],
                            g.get("Sminp", 0.0), g.get("Smaxp", 0.0), g["tfact"], g.get("complete", True), g.get("mat", 0.0),
-                           g.get("out", (1,) * 10), False, device, 0, cells_per_block, g.get("dfsel"))
+                           g.get("out", (1,) * 10), self.array_weather, device, 0, cells_per_block, g.get("dfsel"))
         self._alloc_outputs = lambda: alloc_outputs(self._gm)
         R, Cc = np.shape(snow["vegp"]["pai"])
         oth = dict(snow["other"])
         for k, shp in (("slope", (R, Cc)), ("aspect", (R, Cc)), ("skyview", (R, Cc)), ("wsa", (R, Cc, 8)), ("hor", (R, Cc, 24))):
             oth.setdefault(k, np.zeros(shp))
-        self._sm = marshal_snow(snow["obstime"], snow["climdata"], snow["vegp"], oth, False, pointm=snow["pointm"],
-                                snowenv=snow.get("snowenv", "Alpine"))
-        self._din = _abi.SnowDriverIn()
-        self._din.base = self._sm.inputs
-        self._din.dtm = self._sm.f64(snow["dtm"], (R, Cc), "dtm")
-        self._din.res, self._din.tfact = float(snow["res"]), float(snow.get("tfact", 0.02))
-        self._din.chunk_steps = int(snow.get("chunk_steps", 120))
+        if self.array_weather:
+            self._sm, self._din = _driver_in_array(snow["obstime"], snow["climdata"], snow["pointm"], snow["vegp"], oth,
+                                                   snow.get("snowenv", "Alpine"), snow["dtm"], snow["res"], snow.get("tfact", 0.02),
+                                                   snow["af_wind"], snow.get("wsa_s", 0), snow.get("chunk_steps", 120))
+        else:
+            self._sm = marshal_snow(snow["obstime"], snow["climdata"], snow["vegp"], oth, False, pointm=snow["pointm"],
+                                    snowenv=snow.get("snowenv", "Alpine"))
+            self._din = _abi.SnowDriverIn()
+            self._din.base = self._sm.inputs
+            self._din.dtm = self._sm.f64(snow["dtm"], (R, Cc), "dtm")
+            self._din.res, self._din.tfact = float(snow["res"]), float(snow.get("tfact", 0.02))
+            self._din.chunk_steps = int(snow.get("chunk_steps", 120))
         self._in = _abi.MicrosnowIn()
         self._in.grid = C.pointer(self._gm.inputs)
         self._in.snow = C.pointer(self._din)
@@ -1012,7 +1020,7 @@ class SnowRun:
         the WHOLE series, or None when the year has no snow day -> the ten merged outputs"""
         mi = None
         if micro is not None:
-            self._mm = marshal_snow(micro["obstime"], micro["climdata"], micro["vegp"], micro["other"], False, micro=True)
+            self._mm = marshal_snow(micro["obstime"], micro["climdata"], micro["vegp"], micro["other"], self.array_weather, micro=True)
             mi = C.byref(self._mm.inputs)
         outs, arrays = self._alloc_outputs()
         _abi.check(self._lib.mcf_snowrun_pass2(self._p, mi, float(mat), C.byref(outs)))
@@ -1029,7 +1037,7 @@ def runmicrosnow1(grid: Mapping, snow: Mapping, micro: Mapping | None, mat: floa
         SnowRun._marshal_only(run, grid, snow, device, cells_per_block)
         mi = None
         if micro is not None:
-            run._mm = marshal_snow(micro["obstime"], micro["climdata"], micro["vegp"], micro["other"], False, micro=True)
+            run._mm = marshal_snow(micro["obstime"], micro["climdata"], micro["vegp"], micro["other"], run.array_weather, micro=True)
             run._in.micro = C.pointer(run._mm.inputs)
         run._in.mat = float(mat)
         outs, arrays = alloc_outputs(run._gm)
@@ -1048,5 +1056,15 @@ def runmicrosnow1(grid: Mapping, snow: Mapping, micro: Mapping | None, mat: floa
             mu.n_devices, mu.devices, mu.n_blocks = int(devs.size), devs.ctypes.data_as(_abi.c_int32_p), int(n_blocks)
             _abi.check(lib.mcf_runmicrosnow1_multi(C.byref(run._in), C.byref(run._gm.options), C.byref(mu), C.byref(outs), sop))
         else:
-            _abi.check(lib.mcf_runmicrosnow1(C.byref(run._in), C.byref(run._gm.options), C.byref(outs), sop))
+            fn = lib.mcf_runmicrosnow2 if run.array_weather else lib.mcf_runmicrosnow1
+            _abi.check(fn(C.byref(run._in), C.byref(run._gm.options), C.byref(outs), sop))
     return (arrays, smod) if want_smod else arrays
+
+
+def runmicrosnow2(grid: Mapping, snow: Mapping, micro: Mapping | None, mat: float, **kw):
+    """mcf_runmicrosnow2: `.snowmodel2`'s loop + `.runmicrosnow2` as ONE library call.  `grid` = runmicro2Cpp's arguments for the
+    whole series (array climate / point-model arrays, "lats", "lons"), `snow` as for snowmodel2_device (with "af_wind"[, "wsa_s"]),
+    `micro` = gridmicrosnow2's inputs for the whole series -> the merged outputs[, smod]"""
+    if "af_wind" not in snow:
+        raise ValueError("runmicrosnow2: snow['af_wind'] (the chunk wind series of `.snowmodel2`) is missing")
+    return runmicrosnow1(grid, snow, micro, mat, **kw)
