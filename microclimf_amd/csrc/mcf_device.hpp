@@ -1055,20 +1055,22 @@ __device__ __forceinline__ void flr(double& x, double lo, Canary& cn) {         
 // 1293, so the lane carries 1 / den across the day's barrier instead of den and pass 2 divides by a multiplication)
 // F: `dTmx` is min(dTmx, 80) already (solve_tile): the two caps of cpp:1237-1238 are one v_min_f64.  (A NaN dTmx is ignored by
 // the reference's comparison and by fmin alike.)
-template <bool F>
+// M80: that merge has been done (vector forcing, where dTmx is one value per launch; array forcing's is per CELL — a second
+// per-lane double alive through the whole day loop put scratch into kernels that sit at their register limit — and keeps two caps)
+template <bool F, bool M80 = F>
 __device__ __forceinline__ double pm_temperature_r(double num, double rden, double dTmx, double tc, double tdew, Canary& cn) {
     double dT = num * rden;
     cap<F>(dT, dTmx, cn);
-    if (!F) cap<F>(dT, 80.0, cn);
+    if (!M80) cap<F>(dT, 80.0, cn);
     double Ts = dT + tc;
     flr<F>(Ts, tdew, cn);
     return Ts;
 }
-template <bool F>
+template <bool F, bool M80 = F>
 __device__ __forceinline__ double pm_temperature(double num, double den, double dTmx, double tc, double tdew, Canary& cn) {
     double dT = fdiv_m(num, den);
     cap<F>(dT, dTmx, cn);
-    if (!F) cap<F>(dT, 80.0, cn);
+    if (!M80) cap<F>(dT, 80.0, cn);
     double Ts = dT + tc;
     flr<F>(Ts, tdew, cn);
     return Ts;
@@ -1322,7 +1324,7 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const SL& S, con
     cy.num0 = num0;
     const double rden = frcp_m(den);
     cy.rden = rden;
-    double Tg0 = pm_temperature_r<F>(num0, rden, dTmx, tc, tdew, cn);
+    double Tg0 = pm_temperature_r<F, F && !TM::in_registers>(num0, rden, dTmx, tc, tdew, cn);
     o.Tg0 = Tg0;
     o.absRnet = fabs(radabs - lw_emit(Tg0));
 }
@@ -1409,7 +1411,7 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
     if (F) cn.watch(G);                  // sqrt of the soil diffusivity: NaN for a non-positive conductivity
     cap<F>(G, 0.6 * Rmx, cn);
     flr<F>(G, -0.6 * Rmx, cn);
-    const double Tg = pm_temperature_r<F>(cy.num0 - G, cy.rden, dTmx, tc, tdew, cn);
+    const double Tg = pm_temperature_r<F, F && !TM::in_registers>(cy.num0 - G, cy.rden, dTmx, tc, tdew, cn);
     o.Tg = Tg;
     o.DD = DD;
     if (!above_ground) return;
@@ -1538,9 +1540,9 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
         double rC;
         frcp2_m(dgw, denC, gwet, rC);
         flr<F>(gwet, surfwet, cn);
-        Tcan = pm_temperature_r<F>(numC, rC, dTmx, tc, tdew, cn);
+        Tcan = pm_temperature_r<F, F && !lean>(numC, rC, dTmx, tc, tdew, cn);
     } else {
-        Tcan = pm_temperature<F>(numC, denC, dTmx, tc, tdew, cn);
+        Tcan = pm_temperature<F, F && !lean>(numC, denC, dTmx, tc, tdew, cn);
     }
     double esTcan, muR = 0.0;                               // muR: uf/(a2*h) / uf^2, the below-canopy profile's (cpp:1389)
     if (PAIR) {
@@ -1622,7 +1624,7 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
             if (gs > 0.0) gVl = fdiv_m(gh * gs, gh + gs);
         }
         const double mL = lapk * gVl;
-        const double tleaf = pm_temperature<F>(leafabs - rem - mL * esw - 0.0,
+        const double tleaf = pm_temperature<F, F && !lean>(leafabs - rem - mL * esw - 0.0,
                                                29.3 * (gh + ghr) + mL * De, dTmx, tc, tdew, cn);
         o.tleaf = tleaf;
         o.lwdn = lwdn;

@@ -613,7 +613,8 @@ __device__ __forceinline__ void solve_tile(const SolveArgs& a, const int64_t til
     double dTmx = g.dTmx;
     if (AF && in_grid) dTmx = -0.6273 * a.mxtc[c] + 49.79;   // cpp:1236 with the per-cell mxtc
     // the fast clamps take the two caps of cpp:1237-1238 as one (pm_temperature); a NaN dTmx is ignored by both forms
-    const double dTcap = F ? fmin(dTmx, 80.0) : dTmx;
+    // (vector forcing only: mcf_device.hpp pm_temperature M80)
+    const double dTcap = (F && !AF) ? fmin(dTmx, 80.0) : dTmx;
     // TVaboveground (cpp:2272) is only evaluated when one of its outputs was requested
     const bool need_tv = g.reqhgt >= 0.0 && a.need_tv != 0;
     MathK MK;
@@ -1013,8 +1014,11 @@ __global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_P
 // Redoes, with the reference's compare-and-select clamps, the tiles in which a fast workgroup's canary tripped.  Launched
 // behind every fast launch with a fixed small grid; with an empty list (the normal case) every workgroup leaves at once.
 // An overflowing list means "everything": all tiles, all days of the launch.
+// (built for TWO waves per SIMD where a workgroup's waves allow it — 8-wave tiles: the reference-form clamps' compare-and-select code
+// needs more registers than the fast kernels, the list is normally empty, and occupancy is of no interest here; 12-wave tiles need
+// three per SIMD to be resident at all)
 template <int CPB, int AF>
-__global__ __launch_bounds__(solve_threads(CPB), AF ? MCF_AF_WAVES : MCF_WAVES_PER_EU) void k_solve_fix(SolveArgs a) {
+__global__ __launch_bounds__(solve_threads(CPB), solve_threads(CPB) <= 512 ? 2 : solve_threads(CPB) <= 768 ? 3 : MCF_WAVES_PER_EU) void k_solve_fix(SolveArgs a) {
     const int n = *a.fix_count;
     if (n <= 0) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.fix_count + 1, n);     // running total, for mcf_plan_dispatch_stats

@@ -87,8 +87,11 @@ __global__ __launch_bounds__(256) void k_snow_steps(StepArgs a) {
     snow::snow_tables_init();
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.tsteps) return;
-    StepRow r;
-    memset(&r, 0, sizeof r);
+    // (the record is assembled where it lives: a local StepRow — 44 doubles whose members are then copied as a block — went through
+    // 352 B of scratch per lane)
+    StepRow& r = a.rows[k];
+    r.d = DayT{};
+    r.rnet = 0.0;
     const SolDate sd = sol_date(a.year[k], a.month[k], a.day[k]);
     const double latr = a.lat * kPi / 180.0;
     const SolPos sp = sol_site(sd, a.hour[k], sin(latr), cos(latr), a.lon);
@@ -101,8 +104,9 @@ __global__ __launch_bounds__(256) void k_snow_steps(StepArgs a) {
         r.m.rsw = a.swdown[k]; r.m.rdif = a.difrad[k]; r.m.rlw = a.lwdown[k];
         r.m.umu = a.umu[k]; r.m.u2 = a.windspeed[k]; r.m.gp = a.Gp[k];
         r.rnet = a.RswabsG[k] + a.RlwabsG[k] - r.m.rem;
+    } else {
+        r.m = MetT{};
     }
-    a.rows[k] = r;
 }
 // daily extremes of the point model's net radiation (cpp:4231-4282): one lane per day
 __global__ __launch_bounds__(64) void k_snow_days(StepRow* rows, int tsteps) {
@@ -391,12 +395,11 @@ __global__ __launch_bounds__(256) void k_micro_pack(const StepRow* __restrict__ 
                                                     const double* __restrict__ umu, int T, MicroStep* __restrict__ out) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= T) return;
-    MicroStep m;
+    MicroStep& m = out[k];          // (in place: a local record went through 176 B of scratch)
     m.s = rows[k].s; m.mm = mmet[k];
     m.tc = temp[k]; m.pk = pres[k]; m.u2 = wind[k]; m.rsw = sw[k]; m.rdif = dif[k]; m.rlw = lw[k]; m.umu = umu[k];
     m.alb = rows[k].m.alb; m.ialb = rows[k].m.ialb;
     m.sindex = rows[k].sindex; m.windex = rows[k].windex;
-    out[k] = m;
 }
 template <bool AF>
 __global__ __launch_bounds__(256) void k_microsnow_cell(MicroArgs a) {

@@ -48,6 +48,12 @@ gb = sum(v.nbytes for v in got.values()) / 1e9
 print(f"{a.rows} x {a.cols} x {a.days} days, outputs {want}: {dt:.2f} s ({t1 - t:.2f} s pass 1) = {valid * T / dt:.3e} cell-steps/s, "
       f"{gb:.1f} GB into host arrays; snow days {int(sd.sum())}, no-snow days {int(nd.sum())}, {st}")
 if a.keep_gb > 0:
+    # (an output array of a 1024^2 year is 73.5 GB of host memory: only ONE set is alive at a time — the unkept run's is reduced
+    # to a 64-bit digest per variable first; the box allows a command 270 GB)
+    import hashlib
+    digest = lambda d: {k: hashlib.sha256(np.ascontiguousarray(v).view(np.uint8)).hexdigest()[:16] for k, v in d.items()}      # noqa: E731
+    ref = digest(got)
+    del got
     with S.SnowRun(g, snow) as run:
         run.keep(a.keep_gb)
         for year in (1, 2):
@@ -57,6 +63,7 @@ if a.keep_gb > 0:
             got2 = run.pass2(micro, 7.5)
             dt = time.perf_counter() - t
             st2 = run.stats()
-            print(f"  keep {a.keep_gb:g} GB, year {year} of one handle: {dt:.2f} s ({t1 - t:.2f} s pass 1) = {valid * T / dt:.3e} cell-steps/s, {st2}")
-        same = all(np.array_equal(got[k], got2[k], equal_nan=True) for k in got)
-        print(f"  outputs bitwise the unkept run's: {same}")
+            same = digest(got2) == ref
+            del got2
+            print(f"  keep {a.keep_gb:g} GB, year {year} of one handle: {dt:.2f} s ({t1 - t:.2f} s pass 1) = {valid * T / dt:.3e} cell-steps/s, {st2}; "
+                  f"outputs bitwise the unkept run's: {same}")
