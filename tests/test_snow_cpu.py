@@ -30,7 +30,7 @@ def test_snow_struct_layout():
     assert C.sizeof(_abi.SnowInputs) == 3 * 8 + 8 + 4 * 8 + (10 + 5 + 7 + 15) * 8
     assert C.sizeof(_abi.SnowModelOut) == 9 * 8
     assert C.sizeof(_abi.Snowm) == 5 * 8
-    assert C.sizeof(_abi.SnowDriverIn) == C.sizeof(_abi.SnowInputs) + 8 + 8 + 8 + 8
+    assert C.sizeof(_abi.SnowDriverIn) == C.sizeof(_abi.SnowInputs) + 8 + 8 + 8 + 8 + 8        # (+ af_wind: ABI 6)
     assert C.sizeof(_abi.SnowDriverOut) == 5 * 8
 
 
