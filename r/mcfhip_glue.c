@@ -487,10 +487,19 @@ SEXP mcfhip_applycpp3(SEXP a, SEXP fun_name) {
     UNPROTECT(np);
     return ans;
 }
+/* array_forcing: `.snowmodel2`'s loop — weather / pointm elements are [rows, cols, tsteps] arrays (winddir a vector), other has
+ * lats / lons; the caller sets af_wind / af_wsa_s afterwards (mcfhip_snowrun_create) */
+static void fill_snowdriver_g(mcf_snowdriver_in *din, int *np, int array_forcing, SEXP obstime, SEXP weather, SEXP pointm, SEXP vegp,
+                              SEXP other, SEXP snowenv, SEXP dtm, SEXP res, SEXP tfact);
 static void fill_snowdriver(mcf_snowdriver_in *din, int *np, SEXP obstime, SEXP weather, SEXP pointm, SEXP vegp, SEXP other,
                             SEXP snowenv, SEXP dtm, SEXP res, SEXP tfact) {
+    fill_snowdriver_g(din, np, 0, obstime, weather, pointm, vegp, other, snowenv, dtm, res, tfact);
+}
+static void fill_snowdriver_g(mcf_snowdriver_in *din, int *np, int array_forcing, SEXP obstime, SEXP weather, SEXP pointm, SEXP vegp,
+                              SEXP other, SEXP snowenv, SEXP dtm, SEXP res, SEXP tfact) {
     memset(din, 0, sizeof *din);
     mcf_snow_inputs *in = &din->base;
+    in->array_forcing = array_forcing ? 1 : 0;
     /* fill_snow() wants the terrain members the loop recomputes: take what the driver needs by hand */
     SEXP dim = getAttrib(elt(vegp, "pai", NULL), R_DimSymbol);
     if (TYPEOF(dim) != INTSXP || LENGTH(dim) != 2) Rf_error("mcfhip: vegp$pai must be a matrix");
@@ -510,8 +519,13 @@ static void fill_snowdriver(mcf_snowdriver_in *din, int *np, SEXP obstime, SEXP 
     static const char *vn[4] = {"pai", "hgt", "leaft", "clump"};
     const double **vp = (const double **)&in->vegp;
     for (int i = 0; i < 4; ++i) vp[i] = dbl(elt(vegp, vn[i], NULL), np);
-    in->other.lat = asReal(elt(other, "lat", NULL));
-    in->other.lon = asReal(elt(other, "lon", NULL));
+    if (in->array_forcing) {                 /* `.snowmodel2`: per-cell latitudes / longitudes (R/internal.R:2937-2941) */
+        in->other.lats = dbl(elt(other, "lats", NULL), np);
+        in->other.lons = dbl(elt(other, "lons", NULL), np);
+    } else {
+        in->other.lat = asReal(elt(other, "lat", NULL));
+        in->other.lon = asReal(elt(other, "lon", NULL));
+    }
     in->other.zref = asReal(elt(other, "zref", NULL));
     in->other.isnowdc = dbl(elt(other, "isnowdc", NULL), np);
     in->other.isnowdg = dbl(elt(other, "isnowdg", NULL), np);
@@ -587,8 +601,13 @@ static void snowrun_finalize(SEXP xp) {
     R_ClearExternalPtr(xp);
 }
 SEXP mcfhip_snowrun_create(SEXP grid, SEXP snow) {
-    if (TYPEOF(grid) != VECSXP || LENGTH(grid) != 15) Rf_error("mcfhip: grid must be the list of runmicro1Cpp's fifteen arguments");
-    if (TYPEOF(snow) != VECSXP || LENGTH(snow) != 9) Rf_error("mcfhip: snow must be list(obstime, weather, pointm, vegp, other, snowenv, dtm, res, tfact)");
+    if (TYPEOF(grid) != VECSXP || LENGTH(grid) != 15) Rf_error("mcfhip: grid must be the list of runmicro1Cpp's / runmicro2Cpp's fifteen arguments");
+    /* nine elements: data.frame weather (`.snowmodel1`); eleven: ARRAY weather at the raster's resolution (`.snowmodel2`'s loop +
+     * `.runmicrosnow2`: grid = runmicro2Cpp's arguments) with af_wind = sqrt(wuv^2 + wvv^2) per step and af_wsa_s (include/mcf.h
+     * mcf_snowdriver_in) appended.  NOT EXERCISED: no R here, and r/mcfhip_overrides.R has no stand-in for `.runmicrosnow2` yet. */
+    if (TYPEOF(snow) != VECSXP || (LENGTH(snow) != 9 && LENGTH(snow) != 11))
+        Rf_error("mcfhip: snow must be list(obstime, weather, pointm, vegp, other, snowenv, dtm, res, tfact[, af_wind, af_wsa_s])");
+    const int arrayw = LENGTH(snow) == 11;
     int np = 0;
     g_keep = NULL; g_nkeep = 0;     /* an earlier entry may have left through Rf_error with the list still set: it is unprotected then */
     snowrun_box *b = (snowrun_box *)calloc(1, sizeof *b);
@@ -601,11 +620,15 @@ SEXP mcfhip_snowrun_create(SEXP grid, SEXP snow) {
     R_RegisterCFinalizerEx(xp, snowrun_finalize, TRUE);
     g_keep = keepl; g_nkeep = 0;
 #define G(i) VECTOR_ELT(grid, i)
-    fill_inputs(&b->grid, &b->opt, &np, 0, R_NilValue, G(0), G(1), G(2), G(3), G(4), G(5), G(6), G(7), G(8), G(9), G(10), G(11), G(12),
+    fill_inputs(&b->grid, &b->opt, &np, arrayw, R_NilValue, G(0), G(1), G(2), G(3), G(4), G(5), G(6), G(7), G(8), G(9), G(10), G(11), G(12),
                 G(13), G(14));
 #undef G
 #define S(i) VECTOR_ELT(snow, i)
-    fill_snowdriver(&b->snow, &np, S(0), S(1), S(2), S(3), S(4), S(5), S(6), S(7), S(8));
+    fill_snowdriver_g(&b->snow, &np, arrayw, S(0), S(1), S(2), S(3), S(4), S(5), S(6), S(7), S(8));
+    if (arrayw) {
+        b->snow.af_wind = dbl(S(9), &np);
+        b->snow.af_wsa_s = asInteger(S(10));
+    }
 #undef S
     g_keep = NULL;
     b->in.grid = &b->grid; b->in.snow = &b->snow; b->in.micro = NULL; b->in.mat = 0.0;
@@ -666,7 +689,7 @@ SEXP mcfhip_snowrun_pass2(SEXP h, SEXP obstime, SEXP weather, SEXP vegp, SEXP ot
     g_keep = NULL; g_nkeep = 0;     /* an earlier entry may have left through Rf_error with the list still set: it is unprotected then */
     mcf_snow_inputs micro;
     const int have = obstime != R_NilValue;      /* NULL inputs: a year without a snow day */
-    if (have) fill_snow(&micro, &np, 0, 1, obstime, weather, R_NilValue, vegp, other);
+    if (have) fill_snow(&micro, &np, b->grid.array_forcing ? 1 : 0, 1, obstime, weather, R_NilValue, vegp, other);
     static const char *on[MCF_NOUT] = {"Tz", "tleaf", "relhum", "soilm", "windspeed", "Rdirdown", "Rdifdown",
                                        "Rlwdown", "Rswup", "Rlwup"};
     mcf_outputs res;
