@@ -36,6 +36,7 @@ S.runmicrosnow1(dict(g, obstime={k: v[:240] for k, v in g["obstime"].items()}, c
                      pointm={k: v[:240] for k, v in sw["pointm"].items()}),
                 {"obstime": {k: v[:240] for k, v in sw["obstime"].items()}, "climdata": {k: v[:240] for k, v in sw["climdata"].items()},
                  "vegp": sw["vegp"], "other": sw["other"]}, 7.5)          # warm-up: library, clocks
+print("inputs made, library warm", flush=True)
 t = time.perf_counter()
 with S.SnowRun(g, snow) as run:
     sd, nd = run.pass1()
@@ -46,12 +47,16 @@ dt = time.perf_counter() - t
 valid = int(np.isfinite(dtm).sum())
 gb = sum(v.nbytes for v in got.values()) / 1e9
 print(f"{a.rows} x {a.cols} x {a.days} days, outputs {want}: {dt:.2f} s ({t1 - t:.2f} s pass 1) = {valid * T / dt:.3e} cell-steps/s, "
-      f"{gb:.1f} GB into host arrays; snow days {int(sd.sum())}, no-snow days {int(nd.sum())}, {st}")
+      f"{gb:.1f} GB into host arrays; snow days {int(sd.sum())}, no-snow days {int(nd.sum())}, {st}", flush=True)
 if a.keep_gb > 0:
     # (an output array of a 1024^2 year is 73.5 GB of host memory: only ONE set is alive at a time — the unkept run's is reduced
     # to a 64-bit digest per variable first; the box allows a command 270 GB)
-    import hashlib
-    digest = lambda d: {k: hashlib.sha256(np.ascontiguousarray(v).view(np.uint8)).hexdigest()[:16] for k, v in d.items()}      # noqa: E731
+    def digest(d):       # (xor and wrapping sum of the 64-bit patterns: bitwise equality up to collisions, at memory speed)
+        out = {}
+        for k, v in d.items():
+            u = np.ascontiguousarray(v).reshape(-1).view(np.uint64)
+            out[k] = (int(np.bitwise_xor.reduce(u)), int(np.add.reduce(u, dtype=np.uint64)))
+        return out
     ref = digest(got)
     del got
     with S.SnowRun(g, snow) as run:
@@ -66,4 +71,4 @@ if a.keep_gb > 0:
             same = digest(got2) == ref
             del got2
             print(f"  keep {a.keep_gb:g} GB, year {year} of one handle: {dt:.2f} s ({t1 - t:.2f} s pass 1) = {valid * T / dt:.3e} cell-steps/s, {st2}; "
-                  f"outputs bitwise the unkept run's: {same}")
+                  f"outputs bitwise the unkept run's: {same}", flush=True)
