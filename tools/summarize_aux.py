@@ -3,26 +3,33 @@
 profiles/<tag>_aux_pmc_summary.json: per kernel the mean duration, VALU instructions per lane and the VALU-busy fraction."""
 import csv
 import glob
+import os
 import json
 import shutil
 import sys
 from collections import defaultdict
 from pathlib import Path
 
+
+def newest(pattern):
+    """the files of the LATEST run matching the pattern: gpurun merges a repeated call's output next to the earlier one's"""
+    fs = glob.glob(pattern)
+    return [max(fs, key=os.path.getmtime)] if fs else []
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = Path(__file__).resolve().parents[1]
 src = root / "gpurun_out" / f"prof_{tag}_aux"
 dst = root / "profiles"
-st = glob.glob(str(src / "trace" / "*" / "*_kernel_stats.csv"))
+st = newest(str(src / "trace" / "*" / "*_kernel_stats.csv"))
 if st:
     shutil.copy(st[0], dst / f"{tag}_aux_kernel_stats.csv")
 agg = defaultdict(lambda: defaultdict(list))
 dur = defaultdict(list)
 for d in ("pmc_sq", "pmc_misc", "pmc_fetch", "pmc_write"):
-    for f in glob.glob(str(src / d / "*" / "*_counter_collection.csv")):
+    for f in newest(str(src / d / "*" / "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for f in glob.glob(str(src / d / "*" / "*_kernel_trace.csv")):
+    for f in newest(str(src / d / "*" / "*_kernel_trace.csv")):
         if d == "pmc_misc":
             for r in csv.DictReader(open(f)):
                 dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)

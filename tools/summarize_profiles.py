@@ -5,11 +5,18 @@ k_solve and profiles/traffic.json (HBM bytes per launch, gfx950 FETCH_SIZE corre
 as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes: FETCH_SIZE x2, WRITE_SIZE as is)."""
 import csv
 import glob
+import os
 import json
 import shutil
 import sys
 from collections import defaultdict
 from pathlib import Path
+
+
+def newest(pattern):
+    """the files of the LATEST run matching the pattern: gpurun merges a repeated call's output next to the earlier one's"""
+    fs = glob.glob(pattern)
+    return [max(fs, key=os.path.getmtime)] if fs else []
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = Path(__file__).resolve().parents[1]
@@ -17,7 +24,7 @@ src = root / "gpurun_out" / f"prof_{tag}"
 dst = root / "profiles"
 dst.mkdir(exist_ok=True)
 
-stats = glob.glob(str(src / "trace" / "*" / "*_kernel_stats.csv"))
+stats = newest(str(src / "trace" / "*" / "*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], dst / f"{tag}_bench_kernel_stats.csv")
 for name in ("bench_under_rocprof.json", "bench.json"):
@@ -29,7 +36,7 @@ dur = {}
 kname = "k_solve"
 nlaunch = 0
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc"):
-    cc = glob.glob(str(src / d / "*" / "*_counter_collection.csv"))
+    cc = newest(str(src / d / "*" / "*_counter_collection.csv"))
     if not cc:
         continue
     agg = defaultdict(list)
@@ -40,7 +47,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc"):
     for k, v in agg.items():
         pmc[k] = sum(v) / len(v)
         nlaunch = len(v)
-    kt = glob.glob(str(src / d / "*" / "*_kernel_trace.csv"))[0]
+    kt = newest(str(src / d / "*" / "*_kernel_trace.csv"))[0]
     ds = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(kt))
           if "k_solve<" in r["Kernel_Name"]]
     dur[d] = sum(ds) / len(ds)
