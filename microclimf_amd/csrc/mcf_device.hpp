@@ -69,9 +69,14 @@ enum CellField : int {
     // canopy extinction (cpp:104-132)
     CF_XX, CF_KDENINV,
     // two-stream diffuse constants (cpp:134-162, 1034-1084)
-    CF_PAIT, CF_OM, CF_JDEL, CF_GMA, CF_GMA2, CF_AGM, CF_AGM2, CF_U1, CF_U2, CF_H, CF_S1, CF_INVS1,
-    CF_INVD1, CF_INVD2, CF_GREF, CF_GMAGREF, CF_LOGCLUMP, CF_LOGGI, CF_TRDN, CF_TRDU, CF_AMX,
-    CF_EHP, CF_PAIAA, CF_EHPA, CF_EMHPA, CF_ALBD, CF_RDDNG, CF_RDDNZ, CF_RDUPZ, CF_SVFA,
+    // (KA1 .. KZ2, round 5.  The direct-beam coefficients p6, p7, p9, p10 (cpp:164-185) are linear in two per-step values each —
+    // p6 = v1 k6a - g k6b, p7 = g k7b - v1 k7a with g = S2 v2; p9 = -(p8s k9a + w), p10 = p8s k10a + w with w = v3 / D2 — with
+    // per-CELL factors k.. = (1/D1 | 1/D2) exp(-+h pait) (u -+ h | a + gma -+ h), and they are only ever used in four sums weighted
+    // by per-cell exponentials (cpp:1102-1117): p6 + p7, p6 e^(-h paiaa) + p7 e^(+h paiaa), p9 S1 + p10 e^(h pait),
+    // p9 e^(-h paiaa) + p10 e^(+h paiaa).  Multiplied out once per cell, each sum is two fmas of (v1, g) or (p8s, w).)
+    CF_PAIT, CF_OM, CF_JDEL, CF_GMA, CF_GMA2, CF_AGM, CF_AGM2, CF_U1, CF_U2, CF_KA1, CF_KA2, CF_KB1, CF_KB2, CF_KG1, CF_KG2, CF_KZ1,
+    CF_KZ2, CF_INVD2, CF_GREF, CF_GMAGREF, CF_LOGCLUMP, CF_LOGGI, CF_TRDN, CF_TRDU, CF_AMX,
+    CF_PAIAA, CF_ALBD, CF_RDDNG, CF_RDDNZ, CF_RDUPZ, CF_SVFA,
     CF_HOM, CF_HOMP,
     // long wave (cpp:1165-1175)
     CF_TSV, CF_OMTRDIF,
@@ -1198,11 +1203,9 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const SL& S, con
             // ---- section C operands: extinction + direct-beam two-stream coefficients
             double t_tan2c = T(TF_TAN2C), t_cosc = T(TF_COSC);
             double c_xx = C(CF_XX), c_kdeninv = C(CF_KDENINV), om = C(CF_OM), gma = C(CF_GMA), agm = C(CF_AGM),
-                   u1 = C(CF_U1), u2 = C(CF_U2), h = C(CF_H), S1 = C(CF_S1), c_gma2 = C(CF_GMA2),
-                   c_agm2 = C(CF_AGM2), c_jdel = C(CF_JDEL), c_pait = C(CF_PAIT), c_invd1 = C(CF_INVD1),
-                   c_invs1 = C(CF_INVS1), c_invd2 = C(CF_INVD2), c_gmagref = C(CF_GMAGREF);
-            pin(t_tan2c, t_cosc, c_xx, c_kdeninv, om, gma, agm, u1, u2, h, S1, c_gma2, c_agm2, c_jdel, c_pait,
-                c_invd1, c_invs1, c_invd2, c_gmagref);
+                   u1 = C(CF_U1), u2 = C(CF_U2), c_gma2 = C(CF_GMA2),
+                   c_agm2 = C(CF_AGM2), c_jdel = C(CF_JDEL), c_pait = C(CF_PAIT), c_invd2 = C(CF_INVD2), c_gmagref = C(CF_GMAGREF);
+            pin(t_tan2c, t_cosc, c_xx, c_kdeninv, om, gma, agm, u1, u2, c_gma2, c_agm2, c_jdel, c_pait, c_invd2, c_gmagref);
             // canopy extinction, cpp:104-132
             double k = fsqrt(c_xx + t_tan2c) * c_kdeninv;
             if (flags & (FL_XONE | FL_XINF | FL_XZERO))
@@ -1223,21 +1226,24 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const SL& S, con
             double v1 = ss - (p5 * (agm + kd)) * isig;
             double v2 = ss - gma - p5s * (u1 + kd);
             double gS2v2 = S2 * v2;
-            double p6 = c_invd1 * ((v1 * c_invs1) * (u1 - h) - (agm - h) * gS2v2);
-            double p7 = -c_invd1 * ((v1 * S1) * (u1 + h) - (agm + h) * gS2v2);
             double p8 = sstr * (agm + kd) - gma * ss;
             double p8s = -p8 * isig;  // p8 / (-sig)
             double v3 = (sstr + c_gmagref - p8s * (u2 - kd)) * S2;
-            double p9 = -c_invd2 * ((p8s * c_invs1) * (u2 + h) + v3);
-            double p10 = c_invd2 * ((p8s * S1) * (u2 - h) + v3);
+            const double dv3 = c_invd2 * v3;
             // ---- section D operands: gap transmissions and fluxes
             double c_logclump = C(CF_LOGCLUMP), c_loggi = C(CF_LOGGI), amx = C(CF_AMX), trdn = C(CF_TRDN),
-                   trdu = C(CF_TRDU), c_ehp = C(CF_EHP), c_paiaa = C(CF_PAIAA), emhpa = C(CF_EMHPA),
-                   ehpa = C(CF_EHPA), c_rddng = C(CF_RDDNG), c_albd = C(CF_ALBD), c_rddnz = C(CF_RDDNZ),
+                   trdu = C(CF_TRDU), c_paiaa = C(CF_PAIAA), c_rddng = C(CF_RDDNG), c_albd = C(CF_ALBD), c_rddnz = C(CF_RDDNZ),
                    c_rdupz = C(CF_RDUPZ);
+            // (array forcing holds its time values in registers and sits at its register limit: there the eight factors are read
+            // where they are used, a pair at a time, instead of in this batch)
+            constexpr bool late_k = TM::in_registers;
+            double ka1 = late_k ? 0.0 : C(CF_KA1), ka2 = late_k ? 0.0 : C(CF_KA2), kb1 = late_k ? 0.0 : C(CF_KB1),
+                   kb2 = late_k ? 0.0 : C(CF_KB2), kg1 = late_k ? 0.0 : C(CF_KG1), kg2 = late_k ? 0.0 : C(CF_KG2),
+                   kz1 = late_k ? 0.0 : C(CF_KZ1), kz2 = late_k ? 0.0 : C(CF_KZ2);
             double Rbeam = T(TF_RBEAM), Rb = T(TF_RB);
-            pin(c_logclump, c_loggi, amx, trdn, trdu, c_ehp, c_paiaa, emhpa, ehpa, c_rddng, c_albd, c_rddnz,
-                c_rdupz, Rbeam, Rb);
+            if (late_k) pin(c_logclump, c_loggi, amx, trdn, trdu, c_paiaa, c_rddng, c_albd, c_rddnz, c_rdupz, Rbeam, Rb);
+            else pin(c_logclump, c_loggi, amx, trdn, trdu, c_paiaa, c_rddng, c_albd, c_rddnz, c_rdupz, ka1, ka2, kb1, kb2, kg1, kg2, kz1,
+                     kz2, Rbeam, Rb);
             // gap transmissions, cpp:1095-1100
             // (F: an exponential is never negative — the floors at 0 cannot bind on a regular lane)
             double trbn = fexp(Kc * c_logclump, K);
@@ -1246,20 +1252,24 @@ __device__ __forceinline__ void pass1(const CL& C, const TM& T, const SL& S, con
             double trb = fexp(Kc * c_loggi, K);
             cap<F>(trb, 0.999, cn);
             if (!F) flr<F>(trb, 0.0, cn);
-            double albb = (1.0 - trdn * trbn) * (p5s + p6 + p7) + trdn * trbn * gref;      // cpp:1102
+            if (late_k) { ka1 = C(CF_KA1); ka2 = C(CF_KA2); }
+            double albb = (1.0 - trdn * trbn) * (p5s + (v1 * ka1 + gS2v2 * ka2)) + trdn * trbn * gref;      // cpp:1102: p5s + p6 + p7
             if (F) cn.watch(albb);        // 1/sig, 1/D1, 1/D2 products: NaN if a two-stream denominator vanishes
             cap<F>(albb, amx, cn);
             flr<F>(albb, 0.01, cn);
-            double Rdbdn_g = (1.0 - trbn) * (p8s * S2 + p9 * S1 + p10 * c_ehp);            // cpp:1106
+            if (late_k) { kg1 = C(CF_KG1); kg2 = C(CF_KG2); }
+            double Rdbdn_g = (1.0 - trbn) * (p8s * (S2 + kg1) + dv3 * kg2);                // cpp:1106: p8s S2 + p9 S1 + p10 e^(h pait)
             if (F) cn.watch(Rdbdn_g);
             cap<F>(Rdbdn_g, amx, cn);
             flr<F>(Rdbdn_g, 0.0, cn);
             double S2a = fexp(-kd * c_paiaa, K);
-            double Rdbup_z = (1.0 - trdu * trbn) * (p5s * S2a + p6 * emhpa + p7 * ehpa) + trdu * trbn * gref;
+            if (late_k) { kb1 = C(CF_KB1); kb2 = C(CF_KB2); }
+            double Rdbup_z = (1.0 - trdu * trbn) * (p5s * S2a + (v1 * kb1 + gS2v2 * kb2)) + trdu * trbn * gref;
             // (the same p5s, p6, p7 with finite weights: watched through albb)
             cap<F>(Rdbup_z, amx, cn);
             flr<F>(Rdbup_z, 0.0, cn);
-            double Rdbdn_z = (1.0 - trb) * (p8s * S2a + p9 * emhpa + p10 * ehpa);           // cpp:1117
+            if (late_k) { kz1 = C(CF_KZ1); kz2 = C(CF_KZ2); }
+            double Rdbdn_z = (1.0 - trb) * (p8s * (S2a + kz1) + dv3 * kz2);                 // cpp:1117
             // (p8s, p9, p10: watched through Rdbdn_g)
             cap<F>(Rdbdn_z, amx, cn);
             flr<F>(Rdbdn_z, 0.0, cn);
@@ -1579,7 +1589,9 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
         const double lwabs = 0.97 * 0.5 * (lwup + lwdn);
         // radLsw / radLpar are set to exactly 0 at night and for pai == 0 (cpp:1151-1162); written this
         // way a NaN leaf reflectance stays confined to the daytime values, as in the reference
-        const bool lit = rsw > 0.0 && (flags & FL_PAI);
+        // (F: X is exactly 0 at night and for bare ground — pass 1 sets it only inside `rsw > 0 && pai > 0` — and the reflectance finite,
+        // so the products below ARE the selected values: same bits, no compare and selects)
+        const bool lit = F || (rsw > 0.0 && (flags & FL_PAI));
         const double leafabs = (lit ? c_hom * cy.X : 0.0) + lwabs;   // radLsw + lwabs
         double gh = (0.135 * 1.4) * fsqrt_m(uz * invleafd);
         const double RnetL = leafabs - lwcan;                // cpp:1319 with tc = Tcan
@@ -1639,9 +1651,17 @@ __device__ __forceinline__ void pass2(const CL& C, const TM& T, const SL& S, con
         const double HC = 29.3 * gHa * (Tcan - tc);
         const double ecw = (esTcan - ea) * surfwet;          // shared with the canopy-top vapour pressure below
         const double LC = mC * ecw;
+        // (whether the canopy top lies above d + zh is a property of the CELL: a wave whose cells all do — vegetation always
+        // does — takes the profile form without the per-lane selects; same operations per lane either way)
         bool prof2 = (flags & FL_ABOVE2) != 0;
-        const double Th = prof2 ? tc + (Tcan - tc) * w2 : Tcan;
-        const double eh = prof2 ? ea + ecw * w2 : ea + ecw;
+        double Th, eh;
+        if (F && __builtin_amdgcn_ballot_w64(!prof2) == 0) {
+            Th = tc + (Tcan - tc) * w2;
+            eh = ea + ecw * w2;
+        } else {
+            Th = prof2 ? tc + (Tcan - tc) * w2 : Tcan;
+            eh = prof2 ? ea + ecw * w2 : ea + ecw;
+        }
         // ---- Lagrangian near/far field, cpp:1365-1409 ---------------------------------------------
         const double z = g.reqhgt2;
         if (!PAIR) muR = frcp(C(CF_A2H) * uf);

@@ -140,9 +140,9 @@ __device__ inline double rh_integral(double h, double z) {
 __device__ constexpr int field_reader_class(int f) {
     switch (f) {
     case CF_XX: case CF_KDENINV: return 0;          // also read by pass 2's canopy conductance for every cell
-    case CF_OM: case CF_JDEL: case CF_GMA: case CF_GMA2: case CF_AGM: case CF_AGM2: case CF_U1: case CF_U2: case CF_H:
-    case CF_S1: case CF_INVS1: case CF_INVD1: case CF_INVD2: case CF_GMAGREF: case CF_LOGCLUMP: case CF_LOGGI: case CF_TRDN:
-    case CF_TRDU: case CF_AMX: case CF_EHP: case CF_PAIAA: case CF_EHPA: case CF_EMHPA: case CF_ALBD: case CF_RDDNG:
+    case CF_OM: case CF_JDEL: case CF_GMA: case CF_GMA2: case CF_AGM: case CF_AGM2: case CF_U1: case CF_U2:
+    case CF_KA1: case CF_KA2: case CF_KB1: case CF_KB2: case CF_KG1: case CF_KG2: case CF_KZ1: case CF_KZ2: case CF_INVD2: case CF_GMAGREF: case CF_LOGCLUMP: case CF_LOGGI: case CF_TRDN:
+    case CF_TRDU: case CF_AMX: case CF_PAIAA: case CF_ALBD: case CF_RDDNG:
     case CF_RDDNZ: case CF_RDUPZ: case CF_PAIT: case CF_SHADEFAC:
         return 1;
     case CF_EMG: case CF_EMA: case CF_INVLEAFD: case CF_HOM: case CF_HOMP: case CF_OML2: case CF_HGT: case CF_A2H:
@@ -244,12 +244,21 @@ __global__ __launch_bounds__(256) void k_cell_setup(CellSetupArgs a) {
     if (isnan(omp)) flags |= FL_OMPNAN;
     put(CF_PAIT, pait); put(CF_OM, om); put(CF_JDEL, J * del); put(CF_GMA, gma); put(CF_GMA2, gma * gma);
     put(CF_AGM, aa + gma); put(CF_AGM2, (aa + gma) * (aa + gma)); put(CF_U1, u1); put(CF_U2, u2);
-    put(CF_H, h); put(CF_S1, S1); put(CF_INVS1, 1.0 / S1); put(CF_INVD1, 1.0 / D1); put(CF_INVD2, 1.0 / D2);
+    put(CF_INVD2, 1.0 / D2);
+    {   // the direct-beam coefficients' per-cell factors and their four weighted sums (mcf_device.hpp CF_KA1 ..)
+        const double id1 = 1.0 / D1, id2 = 1.0 / D2, is1 = 1.0 / S1, agm = aa + gma;
+        const double k6a = (id1 * is1) * (u1 - h), k6b = id1 * (agm - h), k7a = (id1 * S1) * (u1 + h), k7b = id1 * (agm + h);
+        const double k9a = (id2 * is1) * (u2 + h), k10a = (id2 * S1) * (u2 - h);
+        put(CF_KA1, k6a - k7a); put(CF_KA2, k7b - k6b);                                         // p6 + p7
+        put(CF_KB1, k6a * emhpa - k7a * ehpa); put(CF_KB2, k7b * ehpa - k6b * emhpa);           // p6 e^(-h paiaa) + p7 e^(h paiaa)
+        put(CF_KG1, k10a * ehp - k9a * S1); put(CF_KG2, ehp - S1);                              // p9 S1 + p10 e^(h pait)
+        put(CF_KZ1, k10a * ehpa - k9a * emhpa); put(CF_KZ2, ehpa - emhpa);                      // p9 e^(-h paiaa) + p10 e^(h paiaa)
+    }
     put(CF_GREF, gref); put(CF_GMAGREF, gma * gref); // pow(clump, Kc) is evaluated as exp(Kc*log(clump)); log(0) = -inf is stored as -1e5 so that
     // the product stays finite (exp still underflows to exactly 0, as pow(0, Kc) does)
     put(CF_LOGCLUMP, fmax(log(clump), -1e5)); put(CF_LOGGI, fmax(log(gi), -1e5));
-    put(CF_TRDN, trdn); put(CF_TRDU, trdu); put(CF_AMX, amx); put(CF_EHP, ehp); put(CF_PAIAA, paiaa);
-    put(CF_EHPA, ehpa); put(CF_EMHPA, emhpa); put(CF_ALBD, albd); put(CF_RDDNG, Rddn_g);
+    put(CF_TRDN, trdn); put(CF_TRDU, trdu); put(CF_AMX, amx); put(CF_PAIAA, paiaa);
+    put(CF_ALBD, albd); put(CF_RDDNG, Rddn_g);
     put(CF_RDDNZ, Rddn_z); put(CF_RDUPZ, Rdup_z);
     const double svfa = a.svfa[c];
     put(CF_SVFA, svfa);
