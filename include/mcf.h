@@ -252,6 +252,18 @@ int mcf_plan_run_days_at(mcf_plan *plan, int32_t day0, int32_t ndays, int32_t sl
  * under snow for the whole run of days are dead — mcf_snowplan_covered_tiles finds those tiles.  skip_tile = NULL: all. */
 int mcf_plan_run_days_masked(mcf_plan *plan, int32_t day0, int32_t ndays, int32_t slot, int32_t slot_day0,
                              const uint8_t *skip_tile, int64_t n_tiles);
+/* ... and for a SUBSET of the CELLS (vector forcing, reqhgt >= 0): need_cell — DEVICE memory on the plan's device, complete when
+ * the call is made, one byte per cell of the column-major raster (n_cells = rows x cols) — marks the cells whose values of these
+ * days are wanted; every other cell's values in the slot stay as they are.  The marked cells are gathered into dense tiles of
+ * their own (their constants copied from the plan's tiles; the cells of the plan's regular tiles and those of its other tiles
+ * apart, so that every cell meets the instantiation it meets in a launch of the plan's own tiles), solved into a ring of their
+ * own and copied to their places in the slot: the same bits as mcf_plan_run_days_at's.  Where tiles are the unit (mcf_plan_run_days_masked) one snow-free cell keeps its
+ * whole 21-cell tile in the launch; on a day that is both a snow day and a no-snow day the cells the merge of `.runmicrosnow1`
+ * (R/internal.R:3632-3655) keeps from the no-snow model are a few per cent scattered over most tiles —
+ * mcf_snowplan_free_cells finds them.  *n_gathered (may be NULL) = marked cells.  Memory: the gathered tiles' constants, and
+ * their ring for as many of the days at a time as an eighth of the plan's ring holds (MCF_CELLS_RING_GB overrides). */
+int mcf_plan_run_days_cells(mcf_plan *plan, int32_t day0, int32_t ndays, int32_t slot, int32_t slot_day0,
+                            const uint8_t *need_cell, int64_t n_cells, int64_t *n_gathered);
 /* Vector forcing: replace the series' maximum air temperature (src/microclimfCpp.cpp:2159-2168; it caps the
  * Penman-Monteith temperature excess, cpp:1236).  The snow branch solves a SUBSET of the days and the reference takes
  * the maximum over that subset. */
@@ -708,6 +720,13 @@ int mcf_snowplan_micro_setup(mcf_snowplan *plan, const mcf_snow_inputs *subset, 
  * solver plan holds an output gridmicrosnow1's `out` mask leaves to the solver.  *n_covered = number of ones. */
 int mcf_snowplan_covered_tiles(mcf_snowplan *plan, mcf_plan *solver, int32_t chunk, int32_t day, int32_t ndays,
                                uint8_t *skip_tile, int64_t n_tiles, int64_t *n_covered);
+/* The same question per cell, answered on the device: (*need_cell)[c] = 1 where cell c is NOT under snow at every step of
+ * those days, or has no vegetation height (gridmicrosnow1 skips it) — the cells whose solver values survive the merge —, 0
+ * elsewhere; all 1 when the solver plan holds an output gridmicrosnow1's `out` mask leaves to the solver.  *need_cell is device
+ * memory of the snow plan (valid until the next call, complete on return), for mcf_plan_run_days_cells; *n_need = number of
+ * ones. */
+int mcf_snowplan_free_cells(mcf_snowplan *plan, mcf_plan *solver, int32_t chunk, int32_t day, int32_t ndays,
+                            const uint8_t **need_cell, int64_t *n_need);
 int mcf_snowplan_microsnow(mcf_snowplan *plan, mcf_plan *solver, int32_t chunk, int32_t slot,
                            const int32_t *nosnowday /* [days of the chunk] */);
 

@@ -179,7 +179,7 @@ EXPORTS = (
     "mcf_plan_set_twi_mean", "mcf_plan_upload_forcing_days", "mcf_plan_run_days",
     "mcf_plan_belowground", "mcf_plan_sync", "mcf_plan_fetch", "mcf_plan_fetch_cells", "mcf_plan_fetch_packed", "mcf_plan_slot_ptr",
     "mcf_plan_ring_layout", "mcf_ring_index", "mcf_plan_run_days_at", "mcf_plan_run_days_masked", "mcf_plan_set_mxtc",
-    "mcf_snowplan_covered_tiles",
+    "mcf_snowplan_covered_tiles", "mcf_plan_run_days_cells", "mcf_snowplan_free_cells",
     "mcf_runmicro1_multi", "mcf_runmicro2_multi", "mcf_runmicro3_multi", "mcf_runmicro4_multi", "mcf_plan_fetch_pitched",
     "mcf_snowplan_reset", "mcf_snowplan_checkpoint", "mcf_snowplan_restore", "mcf_snowplan_fetch_cells", "mcf_snowplan_keep_chunk", "mcf_snowplan_can_keep", "mcf_snowplan_set_keep_budget", "mcf_plan_set_mxtc_days", "mcf_snowplan_set_series",
     "mcf_snowplan_release_kept", "mcf_snowplan_meand_accumulate", "mcf_snowplan_micro_setup", "mcf_snowplan_microsnow",
@@ -332,6 +332,10 @@ def load() -> C.CDLL:
         lib.mcf_plan_run_days_masked.argtypes = [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint8), C.c_int64]
         lib.mcf_snowplan_covered_tiles.restype = C.c_int
         lib.mcf_snowplan_covered_tiles.argtypes = [P, P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint8), C.c_int64, C.POINTER(C.c_int64)]
+        lib.mcf_plan_run_days_cells.restype = C.c_int
+        lib.mcf_plan_run_days_cells.argtypes = [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        lib.mcf_snowplan_free_cells.restype = C.c_int
+        lib.mcf_snowplan_free_cells.argtypes = [P, P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         lib.mcf_snowplan_microsnow.restype = C.c_int
         lib.mcf_snowplan_microsnow.argtypes = [P, P, C.c_int32, C.c_int32, c_int32_p]
     lib.mcf_plan_belowground.restype = C.c_int

@@ -236,6 +236,15 @@ class Plan:
         _abi.check(self._lib.mcf_plan_run_days_masked(self._p, day0, ndays, slot, slot_day0, sk.ctypes.data_as(C.POINTER(C.c_uint8)),
                                                       int(sk.size)))
 
+    def run_days_cells(self, day0: int, ndays: int, slot: int, slot_day0: int, need_cell_dev: int) -> int:
+        """run_days_at for the cells marked in `need_cell_dev` — the ADDRESS of one byte per cell in this device's memory, e.g.
+        SnowPlan.free_cells' or a torch uint8 tensor's data_ptr() — gathered into tiles of their own; every other cell's values
+        in the slot stay (include/mcf.h mcf_plan_run_days_cells).  -> number of marked cells"""
+        n = C.c_int64(0)
+        _abi.check(self._lib.mcf_plan_run_days_cells(self._p, day0, ndays, slot, slot_day0, C.c_void_p(int(need_cell_dev)),
+                                                     int(self.rows * self.cols), C.byref(n)))
+        return int(n.value)
+
     @property
     def n_tiles(self) -> int:
         lay = self.ring_layout()

@@ -101,6 +101,20 @@ struct mcf_plan {
     std::vector<int32_t> h_tiles_fast, h_tiles_slow, h_tiles_sub;
     int32_t* d_tiles_sub = nullptr;
     int64_t tiles_sub_cap = 0, masked_tiles_skipped = 0;
+    // mcf_plan_run_days_cells: the cells' classes, the per-256-cell counts / list offsets, the list of gathered cells, the
+    // gathered tiles' images and their ring (grown as needed)
+    uint8_t* d_cls = nullptr;
+    uint8_t* d_tile_regular = nullptr;      // [ntiles] 1: a tile of the fast list (null: no fast list)
+    int32_t *d_blockcnt = nullptr, *d_celllist = nullptr;
+    double *d_subimg = nullptr, *d_subring = nullptr;
+    int64_t cls_cap = 0, blockcnt_cap = 0, celllist_cap = 0, subimg_cap = 0, subring_cap = 0;      // bytes
+    std::vector<int32_t> h_blockcnt, h_cells_slow;
+    int32_t* d_cells_slow = nullptr;
+    int64_t cells_slow_cap = 0;
+    hipStream_t prep = nullptr;              // the list is made beside the plan's stream, which is not drained for it
+    hipEvent_t ev_prep = nullptr, ev_cells_done = nullptr;
+    bool cells_inflight = false;
+    int64_t cells_runs = 0, cells_gathered = 0;
     int64_t n_fast = 0, n_slow = 0, tiles_cap = 0;
     int32_t *d_fix_count = nullptr, *d_fix_list = nullptr;
     int fix_cap = 8192;
@@ -170,6 +184,24 @@ int dalloc(mcf_plan* p, void** ptr, int64_t nbytes) {
     p->allocs.push_back(*ptr);
     p->bytes += nbytes;
     return MCF_OK;
+}
+
+// a buffer that grows: the old one is released first.  A buffer that has to grow gets a quarter more than is asked for — the
+// sets of cells of successive calls differ by little, and a release + allocation of a gigabyte costs 50 ms
+int dregrow(mcf_plan* p, void** ptr, int64_t* cap, int64_t nbytes) {
+    if (*ptr && *cap >= nbytes) return MCF_OK;
+    if (*ptr) nbytes += nbytes / 4;
+    if (*ptr) {
+        for (size_t i = 0; i < p->allocs.size(); ++i)
+            if (p->allocs[i] == *ptr) { p->allocs.erase(p->allocs.begin() + (long)i); break; }
+        (void)hipFree(*ptr);
+        p->bytes -= *cap;
+        *ptr = nullptr;
+        *cap = 0;
+    }
+    const int rc = dalloc(p, ptr, nbytes);
+    if (!rc) *cap = std::max<int64_t>(nbytes, 8);
+    return rc;
 }
 
 // variable `var` (requested) of ring slot `slot` as its consumers address it
@@ -311,8 +343,13 @@ int ensure_cells(mcf_plan* p) {
             if ((rc = dalloc(p, &q, (int64_t)p->fix_cap * 8))) return rc;
             p->d_fix_list = (int32_t*)q;
         }
-        // tile classes: the fast list borrows d_tiles_fast as the device-side byte scratch first
-        uint8_t* d_flag = (uint8_t*)p->d_tiles_fast;
+        // tile classes (the flags stay on the device for mcf_plan_run_days_cells)
+        if (!p->d_tile_regular) {
+            void* q;
+            if ((rc = dalloc(p, &q, ntiles))) return rc;
+            p->d_tile_regular = (uint8_t*)q;
+        }
+        uint8_t* d_flag = p->d_tile_regular;
         mcf::launch_tile_regular(p->d_cellc, p->N, p->layers, p->cpb, d_flag, p->stream);
         HIP_TRY(hipGetLastError());
         std::vector<uint8_t> flag((size_t)ntiles);
@@ -419,6 +456,9 @@ void mcf_plan_destroy(mcf_plan* p) {
     if (!p) return;
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
+    if (p->prep) { hipStreamSynchronize(p->prep); hipStreamDestroy(p->prep); }
+    if (p->ev_prep) hipEventDestroy(p->ev_prep);
+    if (p->ev_cells_done) hipEventDestroy(p->ev_cells_done);
     for (auto& e : p->kev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (void* a : p->allocs) hipFree(a);
     delete p->pipe;
@@ -879,12 +919,11 @@ int mcf_plan_run_days_at(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot,
     return mcf_plan_run_days_masked(p, day0, ndays, slot, slot_day0, nullptr, 0);
 }
 
-int mcf_plan_run_days_masked(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot, int32_t slot_day0, const uint8_t* skip_tile,
-                             int64_t n_skip_tile) {
-    if (!p) return fail(MCF_ERR_ARG, "null plan");
-    if (skip_tile && (p->bg || p->af)) return fail(MCF_ERR_ARG, "a tile mask needs vector forcing and reqhgt >= 0");
-    if (skip_tile && n_skip_tile != (p->ntiles > 0 ? p->ntiles : (p->N + p->cpb - 1) / p->cpb))
-        return fail(MCF_ERR_ARG, "the tile mask's length is not the plan's number of tiles");
+namespace {
+// the launch description of days [day0, day0 + ndays) into `slot` from its day `slot_day0` on — everything but the tile list —,
+// and which instantiation the days allow: `fast` (the min / max clamps: every day regular), `soil_daily` (the per cell-day soil
+// state shared through LDS)
+int solve_args(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot, int32_t slot_day0, mcf::SolveArgs& a, bool& fast, bool& soil_daily) {
     if (slot < 0 || slot >= p->ring_slots) return fail(MCF_ERR_ARG, "slot out of range");
     if (day0 < 0 || ndays < 1 || day0 + ndays > p->ndays) return fail(MCF_ERR_ARG, "day range out of bounds");
     if (!p->bg && (slot_day0 < 0 || slot_day0 + ndays > p->ring_days)) return fail(MCF_ERR_ARG, "more days than the ring slot holds");
@@ -892,7 +931,7 @@ int mcf_plan_run_days_masked(mcf_plan* p, int32_t day0, int32_t ndays, int32_t s
     HIP_TRY(hipSetDevice(p->device));
     int rc = ensure_cells(p);
     if (rc) return rc;
-    mcf::SolveArgs a{};
+    a = mcf::SolveArgs{};
     a.N = p->N;
     a.cellc = p->d_cellc; a.ntiles_total = p->ntiles; a.tt = p->d_tt;
     a.daylayer = p->d_daylayer;
@@ -934,13 +973,27 @@ int mcf_plan_run_days_masked(mcf_plan* p, int32_t day0, int32_t ndays, int32_t s
     }
     a.g = p->g;
     a.fix_count = p->d_fix_count; a.fix_list = p->d_fix_list; a.fix_cap = p->fix_cap;
-    bool fast = p->fast_enabled && p->n_fast > 0;
+    fast = p->fast_enabled && p->n_fast > 0;
     for (int d = day0; fast && !p->af && d < day0 + ndays; ++d)     // array forcing: every lane checks its own forcing values
         if (p->day_irregular[(size_t)d]) fast = false;
-    bool soil_daily = !p->af && !p->day_soil_daily.empty();
+    soil_daily = !p->af && !p->day_soil_daily.empty();
     for (int d = day0; soil_daily && d < day0 + ndays; ++d)
         if (!p->day_soil_daily[(size_t)d]) soil_daily = false;
     if (p->coarse) soil_daily = p->coarse_lds;      // (coarse array forcing: the same launch flag selects the LDS-staged taps)
+    return MCF_OK;
+}
+}  // namespace
+
+int mcf_plan_run_days_masked(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot, int32_t slot_day0, const uint8_t* skip_tile,
+                             int64_t n_skip_tile) {
+    if (!p) return fail(MCF_ERR_ARG, "null plan");
+    if (skip_tile && (p->bg || p->af)) return fail(MCF_ERR_ARG, "a tile mask needs vector forcing and reqhgt >= 0");
+    if (skip_tile && n_skip_tile != (p->ntiles > 0 ? p->ntiles : (p->N + p->cpb - 1) / p->cpb))
+        return fail(MCF_ERR_ARG, "the tile mask's length is not the plan's number of tiles");
+    mcf::SolveArgs a{};
+    bool fast = false, soil_daily = false;
+    int rc = solve_args(p, day0, ndays, slot, slot_day0, a, fast, soil_daily);
+    if (rc) return rc;
     // a tile mask: the launch's tile lists are the plan's minus the masked tiles (the kernel takes any list; a tile it is not
     // given is simply not touched in the slot)
     const int32_t *sub_fast = nullptr, *sub_slow = nullptr;
@@ -1016,6 +1069,127 @@ int mcf_plan_run_days_masked(mcf_plan* p, int32_t day0, int32_t ndays, int32_t s
         launch();
     }
     HIP_TRY(hipGetLastError());
+    return MCF_OK;
+}
+
+int mcf_plan_run_days_cells(mcf_plan* p, int32_t day0, int32_t ndays, int32_t slot, int32_t slot_day0, const uint8_t* need_cell,
+                            int64_t n_cells, int64_t* n_gathered) {
+    if (!p || !need_cell) return fail(MCF_ERR_ARG, "null argument");
+    if (p->bg || p->af || !p->tiled) return fail(MCF_ERR_ARG, "a cell subset needs vector forcing and reqhgt >= 0");
+    if (n_cells != p->N) return fail(MCF_ERR_ARG, "the cell flags' length is not the plan's number of cells");
+    mcf::SolveArgs a{};
+    bool fast = false, soil_daily = false;
+    int rc = solve_args(p, day0, ndays, slot, slot_day0, a, fast, soil_daily);
+    if (rc) return rc;
+    if (n_gathered) *n_gathered = 0;
+    const int64_t N = p->N;
+    const int cpb = p->cpb;
+    const int64_t nb = (N + 255) / 256, IMG = mcf::tile_image_doubles(cpb), blk = mcf::ring_block_doubles(cpb);
+    // The list of cells is made on a stream of its own: the plan's stream — the previous chunk's solver launches, the snow-day
+    // microclimate over them — is not drained for it, only made to wait for the list.  An earlier call's launches and copies may
+    // still read the buffers and host vectors: its last event first.
+    if (!p->prep) {
+        HIP_TRY(hipStreamCreateWithFlags(&p->prep, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&p->ev_prep, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&p->ev_cells_done, hipEventDisableTiming));
+    }
+    const bool trace = getenv("MCF_CELLS_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    if (p->cells_inflight) { HIP_TRY(hipEventSynchronize(p->ev_cells_done)); p->cells_inflight = false; }
+    const double t1 = now();
+    if ((rc = dregrow(p, (void**)&p->d_cls, &p->cls_cap, N))) return rc;
+    if ((rc = dregrow(p, (void**)&p->d_blockcnt, &p->blockcnt_cap, nb * 8))) return rc;
+    // 1. the wanted cells by class, counted per 256 cells; the list offsets are the host's prefix sums of those counts
+    mcf::launch_cells_class(need_cell, p->fast_enabled ? p->d_tile_regular : nullptr, N, cpb, p->d_cls, p->d_blockcnt, p->prep);
+    HIP_TRY(hipGetLastError());
+    std::vector<int32_t>& cnt = p->h_blockcnt;
+    cnt.resize((size_t)nb * 2);
+    HIP_TRY(hipMemcpyAsync(cnt.data(), p->d_blockcnt, (size_t)nb * 8, hipMemcpyDeviceToHost, p->prep));
+    HIP_TRY(hipStreamSynchronize(p->prep));
+    const double t2 = now();
+    int64_t n1 = 0, n2 = 0;
+    for (int64_t b = 0; b < nb; ++b) { n1 += cnt[(size_t)(2 * b)]; n2 += cnt[(size_t)(2 * b + 1)]; }
+    if (n_gathered) *n_gathered = n1 + n2;
+    if (n1 + n2 == 0) return MCF_OK;
+    // the cells of the plan's fast tiles first, in whole tiles; those of its other tiles in tiles of their own behind them: every
+    // cell meets the instantiation it meets in a launch of the plan's own tiles (the two differ in the last bits)
+    const int64_t base2 = (n1 + cpb - 1) / cpb * cpb, total = base2 + (n2 + cpb - 1) / cpb * cpb;
+    const int64_t nt_sub = total / cpb, nt_fast = base2 / cpb, nt_slow = nt_sub - nt_fast;
+    if (total > INT32_MAX) return fail(MCF_ERR_ARG, "too many cells");
+    {
+        int64_t o1 = 0, o2 = base2;
+        for (int64_t b = 0; b < nb; ++b) {
+            const int32_t c1 = cnt[(size_t)(2 * b)], c2 = cnt[(size_t)(2 * b + 1)];
+            cnt[(size_t)(2 * b)] = (int32_t)o1; cnt[(size_t)(2 * b + 1)] = (int32_t)o2;
+            o1 += c1; o2 += c2;
+        }
+    }
+    // (buffers that grow are released first: hipFree waits for the device)
+    if ((rc = dregrow(p, (void**)&p->d_celllist, &p->celllist_cap, total * 4))) return rc;
+    if ((rc = dregrow(p, (void**)&p->d_subimg, &p->subimg_cap, (int64_t)p->layers * nt_sub * IMG * 8))) return rc;
+    const int64_t day_doubles = p->ring_day_stride;                  // variables x block
+    const double budget_gb = getenv("MCF_CELLS_RING_GB") ? atof(getenv("MCF_CELLS_RING_GB")) : 0.0;
+    const int64_t budget = budget_gb > 0.0 ? (int64_t)(budget_gb * 1e9)
+                                           : std::max<int64_t>((int64_t)512 << 20, (int64_t)p->ring_slots * p->slot_elems);       // (bytes: an eighth of the ring)
+    const int pass_days = (int)std::max<int64_t>(1, std::min<int64_t>(ndays, budget / (nt_sub * day_doubles * 8)));
+    if ((rc = dregrow(p, (void**)&p->d_subring, &p->subring_cap, nt_sub * pass_days * day_doubles * 8))) return rc;
+    if (nt_slow > 0 && fast && (rc = dregrow(p, (void**)&p->d_cells_slow, &p->cells_slow_cap, nt_slow * 4))) return rc;
+    const double t3 = now();
+    HIP_TRY(hipMemcpyAsync(p->d_blockcnt, cnt.data(), (size_t)nb * 8, hipMemcpyHostToDevice, p->prep));
+    HIP_TRY(hipMemsetAsync(p->d_celllist, 0xFF, (size_t)total * 4, p->prep));         // -1: no cell (a class's last tile)
+    mcf::launch_cells_place(p->d_cls, N, p->d_blockcnt, p->d_celllist, p->prep);
+    HIP_TRY(hipGetLastError());
+    if (nt_slow > 0 && fast) {          // the second class's tile numbers, for the launch that takes a list
+        std::vector<int32_t>& l = p->h_cells_slow;
+        l.resize((size_t)nt_slow);
+        for (int64_t t = 0; t < nt_slow; ++t) l[(size_t)t] = (int32_t)(nt_fast + t);
+        HIP_TRY(hipMemcpyAsync(p->d_cells_slow, l.data(), l.size() * 4, hipMemcpyHostToDevice, p->prep));
+    }
+    HIP_TRY(hipEventRecord(p->ev_prep, p->prep));
+    HIP_TRY(hipStreamWaitEvent(p->stream, p->ev_prep, 0));
+    // 2. their tiles' images
+    mcf::launch_gather_image(p->d_celllist, nt_sub, p->d_cellc, p->ntiles, p->layers, cpb, p->d_subimg, p->stream);
+    HIP_TRY(hipGetLastError());
+    // 3. the solver on them, into a ring of their own — as many days at a time as the budget holds —, and from there to the
+    // cells' places in the slot
+    a.cellc = p->d_subimg; a.ntiles_total = nt_sub; a.N = total;
+    a.out_base = p->d_subring;
+    a.out_tile_stride = (int64_t)pass_days * day_doubles; a.out_day_stride = day_doubles; a.out_var_stride = blk;
+    a.slot_day0 = 0;
+    double* const slot_base = p->d_ring + (int64_t)slot * p->slot_elems + (int64_t)slot_day0 * p->ring_day_stride;
+    for (int d = 0; d < ndays; d += pass_days) {
+        const int nd = std::min(pass_days, ndays - d);
+        a.day0 = day0 + d; a.ndays = nd;
+        if (fast) {
+            (void)hipMemsetAsync(p->d_fix_count, 0, 4, p->stream);
+            if (nt_fast > 0) {
+                a.tile_list = nullptr; a.ntiles_launch = nt_fast;
+                mcf::launch_solve(a, cpb, false, false, true, soil_daily, p->stream);
+                ++p->fast_launches;
+            }
+            if (nt_slow > 0) {
+                a.tile_list = p->d_cells_slow; a.ntiles_launch = nt_slow;
+                mcf::launch_solve(a, cpb, false, false, false, soil_daily, p->stream);
+                ++p->slow_launches;
+            }
+        } else {
+            a.tile_list = nullptr; a.ntiles_launch = nt_sub;
+            mcf::launch_solve(a, cpb, false, false, false, soil_daily, p->stream);
+            ++p->slow_launches;
+        }
+        HIP_TRY(hipGetLastError());
+        mcf::launch_scatter_cells(p->d_celllist, nt_sub, p->d_subring, a.out_tile_stride, slot_base + (int64_t)d * p->ring_day_stride,
+                                  p->ring_tile_stride, day_doubles, cpb, nd, p->stream);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(p->ev_cells_done, p->stream));
+    if (trace)
+        fprintf(stderr, "[mcf] run_days_cells: %lld cells x %d days; host ms: wait %.3f, class+counts %.3f, offsets+buffers %.3f, enqueue %.3f\n",
+                (long long)(n1 + n2), (int)ndays, t1 - t0, t2 - t1, t3 - t2, now() - t3);
+    p->cells_inflight = true;
+    ++p->cells_runs;
+    p->cells_gathered += (n1 + n2) * ndays;
     return MCF_OK;
 }
 

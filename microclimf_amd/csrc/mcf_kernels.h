@@ -28,6 +28,18 @@ __host__ __device__ inline int ring_pos(int cpb, int cell, int hour) {
     }
     return hour * cpb + cell;
 }
+// ... and back: the (cell, hour) of place `pos` of a block; false for a padding place
+__host__ __device__ inline bool ring_unpos(int cpb, int pos, int* cell, int* hour) {
+    if (cpb == 21) {
+        const int w = pos >> 6, l = pos & 63;
+        if (l < 48) { *cell = l & 15; *hour = 3 * w + (l >> 4); return true; }
+        const int j = l - 48;
+        *cell = 16 + j % 5; *hour = 3 * w + j / 5;
+        return j < 15;
+    }
+    *cell = pos % cpb; *hour = pos / cpb;
+    return pos < 24 * cpb;
+}
 // One variable of one ring slot: value of cell c (0-based, column-major) at step k of the slot.
 //   cpb == 0  linear [step][N] (reqhgt < 0, staging buffers)
 //   cpb  > 0  tiled (k_solve's layout): tile = c / cpb, block of day k / 24 at tile * tile_stride + day * day_stride
@@ -229,6 +241,21 @@ void launch_mxtc(const double* tc, int64_t N, int nsteps, double* mx, hipStream_
 void launch_solve(const SolveArgs& a, int cells_per_block, bool af, bool bg, bool fast, bool soil_daily, hipStream_t s);
 // out[t] = 1 if every valid cell of tile t (cpb consecutive cells) is FL_REGULAR in all layers
 void launch_tile_regular(const double* cellc, int64_t N, int layers, int cpb, uint8_t* out, hipStream_t s);
+// A launch over a SUBSET of the cells (mcf_plan_run_days_cells): the wanted cells gathered into dense tiles of their own.
+//   cells_class  cls[c] = 0 (need[c] == 0) / 1 (wanted, its tile tile_regular — launch_tile_regular's flags; null: all) / 2 (wanted, not);
+//                blockcnt[2 b + k - 1] = cells of class k among cells 256 b .. 256 b + 255
+//   cells_place  list[blockoff[2 b + k - 1] + rank of the cell among its block's class-k cells] = c  (ascending in each class)
+//   gather_image the sub-tiles' images [layers][ntiles_sub][tile_image_doubles] from the plan's; list entry < 0: an all-zero
+//                column (flags 0: not valid)
+//   scatter_cells the sub-ring's values of `ndays` days to the cells' own places in a ring slot (`ring` = the slot's first day
+//                to write); both rings [tile][day][variable][block], `day_doubles` = variables x block
+void launch_cells_class(const uint8_t* need, const uint8_t* tile_regular, int64_t N, int cpb, uint8_t* cls, int32_t* blockcnt,
+                        hipStream_t s);
+void launch_cells_place(const uint8_t* cls, int64_t N, const int32_t* blockoff, int32_t* list, hipStream_t s);
+void launch_gather_image(const int32_t* list, int64_t ntiles_sub, const double* src, int64_t ntiles_src, int layers, int cpb,
+                         double* dst, hipStream_t s);
+void launch_scatter_cells(const int32_t* list, int64_t ntiles_sub, const double* sub, int64_t sub_tile_stride, double* ring,
+                          int64_t tile_stride, int64_t day_doubles, int cpb, int ndays, hipStream_t s);
 void launch_belowground(const BelowArgs& a, hipStream_t s);
 void launch_selftest_math(int kind, const double* x, const double* y, double* out, int64_t n, hipStream_t s);
 

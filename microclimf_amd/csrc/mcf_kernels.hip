@@ -1061,6 +1061,67 @@ __global__ void k_tile_regular(const double* __restrict__ cellc, int64_t N, int 
     out[t] = ok ? 1 : 0;
 }
 
+// ---- a launch over a SUBSET of the cells (mcf_kernels.h launch_cells_*; mcf_api.hip mcf_plan_run_days_cells) ---------------------
+__global__ __launch_bounds__(256) void k_cells_class(const uint8_t* __restrict__ need, const uint8_t* __restrict__ tile_regular, int64_t N,
+                                                     int cpb, uint8_t* __restrict__ cls, int32_t* __restrict__ blockcnt) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int k = 0;
+    if (c < N && need[c]) k = (!tile_regular || tile_regular[c / cpb]) ? 1 : 2;
+    if (c < N) cls[c] = (uint8_t)k;
+    __shared__ int s_n[2];
+    if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t b1 = __ballot(k == 1), b2 = __ballot(k == 2);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_n[0], __popcll(b1)); atomicAdd(&s_n[1], __popcll(b2)); }
+    __syncthreads();
+    if (threadIdx.x < 2) blockcnt[2 * (int64_t)blockIdx.x + threadIdx.x] = s_n[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void k_cells_place(const uint8_t* __restrict__ cls, int64_t N, const int32_t* __restrict__ blockoff,
+                                                     int32_t* __restrict__ list) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int k = c < N ? cls[c] : 0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ int s_w[4][2];
+    const uint64_t b1 = __ballot(k == 1), b2 = __ballot(k == 2);
+    if (lane == 0) { s_w[wave][0] = __popcll(b1); s_w[wave][1] = __popcll(b2); }
+    __syncthreads();
+    if (k) {
+        int r = __popcll((k == 1 ? b1 : b2) & ((1ull << lane) - 1ull));
+        for (int w = 0; w < wave; ++w) r += s_w[w][k - 1];
+        list[(int64_t)blockoff[2 * (int64_t)blockIdx.x + k - 1] + r] = (int32_t)c;
+    }
+}
+__global__ __launch_bounds__(256) void k_gather_image(const int32_t* __restrict__ list, int64_t ntiles_sub, const double* __restrict__ src,
+                                                      int64_t ntiles_src, int layers, int cpb, double* __restrict__ dst) {
+    const int64_t IMG = tile_image_doubles_dev(cpb);
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)layers * ntiles_sub * IMG) return;
+    const int64_t l = i / (ntiles_sub * IMG), rem = i - l * (ntiles_sub * IMG), t = rem / IMG;
+    const int e = (int)(rem - t * IMG), r = e / cpb, j = e - r * cpb;
+    double v = 0.0;
+    if (r < CF_COUNT + kCellDirs) {
+        const int64_t c = list[t * cpb + j];
+        if (c >= 0) v = src[(l * ntiles_src + c / cpb) * IMG + (int64_t)r * cpb + c % cpb];
+    }
+    dst[i] = v;
+}
+// blockIdx.x = sub-tile, blockIdx.y = day: the day's values of every variable, read in the sub-ring's order
+__global__ __launch_bounds__(256) void k_scatter_cells(const int32_t* __restrict__ list, const double* __restrict__ sub,
+                                                       int64_t sub_tile_stride, double* __restrict__ ring, int64_t tile_stride,
+                                                       int64_t day_doubles, int cpb) {
+    const int64_t t = blockIdx.x;
+    const int d = blockIdx.y, blk = ring_block_doubles(cpb);
+    const double* s = sub + t * sub_tile_stride + (int64_t)d * day_doubles;
+    for (int e = threadIdx.x; e < (int)day_doubles; e += 256) {
+        const int v = e / blk, pos = e - v * blk;
+        int j, h;
+        if (!ring_unpos(cpb, pos, &j, &h)) continue;
+        const int64_t c = list[t * cpb + j];
+        if (c < 0) continue;
+        ring[(c / cpb) * tile_stride + (int64_t)d * day_doubles + (int64_t)v * blk + ring_pos(cpb, (int)(c % cpb), h)] = s[e];
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // Tbelowgroundv, cpp:1474-1539; maCpp cpp:561-572; manCpp cpp:597-627; one lane per cell.
 // tg / tz are [N, tsteps] (cell fastest).  scratch is [N, 2*ndays].
@@ -1612,6 +1673,27 @@ static void launch_solve_cpb(SolveArgs a, bool af, bool bg, bool fast, bool ss, 
         if (ss) hipLaunchKernelGGL((k_solve<CPB, 0, false, false, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((k_solve<CPB, 0, false, false, false>), grid, block, 0, s, a);
     }
+}
+void launch_cells_class(const uint8_t* need, const uint8_t* tile_regular, int64_t N, int cpb, uint8_t* cls, int32_t* blockcnt,
+                        hipStream_t s) {
+    if (N <= 0) return;
+    hipLaunchKernelGGL(k_cells_class, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, need, tile_regular, N, cpb, cls, blockcnt);
+}
+void launch_cells_place(const uint8_t* cls, int64_t N, const int32_t* blockoff, int32_t* list, hipStream_t s) {
+    if (N <= 0) return;
+    hipLaunchKernelGGL(k_cells_place, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, cls, N, blockoff, list);
+}
+void launch_gather_image(const int32_t* list, int64_t ntiles_sub, const double* src, int64_t ntiles_src, int layers, int cpb,
+                         double* dst, hipStream_t s) {
+    const int64_t n = (int64_t)layers * ntiles_sub * tile_image_doubles_dev(cpb);
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_gather_image, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, list, ntiles_sub, src, ntiles_src, layers, cpb, dst);
+}
+void launch_scatter_cells(const int32_t* list, int64_t ntiles_sub, const double* sub, int64_t sub_tile_stride, double* ring,
+                          int64_t tile_stride, int64_t day_doubles, int cpb, int ndays, hipStream_t s) {
+    if (ntiles_sub <= 0 || ndays <= 0) return;
+    hipLaunchKernelGGL(k_scatter_cells, dim3((unsigned)ntiles_sub, (unsigned)ndays), dim3(256), 0, s, list, sub, sub_tile_stride, ring,
+                       tile_stride, day_doubles, cpb);
 }
 void launch_tile_regular(const double* cellc, int64_t N, int layers, int cpb, uint8_t* out, hipStream_t s) {
     const int64_t ntiles = (N + cpb - 1) / cpb;

@@ -1506,6 +1506,8 @@ struct mcf_snowplan {
     uint32_t series_mask = 31, series_valid = 0;
     uint8_t* d_tflag = nullptr;          // mcf_snowplan_covered_tiles: one flag per tile of the solver plan
     int64_t tflag_cap = 0;
+    uint8_t* d_need = nullptr;           // mcf_snowplan_free_cells: one flag per cell + an 8-byte count behind them
+    int64_t need_cap = 0;
     // hand-over state at the start of a chunk (mcf_snowplan_checkpoint): isnowdc, the snow surface, the two age matrices
     std::vector<char*> ckpt;
     // series of chunks kept on the device between the two passes (mcf_snowplan_keep_chunk): a kept chunk's buffers are the ones
@@ -2661,6 +2663,66 @@ extern "C" int mcf_snowplan_covered_tiles(mcf_snowplan* sp, mcf_plan* plan, int3
     int64_t n = 0;
     for (int64_t t = 0; t < n_tiles; ++t) n += skip_tile[t] != 0;
     *n_covered = n;
+    return MCF_OK;
+}
+// one lane per cell: 1 where the cell's solver values of the days survive the merge (k_tiles_covered's test, negated)
+__global__ __launch_bounds__(256) void k_cells_free(const double* __restrict__ swe, const double* __restrict__ hgt, int64_t N, int k0,
+                                                    int nsteps, uint8_t* __restrict__ need, unsigned long long* __restrict__ count) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool cov = false;
+    if (c < N) {
+        cov = !isnan(hgt[c]);
+        for (int k = 0; cov && k < nsteps; ++k) cov = swe[c + N * (int64_t)(k0 + k)] > 0.0;
+        need[c] = cov ? 0 : 1;
+    }
+    __shared__ int s_n;                     // (one atomic per workgroup: a wave-level one on a single address serialises the launch)
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint64_t b = __ballot(c < N && !cov);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&s_n, (int)__popcll(b));
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) atomicAdd(count, (unsigned long long)s_n);
+}
+extern "C" int mcf_snowplan_free_cells(mcf_snowplan* sp, mcf_plan* plan, int32_t ch, int32_t day, int32_t ndays, const uint8_t** need_cell,
+                                       int64_t* n_need) {
+    if (!sp || !plan || !need_cell || !n_need) return mcf::api_fail(MCF_ERR_ARG, "null argument");
+    if (!sp->micro_ready) return mcf::api_fail(MCF_ERR_STATE, "snow plan: mcf_snowplan_micro_setup first");
+    if (ch < 0 || ch >= sp->nchunks) return mcf::api_fail(MCF_ERR_ARG, "chunk out of range");
+    const int ns = std::min(sp->chunk, sp->T - ch * sp->chunk);
+    if (day < 0 || ndays < 1 || (day + ndays) * 24 > ns) return mcf::api_fail(MCF_ERR_ARG, "days outside the chunk");
+    hipStream_t stream;
+    int64_t N;
+    int device, slot_days, rc;
+    mcf::RingView views[MCF_NOUT];
+    int32_t has[MCF_NOUT];
+    if ((rc = mcf::plan_ring_views(plan, 0, views, has, &stream, &N, &device, &slot_days))) return rc;
+    bool all_sel = true, any = false;
+    for (int v = 0; v < MCF_NOUT; ++v)
+        if (has[v]) { any = true; all_sel = all_sel && sp->outsel[v] != 0; }
+    if (!any) return mcf::api_fail(MCF_ERR_STATE, "the solver plan holds no output");
+    if (N != sp->N || device != sp->device) return mcf::api_fail(MCF_ERR_ARG, "snow plan and solver plan differ in raster or device");
+    S_TRY(hipSetDevice(sp->device));
+    if (!sp->d_need || sp->need_cap < N) {
+        if ((rc = sp->b.alloc((void**)&sp->d_need, N + 16))) return rc;
+        sp->need_cap = N;
+    }
+    *need_cell = sp->d_need;
+    unsigned long long* d_count = (unsigned long long*)(sp->d_need + (N + 7) / 8 * 8);
+    if (!all_sel) {                        // an output the snow microclimate does not produce stays the solver's everywhere
+        S_TRY(hipMemset(sp->d_need, 1, (size_t)N));
+        *n_need = N;
+        return MCF_OK;
+    }
+    const bool k = (size_t)ch < sp->kept.size() && sp->kept[ch].Tc;
+    if (!k && !(sp->series_valid & 4u)) return mcf::api_fail(MCF_ERR_STATE, "snow plan: the chunk's totalSWE series was switched off (mcf_snowplan_set_series)");
+    const double* swe = k ? sp->kept[ch].sdepc : sp->a.sdepc;
+    S_TRY(hipMemset(d_count, 0, 8));
+    hipLaunchKernelGGL(k_cells_free, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, nullptr, swe, sp->ma.hgt, N, day * 24, ndays * 24,
+                       sp->d_need, d_count);
+    S_TRY(hipGetLastError());
+    unsigned long long n = 0;
+    S_TRY(hipMemcpy(&n, d_count, 8, hipMemcpyDeviceToHost));       // (also: the flags are complete)
+    *n_need = (int64_t)n;
     return MCF_OK;
 }
 extern "C" int mcf_snowplan_microsnow(mcf_snowplan* sp, mcf_plan* plan, int32_t ch, int32_t slot, const int32_t* nosnowday) {

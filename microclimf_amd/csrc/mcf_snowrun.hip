@@ -626,7 +626,8 @@ extern "C" int mcf_snowrun_pass2(mcf_snowrun* h, const mcf_snow_inputs* micro, d
             };
             // runs of consecutive no-snow days.  Where such a run lies in a chunk with snow, the tiles whose cells are all under snow
             // for the whole run are left out (include/mcf.h mcf_plan_run_days_masked): gridmicrosnow1 overwrites every one of their values
-            static const bool no_skip = getenv("MCF_SNOW_NO_TILE_SKIP") != nullptr;
+            const bool no_skip = getenv("MCF_SNOW_NO_TILE_SKIP") != nullptr;
+            const bool no_cells = getenv("MCF_SNOW_NO_CELL_GATHER") != nullptr;      // (A/B: tiles as the unit, as in round 4)
             std::vector<uint8_t> skip;
             auto solver_days = [&](Block& k, int slot, int ch, int d0, int nd, bool has_snow) -> int {
                 int q = 0;
@@ -639,21 +640,32 @@ extern "C" int mcf_snowrun_pass2(mcf_snowrun* h, const mcf_snow_inputs* micro, d
                 }
                 while (q < nd) {
                     if (!h->nosnowday[(size_t)(d0 + q)]) { ++q; continue; }
+                    // (a run ends where the days' class changes: on a day without snow anywhere every cell is the solver's)
+                    const bool both = h->snowday[(size_t)(d0 + q)] != 0;
                     int e = q;
-                    while (e < nd && h->nosnowday[(size_t)(d0 + e)]) ++e;
+                    while (e < nd && h->nosnowday[(size_t)(d0 + e)] && (h->snowday[(size_t)(d0 + e)] != 0) == both) ++e;
                     int rc2;
-                    int64_t ncov = 0;
-                    bool any_snow_day = false;
-                    for (int d = q; d < e; ++d) any_snow_day |= h->snowday[(size_t)(d0 + d)] != 0;
-                    if (has_snow && any_snow_day && !no_skip && ch >= 0 && !h->af) {
+                    if (has_snow && both && !no_skip && ch >= 0 && !h->af) {
                         mcf_ring_layout lay;
                         if ((rc2 = mcf_plan_ring_layout(k.plan, &lay))) return rc2;
                         const int64_t nt = (lay.cells + lay.cells_per_tile - 1) / lay.cells_per_tile;
-                        skip.resize((size_t)nt);
-                        if ((rc2 = mcf_snowplan_covered_tiles(k.sp, k.plan, ch, q, e - q, skip.data(), nt, &ncov))) return rc2;
-                        rc2 = mcf_plan_run_days_masked(k.plan, d0 + q, e - q, slot, q, ncov ? skip.data() : nullptr, ncov ? nt : 0);
-                        h->st_tile_days += nt * (e - q);
-                        h->st_tile_days_left_out += ncov * (e - q);
+                        const uint8_t* need = nullptr;
+                        int64_t n_need = lay.cells;
+                        if (!no_cells && (rc2 = mcf_snowplan_free_cells(k.sp, k.plan, ch, q, e - q, &need, &n_need))) return rc2;
+                        if (!no_cells && 16 * n_need <= lay.cells) {
+                            // the few cells that are not under snow throughout, gathered into tiles of their own (scattered cells
+                            // pay below ~ 8 % of the raster, profiles/r05_cells_rate.txt: their values reach the ring 8 bytes at a time)
+                            rc2 = mcf_plan_run_days_cells(k.plan, d0 + q, e - q, slot, q, need, lay.cells, nullptr);
+                            h->st_tile_days += nt * (e - q);
+                            h->st_tile_days_left_out += (nt - (n_need + lay.cells_per_tile - 1) / lay.cells_per_tile) * (e - q);
+                        } else {
+                            int64_t ncov = 0;
+                            skip.resize((size_t)nt);
+                            if ((rc2 = mcf_snowplan_covered_tiles(k.sp, k.plan, ch, q, e - q, skip.data(), nt, &ncov))) return rc2;
+                            rc2 = mcf_plan_run_days_masked(k.plan, d0 + q, e - q, slot, q, ncov ? skip.data() : nullptr, ncov ? nt : 0);
+                            h->st_tile_days += nt * (e - q);
+                            h->st_tile_days_left_out += ncov * (e - q);
+                        }
                     } else {
                         rc2 = mcf_plan_run_days_at(k.plan, d0 + q, e - q, slot, q);
                     }

@@ -826,6 +826,14 @@ class SnowPlan:
                                                         sk.ctypes.data_as(C.POINTER(C.c_uint8)), int(sk.size), C.byref(n)))
         return sk, int(n.value)
 
+    def free_cells(self, plan, chunk: int, day: int, ndays: int):
+        """-> (device address of one byte per cell, number of ones): 1 where the cell is NOT under snow at every step of the
+        chunk's days [day, day + ndays) (or has no vegetation height) — the cells whose solver values survive the merge, for
+        Plan.run_days_cells (include/mcf.h mcf_snowplan_free_cells)"""
+        ptr, n = C.c_void_p(0), C.c_int64(0)
+        _abi.check(self._lib.mcf_snowplan_free_cells(self._p, plan._p, int(chunk), int(day), int(ndays), C.byref(ptr), C.byref(n)))
+        return int(ptr.value or 0), int(n.value)
+
     def microsnow(self, plan, chunk: int, slot: int, nosnowday):
         """gridmicrosnow1 on the chunk's snow days, written over the solver's outputs in ring slot `slot` of `plan`."""
         nd = np.ascontiguousarray(nosnowday, dtype=np.int32)

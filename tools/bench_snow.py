@@ -171,6 +171,7 @@ def run_snow_config(args, world, rank, local_rank):
     outm = [1] * 10 if args.reqhgt > 0 else [1 if i in (0, 3, 5, 6, 7, 8, 9) else 0 for i in range(10)]
     ncd = sp.chunks * chunk_days
     tile_skip = os.environ.get("MCF_SNOW_NO_TILE_SKIP") is None
+    cell_gather = os.environ.get("MCF_SNOW_NO_CELL_GATHER") is None
 
     def one_year(probe=None):
         """probe (the untimed verification year): {"cells": ...} — the sample cells' five snow series are read back behind
@@ -231,23 +232,35 @@ def run_snow_config(args, world, rank, local_rank):
             else:
                 stats["chunks_skipped"] = stats.get("chunks_skipped", 0) + 1
             k = 0
-            while k < len(nos):                                       # runs of consecutive no-snow days -> one launch each
+            while k < len(nos):                                       # runs of consecutive no-snow days of one class -> one launch each
                 if not nos[k]:
                     k += 1
                     continue
+                both = bool(snowday[d0 + k])
                 e = k
-                while e < len(nos) and nos[e]:
+                while e < len(nos) and nos[e] and bool(snowday[d0 + e]) == both:
                     e += 1
                 if d0 + k < ndays:
                     nd = min(e, ndays - d0) - k
-                    # tiles whose cells all lie under snow for the whole run: every value the solver would write there is
-                    # overwritten by the snow microclimate below (`.runmicrosnow1`'s merge) — left out of the launch
-                    ncov = 0
-                    if tile_skip and sdays.size and snowday[d0 + k:d0 + k + nd].any():
-                        sk, ncov = sp.covered_tiles(plan, ch, k, nd)
-                    if ncov:
-                        plan.run_days_masked(d0 + k, nd, slot, k, sk)
-                        stats["tile_days_skipped"] = stats.get("tile_days_skipped", 0) + ncov * nd
+                    # a day that is a snow day too: the solver's values survive the merge (`.runmicrosnow1`, step 5) only where a cell
+                    # is not under snow — those cells gathered into tiles of their own (mcf_plan_run_days_cells), or, where they
+                    # are many, the tiles whose cells ALL lie under snow for the whole run left out of the launch
+                    if tile_skip and sdays.size and both:
+                        need, n_need = sp.free_cells(plan, ch, k, nd) if cell_gather else (0, plan.rows * plan.cols)
+                        if os.environ.get("MCF_SNOW_DEBUG"):
+                            print(f"[cells] chunk {ch} days {k}+{nd}: {n_need / (plan.rows * plan.cols):.3f} of the cells not under snow throughout",
+                                  file=sys.stderr, flush=True)
+                        if 16 * n_need <= plan.rows * plan.cols:      # (profiles/r05_cells_rate.txt: pays below ~ 8 % of the cells)
+                            plan.run_days_cells(d0 + k, nd, slot, k, need)
+                            stats["tile_days_skipped"] = stats.get("tile_days_skipped", 0) + (plan.n_tiles - -(-n_need // plan.ring_layout()["cells_per_tile"])) * nd
+                            stats["cell_days_gathered"] = stats.get("cell_days_gathered", 0) + n_need * nd
+                        else:
+                            sk, ncov = sp.covered_tiles(plan, ch, k, nd)
+                            if ncov:
+                                plan.run_days_masked(d0 + k, nd, slot, k, sk)
+                                stats["tile_days_skipped"] = stats.get("tile_days_skipped", 0) + ncov * nd
+                            else:
+                                plan.run_days_at(d0 + k, nd, slot, k)
                     else:
                         plan.run_days_at(d0 + k, nd, slot, k)
                     stats["tile_days"] = stats.get("tile_days", 0) + plan.n_tiles * nd
@@ -429,6 +442,7 @@ def run_snow_config(args, world, rank, local_rank):
         last_days = one_year()
     fence()
     dt = allreduce_max(time.perf_counter() - t0)
+    timed_stats = dict(stats)           # (the verification below walks one more year)
     verified = None
     if not getattr(args, "no_verify", False) and last_days is not None:
         vm = verify_merged()
@@ -440,8 +454,8 @@ def run_snow_config(args, world, rank, local_rank):
     valid_all = allreduce_sum(float(valid))
     value = valid_all * ndays * 24 * args.steps / dt
     if rank == 0:
-        sd = stats["solver_days"] / max(args.steps, 1)
-        snd = stats["snow_days"] / max(args.steps, 1)
+        sd = timed_stats["solver_days"] / max(args.steps, 1)
+        snd = timed_stats["snow_days"] / max(args.steps, 1)
         # 5 snow series per cell-step in each of the two passes + 10 outputs per cell-step of a solver day or a snow day
         passes = 1.0 + (sp.chunks - (stats.get("chunks_skipped", 0) + stats.get("chunks_kept", 0)) / max(stats["years"], 1)) / sp.chunks
         alg = valid_all * 24 * (passes * ndays * 40.0 + (sd + snd) * 80.05) * args.steps
@@ -462,10 +476,13 @@ def run_snow_config(args, world, rank, local_rank):
                 "baseline_config": 4, "rows_per_gpu": rows, "cols": cols, "tsteps": T, "valid_cells": int(valid_all),
                 "solver_days_per_year": sd,
                 "solver_tile_days_left_out": (f"{stats.get('tile_days_skipped', 0) / max(stats.get('tile_days', 0), 1):.3f} of the solver's tile-days: "
-                                              "tiles whose cells all lie under snow for a whole run of days that are snow days as well — "
-                                              "gridmicrosnow1 overwrites every value there (`.runmicrosnow1`'s merge), the merged output is the same "
-                                              "(MCF_SNOW_NO_TILE_SKIP=1 solves them all)") if tile_skip else "none (MCF_SNOW_NO_TILE_SKIP)",
-                "snow_days_per_year": stats["snow_days"] / max(args.steps, 1),
+                                              "on a day that is a snow day as well, gridmicrosnow1 overwrites every value of a cell under snow "
+                                              "(`.runmicrosnow1`'s merge): only the cells not under snow throughout are solved, gathered into tiles "
+                                              "of their own (mcf_plan_run_days_cells; where they are many: the tiles wholly under snow left out) — "
+                                              "the merged output is the same (MCF_SNOW_NO_CELL_GATHER=1: tiles as the unit; MCF_SNOW_NO_TILE_SKIP=1 "
+                                              "solves every cell)") if tile_skip else "none (MCF_SNOW_NO_TILE_SKIP)",
+                "solver_cell_days_gathered": stats.get("cell_days_gathered", 0) // max(stats.get("years", 1), 1),
+                "snow_days_per_year": snd,
                 "halo": (("RCCL" if backend == "nccl" else backend + " (REHEARSAL: ranks share a GPU)")
                          + " send/recv of 128 surface rows per neighbour and chunk, packed and unpacked on the device") if exchange_ok and world > 1 else
                         "generated, not exchanged: the neighbouring blocks' snow-free surface, resident on the device (a rank's share of "
