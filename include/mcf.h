@@ -788,8 +788,9 @@ typedef struct mcf_snowrun mcf_snowrun;
 int mcf_snowrun_create(const mcf_microsnow_in *in, const mcf_options *opt, const mcf_multi *multi, mcf_snowrun **run);
 void mcf_snowrun_destroy(mcf_snowrun *run);
 int32_t mcf_snowrun_days(const mcf_snowrun *run);     /* tsteps / 24 */
-/* What pass 2 was spared (diagnostics; tests assert which path ran): stats[0] tile-days of the solver's runs inside snow chunks,
- * [1] of them left out (tiles wholly under snow, mcf_plan_run_days_masked), [2] snow chunks whose series had stayed in HBM,
+/* What pass 2 was spared (diagnostics; tests assert which path ran): stats[0] tile-days of the solver's days that are snow days as
+ * well, [1] of them left out (tiles wholly under snow, mcf_plan_run_days_masked; or, where few cells are not under snow, all tiles
+ * but the ones those cells fill, mcf_plan_run_days_cells), [2] snow chunks whose series had stayed in HBM,
  * [3] snow chunks re-run from their checkpoints. */
 int mcf_snowrun_stats(const mcf_snowrun *run, int64_t stats[4]);
 /* Keep pass 1's snow chunks in device memory for pass 2, up to `bytes` in all (0: off, the default — on a fresh handle the

@@ -102,8 +102,8 @@ MAT = 10.0
 
 
 def _snow_year(rows, cols, ndays, mode, monkeypatch):
-    """The one-call snow run over a pack with holes (one cell in ten starts bare, no snowfall): most days are snow days AND
-    no-snow days, and hardly a tile lies wholly under snow."""
+    """The one-call snow run over a deep pack with holes (one cell in fifty starts bare, no snowfall): most days are snow days AND
+    no-snow days, few cells are the solver's, and a third of the tiles hold one."""
     for k in ("MCF_SNOW_NO_TILE_SKIP", "MCF_SNOW_NO_CELL_GATHER"):
         monkeypatch.delenv(k, raising=False)
     if mode == "tiles":
@@ -116,7 +116,7 @@ def _snow_year(rows, cols, ndays, mode, monkeypatch):
     _, _, dtm = synthetic.rasters(rows, cols)
     dtm = np.where(np.isnan(sw["vegp"]["hgt"]), np.nan, dtm)
     rng = np.random.default_rng(3)
-    deep = np.where(rng.random((rows, cols)) < 0.9, 0.9, 0.0)
+    deep = np.where(rng.random((rows, cols)) < 0.98, 2.0, 0.0)
     sw["other"] = dict(sw["other"], isnowdc=np.asfortranarray(deep), isnowdg=np.asfortranarray(0.7 * deep))
     sw["climdata"] = dict(sw["climdata"], precip=np.zeros(T))
     snow = dict(sw, dtm=dtm, res=1.0, tfact=0.02)
