@@ -698,8 +698,8 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
         pais = q.C(MQ_PAI) * frac;
     }
     // Roughness and wind (windtiCpp, windCpp cpp:1189-1218, gturbCpp) read nothing the radiation block makes and the radiation
-    // block reads nothing of theirs: inside the canopy they are evaluated BEHIND it (same operations, same values) — five
-    // doubles fewer alive through the two-stream algebra, the fullest stretch of the function.
+    // block reads nothing of theirs: they are evaluated BEHIND it (same operations, same values) — five doubles fewer alive
+    // through the two-stream algebra, the fullest stretch of the function —, once for both canopy classes (below).
     // One logarithm per height: Lref = log((zref - d) / zm) serves the friction velocity, and — as Lref + log 5 = log((zref - d) /
     // (0.2 zm)) — gturbCpp's conductance and the reference height of the temperature / vapour profile; Lz = log((z - d) / zm) of
     // the wind profile's own height z (reqhgt above the canopy, the canopy top inside it) is that profile's too.  (The reference
@@ -744,9 +744,14 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
         if (gHa < 0.0001) gHa = 0.0001;
         if (!sink(4, uz)) out.uz = uz;
     };
+    // The radiation of both classes first, then roughness and wind ONCE for every lane, then the classes' temperatures: a wave
+    // that holds cells of both classes (vegetation above the pack beside buried vegetation) runs the wind block — 250 of the
+    // loop's 3 150 instructions — once, not once per class (round 5: -1 % on configs[4]'s snow-day stage, whose waves are
+    // mostly of one class).
     double ez;
-    if (reqhgt >= hgts) {                                        // above the canopy, cpp:4768-4798
-        wind();
+    const bool above = reqhgt >= hgts;
+    double paias = 0.0, radLsw = 0.0;
+    if (above) {                                                 // above the canopy, cpp:4768-4798
         {
             double Rbdown = 0.0, Rddown = 0.0, Rdup = 0.0;
             if (q.Rsw > 0.0) {
@@ -766,12 +771,8 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
             if (!sink(8, Rdup)) out.Rdup = Rdup;
             if (!sink(9, lwup)) out.Rlwup = lwup;
         }
-        const AboveTV tv = tv_above_l(reqhgt, d, zm, Lz5, Lref5, q.Tc, q.tc, ea);
-        out.Tz = tv.Tz;
-        out.tleaf = q.Tc;
-        ez = tv.ez;
     } else {                                                     // inside the canopy, cpp:4799-4857
-        const double paias = q.C(MQ_PAIA) * frac;                      // (hgts > reqhgt > 0 here)
+        paias = q.C(MQ_PAIA) * frac;                                   // (hgts > reqhgt > 0 here)
         double zi = 0.0;
         if (q.sdepg > 0.0) zi = ((q.sdepc - q.sdepg) * q.sden) * (ihgts * (1.0 / 1000.0));
         double ltras = q.C(MQ_LTRA) * gexp(-10.1 * zi);
@@ -810,7 +811,7 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
         const CanK kp = cank1(sun.kx, sun.kcos, q.si);
         const TsDir dr = ts_dir(pait, fd, q.alb, kp.kd);
         // twostreamCpp (cpp:1086-1178)
-        double Rbdown = 0.0, Rddown = 0.0, Rdup = 0.0, radLsw = 0.0;
+        double Rbdown = 0.0, Rddown = 0.0, Rdup = 0.0;
         if (q.Rsw > 0.0) {
             const double cosz = sun.cosz;
             const double icosz = gdiv(1.0, cosz);
@@ -847,7 +848,14 @@ __device__ __forceinline__ MicroOut micro_above(const MicroIn& q, const MicroMet
         if (!sink(5, Rbdown)) out.Rbdown = Rbdown;
         if (!sink(6, Rddown)) out.Rddown = Rddown;
         if (!sink(8, Rdup)) out.Rdup = Rdup;
-        wind();
+    }
+    wind();
+    if (above) {
+        const AboveTV tv = tv_above_l(reqhgt, d, zm, Lz5, Lref5, q.Tc, q.tc, ea);
+        out.Tz = tv.Tz;
+        out.tleaf = q.Tc;
+        ez = tv.ez;
+    } else {
         // leaftemp (cpp:1333-1364) with gsmax = 999.999: gV = gh
         const double lwcan = 0.97 * kSb * rad4(q.Tc);
         const double lwgro = 0.97 * kSb * rad4(q.Tg);
