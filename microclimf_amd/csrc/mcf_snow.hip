@@ -722,6 +722,8 @@ __global__ __launch_bounds__(64 * kRtWaves, MCF_MICRORING_WAVES) void k_microsno
     __shared__ double s_mc[MC_COUNT][64];
     __shared__ double s_hw[32][64];                   // 24 horizon + 8 wind-shelter planes of the workgroup's cells
     __shared__ double s_tail[MCF_NOUT * 3 * 8 * 16];   // [held variable][tile][hour group][15 values + padding]
+    constexpr int kTzdDays = 8;
+    __shared__ double s_tzd[kTzdDays][64];            // the days' mean ground-snow temperatures (chunks of up to eight days)
     const MicroArgs& a = q.m;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t N = a.N;
@@ -751,6 +753,27 @@ __global__ __launch_bounds__(64 * kRtWaves, MCF_MICRORING_WAVES) void k_microsno
         } else {
             for (int p = wv - 3; p < 32; p += kRtWaves - 3) s_hw[p][lane] = p < 24 ? a.hor[(int64_t)p * N + cc] : a.wsa[(int64_t)(p - 24) * N + cc];
         }
+        // ... and every snow day's mean ground-snow temperature (see k_microsnow_ring), a day per wave from the last wave down:
+        // made per day by one wave in front of the day's barrier, its 24 loads were what the other seven waited for (round 5:
+        // -1.9 % on configs[4]'s snow-day stage)
+        if (q.ndays <= kTzdDays) {
+            for (int day = kRtWaves - 1 - wv; day < q.ndays; day += kRtWaves) {
+                if (tb_daymap[day] < 0) continue;
+                const double* tg = a.sTg + (N * (int64_t)(day * 24) + c0);
+                const int64_t ci = c0 + lane < N ? lane : N - 1 - c0;
+                double v[24];
+#pragma unroll
+                for (int h = 0; h < 24; ++h) v[h] = tg[ci + N * h];
+                double Tzd = NA;
+                if (!isnan(v[0])) {
+                    double sumd = 0.0;
+#pragma unroll
+                    for (int h = 0; h < 24; ++h) sumd += v[h];
+                    Tzd = sumd / 24.0;
+                }
+                s_tzd[day][lane] = Tzd;
+            }
+        }
     }
     // The lane's place: in the raster a uniform base + its lane number; in the tiled ring the block of its tile (uniform base of
     // the workgroup's first tile + tl tile strides) and, for cells 0-15, its column of the hour's line; cells 16-20 go to s_tail.
@@ -768,7 +791,7 @@ __global__ __launch_bounds__(64 * kRtWaves, MCF_MICRORING_WAVES) void k_microsno
         const int k0 = day * 24;
         // the day's mean ground-snow temperature (see k_microsnow_ring) by the last wave; the tails' slots emptied by the threads
         // that flushed them (same thread, same slots: ordered without a barrier)
-        if (wv == kRtWaves - 1) {
+        if (q.ndays > kTzdDays && wv == kRtWaves - 1) {
             const double* tg = a.sTg + (N * k0 + c0);
             const int64_t cc = c0 + lane < N ? lane : N - 1 - c0;
             double Tzd = NA;
@@ -779,6 +802,7 @@ __global__ __launch_bounds__(64 * kRtWaves, MCF_MICRORING_WAVES) void k_microsno
             }
             s_mc[MC_TZD][lane] = Tzd;
         }
+        const double* const tzd_row = q.ndays <= kTzdDays ? &s_tzd[day][0] : &s_mc[MC_TZD][0];
         for (int e = tid; e < nheld * 384; e += 64 * kRtWaves) reinterpret_cast<unsigned long long*>(s_tail)[e] = kTailEmpty;
         __syncthreads();
         // the workgroup's first tile's block of this day (uniform)
@@ -853,7 +877,7 @@ __global__ __launch_bounds__(64 * kRtWaves, MCF_MICRORING_WAVES) void k_microsno
                     const MicroOut mo = micro_above(mi, r.mm, sun, [&](int i, double val) { emit(i, val); return true; });
                     Tz = mo.Tz; tleaf = mo.tleaf; rh = mo.rh;
                 } else {
-                    const double b = micro_below(reqhgts, MC(MC_MEAND), sTg, MC(MC_TZD), a.mat, a.hiy);
+                    const double b = micro_below(reqhgts, MC(MC_MEAND), sTg, tzd_row[li], a.mat, a.hiy);
                     Tz = b; tleaf = b; rh = 100.0;
                     for (int i = 4; i < MCF_NOUT; ++i) emit(i, 0.0);
                 }

@@ -1,9 +1,13 @@
 #!/bin/bash
-# round 5, call T: configs[4] share, stage times, the library before / after the snow-day microclimate's wind block was made common
+# round 5, call T: the snow-day microclimate kernel with the days' mean ground-snow temperatures made in the prologue: snow tests,
+# then configs[4] share, stage times, the library before / after
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && o=gpurun_out/r05t && mkdir -p $o
+timeout -k 10 900 python -m pytest tests/test_snow_gpu.py tests/test_random_snow_gpu.py tests/test_snowrun_gpu.py tests/test_snow_micro_pipeline_gpu.py tests/test_snowrun2_gpu.py tests/test_cells_run_gpu.py -x -q > $o/pytest.txt 2>&1
+rc=$?; tail -3 $o/pytest.txt
+[ $rc -eq 0 ] || exit $rc
 export MCF_BENCH_STAGES=1
 for m in pre new pre2 new2; do
-  case $m in pre*) export MCF_LIB=$GRAFT_REPO_ROOT/build/variants/libmcfhip_prewind.so;; *) unset MCF_LIB;; esac
+  case $m in pre*) export MCF_LIB=$GRAFT_REPO_ROOT/build/variants/libmcfhip_pretzd.so;; *) unset MCF_LIB;; esac
   timeout -k 10 300 python3 bench.py --config 4 --share 8 --steps 2 --warmup 1 --no-verify --no-cpu-baseline > $o/ab_$m.json 2> $o/ab_$m.err || exit 1
   python3 -c "
 import json; d=json.load(open('$o/ab_$m.json')); print('$m', '%.4e' % d['value'], round(d['ms_per_step'],1), {k: round(v, 3) for k, v in (d.get('stage_seconds') or {}).items()})"
