@@ -24,7 +24,7 @@ def _bits(a):
     return np.ascontiguousarray(a).view(np.uint64)
 
 
-@pytest.mark.parametrize("case", ["plain", "irregular_cells", "irregular_day", "layers", "ground", "few", "all"])
+@pytest.mark.parametrize("case", ["plain", "irregular_cells", "irregular_day", "layers", "ground", "few", "all", "cpb16", "cpb32", "cpb42"])
 def test_marked_cells_get_the_plain_launch_s_bits_and_the_others_keep_theirs(case, monkeypatch):
     rows, cols, nd = (57, 31, 4)
     T = 8 * 24
@@ -51,7 +51,9 @@ def test_marked_cells_get_the_plain_launch_s_bits_and_the_others_keep_theirs(cas
         need[5, 7] = need[40, 30] = True
     nsel = [k for k in OUT if not (rq == 0.0 and k in ("tleaf", "relhum"))]
     a["out"] = [k in nsel for k in OUT]
-    with Plan(**a, ring_days=5, ring_slots=2) as p:
+    cpb = int(case[3:]) if case.startswith("cpb") else 0     # (other tile sizes: the block's places are hour-major)
+    with Plan(**a, ring_days=5, ring_slots=2, cells_per_block=cpb) as p:
+        assert cpb == 0 or p.ring_layout()["cells_per_tile"] == cpb
         p.run_days_at(0, nd, 0, 1)                      # the plain launch of days 0 .. 3 at day 1 of slot 0
         p.run_days_at(4, nd, 1, 1)                      # slot 1 holds days 4 .. 7 there
         held = {k: p.fetch(1, k, 24, nd * 24).copy() for k in nsel}
