@@ -17,6 +17,7 @@ ap.add_argument("--rows", type=int, default=96)
 ap.add_argument("--cols", type=int, default=96)
 ap.add_argument("--reqhgt", type=float, default=0.05)
 ap.add_argument("--coarse", type=str, default="", help="CRxCC: coarse array forcing against expand-then-solve through the oracle")
+ap.add_argument("--array", action="store_true", help="array forcing (runmicro2Cpp's geometry): every forcing value per cell")
 a = ap.parse_args()
 if a.coarse:
     from microclimf_amd.api import runmicro2Cpp_coarse
@@ -33,6 +34,16 @@ if a.coarse:
     b.update(climdata=clim, pointm=pm)
     want = O.run_grid(**b, array_forcing=True)
     t2 = time.perf_counter()
+elif a.array:
+    from microclimf_amd.api import runmicro2Cpp
+    w = synthetic.workload(a.rows, a.cols, 8760, reqhgt=a.reqhgt, variety=True, na_frac=0.02, array_forcing=True)
+    order = ("obstime", "climdata", "pointm", "vegp", "soilc", "reqhgt", "zref", "lat", "lon", "Sminp", "Smaxp", "tfact", "complete",
+             "mat", "out")
+    t0 = time.perf_counter()
+    got = runmicro2Cpp(*[w[k] for k in order])
+    t1 = time.perf_counter()
+    want = O.run_grid(**w, array_forcing=True)
+    t2 = time.perf_counter()
 else:
     w = synthetic.workload(a.rows, a.cols, 8760, reqhgt=a.reqhgt, variety=True, na_frac=0.02)
     t0 = time.perf_counter()
@@ -40,7 +51,7 @@ else:
     t1 = time.perf_counter()
     want = O.run_grid(**w)
     t2 = time.perf_counter()
-print(f"{a.rows} x {a.cols} x 8760, reqhgt {a.reqhgt}{', coarse ' + a.coarse if a.coarse else ''}: HIP one-shot {t1 - t0:.2f} s, oracle {t2 - t1:.1f} s")
+print(f"{a.rows} x {a.cols} x 8760, reqhgt {a.reqhgt}{', coarse ' + a.coarse if a.coarse else ', array forcing' if a.array else ''}: HIP one-shot {t1 - t0:.2f} s, oracle {t2 - t1:.1f} s")
 worst = 0.0
 for k, x in want.items():
     g = got[k]
