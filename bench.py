@@ -252,6 +252,15 @@ def committed_counters(rows, cols, ring_days):
             pf = ROOT / "profiles" / f"{e.get('tag')}_pmc_summary.json"
             pj = json.loads(pf.read_text()) if pf.exists() else None
             return e, pj, None
+    # no counter run of this raster: k_solve's bytes per cell-step do not depend on the raster's shape — the current-source entry
+    # whose launches are closest in days, its reads (per-launch constant images) to be scaled by cells, its writes by cell-steps
+    cand = [e for e in entries if e.get("kernel_hash") == kernel_hash() and e.get("read_bytes") is not None and e.get("ring_days")]
+    if cand:
+        e = dict(min(cand, key=lambda x: abs(x["ring_days"] - ring_days)))
+        e["other_raster"] = f"{e.get('rows')}x{e.get('cols')}, {e.get('ring_days')}-day launches"
+        pf = ROOT / "profiles" / f"{e.get('tag')}_pmc_summary.json"
+        pj = json.loads(pf.read_text()) if pf.exists() else None
+        return e, pj, None
     return None, None, f"no counters for {rows}x{cols} with {ring_days}-day launches"
 
 
@@ -466,7 +475,18 @@ def roofline_block(valid, T, steps_per_launch, avg_ms, klaunches, af, rows, cols
         e, pj, note = committed_counters(rows, cols, ring_days)
         if e is not None:
             cs_pmc = (pj or {}).get("cell_steps_per_launch") or e.get("cell_steps_per_launch")
-            if cs_pmc and e.get("read_bytes") is not None:
+            if cs_pmc and e.get("read_bytes") is not None and e.get("other_raster"):
+                # (another raster's counters: the reads go with the cells of a launch, the writes with its cell-steps)
+                k_w = cs_bench / cs_pmc
+                k_r = (cs_bench / max(steps_per_launch, 1e-9)) / (cs_pmc / (24.0 * e["ring_days"]))
+                traffic = e["read_bytes"] * k_r + e["write_bytes"] * k_w
+                basis = {"source": f"profiles/traffic.json [{e.get('tag')}] — counters of ANOTHER raster ({e['other_raster']}): k_solve's "
+                                   "bytes per cell-step do not depend on the raster's shape",
+                         "counter_run_cell_steps_per_launch": cs_pmc, "this_run_cell_steps_per_launch": cs_bench,
+                         "reads_scaled_by_cells": k_r, "writes_scaled_by_cell_steps": k_w,
+                         "counter_run_bytes": {"read": e["read_bytes"], "write": e["write_bytes"]},
+                         "ratio_to_algorithmic": traffic / bpl if bpl else None}
+            elif cs_pmc and e.get("read_bytes") is not None:
                 traffic, basis = on_this_basis(e["read_bytes"], e["write_bytes"], cs_pmc, f"profiles/traffic.json [{e.get('tag')}]")
             else:
                 traffic = e.get("hbm_bytes_per_launch")

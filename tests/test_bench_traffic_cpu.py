@@ -49,3 +49,24 @@ def test_pipeline_traffic_needs_the_snow_sources_hash(monkeypatch, tmp_path):
     monkeypatch.setattr(bench, "snow_kernel_hash", lambda: "h2")
     t, note = bench.committed_pipeline_traffic()
     assert t is None and "stale" in note
+
+
+def test_another_rasters_counters_are_scaled_reads_by_cells_writes_by_cell_steps(monkeypatch, tmp_path):
+    """A raster with no counter run of its own (a rank's block of configs[3]): k_solve's bytes per cell-step do not depend on the
+    raster's shape — the current-source entry is used, said so, with the reads (per-launch constant images) scaled by the cells
+    of a launch and the writes by its cell-steps."""
+    monkeypatch.setattr(bench, "kernel_hash", lambda: "abc")
+    _fake(monkeypatch, tmp_path, "abc")          # 64 x 64, 7-day launches: 1000 cell-steps per launch
+    # this run: 3 x as many cells, 14-day launches
+    cells_pmc = 1000.0 / (24 * 7)
+    valid, spl = 3 * cells_pmc, 24 * 14
+    rb = bench.roofline_block(valid=valid, T=8760, steps_per_launch=spl, avg_ms=1.0, klaunches=5, af=False, rows=128, cols=96,
+                              ring_days=14, rate_per_gpu=1e9, coarse=None)
+    assert abs(rb["traffic"] - (10.0 * 3 + 100.0 * 6)) < 1e-9
+    tb = rb["traffic_basis"]
+    assert "ANOTHER raster" in tb["source"] and abs(tb["reads_scaled_by_cells"] - 3.0) < 1e-12 and abs(tb["writes_scaled_by_cell_steps"] - 6.0) < 1e-12
+    # ... but never counters of other sources
+    monkeypatch.setattr(bench, "kernel_hash", lambda: "new")
+    rb = bench.roofline_block(valid=valid, T=8760, steps_per_launch=spl, avg_ms=1.0, klaunches=5, af=False, rows=128, cols=96,
+                              ring_days=14, rate_per_gpu=1e9, coarse=None)
+    assert rb["traffic"] is None and "no counters" in rb["counters"]
