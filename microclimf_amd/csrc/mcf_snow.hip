@@ -174,6 +174,10 @@ struct ModelArgs {
     double tpimean;
     double *isnowdc_out, *dtms;
     int32_t *isnowac_out, *isnowag_out;
+    // [N][T / 24] or null (data.frame climate): the day's mean of the Tg series, as the snow-day microclimate takes it (cpp:5010-5016:
+    // the 24 values added in their order, / 24; NA where the day's first value is) — made here, where the values are, its reader
+    // does not read the series a second time for it
+    double* tzd;
 };
 
 template <bool AF>
@@ -228,6 +232,10 @@ __global__ __launch_bounds__(256, AF ? MCF_SNOW_WAVES_AF : MCF_SNOW_WAVES) void 
             if (a.sdepg) a.sdepg[o] = dg;
             if (a.sden) a.sden[o] = NA;
         }
+        if constexpr (!AF) {
+            if (a.tzd && a.Tg)
+                for (int d = 0; d < a.tsteps / 24; ++d) a.tzd[c + N * d] = NA;
+        }
         if (redist && a.tsteps > 0) { a.isnowdc_out[c] = s_cv[RV_TOT][threadIdx.x]; a.dtms[c] = a.dtm[c] + s_cv[RV_GD][threadIdx.x]; }
         if (a.agec) a.agec[c] = NA;
         if (a.ageg) a.ageg[c] = NA;
@@ -262,6 +270,8 @@ __global__ __launch_bounds__(256, AF ? MCF_SNOW_WAVES_AF : MCF_SNOW_WAVES) void 
     const int ndays = a.tsteps / 24;
     int hs = 0;
     DayT dy;
+    [[maybe_unused]] double tzsum = 0.0;         // the day's Tg values added up (tzd)
+    [[maybe_unused]] bool tz_na = false;
     for (int k = 0; k < a.tsteps; ++k) {
         const int64_t o = c + N * k;
         // (an opaque lane index per step: the table's values are read at their uses, not hoisted in front of the loop)
@@ -334,6 +344,14 @@ __global__ __launch_bounds__(256, AF ? MCF_SNOW_WAVES_AF : MCF_SNOW_WAVES) void 
             if (a.sdepg) st(a.sdepg, vdg);
             if (a.sden) st(a.sden, vden);
         }
+        if constexpr (!AF) {
+            if (a.tzd && a.Tg) {
+                const int h = k % 24;
+                if (h == 0) { tzsum = 0.0; tz_na = isnan(vTg); }
+                tzsum += vTg;
+                if (h == 23) a.tzd[c + N * (k / 24)] = tz_na ? NA : tzsum / 24.0;
+            }
+        }
     }
     if (a.agec) a.agec[c] = (double)s.agec;
     if (a.ageg) a.ageg[c] = (double)s.ageg;
@@ -362,6 +380,7 @@ struct MicroArgs {
     int32_t day0;          // first day of this launch (blockIdx.y counts from it)
     const double *temp, *relhum, *pres, *swdown, *difrad, *lwdown, *windspeed, *precip, *umu;   // [T] or [N][T]
     const double *sTc, *sTg, *swe, *sdepg, *sden;   // snowm, [N][T]
+    const double* tzd;  // [N][T / 24] the days' means of sTg made by the snow model's kernel (ModelArgs::tzd), or null: made here
     double* meanD;      // [N]
     double* mxtc;       // [N]        array climate
     int32_t* hs0;       // [N][nchunks] hours since snowfall at the start of each day (array climate)
@@ -759,8 +778,12 @@ __global__ __launch_bounds__(64 * kRtWaves, MCF_MICRORING_WAVES) void k_microsno
         if (q.ndays <= kTzdDays) {
             for (int day = kRtWaves - 1 - wv; day < q.ndays; day += kRtWaves) {
                 if (tb_daymap[day] < 0) continue;
-                const double* tg = a.sTg + (N * (int64_t)(day * 24) + c0);
                 const int64_t ci = c0 + lane < N ? lane : N - 1 - c0;
+                if (a.tzd) {        // the snow model's kernel made them as it wrote the series (ModelArgs::tzd): one value, not 24
+                    s_tzd[day][lane] = a.tzd[N * (int64_t)day + c0 + ci];
+                    continue;
+                }
+                const double* tg = a.sTg + (N * (int64_t)(day * 24) + c0);
                 double v[24];
 #pragma unroll
                 for (int h = 0; h < 24; ++h) v[h] = tg[ci + N * h];
@@ -1536,7 +1559,7 @@ struct mcf_snowplan {
     std::vector<char*> ckpt;
     // series of chunks kept on the device between the two passes (mcf_snowplan_keep_chunk): a kept chunk's buffers are the ones
     // the model wrote — the plan goes on with fresh ones — so pass 2 neither re-runs the chunk nor copies anything
-    struct Kept { double *Tc = nullptr, *Tg = nullptr, *sdepc = nullptr, *sdepg = nullptr, *sden = nullptr; };
+    struct Kept { double *Tc = nullptr, *Tg = nullptr, *sdepc = nullptr, *sdepg = nullptr, *sden = nullptr, *tzd = nullptr; };
     // (a kept set belongs to the run of its chunk that was current when it was handed over: running the chunk again — a new
     // pass 1 without mcf_snowplan_release_kept, a re-run after mcf_snowplan_reset — returns the stale set to the pool, so that
     // mcf_snowplan_microsnow can never read last year's series for it)
@@ -1678,6 +1701,7 @@ extern "C" int mcf_snowplan_create(const mcf_snowdriver_in* din, int64_t row0, i
     if ((rc = b.alloc((void**)&a.sdepc, CN * 8))) return rc;
     if ((rc = b.alloc((void**)&a.sdepg, CN * 8))) return rc;
     if ((rc = b.alloc((void**)&a.sden, CN * 8))) return rc;
+    if (!sp->af && (rc = b.alloc((void**)&a.tzd, (int64_t)std::max(sp->chunk / 24, 1) * N * 8))) return rc;
     if ((rc = b.alloc((void**)&a.agec, N * 8))) return rc;
     if ((rc = b.alloc((void**)&a.ageg, N * 8))) return rc;
     hipLaunchKernelGGL(k_add_snow, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, nullptr, sp->d_dtm, sp->d_isnowdg, 1.0,
@@ -2365,18 +2389,20 @@ extern "C" int mcf_snowplan_keep_chunk(mcf_snowplan* sp, int32_t ch, int64_t res
     if (sp->kept[ch].Tc) { *kept = 1; return MCF_OK; }
     if (sp->series_valid != 31) return MCF_OK;      // (a chunk run with some series switched off cannot be kept)
     const int64_t one = (int64_t)sp->chunk * sp->N * 8;
-    double* fresh[5] = {};
+    const int64_t small = sp->a.tzd ? (int64_t)std::max(sp->chunk / 24, 1) * sp->N * 8 : 0;      // the days' means of Tg beside them
+    double* fresh[6] = {};
     if (!sp->pool.empty()) {               // a set an earlier year released
         const mcf_snowplan::Kept f = sp->pool.back();
         sp->pool.pop_back();
-        fresh[0] = f.Tc; fresh[1] = f.Tg; fresh[2] = f.sdepc; fresh[3] = f.sdepg; fresh[4] = f.sden;
+        fresh[0] = f.Tc; fresh[1] = f.Tg; fresh[2] = f.sdepc; fresh[3] = f.sdepg; fresh[4] = f.sden; fresh[5] = f.tzd;
     } else {
         size_t free_b = 0, total_b = 0;
         S_TRY(hipMemGetInfo(&free_b, &total_b));
-        if ((int64_t)free_b < 5 * one + std::max<int64_t>(reserve_bytes, 0)) return MCF_OK;
+        if ((int64_t)free_b < 5 * one + small + std::max<int64_t>(reserve_bytes, 0)) return MCF_OK;
         if (sp->keep_budget >= 0 && sp->keep_allocated + 5 * one > sp->keep_budget) return MCF_OK;
-        for (int v = 0; v < 5; ++v) {
-            if (hipMalloc((void**)&fresh[v], (size_t)one) != hipSuccess) {      // (another process took the room: not an error)
+        for (int v = 0; v < 6; ++v) {
+            if (v == 5 && !small) break;
+            if (hipMalloc((void**)&fresh[v], (size_t)(v == 5 ? small : one)) != hipSuccess) {      // (another process took the room: not an error)
                 (void)hipGetLastError();
                 for (int u = 0; u < v; ++u) { (void)hipFree(fresh[u]); sp->kb.p.pop_back(); }
                 return MCF_OK;
@@ -2388,8 +2414,8 @@ extern "C" int mcf_snowplan_keep_chunk(mcf_snowplan* sp, int32_t ch, int64_t res
     S_TRY(hipDeviceSynchronize());         // (the chunk's kernels are done before its buffers change hands)
     ModelArgs& a = sp->a;
     mcf_snowplan::Kept k;
-    k.Tc = a.Tc; k.Tg = a.Tg; k.sdepc = a.sdepc; k.sdepg = a.sdepg; k.sden = a.sden;
-    a.Tc = fresh[0]; a.Tg = fresh[1]; a.sdepc = fresh[2]; a.sdepg = fresh[3]; a.sden = fresh[4];
+    k.Tc = a.Tc; k.Tg = a.Tg; k.sdepc = a.sdepc; k.sdepg = a.sdepg; k.sden = a.sden; k.tzd = a.tzd;
+    a.Tc = fresh[0]; a.Tg = fresh[1]; a.sdepc = fresh[2]; a.sdepg = fresh[3]; a.sden = fresh[4]; a.tzd = fresh[5];
     sp->kept[ch] = k;
     sp->mm_chunk = -1;                     // (the plan's buffers are fresh ones now)
     *kept = 1;
@@ -2798,6 +2824,7 @@ extern "C" int mcf_snowplan_microsnow(mcf_snowplan* sp, mcf_plan* plan, int32_t 
         if (!k && sp->series_valid != 31) return mcf::api_fail(MCF_ERR_STATE, "snow plan: the chunk was run with series switched off (mcf_snowplan_set_series)");
         q.m.sTc = k ? sp->kept[ch].Tc : sp->a.Tc;
         q.m.sTg = k ? sp->kept[ch].Tg : sp->a.Tg;
+        q.m.tzd = k ? sp->kept[ch].tzd : sp->a.tzd;          // (written with the Tg series: every series of the chunk is there, checked above)
         q.m.swe = k ? sp->kept[ch].sdepc : sp->a.sdepc;
         q.m.sdepg = k ? sp->kept[ch].sdepg : sp->a.sdepg;
         q.m.sden = k ? sp->kept[ch].sden : sp->a.sden;
