@@ -420,6 +420,13 @@ __global__ __launch_bounds__(256) void k_micro_pack(const StepRow* __restrict__ 
     m.alb = rows[k].m.alb; m.ialb = rows[k].m.ialb;
     m.sindex = rows[k].sindex; m.windex = rows[k].windex;
 }
+// a step's term of meanDsnow (cpp:4713-4737): sqrt(2 kappa / omega), kappa from the pack's density (> 0, or NaN) — with the lean
+// exponential, quotient and root (the device libm's made k_meand_accumulate a compute-bound kernel: 11 000 instructions per wave)
+__device__ __forceinline__ double snow_damping_term(double den) {
+    const double co = 0.0442 * gexp(5.181 * den * (1.0 / 1000.0));
+    const double kap = gdiv(co, den * 2090.0);
+    return gsqrt(kap * (2.0 / kOmdy));
+}
 template <bool AF>
 __global__ __launch_bounds__(256) void k_microsnow_cell(MicroArgs a) {
     snow::snow_tables_init();
@@ -431,10 +438,7 @@ __global__ __launch_bounds__(256) void k_microsnow_cell(MicroArgs a) {
     if (!isnan(a.sden[c])) {
         double sumD = 0.0;
         for (int k = 0; k < a.tsteps; ++k) {
-            const double den = a.sden[c + N * k];
-            const double co = 0.0442 * exp(5.181 * den / 1000.0);
-            const double kap = co / (den * 2090.0);
-            sumD += sqrt(2.0 * kap / kOmdy);
+            sumD += snow_damping_term(a.sden[c + N * k]);
         }
         meanD = sumD / (double)a.tsteps;
     }
@@ -493,10 +497,7 @@ __global__ __launch_bounds__(256) void k_meand_accumulate(const double* __restri
         if (!snowday[d]) continue;
         if (!seen) { sden_na[c] = isnan(sden[c + N * (d * 24)]) ? 1 : 0; seen = true; }
         for (int h = 0; h < 24; ++h) {
-            const double den = sden[c + N * (d * 24 + h)];
-            const double co = 0.0442 * exp(5.181 * den / 1000.0);
-            const double kap = co / (den * 2090.0);
-            s += sqrt(2.0 * kap / kOmdy);
+            s += snow_damping_term(sden[c + N * (d * 24 + h)]);
         }
     }
     sumD[c] = s;
@@ -1744,7 +1745,9 @@ __global__ __launch_bounds__(256) void k_surface_differs(const double* __restric
                                                          int32_t* __restrict__ diff) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool d = t < n && __double_as_longlong(a[t]) != __double_as_longlong(b[t]);
-    if (__builtin_amdgcn_ballot_w64(d) != 0 && (threadIdx.x & 63) == 0) atomicOr(diff, 1);
+    // (a wave that sees the flag up already leaves it alone: with surfaces that differ everywhere — every chunk of the snow season —
+    // 40 000 atomics on one address took 0.2 ms of a launch that reads 33 MB)
+    if (__builtin_amdgcn_ballot_w64(d) != 0 && (threadIdx.x & 63) == 0 && *(volatile int32_t*)diff == 0) atomicOr(diff, 1);
 }
 // own block + halo rows, column-major [hn + rows + hs, cols], put together on the device from three column-major pieces
 __global__ void k_ext_assemble(double* __restrict__ ext, const double* __restrict__ own, const double* __restrict__ north,
